@@ -1,0 +1,117 @@
+"""Shared, VapourSynth-free test inputs.
+
+`crop_rgb24()` is the reference suite's own source picture (reference
+tests/conftest.py:72-77); the derived formats restate what zimg does for the
+only conversions that are reproducible without zimg:
+  RGBS  = v * f32(1/255)                       (exact)
+  GRAY8 = limited-range BT.709 luma, f64, +0.5 floor   (exact)
+  GRAY16 / GRAYS luma                          (approximate, soft checks only)
+"""
+from __future__ import annotations
+
+import json
+from functools import lru_cache
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+
+
+@lru_cache(maxsize=None)
+def crop_rgb24() -> np.ndarray:
+    a = np.load(GOLDEN_DIR / "crop_rgb24.npy")
+    assert a.shape == (3, 320, 640) and a.dtype == np.uint8
+    a.setflags(write=False)
+    return a
+
+
+@lru_cache(maxsize=None)
+def crop_rgbs() -> np.ndarray:
+    a = crop_rgb24().astype(np.float32) * np.float32(1.0 / 255.0)
+    a.setflags(write=False)
+    return a
+
+
+@lru_cache(maxsize=None)
+def crop_gray8() -> np.ndarray:
+    r, g, b = (crop_rgb24()[i].astype(np.float64) for i in range(3))
+    y = np.floor((0.2126 * r + 0.7152 * g + 0.0722 * b) * 219.0 / 255.0 + 16.0 + 0.5)
+    a = y.astype(np.uint8)
+    a.setflags(write=False)
+    return a
+
+
+@lru_cache(maxsize=None)
+def crop_grays() -> np.ndarray:
+    """Approximate zimg RGB24 -> GRAYS (matrix=1); soft checks only."""
+    f = np.float32
+    r, g, b = (crop_rgbs()[i] for i in range(3))
+    y = ((f(0.2126) * r + f(0.7152) * g) + f(0.0722) * b).astype(np.float32)
+    y.setflags(write=False)
+    return y
+
+
+@lru_cache(maxsize=None)
+def crop_gray16() -> np.ndarray:
+    """Approximate zimg RGB24 -> GRAY16 limited range; soft checks only."""
+    f = np.float32
+    y = np.floor(crop_grays() * f(56064.0) + f(4096.0) + f(0.5))
+    a = y.astype(np.uint16)
+    a.setflags(write=False)
+    return a
+
+
+@lru_cache(maxsize=None)
+def ref_goldens() -> dict:
+    return json.loads((GOLDEN_DIR / "ref_goldens.json").read_text())
+
+
+def plane_stats(p: np.ndarray) -> dict:
+    """std.PlaneStats as the reference's golden_stats uses it (tests/golden.py:106-121):
+    avg normalised by peak for integer formats, min/max raw."""
+    if p.dtype.kind == "u":
+        peak = float((1 << (8 * p.dtype.itemsize)) - 1)
+        avg = float(p.astype(np.uint64).sum()) / p.size / peak
+        return {"avg": avg, "min": int(p.min()), "max": int(p.max())}
+    q = p.astype(np.float32)
+    return {"avg": float(q.astype(np.float64).sum() / q.size), "min": float(q.min()), "max": float(q.max())}
+
+
+def splitmix64_plane(seed: int, shape, dtype) -> np.ndarray:
+    """Deterministic noise plane: splitmix64 stream -> full-range
+    integers or uniform [0,1) floats."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        x = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    dtype = np.dtype(dtype)
+    if dtype == np.uint8:
+        out = (x >> np.uint64(56)).astype(np.uint8)
+    elif dtype == np.uint16:
+        out = (x >> np.uint64(48)).astype(np.uint16)
+    elif dtype == np.float32:
+        out = ((x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).astype(np.float32)
+    elif dtype == np.float16:
+        out = ((x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).astype(np.float16)
+    else:
+        raise TypeError(dtype)
+    return out.reshape(shape)
+
+
+def tiled_natural(shape, dtype, plane: int = 0) -> np.ndarray:
+    """Natural-content plane of any size: the reference crop tiled."""
+    h, w = shape
+    dtype = np.dtype(dtype)
+    base = crop_rgb24()[plane]
+    reps = (-(-h // base.shape[0]), -(-w // base.shape[1]))
+    t = np.tile(base, reps)[:h, :w]
+    if dtype == np.uint8:
+        return np.ascontiguousarray(t)
+    if dtype == np.uint16:
+        return (t.astype(np.uint16) * np.uint16(257)).astype(np.uint16)
+    return (t.astype(np.float32) * np.float32(1.0 / 255.0)).astype(dtype)
