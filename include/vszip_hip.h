@@ -1,0 +1,96 @@
+/*
+ * vszip_hip.h — flat C ABI of the MI355X (gfx950) vszip pixel kernels.
+ *
+ * This is the drop-in boundary: the cut between the reference's filter wrappers
+ * (src/vapoursynth/NAME.zig, layer L2) and its pixel kernels (src/filters/NAME.zig,
+ * layer L3).  Every entry point replaces one L3 function the wrappers call, takes
+ * plain pointers, strides IN ELEMENTS (as ZAPI getDimensions2 returns them,
+ * src/vapoursynth/boxblur.zig:46) and scalars, and returns 0 or a negative
+ * vszip_status.  No C++ / HIP / torch types appear in any signature; a Zig host
+ * binds it with `extern "c"` declarations.
+ *
+ * All plane pointers are DEVICE pointers (hipMalloc, or any allocator that
+ * yields device-accessible memory, e.g. a torch CUDA tensor's data_ptr).  Host
+ * VSFrame planes are staged with vszip_copy_h2d_2d / vszip_copy_d2h_2d on the
+ * context's stream.  Kernels are enqueued on the context's stream and return
+ * without synchronising unless stated (the metric filters copy their scalars
+ * back and synchronise, because their result is a host scalar).
+ */
+#ifndef VSZIP_HIP_H
+#define VSZIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSZIP_ABI_VERSION 1
+
+typedef struct vszip_ctx vszip_ctx;
+
+/* sample types: helper.zig:59-108 DataType (U32 is PlaneAverage-only and not offered) */
+enum vszip_dtype { VSZIP_U8 = 0, VSZIP_U16 = 1, VSZIP_F16 = 2, VSZIP_F32 = 3 };
+
+enum vszip_status {
+    VSZIP_OK = 0,
+    VSZIP_ERR_ARG = -1,         /* invalid argument (the wrapper's create-time checks) */
+    VSZIP_ERR_HIP = -2,         /* a HIP runtime call failed; see vszip_last_error */
+    VSZIP_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet */
+    VSZIP_ERR_NOMEM = -4
+};
+
+/* ---- context: one per (process, GPU); owns a stream and scratch ---------- */
+int vszip_ctx_create(int device, vszip_ctx **out);
+void vszip_ctx_destroy(vszip_ctx *ctx);
+/* Use an externally owned hipStream_t (passed as void*) instead of the context's own. */
+int vszip_ctx_set_stream(vszip_ctx *ctx, void *hip_stream);
+void *vszip_ctx_stream(vszip_ctx *ctx);
+int vszip_ctx_sync(vszip_ctx *ctx);
+const char *vszip_last_error(vszip_ctx *ctx);
+int vszip_abi_version(void);
+
+/* ---- device memory + staging (replaces nothing: the reference is host-only) */
+int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
+int vszip_dev_free(vszip_ctx *ctx, void *dptr);
+int vszip_dev_memset(vszip_ctx *ctx, void *dptr, int value, size_t bytes);
+int vszip_host_alloc_pinned(vszip_ctx *ctx, size_t bytes, void **hptr);
+int vszip_host_free_pinned(vszip_ctx *ctx, void *hptr);
+/* pitches in BYTES; async on the context stream */
+int vszip_copy_h2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);
+int vszip_copy_d2h_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);
+int vszip_copy_d2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);
+
+/* ---- timing helpers (HIP events on the context stream; used by bench.py) -- */
+int vszip_timer_start(vszip_ctx *ctx);
+int vszip_timer_stop_ms(vszip_ctx *ctx, float *ms); /* synchronises */
+
+/* One plane of one frame. Strides in elements of the sample type. */
+typedef struct vszip_plane {
+    const void *src; /* input plane */
+    void *dst;       /* output plane (filters that write pixels) */
+    const void *ref; /* second input: Bilateral `ref`, PlaneAverage/MinMax `clipb`; NULL if none */
+    ptrdiff_t src_stride;
+    ptrdiff_t dst_stride;
+    ptrdiff_t ref_stride;
+    int32_t w;
+    int32_t h;
+} vszip_plane;
+
+/*
+ * BoxBlur — replaces boxblur_ct.hvBlur (src/filters/boxblur_comptime.zig:10) and
+ * the RT chain hblur / vblur / hvBlurFused (src/filters/boxblur_runtime.zig:121,
+ * 153, 283) as dispatched by src/vapoursynth/boxblur.zig:85-113,188-209.
+ * Processes `nplanes` independent planes (any mix of sizes, e.g. Y,U,V of many
+ * frames) in one call; path choice (CT vs RT) follows boxblur.zig:188.
+ * Errors mirror boxBlurCreate (boxblur.zig:150-179): nothing to be performed,
+ * 2*radius >= plane size -> VSZIP_ERR_ARG.
+ */
+int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
+                  int hradius, int hpasses, int vradius, int vpasses);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSZIP_HIP_H */

@@ -1,0 +1,69 @@
+"""Build libvszip_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in tree.
+
+    python vapoursynth-zip_amd/build.py [--force] [--keep-temps]
+
+hipcc cross-compiles without a GPU. -ffp-contract=off: the float kernels must
+keep the reference's unfused f32 operation order; fmaf() is written where the
+reference writes @mulAdd.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "_build"
+LIB = PKG / "libvszip_hip.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+    "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.is_file():
+        return True
+    t = out.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build(force: bool = False, keep_temps: bool = False) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+    hdrs = list(CSRC.glob("*.hpp")) + list((PKG.parent / "include").glob("*.h"))
+    jobs = []
+    for s in srcs:
+        o = OBJ / (s.stem + ".o")
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC, *FLAGS, "-c", str(s), "-o", str(o)]
+            if keep_temps:
+                cmd += ["-save-temps=obj"]
+            jobs.append(cmd)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(OBJ))
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        for warn in ex.map(run, jobs):
+            if warn.strip():
+                sys.stderr.write(warn)
+    objs = [OBJ / (s.stem + ".o") for s in srcs]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv)
+    print(p)

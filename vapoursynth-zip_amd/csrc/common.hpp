@@ -1,0 +1,86 @@
+// Shared host/device helpers for the gfx950 vszip kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vszip_hip.h"
+
+#define VSZIP_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct vszip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // grow-only device scratch (filters that need intermediates) and a small
+    // pinned + device pair for returning scalars
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *scalars_dev = nullptr;
+    void *scalars_host = nullptr;
+    size_t scalars_bytes = 0;
+    int scan_mode = 0;  // 0 = DPP wave scan, 1 = shuffle scan (debug / cross-check)
+};
+
+int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
+int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes);
+int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
+
+#define VSZIP_HIP_CHECK(ctx, call)                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return vszip_set_error((ctx), VSZIP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int vszip_dtype_size(int dt) {
+    switch (dt) {
+        case VSZIP_U8: return 1;
+        case VSZIP_U16: return 2;
+        case VSZIP_F16: return 2;
+        case VSZIP_F32: return 4;
+    }
+    return 0;
+}
+
+// ---- device-side helpers ---------------------------------------------------
+#if defined(__HIPCC__)
+
+// Inclusive prefix sum across the 64 lanes of a wave, DPP form (gfx9 row_shr /
+// row_bcast). update_dpp(old=0, src, ...) yields 0 for lanes whose source lane
+// is outside the row / masked off.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_shfl(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;  // valid in lane 0
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,163 @@
+// Context, device memory, staging copies and timers behind include/vszip_hip.h.
+#include "common.hpp"
+
+int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return VSZIP_OK;
+    if (ctx->scratch) {
+        VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        VSZIP_HIP_CHECK(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    const size_t want = bytes + (bytes >> 3) + 4096;
+    if (hipMalloc(&ctx->scratch, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "scratch allocation of %zu bytes failed", want);
+    ctx->scratch_bytes = want;
+    return VSZIP_OK;
+}
+
+int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scalars_bytes) return VSZIP_OK;
+    if (ctx->scalars_dev) {
+        VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->scalars_dev);
+        (void)hipHostFree(ctx->scalars_host);
+        ctx->scalars_dev = ctx->scalars_host = nullptr;
+        ctx->scalars_bytes = 0;
+    }
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    if (hipMalloc(&ctx->scalars_dev, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "scalar buffer allocation failed");
+    if (hipHostMalloc(&ctx->scalars_host, want, hipHostMallocDefault) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "pinned scalar buffer allocation failed");
+    ctx->scalars_bytes = want;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_abi_version(void) { return VSZIP_ABI_VERSION; }
+
+VSZIP_EXPORT int vszip_ctx_create(int device, vszip_ctx **out) {
+    if (!out) return VSZIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return VSZIP_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return VSZIP_ERR_HIP;
+    vszip_ctx *c = new vszip_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return VSZIP_ERR_HIP;
+    }
+    c->own_stream = true;
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    const char *sm = getenv("VSZIP_SCAN_MODE");
+    if (sm) c->scan_mode = atoi(sm);
+    *out = c;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
+    if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+VSZIP_EXPORT int vszip_ctx_set_stream(vszip_ctx *ctx, void *hip_stream) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT void *vszip_ctx_stream(vszip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+VSZIP_EXPORT int vszip_ctx_sync(vszip_ctx *ctx) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT const char *vszip_last_error(vszip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipFree(dptr));
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_dev_memset(vszip_ctx *ctx, void *dptr, int value, size_t bytes) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_host_alloc_pinned(vszip_ctx *ctx, size_t bytes, void **hptr) {
+    if (!ctx || !hptr) return VSZIP_ERR_ARG;
+    if (hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_host_free_pinned(vszip_ctx *ctx, void *hptr) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipHostFree(hptr));
+    return VSZIP_OK;
+}
+
+static int copy2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows, hipMemcpyKind kind) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    if (wb == 0 || rows == 0) return VSZIP_OK;
+    VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, wb, rows, kind, ctx->stream));
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_copy_h2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows) {
+    return copy2d(ctx, dst, dpitch, src, spitch, wb, rows, hipMemcpyHostToDevice);
+}
+VSZIP_EXPORT int vszip_copy_d2h_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows) {
+    return copy2d(ctx, dst, dpitch, src, spitch, wb, rows, hipMemcpyDeviceToHost);
+}
+VSZIP_EXPORT int vszip_copy_d2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows) {
+    return copy2d(ctx, dst, dpitch, src, spitch, wb, rows, hipMemcpyDeviceToDevice);
+}
+
+VSZIP_EXPORT int vszip_timer_start(vszip_ctx *ctx) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_timer_stop_ms(vszip_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    VSZIP_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VSZIP_OK;
+}
