@@ -78,6 +78,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +112,7 @@ def main() -> int:
     table = dev.plane_table(srcs, dsts)
 
     def step():
-        dev.boxblur_table(np.uint16, table, RADIUS, 1, RADIUS, 1)
+        dev.boxblur_table(np.uint16, table, a.radius, 1, a.radius, 1)
 
     def barrier():
         if world > 1:

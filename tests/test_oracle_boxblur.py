@@ -98,6 +98,13 @@ def test_ct_int_closed_forms():
         assert np.array_equal(ref, (col + np.uint64(r)) // np.uint64(k)), r
         m = -(-(1 << 32) // k)
         assert np.array_equal(ref, ((col + np.uint64(r)) * np.uint64(m)) >> np.uint64(32)), r
+        # 24-bit reciprocal form (RingGeom::DIVM / DIVS in csrc/boxblur.hip)
+        sh = 0
+        while (1 << sh) <= (65535 * k + r) * k:
+            sh += 1
+        m24 = -(-(1 << sh) // k)
+        assert m24 < (1 << 24) and sh < 32
+        assert np.array_equal(ref, ((col + np.uint64(r)) * np.uint64(m24)) >> np.uint64(sh)), r
 
 
 def test_ct_hblur_closed_form(oracle):

@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box: rebuild the BoxBlur dev kernel (r=13 only) with extra flag sets and bench each.
+cd $GRAFT_REPO_ROOT
+for flags in "$@"; do
+  VSZIP_DEV_R=13 VSZIP_EXTRA_FLAGS="$flags" python vapoursynth-zip_amd/build.py > /dev/null 2>&1
+  echo -n "[$flags] : "
+  python __graft_entry__.py --smoke 2>&1 | tail -1 | cut -c1-12 | tr '\n' ' '
+  python -m pytest tests/test_gpu_boxblur.py -q -x -k "natural or batch" 2>&1 | tail -1 | cut -c1-20 | tr '\n' ' '
+  python bench.py --steps 20 --warmup 3 --no-cpu 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'fps', round(d['roofline']['avg_launch_us'],1), 'us/launch', round(d['roofline']['frac'],3))"
+done

@@ -34,13 +34,20 @@ def _stale(out: Path, deps) -> bool:
 
 def build(force: bool = False, keep_temps: bool = False) -> Path:
     OBJ.mkdir(exist_ok=True)
+    flags = list(FLAGS)
+    if os.environ.get("VSZIP_DEV_R"):  # development only: one BoxBlur CT radius
+        flags.append("-DVSZIP_DEV_R=" + os.environ["VSZIP_DEV_R"])
+        force = True
+    if os.environ.get("VSZIP_EXTRA_FLAGS"):  # development only
+        flags += os.environ["VSZIP_EXTRA_FLAGS"].split()
+        force = True
     srcs = sorted(CSRC.glob("*.hip"))
-    hdrs = list(CSRC.glob("*.hpp")) + list((PKG.parent / "include").glob("*.h"))
+    hdrs = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list((PKG.parent / "include").glob("*.h"))
     jobs = []
     for s in srcs:
         o = OBJ / (s.stem + ".o")
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC, *FLAGS, "-c", str(s), "-o", str(o)]
+            cmd = [HIPCC, *flags, "-c", str(s), "-o", str(o)]
             if keep_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
@@ -51,7 +58,7 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         for warn in ex.map(run, jobs):
             if warn.strip():
                 sys.stderr.write(warn)

@@ -1,0 +1,849 @@
+// vszip.BoxBlur on gfx950.
+//
+// Replaces src/filters/boxblur_comptime.zig (CT path: hradius == vradius in
+// [1,22], one pass per axis) and src/filters/boxblur_runtime.zig (RT path), as
+// dispatched by src/vapoursynth/boxblur.zig:85-113,188-209.
+//
+// CT integer path (the BASELINE r=13 YUV420P16 case) — one wave streams a
+// column tile down a band of rows:
+//   * lane l owns 8 adjacent columns (one 16-byte load per row for u16);
+//     vertical column sums live in registers and slide by one row per step
+//     (+ entering row, - leaving row), which is exact integer arithmetic and so
+//     identical to the reference's colUpdate/colRecompute (:72-112);
+//   * tmp = (col*inv + 2^31) >> 32 is evaluated as mulhi(col + r, ceil(2^32/k))
+//     (identical for every reachable col; tests/test_oracle_boxblur.py proves it
+//     exhaustively);
+//   * the horizontal 16.16 running sum of hBlurInt (:130-159) has the closed
+//     form  dst[x] = (inv2*E_x + 32768 + ((E_0*invlo) >> 16)) >> 16  with E_x
+//     the edge-duplicating mirrored window sum of tmp, E_0 the one at x = 0,
+//     inv2 = inv >> 16 and invlo = inv & 0xffff.  E_x comes from a wave-wide
+//     prefix sum of tmp (in-lane adds + a DPP scan of the lane totals) parked in
+//     2 KiB of LDS: E_x = P[x+r] - P[x-r-1].  The first lanes of every wave own
+//     plane columns [0, r] so that E_0 is available to every tile.
+//   * virtual columns left of 0 / right of w-1 are loaded from their mirrored
+//     source column, so tile edges need no special window arithmetic.
+// HBM traffic is one read + one write of the plane; the halo rows/columns
+// re-read by neighbouring tiles are L2 / Infinity-Cache hits.
+//
+// Two kernels implement it:
+//   boxblur_ct_ring_kernel  (16-byte aligned planes — every VapourSynth frame):
+//     the 2r+1 window rows stay PACKED IN REGISTERS (a ring of 2r+1+D uint4 per
+//     lane, the row loop unrolled over one ring period so that every slot index
+//     is a compile-time constant), so each source row crosses the fabric once;
+//     rows are prefetched D steps ahead; E_0's term comes from a per-row table
+//     written by boxblur_ct_krow_kernel, which frees two lanes and makes 480
+//     output columns per wave (3840 = 8 tiles, 1920 = 4, 960 = 2); blockIdx is
+//     remapped so that neighbouring tiles/bands run on one XCD and find their
+//     halo in that XCD's L2.
+//   boxblur_ct_int_kernel   (any alignment / stride): window rows re-read from
+//     cache, first lanes own columns [0, r] for E_0.
+#pragma once
+#include <utility>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxPlanes = 48;  // planes per launch (kernel-argument table)
+constexpr int PX = 8;           // pixels per lane per row
+
+struct BBPlane {
+    const void *src;
+    void *dst;
+    int sstride, dstride;  // elements
+    int w, h;
+    int block0;  // first block index of this plane
+    int ntx;     // column tiles
+    int nbands;  // row bands
+    int krow0;   // first entry of this plane in the per-row K table (ring kernel)
+    int kblk0;   // first block of this plane in the K_row kernel's grid
+};
+
+struct BBParams {
+    BBPlane p[kMaxPlanes];
+    int nplanes;
+    int band_rows;
+    int nblocks;
+    uint32_t *krow;  // K_row = 32768 + ((E_0 * invlo) >> 16) per plane row
+};
+
+// boxblur_comptime.zig:50-70 — source row of tap k for output row i.
+__device__ __forceinline__ int ct_tap_row(int k, int i, int radius, int ih) {
+    const int dist_from_bottom = ih - 1 - i;
+    if (k < radius) return (i < radius - k) ? min(radius - k - i, ih - 1) : (i - radius + k);
+    return (dist_from_bottom < k - radius) ? (i - min(k - radius - dist_from_bottom, i)) : (i - radius + k);
+}
+
+// Eight pixels of one lane, still packed as loaded (kept packed while the load is
+// in flight so that no s_waitcnt lands before the row's arithmetic).
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<uint16_t> {
+    uint4 q;
+};
+template <>
+struct Raw8<uint8_t> {
+    uint2 q;
+};
+
+__device__ __forceinline__ void unpack8(const Raw8<uint16_t> &r, uint32_t v[PX]) {
+    v[0] = r.q.x & 0xffffu; v[1] = r.q.x >> 16;
+    v[2] = r.q.y & 0xffffu; v[3] = r.q.y >> 16;
+    v[4] = r.q.z & 0xffffu; v[5] = r.q.z >> 16;
+    v[6] = r.q.w & 0xffffu; v[7] = r.q.w >> 16;
+}
+
+__device__ __forceinline__ void unpack8(const Raw8<uint8_t> &r, uint32_t v[PX]) {
+    v[0] = r.q.x & 0xffu; v[1] = (r.q.x >> 8) & 0xffu; v[2] = (r.q.x >> 16) & 0xffu; v[3] = r.q.x >> 24;
+    v[4] = r.q.y & 0xffu; v[5] = (r.q.y >> 8) & 0xffu; v[6] = (r.q.y >> 16) & 0xffu; v[7] = r.q.y >> 24;
+}
+
+__device__ __forceinline__ void pack8(const uint32_t v[PX], Raw8<uint16_t> &r) {
+    r.q.x = v[0] | (v[1] << 16);
+    r.q.y = v[2] | (v[3] << 16);
+    r.q.z = v[4] | (v[5] << 16);
+    r.q.w = v[6] | (v[7] << 16);
+}
+
+__device__ __forceinline__ void pack8(const uint32_t v[PX], Raw8<uint8_t> &r) {
+    r.q.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    r.q.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+}
+
+// Edge-duplicating mirror of a virtual column (hBlurInt's implicit padding:
+// index -k -> k-1, index w-1+k -> w-k), clamped for halo columns nobody reads.
+__device__ __forceinline__ int mirror_col(int c, int w) {
+    c = c < 0 ? -c - 1 : c;
+    c = c >= w ? 2 * w - 1 - c : c;
+    return min(max(c, 0), w - 1);
+}
+
+template <typename T>
+__device__ __forceinline__ Raw8<T> load8(const T *row, int vx0, int w, bool fast) {
+    Raw8<T> r;
+    if (fast) {
+        r.q = *reinterpret_cast<const decltype(r.q) *>(row + vx0);
+    } else {
+        uint32_t v[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) v[k] = row[mirror_col(vx0 + k, w)];
+        pack8(v, r);
+    }
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(T *row, int x0, int w, bool fast, const uint32_t o[PX]);
+
+template <>
+__device__ __forceinline__ void store8<uint16_t>(uint16_t *row, int x0, int w, bool fast, const uint32_t o[PX]) {
+    if (fast) {
+        uint4 q;
+        q.x = (o[0] & 0xffffu) | (o[1] << 16);
+        q.y = (o[2] & 0xffffu) | (o[3] << 16);
+        q.z = (o[4] & 0xffffu) | (o[5] << 16);
+        q.w = (o[6] & 0xffffu) | (o[7] << 16);
+        *reinterpret_cast<uint4 *>(row + x0) = q;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PX; ++k)
+            if (x0 + k < w) row[x0 + k] = (uint16_t)o[k];
+    }
+}
+
+template <>
+__device__ __forceinline__ void store8<uint8_t>(uint8_t *row, int x0, int w, bool fast, const uint32_t o[PX]) {
+    if (fast) {
+        uint2 q;
+        q.x = (o[0] & 0xffu) | ((o[1] & 0xffu) << 8) | ((o[2] & 0xffu) << 16) | (o[3] << 24);
+        q.y = (o[4] & 0xffu) | ((o[5] & 0xffu) << 8) | ((o[6] & 0xffu) << 16) | (o[7] << 24);
+        *reinterpret_cast<uint2 *>(row + x0) = q;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PX; ++k)
+            if (x0 + k < w) row[x0 + k] = (uint8_t)o[k];
+    }
+}
+
+template <int R>
+struct CtGeom {
+    static constexpr int K = 2 * R + 1;
+    static constexpr int NE = (R + 1 + PX - 1) / PX;   // lanes owning plane columns [0, 8*NE) for E_0
+    static constexpr int HL = NE * PX;                 // left halo  (>= R + 1)
+    static constexpr int HR = ((R + PX - 1) / PX) * PX; // right halo (>= R)
+    static constexpr int OUT_LANES = 64 - NE - HL / PX - HR / PX;
+    static constexpr int TWO = OUT_LANES * PX;         // output columns per wave tile
+};
+
+// Wave-level ordering of LDS traffic (single-wave workgroups: no s_barrier, no
+// vmcnt drain — global prefetches stay in flight across it).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int R, bool DPP>
+__global__ __launch_bounds__(64) void boxblur_ct_int_kernel(const BBParams prm) {
+    using G = CtGeom<R>;
+    constexpr uint32_t K = G::K;
+    constexpr uint32_t MAGIC = (uint32_t)(((1ull << 32) + K - 1) / K);  // ceil(2^32 / k)
+    constexpr uint64_t INV = ((1ull << 32) + R) / K;                    // boxblur_comptime.zig:28
+    constexpr uint32_t INV2 = (uint32_t)(INV >> 16);
+    constexpr uint32_t INVLO = (uint32_t)(INV & 0xffffu);
+
+    __shared__ __attribute__((aligned(16))) uint32_t P[64 * PX];
+
+    // block -> (plane, column tile, row band)
+    int pi = 0;
+    const int b = blockIdx.x;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const BBPlane pl = prm.p[pi];
+    const int lb = b - pl.block0;
+    const int tx = lb % pl.ntx;
+    const int by = lb / pl.ntx;
+    const int w = pl.w, h = pl.h;
+    const int y0 = by * prm.band_rows;
+    const int y1 = min(y0 + prm.band_rows, h);
+    const T *src = static_cast<const T *>(pl.src);
+    T *dst = static_cast<T *>(pl.dst);
+
+    const int lane = threadIdx.x;
+    const int X0 = tx * G::TWO;
+    const int vx0 = lane < G::NE ? lane * PX : X0 - G::HL + (lane - G::NE) * PX;
+    constexpr int VB = sizeof(T) * PX;  // bytes per lane-load
+    const bool src_al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)((size_t)pl.sstride * sizeof(T))) & (VB - 1)) == 0;
+    const bool dst_al = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)((size_t)pl.dstride * sizeof(T))) & (VB - 1)) == 0;
+    const bool in_fast = src_al && vx0 >= 0 && vx0 + PX <= w;
+    const bool is_out = lane >= G::NE + G::HL / PX && lane < G::NE + G::HL / PX + G::OUT_LANES && vx0 < w;
+    const bool out_fast = dst_al && vx0 + PX <= w;
+
+    // column sums of the first row of the band: the ksize mirrored taps (:50-70, :91-112)
+    uint32_t col[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) col[k] = 0;
+#pragma unroll 1
+    for (int k = 0; k < (int)K; ++k) {
+        uint32_t v[PX];
+        unpack8(load8<T>(src + (size_t)ct_tap_row(k, y0, R, h) * pl.sstride, vx0, w, in_fast), v);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) col[j] += v[j];
+    }
+
+    const int ci = lane * PX;  // this lane's first index into P
+#pragma unroll 1
+    for (int i = y0; i < y1; ++i) {
+        // prefetch the rows that slide the window to output row i+1:
+        //   entering row (i+1)+r, or (i+1)-1 once the window hangs over the bottom edge;
+        //   leaving  row (i+1)-r-1, or r-(i+1)+1 while the window hangs over the top edge.
+        Raw8<T> an, sn;
+        const bool more = i + 1 < y1;
+        if (more) {
+            const int n = i + 1;
+            const int ar = (n + R < h) ? n + R : n - 1;
+            const int sr = (n <= R) ? R - n + 1 : n - R - 1;
+            an = load8<T>(src + (size_t)ar * pl.sstride, vx0, w, in_fast);
+            sn = load8<T>(src + (size_t)sr * pl.sstride, vx0, w, in_fast);
+        }
+
+        // vertical mean, rounded (:114-128), then in-lane inclusive prefix
+        uint32_t p[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) p[k] = __umulhi(col[k] + R, MAGIC);
+#pragma unroll
+        for (int k = 1; k < PX; ++k) p[k] += p[k - 1];
+        const uint32_t incl = DPP ? wave_incl_scan_dpp(p[PX - 1]) : wave_incl_scan_shfl(p[PX - 1]);
+        const uint32_t base = incl - p[PX - 1];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) p[k] += base;
+        *reinterpret_cast<uint4 *>(&P[ci]) = make_uint4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<uint4 *>(&P[ci + 4]) = make_uint4(p[4], p[5], p[6], p[7]);
+        wave_lds_fence();
+
+        if (is_out) {
+            // E_0 = tmp[r] + 2*sum_{x<r} tmp[x]  (:131-137)
+            const uint32_t e0 = P[R] + P[R - 1];
+            const uint32_t krow = 32768u + (uint32_t)(((uint64_t)e0 * INVLO) >> 16);
+            uint32_t o[PX];
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                const uint32_t e = P[ci + k + R] - P[ci + k - R - 1];
+                o[k] = (uint32_t)(((uint64_t)e * INV2 + krow) >> 16);
+            }
+            store8<T>(dst + (size_t)i * pl.dstride, vx0, w, out_fast, o);
+        }
+        wave_lds_fence();
+
+        if (more) {
+            uint32_t a[PX], sb[PX];
+            unpack8(an, a);
+            unpack8(sn, sb);
+#pragma unroll
+            for (int k = 0; k < PX; ++k) col[k] += a[k] - sb[k];
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Ring kernel
+// ---------------------------------------------------------------------------
+
+template <int R, int SLOT_VGPRS = 4>
+struct RingGeom {
+    static constexpr int K = 2 * R + 1;
+    static constexpr int HL = ((R + 1 + PX - 1) / PX) * PX;  // left halo  (>= R + 1)
+    static constexpr int HR = ((R + PX - 1) / PX) * PX;      // right halo (>= R)
+    static constexpr int OUT_LANES = 64 - HL / PX - HR / PX;
+    static constexpr int TWO = OUT_LANES * PX;
+    // rows prefetched ahead of their first use. D is odd so that NR is even (the
+    // LDS double buffer alternates with the slot).
+#ifdef VSZIP_RING_D
+    static constexpr int D = VSZIP_RING_D | 1;
+#else
+    static constexpr int D = 3;
+#endif
+    static constexpr int NR = 2 * R + 1 + D;   // ring slots (<= 64: K_row travels by readlane)
+    static constexpr int EC = HL;              // columns the K_row kernel loads (>= R + 1)
+    // tmp = (col + r) / k as (n * DIVM) >> DIVS with 24-bit operands (full-rate
+    // v_mul_u32_u24 / v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32):
+    // exact while 2^DIVS > n_max * k (tests/test_oracle_boxblur.py checks every n).
+    static constexpr int div_shift() {
+        int s = 0;
+        while ((1ull << s) <= (65535ull * K + R) * K) ++s;
+        return s;
+    }
+    static constexpr uint32_t MAGIC = (uint32_t)(((1ull << 32) + K - 1) / K);  // ceil(2^32 / k): mulhi(n, MAGIC) == n / k
+    static constexpr int DIVS = div_shift();
+    static constexpr uint32_t DIVM = (uint32_t)(((1ull << DIVS) + K - 1) / K);
+    static_assert(DIVM < (1u << 24) && DIVS < 32, "24-bit reciprocal out of range");
+};
+
+// K_row for every row of every plane: E_0 = tmp[r] + 2*sum_{x<r} tmp[x] needs the
+// vertical means of columns 0..r only (boxblur_comptime.zig:131-137). One wave per
+// 64 rows: every needed source row segment (EC columns) is read from memory once
+// into LDS, each lane then sums its row's 2r+1 taps from LDS.
+template <typename T, int R>
+__global__ __launch_bounds__(64) void boxblur_ct_krow_kernel(const BBParams prm) {
+    using G = RingGeom<R>;
+    constexpr int K = G::K;
+    constexpr uint64_t INV = ((1ull << 32) + R) / K;
+    constexpr uint32_t INVLO = (uint32_t)(INV & 0xffffu);
+    constexpr int ROWS = 64 + 2 * R;
+    constexpr int NV = G::EC / PX;  // lane-vectors per row segment
+    __shared__ __attribute__((aligned(16))) Raw8<T> tile[ROWS * NV];
+
+    const int b = blockIdx.x;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].kblk0) pi = i;
+    const BBPlane pl = prm.p[pi];
+    const int y0 = (b - pl.kblk0) * 64;
+    const int h = pl.h;
+    const T *src = static_cast<const T *>(pl.src);
+    const int lane = threadIdx.x;
+
+    // tile row j holds virtual row v = y0 - r + j: |v| above the top edge (reflect-101);
+    // rows past the bottom are clamped (the bottom taps below never index them)
+#pragma unroll
+    for (int j0 = 0; j0 < ROWS; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < ROWS) {
+            const int v = y0 - R + j;
+            const T *row = src + (size_t)min(v < 0 ? -v : v, h - 1) * pl.sstride;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) tile[j * NV + c].q = *reinterpret_cast<const decltype(tile[0].q) *>(row + c * PX);
+        }
+    }
+    __syncthreads();
+
+    const int i = y0 + lane;
+    if (i >= h) return;
+    uint32_t col[G::EC];
+#pragma unroll
+    for (int c = 0; c < G::EC; ++c) col[c] = R;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        // boxblur_comptime.zig:50-70: taps past the bottom edge mirror about row i
+        const int v = i - R + k;
+        const int j = v <= h - 1 ? lane + k : lane + R - (v - (h - 1));
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            uint32_t x[PX];
+            unpack8(tile[j * NV + c], x);
+#pragma unroll
+            for (int q = 0; q < PX; ++q) col[c * PX + q] += x[q];
+        }
+    }
+    uint32_t e0 = col[R] / (uint32_t)K;
+#pragma unroll
+    for (int c = 0; c < R; ++c) e0 += 2u * (col[c] / (uint32_t)K);
+    prm.krow[pl.krow0 + i] = 32768u + (uint32_t)(((uint64_t)e0 * INVLO) >> 16);
+}
+
+// All per-wave state of the ring kernel. step<S>() is instantiated once per ring
+// slot so that every ring index is a compile-time constant and the ring stays in
+// VGPRs (a runtime-indexed array would be demoted to scratch). A ring period is
+// straight-line code: bands are whole periods (the last band of a plane is
+// shifted up to end at the last row and recomputes a few rows of its neighbour,
+// writing identical values), so no step is conditional and every row load lands
+// directly in its slot, D steps before its first use.
+//
+// GENERAL = false needs w % 8 == 0: lanes whose columns fall outside the plane hold
+// the edge-duplicating mirror image (hBlurInt's implicit padding, :139-158) of a
+// real 8-pixel group, pixel order reversed in registers, so that the window sum is
+// the same compile-time-offset prefix difference everywhere. GENERAL = true takes
+// any width: plane edges are evaluated as prefix differences over real columns.
+template <typename T, int R, bool GENERAL>
+struct RingWave {
+    using G = RingGeom<R, (int)(sizeof(T) * PX / 4)>;
+    using Vec = decltype(Raw8<T>{}.q);
+    static constexpr int NR = G::NR;
+    static constexpr uint64_t INV = ((1ull << 32) + R) / (uint64_t)G::K;
+    static constexpr uint32_t INV2 = (uint32_t)(INV >> 16);
+
+    Raw8<T> ring[NR];
+    uint32_t col[PX];
+    uint32_t krv;       // lane l: K_row of row i0 + l of the current ring period
+    uint32_t kr_carry;  // K_row of the last row of the previous period
+    uint32_t *P;
+    const char *srcb;   // wave-uniform plane bases
+    char *dstb;
+    const uint32_t *krow;
+    uint32_t coff;      // byte offset of this lane's (real) column group in a row
+    uint32_t doff;      // byte offset of this lane's output group in a row
+    uint32_t next_off;  // wave-uniform: byte offset of the source row the next refill reads
+    uint32_t out_off;   // wave-uniform: byte offset of the destination row the next emit writes
+    uint32_t srow, drow;  // row pitches in bytes
+    int w, h, lane, c0;
+    bool rev, ld_ok, is_out, out_full;
+    bool any_rev;  // wave-uniform: this tile has mirrored lanes
+    bool plain;    // wave-uniform: every row this band touches is an interior source row
+
+    __device__ __forceinline__ Raw8<T> fetch_off(uint32_t row_off) const {
+        Raw8<T> t;
+        t.q = *reinterpret_cast<const Vec *>(srcb + (row_off + coff));
+        return t;
+    }
+    // Virtual row v of the sliding window -> source row. Above the top edge: |v|
+    // (reflect-101, boxblur_comptime.zig:56-59). Past the bottom edge the window
+    // mirrors about the CURRENT row (:61-66): sliding from row i to i+1 then adds
+    // row i, not row i+1+r, i.e. virtual row v >= h stands for source row v-r-1.
+    // With that map the ring's "entering row" slot is always the right one.
+    __device__ __forceinline__ uint32_t row_off(int v) const {
+        const int r = v < 0 ? -v : (v < h ? v : v - R - 1);
+        return (uint32_t)min(r, h - 1) * srow;
+    }
+
+    template <int J>
+    __device__ __forceinline__ void fill(int y0) {
+        ring[J] = fetch_off(row_off(y0 - R + J));
+    }
+    template <int J>
+    __device__ __forceinline__ void accum() {
+        uint32_t v[PX];
+        unpack8(ring[J], v);
+#pragma unroll
+        for (int k = 0; k < PX; ++k) col[k] += v[k];
+    }
+    template <int... J>
+    __device__ __forceinline__ void fill_all(int y0, std::integer_sequence<int, J...>) {
+        (fill<J>(y0), ...);
+    }
+    template <int... J>
+    __device__ __forceinline__ void accum_all(std::integer_sequence<int, J...>) {
+        (accum<J>(), ...);
+    }
+
+    // LDS layout of the prefix: column c of the wave tile lives at (c % 8) * 64 + c / 8,
+    // i.e. [pixel-in-lane][lane]. For a fixed pixel index the 64 lanes touch 64
+    // consecutive dwords, so every read and write is bank-conflict free (the natural
+    // [lane][pixel] layout is an 8-way conflict: lane stride = 8 dwords over 32 banks).
+    static __device__ __forceinline__ int pidx(int c) { return (c & (PX - 1)) * 64 + (c >> 3); }
+
+    // Window sums E_x of one row from the prefix parked in LDS.
+    __device__ __forceinline__ void window_sums(const uint32_t *Pb, uint32_t e[PX]) const {
+        if constexpr (!GENERAL) {
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                // compile-time offsets from the lane's own slot: (k+r) and (k-r-1) split
+                // into pixel-in-lane and lane displacement
+                const int hi = k + R, lo = k - R - 1;
+                const int hi_px = hi & (PX - 1), hi_ln = hi >> 3;
+                const int lo_px = lo & (PX - 1), lo_ln = (lo - lo_px) / PX;  // floor
+                e[k] = Pb[hi_px * 64 + lane + hi_ln] - Pb[lo_px * 64 + lane + lo_ln];
+            }
+        } else {
+            // Plane edges as prefix differences over real columns, Q(c) = sum_{j<=c} tmp[j], Q(-1) = 0:
+            //   E_x = Q(min(x+r, w-1)) - Q(x-r-1) + Q(w-1) - Q(min(2w-2-x-r, w-1)) + Q(r-x-1)
+            // (the mirrored terms cancel by themselves away from the edges).
+            const int off = lane * PX - c0;  // tile index of plane column c is c + off
+            auto lds = [&](int idx) { return Pb[pidx(min(max(idx, 0), 64 * PX - 1))]; };
+            const uint32_t qw = lds(w - 1 + off);
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                const int x = c0 + k;
+                const int lo = x - R - 1, ml = R - x - 1;
+                uint32_t v = lds(min(x + R, w - 1) + off) + qw - lds(min(2 * w - 2 - x - R, w - 1) + off);
+                v -= lo >= 0 ? lds(lo + off) : 0u;
+                v += ml >= 0 ? lds(ml + off) : 0u;
+                e[k] = v;
+            }
+        }
+    }
+
+    // dst[x] = (inv2*E_x + K_row) >> 16 (hBlurInt :130-159 in closed form). The 16.16
+    // sum is the running mean + 0.5 and never exceeds 65535.5 * 65536, so it fits 32
+    // bits: one 24-bit multiply-add per pixel, the result is the high half.
+    __device__ __forceinline__ void emit_row(const uint32_t e[PX], uint32_t row_off_bytes, uint32_t kr) const {
+#ifdef VSZIP_ABL_NOEMIT
+        return;
+#endif
+        if (!is_out) return;
+        uint32_t t[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) t[k] = __umul24(e[k], INV2) + kr;
+#ifdef VSZIP_ABL_NOSTORE
+        if (t[0] + t[3] + t[7] != 0x12345u) return;  // keeps the arithmetic alive, never stores
+#endif
+        T *q = reinterpret_cast<T *>(dstb + (row_off_bytes + doff));
+        if (!GENERAL || out_full) {
+            if constexpr (sizeof(T) == 2) {
+                uint4 v;
+                v.x = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u);
+                v.y = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u);
+                v.z = __builtin_amdgcn_perm(t[5], t[4], 0x07060302u);
+                v.w = __builtin_amdgcn_perm(t[7], t[6], 0x07060302u);
+                *reinterpret_cast<uint4 *>(q) = v;
+            } else {
+                uint2 v;
+                const uint32_t a0 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u);  // bytes: t0.2, t1.2, 0, 0
+                const uint32_t a1 = __builtin_amdgcn_perm(t[3], t[2], 0x0c0c0602u);
+                const uint32_t a2 = __builtin_amdgcn_perm(t[5], t[4], 0x0c0c0602u);
+                const uint32_t a3 = __builtin_amdgcn_perm(t[7], t[6], 0x0c0c0602u);
+                v.x = a0 | (a1 << 16);
+                v.y = a2 | (a3 << 16);
+                *reinterpret_cast<uint2 *>(q) = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PX; ++k)
+                if (c0 + k < w) q[k] = (T)(t[k] >> 16);
+        }
+    }
+
+    // One row step, software-pipelined by one row so that two independent
+    // dependency chains are in flight per wave:
+    //   A(i):   column sums -> rounded vertical mean -> wave prefix -> LDS buffer S&1
+    //   B(i-1): window sums of the previous row from LDS buffer (S&1)^1 -> store
+    // NR is even, so the buffer parity is a compile-time property of the slot.
+    template <int S>
+    __device__ __forceinline__ void step(int i, int y0) {
+        uint32_t *Pa = P + (S & 1) * (64 * PX);
+        const uint32_t *Pb = P + ((S & 1) ^ 1) * (64 * PX);
+
+        // B (first half): LDS reads of the previous row's prefix
+        uint32_t e[PX];
+        const bool have_prev = S > 0 || i > y0;
+        if (have_prev) window_sums(Pb, e);
+
+        // A: vertical mean, rounded (:114-128; col carries the +r), wave-wide inclusive prefix
+        uint32_t t[PX], p[PX];
+#pragma unroll
+#ifdef VSZIP_DIV24
+        for (int k = 0; k < PX; ++k) t[k] = (uint32_t)(((uint64_t)(col[k] & 0xffffffu) * G::DIVM) >> G::DIVS);
+#else
+        for (int k = 0; k < PX; ++k) t[k] = __umulhi(col[k], G::MAGIC);
+#endif
+        if constexpr (!GENERAL) {
+            // mirrored lanes hold their pixels in reverse plane order
+            if (any_rev) {
+#pragma unroll
+                for (int k = 0; k < PX; ++k) p[k] = rev ? t[PX - 1 - k] : t[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < PX; ++k) p[k] = t[k];
+            }
+        } else {
+            const uint32_t m = ld_ok ? 0xffffffffu : 0u;  // lanes outside the plane hold zeros
+#pragma unroll
+            for (int k = 0; k < PX; ++k) p[k] = t[k] & m;
+        }
+#pragma unroll
+        for (int k = 1; k < PX; ++k) p[k] += p[k - 1];
+        const uint32_t incl = wave_incl_scan_dpp(p[PX - 1]);
+        const uint32_t base = incl - p[PX - 1];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) Pa[k * 64 + lane] = p[k] + base;
+
+        // slide the window to row i+1: entering row i+1+r (or row i once the window
+        // hangs over the bottom edge, :61-66), leaving row i-r; refill the freed slot
+        // with row i+1+r+D (|v| above the top edge, clamped below the bottom edge).
+        {
+            uint32_t a[PX], sb[PX];
+            unpack8(ring[(S + 1 + 2 * R) % NR], a);
+            unpack8(ring[S], sb);
+#pragma unroll
+            for (int k = 0; k < PX; ++k) col[k] += a[k] - sb[k];
+#ifndef VSZIP_ABL_NOLOAD
+            ring[S] = fetch_off(next_off);
+#endif
+            // advance the refill row: plain bands just step down one row
+            if (plain)
+                next_off += srow;
+            else
+                next_off = row_off(i + 2 + R + G::D);
+        }
+
+        // B (second half): scale and store the previous row
+        if (have_prev) {
+            const uint32_t kr = S > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)krv, S > 0 ? S - 1 : 0) : kr_carry;
+            emit_row(e, out_off, kr);
+            out_off += drow;
+        }
+        if (S == NR - 1) kr_carry = (uint32_t)__builtin_amdgcn_readlane((int)krv, NR - 1);
+        wave_lds_fence();
+    }
+
+    template <int... S>
+    __device__ __forceinline__ void period(int i0, int y0, std::integer_sequence<int, S...>) {
+        krv = krow[i0 + lane < h ? i0 + lane : h - 1];
+        (step<S>(i0 + S, y0), ...);
+    }
+};
+
+#ifndef VSZIP_RING_WPE
+#define VSZIP_RING_WPE 2
+#endif
+
+template <typename T, int R, bool GENERAL>
+__global__ __launch_bounds__(64, VSZIP_RING_WPE) void boxblur_ct_ring_kernel(const BBParams prm) {
+    using W = RingWave<T, R, GENERAL>;
+    using G = typename W::G;
+    static_assert(G::NR % 2 == 0 && G::NR <= 64, "ring period must be even and fit a wave");
+    __shared__ __attribute__((aligned(16))) uint32_t P[2 * 64 * PX];
+
+    // XCD-aware remap: blocks b and b+8 share an XCD, so give every XCD one
+    // contiguous chunk of the (plane, band, tile) list — neighbours share an L2.
+    const int chunk = (prm.nblocks + 7) >> 3;
+    const int b = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (b >= prm.nblocks) return;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const BBPlane pl = prm.p[pi];
+    const int lb = b - pl.block0;
+    const int tx = lb % pl.ntx;
+    const int by = lb / pl.ntx;
+    const int y0 = min(by * prm.band_rows, pl.h - prm.band_rows);  // last band shifted up
+    const int w = pl.w;
+
+    W st;
+    st.P = P;
+    st.w = w;
+    st.h = pl.h;
+    st.srow = (uint32_t)pl.sstride * (uint32_t)sizeof(T);
+    st.drow = (uint32_t)pl.dstride * (uint32_t)sizeof(T);
+    st.srcb = static_cast<const char *>(pl.src);
+    st.dstb = static_cast<char *>(pl.dst);
+    st.krow = prm.krow + pl.krow0;
+    const int lane = threadIdx.x;
+    st.lane = lane;
+    const int vc0 = tx * G::TWO - G::HL + lane * PX;  // first (virtual) plane column of this lane
+    st.c0 = vc0;
+    st.is_out = lane >= G::HL / PX && lane < G::HL / PX + G::OUT_LANES && vc0 < w;
+    st.doff = (uint32_t)(max(vc0, 0) * (int)sizeof(T));
+    st.out_full = vc0 + PX <= w;
+    if constexpr (!GENERAL) {
+        // real 8-pixel group behind this lane: itself, or its edge-duplicating mirror image
+        int g = vc0;
+        st.rev = false;
+        if (vc0 < 0) {
+            g = -vc0 - PX;
+            st.rev = true;
+        } else if (vc0 >= w) {
+            g = 2 * w - vc0 - PX;
+            st.rev = true;
+        }
+        g = min(max(g, 0), w - PX);
+        st.coff = (uint32_t)(g * (int)sizeof(T));
+        st.ld_ok = true;
+    } else {
+        st.rev = false;
+        st.ld_ok = vc0 >= 0 && vc0 < w;  // [w, stride) is readable padding
+        st.coff = (uint32_t)(min(max(vc0, 0), ((w - 1) / PX) * PX) * (int)sizeof(T));
+    }
+
+    st.any_rev = !GENERAL && (tx == 0 || (tx + 1) * G::TWO + G::HR > w);
+    st.plain = (y0 - R >= 0) && (y0 + prm.band_rows + R + G::D + 2 < pl.h);
+
+    st.fill_all(y0, std::make_integer_sequence<int, G::NR>{});
+#pragma unroll
+    for (int k = 0; k < PX; ++k) st.col[k] = R;  // the rounding term of (col + r) / k rides along
+    st.accum_all(std::make_integer_sequence<int, (int)G::K>{});
+    st.kr_carry = 0;
+    st.next_off = st.row_off(y0 + 1 + R + G::D);  // window rows y0-r .. y0+r+D are in the ring
+    st.out_off = (uint32_t)y0 * st.drow;
+
+    const int y1 = y0 + prm.band_rows;
+#pragma unroll 1
+    for (int i0 = y0; i0 < y1; i0 += G::NR) st.period(i0, y0, std::make_integer_sequence<int, G::NR>{});
+    {
+        uint32_t e[PX];  // last row of the band: slot NR-1 wrote the odd buffer
+        st.window_sums(P + 64 * PX, e);
+        st.emit_row(e, st.out_off, st.kr_carry);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+template <typename T, int R>
+int launch_ct_int(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
+    using G = CtGeom<R>;
+    int done = 0;
+    while (done < nplanes) {
+        BBParams prm;
+        const int n = std::min(kMaxPlanes, nplanes - done);
+        prm.nplanes = n;
+        // rows per band: enough bands to fill the chip, few enough that the
+        // (2r+1)-row warm-up of every band stays a small fraction of the work
+        long total_px = 0;
+        for (int i = 0; i < n; ++i) total_px += (long)planes[done + i].w * planes[done + i].h;
+        int band = 64;
+        while (band > 16 && total_px / ((long)G::TWO * band) < 4096) band >>= 1;
+        prm.band_rows = band;
+        prm.krow = nullptr;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const vszip_plane &s = planes[done + i];
+            BBPlane &d = prm.p[i];
+            d.src = s.src;
+            d.dst = s.dst;
+            d.sstride = (int)s.src_stride;
+            d.dstride = (int)s.dst_stride;
+            d.w = s.w;
+            d.h = s.h;
+            d.block0 = blocks;
+            d.ntx = (s.w + G::TWO - 1) / G::TWO;
+            d.nbands = (s.h + band - 1) / band;
+            d.krow0 = 0;
+            d.kblk0 = 0;
+            blocks += d.ntx * d.nbands;
+        }
+        if (ctx->scan_mode == 1)
+            hipLaunchKernelGGL((boxblur_ct_int_kernel<T, R, false>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+        else
+            hipLaunchKernelGGL((boxblur_ct_int_kernel<T, R, true>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
+}
+
+template <typename T, int R>
+int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
+    using G = typename RingWave<T, R, false>::G;
+    int done = 0;
+    while (done < nplanes) {
+        BBParams prm;
+        const int n = std::min(kMaxPlanes, nplanes - done);
+        long wave_rows = 0;
+        int total_rows = 0, min_h = 1 << 30;
+        bool mult8 = true;
+        for (int i = 0; i < n; ++i) {
+            const vszip_plane &s = planes[done + i];
+            wave_rows += (long)((s.w + G::TWO - 1) / G::TWO) * s.h;
+            total_rows += s.h;
+            min_h = std::min(min_h, (int)s.h);
+            mult8 = mult8 && (s.w % PX == 0);
+        }
+        // rows per band = whole ring periods: at least ~4 generations of the waves the
+        // chip holds at two waves per SIMD, so the last generation's tail stays small
+        int periods = 4;
+        while (periods > 1 && (wave_rows / ((long)periods * G::NR) < 8192 || periods * G::NR > min_h)) --periods;
+        const int band = periods * G::NR;
+        VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        int rc = vszip_ensure_scratch(ctx, (size_t)total_rows * sizeof(uint32_t));
+        if (rc != VSZIP_OK) return rc;
+        prm.nplanes = n;
+        prm.band_rows = band;
+        prm.krow = static_cast<uint32_t *>(ctx->scratch);
+        int blocks = 0, kblocks = 0, rows = 0;
+        for (int i = 0; i < n; ++i) {
+            const vszip_plane &s = planes[done + i];
+            BBPlane &d = prm.p[i];
+            d.src = s.src;
+            d.dst = s.dst;
+            d.sstride = (int)s.src_stride;
+            d.dstride = (int)s.dst_stride;
+            d.w = s.w;
+            d.h = s.h;
+            d.nbands = (s.h + band - 1) / band;
+            d.krow0 = rows;
+            d.kblk0 = kblocks;
+            d.ntx = (s.w + G::TWO - 1) / G::TWO;
+            d.block0 = blocks;
+            blocks += d.ntx * d.nbands;
+            kblocks += (s.h + 63) / 64;
+            rows += s.h;
+        }
+        prm.nblocks = blocks;
+        hipLaunchKernelGGL((boxblur_ct_krow_kernel<T, R>), dim3(kblocks), dim3(64), 0, ctx->stream, prm);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        const dim3 grid(((blocks + 7) / 8) * 8);
+        if (mult8)
+            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false>), grid, dim3(64), 0, ctx->stream, prm);
+        else
+            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
+}
+
+// The ring kernel needs 16-byte (u8: 8-byte) aligned rows and a row pitch that
+// covers whole lane groups; VapourSynth frames always satisfy this.
+template <typename T>
+bool ring_ok(const vszip_plane *planes, int nplanes) {
+    constexpr uintptr_t VB = sizeof(T) * PX;
+    for (int i = 0; i < nplanes; ++i) {
+        const vszip_plane &p = planes[i];
+        if ((reinterpret_cast<uintptr_t>(p.src) | reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)(p.src_stride * sizeof(T)) | (uintptr_t)(p.dst_stride * sizeof(T))) & (VB - 1)) return false;
+        if (p.src_stride < ((p.w + PX - 1) / PX) * PX) return false;
+        if (p.src_stride < 24) return false;       // K_row kernel reads columns [0, HL)
+        if (p.h < 2 * 22 + 1 + 8) return false;    // a band is at least one ring period
+        if ((uint64_t)p.src_stride * p.h * sizeof(T) >= (1ull << 32) || (uint64_t)p.dst_stride * p.h * sizeof(T) >= (1ull << 32)) return false;  // 32-bit row offsets
+    }
+    return true;
+}
+
+// Development builds (-DVSZIP_DEV_R=13) instantiate a single radius to keep the
+// edit-compile-measure loop short; release builds carry all 22.
+#ifdef VSZIP_DEV_R
+#define VSZIP_R_ENABLED(R) ((R) == VSZIP_DEV_R)
+#else
+#define VSZIP_R_ENABLED(R) true
+#endif
+
+template <typename T, int R, int RLO>
+struct CtIntDispatch {
+    static int run(vszip_ctx *ctx, int r, const vszip_plane *planes, int nplanes) {
+        if constexpr (VSZIP_R_ENABLED(R)) if (r == R) {
+            if (ctx->scan_mode == 0 && ring_ok<T>(planes, nplanes)) return launch_ct_ring<T, R>(ctx, planes, nplanes);
+            return launch_ct_int<T, R>(ctx, planes, nplanes);
+        }
+        if constexpr (R > RLO)
+            return CtIntDispatch<T, R - 1, RLO>::run(ctx, r, planes, nplanes);
+        else
+            return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: CT radius not built (development build?)");
+    }
+};
+
+}  // namespace

@@ -26,7 +26,7 @@ struct vszip_ctx {
     void *scalars_dev = nullptr;
     void *scalars_host = nullptr;
     size_t scalars_bytes = 0;
-    int scan_mode = 0;  // 0 = DPP wave scan, 1 = shuffle scan (debug / cross-check)
+    int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
 };
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
