@@ -1,0 +1,213 @@
+"""CPU oracle vs the reference's goldens / known-answer tests for Bilateral, EEDI3(H),
+PlaneAverage, PlaneMinMax, SSIMULACRA2, XPSNR. Keys are the reference's own
+(tests/goldens/*.json; cases in tests/test_*.py) on the inputs that are reproducible
+without VapourSynth/zimg."""
+import math
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+REL = 1e-6
+
+
+def _check(stats, gold, rel=REL):
+    for k in ("avg", "min", "max"):
+        assert stats[k] == pytest.approx(gold[k], rel=rel, abs=1e-9), (k, stats[k], gold[k])
+
+
+# ---- Bilateral --------------------------------------------------------------
+def _bilateral(oracle, planes, sigmaS, sigmaR, **kw):
+    prm = oracle.bilateral_params([sigmaS], [sigmaR], **kw)
+    out = []
+    for i, p in enumerate(planes):
+        out.append(oracle.bilateral_plane(np.ascontiguousarray(p), prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i],
+                                          prm["step"][i], prm["PBFICnum"][i]))
+    return out, prm
+
+
+def test_bilateral_params_baseline(oracle):
+    """BASELINE config: sigmaS=2 sigmaR=2 on YUV420 -> sigmaS [2,1,1], radius/step luma 3/2 chroma 2/1,
+    algorithm 2 everywhere, PBFICnum [4,5,5]."""
+    prm = oracle.bilateral_params([2], [2], yuv=True, ssw=1, ssh=1)
+    assert prm["sigmaS"] == [2.0, 1.0, 1.0]
+    assert prm["radius"] == [3, 2, 2] and prm["step"] == [2, 1, 1] and prm["samples"] == [2, 2, 2]
+    assert prm["algorithm"] == [2, 2, 2] and prm["PBFICnum"] == [4, 5, 5]
+
+
+def test_bilateral_golden_rgb24(oracle):
+    g = fx.ref_goldens()["exact"]["bilateral"]["RGB24|full|sigmaR=2,sigmaS=2"]
+    out, _ = _bilateral(oracle, fx.crop_rgb24(), 2, 2)
+    for p in range(3):
+        _check(fx.plane_stats(out[p]), g[f"p{p}"])
+
+
+def test_bilateral_golden_rgbs(oracle):
+    g = fx.ref_goldens()["exact"]["bilateral"]["RGBS|full|sigmaR=2,sigmaS=2"]
+    out, _ = _bilateral(oracle, fx.crop_rgbs(), 2, 2)
+    for p in range(3):
+        _check(fx.plane_stats(out[p]), g[f"p{p}"])
+
+
+def test_bilateral_golden_gray8(oracle):
+    g = fx.ref_goldens()["exact"]["bilateral"]["GRAY8|full|sigmaR=2,sigmaS=2"]
+    out, _ = _bilateral(oracle, [fx.crop_gray8()], 2, 2)
+    _check(fx.plane_stats(out[0]), g["p0"])
+
+
+@pytest.mark.parametrize("key,sS,sR,alg,num", [
+    ("GRAY16|full|PBFICnum=4,algorithm=1,sigmaR=0.1,sigmaS=3", 3, 0.1, 1, 4),
+    ("GRAY16|full|PBFICnum=32,algorithm=1,sigmaR=0.1,sigmaS=3", 3, 0.1, 1, 32),
+    ("GRAY16|full|algorithm=2,sigmaR=0.02,sigmaS=3", 3, 0.02, 2, 0),
+    ("GRAY16|full|sigmaR=2,sigmaS=5", 5, 2, 0, 0),
+    ("GRAY16|full|sigmaR=0.02,sigmaS=0.8", 0.8, 0.02, 0, 0),
+])
+def test_bilateral_soft_gray16(oracle, key, sS, sR, alg, num):
+    g = fx.ref_goldens()["soft"]["bilateral"][key]["p0"]
+    prm = oracle.bilateral_params([sS], [sR], algorithm=[alg], pbficnum=[num])
+    out = oracle.bilateral_plane(np.ascontiguousarray(fx.crop_gray16()), prm["sigmaS"][0], prm["sigmaR"][0], prm["algorithm"][0], prm["radius"][0],
+                                 prm["step"][0], prm["PBFICnum"][0])
+    st = fx.plane_stats(out)
+    assert st["avg"] == pytest.approx(g["avg"], rel=1e-7)
+    assert abs(st["min"] - g["min"]) <= 1 and abs(st["max"] - g["max"]) <= 1
+
+
+# ---- EEDI3 / EEDI3H -----------------------------------------------------------
+def test_eedi3_golden_rgbs(oracle):
+    g = fx.ref_goldens()["exact"]["eedi3"]["RGBS|full|field=1"]
+    for p in range(3):
+        _check(fx.plane_stats(oracle.eedi3(fx.crop_rgbs()[p], field=1)), g[f"p{p}"])
+
+
+def test_eedi3h_golden_rgbs(oracle):
+    g = fx.ref_goldens()["exact"]["eedi3h"]["RGBS|full|field=1"]
+    for p in range(3):
+        _check(fx.plane_stats(oracle.eedi3(fx.crop_rgbs()[p], field=1, horizontal=True)), g[f"p{p}"])
+
+
+def test_eedi3h_is_transposed_eedi3(oracle):
+    """EEDI3H == Transpose o EEDI3 o Transpose, bit-exact (reference tests/test_eedi3.py:111-118)."""
+    src = fx.crop_rgbs()[0][:96, :128]
+    a = oracle.eedi3(src, field=1, horizontal=True)
+    b = oracle.eedi3(np.ascontiguousarray(src.T), field=1).T
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("key,kw", [
+    ("GRAYS|full|dh=1,field=1", dict(field=1, dh=True)),
+    ("GRAYS|full|field=0", dict(field=0)),
+    ("GRAYS|full|field=1,mdis=40,nrad=3", dict(field=1, mdis=40, nrad=3)),
+    ("GRAYS|full|field=1,gamma=0", dict(field=1, gamma=0.0)),
+    ("GRAYS|full|field=1,hp=1", dict(field=1, hp=True)),
+])
+def test_eedi3_soft_grays(oracle, key, kw):
+    """Approximate GRAYS fixture: EEDI3's discrete path can flip on ulp-level input
+    differences, so this is a magnitude check (1e-5), not a gate."""
+    g = fx.ref_goldens()["soft"]["eedi3"][key]["p0"]
+    st = fx.plane_stats(oracle.eedi3(fx.crop_grays(), **kw))
+    assert st["avg"] == pytest.approx(g["avg"], rel=1e-5)
+
+
+# ---- PlaneAverage / PlaneMinMax ----------------------------------------------------
+def test_planeaverage_goldens(oracle):
+    g = fx.ref_goldens()["exact"]["planeaverage"]
+    rgb, rgbs, g8 = fx.crop_rgb24(), fx.crop_rgbs(), fx.crop_gray8()
+    avg = lambda p, ex: oracle.plane_average(np.ascontiguousarray(p), ex)[0]
+    assert avg(rgb[0], [-1]) == pytest.approx(g["RGB24|full|exclude=[-1]"]["avg"], rel=1e-12)
+    assert [avg(rgb[i], [-1]) for i in range(3)] == pytest.approx(g["RGB24|full|exclude=[-1],planes=[0,1,2]"]["avg"], rel=1e-12)
+    assert [avg(rgbs[i], [-1]) for i in range(3)] == pytest.approx(g["RGBS|full|exclude=[-1],planes=[0,1,2]"]["avg"], rel=1e-12)
+    assert avg(g8, [-1]) == pytest.approx(g["GRAY8|full|exclude=[-1]"]["avg"], rel=1e-12)
+    assert avg(g8, [128]) == pytest.approx(g["GRAY8|full|exclude=[128]"]["avg"], rel=1e-12)
+    assert avg(g8, [100, 150, 200]) == pytest.approx(g["GRAY8|full|exclude=[100,150,200]"]["avg"], rel=1e-12)
+    assert avg(g8[:-1, :-1], [-1]) == pytest.approx(g["GRAY8|odd|exclude=[-1]"]["avg"], rel=1e-12)
+    assert avg(g8[100:107, 200:213], [-1]) == pytest.approx(g["GRAY8|tiny|exclude=[-1]"]["avg"], rel=1e-12)
+
+
+def test_planeaverage_known_answers(oracle):
+    """reference tests/test_planeaverage.py:118-147 (two-tone exclude, 6777/65535)."""
+    two = np.concatenate([np.full((32, 64), 1000, np.uint16), np.full((32, 64), 3000, np.uint16)], axis=1)
+    assert oracle.plane_average(two, [1000])[0] == 3000 / 65535
+    assert oracle.plane_average(two, [3000])[0] == 1000 / 65535
+    assert oracle.plane_average(two, [1000, 3000])[0] == 0.0
+    assert oracle.plane_average(np.full((32, 64), 6777, np.uint16), [-1])[0] == 0.10341039139391164
+    f = np.concatenate([np.full((32, 64), 1.0, np.float32), np.full((32, 64), 3.0, np.float32)], axis=1)
+    assert oracle.plane_average(f, [3])[0] == 1.0
+
+
+def test_planeminmax_goldens(oracle):
+    g = fx.ref_goldens()["exact"]["planeminmax"]
+    rgb, rgbs, g8 = fx.crop_rgb24(), fx.crop_rgbs(), fx.crop_gray8()
+    mm = lambda p, lo, hi, ref=None: oracle.plane_minmax(np.ascontiguousarray(p), lo, hi, ref)
+    e = g["RGB24|full|maxthr=0.1,minthr=0.1"]
+    assert mm(rgb[0], 0.1, 0.1)[:2] == (e["Min"], e["Max"])
+    e = g["GRAY8|full|maxthr=0.1,minthr=0.1"]
+    assert mm(g8, 0.1, 0.1)[:2] == (e["Min"], e["Max"])
+    e = g["RGBS|full|maxthr=0.3,minthr=0.2,planes=[0,1,2]"]
+    for i in range(3):
+        lo, hi, _ = mm(rgbs[i], 0.2, 0.3)
+        assert lo == pytest.approx(e["Min"][i], rel=1e-7) and hi == pytest.approx(e["Max"][i], rel=1e-7)
+    # clipb = vszip.BoxBlur(1,1) (reference tests/test_planeminmax.py:73-75): pins the CT integer BoxBlur too
+    e = g["RGB24|full|maxthr=0.1,minthr=0.1,planes=[0,1,2]|ref"]
+    for i in range(3):
+        p = np.ascontiguousarray(rgb[i])
+        lo, hi, df = mm(p, 0.1, 0.1, oracle.boxblur(p, 1, 1, 1, 1))
+        assert (lo, hi) == (e["Min"][i], e["Max"][i])
+        assert df == pytest.approx(e["Diff"][i], rel=1e-12)
+
+
+def test_planeminmax_known_answers(oracle):
+    """reference tests/test_planeminmax.py:99-110,228-236: 25% zeros + thresholds; minthr=1 -> peak, maxthr=1 -> 0."""
+    p = np.full((32, 64), 200, np.uint8)
+    p[:8, :] = 0
+    assert oracle.plane_minmax(p, 0.2, 0.0)[:2] == (0, 200)
+    assert oracle.plane_minmax(p, 0.3, 0.0)[:2] == (200, 200)
+    q = np.full((32, 64), 1234, np.uint16)
+    assert oracle.plane_minmax(q, 1.0, 0.0)[0] == 65535
+    assert oracle.plane_minmax(q, 0.0, 1.0)[1] == 0
+
+
+# ---- SSIMULACRA2 -----------------------------------------------------------------------
+def _srgb_to_linear(v):
+    v = v.astype(np.float64)
+    return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
+
+
+def test_ssimulacra2_identical_is_100(oracle):
+    """reference tests/test_ssimulacra2.py:65-71"""
+    c = [np.full((64, 64), v, np.float32) for v in (0.3, 0.2, 0.5)]
+    assert oracle.ssimulacra2(c, c) == 100.0
+    lin = [_srgb_to_linear(p) for p in fx.crop_rgbs()]
+    assert oracle.ssimulacra2(lin, lin) > 99.9
+
+
+def test_ssimulacra2_golden_blur1_soft(oracle):
+    """RGBS|full|dist=blur1 = 3.974185 in the reference (rel 1e-3 there). The distorted clip
+    is std.BoxBlur(1,1) and both are linearised by zimg; restated with the textbook sRGB EOTF
+    and vszip's own r=1 box, so this pins skip table / weights / cbrt / mirror / score to ~2e-3."""
+    g = fx.ref_goldens()["exact"]["ssimulacra2"]["RGBS|full|dist=blur1"]
+    ref = [np.ascontiguousarray(p) for p in fx.crop_rgbs()]
+    dis = [oracle.boxblur(p, 1, 1, 1, 1) for p in ref]
+    s = oracle.ssimulacra2([_srgb_to_linear(p) for p in ref], [_srgb_to_linear(p) for p in dis])
+    assert s == pytest.approx(g, rel=3e-3)
+
+
+# ---- XPSNR -------------------------------------------------------------------------------
+def test_xpsnr_identical_is_inf(oracle):
+    """reference tests/test_xpsnr.py:222-225"""
+    y = fx.splitmix64_plane(3, (64, 96), np.uint8)
+    u = fx.splitmix64_plane(4, (32, 48), np.uint8)
+    w = oracle.xpsnr_wsse([y, u, u], [y, u, u], depth=8)
+    assert w == [0, 0, 0]
+    assert math.isinf(oracle.xpsnr_frame(0, 96, 64, 8))
+
+
+def test_xpsnr_magnitude(oracle):
+    """No reachable golden (all need zimg YUV): sanity — a +-2 LSB perturbation of an 8-bit
+    frame lands in the 40-60 dB band every XPSNR golden of that kind sits in."""
+    rng = np.random.default_rng(1)
+    y = fx.tiled_natural((288, 352), np.uint8)
+    d = np.clip(y.astype(np.int16) + rng.integers(-2, 3, y.shape), 0, 255).astype(np.uint8)
+    w = oracle.xpsnr_wsse([y], [d], depth=8, temporal=False)
+    x = oracle.xpsnr_frame(w[0], 352, 288, 8)
+    assert 35.0 < x < 60.0
