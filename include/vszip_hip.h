@@ -90,6 +90,70 @@ typedef struct vszip_plane {
 int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
                   int hradius, int hpasses, int vradius, int vpasses);
 
+/*
+ * PlaneAverage — replaces filter.average / filter.averageRef
+ * (src/filters/planeaverage.zig:26,47) called from src/vapoursynth/planeaverage.zig:55-61.
+ * planes[i].ref != NULL on plane 0 selects the clipb variant for all planes.
+ * `exclude` is the i32 list of the wrapper (:122-137; compared as @floatFromInt for
+ * float clips), at most 8 values. bits_per_sample gives peak = 2^bits - 1 (:115).
+ * Results are written to host arrays avg[nplanes] and (clipb) diff[nplanes]; the call
+ * synchronises the stream. Integer planes are exact; float planes differ from the
+ * reference's sequential f64 sum by rounding only.
+ */
+int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
+                        const int32_t *exclude, int nexclude, int bits_per_sample,
+                        double *avg, double *diff);
+
+/*
+ * PlaneMinMax — replaces filter.minMax / minMaxRef / minMaxNoThr / minMaxNoThrRef
+ * (src/filters/planeminmax.zig:72-133) called from src/vapoursynth/planeminmax.zig:60-77.
+ * minthr == maxthr == 0 is the exact path; otherwise the histogram-percentile rule of
+ * minMaxImpl (:43-57). vmin/vmax hold integers for integer clips and idx/65535 (as f32)
+ * for float clips, exactly the values the wrapper stores in psmMin/psmMax (:59-68).
+ */
+int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
+                       float minthr, float maxthr, int bits_per_sample,
+                       double *vmin, double *vmax, double *diff);
+
+/*
+ * Bilateral — replaces filter.bilateral (src/filters/bilateral.zig:81) and the create-time
+ * work of bilateralCreate (src/vapoursynth/bilateral.zig:104-231).
+ *
+ * One vszip_bilateral_cfg per PLANE INDEX of the clip (Y,U,V / R,G,B):
+ *   vszip_bilateral_derive  fills sigmaS/sigmaR/process/algorithm/pbficnum/radius/step/samples
+ *                           from the user arrays (already expanded to 3 entries with hz.getArray's
+ *                           repeat-last rule; sigmaS is passed raw with its element count because
+ *                           its chroma default depends on the subsampling, :104-124). Host only.
+ *                           Returns VSZIP_ERR_ARG for the cases bilateralCreate rejects.
+ *   vszip_bilateral_luts    builds gs_lut ((radius+1)^2) and gr_lut (hist_len) exactly as
+ *                           bilateral.zig:306-339 and uploads them (device memory owned by the
+ *                           caller: vszip_dev_free). hist_len = 1 << bits, 65536 for float clips.
+ *   vszip_bilateral         filters `nplanes` planes; cfgs[i] is the config of planes[i]'s plane
+ *                           index. planes[i].ref == NULL means ref == src (no joint clip).
+ *                           peak = hist_len - 1 as float (:101-102).
+ * Planes with process == 0 (sigmaS == 0 or sigmaR == 0) are pass-through in the reference
+ * (newVideoFrame2 copies them); copy them with vszip_copy_d2d_2d.
+ */
+typedef struct vszip_bilateral_cfg {
+    double sigmaS;
+    double sigmaR;
+    int32_t process;
+    int32_t algorithm; /* 1 = PBFIC, 2 = truncated window */
+    int32_t pbficnum;
+    int32_t radius;
+    int32_t step;
+    int32_t samples;
+    float *gs_lut; /* device */
+    float *gr_lut; /* device */
+} vszip_bilateral_cfg;
+
+int vszip_bilateral_derive(const double *sigmaS, int n_sigmaS, const double *sigmaR3, const int *algorithm3,
+                           const int *pbficnum3, int is_yuv, int subsampling_w, int subsampling_h,
+                           const int *planes3, vszip_bilateral_cfg *out3);
+int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, int hist_len);
+int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *planes,
+                    const vszip_bilateral_cfg *const *cfgs, int nplanes, float peak);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""GPU parity: vszip_plane_average / vszip_plane_minmax vs the CPU oracle.
+Integer results bit-exact; float sums within 1e-12 relative (reduction order)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    yield d
+    d.close()
+
+
+SHAPES = [(320, 640), (319, 639), (7, 13), (1080, 1920)]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float16])
+def test_average_matches_oracle(dev, oracle, dtype):
+    for shape in SHAPES:
+        a = fx.splitmix64_plane(21, shape, dtype)
+        b = fx.splitmix64_plane(22, shape, dtype)
+        if np.dtype(dtype).kind == "u":
+            a[::3, ::5] = 100
+        else:
+            a[::3, ::5] = 1.0
+        for excl in ([-1], [100, 7], [1]):
+            da, db = dev.upload(a), dev.upload(b)
+            avg, diff = dev.plane_average([da], excl, [db])
+            oavg, odiff = oracle.plane_average(a, excl, b)
+            if np.dtype(dtype).kind == "u":
+                assert avg[0] == oavg and diff[0] == odiff
+            else:
+                assert avg[0] == pytest.approx(oavg, rel=1e-12) and diff[0] == pytest.approx(odiff, rel=1e-12)
+            avg2, none = dev.plane_average([da], excl)
+            assert none is None and (avg2[0] == avg[0])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float16])
+@pytest.mark.parametrize("thr", [(0.0, 0.0), (0.1, 0.1), (0.4, 0.0), (0.0, 0.3), (1.0, 1.0)])
+def test_minmax_matches_oracle(dev, oracle, dtype, thr):
+    for shape in SHAPES[:3]:
+        a = fx.tiled_natural(shape, dtype) if shape[0] > 10 else fx.splitmix64_plane(5, shape, dtype)
+        b = fx.splitmix64_plane(23, shape, dtype)
+        da, db = dev.upload(a), dev.upload(b)
+        mn, mx, df = dev.plane_minmax([da], thr[0], thr[1], [db])
+        omn, omx, odf = oracle.plane_minmax(a, thr[0], thr[1], b)
+        assert (mn[0], mx[0]) == (omn, omx), (dtype, thr, shape)
+        if np.dtype(dtype).kind == "u":
+            assert df[0] == odf
+        else:
+            assert df[0] == pytest.approx(odf, rel=1e-12)
+
+
+def test_ten_bit_and_batch(dev, oracle):
+    planes = [fx.splitmix64_plane(30 + i, s, np.uint16) >> 6 for i, s in enumerate([(216, 384), (108, 192), (108, 192)])]
+    ds = [dev.upload(p) for p in planes]
+    mn, mx, _ = dev.plane_minmax(ds, 0.05, 0.05, bits=10)
+    avg, _ = dev.plane_average(ds, [-1], bits=10)
+    for i, p in enumerate(planes):
+        o = oracle.plane_minmax(p, 0.05, 0.05, bits=10)
+        assert (mn[i], mx[i]) == o[:2]
+        assert avg[i] == oracle.plane_average(p, [-1], bits=10)[0]
+
+
+def test_known_answers(dev):
+    """reference tests/test_planeaverage.py:118-147, tests/test_planeminmax.py:99-110,228-236"""
+    two = np.concatenate([np.full((32, 64), 1000, np.uint16), np.full((32, 64), 3000, np.uint16)], axis=1)
+    d = dev.upload(two)
+    assert dev.plane_average([d], [1000])[0][0] == 3000 / 65535
+    assert dev.plane_average([d], [1000, 3000])[0][0] == 0.0
+    q = dev.upload(np.full((32, 64), 1234, np.uint16))
+    assert dev.plane_minmax([q], 1.0, 0.0)[0][0] == 65535
+    assert dev.plane_minmax([q], 0.0, 1.0)[1][0] == 0
+    p = np.full((32, 64), 200, np.uint8)
+    p[:8, :] = 0
+    dp = dev.upload(p)
+    assert (dev.plane_minmax([dp], 0.2, 0.0)[0][0], dev.plane_minmax([dp], 0.3, 0.0)[0][0]) == (0, 200)

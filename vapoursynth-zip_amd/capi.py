@@ -34,6 +34,14 @@ class Plane(C.Structure):
     ]
 
 
+class BilateralCfg(C.Structure):
+    _fields_ = [
+        ("sigmaS", C.c_double), ("sigmaR", C.c_double), ("process", C.c_int32), ("algorithm", C.c_int32),
+        ("pbficnum", C.c_int32), ("radius", C.c_int32), ("step", C.c_int32), ("samples", C.c_int32),
+        ("gs_lut", C.c_void_p), ("gr_lut", C.c_void_p),
+    ]
+
+
 # every symbol include/vszip_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _sz, _pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
 _PP = C.POINTER(Plane)
@@ -56,6 +64,12 @@ SYMBOLS = {
     "vszip_timer_start": (_i, [_vp]),
     "vszip_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "vszip_boxblur": (_i, [_vp, _i, _PP, _i, _i, _i, _i, _i]),
+    "vszip_bilateral_derive": (_i, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _i, _i,
+                                    C.POINTER(C.c_int), C.POINTER(BilateralCfg)]),
+    "vszip_bilateral_luts": (_i, [_vp, C.POINTER(BilateralCfg), _i]),
+    "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
+    "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -175,3 +189,61 @@ class Device:
 
     def boxblur(self, srcs, dsts, hradius=1, hpasses=1, vradius=1, vpasses=1):
         self.boxblur_table(srcs[0].dtype, self.plane_table(srcs, dsts), hradius, hpasses, vradius, vpasses)
+
+    def plane_average(self, srcs, exclude=(), refs=None, bits=None):
+        """-> (avg[], diff[] or None) for a list of planes of one sample type."""
+        n = len(srcs)
+        table = self.plane_table(srcs, None, refs)
+        ex = (C.c_int32 * max(1, len(exclude)))(*exclude)
+        avg, diff = (C.c_double * n)(), (C.c_double * n)()
+        b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
+        self.check(self.lib.vszip_plane_average(self.ctx, _NP2DT[srcs[0].dtype], table, n, ex, len(exclude), b, avg, diff))
+        return list(avg), (list(diff) if refs is not None else None)
+
+    def plane_minmax(self, srcs, minthr=0.0, maxthr=0.0, refs=None, bits=None):
+        n = len(srcs)
+        table = self.plane_table(srcs, None, refs)
+        mn, mx, df = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
+        self.check(self.lib.vszip_plane_minmax(self.ctx, _NP2DT[srcs[0].dtype], table, n, minthr, maxthr, b, mn, mx, df))
+        return list(mn), list(mx), (list(df) if refs is not None else None)
+
+    @staticmethod
+    def _arr3(vals, default):
+        out = []
+        for i in range(3):
+            out.append(vals[i] if i < len(vals) else (default if i == 0 else out[i - 1]))
+        return out
+
+    def bilateral_cfg(self, sigmaS=(), sigmaR=(), algorithm=(), pbficnum=(), planes=(True, True, True), yuv=False, ssw=0, ssh=0, hist_len=65536):
+        """bilateralCreate: derive the 3 per-plane configs and build their LUTs on the device."""
+        sS = (C.c_double * 3)(*(list(sigmaS) + [0.0] * 3)[:3])
+        sR = (C.c_double * 3)(*self._arr3(list(sigmaR), 0.02))
+        al = (C.c_int * 3)(*self._arr3(list(algorithm), 0))
+        pb = (C.c_int * 3)(*self._arr3(list(pbficnum), 0))
+        pl = (C.c_int * 3)(*[int(bool(x)) for x in planes])
+        cfg = (BilateralCfg * 3)()
+        rc = self.lib.vszip_bilateral_derive(sS, len(sigmaS), sR, al, pb, int(yuv), ssw, ssh, pl, cfg)
+        if rc != OK:
+            raise VszipError(rc, "Bilateral: invalid parameters")
+        for i in range(3):
+            self.check(self.lib.vszip_bilateral_luts(self.ctx, C.byref(cfg[i]), hist_len))
+        return cfg
+
+    def bilateral_free(self, cfg):
+        for i in range(3):
+            for f in ("gs_lut", "gr_lut"):
+                p = getattr(cfg[i], f)
+                if p:
+                    self.lib.vszip_dev_free(self.ctx, p)
+                    setattr(cfg[i], f, None)
+
+    def bilateral(self, srcs, dsts, cfg, plane_index, refs=None, peak=None):
+        """plane_index[i] = which of the 3 configs plane i uses."""
+        n = len(srcs)
+        table = self.plane_table(srcs, dsts, refs)
+        ptrs = (C.POINTER(BilateralCfg) * n)(*[C.pointer(cfg[k]) for k in plane_index])
+        dt = srcs[0].dtype
+        if peak is None:
+            peak = float((1 << (8 * dt.itemsize)) - 1) if dt.kind == "u" else 65535.0
+        self.check(self.lib.vszip_bilateral(self.ctx, _NP2DT[dt], table, ptrs, n, peak))
