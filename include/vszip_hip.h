@@ -154,6 +154,17 @@ int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, int hist_len)
 int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *planes,
                     const vszip_bilateral_cfg *const *cfgs, int nplanes, float peak);
 
+/*
+ * SSIMULACRA2 — replaces filter_ssim.process (src/filters/ssimulacra2.zig:46) called from
+ * ssimulacra2GetFrame (src/vapoursynth/ssimulacra2.zig:40-66). Inputs are linear-light
+ * RGBS planes (what hz.toRGBS + sRGBtoLinearRGB hand to the kernel, :115-118): ref3 / dis3
+ * are HOST arrays of 3 * npairs device pointers (R,G,B of pair 0, R,G,B of pair 1, ...),
+ * all planes w x h with the same stride (elements). scores[npairs] receives the value the
+ * wrapper stores in the "SSIMULACRA2" frame property. Synchronises the stream.
+ */
+int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3,
+                      ptrdiff_t stride, int w, int h, int npairs, double *scores);
+
 #ifdef __cplusplus
 }
 #endif

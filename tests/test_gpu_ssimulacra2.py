@@ -1,0 +1,66 @@
+"""GPU parity: vszip_ssimulacra2 vs the CPU oracle. The f32 maps are computed with the
+reference's operation order; only the f64 pooling order differs, so scores agree to
+~1e-9 absolute (asserted: 1e-7; north-star bound for float results: 1e-5)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    yield d
+    d.close()
+
+
+def _lin(v):
+    v = v.astype(np.float64)
+    return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
+
+
+def _pair(shape, seed, sigma=0.03):
+    rng = np.random.default_rng(seed)
+    ref = [_lin(fx.tiled_natural(shape, np.float32, p)) for p in range(3)]
+    dis = [np.clip(p + rng.normal(0, sigma, p.shape).astype(np.float32), 0, 1).astype(np.float32) for p in ref]
+    return ref, dis
+
+
+def _gpu(dev, ref, dis):
+    r = [dev.upload(np.ascontiguousarray(p), 1) for p in ref]
+    d = [dev.upload(np.ascontiguousarray(p), 1) for p in dis]
+    return dev.ssimulacra2(r, d)
+
+
+@pytest.mark.parametrize("shape", [(320, 640), (319, 639), (64, 64), (135, 241), (540, 960)])
+def test_matches_oracle(dev, oracle, shape):
+    ref, dis = _pair(shape, 7)
+    got = _gpu(dev, ref, dis)[0]
+    want = oracle.ssimulacra2(ref, dis)
+    assert got == pytest.approx(want, abs=TOL), (shape, got, want)
+
+
+def test_blur_distortion_and_batch(dev, oracle):
+    ref = [_lin(np.ascontiguousarray(p)) for p in fx.crop_rgbs()]
+    dis1 = [_lin(oracle.boxblur(np.ascontiguousarray(p), 1, 1, 1, 1)) for p in fx.crop_rgbs()]
+    dis3 = [_lin(oracle.boxblur(np.ascontiguousarray(p), 3, 1, 3, 1)) for p in fx.crop_rgbs()]
+    r = [dev.upload(p, 1) for p in ref] * 2
+    d = [dev.upload(p, 1) for p in dis1] + [dev.upload(p, 1) for p in dis3]
+    got = dev.ssimulacra2(r, d)
+    assert got[0] == pytest.approx(oracle.ssimulacra2(ref, dis1), abs=TOL)
+    assert got[1] == pytest.approx(oracle.ssimulacra2(ref, dis3), abs=TOL)
+    # the reference's golden for this case (RGBS|full|dist=blur1, rel 1e-3 there; soft here, see oracle test)
+    assert got[0] == pytest.approx(fx.ref_goldens()["exact"]["ssimulacra2"]["RGBS|full|dist=blur1"], rel=3e-3)
+
+
+def test_identical_is_exactly_100(dev):
+    """reference tests/test_ssimulacra2.py:65-71"""
+    c = [np.full((64, 64), v, np.float32) for v in (0.3, 0.2, 0.5)]
+    assert _gpu(dev, c, c)[0] == 100.0
+    lin = [_lin(np.ascontiguousarray(p)) for p in fx.crop_rgbs()]
+    assert _gpu(dev, lin, lin)[0] > 99.9

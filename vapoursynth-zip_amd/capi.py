@@ -68,6 +68,7 @@ SYMBOLS = {
                                     C.POINTER(C.c_int), C.POINTER(BilateralCfg)]),
     "vszip_bilateral_luts": (_i, [_vp, C.POINTER(BilateralCfg), _i]),
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
+    "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -247,3 +248,13 @@ class Device:
         if peak is None:
             peak = float((1 << (8 * dt.itemsize)) - 1) if dt.kind == "u" else 65535.0
         self.check(self.lib.vszip_bilateral(self.ctx, _NP2DT[dt], table, ptrs, n, peak))
+
+    def ssimulacra2(self, ref_planes, dis_planes):
+        """ref_planes / dis_planes: flat lists of 3*npairs f32 DevPlanes (same geometry). -> scores[npairs]"""
+        n = len(ref_planes) // 3
+        r = (C.c_void_p * (3 * n))(*[p.ptr for p in ref_planes])
+        d = (C.c_void_p * (3 * n))(*[p.ptr for p in dis_planes])
+        out = (C.c_double * n)()
+        p0 = ref_planes[0]
+        self.check(self.lib.vszip_ssimulacra2(self.ctx, r, d, p0.stride, p0.w, p0.h, n, out))
+        return list(out)

@@ -1,0 +1,477 @@
+// vszip.SSIMULACRA2 on gfx950: the per-frame kernel of src/filters/ssimulacra2.zig
+// (`process`, :46-136) — two linear-light RGBS frames in, one f64 score out.
+//
+// Per scale s = 0..4 (scale 5 carries only pruned weights, :22-37, and is never built):
+//   ssim_xyb_down_kernel  reads the linear RGB of both frames at scale s once and writes
+//                         (a) the XYB planes scale s actually needs (toXYB :392-472 with the
+//                         VCL cbrt of src/vcl.zig:40-81) and (b) the 2x2-box-filtered linear
+//                         RGB of scale s+1 (downscale :138-209) — one read feeds both.
+//   ssim_maps_kernel      one 32x32 tile per block and one launch per scale for all active
+//                         planes: stages the XYB tile (+4 halo) of both frames in LDS, forms
+//                         im1*im2, (im1+im2)^2, im1, im2 on the fly, runs the separable 9-tap
+//                         FIR (blur :247-372: vertical then horizontal, asymmetric mirror),
+//                         evaluates ssimMap / edgeMap (:480-628) per pixel in f64 and reduces
+//                         d, d^4, artifact, artifact^4, detail, detail^4 to one partial per
+//                         block. No blurred map ever touches HBM.
+//   ssim_final_kernel     folds the partials in a fixed order (reproducible) into the
+//                         6x6 / 6x12 average tables; the host applies `score` (:630-663).
+// f32 arithmetic keeps the reference's operation order; the vertical FIR is fused
+// (fmaf) for columns below w - w % 8 and unfused beyond, as the reference's AVX2 build
+// does (:318 vs :326). Only the f64 pooling order differs (~1e-15 relative).
+#include <cmath>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kScales = 5;  // scales that carry a non-pruned weight
+constexpr int TW = 32, TH = 32, HALO = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
+constexpr int kVecW = 8;    // reference SIMD width baked into the FMA rule
+
+__constant__ float c_kernel[9] = {
+    0.0076144188642501831054687500f, 0.0360749699175357818603515625f, 0.1095860823988914489746093750f,
+    0.2134445458650588989257812500f, 0.2665599882602691650390625000f, 0.2134445458650588989257812500f,
+    0.1095860823988914489746093750f, 0.0360749699175357818603515625f, 0.0076144188642501831054687500f,
+};
+
+// src/vcl.zig:40-81
+__device__ __forceinline__ float vcl_cbrt(float x) {
+    const float one_third = 1.0f / 3.0f, four_third = 4.0f / 3.0f;
+    const float xa = fabsf(x);
+    const float xa3 = one_third * xa;
+    const uint32_t m1 = __float_as_uint(xa);
+    float a = __uint_as_float(0x54800000u - ((m1 >> 23) * 0x002AAAAAu));
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const float a2 = a * a;
+        a = (four_third * a) - (xa3 * (a2 * a2));
+    }
+    const float a2 = a * a;
+    a = a + (one_third * (a - (xa * (a2 * a2))));
+    a = (a * a) * x;
+    return m1 <= 0x00800000u ? 0.0f : a;
+}
+
+struct XybK {
+    float m[9], bias, kd1;
+};
+
+struct XybArgs {
+    const float *rgb1[3], *rgb2[3];  // scale s linear RGB
+    float *xyb1[3], *xyb2[3];        // scale s XYB (NULL = plane not needed)
+    float *next1[3], *next2[3];      // scale s+1 linear RGB (NULL at the last scale)
+    int stride, w, h;                // scale s geometry (elements)
+    int nstride, nw, nh;             // scale s+1 geometry
+    int xstride;
+    XybK k;
+};
+
+__device__ __forceinline__ void to_xyb_px(const XybK &k, float r, float g, float b, bool need_b, float &X, float &Y, float &B) {
+    const float ox = fmaf(k.m[0], r, fmaf(k.m[1], g, fmaf(k.m[2], b, k.bias)));
+    const float oy = fmaf(k.m[3], r, fmaf(k.m[4], g, fmaf(k.m[5], b, k.bias)));
+    const float cx = vcl_cbrt(fmaxf(ox, 0.0f)) - k.kd1;
+    const float cy = vcl_cbrt(fmaxf(oy, 0.0f)) - k.kd1;
+    const float xv = 0.5f * (cx - cy);
+    const float yv = 0.5f * (cx + cy);
+    X = xv * 14.0f + 0.42f;
+    Y = yv + 0.01f;
+    if (need_b) {
+        const float oz = fmaf(k.m[6], r, fmaf(k.m[7], g, fmaf(k.m[8], b, k.bias)));
+        const float cz = vcl_cbrt(fmaxf(oz, 0.0f)) - k.kd1;
+        B = (cz - yv) + 0.55f;
+    }
+}
+
+// One thread per scale-(s+1) pixel = one 2x2 block of scale-s pixels.
+__global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
+    const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (ox >= a.nw || oy >= a.nh) return;
+    const bool need_b = a.xyb1[2] != nullptr;
+#pragma unroll
+    for (int img = 0; img < 2; ++img) {
+        const float *const *rgb = img ? a.rgb2 : a.rgb1;
+        float *const *xyb = img ? a.xyb2 : a.xyb1;
+        float *const *nxt = img ? a.next2 : a.next1;
+        float v[3][4];
+        // downscale :186-200: samples clamp to the last row/column, summed ((a+b)+c)+d
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const int x = min(ox * 2 + ix, a.w - 1), y = min(oy * 2 + iy, a.h - 1);
+                const size_t o = (size_t)y * a.stride + x;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c][iy * 2 + ix] = rgb[c][o];
+            }
+        if (nxt[0]) {
+            const size_t o = (size_t)oy * a.nstride + ox;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nxt[c][o] = (((v[c][0] + v[c][1]) + v[c][2]) + v[c][3]) * 0.25f;
+        }
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const int x = ox * 2 + ix, y = oy * 2 + iy;
+                if (x >= a.w || y >= a.h) continue;
+                float X, Y, B = 0.0f;
+                to_xyb_px(a.k, v[0][iy * 2 + ix], v[1][iy * 2 + ix], v[2][iy * 2 + ix], need_b, X, Y, B);
+                const size_t o = (size_t)y * a.xstride + x;
+                if (xyb[0]) xyb[0][o] = X;
+                if (xyb[1]) xyb[1][o] = Y;
+                if (need_b) xyb[2][o] = B;
+            }
+    }
+}
+
+struct MapsArgs {
+    const float *im1[3], *im2[3];  // XYB planes of the active plane slots
+    int flags[3];                  // bit0: ssim map, bit1: edge map
+    int slot[3];                   // partial-table slot (scale * 3 + plane)
+    int nactive;
+    int stride, w, h;
+    int tiles_x, tiles_y;
+    double *partial;  // [slot][tile][6]
+    int max_tiles;
+};
+
+// the asymmetric mirror of blur (:254,260,357,364): reflect-101 at the start,
+// mirror about the CURRENT index at the end
+__device__ __forceinline__ int tap_index(int k, int i, int n) {
+    const int dist_from_end = n - 1 - i;
+    if (k < HALO) return (i < HALO - k) ? min(HALO - k - i, n - 1) : (i - HALO + k);
+    return (dist_from_end < k - HALO) ? (i - min(k - HALO - dist_from_end, i)) : (i - HALO + k);
+}
+
+__global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
+    __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];  // XYB tile of both frames
+    __shared__ float vt[4][TH][IW + 1];               // vertical pass of the 4 maps
+    __shared__ double red[4][6];
+
+    const int ps = blockIdx.z;
+    const float *im1 = a.im1[ps], *im2 = a.im2[ps];
+    const int w = a.w, h = a.h;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int cx0 = max(x0 - HALO, 0), cy0 = max(y0 - HALO, 0);  // real coords of LDS (0,0)
+    const int cw = min(x0 + TW + HALO, w) - cx0, ch = min(y0 + TH + HALO, h) - cy0;
+    const bool do_ssim = a.flags[ps] & 1, do_edge = a.flags[ps] & 2;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < ch * cw; i += 256) {
+        const int r = i / cw, c = i - r * cw;
+        const size_t o = (size_t)(cy0 + r) * a.stride + (cx0 + c);
+        s1[r][c] = im1[o];
+        s2[r][c] = im2[o];
+    }
+    __syncthreads();
+
+    // vertical pass: rows of the tile, every staged column (blurV :308-330)
+    const int th = min(TH, h - y0);
+    const int wv = w - (w % kVecW);
+    for (int i = tid; i < th * cw; i += 256) {
+        const int r = i / cw, c = i - r * cw;
+        const int y = y0 + r;
+        const bool fused = (cx0 + c) < wv;
+        float m12 = 0.0f, msq = 0.0f, m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int rr = tap_index(k, y, h) - cy0;
+            const float p = s1[rr][c], q = s2[rr][c];
+            const float kk = c_kernel[k];
+            const float sum = p + q;
+            if (fused) {
+                m1 = fmaf(kk, p, m1);
+                m2 = fmaf(kk, q, m2);
+                if (do_ssim) {
+                    m12 = fmaf(kk, p * q, m12);
+                    msq = fmaf(kk, sum * sum, msq);
+                }
+            } else {
+                m1 += kk * p;
+                m2 += kk * q;
+                if (do_ssim) {
+                    m12 += kk * (p * q);
+                    msq += kk * (sum * sum);
+                }
+            }
+        }
+        vt[0][r][c] = m12;
+        vt[1][r][c] = msq;
+        vt[2][r][c] = m1;
+        vt[3][r][c] = m2;
+    }
+    __syncthreads();
+
+    // horizontal pass (blurH :247-306, unfused acc + k*s) and the per-pixel maps
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int tw = min(TW, w - x0);
+    for (int i = tid; i < th * tw; i += 256) {
+        const int r = i / tw, c = i - r * tw;
+        const int x = x0 + c;
+        float b12 = 0.0f, bsq = 0.0f, mu1 = 0.0f, mu2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int cc = tap_index(k, x, w) - cx0;
+            const float kk = c_kernel[k];
+            mu1 += kk * vt[2][r][cc];
+            mu2 += kk * vt[3][r][cc];
+            if (do_ssim) {
+                b12 += kk * vt[0][r][cc];
+                bsq += kk * vt[1][r][cc];
+            }
+        }
+        if (do_ssim) {  // ssimMap :511-523
+            const float m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2, md = mu1 - mu2;
+            const double num_m = (double)fmaf(md, -md, 1.0f);
+            const double num_s = (double)fmaf(b12 - m12, 2.0f, 0.0009f);
+            const double denom_s = (double)(bsq - 2.0f * b12 - m11 - m22 + 0.0009f);
+            const double d1 = fmax(1.0 - ((num_m * num_s) / denom_s), 0.0);
+            double t = d1 * d1;
+            acc[0] += d1;
+            acc[1] += t * t;
+        }
+        if (do_edge) {  // edgeMap :585-603
+            const float v1 = s1[y0 + r - cy0][x - cx0], v2 = s2[y0 + r - cy0][x - cx0];
+            const double n2 = (double)fabsf(v2 - mu2), n1 = (double)fabsf(v1 - mu1);
+            const double d1 = (1.0 + n2) / (1.0 + n1) - 1.0;
+            const double art = fmax(d1, 0.0), det = fmax(-d1, 0.0);
+            double t = art * art;
+            acc[2] += art;
+            acc[3] += t * t;
+            t = det * det;
+            acc[4] += det;
+            acc[5] += t * t;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc[q] = wave_reduce_sum(acc[q]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
+    }
+    __syncthreads();
+    if (tid < 6) {
+        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        const int tile = blockIdx.y * a.tiles_x + blockIdx.x;
+        a.partial[((size_t)a.slot[ps] * a.max_tiles + tile) * 6 + tid] = v;
+    }
+}
+
+struct FinalArgs {
+    const double *partial;
+    double *avg;  // [18 slots][6]: ssim avg, ssim 4th-root, art avg, art 4th-root, det avg, det 4th-root
+    int ntiles[18];
+    double one_per_pixels[18];
+    int max_tiles;
+};
+
+__global__ __launch_bounds__(64) void ssim_final_kernel(const FinalArgs a) {
+    const int slot = blockIdx.x;
+    const int n = a.ntiles[slot];
+    const int lane = threadIdx.x;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = lane; t < n; t += 64) {
+        const double *p = a.partial + ((size_t)slot * a.max_tiles + t) * 6;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s[q] += p[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s[q] = wave_reduce_sum(s[q]);
+    if (lane == 0) {
+        const double opp = a.one_per_pixels[slot];
+        double *o = a.avg + slot * 6;
+        o[0] = opp * s[0];
+        o[1] = sqrt(sqrt(opp * s[1]));
+        o[2] = opp * s[2];
+        o[3] = sqrt(sqrt(opp * s[3]));
+        o[4] = opp * s[4];
+        o[5] = sqrt(sqrt(opp * s[5]));
+    }
+}
+
+const double kWeight[108] = {
+    0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0,
+    1.1041726426657346, 0.00066284834129271, 0.00015231632783718752, 0.0, 0.0016406437456599754, 0.0,
+    1.8422455520539298, 11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0,
+    1.8787594979546387, 10.94906990605142, 0.0, 0.0007289346991508072, 0.9677937080626833, 0.0,
+    0.00014003424285435884, 0.9981766977854967, 0.00031949755934435053, 0.0004550992113792063, 0.0, 0.0,
+    0.0013648766163243398, 0.0, 0.0, 0.0, 0.0, 0.0, 7.466890328078848, 0.0, 17.445833984131262,
+    0.0006235601634041466, 0.0, 0.0, 6.683678146179332, 0.00037724407979611296, 1.027889937768264,
+    225.20515300849274, 0.0, 0.0, 19.213238186143016, 0.0011401524586618361, 0.001237755635509985,
+    176.39317598450694, 0.0, 0.0, 24.43300999870476, 0.28520802612117757, 0.0004485436923833408, 0.0, 0.0,
+    0.0, 34.77906344483772, 44.835625328877896, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0008680556573291698,
+    0.0, 0.0, 0.0, 0.0, 0.0, 0.0005313191874358747, 0.0, 0.00016533814161379112, 0.0, 0.0, 0.0, 0.0, 0.0,
+    0.0004179171803251336, 0.0017290828234722833, 0.0, 0.0020827005846636437, 0.0, 0.0, 8.826982764996862,
+    23.19243343998926, 0.0, 95.1080498811086, 0.9863978034400682, 0.9834382792465353, 0.0012286405048278493,
+    171.2667255897307, 0.9807858872435379, 0.0, 0.0, 0.0, 0.0005130064588990679, 0.0, 0.00010854057858411537,
+};
+
+struct Skip {
+    bool ssim, artifact, detail;
+    bool all() const { return ssim && artifact && detail; }
+};
+Skip skip_of(int plane, int scale) {  // ssimulacra2.zig:22-37
+    const int base = plane * 36 + scale * 6;
+    const double p = 0.01;
+    return {kWeight[base + 0] <= p && kWeight[base + 3] <= p, kWeight[base + 1] <= p && kWeight[base + 4] <= p, kWeight[base + 2] <= p && kWeight[base + 5] <= p};
+}
+
+// musl cbrtf == Zig's std.math.cbrt(f32): K_D1 = cbrt(K_D0) at the reference's comptime
+float cbrtf_musl(float x) {
+    uint32_t ui;
+    std::memcpy(&ui, &x, 4);
+    uint32_t hx = (ui & 0x7fffffffu) / 3 + 709958130u;
+    ui = (ui & 0x80000000u) | hx;
+    float tf;
+    std::memcpy(&tf, &ui, 4);
+    double T = tf, r = T * T * T;
+    T = T * ((double)x + x + r) / (x + r + r);
+    r = T * T * T;
+    T = T * ((double)x + x + r) / (x + r + r);
+    return (float)T;
+}
+
+XybK make_xyb_consts() {  // ssimulacra2.zig:374-390
+    XybK k;
+    const float K_D0 = 0.0037930734f, K_M02 = 0.078f, K_M00 = 0.30f, K_M12 = 0.078f, K_M10 = 0.23f, K_M20 = 0.24342269f, K_M21 = 0.20476745f;
+    k.m[0] = K_M00;
+    k.m[1] = 1.0f - K_M02 - K_M00;
+    k.m[2] = K_M02;
+    k.m[3] = K_M10;
+    k.m[4] = 1.0f - K_M12 - K_M10;
+    k.m[5] = K_M12;
+    k.m[6] = K_M20;
+    k.m[7] = K_M21;
+    k.m[8] = 1.0f - K_M20 - K_M21;
+    k.bias = K_D0;
+    k.kd1 = cbrtf_musl(K_D0);
+    return k;
+}
+
+double score_of(const double avg[18][6]) {  // ssimulacra2.zig:630-663; slot = scale * 3 + plane
+    double s = 0.0;
+    int i = 0;
+    for (int plane = 0; plane < 3; ++plane)
+        for (int sc = 0; sc < 6; ++sc)
+            for (int n = 0; n < 2; ++n) {
+                const double *a = sc < kScales ? avg[sc * 3 + plane] : nullptr;
+                s = std::fma(kWeight[i++], a ? std::fabs(a[0 + n]) : 0.0, s);
+                s = std::fma(kWeight[i++], a ? std::fabs(a[2 + n]) : 0.0, s);
+                s = std::fma(kWeight[i++], a ? std::fabs(a[4 + n]) : 0.0, s);
+            }
+    s *= 0.9562382616834844;
+    s = (6.248496625763138e-5 * s * s) * s + 2.326765642916932 * s - 0.020884521182843837 * s * s;
+    if (s > 0.0)
+        s = std::pow(s, 0.6276336467831387) * -10.0 + 100.0;
+    else
+        s = 100.0;
+    return s;
+}
+
+}  // namespace
+
+// Scratch (floats): XYB planes of one scale (6 * w * h) + two RGB pyramids that ping-pong
+// (scale s+1 is written while scale s is read): 2 * 6 * (w/2+1)*(h/2+1).
+VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3, ptrdiff_t stride, int w, int h, int npairs, double *scores) {
+    if (!ctx || !ref3 || !dis3 || !scores || npairs <= 0 || w <= 0 || h <= 0) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    static const XybK kx = make_xyb_consts();
+    const size_t n0 = (size_t)w * h;
+    const int w1 = (w + 1) / 2, h1 = (h + 1) / 2;
+    const size_t n1 = (size_t)w1 * h1;
+    const int tiles0 = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
+    const size_t f_xyb = 6 * n0, f_pyr = 6 * n1 + 6 * (((size_t)(w1 + 1) / 2) * ((h1 + 1) / 2));
+    const size_t bytes_part = (size_t)18 * tiles0 * 6 * sizeof(double);
+    const size_t bytes_avg = (size_t)npairs * 18 * 6 * sizeof(double);
+    const size_t need = (f_xyb + f_pyr) * sizeof(float) + bytes_part + bytes_avg + 1024;
+    int rc = vszip_ensure_scratch(ctx, need);
+    if (rc != VSZIP_OK) return rc;
+    rc = vszip_ensure_scalars(ctx, bytes_avg);
+    if (rc != VSZIP_OK) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    double *partial = reinterpret_cast<double *>(base);
+    double *avg_dev = reinterpret_cast<double *>(base + bytes_part);
+    float *fxyb = reinterpret_cast<float *>(base + bytes_part + ((bytes_avg + 255) & ~(size_t)255));
+    float *pyrA = fxyb + f_xyb;       // scales 1, 3
+    float *pyrB = pyrA + 6 * n1;      // scales 2, 4
+    VSZIP_HIP_CHECK(ctx, hipMemsetAsync(avg_dev, 0, bytes_avg, ctx->stream));
+
+    for (int pair = 0; pair < npairs; ++pair) {
+        const float *cur1[3] = {ref3[pair * 3 + 0], ref3[pair * 3 + 1], ref3[pair * 3 + 2]};
+        const float *cur2[3] = {dis3[pair * 3 + 0], dis3[pair * 3 + 1], dis3[pair * 3 + 2]};
+        int cw = w, ch = h, cstride = (int)stride;
+        FinalArgs fin;
+        fin.partial = partial;
+        fin.avg = avg_dev + (size_t)pair * 18 * 6;
+        fin.max_tiles = tiles0;
+        for (int i = 0; i < 18; ++i) {
+            fin.ntiles[i] = 0;
+            fin.one_per_pixels[i] = 0;
+        }
+        for (int scale = 0; scale < kScales; ++scale) {
+            const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+            const size_t n = (size_t)cw * ch;
+            XybArgs xa;
+            MapsArgs ma;
+            ma.nactive = 0;
+            float *pyr = (scale & 1) ? pyrB : pyrA;
+            for (int c = 0; c < 3; ++c) {
+                xa.rgb1[c] = cur1[c];
+                xa.rgb2[c] = cur2[c];
+                const Skip sk = skip_of(c, scale);
+                const bool need = !sk.all();
+                xa.xyb1[c] = need ? fxyb + (size_t)c * n : nullptr;
+                xa.xyb2[c] = need ? fxyb + (size_t)(3 + c) * n : nullptr;
+                const bool last = scale == kScales - 1;
+                xa.next1[c] = last ? nullptr : pyr + (size_t)c * nw * nh;
+                xa.next2[c] = last ? nullptr : pyr + (size_t)(3 + c) * nw * nh;
+                if (need) {
+                    const int k = ma.nactive++;
+                    ma.im1[k] = xa.xyb1[c];
+                    ma.im2[k] = xa.xyb2[c];
+                    ma.flags[k] = (sk.ssim ? 0 : 1) | ((!sk.artifact || !sk.detail) ? 2 : 0);
+                    ma.slot[k] = scale * 3 + c;
+                }
+            }
+            xa.stride = cstride;
+            xa.w = cw;
+            xa.h = ch;
+            xa.nstride = nw;
+            xa.nw = nw;
+            xa.nh = nh;
+            xa.xstride = cw;
+            xa.k = kx;
+            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8), dim3(256), 0, ctx->stream, xa);
+            ma.stride = cw;
+            ma.w = cw;
+            ma.h = ch;
+            ma.tiles_x = (cw + TW - 1) / TW;
+            ma.tiles_y = (ch + TH - 1) / TH;
+            ma.partial = partial;
+            ma.max_tiles = tiles0;
+            if (ma.nactive > 0) hipLaunchKernelGGL(ssim_maps_kernel, dim3(ma.tiles_x, ma.tiles_y, ma.nactive), dim3(256), 0, ctx->stream, ma);
+            for (int k = 0; k < ma.nactive; ++k) {
+                fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
+                fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
+            }
+            if (scale < kScales - 1) {
+                for (int c = 0; c < 3; ++c) {
+                    cur1[c] = xa.next1[c];
+                    cur2[c] = xa.next2[c];
+                }
+                cw = nw;
+                ch = nh;
+                cstride = nw;
+            }
+        }
+        hipLaunchKernelGGL(ssim_final_kernel, dim3(18), dim3(64), 0, ctx->stream, fin);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, avg_dev, bytes_avg, hipMemcpyDeviceToHost, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
+    for (int pair = 0; pair < npairs; ++pair) scores[pair] = score_of(avg[pair]);
+    return VSZIP_OK;
+}
