@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Headline bench: vszip.BoxBlur(hradius=vradius=13) on 3840x2160 YUV420P16.
+"""Headline bench: frames/s of the vszip hot path on MI355X, inputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload boxblur|bilateral|ssimulacra2]
+                    [--frames F] [--no-cpu] [--no-others]
 
-A step is one pass of the hot path over one batch of F synthetic frames that are
-already resident in HBM (F*3 planes -> one or two kernel launches). For N > 1 the
-driver starts one process per GPU through torch.distributed.run; frames shard
-across ranks with no data-path collective (weak scaling: every rank owns its own
-F frames), the only collective is the max-reduce of the timings.
-Rank 0 prints ONE JSON line (see README / DESIGN.md section "Measurement").
+Default workload (the JSON line's `value` and `roofline`): vszip.BoxBlur(hradius=vradius=13)
+on 3840x2160 YUV420P16 — the north-star roofline target. A step is one pass of the hot path
+over one batch of F synthetic frames already resident in HBM (F*3 planes = one launch group).
+The other two headline filters (Bilateral sigmaS=2 sigmaR=2, SSIMULACRA2 ref vs dist) are
+measured in the same run on their BASELINE configs and reported under "others", each beside
+the CPU oracle timed on this box's host cores.
+For N > 1 the driver starts one process per GPU through torch.distributed.run; frames shard
+across ranks with no data-path collective (weak scaling: every rank owns its own F frames);
+the only collective is the max-reduce of the timings.
+Rank 0 prints ONE JSON line (DESIGN.md section "Measurement").
 """
 from __future__ import annotations
 
@@ -27,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 W4K, H4K = 3840, 2160
+W1080, H1080 = 1920, 1080
 RADIUS = 13
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -42,9 +48,48 @@ def make_frame(seed: int, w: int, h: int):
     return [fx.splitmix64_plane(0x5A170000 + 16 * seed + p, s, np.uint16) for p, s in enumerate(yuv420_shapes(w, h))]
 
 
-def cpu_baseline(seconds_budget: float = 15.0):
-    """The CPU oracle (a scalar C++ port of the reference arithmetic) timed on this
-    box's host cores, one 4K frame per thread, on a bounded sample."""
+def natural_frame(w: int, h: int):
+    """Natural-content YUV420P16-shaped planes: the reference test picture tiled."""
+    import fixtures as fx
+
+    return [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate(yuv420_shapes(w, h))]
+
+
+def _lin(v):
+    v = v.astype(np.float64)
+    return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
+
+
+def rgbs_pair(w: int, h: int, seed: int = 1):
+    """ref = tiled natural picture (linear light), dist = ref + noise sigma 0.02, clipped."""
+    import fixtures as fx
+
+    rng = np.random.default_rng(seed)
+    ref = [_lin(fx.tiled_natural((h, w), np.float32, p)) for p in range(3)]
+    dis = [np.clip(p + rng.normal(0, 0.02, p.shape).astype(np.float32), 0, 1).astype(np.float32) for p in ref]
+    return ref, dis
+
+
+# ---------------------------------------------------------------------------
+# CPU baselines: the oracle (scalar C++ port of the reference arithmetic), one unit
+# per thread on all host cores, bounded sample.
+# ---------------------------------------------------------------------------
+def _timed_pool(fn, cores: int, budget_s: float, unit_desc: str, t_single: float):
+    """Waves of `cores` units (one per thread) until the budget is used; at least one wave."""
+    n = 0
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        while True:
+            list(ex.map(fn, range(cores)))
+            n += cores
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or dt + dt / (n // cores) > 2.5 * budget_s:
+                break
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x {unit_desc}, one per thread on {cores} threads, {dt:.1f}s"}
+
+
+def cpu_boxblur(budget_s=6.0):
     from oracle import oracle as orc
 
     orc.build()
@@ -57,18 +102,94 @@ def cpu_baseline(seconds_budget: float = 15.0):
 
     t0 = time.perf_counter()
     one(0)
-    t1 = time.perf_counter() - t0  # single-thread time per frame
-    nframes = max(cores, int(seconds_budget / max(t1, 1e-3)) // 1)
-    nframes = min(nframes, 64 * cores)
-    nframes = (nframes // cores) * cores or cores
-    with ThreadPoolExecutor(cores) as ex:
+    return _timed_pool(one, cores, budget_s, "3840x2160 YUV420P16 frame, BoxBlur r=13", time.perf_counter() - t0)
+
+
+def cpu_bilateral(w, h, budget_s=6.0):
+    from oracle import oracle as orc
+
+    cores = os.cpu_count() or 1
+    frame = natural_frame(w, h)
+    prm = orc.bilateral_params([2], [2], yuv=True, ssw=1, ssh=1)
+
+    def one(_):
+        for i, p in enumerate(frame):
+            orc.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i])
+
+    t0 = time.perf_counter()
+    one(0)
+    return _timed_pool(one, cores, budget_s, f"{w}x{h} YUV420P16 frame, Bilateral sigmaS=2 sigmaR=2", time.perf_counter() - t0)
+
+
+def cpu_ssimulacra2(w, h, budget_s=8.0):
+    from oracle import oracle as orc
+
+    cores = os.cpu_count() or 1
+    ref, dis = rgbs_pair(w, h)
+
+    def one(_):
+        orc.ssimulacra2(ref, dis)
+
+    t0 = time.perf_counter()
+    one(0)
+    r = _timed_pool(one, cores, budget_s, f"{w}x{h} RGBS pair, SSIMULACRA2", time.perf_counter() - t0)
+    r["unit"] = "pairs/s"
+    return r
+
+
+# ---------------------------------------------------------------------------
+# GPU workloads
+# ---------------------------------------------------------------------------
+class Timed:
+    def __init__(self, dev, barrier):
+        self.dev, self.barrier = dev, barrier
+
+    def run(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.barrier()
         t0 = time.perf_counter()
-        list(ex.map(one, range(nframes)))
-        dt = time.perf_counter() - t0
-    return {
-        "value": nframes / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": f"{nframes} frames 3840x2160 YUV420P16 BoxBlur r=13, one frame per thread, {cores} threads, {dt:.1f}s",
-    }
+        self.dev.timer_start()
+        for _ in range(steps):
+            step()
+        kernel_ms = self.dev.timer_stop_ms()  # HIP events on the kernels' stream; synchronises it
+        self.barrier()
+        return time.perf_counter() - t0, kernel_ms
+
+
+def setup_boxblur(dev, rank, frames, radius):
+    base = make_frame(rank, W4K, H4K)
+    srcs, dsts = [], []
+    for f in range(frames):
+        for plane in base:
+            # distinct buffers per frame; content = noise rolled by the frame index
+            srcs.append(dev.upload(np.roll(plane, f * 17 + 1, axis=1)))
+            dsts.append(dev.empty(plane.shape[0], plane.shape[1], plane.dtype))
+    table = dev.plane_table(srcs, dsts)
+    keep = (srcs, dsts)
+    return (lambda: dev.boxblur_table(np.uint16, table, radius, 1, radius, 1)), keep
+
+
+def setup_bilateral(dev, w, h, frames):
+    base = natural_frame(w, h)
+    cfg = dev.bilateral_cfg([2], [2], yuv=True, ssw=1, ssh=1, hist_len=65536)
+    srcs, dsts, idx = [], [], []
+    for f in range(frames):
+        for i, plane in enumerate(base):
+            srcs.append(dev.upload(np.roll(plane, f * 13, axis=1)))
+            dsts.append(dev.empty(plane.shape[0], plane.shape[1], plane.dtype))
+            idx.append(i)
+    keep = (srcs, dsts, cfg)
+    return (lambda: dev.bilateral(srcs, dsts, cfg, idx)), keep
+
+
+def setup_ssimulacra2(dev, w, h, pairs):
+    ref, dis = rgbs_pair(w, h)
+    r, d = [], []
+    for p in range(pairs):
+        r += [dev.upload(np.roll(x, p * 7, axis=1), 1) for x in ref]
+        d += [dev.upload(np.roll(x, p * 7, axis=1), 1) for x in dis]
+    return (lambda: dev.ssimulacra2(r, d)), (r, d)
 
 
 def main() -> int:
@@ -77,15 +198,15 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--workload", default="boxblur", choices=["boxblur", "bilateral", "ssimulacra2"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-others", action="store_true")
     ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        print(f"WORLD_SIZE={world} != --gpus {a.gpus}", file=sys.stderr)
 
     # torch first: its bundled HIP runtime must be the one libvszip_hip.so binds to
     import torch
@@ -101,18 +222,6 @@ def main() -> int:
     import vszip_amd
 
     dev = vszip_amd.Device(local_rank)
-    F = a.frames
-    srcs, dsts = [], []
-    base = make_frame(rank, W4K, H4K)
-    for f in range(F):
-        for p, plane in enumerate(base):
-            # distinct buffers per frame; content = noise rolled by the frame index
-            srcs.append(dev.upload(np.roll(plane, f * 17 + 1, axis=1)))
-            dsts.append(dev.empty(plane.shape[0], plane.shape[1], plane.dtype))
-    table = dev.plane_table(srcs, dsts)
-
-    def step():
-        dev.boxblur_table(np.uint16, table, a.radius, 1, a.radius, 1)
 
     def barrier():
         if world > 1:
@@ -120,53 +229,90 @@ def main() -> int:
         torch.cuda.synchronize()
         dev.sync()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    dev.timer_start()
-    for _ in range(a.steps):
-        step()
-    kernel_ms = dev.timer_stop_ms()  # HIP events on the kernels' stream; synchronises it
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    timed = Timed(dev, barrier)
+
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    F = a.frames
+    out = None
+    if a.workload == "boxblur":
+        step, keep = setup_boxblur(dev, rank, F, a.radius)
+        dt, kernel_ms = timed.run(step, a.steps, a.warmup)
+        dt = max_over_ranks(dt)
+        frame_bytes = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K))  # 24 883 200
+        groups = -(-(3 * F) // 48)                      # launch groups (K_row pre-pass + ring kernel) per step
+        alg_bytes = 2 * frame_bytes * F / groups        # read once + write once
+        avg_s = kernel_ms * 1e-3 / (a.steps * groups)
+        achieved = alg_bytes / avg_s / 1e9
+        out = {
+            "metric": "frames/sec at 4K YUV420P16: Bilateral, BoxBlur, SSIMULACRA2 on 1/2/4/8 MI355X",
+            "value": world * F * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "vszip.BoxBlur hradius=vradius=13, 3840x2160 YUV420P16, splitmix64 noise, HBM-resident",
+                       "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "boxblur_ct_ring_kernel<u16,13> (+ boxblur_ct_krow_kernel pre-pass, included in the time)",
+                         "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        del keep
+        if rank == 0 and world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_boxblur()
+        if world == 1 and not a.no_others:
+            others = {}
+            for name, (w, h, nf) in {"bilateral_1080p": (W1080, H1080, 16), "bilateral_4k": (W4K, H4K, 8)}.items():
+                st, keep = setup_bilateral(dev, w, h, nf)
+                dt2, kms = timed.run(st, 10, 2)
+                others[name] = {"value": nf * 10 / dt2, "unit": "frames/s", "kernel_ms_per_frame": kms / (10 * nf),
+                                "workload": f"vszip.Bilateral sigmaS=2 sigmaR=2 {w}x{h} YUV420P16 (natural content tiled), HBM-resident"}
+                if not a.no_cpu:
+                    others[name]["cpu_baseline"] = cpu_bilateral(w, h, 5.0 if h < 2000 else 3.0)
+                del keep
+            st, keep = setup_ssimulacra2(dev, W4K, H4K, 4)
+            dt3, kms = timed.run(st, 5, 1)
+            others["ssimulacra2_4k"] = {"value": 4 * 5 / dt3, "unit": "pairs/s", "ms_per_pair": dt3 * 1e3 / 20,
+                                        "workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS (linear), HBM-resident; includes the scalar D2H + sync"}
+            if not a.no_cpu:
+                others["ssimulacra2_4k"]["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K, 6.0)
+            del keep
+            out["others"] = others
+    elif a.workload == "bilateral":
+        step, keep = setup_bilateral(dev, W1080, H1080, F)
+        dt, kernel_ms = timed.run(step, a.steps, a.warmup)
+        dt = max_over_ranks(dt)
+        fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W1080, H1080))
+        avg_s = kernel_ms * 1e-3 / a.steps
+        achieved = 2 * fb * F / avg_s / 1e9
+        out = {"metric": "frames/sec: vszip.Bilateral sigmaS=2 sigmaR=2 1920x1080 YUV420P16", "value": world * F * a.steps / dt, "unit": "frames/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "vszip.Bilateral sigmaS=2 sigmaR=2, 1920x1080 YUV420P16, natural content tiled", "frames_per_step_per_gpu": F},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "bilateral_truncated_kernel<u16>"}}
+        if rank == 0 and world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_bilateral(W1080, H1080)
+    else:
+        pairs = max(1, F // 4)
+        step, keep = setup_ssimulacra2(dev, W4K, H4K, pairs)
+        dt, kernel_ms = timed.run(step, a.steps, a.warmup)
+        dt = max_over_ranks(dt)
+        avg_s = kernel_ms * 1e-3 / a.steps
+        achieved = 2 * 3 * W4K * H4K * 4 * pairs / avg_s / 1e9
+        out = {"metric": "pairs/sec: vszip.SSIMULACRA2 3840x2160 RGBS", "value": world * pairs * a.steps / dt, "unit": "pairs/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS linear", "pairs_per_step_per_gpu": pairs},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "ssim_maps_kernel"}}
+        if rank == 0 and world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K)
 
     if rank == 0:
-        frame_bytes = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K))  # 24 883 200
-        launches_per_step = -(-len(srcs) // 48)
-        alg_bytes_per_launch = 2 * frame_bytes * F / launches_per_step  # read once + write once
-        avg_launch_s = kernel_ms * 1e-3 / (a.steps * launches_per_step)
-        achieved = alg_bytes_per_launch / avg_launch_s / 1e9
-        out = {
-            "metric": "frames/sec at 4K YUV420P16: BoxBlur r=13 (Bilateral, SSIMULACRA2 reported by their own workloads)",
-            "value": world * F * a.steps / dt,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": dt * 1e3 / a.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u16",
-            "data": "synthetic",
-            "config": {
-                "workload": "vszip.BoxBlur hradius=vradius=13, 3840x2160 YUV420P16, splitmix64 noise, HBM-resident",
-                "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}",
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "boxblur_ct_int_kernel<u16,13>", "avg_launch_us": avg_launch_s * 1e6,
-                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-            },
-        }
-        if not a.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

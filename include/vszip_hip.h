@@ -165,6 +165,28 @@ int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *planes,
 int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3,
                       ptrdiff_t stride, int w, int h, int npairs, double *scores);
 
+/*
+ * EEDI3 / EEDI3H — replaces processPlane (src/vapoursynth/eedi3.zig:26-140) with its kernels
+ * interpLine / vcheckLine (src/filters/eedi3.zig:349-592, 915-1046) and, for horizontal != 0,
+ * the transposes of :220-246. 32-bit float planes only (createImpl :316-319).
+ * planes[i].src is src_w x src_h; planes[i].dst is src_w x (dh ? 2*src_h : src_h) for EEDI3 and
+ * (dh ? 2*src_w : src_w) x src_h for EEDI3H. `field` is the frame's resolved parity 0/1
+ * (getFrame :166-172 folds _FieldBased and field 2/3 into it). sclips[i] (may be NULL, as may
+ * the array) has dst's geometry. Parameters are the user-level ones (defaults: alpha .2,
+ * beta .25, gamma 20, nrad 2, mdis 20, hp 0, vcheck 2, vthresh 32/64/4); the scaling of
+ * :465-473 happens inside. Errors mirror createImpl's messages.
+ */
+typedef struct vszip_eedi3_params {
+    int32_t dh;
+    float alpha, beta, gamma;
+    int32_t nrad, mdis, hp, vcheck;
+    float vthresh0, vthresh1, vthresh2;
+} vszip_eedi3_params;
+
+int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips,
+                const ptrdiff_t *sclip_strides, int nplanes, int field, int horizontal,
+                const vszip_eedi3_params *params);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""GPU parity: vszip_eedi3 vs the CPU oracle, bit-exact (the discrete Viterbi path makes any
+arithmetic deviation visible), plus the reference's own goldens and the EEDI3H identity
+(reference tests/test_eedi3.py:23-62,111-118)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    yield d
+    d.close()
+
+
+def _gpu(dev, src, field, **kw):
+    s = dev.upload(np.ascontiguousarray(src, np.float32))
+    (d,) = dev.eedi3([s], field, **kw)
+    return dev.download(d)
+
+
+CASES = [
+    dict(field=1), dict(field=0), dict(field=1, dh=True), dict(field=0, dh=True),
+    dict(field=1, vcheck=0), dict(field=1, vcheck=1), dict(field=1, vcheck=3),
+    dict(field=1, mdis=31, nrad=3), dict(field=1, mdis=5, nrad=0), dict(field=1, gamma=0.0),
+    dict(field=1, alpha=0.4, beta=0.3, gamma=40.0), dict(field=1, alpha=0.9, beta=0.05, gamma=2.0, mdis=30),
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) for c in CASES])
+def test_matches_oracle(dev, oracle, kw):
+    src = fx.crop_rgbs()[1][:120, :333]
+    kw = dict(kw)
+    field = kw.pop("field")
+    got = _gpu(dev, src, field, **kw)
+    want = oracle.eedi3(src, field, **kw)
+    assert np.array_equal(got, want), (kw, int((got != want).sum()))
+
+
+def test_horizontal_matches_oracle_and_identity(dev, oracle):
+    src = fx.crop_rgbs()[0][:150, :200]
+    for dh in (False, True):
+        got = _gpu(dev, src, 1, dh=dh, horizontal=True)
+        assert np.array_equal(got, oracle.eedi3(src, 1, dh=dh, horizontal=True))
+        vert = _gpu(dev, np.ascontiguousarray(src.T), 1, dh=dh)
+        assert np.array_equal(got, vert.T)
+
+
+def test_sclip(dev, oracle):
+    src = fx.crop_rgbs()[2][:96, :160]
+    sc = fx.splitmix64_plane(9, (96, 160), np.float32)
+    s, c = dev.upload(src), dev.upload(sc)
+    (d,) = dev.eedi3([s], 1, sclips=[c])
+    assert np.array_equal(dev.download(d), oracle.eedi3(src, 1, sclip=sc))
+
+
+def test_reference_goldens(dev):
+    g = fx.ref_goldens()["exact"]
+    planes = [dev.upload(np.ascontiguousarray(p)) for p in fx.crop_rgbs()]
+    for key, horiz in (("eedi3", False), ("eedi3h", True)):
+        outs = dev.eedi3(planes, 1, horizontal=horiz)
+        for p in range(3):
+            st = fx.plane_stats(dev.download(outs[p]))
+            for k in ("avg", "min", "max"):
+                assert st[k] == pytest.approx(g[key]["RGBS|full|field=1"][f"p{p}"][k], rel=1e-6, abs=1e-9)
+
+
+def test_errors(dev):
+    import vszip_amd
+
+    s = dev.upload(np.zeros((64, 128), np.float32))
+    for kw, msg in ((dict(alpha=0.8, beta=0.5), "alpha \\+ beta"), (dict(nrad=4), "nrad must be"), (dict(mdis=0), "mdis must be"), (dict(vcheck=4), "vcheck must be")):
+        with pytest.raises(vszip_amd.VszipError, match=msg):
+            dev.eedi3([s], 1, **kw)
+    odd = dev.upload(np.zeros((63, 128), np.float32))
+    with pytest.raises(vszip_amd.VszipError, match="height must be mod 2"):
+        dev.eedi3([odd], 1)

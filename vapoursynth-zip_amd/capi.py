@@ -42,6 +42,11 @@ class BilateralCfg(C.Structure):
     ]
 
 
+class Eedi3Params(C.Structure):
+    _fields_ = [("dh", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float), ("nrad", C.c_int32), ("mdis", C.c_int32),
+                ("hp", C.c_int32), ("vcheck", C.c_int32), ("vthresh0", C.c_float), ("vthresh1", C.c_float), ("vthresh2", C.c_float)]
+
+
 # every symbol include/vszip_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _sz, _pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
 _PP = C.POINTER(Plane)
@@ -69,6 +74,7 @@ SYMBOLS = {
     "vszip_bilateral_luts": (_i, [_vp, C.POINTER(BilateralCfg), _i]),
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
     "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
+    "vszip_eedi3": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -258,3 +264,23 @@ class Device:
         p0 = ref_planes[0]
         self.check(self.lib.vszip_ssimulacra2(self.ctx, r, d, p0.stride, p0.w, p0.h, n, out))
         return list(out)
+
+    def eedi3(self, srcs, field, dh=False, alpha=0.2, beta=0.25, gamma=20.0, nrad=2, mdis=20, hp=False, vcheck=2,
+              vthresh0=32.0, vthresh1=64.0, vthresh2=4.0, sclips=None, horizontal=False):
+        """srcs: f32 DevPlanes. Returns the output DevPlanes."""
+        dsts = []
+        for s in srcs:
+            if horizontal:
+                dsts.append(self.empty(s.h, s.w * 2 if dh else s.w, np.float32))
+            else:
+                dsts.append(self.empty(s.h * 2 if dh else s.h, s.w, np.float32))
+        n = len(srcs)
+        table = self.plane_table(srcs, dsts)
+        prm = Eedi3Params(int(dh), alpha, beta, gamma, nrad, mdis, int(hp), vcheck, vthresh0, vthresh1, vthresh2)
+        if sclips is not None:
+            sp = (C.c_void_p * n)(*[(s.ptr if s is not None else None) for s in sclips])
+            ss = (C.c_ssize_t * n)(*[(s.stride if s is not None else 0) for s in sclips])
+        else:
+            sp, ss = None, None
+        self.check(self.lib.vszip_eedi3(self.ctx, table, sp, ss, n, field, int(horizontal), C.byref(prm)))
+        return dsts

@@ -1,0 +1,457 @@
+// vszip.EEDI3 / EEDI3H on gfx950 (32-bit float planes, like the reference).
+//
+// Replaces processPlane (src/vapoursynth/eedi3.zig:26-140) and its kernels
+// interpLine (src/filters/eedi3.zig:349-592, with costBlockDirect :311-347) and
+// vcheckLine (:915-1046); EEDI3H is transpose -> vertical pipeline -> transpose
+// (src/vapoursynth/eedi3.zig:220-246). hp=True (interpLineHP) and mclip are reported as
+// VSZIP_ERR_UNSUPPORTED for now; mdis is limited to 31 (one DP state per lane).
+//
+// eedi3_line_kernel — one wave per interpolated line, x processed in blocks of 64:
+//   cost phase (lanes = x): for every direction u the per-column base term
+//     t_base[j] = |r3p[j]-r1p[j-2u]| + |r1p[j]-r1n[j-2u]| + |r1n[j]-r3n[j-2u]|
+//   goes to LDS, the three (2*nrad+1)-tap window sums are re-formed in the reference's
+//   k order (fresh sums, not a running one), and cost[u][x] lands in a 64 x tpitch LDS tile;
+//   DP phase (lanes = directions): the Viterbi recurrence over the 64 columns with the
+//   reference's strict-< tie-breaking (centre, then left, then right), neighbours through
+//   wave shuffles, back-pointers into an LDS tile that is flushed to a global scratch;
+//   after the last block the path is walked back block by block and every lane writes its
+//   column's cubic / linear interpolation and direction.
+// eedi3_vcheck_kernel — the vertical-consistency blend; it reads the already-updated line
+//   pd-2, so lines are processed in order by one workgroup per plane, 1024 columns wide.
+// All f32 arithmetic is unfused and in the reference's operation order: results are
+// bit-identical to the CPU oracle (the discrete path makes anything less visible).
+#include <cfloat>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxMdis = 31;
+constexpr int kXB = 64;         // columns per block
+constexpr int kTbMax = 64 + 4 * kMaxMdis + 2 * 3 + 8;
+constexpr int kMaxPlanesE = 16;
+
+struct EPlane {
+    const float *src;   // field-source plane (vertical layout: rows = lines)
+    float *dst;
+    int *dmap;          // [n_interp][w]
+    int8_t *pback;      // [lines of this plane][w][tpitch]
+    int sstride, dstride;
+    int w, n_src, n_dst, n_interp;
+    int line0;          // first global line id of this plane
+};
+
+struct EParams {
+    EPlane p[kMaxPlanesE];
+    int nplanes;
+    int field, dh;
+    int mdis, nrad;
+    float alpha, beta, gamma, one_minus_ab;
+};
+
+__device__ __forceinline__ int reflect_row(int y, int h) {  // eedi3.zig:88-96
+    if (h == 1) return 0;
+    int r = y;
+    while (r < 0 || r >= h) {
+        if (r < 0) r = -r;
+        if (r >= h) r = 2 * (h - 1) - r;
+    }
+    return r;
+}
+__device__ __forceinline__ int src_col(bool dh, int off, int n_src) {  // :102-104
+    return dh ? reflect_row(off, 2 * n_src) / 2 : reflect_row(off, n_src);
+}
+
+// Column c of a mirror-padded row (mirrorPad :107-110 is reflect-101 on both sides for
+// every column the kernels touch when w >= 2*mdis + nrad + 2).
+__device__ __forceinline__ float rowv(const float *row, int c, int w) {
+    c = c < 0 ? -c : c;
+    c = c >= w ? 2 * (w - 1) - c : c;
+    return row[c];
+}
+
+__global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
+    const float kFltMax09 = FLT_MAX * 0.9f;
+    __shared__ float tb[kTbMax];
+    __shared__ float ctile[2 * kMaxMdis + 1][kXB + 1];
+    __shared__ int8_t ptile[kXB][64];
+    __shared__ int fpt[kXB];
+
+    int pi = 0;
+    const int gl = blockIdx.x;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (gl >= prm.p[i].line0) pi = i;
+    const EPlane pl = prm.p[pi];
+    const int off = gl - pl.line0;              // interpolated-line index within the plane
+    const int line = prm.field + 2 * off;       // destination line
+    const int w = pl.w, mdis = prm.mdis, nrad = prm.nrad, tpitch = 2 * mdis + 1;
+    const int lane = threadIdx.x;
+    const bool dh = prm.dh != 0;
+    const float *r3p = pl.src + (size_t)src_col(dh, line - 3, pl.n_src) * pl.sstride;
+    const float *r1p = pl.src + (size_t)src_col(dh, line - 1, pl.n_src) * pl.sstride;
+    const float *r1n = pl.src + (size_t)src_col(dh, line + 1, pl.n_src) * pl.sstride;
+    const float *r3n = pl.src + (size_t)src_col(dh, line + 3, pl.n_src) * pl.sstride;
+    int8_t *pback = pl.pback + (size_t)off * w * tpitch;
+    float *out = pl.dst + (size_t)line * pl.dstride;
+    int *dmap = pl.dmap + (size_t)off * w;
+
+    float pcost = kFltMax09;  // DP state of direction `lane` (inactive lanes stay at the sentinel)
+    const int nblk = (w + kXB - 1) / kXB;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int xb = blk * kXB;
+        const int x = xb + lane;
+        // ---- cost phase, lanes = x -------------------------------------------------
+        for (int u = -mdis; u <= mdis; ++u) {
+            const int two_u = 2 * u;
+            const int jlo = min(u, min(0, two_u)) - nrad, jhi = max(u, max(0, two_u)) + nrad;
+            const int span = kXB + jhi - jlo;  // t_base columns xb+jlo .. xb+63+jhi
+            __syncthreads();
+            for (int t = lane; t < span; t += 64) {
+                const int j = xb + jlo + t;
+                const float a = rowv(r3p, j, w), b = rowv(r1p, j - two_u, w), c = rowv(r1p, j, w);
+                const float d = rowv(r1n, j - two_u, w), e = rowv(r1n, j, w), f = rowv(r3n, j - two_u, w);
+                tb[t] = fabsf(a - b) + fabsf(c - d) + fabsf(e - f);  // :415-425
+            }
+            __syncthreads();
+            if (x < w) {
+                float sw0 = 0.0f, sw1 = 0.0f, sw2 = 0.0f;
+                const int base = lane - jlo;  // index of column x
+                for (int k = -nrad; k <= nrad; ++k) {  // :443-450 fresh window sums in k order
+                    sw1 += tb[base + k];
+                    sw0 += tb[base + u + k];
+                    sw2 += tb[base + two_u + k];
+                }
+                const float ip = (rowv(r1p, x + u, w) + rowv(r1n, x - u, w)) * 0.5f;
+                const float v = fabsf(rowv(r1p, x, w) - ip) + fabsf(rowv(r1n, x, w) - ip);
+                ctile[mdis + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
+            }
+        }
+        __syncthreads();
+        // ---- DP phase, lanes = direction index ---------------------------------------
+        const int xe = min(kXB, w - xb);
+        for (int xl = 0; xl < xe; ++xl) {
+            const int xx = xb + xl;
+            const float tc = lane < tpitch ? ctile[lane][xl] : 0.0f;
+            if (xx == 0) {
+                pcost = lane < tpitch ? tc : kFltMax09;  // :461-463
+                continue;
+            }
+            float left = __shfl_up(pcost, 1, 64);
+            float right = __shfl_down(pcost, 1, 64);
+            if (lane == 0) left = kFltMax09;
+            if (lane >= tpitch - 1) right = kFltMax09;
+            const float left_cc = left + prm.gamma, right_cc = right + prm.gamma;
+            float bval = pcost;  // :536-548
+            int bd = 0;
+            if (left_cc < bval) {
+                bval = left_cc;
+                bd = -1;
+            }
+            if (right_cc < bval) {
+                bval = right_cc;
+                bd = 1;
+            }
+            if (lane < tpitch) pcost = fminf(bval + tc, kFltMax09);
+            // back-pointer of column xx-1 (:472): stored at the tile row of xx-1
+            if (xl == 0) {
+                if (lane < tpitch) pback[(size_t)(xx - 1) * tpitch + lane] = (int8_t)bd;  // last row of the previous block
+            } else {
+                ptile[xl - 1][lane] = (int8_t)bd;
+            }
+        }
+        __syncthreads();
+        // flush the block's back-pointers (rows xb .. xb+xe-2; row xb+xe-1 comes with the next block)
+        for (int t = lane; t < (xe - 1) * tpitch; t += 64) {
+            const int r = t / tpitch, c = t - r * tpitch;
+            pback[(size_t)(xb + r) * tpitch + c] = ptile[r][c];
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+
+    // ---- backtrack (:557-565) + output (:577-591), block by block from the right ------------
+    int carry = 0;  // fpath of the first column of the block to the right
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int xb = blk * kXB;
+        const int xe = min(kXB, w - xb);
+        __syncthreads();
+        for (int t = lane; t < xe * tpitch; t += 64) {
+            const int r = t / tpitch, c = t - r * tpitch;
+            if (xb + r < w - 1) ptile[r][c] = pback[(size_t)(xb + r) * tpitch + c];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int fp = carry;
+            for (int xl = xe - 1; xl >= 0; --xl) {
+                const int xx = xb + xl;
+                if (xx == w - 1)
+                    fp = 0;
+                else
+                    fp = fp + ptile[xl][mdis + fp];
+                fpt[xl] = fp;
+            }
+        }
+        __syncthreads();
+        carry = fpt[0];
+        if (lane < xe) {
+            const int xx = xb + lane;
+            const int dir = fpt[lane], ad = abs(dir);
+            dmap[xx] = dir;
+            float v;
+            if (xx >= ad * 3 && xx + ad * 3 <= w - 1)
+                v = 0.5625f * (rowv(r1p, xx + dir, w) + rowv(r1n, xx - dir, w)) - 0.0625f * (rowv(r3p, xx + dir * 3, w) + rowv(r3n, xx - dir * 3, w));
+            else
+                v = (rowv(r1p, xx + dir, w) + rowv(r1n, xx - dir, w)) * 0.5f;
+            out[xx] = v;
+        }
+    }
+}
+
+// Copy the kept field (processPlane :41-53).
+__global__ void eedi3_copy_kernel(const EParams prm) {
+    const EPlane pl = prm.p[blockIdx.z];
+    const int k = blockIdx.y;
+    if (k >= pl.n_src) return;
+    int dl;
+    if (prm.dh) {
+        dl = 2 * k + (1 - prm.field);
+    } else {
+        if ((k & 1) != ((1 - prm.field) & 1)) return;
+        dl = k;
+    }
+    const float *s = pl.src + (size_t)k * pl.sstride;
+    float *d = pl.dst + (size_t)dl * pl.dstride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < pl.w; x += gridDim.x * blockDim.x) d[x] = s[x];
+}
+
+struct VParams {
+    EPlane p[kMaxPlanesE];
+    const float *scp[kMaxPlanesE];
+    int scstride[kMaxPlanesE];
+    int field, dh, vcheck;
+    float vthresh2, rcp0, rcp1, rcp2;
+};
+
+// vcheckLine (:915-1046), hp = false. One workgroup per plane walks the lines in order.
+__global__ __launch_bounds__(1024) void eedi3_vcheck_kernel(const VParams prm) {
+    const EPlane pl = prm.p[blockIdx.x];
+    const float *scp = prm.scp[blockIdx.x];
+    const int L = pl.w;
+    const bool dh = prm.dh != 0;
+    for (int off = 1; off + 1 < pl.n_interp; ++off) {
+        const int pd = prm.field + 2 * off;
+        if (pd < 2 || pd + 2 >= pl.n_dst) continue;
+        float *dl = pl.dst + (size_t)pd * pl.dstride;
+        const float *d1p = pl.dst + (size_t)(pd - 1) * pl.dstride, *d2p = pl.dst + (size_t)(pd - 2) * pl.dstride;
+        const float *d1n = pl.dst + (size_t)(pd + 1) * pl.dstride, *d2n = pl.dst + (size_t)(pd + 2) * pl.dstride;
+        const float *d3p = pl.src + (size_t)src_col(dh, pd - 3, pl.n_src) * pl.sstride;
+        const float *d3n = pl.src + (size_t)src_col(dh, pd + 3, pl.n_src) * pl.sstride;
+        const int *dc = pl.dmap + (size_t)off * L, *dp = pl.dmap + (size_t)(off - 1) * L, *dn = pl.dmap + (size_t)(off + 1) * L;
+        const float *sl = scp ? scp + (size_t)pd * prm.scstride[blockIdx.x] : nullptr;
+        // every column first computes its blended value from the line as it stands, then all
+        // columns store (tline + memcpy in the reference)
+        float res[4];
+        int cnt = 0;
+        for (int i = threadIdx.x; i < L; i += 1024, ++cnt) {
+            const int dirc = dc[i];
+            const float cint = sl ? sl[i] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
+            float r = cint;
+            const int dirt = dp[i], dirb = dn[i];
+            const int maxoff = abs(dirc);
+            if (dirc != 0 && !(max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) && !(i + maxoff >= L || i - maxoff < 0)) {
+                const int ipd = i + dirc, imd = i - dirc;
+                const float it = (d2p[ipd] + dl[imd]) * 0.5f;
+                const float ib = (dl[ipd] + d2n[imd]) * 0.5f;
+                const float vt = fabsf(d2p[ipd] - d1p[ipd]) + fabsf(dl[ipd] - d1p[ipd]);
+                const float vb = fabsf(d2n[imd] - d1n[imd]) + fabsf(dl[imd] - d1n[imd]);
+                const float vc = fabsf(dl[i] - d1p[i]) + fabsf(dl[i] - d1n[i]);
+                const float e0 = fabsf(it - d1p[i]), e1 = fabsf(ib - d1n[i]), e2 = fabsf(vt - vc), e3 = fabsf(vb - vc);
+                float m0, m1;
+                if (prm.vcheck == 1) {
+                    m0 = fminf(e0, e1);
+                    m1 = fminf(e2, e3);
+                } else if (prm.vcheck == 2) {
+                    m0 = (e0 + e1) * 0.5f;
+                    m1 = (e2 + e3) * 0.5f;
+                } else {
+                    m0 = fmaxf(e0, e1);
+                    m1 = fmaxf(e2, e3);
+                }
+                const float a0 = m0 * prm.rcp0, a1 = m1 * prm.rcp1;
+                const float a2 = fmaxf((prm.vthresh2 - (float)maxoff) * prm.rcp2, 0.0f);
+                const float a = fminf(fmaxf(a0, fmaxf(a1, a2)), 1.0f);
+                r = (1.0f - a) * dl[i] + a * cint;
+            }
+            if (cnt < 4) res[cnt] = r;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = threadIdx.x; i < L; i += 1024, ++cnt) dl[i] = res[cnt];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+constexpr int kTT = 32;
+__global__ void transpose_kernel(const float *src, float *dst, int sstride, int dstride, int w, int h) {
+    __shared__ float t[kTT][kTT + 1];
+    const int x0 = blockIdx.x * kTT, y0 = blockIdx.y * kTT;
+    for (int r = threadIdx.y; r < kTT; r += blockDim.y) {
+        const int x = x0 + threadIdx.x, y = y0 + r;
+        if (x < w && y < h) t[r][threadIdx.x] = src[(size_t)y * sstride + x];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < kTT; r += blockDim.y) {
+        const int y = y0 + threadIdx.x, x = x0 + r;  // dst[x][y] = src[y][x]
+        if (x < w && y < h) dst[(size_t)x * dstride + y] = t[threadIdx.x][r];
+    }
+}
+
+}  // namespace
+
+VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips, const ptrdiff_t *sclip_strides, int nplanes, int field,
+                             int horizontal, const vszip_eedi3_params *up) {
+    if (!ctx || !planes || !up || nplanes <= 0 || nplanes > kMaxPlanesE) return VSZIP_ERR_ARG;
+    const char *name = horizontal ? "EEDI3H" : "EEDI3";
+    // createImpl :316-410
+    if (field < 0 || field > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: field must be 0 or 1 here (the wrapper resolves 2/3 per frame).", name);
+    if (up->alpha < 0.0f || up->alpha > 1.0f) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: alpha must be between 0.0 and 1.0 (inclusive).", name);
+    if (up->beta < 0.0f || up->beta > 1.0f) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: beta must be between 0.0 and 1.0 (inclusive).", name);
+    if (up->alpha + up->beta > 1.0f) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: alpha + beta must be less than or equal to 1.0.", name);
+    if (up->gamma < 0.0f) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: gamma must be greater than or equal to 0.0.", name);
+    if (up->nrad < 0 || up->nrad > 3) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: nrad must be between 0 and 3 (inclusive).", name);
+    if (up->mdis < 1 || up->mdis > 40) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: mdis must be between 1 and 40 (inclusive).", name);
+    if (up->vcheck < 0 || up->vcheck > 3) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: vcheck must be 0, 1, 2, or 3.", name);
+    if (up->vcheck > 0 && (up->vthresh0 <= 0.0f || up->vthresh1 <= 0.0f || up->vthresh2 <= 0.0f))
+        return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: vthresh0, vthresh1 and vthresh2 must be greater than 0.0.", name);
+    if (up->hp) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: hp=True not built yet", name);
+    if (up->mdis > kMaxMdis) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: mdis > %d not built yet", name, kMaxMdis);
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const bool dh = up->dh != 0;
+    const int tpitch = 2 * up->mdis + 1;
+
+    // geometry of the vertical pipeline per plane (EEDI3H runs it on the transposed plane)
+    struct Geo {
+        int L, n_src, n_dst, n_interp;
+        size_t srcT, dstT, scT;  // float offsets into scratch (horizontal only)
+    };
+    std::vector<Geo> geo(nplanes);
+    size_t fl = 0, lines = 0, pb = 0, dm = 0;
+    for (int i = 0; i < nplanes; ++i) {
+        const vszip_plane &s = planes[i];
+        if (!s.src || !s.dst || s.w <= 0 || s.h <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: bad plane %d", name, i);
+        const int axis = horizontal ? s.w : s.h;
+        if (!dh && (axis & 1)) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: %s must be mod 2 when dh=False.", name, horizontal ? "width" : "height");
+        Geo &g = geo[i];
+        g.L = horizontal ? s.h : s.w;
+        g.n_src = horizontal ? s.w : s.h;
+        g.n_dst = dh ? 2 * g.n_src : g.n_src;
+        g.n_interp = dh ? g.n_src : g.n_src / 2;
+        if (g.L < 2 * up->mdis + up->nrad + 2) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines shorter than 2*mdis+nrad+2 not built yet", name);
+        if (horizontal) {
+            g.srcT = fl;
+            fl += (size_t)g.n_src * g.L;
+            g.dstT = fl;
+            fl += (size_t)g.n_dst * g.L;
+            g.scT = fl;
+            if (up->vcheck > 0 && sclips && sclips[i]) fl += (size_t)g.n_dst * g.L;
+        }
+        lines += g.n_interp;
+        pb += (size_t)g.n_interp * g.L * tpitch;
+        dm += (size_t)g.n_interp * g.L;
+    }
+    const size_t bytes = fl * sizeof(float) + dm * sizeof(int) + pb + 4096;
+    int rc = vszip_ensure_scratch(ctx, bytes);
+    if (rc != VSZIP_OK) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    float *fbase = reinterpret_cast<float *>(base);
+    int *dbase = reinterpret_cast<int *>(base + fl * sizeof(float));
+    int8_t *pbase = reinterpret_cast<int8_t *>(base + fl * sizeof(float) + dm * sizeof(int));
+
+    EParams ep;
+    VParams vp;
+    ep.nplanes = nplanes;
+    ep.field = field;
+    ep.dh = dh;
+    ep.mdis = up->mdis;
+    ep.nrad = up->nrad;
+    // src/vapoursynth/eedi3.zig:465-473
+    ep.one_minus_ab = 1.0f - up->alpha - up->beta;
+    ep.alpha = up->alpha / 3.0f;
+    ep.beta = up->beta / 255.0f;
+    ep.gamma = up->gamma / 255.0f;
+    vp.field = field;
+    vp.dh = dh;
+    vp.vcheck = up->vcheck;
+    const float vt0 = up->vthresh0 / 255.0f, vt1 = up->vthresh1 / 255.0f;
+    vp.vthresh2 = up->vthresh2;
+    vp.rcp0 = 1.0f / vt0;
+    vp.rcp1 = 1.0f / vt1;
+    vp.rcp2 = 1.0f / up->vthresh2;
+    size_t dmo = 0, pbo = 0;
+    int line0 = 0, maxw = 0, maxsrc = 0;
+    const dim3 tb(kTT, 8);
+    for (int i = 0; i < nplanes; ++i) {
+        const vszip_plane &s = planes[i];
+        const Geo &g = geo[i];
+        EPlane &d = ep.p[i];
+        if (horizontal) {
+            float *srcT = fbase + g.srcT;
+            hipLaunchKernelGGL(transpose_kernel, dim3((s.w + kTT - 1) / kTT, (s.h + kTT - 1) / kTT), tb, 0, ctx->stream, static_cast<const float *>(s.src), srcT,
+                               (int)s.src_stride, g.L, s.w, s.h);
+            d.src = srcT;
+            d.dst = fbase + g.dstT;
+            d.sstride = d.dstride = g.L;
+            vp.scp[i] = nullptr;
+            vp.scstride[i] = g.L;
+            if (up->vcheck > 0 && sclips && sclips[i]) {
+                float *scT = fbase + g.scT;
+                hipLaunchKernelGGL(transpose_kernel, dim3((g.n_dst + kTT - 1) / kTT, (s.h + kTT - 1) / kTT), tb, 0, ctx->stream, sclips[i], scT,
+                                   (int)sclip_strides[i], g.L, g.n_dst, s.h);
+                vp.scp[i] = scT;
+            }
+        } else {
+            d.src = static_cast<const float *>(s.src);
+            d.dst = static_cast<float *>(s.dst);
+            d.sstride = (int)s.src_stride;
+            d.dstride = (int)s.dst_stride;
+            vp.scp[i] = (up->vcheck > 0 && sclips) ? sclips[i] : nullptr;
+            vp.scstride[i] = (sclips && sclip_strides) ? (int)sclip_strides[i] : 0;
+        }
+        d.w = g.L;
+        d.n_src = g.n_src;
+        d.n_dst = g.n_dst;
+        d.n_interp = g.n_interp;
+        d.dmap = dbase + dmo;
+        d.pback = pbase + pbo;
+        d.line0 = line0;
+        dmo += (size_t)g.n_interp * g.L;
+        pbo += (size_t)g.n_interp * g.L * tpitch;
+        line0 += g.n_interp;
+        maxw = std::max(maxw, g.L);
+        maxsrc = std::max(maxsrc, g.n_src);
+        vp.p[i] = d;
+    }
+    hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);
+    hipLaunchKernelGGL(eedi3_line_kernel, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep);
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    if (up->vcheck > 0) {
+        for (int i = 0; i < nplanes; ++i)
+            if (geo[i].L > 4096) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: vcheck on lines longer than 4096 not built yet", name);
+        hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (horizontal) {
+        for (int i = 0; i < nplanes; ++i) {
+            const vszip_plane &s = planes[i];
+            const Geo &g = geo[i];
+            // dstT is n_dst lines of L -> dst is L (= src_h) rows of n_dst columns
+            hipLaunchKernelGGL(transpose_kernel, dim3((g.L + kTT - 1) / kTT, (g.n_dst + kTT - 1) / kTT), tb, 0, ctx->stream, fbase + g.dstT, static_cast<float *>(s.dst), g.L,
+                               (int)s.dst_stride, g.L, g.n_dst);
+        }
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return VSZIP_OK;
+}
