@@ -187,6 +187,22 @@ int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const float *const *s
                 const ptrdiff_t *sclip_strides, int nplanes, int field, int horizontal,
                 const vszip_eedi3_params *params);
 
+/*
+ * XPSNR — replaces filter.getWSSE (src/filters/xpsnr.zig:376) called from XPSNR(T).getFrame
+ * (src/vapoursynth/xpsnr.zig:72-82): org3/rec3 are host arrays of num_comps device plane
+ * pointers (u8 or u16 samples: bytes_per_sample 1 or 2, depth 8 or 10), prev1/prev2 the luma of
+ * reference frames n-1 / n-2 or NULL (n == 0/1, or temporal off). wsse3 receives wsse64[0..2].
+ * Synchronises the stream. vszip_xpsnr_value / _average are getFrameXPSNR / getAvgXPSNR
+ * (:359-374), host-only helpers for the wrapper's props and its per-clip summary.
+ */
+int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const void *const *org3, const void *const *rec3,
+                     const void *prev1, const void *prev2, const int *width3, const int *height3,
+                     const ptrdiff_t *stride3, int depth, int num_comps, unsigned frame_rate, int temporal,
+                     uint64_t *wsse3);
+double vszip_xpsnr_value(uint64_t wsse, uint64_t width, uint64_t height, int depth);
+double vszip_xpsnr_average(double sum_wdist, double sum_xpsnr, uint64_t width, uint64_t height, int depth,
+                           uint64_t num_frames);
+
 #ifdef __cplusplus
 }
 #endif

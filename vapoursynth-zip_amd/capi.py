@@ -75,6 +75,10 @@ SYMBOLS = {
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
     "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
     "vszip_eedi3": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
+    "vszip_xpsnr_wsse": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd), _i, _i, C.c_uint, _i,
+                              C.POINTER(C.c_uint64)]),
+    "vszip_xpsnr_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64, _i]),
+    "vszip_xpsnr_average": (C.c_double, [C.c_double, C.c_double, C.c_uint64, C.c_uint64, _i, C.c_uint64]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -284,3 +288,15 @@ class Device:
             sp, ss = None, None
         self.check(self.lib.vszip_eedi3(self.ctx, table, sp, ss, n, field, int(horizontal), C.byref(prm)))
         return dsts
+
+    def xpsnr_wsse(self, org, rec, prev1=None, prev2=None, depth=8, frame_rate=24, temporal=True):
+        """org / rec: lists of 1 or 3 DevPlanes (u8/u16). -> [wsse64 per plane]"""
+        n = len(org)
+        vp3 = lambda l: (C.c_void_p * 3)(*([p.ptr for p in l] + [None] * (3 - n)))
+        w = (C.c_int * 3)(*([p.w for p in org] + [0] * (3 - n)))
+        h = (C.c_int * 3)(*([p.h for p in org] + [0] * (3 - n)))
+        st = (C.c_ssize_t * 3)(*([p.stride for p in org] + [0] * (3 - n)))
+        out = (C.c_uint64 * 3)()
+        self.check(self.lib.vszip_xpsnr_wsse(self.ctx, org[0].dtype.itemsize, vp3(org), vp3(rec), prev1.ptr if prev1 else None, prev2.ptr if prev2 else None,
+                                             w, h, st, depth, n, frame_rate, int(temporal), out))
+        return [int(out[i]) for i in range(n)]
