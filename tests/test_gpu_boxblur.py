@@ -101,3 +101,39 @@ def test_errors(dev):
         dev.boxblur([src], [dst], 0, 1, 0, 1)
     with pytest.raises(vszip_amd.VszipError, match="hradius too large"):
         dev.boxblur([src], [dst], 10, 1, 10, 1)
+
+
+# ---- CT float and RT paths -------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("r", [1, 2, 7, 13, 22])
+def test_ct_float_matches_oracle(dev, oracle, dtype, r):
+    for shape in [(120, 200), (67, 131), (300, 500)]:
+        if 2 * r >= min(shape):
+            continue
+        src = fx.splitmix64_plane(50 + r, shape, dtype)
+        got = _run(dev, src, r, 1, r, 1)
+        want = oracle.boxblur(src, r, 1, r, 1)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, r, shape)
+
+
+RT_CASES = [(23, 1, 23, 1), (40, 1, 40, 1), (4, 1, 9, 1), (9, 1, 4, 1), (5, 3, 5, 3), (5, 1, 5, 2), (5, 2, 5, 1), (0, 0, 7, 1), (7, 1, 0, 0), (6, 2, 3, 3)]
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float16])
+@pytest.mark.parametrize("case", RT_CASES, ids=[f"h{c[0]}x{c[1]}_v{c[2]}x{c[3]}" for c in RT_CASES])
+def test_rt_matches_oracle(dev, oracle, dtype, case):
+    for shape in [(120, 200), (97, 131)]:
+        src = fx.splitmix64_plane(70, shape, dtype)
+        got = _run(dev, src, *case)
+        want = oracle.boxblur(src, *case)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, case, shape)
+
+
+def test_rt_reference_golden_rgbs(dev):
+    """RGBS|full|hpasses=2,hradius=6,vpasses=3,vradius=3 and RGBS|full|hradius=2,vradius=2 (reference goldens)."""
+    g = fx.ref_goldens()["exact"]["boxblur"]
+    for key, args in (("RGBS|full|hpasses=2,hradius=6,vpasses=3,vradius=3", (6, 2, 3, 3)), ("RGBS|full|hradius=2,vradius=2", (2, 1, 2, 1))):
+        for p in range(3):
+            st = fx.plane_stats(_run(dev, np.ascontiguousarray(fx.crop_rgbs()[p]), *args))
+            for k in ("avg", "min", "max"):
+                assert st[k] == pytest.approx(g[key][f"p{p}"][k], rel=1e-6, abs=1e-9)

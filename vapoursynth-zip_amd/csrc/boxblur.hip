@@ -9,6 +9,9 @@ int vszip_bb_ct_u8_c(vszip_ctx *, int, const vszip_plane *, int);
 int vszip_bb_ct_u16_a(vszip_ctx *, int, const vszip_plane *, int);
 int vszip_bb_ct_u16_b(vszip_ctx *, int, const vszip_plane *, int);
 int vszip_bb_ct_u16_c(vszip_ctx *, int, const vszip_plane *, int);
+// boxblur_rt.hip
+int vszip_bb_rt(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses);
+int vszip_bb_ct_float(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int radius);
 
 static int ct_int(vszip_ctx *ctx, int dtype, int r, const vszip_plane *planes, int nplanes) {
     if (dtype == VSZIP_U8) return r <= 8 ? vszip_bb_ct_u8_a(ctx, r, planes, nplanes) : r <= 15 ? vszip_bb_ct_u8_b(ctx, r, planes, nplanes) : vszip_bb_ct_u8_c(ctx, r, planes, nplanes);
@@ -37,8 +40,10 @@ VSZIP_EXPORT int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *pla
         switch (dtype) {
             case VSZIP_U8:
             case VSZIP_U16: return ct_int(ctx, dtype, hradius, planes, nplanes);
-            default: return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: CT float path not built yet");
+            case VSZIP_F16:
+            case VSZIP_F32: return vszip_bb_ct_float(ctx, dtype, planes, nplanes, hradius);
+            default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: not supported Int format.");
         }
     }
-    return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: RT path not built yet");
+    return vszip_bb_rt(ctx, dtype, planes, nplanes, hradius, hpasses, vradius, vpasses);
 }

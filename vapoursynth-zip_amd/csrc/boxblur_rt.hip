@@ -1,0 +1,352 @@
+// vszip.BoxBlur — the paths besides the CT integer kernel:
+//   * CT float (f32 / f16): boxblur_comptime.zig:161-263 (vBlurFloat / hBlurFloat): both
+//     axes accumulate `acc + div * tap` over the 2r+1 taps IN TAP ORDER with the asymmetric
+//     mirror of mirrorRows (:50-70). LDS-tiled; unfused f32, so results are bit-identical.
+//   * RT integer (any radius, passes, hradius != vradius): boxblur_runtime.zig:10-41 blurInt,
+//     one launch per pass and axis. The 16.16 running sum has the closed form
+//         dst[x] = (inv2*E_x + 32768 + ((E_0*invlo) >> 16)) >> 16
+//     with E_x the edge-duplicating mirrored window sum. Horizontal: one workgroup per row,
+//     block-wide prefix sum of the row in LDS, E_x as prefix differences. Vertical: one thread
+//     per column walks its rows with a sliding window sum (lanes = columns, coalesced).
+//   * RT float: boxblur_runtime.zig:43-79 blurFloat keeps a RUNNING f32 sum whose rounding
+//     depends on the visiting order, so every row (horizontal) / column (vertical) is walked
+//     sequentially by one thread in exactly the reference's order: bit-identical, at the price
+//     of parallelism = rows (columns) x planes. This path is not on any headline config.
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxPlanesRT = 48;
+
+struct RPlane {
+    const void *src;
+    void *dst;
+    int sstride, dstride, w, h;
+    int block0;
+};
+struct RParams {
+    RPlane p[kMaxPlanesRT];
+    int nplanes;
+    int radius;
+};
+
+__device__ __forceinline__ int rt_find(const RParams &prm, int b) {
+    int pi = 0;
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    return pi;
+}
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T *p) {
+    return (float)*p;
+}
+
+// boxblur_comptime.zig:50-70 — index of tap k for output index i (rows and columns alike)
+__device__ __forceinline__ int ct_tap(int k, int i, int radius, int n) {
+    const int dist_from_end = n - 1 - i;
+    if (k < radius) return (i < radius - k) ? min(radius - k - i, n - 1) : (i - radius + k);
+    return (dist_from_end < k - radius) ? (i - min(k - radius - dist_from_end, i)) : (i - radius + k);
+}
+
+// ---- CT float ---------------------------------------------------------------------------
+constexpr int FTW = 64, FTH = 32, FRMAX = 22;
+constexpr int FIW = FTW + 2 * FRMAX, FIH = FTH + 2 * FRMAX;
+
+struct FParams {
+    RPlane p[kMaxPlanesRT];
+    int nbx[kMaxPlanesRT];
+    int nplanes;
+    int radius;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void boxblur_ct_float_kernel(const FParams prm) {
+    __shared__ float tile[FIH][FIW + 1];
+    __shared__ float vt[FTH][FIW + 1];
+    int pi = 0;
+    const int b = blockIdx.x;
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const RPlane pl = prm.p[pi];
+    const int lb = b - pl.block0;
+    const int R = prm.radius, K = 2 * R + 1;
+    const int w = pl.w, h = pl.h;
+    const int x0 = (lb % prm.nbx[pi]) * FTW, y0 = (lb / prm.nbx[pi]) * FTH;
+    const int cx0 = max(x0 - R, 0), cy0 = max(y0 - R, 0);
+    const int cw = min(x0 + FTW + R, w) - cx0, ch = min(y0 + FTH + R, h) - cy0;
+    const T *src = static_cast<const T *>(pl.src);
+    T *dst = static_cast<T *>(pl.dst);
+    const float div = 1.0f / (float)K;  // :39
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ch * cw; i += 256) {
+        const int r = i / cw, c = i - r * cw;
+        tile[r][c] = (float)src[(size_t)(cy0 + r) * pl.sstride + cx0 + c];
+    }
+    __syncthreads();
+    const int th = min(FTH, h - y0), tw = min(FTW, w - x0);
+    for (int i = tid; i < th * cw; i += 256) {  // vBlurFloat :161-190
+        const int r = i / cw, c = i - r * cw;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = acc + div * tile[ct_tap(k, y0 + r, R, h) - cy0][c];
+        vt[r][c] = (float)(T)acc;  // tmp row is stored as T
+    }
+    __syncthreads();
+    for (int i = tid; i < th * tw; i += 256) {  // hBlurFloat :192-263
+        const int r = i / tw, c = i - r * tw;
+        float sum = 0.0f;
+        for (int k = 0; k < K; ++k) sum += div * vt[r][ct_tap(k, x0 + c, R, w) - cx0];
+        dst[(size_t)(y0 + r) * pl.dstride + x0 + c] = (T)sum;
+    }
+}
+
+// ---- RT integer -----------------------------------------------------------------------------
+// Horizontal: one workgroup per row. LDS holds the inclusive prefix of the row.
+template <typename T>
+__global__ __launch_bounds__(256) void boxblur_rt_hint_kernel(const RParams prm) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t P[];
+    __shared__ uint32_t wsum[4];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int y = b - pl.block0;
+    const int w = pl.w, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
+    const int tid = threadIdx.x;
+    const int per = (w + 255) / 256;
+    const int lo = min(tid * per, w), hi = min(lo + per, w);
+    uint32_t run = 0;
+    for (int x = lo; x < hi; ++x) {
+        run += s[x];
+        P[x] = run;
+    }
+    // block-wide exclusive scan of the 256 chunk totals
+    uint32_t incl = wave_incl_scan_shfl(run);
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (int i = 0; i < (tid >> 6); ++i) base += wsum[i];
+    for (int x = lo; x < hi; ++x) P[x] += base;
+    __syncthreads();
+    const uint32_t ksize = 2u * (uint32_t)R + 1u;
+    const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : P[min(c, w - 1)]; };
+    const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2*sum_{x<r} srcp[x]
+    const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
+    for (int x = tid; x < w; x += 256) {
+        // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
+        uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
+        if (x - R - 1 < -1) e += Q(R - x - 1);
+        if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
+        d[x] = (T)(((uint64_t)e * inv2 + kr) >> 16);
+    }
+}
+
+// Vertical: one thread per column, sliding window down the rows.
+template <typename T>
+__global__ __launch_bounds__(64) void boxblur_rt_vint_kernel(const RParams prm) {
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int x = (b - pl.block0) * 64 + threadIdx.x;
+    if (x >= pl.w) return;
+    const int len = pl.h, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + x;
+    T *d = static_cast<T *>(pl.dst) + x;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    const uint32_t ksize = 2u * (uint32_t)R + 1u;
+    const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    const uint64_t inv2 = inv >> 16;
+    // blurInt verbatim :10-41 (a u64 16.16 running sum is exact, so it IS the closed form)
+    uint64_t sum = s[(size_t)R * ss];
+    for (int i = 0; i < R; ++i) sum += (uint32_t)s[(size_t)i * ss] << 1;
+    sum = (sum * inv + (1ull << 31)) >> 16;
+    int i = 0;
+    for (; i <= R; ++i) {
+        sum += s[(size_t)(R + i) * ss] * inv2;
+        sum -= s[(size_t)(R - i) * ss] * inv2;
+        d[(size_t)i * ds] = (T)(sum >> 16);
+    }
+    for (; i < len - R; ++i) {
+        sum += s[(size_t)(R + i) * ss] * inv2;
+        sum -= s[(size_t)(i - R - 1) * ss] * inv2;
+        d[(size_t)i * ds] = (T)(sum >> 16);
+    }
+    for (; i < len; ++i) {
+        sum += s[(size_t)(2 * len - R - i - 1) * ss] * inv2;
+        sum -= s[(size_t)(i - R - 1) * ss] * inv2;
+        d[(size_t)i * ds] = (T)(sum >> 16);
+    }
+}
+
+// ---- RT float: blurFloat verbatim (:43-79), one thread per line ------------------------------
+template <typename T>
+__device__ __forceinline__ void blur_float_line(const T *s, size_t ss, T *d, size_t ds, int len, int R) {
+    const float ksize = (float)(R * 2 + 1);
+    const float div = 1.0f / ksize;
+    float sum = (float)s[(size_t)R * ss];
+    for (int x = 0; x < R; ++x) sum += (float)s[(size_t)x * ss] * 2;
+    sum = sum * div;
+    int x = 0;
+    for (; x <= R; ++x) {
+        sum += ((float)s[(size_t)(R + x) * ss] - (float)s[(size_t)(R - x) * ss]) * div;
+        d[(size_t)x * ds] = (T)sum;
+    }
+    for (; x < len - R; ++x) {
+        sum += ((float)s[(size_t)(R + x) * ss] - (float)s[(size_t)(x - R - 1) * ss]) * div;
+        d[(size_t)x * ds] = (T)sum;
+    }
+    for (; x < len; ++x) {
+        sum += ((float)s[(size_t)(2 * len - R - x - 1) * ss] - (float)s[(size_t)(x - R - 1) * ss]) * div;
+        d[(size_t)x * ds] = (T)sum;
+    }
+}
+
+template <typename T, bool VERT>
+__global__ __launch_bounds__(64) void boxblur_rt_float_kernel(const RParams prm) {
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int i = (b - pl.block0) * 64 + threadIdx.x;
+    const T *s = static_cast<const T *>(pl.src);
+    T *d = static_cast<T *>(pl.dst);
+    if (VERT) {
+        if (i < pl.w) blur_float_line<T>(s + i, pl.sstride, d + i, pl.dstride, pl.h, prm.radius);
+    } else {
+        if (i < pl.h) blur_float_line<T>(s + (size_t)i * pl.sstride, 1, d + (size_t)i * pl.dstride, 1, pl.w, prm.radius);
+    }
+}
+
+template <typename T>
+int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool vertical) {
+    constexpr bool is_int = std::is_integral<T>::value;
+    size_t done = 0;
+    while (done < pl.size()) {
+        RParams prm;
+        const int n = (int)std::min<size_t>(kMaxPlanesRT, pl.size() - done);
+        prm.nplanes = n;
+        prm.radius = radius;
+        int blocks = 0, maxw = 0;
+        for (int i = 0; i < n; ++i) {
+            prm.p[i] = pl[done + i];
+            prm.p[i].block0 = blocks;
+            if (is_int && !vertical)
+                blocks += prm.p[i].h;
+            else
+                blocks += ((vertical ? prm.p[i].w : prm.p[i].h) + 63) / 64;
+            maxw = std::max(maxw, prm.p[i].w);
+        }
+        if constexpr (is_int) {
+            if (!vertical)
+                hipLaunchKernelGGL((boxblur_rt_hint_kernel<T>), dim3(blocks), dim3(256), (size_t)maxw * sizeof(uint32_t), ctx->stream, prm);
+            else
+                hipLaunchKernelGGL((boxblur_rt_vint_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+        } else {
+            if (vertical)
+                hipLaunchKernelGGL((boxblur_rt_float_kernel<T, true>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+            else
+                hipLaunchKernelGGL((boxblur_rt_float_kernel<T, false>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+        }
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
+}
+
+template <typename T>
+int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses) {
+    // boxblur.zig:85-112: hpasses horizontal passes, then vpasses vertical passes
+    const bool hb = hradius > 0 && hpasses > 0, vb = vradius > 0 && vpasses > 0;
+    const int total = (hb ? hpasses : 0) + (vb ? vpasses : 0);
+    size_t elems = 0;
+    std::vector<size_t> off(nplanes);
+    for (int i = 0; i < nplanes; ++i) {
+        off[i] = elems;
+        elems += (size_t)((planes[i].w + 63) & ~63) * planes[i].h;
+        if (std::is_integral<T>::value && hb && (size_t)planes[i].w * sizeof(uint32_t) > 60000)
+            return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: rows longer than 15000 samples not built yet on the RT integer path");
+    }
+    T *scratch[2] = {nullptr, nullptr};
+    if (total > 1) {
+        int rc = vszip_ensure_scratch(ctx, 2 * elems * sizeof(T) + 256);
+        if (rc != VSZIP_OK) return rc;
+        scratch[0] = static_cast<T *>(ctx->scratch);
+        scratch[1] = scratch[0] + elems;
+    }
+    std::vector<RPlane> cur(nplanes);
+    for (int i = 0; i < nplanes; ++i) {
+        cur[i].src = planes[i].src;
+        cur[i].sstride = (int)planes[i].src_stride;
+        cur[i].w = planes[i].w;
+        cur[i].h = planes[i].h;
+    }
+    int which = 0;
+    for (int p = 0; p < total; ++p) {
+        const bool vertical = p >= (hb ? hpasses : 0);
+        const bool last = p == total - 1;
+        for (int i = 0; i < nplanes; ++i) {
+            if (last) {
+                cur[i].dst = planes[i].dst;
+                cur[i].dstride = (int)planes[i].dst_stride;
+            } else {
+                cur[i].dst = scratch[which] + off[i];
+                cur[i].dstride = (planes[i].w + 63) & ~63;
+            }
+        }
+        int rc = launch_pass<T>(ctx, cur, vertical ? vradius : hradius, vertical);
+        if (rc != VSZIP_OK) return rc;
+        for (int i = 0; i < nplanes; ++i) {
+            cur[i].src = cur[i].dst;
+            cur[i].sstride = cur[i].dstride;
+        }
+        which ^= 1;
+    }
+    return VSZIP_OK;
+}
+
+template <typename T>
+int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int radius) {
+    int done = 0;
+    while (done < nplanes) {
+        FParams prm;
+        const int n = std::min(kMaxPlanesRT, nplanes - done);
+        prm.nplanes = n;
+        prm.radius = radius;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const vszip_plane &s = planes[done + i];
+            RPlane &d = prm.p[i];
+            d.src = s.src;
+            d.dst = s.dst;
+            d.sstride = (int)s.src_stride;
+            d.dstride = (int)s.dst_stride;
+            d.w = s.w;
+            d.h = s.h;
+            d.block0 = blocks;
+            prm.nbx[i] = (s.w + FTW - 1) / FTW;
+            blocks += prm.nbx[i] * ((s.h + FTH - 1) / FTH);
+        }
+        hipLaunchKernelGGL((boxblur_ct_float_kernel<T>), dim3(blocks), dim3(256), 0, ctx->stream, prm);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
+}
+
+}  // namespace
+
+int vszip_bb_rt(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses) {
+    switch (dtype) {
+        case VSZIP_U8: return run_rt<uint8_t>(ctx, planes, nplanes, hradius, hpasses, vradius, vpasses);
+        case VSZIP_U16: return run_rt<uint16_t>(ctx, planes, nplanes, hradius, hpasses, vradius, vpasses);
+        case VSZIP_F16: return run_rt<_Float16>(ctx, planes, nplanes, hradius, hpasses, vradius, vpasses);
+        case VSZIP_F32: return run_rt<float>(ctx, planes, nplanes, hradius, hpasses, vradius, vpasses);
+    }
+    return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: not supported Int format.");
+}
+
+int vszip_bb_ct_float(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int radius) {
+    if (dtype == VSZIP_F16) return run_ct_float<_Float16>(ctx, planes, nplanes, radius);
+    return run_ct_float<float>(ctx, planes, nplanes, radius);
+}
