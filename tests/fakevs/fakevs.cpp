@@ -1,0 +1,684 @@
+// A small VapourSynth-API-v4 host for tests: enough of VSAPI / VSPLUGINAPI to load
+// libvszip.so, build clips from caller-supplied planes, invoke plugin functions with an
+// argument map, and pull frames through the filter's getFrame state machine (arInitial ->
+// requested frames resolved recursively -> arAllFramesReady). No VapourSynth exists in the
+// build image or on the GPU box; this is what exercises the plugin boundary there.
+// It is built against the same VapourSynth4_min.h as the plugin (see that header's note).
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../vapoursynth-zip_amd/plugin/VapourSynth4_min.h"
+
+struct Prop {
+    int type = ptUnset;
+    std::vector<int64_t> i;
+    std::vector<double> f;
+    std::vector<std::string> d;
+    std::vector<VSNode *> nodes;
+};
+struct VSMap {
+    std::vector<std::pair<std::string, Prop>> items;
+    std::string error;
+    bool has_error = false;
+    Prop *find(const char *k) {
+        for (auto &kv : items)
+            if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+    const Prop *find(const char *k) const { return const_cast<VSMap *>(this)->find(k); }
+    Prop &get(const char *k) {
+        if (Prop *p = find(k)) return *p;
+        items.emplace_back(k, Prop());
+        return items.back().second;
+    }
+};
+struct PlaneBuf {
+    uint8_t *base = nullptr;
+    ~PlaneBuf() { free(base); }
+};
+struct VSFrame {
+    int refs = 1;
+    VSVideoFormat fmt;
+    int w, h;
+    std::shared_ptr<PlaneBuf> buf[3];
+    uint8_t *ptr[3] = {nullptr, nullptr, nullptr};
+    ptrdiff_t stride[3] = {0, 0, 0};
+    VSMap props;
+};
+struct VSNode {
+    int refs = 1;
+    VSVideoInfo vi;
+    std::vector<VSFrame *> frames;  // source node
+    std::string name;
+    VSFilterGetFrame getFrame = nullptr;
+    VSFilterFree freeFn = nullptr;
+    void *inst = nullptr;
+    std::vector<VSNode *> deps;
+};
+struct VSFrameContext {
+    std::vector<std::pair<VSNode *, int>> requests;
+    std::map<std::pair<VSNode *, int>, const VSFrame *> ready;
+    std::string error;
+    bool has_error = false;
+};
+struct Func {
+    std::string args, ret;
+    VSPublicFunction fn;
+    void *data;
+};
+struct VSPlugin {
+    std::string id, ns, name;
+    int version = 0;
+    std::map<std::string, Func> funcs;
+    void *dl = nullptr;
+};
+struct VSCore {
+    std::vector<std::unique_ptr<VSPlugin>> plugins;
+    int frame_alignment = 32;
+};
+
+static VSCore g_core;
+static const VSAPI *api();
+
+static void node_unref(VSNode *n);
+static void map_clear(VSMap *m) {
+    for (auto &kv : m->items)
+        for (VSNode *n : kv.second.nodes) node_unref(n);
+    m->items.clear();
+    m->error.clear();
+    m->has_error = false;
+}
+
+// ---- frames -----------------------------------------------------------------
+static int plane_w(const VSVideoFormat &f, int w, int p) { return p ? w >> f.subSamplingW : w; }
+static int plane_h(const VSVideoFormat &f, int h, int p) { return p ? h >> f.subSamplingH : h; }
+
+static VSFrame *frame_new(const VSVideoFormat *fmt, int w, int h, int extra_stride = 0, int offset = 0) {
+    VSFrame *f = new VSFrame();
+    f->fmt = *fmt;
+    f->w = w;
+    f->h = h;
+    const int al = g_core.frame_alignment;
+    for (int p = 0; p < fmt->numPlanes; ++p) {
+        const int pw = plane_w(*fmt, w, p), ph = plane_h(*fmt, h, p);
+        ptrdiff_t st = ((ptrdiff_t)pw * fmt->bytesPerSample + al - 1) / al * al + extra_stride;
+        f->buf[p] = std::make_shared<PlaneBuf>();
+        void *mem = nullptr;
+        if (posix_memalign(&mem, 64, (size_t)st * ph + offset + 64)) abort();
+        memset(mem, 0xA5, (size_t)st * ph + offset + 64);
+        f->buf[p]->base = static_cast<uint8_t *>(mem);
+        f->ptr[p] = f->buf[p]->base + offset;
+        f->stride[p] = st;
+    }
+    return f;
+}
+static void frame_unref(const VSFrame *cf) {
+    VSFrame *f = const_cast<VSFrame *>(cf);
+    if (f && --f->refs == 0) {
+        map_clear(&f->props);
+        delete f;
+    }
+}
+static void map_copy(const VSMap *s, VSMap *d) {
+    for (auto &kv : s->items) {
+        Prop &p = d->get(kv.first.c_str());
+        for (VSNode *n : p.nodes) node_unref(n);
+        p = kv.second;
+        for (VSNode *n : p.nodes) n->refs++;
+    }
+}
+
+// ---- nodes ------------------------------------------------------------------
+static void node_unref(VSNode *n) {
+    if (!n || --n->refs > 0) return;
+    if (n->freeFn) n->freeFn(n->inst, &g_core, api());
+    for (VSFrame *f : n->frames) frame_unref(f);
+    delete n;
+}
+
+static const VSFrame *node_get_frame(VSNode *node, int n, std::string *err) {
+    if (n < 0) n = 0;
+    if (!node->getFrame) {
+        VSFrame *f = node->frames[std::min<size_t>(n, node->frames.size() - 1)];
+        f->refs++;
+        return f;
+    }
+    if (n >= node->vi.numFrames) n = node->vi.numFrames - 1;
+    VSFrameContext ctx;
+    void *frameData = nullptr;
+    const VSFrame *r = node->getFrame(n, arInitial, node->inst, &frameData, &ctx, &g_core, api());
+    if (!r && !ctx.has_error) {
+        for (size_t i = 0; i < ctx.requests.size(); ++i) {  // getFrame may not append while we iterate: copy
+            auto rq = ctx.requests[i];
+            if (ctx.ready.count(rq)) continue;
+            const VSFrame *f = node_get_frame(rq.first, rq.second, err);
+            if (!f) {
+                for (auto &kv : ctx.ready) frame_unref(kv.second);
+                return nullptr;
+            }
+            ctx.ready[rq] = f;
+        }
+        r = node->getFrame(n, arAllFramesReady, node->inst, &frameData, &ctx, &g_core, api());
+    }
+    for (auto &kv : ctx.ready) frame_unref(kv.second);
+    if (!r) *err = ctx.has_error ? ctx.error : (node->name + ": filter returned no frame");
+    return r;
+}
+
+// ---- VSAPI implementation ---------------------------------------------------------
+#define A(name) api_##name
+static void VS_CC A(createVideoFilter)(VSMap *out, const char *name, const VSVideoInfo *vi, VSFilterGetFrame gf, VSFilterFree fr, int, const VSFilterDependency *deps, int nd,
+                                       void *inst, VSCore *) {
+    VSNode *n = new VSNode();
+    n->vi = *vi;
+    n->name = name;
+    n->getFrame = gf;
+    n->freeFn = fr;
+    n->inst = inst;
+    for (int i = 0; i < nd; ++i) n->deps.push_back(deps[i].source);
+    Prop &p = out->get("clip");
+    p.type = ptVideoNode;
+    p.nodes.push_back(n);
+}
+static void VS_CC A(freeNode)(VSNode *n) { node_unref(n); }
+static VSNode *VS_CC A(addNodeRef)(VSNode *n) {
+    n->refs++;
+    return n;
+}
+static int VS_CC A(getNodeType)(VSNode *) { return mtVideo; }
+static const VSVideoInfo *VS_CC A(getVideoInfo)(VSNode *n) { return &n->vi; }
+static VSFrame *VS_CC A(newVideoFrame)(const VSVideoFormat *fmt, int w, int h, const VSFrame *propSrc, VSCore *) {
+    VSFrame *f = frame_new(fmt, w, h);
+    if (propSrc) map_copy(&propSrc->props, &f->props);
+    return f;
+}
+static VSFrame *VS_CC A(newVideoFrame2)(const VSVideoFormat *fmt, int w, int h, const VSFrame **planeSrc, const int *planes, const VSFrame *propSrc, VSCore *) {
+    VSFrame *f = frame_new(fmt, w, h);
+    if (propSrc) map_copy(&propSrc->props, &f->props);
+    for (int p = 0; p < fmt->numPlanes; ++p) {
+        if (planeSrc && planeSrc[p]) {  // the real core shares the plane; a copy is observably the same
+            const VSFrame *s = planeSrc[p];
+            const int sp = planes ? planes[p] : p;
+            const int pw = plane_w(*fmt, w, p) * fmt->bytesPerSample, ph = plane_h(*fmt, h, p);
+            for (int y = 0; y < ph; ++y) memcpy(f->ptr[p] + (size_t)y * f->stride[p], s->ptr[sp] + (size_t)y * s->stride[sp], pw);
+        }
+    }
+    return f;
+}
+static void VS_CC A(freeFrame)(const VSFrame *f) { frame_unref(f); }
+static const VSFrame *VS_CC A(addFrameRef)(const VSFrame *f) {
+    const_cast<VSFrame *>(f)->refs++;
+    return f;
+}
+static VSFrame *VS_CC A(copyFrame)(const VSFrame *s, VSCore *) {
+    VSFrame *f = frame_new(&s->fmt, s->w, s->h);
+    map_copy(&s->props, &f->props);
+    for (int p = 0; p < s->fmt.numPlanes; ++p) {
+        const int pw = plane_w(s->fmt, s->w, p) * s->fmt.bytesPerSample, ph = plane_h(s->fmt, s->h, p);
+        for (int y = 0; y < ph; ++y) memcpy(f->ptr[p] + (size_t)y * f->stride[p], s->ptr[p] + (size_t)y * s->stride[p], pw);
+    }
+    return f;
+}
+static const VSMap *VS_CC A(getFramePropertiesRO)(const VSFrame *f) { return &f->props; }
+static VSMap *VS_CC A(getFramePropertiesRW)(VSFrame *f) { return &f->props; }
+static ptrdiff_t VS_CC A(getStride)(const VSFrame *f, int p) { return f->stride[p]; }
+static const uint8_t *VS_CC A(getReadPtr)(const VSFrame *f, int p) { return f->ptr[p]; }
+static uint8_t *VS_CC A(getWritePtr)(VSFrame *f, int p) { return f->ptr[p]; }
+static const VSVideoFormat *VS_CC A(getVideoFrameFormat)(const VSFrame *f) { return &f->fmt; }
+static int VS_CC A(getFrameType)(const VSFrame *) { return mtVideo; }
+static int VS_CC A(getFrameWidth)(const VSFrame *f, int p) { return plane_w(f->fmt, f->w, p); }
+static int VS_CC A(getFrameHeight)(const VSFrame *f, int p) { return plane_h(f->fmt, f->h, p); }
+static int VS_CC A(queryVideoFormat)(VSVideoFormat *f, int cf, int st, int bits, int ssw, int ssh, VSCore *) {
+    f->colorFamily = cf;
+    f->sampleType = st;
+    f->bitsPerSample = bits;
+    f->bytesPerSample = bits <= 8 ? 1 : (bits <= 16 ? 2 : 4);
+    f->subSamplingW = ssw;
+    f->subSamplingH = ssh;
+    f->numPlanes = cf == cfGray ? 1 : 3;
+    return 1;
+}
+static uint32_t VS_CC A(queryVideoFormatID)(int cf, int st, int bits, int ssw, int ssh, VSCore *) { return (uint32_t)VS_MAKE_VIDEO_ID(cf, st, bits, ssw, ssh); }
+static int VS_CC A(getVideoFormatByID)(VSVideoFormat *f, uint32_t id, VSCore *c) {
+    return A(queryVideoFormat)(f, (id >> 28) & 0xF, (id >> 24) & 0xF, (id >> 16) & 0xFF, (id >> 8) & 0xFF, id & 0xFF, c);
+}
+static const VSFrame *VS_CC A(getFrame)(int n, VSNode *node, char *errorMsg, int bufSize) {
+    std::string err;
+    const VSFrame *f = node_get_frame(node, n, &err);
+    if (!f && errorMsg && bufSize > 0) snprintf(errorMsg, bufSize, "%s", err.c_str());
+    return f;
+}
+static const VSFrame *VS_CC A(getFrameFilter)(int n, VSNode *node, VSFrameContext *ctx) {
+    if (n < 0) n = 0;
+    if (n >= node->vi.numFrames) n = node->vi.numFrames - 1;
+    auto it = ctx->ready.find({node, n});
+    if (it == ctx->ready.end()) return nullptr;
+    const_cast<VSFrame *>(it->second)->refs++;
+    return it->second;
+}
+static void VS_CC A(requestFrameFilter)(int n, VSNode *node, VSFrameContext *ctx) {
+    if (n < 0) n = 0;
+    if (n >= node->vi.numFrames) n = node->vi.numFrames - 1;
+    ctx->requests.push_back({node, n});
+}
+static void VS_CC A(setFilterError)(const char *msg, VSFrameContext *ctx) {
+    ctx->error = msg;
+    ctx->has_error = true;
+}
+static VSMap *VS_CC A(createMap)(void) { return new VSMap(); }
+static void VS_CC A(freeMap)(VSMap *m) {
+    if (m) {
+        map_clear(m);
+        delete m;
+    }
+}
+static void VS_CC A(clearMap)(VSMap *m) { map_clear(m); }
+static void VS_CC A(copyMap)(const VSMap *s, VSMap *d) { map_copy(s, d); }
+static void VS_CC A(mapSetError)(VSMap *m, const char *e) {
+    map_clear(m);
+    m->error = e ? e : "Error: no error specified";
+    m->has_error = true;
+}
+static const char *VS_CC A(mapGetError)(const VSMap *m) { return m->has_error ? m->error.c_str() : nullptr; }
+static int VS_CC A(mapNumKeys)(const VSMap *m) { return (int)m->items.size(); }
+static const char *VS_CC A(mapGetKey)(const VSMap *m, int i) { return m->items[i].first.c_str(); }
+static int VS_CC A(mapDeleteKey)(VSMap *m, const char *k) {
+    for (size_t i = 0; i < m->items.size(); ++i)
+        if (m->items[i].first == k) {
+            for (VSNode *n : m->items[i].second.nodes) node_unref(n);
+            m->items.erase(m->items.begin() + i);
+            return 1;
+        }
+    return 0;
+}
+static int prop_count(const Prop *p) {
+    if (!p) return -1;
+    switch (p->type) {
+        case ptInt: return (int)p->i.size();
+        case ptFloat: return (int)p->f.size();
+        case ptData: return (int)p->d.size();
+        case ptVideoNode: return (int)p->nodes.size();
+        default: return 0;
+    }
+}
+static int VS_CC A(mapNumElements)(const VSMap *m, const char *k) { return prop_count(m->find(k)); }
+static int VS_CC A(mapGetType)(const VSMap *m, const char *k) {
+    const Prop *p = m->find(k);
+    return p ? p->type : ptUnset;
+}
+template <typename V>
+static bool fetch(const VSMap *m, const char *k, int idx, int type, const std::vector<V> Prop::*vec, V *out, int *error) {
+    const Prop *p = m->find(k);
+    int e = peSuccess;
+    if (!p)
+        e = peUnset;
+    else if (p->type != type)
+        e = peType;
+    else if (idx < 0 || idx >= (int)(p->*vec).size())
+        e = peIndex;
+    if (error) *error = e;
+    if (e != peSuccess) return false;
+    *out = (p->*vec)[idx];
+    return true;
+}
+static int64_t VS_CC A(mapGetInt)(const VSMap *m, const char *k, int idx, int *err) {
+    int64_t v = 0;
+    fetch<int64_t>(m, k, idx, ptInt, &Prop::i, &v, err);
+    return v;
+}
+static const int64_t *VS_CC A(mapGetIntArray)(const VSMap *m, const char *k, int *err) {
+    const Prop *p = m->find(k);
+    if (!p || p->type != ptInt) {
+        if (err) *err = p ? peType : peUnset;
+        return nullptr;
+    }
+    if (err) *err = peSuccess;
+    return p->i.data();
+}
+static int VS_CC A(mapSetInt)(VSMap *m, const char *k, int64_t v, int append) {
+    Prop &p = m->get(k);
+    if (append == maReplace || p.type != ptInt) {
+        p = Prop();
+        p.type = ptInt;
+    }
+    p.i.push_back(v);
+    return 0;
+}
+static double VS_CC A(mapGetFloat)(const VSMap *m, const char *k, int idx, int *err) {
+    double v = 0;
+    fetch<double>(m, k, idx, ptFloat, &Prop::f, &v, err);
+    return v;
+}
+static const double *VS_CC A(mapGetFloatArray)(const VSMap *m, const char *k, int *err) {
+    const Prop *p = m->find(k);
+    if (!p || p->type != ptFloat) {
+        if (err) *err = p ? peType : peUnset;
+        return nullptr;
+    }
+    if (err) *err = peSuccess;
+    return p->f.data();
+}
+static int VS_CC A(mapSetFloat)(VSMap *m, const char *k, double v, int append) {
+    Prop &p = m->get(k);
+    if (append == maReplace || p.type != ptFloat) {
+        p = Prop();
+        p.type = ptFloat;
+    }
+    p.f.push_back(v);
+    return 0;
+}
+static const char *VS_CC A(mapGetData)(const VSMap *m, const char *k, int idx, int *err) {
+    const Prop *p = m->find(k);
+    int e = !p ? peUnset : (p->type != ptData ? peType : ((idx < 0 || idx >= (int)p->d.size()) ? peIndex : peSuccess));
+    if (err) *err = e;
+    return e == peSuccess ? p->d[idx].c_str() : nullptr;
+}
+static int VS_CC A(mapGetDataSize)(const VSMap *m, const char *k, int idx, int *err) {
+    const char *s = A(mapGetData)(m, k, idx, err);
+    return s ? (int)m->find(k)->d[idx].size() : 0;
+}
+static int VS_CC A(mapSetData)(VSMap *m, const char *k, const char *data, int size, int, int append) {
+    Prop &p = m->get(k);
+    if (append == maReplace || p.type != ptData) {
+        p = Prop();
+        p.type = ptData;
+    }
+    p.d.emplace_back(size < 0 ? std::string(data) : std::string(data, size));
+    return 0;
+}
+static VSNode *VS_CC A(mapGetNode)(const VSMap *m, const char *k, int idx, int *err) {
+    const Prop *p = m->find(k);
+    int e = !p ? peUnset : (p->type != ptVideoNode ? peType : ((idx < 0 || idx >= (int)p->nodes.size()) ? peIndex : peSuccess));
+    if (err) *err = e;
+    if (e != peSuccess) return nullptr;
+    p->nodes[idx]->refs++;
+    return p->nodes[idx];
+}
+static int VS_CC A(mapSetNode)(VSMap *m, const char *k, VSNode *n, int append) {
+    Prop &p = m->get(k);
+    if (append == maReplace || p.type != ptVideoNode) {
+        for (VSNode *o : p.nodes) node_unref(o);
+        p = Prop();
+        p.type = ptVideoNode;
+    }
+    n->refs++;
+    p.nodes.push_back(n);
+    return 0;
+}
+static int VS_CC A(mapConsumeNode)(VSMap *m, const char *k, VSNode *n, int append) {
+    A(mapSetNode)(m, k, n, append);
+    node_unref(n);
+    return 0;
+}
+static VSPlugin *VS_CC A(getPluginByID)(const char *id, VSCore *c) {
+    for (auto &p : c->plugins)
+        if (p->id == id) return p.get();
+    return nullptr;
+}
+static VSPlugin *VS_CC A(getPluginByNamespace)(const char *ns, VSCore *c) {
+    for (auto &p : c->plugins)
+        if (p->ns == ns) return p.get();
+    return nullptr;
+}
+
+// Argument check the way the core does it before calling the function: required
+// arguments present, no unknown arguments, element kinds match the signature.
+static bool check_args(const std::string &fname, const std::string &sig, const VSMap *args, VSMap *out) {
+    std::vector<std::string> known;
+    size_t pos = 0;
+    while (pos < sig.size()) {
+        size_t end = sig.find(';', pos);
+        if (end == std::string::npos) end = sig.size();
+        const std::string item = sig.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        std::vector<std::string> parts;
+        size_t q = 0;
+        while (true) {
+            size_t c = item.find(':', q);
+            parts.push_back(item.substr(q, c == std::string::npos ? std::string::npos : c - q));
+            if (c == std::string::npos) break;
+            q = c + 1;
+        }
+        const std::string &key = parts[0];
+        std::string type = parts.size() > 1 ? parts[1] : "";
+        bool opt = false;
+        for (size_t i = 2; i < parts.size(); ++i) opt = opt || parts[i] == "opt";
+        const bool arr = type.size() > 2 && type.substr(type.size() - 2) == "[]";
+        if (arr) type = type.substr(0, type.size() - 2);
+        known.push_back(key);
+        const Prop *p = args->find(key.c_str());
+        if (!p) {
+            if (!opt) {
+                A(mapSetError)(out, (fname + ": argument " + key + " is required").c_str());
+                return false;
+            }
+            continue;
+        }
+        const int want = type == "int" ? ptInt : type == "float" ? ptFloat : type == "data" ? ptData : ptVideoNode;
+        if (p->type != want && !(want == ptFloat && p->type == ptInt)) {
+            A(mapSetError)(out, (fname + ": argument " + key + " is not of the correct type").c_str());
+            return false;
+        }
+        if (!arr && prop_count(p) > 1) {
+            A(mapSetError)(out, (fname + ": argument " + key + " is not of array type but more than one value was supplied").c_str());
+            return false;
+        }
+    }
+    for (auto &kv : args->items) {
+        bool ok = false;
+        for (auto &k : known) ok = ok || k == kv.first;
+        if (!ok) {
+            A(mapSetError)(out, (fname + ": no argument named " + kv.first).c_str());
+            return false;
+        }
+    }
+    return true;
+}
+
+static VSMap *VS_CC A(invoke)(VSPlugin *plugin, const char *name, const VSMap *args) {
+    VSMap *out = new VSMap();
+    auto it = plugin->funcs.find(name);
+    if (it == plugin->funcs.end()) {
+        A(mapSetError)(out, (std::string("Function '") + name + "' not found in " + plugin->ns).c_str());
+        return out;
+    }
+    if (!check_args(name, it->second.args, args, out)) return out;
+    // ints given for float arguments are converted, like the core does
+    VSMap conv;
+    map_copy(args, &conv);
+    const std::string &sig = it->second.args;
+    for (auto &kv : conv.items) {
+        if (kv.second.type == ptInt && sig.find(kv.first + ":float") != std::string::npos) {
+            kv.second.type = ptFloat;
+            for (int64_t v : kv.second.i) kv.second.f.push_back((double)v);
+            kv.second.i.clear();
+        }
+    }
+    it->second.fn(&conv, out, it->second.data, &g_core, api());
+    map_clear(&conv);
+    return out;
+}
+static int VS_CC A(getAPIVersion)(void) { return VAPOURSYNTH_API_VERSION; }
+static void VS_CC A(logMessage)(int, const char *msg, VSCore *) { fprintf(stderr, "[fakevs] %s\n", msg); }
+
+static const VSAPI *api() {
+    static VSAPI a;
+    static bool init = false;
+    if (!init) {
+        memset(&a, 0, sizeof a);  // anything the plugin does not use stays NULL and crashes loudly
+        a.createVideoFilter = A(createVideoFilter);
+        a.freeNode = A(freeNode);
+        a.addNodeRef = A(addNodeRef);
+        a.getNodeType = A(getNodeType);
+        a.getVideoInfo = A(getVideoInfo);
+        a.newVideoFrame = A(newVideoFrame);
+        a.newVideoFrame2 = A(newVideoFrame2);
+        a.freeFrame = A(freeFrame);
+        a.addFrameRef = A(addFrameRef);
+        a.copyFrame = A(copyFrame);
+        a.getFramePropertiesRO = A(getFramePropertiesRO);
+        a.getFramePropertiesRW = A(getFramePropertiesRW);
+        a.getStride = A(getStride);
+        a.getReadPtr = A(getReadPtr);
+        a.getWritePtr = A(getWritePtr);
+        a.getVideoFrameFormat = A(getVideoFrameFormat);
+        a.getFrameType = A(getFrameType);
+        a.getFrameWidth = A(getFrameWidth);
+        a.getFrameHeight = A(getFrameHeight);
+        a.queryVideoFormat = A(queryVideoFormat);
+        a.queryVideoFormatID = A(queryVideoFormatID);
+        a.getVideoFormatByID = A(getVideoFormatByID);
+        a.getFrame = A(getFrame);
+        a.getFrameFilter = A(getFrameFilter);
+        a.requestFrameFilter = A(requestFrameFilter);
+        a.setFilterError = A(setFilterError);
+        a.createMap = A(createMap);
+        a.freeMap = A(freeMap);
+        a.clearMap = A(clearMap);
+        a.copyMap = A(copyMap);
+        a.mapSetError = A(mapSetError);
+        a.mapGetError = A(mapGetError);
+        a.mapNumKeys = A(mapNumKeys);
+        a.mapGetKey = A(mapGetKey);
+        a.mapDeleteKey = A(mapDeleteKey);
+        a.mapNumElements = A(mapNumElements);
+        a.mapGetType = A(mapGetType);
+        a.mapGetInt = A(mapGetInt);
+        a.mapGetIntArray = A(mapGetIntArray);
+        a.mapSetInt = A(mapSetInt);
+        a.mapGetFloat = A(mapGetFloat);
+        a.mapGetFloatArray = A(mapGetFloatArray);
+        a.mapSetFloat = A(mapSetFloat);
+        a.mapGetData = A(mapGetData);
+        a.mapGetDataSize = A(mapGetDataSize);
+        a.mapSetData = A(mapSetData);
+        a.mapGetNode = A(mapGetNode);
+        a.mapSetNode = A(mapSetNode);
+        a.mapConsumeNode = A(mapConsumeNode);
+        a.getPluginByID = A(getPluginByID);
+        a.getPluginByNamespace = A(getPluginByNamespace);
+        a.invoke = A(invoke);
+        a.getAPIVersion = A(getAPIVersion);
+        a.logMessage = A(logMessage);
+        init = true;
+    }
+    return &a;
+}
+
+// ---- VSPLUGINAPI ---------------------------------------------------------------------
+static int VS_CC papi_getAPIVersion(void) { return VAPOURSYNTH_API_VERSION; }
+static int VS_CC papi_configPlugin(const char *id, const char *ns, const char *name, int version, int, int, VSPlugin *p) {
+    p->id = id;
+    p->ns = ns;
+    p->name = name;
+    p->version = version;
+    return 1;
+}
+static int VS_CC papi_registerFunction(const char *name, const char *args, const char *ret, VSPublicFunction fn, void *data, VSPlugin *p) {
+    p->funcs[name] = Func{args, ret, fn, data};
+    return 1;
+}
+
+// ---- C driver API for the Python test harness ----------------------------------------------
+#define DRV extern "C" __attribute__((visibility("default")))
+
+DRV int fakevs_load_plugin(const char *path, char *err, int errlen) {
+    void *dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) {
+        snprintf(err, errlen, "%s", dlerror());
+        return -1;
+    }
+    auto init = reinterpret_cast<VSInitPlugin>(dlsym(dl, "VapourSynthPluginInit2"));
+    if (!init) {
+        snprintf(err, errlen, "VapourSynthPluginInit2 not exported");
+        return -2;
+    }
+    static const VSPLUGINAPI papi = {papi_getAPIVersion, papi_configPlugin, papi_registerFunction};
+    auto p = std::make_unique<VSPlugin>();
+    p->dl = dl;
+    init(p.get(), &papi);
+    g_core.plugins.push_back(std::move(p));
+    return 0;
+}
+DRV void fakevs_set_alignment(int bytes) { g_core.frame_alignment = bytes; }
+DRV int fakevs_plugin_info(const char *ns, char *id, int idlen, int *version, int *nfuncs) {
+    VSPlugin *p = A(getPluginByNamespace)(ns, &g_core);
+    if (!p) return -1;
+    snprintf(id, idlen, "%s", p->id.c_str());
+    *version = p->version;
+    *nfuncs = (int)p->funcs.size();
+    return 0;
+}
+DRV const char *fakevs_function_args(const char *ns, const char *fn) {
+    VSPlugin *p = A(getPluginByNamespace)(ns, &g_core);
+    if (!p || !p->funcs.count(fn)) return nullptr;
+    return p->funcs[fn].args.c_str();
+}
+DRV VSNode *fakevs_source(uint32_t format_id, int w, int h, int nframes, int64_t fps_num, int64_t fps_den, int extra_stride, int offset) {
+    VSNode *n = new VSNode();
+    A(getVideoFormatByID)(&n->vi.format, format_id, &g_core);
+    n->vi.width = w;
+    n->vi.height = h;
+    n->vi.numFrames = nframes;
+    n->vi.fpsNum = fps_num;
+    n->vi.fpsDen = fps_den;
+    n->name = "Source";
+    for (int i = 0; i < nframes; ++i) n->frames.push_back(frame_new(&n->vi.format, w, h, extra_stride, offset));
+    return n;
+}
+DRV VSFrame *fakevs_source_frame(VSNode *n, int i) { return n->frames[i]; }
+DRV void fakevs_node_free(VSNode *n) { node_unref(n); }
+DRV void fakevs_node_info(VSNode *n, int *w, int *h, int *nframes, uint32_t *fmt, int64_t *fpsn, int64_t *fpsd) {
+    *w = n->vi.width;
+    *h = n->vi.height;
+    *nframes = n->vi.numFrames;
+    const VSVideoFormat &f = n->vi.format;
+    *fmt = (uint32_t)VS_MAKE_VIDEO_ID(f.colorFamily, f.sampleType, f.bitsPerSample, f.subSamplingW, f.subSamplingH);
+    *fpsn = n->vi.fpsNum;
+    *fpsd = n->vi.fpsDen;
+}
+DRV VSMap *fakevs_map_new() { return new VSMap(); }
+DRV void fakevs_map_free(VSMap *m) { A(freeMap)(m); }
+DRV void fakevs_map_set_int(VSMap *m, const char *k, int64_t v) { A(mapSetInt)(m, k, v, maAppend); }
+DRV void fakevs_map_set_float(VSMap *m, const char *k, double v) { A(mapSetFloat)(m, k, v, maAppend); }
+DRV void fakevs_map_set_data(VSMap *m, const char *k, const char *v) { A(mapSetData)(m, k, v, -1, dtUtf8, maAppend); }
+DRV void fakevs_map_set_node(VSMap *m, const char *k, VSNode *n) { A(mapSetNode)(m, k, n, maAppend); }
+DRV void fakevs_map_set_empty(VSMap *m, const char *k, int type) { m->get(k).type = type; }
+DRV VSMap *fakevs_invoke(const char *ns, const char *fn, VSMap *args) {
+    VSPlugin *p = A(getPluginByNamespace)(ns, &g_core);
+    if (!p) {
+        VSMap *o = new VSMap();
+        A(mapSetError)(o, "no such plugin");
+        return o;
+    }
+    return A(invoke)(p, fn, args);
+}
+DRV const char *fakevs_map_error(VSMap *m) { return A(mapGetError)(m); }
+DRV VSNode *fakevs_map_node(VSMap *m, const char *k) {
+    int e = 0;
+    return A(mapGetNode)(m, k, 0, &e);
+}
+DRV const VSFrame *fakevs_get_frame(VSNode *n, int i, char *err, int errlen) { return A(getFrame)(i, n, err, errlen); }
+DRV void fakevs_frame_free(const VSFrame *f) { frame_unref(f); }
+DRV uint8_t *fakevs_frame_plane(const VSFrame *f, int p, int *w, int *h, ptrdiff_t *stride) {
+    *w = plane_w(f->fmt, f->w, p);
+    *h = plane_h(f->fmt, f->h, p);
+    *stride = f->stride[p];
+    return f->ptr[p];
+}
+DRV int fakevs_frame_num_planes(const VSFrame *f) { return f->fmt.numPlanes; }
+DRV int fakevs_frame_prop_count(const VSFrame *f, const char *k) { return prop_count(f->props.find(k)); }
+DRV int fakevs_frame_prop_type(const VSFrame *f, const char *k) { return A(mapGetType)(&f->props, k); }
+DRV int64_t fakevs_frame_prop_int(const VSFrame *f, const char *k, int i) { return A(mapGetInt)(&f->props, k, i, nullptr); }
+DRV double fakevs_frame_prop_float(const VSFrame *f, const char *k, int i) { return A(mapGetFloat)(&f->props, k, i, nullptr); }
+DRV void fakevs_frame_set_prop_int(VSFrame *f, const char *k, int64_t v) { A(mapSetInt)(&f->props, k, v, maReplace); }
+DRV int fakevs_frame_num_props(const VSFrame *f) { return (int)f->props.items.size(); }
+DRV const char *fakevs_frame_prop_key(const VSFrame *f, int i) { return f->props.items[i].first.c_str(); }

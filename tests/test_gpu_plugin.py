@@ -1,0 +1,155 @@
+"""End-to-end through the plugin boundary on the GPU: fake VS host -> libvszip.so ->
+C ABI -> HIP kernels -> frames/props, compared with the CPU oracle and the reference's
+known-answer tests (tests/test_*.py of the reference, cited per test)."""
+import math
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+from fakevs import fakevs as vs
+
+pytestmark = pytest.mark.gpu
+
+
+def _yuv420p16(seed=0, w=384, h=216):
+    return [fx.splitmix64_plane(seed + p, s, np.uint16) for p, s in enumerate([(h, w), (h // 2, w // 2), (h // 2, w // 2)])]
+
+
+def test_boxblur_yuv420p16_matches_oracle(oracle):
+    planes = _yuv420p16()
+    out = vs.source([planes], vs.YUV420P16).vszip.BoxBlur(hradius=13, vradius=13).get_frame(0)
+    for p in range(3):
+        assert np.array_equal(out[p], oracle.boxblur(planes[p], 13, 1, 13, 1))
+
+
+def test_boxblur_planes_and_props(oracle):
+    """planes=[0] copies the other planes (reference tests/test_boxblur.py:111-121); props pass through."""
+    planes = _yuv420p16(3)
+    out = vs.source([planes], vs.YUV420P16, props={"_Matrix": 1}).vszip.BoxBlur(planes=[0], hradius=5, vradius=5).get_frame(0)
+    assert np.array_equal(out[1], planes[1]) and np.array_equal(out[2], planes[2])
+    assert np.array_equal(out[0], oracle.boxblur(planes[0], 5, 1, 5, 1))
+    assert out.props["_Matrix"] == 1
+
+
+@pytest.mark.parametrize("fmt,dtype", [(vs.GRAY8, np.uint8), (vs.GRAY16, np.uint16), (vs.GRAYS, np.float32)])
+@pytest.mark.parametrize("radius", [10, 30])
+def test_boxblur_stride_handling(oracle, fmt, dtype, radius):
+    """offset plane pointers + stride > width (reference tests/test_boxblur.py:122-128)."""
+    p = fx.splitmix64_plane(9, (120, 613), dtype)
+    a = vs.source([[p]], fmt, extra_stride=96, offset=54).vszip.BoxBlur(hradius=radius, vradius=radius).get_frame(0)
+    b = vs.source([[p]], fmt).vszip.BoxBlur(hradius=radius, vradius=radius).get_frame(0)
+    assert np.array_equal(a[0].view(np.uint8), b[0].view(np.uint8))
+    assert np.array_equal(a[0].view(np.uint8), oracle.boxblur(p, radius, 1, radius, 1).view(np.uint8))
+
+
+def test_boxblur_pass_composition():
+    """reference tests/test_boxblur.py:86-101"""
+    src = vs.source([[fx.splitmix64_plane(4, (90, 160), np.uint16)]], vs.GRAY16)
+    two = src.vszip.BoxBlur(hradius=7, hpasses=2, vradius=0, vpasses=0).get_frame(0)[0]
+    one = src.vszip.BoxBlur(hradius=7, vradius=0, vpasses=0).vszip.BoxBlur(hradius=7, vradius=0, vpasses=0).get_frame(0)[0]
+    assert np.array_equal(two, one)
+
+
+def test_bilateral_yuv420p16(oracle):
+    planes = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate([(216, 384), (108, 192), (108, 192)])]
+    out = vs.source([planes], vs.YUV420P16).vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).get_frame(0)
+    prm = oracle.bilateral_params([2], [2], yuv=True, ssw=1, ssh=1)
+    for p in range(3):
+        want = oracle.bilateral_plane(planes[p], prm["sigmaS"][p], prm["sigmaR"][p], prm["algorithm"][p], prm["radius"][p], prm["step"][p], prm["PBFICnum"][p])
+        assert np.array_equal(out[p], want)
+
+
+def test_bilateral_sigma_zero_is_passthrough():
+    """reference tests/test_bilateral.py:84-87"""
+    planes = _yuv420p16(5, 128, 64)
+    out = vs.source([planes], vs.YUV420P16).vszip.Bilateral(sigmaS=0.0).get_frame(0)
+    for p in range(3):
+        assert np.array_equal(out[p], planes[p])
+
+
+def test_planeaverage_known_answers():
+    """reference tests/test_planeaverage.py:118-147"""
+    two = np.concatenate([np.full((32, 64), 1000, np.uint16), np.full((32, 64), 3000, np.uint16)], axis=1)
+    src = vs.source([[two]], vs.GRAY16)
+    assert src.vszip.PlaneAverage(exclude=[1000]).get_frame(0).props["psmAvg"] == 3000 / 65535
+    assert src.vszip.PlaneAverage(exclude=[3000]).get_frame(0).props["psmAvg"] == 1000 / 65535
+    assert src.vszip.PlaneAverage(exclude=[1000, 3000]).get_frame(0).props["psmAvg"] == 0.0
+    y = vs.blank(vs.YUV420P16, 64, 32, [6777, 32768, 0])
+    p = y.vszip.PlaneAverage(exclude=[-1], prop="avg_test").get_frame(0).props
+    assert p["avg_testAvg"] == 0.10341039139391164
+    multi = y.vszip.PlaneAverage(exclude=[-1], planes=[0, 1, 2]).get_frame(0).props["psmAvg"]
+    assert multi == [6777 / 65535, 32768 / 65535, 0.0]
+    f = vs.source([[np.concatenate([np.full((32, 64), 1.0, np.float32), np.full((32, 64), 3.0, np.float32)], axis=1)]], vs.GRAYS)
+    assert f.vszip.PlaneAverage(exclude=[3]).get_frame(0).props["psmAvg"] == 1.0
+
+
+def test_planeminmax_known_answers(oracle):
+    """reference tests/test_planeminmax.py:99-110,228-236"""
+    p = np.full((32, 64), 200, np.uint8)
+    p[:8, :] = 0
+    src = vs.source([[p]], vs.GRAY8)
+    a = src.vszip.PlaneMinMax(minthr=0.2).get_frame(0).props
+    b = src.vszip.PlaneMinMax(minthr=0.3).get_frame(0).props
+    assert (a["psmMin"], a["psmMax"], b["psmMin"]) == (0, 200, 200)
+    q = vs.blank(vs.GRAY16, 64, 32, 1234)
+    assert q.vszip.PlaneMinMax(minthr=1.0).get_frame(0).props["psmMin"] == 65535
+    assert q.vszip.PlaneMinMax(maxthr=1.0).get_frame(0).props["psmMax"] == 0
+    g = fx.crop_gray8()
+    pr = vs.source([[g]], vs.GRAY8).vszip.PlaneMinMax(minthr=0.1, maxthr=0.1, clipb=vs.source([[g]], vs.GRAY8).vszip.BoxBlur(hradius=1, vradius=1)).get_frame(0).props
+    gold = fx.ref_goldens()["exact"]["planeminmax"]["GRAY8|full|maxthr=0.1,minthr=0.1"]
+    assert (pr["psmMin"], pr["psmMax"]) == (gold["Min"], gold["Max"])
+    assert pr["psmDiff"] == oracle.plane_minmax(g, 0.1, 0.1, oracle.boxblur(np.ascontiguousarray(g), 1, 1, 1, 1))[2]
+
+
+def test_ssimulacra2_props():
+    """reference tests/test_ssimulacra2.py:65-71 (linear RGBS fed directly: _Transfer = 8)."""
+    c = vs.blank(vs.RGBS, 64, 64, [0.3, 0.2, 0.5])
+    lin = vs.source([[np.full((64, 64), v, np.float32) for v in (0.3, 0.2, 0.5)]], vs.RGBS, props={"_Transfer": 8})
+    assert lin.vszip.SSIMULACRA2(lin).get_frame(0).props["SSIMULACRA2"] == 100.0
+    with pytest.raises(vs.Error, match="linear-light RGBS"):
+        c.vszip.SSIMULACRA2(c)
+
+
+def test_ssimulacra2_matches_oracle(oracle):
+    rng = np.random.default_rng(2)
+    ref = [np.ascontiguousarray(p) for p in fx.crop_rgbs()]
+    dis = [np.clip(p + rng.normal(0, 0.03, p.shape).astype(np.float32), 0, 1) for p in ref]
+    a = vs.source([ref], vs.RGBS, props={"_Transfer": 8})
+    b = vs.source([dis], vs.RGBS, props={"_Transfer": 8})
+    out = a.vszip.SSIMULACRA2(b).get_frame(0)
+    assert out.props["SSIMULACRA2"] == pytest.approx(oracle.ssimulacra2(ref, dis), abs=1e-7)
+    assert np.array_equal(out[0], ref[0])  # the output clip is the reference clip + prop
+
+
+def test_xpsnr_props(oracle):
+    """identical -> +inf (reference tests/test_xpsnr.py:222-225); a distorted clip matches the oracle."""
+    frames = []
+    rng = np.random.default_rng(0)
+    for f in range(3):
+        frames.append([np.roll(fx.tiled_natural((288, 352), np.uint8), f, 0), fx.tiled_natural((144, 176), np.uint8, 1), fx.tiled_natural((144, 176), np.uint8, 2)])
+    dist = [[np.clip(p.astype(np.int16) + rng.integers(-2, 3, p.shape), 0, 255).astype(np.uint8) for p in fr] for fr in frames]
+    a, b = vs.source(frames, vs.YUV420P8), vs.source(dist, vs.YUV420P8)
+    same = a.vszip.XPSNR(a, verbose=0).get_frame(1).props
+    assert math.isinf(same["XPSNR_Y"]) and math.isinf(same["XPSNR_U"])
+    got = a.vszip.XPSNR(b, verbose=0).get_frame(2).props
+    w = oracle.xpsnr_wsse(frames[2], dist[2], frames[1][0], None, depth=8, frame_rate=24, temporal=True)
+    assert got["XPSNR_Y"] == oracle.xpsnr_frame(w[0], 352, 288, 8)
+    assert got["XPSNR_V"] == oracle.xpsnr_frame(w[2], 176, 144, 8)
+
+
+def test_eedi3_through_plugin(oracle):
+    planes = [np.ascontiguousarray(fx.crop_rgbs()[0][:96, :200]), np.ascontiguousarray(fx.crop_rgbs()[1][:48, :100]), np.ascontiguousarray(fx.crop_rgbs()[2][:48, :100])]
+    src = vs.source([planes] * 2, vs.YUV420PS)
+    out = src.vszip.EEDI3(field=1, dh=1).get_frame(0)
+    for p in range(3):
+        assert np.array_equal(out[p], oracle.eedi3(planes[p], 1, dh=True))
+    assert out.props["_FieldBased"] == 0
+    # _FieldBased on the source frame overrides `field` (src/vapoursynth/eedi3.zig:166-172): 1 = bottom -> field 0
+    bff = vs.source([planes], vs.YUV420PS, props={"_FieldBased": 1}).vszip.EEDI3(field=1).get_frame(0)
+    assert np.array_equal(bff[0], oracle.eedi3(planes[0], 0))
+    # double rate: frame 1 takes the opposite field
+    dbl = src.vszip.EEDI3(field=3)
+    assert np.array_equal(dbl.get_frame(0)[0], oracle.eedi3(planes[0], 1)) and np.array_equal(dbl.get_frame(1)[0], oracle.eedi3(planes[0], 0))
+    h = vs.source([[planes[0]]], vs.GRAYS).vszip.EEDI3H(field=1).get_frame(0)
+    assert np.array_equal(h[0], oracle.eedi3(planes[0], 1, horizontal=True))

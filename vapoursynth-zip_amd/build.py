@@ -68,7 +68,31 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    build_plugin(force or bool(jobs))
     return LIB
+
+
+PLUGIN = PKG / "libvszip.so"
+FAKEVS = PKG.parent / "tests" / "fakevs" / "libfakevs.so"
+
+
+def build_plugin(force: bool = False) -> None:
+    """libvszip.so (the VapourSynth plugin: plain C++ over the C ABI, linked to libvszip_hip.so
+    next to it) and the VapourSynth-free test host tests/fakevs/libfakevs.so."""
+    psrc = PKG / "plugin" / "vszip_plugin.cpp"
+    pdeps = [psrc, PKG / "plugin" / "VapourSynth4_min.h", PKG.parent / "include" / "vszip_hip.h"]
+    if force or _stale(PLUGIN, pdeps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-o", str(PLUGIN), str(psrc),
+               "-L" + str(PKG), "-lvszip_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("plugin build failed:\n" + r.stdout + r.stderr)
+    fsrc = FAKEVS.parent / "fakevs.cpp"
+    if fsrc.is_file() and (force or _stale(FAKEVS, [fsrc, PKG / "plugin" / "VapourSynth4_min.h"])):
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-o", str(FAKEVS), str(fsrc), "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("fakevs build failed:\n" + r.stdout + r.stderr)
 
 
 if __name__ == "__main__":

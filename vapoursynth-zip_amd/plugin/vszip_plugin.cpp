@@ -1,0 +1,1145 @@
+// libvszip.so — the VapourSynth plugin boundary of the MI355X vszip filter pack.
+//
+// Host side of the drop-in: the same exported entry point (VapourSynthPluginInit2,
+// reference src/vszip.zig:35), plugin id / namespace (:36) and byte-identical function
+// signature strings (:38-223, EEDI3: src/vapoursynth/eedi3.zig:494) as the reference, the same
+// argument defaults, validation order and error strings as its Zig wrappers
+// (src/vapoursynth/{boxblur,bilateral,ssimulacra2,xpsnr,eedi3,planeaverage,planeminmax}.zig and
+// src/helper.zig), written in C++ because no Zig toolchain exists in the build image. Every
+// getFrame stages the VSFrame planes to the GPU, calls the flat C ABI of include/vszip_hip.h and
+// stages the result back; frames shard over the visible GPUs by frame index (n mod #GPUs), one
+// context (stream + scratch) per worker thread and device, so getFrame stays re-entrant
+// (fmParallel) exactly like the reference's.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vszip_hip.h"
+#include "VapourSynth4_min.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// GPU side: per (thread, device) context with a grow-only device slab
+// ---------------------------------------------------------------------------
+struct Gpu {
+    vszip_ctx *ctx = nullptr;
+    int device = 0;
+    char *slab = nullptr;
+    size_t slab_size = 0, used = 0;
+    std::vector<void *> retired;
+
+    void reset() {
+        used = 0;
+        for (void *p : retired) vszip_dev_free(ctx, p);
+        retired.clear();
+    }
+    void *alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (used + bytes > slab_size) {
+            // keep the old slab alive until the frame is done (pointers into it are in use)
+            const size_t want = std::max(slab_size * 2, used + bytes + (size_t)(8 << 20));
+            if (slab) retired.push_back(slab);
+            void *p = nullptr;
+            if (vszip_dev_alloc(ctx, want, &p) != VSZIP_OK) return nullptr;
+            slab = static_cast<char *>(p);
+            slab_size = want;
+            used = 0;
+        }
+        void *r = slab + used;
+        used += bytes;
+        return r;
+    }
+};
+
+int device_count() {
+    static int n = [] {
+        const char *e = getenv("VSZIP_NUM_DEVICES");
+        int want = e ? atoi(e) : 0;
+        int found = 0;
+        for (int d = 0; d < 64; ++d) {
+            vszip_ctx *c = nullptr;
+            if (vszip_ctx_create(d, &c) != VSZIP_OK) break;
+            vszip_ctx_destroy(c);
+            ++found;
+        }
+        return want > 0 ? std::min(want, found) : found;
+    }();
+    return n;
+}
+
+Gpu *gpu_for_frame(int n) {
+    const int nd = device_count();
+    if (nd <= 0) return nullptr;
+    thread_local std::map<int, std::unique_ptr<Gpu>> pool;
+    const int dev = ((n % nd) + nd) % nd;  // frame-index round-robin over the GPUs of the node
+    auto &g = pool[dev];
+    if (!g) {
+        g.reset(new Gpu());
+        g->device = dev;
+        if (vszip_ctx_create(dev, &g->ctx) != VSZIP_OK) {
+            g.reset();
+            return nullptr;
+        }
+    }
+    g->reset();
+    return g.get();
+}
+
+struct DPlane {
+    void *ptr = nullptr;
+    ptrdiff_t stride = 0;  // elements
+    int w = 0, h = 0, bps = 1;
+};
+
+// ---------------------------------------------------------------------------
+// Thin helpers over the VS API (what ZAPI is to the reference)
+// ---------------------------------------------------------------------------
+struct Z {
+    const VSAPI *api;
+    VSCore *core;
+    VSFrameContext *fctx;
+
+    void setError(VSMap *out, const char *fmt, ...) const {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        api->mapSetError(out, buf);
+    }
+    bool has(const VSMap *m, const char *k) const { return api->mapNumElements(m, k) > 0; }
+    int64_t getInt(const VSMap *m, const char *k, int64_t def, int idx = 0) const {
+        int err = 0;
+        const int64_t v = api->mapGetInt(m, k, idx, &err);
+        return err ? def : v;
+    }
+    double getFloat(const VSMap *m, const char *k, double def, int idx = 0) const {
+        int err = 0;
+        const double v = api->mapGetFloat(m, k, idx, &err);
+        return err ? def : v;
+    }
+    VSNode *getNode(const VSMap *m, const char *k) const {
+        int err = 0;
+        VSNode *n = api->mapGetNode(m, k, 0, &err);
+        return err ? nullptr : n;
+    }
+
+    DPlane upload(Gpu *g, const VSFrame *f, int plane) const {
+        DPlane d;
+        const VSVideoFormat *vf = api->getVideoFrameFormat(f);
+        d.bps = vf->bytesPerSample;
+        d.w = api->getFrameWidth(f, plane);
+        d.h = api->getFrameHeight(f, plane);
+        const size_t pitch = ((size_t)d.w * d.bps + 255) & ~(size_t)255;
+        d.stride = (ptrdiff_t)(pitch / d.bps);
+        d.ptr = g->alloc(pitch * d.h);
+        if (!d.ptr) return d;
+        if (vszip_copy_h2d_2d(g->ctx, d.ptr, pitch, api->getReadPtr(f, plane), (size_t)api->getStride(f, plane), (size_t)d.w * d.bps, d.h) != VSZIP_OK) d.ptr = nullptr;
+        return d;
+    }
+    DPlane blank(Gpu *g, int w, int h, int bps) const {
+        DPlane d;
+        d.bps = bps;
+        d.w = w;
+        d.h = h;
+        const size_t pitch = ((size_t)w * bps + 255) & ~(size_t)255;
+        d.stride = (ptrdiff_t)(pitch / bps);
+        d.ptr = g->alloc(pitch * h);
+        return d;
+    }
+    bool download(Gpu *g, const DPlane &d, VSFrame *f, int plane) const {
+        return vszip_copy_d2h_2d(g->ctx, api->getWritePtr(f, plane), (size_t)api->getStride(f, plane), d.ptr, (size_t)d.stride * d.bps, (size_t)d.w * d.bps, d.h) == VSZIP_OK;
+    }
+};
+
+int dtype_of(const VSVideoFormat &f) {
+    if (f.sampleType == stInteger) return f.bytesPerSample == 1 ? VSZIP_U8 : (f.bytesPerSample == 2 ? VSZIP_U16 : -1);
+    return f.bytesPerSample == 2 ? VSZIP_F16 : (f.bytesPerSample == 4 ? VSZIP_F32 : -1);
+}
+
+// hz.DataType.select (helper.zig:59-98)
+bool select_dtype(const Z &z, VSMap *out, VSNode *node, const VSVideoInfo *vi, const char *name, bool enable_u32, int *dt) {
+    const VSVideoFormat &f = vi->format;
+    const char *msg = nullptr;
+    if (f.sampleType == stInteger) {
+        if (f.bytesPerSample == 1)
+            *dt = VSZIP_U8;
+        else if (f.bytesPerSample == 2)
+            *dt = VSZIP_U16;
+        else if (f.bytesPerSample == 4 && enable_u32)
+            *dt = 100;  // U32: PlaneAverage only
+        else
+            msg = "not supported Int format.";
+    } else {
+        if (f.bytesPerSample == 2)
+            *dt = VSZIP_F16;
+        else if (f.bytesPerSample == 4)
+            *dt = VSZIP_F32;
+        else
+            msg = "not supported Float format.";
+    }
+    if (msg) {
+        z.setError(out, "%s: %s", name, msg);
+        z.api->freeNode(node);
+        return false;
+    }
+    return true;
+}
+
+// hz.mapGetPlanes (helper.zig:128-164)
+bool get_planes(const Z &z, const VSMap *in, VSMap *out, std::initializer_list<VSNode *> nodes, bool process[3], int num_planes, const char *name) {
+    const int ne = z.api->mapNumElements(in, "planes");
+    if (ne <= 0) return true;
+    process[0] = process[1] = process[2] = false;
+    const char *msg = nullptr;
+    for (int i = 0; i < ne && !msg; ++i) {
+        const int64_t e = z.getInt(in, "planes", 0, i);
+        if (e < 0 || e >= num_planes)
+            msg = "plane index out of range";
+        else if (process[e])
+            msg = "plane specified twice.";
+        else
+            process[e] = true;
+    }
+    if (msg) {
+        z.setError(out, "%s: %s", name, msg);
+        for (VSNode *n : nodes)
+            if (n) z.api->freeNode(n);
+        return false;
+    }
+    return true;
+}
+
+bool is_constant_format(const VSVideoInfo *vi) { return vi->height > 0 && vi->width > 0 && vi->format.colorFamily != cfUndefined; }
+
+// hz.compareNodes (helper.zig:166-215); len_mode: 0 SAME_LEN, 1 BIGGER_THAN, 2 MISMATCH
+bool compare_nodes(const Z &z, VSMap *out, VSNode *n0, VSNode *n1, int len_mode, const char *name) {
+    if (!n1) return true;
+    const VSVideoInfo *a = z.api->getVideoInfo(n0), *b = z.api->getVideoInfo(n1);
+    const char *msg = nullptr;
+    if (!is_constant_format(b))
+        msg = "all input clips must have constant format.";
+    else if (a->width != b->width || a->height != b->height)
+        msg = "all input clips must have the same width and height.";
+    else if (a->format.colorFamily != b->format.colorFamily)
+        msg = "all input clips must have the same color family.";
+    else if (a->format.subSamplingW != b->format.subSamplingW || a->format.subSamplingH != b->format.subSamplingH)
+        msg = "all input clips must have the same subsampling.";
+    else if (a->format.bitsPerSample != b->format.bitsPerSample)
+        msg = "all input clips must have the same bit depth.";
+    else if (len_mode == 0 && a->numFrames != b->numFrames)
+        msg = "all input clips must have the same length.";
+    else if (len_mode == 1 && a->numFrames > b->numFrames)
+        msg = "second clip has less frames than input clip.";
+    if (msg) {
+        z.setError(out, "%s: %s", name, msg);
+        z.api->freeNode(n0);
+        z.api->freeNode(n1);
+        return false;
+    }
+    return true;
+}
+
+const VSFrame *fail(const Z &z, Gpu *g, VSFrame *dst, const char *name, const char *what) {
+    char buf[600];
+    snprintf(buf, sizeof buf, "%s: %s%s%s", name, what, g ? " — " : "", g ? vszip_last_error(g->ctx) : "");
+    z.api->setFilterError(buf, z.fctx);
+    if (dst) z.api->freeFrame(dst);
+    return nullptr;
+}
+
+vszip_plane mk_plane(const DPlane &s, const DPlane *d, const DPlane *r) {
+    vszip_plane p;
+    memset(&p, 0, sizeof p);
+    p.src = s.ptr;
+    p.src_stride = s.stride;
+    p.w = s.w;
+    p.h = s.h;
+    if (d) {
+        p.dst = d->ptr;
+        p.dst_stride = d->stride;
+    }
+    if (r) {
+        p.ref = r->ptr;
+        p.ref_stride = r->stride;
+    }
+    return p;
+}
+
+// ===========================================================================
+// BoxBlur — src/vapoursynth/boxblur.zig
+// ===========================================================================
+struct BoxBlurData {
+    VSNode *node;
+    const VSVideoInfo *vi;
+    int hradius, vradius, hpasses, vpasses, dt;
+    bool planes[3];
+};
+
+const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<BoxBlurData *>(inst);
+    Z z{api, core, fctx};
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->node, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *src = api->getFrameFilter(n, d->node, fctx);
+        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+        const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
+        const int pidx[3] = {0, 1, 2};
+        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
+        Gpu *g = gpu_for_frame(n);
+        if (!g) {
+            api->freeFrame(src);
+            return fail(z, nullptr, dst, "BoxBlur", "no MI355X device available (the plugin has no CPU fallback)");
+        }
+        std::vector<vszip_plane> tab;
+        std::vector<DPlane> outs;
+        std::vector<int> which;
+        for (int p = 0; p < vf->numPlanes; ++p) {
+            if (!d->planes[p]) continue;
+            DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps);
+            if (!s.ptr || !o.ptr) {
+                api->freeFrame(src);
+                return fail(z, g, dst, "BoxBlur", "device staging failed");
+            }
+            tab.push_back(mk_plane(s, &o, nullptr));
+            outs.push_back(o);
+            which.push_back(p);
+        }
+        int rc = tab.empty() ? VSZIP_OK : vszip_boxblur(g->ctx, d->dt, tab.data(), (int)tab.size(), d->hradius, d->hpasses, d->vradius, d->vpasses);
+        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
+            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
+        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        api->freeFrame(src);
+        if (rc != VSZIP_OK) return fail(z, g, dst, "BoxBlur", "GPU kernel failed");
+        return dst;
+    }
+    return nullptr;
+}
+
+void VS_CC boxblurFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<BoxBlurData *>(inst);
+    api->freeNode(d->node);
+    delete d;
+}
+
+void VS_CC boxblurCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) {
+    Z z{api, core, nullptr};
+    BoxBlurData d{};
+    d.node = z.getNode(in, "clip");
+    d.vi = api->getVideoInfo(d.node);
+    if (!select_dtype(z, out, d.node, d.vi, "BoxBlur", false, &d.dt)) return;
+    d.planes[0] = d.planes[1] = d.planes[2] = true;
+    if (!get_planes(z, in, out, {d.node}, d.planes, d.vi->format.numPlanes, "BoxBlur")) return;
+    d.hradius = (int)z.getInt(in, "hradius", 1);
+    d.vradius = (int)z.getInt(in, "vradius", 1);
+    d.hpasses = (int)z.getInt(in, "hpasses", 1);
+    d.vpasses = (int)z.getInt(in, "vpasses", 1);
+    const bool vblur = d.vradius > 0 && d.vpasses > 0, hblur = d.hradius > 0 && d.hpasses > 0;
+    if (!vblur && !hblur) {
+        z.setError(out, "BoxBlur: nothing to be performed");
+        api->freeNode(d.node);
+        return;
+    }
+    for (int p = 0; p < d.vi->format.numPlanes; ++p) {
+        if (!d.planes[p]) continue;
+        const int pw = d.vi->width >> (p ? d.vi->format.subSamplingW : 0), ph = d.vi->height >> (p ? d.vi->format.subSamplingH : 0);
+        if (hblur && (int64_t)d.hradius * 2 >= pw) {
+            z.setError(out, "BoxBlur: hradius too large; 2*hradius must be < the (smallest processed) plane width.");
+            api->freeNode(d.node);
+            return;
+        }
+        if (vblur && (int64_t)d.vradius * 2 >= ph) {
+            z.setError(out, "BoxBlur: vradius too large; 2*vradius must be < the (smallest processed) plane height.");
+            api->freeNode(d.node);
+            return;
+        }
+    }
+    auto *data = new BoxBlurData(d);
+    VSFilterDependency deps[] = {{d.node, rpStrictSpatial}};
+    api->createVideoFilter(out, "BoxBlur", d.vi, boxblurGetFrame, boxblurFree, fmParallel, deps, 1, data, core);
+}
+
+// hz.getArray (helper.zig:340-404): up to 3 values, missing entries repeat the previous one
+template <typename T>
+bool get_array3(const Z &z, const VSMap *in, VSMap *out, const char *key, const char *name, T def, T mn, T mx, bool is_float, T arr[3], std::initializer_list<VSNode *> nodes) {
+    const int len = std::max(0, z.api->mapNumElements(in, key));
+    char msg[256] = {0};
+    if (len > 3) {
+        snprintf(msg, sizeof msg, "%s: %s has too many elements (got %d, max 3).", name, key, len);
+    } else {
+        for (int i = 0; i < 3 && !msg[0]; ++i) {
+            if (i < len)
+                arr[i] = is_float ? (T)z.getFloat(in, key, 0, i) : (T)z.getInt(in, key, 0, i);
+            else if (i == 0)
+                arr[i] = def;
+            else
+                arr[i] = arr[i - 1];
+            if (arr[i] < mn)
+                snprintf(msg, sizeof msg, "%s: %s value %g is below minimum %g.", name, key, (double)arr[i], (double)mn);
+            else if (arr[i] > mx)
+                snprintf(msg, sizeof msg, "%s: %s value %g is above maximum %g.", name, key, (double)arr[i], (double)mx);
+        }
+    }
+    if (msg[0]) {
+        z.api->mapSetError(out, msg);
+        for (VSNode *n : nodes)
+            if (n) z.api->freeNode(n);
+        return false;
+    }
+    return true;
+}
+
+// ===========================================================================
+// Bilateral — src/vapoursynth/bilateral.zig
+// ===========================================================================
+struct BilateralData {
+    VSNode *node1, *node2;
+    const VSVideoInfo *vi;
+    vszip_bilateral_cfg cfg[3];
+    int dt, hist_len;
+    float peak;
+    std::mutex mu;
+    std::map<int, std::vector<vszip_bilateral_cfg>> per_device;  // LUTs live in device memory
+};
+
+const VSFrame *VS_CC bilateralGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<BilateralData *>(inst);
+    Z z{api, core, fctx};
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->node1, fctx);
+        if (d->node2) api->requestFrameFilter(n, d->node2, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *src = api->getFrameFilter(n, d->node1, fctx);
+        const VSFrame *ref = d->node2 ? api->getFrameFilter(n, d->node2, fctx) : nullptr;
+        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+        const VSFrame *psrc[3];
+        const int pidx[3] = {0, 1, 2};
+        for (int p = 0; p < 3; ++p) psrc[p] = d->cfg[p].process ? nullptr : src;
+        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
+        auto done = [&](const VSFrame *r) {
+            api->freeFrame(src);
+            if (ref) api->freeFrame(ref);
+            return r;
+        };
+        Gpu *g = gpu_for_frame(n);
+        if (!g) return done(fail(z, nullptr, dst, "Bilateral", "no MI355X device available (the plugin has no CPU fallback)"));
+        vszip_bilateral_cfg *cfg;
+        {
+            std::lock_guard<std::mutex> lk(d->mu);
+            auto &v = d->per_device[g->device];
+            if (v.empty()) {
+                v.assign(d->cfg, d->cfg + 3);
+                for (int p = 0; p < 3; ++p)
+                    if (vszip_bilateral_luts(g->ctx, &v[p], d->hist_len) != VSZIP_OK) return done(fail(z, g, dst, "Bilateral", "LUT upload failed"));
+            }
+            cfg = v.data();
+        }
+        std::vector<vszip_plane> tab;
+        std::vector<const vszip_bilateral_cfg *> cfgs;
+        std::vector<DPlane> outs;
+        std::vector<int> which;
+        for (int p = 0; p < vf->numPlanes; ++p) {
+            if (!cfg[p].process) continue;
+            DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps), r;
+            if (ref) r = z.upload(g, ref, p);
+            if (!s.ptr || !o.ptr || (ref && !r.ptr)) return done(fail(z, g, dst, "Bilateral", "device staging failed"));
+            tab.push_back(mk_plane(s, &o, ref ? &r : nullptr));
+            cfgs.push_back(&cfg[p]);
+            outs.push_back(o);
+            which.push_back(p);
+        }
+        int rc = tab.empty() ? VSZIP_OK : vszip_bilateral(g->ctx, d->dt, tab.data(), cfgs.data(), (int)tab.size(), d->peak);
+        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
+            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
+        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        if (rc != VSZIP_OK) return done(fail(z, g, dst, "Bilateral", "GPU kernel failed"));
+        return done(dst);
+    }
+    return nullptr;
+}
+
+void VS_CC bilateralFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<BilateralData *>(inst);
+    for (auto &kv : d->per_device) {
+        vszip_ctx *c = nullptr;
+        if (vszip_ctx_create(kv.first, &c) == VSZIP_OK) {
+            for (auto &cf : kv.second) {
+                if (cf.gs_lut) vszip_dev_free(c, cf.gs_lut);
+                if (cf.gr_lut) vszip_dev_free(c, cf.gr_lut);
+            }
+            vszip_ctx_destroy(c);
+        }
+    }
+    api->freeNode(d->node1);
+    if (d->node2) api->freeNode(d->node2);
+    delete d;
+}
+
+void VS_CC bilateralCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) {
+    Z z{api, core, nullptr};
+    auto d = std::make_unique<BilateralData>();
+    d->node1 = z.getNode(in, "clip");
+    d->node2 = nullptr;
+    d->vi = api->getVideoInfo(d->node1);
+    if (!select_dtype(z, out, d->node1, d->vi, "Bilateral", false, &d->dt)) return;
+    const VSVideoFormat &f = d->vi->format;
+    const bool yuv = f.colorFamily == cfYUV;
+    d->hist_len = f.sampleType == stInteger ? (1 << f.bitsPerSample) : 65536;  // hz.getHistLen
+    d->peak = (float)(d->hist_len - 1);
+    double sS[3] = {0, 0, 0};
+    const int m = std::max(0, api->mapNumElements(in, "sigmaS"));
+    for (int i = 0; i < std::min(m, 3); ++i) {
+        sS[i] = z.getFloat(in, "sigmaS", 0, i);
+        if (sS[i] < 0) {
+            z.setError(out, "Bilateral: Invalid \"sigmaS\" assigned, must be non-negative float number");
+            api->freeNode(d->node1);
+            return;
+        }
+    }
+    double sR[3];
+    int alg[3], num[3];
+    if (!get_array3<double>(z, in, out, "sigmaR", "Bilateral", 0.02, 0.0, 1.7976931348623157e308, true, sR, {d->node1})) return;
+    if (!get_array3<int>(z, in, out, "algorithm", "Bilateral", 0, 0, 2, false, alg, {d->node1})) return;
+    if (!get_array3<int>(z, in, out, "PBFICnum", "Bilateral", 0, 0, 256, false, num, {d->node1})) return;
+    bool planes[3] = {true, true, true};
+    if (!get_planes(z, in, out, {d->node1}, planes, f.numPlanes, "Bilateral")) return;
+    for (int v : num)
+        if (v == 1) {
+            z.setError(out, "Bilateral: Invalid \"PBFICnum\" assigned, must be integer ranges in [0,256] except 1");
+            api->freeNode(d->node1);
+            return;
+        }
+    const int pl[3] = {planes[0], planes[1], planes[2]};
+    if (vszip_bilateral_derive(sS, std::min(m, 3), sR, alg, num, yuv, f.subSamplingW, f.subSamplingH, pl, d->cfg) != VSZIP_OK) {
+        z.setError(out, "Bilateral: Invalid \"sigmaS\" assigned, must be non-negative float number");
+        api->freeNode(d->node1);
+        return;
+    }
+    for (int i = 0; i < f.numPlanes; ++i) {
+        if (d->cfg[i].process && d->cfg[i].algorithm == 2) {
+            const int pw = d->vi->width >> (i ? f.subSamplingW : 0), ph = d->vi->height >> (i ? f.subSamplingH : 0);
+            if (pw <= 2 * d->cfg[i].radius || ph <= 2 * d->cfg[i].radius) {
+                z.setError(out, "Bilateral: plane too small for the spatial radius derived from sigmaS; lower sigmaS or use a larger clip.");
+                api->freeNode(d->node1);
+                return;
+            }
+        }
+        if (d->cfg[i].process && d->cfg[i].algorithm == 1) {
+            z.setError(out, "Bilateral: algorithm 1 (PBFIC) is not available in the MI355X build yet");
+            api->freeNode(d->node1);
+            return;
+        }
+    }
+    for (int i = f.numPlanes; i < 3; ++i) d->cfg[i].process = 0;
+    d->node2 = z.getNode(in, "ref");
+    if (d->node2 && !compare_nodes(z, out, d->node1, d->node2, 1, "Bilateral")) return;
+    const int rp2 = (d->node2 && d->vi->numFrames <= api->getVideoInfo(d->node2)->numFrames) ? rpStrictSpatial : rpFrameReuseLastOnly;
+    VSFilterDependency deps[] = {{d->node1, rpStrictSpatial}, {d->node2, rp2}};
+    BilateralData *raw = d.release();
+    api->createVideoFilter(out, "Bilateral", raw->vi, bilateralGetFrame, bilateralFree, fmParallel, deps, raw->node2 ? 2 : 1, raw, core);
+}
+
+// ===========================================================================
+// PlaneAverage / PlaneMinMax — src/vapoursynth/planeaverage.zig, planeminmax.zig
+// ===========================================================================
+struct PlaneStatData {
+    VSNode *node1, *node2;
+    const VSVideoInfo *vi;
+    int dt;
+    bool planes[3];
+    std::vector<int32_t> exclude;
+    float minthr, maxthr;
+    std::string key_a, key_b, key_d;  // Avg | Min, Max, Diff
+    bool minmax;
+};
+
+const VSFrame *VS_CC planeStatGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<PlaneStatData *>(inst);
+    Z z{api, core, fctx};
+    const char *name = d->minmax ? "PlaneMinMax" : "PlaneAverage";
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->node1, fctx);
+        if (d->node2) api->requestFrameFilter(n, d->node2, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *src = api->getFrameFilter(n, d->node1, fctx);
+        const VSFrame *ref = d->node2 ? api->getFrameFilter(n, d->node2, fctx) : nullptr;
+        VSFrame *dst = api->copyFrame(src, core);
+        VSMap *props = api->getFramePropertiesRW(dst);
+        api->mapDeleteKey(props, d->key_d.c_str());
+        api->mapDeleteKey(props, d->key_a.c_str());
+        if (d->minmax) api->mapDeleteKey(props, d->key_b.c_str());
+        auto done = [&](const VSFrame *r) {
+            api->freeFrame(src);
+            if (ref) api->freeFrame(ref);
+            return r;
+        };
+        Gpu *g = gpu_for_frame(n);
+        if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
+        std::vector<vszip_plane> tab;
+        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+        for (int p = 0; p < vf->numPlanes; ++p) {
+            if (!d->planes[p]) continue;
+            DPlane s = z.upload(g, src, p), r;
+            if (ref) r = z.upload(g, ref, p);
+            if (!s.ptr || (ref && !r.ptr)) return done(fail(z, g, dst, name, "device staging failed"));
+            tab.push_back(mk_plane(s, nullptr, ref ? &r : nullptr));
+        }
+        const int np = (int)tab.size();
+        std::vector<double> a(np), b(np), df(np);
+        int rc = VSZIP_OK;
+        if (np > 0) {
+            if (d->minmax)
+                rc = vszip_plane_minmax(g->ctx, d->dt, tab.data(), np, d->minthr, d->maxthr, vf->bitsPerSample, a.data(), b.data(), df.data());
+            else
+                rc = vszip_plane_average(g->ctx, d->dt, tab.data(), np, d->exclude.data(), (int)d->exclude.size(), vf->bitsPerSample, a.data(), df.data());
+        }
+        if (rc != VSZIP_OK) return done(fail(z, g, dst, name, "GPU kernel failed"));
+        const bool is_int = vf->sampleType == stInteger;
+        for (int i = 0; i < np; ++i) {
+            if (d->minmax) {  // planeminmax.zig(filters):59-68
+                if (is_int) {
+                    api->mapSetInt(props, d->key_a.c_str(), (int64_t)a[i], maAppend);
+                    api->mapSetInt(props, d->key_b.c_str(), (int64_t)b[i], maAppend);
+                } else {
+                    api->mapSetFloat(props, d->key_a.c_str(), a[i], maAppend);
+                    api->mapSetFloat(props, d->key_b.c_str(), b[i], maAppend);
+                }
+                if (ref) api->mapSetFloat(props, d->key_d.c_str(), df[i], maAppend);
+            } else {  // planeaverage.zig:55-64
+                if (ref) api->mapSetFloat(props, d->key_d.c_str(), df[i], maAppend);
+                api->mapSetFloat(props, d->key_a.c_str(), a[i], maAppend);
+            }
+        }
+        return done(dst);
+    }
+    return nullptr;
+}
+
+void VS_CC planeStatFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<PlaneStatData *>(inst);
+    if (d->node2) api->freeNode(d->node2);
+    api->freeNode(d->node1);
+    delete d;
+}
+
+void plane_stat_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *api, bool minmax) {
+    Z z{api, core, nullptr};
+    const char *name = minmax ? "PlaneMinMax" : "PlaneAverage";
+    auto d = std::make_unique<PlaneStatData>();
+    d->minmax = minmax;
+    d->node1 = z.getNode(in, "clipa");
+    d->vi = api->getVideoInfo(d->node1);
+    if (!select_dtype(z, out, d->node1, d->vi, name, !minmax, &d->dt)) return;
+    d->node2 = z.getNode(in, "clipb");
+    if (d->node2 && !compare_nodes(z, out, d->node1, d->node2, 1, name)) return;
+    d->planes[0] = true;
+    d->planes[1] = d->planes[2] = false;
+    if (!get_planes(z, in, out, {d->node1, d->node2}, d->planes, d->vi->format.numPlanes, name)) return;
+    auto bail = [&](const char *msg) {
+        z.setError(out, "%s", msg);
+        api->freeNode(d->node1);
+        if (d->node2) api->freeNode(d->node2);
+    };
+    int err = 0;
+    const char *prop = api->mapGetData(in, "prop", 0, &err);
+    const std::string pfx = (err || !prop) ? "psm" : prop;
+    d->key_d = pfx + "Diff";
+    if (minmax) {
+        d->key_a = pfx + "Min";
+        d->key_b = pfx + "Max";
+        for (const char *k : {"maxthr", "minthr"}) {  // getThr, planeminmax.zig:175-192
+            const float thr = (float)z.getFloat(in, k, 0.0);
+            if (thr < 0 || thr > 1) {
+                char msg[128];
+                snprintf(msg, sizeof msg, "PlaneMinMax: %s should be a float between 0.0 and 1.0", k);
+                return bail(msg);
+            }
+            (strcmp(k, "maxthr") ? d->minthr : d->maxthr) = thr;
+        }
+        const bool no_thr = d->maxthr == 0 && d->minthr == 0;
+        if ((d->planes[1] || d->planes[2]) && !no_thr && d->vi->format.colorFamily == cfYUV && d->vi->format.sampleType == stFloat)
+            return bail("PlaneMinMax: you can't use maxthr/minthr with float chroma, use planes=[0] or maxthr/minthr=0");
+    } else {
+        d->key_a = pfx + "Avg";
+        const int ne = std::max(0, api->mapNumElements(in, "exclude"));
+        if (d->dt == 100) return bail(ne > 0 ? "PlaneAverage: exclude is not supported for 32-bit integer clips." : "PlaneAverage: 32-bit integer clips are not available in the MI355X build yet");
+        if (ne > 8) return bail("PlaneAverage: more than 8 exclude values are not available in the MI355X build yet");
+        for (int i = 0; i < ne; ++i) {
+            const int64_t v = z.getInt(in, "exclude", 0, i);
+            d->exclude.push_back((int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, v)));  // math.lossyCast(i32, ...)
+        }
+    }
+    const int rp2 = (d->node2 && d->vi->numFrames <= api->getVideoInfo(d->node2)->numFrames) ? rpStrictSpatial : rpFrameReuseLastOnly;
+    VSFilterDependency deps[] = {{d->node1, rpStrictSpatial}, {d->node2, rp2}};
+    PlaneStatData *raw = d.release();
+    api->createVideoFilter(out, name, raw->vi, planeStatGetFrame, planeStatFree, fmParallel, deps, raw->node2 ? 2 : 1, raw, core);
+}
+void VS_CC planeAverageCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { plane_stat_create(in, out, core, api, false); }
+void VS_CC planeMinMaxCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { plane_stat_create(in, out, core, api, true); }
+
+// ===========================================================================
+// SSIMULACRA2 — src/vapoursynth/ssimulacra2.zig
+// ===========================================================================
+struct SsimData {
+    VSNode *node1, *node2;
+};
+
+// hz.toRGBS + sRGBtoLinearRGB (helper.zig:225-243, ssimulacra2.zig:132-162): delegated to the
+// host's resize/std plugins exactly like the reference; a host without them can only feed RGBS
+// clips that are already linear (_Transfer == 8).
+VSNode *to_linear_rgbs(const Z &z, VSNode *node, VSMap *out, bool *ok) {
+    const VSAPI *api = z.api;
+    const VSVideoInfo *vi = api->getVideoInfo(node);
+    const uint32_t id = api->queryVideoFormatID(vi->format.colorFamily, vi->format.sampleType, vi->format.bitsPerSample, vi->format.subSamplingW, vi->format.subSamplingH, z.core);
+    VSPlugin *resize = api->getPluginByID("com.vapoursynth.resize", z.core);
+    if (id != (uint32_t)pfRGBS) {
+        if (!resize) {
+            z.setError(out, "SSIMULACRA2 : the host has no resize plugin; feed RGBS clips");
+            *ok = false;
+            return node;
+        }
+        VSMap *args = api->createMap();
+        api->mapConsumeNode(args, "clip", node, maReplace);
+        api->mapSetInt(args, "matrix_in", vi->height > 650 ? 1 : 6, maReplace);
+        api->mapSetInt(args, "format", pfRGBS, maReplace);
+        VSMap *ret = api->invoke(resize, "Bicubic", args);
+        node = z.getNode(ret, "clip");
+        api->freeMap(ret);
+        api->freeMap(args);
+        if (!node) {
+            z.setError(out, "SSIMULACRA2 : conversion to RGBS failed");
+            *ok = false;
+            return nullptr;
+        }
+    }
+    char err[256];
+    const VSFrame *f0 = api->getFrame(0, node, err, sizeof err);
+    int64_t transfer = 2;  // unspecified
+    if (f0) {
+        int e = 0;
+        const int64_t t = api->mapGetInt(api->getFramePropertiesRO(f0), "_Transfer", 0, &e);
+        if (!e) transfer = t;
+        api->freeFrame(f0);
+    }
+    if (transfer == 8) return node;  // LINEAR
+    VSPlugin *stdp = api->getPluginByID("com.vapoursynth.std", z.core);
+    if (!resize || !stdp) {
+        z.setError(out, "SSIMULACRA2 : the host has no resize/std plugins; feed linear-light RGBS (_Transfer=8)");
+        *ok = false;
+        return node;
+    }
+    VSMap *args = api->createMap();
+    api->mapConsumeNode(args, "clip", node, maReplace);
+    api->mapSetData(args, "prop", "_Transfer", -1, dtUtf8, maReplace);
+    api->mapSetInt(args, "intval", 13, maReplace);  // IEC 61966-2-1
+    VSMap *ret = api->invoke(stdp, "SetFrameProp", args);
+    node = z.getNode(ret, "clip");
+    api->freeMap(ret);
+    api->clearMap(args);
+    api->mapConsumeNode(args, "clip", node, maReplace);
+    api->mapSetInt(args, "transfer", 8, maReplace);
+    ret = api->invoke(resize, "Bicubic", args);
+    node = z.getNode(ret, "clip");
+    api->freeMap(ret);
+    api->freeMap(args);
+    return node;
+}
+
+const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<SsimData *>(inst);
+    Z z{api, core, fctx};
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->node1, fctx);
+        api->requestFrameFilter(n, d->node2, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx), *s2 = api->getFrameFilter(n, d->node2, fctx);
+        VSFrame *dst = api->copyFrame(s1, core);
+        auto done = [&](const VSFrame *r) {
+            api->freeFrame(s1);
+            api->freeFrame(s2);
+            return r;
+        };
+        Gpu *g = gpu_for_frame(n);
+        if (!g) return done(fail(z, nullptr, dst, "SSIMULACRA2", "no MI355X device available (the plugin has no CPU fallback)"));
+        // all six planes at one common pitch
+        const int w = api->getFrameWidth(s1, 0), h = api->getFrameHeight(s1, 0);
+        const size_t pitch = ((size_t)w * 4 + 255) & ~(size_t)255;
+        const float *r3[3], *d3[3];
+        for (int p = 0; p < 3; ++p) {
+            void *a = g->alloc(pitch * h), *b = g->alloc(pitch * h);
+            if (!a || !b || vszip_copy_h2d_2d(g->ctx, a, pitch, api->getReadPtr(s1, p), (size_t)api->getStride(s1, p), (size_t)w * 4, h) != VSZIP_OK ||
+                vszip_copy_h2d_2d(g->ctx, b, pitch, api->getReadPtr(s2, p), (size_t)api->getStride(s2, p), (size_t)w * 4, h) != VSZIP_OK)
+                return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+            r3[p] = static_cast<const float *>(a);
+            d3[p] = static_cast<const float *>(b);
+        }
+        double score = 0;
+        if (vszip_ssimulacra2(g->ctx, r3, d3, (ptrdiff_t)(pitch / 4), w, h, 1, &score) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "GPU kernel failed"));
+        api->mapSetFloat(api->getFramePropertiesRW(dst), "SSIMULACRA2", score, maReplace);
+        return done(dst);
+    }
+    return nullptr;
+}
+
+void VS_CC ssimFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<SsimData *>(inst);
+    api->freeNode(d->node1);
+    api->freeNode(d->node2);
+    delete d;
+}
+
+void VS_CC ssimCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) {
+    Z z{api, core, nullptr};
+    SsimData d{z.getNode(in, "reference"), z.getNode(in, "distorted")};
+    const VSVideoInfo *v1 = api->getVideoInfo(d.node1), *v2 = api->getVideoInfo(d.node2);
+    const char *msg = nullptr;
+    if (v1->width != v2->width || v1->height != v2->height)
+        msg = "SSIMULACRA2 : clips must have the same dimensions.";
+    else if (v1->numFrames != v2->numFrames)
+        msg = "SSIMULACRA2 : clips must have the same length.";
+    else if ((v1->format.sampleType == stFloat && v1->format.bitsPerSample == 16) || (v2->format.sampleType == stFloat && v2->format.bitsPerSample == 16))
+        msg = "SSIMULACRA2 : half-float (f16) format is not supported.";
+    if (msg) {
+        z.setError(out, "%s", msg);
+        api->freeNode(d.node1);
+        api->freeNode(d.node2);
+        return;
+    }
+    bool ok = true;
+    d.node1 = to_linear_rgbs(z, d.node1, out, &ok);
+    if (ok) d.node2 = to_linear_rgbs(z, d.node2, out, &ok);
+    if (!ok) {
+        if (d.node1) api->freeNode(d.node1);
+        if (d.node2) api->freeNode(d.node2);
+        return;
+    }
+    auto *data = new SsimData(d);
+    VSFilterDependency deps[] = {{d.node1, rpStrictSpatial}, {d.node2, rpStrictSpatial}};
+    api->createVideoFilter(out, "SSIMULACRA2", api->getVideoInfo(d.node1), ssimGetFrame, ssimFree, fmParallel, deps, 2, data, core);
+}
+
+// ===========================================================================
+// XPSNR — src/vapoursynth/xpsnr.zig
+// ===========================================================================
+struct XpsnrData {
+    VSNode *node1, *node2;
+    const VSVideoInfo *vi;
+    int depth, num_comps;
+    unsigned frame_rate;
+    int width[3], height[3];
+    bool temporal, verbose;
+    std::mutex mu;
+    uint64_t num_frames = 0;
+    double sum_wdist[3] = {0, 0, 0}, sum_xpsnr[3] = {0, 0, 0};
+};
+
+const VSFrame *VS_CC xpsnrGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<XpsnrData *>(inst);
+    Z z{api, core, fctx};
+    const bool want1 = d->temporal && n > 0, want2 = d->temporal && d->frame_rate >= 32 && n > 1;
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->node1, fctx);
+        api->requestFrameFilter(n, d->node2, fctx);
+        if (want1) api->requestFrameFilter(n - 1, d->node1, fctx);
+        if (want2) api->requestFrameFilter(n - 2, d->node1, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx), *s2 = api->getFrameFilter(n, d->node2, fctx);
+        const VSFrame *p1 = want1 ? api->getFrameFilter(n - 1, d->node1, fctx) : nullptr;
+        const VSFrame *p2 = want2 ? api->getFrameFilter(n - 2, d->node1, fctx) : nullptr;
+        VSFrame *dst = api->copyFrame(s2, core);
+        auto done = [&](const VSFrame *r) {
+            api->freeFrame(s1);
+            api->freeFrame(s2);
+            if (p1) api->freeFrame(p1);
+            if (p2) api->freeFrame(p2);
+            return r;
+        };
+        Gpu *g = gpu_for_frame(n);
+        if (!g) return done(fail(z, nullptr, dst, "XPSNR", "no MI355X device available (the plugin has no CPU fallback)"));
+        const void *o3[3] = {nullptr, nullptr, nullptr}, *r3[3] = {nullptr, nullptr, nullptr};
+        ptrdiff_t st[3] = {0, 0, 0};
+        for (int c = 0; c < d->num_comps; ++c) {
+            DPlane a = z.upload(g, s1, c), b = z.upload(g, s2, c);
+            if (!a.ptr || !b.ptr) return done(fail(z, g, dst, "XPSNR", "device staging failed"));
+            o3[c] = a.ptr;
+            r3[c] = b.ptr;
+            st[c] = a.stride;  // same geometry and bit depth => same pitch
+        }
+        DPlane q1, q2;
+        if (p1) q1 = z.upload(g, p1, 0);
+        if (p2) q2 = z.upload(g, p2, 0);
+        uint64_t wsse[3] = {0, 0, 0};
+        if (vszip_xpsnr_wsse(g->ctx, d->vi->format.bytesPerSample, o3, r3, q1.ptr, q2.ptr, d->width, d->height, st, d->depth, d->num_comps, d->frame_rate, d->temporal, wsse) != VSZIP_OK)
+            return done(fail(z, g, dst, "XPSNR", "GPU kernel failed"));
+        double cur[3] = {INFINITY, INFINITY, INFINITY};
+        for (int c = 0; c < d->num_comps; ++c) cur[c] = vszip_xpsnr_value(wsse[c], d->width[c], d->height[c], d->depth);
+        {
+            std::lock_guard<std::mutex> lk(d->mu);  // xpsnr.zig:89-96
+            d->num_frames += 1;
+            for (int c = 0; c < d->num_comps; ++c) {
+                d->sum_wdist[c] += std::sqrt((double)wsse[c]);
+                d->sum_xpsnr[c] += cur[c];
+            }
+        }
+        VSMap *props = api->getFramePropertiesRW(dst);
+        api->mapSetFloat(props, "XPSNR_Y", cur[0], maReplace);
+        api->mapSetFloat(props, "XPSNR_U", cur[1], maReplace);
+        api->mapSetFloat(props, "XPSNR_V", cur[2], maReplace);
+        return done(dst);
+    }
+    return nullptr;
+}
+
+void VS_CC xpsnrFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<XpsnrData *>(inst);
+    if (d->verbose) {  // xpsnr.zig:114-128
+        printf("XPSNR average, %llu frames  ", (unsigned long long)d->num_frames);
+        const char ch[3] = {'y', 'u', 'v'};
+        for (int c = 0; c < d->num_comps; ++c)
+            printf("%c: %.4f  ", ch[c], vszip_xpsnr_average(d->sum_wdist[c], d->sum_xpsnr[c], d->width[c], d->height[c], d->depth, d->num_frames));
+        printf("\n");
+        fflush(stdout);
+    }
+    api->freeNode(d->node1);
+    api->freeNode(d->node2);
+    delete d;
+}
+
+void VS_CC xpsnrCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) {
+    Z z{api, core, nullptr};
+    auto d = std::make_unique<XpsnrData>();
+    d->node1 = z.getNode(in, "reference");
+    const VSVideoInfo *v1 = api->getVideoInfo(d->node1);
+    const char *msg = nullptr;
+    if (v1->format.colorFamily != cfYUV)
+        msg = "XPSNR : only supports YUV format clips";
+    else if (v1->format.bitsPerSample != 8 && v1->format.bitsPerSample != 10)
+        msg = "XPSNR : only supports 8 or 10 bit clips";
+    else if ((v1->width & 1) || (v1->height & 1))
+        msg = "XPSNR : only supports even width and height";
+    if (msg) {
+        z.setError(out, "%s", msg);
+        api->freeNode(d->node1);
+        return;
+    }
+    d->node2 = z.getNode(in, "distorted");
+    const VSVideoInfo *v2 = api->getVideoInfo(d->node2);
+    if (v1->format.bitsPerSample != v2->format.bitsPerSample) {
+        // hz.bitDepth (helper.zig:470-494) delegates to resize.Point; equal depths are required here
+        z.setError(out, "XPSNR : clips of different bit depth need the host's resize plugin; convert before calling");
+        api->freeNode(d->node1);
+        api->freeNode(d->node2);
+        return;
+    }
+    d->vi = v1;
+    if (!compare_nodes(z, out, d->node1, d->node2, 0, "XPSNR")) return;
+    d->temporal = z.getInt(in, "temporal", 1) != 0;
+    d->verbose = z.getInt(in, "verbose", 1) != 0;
+    d->depth = v1->format.bitsPerSample;
+    d->frame_rate = v2->fpsDen != 0 ? (unsigned)(v2->fpsNum / v2->fpsDen) : (v1->fpsDen != 0 ? (unsigned)(v1->fpsNum / v1->fpsDen) : 0);
+    d->num_comps = v1->format.numPlanes;
+    for (int c = 0; c < 3; ++c) {
+        d->width[c] = c < d->num_comps ? (v1->width >> (c ? v1->format.subSamplingW : 0)) : 0;
+        d->height[c] = c < d->num_comps ? (v1->height >> (c ? v1->format.subSamplingH : 0)) : 0;
+    }
+    VSFilterDependency deps[] = {{d->node1, rpGeneral}, {d->node2, rpStrictSpatial}};
+    XpsnrData *raw = d.release();
+    api->createVideoFilter(out, "XPSNR", raw->vi, xpsnrGetFrame, xpsnrFree, fmParallel, deps, 2, raw, core);
+}
+
+// ===========================================================================
+// EEDI3 / EEDI3H — src/vapoursynth/eedi3.zig
+// ===========================================================================
+struct Eedi3Data {
+    VSNode *node, *sclip;
+    VSVideoInfo vi;
+    vszip_eedi3_params prm;
+    int field;
+    bool horizontal;
+};
+
+void muldiv_rational(int64_t *num, int64_t *den, int64_t mul, int64_t div) {  // vsh.muldivRational
+    if (!*den) return;
+    *num *= mul;
+    *den *= div;
+    int64_t a = *num, b = *den;
+    while (b) {
+        const int64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    if (a < 0) a = -a;
+    if (a) {
+        *num /= a;
+        *den /= a;
+    }
+}
+
+const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<Eedi3Data *>(inst);
+    Z z{api, core, fctx};
+    const char *name = d->horizontal ? "EEDI3H" : "EEDI3";
+    const int src_n = d->field > 1 ? n / 2 : n;
+    if (reason == arInitial) {
+        api->requestFrameFilter(src_n, d->node, fctx);
+        if (d->prm.vcheck > 0 && d->sclip) api->requestFrameFilter(n, d->sclip, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *src = api->getFrameFilter(src_n, d->node, fctx);
+        const VSFrame *scp = (d->prm.vcheck > 0 && d->sclip) ? api->getFrameFilter(n, d->sclip, fctx) : nullptr;
+        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+        VSFrame *dst = api->newVideoFrame(vf, d->vi.width, d->vi.height, src, core);
+        VSMap *props = api->getFramePropertiesRW(dst);
+        auto done = [&](const VSFrame *r) {
+            api->freeFrame(src);
+            if (scp) api->freeFrame(scp);
+            return r;
+        };
+        int field = d->field & 1;  // eedi3.zig:166-172
+        int e = 0;
+        const int64_t fb = api->mapGetInt(props, "_FieldBased", 0, &e);
+        if (!e && fb == 1) field = 0;  // BOTTOM
+        if (!e && fb == 2) field = 1;  // TOP
+        if (d->field > 1) field = (n & 1) ^ field;
+        Gpu *g = gpu_for_frame(n);
+        if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
+        std::vector<vszip_plane> tab;
+        std::vector<DPlane> outs;
+        std::vector<const float *> scl;
+        std::vector<ptrdiff_t> scs;
+        for (int p = 0; p < vf->numPlanes; ++p) {
+            DPlane s = z.upload(g, src, p), o = z.blank(g, api->getFrameWidth(dst, p), api->getFrameHeight(dst, p), 4), c;
+            if (scp) c = z.upload(g, scp, p);
+            if (!s.ptr || !o.ptr || (scp && !c.ptr)) return done(fail(z, g, dst, name, "device staging failed"));
+            tab.push_back(mk_plane(s, &o, nullptr));
+            outs.push_back(o);
+            scl.push_back(static_cast<const float *>(c.ptr));
+            scs.push_back(c.stride);
+        }
+        int rc = vszip_eedi3(g->ctx, tab.data(), scp ? scl.data() : nullptr, scp ? scs.data() : nullptr, (int)tab.size(), field, d->horizontal, &d->prm);
+        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
+            if (!z.download(g, outs[i], dst, (int)i)) rc = VSZIP_ERR_HIP;
+        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        if (rc != VSZIP_OK) return done(fail(z, g, dst, name, "GPU kernel failed"));
+        api->mapSetInt(props, "_FieldBased", 0, maReplace);
+        if (d->field > 1) {
+            int e1 = 0, e2 = 0;
+            int64_t dn = api->mapGetInt(props, "_DurationNum", 0, &e1), dd = api->mapGetInt(props, "_DurationDen", 0, &e2);
+            if (!e1 && !e2) {
+                muldiv_rational(&dn, &dd, 1, 2);
+                api->mapSetInt(props, "_DurationNum", dn, maReplace);
+                api->mapSetInt(props, "_DurationDen", dd, maReplace);
+            }
+        }
+        return done(dst);
+    }
+    return nullptr;
+}
+
+void VS_CC eedi3Free(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<Eedi3Data *>(inst);
+    api->freeNode(d->node);
+    if (d->sclip) api->freeNode(d->sclip);
+    delete d;
+}
+
+void eedi3_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *api, bool horizontal) {
+    Z z{api, core, nullptr};
+    const char *name = horizontal ? "EEDI3H" : "EEDI3";
+    auto d = std::make_unique<Eedi3Data>();
+    d->horizontal = horizontal;
+    d->node = z.getNode(in, "clip");
+    d->vi = *api->getVideoInfo(d->node);
+    const int vcheck = (int)z.getInt(in, "vcheck", 2);
+    d->sclip = vcheck > 0 ? z.getNode(in, "sclip") : nullptr;
+    VSNode *mclip = z.getNode(in, "mclip");
+    auto bail = [&](const char *fmt, ...) {
+        char buf[256];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        api->mapSetError(out, buf);
+        api->freeNode(d->node);
+        if (d->sclip) api->freeNode(d->sclip);
+        if (mclip) api->freeNode(mclip);
+    };
+    if (d->vi.format.sampleType != stFloat || d->vi.format.bitsPerSample != 32) return bail("%s: only 32-bit float input is supported.", name);
+    const int field = (int)z.getInt(in, "field", 0), mdis = (int)z.getInt(in, "mdis", 20), nrad = (int)z.getInt(in, "nrad", 2);
+    vszip_eedi3_params &p = d->prm;
+    p.alpha = (float)z.getFloat(in, "alpha", 0.2);
+    p.beta = (float)z.getFloat(in, "beta", 0.25);
+    p.gamma = (float)z.getFloat(in, "gamma", 20.0);
+    p.dh = z.getInt(in, "dh", 0) != 0;
+    p.hp = z.getInt(in, "hp", 0) != 0;
+    p.vthresh0 = (float)z.getFloat(in, "vthresh0", 32.0);
+    p.vthresh1 = (float)z.getFloat(in, "vthresh1", 64.0);
+    p.vthresh2 = (float)z.getFloat(in, "vthresh2", 4.0);
+    p.nrad = nrad;
+    p.mdis = mdis;
+    p.vcheck = vcheck;
+    const int axis = horizontal ? d->vi.width : d->vi.height;
+    if (field < 0 || field > 3) return bail("%s: field must be 0, 1, 2, or 3.", name);
+    if (p.dh && field > 1) return bail("%s: field must be 0 or 1 when dh=True.", name);
+    if (!p.dh && (axis & 1)) return bail("%s: %s must be mod 2 when dh=False.", name, horizontal ? "width" : "height");
+    if (p.alpha < 0.0f || p.alpha > 1.0f) return bail("%s: alpha must be between 0.0 and 1.0 (inclusive).", name);
+    if (p.beta < 0.0f || p.beta > 1.0f) return bail("%s: beta must be between 0.0 and 1.0 (inclusive).", name);
+    if (p.alpha + p.beta > 1.0f) return bail("%s: alpha + beta must be less than or equal to 1.0.", name);
+    if (p.gamma < 0.0f) return bail("%s: gamma must be greater than or equal to 0.0.", name);
+    if (nrad < 0 || nrad > 3) return bail("%s: nrad must be between 0 and 3 (inclusive).", name);
+    if (mdis < 1 || mdis > 40) return bail("%s: mdis must be between 1 and 40 (inclusive).", name);
+    if (vcheck < 0 || vcheck > 3) return bail("%s: vcheck must be 0, 1, 2, or 3.", name);
+    if (vcheck > 0 && (p.vthresh0 <= 0.0f || p.vthresh1 <= 0.0f || p.vthresh2 <= 0.0f)) return bail("%s: vthresh0, vthresh1 and vthresh2 must be greater than 0.0.", name);
+    if (mclip) return bail("%s: mclip is not available in the MI355X build yet.", name);
+    if (p.hp) return bail("%s: hp=True is not available in the MI355X build yet.", name);
+    if (mdis > 31) return bail("%s: mdis > 31 is not available in the MI355X build yet.", name);
+    if (field > 1) {
+        if (d->vi.numFrames > INT32_MAX / 2) return bail("%s: resulting clip is too long.", name);
+        d->vi.numFrames *= 2;
+        muldiv_rational(&d->vi.fpsNum, &d->vi.fpsDen, 2, 1);
+    }
+    if (p.dh) (horizontal ? d->vi.width : d->vi.height) *= 2;
+    if (vcheck > 0 && d->sclip) {
+        const VSVideoInfo *sv = api->getVideoInfo(d->sclip);
+        if (sv->width != d->vi.width || sv->height != d->vi.height || memcmp(&sv->format, &d->vi.format, sizeof(VSVideoFormat)) != 0)
+            return bail("%s: sclip's format and dimensions don't match.", name);
+        if (sv->numFrames != d->vi.numFrames) return bail("%s: sclip's number of frames doesn't match.", name);
+    }
+    d->field = field;
+    VSFilterDependency deps[2] = {{d->node, rpStrictSpatial}, {d->sclip, rpStrictSpatial}};
+    Eedi3Data *raw = d.release();
+    api->createVideoFilter(out, name, &raw->vi, eedi3GetFrame, eedi3Free, fmParallel, deps, raw->sclip ? 2 : 1, raw, core);
+}
+void VS_CC eedi3Create(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { eedi3_create(in, out, core, api, false); }
+void VS_CC eedi3hCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { eedi3_create(in, out, core, api, true); }
+
+const char *kEedi3Args =
+    "clip:vnode;field:int;dh:int:opt;alpha:float:opt;beta:float:opt;gamma:float:opt;nrad:int:opt;mdis:int:opt;hp:int:opt;vcheck:int:opt;vthresh0:float:opt;"
+    "vthresh1:float:opt;vthresh2:float:opt;sclip:vnode:opt;mclip:vnode:opt;";
+
+}  // namespace
+
+// src/vszip.zig:35-223 — the seven hot-path filters of the pack, same id / namespace / signatures.
+// pluginVersion: zon.version "19.0.0" packed by vapoursynth-zig (un-vendored) — major only here.
+VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
+    vspapi->configPlugin("com.julek.vszip", "vszip", "VapourSynth Zig Image Process", VS_MAKE_VERSION(19, 0), VAPOURSYNTH_API_VERSION, 0, plugin);
+    vspapi->registerFunction("Bilateral", "clip:vnode;ref:vnode:opt;sigmaS:float[]:opt;sigmaR:float[]:opt;planes:int[]:opt;algorithm:int[]:opt;PBFICnum:int[]:opt",
+                             "clip:vnode;", bilateralCreate, nullptr, plugin);
+    vspapi->registerFunction("BoxBlur", "clip:vnode;planes:int[]:opt;hradius:int:opt;hpasses:int:opt;vradius:int:opt;vpasses:int:opt", "clip:vnode;", boxblurCreate, nullptr, plugin);
+    vspapi->registerFunction("EEDI3", kEedi3Args, "clip:vnode;", eedi3Create, nullptr, plugin);
+    vspapi->registerFunction("EEDI3H", kEedi3Args, "clip:vnode;", eedi3hCreate, nullptr, plugin);
+    vspapi->registerFunction("PlaneAverage", "clipa:vnode;exclude:int[];clipb:vnode:opt;planes:int[]:opt;prop:data:opt;", "clip:vnode;", planeAverageCreate, nullptr, plugin);
+    vspapi->registerFunction("PlaneMinMax", "clipa:vnode;minthr:float:opt;maxthr:float:opt;clipb:vnode:opt;planes:int[]:opt;prop:data:opt;", "clip:vnode;", planeMinMaxCreate, nullptr,
+                             plugin);
+    vspapi->registerFunction("SSIMULACRA2", "reference:vnode;distorted:vnode;", "clip:vnode;", ssimCreate, nullptr, plugin);
+    vspapi->registerFunction("XPSNR", "reference:vnode;distorted:vnode;temporal:int:opt;verbose:int:opt;", "clip:vnode;", xpsnrCreate, nullptr, plugin);
+}
