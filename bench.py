@@ -137,6 +137,24 @@ def cpu_ssimulacra2(w, h, budget_s=8.0):
     return r
 
 
+def profile_traffic(kernel_prefix: str, frames: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+    command (profiles/r*_boxblur_pmc.json, written by tools/prof.sh + tools/summarize_prof.py:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs). None when no matching profile."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_boxblur_pmc.json")):
+        try:
+            j = json.loads(f.read_text())
+            if j["bench_line_under_tracing"]["config"]["frames_per_step_per_gpu"] != frames:
+                continue
+            for k, m in j["kernels"].items():
+                if k.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in m:
+                    best = m["hbm_traffic_bytes_per_launch"]
+        except Exception:
+            continue
+    return best
+
+
 # ---------------------------------------------------------------------------
 # GPU workloads
 # ---------------------------------------------------------------------------
@@ -145,16 +163,24 @@ class Timed:
         self.dev, self.barrier = dev, barrier
 
     def run(self, step, steps, warmup):
+        """-> (wall seconds, stream ms over the region, summed dominant-kernel ms, dominant-kernel launches).
+        All three GPU figures are HIP events recorded on the stream the kernels are launched on
+        (the library's own stream, not torch's): timer_* brackets the whole region, the probe
+        brackets every launch of the filter's dominant kernel inside it."""
         for _ in range(warmup):
             step()
         self.barrier()
+        self.dev.probe_enable(True)
         t0 = time.perf_counter()
         self.dev.timer_start()
         for _ in range(steps):
             step()
-        kernel_ms = self.dev.timer_stop_ms()  # HIP events on the kernels' stream; synchronises it
+        region_ms = self.dev.timer_stop_ms()  # synchronises the stream
         self.barrier()
-        return time.perf_counter() - t0, kernel_ms
+        dt = time.perf_counter() - t0
+        dom_ms, launches = self.dev.probe_read()
+        self.dev.probe_enable(False)
+        return dt, region_ms, dom_ms, launches
 
 
 def setup_boxblur(dev, rank, frames, radius):
@@ -242,13 +268,13 @@ def main() -> int:
     out = None
     if a.workload == "boxblur":
         step, keep = setup_boxblur(dev, rank, F, a.radius)
-        dt, kernel_ms = timed.run(step, a.steps, a.warmup)
+        dt, region_ms, dom_ms, launches = timed.run(step, a.steps, a.warmup)
         dt = max_over_ranks(dt)
         frame_bytes = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K))  # 24 883 200
-        groups = -(-(3 * F) // 48)                      # launch groups (K_row pre-pass + ring kernel) per step
-        alg_bytes = 2 * frame_bytes * F / groups        # read once + write once
-        avg_s = kernel_ms * 1e-3 / (a.steps * groups)
+        alg_bytes = 2 * frame_bytes * F * a.steps / launches   # per ring-kernel launch: every pixel read once + written once
+        avg_s = dom_ms * 1e-3 / launches
         achieved = alg_bytes / avg_s / 1e9
+        group_s = region_ms * 1e-3 / launches                   # K_row pre-pass + ring kernel + launch gaps
         out = {
             "metric": "frames/sec at 4K YUV420P16: Bilateral, BoxBlur, SSIMULACRA2 on 1/2/4/8 MI355X",
             "value": world * F * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -257,8 +283,11 @@ def main() -> int:
             "config": {"workload": "vszip.BoxBlur hradius=vradius=13, 3840x2160 YUV420P16, splitmix64 noise, HBM-resident",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "boxblur_ct_ring_kernel<u16,13> (+ boxblur_ct_krow_kernel pre-pass, included in the time)",
-                         "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": profile_traffic("boxblur_ct_ring_kernel<unsigned short, 13", F) if a.radius == RADIUS else None,
+                         "kernel": "boxblur_ct_ring_kernel<u16,13>", "avg_launch_us": avg_s * 1e6, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "whole_filter": {"note": "K_row pre-pass + ring kernel + launch gaps, HIP events over the whole timed region",
+                                          "avg_us": group_s * 1e6, "achieved": alg_bytes / group_s / 1e9, "frac": alg_bytes / group_s / 1e9 / HBM_PEAK_GBS}},
         }
         del keep
         if rank == 0 and world == 1 and not a.no_cpu:
@@ -267,14 +296,18 @@ def main() -> int:
             others = {}
             for name, (w, h, nf) in {"bilateral_1080p": (W1080, H1080, 16), "bilateral_4k": (W4K, H4K, 8)}.items():
                 st, keep = setup_bilateral(dev, w, h, nf)
-                dt2, kms = timed.run(st, 10, 2)
+                dt2, kms, dms, nl = timed.run(st, 10, 2)
+                fb2 = sum(2 * s_[0] * s_[1] for s_ in yuv420_shapes(w, h))
                 others[name] = {"value": nf * 10 / dt2, "unit": "frames/s", "kernel_ms_per_frame": kms / (10 * nf),
+                                "roofline": {"bound": "hbm", "achieved": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                             "kernel": "bilateral_truncated_kernel<u16>", "avg_launch_us": dms * 1e3 / nl},
                                 "workload": f"vszip.Bilateral sigmaS=2 sigmaR=2 {w}x{h} YUV420P16 (natural content tiled), HBM-resident"}
                 if not a.no_cpu:
                     others[name]["cpu_baseline"] = cpu_bilateral(w, h, 5.0 if h < 2000 else 3.0)
                 del keep
             st, keep = setup_ssimulacra2(dev, W4K, H4K, 4)
-            dt3, kms = timed.run(st, 5, 1)
+            dt3, kms, _, _ = timed.run(st, 5, 1)
             others["ssimulacra2_4k"] = {"value": 4 * 5 / dt3, "unit": "pairs/s", "ms_per_pair": dt3 * 1e3 / 20,
                                         "workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS (linear), HBM-resident; includes the scalar D2H + sync"}
             if not a.no_cpu:
@@ -283,10 +316,10 @@ def main() -> int:
             out["others"] = others
     elif a.workload == "bilateral":
         step, keep = setup_bilateral(dev, W1080, H1080, F)
-        dt, kernel_ms = timed.run(step, a.steps, a.warmup)
+        dt, _, dom_ms, launches = timed.run(step, a.steps, a.warmup)
         dt = max_over_ranks(dt)
         fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W1080, H1080))
-        avg_s = kernel_ms * 1e-3 / a.steps
+        avg_s = dom_ms * 1e-3 / a.steps
         achieved = 2 * fb * F / avg_s / 1e9
         out = {"metric": "frames/sec: vszip.Bilateral sigmaS=2 sigmaR=2 1920x1080 YUV420P16", "value": world * F * a.steps / dt, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
@@ -299,16 +332,16 @@ def main() -> int:
     else:
         pairs = max(1, F // 4)
         step, keep = setup_ssimulacra2(dev, W4K, H4K, pairs)
-        dt, kernel_ms = timed.run(step, a.steps, a.warmup)
+        dt, kernel_ms, _, _ = timed.run(step, a.steps, a.warmup)
         dt = max_over_ranks(dt)
-        avg_s = kernel_ms * 1e-3 / a.steps
+        avg_s = kernel_ms * 1e-3 / a.steps  # whole pipeline (6 scales x {xyb/downscale, maps} + final), not one kernel
         achieved = 2 * 3 * W4K * H4K * 4 * pairs / avg_s / 1e9
         out = {"metric": "pairs/sec: vszip.SSIMULACRA2 3840x2160 RGBS", "value": world * pairs * a.steps / dt, "unit": "pairs/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS linear", "pairs_per_step_per_gpu": pairs},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": "ssim_maps_kernel"}}
+                            "kernel": "whole SSIMULACRA2 pipeline (ssim_xyb_down + ssim_maps x6 scales + ssim_final); algorithmic bytes = the two input frames"}}
         if rank == 0 and world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K)
 

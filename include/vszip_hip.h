@@ -65,6 +65,13 @@ int vszip_copy_d2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src,
 /* ---- timing helpers (HIP events on the context stream; used by bench.py) -- */
 int vszip_timer_start(vszip_ctx *ctx);
 int vszip_timer_stop_ms(vszip_ctx *ctx, float *ms); /* synchronises */
+/* Dominant-kernel probe: while enabled, every filter call brackets the launch of its dominant
+ * kernel (BoxBlur: the CT ring kernel; Bilateral: the truncated-window kernel; SSIMULACRA2: the
+ * per-scale maps kernel) with HIP events on the context's stream. vszip_probe_read synchronises,
+ * returns the summed kernel time and the number of launches, and resets the probe. Measurement
+ * aid for bench.py's roofline (the figure rocprofv3 --kernel-trace reports per kernel). */
+int vszip_probe_enable(vszip_ctx *ctx, int on);
+int vszip_probe_read(vszip_ctx *ctx, double *total_ms, int *launches);
 
 /* One plane of one frame. Strides in elements of the sample type. */
 typedef struct vszip_plane {

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn one tools/prof.sh output directory (gpurun_out/prof_<tag>) into the tracked summaries
+under profiles/:  <name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
+<name>_pmc.json (per-kernel mean counter values + HBM traffic per launch) and <name>.md.
+
+HBM traffic per launch follows MI355X_MICROARCH.md "HBM / rocprofv3": FETCH_SIZE and WRITE_SIZE
+come from separate --pmc passes; rocprofv3 reports both in KB (1024 B). On gfx950 FETCH_SIZE
+tallies the 128-B requests of wide coalesced streaming reads at 64 B, so it is doubled;
+WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+usage: summarize_prof.py gpurun_out/prof_<tag> profiles/<name>
+"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+
+def short(name: str) -> str:
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0]
+
+
+def main():
+    src, dst = Path(sys.argv[1]), Path(sys.argv[2])
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    stats = glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv"))
+    rows = []
+    if stats:
+        shutil.copy(stats[0], f"{dst}_kernel_stats.csv")
+        rows = list(csv.DictReader(open(stats[0])))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(str(src / "pmc_*" / "*" / "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    pmc = {}
+    for k, d in agg.items():
+        m = {c: sum(v) / len(v) for c, v in d.items()}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            m["hbm_read_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE = half the bytes
+            m["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
+            m["hbm_traffic_bytes_per_launch"] = m["hbm_read_bytes_per_launch"] + m["hbm_write_bytes_per_launch"]
+        m["dispatches_sampled"] = max(len(v) for v in d.values())
+        pmc[k] = m
+    bench = None
+    bj = src / "bench_trace.json"
+    if bj.exists():
+        for line in bj.read_text().splitlines():
+            if line.startswith("{"):
+                bench = json.loads(line)
+    json.dump({"source": str(src), "bench_line_under_tracing": bench, "kernels": pmc}, open(f"{dst}_pmc.json", "w"), indent=1)
+    with open(f"{dst}.md", "w") as o:
+        o.write(f"# {dst.name}: rocprofv3 summary\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu ...` (tools/prof.sh), PMC in separate passes.\n\n")
+        o.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+        for r in rows:
+            o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |\n")
+        o.write("\n## PMC (mean per dispatch)\n\n")
+        for k, m in pmc.items():
+            o.write(f"### `{k}`\n\n")
+            for c, v in sorted(m.items()):
+                o.write(f"- {c}: {v:,.1f}\n")
+            o.write("\n")
+    print(open(f"{dst}.md").read())
+
+
+if __name__ == "__main__":
+    main()

@@ -5,3 +5,4 @@ so import it through the `vszip_amd` shim at the repo root:  `import vszip_amd`.
 """
 from . import capi  # noqa: F401
 from .capi import Device, DevPlane, VszipError  # noqa: F401
+from . import cluster  # noqa: F401

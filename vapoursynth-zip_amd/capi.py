@@ -68,6 +68,8 @@ SYMBOLS = {
     "vszip_copy_d2d_2d": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "vszip_timer_start": (_i, [_vp]),
     "vszip_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "vszip_probe_enable": (_i, [_vp, _i]),
+    "vszip_probe_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     "vszip_boxblur": (_i, [_vp, _i, _PP, _i, _i, _i, _i, _i]),
     "vszip_bilateral_derive": (_i, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _i, _i,
                                     C.POINTER(C.c_int), C.POINTER(BilateralCfg)]),
@@ -176,6 +178,15 @@ class Device:
     # -- timing ---------------------------------------------------------------
     def timer_start(self):
         self.check(self.lib.vszip_timer_start(self.ctx))
+
+    def probe_enable(self, on: bool):
+        self.check(self.lib.vszip_probe_enable(self.ctx, int(on)))
+
+    def probe_read(self):
+        """(summed dominant-kernel ms, launches) since the probe was enabled / last read."""
+        ms, n = C.c_double(), C.c_int()
+        self.check(self.lib.vszip_probe_read(self.ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def timer_stop_ms(self) -> float:
         ms = C.c_float()

@@ -121,7 +121,10 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_truncated_kernel(const BLP
 
 template <typename T>
 int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks) {
-    hipLaunchKernelGGL((bilateral_truncated_kernel<T>), dim3(blocks), dim3(kBX, kBY), 0, ctx->stream, prm);
+    {
+        vszip_probe_scope probe(ctx);
+        hipLaunchKernelGGL((bilateral_truncated_kernel<T>), dim3(blocks), dim3(kBX, kBY), 0, ctx->stream, prm);
+    }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }

@@ -38,11 +38,15 @@
 //   boxblur_ct_int_kernel   (any alignment / stride): window rows re-read from
 //     cache, first lanes own columns [0, r] for E_0.
 #pragma once
+#include <cstdlib>
 #include <utility>
 
 #include "common.hpp"
 
 namespace {
+
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t U32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxPlanes = 48;  // planes per launch (kernel-argument table)
 constexpr int PX = 8;           // pixels per lane per row
@@ -55,6 +59,7 @@ struct BBPlane {
     int block0;  // first block index of this plane
     int ntx;     // column tiles
     int nbands;  // row bands
+    int nperiods;  // ring kernel: ring periods covering the plane, ceil(h / NR), split evenly over the bands
     int krow0;   // first entry of this plane in the per-row K table (ring kernel)
     int kblk0;   // first block of this plane in the K_row kernel's grid
 };
@@ -421,13 +426,43 @@ struct RingWave {
     uint32_t srow, drow;  // row pitches in bytes
     int w, h, lane, c0;
     bool rev, ld_ok, is_out, out_full;
-    bool any_rev;  // wave-uniform: this tile has mirrored lanes
     bool plain;    // wave-uniform: every row this band touches is an interior source row
+    // Raw buffer descriptors of the two planes: the row offset rides in an SGPR (soffset) and
+    // a lane is switched off by giving it an out-of-range voffset (the hardware drops the
+    // access), so every step issues exactly one load and one store with no divergent
+    // branch around them — the s_waitcnt vmcnt() counts stay exact and D rows deep.
+    __amdgpu_buffer_rsrc_t rs, rd;
+    uint32_t sdoff;  // store voffset: doff for output lanes, kOOB for halo lanes
+    uint32_t psel;   // v_perm selector: identity, or "reversed half of the mirror partner" (mirrored lanes)
+    static constexpr uint32_t kOOB = 0xfffffff0u;
 
     __device__ __forceinline__ Raw8<T> fetch_off(uint32_t row_off) const {
         Raw8<T> t;
-        t.q = *reinterpret_cast<const Vec *>(srcb + (row_off + coff));
+        if constexpr (sizeof(T) == 2) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, coff, row_off, 0);
+            t.q = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, coff, row_off, 0);
+            t.q = make_uint2(v[0], v[1]);
+        }
         return t;
+    }
+    // Mirrored lanes hold the 8 pixels of their mirror image; put them in plane order
+    // (reversed) once, when the row enters the window: one v_perm per dword with a
+    // per-lane selector, identity for ordinary lanes.
+    __device__ __forceinline__ void fix_order(Raw8<T> &r) const {
+        if constexpr (GENERAL) return;
+        if constexpr (sizeof(T) == 2) {
+            const uint4 o = r.q;
+            r.q.x = __builtin_amdgcn_perm(o.w, o.x, psel);
+            r.q.y = __builtin_amdgcn_perm(o.z, o.y, psel);
+            r.q.z = __builtin_amdgcn_perm(o.y, o.z, psel);
+            r.q.w = __builtin_amdgcn_perm(o.x, o.w, psel);
+        } else {
+            const uint2 o = r.q;
+            r.q.x = __builtin_amdgcn_perm(o.y, o.x, psel);
+            r.q.y = __builtin_amdgcn_perm(o.x, o.y, psel);
+        }
     }
     // Virtual row v of the sliding window -> source row. Above the top edge: |v|
     // (reflect-101, boxblur_comptime.zig:56-59). Past the bottom edge the window
@@ -446,13 +481,16 @@ struct RingWave {
     template <int J>
     __device__ __forceinline__ void accum() {
         uint32_t v[PX];
+        fix_order(ring[J]);
         unpack8(ring[J], v);
 #pragma unroll
         for (int k = 0; k < PX; ++k) col[k] += v[k];
     }
+    // the D prefetched rows first: loads return in order, so by the time the window rows
+    // have been summed the first steps of the band find their entering rows in place
     template <int... J>
     __device__ __forceinline__ void fill_all(int y0, std::integer_sequence<int, J...>) {
-        (fill<J>(y0), ...);
+        (fill<(J + G::K) % NR>(y0), ...);
     }
     template <int... J>
     __device__ __forceinline__ void accum_all(std::integer_sequence<int, J...>) {
@@ -499,40 +537,63 @@ struct RingWave {
     // dst[x] = (inv2*E_x + K_row) >> 16 (hBlurInt :130-159 in closed form). The 16.16
     // sum is the running mean + 0.5 and never exceeds 65535.5 * 65536, so it fits 32
     // bits: one 24-bit multiply-add per pixel, the result is the high half.
-    __device__ __forceinline__ void emit_row(const uint32_t e[PX], uint32_t row_off_bytes, uint32_t kr) const {
+    __device__ __forceinline__ void emit_row(const uint32_t e[PX], uint32_t row_off_bytes, uint32_t kr, bool live) const {
 #ifdef VSZIP_ABL_NOEMIT
         return;
 #endif
-        if (!is_out) return;
+        if constexpr (GENERAL) {
+            if (!live || !is_out) return;
+        }
         uint32_t t[PX];
 #pragma unroll
         for (int k = 0; k < PX; ++k) t[k] = __umul24(e[k], INV2) + kr;
 #ifdef VSZIP_ABL_NOSTORE
         if (t[0] + t[3] + t[7] != 0x12345u) return;  // keeps the arithmetic alive, never stores
 #endif
-        T *q = reinterpret_cast<T *>(dstb + (row_off_bytes + doff));
-        if (!GENERAL || out_full) {
+        if constexpr (!GENERAL) {
+            const uint32_t vo = live ? sdoff : kOOB;
             if constexpr (sizeof(T) == 2) {
-                uint4 v;
+                U32x4 v;
                 v.x = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u);
                 v.y = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u);
                 v.z = __builtin_amdgcn_perm(t[5], t[4], 0x07060302u);
                 v.w = __builtin_amdgcn_perm(t[7], t[6], 0x07060302u);
-                *reinterpret_cast<uint4 *>(q) = v;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, vo, row_off_bytes, 0);
             } else {
-                uint2 v;
+                U32x2 v;
                 const uint32_t a0 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u);  // bytes: t0.2, t1.2, 0, 0
                 const uint32_t a1 = __builtin_amdgcn_perm(t[3], t[2], 0x0c0c0602u);
                 const uint32_t a2 = __builtin_amdgcn_perm(t[5], t[4], 0x0c0c0602u);
                 const uint32_t a3 = __builtin_amdgcn_perm(t[7], t[6], 0x0c0c0602u);
                 v.x = a0 | (a1 << 16);
                 v.y = a2 | (a3 << 16);
-                *reinterpret_cast<uint2 *>(q) = v;
+                __builtin_amdgcn_raw_buffer_store_b64(v, rd, vo, row_off_bytes, 0);
             }
         } else {
+            T *q = reinterpret_cast<T *>(dstb + (row_off_bytes + doff));
+            if (out_full) {
+                if constexpr (sizeof(T) == 2) {
+                    uint4 v;
+                    v.x = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u);
+                    v.y = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u);
+                    v.z = __builtin_amdgcn_perm(t[5], t[4], 0x07060302u);
+                    v.w = __builtin_amdgcn_perm(t[7], t[6], 0x07060302u);
+                    *reinterpret_cast<uint4 *>(q) = v;
+                } else {
+                    uint2 v;
+                    const uint32_t a0 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u);
+                    const uint32_t a1 = __builtin_amdgcn_perm(t[3], t[2], 0x0c0c0602u);
+                    const uint32_t a2 = __builtin_amdgcn_perm(t[5], t[4], 0x0c0c0602u);
+                    const uint32_t a3 = __builtin_amdgcn_perm(t[7], t[6], 0x0c0c0602u);
+                    v.x = a0 | (a1 << 16);
+                    v.y = a2 | (a3 << 16);
+                    *reinterpret_cast<uint2 *>(q) = v;
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < PX; ++k)
-                if (c0 + k < w) q[k] = (T)(t[k] >> 16);
+                for (int k = 0; k < PX; ++k)
+                    if (c0 + k < w) q[k] = (T)(t[k] >> 16);
+            }
         }
     }
 
@@ -545,47 +606,65 @@ struct RingWave {
     __device__ __forceinline__ void step(int i, int y0) {
         uint32_t *Pa = P + (S & 1) * (64 * PX);
         const uint32_t *Pb = P + ((S & 1) ^ 1) * (64 * PX);
+        // Steps are scheduled one at a time: without the fence the scheduler hoists the first
+        // use of a prefetched row (fix_order) to just behind its load, and the s_waitcnt that
+        // comes with it collapses the D-row prefetch distance to about one row.
+        __builtin_amdgcn_sched_barrier(0);
 
-        // B (first half): LDS reads of the previous row's prefix
+        // B (first half): LDS reads of the previous row's prefix. The very first step of a
+        // band has no previous row: it reads stale LDS and its store is switched off.
         uint32_t e[PX];
         const bool have_prev = S > 0 || i > y0;
-        if (have_prev) window_sums(Pb, e);
+#ifdef VSZIP_ABL_NOLDS
+#pragma unroll
+        for (int k = 0; k < PX; ++k) e[k] = col[k] ^ (uint32_t)k;
+#else
+        if (!GENERAL || have_prev) window_sums(Pb, e);
+#endif
 
         // A: vertical mean, rounded (:114-128; col carries the +r), wave-wide inclusive prefix
-        uint32_t t[PX], p[PX];
+        uint32_t p[PX];
 #pragma unroll
-#ifdef VSZIP_DIV24
-        for (int k = 0; k < PX; ++k) t[k] = (uint32_t)(((uint64_t)(col[k] & 0xffffffu) * G::DIVM) >> G::DIVS);
+#if defined(VSZIP_ABL_MULHI)
+        for (int k = 0; k < PX; ++k) p[k] = col[k] >> 5;
+#elif defined(VSZIP_DIV24)
+        for (int k = 0; k < PX; ++k) p[k] = (uint32_t)(((uint64_t)(col[k] & 0xffffffu) * G::DIVM) >> G::DIVS);
 #else
-        for (int k = 0; k < PX; ++k) t[k] = __umulhi(col[k], G::MAGIC);
+        for (int k = 0; k < PX; ++k) p[k] = __umulhi(col[k], G::MAGIC);
 #endif
-        if constexpr (!GENERAL) {
-            // mirrored lanes hold their pixels in reverse plane order
-            if (any_rev) {
-#pragma unroll
-                for (int k = 0; k < PX; ++k) p[k] = rev ? t[PX - 1 - k] : t[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < PX; ++k) p[k] = t[k];
-            }
-        } else {
+        if constexpr (GENERAL) {
             const uint32_t m = ld_ok ? 0xffffffffu : 0u;  // lanes outside the plane hold zeros
 #pragma unroll
-            for (int k = 0; k < PX; ++k) p[k] = t[k] & m;
+            for (int k = 0; k < PX; ++k) p[k] &= m;
         }
 #pragma unroll
         for (int k = 1; k < PX; ++k) p[k] += p[k - 1];
+#ifdef VSZIP_ABL_NOSCAN
+        const uint32_t incl = p[PX - 1] * 3u;
+#else
         const uint32_t incl = wave_incl_scan_dpp(p[PX - 1]);
+#endif
         const uint32_t base = incl - p[PX - 1];
+#ifdef VSZIP_ABL_NOLDS
+        {
+            uint32_t x = base;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) x ^= p[k];
+            if (x == 0x12345u) Pa[lane] = x;
+        }
+#else
 #pragma unroll
         for (int k = 0; k < PX; ++k) Pa[k * 64 + lane] = p[k] + base;
+#endif
 
         // slide the window to row i+1: entering row i+1+r (or row i once the window
         // hangs over the bottom edge, :61-66), leaving row i-r; refill the freed slot
         // with row i+1+r+D (|v| above the top edge, clamped below the bottom edge).
         {
+            constexpr int E = (S + 1 + 2 * R) % NR;
             uint32_t a[PX], sb[PX];
-            unpack8(ring[(S + 1 + 2 * R) % NR], a);
+            fix_order(ring[E]);
+            unpack8(ring[E], a);
             unpack8(ring[S], sb);
 #pragma unroll
             for (int k = 0; k < PX; ++k) col[k] += a[k] - sb[k];
@@ -593,17 +672,15 @@ struct RingWave {
             ring[S] = fetch_off(next_off);
 #endif
             // advance the refill row: plain bands just step down one row
-            if (plain)
-                next_off += srow;
-            else
-                next_off = row_off(i + 2 + R + G::D);
+            const uint32_t edge_off = row_off(i + 2 + R + G::D);
+            next_off = plain ? next_off + srow : edge_off;
         }
 
         // B (second half): scale and store the previous row
-        if (have_prev) {
+        {
             const uint32_t kr = S > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)krv, S > 0 ? S - 1 : 0) : kr_carry;
-            emit_row(e, out_off, kr);
-            out_off += drow;
+            emit_row(e, out_off, kr, have_prev);
+            out_off += have_prev ? drow : 0u;
         }
         if (S == NR - 1) kr_carry = (uint32_t)__builtin_amdgcn_readlane((int)krv, NR - 1);
         wave_lds_fence();
@@ -640,7 +717,12 @@ __global__ __launch_bounds__(64, VSZIP_RING_WPE) void boxblur_ct_ring_kernel(con
     const int lb = b - pl.block0;
     const int tx = lb % pl.ntx;
     const int by = lb / pl.ntx;
-    const int y0 = min(by * prm.band_rows, pl.h - prm.band_rows);  // last band shifted up
+    // band `by` owns ring periods [by*P/nb, (by+1)*P/nb); the last band is shifted up to end
+    // at the last row (it recomputes < NR rows of its neighbour, writing identical values)
+    const int p0 = (int)((long)by * pl.nperiods / pl.nbands);
+    const int p1 = (int)((long)(by + 1) * pl.nperiods / pl.nbands);
+    const int band_rows = (p1 - p0) * G::NR;
+    const int y0 = min(p0 * G::NR, pl.h - band_rows);
     const int w = pl.w;
 
     W st;
@@ -679,8 +761,12 @@ __global__ __launch_bounds__(64, VSZIP_RING_WPE) void boxblur_ct_ring_kernel(con
         st.coff = (uint32_t)(min(max(vc0, 0), ((w - 1) / PX) * PX) * (int)sizeof(T));
     }
 
-    st.any_rev = !GENERAL && (tx == 0 || (tx + 1) * G::TWO + G::HR > w);
-    st.plain = (y0 - R >= 0) && (y0 + prm.band_rows + R + G::D + 2 < pl.h);
+    st.psel = st.rev ? (sizeof(T) == 2 ? 0x05040706u : 0x04050607u) : 0x03020100u;
+    st.sdoff = st.is_out ? st.doff : W::kOOB;
+    // descriptors: raw (stride 0), 32-bit data format; num_records = plane bytes (ring_ok keeps it < 4 GiB)
+    st.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pl.src), 0, (int)((uint32_t)pl.h * st.srow), 0x00020000);
+    st.rd = __builtin_amdgcn_make_buffer_rsrc(pl.dst, 0, (int)((uint32_t)pl.h * st.drow), 0x00020000);
+    st.plain = (y0 - R >= 0) && (y0 + band_rows + R + G::D + 2 < pl.h);
 
     st.fill_all(y0, std::make_integer_sequence<int, G::NR>{});
 #pragma unroll
@@ -690,13 +776,13 @@ __global__ __launch_bounds__(64, VSZIP_RING_WPE) void boxblur_ct_ring_kernel(con
     st.next_off = st.row_off(y0 + 1 + R + G::D);  // window rows y0-r .. y0+r+D are in the ring
     st.out_off = (uint32_t)y0 * st.drow;
 
-    const int y1 = y0 + prm.band_rows;
+    const int y1 = y0 + band_rows;
 #pragma unroll 1
     for (int i0 = y0; i0 < y1; i0 += G::NR) st.period(i0, y0, std::make_integer_sequence<int, G::NR>{});
     {
         uint32_t e[PX];  // last row of the band: slot NR-1 wrote the odd buffer
         st.window_sums(P + 64 * PX, e);
-        st.emit_row(e, st.out_off, st.kr_carry);
+        st.emit_row(e, st.out_off, st.kr_carry, true);
     }
 }
 
@@ -754,26 +840,37 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     while (done < nplanes) {
         BBParams prm;
         const int n = std::min(kMaxPlanes, nplanes - done);
-        long wave_rows = 0;
-        int total_rows = 0, min_h = 1 << 30;
+        int total_rows = 0;
         bool mult8 = true;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
-            wave_rows += (long)((s.w + G::TWO - 1) / G::TWO) * s.h;
             total_rows += s.h;
-            min_h = std::min(min_h, (int)s.h);
             mult8 = mult8 && (s.w % PX == 0);
         }
-        // rows per band = whole ring periods: at least ~4 generations of the waves the
-        // chip holds at two waves per SIMD, so the last generation's tail stays small
-        int periods = 4;
-        while (periods > 1 && (wave_rows / ((long)periods * G::NR) < 8192 || periods * G::NR > min_h)) --periods;
-        const int band = periods * G::NR;
+        // Band length. The kernel is HBM-bound once about 1500 waves are resident (measured:
+        // tools/membw.hip), so take the longest bands (fewest re-read halo rows: 2r+D per
+        // band) that still leave that many waves; every plane is cut into bands of about
+        // `target` ring periods so that all waves run about equally long.
+        // a shifted-up last band must fit the plane: two bands at least when h is not whole periods
+        auto bands_for = [](int h, int P, int target) { return std::max((h % G::NR != 0 && P >= 2) ? 2 : 1, (P + target / 2) / target); };
+        auto waves_for = [&](int target) {
+            long wv = 0;
+            for (int i = 0; i < n; ++i) {
+                const vszip_plane &s = planes[done + i];
+                const int P = (s.h + G::NR - 1) / G::NR;
+                wv += (long)((s.w + G::TWO - 1) / G::TWO) * bands_for(s.h, P, target);
+            }
+            return wv;
+        };
+        int target = 1;
+        for (int t = 2; t <= 64; ++t)
+            if (waves_for(t) >= 1536) target = t;
+        if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         int rc = vszip_ensure_scratch(ctx, (size_t)total_rows * sizeof(uint32_t));
         if (rc != VSZIP_OK) return rc;
         prm.nplanes = n;
-        prm.band_rows = band;
+        prm.band_rows = 0;
         prm.krow = static_cast<uint32_t *>(ctx->scratch);
         int blocks = 0, kblocks = 0, rows = 0;
         for (int i = 0; i < n; ++i) {
@@ -785,7 +882,8 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             d.dstride = (int)s.dst_stride;
             d.w = s.w;
             d.h = s.h;
-            d.nbands = (s.h + band - 1) / band;
+            d.nperiods = (s.h + G::NR - 1) / G::NR;
+            d.nbands = bands_for(s.h, d.nperiods, target);
             d.krow0 = rows;
             d.kblk0 = kblocks;
             d.ntx = (s.w + G::TWO - 1) / G::TWO;
@@ -798,10 +896,13 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         hipLaunchKernelGGL((boxblur_ct_krow_kernel<T, R>), dim3(kblocks), dim3(64), 0, ctx->stream, prm);
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
         const dim3 grid(((blocks + 7) / 8) * 8);
-        if (mult8)
-            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false>), grid, dim3(64), 0, ctx->stream, prm);
-        else
-            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
+        {
+            vszip_probe_scope probe(ctx);
+            if (mult8)
+                hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false>), grid, dim3(64), 0, ctx->stream, prm);
+            else
+                hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
+        }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
         done += n;
     }

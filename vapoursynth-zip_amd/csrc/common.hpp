@@ -26,12 +26,24 @@ struct vszip_ctx {
     void *scalars_dev = nullptr;
     void *scalars_host = nullptr;
     size_t scalars_bytes = 0;
+    // dominant-kernel probe (vszip_probe_*): HIP event pairs recorded on `stream` around the
+    // kernel a filter names as its dominant one; resolved lazily in vszip_probe_read
+    bool probe_on = false;
+    std::vector<hipEvent_t> probe_events;  // begin/end pairs
+    size_t probe_used = 0;
     int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
 };
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
 int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes);
 int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
+// Bracket the launch of a filter's dominant kernel; no-ops unless the probe is enabled.
+void vszip_probe_mark(vszip_ctx *ctx);
+struct vszip_probe_scope {
+    vszip_ctx *c;
+    explicit vszip_probe_scope(vszip_ctx *ctx) : c(ctx) { if (c->probe_on) vszip_probe_mark(c); }
+    ~vszip_probe_scope() { if (c->probe_on) vszip_probe_mark(c); }
+};
 
 #define VSZIP_HIP_CHECK(ctx, call)                                                              \
     do {                                                                                        \

@@ -75,6 +75,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->probe_events) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -159,5 +160,38 @@ VSZIP_EXPORT int vszip_timer_stop_ms(vszip_ctx *ctx, float *ms) {
     VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     VSZIP_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
     VSZIP_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VSZIP_OK;
+}
+
+// ---- dominant-kernel probe --------------------------------------------------
+void vszip_probe_mark(vszip_ctx *ctx) {
+    if (ctx->probe_used == ctx->probe_events.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ctx->probe_events.push_back(e);
+    }
+    (void)hipEventRecord(ctx->probe_events[ctx->probe_used++], ctx->stream);
+}
+
+VSZIP_EXPORT int vszip_probe_enable(vszip_ctx *ctx, int on) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    ctx->probe_on = on != 0;
+    ctx->probe_used = 0;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_probe_read(vszip_ctx *ctx, double *total_ms, int *launches) {
+    if (!ctx || !total_ms || !launches) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    const size_t pairs = ctx->probe_used / 2;
+    for (size_t i = 0; i < pairs; ++i) {
+        float ms = 0;
+        VSZIP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->probe_events[2 * i], ctx->probe_events[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int)pairs;
+    ctx->probe_used = 0;
     return VSZIP_OK;
 }

@@ -451,7 +451,10 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
             ma.tiles_y = (ch + TH - 1) / TH;
             ma.partial = partial;
             ma.max_tiles = tiles0;
-            if (ma.nactive > 0) hipLaunchKernelGGL(ssim_maps_kernel, dim3(ma.tiles_x, ma.tiles_y, ma.nactive), dim3(256), 0, ctx->stream, ma);
+            if (ma.nactive > 0) {
+                vszip_probe_scope probe(ctx);
+                hipLaunchKernelGGL(ssim_maps_kernel, dim3(ma.tiles_x, ma.tiles_y, ma.nactive), dim3(256), 0, ctx->stream, ma);
+            }
             for (int k = 0; k < ma.nactive; ++k) {
                 fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
                 fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
