@@ -218,6 +218,47 @@ def setup_ssimulacra2(dev, w, h, pairs):
     return (lambda: dev.ssimulacra2(r, d)), (r, d)
 
 
+def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, rounds: int = 12):
+    """PCIe-inclusive BoxBlur rate, the path a VapourSynth host pays: every frame is copied from
+    pinned host memory to the GPU, blurred, and copied back. `nctx` contexts (one stream each,
+    like the plugin's per-worker contexts) keep H2D, kernels and D2H of different frames in flight."""
+    ctxs = []
+    for c in range(nctx):
+        d = vszip_amd.Device(device_index)
+        frame = make_frame(c, W4K, H4K)
+        hin = [d.pinned_array(p.shape, p.dtype) for p in frame]
+        hout = [d.pinned_array(p.shape, p.dtype) for p in frame]
+        for a, p in zip(hin, frame):
+            a[...] = p
+        dsrc = [d.empty(p.shape[0], p.shape[1], p.dtype) for p in frame]
+        ddst = [d.empty(p.shape[0], p.shape[1], p.dtype) for p in frame]
+        ctxs.append((d, hin, hout, dsrc, ddst, d.plane_table(dsrc, ddst)))
+
+    def one_round():
+        for d, hin, hout, dsrc, ddst, table in ctxs:
+            for a, dp in zip(hin, dsrc):
+                d.copy_in(dp, a)
+            d.boxblur_table(np.uint16, table, radius, 1, radius, 1)
+            for a, dp in zip(hout, ddst):
+                d.copy_out(a, dp)
+        for c in ctxs:
+            c[0].sync()
+
+    one_round()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        one_round()
+    dt = time.perf_counter() - t0
+    fps = nctx * rounds / dt
+    fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K))
+    res = {"value": fps, "unit": "frames/s", "host_to_host": True, "contexts": nctx,
+           "pcie_GBps_each_direction": fps * fb / 1e9,
+           "workload": "vszip.BoxBlur r=13 3840x2160 YUV420P16, pinned host frame -> GPU -> pinned host frame (never the headline value)"}
+    for c in ctxs:
+        c[0].close()
+    return res
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +354,10 @@ def main() -> int:
             if not a.no_cpu:
                 others["ssimulacra2_4k"]["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K, 6.0)
             del keep
+            try:
+                others["boxblur_4k_pcie"] = pcie_boxblur(vszip_amd, local_rank, a.radius)
+            except Exception as e:  # the PCIe leg is informative only
+                others["boxblur_4k_pcie"] = {"error": str(e)}
             out["others"] = others
     elif a.workload == "bilateral":
         step, keep = setup_bilateral(dev, W1080, H1080, F)

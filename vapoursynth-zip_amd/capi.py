@@ -144,6 +144,9 @@ class Device:
 
     def close(self):
         if self.ctx:
+            for hp in getattr(self, "_pinned", []):
+                self.lib.vszip_host_free_pinned(self.ctx, C.c_void_p(hp))
+            self._pinned = []
             self.lib.vszip_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -168,6 +171,25 @@ class Device:
         self.check(self.lib.vszip_copy_h2d_2d(self.ctx, d.ptr, d.stride * a.itemsize, a.ctypes.data, a.strides[0], a.shape[1] * a.itemsize, a.shape[0]))
         self.sync()
         return d
+
+    def pinned_array(self, shape, dtype) -> np.ndarray:
+        """Host array in page-locked memory (async copies; what a plugin keeps per worker)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self.check(self.lib.vszip_host_alloc_pinned(self.ctx, n, C.byref(p)))
+        buf = (C.c_char * n).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", []) + [p.value]
+        return a
+
+    def copy_in(self, d: DevPlane, a: np.ndarray):
+        """Async H2D of a host array into an existing device plane (no synchronisation)."""
+        self.check(self.lib.vszip_copy_h2d_2d(self.ctx, d.ptr, d.stride * a.itemsize, a.ctypes.data, a.strides[0], a.shape[1] * a.itemsize, a.shape[0]))
+
+    def copy_out(self, a: np.ndarray, d: DevPlane):
+        """Async D2H of a device plane into a host array (no synchronisation)."""
+        self.check(self.lib.vszip_copy_d2h_2d(self.ctx, a.ctypes.data, a.strides[0], d.ptr, d.stride * d.dtype.itemsize, d.w * d.dtype.itemsize, d.h))
 
     def download(self, d: DevPlane) -> np.ndarray:
         out = np.empty((d.h, d.w), dtype=d.dtype)

@@ -312,6 +312,13 @@ struct RingGeom {
     static constexpr int D = 3;
 #endif
     static constexpr int NR = 2 * R + 1 + D;   // ring slots (<= 64: K_row travels by readlane)
+    // waves per SIMD the kernel is compiled for: the ring takes NR * SLOT_VGPRS registers, the
+    // rest of a step about 48 (r=13 u16: 120 + 46 = 166 <= 168 -> 3 waves). 512 VGPRs per SIMD lane.
+#ifdef VSZIP_RING_WPE
+    static constexpr int WPE = VSZIP_RING_WPE;
+#else
+    static constexpr int WPE = NR * SLOT_VGPRS + 56 <= 128 ? 4 : (NR * SLOT_VGPRS + 48 <= 168 ? 3 : 2);
+#endif
     static constexpr int EC = HL;              // columns the K_row kernel loads (>= R + 1)
     // tmp = (col + r) / k as (n * DIVM) >> DIVS with 24-bit operands (full-rate
     // v_mul_u32_u24 / v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32):
@@ -693,12 +700,8 @@ struct RingWave {
     }
 };
 
-#ifndef VSZIP_RING_WPE
-#define VSZIP_RING_WPE 2
-#endif
-
 template <typename T, int R, bool GENERAL>
-__global__ __launch_bounds__(64, VSZIP_RING_WPE) void boxblur_ct_ring_kernel(const BBParams prm) {
+__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX / 4)>::WPE)) void boxblur_ct_ring_kernel(const BBParams prm) {
     using W = RingWave<T, R, GENERAL>;
     using G = typename W::G;
     static_assert(G::NR % 2 == 0 && G::NR <= 64, "ring period must be even and fit a wave");
@@ -847,8 +850,8 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             total_rows += s.h;
             mult8 = mult8 && (s.w % PX == 0);
         }
-        // Band length. The kernel is HBM-bound once about 1500 waves are resident (measured:
-        // tools/membw.hip), so take the longest bands (fewest re-read halo rows: 2r+D per
+        // Band length. The kernel is HBM-bound once most wave slots are filled (measured:
+        // tools/membw.hip, tools/sweep_periods.sh), so take the longest bands (fewest re-read halo rows: 2r+D per
         // band) that still leave that many waves; every plane is cut into bands of about
         // `target` ring periods so that all waves run about equally long.
         // a shifted-up last band must fit the plane: two bands at least when h is not whole periods
@@ -862,9 +865,10 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             }
             return wv;
         };
+        const long min_waves = 256L * 4 * G::WPE * 3 / 4;  // 3/4 of the chip's wave slots for this kernel
         int target = 1;
         for (int t = 2; t <= 64; ++t)
-            if (waves_for(t) >= 1536) target = t;
+            if (waves_for(t) >= min_waves) target = t;
         if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         int rc = vszip_ensure_scratch(ctx, (size_t)total_rows * sizeof(uint32_t));
