@@ -5,7 +5,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
-mkdir -p $out
+rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --no-cpu "$@" > $out/bench_trace.json 2> $out/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $R/bench.py --no-cpu "$@" > /dev/null 2> $out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write -- python3 $R/bench.py --no-cpu "$@" > /dev/null 2> $out/pmc_write.err

@@ -29,12 +29,12 @@
 //   boxblur_ct_ring_kernel  (16-byte aligned planes — every VapourSynth frame):
 //     the 2r+1 window rows stay PACKED IN REGISTERS (a ring of 2r+1+D uint4 per
 //     lane, the row loop unrolled over one ring period so that every slot index
-//     is a compile-time constant), so each source row crosses the fabric once;
-//     rows are prefetched D steps ahead; E_0's term comes from a per-row table
-//     written by boxblur_ct_krow_kernel, which frees two lanes and makes 480
-//     output columns per wave (3840 = 8 tiles, 1920 = 4, 960 = 2); blockIdx is
-//     remapped so that neighbouring tiles/bands run on one XCD and find their
-//     halo in that XCD's L2.
+//     is a compile-time constant), so each source row crosses the fabric once
+//     per band; rows are prefetched D steps ahead; E_0's term is kept per wave
+//     from plane columns 0..r (two 1-pixel loads per step), which frees two
+//     lanes and makes 480 output columns per wave (3840 = 8 tiles, 1920 = 4,
+//     960 = 2); blockIdx is remapped so that neighbouring tiles/bands run on
+//     one XCD and find their halo in that XCD's L2.
 //   boxblur_ct_int_kernel   (any alignment / stride): window rows re-read from
 //     cache, first lanes own columns [0, r] for E_0.
 #pragma once
@@ -60,8 +60,6 @@ struct BBPlane {
     int ntx;     // column tiles
     int nbands;  // row bands
     int nperiods;  // ring kernel: ring periods covering the plane, ceil(h / NR), split evenly over the bands
-    int krow0;   // first entry of this plane in the per-row K table (ring kernel)
-    int kblk0;   // first block of this plane in the K_row kernel's grid
 };
 
 struct BBParams {
@@ -69,7 +67,6 @@ struct BBParams {
     int nplanes;
     int band_rows;
     int nblocks;
-    uint32_t *krow;  // K_row = 32768 + ((E_0 * invlo) >> 16) per plane row
 };
 
 // boxblur_comptime.zig:50-70 — source row of tap k for output row i.
@@ -304,22 +301,30 @@ struct RingGeom {
     static constexpr int HR = ((R + PX - 1) / PX) * PX;      // right halo (>= R)
     static constexpr int OUT_LANES = 64 - HL / PX - HR / PX;
     static constexpr int TWO = OUT_LANES * PX;
-    // rows prefetched ahead of their first use. D is odd so that NR is even (the
-    // LDS double buffer alternates with the slot).
+    // Rows prefetched ahead of their first use: D is odd so that NR is even (the LDS double
+    // buffer alternates with the slot). The ring takes NR * SLOT_VGPRS registers, the rest of a
+    // step about 56 (r=13 u16, D=1: 112 + 55 = 167 <= 168 -> 3 waves per SIMD out of the 512
+    // VGPRs a SIMD lane has). A shallow prefetch (D = 1) is taken when it buys a wave per SIMD —
+    // the other waves then hide the latency; otherwise D is 3, 5 or 7, whichever makes NR a
+    // multiple of KL, the prefetch ring of the K_row column pixels (statically indexed, S % KL).
+    static constexpr int est_vgprs(int d) { return (2 * R + 1 + d) * SLOT_VGPRS + 56; }
+    static constexpr int tier(int v) { return v <= 128 ? 4 : (v <= 168 ? 3 : 2); }
+    static constexpr int D3 = (2 * R + 4) % 3 == 0 ? 3 : ((2 * R + 6) % 3 == 0 ? 5 : 7);
 #ifdef VSZIP_RING_D
     static constexpr int D = VSZIP_RING_D | 1;
+    static constexpr int KL = (2 * R + 1 + D) % 3 == 0 ? 3 : 2;
 #else
-    static constexpr int D = 3;
+    static constexpr bool SHALLOW = tier(est_vgprs(1)) > tier(est_vgprs(D3));
+    static constexpr int D = SHALLOW ? 1 : D3;
+    static constexpr int KL = SHALLOW ? 2 : 3;
 #endif
-    static constexpr int NR = 2 * R + 1 + D;   // ring slots (<= 64: K_row travels by readlane)
-    // waves per SIMD the kernel is compiled for: the ring takes NR * SLOT_VGPRS registers, the
-    // rest of a step about 48 (r=13 u16: 120 + 46 = 166 <= 168 -> 3 waves). 512 VGPRs per SIMD lane.
+    static constexpr int NR = 2 * R + 1 + D;   // ring slots
 #ifdef VSZIP_RING_WPE
     static constexpr int WPE = VSZIP_RING_WPE;
 #else
-    static constexpr int WPE = NR * SLOT_VGPRS + 56 <= 128 ? 4 : (NR * SLOT_VGPRS + 48 <= 168 ? 3 : 2);
+    static constexpr int WPE = tier(est_vgprs(D));
 #endif
-    static constexpr int EC = HL;              // columns the K_row kernel loads (>= R + 1)
+    static_assert(NR % KL == 0, "K-column ring must divide the period");
     // tmp = (col + r) / k as (n * DIVM) >> DIVS with 24-bit operands (full-rate
     // v_mul_u32_u24 / v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32):
     // exact while 2^DIVS > n_max * k (tests/test_oracle_boxblur.py checks every n).
@@ -333,69 +338,6 @@ struct RingGeom {
     static constexpr uint32_t DIVM = (uint32_t)(((1ull << DIVS) + K - 1) / K);
     static_assert(DIVM < (1u << 24) && DIVS < 32, "24-bit reciprocal out of range");
 };
-
-// K_row for every row of every plane: E_0 = tmp[r] + 2*sum_{x<r} tmp[x] needs the
-// vertical means of columns 0..r only (boxblur_comptime.zig:131-137). One wave per
-// 64 rows: every needed source row segment (EC columns) is read from memory once
-// into LDS, each lane then sums its row's 2r+1 taps from LDS.
-template <typename T, int R>
-__global__ __launch_bounds__(64) void boxblur_ct_krow_kernel(const BBParams prm) {
-    using G = RingGeom<R>;
-    constexpr int K = G::K;
-    constexpr uint64_t INV = ((1ull << 32) + R) / K;
-    constexpr uint32_t INVLO = (uint32_t)(INV & 0xffffu);
-    constexpr int ROWS = 64 + 2 * R;
-    constexpr int NV = G::EC / PX;  // lane-vectors per row segment
-    __shared__ __attribute__((aligned(16))) Raw8<T> tile[ROWS * NV];
-
-    const int b = blockIdx.x;
-    int pi = 0;
-#pragma unroll 1
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].kblk0) pi = i;
-    const BBPlane pl = prm.p[pi];
-    const int y0 = (b - pl.kblk0) * 64;
-    const int h = pl.h;
-    const T *src = static_cast<const T *>(pl.src);
-    const int lane = threadIdx.x;
-
-    // tile row j holds virtual row v = y0 - r + j: |v| above the top edge (reflect-101);
-    // rows past the bottom are clamped (the bottom taps below never index them)
-#pragma unroll
-    for (int j0 = 0; j0 < ROWS; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < ROWS) {
-            const int v = y0 - R + j;
-            const T *row = src + (size_t)min(v < 0 ? -v : v, h - 1) * pl.sstride;
-#pragma unroll
-            for (int c = 0; c < NV; ++c) tile[j * NV + c].q = *reinterpret_cast<const decltype(tile[0].q) *>(row + c * PX);
-        }
-    }
-    __syncthreads();
-
-    const int i = y0 + lane;
-    if (i >= h) return;
-    uint32_t col[G::EC];
-#pragma unroll
-    for (int c = 0; c < G::EC; ++c) col[c] = R;
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-        // boxblur_comptime.zig:50-70: taps past the bottom edge mirror about row i
-        const int v = i - R + k;
-        const int j = v <= h - 1 ? lane + k : lane + R - (v - (h - 1));
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            uint32_t x[PX];
-            unpack8(tile[j * NV + c], x);
-#pragma unroll
-            for (int q = 0; q < PX; ++q) col[c * PX + q] += x[q];
-        }
-    }
-    uint32_t e0 = col[R] / (uint32_t)K;
-#pragma unroll
-    for (int c = 0; c < R; ++c) e0 += 2u * (col[c] / (uint32_t)K);
-    prm.krow[pl.krow0 + i] = 32768u + (uint32_t)(((uint64_t)e0 * INVLO) >> 16);
-}
 
 // All per-wave state of the ring kernel. step<S>() is instantiated once per ring
 // slot so that every ring index is a compile-time constant and the ring stays in
@@ -420,12 +362,20 @@ struct RingWave {
 
     Raw8<T> ring[NR];
     uint32_t col[PX];
-    uint32_t krv;       // lane l: K_row of row i0 + l of the current ring period
-    uint32_t kr_carry;  // K_row of the last row of the previous period
+    // K_row = 32768 + ((E_0 * invlo) >> 16) with E_0 = tmp[r] + 2*sum_{x<r} tmp[x] (hBlurInt's
+    // start value, boxblur_comptime.zig:131-137) needs the vertical means of plane columns
+    // 0..r only. Every wave keeps them itself: lane c < 32 slides the column sum of plane column
+    // min(c, r) down its band (one 1-pixel load each for the entering and the leaving row,
+    // prefetched KL steps ahead), a DPP row reduction gives E_0, the scalar unit the rest.
+    uint32_t kcol;        // column sum (+r) of plane column min(lane, r)
+    uint32_t kwgt;        // 2 for lanes < r, 1 for lane r, 0 above
+    uint32_t kvo;         // byte offset of that column in a row
+    uint32_t kn[G::KL], ko[G::KL];  // prefetched entering / leaving pixels
+    uint32_t kn_off, ko_off;        // wave-uniform: row offsets of the next prefetch
+    uint32_t kr_prev;     // wave-uniform: K_row of the previous row
     uint32_t *P;
     const char *srcb;   // wave-uniform plane bases
     char *dstb;
-    const uint32_t *krow;
     uint32_t coff;      // byte offset of this lane's (real) column group in a row
     uint32_t doff;      // byte offset of this lane's output group in a row
     uint32_t next_off;  // wave-uniform: byte offset of the source row the next refill reads
@@ -454,6 +404,30 @@ struct RingWave {
         }
         return t;
     }
+    __device__ __forceinline__ uint32_t fetch_px(uint32_t row_off) const {
+        if constexpr (sizeof(T) == 2)
+            return __builtin_amdgcn_raw_buffer_load_b16(rs, kvo, row_off, 0);
+        else
+            return __builtin_amdgcn_raw_buffer_load_b8(rs, kvo, row_off, 0);
+    }
+    // E_0 of the current row from the K columns: lanes 0..r hold weight * tmp, the rest 0
+    __device__ __forceinline__ uint32_t krow_now() const {
+        constexpr uint32_t INVLO = (uint32_t)(INV & 0xffffu);
+        uint32_t v = __umul24(__umulhi(kcol, G::MAGIC), kwgt);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+        uint32_t e0;
+        if constexpr (R < 16) {
+            e0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+        } else {
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+            e0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+        }
+        return 32768u + (uint32_t)(((uint64_t)e0 * INVLO) >> 16);
+    }
+
     // Mirrored lanes hold the 8 pixels of their mirror image; put them in plane order
     // (reversed) once, when the row enters the window: one v_perm per dword with a
     // per-lane selector, identity for ordinary lanes.
@@ -679,23 +653,48 @@ struct RingWave {
             ring[S] = fetch_off(next_off);
 #endif
             // advance the refill row: plain bands just step down one row
-            const uint32_t edge_off = row_off(i + 2 + R + G::D);
-            next_off = plain ? next_off + srow : edge_off;
+
+        }
+        // K_row of this row (used by the next step's store), then slide the K columns
+        const uint32_t kr_cur = krow_now();
+        {
+            constexpr int J = S % G::KL;
+            kcol += kn[J] - ko[J];
+            kn[J] = fetch_px(kn_off);
+            ko[J] = fetch_px(ko_off);
+
         }
 
         // B (second half): scale and store the previous row
+        emit_row(e, out_off, kr_prev, have_prev);
+        out_off += have_prev ? drow : 0u;
+        kr_prev = kr_cur;
+        // advance the three prefetch rows. Bands that touch no plane edge just step down one
+        // row; the mirror arithmetic (about 20 scalar instructions) sits behind a wave-uniform
+        // branch that holds no memory instruction, so the vmcnt bookkeeping stays exact.
+#ifdef VSZIP_OFFS_SELECT
         {
-            const uint32_t kr = S > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)krv, S > 0 ? S - 1 : 0) : kr_carry;
-            emit_row(e, out_off, kr, have_prev);
-            out_off += have_prev ? drow : 0u;
+            const uint32_t e0 = row_off(i + 2 + R + G::D), e1 = row_off(i + 2 + R + G::KL), e2 = row_off(i + 1 - R + G::KL);
+            next_off = plain ? next_off + srow : e0;
+            kn_off = plain ? kn_off + srow : e1;
+            ko_off = plain ? ko_off + srow : e2;
         }
-        if (S == NR - 1) kr_carry = (uint32_t)__builtin_amdgcn_readlane((int)krv, NR - 1);
+#else
+        if (plain) {
+            next_off += srow;
+            kn_off += srow;
+            ko_off += srow;
+        } else {
+            next_off = row_off(i + 2 + R + G::D);
+            kn_off = row_off(i + 2 + R + G::KL);
+            ko_off = row_off(i + 1 - R + G::KL);
+        }
+#endif
         wave_lds_fence();
     }
 
     template <int... S>
     __device__ __forceinline__ void period(int i0, int y0, std::integer_sequence<int, S...>) {
-        krv = krow[i0 + lane < h ? i0 + lane : h - 1];
         (step<S>(i0 + S, y0), ...);
     }
 };
@@ -736,7 +735,6 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     st.drow = (uint32_t)pl.dstride * (uint32_t)sizeof(T);
     st.srcb = static_cast<const char *>(pl.src);
     st.dstb = static_cast<char *>(pl.dst);
-    st.krow = prm.krow + pl.krow0;
     const int lane = threadIdx.x;
     st.lane = lane;
     const int vc0 = tx * G::TWO - G::HL + lane * PX;  // first (virtual) plane column of this lane
@@ -775,7 +773,29 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
 #pragma unroll
     for (int k = 0; k < PX; ++k) st.col[k] = R;  // the rounding term of (col + r) / k rides along
     st.accum_all(std::make_integer_sequence<int, (int)G::K>{});
-    st.kr_carry = 0;
+    // K columns: window sum of rows y0-r .. y0+r at plane column min(lane, r), then the first KL
+    // entering / leaving pixels
+    {
+        const int kc = min(lane, R);
+#ifdef VSZIP_K_OOB
+        st.kvo = lane <= R ? (uint32_t)(kc * (int)sizeof(T)) : W::kOOB;  // lanes above r fetch nothing
+#else
+        st.kvo = (uint32_t)(kc * (int)sizeof(T));
+#endif
+        st.kwgt = lane < R ? 2u : (lane == R ? 1u : 0u);
+        uint32_t acc = R;
+#pragma unroll
+        for (int k = 0; k < (int)G::K; ++k) acc += st.fetch_px(st.row_off(y0 - R + k));
+        st.kcol = acc;
+#pragma unroll
+        for (int j = 0; j < G::KL; ++j) {
+            st.kn[j] = st.fetch_px(st.row_off(y0 + j + 1 + R));
+            st.ko[j] = st.fetch_px(st.row_off(y0 + j - R));
+        }
+        st.kn_off = st.row_off(y0 + G::KL + 1 + R);
+        st.ko_off = st.row_off(y0 + G::KL - R);
+        st.kr_prev = 0;
+    }
     st.next_off = st.row_off(y0 + 1 + R + G::D);  // window rows y0-r .. y0+r+D are in the ring
     st.out_off = (uint32_t)y0 * st.drow;
 
@@ -785,7 +805,7 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     {
         uint32_t e[PX];  // last row of the band: slot NR-1 wrote the odd buffer
         st.window_sums(P + 64 * PX, e);
-        st.emit_row(e, st.out_off, st.kr_carry, true);
+        st.emit_row(e, st.out_off, st.kr_prev, true);
     }
 }
 
@@ -808,7 +828,6 @@ int launch_ct_int(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         int band = 64;
         while (band > 16 && total_px / ((long)G::TWO * band) < 4096) band >>= 1;
         prm.band_rows = band;
-        prm.krow = nullptr;
         int blocks = 0;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
@@ -822,8 +841,6 @@ int launch_ct_int(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             d.block0 = blocks;
             d.ntx = (s.w + G::TWO - 1) / G::TWO;
             d.nbands = (s.h + band - 1) / band;
-            d.krow0 = 0;
-            d.kblk0 = 0;
             blocks += d.ntx * d.nbands;
         }
         if (ctx->scan_mode == 1)
@@ -843,11 +860,9 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     while (done < nplanes) {
         BBParams prm;
         const int n = std::min(kMaxPlanes, nplanes - done);
-        int total_rows = 0;
         bool mult8 = true;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
-            total_rows += s.h;
             mult8 = mult8 && (s.w % PX == 0);
         }
         // Band length. The kernel is HBM-bound once most wave slots are filled (measured:
@@ -871,12 +886,9 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             if (waves_for(t) >= min_waves) target = t;
         if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        int rc = vszip_ensure_scratch(ctx, (size_t)total_rows * sizeof(uint32_t));
-        if (rc != VSZIP_OK) return rc;
         prm.nplanes = n;
         prm.band_rows = 0;
-        prm.krow = static_cast<uint32_t *>(ctx->scratch);
-        int blocks = 0, kblocks = 0, rows = 0;
+        int blocks = 0;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
             BBPlane &d = prm.p[i];
@@ -888,17 +900,11 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             d.h = s.h;
             d.nperiods = (s.h + G::NR - 1) / G::NR;
             d.nbands = bands_for(s.h, d.nperiods, target);
-            d.krow0 = rows;
-            d.kblk0 = kblocks;
             d.ntx = (s.w + G::TWO - 1) / G::TWO;
             d.block0 = blocks;
             blocks += d.ntx * d.nbands;
-            kblocks += (s.h + 63) / 64;
-            rows += s.h;
         }
         prm.nblocks = blocks;
-        hipLaunchKernelGGL((boxblur_ct_krow_kernel<T, R>), dim3(kblocks), dim3(64), 0, ctx->stream, prm);
-        VSZIP_HIP_CHECK(ctx, hipGetLastError());
         const dim3 grid(((blocks + 7) / 8) * 8);
         {
             vszip_probe_scope probe(ctx);
