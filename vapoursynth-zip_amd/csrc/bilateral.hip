@@ -5,15 +5,21 @@
 // (:306-339); parameter derivation follows src/vapoursynth/bilateral.zig:104-231.
 // Algorithm 1 (PBFIC, :91-171) is reported as VSZIP_ERR_UNSUPPORTED for now.
 //
-// One thread per output pixel. The (radius/step)^2 diagonal-quadrant taps are
-// accumulated in exactly the reference's order with unfused f32 multiplies and adds
-// (-ffp-contract=off) and an IEEE division, so integer outputs are bit-exact and
-// float outputs identical. Source/reference taps are plain cached loads (a wave
-// covers 64 adjacent pixels, so every tap row is one or two coalesced lines that the
-// neighbouring taps re-hit in L1); the range LUT (256 KiB for 16-bit and float input,
-// too large for LDS) is gathered through L1/L2, where natural content keeps the
-// low-difference end hot.
+// The (radius/step)^2 diagonal-quadrant taps are accumulated in exactly the
+// reference's order with unfused f32 multiplies and adds (-ffp-contract=off) and an
+// IEEE division, so integer outputs are bit-exact and float outputs identical.
+//
+// bilateral_tiled_kernel (radius <= 16): a 256-thread workgroup stages a 64 x 32
+// output tile plus its halo in LDS with replicate padding baked in (truncatedEdges'
+// coordinate clamp, :281-289, becomes the identity), then each thread walks 8 rows.
+// The kernel is bound by the texture-address unit — one vector-memory instruction per
+// tap per wave — so moving the 16 (32 with a joint `ref` clip) pixel taps per pixel to
+// LDS reads leaves only the range-LUT gathers on that path. The range LUT (256 KiB
+// for 16-bit and float input, too large for LDS) is gathered through L1/L2, where
+// natural content keeps the low-difference end hot.
+// bilateral_truncated_kernel (any radius): one thread per pixel, taps as cached loads.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -70,6 +76,83 @@ struct BSmp<_Float16> {
 };
 
 constexpr int kBX = 64, kBY = 4;  // one wave per row segment
+constexpr int kTileH = 32;        // tiled kernel: output rows per workgroup (8 per thread)
+constexpr int kTileMaxR = 16;     // largest radius the tiled kernel stages
+
+template <typename T, bool JOINT>
+__global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParams prm) {
+    using S = BSmp<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int pi = 0;
+    const int b = blockIdx.x;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const BLPlane pl = prm.p[pi];
+    const int lb = b - pl.block0;
+    const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kTileH;
+    const int r = pl.radius;
+    const int tw = kBX + 2 * r, th = kTileH + 2 * r;
+    const T *src = static_cast<const T *>(pl.src);
+    const T *ref = static_cast<const T *>(pl.ref);
+    T *tr = reinterpret_cast<T *>(smem);
+    T *ts = JOINT ? tr + th * tw : tr;
+    const int w1 = pl.w - 1, h1 = pl.h - 1;
+    const int lx = (int)threadIdx.x, tyi = (int)threadIdx.y;
+
+    // stage: tile row t holds source row clamp(y0 - r + t), tile column c source column clamp(x0 - r + c)
+    for (int t = tyi; t < th; t += kBY) {
+        const int gy = min(max(y0 - r + t, 0), h1);
+        const T *rr = ref + (size_t)gy * pl.rstride;
+        const T *sr = src + (size_t)gy * pl.sstride;
+        for (int c = lx; c < tw; c += kBX) {
+            const int gx = min(max(x0 - r + c, 0), w1);
+            tr[t * tw + c] = rr[gx];
+            if constexpr (JOINT) ts[t * tw + c] = sr[gx];
+        }
+    }
+    __syncthreads();
+
+    const int x = x0 + lx;
+    if (x >= pl.w) return;
+    T *dst = static_cast<T *>(pl.dst);
+    const float *gs = pl.gs, *gr = pl.gr;
+    const int radius2 = r + 1, step = pl.step;
+    const float w0 = gs[0] * gr[0];
+#pragma unroll 1
+    for (int k = 0; k < kTileH / kBY; ++k) {
+        const int ly = tyi + kBY * k;  // a wave owns one row of 64 pixels at a time
+        const int y = y0 + ly;
+        if (y >= pl.h) break;
+        const int c0 = (ly + r) * tw + lx + r;
+        const T cx = tr[c0];
+        float wsum = w0;
+        float sum = S::f(ts[c0]) * wsum;
+        for (int yy = 1; yy < radius2; yy += step) {
+            const int oa = c0 - yy * tw, ob = c0 + yy * tw;
+            for (int xx = 1; xx < radius2; xx += step) {
+                const float swei = gs[yy * radius2 + xx];
+                const T ra1 = tr[oa + xx], ra2 = tr[ob + xx], ra3 = tr[oa - xx], ra4 = tr[ob - xx];
+                const float rw1 = gr[S::ridx(cx, ra1)];
+                const float rw2 = gr[S::ridx(cx, ra2)];
+                const float rw3 = gr[S::ridx(cx, ra3)];
+                const float rw4 = gr[S::ridx(cx, ra4)];
+                wsum += swei * (rw1 + rw2 + rw3 + rw4);
+                if constexpr (JOINT)
+                    sum += swei * (S::f(ts[oa + xx]) * rw1 + S::f(ts[ob + xx]) * rw2 + S::f(ts[oa - xx]) * rw3 + S::f(ts[ob - xx]) * rw4);
+                else
+                    sum += swei * (S::f(ra1) * rw1 + S::f(ra2) * rw2 + S::f(ra3) * rw3 + S::f(ra4) * rw4);
+            }
+        }
+        const float q = __fdiv_rn(sum, wsum);
+        if constexpr (S::is_int) {
+            const float v = fminf(fmaxf(q + 0.5f, 0.0f), prm.peak);  // finalize :30-36
+            dst[(size_t)y * pl.dstride + x] = (T)truncf(v);
+        } else {
+            dst[(size_t)y * pl.dstride + x] = (T)q;
+        }
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(kBX *kBY) void bilateral_truncated_kernel(const BLParams prm) {
@@ -120,10 +203,18 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_truncated_kernel(const BLP
 }
 
 template <typename T>
-int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks) {
+int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled, bool joint, int max_radius) {
     {
         vszip_probe_scope probe(ctx);
-        hipLaunchKernelGGL((bilateral_truncated_kernel<T>), dim3(blocks), dim3(kBX, kBY), 0, ctx->stream, prm);
+        if (tiled) {
+            const size_t lds = (size_t)(kBX + 2 * max_radius) * (kTileH + 2 * max_radius) * sizeof(T) * (joint ? 2 : 1);
+            if (joint)
+                hipLaunchKernelGGL((bilateral_tiled_kernel<T, true>), dim3(blocks), dim3(kBX, kBY), lds, ctx->stream, prm);
+            else
+                hipLaunchKernelGGL((bilateral_tiled_kernel<T, false>), dim3(blocks), dim3(kBX, kBY), lds, ctx->stream, prm);
+        } else {
+            hipLaunchKernelGGL((bilateral_truncated_kernel<T>), dim3(blocks), dim3(kBX, kBY), 0, ctx->stream, prm);
+        }
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
@@ -233,6 +324,17 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         BLParams prm;
         prm.peak = peak;
         int n = 0, blocks = 0;
+        // one launch group: the tiled kernel when every radius fits its LDS tile; `joint` if any
+        // plane of the group brings a separate ref clip
+        bool tiled = !getenv("VSZIP_BILATERAL_UNTILED"), joint = false;
+        int max_radius = 0;
+        for (int i = done; i < nplanes && i < done + kMaxPlanesBL; ++i) {
+            if (!cfgs[i]) break;
+            tiled = tiled && cfgs[i]->radius <= kTileMaxR;
+            joint = joint || (planes[i].ref && planes[i].ref != planes[i].src);
+            max_radius = std::max(max_radius, cfgs[i]->radius);
+        }
+        const int rows_per_block = tiled ? kTileH : kBY;
         for (; done + n < nplanes && n < kMaxPlanesBL; ++n) {
             const vszip_plane &s = planes[done + n];
             const vszip_bilateral_cfg *c = cfgs[done + n];
@@ -258,15 +360,15 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             d.step = c->step;
             d.gs = c->gs_lut;
             d.gr = c->gr_lut;
-            blocks += d.nbx * ((s.h + kBY - 1) / kBY);
+            blocks += d.nbx * ((s.h + rows_per_block - 1) / rows_per_block);
         }
         prm.nplanes = n;
         int rc;
         switch (dtype) {
-            case VSZIP_U8: rc = launch_truncated<uint8_t>(ctx, prm, blocks); break;
-            case VSZIP_U16: rc = launch_truncated<uint16_t>(ctx, prm, blocks); break;
-            case VSZIP_F16: rc = launch_truncated<_Float16>(ctx, prm, blocks); break;
-            case VSZIP_F32: rc = launch_truncated<float>(ctx, prm, blocks); break;
+            case VSZIP_U8: rc = launch_truncated<uint8_t>(ctx, prm, blocks, tiled, joint, max_radius); break;
+            case VSZIP_U16: rc = launch_truncated<uint16_t>(ctx, prm, blocks, tiled, joint, max_radius); break;
+            case VSZIP_F16: rc = launch_truncated<_Float16>(ctx, prm, blocks, tiled, joint, max_radius); break;
+            case VSZIP_F32: rc = launch_truncated<float>(ctx, prm, blocks, tiled, joint, max_radius); break;
             default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: not supported Int format.");
         }
         if (rc != VSZIP_OK) return rc;
