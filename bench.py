@@ -6,7 +6,7 @@
 
 Default workload (the JSON line's `value` and `roofline`): vszip.BoxBlur(hradius=vradius=13)
 on 3840x2160 YUV420P16 — the north-star roofline target. A step is one pass of the hot path
-over one batch of F synthetic frames already resident in HBM (F*3 planes = one launch group).
+over one batch of F = 64 synthetic frames already resident in HBM (F*3 = 192 planes = one launch).
 The other two headline filters (Bilateral sigmaS=2 sigmaR=2, SSIMULACRA2 ref vs dist) are
 measured in the same run on their BASELINE configs and reported under "others", each beside
 the CPU oracle timed on this box's host cores.
@@ -264,7 +264,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (64 4K YUV420P16 frames = 192 planes = one BoxBlur launch)")
     ap.add_argument("--workload", default="boxblur", choices=["boxblur", "bilateral", "ssimulacra2"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")

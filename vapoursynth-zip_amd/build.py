@@ -41,6 +41,10 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
     if os.environ.get("VSZIP_EXTRA_FLAGS"):  # development only
         flags += os.environ["VSZIP_EXTRA_FLAGS"].split()
         force = True
+    # a change of flags (e.g. a development build before) invalidates every object
+    stamp = OBJ / "flags.txt"
+    if not stamp.is_file() or stamp.read_text() != " ".join(flags):
+        force = True
     srcs = sorted(CSRC.glob("*.hip"))
     hdrs = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list((PKG.parent / "include").glob("*.h"))
     jobs = []
@@ -62,6 +66,7 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
         for warn in ex.map(run, jobs):
             if warn.strip():
                 sys.stderr.write(warn)
+    stamp.write_text(" ".join(flags))
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

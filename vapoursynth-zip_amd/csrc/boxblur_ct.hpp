@@ -69,6 +69,17 @@ struct BBParams {
     int nblocks;
 };
 
+// Ring kernel launch table: up to 64 4K YUV frames per launch (longer bands, fewer re-read halo
+// rows). The block -> plane map replaces a linear scan of the plane table by every wave.
+constexpr int kRingMaxPlanes = 192;
+constexpr int kRingMaxBlocks = 8192;
+struct RingParams {
+    BBPlane p[kRingMaxPlanes];
+    int nplanes;
+    int nblocks;
+    uint8_t plane_of_block[kRingMaxBlocks];
+};
+
 // boxblur_comptime.zig:50-70 — source row of tap k for output row i.
 __device__ __forceinline__ int ct_tap_row(int k, int i, int radius, int ih) {
     const int dist_from_bottom = ih - 1 - i;
@@ -700,7 +711,7 @@ struct RingWave {
 };
 
 template <typename T, int R, bool GENERAL>
-__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX / 4)>::WPE)) void boxblur_ct_ring_kernel(const BBParams prm) {
+__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX / 4)>::WPE)) void boxblur_ct_ring_kernel(const RingParams prm) {
     using W = RingWave<T, R, GENERAL>;
     using G = typename W::G;
     static_assert(G::NR % 2 == 0 && G::NR <= 64, "ring period must be even and fit a wave");
@@ -711,10 +722,7 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     const int chunk = (prm.nblocks + 7) >> 3;
     const int b = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (b >= prm.nblocks) return;
-    int pi = 0;
-#pragma unroll 1
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
+    const int pi = prm.plane_of_block[b];
     const BBPlane pl = prm.p[pi];
     const int lb = b - pl.block0;
     const int tx = lb % pl.ntx;
@@ -858,8 +866,8 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     using G = typename RingWave<T, R, false>::G;
     int done = 0;
     while (done < nplanes) {
-        BBParams prm;
-        const int n = std::min(kMaxPlanes, nplanes - done);
+        RingParams prm;
+        const int n = std::min(kRingMaxPlanes, nplanes - done);
         bool mult8 = true;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
@@ -887,7 +895,6 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         prm.nplanes = n;
-        prm.band_rows = 0;
         int blocks = 0;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
@@ -902,6 +909,8 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             d.nbands = bands_for(s.h, d.nperiods, target);
             d.ntx = (s.w + G::TWO - 1) / G::TWO;
             d.block0 = blocks;
+            if (blocks + d.ntx * d.nbands > kRingMaxBlocks) return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: launch table overflow (%d blocks)", blocks + d.ntx * d.nbands);
+            for (int k = 0; k < d.ntx * d.nbands; ++k) prm.plane_of_block[blocks + k] = (uint8_t)i;
             blocks += d.ntx * d.nbands;
         }
         prm.nblocks = blocks;
