@@ -44,6 +44,41 @@ def test_matches_oracle(dev, oracle, dtype, sig):
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, sig, shape)
 
 
+def _noise(shape, dtype):
+    n = fx.splitmix64_plane(9, shape, np.uint16)
+    if np.dtype(dtype) == np.uint8:
+        return (n >> 8).astype(np.uint8)
+    if np.dtype(dtype) == np.uint16:
+        return n
+    return (n / 65535.0).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float16])
+@pytest.mark.parametrize("case", [dict(sS=3, sR=0.1, num=4), dict(sS=3, sR=0.1, num=32), dict(sS=8, sR=2, num=0), dict(sS=1.5, sR=0.05, num=7)])
+def test_pbfic_matches_oracle(dev, oracle, dtype, case):
+    """algorithm 1 (PBFIC + recursive Gaussian): the IIR recursion keeps the reference's operation
+    order line by line, so the result is bit-exact for every sample type."""
+    for shape in [(120, 200), (67, 131), (3, 5), (1, 70), (70, 1)]:
+        src = fx.tiled_natural(shape, dtype, 1) if min(shape) > 8 else _noise(shape, dtype)
+        (got,), cfgs = _gpu(dev, [src], case["sS"], case["sR"], algorithm=[1], pbficnum=[case["num"]])
+        sS, sR, alg, rad, step, num = cfgs[0]
+        assert alg == 1
+        want = oracle.bilateral_plane(np.ascontiguousarray(src), sS, sR, alg, rad, step, num)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, case, shape)
+
+
+def test_pbfic_joint_ref_and_auto_selection(dev, oracle):
+    """A separate ref clip drives the range weights; algorithm 0 auto-selects PBFIC for a wide
+    spatial sigma with a wide range sigma (bilateral.zig(vs):196)."""
+    src = fx.tiled_natural((96, 160), np.uint16, 0)
+    ref = fx.tiled_natural((96, 160), np.uint16, 2)
+    (got,), cfgs = _gpu(dev, [src], 8, 2, refs=[ref])
+    sS, sR, alg, rad, step, num = cfgs[0]
+    assert alg == 1
+    want = oracle.bilateral_plane(src, sS, sR, alg, rad, step, num, ref=ref)
+    assert np.array_equal(got, want)
+
+
 def test_joint_ref_and_noise(dev, oracle):
     src = fx.splitmix64_plane(1, (90, 150), np.uint16)
     ref = fx.tiled_natural((90, 150), np.uint16)

@@ -60,6 +60,16 @@ def test_bilateral_yuv420p16(oracle):
         assert np.array_equal(out[p], want)
 
 
+def test_bilateral_pbfic_gray16(oracle):
+    """algorithm=1 through the plugin (reference tests/test_bilateral.py:22-23: sigmaS=3 sigmaR=0.1, PBFICnum 4 and 32)."""
+    p = fx.tiled_natural((120, 200), np.uint16, 0)
+    for num in (4, 32):
+        out = vs.source([[p]], vs.GRAY16).vszip.Bilateral(sigmaS=3.0, sigmaR=0.1, algorithm=1, PBFICnum=num).get_frame(0)
+        prm = oracle.bilateral_params([3], [0.1], algorithm=[1], pbficnum=[num])
+        want = oracle.bilateral_plane(p, prm["sigmaS"][0], prm["sigmaR"][0], 1, prm["radius"][0], prm["step"][0], prm["PBFICnum"][0])
+        assert np.array_equal(out[0], want)
+
+
 def test_bilateral_sigma_zero_is_passthrough():
     """reference tests/test_bilateral.py:84-87"""
     planes = _yuv420p16(5, 128, 64)

@@ -3,7 +3,7 @@
 // Replaces filter.bilateral (src/filters/bilateral.zig:81-89) -> truncated (:178-304,
 // algorithm 2: truncated spatial window with sub-sampling) and the LUT generators
 // (:306-339); parameter derivation follows src/vapoursynth/bilateral.zig:104-231.
-// Algorithm 1 (PBFIC, :91-171) is reported as VSZIP_ERR_UNSUPPORTED for now.
+// Algorithm 1 (PBFIC, :91-171) keeps every range layer resident in HBM; see below.
 //
 // The (radius/step)^2 diagonal-quadrant taps are accumulated in exactly the
 // reference's order with unfused f32 multiplies and adds (-ffp-contract=off) and an
@@ -202,6 +202,252 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_truncated_kernel(const BLP
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Algorithm 1: PBFIC (Yang's O(1) bilateral), bilateral.zig:91-171 + the recursive
+// Gaussian of :336-431. All PBFICnum range layers of a plane are processed at once —
+// layer k has its own W_k / J_k f32 planes (dense, stride == width) in the context
+// scratch; 288 GB of HBM make that affordable (4K luma, 32 layers: 2.1 GB) and it is
+// what gives the IIR passes their parallelism: the recursion is sequential along a
+// line (kept exactly in the reference's operation order), so a pass has only
+// lines x planes independent chains.
+//   pbfic_wj_kernel   W_k = gr[|pk - ref|], J_k = W_k * src                       (:118-131)
+//   pbfic_rg_h_kernel causal + anticausal 3rd-order IIR along x, one wave per 64 rows,
+//                     64x64 tiles staged through LDS so HBM sees coalesced rows       (:411-431)
+//   pbfic_rg_v_kernel the same along y, one thread per column                       (:366-409)
+//   pbfic_out_kernel  layer = J/W, linear interpolation between the two layers that
+//                     bracket the pixel's ref value, finalize                       (:133-171)
+// ---------------------------------------------------------------------------
+struct PBArgs {
+    const void *src, *ref;
+    void *dst;
+    int sstride, rstride, dstride, w, h;
+    float *wj;         // [2 * num] planes of w*h floats: W_0, J_0, W_1, J_1, ...
+    const float *gr;
+    const void *pk;    // [num] layer values in T
+    int num;
+    float peak;
+    float b, b1, b2, b3;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pbfic_wj_kernel(const PBArgs a) {
+    using S = BSmp<T>;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= a.w) return;
+    const T rv = static_cast<const T *>(a.ref)[(size_t)y * a.rstride + x];
+    const T sv = static_cast<const T *>(a.src)[(size_t)y * a.sstride + x];
+    const T pk = static_cast<const T *>(a.pk)[k];
+    const float wv = a.gr[S::ridx(pk, rv)];
+    const size_t plane = (size_t)a.w * a.h, i = (size_t)y * a.w + x;
+    a.wj[(size_t)(2 * k) * plane + i] = wv;
+    a.wj[(size_t)(2 * k + 1) * plane + i] = wv * S::f(sv);
+}
+
+__global__ __launch_bounds__(64) void pbfic_rg_h_kernel(const PBArgs a) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    const int y0 = blockIdx.x * 64;
+    const size_t plane = (size_t)a.w * a.h;
+    float *io = a.wj + (size_t)blockIdx.y * plane;
+    const int rows = min(64, a.h - y0);
+    const int w = a.w, nchunk = (w + 63) / 64;
+    const float b = a.b, b1 = a.b1, b2 = a.b2, b3 = a.b3;
+    float p1 = 0, p2 = 0, p3 = 0;
+    // causal pass, left to right (:413-424): the first sample passes through
+    for (int c = 0; c < nchunk; ++c) {
+        const int x0 = c * 64, cw = min(64, w - x0);
+        for (int r = 0; r < rows; ++r)
+            if (lane < cw) tile[r][lane] = io[(size_t)(y0 + r) * w + x0 + lane];
+        __syncthreads();
+        if (lane < rows) {
+            for (int i = 0; i < cw; ++i) {
+                const float v = tile[lane][i];
+                float o;
+                if (x0 + i == 0) {
+                    p1 = p2 = p3 = v;
+                    o = v;
+                } else {
+                    o = b * v + b1 * p1 + b2 * p2 + b3 * p3;
+                    p3 = p2;
+                    p2 = p1;
+                    p1 = o;
+                }
+                tile[lane][i] = o;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r)
+            if (lane < cw) io[(size_t)(y0 + r) * w + x0 + lane] = tile[r][lane];
+        __syncthreads();
+    }
+    // anticausal pass, right to left (:425-431): the last sample passes through
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int x0 = c * 64, cw = min(64, w - x0);
+        for (int r = 0; r < rows; ++r)
+            if (lane < cw) tile[r][lane] = io[(size_t)(y0 + r) * w + x0 + lane];
+        __syncthreads();
+        if (lane < rows) {
+            for (int i = cw - 1; i >= 0; --i) {
+                const float v = tile[lane][i];
+                float o;
+                if (x0 + i == w - 1) {
+                    p1 = p2 = p3 = v;
+                    o = v;
+                } else {
+                    o = b * v + b1 * p1 + b2 * p2 + b3 * p3;
+                    p3 = p2;
+                    p2 = p1;
+                    p1 = o;
+                }
+                tile[lane][i] = o;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r)
+            if (lane < cw) io[(size_t)(y0 + r) * w + x0 + lane] = tile[r][lane];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void pbfic_rg_v_kernel(const PBArgs a) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= a.w) return;
+    const size_t plane = (size_t)a.w * a.h;
+    float *io = a.wj + (size_t)blockIdx.y * plane + x;
+    const int w = a.w, h = a.h;
+    const float b = a.b, b1 = a.b1, b2 = a.b2, b3 = a.b3;
+    // :368-387 — rows 0..2 reuse the nearest already-filtered row for the missing taps
+    float p1, p2, p3;
+    {
+        const float v = io[0];
+        const float o = b * v + b1 * v + b2 * v + b3 * v;
+        io[0] = o;
+        p1 = p2 = p3 = o;
+    }
+    constexpr int U = 8;
+    for (int j = 1; j < h; j += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (j + u < h) ? io[(size_t)(j + u) * w] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j + u < h) {
+                const float o = b * v[u] + b1 * p1 + b2 * p2 + b3 * p3;
+                p3 = p2;
+                p2 = p1;
+                p1 = o;
+                io[(size_t)(j + u) * w] = o;
+            }
+        }
+    }
+    // :388-408 — bottom to top
+    {
+        const float v = io[(size_t)(h - 1) * w];
+        const float o = b * v + b1 * v + b2 * v + b3 * v;
+        io[(size_t)(h - 1) * w] = o;
+        p1 = p2 = p3 = o;
+    }
+    for (int j = h - 2; j >= 0; j -= U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (j - u >= 0) ? io[(size_t)(j - u) * w] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j - u >= 0) {
+                const float o = b * v[u] + b1 * p1 + b2 * p2 + b3 * p3;
+                p3 = p2;
+                p2 = p1;
+                p1 = o;
+                io[(size_t)(j - u) * w] = o;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pbfic_out_kernel(const PBArgs a) {
+    using S = BSmp<T>;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.w) return;
+    const T *pk = static_cast<const T *>(a.pk);
+    const float rf = S::f(static_cast<const T *>(a.ref)[(size_t)y * a.rstride + x]);
+    int k = 0;
+    for (; k < a.num - 2; ++k)
+        if (rf < S::f(pk[k + 1]) && rf >= S::f(pk[k])) break;
+    const float p0f = S::f(pk[k]), p1f = S::f(pk[k + 1]);
+    const size_t plane = (size_t)a.w * a.h, i = (size_t)y * a.w + x;
+    const float w0 = a.wj[(size_t)(2 * k) * plane + i], j0 = a.wj[(size_t)(2 * k + 1) * plane + i];
+    const float w1 = a.wj[(size_t)(2 * k + 2) * plane + i], j1 = a.wj[(size_t)(2 * k + 3) * plane + i];
+    const float lo = (w0 == 0.0f) ? 0.0f : __fdiv_rn(j0, w0);
+    const float hi = (w1 == 0.0f) ? 0.0f : __fdiv_rn(j1, w1);
+    const float vf = __fdiv_rn((p1f - rf) * lo + (rf - p0f) * hi, p1f - p0f);
+    T *dst = static_cast<T *>(a.dst);
+    if constexpr (S::is_int) {
+        const float v = fminf(fmaxf(__fdiv_rn(vf, 1.0f) + 0.5f, 0.0f), a.peak);
+        dst[(size_t)y * a.dstride + x] = (T)truncf(v);
+    } else {
+        dst[(size_t)y * a.dstride + x] = (T)vf;
+    }
+}
+
+// bilateral.zig:350-364
+void rg_params(double sigma, float *b, float *b1, float *b2, float *b3) {
+    const double q = (sigma < 2.5) ? (3.97156 - 4.14554 * std::sqrt(1 - 0.26891 * sigma)) : 0.98711 * sigma - 0.96330;
+    const double den = 1.57825 + 2.44413 * q + 1.4281 * q * q + 0.422205 * q * q * q;
+    const double n1 = 2.44413 * q + 2.85619 * q * q + 1.26661 * q * q * q;
+    const double n2 = -(1.4281 * q * q + 1.26661 * q * q * q);
+    const double n3 = 0.422205 * q * q * q;
+    *b = (float)(1 - (n1 + n2 + n3) / den);
+    *b1 = (float)(n1 / den);
+    *b2 = (float)(n2 / den);
+    *b3 = (float)(n3 / den);
+}
+
+template <typename T>
+int run_pbfic(vszip_ctx *ctx, const vszip_plane &s, const vszip_bilateral_cfg &c, float peak) {
+    const int num = c.pbficnum;
+    if (num < 2 || num > 256) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: PBFICnum %d out of range", num);
+    const size_t plane = (size_t)s.w * s.h;
+    const size_t pk_bytes = 1024;
+    int rc = vszip_ensure_scratch(ctx, pk_bytes + (size_t)2 * num * plane * sizeof(float));
+    if (rc != VSZIP_OK) return rc;
+    // layer values, in T exactly as :96-116 (integer: trunc(peak*k/(num-1) + .5); float: k/(num-1) in T)
+    T pk[256];
+    for (int k = 0; k < num; ++k) {
+        if constexpr (BSmp<T>::is_int) {
+            const float v = peak * (float)k / ((float)num - 1) + 0.5f;
+            pk[k] = (T)v;
+        } else {
+            pk[k] = (T)((T)(float)k / (T)(float)(num - 1));
+        }
+    }
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scratch, pk, sizeof(T) * num, hipMemcpyHostToDevice, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // pk lives on this stack frame
+    PBArgs a;
+    a.src = s.src;
+    a.ref = s.ref ? s.ref : s.src;
+    a.dst = s.dst;
+    a.sstride = (int)s.src_stride;
+    a.rstride = s.ref ? (int)s.ref_stride : (int)s.src_stride;
+    a.dstride = (int)s.dst_stride;
+    a.w = s.w;
+    a.h = s.h;
+    a.pk = ctx->scratch;
+    a.wj = reinterpret_cast<float *>(static_cast<char *>(ctx->scratch) + pk_bytes);
+    a.gr = c.gr_lut;
+    a.num = num;
+    a.peak = peak;
+    rg_params(c.sigmaS, &a.b, &a.b1, &a.b2, &a.b3);
+    const dim3 gpx((s.w + 255) / 256, s.h, num);
+    hipLaunchKernelGGL((pbfic_wj_kernel<T>), gpx, dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(pbfic_rg_h_kernel, dim3((s.h + 63) / 64, 2 * num), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(pbfic_rg_v_kernel, dim3((s.w + 255) / 256, 2 * num), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((pbfic_out_kernel<T>), dim3((s.w + 255) / 256, s.h), dim3(256), 0, ctx->stream, a);
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    return VSZIP_OK;
+}
+
 template <typename T>
 int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled, bool joint, int max_radius) {
     {
@@ -328,8 +574,26 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         // plane of the group brings a separate ref clip
         bool tiled = !getenv("VSZIP_BILATERAL_UNTILED"), joint = false;
         int max_radius = 0;
+        // algorithm 1 planes run one by one (each is its own set of launches)
+        if (cfgs[done] && cfgs[done]->process && cfgs[done]->algorithm == 1) {
+            const vszip_plane &s1 = planes[done];
+            const vszip_bilateral_cfg *c1 = cfgs[done];
+            if (!s1.src || !s1.dst || s1.w <= 0 || s1.h <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: bad plane %d", done);
+            if (!c1->gr_lut) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: LUTs missing (vszip_bilateral_luts)");
+            int rc1;
+            switch (dtype) {
+                case VSZIP_U8: rc1 = run_pbfic<uint8_t>(ctx, s1, *c1, peak); break;
+                case VSZIP_U16: rc1 = run_pbfic<uint16_t>(ctx, s1, *c1, peak); break;
+                case VSZIP_F16: rc1 = run_pbfic<_Float16>(ctx, s1, *c1, peak); break;
+                case VSZIP_F32: rc1 = run_pbfic<float>(ctx, s1, *c1, peak); break;
+                default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: not supported Int format.");
+            }
+            if (rc1 != VSZIP_OK) return rc1;
+            ++done;
+            continue;
+        }
         for (int i = done; i < nplanes && i < done + kMaxPlanesBL; ++i) {
-            if (!cfgs[i]) break;
+            if (!cfgs[i] || (cfgs[i]->process && cfgs[i]->algorithm == 1)) break;
             tiled = tiled && cfgs[i]->radius <= kTileMaxR;
             joint = joint || (planes[i].ref && planes[i].ref != planes[i].src);
             max_radius = std::max(max_radius, cfgs[i]->radius);
@@ -338,9 +602,10 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         for (; done + n < nplanes && n < kMaxPlanesBL; ++n) {
             const vszip_plane &s = planes[done + n];
             const vszip_bilateral_cfg *c = cfgs[done + n];
+            if (c && c->process && c->algorithm == 1) break;  // next group
             if (!c || !s.src || !s.dst || s.w <= 0 || s.h <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: bad plane %d", done + n);
             if (!c->process) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: plane %d is not processed (sigma 0); copy it instead", done + n);
-            if (c->algorithm != 2) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "Bilateral: algorithm 1 (PBFIC) not built yet");
+            if (c->algorithm != 2) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: invalid algorithm %d", c->algorithm);
             if (!c->gs_lut || !c->gr_lut) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: LUTs missing (vszip_bilateral_luts)");
             // src/vapoursynth/bilateral.zig:206-209
             if (s.w <= 2 * c->radius || s.h <= 2 * c->radius)

@@ -534,11 +534,6 @@ void VS_CC bilateralCreate(const VSMap *in, VSMap *out, void *, VSCore *core, co
                 return;
             }
         }
-        if (d->cfg[i].process && d->cfg[i].algorithm == 1) {
-            z.setError(out, "Bilateral: algorithm 1 (PBFIC) is not available in the MI355X build yet");
-            api->freeNode(d->node1);
-            return;
-        }
     }
     for (int i = f.numPlanes; i < 3; ++i) d->cfg[i].process = 0;
     d->node2 = z.getNode(in, "ref");
