@@ -15,11 +15,16 @@
 //                         block. No blurred map ever touches HBM.
 //   ssim_final_kernel     folds the partials in a fixed order (reproducible) into the
 //                         6x6 / 6x12 average tables; the host applies `score` (:630-663).
+// All pairs of a call share every launch (grid z = pair): each pair has its own XYB planes
+// and RGB pyramid in the context scratch (261 MB per 4K pair — HBM is 288 GB), and a
+// device table of plane pointers per (scale, pair) tells a block where its pair lives.
+// Tiles that touch no plane border take a fast path with compile-time tap offsets.
 // f32 arithmetic keeps the reference's operation order; the vertical FIR is fused
 // (fmaf) for columns below w - w % 8 and unfused beyond, as the reference's AVX2 build
 // does (:318 vs :326). Only the f64 pooling order differs (~1e-15 relative).
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "common.hpp"
 
@@ -57,10 +62,15 @@ struct XybK {
     float m[9], bias, kd1;
 };
 
-struct XybArgs {
+// plane pointers of one (scale, pair): the kernels index this table by blockIdx.z
+struct PairPtrs {
     const float *rgb1[3], *rgb2[3];  // scale s linear RGB
     float *xyb1[3], *xyb2[3];        // scale s XYB (NULL = plane not needed)
     float *next1[3], *next2[3];      // scale s+1 linear RGB (NULL at the last scale)
+};
+
+struct XybArgs {
+    const PairPtrs *tab;             // [npairs] for this scale
     int stride, w, h;                // scale s geometry (elements)
     int nstride, nw, nh;             // scale s+1 geometry
     int xstride;
@@ -88,12 +98,13 @@ __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
     const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
     const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (ox >= a.nw || oy >= a.nh) return;
-    const bool need_b = a.xyb1[2] != nullptr;
+    const PairPtrs pp = a.tab[blockIdx.z];
+    const bool need_b = pp.xyb1[2] != nullptr;
 #pragma unroll
     for (int img = 0; img < 2; ++img) {
-        const float *const *rgb = img ? a.rgb2 : a.rgb1;
-        float *const *xyb = img ? a.xyb2 : a.xyb1;
-        float *const *nxt = img ? a.next2 : a.next1;
+        const float *const *rgb = img ? pp.rgb2 : pp.rgb1;
+        float *const *xyb = img ? pp.xyb2 : pp.xyb1;
+        float *const *nxt = img ? pp.next2 : pp.next1;
         float v[3][4];
         // downscale :186-200: samples clamp to the last row/column, summed ((a+b)+c)+d
 #pragma unroll
@@ -127,13 +138,14 @@ __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
 }
 
 struct MapsArgs {
-    const float *im1[3], *im2[3];  // XYB planes of the active plane slots
-    int flags[3];                  // bit0: ssim map, bit1: edge map
-    int slot[3];                   // partial-table slot (scale * 3 + plane)
+    const PairPtrs *tab;  // [npairs] for this scale
+    int plane[3];         // XYB plane index of the active plane slots
+    int flags[3];         // bit0: ssim map, bit1: edge map
+    int slot[3];          // partial-table slot (scale * 3 + plane)
     int nactive;
     int stride, w, h;
     int tiles_x, tiles_y;
-    double *partial;  // [slot][tile][6]
+    double *partial;  // [pair][slot][tile][6]
     int max_tiles;
 };
 
@@ -145,18 +157,14 @@ __device__ __forceinline__ int tap_index(int k, int i, int n) {
     return (dist_from_end < k - HALO) ? (i - min(k - HALO - dist_from_end, i)) : (i - HALO + k);
 }
 
-__global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
-    __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];  // XYB tile of both frames
-    __shared__ float vt[4][TH][IW + 1];               // vertical pass of the 4 maps
-    __shared__ double red[4][6];
-
-    const int ps = blockIdx.z;
-    const float *im1 = a.im1[ps], *im2 = a.im2[ps];
+// INTERIOR: the tile plus its halo lies inside the plane and left of the fused/unfused column
+// split, so every tap offset is a compile-time constant and the index arithmetic folds away.
+template <bool INTERIOR>
+__device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0,
+                                               float (*s1)[IW + 1], float (*s2)[IW + 1], float (*vt)[TH][IW + 1], double acc[6]) {
     const int w = a.w, h = a.h;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int cx0 = max(x0 - HALO, 0), cy0 = max(y0 - HALO, 0);  // real coords of LDS (0,0)
-    const int cw = min(x0 + TW + HALO, w) - cx0, ch = min(y0 + TH + HALO, h) - cy0;
-    const bool do_ssim = a.flags[ps] & 1, do_edge = a.flags[ps] & 2;
+    const int cx0 = INTERIOR ? x0 - HALO : max(x0 - HALO, 0), cy0 = INTERIOR ? y0 - HALO : max(y0 - HALO, 0);  // real coords of LDS (0,0)
+    const int cw = INTERIOR ? IW : min(x0 + TW + HALO, w) - cx0, ch = INTERIOR ? IH : min(y0 + TH + HALO, h) - cy0;
     const int tid = threadIdx.x;
 
     for (int i = tid; i < ch * cw; i += 256) {
@@ -168,16 +176,16 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
     __syncthreads();
 
     // vertical pass: rows of the tile, every staged column (blurV :308-330)
-    const int th = min(TH, h - y0);
+    const int th = INTERIOR ? TH : min(TH, h - y0);
     const int wv = w - (w % kVecW);
     for (int i = tid; i < th * cw; i += 256) {
         const int r = i / cw, c = i - r * cw;
         const int y = y0 + r;
-        const bool fused = (cx0 + c) < wv;
+        const bool fused = INTERIOR || (cx0 + c) < wv;
         float m12 = 0.0f, msq = 0.0f, m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int rr = tap_index(k, y, h) - cy0;
+            const int rr = INTERIOR ? r + k : tap_index(k, y, h) - cy0;
             const float p = s1[rr][c], q = s2[rr][c];
             const float kk = c_kernel[k];
             const float sum = p + q;
@@ -205,15 +213,14 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
     __syncthreads();
 
     // horizontal pass (blurH :247-306, unfused acc + k*s) and the per-pixel maps
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const int tw = min(TW, w - x0);
+    const int tw = INTERIOR ? TW : min(TW, w - x0);
     for (int i = tid; i < th * tw; i += 256) {
         const int r = i / tw, c = i - r * tw;
         const int x = x0 + c;
         float b12 = 0.0f, bsq = 0.0f, mu1 = 0.0f, mu2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int cc = tap_index(k, x, w) - cx0;
+            const int cc = INTERIOR ? c + k : tap_index(k, x, w) - cx0;
             const float kk = c_kernel[k];
             mu1 += kk * vt[2][r][cc];
             mu2 += kk * vt[3][r][cc];
@@ -245,6 +252,27 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
             acc[5] += t * t;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
+    __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];  // XYB tile of both frames
+    __shared__ float vt[4][TH][IW + 1];               // vertical pass of the 4 maps
+    __shared__ double red[4][6];
+
+    const int ps = blockIdx.z % a.nactive, pair = blockIdx.z / a.nactive;
+    const PairPtrs &pp = a.tab[pair];
+    const float *im1 = pp.xyb1[a.plane[ps]], *im2 = pp.xyb2[a.plane[ps]];
+    const int w = a.w, h = a.h;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const bool do_ssim = a.flags[ps] & 1, do_edge = a.flags[ps] & 2;
+    const int tid = threadIdx.x;
+    const bool interior = x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h;
+
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (interior)
+        ssim_maps_tile<true>(a, im1, im2, do_ssim, do_edge, x0, y0, s1, s2, vt, acc);
+    else
+        ssim_maps_tile<false>(a, im1, im2, do_ssim, do_edge, x0, y0, s1, s2, vt, acc);
 #pragma unroll
     for (int q = 0; q < 6; ++q) acc[q] = wave_reduce_sum(acc[q]);
     if ((tid & 63) == 0) {
@@ -255,25 +283,25 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
     if (tid < 6) {
         const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         const int tile = blockIdx.y * a.tiles_x + blockIdx.x;
-        a.partial[((size_t)a.slot[ps] * a.max_tiles + tile) * 6 + tid] = v;
+        a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
     }
 }
 
 struct FinalArgs {
-    const double *partial;
-    double *avg;  // [18 slots][6]: ssim avg, ssim 4th-root, art avg, art 4th-root, det avg, det 4th-root
+    const double *partial;  // [pair][slot][tile][6]
+    double *avg;  // [pair][18 slots][6]: ssim avg, ssim 4th-root, art avg, art 4th-root, det avg, det 4th-root
     int ntiles[18];
     double one_per_pixels[18];
     int max_tiles;
 };
 
 __global__ __launch_bounds__(64) void ssim_final_kernel(const FinalArgs a) {
-    const int slot = blockIdx.x;
+    const int slot = blockIdx.x, pair = blockIdx.y;
     const int n = a.ntiles[slot];
     const int lane = threadIdx.x;
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (int t = lane; t < n; t += 64) {
-        const double *p = a.partial + ((size_t)slot * a.max_tiles + t) * 6;
+        const double *p = a.partial + (((size_t)pair * 18 + slot) * a.max_tiles + t) * 6;
 #pragma unroll
         for (int q = 0; q < 6; ++q) s[q] += p[q];
     }
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(64) void ssim_final_kernel(const FinalArgs a) {
     for (int q = 0; q < 6; ++q) s[q] = wave_reduce_sum(s[q]);
     if (lane == 0) {
         const double opp = a.one_per_pixels[slot];
-        double *o = a.avg + slot * 6;
+        double *o = a.avg + ((size_t)pair * 18 + slot) * 6;
         o[0] = opp * s[0];
         o[1] = sqrt(sqrt(opp * s[1]));
         o[2] = opp * s[2];
@@ -372,8 +400,8 @@ double score_of(const double avg[18][6]) {  // ssimulacra2.zig:630-663; slot = s
 
 }  // namespace
 
-// Scratch (floats): XYB planes of one scale (6 * w * h) + two RGB pyramids that ping-pong
-// (scale s+1 is written while scale s is read): 2 * 6 * (w/2+1)*(h/2+1).
+// Scratch per pair (floats): XYB planes of one scale (6 * w * h) + two RGB pyramids that
+// ping-pong (scale s+1 is written while scale s is read): 2 * 6 * (w/2+1)*(h/2+1).
 VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3, ptrdiff_t stride, int w, int h, int npairs, double *scores) {
     if (!ctx || !ref3 || !dis3 || !scores || npairs <= 0 || w <= 0 || h <= 0) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -382,10 +410,12 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
     const int w1 = (w + 1) / 2, h1 = (h + 1) / 2;
     const size_t n1 = (size_t)w1 * h1;
     const int tiles0 = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
-    const size_t f_xyb = 6 * n0, f_pyr = 6 * n1 + 6 * (((size_t)(w1 + 1) / 2) * ((h1 + 1) / 2));
-    const size_t bytes_part = (size_t)18 * tiles0 * 6 * sizeof(double);
-    const size_t bytes_avg = (size_t)npairs * 18 * 6 * sizeof(double);
-    const size_t need = (f_xyb + f_pyr) * sizeof(float) + bytes_part + bytes_avg + 1024;
+    const size_t f_xyb = 6 * n0, f_pyrA = 6 * n1, f_pyrB = 6 * (((size_t)(w1 + 1) / 2) * ((h1 + 1) / 2));
+    const size_t f_pair = (f_xyb + f_pyrA + f_pyrB + 63) & ~(size_t)63;
+    const size_t bytes_part = ((size_t)npairs * 18 * tiles0 * 6 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t bytes_avg = ((size_t)npairs * 18 * 6 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t bytes_tab = ((size_t)kScales * npairs * sizeof(PairPtrs) + 255) & ~(size_t)255;
+    const size_t need = bytes_part + bytes_avg + bytes_tab + (size_t)npairs * f_pair * sizeof(float) + 1024;
     int rc = vszip_ensure_scratch(ctx, need);
     if (rc != VSZIP_OK) return rc;
     rc = vszip_ensure_scalars(ctx, bytes_avg);
@@ -393,86 +423,96 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
     char *base = static_cast<char *>(ctx->scratch);
     double *partial = reinterpret_cast<double *>(base);
     double *avg_dev = reinterpret_cast<double *>(base + bytes_part);
-    float *fxyb = reinterpret_cast<float *>(base + bytes_part + ((bytes_avg + 255) & ~(size_t)255));
-    float *pyrA = fxyb + f_xyb;       // scales 1, 3
-    float *pyrB = pyrA + 6 * n1;      // scales 2, 4
-    VSZIP_HIP_CHECK(ctx, hipMemsetAsync(avg_dev, 0, bytes_avg, ctx->stream));
+    PairPtrs *tab_dev = reinterpret_cast<PairPtrs *>(base + bytes_part + bytes_avg);
+    float *fbase = reinterpret_cast<float *>(base + bytes_part + bytes_avg + bytes_tab);
 
+    // geometry of every scale + the plane pointers of every (scale, pair)
+    int sw[kScales + 1], sh[kScales + 1];
+    sw[0] = w;
+    sh[0] = h;
+    for (int s = 1; s <= kScales; ++s) {
+        sw[s] = (sw[s - 1] + 1) / 2;
+        sh[s] = (sh[s - 1] + 1) / 2;
+    }
+    std::vector<PairPtrs> tab((size_t)kScales * npairs);
     for (int pair = 0; pair < npairs; ++pair) {
+        float *fxyb = fbase + (size_t)pair * f_pair;
+        float *pyrA = fxyb + f_xyb;   // scales 1, 3
+        float *pyrB = pyrA + f_pyrA;  // scales 2, 4
         const float *cur1[3] = {ref3[pair * 3 + 0], ref3[pair * 3 + 1], ref3[pair * 3 + 2]};
         const float *cur2[3] = {dis3[pair * 3 + 0], dis3[pair * 3 + 1], dis3[pair * 3 + 2]};
-        int cw = w, ch = h, cstride = (int)stride;
-        FinalArgs fin;
-        fin.partial = partial;
-        fin.avg = avg_dev + (size_t)pair * 18 * 6;
-        fin.max_tiles = tiles0;
-        for (int i = 0; i < 18; ++i) {
-            fin.ntiles[i] = 0;
-            fin.one_per_pixels[i] = 0;
-        }
         for (int scale = 0; scale < kScales; ++scale) {
-            const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
-            const size_t n = (size_t)cw * ch;
-            XybArgs xa;
-            MapsArgs ma;
-            ma.nactive = 0;
+            PairPtrs &pp = tab[(size_t)scale * npairs + pair];
+            const size_t n = (size_t)sw[scale] * sh[scale], nn = (size_t)sw[scale + 1] * sh[scale + 1];
             float *pyr = (scale & 1) ? pyrB : pyrA;
+            const bool last = scale == kScales - 1;
             for (int c = 0; c < 3; ++c) {
-                xa.rgb1[c] = cur1[c];
-                xa.rgb2[c] = cur2[c];
-                const Skip sk = skip_of(c, scale);
-                const bool need = !sk.all();
-                xa.xyb1[c] = need ? fxyb + (size_t)c * n : nullptr;
-                xa.xyb2[c] = need ? fxyb + (size_t)(3 + c) * n : nullptr;
-                const bool last = scale == kScales - 1;
-                xa.next1[c] = last ? nullptr : pyr + (size_t)c * nw * nh;
-                xa.next2[c] = last ? nullptr : pyr + (size_t)(3 + c) * nw * nh;
-                if (need) {
-                    const int k = ma.nactive++;
-                    ma.im1[k] = xa.xyb1[c];
-                    ma.im2[k] = xa.xyb2[c];
-                    ma.flags[k] = (sk.ssim ? 0 : 1) | ((!sk.artifact || !sk.detail) ? 2 : 0);
-                    ma.slot[k] = scale * 3 + c;
-                }
-            }
-            xa.stride = cstride;
-            xa.w = cw;
-            xa.h = ch;
-            xa.nstride = nw;
-            xa.nw = nw;
-            xa.nh = nh;
-            xa.xstride = cw;
-            xa.k = kx;
-            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8), dim3(256), 0, ctx->stream, xa);
-            ma.stride = cw;
-            ma.w = cw;
-            ma.h = ch;
-            ma.tiles_x = (cw + TW - 1) / TW;
-            ma.tiles_y = (ch + TH - 1) / TH;
-            ma.partial = partial;
-            ma.max_tiles = tiles0;
-            if (ma.nactive > 0) {
-                vszip_probe_scope probe(ctx);
-                hipLaunchKernelGGL(ssim_maps_kernel, dim3(ma.tiles_x, ma.tiles_y, ma.nactive), dim3(256), 0, ctx->stream, ma);
-            }
-            for (int k = 0; k < ma.nactive; ++k) {
-                fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
-                fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
-            }
-            if (scale < kScales - 1) {
-                for (int c = 0; c < 3; ++c) {
-                    cur1[c] = xa.next1[c];
-                    cur2[c] = xa.next2[c];
-                }
-                cw = nw;
-                ch = nh;
-                cstride = nw;
+                pp.rgb1[c] = cur1[c];
+                pp.rgb2[c] = cur2[c];
+                const bool need_plane = !skip_of(c, scale).all();
+                pp.xyb1[c] = need_plane ? fxyb + (size_t)c * n : nullptr;
+                pp.xyb2[c] = need_plane ? fxyb + (size_t)(3 + c) * n : nullptr;
+                pp.next1[c] = last ? nullptr : pyr + (size_t)c * nn;
+                pp.next2[c] = last ? nullptr : pyr + (size_t)(3 + c) * nn;
+                cur1[c] = pp.next1[c];
+                cur2[c] = pp.next2[c];
             }
         }
-        hipLaunchKernelGGL(ssim_final_kernel, dim3(18), dim3(64), 0, ctx->stream, fin);
-        VSZIP_HIP_CHECK(ctx, hipGetLastError());
     }
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, avg_dev, bytes_avg, hipMemcpyDeviceToHost, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab.data(), tab.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `tab` is pageable host memory
+
+    FinalArgs fin;
+    fin.partial = partial;
+    fin.avg = avg_dev;
+    fin.max_tiles = tiles0;
+    for (int i = 0; i < 18; ++i) {
+        fin.ntiles[i] = 0;
+        fin.one_per_pixels[i] = 0;
+    }
+    for (int scale = 0; scale < kScales; ++scale) {
+        const int cw = sw[scale], ch = sh[scale], nw = sw[scale + 1], nh = sh[scale + 1];
+        XybArgs xa;
+        xa.tab = tab_dev + (size_t)scale * npairs;
+        xa.stride = scale == 0 ? (int)stride : cw;
+        xa.w = cw;
+        xa.h = ch;
+        xa.nstride = nw;
+        xa.nw = nw;
+        xa.nh = nh;
+        xa.xstride = cw;
+        xa.k = kx;
+        hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, npairs), dim3(256), 0, ctx->stream, xa);
+        MapsArgs ma;
+        ma.tab = xa.tab;
+        ma.nactive = 0;
+        for (int c = 0; c < 3; ++c) {
+            const Skip sk = skip_of(c, scale);
+            if (sk.all()) continue;
+            const int k = ma.nactive++;
+            ma.plane[k] = c;
+            ma.flags[k] = (sk.ssim ? 0 : 1) | ((!sk.artifact || !sk.detail) ? 2 : 0);
+            ma.slot[k] = scale * 3 + c;
+        }
+        ma.stride = cw;
+        ma.w = cw;
+        ma.h = ch;
+        ma.tiles_x = (cw + TW - 1) / TW;
+        ma.tiles_y = (ch + TH - 1) / TH;
+        ma.partial = partial;
+        ma.max_tiles = tiles0;
+        if (ma.nactive > 0) {
+            vszip_probe_scope probe(ctx);
+            hipLaunchKernelGGL(ssim_maps_kernel, dim3(ma.tiles_x, ma.tiles_y, ma.nactive * npairs), dim3(256), 0, ctx->stream, ma);
+        }
+        for (int k = 0; k < ma.nactive; ++k) {
+            fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
+            fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
+        }
+    }
+    hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(64), 0, ctx->stream, fin);
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, avg_dev, (size_t)npairs * 18 * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
     for (int pair = 0; pair < npairs; ++pair) scores[pair] = score_of(avg[pair]);
