@@ -218,6 +218,100 @@ def setup_ssimulacra2(dev, w, h, pairs):
     return (lambda: dev.ssimulacra2(r, d)), (r, d)
 
 
+def eedi3_leg(dev, timed, no_cpu, frames=4):
+    """BASELINE config 4: EEDI3 field=1 dh=1 on 1920x1080 YUV420PS -> 1920x2160 (f32; the reference
+    rejects integer input). Latency/compute bound: reported as frames/s and interpolated lines/s."""
+    import fixtures as fx
+
+    base = [np.ascontiguousarray(fx.tiled_natural(s, np.float32, p)) for p, s in enumerate(yuv420_shapes(W1080, H1080))]
+    srcs = []
+    for f in range(frames):
+        srcs += [dev.upload(np.roll(p, f * 11, axis=1)) for p in base]
+    dsts = dev.eedi3(srcs, 1, dh=True)  # allocates the outputs once
+
+    def step():
+        table = dev.plane_table(srcs, dsts)
+        prm = _eedi3_params()
+        dev.check(dev.lib.vszip_eedi3(dev.ctx, table, None, None, len(srcs), 1, 0, prm))
+
+    dt, _, _, _ = timed.run(step, 5, 1)
+    lines = sum(s[0] for s in yuv420_shapes(W1080, H1080))  # one interpolated line per source line (dh)
+    res = {"value": frames * 5 / dt, "unit": "frames/s", "interpolated_lines_per_s": frames * 5 * lines / dt,
+           "workload": "vszip.EEDI3 field=1 dh=1 (defaults: mdis 20, nrad 2, vcheck 2), 1920x1080 YUV420PS -> 1920x2160, HBM-resident"}
+    if not no_cpu:
+        from oracle import oracle as orc
+
+        cores = os.cpu_count() or 1
+
+        def one(_):
+            for p in base:
+                orc.eedi3(p, 1, dh=True)
+
+        t0 = time.perf_counter()
+        one(0)
+        res["cpu_baseline"] = _timed_pool(one, cores, 4.0, "1920x1080 YUV420PS frame, EEDI3 field=1 dh=1", time.perf_counter() - t0)
+    return res
+
+
+def _eedi3_params():
+    import ctypes as C
+
+    from vszip_amd.capi import Eedi3Params
+
+    return C.byref(Eedi3Params(1, 0.2, 0.25, 20.0, 2, 20, 0, 2, 32.0, 64.0, 4.0))
+
+
+def xpsnr_leg(dev, timed, no_cpu, frames=8):
+    """XPSNR (getWSSE) on 1920x1080 YUV420P8 with temporal weighting; every frame is its own call
+    (the result is a host scalar, so each call synchronises)."""
+    import fixtures as fx
+
+    rng = np.random.default_rng(3)
+    org = [[np.roll(fx.tiled_natural(s, np.uint8, p), 5 * f, axis=1) for p, s in enumerate(yuv420_shapes(W1080, H1080))] for f in range(frames)]
+    rec = [[np.clip(p.astype(np.int16) + rng.integers(-3, 4, p.shape), 0, 255).astype(np.uint8) for p in fr] for fr in org]
+    dorg = [[dev.upload(p) for p in fr] for fr in org]
+    drec = [[dev.upload(p) for p in fr] for fr in rec]
+
+    def step():
+        for f in range(frames):
+            dev.xpsnr_wsse(dorg[f], drec[f], dorg[f - 1][0] if f >= 1 else None, dorg[f - 2][0] if f >= 2 else None, depth=8, frame_rate=24)
+
+    dt, _, _, _ = timed.run(step, 5, 1)
+    fb = 2 * sum(s[0] * s[1] for s in yuv420_shapes(W1080, H1080))
+    res = {"value": frames * 5 / dt, "unit": "frames/s", "algorithmic_GBps": frames * 5 * fb / dt / 1e9,
+           "workload": "vszip.XPSNR getWSSE, 1920x1080 YUV420P8 org vs rec, temporal, one synchronising call per frame"}
+    if not no_cpu:
+        from oracle import oracle as orc
+
+        cores = os.cpu_count() or 1
+
+        def one(_):
+            orc.xpsnr_wsse(org[2], rec[2], org[1][0], org[0][0], depth=8, frame_rate=24)
+
+        t0 = time.perf_counter()
+        one(0)
+        res["cpu_baseline"] = _timed_pool(one, cores, 2.0, "1920x1080 YUV420P8 frame pair, XPSNR", time.perf_counter() - t0)
+    return res
+
+
+def planestats_leg(dev, timed, frames=16):
+    """PlaneAverage / PlaneMinMax on 3840x2160 YUV420P16: single-pass readers, HBM roofline = bytes read once."""
+    base = make_frame(7, W4K, H4K)
+    planes = []
+    for f in range(frames):
+        planes += [dev.upload(np.roll(p, f * 3, axis=1)) for p in base]
+    fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K)) * frames
+    out = {}
+    for name, fn in (("plane_average_4k", lambda: dev.plane_average(planes, exclude=[-1])),
+                     ("plane_minmax_4k", lambda: dev.plane_minmax(planes)),
+                     ("plane_minmax_thr_4k", lambda: dev.plane_minmax(planes, 0.1, 0.1))):
+        dt, kms, _, _ = timed.run(fn, 10, 2)
+        gbs = fb * 10 / (kms * 1e-3) / 1e9
+        out[name] = {"value": frames * 10 / dt, "unit": "frames/s", "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
+                     "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call (48 planes), HBM-resident, includes the scalar D2H + sync"}
+    return out
+
+
 def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, rounds: int = 12):
     """PCIe-inclusive BoxBlur rate, the path a VapourSynth host pays: every frame is copied from
     pinned host memory to the GPU, blurred, and copied back. `nctx` contexts (one stream each,
@@ -354,6 +448,15 @@ def main() -> int:
             if not a.no_cpu:
                 others["ssimulacra2_4k"]["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K, 6.0)
             del keep
+            for leg_name, leg in (("eedi3_1080p", lambda: eedi3_leg(dev, timed, a.no_cpu)), ("xpsnr_1080p", lambda: xpsnr_leg(dev, timed, a.no_cpu))):
+                try:
+                    others[leg_name] = leg()
+                except Exception as e:
+                    others[leg_name] = {"error": str(e)}
+            try:
+                others.update(planestats_leg(dev, timed))
+            except Exception as e:
+                others["plane_stats_4k"] = {"error": str(e)}
             try:
                 others["boxblur_4k_pcie"] = pcie_boxblur(vszip_amd, local_rank, a.radius)
             except Exception as e:  # the PCIe leg is informative only

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Run single bench legs (eedi3 | xpsnr | planestats) for rocprofv3 --kernel-trace --stats."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import torch  # noqa: F401  (its HIP runtime first)
+
+import bench
+import vszip_amd
+
+dev = vszip_amd.Device(0)
+timed = bench.Timed(dev, dev.sync)
+for leg in sys.argv[1:]:
+    if leg == "eedi3":
+        print(bench.eedi3_leg(dev, timed, True))
+    elif leg == "xpsnr":
+        print(bench.xpsnr_leg(dev, timed, True))
+    elif leg == "planestats":
+        print(bench.planestats_leg(dev, timed))

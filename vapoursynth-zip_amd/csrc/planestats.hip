@@ -91,6 +91,30 @@ __device__ __forceinline__ A block_sum(A v, A *sh) {
     return r;
 }
 
+// One row through fn(v, j): 16-byte vector loads when the row(s) are 16-byte aligned (every
+// VapourSynth row is), scalar loads for the tail and for unaligned rows.
+template <typename T, bool REF, typename F>
+__device__ __forceinline__ void row_apply(const T *s, const T *r, int w, F &&fn) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool vec = ((reinterpret_cast<uintptr_t>(s) & 15) == 0) && (!REF || (reinterpret_cast<uintptr_t>(r) & 15) == 0);
+    int x0 = 0;
+    if (vec) {
+        const int nv = w / V;
+        for (int i = threadIdx.x; i < nv; i += kThreads) {
+            union {
+                uint4 q;
+                T e[V];
+            } a, b;
+            a.q = reinterpret_cast<const uint4 *>(s)[i];
+            if constexpr (REF) b.q = reinterpret_cast<const uint4 *>(r)[i];
+#pragma unroll
+            for (int k = 0; k < V; ++k) fn(a.e[k], REF ? b.e[k] : a.e[k]);
+        }
+        x0 = nv * V;
+    }
+    for (int x = x0 + (int)threadIdx.x; x < w; x += kThreads) fn(s[x], REF ? r[x] : s[x]);
+}
+
 __device__ __forceinline__ int find_plane(const PSParams &prm, int b) {
     int pi = 0;
     for (int i = 1; i < prm.nplanes; ++i)
@@ -99,7 +123,10 @@ __device__ __forceinline__ int find_plane(const PSParams &prm, int b) {
 }
 
 // ---- PlaneAverage ---------------------------------------------------------------
-template <typename T, bool REF>
+// NEX: compile-time size of the exclude list (0, 1 or 8 entries; a list shorter than NEX is
+// padded with copies of its first entry by the host) — the common exclude=[-1] on an integer
+// clip can never match and compiles to no compare at all.
+template <typename T, bool REF, int NEX>
 __global__ __launch_bounds__(kThreads) void average_kernel(const PSParams prm) {
     using S = Smp<T>;
     using Acc = typename S::Acc;
@@ -113,24 +140,26 @@ __global__ __launch_bounds__(kThreads) void average_kernel(const PSParams prm) {
     const T *ref = static_cast<const T *>(pl.ref);
     Acc acc = 0, dacc = 0;
     uint32_t cnt = 0;
+    int32_t ex[NEX > 0 ? NEX : 1];
+#pragma unroll
+    for (int e = 0; e < NEX; ++e) ex[e] = prm.excl[e];
     for (int y = y0; y < y1; ++y) {
         const T *s = src + (size_t)y * pl.sstride;
         const T *r = REF ? ref + (size_t)y * pl.rstride : nullptr;
-        for (int x = threadIdx.x; x < pl.w; x += kThreads) {
-            const T v = s[x];
+        row_apply<T, REF>(s, r, pl.w, [&](T v, T j) {
             bool found = false;
-            for (int e = 0; e < prm.nexcl; ++e) {
+#pragma unroll
+            for (int e = 0; e < NEX; ++e) {
                 if constexpr (S::is_int)
-                    found = found || ((int32_t)v == prm.excl[e]);
+                    found = found || ((int32_t)v == ex[e]);
                 else
-                    found = found || (S::f(v) == (float)prm.excl[e]);
+                    found = found || (S::f(v) == (float)ex[e]);
             }
             if (!found) {
                 if constexpr (S::is_int) acc += v; else acc += (double)S::f(v);
                 ++cnt;
             }
             if constexpr (REF) {
-                const T j = r[x];
                 if constexpr (S::is_int) {
                     dacc += v > j ? (uint64_t)(v - j) : (uint64_t)(j - v);
                 } else {
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void average_kernel(const PSParams prm) {
                     dacc += (double)S::f(d);
                 }
             }
-        }
+        });
     }
     const Acc tot = block_sum<Acc>(acc, sh);
     const Acc dtot = REF ? block_sum<Acc>(dacc, sh) : Acc(0);
@@ -158,31 +187,38 @@ __global__ __launch_bounds__(kThreads) void average_kernel(const PSParams prm) {
 }
 
 template <bool IS_INT>
-__global__ void average_final_kernel(const PSParams prm) {
-    const int pi = blockIdx.x;
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void average_final_kernel(const PSParams prm) {
+    const int pi = blockIdx.x, lane = threadIdx.x;
     const PSPlane pl = prm.p[pi];
     double *res = prm.result + (size_t)pi * 4;
     double total = 0;
     if constexpr (IS_INT) {
-        uint64_t s = 0, d = 0;
-        for (int b = 0; b < pl.nblocks; ++b) {
+        unsigned long long s = 0, d = 0;
+        for (int b = lane; b < pl.nblocks; b += 64) {
             const double *o = prm.partial + (size_t)(pl.block0 + b) * 4;
-            s += reinterpret_cast<const uint64_t *>(o)[0];
-            d += reinterpret_cast<const uint64_t *>(o)[2];
-            total += o[1];
+            s += reinterpret_cast<const unsigned long long *>(o)[0];
+            d += reinterpret_cast<const unsigned long long *>(o)[2];
+            total += o[1];  // pixel counts: exact in f64 in any order
         }
+        s = wave_reduce_sum(s);
+        d = wave_reduce_sum(d);
+        total = wave_reduce_sum(total);
+        if (lane != 0) return;
         // result(): planeaverage.zig:16-24
         res[0] = total == 0 ? 0.0 : (double)s / total / (double)prm.peak;
         res[1] = (double)d / (double)((uint32_t)pl.w * (uint32_t)pl.h) / (double)prm.peak;
     } else {
         double s = 0, d = 0;
-        for (int b = 0; b < pl.nblocks; ++b) {
+        for (int b = lane; b < pl.nblocks; b += 64) {
             const double *o = prm.partial + (size_t)(pl.block0 + b) * 4;
             s += o[0];
             d += o[2];
             total += o[1];
         }
+        s = wave_reduce_sum(s);  // fixed tree: reproducible
+        d = wave_reduce_sum(d);
+        total = wave_reduce_sum(total);
+        if (lane != 0) return;
         res[0] = total == 0 ? 0.0 : s / total;
         res[1] = d / (double)((uint32_t)pl.w * (uint32_t)pl.h);
     }
@@ -205,17 +241,17 @@ __global__ __launch_bounds__(kThreads) void minmax_kernel(const PSParams prm) {
     for (int y = y0; y < y1; ++y) {
         const T *s = src + (size_t)y * pl.sstride;
         const T *r = REF ? ref + (size_t)y * pl.rstride : nullptr;
-        for (int x = threadIdx.x; x < pl.w; x += kThreads) {
-            const float v = S::f(s[x]);
+        row_apply<T, REF>(s, r, pl.w, [&](T sv, T rv) {
+            const float v = S::f(sv);
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
             if constexpr (REF) {
                 if constexpr (S::is_int)
-                    dacc += fabs((double)v - (double)S::f(r[x]));  // planeminmax.zig:135-139
+                    dacc += fabs((double)v - (double)S::f(rv));  // planeminmax.zig:135-139
                 else
-                    dacc += (double)S::f((T)fabsf((float)(T)(s[x] - r[x])));  // @abs(v - j) in T
+                    dacc += (double)S::f((T)fabsf((float)(T)(sv - rv)));  // @abs(v - j) in T
             }
-        }
+        });
     }
     for (int d = 32; d >= 1; d >>= 1) {
         mn = fminf(mn, __shfl_down(mn, d, 64));
@@ -239,17 +275,22 @@ __global__ __launch_bounds__(kThreads) void minmax_kernel(const PSParams prm) {
     }
 }
 
-__global__ void minmax_final_kernel(const PSParams prm, int is_int) {
-    const int pi = blockIdx.x;
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void minmax_final_kernel(const PSParams prm, int is_int) {
+    const int pi = blockIdx.x, lane = threadIdx.x;
     const PSPlane pl = prm.p[pi];
     double mn = INFINITY, mx = -INFINITY, d = 0;
-    for (int b = 0; b < pl.nblocks; ++b) {
+    for (int b = lane; b < pl.nblocks; b += 64) {
         const double *o = prm.partial + (size_t)(pl.block0 + b) * 4;
         mn = fmin(mn, o[0]);
         mx = fmax(mx, o[1]);
         d += o[2];
     }
+    for (int k = 32; k >= 1; k >>= 1) {
+        mn = fmin(mn, __shfl_down(mn, k, 64));
+        mx = fmax(mx, __shfl_down(mx, k, 64));
+    }
+    d = wave_reduce_sum(d);
+    if (lane != 0) return;
     double *res = prm.result + (size_t)pi * 4;
     const double total = (double)((uint32_t)pl.w * (uint32_t)pl.h);
     res[0] = mn;
@@ -285,20 +326,23 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const PSParams prm) {
     for (int y = y0; y < y1; ++y) {
         const T *s = src + (size_t)y * pl.sstride;
         const T *r = (REF && LEVEL == 0) ? ref + (size_t)y * pl.rstride : nullptr;
-        for (int x = threadIdx.x; x < pl.w; x += kThreads) {
-            const uint32_t idx = S::idx(s[x]);
-            if (LEVEL == 0) {
+        if (LEVEL == 0) {
+            row_apply<T, REF>(s, r, pl.w, [&](T sv, T rv) {
+                const uint32_t idx = S::idx(sv);
                 atomicAdd(&h0[wide ? (idx >> 8) : idx], 1u);
                 if constexpr (REF) {
                     if constexpr (S::is_int)
-                        dacc += fabs((double)S::f(s[x]) - (double)S::f(r[x]));
+                        dacc += fabs((double)S::f(sv) - (double)S::f(rv));
                     else
-                        dacc += (double)S::f((T)fabsf((float)(T)(s[x] - r[x])));
+                        dacc += (double)S::f((T)fabsf((float)(T)(sv - rv)));
                 }
-            } else {
+            });
+        } else {
+            row_apply<T, false>(s, s, pl.w, [&](T sv, T) {
+                const uint32_t idx = S::idx(sv);
                 if ((idx >> 8) == blo) atomicAdd(&h0[idx & 255u], 1u);
                 if ((idx >> 8) == bhi) atomicAdd(&h1[idx & 255u], 1u);
-            }
+            });
         }
     }
     __syncthreads();
@@ -348,10 +392,13 @@ __global__ void bucket_kernel(const PSParams prm, int wide) {
     for (int u = 0; u < 512; ++u) g[u] = wide ? 0u : g[u];  // level 1 reuses the table
 }
 
-__global__ void thr_final_kernel(const PSParams prm, int wide, int is_int) {
+__global__ __launch_bounds__(64) void thr_final_kernel(const PSParams prm, int wide, int is_int) {
     const int pi = blockIdx.x;
-    if (threadIdx.x != 0) return;
     const PSPlane pl = prm.p[pi];
+    double d = 0;
+    for (int b = threadIdx.x; b < pl.nblocks; b += 64) d += prm.partial[(size_t)(pl.block0 + b) * 4 + 2];
+    d = wave_reduce_sum(d);
+    if (threadIdx.x != 0) return;
     const uint32_t *g = prm.hist + (size_t)pi * 512;
     const uint32_t *bk = prm.bucket + pi * 8;
     const double total = (double)((uint32_t)pl.w * (uint32_t)pl.h);
@@ -384,8 +431,6 @@ __global__ void thr_final_kernel(const PSParams prm, int wide, int is_int) {
         if (bk[0] != 0xffffffffu) retmin = bk[0];
         if (bk[2] != 0xffffffffu) retmax = bk[2];
     }
-    double d = 0;
-    for (int b = 0; b < pl.nblocks; ++b) d += prm.partial[(size_t)(pl.block0 + b) * 4 + 2];
     double *res = prm.result + (size_t)pi * 4;
     if (is_int) {
         res[0] = retmin;
@@ -463,10 +508,29 @@ int fetch(vszip_ctx *ctx, const Launch &L, double *r0, double *r1, double *r2) {
 
 template <typename T>
 int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
-    if (ref)
-        hipLaunchKernelGGL((average_kernel<T, true>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+    // exclude values an integer sample can never take are dropped (the usual exclude=[-1]);
+    // the list is then padded to the kernel's compile-time size with copies of its first entry
+    int n = 0;
+    for (int i = 0; i < L.prm.nexcl; ++i)
+        if (!Smp<T>::is_int || (L.prm.excl[i] >= 0 && L.prm.excl[i] <= (int32_t)L.prm.peak)) L.prm.excl[n++] = L.prm.excl[i];
+    L.prm.nexcl = n;
+    const int nex = n == 0 ? 0 : (n == 1 ? 1 : 8);
+    for (int i = n; i < nex; ++i) L.prm.excl[i] = L.prm.excl[0];
+    const dim3 grid(L.total_blocks), block(kThreads);
+#define VSZIP_AVG_LAUNCH(NEX)                                                                        \
+    do {                                                                                             \
+        if (ref)                                                                                     \
+            hipLaunchKernelGGL((average_kernel<T, true, NEX>), grid, block, 0, ctx->stream, L.prm);  \
+        else                                                                                         \
+            hipLaunchKernelGGL((average_kernel<T, false, NEX>), grid, block, 0, ctx->stream, L.prm); \
+    } while (0)
+    if (nex == 0)
+        VSZIP_AVG_LAUNCH(0);
+    else if (nex == 1)
+        VSZIP_AVG_LAUNCH(1);
     else
-        hipLaunchKernelGGL((average_kernel<T, false>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+        VSZIP_AVG_LAUNCH(8);
+#undef VSZIP_AVG_LAUNCH
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (Smp<T>::is_int)
         hipLaunchKernelGGL((average_final_kernel<true>), dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm);
