@@ -218,7 +218,7 @@ def setup_ssimulacra2(dev, w, h, pairs):
     return (lambda: dev.ssimulacra2(r, d)), (r, d)
 
 
-def eedi3_leg(dev, timed, no_cpu, frames=4):
+def eedi3_leg(dev, timed, no_cpu, frames=16):
     """BASELINE config 4: EEDI3 field=1 dh=1 on 1920x1080 YUV420PS -> 1920x2160 (f32; the reference
     rejects integer input). Latency/compute bound: reported as frames/s and interpolated lines/s."""
     import fixtures as fx

@@ -30,7 +30,7 @@ namespace {
 constexpr int kMaxMdis = 31;
 constexpr int kXB = 64;         // columns per block
 constexpr int kTbMax = 64 + 4 * kMaxMdis + 2 * 3 + 8;
-constexpr int kMaxPlanesE = 16;
+constexpr int kMaxPlanesE = 48;  // planes per call (16 YUV frames): the per-plane vcheck chains run side by side
 
 struct EPlane {
     const float *src;   // field-source plane (vertical layout: rows = lines)
@@ -71,9 +71,32 @@ __device__ __forceinline__ float rowv(const float *row, int c, int w) {
     return row[c];
 }
 
+// Single-wave workgroups: LDS traffic is ordered by a wave-level fence, no s_barrier.
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// value of the lane below / above through a DPP wave shift (no LDS round trip); the first /
+// last lane receives `edge`
+__device__ __forceinline__ float lane_below(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));  // wave_shr:1
+}
+__device__ __forceinline__ float lane_above(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
+}
+
+constexpr int kU = 4;  // directions per cost pass
+constexpr int kRowW = kXB + 2 * (2 * kMaxMdis + 3);  // staged columns per source row: block + reach 2*mdis + nrad each side
+
+// NRAD is a template parameter so that the window-sum loop unrolls: with a runtime trip count
+// its LDS reads are issued one per iteration and each waits out the full LDS latency.
+template <int NRAD>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const float kFltMax09 = FLT_MAX * 0.9f;
-    __shared__ float tb[kTbMax];
+    __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
+    __shared__ float tb[kU][kTbMax];  // t_base of the kU directions of the current pass
+    __shared__ float ws[kU][kTbMax];  // their (2*nrad+1)-tap window sums
     __shared__ float ctile[2 * kMaxMdis + 1][kXB + 1];
     __shared__ int8_t ptile[kXB][64];
     __shared__ int fpt[kXB];
@@ -86,7 +109,8 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const EPlane pl = prm.p[pi];
     const int off = gl - pl.line0;              // interpolated-line index within the plane
     const int line = prm.field + 2 * off;       // destination line
-    const int w = pl.w, mdis = prm.mdis, nrad = prm.nrad, tpitch = 2 * mdis + 1;
+    constexpr int nrad = NRAD;
+    const int w = pl.w, mdis = prm.mdis, tpitch = 2 * mdis + 1;
     const int lane = threadIdx.x;
     const bool dh = prm.dh != 0;
     const float *r3p = pl.src + (size_t)src_col(dh, line - 3, pl.n_src) * pl.sstride;
@@ -96,39 +120,82 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     int8_t *pback = pl.pback + (size_t)off * w * tpitch;
     float *out = pl.dst + (size_t)line * pl.dstride;
     int *dmap = pl.dmap + (size_t)off * w;
+    const int reach = 2 * mdis + nrad, roww = kXB + 2 * reach;
 
     float pcost = kFltMax09;  // DP state of direction `lane` (inactive lanes stay at the sentinel)
     const int nblk = (w + kXB - 1) / kXB;
     for (int blk = 0; blk < nblk; ++blk) {
         const int xb = blk * kXB;
         const int x = xb + lane;
-        // ---- cost phase, lanes = x -------------------------------------------------
-        for (int u = -mdis; u <= mdis; ++u) {
-            const int two_u = 2 * u;
-            const int jlo = min(u, min(0, two_u)) - nrad, jhi = max(u, max(0, two_u)) + nrad;
-            const int span = kXB + jhi - jlo;  // t_base columns xb+jlo .. xb+63+jhi
-            __syncthreads();
-            for (int t = lane; t < span; t += 64) {
-                const int j = xb + jlo + t;
-                const float a = rowv(r3p, j, w), b = rowv(r1p, j - two_u, w), c = rowv(r1p, j, w);
-                const float d = rowv(r1n, j - two_u, w), e = rowv(r1n, j, w), f = rowv(r3n, j - two_u, w);
-                tb[t] = fabsf(a - b) + fabsf(c - d) + fabsf(e - f);  // :415-425
-            }
-            __syncthreads();
-            if (x < w) {
-                float sw0 = 0.0f, sw1 = 0.0f, sw2 = 0.0f;
-                const int base = lane - jlo;  // index of column x
-                for (int k = -nrad; k <= nrad; ++k) {  // :443-450 fresh window sums in k order
-                    sw1 += tb[base + k];
-                    sw0 += tb[base + u + k];
-                    sw2 += tb[base + two_u + k];
-                }
-                const float ip = (rowv(r1p, x + u, w) + rowv(r1n, x - u, w)) * 0.5f;
-                const float v = fabsf(rowv(r1p, x, w) - ip) + fabsf(rowv(r1n, x, w) - ip);
-                ctile[mdis + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
-            }
+        const int c0 = xb - reach;  // plane column of rows[.][0]
+        // ---- stage the four source rows once per block ------------------------------------
+        wave_fence();
+        for (int t = lane; t < roww; t += 64) {
+            const int c = min(c0 + t, w - 1 + reach);  // columns past the padding are never read back
+            rows[0][t] = rowv(r3p, c, w);
+            rows[1][t] = rowv(r1p, c, w);
+            rows[2][t] = rowv(r1n, c, w);
+            rows[3][t] = rowv(r3n, c, w);
         }
-        __syncthreads();
+        wave_fence();
+        const int lx = lane + reach;  // rows[] index of column x
+        // ---- cost phase, lanes = x; kU directions per pass -------------------------------
+        // The three steps of a direction (t_base -> window sums -> cost) are a chain of LDS
+        // round trips; one direction at a time leaves the wave waiting on LDS latency most of
+        // the time, so kU directions go through each step together (independent work in flight).
+        for (int ug = -mdis; ug <= mdis; ug += kU) {
+            int jlo[kU], span[kU];
+            int span_max = 0;
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {
+                const int u = min(ug + i, mdis), two_u = 2 * u;  // a clamped duplicate past +mdis is computed but never stored
+                jlo[i] = min(u, min(0, two_u)) - nrad;
+                span[i] = kXB + max(u, max(0, two_u)) + nrad - jlo[i];  // t_base columns xb+jlo .. xb+63+jhi
+                span_max = max(span_max, span[i]);
+            }
+            for (int t = lane; t < span_max; t += 64) {
+#pragma unroll
+                for (int i = 0; i < kU; ++i) {
+                    if (t < span[i]) {
+                        const int two_u = 2 * min(ug + i, mdis);
+                        const int j = jlo[i] + t + reach;  // rows[] index of column xb + jlo + t
+                        const float a = rows[0][j], b = rows[1][j - two_u], c = rows[1][j];
+                        const float d = rows[2][j - two_u], e = rows[2][j], f = rows[3][j - two_u];
+                        tb[i][t] = fabsf(a - b) + fabsf(c - d) + fabsf(e - f);  // :415-425
+                    }
+                }
+            }
+            wave_fence();
+            // window sums, accumulated from 0 in k order exactly like sw0/sw1/sw2 (:443-450): the
+            // three sums of a pixel are the same function of t_base at x+u, x, x+2u
+            for (int t = lane + nrad; t < span_max - nrad; t += 64) {
+#pragma unroll
+                for (int i = 0; i < kU; ++i) {
+                    if (t < span[i] - nrad) {
+                        float sw = 0.0f;
+#pragma unroll
+                        for (int k = -nrad; k <= nrad; ++k) sw += tb[i][t + k];
+                        ws[i][t] = sw;
+                    }
+                }
+            }
+            wave_fence();
+            if (x < w) {
+#pragma unroll
+                for (int i = 0; i < kU; ++i) {
+                    const int u = ug + i, two_u = 2 * u;
+                    if (u <= mdis) {
+                        const int base = lane - jlo[i];  // tb/ws index of column x
+                        const float sw1 = ws[i][base], sw0 = ws[i][base + u], sw2 = ws[i][base + two_u];
+                        const float ip = (rows[1][lx + u] + rows[2][lx - u]) * 0.5f;
+                        const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
+                        ctile[mdis + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
+                    }
+                }
+            }
+            wave_fence();  // tb / ws are rewritten by the next pass
+        }
+        wave_fence();
         // ---- DP phase, lanes = direction index ---------------------------------------
         const int xe = min(kXB, w - xb);
         for (int xl = 0; xl < xe; ++xl) {
@@ -138,9 +205,8 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 pcost = lane < tpitch ? tc : kFltMax09;  // :461-463
                 continue;
             }
-            float left = __shfl_up(pcost, 1, 64);
-            float right = __shfl_down(pcost, 1, 64);
-            if (lane == 0) left = kFltMax09;
+            const float left = lane_below(pcost, kFltMax09);
+            float right = lane_above(pcost, kFltMax09);
             if (lane >= tpitch - 1) right = kFltMax09;
             const float left_cc = left + prm.gamma, right_cc = right + prm.gamma;
             float bval = pcost;  // :536-548
@@ -161,7 +227,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 ptile[xl - 1][lane] = (int8_t)bd;
             }
         }
-        __syncthreads();
+        wave_fence();
         // flush the block's back-pointers (rows xb .. xb+xe-2; row xb+xe-1 comes with the next block)
         for (int t = lane; t < (xe - 1) * tpitch; t += 64) {
             const int r = t / tpitch, c = t - r * tpitch;
@@ -234,63 +300,141 @@ struct VParams {
     float vthresh2, rcp0, rcp1, rcp2;
 };
 
-// vcheckLine (:915-1046), hp = false. One workgroup per plane walks the lines in order.
-__global__ __launch_bounds__(1024) void eedi3_vcheck_kernel(const VParams prm) {
-    const EPlane pl = prm.p[blockIdx.x];
-    const float *scp = prm.scp[blockIdx.x];
+// vcheckLine (:915-1046), hp = false. Line pd blends against line pd-2 AS ALREADY BLENDED, so
+// the lines of a plane form a sequential chain; one workgroup per plane walks it, 1024 columns
+// at a time. Only two terms of a pixel depend on the chain (d2p[i+dir], twice): everything
+// else — nine gathers and most of the arithmetic — is prepared one line ahead in registers
+// while the current line resolves, and the blended line is handed to the next iteration
+// through LDS, so the per-line critical path is one LDS read, ~30 ALU ops, one LDS write and
+// one barrier instead of a round trip through global memory.
+constexpr int kVcCols = 4;  // columns per thread: lines up to 4096 wide
+
+struct VcPre {
+    float cint, dl_i, d1p_i, d1n_i, dl_imd, d1p_ipd, t_ipd, ib, vb, vc, a2;
+    int ipd;  // < 0: the pixel keeps cint (no direction / inconsistent neighbours / too close to the edge)
+};
+
+__device__ __forceinline__ void vcheck_prepare(const EPlane &pl, const VParams &prm, const float *scp, int scstride, int off, int i, VcPre &q) {
     const int L = pl.w;
     const bool dh = prm.dh != 0;
-    for (int off = 1; off + 1 < pl.n_interp; ++off) {
+    const int pd = prm.field + 2 * off;
+    const float *dl = pl.dst + (size_t)pd * pl.dstride;
+    const float *d1p = pl.dst + (size_t)(pd - 1) * pl.dstride, *d1n = pl.dst + (size_t)(pd + 1) * pl.dstride;
+    const float *d2n = pl.dst + (size_t)(pd + 2) * pl.dstride;
+    const float *d3p = pl.src + (size_t)src_col(dh, pd - 3, pl.n_src) * pl.sstride;
+    const float *d3n = pl.src + (size_t)src_col(dh, pd + 3, pl.n_src) * pl.sstride;
+    const int *dc = pl.dmap + (size_t)off * L, *dp = pl.dmap + (size_t)(off - 1) * L, *dn = pl.dmap + (size_t)(off + 1) * L;
+    const int dirc = dc[i];
+    q.d1p_i = d1p[i];
+    q.d1n_i = d1n[i];
+    q.cint = scp ? scp[(size_t)pd * scstride + i] : 0.5625f * (q.d1p_i + q.d1n_i) - 0.0625f * (d3p[i] + d3n[i]);
+    q.dl_i = dl[i];
+    q.ipd = -1;
+    const int dirt = dp[i], dirb = dn[i];
+    const int maxoff = abs(dirc);
+    if (dirc != 0 && !(max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) && !(i + maxoff >= L || i - maxoff < 0)) {
+        const int ipd = i + dirc, imd = i - dirc;
+        q.ipd = ipd;
+        q.dl_imd = dl[imd];
+        q.d1p_ipd = d1p[ipd];
+        const float dl_ipd = dl[ipd], d2n_imd = d2n[imd], d1n_imd = d1n[imd];
+        q.t_ipd = fabsf(dl_ipd - q.d1p_ipd);
+        q.ib = (dl_ipd + d2n_imd) * 0.5f;
+        q.vb = fabsf(d2n_imd - d1n_imd) + fabsf(q.dl_imd - d1n_imd);
+        q.vc = fabsf(q.dl_i - q.d1p_i) + fabsf(q.dl_i - q.d1n_i);
+        q.a2 = fmaxf((prm.vthresh2 - (float)maxoff) * prm.rcp2, 0.0f);
+    }
+}
+
+__device__ __forceinline__ float vcheck_resolve(const VParams &prm, const VcPre &q, const float *prev) {
+    if (q.ipd < 0) return q.cint;
+    const float d2 = prev[q.ipd];
+    const float it = (d2 + q.dl_imd) * 0.5f;
+    const float vt = fabsf(d2 - q.d1p_ipd) + q.t_ipd;
+    const float e0 = fabsf(it - q.d1p_i), e1 = fabsf(q.ib - q.d1n_i), e2 = fabsf(vt - q.vc), e3 = fabsf(q.vb - q.vc);
+    float m0, m1;
+    if (prm.vcheck == 1) {
+        m0 = fminf(e0, e1);
+        m1 = fminf(e2, e3);
+    } else if (prm.vcheck == 2) {
+        m0 = (e0 + e1) * 0.5f;
+        m1 = (e2 + e3) * 0.5f;
+    } else {
+        m0 = fmaxf(e0, e1);
+        m1 = fmaxf(e2, e3);
+    }
+    const float a0 = m0 * prm.rcp0, a1 = m1 * prm.rcp1;
+    const float a = fminf(fmaxf(a0, fmaxf(a1, q.a2)), 1.0f);
+    return (1.0f - a) * q.dl_i + a * q.cint;
+}
+
+__global__ __launch_bounds__(1024) void eedi3_vcheck_kernel(const VParams prm) {
+    __shared__ float prevl[2][1024 * kVcCols];
+    const EPlane pl = prm.p[blockIdx.x];
+    const float *scp = prm.scp[blockIdx.x];
+    const int scstride = prm.scstride[blockIdx.x];
+    const int L = pl.w;
+    const int tid = threadIdx.x;
+    auto processed = [&](int off) {
         const int pd = prm.field + 2 * off;
-        if (pd < 2 || pd + 2 >= pl.n_dst) continue;
+        return off >= 1 && off + 1 < pl.n_interp && pd >= 2 && pd + 2 < pl.n_dst;
+    };
+    int cur = 0;
+    bool have_prev = false;  // prevl[cur] holds the blended line pd-2
+    VcPre q[kVcCols], qn[kVcCols];
+    int off = 1;
+    while (off + 1 < pl.n_interp && !processed(off)) ++off;
+    if (off + 1 < pl.n_interp) {
+#pragma unroll
+        for (int c = 0; c < kVcCols; ++c)
+            if (tid + c * 1024 < L) vcheck_prepare(pl, prm, scp, scstride, off, tid + c * 1024, q[c]);
+    }
+    for (; off + 1 < pl.n_interp; ++off) {
+        if (!processed(off)) {
+            have_prev = false;
+            continue;
+        }
+        const int pd = prm.field + 2 * off;
         float *dl = pl.dst + (size_t)pd * pl.dstride;
-        const float *d1p = pl.dst + (size_t)(pd - 1) * pl.dstride, *d2p = pl.dst + (size_t)(pd - 2) * pl.dstride;
-        const float *d1n = pl.dst + (size_t)(pd + 1) * pl.dstride, *d2n = pl.dst + (size_t)(pd + 2) * pl.dstride;
-        const float *d3p = pl.src + (size_t)src_col(dh, pd - 3, pl.n_src) * pl.sstride;
-        const float *d3n = pl.src + (size_t)src_col(dh, pd + 3, pl.n_src) * pl.sstride;
-        const int *dc = pl.dmap + (size_t)off * L, *dp = pl.dmap + (size_t)(off - 1) * L, *dn = pl.dmap + (size_t)(off + 1) * L;
-        const float *sl = scp ? scp + (size_t)pd * prm.scstride[blockIdx.x] : nullptr;
-        // every column first computes its blended value from the line as it stands, then all
-        // columns store (tline + memcpy in the reference)
-        float res[4];
-        int cnt = 0;
-        for (int i = threadIdx.x; i < L; i += 1024, ++cnt) {
-            const int dirc = dc[i];
-            const float cint = sl ? sl[i] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
-            float r = cint;
-            const int dirt = dp[i], dirb = dn[i];
-            const int maxoff = abs(dirc);
-            if (dirc != 0 && !(max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) && !(i + maxoff >= L || i - maxoff < 0)) {
-                const int ipd = i + dirc, imd = i - dirc;
-                const float it = (d2p[ipd] + dl[imd]) * 0.5f;
-                const float ib = (dl[ipd] + d2n[imd]) * 0.5f;
-                const float vt = fabsf(d2p[ipd] - d1p[ipd]) + fabsf(dl[ipd] - d1p[ipd]);
-                const float vb = fabsf(d2n[imd] - d1n[imd]) + fabsf(dl[imd] - d1n[imd]);
-                const float vc = fabsf(dl[i] - d1p[i]) + fabsf(dl[i] - d1n[i]);
-                const float e0 = fabsf(it - d1p[i]), e1 = fabsf(ib - d1n[i]), e2 = fabsf(vt - vc), e3 = fabsf(vb - vc);
-                float m0, m1;
-                if (prm.vcheck == 1) {
-                    m0 = fminf(e0, e1);
-                    m1 = fminf(e2, e3);
-                } else if (prm.vcheck == 2) {
-                    m0 = (e0 + e1) * 0.5f;
-                    m1 = (e2 + e3) * 0.5f;
-                } else {
-                    m0 = fmaxf(e0, e1);
-                    m1 = fmaxf(e2, e3);
-                }
-                const float a0 = m0 * prm.rcp0, a1 = m1 * prm.rcp1;
-                const float a2 = fmaxf((prm.vthresh2 - (float)maxoff) * prm.rcp2, 0.0f);
-                const float a = fminf(fmaxf(a0, fmaxf(a1, a2)), 1.0f);
-                r = (1.0f - a) * dl[i] + a * cint;
+        if (!have_prev) {  // line pd-2 was not blended by this pass: take it from memory
+            const float *d2p = pl.dst + (size_t)(pd - 2) * pl.dstride;
+#pragma unroll
+            for (int c = 0; c < kVcCols; ++c)
+                if (tid + c * 1024 < L) prevl[cur][tid + c * 1024] = d2p[tid + c * 1024];
+            __syncthreads();
+        }
+        // the next line's chain-independent part, issued before this line resolves
+        const bool next = processed(off + 1);
+        if (next) {
+#pragma unroll
+            for (int c = 0; c < kVcCols; ++c)
+                if (tid + c * 1024 < L) vcheck_prepare(pl, prm, scp, scstride, off + 1, tid + c * 1024, qn[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < kVcCols; ++c) {
+            const int i = tid + c * 1024;
+            if (i < L) {
+                const float r = vcheck_resolve(prm, q[c], prevl[cur]);
+                prevl[cur ^ 1][i] = r;
+                dl[i] = r;
             }
-            if (cnt < 4) res[cnt] = r;
         }
         __syncthreads();
-        cnt = 0;
-        for (int i = threadIdx.x; i < L; i += 1024, ++cnt) dl[i] = res[cnt];
-        __threadfence_block();
-        __syncthreads();
+        cur ^= 1;
+        have_prev = true;
+        if (next) {
+#pragma unroll
+            for (int c = 0; c < kVcCols; ++c) q[c] = qn[c];
+        } else if (off + 2 < pl.n_interp) {
+            // a skipped line follows: prepare the one after it when its turn comes
+            int o2 = off + 1;
+            while (o2 + 1 < pl.n_interp && !processed(o2)) ++o2;
+            if (o2 + 1 < pl.n_interp) {
+#pragma unroll
+                for (int c = 0; c < kVcCols; ++c)
+                    if (tid + c * 1024 < L) vcheck_prepare(pl, prm, scp, scstride, o2, tid + c * 1024, q[c]);
+            }
+        }
     }
 }
 
@@ -435,7 +579,12 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
         vp.p[i] = d;
     }
     hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);
-    hipLaunchKernelGGL(eedi3_line_kernel, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep);
+    switch (up->nrad) {
+        case 0: hipLaunchKernelGGL(eedi3_line_kernel<0>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+        case 1: hipLaunchKernelGGL(eedi3_line_kernel<1>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+        case 2: hipLaunchKernelGGL(eedi3_line_kernel<2>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+        default: hipLaunchKernelGGL(eedi3_line_kernel<3>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+    }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (up->vcheck > 0) {
         for (int i = 0; i < nplanes; ++i)
