@@ -37,7 +37,7 @@ enum vszip_status {
     VSZIP_OK = 0,
     VSZIP_ERR_ARG = -1,         /* invalid argument (the wrapper's create-time checks) */
     VSZIP_ERR_HIP = -2,         /* a HIP runtime call failed; see vszip_last_error */
-    VSZIP_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet */
+    VSZIP_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet (DESIGN.md section 1 lists the cases) */
     VSZIP_ERR_NOMEM = -4
 };
 
@@ -193,6 +193,15 @@ typedef struct vszip_eedi3_params {
 int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips,
                 const ptrdiff_t *sclip_strides, int nplanes, int field, int horizontal,
                 const vszip_eedi3_params *params);
+/* The same with the `mclip` mask (createImpl :393-433, buildBmask src/filters/eedi3.zig:285-304):
+ * mclips[i] (may be NULL, as may the array) is an 8-bit plane with the geometry of planes[i].src —
+ * the wrapper passes the same Gray mask for every plane, like getFrame :215-218 — strides in
+ * bytes == elements. Pixels whose +-mdis neighbourhood holds no mask sample keep the plain
+ * vertical cubic. */
+int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips,
+                      const ptrdiff_t *sclip_strides, const uint8_t *const *mclips,
+                      const ptrdiff_t *mclip_strides, int nplanes, int field, int horizontal,
+                      const vszip_eedi3_params *params);
 
 /*
  * XPSNR — replaces filter.getWSSE (src/filters/xpsnr.zig:376) called from XPSNR(T).getFrame

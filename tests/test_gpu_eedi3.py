@@ -42,6 +42,45 @@ def test_matches_oracle(dev, oracle, kw):
     assert np.array_equal(got, want), (kw, int((got != want).sum()))
 
 
+GENERAL = [
+    dict(field=1, hp=True), dict(field=0, hp=True, dh=True), dict(field=1, hp=True, vcheck=0), dict(field=1, hp=True, vcheck=3, mdis=10, nrad=1),
+    dict(field=1, hp=True, mdis=40, nrad=3), dict(field=1, mdis=40, nrad=3), dict(field=1, mdis=40, nrad=0), dict(field=0, mdis=33, gamma=0.0, vcheck=1),
+    dict(field=1, hp=True, mdis=7, nrad=0, alpha=0.4, beta=0.3, gamma=40.0),
+]
+
+
+@pytest.mark.parametrize("kw", GENERAL, ids=[",".join(f"{k}={v}" for k, v in c.items()) for c in GENERAL])
+def test_general_kernel_matches_oracle(dev, oracle, kw):
+    """hp=True (half-pel directions, +-2 transitions) and mdis up to 40 go through the general line
+    kernel (reference tests/test_eedi3.py: hp=1, mdis=40 cases)."""
+    src = fx.crop_rgbs()[1][:96, :401]
+    kw = dict(kw)
+    field = kw.pop("field")
+    got = _gpu(dev, src, field, **kw)
+    want = oracle.eedi3(src, field, **kw)
+    assert np.array_equal(got, want), (kw, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("hp", [False, True])
+@pytest.mark.parametrize("horizontal", [False, True])
+def test_mclip(dev, oracle, hp, horizontal):
+    """mclip: only pixels with a mask sample within +-mdis are connected (buildBmask), an all-zero
+    mask line falls back to the vertical cubic."""
+    src = np.ascontiguousarray(fx.crop_rgbs()[0][:90, :300])
+    rng = np.random.default_rng(5)
+    mask = (rng.random(src.shape) < 0.01).astype(np.uint8) * 255
+    mask[10:20] = 0          # lines without any sample
+    mask[:, 120:220] = 0     # a wide unmasked band
+    s = dev.upload(src)
+    m = dev.upload(mask)
+    (d,) = dev.eedi3([s], 1, hp=hp, horizontal=horizontal, mclips=[m])
+    want = oracle.eedi3(src, 1, hp=hp, horizontal=horizontal, mclip=mask)
+    got = dev.download(d)
+    assert np.array_equal(got, want), int((got != want).sum())
+    (d0,) = dev.eedi3([s], 1, hp=hp, horizontal=horizontal, mclips=[dev.upload(np.zeros_like(mask))])
+    assert np.array_equal(dev.download(d0), oracle.eedi3(src, 1, hp=hp, horizontal=horizontal, mclip=np.zeros_like(mask)))
+
+
 def test_horizontal_matches_oracle_and_identity(dev, oracle):
     src = fx.crop_rgbs()[0][:150, :200]
     for dh in (False, True):

@@ -163,3 +163,25 @@ def test_eedi3_through_plugin(oracle):
     assert np.array_equal(dbl.get_frame(0)[0], oracle.eedi3(planes[0], 1)) and np.array_equal(dbl.get_frame(1)[0], oracle.eedi3(planes[0], 0))
     h = vs.source([[planes[0]]], vs.GRAYS).vszip.EEDI3H(field=1).get_frame(0)
     assert np.array_equal(h[0], oracle.eedi3(planes[0], 1, horizontal=True))
+
+
+def test_eedi3_hp_mdis40_mclip_through_plugin(oracle):
+    """The rest of the EEDI3 signature: hp=1, mdis up to 40, and a Gray8 mclip that drives every
+    plane of a YUV clip (its top-left region for the subsampled planes, src/vapoursynth/eedi3.zig:215-218)."""
+    planes = [np.ascontiguousarray(fx.crop_rgbs()[0][:96, :240]), np.ascontiguousarray(fx.crop_rgbs()[1][:48, :120]), np.ascontiguousarray(fx.crop_rgbs()[2][:48, :120])]
+    src = vs.source([planes], vs.YUV420PS)
+    hp = src.vszip.EEDI3(field=1, hp=1).get_frame(0)
+    wide = src.vszip.EEDI3(field=0, mdis=40, nrad=3).get_frame(0)
+    for p in range(3):
+        assert np.array_equal(hp[p], oracle.eedi3(planes[p], 1, hp=True))
+        assert np.array_equal(wide[p], oracle.eedi3(planes[p], 0, mdis=40, nrad=3))
+    rng = np.random.default_rng(11)
+    mask = (rng.random(planes[0].shape) < 0.02).astype(np.uint8) * 255
+    mask[30:40] = 0
+    m = vs.source([[mask]], vs.GRAY8)
+    out = src.vszip.EEDI3(field=1, mclip=m).get_frame(0)
+    for p in range(3):
+        h, w = planes[p].shape
+        assert np.array_equal(out[p], oracle.eedi3(planes[p], 1, mclip=np.ascontiguousarray(mask[:h, :w])))
+    with pytest.raises(vs.Error, match="mclip's dimensions don't match"):
+        src.vszip.EEDI3(field=1, mclip=vs.source([[mask[:50]]], vs.GRAY8))

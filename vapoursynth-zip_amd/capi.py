@@ -77,6 +77,7 @@ SYMBOLS = {
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
     "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
     "vszip_eedi3": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
+    "vszip_eedi3_mclip": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
     "vszip_xpsnr_wsse": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd), _i, _i, C.c_uint, _i,
                               C.POINTER(C.c_uint64)]),
     "vszip_xpsnr_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64, _i]),
@@ -303,8 +304,8 @@ class Device:
         return list(out)
 
     def eedi3(self, srcs, field, dh=False, alpha=0.2, beta=0.25, gamma=20.0, nrad=2, mdis=20, hp=False, vcheck=2,
-              vthresh0=32.0, vthresh1=64.0, vthresh2=4.0, sclips=None, horizontal=False):
-        """srcs: f32 DevPlanes. Returns the output DevPlanes."""
+              vthresh0=32.0, vthresh1=64.0, vthresh2=4.0, sclips=None, horizontal=False, mclips=None):
+        """srcs: f32 DevPlanes; mclips: optional u8 DevPlanes with the geometry of srcs. Returns the output DevPlanes."""
         dsts = []
         for s in srcs:
             if horizontal:
@@ -319,7 +320,12 @@ class Device:
             ss = (C.c_ssize_t * n)(*[(s.stride if s is not None else 0) for s in sclips])
         else:
             sp, ss = None, None
-        self.check(self.lib.vszip_eedi3(self.ctx, table, sp, ss, n, field, int(horizontal), C.byref(prm)))
+        if mclips is not None:
+            mp = (C.c_void_p * n)(*[(m.ptr if m is not None else None) for m in mclips])
+            ms = (C.c_ssize_t * n)(*[(m.stride if m is not None else 0) for m in mclips])
+            self.check(self.lib.vszip_eedi3_mclip(self.ctx, table, sp, ss, mp, ms, n, field, int(horizontal), C.byref(prm)))
+        else:
+            self.check(self.lib.vszip_eedi3(self.ctx, table, sp, ss, n, field, int(horizontal), C.byref(prm)))
         return dsts
 
     def xpsnr_wsse(self, org, rec, prev1=None, prev2=None, depth=8, frame_rate=24, temporal=True):

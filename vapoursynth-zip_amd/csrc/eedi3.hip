@@ -3,8 +3,8 @@
 // Replaces processPlane (src/vapoursynth/eedi3.zig:26-140) and its kernels
 // interpLine (src/filters/eedi3.zig:349-592, with costBlockDirect :311-347) and
 // vcheckLine (:915-1046); EEDI3H is transpose -> vertical pipeline -> transpose
-// (src/vapoursynth/eedi3.zig:220-246). hp=True (interpLineHP) and mclip are reported as
-// VSZIP_ERR_UNSUPPORTED for now; mdis is limited to 31 (one DP state per lane).
+// (src/vapoursynth/eedi3.zig:220-246). The tuned line kernel covers hp=False, mdis <= 31 without
+// a mask; hp=True (interpLineHP), mdis up to 40 and mclip go through the general line kernel.
 //
 // eedi3_line_kernel — one wave per interpolated line, x processed in blocks of 64:
 //   cost phase (lanes = x): for every direction u the per-column base term
@@ -275,6 +275,351 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// General line kernel: everything eedi3_line_kernel leaves out — mdis up to 40 (81 directions),
+// hp=True (interpLineHP :619-904: half-pel directions, 4*mdis+1 of them, transitions up to +-2)
+// and mclip (buildBmask :285-304 + the masked branches of :468-484 / :779-795). Same structure
+// (one wave per line; cost phase lanes = x, DP phase lanes = directions), but 32-column blocks
+// and up to three DP states per lane so that 161 directions fit one wave; neighbour states
+// cross the lane boundary with v_readlane. Built for completeness of the EEDI3 signature, not
+// tuned: one direction per cost pass.
+// ---------------------------------------------------------------------------
+constexpr int kGMaxMdis = 40;
+constexpr int kGXB = 32;                                      // columns per block
+constexpr int kGReach = 2 * kGMaxMdis + 3 + 2;                // 2*mdis + nrad, +2 for the half-pel taps
+constexpr int kGRowW = kGXB + 2 * kGReach;
+constexpr int kGTbMax = kGXB + 2 * kGMaxMdis + 2 * 3 + 8;
+constexpr int kGNS = 3;                                       // DP states per lane: 3 * 64 >= 4 * 40 + 1
+constexpr int kGTpMax = 4 * kGMaxMdis + 1;
+
+struct GExtra {
+    const uint8_t *mask[kMaxPlanesE];  // mclip rows (NULL: no mask), geometry of the (transposed) source plane
+    int mstride[kMaxPlanesE];
+    int hp;
+};
+
+template <int NRAD, bool HP>
+__global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams prm, const GExtra ex) {
+    const float kFltMax09 = FLT_MAX * 0.9f;
+    __shared__ float rows[4][kGRowW];  // r3p, r1p, r1n, r3n
+    __shared__ float hrow[4][kGRowW];  // their half-pel rows (computeHpRow :602-617), HP only
+    __shared__ float tbm[kGTbMax], tbh[kGTbMax], wsm[kGTbMax], wsh[kGTbMax];
+    __shared__ float ctile[kGTpMax][kGXB + 1];
+    __shared__ int8_t ptile[kGXB][kGNS * 64];
+    __shared__ int fpt[kGXB];
+    __shared__ uint8_t bmt[kGXB];
+    __shared__ int any_mask;
+
+    int pi = 0;
+    const int gl = blockIdx.x;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (gl >= prm.p[i].line0) pi = i;
+    const EPlane pl = prm.p[pi];
+    const int off = gl - pl.line0;
+    const int line = prm.field + 2 * off;
+    constexpr int nrad = NRAD;
+    const int w = pl.w, mdis = prm.mdis;
+    const int cen = HP ? 2 * mdis : mdis, tpitch = 2 * cen + 1;
+    const int lane = threadIdx.x;
+    const bool dh = prm.dh != 0;
+    const float *r3p = pl.src + (size_t)src_col(dh, line - 3, pl.n_src) * pl.sstride;
+    const float *r1p = pl.src + (size_t)src_col(dh, line - 1, pl.n_src) * pl.sstride;
+    const float *r1n = pl.src + (size_t)src_col(dh, line + 1, pl.n_src) * pl.sstride;
+    const float *r3n = pl.src + (size_t)src_col(dh, line + 3, pl.n_src) * pl.sstride;
+    int8_t *pback = pl.pback + (size_t)off * w * tpitch;
+    float *out = pl.dst + (size_t)line * pl.dstride;
+    int *dmap = pl.dmap + (size_t)off * w;
+    const uint8_t *maskp = ex.mask[pi] ? ex.mask[pi] + (size_t)(dh ? off : line) * ex.mstride[pi] : nullptr;
+    const int reach = 2 * mdis + nrad + 2, roww = kGXB + 2 * reach;
+
+    // bmask[x] = any mask sample within +-mdis of x (the running `last` of buildBmask in closed form)
+    auto bmask_at = [&](int x) -> bool {
+        const int lo = max(x - mdis, 0), hi = min(x + mdis, w - 1);
+        bool m = false;
+        for (int q = lo; q <= hi; ++q) m = m || (maskp[q] != 0);
+        return m;
+    };
+    if (maskp) {
+        if (lane == 0) any_mask = 0;
+        __syncthreads();
+        bool m = false;
+        for (int q = lane; q < w; q += 64) m = m || (maskp[q] != 0);
+        if (m) any_mask = 1;
+        __syncthreads();
+        if (!any_mask) {  // :361-373 / :637-649: nothing to connect, plain vertical cubic
+            for (int x = lane; x < w; x += 64) {
+                dmap[x] = 0;
+                out[x] = 0.5625f * (r1p[x] + r1n[x]) - 0.0625f * (r3p[x] + r3n[x]);
+            }
+            return;
+        }
+    }
+
+    float pc[kGNS];  // DP states ui = lane + 64 * s (out-of-range states stay at the sentinel)
+    int8_t lastbd[kGNS];
+#pragma unroll
+    for (int s = 0; s < kGNS; ++s) {
+        pc[s] = kFltMax09;
+        lastbd[s] = 0;
+    }
+    const float g1 = HP ? prm.gamma * 0.5f : prm.gamma, g2 = prm.gamma;
+    const int nvec = (tpitch / 8) * 8;
+    const int nblk = (w + kGXB - 1) / kGXB;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int xb = blk * kGXB;
+        const int c0 = xb - reach;
+        __syncthreads();
+        for (int t = lane; t < roww; t += 64) {
+            const int c = min(c0 + t, w - 1 + reach);
+            rows[0][t] = rowv(r3p, c, w);
+            rows[1][t] = rowv(r1p, c, w);
+            rows[2][t] = rowv(r1n, c, w);
+            rows[3][t] = rowv(r3n, c, w);
+        }
+        if (maskp && lane < kGXB && xb + lane < w) bmt[lane] = bmask_at(xb + lane) ? 1 : 0;
+        __syncthreads();
+        if (HP) {
+            for (int t = lane + 1; t < roww - 2; t += 64) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hrow[r][t] = 0.5625f * (rows[r][t] + rows[r][t + 1]) - 0.0625f * (rows[r][t - 1] + rows[r][t + 2]);
+            }
+            __syncthreads();
+        }
+        const bool act = lane < kGXB && xb + lane < w;
+        const int lx = lane + reach;
+        // ---- cost phase ---------------------------------------------------------------
+        for (int u = -cen; u <= cen; ++u) {
+            if (!HP) {
+                const int two_u = 2 * u;
+                const int jlo = min(u, min(0, two_u)) - nrad, jhi = max(u, max(0, two_u)) + nrad;
+                const int span = kGXB + jhi - jlo;
+                for (int t = lane; t < span; t += 64) {
+                    const int j = jlo + t + reach;
+                    tbm[t] = fabsf(rows[0][j] - rows[1][j - two_u]) + fabsf(rows[1][j] - rows[2][j - two_u]) + fabsf(rows[2][j] - rows[3][j - two_u]);
+                }
+                __syncthreads();
+                for (int t = lane + nrad; t < span - nrad; t += 64) {
+                    float sw = 0.0f;
+#pragma unroll
+                    for (int k = -nrad; k <= nrad; ++k) sw += tbm[t + k];
+                    wsm[t] = sw;
+                }
+                __syncthreads();
+                if (act) {
+                    const int base = lane - jlo;
+                    const float sw1 = wsm[base], sw0 = wsm[base + u], sw2 = wsm[base + two_u];
+                    const float ip = (rows[1][lx + u] + rows[2][lx - u]) * 0.5f;
+                    const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
+                    ctile[cen + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
+                }
+                __syncthreads();
+            } else {
+                // :659-702 — u in half pels; baseM pairs full-pel rows shifted by u, baseHp (odd u)
+                // pairs the half-pel rows; s1/s2 window baseM at x and x+u, s0 the u/2 neighbour
+                const int uh = u >> 1;
+                const bool odd = (u & 1) != 0;
+                const int lo0 = odd ? -uh - 1 : -uh;
+                const int jlo = min(0, min(u, uh)) - nrad, jhi = max(0, max(u, uh)) + nrad;
+                const int span = kGXB + jhi - jlo;
+                for (int t = lane; t < span; t += 64) {
+                    const int j = jlo + t + reach;
+                    tbm[t] = fabsf(rows[0][j] - rows[1][j - u]) + fabsf(rows[1][j] - rows[2][j - u]) + fabsf(rows[2][j] - rows[3][j - u]);
+                    if (odd) tbh[t] = fabsf(hrow[0][j] - hrow[1][j - u]) + fabsf(hrow[1][j] - hrow[2][j - u]) + fabsf(hrow[2][j] - hrow[3][j - u]);
+                }
+                __syncthreads();
+                for (int t = lane + nrad; t < span - nrad; t += 64) {
+                    float sm = 0.0f, sh = 0.0f;
+#pragma unroll
+                    for (int k = -nrad; k <= nrad; ++k) {
+                        sm += tbm[t + k];
+                        if (odd) sh += tbh[t + k];
+                    }
+                    wsm[t] = sm;
+                    wsh[t] = sh;
+                }
+                __syncthreads();
+                if (act) {
+                    const int base = lane - jlo;
+                    const float s1 = wsm[base], s2 = wsm[base + u], s0 = odd ? wsh[base + uh] : wsm[base + uh];
+                    const float bq = odd ? hrow[1][lx + uh] : rows[1][lx + uh];
+                    const float cq = odd ? hrow[2][lx + lo0] : rows[2][lx + lo0];
+                    const float ip = (bq + cq) * 0.5f;
+                    const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
+                    ctile[cen + u][lane] = prm.alpha * (s0 + s1 + s2) + (prm.beta * (float)abs(u) * 0.5f) + prm.one_minus_ab * v;
+                }
+                __syncthreads();
+            }
+        }
+        // ---- DP phase --------------------------------------------------------------------
+        const int xe = min(kGXB, w - xb);
+        for (int xl = 0; xl < xe; ++xl) {
+            const int xx = xb + xl;
+            float tc[kGNS];
+#pragma unroll
+            for (int s = 0; s < kGNS; ++s) tc[s] = (lane + 64 * s < tpitch) ? ctile[lane + 64 * s][xl] : 0.0f;
+            if (xx == 0) {
+#pragma unroll
+                for (int s = 0; s < kGNS; ++s) pc[s] = (lane + 64 * s < tpitch) ? tc[s] : kFltMax09;
+                continue;
+            }
+            const bool masked = maskp && !bmt[xl];
+            float pn[kGNS];
+            int8_t bdn[kGNS];
+            if (masked) {  // :474-484 / :785-795
+#pragma unroll
+                for (int s = 0; s < kGNS; ++s) {
+                    const bool valid = lane + 64 * s < tpitch;
+                    pn[s] = xx == 1 ? (valid ? tc[s] : kFltMax09) : pc[s];
+                    bdn[s] = xx == 1 ? (int8_t)0 : lastbd[s];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < kGNS; ++s) {
+                    const int ui = lane + 64 * s;
+                    const bool valid = ui < tpitch;
+                    // neighbours ui-1, ui+1 (and ui-2, ui+2): DPP shift inside the lane group, readlane across it
+                    const float e_b1 = s > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s > 0 ? s - 1 : 0]), 63)) : kFltMax09;
+                    const float e_a1 = s < kGNS - 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s < kGNS - 1 ? s + 1 : s]), 0)) : kFltMax09;
+                    const float b1 = lane_below(pc[s], e_b1), a1 = lane_above(pc[s], e_a1);
+                    float bval;
+                    int bd;
+                    if (!HP) {
+                        const float left = b1 + g2, right = a1 + g2;  // :536-548
+                        bval = pc[s];
+                        bd = 0;
+                        if (left < bval) {
+                            bval = left;
+                            bd = -1;
+                        }
+                        if (right < bval) {
+                            bval = right;
+                            bd = 1;
+                        }
+                    } else {
+                        const float e_b2 = s > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s > 0 ? s - 1 : 0]), 62)) : kFltMax09;
+                        const float e_a2 = s < kGNS - 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s < kGNS - 1 ? s + 1 : s]), 1)) : kFltMax09;
+                        const float b2 = lane_below(b1, e_b2), a2 = lane_above(a1, e_a2);
+                        const float c_m2 = b2 + g2, c_m1 = b1 + g1, c_0 = pc[s], c_p1 = a1 + g1, c_p2 = a2 + g2;
+                        if (ui < nvec) {  // vector body :806-832 starts from the -2 candidate
+                            bval = c_m2;
+                            bd = -2;
+                        } else {  // scalar tail :834-849 starts from the sentinel
+                            bval = kFltMax09;
+                            bd = 0;
+                            if (c_m2 < bval) {
+                                bval = c_m2;
+                                bd = -2;
+                            }
+                        }
+                        if (c_m1 < bval) {
+                            bval = c_m1;
+                            bd = -1;
+                        }
+                        if (c_0 < bval) {
+                            bval = c_0;
+                            bd = 0;
+                        }
+                        if (c_p1 < bval) {
+                            bval = c_p1;
+                            bd = 1;
+                        }
+                        if (c_p2 < bval) {
+                            bval = c_p2;
+                            bd = 2;
+                        }
+                    }
+                    pn[s] = valid ? fminf(bval + tc[s], kFltMax09) : kFltMax09;
+                    bdn[s] = (int8_t)bd;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kGNS; ++s) {
+                pc[s] = pn[s];
+                lastbd[s] = bdn[s];
+                const int ui = lane + 64 * s;
+                if (ui < tpitch) {
+                    if (xl == 0)
+                        pback[(size_t)(xx - 1) * tpitch + ui] = bdn[s];
+                    else
+                        ptile[xl - 1][ui] = bdn[s];
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = lane; t < (xe - 1) * tpitch; t += 64) {
+            const int r = t / tpitch, c = t - r * tpitch;
+            pback[(size_t)(xb + r) * tpitch + c] = ptile[r][c];
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+
+    // ---- backtrack + output --------------------------------------------------------------
+    int carry = 0;
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int xb = blk * kGXB;
+        const int xe = min(kGXB, w - xb);
+        __syncthreads();
+        for (int t = lane; t < xe * tpitch; t += 64) {
+            const int r = t / tpitch, c = t - r * tpitch;
+            if (xb + r < w - 1) ptile[r][c] = pback[(size_t)(xb + r) * tpitch + c];
+        }
+        if (maskp && lane < xe) bmt[lane] = bmask_at(xb + lane) ? 1 : 0;
+        __syncthreads();
+        if (lane == 0) {
+            int fp = carry;
+            for (int xl = xe - 1; xl >= 0; --xl) {
+                const int xx = xb + xl;
+                if (xx == w - 1)
+                    fp = 0;
+                else
+                    fp = fp + ptile[xl][cen + fp];
+                fpt[xl] = fp;
+            }
+        }
+        __syncthreads();
+        carry = fpt[0];
+        if (lane < xe) {
+            const int xx = xb + lane;
+            const bool masked = maskp && !bmt[lane];
+            int dir = fpt[lane];
+            float v;
+            if (!HP) {
+                if (masked) dir = 0;  // :566-569
+                const int ad = abs(dir);
+                if (xx >= ad * 3 && xx + ad * 3 <= w - 1)
+                    v = 0.5625f * (rowv(r1p, xx + dir, w) + rowv(r1n, xx - dir, w)) - 0.0625f * (rowv(r3p, xx + dir * 3, w) + rowv(r3n, xx - dir * 3, w));
+                else
+                    v = (rowv(r1p, xx + dir, w) + rowv(r1n, xx - dir, w)) * 0.5f;
+            } else if (masked) {  // :866-870
+                dir = 0;
+                v = 0.5625f * (r1p[xx] + r1n[xx]) - 0.0625f * (r3p[xx] + r3n[xx]);
+            } else if ((dir & 1) == 0) {  // :874-881
+                const int d2 = dir >> 1, ad = abs(d2);
+                if (xx >= ad * 3 && xx + ad * 3 <= w - 1)
+                    v = 0.5625f * (rowv(r1p, xx + d2, w) + rowv(r1n, xx - d2, w)) - 0.0625f * (rowv(r3p, xx + d2 * 3, w) + rowv(r3n, xx - d2 * 3, w));
+                else
+                    v = (rowv(r1p, xx + d2, w) + rowv(r1n, xx - d2, w)) * 0.5f;
+            } else {  // :882-901
+                const int d20 = dir >> 1, d21 = (dir + 1) >> 1, d30 = (dir * 3) >> 1, d31 = (dir * 3 + 1) >> 1;
+                const int ad = max(abs(d30), abs(d31));
+                if (xx >= ad && xx + ad <= w - 1) {
+                    const float q0 = rowv(r3p, xx + d30, w) + rowv(r3p, xx + d31, w);
+                    const float q1 = rowv(r1p, xx + d20, w) + rowv(r1p, xx + d21, w);
+                    const float q2 = rowv(r1n, xx - d20, w) + rowv(r1n, xx - d21, w);
+                    const float q3 = rowv(r3n, xx - d30, w) + rowv(r3n, xx - d31, w);
+                    v = 0.28125f * (q1 + q2) - 0.03125f * (q0 + q3);
+                } else {
+                    v = (rowv(r1p, xx + d20, w) + rowv(r1p, xx + d21, w) + rowv(r1n, xx - d20, w) + rowv(r1n, xx - d21, w)) * 0.25f;
+                }
+            }
+            dmap[xx] = dir;
+            out[xx] = v;
+        }
+    }
+}
+
 // Copy the kept field (processPlane :41-53).
 __global__ void eedi3_copy_kernel(const EParams prm) {
     const EPlane pl = prm.p[blockIdx.z];
@@ -296,7 +641,7 @@ struct VParams {
     EPlane p[kMaxPlanesE];
     const float *scp[kMaxPlanesE];
     int scstride[kMaxPlanesE];
-    int field, dh, vcheck;
+    int field, dh, vcheck, hp;
     float vthresh2, rcp0, rcp1, rcp2;
 };
 
@@ -311,7 +656,8 @@ constexpr int kVcCols = 4;  // columns per thread: lines up to 4096 wide
 
 struct VcPre {
     float cint, dl_i, d1p_i, d1n_i, dl_imd, d1p_ipd, t_ipd, ib, vb, vc, a2;
-    int ipd;  // < 0: the pixel keeps cint (no direction / inconsistent neighbours / too close to the edge)
+    int ipd;   // < 0: the pixel keeps cint (no direction / inconsistent neighbours / too close to the edge)
+    int ipd2;  // hp, odd direction: the second of the two columns averaged (:969-985); -1 otherwise
 };
 
 __device__ __forceinline__ void vcheck_prepare(const EPlane &pl, const VParams &prm, const float *scp, int scstride, int off, int i, VcPre &q) {
@@ -330,27 +676,54 @@ __device__ __forceinline__ void vcheck_prepare(const EPlane &pl, const VParams &
     q.cint = scp ? scp[(size_t)pd * scstride + i] : 0.5625f * (q.d1p_i + q.d1n_i) - 0.0625f * (d3p[i] + d3n[i]);
     q.dl_i = dl[i];
     q.ipd = -1;
+    q.ipd2 = -1;
     const int dirt = dp[i], dirb = dn[i];
-    const int maxoff = abs(dirc);
+    const bool hp = prm.hp != 0;
+    const int maxoff = !hp ? abs(dirc) : (((dirc & 1) == 0) ? abs(dirc >> 1) : max(abs(dirc >> 1), abs((dirc + 1) >> 1)));
     if (dirc != 0 && !(max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) && !(i + maxoff >= L || i - maxoff < 0)) {
-        const int ipd = i + dirc, imd = i - dirc;
-        q.ipd = ipd;
-        q.dl_imd = dl[imd];
-        q.d1p_ipd = d1p[ipd];
-        const float dl_ipd = dl[ipd], d2n_imd = d2n[imd], d1n_imd = d1n[imd];
-        q.t_ipd = fabsf(dl_ipd - q.d1p_ipd);
-        q.ib = (dl_ipd + d2n_imd) * 0.5f;
-        q.vb = fabsf(d2n_imd - d1n_imd) + fabsf(q.dl_imd - d1n_imd);
+        int dabs;
+        if (hp && (dirc & 1) != 0) {  // :969-985: both half-pel neighbours, summed
+            const int d20 = dirc >> 1, d21 = (dirc + 1) >> 1;
+            const int ip0 = i + d20, ip1 = i + d21, im0 = i - d20, im1 = i - d21;
+            q.ipd = ip0;
+            q.ipd2 = ip1;
+            const float s1p = d1p[ip0] + d1p[ip1], pa0 = dl[ip0] + dl[ip1], ps0 = dl[im0] + dl[im1];
+            const float s1n = d1n[im0] + d1n[im1], s2n = d2n[im0] + d2n[im1];
+            q.dl_imd = ps0;
+            q.d1p_ipd = s1p;
+            q.t_ipd = fabsf(pa0 - s1p);
+            q.ib = (pa0 + s2n) * 0.25f;
+            q.vb = (fabsf(s2n - s1n) + fabsf(ps0 - s1n)) * 0.5f;
+            dabs = abs(dirc) >> 1;
+        } else {
+            const int offh = hp ? dirc >> 1 : dirc;
+            const int ipd = i + offh, imd = i - offh;
+            q.ipd = ipd;
+            q.dl_imd = dl[imd];
+            q.d1p_ipd = d1p[ipd];
+            const float dl_ipd = dl[ipd], d2n_imd = d2n[imd], d1n_imd = d1n[imd];
+            q.t_ipd = fabsf(dl_ipd - q.d1p_ipd);
+            q.ib = (dl_ipd + d2n_imd) * 0.5f;
+            q.vb = fabsf(d2n_imd - d1n_imd) + fabsf(q.dl_imd - d1n_imd);
+            dabs = hp ? abs(dirc) >> 1 : abs(dirc);
+        }
         q.vc = fabsf(q.dl_i - q.d1p_i) + fabsf(q.dl_i - q.d1n_i);
-        q.a2 = fmaxf((prm.vthresh2 - (float)maxoff) * prm.rcp2, 0.0f);
+        q.a2 = fmaxf((prm.vthresh2 - (float)dabs) * prm.rcp2, 0.0f);
     }
 }
 
 __device__ __forceinline__ float vcheck_resolve(const VParams &prm, const VcPre &q, const float *prev) {
     if (q.ipd < 0) return q.cint;
-    const float d2 = prev[q.ipd];
-    const float it = (d2 + q.dl_imd) * 0.5f;
-    const float vt = fabsf(d2 - q.d1p_ipd) + q.t_ipd;
+    float it, vt;
+    if (q.ipd2 >= 0) {
+        const float s2p = prev[q.ipd] + prev[q.ipd2];
+        it = (s2p + q.dl_imd) * 0.25f;
+        vt = (fabsf(s2p - q.d1p_ipd) + q.t_ipd) * 0.5f;
+    } else {
+        const float d2 = prev[q.ipd];
+        it = (d2 + q.dl_imd) * 0.5f;
+        vt = fabsf(d2 - q.d1p_ipd) + q.t_ipd;
+    }
     const float e0 = fabsf(it - q.d1p_i), e1 = fabsf(q.ib - q.d1n_i), e2 = fabsf(vt - q.vc), e3 = fabsf(q.vb - q.vc);
     float m0, m1;
     if (prm.vcheck == 1) {
@@ -453,10 +826,38 @@ __global__ void transpose_kernel(const float *src, float *dst, int sstride, int 
     }
 }
 
+__global__ void transpose_u8_kernel(const uint8_t *src, uint8_t *dst, int sstride, int dstride, int w, int h) {
+    __shared__ uint8_t t[kTT][kTT + 4];
+    const int x0 = blockIdx.x * kTT, y0 = blockIdx.y * kTT;
+    for (int r = threadIdx.y; r < kTT; r += blockDim.y) {
+        const int x = x0 + threadIdx.x, y = y0 + r;
+        if (x < w && y < h) t[r][threadIdx.x] = src[(size_t)y * sstride + x];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < kTT; r += blockDim.y) {
+        const int y = y0 + threadIdx.x, x = x0 + r;
+        if (x < w && y < h) dst[(size_t)x * dstride + y] = t[threadIdx.x][r];
+    }
+}
+
+template <int NRAD>
+void launch_general(vszip_ctx *ctx, bool hp, unsigned lines, const EParams &ep, const GExtra &gx) {
+    if (hp)
+        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, true>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
+    else
+        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, false>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
+}
+
 }  // namespace
 
 VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips, const ptrdiff_t *sclip_strides, int nplanes, int field,
                              int horizontal, const vszip_eedi3_params *up) {
+    return vszip_eedi3_mclip(ctx, planes, sclips, sclip_strides, nullptr, nullptr, nplanes, field, horizontal, up);
+}
+
+VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips, const ptrdiff_t *sclip_strides,
+                                   const uint8_t *const *mclips, const ptrdiff_t *mclip_strides, int nplanes, int field, int horizontal,
+                                   const vszip_eedi3_params *up) {
     if (!ctx || !planes || !up || nplanes <= 0 || nplanes > kMaxPlanesE) return VSZIP_ERR_ARG;
     const char *name = horizontal ? "EEDI3H" : "EEDI3";
     // createImpl :316-410
@@ -470,19 +871,24 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
     if (up->vcheck < 0 || up->vcheck > 3) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: vcheck must be 0, 1, 2, or 3.", name);
     if (up->vcheck > 0 && (up->vthresh0 <= 0.0f || up->vthresh1 <= 0.0f || up->vthresh2 <= 0.0f))
         return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: vthresh0, vthresh1 and vthresh2 must be greater than 0.0.", name);
-    if (up->hp) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: hp=True not built yet", name);
-    if (up->mdis > kMaxMdis) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: mdis > %d not built yet", name, kMaxMdis);
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const bool dh = up->dh != 0;
-    const int tpitch = 2 * up->mdis + 1;
+    const bool hp = up->hp != 0;
+    bool any_mask = false;
+    for (int i = 0; i < nplanes && mclips; ++i) any_mask = any_mask || mclips[i] != nullptr;
+    if (any_mask && !mclip_strides) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: mclip strides missing", name);
+    // the tuned kernel covers the common case; hp, mdis > 31 and mclip take the general one
+    const bool general = hp || up->mdis > kMaxMdis || any_mask;
+    const int tpitch = hp ? 4 * up->mdis + 1 : 2 * up->mdis + 1;
 
     // geometry of the vertical pipeline per plane (EEDI3H runs it on the transposed plane)
     struct Geo {
         int L, n_src, n_dst, n_interp;
         size_t srcT, dstT, scT;  // float offsets into scratch (horizontal only)
+        size_t mT;               // byte offset of the transposed mask (horizontal only)
     };
     std::vector<Geo> geo(nplanes);
-    size_t fl = 0, lines = 0, pb = 0, dm = 0;
+    size_t fl = 0, lines = 0, pb = 0, dm = 0, mb = 0;
     for (int i = 0; i < nplanes; ++i) {
         const vszip_plane &s = planes[i];
         if (!s.src || !s.dst || s.w <= 0 || s.h <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: bad plane %d", name, i);
@@ -493,7 +899,8 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
         g.n_src = horizontal ? s.w : s.h;
         g.n_dst = dh ? 2 * g.n_src : g.n_src;
         g.n_interp = dh ? g.n_src : g.n_src / 2;
-        if (g.L < 2 * up->mdis + up->nrad + 2) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines shorter than 2*mdis+nrad+2 not built yet", name);
+        if (g.L < 2 * up->mdis + up->nrad + (general ? 4 : 2))
+            return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines shorter than 2*mdis+nrad+%d not built yet", name, general ? 4 : 2);
         if (horizontal) {
             g.srcT = fl;
             fl += (size_t)g.n_src * g.L;
@@ -501,18 +908,23 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
             fl += (size_t)g.n_dst * g.L;
             g.scT = fl;
             if (up->vcheck > 0 && sclips && sclips[i]) fl += (size_t)g.n_dst * g.L;
+            g.mT = mb;
+            if (mclips && mclips[i]) mb += (((size_t)g.n_src * g.L) + 255) & ~(size_t)255;
         }
         lines += g.n_interp;
         pb += (size_t)g.n_interp * g.L * tpitch;
         dm += (size_t)g.n_interp * g.L;
     }
-    const size_t bytes = fl * sizeof(float) + dm * sizeof(int) + pb + 4096;
+    const size_t bytes = fl * sizeof(float) + dm * sizeof(int) + pb + mb + 4096;
     int rc = vszip_ensure_scratch(ctx, bytes);
     if (rc != VSZIP_OK) return rc;
     char *base = static_cast<char *>(ctx->scratch);
     float *fbase = reinterpret_cast<float *>(base);
     int *dbase = reinterpret_cast<int *>(base + fl * sizeof(float));
     int8_t *pbase = reinterpret_cast<int8_t *>(base + fl * sizeof(float) + dm * sizeof(int));
+    uint8_t *mbase = reinterpret_cast<uint8_t *>(base + fl * sizeof(float) + dm * sizeof(int) + pb);
+    GExtra gx;
+    gx.hp = hp;
 
     EParams ep;
     VParams vp;
@@ -529,6 +941,7 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
     vp.field = field;
     vp.dh = dh;
     vp.vcheck = up->vcheck;
+    vp.hp = hp;
     const float vt0 = up->vthresh0 / 255.0f, vt1 = up->vthresh1 / 255.0f;
     vp.vthresh2 = up->vthresh2;
     vp.rcp0 = 1.0f / vt0;
@@ -556,7 +969,17 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
                                    (int)sclip_strides[i], g.L, g.n_dst, s.h);
                 vp.scp[i] = scT;
             }
+            gx.mask[i] = nullptr;
+            gx.mstride[i] = g.L;
+            if (mclips && mclips[i]) {  // mask has the source plane's geometry (w x h) -> transposed: w lines of h
+                uint8_t *mT = mbase + g.mT;
+                hipLaunchKernelGGL(transpose_u8_kernel, dim3((s.w + kTT - 1) / kTT, (s.h + kTT - 1) / kTT), tb, 0, ctx->stream, mclips[i], mT, (int)mclip_strides[i], g.L,
+                                   s.w, s.h);
+                gx.mask[i] = mT;
+            }
         } else {
+            gx.mask[i] = mclips ? mclips[i] : nullptr;
+            gx.mstride[i] = (mclips && mclips[i]) ? (int)mclip_strides[i] : 0;
             d.src = static_cast<const float *>(s.src);
             d.dst = static_cast<float *>(s.dst);
             d.sstride = (int)s.src_stride;
@@ -579,11 +1002,20 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
         vp.p[i] = d;
     }
     hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);
-    switch (up->nrad) {
-        case 0: hipLaunchKernelGGL(eedi3_line_kernel<0>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
-        case 1: hipLaunchKernelGGL(eedi3_line_kernel<1>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
-        case 2: hipLaunchKernelGGL(eedi3_line_kernel<2>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
-        default: hipLaunchKernelGGL(eedi3_line_kernel<3>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+    if (general) {
+        switch (up->nrad) {
+            case 0: launch_general<0>(ctx, hp, (unsigned)lines, ep, gx); break;
+            case 1: launch_general<1>(ctx, hp, (unsigned)lines, ep, gx); break;
+            case 2: launch_general<2>(ctx, hp, (unsigned)lines, ep, gx); break;
+            default: launch_general<3>(ctx, hp, (unsigned)lines, ep, gx); break;
+        }
+    } else {
+        switch (up->nrad) {
+            case 0: hipLaunchKernelGGL(eedi3_line_kernel<0>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+            case 1: hipLaunchKernelGGL(eedi3_line_kernel<1>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+            case 2: hipLaunchKernelGGL(eedi3_line_kernel<2>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+            default: hipLaunchKernelGGL(eedi3_line_kernel<3>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+        }
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (up->vcheck > 0) {

@@ -957,6 +957,7 @@ void VS_CC xpsnrCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const 
 // ===========================================================================
 struct Eedi3Data {
     VSNode *node, *sclip;
+    VSNode *mclip = nullptr;
     VSVideoInfo vi;
     vszip_eedi3_params prm;
     int field;
@@ -988,15 +989,18 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
     if (reason == arInitial) {
         api->requestFrameFilter(src_n, d->node, fctx);
         if (d->prm.vcheck > 0 && d->sclip) api->requestFrameFilter(n, d->sclip, fctx);
+        if (d->mclip) api->requestFrameFilter(src_n, d->mclip, fctx);  // eedi3.zig:150
     } else if (reason == arAllFramesReady) {
         const VSFrame *src = api->getFrameFilter(src_n, d->node, fctx);
         const VSFrame *scp = (d->prm.vcheck > 0 && d->sclip) ? api->getFrameFilter(n, d->sclip, fctx) : nullptr;
+        const VSFrame *mcp = d->mclip ? api->getFrameFilter(src_n, d->mclip, fctx) : nullptr;
         const VSVideoFormat *vf = api->getVideoFrameFormat(src);
         VSFrame *dst = api->newVideoFrame(vf, d->vi.width, d->vi.height, src, core);
         VSMap *props = api->getFramePropertiesRW(dst);
         auto done = [&](const VSFrame *r) {
             api->freeFrame(src);
             if (scp) api->freeFrame(scp);
+            if (mcp) api->freeFrame(mcp);
             return r;
         };
         int field = d->field & 1;  // eedi3.zig:166-172
@@ -1011,6 +1015,14 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
         std::vector<DPlane> outs;
         std::vector<const float *> scl;
         std::vector<ptrdiff_t> scs;
+        // the single Gray mask plane drives every processed plane (eedi3.zig:215-218)
+        DPlane mk;
+        if (mcp) {
+            mk = z.upload(g, mcp, 0);
+            if (!mk.ptr) return done(fail(z, g, dst, name, "device staging failed"));
+        }
+        std::vector<const uint8_t *> mcl(vf->numPlanes, static_cast<const uint8_t *>(mk.ptr));
+        std::vector<ptrdiff_t> mcs(vf->numPlanes, mk.stride);
         for (int p = 0; p < vf->numPlanes; ++p) {
             DPlane s = z.upload(g, src, p), o = z.blank(g, api->getFrameWidth(dst, p), api->getFrameHeight(dst, p), 4), c;
             if (scp) c = z.upload(g, scp, p);
@@ -1020,7 +1032,8 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
             scl.push_back(static_cast<const float *>(c.ptr));
             scs.push_back(c.stride);
         }
-        int rc = vszip_eedi3(g->ctx, tab.data(), scp ? scl.data() : nullptr, scp ? scs.data() : nullptr, (int)tab.size(), field, d->horizontal, &d->prm);
+        int rc = vszip_eedi3_mclip(g->ctx, tab.data(), scp ? scl.data() : nullptr, scp ? scs.data() : nullptr, mcp ? mcl.data() : nullptr, mcp ? mcs.data() : nullptr,
+                                   (int)tab.size(), field, d->horizontal, &d->prm);
         for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
             if (!z.download(g, outs[i], dst, (int)i)) rc = VSZIP_ERR_HIP;
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
@@ -1044,6 +1057,7 @@ void VS_CC eedi3Free(void *inst, VSCore *, const VSAPI *api) {
     auto *d = static_cast<Eedi3Data *>(inst);
     api->freeNode(d->node);
     if (d->sclip) api->freeNode(d->sclip);
+    if (d->mclip) api->freeNode(d->mclip);
     delete d;
 }
 
@@ -1094,9 +1108,14 @@ void eedi3_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *api, b
     if (mdis < 1 || mdis > 40) return bail("%s: mdis must be between 1 and 40 (inclusive).", name);
     if (vcheck < 0 || vcheck > 3) return bail("%s: vcheck must be 0, 1, 2, or 3.", name);
     if (vcheck > 0 && (p.vthresh0 <= 0.0f || p.vthresh1 <= 0.0f || p.vthresh2 <= 0.0f)) return bail("%s: vthresh0, vthresh1 and vthresh2 must be greater than 0.0.", name);
-    if (mclip) return bail("%s: mclip is not available in the MI355X build yet.", name);
-    if (p.hp) return bail("%s: hp=True is not available in the MI355X build yet.", name);
-    if (mdis > 31) return bail("%s: mdis > 31 is not available in the MI355X build yet.", name);
+    if (mclip) {  // eedi3.zig:393-433
+        const VSVideoInfo *mv = api->getVideoInfo(mclip);
+        if (mv->format.colorFamily != cfGray) return bail("%s: mclip must be Gray.", name);
+        if (mv->width != d->vi.width || mv->height != d->vi.height) return bail("%s: mclip's dimensions don't match.", name);
+        if (mv->numFrames != d->vi.numFrames) return bail("%s: mclip's number of frames doesn't match.", name);
+        // the reference converts other depths with std.SetFrameProps + resize.Point (:411-432); this build takes the 8-bit mask as is
+        if (mv->format.bitsPerSample != 8 || mv->format.sampleType != stInteger) return bail("%s: mclip must be 8-bit Gray in the MI355X build (convert it with resize.Point first).", name);
+    }
     if (field > 1) {
         if (d->vi.numFrames > INT32_MAX / 2) return bail("%s: resulting clip is too long.", name);
         d->vi.numFrames *= 2;
@@ -1110,9 +1129,14 @@ void eedi3_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *api, b
         if (sv->numFrames != d->vi.numFrames) return bail("%s: sclip's number of frames doesn't match.", name);
     }
     d->field = field;
-    VSFilterDependency deps[2] = {{d->node, rpStrictSpatial}, {d->sclip, rpStrictSpatial}};
+    d->mclip = mclip;
+    VSFilterDependency deps[3];
+    int ndeps = 0;
+    deps[ndeps++] = {d->node, rpStrictSpatial};
+    if (d->sclip) deps[ndeps++] = {d->sclip, rpStrictSpatial};
+    if (d->mclip) deps[ndeps++] = {d->mclip, rpStrictSpatial};
     Eedi3Data *raw = d.release();
-    api->createVideoFilter(out, name, &raw->vi, eedi3GetFrame, eedi3Free, fmParallel, deps, raw->sclip ? 2 : 1, raw, core);
+    api->createVideoFilter(out, name, &raw->vi, eedi3GetFrame, eedi3Free, fmParallel, deps, ndeps, raw, core);
 }
 void VS_CC eedi3Create(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { eedi3_create(in, out, core, api, false); }
 void VS_CC eedi3hCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { eedi3_create(in, out, core, api, true); }
