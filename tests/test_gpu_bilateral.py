@@ -79,6 +79,19 @@ def test_pbfic_joint_ref_and_auto_selection(dev, oracle):
     assert np.array_equal(got, want)
 
 
+def test_ten_bit_clip_lut_in_lds(dev, oracle):
+    """10-bit samples in a u16 container: hist_len 1024, peak 1023 — the range LUT is staged in LDS."""
+    src = (fx.tiled_natural((120, 200), np.uint16, 0) >> 6).astype(np.uint16)
+    ref = (fx.tiled_natural((120, 200), np.uint16, 2) >> 6).astype(np.uint16)
+    for refs in (None, [ref]):
+        cfg = dev.bilateral_cfg([2], [0.1], hist_len=1024)
+        s, d = dev.upload(src), dev.empty(120, 200, np.uint16)
+        dev.bilateral([s], [d], cfg, [0], [dev.upload(ref)] if refs else None, peak=1023.0)
+        want = oracle.bilateral_plane(src, cfg[0].sigmaS, cfg[0].sigmaR, cfg[0].algorithm, cfg[0].radius, cfg[0].step, cfg[0].pbficnum, ref=ref if refs else None, bits=10)
+        assert np.array_equal(dev.download(d), want)
+        dev.bilateral_free(cfg)
+
+
 def test_joint_ref_and_noise(dev, oracle):
     src = fx.splitmix64_plane(1, (90, 150), np.uint16)
     ref = fx.tiled_natural((90, 150), np.uint16)

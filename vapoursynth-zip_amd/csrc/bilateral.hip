@@ -42,6 +42,7 @@ struct BLParams {
     BLPlane p[kMaxPlanesBL];
     int nplanes;
     float peak;
+    int lut_len, lut_offset;  // tiled kernel with the range LUT in LDS: entries, byte offset behind the tiles
 };
 
 template <typename T>
@@ -79,7 +80,11 @@ constexpr int kBX = 64, kBY = 4;  // one wave per row segment
 constexpr int kTileH = 32;        // tiled kernel: output rows per workgroup (8 per thread)
 constexpr int kTileMaxR = 16;     // largest radius the tiled kernel stages
 
-template <typename T, bool JOINT>
+// LDSLUT: the range LUT has at most kLdsLutMax entries (8/10/12-bit clips) and is staged in LDS
+// behind the tiles, which takes the gathers off the texture-address path as well.
+constexpr int kLdsLutMax = 4096;
+
+template <typename T, bool JOINT, bool LDSLUT>
 __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParams prm) {
     using S = BSmp<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,6 +104,12 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParam
     T *ts = JOINT ? tr + th * tw : tr;
     const int w1 = pl.w - 1, h1 = pl.h - 1;
     const int lx = (int)threadIdx.x, tyi = (int)threadIdx.y;
+    const float *gr = pl.gr;
+    if constexpr (LDSLUT) {
+        float *lut = reinterpret_cast<float *>(smem + prm.lut_offset);
+        for (int i = tyi * kBX + lx; i < prm.lut_len; i += kBX * kBY) lut[i] = pl.gr[i];
+        gr = lut;
+    }
 
     // stage: tile row t holds source row clamp(y0 - r + t), tile column c source column clamp(x0 - r + c)
     for (int t = tyi; t < th; t += kBY) {
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParam
     const int x = x0 + lx;
     if (x >= pl.w) return;
     T *dst = static_cast<T *>(pl.dst);
-    const float *gs = pl.gs, *gr = pl.gr;
+    const float *gs = pl.gs;
     const int radius2 = r + 1, step = pl.step;
     const float w0 = gs[0] * gr[0];
 #pragma unroll 1
@@ -453,11 +464,23 @@ int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled
     {
         vszip_probe_scope probe(ctx);
         if (tiled) {
-            const size_t lds = (size_t)(kBX + 2 * max_radius) * (kTileH + 2 * max_radius) * sizeof(T) * (joint ? 2 : 1);
-            if (joint)
-                hipLaunchKernelGGL((bilateral_tiled_kernel<T, true>), dim3(blocks), dim3(kBX, kBY), lds, ctx->stream, prm);
+            size_t lds = (size_t)(kBX + 2 * max_radius) * (kTileH + 2 * max_radius) * sizeof(T) * (joint ? 2 : 1);
+            const bool ldslut = BSmp<T>::is_int && prm.lut_len <= kLdsLutMax;
+            BLParams q = prm;
+            if (ldslut) {
+                lds = (lds + 15) & ~(size_t)15;
+                q.lut_offset = (int)lds;
+                lds += (size_t)q.lut_len * sizeof(float);
+            }
+            const dim3 grid(blocks), block(kBX, kBY);
+            if (joint && ldslut)
+                hipLaunchKernelGGL((bilateral_tiled_kernel<T, true, true>), grid, block, lds, ctx->stream, q);
+            else if (joint)
+                hipLaunchKernelGGL((bilateral_tiled_kernel<T, true, false>), grid, block, lds, ctx->stream, q);
+            else if (ldslut)
+                hipLaunchKernelGGL((bilateral_tiled_kernel<T, false, true>), grid, block, lds, ctx->stream, q);
             else
-                hipLaunchKernelGGL((bilateral_tiled_kernel<T, false>), dim3(blocks), dim3(kBX, kBY), lds, ctx->stream, prm);
+                hipLaunchKernelGGL((bilateral_tiled_kernel<T, false, false>), grid, block, lds, ctx->stream, q);
         } else {
             hipLaunchKernelGGL((bilateral_truncated_kernel<T>), dim3(blocks), dim3(kBX, kBY), 0, ctx->stream, prm);
         }
@@ -569,6 +592,8 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
     while (done < nplanes) {
         BLParams prm;
         prm.peak = peak;
+        prm.lut_len = (int)peak + 1;  // hist_len of the clip (bilateral.zig(vs):101-102); the planes of a call share it
+        prm.lut_offset = 0;
         int n = 0, blocks = 0;
         // one launch group: the tiled kernel when every radius fits its LDS tile; `joint` if any
         // plane of the group brings a separate ref clip
