@@ -98,7 +98,7 @@ def test_ct_int_closed_forms():
         assert np.array_equal(ref, (col + np.uint64(r)) // np.uint64(k)), r
         m = -(-(1 << 32) // k)
         assert np.array_equal(ref, ((col + np.uint64(r)) * np.uint64(m)) >> np.uint64(32)), r
-        # 24-bit reciprocal form (RingGeom::DIVM / DIVS in csrc/boxblur.hip)
+        # a 24-bit reciprocal (full-rate v_mul_u32_u24 pair) is exact too; measured slower than mulhi on MI355X, not used
         sh = 0
         while (1 << sh) <= (65535 * k + r) * k:
             sh += 1

@@ -336,18 +336,7 @@ struct RingGeom {
     static constexpr int WPE = tier(est_vgprs(D));
 #endif
     static_assert(NR % KL == 0, "K-column ring must divide the period");
-    // tmp = (col + r) / k as (n * DIVM) >> DIVS with 24-bit operands (full-rate
-    // v_mul_u32_u24 / v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32):
-    // exact while 2^DIVS > n_max * k (tests/test_oracle_boxblur.py checks every n).
-    static constexpr int div_shift() {
-        int s = 0;
-        while ((1ull << s) <= (65535ull * K + R) * K) ++s;
-        return s;
-    }
     static constexpr uint32_t MAGIC = (uint32_t)(((1ull << 32) + K - 1) / K);  // ceil(2^32 / k): mulhi(n, MAGIC) == n / k
-    static constexpr int DIVS = div_shift();
-    static constexpr uint32_t DIVM = (uint32_t)(((1ull << DIVS) + K - 1) / K);
-    static_assert(DIVM < (1u << 24) && DIVS < 32, "24-bit reciprocal out of range");
 };
 
 // All per-wave state of the ring kernel. step<S>() is instantiated once per ring
@@ -530,18 +519,12 @@ struct RingWave {
     // sum is the running mean + 0.5 and never exceeds 65535.5 * 65536, so it fits 32
     // bits: one 24-bit multiply-add per pixel, the result is the high half.
     __device__ __forceinline__ void emit_row(const uint32_t e[PX], uint32_t row_off_bytes, uint32_t kr, bool live) const {
-#ifdef VSZIP_ABL_NOEMIT
-        return;
-#endif
         if constexpr (GENERAL) {
             if (!live || !is_out) return;
         }
         uint32_t t[PX];
 #pragma unroll
         for (int k = 0; k < PX; ++k) t[k] = __umul24(e[k], INV2) + kr;
-#ifdef VSZIP_ABL_NOSTORE
-        if (t[0] + t[3] + t[7] != 0x12345u) return;  // keeps the arithmetic alive, never stores
-#endif
         if constexpr (!GENERAL) {
             const uint32_t vo = live ? sdoff : kOOB;
             if constexpr (sizeof(T) == 2) {
@@ -607,23 +590,12 @@ struct RingWave {
         // band has no previous row: it reads stale LDS and its store is switched off.
         uint32_t e[PX];
         const bool have_prev = S > 0 || i > y0;
-#ifdef VSZIP_ABL_NOLDS
-#pragma unroll
-        for (int k = 0; k < PX; ++k) e[k] = col[k] ^ (uint32_t)k;
-#else
         if (!GENERAL || have_prev) window_sums(Pb, e);
-#endif
 
         // A: vertical mean, rounded (:114-128; col carries the +r), wave-wide inclusive prefix
         uint32_t p[PX];
 #pragma unroll
-#if defined(VSZIP_ABL_MULHI)
-        for (int k = 0; k < PX; ++k) p[k] = col[k] >> 5;
-#elif defined(VSZIP_DIV24)
-        for (int k = 0; k < PX; ++k) p[k] = (uint32_t)(((uint64_t)(col[k] & 0xffffffu) * G::DIVM) >> G::DIVS);
-#else
         for (int k = 0; k < PX; ++k) p[k] = __umulhi(col[k], G::MAGIC);
-#endif
         if constexpr (GENERAL) {
             const uint32_t m = ld_ok ? 0xffffffffu : 0u;  // lanes outside the plane hold zeros
 #pragma unroll
@@ -631,23 +603,10 @@ struct RingWave {
         }
 #pragma unroll
         for (int k = 1; k < PX; ++k) p[k] += p[k - 1];
-#ifdef VSZIP_ABL_NOSCAN
-        const uint32_t incl = p[PX - 1] * 3u;
-#else
         const uint32_t incl = wave_incl_scan_dpp(p[PX - 1]);
-#endif
         const uint32_t base = incl - p[PX - 1];
-#ifdef VSZIP_ABL_NOLDS
-        {
-            uint32_t x = base;
-#pragma unroll
-            for (int k = 0; k < PX; ++k) x ^= p[k];
-            if (x == 0x12345u) Pa[lane] = x;
-        }
-#else
 #pragma unroll
         for (int k = 0; k < PX; ++k) Pa[k * 64 + lane] = p[k] + base;
-#endif
 
         // slide the window to row i+1: entering row i+1+r (or row i once the window
         // hangs over the bottom edge, :61-66), leaving row i-r; refill the freed slot
@@ -660,9 +619,7 @@ struct RingWave {
             unpack8(ring[S], sb);
 #pragma unroll
             for (int k = 0; k < PX; ++k) col[k] += a[k] - sb[k];
-#ifndef VSZIP_ABL_NOLOAD
             ring[S] = fetch_off(next_off);
-#endif
             // advance the refill row: plain bands just step down one row
 
         }
@@ -683,14 +640,6 @@ struct RingWave {
         // advance the three prefetch rows. Bands that touch no plane edge just step down one
         // row; the mirror arithmetic (about 20 scalar instructions) sits behind a wave-uniform
         // branch that holds no memory instruction, so the vmcnt bookkeeping stays exact.
-#ifdef VSZIP_OFFS_SELECT
-        {
-            const uint32_t e0 = row_off(i + 2 + R + G::D), e1 = row_off(i + 2 + R + G::KL), e2 = row_off(i + 1 - R + G::KL);
-            next_off = plain ? next_off + srow : e0;
-            kn_off = plain ? kn_off + srow : e1;
-            ko_off = plain ? ko_off + srow : e2;
-        }
-#else
         if (plain) {
             next_off += srow;
             kn_off += srow;
@@ -700,7 +649,6 @@ struct RingWave {
             kn_off = row_off(i + 2 + R + G::KL);
             ko_off = row_off(i + 1 - R + G::KL);
         }
-#endif
         wave_lds_fence();
     }
 
@@ -785,11 +733,7 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     // entering / leaving pixels
     {
         const int kc = min(lane, R);
-#ifdef VSZIP_K_OOB
-        st.kvo = lane <= R ? (uint32_t)(kc * (int)sizeof(T)) : W::kOOB;  // lanes above r fetch nothing
-#else
         st.kvo = (uint32_t)(kc * (int)sizeof(T));
-#endif
         st.kwgt = lane < R ? 2u : (lane == R ? 1u : 0u);
         uint32_t acc = R;
 #pragma unroll
