@@ -94,7 +94,7 @@ constexpr int kRowW = kXB + 2 * (2 * kMaxMdis + 3);  // staged columns per sourc
 template <int NRAD>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const float kFltMax09 = FLT_MAX * 0.9f;
-    __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
+    __shared__ float rows[4][kRowW + 16];  // r3p, r1p, r1n, r3n around the block, mirror padding applied (+16: see the cost phase)
     __shared__ float tb[kU][kTbMax];  // t_base of the kU directions of the current pass
     __shared__ float ws[kU][kTbMax];  // their (2*nrad+1)-tap window sums
     __shared__ float ctile[2 * kMaxMdis + 1][kXB + 1];
@@ -144,53 +144,64 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         // round trips; one direction at a time leaves the wave waiting on LDS latency most of
         // the time, so kU directions go through each step together (independent work in flight).
         for (int ug = -mdis; ug <= mdis; ug += kU) {
-            int jlo[kU], span[kU];
+            // Everything below is branch-free across the kU directions, so that the compiler can
+            // keep the LDS reads of all kU directions in flight together: a direction whose span is
+            // shorter than the pass's longest simply computes a few entries nobody reads (rows[],
+            // tb[] and ws[] are padded for the overshoot).
+            int uu[kU], jlo[kU], span[kU];
             int span_max = 0;
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
-                const int u = min(ug + i, mdis), two_u = 2 * u;  // a clamped duplicate past +mdis is computed but never stored
+                const int u = min(ug + i, mdis), two_u = 2 * u;  // past +mdis: a duplicate of the last direction (same values, same slots)
+                uu[i] = u;
                 jlo[i] = min(u, min(0, two_u)) - nrad;
                 span[i] = kXB + max(u, max(0, two_u)) + nrad - jlo[i];  // t_base columns xb+jlo .. xb+63+jhi
                 span_max = max(span_max, span[i]);
             }
             for (int t = lane; t < span_max; t += 64) {
+                float val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
-                    if (t < span[i]) {
-                        const int two_u = 2 * min(ug + i, mdis);
-                        const int j = jlo[i] + t + reach;  // rows[] index of column xb + jlo + t
-                        const float a = rows[0][j], b = rows[1][j - two_u], c = rows[1][j];
-                        const float d = rows[2][j - two_u], e = rows[2][j], f = rows[3][j - two_u];
-                        tb[i][t] = fabsf(a - b) + fabsf(c - d) + fabsf(e - f);  // :415-425
-                    }
+                    const int two_u = 2 * uu[i];
+                    const int j = jlo[i] + t + reach;  // rows[] index of column xb + jlo + t
+                    const float a = rows[0][j], b = rows[1][j - two_u], c = rows[1][j];
+                    const float d = rows[2][j - two_u], e = rows[2][j], f = rows[3][j - two_u];
+                    val[i] = fabsf(a - b) + fabsf(c - d) + fabsf(e - f);  // :415-425
                 }
+#pragma unroll
+                for (int i = 0; i < kU; ++i) tb[i][t] = val[i];
             }
             wave_fence();
             // window sums, accumulated from 0 in k order exactly like sw0/sw1/sw2 (:443-450): the
             // three sums of a pixel are the same function of t_base at x+u, x, x+2u
             for (int t = lane + nrad; t < span_max - nrad; t += 64) {
+                float val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
-                    if (t < span[i] - nrad) {
-                        float sw = 0.0f;
+                    float sw = 0.0f;
 #pragma unroll
-                        for (int k = -nrad; k <= nrad; ++k) sw += tb[i][t + k];
-                        ws[i][t] = sw;
-                    }
+                    for (int k = -nrad; k <= nrad; ++k) sw += tb[i][t + k];
+                    val[i] = sw;
                 }
+#pragma unroll
+                for (int i = 0; i < kU; ++i) ws[i][t] = val[i];
             }
             wave_fence();
-            if (x < w) {
+            {
+                const int lxc = lx;  // lanes past the line end compute on staged (clamped) columns and store nothing
+                float val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
-                    const int u = ug + i, two_u = 2 * u;
-                    if (u <= mdis) {
-                        const int base = lane - jlo[i];  // tb/ws index of column x
-                        const float sw1 = ws[i][base], sw0 = ws[i][base + u], sw2 = ws[i][base + two_u];
-                        const float ip = (rows[1][lx + u] + rows[2][lx - u]) * 0.5f;
-                        const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
-                        ctile[mdis + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
-                    }
+                    const int u = uu[i], two_u = 2 * u;
+                    const int base = (lxc - reach) - jlo[i];  // tb/ws index of the column
+                    const float sw1 = ws[i][base], sw0 = ws[i][base + u], sw2 = ws[i][base + two_u];
+                    const float ip = (rows[1][lxc + u] + rows[2][lxc - u]) * 0.5f;
+                    const float v = fabsf(rows[1][lxc] - ip) + fabsf(rows[2][lxc] - ip);
+                    val[i] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
+                }
+                if (x < w) {
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) ctile[mdis + uu[i]][lane] = val[i];
                 }
             }
             wave_fence();  // tb / ws are rewritten by the next pass
