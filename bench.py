@@ -312,6 +312,31 @@ def planestats_leg(dev, timed, frames=16):
     return out
 
 
+def boxblur_other_paths_leg(dev, timed, frames=8):
+    """The BoxBlur paths beside the headline one: the runtime path (radius > 22 or several passes,
+    boxblur_runtime.zig) on 4K YUV420P16 and the compile-time float path on 4K YUV420PS."""
+    out = {}
+    base16 = make_frame(3, W4K, H4K)
+    basef = [(p.astype(np.float32) / 65535.0) for p in base16]
+    for name, base, args, dt_ in (("boxblur_rt_r30_4k", base16, (30, 1, 30, 1), np.uint16), ("boxblur_rt_r5x3_4k", base16, (5, 3, 5, 3), np.uint16),
+                                  ("boxblur_ct_float_r13_4k", basef, (13, 1, 13, 1), np.float32)):
+        srcs, dsts = [], []
+        for f in range(frames):
+            for p in base:
+                srcs.append(dev.upload(np.roll(p, f + 1, axis=1)))
+                dsts.append(dev.empty(p.shape[0], p.shape[1], p.dtype))
+        table = dev.plane_table(srcs, dsts)
+        dt, kms, _, _ = timed.run(lambda: dev.boxblur_table(dt_, table, *args), 5, 1)
+        fb = 2 * sum(p.nbytes for p in base) * frames
+        gbs = fb * 5 / (kms * 1e-3) / 1e9
+        out[name] = {"value": frames * 5 / dt, "unit": "frames/s",
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                  "note": "algorithmic bytes = one read + one write of the frame, whatever the number of passes"},
+                     "workload": f"vszip.BoxBlur hradius={args[0]} hpasses={args[1]} vradius={args[2]} vpasses={args[3]}, 3840x2160 {'YUV420P16' if dt_ == np.uint16 else 'YUV420PS'}, HBM-resident"}
+        del srcs, dsts
+    return out
+
+
 def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, rounds: int = 12):
     """PCIe-inclusive BoxBlur rate, the path a VapourSynth host pays: every frame is copied from
     pinned host memory to the GPU, blurred, and copied back. `nctx` contexts (one stream each,
@@ -453,6 +478,10 @@ def main() -> int:
                     others[leg_name] = leg()
                 except Exception as e:
                     others[leg_name] = {"error": str(e)}
+            try:
+                others.update(boxblur_other_paths_leg(dev, timed))
+            except Exception as e:
+                others["boxblur_other_paths"] = {"error": str(e)}
             try:
                 others.update(planestats_leg(dev, timed))
             except Exception as e:

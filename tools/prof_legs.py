@@ -18,5 +18,7 @@ for leg in sys.argv[1:]:
         print(bench.eedi3_leg(dev, timed, True))
     elif leg == "xpsnr":
         print(bench.xpsnr_leg(dev, timed, True))
+    elif leg == "boxblur_other":
+        print(bench.boxblur_other_paths_leg(dev, timed))
     elif leg == "planestats":
         print(bench.planestats_leg(dev, timed))

@@ -181,6 +181,175 @@ __global__ __launch_bounds__(64) void boxblur_rt_vint_kernel(const RParams prm) 
     }
 }
 
+
+// ---- RT integer, vectorised (rows 16-byte aligned: every VapourSynth frame) ---------------------
+// The 16.16 running sum of blurInt (:10-41) has the closed form
+//     dst[i] = (inv2 * E_i + 32768 + ((E_0 * invlo) >> 16)) >> 16,
+// E_i the edge-duplicating mirrored window sum (index j < 0 -> -j-1, j >= len -> 2*len-1-j), so a
+// line can be cut anywhere: only E at the cut and the line's E_0 are needed.
+template <typename T>
+struct RtVec {
+    static constexpr int V = 16 / (int)sizeof(T);
+    static __device__ __forceinline__ void load(const T *p, uint32_t v[V]) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+        const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if constexpr (sizeof(T) == 2)
+                v[k] = (d[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            else
+                v[k] = (d[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        }
+    }
+    static __device__ __forceinline__ void store(T *p, const uint32_t v[V], int n) {
+        if (n >= V) {
+            uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                if constexpr (sizeof(T) == 2)
+                    d[k >> 1] |= v[k] << ((k & 1) * 16);
+                else
+                    d[k >> 2] |= v[k] << ((k & 3) * 8);
+            }
+            *reinterpret_cast<uint4 *>(p) = make_uint4(d[0], d[1], d[2], d[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (k < n) p[k] = (T)v[k];
+        }
+    }
+};
+
+struct RVParams {
+    RPlane p[kMaxPlanesRT];
+    int ncg[kMaxPlanesRT];  // column groups (64 lanes x V columns) per plane
+    int nplanes, radius, band;
+};
+
+// Vertical: lane = V adjacent columns, one wave per (column group, band of rows). E_0 and the
+// window sum at the top of the band are summed directly, then the window slides (one entering and
+// one leaving row vector per output row).
+template <typename T>
+__global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm) {
+    using X = RtVec<T>;
+    constexpr int V = X::V;
+    int pi = 0;
+    const int b = blockIdx.x;
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const RPlane pl = prm.p[pi];
+    const int lb = b - pl.block0, ncg = prm.ncg[pi];
+    const int x0 = ((lb % ncg) * 64 + (int)threadIdx.x) * V;
+    if (x0 >= pl.w) return;
+    const int len = pl.h, R = prm.radius;
+    const int y0 = (lb / ncg) * prm.band, y1 = min(y0 + prm.band, len);
+    const T *s = static_cast<const T *>(pl.src) + x0;
+    T *d = static_cast<T *>(pl.dst) + x0;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    const int nst = min(V, pl.w - x0);
+    const uint32_t ksize = 2u * (uint32_t)R + 1u;
+    const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    auto mrow = [&](int j) { return j < 0 ? -j - 1 : (j >= len ? 2 * len - 1 - j : j); };
+
+    uint32_t e0[V], e[V], kk[V], t[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) e0[k] = 0;
+    for (int r = 0; r <= R; ++r) {  // E_0 = s[R] + 2 * sum_{i<R} s[i]
+        X::load(s + (size_t)r * ss, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) e0[k] += r < R ? 2u * t[k] : t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) kk[k] = 32768u + (uint32_t)(((uint64_t)e0[k] * invlo) >> 16);
+    if (y0 == 0) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) e[k] = e0[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) e[k] = 0;
+        for (int j = y0 - R; j <= y0 + R; ++j) {
+            X::load(s + (size_t)mrow(j) * ss, t);
+#pragma unroll
+            for (int k = 0; k < V; ++k) e[k] += t[k];
+        }
+    }
+#pragma unroll 4
+    for (int i = y0; i < y1; ++i) {
+        uint32_t o[V], a[V], c[V];
+        X::load(s + (size_t)mrow(i + 1 + R) * ss, a);
+        X::load(s + (size_t)mrow(i - R) * ss, c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            o[k] = (uint32_t)(((uint64_t)e[k] * inv2 + kk[k]) >> 16);
+            e[k] += a[k] - c[k];
+        }
+        X::store(d + (size_t)i * ds, o, nst);
+    }
+}
+
+// Horizontal: one wave per row. Pass 1 builds the inclusive prefix of the row in LDS (in-lane
+// prefix + DPP wave scan + a running carry), laid out [chunk][pixel-in-lane][lane] so that both
+// passes are bank-conflict free; pass 2 forms E_x as prefix differences and stores.
+template <typename T>
+__global__ __launch_bounds__(64) void boxblur_rt_hrow_kernel(const RParams prm) {
+    using X = RtVec<T>;
+    constexpr int V = X::V, CH = 64 * V;
+    extern __shared__ __attribute__((aligned(16))) uint32_t P[];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int y = b - pl.block0;
+    const int w = pl.w, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
+    const int lane = threadIdx.x;
+    const int nch = (w + CH - 1) / CH;
+    auto pidx = [&](int c) { return (c / CH) * CH + (c % V) * 64 + (c % CH) / V; };
+    uint32_t carry = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int x0 = ch * CH + lane * V;
+        uint32_t v[V];
+        if (x0 < w) {
+            X::load(s + x0, v);  // [w, stride) is readable padding; masked below
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (x0 + k >= w) v[k] = 0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = 0;
+        }
+#pragma unroll
+        for (int k = 1; k < V; ++k) v[k] += v[k - 1];
+        const uint32_t incl = wave_incl_scan_dpp(v[V - 1]);
+        const uint32_t base = carry + incl - v[V - 1];
+#pragma unroll
+        for (int k = 0; k < V; ++k) P[ch * CH + k * 64 + lane] = v[k] + base;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    __syncthreads();
+    const uint32_t ksize = 2u * (uint32_t)R + 1u;
+    const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : P[pidx(min(c, w - 1))]; };
+    const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2*sum_{x<r} srcp[x]
+    const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int x0 = ch * CH + lane * V;
+        if (x0 >= w) break;
+        uint32_t o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int x = x0 + k;
+            // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
+            uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
+            if (x - R - 1 < -1) e += Q(R - x - 1);
+            if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
+            o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+        }
+        X::store(d + x0, o, min(V, w - x0));
+    }
+}
+
 // ---- RT float: blurFloat verbatim (:43-79), one thread per line ------------------------------
 template <typename T>
 __device__ __forceinline__ void blur_float_line(const T *s, size_t ss, T *d, size_t ds, int len, int R) {
@@ -238,10 +407,43 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
             maxw = std::max(maxw, prm.p[i].w);
         }
         if constexpr (is_int) {
-            if (!vertical)
+            bool aligned = true;
+            for (int i = 0; i < n; ++i) {
+                const RPlane &q = prm.p[i];
+                aligned = aligned && (((reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) |
+                                        (uintptr_t)((size_t)q.dstride * sizeof(T))) & 15) == 0) && q.sstride >= ((q.w + RtVec<T>::V - 1) / RtVec<T>::V) * RtVec<T>::V;
+            }
+            if (aligned && !vertical) {
+                constexpr int CH = 64 * RtVec<T>::V;
+                const size_t lds = (size_t)((maxw + CH - 1) / CH) * CH * sizeof(uint32_t);
+                hipLaunchKernelGGL((boxblur_rt_hrow_kernel<T>), dim3(blocks), dim3(64), lds, ctx->stream, prm);
+            } else if (aligned) {
+                RVParams vp;
+                vp.nplanes = n;
+                vp.radius = radius;
+                // bands: enough waves to fill the chip, long enough that the 3r+2 warm-up rows stay a fraction
+                long colgroups = 0;
+                int maxh = 0;
+                for (int i = 0; i < n; ++i) {
+                    colgroups += (prm.p[i].w + 64 * RtVec<T>::V - 1) / (64 * RtVec<T>::V);
+                    maxh = std::max(maxh, prm.p[i].h);
+                }
+                int band = std::max(64, 4 * radius);
+                while (band < maxh && colgroups * ((maxh + band - 1) / band) > 16384) band *= 2;
+                vp.band = band;
+                int vb = 0;
+                for (int i = 0; i < n; ++i) {
+                    vp.p[i] = prm.p[i];
+                    vp.p[i].block0 = vb;
+                    vp.ncg[i] = (prm.p[i].w + 64 * RtVec<T>::V - 1) / (64 * RtVec<T>::V);
+                    vb += vp.ncg[i] * ((prm.p[i].h + band - 1) / band);
+                }
+                hipLaunchKernelGGL((boxblur_rt_vband_kernel<T>), dim3(vb), dim3(64), 0, ctx->stream, vp);
+            } else if (!vertical) {
                 hipLaunchKernelGGL((boxblur_rt_hint_kernel<T>), dim3(blocks), dim3(256), (size_t)maxw * sizeof(uint32_t), ctx->stream, prm);
-            else
+            } else {
                 hipLaunchKernelGGL((boxblur_rt_vint_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+            }
         } else {
             if (vertical)
                 hipLaunchKernelGGL((boxblur_rt_float_kernel<T, true>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
@@ -264,7 +466,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
     for (int i = 0; i < nplanes; ++i) {
         off[i] = elems;
         elems += (size_t)((planes[i].w + 63) & ~63) * planes[i].h;
-        if (std::is_integral<T>::value && hb && (size_t)planes[i].w * sizeof(uint32_t) > 60000)
+        if (std::is_integral<T>::value && hb && (size_t)(planes[i].w + 1024) * sizeof(uint32_t) > 60000)
             return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: rows longer than 15000 samples not built yet on the RT integer path");
     }
     T *scratch[2] = {nullptr, nullptr};
