@@ -1,7 +1,5 @@
 // vszip.BoxBlur — the paths besides the CT integer kernel:
-//   * CT float (f32 / f16): boxblur_comptime.zig:161-263 (vBlurFloat / hBlurFloat): both
-//     axes accumulate `acc + div * tap` over the 2r+1 taps IN TAP ORDER with the asymmetric
-//     mirror of mirrorRows (:50-70). LDS-tiled; unfused f32, so results are bit-identical.
+//   * (CT float lives in boxblur_ctf.hip)
 //   * RT integer (any radius, passes, hradius != vradius): boxblur_runtime.zig:10-41 blurInt,
 //     one launch per pass and axis. The 16.16 running sum has the closed form
 //         dst[x] = (inv2*E_x + 32768 + ((E_0*invlo) >> 16)) >> 16
@@ -49,57 +47,6 @@ __device__ __forceinline__ int ct_tap(int k, int i, int radius, int n) {
     const int dist_from_end = n - 1 - i;
     if (k < radius) return (i < radius - k) ? min(radius - k - i, n - 1) : (i - radius + k);
     return (dist_from_end < k - radius) ? (i - min(k - radius - dist_from_end, i)) : (i - radius + k);
-}
-
-// ---- CT float ---------------------------------------------------------------------------
-constexpr int FTW = 64, FTH = 32, FRMAX = 22;
-constexpr int FIW = FTW + 2 * FRMAX, FIH = FTH + 2 * FRMAX;
-
-struct FParams {
-    RPlane p[kMaxPlanesRT];
-    int nbx[kMaxPlanesRT];
-    int nplanes;
-    int radius;
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void boxblur_ct_float_kernel(const FParams prm) {
-    __shared__ float tile[FIH][FIW + 1];
-    __shared__ float vt[FTH][FIW + 1];
-    int pi = 0;
-    const int b = blockIdx.x;
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
-    const RPlane pl = prm.p[pi];
-    const int lb = b - pl.block0;
-    const int R = prm.radius, K = 2 * R + 1;
-    const int w = pl.w, h = pl.h;
-    const int x0 = (lb % prm.nbx[pi]) * FTW, y0 = (lb / prm.nbx[pi]) * FTH;
-    const int cx0 = max(x0 - R, 0), cy0 = max(y0 - R, 0);
-    const int cw = min(x0 + FTW + R, w) - cx0, ch = min(y0 + FTH + R, h) - cy0;
-    const T *src = static_cast<const T *>(pl.src);
-    T *dst = static_cast<T *>(pl.dst);
-    const float div = 1.0f / (float)K;  // :39
-    const int tid = threadIdx.x;
-    for (int i = tid; i < ch * cw; i += 256) {
-        const int r = i / cw, c = i - r * cw;
-        tile[r][c] = (float)src[(size_t)(cy0 + r) * pl.sstride + cx0 + c];
-    }
-    __syncthreads();
-    const int th = min(FTH, h - y0), tw = min(FTW, w - x0);
-    for (int i = tid; i < th * cw; i += 256) {  // vBlurFloat :161-190
-        const int r = i / cw, c = i - r * cw;
-        float acc = 0.0f;
-        for (int k = 0; k < K; ++k) acc = acc + div * tile[ct_tap(k, y0 + r, R, h) - cy0][c];
-        vt[r][c] = (float)(T)acc;  // tmp row is stored as T
-    }
-    __syncthreads();
-    for (int i = tid; i < th * tw; i += 256) {  // hBlurFloat :192-263
-        const int r = i / tw, c = i - r * tw;
-        float sum = 0.0f;
-        for (int k = 0; k < K; ++k) sum += div * vt[r][ct_tap(k, x0 + c, R, w) - cx0];
-        dst[(size_t)(y0 + r) * pl.dstride + x0 + c] = (T)sum;
-    }
 }
 
 // ---- RT integer -----------------------------------------------------------------------------
@@ -507,35 +454,6 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
     return VSZIP_OK;
 }
 
-template <typename T>
-int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int radius) {
-    int done = 0;
-    while (done < nplanes) {
-        FParams prm;
-        const int n = std::min(kMaxPlanesRT, nplanes - done);
-        prm.nplanes = n;
-        prm.radius = radius;
-        int blocks = 0;
-        for (int i = 0; i < n; ++i) {
-            const vszip_plane &s = planes[done + i];
-            RPlane &d = prm.p[i];
-            d.src = s.src;
-            d.dst = s.dst;
-            d.sstride = (int)s.src_stride;
-            d.dstride = (int)s.dst_stride;
-            d.w = s.w;
-            d.h = s.h;
-            d.block0 = blocks;
-            prm.nbx[i] = (s.w + FTW - 1) / FTW;
-            blocks += prm.nbx[i] * ((s.h + FTH - 1) / FTH);
-        }
-        hipLaunchKernelGGL((boxblur_ct_float_kernel<T>), dim3(blocks), dim3(256), 0, ctx->stream, prm);
-        VSZIP_HIP_CHECK(ctx, hipGetLastError());
-        done += n;
-    }
-    return VSZIP_OK;
-}
-
 }  // namespace
 
 int vszip_bb_rt(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses) {
@@ -546,9 +464,4 @@ int vszip_bb_rt(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplane
         case VSZIP_F32: return run_rt<float>(ctx, planes, nplanes, hradius, hpasses, vradius, vpasses);
     }
     return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: not supported Int format.");
-}
-
-int vszip_bb_ct_float(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int radius) {
-    if (dtype == VSZIP_F16) return run_ct_float<_Float16>(ctx, planes, nplanes, radius);
-    return run_ct_float<float>(ctx, planes, nplanes, radius);
 }
