@@ -1,0 +1,168 @@
+"""Seeded random-geometry parity: plane sizes, strides, radii and batch compositions that no
+hand-written case covers (band splits of the ring kernel, launch-table limits, tiles that are
+all border, lines barely longer than the search reach). Bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    yield d
+    d.close()
+
+
+def _plane(rng, shape, dtype):
+    if np.dtype(dtype).kind == "u":
+        peak = np.iinfo(dtype).max
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            return rng.integers(0, peak + 1, size=shape, dtype=dtype)
+        if kind == 1:
+            return fx.tiled_natural(shape, dtype, int(rng.integers(0, 3)))
+        return np.full(shape, peak if rng.integers(0, 2) else 0, dtype)  # extremes: no overflow at full scale
+    return rng.random(shape).astype(dtype)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_boxblur_int_random_batches(dev, oracle, seed):
+    """CT (ring + generic kernel) and RT integer paths on random batches of mixed plane sizes."""
+    rng = np.random.default_rng(1000 + seed)
+    dtype = [np.uint8, np.uint16][seed % 2]
+    ct = seed % 3 != 2
+    r = int(rng.integers(1, 23)) if ct else int(rng.integers(1, 40))
+    args = (r, 1, r, 1) if ct else (r, int(rng.integers(1, 3)), int(rng.integers(1, 40)), int(rng.integers(0, 3)))
+    need = 2 * max(args[0], args[2]) + 1
+    planes = []
+    for _ in range(int(rng.integers(1, 9))):
+        h = int(rng.integers(max(need, 54), 400))
+        w = int(rng.integers(max(need, 24), 700))
+        if rng.integers(0, 3):
+            w = (w + 7) // 8 * 8  # the ring kernel's fast variant
+        planes.append(_plane(rng, (h, w), dtype))
+    align = int(rng.choice([1, 8, 32]))
+    srcs = [dev.upload(p, align) for p in planes]
+    dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype, align) for p in planes]
+    dev.boxblur(srcs, dsts, *args)
+    for p, d in zip(planes, dsts):
+        assert np.array_equal(dev.download(d), oracle.boxblur(p, *args)), (seed, p.shape, args, align)
+
+
+def test_boxblur_ring_many_planes(dev, oracle):
+    """More planes than one launch table holds (192) and more than the old 48: exercises the
+    block -> plane map and the launch split."""
+    rng = np.random.default_rng(7)
+    planes = [rng.integers(0, 65536, size=(int(rng.integers(60, 90)), 64 + 8 * int(rng.integers(0, 8))), dtype=np.uint16) for _ in range(230)]
+    srcs = [dev.upload(p) for p in planes]
+    dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+    dev.boxblur(srcs, dsts, 5, 1, 5, 1)
+    for i in (0, 47, 48, 191, 192, 229):
+        assert np.array_equal(dev.download(dsts[i]), oracle.boxblur(planes[i], 5, 1, 5, 1)), i
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_boxblur_float_random(dev, oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    dtype = [np.float32, np.float16][seed % 2]
+    r = int(rng.integers(1, 23))
+    h, w = int(rng.integers(2 * r + 1, 200)), int(rng.integers(2 * r + 1, 300))
+    p = _plane(rng, (h, w), dtype)
+    s, d = dev.upload(p), dev.empty(h, w, dtype)
+    dev.boxblur([s], [d], r, 1, r, 1)
+    assert np.array_equal(dev.download(d).view(np.uint8), oracle.boxblur(p, r, 1, r, 1).view(np.uint8)), (seed, r, h, w)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_bilateral_random(dev, oracle, seed):
+    rng = np.random.default_rng(3000 + seed)
+    dtype = [np.uint8, np.uint16, np.float32, np.float16][seed % 4]
+    sS = float(rng.choice([0.6, 1.0, 2.0, 3.5, 6.0]))
+    sR = float(rng.choice([0.02, 0.1, 0.5, 2.0]))
+    cfg = dev.bilateral_cfg([sS], [sR], hist_len=(1 << (8 * np.dtype(dtype).itemsize)) if np.dtype(dtype).kind == "u" else 65536)
+    rad = cfg[0].radius if cfg[0].algorithm == 2 else 1
+    h, w = int(rng.integers(2 * rad + 1, 150)), int(rng.integers(2 * rad + 1, 260))
+    p = _plane(rng, (h, w), dtype)
+    ref = _plane(rng, (h, w), dtype) if seed % 2 else None
+    s, d = dev.upload(p), dev.empty(h, w, dtype)
+    dev.bilateral([s], [d], cfg, [0], [dev.upload(ref)] if ref is not None else None)
+    want = oracle.bilateral_plane(p, cfg[0].sigmaS, cfg[0].sigmaR, cfg[0].algorithm, cfg[0].radius, cfg[0].step, cfg[0].pbficnum, ref=ref)
+    assert np.array_equal(dev.download(d).view(np.uint8), want.view(np.uint8)), (seed, sS, sR, cfg[0].algorithm, h, w)
+    dev.bilateral_free(cfg)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_eedi3_random(dev, oracle, seed):
+    rng = np.random.default_rng(4000 + seed)
+    hp = bool(seed % 2)
+    mdis = int(rng.integers(1, 41))
+    nrad = int(rng.integers(0, 4))
+    dh = bool(rng.integers(0, 2))
+    w = int(rng.integers(2 * mdis + nrad + 4, 2 * mdis + nrad + 200))
+    h = int(rng.integers(4, 40)) * 2
+    p = rng.random((h, w)).astype(np.float32)
+    kw = dict(dh=dh, hp=hp, mdis=mdis, nrad=nrad, vcheck=int(rng.integers(0, 4)), gamma=float(rng.choice([0.0, 5.0, 20.0, 80.0])))
+    field = int(rng.integers(0, 2))
+    s = dev.upload(p)
+    (d,) = dev.eedi3([s], field, **kw)
+    assert np.array_equal(dev.download(d), oracle.eedi3(p, field, **kw)), (seed, field, kw, p.shape)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_planestats_random(dev, oracle, seed):
+    rng = np.random.default_rng(5000 + seed)
+    dtype = [np.uint8, np.uint16, np.float32][seed % 3]
+    planes = [_plane(rng, (int(rng.integers(1, 200)), int(rng.integers(1, 500))), dtype) for _ in range(int(rng.integers(1, 6)))]
+    align = int(rng.choice([1, 8, 32]))
+    srcs = [dev.upload(p, align) for p in planes]
+    excl = [int(x) for x in rng.integers(0, 256, size=int(rng.integers(0, 4)))]
+    avg, _ = dev.plane_average(srcs, exclude=excl)
+    thr = float(rng.choice([0.0, 0.05, 0.3]))
+    mn, mx, _ = dev.plane_minmax(srcs, thr, thr)
+    for i, p in enumerate(planes):
+        oa = oracle.plane_average(p, exclude=excl)[0]
+        assert avg[i] == (oa if np.dtype(dtype).kind == "u" else pytest.approx(oa, rel=1e-12)), (seed, i)
+        omn, omx = oracle.plane_minmax(p, thr, thr)[:2]
+        assert (mn[i], mx[i]) == (omn, omx), (seed, i, thr)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ssimulacra2_random_sizes(dev, oracle, seed):
+    """Odd and tiny frames (down to one 8x8 tile at scale 0; five halvings) and a batch of pairs."""
+    rng = np.random.default_rng(6000 + seed)
+    h, w = int(rng.integers(8, 300)), int(rng.integers(8, 400))
+    npairs = int(rng.integers(1, 4))
+    ref, dis = [], []
+    for _ in range(npairs):
+        r = [rng.random((h, w)).astype(np.float32) for _ in range(3)]
+        ref.append(r)
+        dis.append([np.clip(p + rng.normal(0, 0.05, p.shape).astype(np.float32), 0, 1).astype(np.float32) for p in r])
+    rr = [dev.upload(p, 1) for pr in ref for p in pr]
+    dd = [dev.upload(p, 1) for pr in dis for p in pr]
+    got = dev.ssimulacra2(rr, dd)
+    for i in range(npairs):
+        assert got[i] == pytest.approx(oracle.ssimulacra2(ref[i], dis[i]), abs=1e-7), (seed, i, h, w)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_xpsnr_random(dev, oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    dtype, depth = [(np.uint8, 8), (np.uint16, 10)][seed % 2]
+    h, w = int(rng.integers(16, 140)) * 2, int(rng.integers(16, 200)) * 2
+    peak = (1 << depth) - 1
+    shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+    frames = [[rng.integers(0, peak + 1, size=s).astype(dtype) for s in shapes] for _ in range(3)]
+    recs = [[np.clip(p.astype(np.int32) + rng.integers(-6, 7, p.shape), 0, peak).astype(dtype) for p in fr] for fr in frames]
+    dfr = [[dev.upload(p) for p in fr] for fr in frames]
+    drc = [[dev.upload(p) for p in fr] for fr in recs]
+    fps = int(rng.choice([24, 60]))
+    for n in range(3):
+        p1, p2 = (dfr[n - 1][0] if n >= 1 else None), (dfr[n - 2][0] if n >= 2 else None)
+        got = dev.xpsnr_wsse(dfr[n], drc[n], p1, p2, depth=depth, frame_rate=fps)
+        want = oracle.xpsnr_wsse(frames[n], recs[n], frames[n - 1][0] if n >= 1 else None, frames[n - 2][0] if n >= 2 else None, depth=depth, frame_rate=fps)
+        assert got == want, (seed, n, h, w, fps)
