@@ -390,6 +390,12 @@ def main() -> int:
     ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON. Libraries that print to fd 1 (RCCL's version banner
+    # does) are sent to stderr for the lifetime of the process; the JSON goes to the saved fd.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -402,7 +408,10 @@ def main() -> int:
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VSZIP_BENCH_FORCE_DIST=1 (under torch.distributed.run with one process): run the RCCL path
+    # — barrier, timing max-reduce, per-clip scalar all-reduce — even with a single rank
+    use_dist = world > 1 or (os.environ.get("VSZIP_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import vszip_amd
@@ -410,7 +419,7 @@ def main() -> int:
     dev = vszip_amd.Device(local_rank)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dev.sync()
@@ -418,7 +427,7 @@ def main() -> int:
     timed = Timed(dev, barrier)
 
     def max_over_ranks(dt):
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -449,6 +458,16 @@ def main() -> int:
                          "whole_filter": {"note": "ring kernel + launch gaps, HIP events over the whole timed region",
                                           "avg_us": group_s * 1e6, "achieved": alg_bytes / group_s / 1e9, "frac": alg_bytes / group_s / 1e9 / HBM_PEAK_GBS}},
         }
+        # Outside the timed region: the one collective of the design — a per-clip scalar (here the
+        # mean luma of the blurred clip, PlaneAverage over every rank's frames) all-reduced over
+        # RCCL, like XPSNR's / SSIMULACRA2's per-clip sums (vszip_amd.cluster).
+        try:
+            luma = keep[1][0::3]
+            avgs, _ = dev.plane_average(luma[:48], exclude=[-1])
+            tot = vszip_amd.cluster.allreduce_clip_scalars(np.array([float(np.sum(avgs)), float(len(avgs))]), device="cuda" if use_dist else None)
+            out["config"]["clip_mean_luma"] = {"value": float(tot[0] / tot[1]), "frames": int(tot[1]), "reduced_over_ranks": world}
+        except Exception as e:  # informative only
+            out["config"]["clip_mean_luma"] = {"error": str(e)}
         del keep
         if rank == 0 and world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_boxblur()
@@ -523,8 +542,9 @@ def main() -> int:
             out["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
+    if use_dist:
         dist.destroy_process_group()
     dev.close()
     return 0

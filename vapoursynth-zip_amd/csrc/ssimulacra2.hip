@@ -33,6 +33,7 @@ namespace {
 constexpr int kScales = 5;  // scales that carry a non-pruned weight
 constexpr int TW = 32, TH = 32, HALO = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
 constexpr int kVecW = 8;    // reference SIMD width baked into the FMA rule
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __constant__ float c_kernel[9] = {
     0.0076144188642501831054687500f, 0.0360749699175357818603515625f, 0.1095860823988914489746093750f,
@@ -182,33 +183,29 @@ __device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *i
         const int r = i / cw, c = i - r * cw;
         const int y = y0 + r;
         const bool fused = INTERIOR || (cx0 + c) < wv;
-        float m12 = 0.0f, msq = 0.0f, m1 = 0.0f, m2 = 0.0f;
+        // two maps per packed instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): (m1, m2)
+        // and (m12, msq); element-wise IEEE, so every lane value equals the scalar form
+        v2f m = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int rr = INTERIOR ? r + k : tap_index(k, y, h) - cy0;
             const float p = s1[rr][c], q = s2[rr][c];
-            const float kk = c_kernel[k];
+            const v2f kk = {c_kernel[k], c_kernel[k]};
+            const v2f pq = {p, q};
             const float sum = p + q;
+            const v2f a = {p, sum}, b2 = {q, sum};
             if (fused) {
-                m1 = fmaf(kk, p, m1);
-                m2 = fmaf(kk, q, m2);
-                if (do_ssim) {
-                    m12 = fmaf(kk, p * q, m12);
-                    msq = fmaf(kk, sum * sum, msq);
-                }
+                m = __builtin_elementwise_fma(kk, pq, m);
+                if (do_ssim) ms = __builtin_elementwise_fma(kk, a * b2, ms);
             } else {
-                m1 += kk * p;
-                m2 += kk * q;
-                if (do_ssim) {
-                    m12 += kk * (p * q);
-                    msq += kk * (sum * sum);
-                }
+                m = m + kk * pq;
+                if (do_ssim) ms = ms + kk * (a * b2);
             }
         }
-        vt[0][r][c] = m12;
-        vt[1][r][c] = msq;
-        vt[2][r][c] = m1;
-        vt[3][r][c] = m2;
+        vt[0][r][c] = ms.x;
+        vt[1][r][c] = ms.y;
+        vt[2][r][c] = m.x;
+        vt[3][r][c] = m.y;
     }
     __syncthreads();
 
@@ -217,18 +214,19 @@ __device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *i
     for (int i = tid; i < th * tw; i += 256) {
         const int r = i / tw, c = i - r * tw;
         const int x = x0 + c;
-        float b12 = 0.0f, bsq = 0.0f, mu1 = 0.0f, mu2 = 0.0f;
+        v2f mu = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int cc = INTERIOR ? c + k : tap_index(k, x, w) - cx0;
-            const float kk = c_kernel[k];
-            mu1 += kk * vt[2][r][cc];
-            mu2 += kk * vt[3][r][cc];
+            const v2f kk = {c_kernel[k], c_kernel[k]};
+            const v2f v23 = {vt[2][r][cc], vt[3][r][cc]};
+            mu = mu + kk * v23;
             if (do_ssim) {
-                b12 += kk * vt[0][r][cc];
-                bsq += kk * vt[1][r][cc];
+                const v2f v01 = {vt[0][r][cc], vt[1][r][cc]};
+                bs = bs + kk * v01;
             }
         }
+        const float mu1 = mu.x, mu2 = mu.y, b12 = bs.x, bsq = bs.y;
         if (do_ssim) {  // ssimMap :511-523
             const float m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2, md = mu1 - mu2;
             const double num_m = (double)fmaf(md, -md, 1.0f);
