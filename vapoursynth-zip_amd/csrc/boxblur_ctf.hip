@@ -7,7 +7,8 @@
 // halo in LDS, runs the vertical taps into a second LDS tile (stored as T, like the reference's
 // tmp row) and then the horizontal taps. The radius is a template parameter: the tap loops
 // unroll, and tiles that touch no plane border use compile-time tap offsets (the mirror index
-// arithmetic costs more than the taps themselves).
+// arithmetic costs more than the taps themselves) and are register blocked (8 outputs per
+// work item share their 8 + 2r loads).
 #include "common.hpp"
 
 namespace {
@@ -58,20 +59,37 @@ __global__ __launch_bounds__(256) void boxblur_ct_float_kernel(const FParams prm
             tile[r][c] = (float)src[(size_t)(y0 - R + r) * pl.sstride + x0 - R + c];
         }
         __syncthreads();
-        for (int i = tid; i < FTH * IW; i += 256) {  // vBlurFloat :161-190
-            const int r = i / IW, c = i - r * IW;
-            float acc = 0.0f;
+        // register blocked: a work item owns 8 consecutive outputs of a column (vertical pass) or of
+        // a row (horizontal pass) and loads its 8 + 2r inputs once; each output still accumulates
+        // its 2r+1 taps in tap order, unfused, so the arithmetic is the reference's
+        constexpr int NB = 8;
+        for (int i = tid; i < (FTH / NB) * IW; i += 256) {  // vBlurFloat :161-190
+            const int c = i % IW, r0 = (i / IW) * NB;
+            float v[NB + 2 * R];
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc = acc + div * tile[r + k][c];
-            vt[r][c] = (float)(T)acc;  // tmp row is stored as T
+            for (int j = 0; j < NB + 2 * R; ++j) v[j] = tile[r0 + j][c];
+#pragma unroll
+            for (int o = 0; o < NB; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = acc + div * v[o + k];
+                vt[r0 + o][c] = (float)(T)acc;  // tmp row is stored as T
+            }
         }
         __syncthreads();
-        for (int i = tid; i < FTH * FTW; i += 256) {  // hBlurFloat :192-263
-            const int r = i / FTW, c = i - r * FTW;
-            float sum = 0.0f;
+        {  // hBlurFloat :192-263: 32 rows x 8 strips of 8 outputs = 256 work items
+            const int r = tid / (FTW / NB), c0 = (tid % (FTW / NB)) * NB;
+            float v[NB + 2 * R];
 #pragma unroll
-            for (int k = 0; k < K; ++k) sum += div * vt[r][c + k];
-            dst[(size_t)(y0 + r) * pl.dstride + x0 + c] = (T)sum;
+            for (int j = 0; j < NB + 2 * R; ++j) v[j] = vt[r][c0 + j];
+            T *drow = dst + (size_t)(y0 + r) * pl.dstride + x0 + c0;
+#pragma unroll
+            for (int o = 0; o < NB; ++o) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sum += div * v[o + k];
+                drow[o] = (T)sum;
+            }
         }
         return;
     }
