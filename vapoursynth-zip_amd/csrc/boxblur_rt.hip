@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hrow_kernel(const RParams prm) 
     T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
     const int lane = threadIdx.x;
     const int nch = (w + CH - 1) / CH;
-    auto pidx = [&](int c) { return (c / CH) * CH + (c % V) * 64 + (c % CH) / V; };
+    auto pidx = [&](uint32_t c) { return (c / (uint32_t)CH) * (uint32_t)CH + (c % (uint32_t)V) * 64u + (c % (uint32_t)CH) / (uint32_t)V; };  // unsigned: shifts and masks
     uint32_t carry = 0;
     for (int ch = 0; ch < nch; ++ch) {
         const int x0 = ch * CH + lane * V;
@@ -277,21 +277,32 @@ __global__ __launch_bounds__(64) void boxblur_rt_hrow_kernel(const RParams prm) 
     const uint32_t ksize = 2u * (uint32_t)R + 1u;
     const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
     const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
-    auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : P[pidx(min(c, w - 1))]; };
+    auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : P[pidx((uint32_t)min(c, w - 1))]; };
     const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2*sum_{x<r} srcp[x]
     const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
     for (int ch = 0; ch < nch; ++ch) {
         const int x0 = ch * CH + lane * V;
+        // chunks whose windows stay inside the row need no mirror terms (wave-uniform test)
+        const bool inner = ch * CH - R - 1 >= 0 && ch * CH + CH - 1 + R <= w - 1;
         if (x0 >= w) break;
         uint32_t o[V];
+        if (inner) {
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const int x = x0 + k;
-            // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
-            uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
-            if (x - R - 1 < -1) e += Q(R - x - 1);
-            if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
-            o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+            for (int k = 0; k < V; ++k) {
+                const uint32_t x = (uint32_t)(x0 + k);
+                const uint32_t e = P[pidx(x + (uint32_t)R)] - P[pidx(x - (uint32_t)R - 1u)];
+                o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int x = x0 + k;
+                // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
+                uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
+                if (x - R - 1 < -1) e += Q(R - x - 1);
+                if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
+                o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+            }
         }
         X::store(d + x0, o, min(V, w - x0));
     }
