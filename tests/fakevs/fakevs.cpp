@@ -6,6 +6,7 @@
 // It is built against the same VapourSynth4_min.h as the plugin (see that header's note).
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,7 +45,7 @@ struct PlaneBuf {
     ~PlaneBuf() { free(base); }
 };
 struct VSFrame {
-    int refs = 1;
+    std::atomic<int> refs{1};
     VSVideoFormat fmt;
     int w, h;
     std::shared_ptr<PlaneBuf> buf[3];
@@ -53,7 +54,7 @@ struct VSFrame {
     VSMap props;
 };
 struct VSNode {
-    int refs = 1;
+    std::atomic<int> refs{1};
     VSVideoInfo vi;
     std::vector<VSFrame *> frames;  // source node
     std::string name;

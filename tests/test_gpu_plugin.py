@@ -185,3 +185,40 @@ def test_eedi3_hp_mdis40_mclip_through_plugin(oracle):
         assert np.array_equal(out[p], oracle.eedi3(planes[p], 1, mclip=np.ascontiguousarray(mask[:h, :w])))
     with pytest.raises(vs.Error, match="mclip's dimensions don't match"):
         src.vszip.EEDI3(field=1, mclip=vs.source([[mask[:50]]], vs.GRAY8))
+
+
+def test_concurrent_get_frame_threads(oracle):
+    """fmParallel: VapourSynth calls getFrame from several worker threads at once. Eight threads pull
+    frames of a BoxBlur and a Bilateral clip concurrently (one context + slab per (thread, GPU) in
+    the plugin); every frame must equal the oracle's."""
+    import threading
+
+    frames = [[fx.splitmix64_plane(100 + 3 * n + p, s, np.uint16) for p, s in enumerate([(120, 200), (60, 100), (60, 100)])] for n in range(12)]
+    src = vs.source(frames, vs.YUV420P16)
+    blur = src.vszip.BoxBlur(hradius=5, vradius=5)
+    bil = src.vszip.Bilateral(sigmaS=1.0, sigmaR=0.05)
+    prm = oracle.bilateral_params([1.0], [0.05], yuv=True, ssw=1, ssh=1)
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(3):
+                for n in range(tid % 4, 12, 4):
+                    out = blur.get_frame(n)
+                    for p in range(3):
+                        if not np.array_equal(out[p], oracle.boxblur(frames[n][p], 5, 1, 5, 1)):
+                            errors.append(("boxblur", tid, n, p))
+                    out = bil.get_frame(n)
+                    for p in range(3):
+                        want = oracle.bilateral_plane(frames[n][p], prm["sigmaS"][p], prm["sigmaR"][p], prm["algorithm"][p], prm["radius"][p], prm["step"][p], prm["PBFICnum"][p])
+                        if not np.array_equal(out[p], want):
+                            errors.append(("bilateral", tid, n, p))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
