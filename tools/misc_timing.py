@@ -27,3 +27,16 @@ pf = [(p / 65535.0).astype(np.float32) for p in planes]
 srcs = [dev.upload(p) for p in pf]; dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in pf]
 t = timeit(lambda: dev.boxblur(srcs, dsts, 30, 1, 30, 1))
 print(f"BoxBlur RT float r=30 1080p YUV420PS: {1/t:.1f} fps ({t*1e3:.2f} ms/frame)")
+
+# BoxBlur r=13 on 4K YUV420P8 (8-bit video is the common case)
+import bench as _b
+shapes4k = _b.yuv420_shapes(3840, 2160)
+base8 = [(fx.splitmix64_plane(50 + p, s, np.uint16) >> 8).astype(np.uint8) for p, s in enumerate(shapes4k)]
+srcs, dsts = [], []
+for f in range(32):
+    for p in base8:
+        srcs.append(dev.upload(np.roll(p, f, 1))); dsts.append(dev.empty(p.shape[0], p.shape[1], np.uint8))
+table = dev.plane_table(srcs, dsts)
+t = timeit(lambda: dev.boxblur_table(np.uint8, table, 13, 1, 13, 1), n=20)
+fb = 2 * sum(p.nbytes for p in base8) * 32
+print(f"BoxBlur r=13 4K YUV420P8: {32/t:.0f} fps, {fb/t/1e9:.0f} GB/s = {fb/t/8e12:.3f} of peak")
