@@ -30,8 +30,9 @@ extern "C" {
 
 typedef struct vszip_ctx vszip_ctx;
 
-/* sample types: helper.zig:59-108 DataType (U32 is PlaneAverage-only and not offered) */
-enum vszip_dtype { VSZIP_U8 = 0, VSZIP_U16 = 1, VSZIP_F16 = 2, VSZIP_F32 = 3 };
+/* sample types: helper.zig:59-108 DataType. U32 is accepted by vszip_plane_average only, like in
+ * the reference (enable_u32, helper.zig:78), and without an exclude list (planeaverage.zig(vs):127). */
+enum vszip_dtype { VSZIP_U8 = 0, VSZIP_U16 = 1, VSZIP_F16 = 2, VSZIP_F32 = 3, VSZIP_U32 = 4 };
 
 enum vszip_status {
     VSZIP_OK = 0,

@@ -15,7 +15,7 @@ _DIR = Path(__file__).resolve().parent
 _LIB_PATH = _DIR / "liboracle_vszip.so"
 
 U8, U16, F16, F32 = 0, 1, 2, 3
-_NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.float16): F16, np.dtype(np.float32): F32}
+_NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.uint32): 4}
 
 
 def build(force: bool = False) -> Path:

@@ -18,7 +18,7 @@
 #include <vector>
 
 // dtype codes shared with include/vszip_hip.h
-enum { VSZO_U8 = 0, VSZO_U16 = 1, VSZO_F16 = 2, VSZO_F32 = 3 };
+enum { VSZO_U8 = 0, VSZO_U16 = 1, VSZO_F16 = 2, VSZO_F32 = 3, VSZO_U32 = 4 /* PlaneAverage only, helper.zig:78 */ };
 
 // IEEE binary16 storage type with explicit conversions (g++ 11 has no
 // _Float16 on x86). f32 -> f16 is round-to-nearest-even like Zig's @floatCast.
@@ -99,6 +99,11 @@ template <>
 struct px_traits<uint16_t> {
     static constexpr bool is_int = true;
     static inline float to_f32(uint16_t v) { return (float)v; }
+};
+template <>
+struct px_traits<uint32_t> {
+    static constexpr bool is_int = true;
+    static inline float to_f32(uint32_t v) { return (float)v; }
 };
 template <>
 struct px_traits<float> {

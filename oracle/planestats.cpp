@@ -178,6 +178,10 @@ VSZO_API int vszo_plane_average(int dtype, const void* src, const void* ref, ptr
         case VSZO_U16: plane_average<uint16_t>((const uint16_t*)src, (const uint16_t*)ref, sstride, rstride, w, h, excl, nexcl, peak, avg, diff); return 0;
         case VSZO_F16: plane_average<half_t>((const half_t*)src, (const half_t*)ref, sstride, rstride, w, h, excl, nexcl, peak, avg, diff); return 0;
         case VSZO_F32: plane_average<float>((const float*)src, (const float*)ref, sstride, rstride, w, h, excl, nexcl, peak, avg, diff); return 0;
+        case VSZO_U32:  // planeaverage.zig(vs):127 rejects exclude for 32-bit integer clips
+            if (nexcl > 0) return -1;
+            plane_average<uint32_t>((const uint32_t*)src, (const uint32_t*)ref, sstride, rstride, w, h, excl, 0, peak, avg, diff);
+            return 0;
     }
     return -1;
 }

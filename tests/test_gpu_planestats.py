@@ -81,3 +81,19 @@ def test_known_answers(dev):
     p[:8, :] = 0
     dp = dev.upload(p)
     assert (dev.plane_minmax([dp], 0.2, 0.0)[0][0], dev.plane_minmax([dp], 0.3, 0.0)[0][0]) == (0, 200)
+
+
+def test_average_u32(dev, oracle):
+    """32-bit integer clips: PlaneAverage only, no exclude list (planeaverage.zig(vs):127)."""
+    import vszip_amd
+
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 2**32, size=(67, 131), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, size=(67, 131), dtype=np.uint64).astype(np.uint32)
+    avg, diff = dev.plane_average([dev.upload(a)], refs=[dev.upload(b)])
+    oa, od = oracle.plane_average(a, ref=b)
+    assert (avg[0], diff[0]) == (oa, od)
+    full = np.full((5, 9), 0xFFFFFFFF, np.uint32)
+    assert dev.plane_average([dev.upload(full)])[0][0] == oracle.plane_average(full)[0]
+    with pytest.raises(vszip_amd.VszipError, match="exclude is not supported"):
+        dev.plane_average([dev.upload(a)], exclude=[3])

@@ -16,7 +16,7 @@ LIB_PATH = PKG / "libvszip_hip.so"
 
 U8, U16, F16, F32 = 0, 1, 2, 3
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4
-_NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.float16): F16, np.dtype(np.float32): F32}
+_NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.uint32): 4}
 _DT2NP = {v: k for k, v in _NP2DT.items()}
 
 

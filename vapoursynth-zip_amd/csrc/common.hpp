@@ -58,6 +58,7 @@ static inline int vszip_dtype_size(int dt) {
         case VSZIP_U16: return 2;
         case VSZIP_F16: return 2;
         case VSZIP_F32: return 4;
+        case VSZIP_U32: return 4;
     }
     return 0;
 }

@@ -65,6 +65,13 @@ __device__ __forceinline__ uint32_t float_bin(float v) {
     return (t != t) ? 0u : (t <= 0.0f ? 0u : (t >= 65535.0f ? 65535u : (uint32_t)t));
 }
 template <>
+struct Smp<uint32_t> {  // PlaneAverage only
+    static constexpr bool is_int = true;
+    using Acc = uint64_t;
+    static __device__ __forceinline__ uint32_t idx(uint32_t v) { return v; }
+    static __device__ __forceinline__ float f(uint32_t v) { return (float)v; }
+};
+template <>
 struct Smp<float> {
     static constexpr bool is_int = false;
     using Acc = double;
@@ -580,6 +587,10 @@ VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plan
         case VSZIP_U16: rc = run_average<uint16_t>(ctx, L, ref); break;
         case VSZIP_F16: rc = run_average<_Float16>(ctx, L, ref); break;
         case VSZIP_F32: rc = run_average<float>(ctx, L, ref); break;
+        case VSZIP_U32:
+            if (nexclude > 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneAverage: exclude is not supported for 32-bit integer clips.");
+            rc = run_average<uint32_t>(ctx, L, ref);
+            break;
         default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneAverage: not supported Int format.");
     }
     if (rc != VSZIP_OK) return rc;

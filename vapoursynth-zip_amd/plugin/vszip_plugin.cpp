@@ -176,7 +176,7 @@ bool select_dtype(const Z &z, VSMap *out, VSNode *node, const VSVideoInfo *vi, c
         else if (f.bytesPerSample == 2)
             *dt = VSZIP_U16;
         else if (f.bytesPerSample == 4 && enable_u32)
-            *dt = 100;  // U32: PlaneAverage only
+            *dt = VSZIP_U32;  // PlaneAverage only
         else
             msg = "not supported Int format.";
     } else {
@@ -667,7 +667,7 @@ void plane_stat_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *a
     } else {
         d->key_a = pfx + "Avg";
         const int ne = std::max(0, api->mapNumElements(in, "exclude"));
-        if (d->dt == 100) return bail(ne > 0 ? "PlaneAverage: exclude is not supported for 32-bit integer clips." : "PlaneAverage: 32-bit integer clips are not available in the MI355X build yet");
+        if (d->dt == VSZIP_U32 && ne > 0) return bail("PlaneAverage: exclude is not supported for 32-bit integer clips.");
         if (ne > 8) return bail("PlaneAverage: more than 8 exclude values are not available in the MI355X build yet");
         for (int i = 0; i < ne; ++i) {
             const int64_t v = z.getInt(in, "exclude", 0, i);
