@@ -29,7 +29,6 @@ namespace {
 
 constexpr int kMaxMdis = 31;
 constexpr int kXB = 64;         // columns per block
-constexpr int kTbMax = 64 + 4 * kMaxMdis + 2 * 3 + 8;
 constexpr int kMaxPlanesE = 48;  // planes per call (16 YUV frames): the per-plane vcheck chains run side by side
 
 struct EPlane {
@@ -87,19 +86,26 @@ __device__ __forceinline__ float lane_above(float v, float edge) {
 }
 
 constexpr int kU = 4;  // directions per cost pass
-constexpr int kRowW = kXB + 2 * (2 * kMaxMdis + 3);  // staged columns per source row: block + reach 2*mdis + nrad each side
-
-// NRAD is a template parameter so that the window-sum loop unrolls: with a runtime trip count
-// its LDS reads are issued one per iteration and each waits out the full LDS latency.
-template <int NRAD>
+// NRAD is a template parameter so that the window-sum loop unrolls (with a runtime trip count
+// its LDS reads are issued one per iteration and each waits out the full LDS latency); MD is the
+// largest mdis the instantiation serves (20: the default and below, 31: one DP state per lane) and
+// sizes the LDS arrays — the default geometry takes 20 KiB per wave instead of 29, i.e. 7 instead of
+// 5 waves per CU, and the kernel is latency bound.
+template <int NRAD, int MD>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
+    constexpr int kRowW = kXB + 2 * (2 * MD + 3) + 16;  // staged columns per source row: block + reach 2*mdis + nrad each side (+16: see the cost phase)
+    constexpr int kTbW = kXB + 2 * MD + 2 * 3 + 8;      // longest t_base span
+    constexpr int kPtW = (2 * MD + 1 + 3) & ~3;
     const float kFltMax09 = FLT_MAX * 0.9f;
-    __shared__ float rows[4][kRowW + 16];  // r3p, r1p, r1n, r3n around the block, mirror padding applied (+16: see the cost phase)
-    __shared__ float tb[kU][kTbMax];  // t_base of the kU directions of the current pass
-    __shared__ float ws[kU][kTbMax];  // their (2*nrad+1)-tap window sums
-    __shared__ float ctile[2 * kMaxMdis + 1][kXB + 1];
-    __shared__ int8_t ptile[kXB][64];
+    __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
+    __shared__ float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
+    __shared__ float ctile[2 * MD + 1][kXB + 1];
     __shared__ int fpt[kXB];
+    float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[1];
+    // the back-pointer tile lives in the same LDS as tb/ws: those are dead once a block's costs
+    // are in ctile, and every phase change is fenced (fewer bytes per wave = more waves per CU)
+    static_assert(sizeof(tbws) >= (size_t)kXB * kPtW, "back-pointer tile must fit the t_base scratch");
+    int8_t (*ptile)[kPtW] = reinterpret_cast<int8_t (*)[kPtW]>(&tbws[0][0][0]);
 
     int pi = 0;
     const int gl = blockIdx.x;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             // back-pointer of column xx-1 (:472): stored at the tile row of xx-1
             if (xl == 0) {
                 if (lane < tpitch) pback[(size_t)(xx - 1) * tpitch + lane] = (int8_t)bd;  // last row of the previous block
-            } else {
+            } else if (lane < tpitch) {  // a tile row is only as wide as the directions in use
                 ptile[xl - 1][lane] = (int8_t)bd;
             }
         }
@@ -1021,12 +1027,21 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
             default: launch_general<3>(ctx, hp, (unsigned)lines, ep, gx); break;
         }
     } else {
+        const dim3 lgrid((unsigned)lines), lblock(64);
+#define VSZIP_E3_LAUNCH(N)                                                                        \
+    do {                                                                                          \
+        if (up->mdis <= 20)                                                                       \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20>), lgrid, lblock, 0, ctx->stream, ep);    \
+        else                                                                                      \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, kMaxMdis>), lgrid, lblock, 0, ctx->stream, ep); \
+    } while (0)
         switch (up->nrad) {
-            case 0: hipLaunchKernelGGL(eedi3_line_kernel<0>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
-            case 1: hipLaunchKernelGGL(eedi3_line_kernel<1>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
-            case 2: hipLaunchKernelGGL(eedi3_line_kernel<2>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
-            default: hipLaunchKernelGGL(eedi3_line_kernel<3>, dim3((unsigned)lines), dim3(64), 0, ctx->stream, ep); break;
+            case 0: VSZIP_E3_LAUNCH(0); break;
+            case 1: VSZIP_E3_LAUNCH(1); break;
+            case 2: VSZIP_E3_LAUNCH(2); break;
+            default: VSZIP_E3_LAUNCH(3); break;
         }
+#undef VSZIP_E3_LAUNCH
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (up->vcheck > 0) {
