@@ -166,3 +166,16 @@ def test_xpsnr_random(dev, oracle, seed):
         got = dev.xpsnr_wsse(dfr[n], drc[n], p1, p2, depth=depth, frame_rate=fps)
         want = oracle.xpsnr_wsse(frames[n], recs[n], frames[n - 1][0] if n >= 1 else None, frames[n - 2][0] if n >= 2 else None, depth=depth, frame_rate=fps)
         assert got == want, (seed, n, h, w, fps)
+
+
+def test_boxblur_rt_huge_radius(dev, oracle):
+    """A horizontal radius beyond one 512-column chunk takes the whole-row-prefix kernel instead of
+    the ring one; a vertical radius larger than the band heuristic's minimum."""
+    p = fx.splitmix64_plane(12, (700, 1400), np.uint16)
+    s, d = dev.upload(p), dev.empty(700, 1400, np.uint16)
+    dev.boxblur([s], [d], 600, 1, 300, 2)
+    assert np.array_equal(dev.download(d), oracle.boxblur(p, 600, 1, 300, 2))
+    p8 = (fx.splitmix64_plane(13, (64, 2300), np.uint16) >> 8).astype(np.uint8)
+    s, d = dev.upload(p8), dev.empty(64, 2300, np.uint8)
+    dev.boxblur([s], [d], 1030, 1, 0, 0)
+    assert np.array_equal(dev.download(d), oracle.boxblur(p8, 1030, 1, 0, 0))

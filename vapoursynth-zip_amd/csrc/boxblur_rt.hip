@@ -10,6 +10,7 @@
 //     depends on the visiting order, so every row (horizontal) / column (vertical) is walked
 //     sequentially by one thread in exactly the reference's order: bit-identical, at the price
 //     of parallelism = rows (columns) x planes. This path is not on any headline config.
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -308,6 +309,90 @@ __global__ __launch_bounds__(64) void boxblur_rt_hrow_kernel(const RParams prm) 
     }
 }
 
+
+// Horizontal, single pass (radius < one chunk of 64 * V columns): the prefix lives in a ring of
+// three chunks in LDS instead of the whole row — 6 KiB (u16) per wave instead of 4 bytes per
+// column, so 3x the waves per CU — and the row is read once: chunk c+1 is prefixed while chunk c
+// is emitted from the chunks c-1, c, c+1 that its windows (and the mirror terms at the row ends)
+// can reach.
+template <typename T>
+__global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm) {
+    using X = RtVec<T>;
+    constexpr int V = X::V, CH = 64 * V;
+    __shared__ __attribute__((aligned(16))) uint32_t P[3 * CH];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int y = b - pl.block0;
+    const int w = pl.w, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
+    const int lane = threadIdx.x;
+    const int nch = (w + CH - 1) / CH;
+    auto pidx = [&](uint32_t c) { return ((c / (uint32_t)CH) % 3u) * (uint32_t)CH + (c % (uint32_t)V) * 64u + (c % (uint32_t)CH) / (uint32_t)V; };
+    uint32_t carry = 0;
+    auto prefix_chunk = [&](int ch) {
+        const int x0 = ch * CH + lane * V;
+        uint32_t v[V];
+        if (x0 < w) {
+            X::load(s + x0, v);  // [w, stride) is readable padding; masked below
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (x0 + k >= w) v[k] = 0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = 0;
+        }
+#pragma unroll
+        for (int k = 1; k < V; ++k) v[k] += v[k - 1];
+        const uint32_t incl = wave_incl_scan_dpp(v[V - 1]);
+        const uint32_t base = carry + incl - v[V - 1];
+        uint32_t *slot = P + (ch % 3) * CH;
+#pragma unroll
+        for (int k = 0; k < V; ++k) slot[k * 64 + lane] = v[k] + base;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    };
+    prefix_chunk(0);
+    if (nch > 1) prefix_chunk(1);
+    vszip_wave_fence();
+    const uint32_t ksize = 2u * (uint32_t)R + 1u;
+    const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : P[pidx((uint32_t)min(c, w - 1))]; };
+    const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2*sum_{x<r} srcp[x]; r < CH: chunks 0 / 1
+    const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch >= 1 && ch + 1 < nch) {  // chunk ch+1 replaces chunk ch-2, which no window reaches any more
+            prefix_chunk(ch + 1);
+            vszip_wave_fence();
+        }
+        const int x0 = ch * CH + lane * V;
+        const bool inner = ch * CH - R - 1 >= 0 && ch * CH + CH - 1 + R <= w - 1;
+        if (x0 < w) {
+            uint32_t o[V];
+            if (inner) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const uint32_t x = (uint32_t)(x0 + k);
+                    const uint32_t e = P[pidx(x + (uint32_t)R)] - P[pidx(x - (uint32_t)R - 1u)];
+                    o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const int x = x0 + k;
+                    // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
+                    uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
+                    if (x - R - 1 < -1) e += Q(R - x - 1);
+                    if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
+                    o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+                }
+            }
+            X::store(d + x0, o, min(V, w - x0));
+        }
+        vszip_wave_fence();  // the next iteration overwrites a ring slot
+    }
+}
+
 // ---- RT float: blurFloat verbatim (:43-79), one thread per line ------------------------------
 template <typename T>
 __device__ __forceinline__ void blur_float_line(const T *s, size_t ss, T *d, size_t ds, int len, int R) {
@@ -373,8 +458,12 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
             }
             if (aligned && !vertical) {
                 constexpr int CH = 64 * RtVec<T>::V;
-                const size_t lds = (size_t)((maxw + CH - 1) / CH) * CH * sizeof(uint32_t);
-                hipLaunchKernelGGL((boxblur_rt_hrow_kernel<T>), dim3(blocks), dim3(64), lds, ctx->stream, prm);
+                if (radius < CH - 1 && !getenv("VSZIP_RT_HROW")) {
+                    hipLaunchKernelGGL((boxblur_rt_hring_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+                } else {
+                    const size_t lds = (size_t)((maxw + CH - 1) / CH) * CH * sizeof(uint32_t);
+                    hipLaunchKernelGGL((boxblur_rt_hrow_kernel<T>), dim3(blocks), dim3(64), lds, ctx->stream, prm);
+                }
             } else if (aligned) {
                 RVParams vp;
                 vp.nplanes = n;

@@ -89,6 +89,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan_shfl(uint32_t v) {
     return v;
 }
 
+// Orders LDS traffic between the lanes of ONE wave (single-wave workgroups): no s_barrier, no
+// vmcnt drain.
+__device__ __forceinline__ void vszip_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {
 #pragma unroll
