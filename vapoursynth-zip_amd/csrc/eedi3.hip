@@ -21,6 +21,7 @@
 // All f32 arithmetic is unfused and in the reference's operation order: results are
 // bit-identical to the CPU oracle (the discrete path makes anything less visible).
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -828,6 +829,151 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_kernel(const VParams prm) {
     }
 }
 
+// vcheckLine for lines of at most 1920 columns, rows in LDS. The kernel above sends every load
+// of a plane through one CU's memory pipeline (32 gather instructions per thread and line), and
+// that pipeline, not the chain's latency, sets its pace. Consecutive lines share five of the seven
+// dst rows they touch (pd-3 .. pd+3; the +-3 rows are the kept field lines the reference reads
+// from `src`), so the rows live in a 7-slot LDS ring (row r -> slot r mod 7) next to a 4-slot int8
+// ring of direction-map rows: a line loads two new rows and one map row with coalesced loads and
+// gathers from LDS; the blended line is written back into its ring slot, where the next line
+// finds it as d2p.
+__device__ __forceinline__ float vcheck_pixel(const VParams &prm, int L, int i, int dirc, int dirt, int dirb, float cint, const float *d1p, const float *d1n,
+                                              const float *dl, const float *d2p, const float *d2n) {
+    if (dirc == 0) return cint;
+    if (max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) return cint;
+    const bool hp = prm.hp != 0;
+    const int maxoff = !hp ? abs(dirc) : (((dirc & 1) == 0) ? abs(dirc >> 1) : max(abs(dirc >> 1), abs((dirc + 1) >> 1)));
+    if (i + maxoff >= L || i - maxoff < 0) return cint;
+    float it, ib, vt, vb;
+    int dabs;
+    if (hp && (dirc & 1) != 0) {  // :969-985
+        const int d20 = dirc >> 1, d21 = (dirc + 1) >> 1;
+        const int ip0 = i + d20, ip1 = i + d21, im0 = i - d20, im1 = i - d21;
+        const float s2p = d2p[ip0] + d2p[ip1], s1p = d1p[ip0] + d1p[ip1], pa0 = dl[ip0] + dl[ip1], ps0 = dl[im0] + dl[im1];
+        const float s1n = d1n[im0] + d1n[im1], s2n = d2n[im0] + d2n[im1];
+        it = (s2p + ps0) * 0.25f;
+        vt = (fabsf(s2p - s1p) + fabsf(pa0 - s1p)) * 0.5f;
+        ib = (pa0 + s2n) * 0.25f;
+        vb = (fabsf(s2n - s1n) + fabsf(ps0 - s1n)) * 0.5f;
+        dabs = abs(dirc) >> 1;
+    } else {
+        const int offh = hp ? dirc >> 1 : dirc;
+        const int ipd = i + offh, imd = i - offh;
+        it = (d2p[ipd] + dl[imd]) * 0.5f;
+        ib = (dl[ipd] + d2n[imd]) * 0.5f;
+        vt = fabsf(d2p[ipd] - d1p[ipd]) + fabsf(dl[ipd] - d1p[ipd]);
+        vb = fabsf(d2n[imd] - d1n[imd]) + fabsf(dl[imd] - d1n[imd]);
+        dabs = hp ? abs(dirc) >> 1 : abs(dirc);
+    }
+    const float vc = fabsf(dl[i] - d1p[i]) + fabsf(dl[i] - d1n[i]);
+    const float e0 = fabsf(it - d1p[i]), e1 = fabsf(ib - d1n[i]), e2 = fabsf(vt - vc), e3 = fabsf(vb - vc);
+    float m0, m1;
+    if (prm.vcheck == 1) {
+        m0 = fminf(e0, e1);
+        m1 = fminf(e2, e3);
+    } else if (prm.vcheck == 2) {
+        m0 = (e0 + e1) * 0.5f;
+        m1 = (e2 + e3) * 0.5f;
+    } else {
+        m0 = fmaxf(e0, e1);
+        m1 = fmaxf(e2, e3);
+    }
+    const float a0 = m0 * prm.rcp0, a1 = m1 * prm.rcp1;
+    const float a2 = fmaxf((prm.vthresh2 - (float)dabs) * prm.rcp2, 0.0f);
+    const float a = fminf(fmaxf(a0, fmaxf(a1, a2)), 1.0f);
+    return (1.0f - a) * dl[i] + a * cint;
+}
+
+constexpr int kVcLdsMaxL = 1920;
+
+__global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams prm) {
+    constexpr int C = 2;  // columns per thread: lines up to 2048 (LDS allows 1920)
+    extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
+    const EPlane pl = prm.p[blockIdx.x];
+    const float *scp = prm.scp[blockIdx.x];
+    const int scstride = prm.scstride[blockIdx.x];
+    const int L = pl.w, n_dst = pl.n_dst;
+    const int tid = threadIdx.x;
+    float *ring = reinterpret_cast<float *>(vsm);
+    int8_t *dring = reinterpret_cast<int8_t *>(ring + (size_t)7 * L);
+    auto row = [&](int r) -> float * { return ring + (size_t)(r % 7) * L; };
+    auto dmr = [&](int o) -> int8_t * { return dring + (size_t)(o & 3) * L; };
+    // processed lines form one contiguous range of interpolated-line indices (:921-925)
+    int first = 1, last = pl.n_interp - 2;
+    while (first <= last && prm.field + 2 * first < 2) ++first;
+    while (last >= first && prm.field + 2 * last + 2 >= n_dst) --last;
+    if (first > last) return;
+    {
+        const int pd0 = prm.field + 2 * first;
+        for (int r = pd0 - 3; r <= pd0 + 3; ++r) {
+            if (r < 0 || r >= n_dst) continue;
+            const float *g = pl.dst + (size_t)r * pl.dstride;
+            float *d = row(r);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (tid + c * 1024 < L) d[tid + c * 1024] = g[tid + c * 1024];
+        }
+        for (int o = first - 1; o <= first + 1; ++o) {
+            const int *g = pl.dmap + (size_t)o * L;
+            int8_t *d = dmr(o);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (tid + c * 1024 < L) d[tid + c * 1024] = (int8_t)g[tid + c * 1024];
+        }
+    }
+    __syncthreads();
+    for (int off = first; off <= last; ++off) {
+        const int pd = prm.field + 2 * off;
+        const bool nxt = off + 1 <= last;
+        // the next line's two new rows and map row: coalesced loads, parked in registers
+        float n4[C], n5[C], sc[C];
+        int nd[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = tid + c * 1024;
+            n4[c] = n5[c] = sc[c] = 0.0f;
+            nd[c] = 0;
+            if (i < L) {
+                if (nxt) {
+                    if (pd + 4 < n_dst) n4[c] = pl.dst[(size_t)(pd + 4) * pl.dstride + i];
+                    if (pd + 5 < n_dst) n5[c] = pl.dst[(size_t)(pd + 5) * pl.dstride + i];
+                    nd[c] = pl.dmap[(size_t)(off + 2) * L + i];
+                }
+                if (scp) sc[c] = scp[(size_t)pd * scstride + i];
+            }
+        }
+        const float *d1p = row(pd - 1), *d1n = row(pd + 1), *dl = row(pd), *d2p = row(pd - 2), *d2n = row(pd + 2);
+        const float *d3p = row(reflect_row(pd - 3, n_dst)), *d3n = row(reflect_row(pd + 3, n_dst));
+        const int8_t *dc = dmr(off), *dp = dmr(off - 1), *dn = dmr(off + 1);
+        float res[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = tid + c * 1024;
+            if (i < L) {
+                const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
+                res[c] = vcheck_pixel(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
+            }
+        }
+        __syncthreads();  // every read of the un-blended line pd is done
+        float *dlw = row(pd);
+        float *gout = pl.dst + (size_t)pd * pl.dstride;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int i = tid + c * 1024;
+            if (i < L) {
+                dlw[i] = res[c];
+                gout[i] = res[c];
+                if (nxt) {
+                    if (pd + 4 < n_dst) row(pd + 4)[i] = n4[c];
+                    if (pd + 5 < n_dst) row(pd + 5)[i] = n5[c];
+                    dmr(off + 2)[i] = (int8_t)nd[c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 constexpr int kTT = 32;
 __global__ void transpose_kernel(const float *src, float *dst, int sstride, int dstride, int w, int h) {
     __shared__ float t[kTT][kTT + 1];
@@ -1047,7 +1193,12 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
     if (up->vcheck > 0) {
         for (int i = 0; i < nplanes; ++i)
             if (geo[i].L > 4096) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: vcheck on lines longer than 4096 not built yet", name);
-        hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
+        int maxL = 0;
+        for (int i = 0; i < nplanes; ++i) maxL = std::max(maxL, geo[i].L);
+        if (maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL"))
+            hipLaunchKernelGGL(eedi3_vcheck_lds_kernel, dim3(nplanes), dim3(1024), (size_t)maxL * (7 * sizeof(float) + 4), ctx->stream, vp);
+        else
+            hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (horizontal) {
