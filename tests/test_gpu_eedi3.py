@@ -119,3 +119,13 @@ def test_errors(dev):
     odd = dev.upload(np.zeros((63, 128), np.float32))
     with pytest.raises(vszip_amd.VszipError, match="height must be mod 2"):
         dev.eedi3([odd], 1)
+
+
+@pytest.mark.parametrize("w", [4097, 7680])
+def test_vcheck_on_wide_lines(dev, oracle, w):
+    """Lines wider than the pipelined vcheck kernels serve (8K frames) take the wide-line kernel."""
+    rng = np.random.default_rng(w)
+    src = rng.random((16, w)).astype(np.float32)
+    for kw in (dict(vcheck=2), dict(vcheck=3, dh=True)):
+        got = _gpu(dev, src, 1, **kw)
+        assert np.array_equal(got, oracle.eedi3(src, 1, **kw)), kw

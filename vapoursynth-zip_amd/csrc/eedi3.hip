@@ -884,6 +884,59 @@ __device__ __forceinline__ float vcheck_pixel(const VParams &prm, int L, int i, 
     return (1.0f - a) * dl[i] + a * cint;
 }
 
+// vcheckLine for very wide lines (4096 < L <= 8192, e.g. 8K frames): the chain without any
+// cross-line pipelining — every line prepares and resolves its pixels in column chunks of 1024,
+// the blended line is handed on through (dynamic) LDS. Correct first; not tuned.
+__global__ __launch_bounds__(1024) void eedi3_vcheck_wide_kernel(const VParams prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
+    const EPlane pl = prm.p[blockIdx.x];
+    const float *scp = prm.scp[blockIdx.x];
+    const int scstride = prm.scstride[blockIdx.x];
+    const int L = pl.w;
+    const int tid = threadIdx.x;
+    float *prevl[2] = {reinterpret_cast<float *>(vsm), reinterpret_cast<float *>(vsm) + L};
+    int cur = 0;
+    bool have_prev = false;
+    for (int off = 1; off + 1 < pl.n_interp; ++off) {
+        const int pd = prm.field + 2 * off;
+        if (pd < 2 || pd + 2 >= pl.n_dst) {
+            have_prev = false;
+            continue;
+        }
+        float *dl = pl.dst + (size_t)pd * pl.dstride;
+        if (!have_prev) {
+            const float *d2p = pl.dst + (size_t)(pd - 2) * pl.dstride;
+            for (int i = tid; i < L; i += 1024) prevl[cur][i] = d2p[i];
+            __syncthreads();
+        }
+        for (int i0 = 0; i0 < L; i0 += 4096) {  // results of a chunk go to the other buffer and to memory only after
+            float res[4];                       // every pixel of the chunk has read the un-blended line around it
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = i0 + tid + c * 1024;
+                if (i < L) {
+                    VcPre q;
+                    vcheck_prepare(pl, prm, scp, scstride, off, i, q);
+                    res[c] = vcheck_resolve(prm, q, prevl[cur]);
+                }
+            }
+            // a pixel gathers dl[] up to mdis columns away, possibly across the chunk boundary: the
+            // writes of this chunk wait until the whole line has been computed (tline in the reference)
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = i0 + tid + c * 1024;
+                if (i < L) prevl[cur ^ 1][i] = res[c];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < L; i += 1024) dl[i] = prevl[cur ^ 1][i];  // memcpy(dl, tline) :1044
+        __syncthreads();
+        cur ^= 1;
+        have_prev = true;
+    }
+}
+
 constexpr int kVcLdsMaxL = 1920;
 
 __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams prm) {
@@ -1192,13 +1245,15 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (up->vcheck > 0) {
         for (int i = 0; i < nplanes; ++i)
-            if (geo[i].L > 4096) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: vcheck on lines longer than 4096 not built yet", name);
+            if (geo[i].L > 8192) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: vcheck on lines longer than 8192 not built yet", name);
         int maxL = 0;
         for (int i = 0; i < nplanes; ++i) maxL = std::max(maxL, geo[i].L);
         if (maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL"))
             hipLaunchKernelGGL(eedi3_vcheck_lds_kernel, dim3(nplanes), dim3(1024), (size_t)maxL * (7 * sizeof(float) + 4), ctx->stream, vp);
-        else
+        else if (maxL <= 4096)
             hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
+        else
+            hipLaunchKernelGGL(eedi3_vcheck_wide_kernel, dim3(nplanes), dim3(1024), (size_t)maxL * 2 * sizeof(float), ctx->stream, vp);
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (horizontal) {
