@@ -364,39 +364,64 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const PSParams prm) {
 
 // After level 0: locate the buckets (planeminmax.zig:43-57: count > trunc(total * thr)
 // scanning up from 0 for the minimum, down from the peak for the maximum).
-__global__ void bucket_kernel(const PSParams prm, int wide) {
+// One wave per plane: the 256-bin table is scanned with a wave prefix sum (4 bins per lane) instead
+// of a serial loop; "first bin whose running count exceeds the threshold" = the lowest lane/bin
+// whose inclusive prefix does.
+__device__ __forceinline__ void scan_bins(const uint32_t *g, int nb, bool from_top, uint32_t thr, uint32_t *bucket, uint32_t *below) {
+    // lane l owns bins 4l..4l+3 in scan order (ascending, or descending from nb-1)
+    const int lane = threadIdx.x;
+    uint32_t v[4], loc[4];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = lane * 4 + k;
+        const int bin = from_top ? nb - 1 - idx : idx;
+        v[k] = idx < nb ? g[bin] : 0u;
+        run += v[k];
+        loc[k] = run;
+    }
+    const uint32_t incl = wave_incl_scan_shfl(run);
+    const uint32_t base = incl - run;
+    // first scan position whose inclusive count exceeds thr
+    int pos = 1 << 30;
+#pragma unroll
+    for (int k = 3; k >= 0; --k)
+        if (lane * 4 + k < nb && base + loc[k] > thr) pos = lane * 4 + k;
+    for (int d = 32; d >= 1; d >>= 1) pos = min(pos, __shfl_xor(pos, d, 64));
+    const uint32_t tot = __shfl(incl, 63, 64);
+    if (pos == (1 << 30)) {  // wave-uniform: no bin qualifies
+        if (lane == 0) {
+            *bucket = 0xffffffffu;
+            *below = tot;
+        }
+        return;
+    }
+    // count of the bins before `pos` in scan order
+    const int pl = pos >> 2, pk = pos & 3;
+    const uint32_t bl = __shfl(base, pl, 64);
+    const uint32_t l0 = __shfl(loc[0], pl, 64), l1 = __shfl(loc[1], pl, 64), l2 = __shfl(loc[2], pl, 64);
+    const uint32_t before = bl + (pk == 0 ? 0u : (pk == 1 ? l0 : (pk == 2 ? l1 : l2)));
+    if (lane == 0) {
+        *bucket = (uint32_t)(from_top ? nb - 1 - pos : pos);
+        *below = before;
+    }
+}
+
+__global__ __launch_bounds__(64) void bucket_kernel(const PSParams prm, int wide) {
     const int pi = blockIdx.x;
-    if (threadIdx.x != 0) return;
     const PSPlane pl = prm.p[pi];
     uint32_t *g = prm.hist + (size_t)pi * 512;
     const double total = (double)((uint32_t)pl.w * (uint32_t)pl.h);
     const uint32_t totalmin = (uint32_t)trunc(total * (double)prm.minthr);
     const uint32_t totalmax = (uint32_t)trunc(total * (double)prm.maxthr);
-    const int nb = wide ? (prm.hist_size >> 8) : prm.hist_size;
+    const int nb = wide ? (prm.hist_size >> 8) : prm.hist_size;  // <= 256
     uint32_t *bk = prm.bucket + pi * 8;
-    uint32_t count = 0;
-    int lo = -1;
-    for (int u = 0; u < nb; ++u) {
-        if (count + g[u] > totalmin) {
-            lo = u;
-            break;
-        }
-        count += g[u];
-    }
-    bk[0] = lo < 0 ? 0xffffffffu : (uint32_t)lo;
-    bk[1] = count;
-    count = 0;
-    int hi = -1;
-    for (int u = nb - 1; u >= 0; --u) {
-        if (count + g[u] > totalmax) {
-            hi = u;
-            break;
-        }
-        count += g[u];
-    }
-    bk[2] = hi < 0 ? 0xffffffffu : (uint32_t)hi;
-    bk[3] = count;
-    for (int u = 0; u < 512; ++u) g[u] = wide ? 0u : g[u];  // level 1 reuses the table
+    // planeminmax.zig:43-57: count > trunc(total * thr), scanning up from 0 / down from the peak
+    scan_bins(g, nb, false, totalmin, &bk[0], &bk[1]);
+    scan_bins(g, nb, true, totalmax, &bk[2], &bk[3]);
+    __syncthreads();
+    if (wide)
+        for (int u = threadIdx.x; u < 512; u += 64) g[u] = 0u;  // level 1 reuses the table
 }
 
 __global__ __launch_bounds__(64) void thr_final_kernel(const PSParams prm, int wide, int is_int) {
