@@ -159,7 +159,9 @@ struct RtVec {
                 else
                     d[k >> 2] |= v[k] << ((k & 3) * 8);
             }
-            *reinterpret_cast<uint4 *>(p) = make_uint4(d[0], d[1], d[2], d[3]);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 q = {d[0], d[1], d[2], d[3]};
+            __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(p));  // streamed output: keep it out of L2
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k)
