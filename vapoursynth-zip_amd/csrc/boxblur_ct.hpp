@@ -38,6 +38,7 @@
 //   boxblur_ct_int_kernel   (any alignment / stride): window rows re-read from
 //     cache, first lanes own columns [0, r] for E_0.
 #pragma once
+#include <cmath>
 #include <cstdlib>
 #include <utility>
 
@@ -828,25 +829,48 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             const vszip_plane &s = planes[done + i];
             mult8 = mult8 && (s.w % PX == 0);
         }
-        // Band length. The kernel is HBM-bound once most wave slots are filled (measured:
-        // tools/membw.hip, tools/sweep_periods.sh), so take the longest bands (fewest re-read halo rows: 2r+D per
-        // band) that still leave that many waves; every plane is cut into bands of about
-        // `target` ring periods so that all waves run about equally long.
-        // a shifted-up last band must fit the plane: two bands at least when h is not whole periods
+        // Band length: every plane is cut into bands of about `target` ring periods. The choice
+        // trades re-read halo rows (2r+D per band: shorter bands = more traffic) against how well
+        // the waves fill the chip's wave slots over time: with W waves of up to max_len periods
+        // running in ceil(W / slots) generations, the fraction of slot-time doing work is
+        //     eff = total_work / (slots * generations * max_len),
+        // and measured launch times follow  total_work * (1 + 0.3 * (1 - eff))  within a few percent
+        // (tools/sweep_periods.sh: e.g. 64 4K frames — 19 periods: 4+2 equal bands, 3072 waves =
+        // every slot, 603 us; 26: 635 us; 16: 1.17 generations, 710 us; 39: half the slots, 694 us).
         auto bands_for = [](int h, int P, int target) { return std::max((h % G::NR != 0 && P >= 2) ? 2 : 1, (P + target / 2) / target); };
-        auto waves_for = [&](int target) {
-            long wv = 0;
+        const double halo_p = (double)(2 * R + G::D) / G::NR;  // warm-up rows of a band, in periods
+        const double slots = 256.0 * 4 * G::WPE;
+        double waves_out = 0;
+        auto cost_for = [&](int target) {
+            double work = 0, waves = 0, max_len = 0;
             for (int i = 0; i < n; ++i) {
                 const vszip_plane &s = planes[done + i];
                 const int P = (s.h + G::NR - 1) / G::NR;
-                wv += (long)((s.w + G::TWO - 1) / G::TWO) * bands_for(s.h, P, target);
+                const int nb = bands_for(s.h, P, target);
+                const double ntx = (double)((s.w + G::TWO - 1) / G::TWO);
+                work += ntx * (P + nb * halo_p);
+                waves += ntx * nb;
+                max_len = std::max(max_len, (double)((P + nb - 1) / nb) + halo_p);
             }
-            return wv;
+            waves_out = waves;
+            const double gens = std::ceil(waves / slots);
+            const double eff = std::min(1.0, work / (slots * gens * max_len));
+            // a launch that cannot fill the chip ends with its longest wave (a lone wave steps about
+            // three times as fast as one of a full chip): small inputs get many short bands
+            return std::max(work / slots * (1.0 + 0.3 * (1.0 - eff)), 0.3 * max_len);
         };
-        const long min_waves = 256L * 4 * G::WPE * 3 / 4;  // 3/4 of the chip's wave slots for this kernel
+        // (small launches run out of the 256 MiB Infinity Cache and reward occupancy more than the
+        // model says: never go below 60 % of the slots when shorter bands can fill them)
         int target = 1;
-        for (int t = 2; t <= 64; ++t)
-            if (waves_for(t) >= min_waves) target = t;
+        double best = cost_for(1);
+        const double min_waves = std::min(0.6 * slots, waves_out);
+        for (int t = 2; t <= 96; ++t) {
+            const double c = cost_for(t);
+            if (waves_out >= min_waves && c < best) {
+                best = c;
+                target = t;
+            }
+        }
         if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         prm.nplanes = n;
