@@ -137,3 +137,27 @@ def test_rt_reference_golden_rgbs(dev):
             st = fx.plane_stats(_run(dev, np.ascontiguousarray(fx.crop_rgbs()[p]), *args))
             for k in ("avg", "min", "max"):
                 assert st[k] == pytest.approx(g[key][f"p{p}"][k], rel=1e-6, abs=1e-9)
+
+
+def test_torch_tensors_on_a_torch_stream(oracle):
+    """PyTorch as plumbing: planes are torch CUDA tensors (data_ptr), the kernels are enqueued on a
+    torch stream handed over with vszip_ctx_set_stream, and torch sees the result after syncing
+    that stream."""
+    import torch
+
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    st = torch.cuda.Stream()
+    d.set_stream(st.cuda_stream)
+    src_np = fx.splitmix64_plane(31, (270, 480), np.uint16)
+    with torch.cuda.stream(st):
+        src = torch.from_numpy(src_np.astype(np.int32)).to("cuda").to(torch.int16)  # bit pattern of the u16 samples
+        dst = torch.empty_like(src)
+        s = d.wrap(src.data_ptr(), 270, 480, src.stride(0), np.uint16)
+        o = d.wrap(dst.data_ptr(), 270, 480, dst.stride(0), np.uint16)
+        d.boxblur([s], [o], 13, 1, 13, 1)
+    st.synchronize()
+    got = dst.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, oracle.boxblur(src_np, 13, 1, 13, 1))
+    d.close()

@@ -158,6 +158,14 @@ class Device:
     def sync(self):
         self.check(self.lib.vszip_ctx_sync(self.ctx))
 
+    def set_stream(self, hip_stream: int):
+        """Enqueue on an externally owned hipStream_t (e.g. torch.cuda.Stream().cuda_stream)."""
+        self.check(self.lib.vszip_ctx_set_stream(self.ctx, C.c_void_p(hip_stream)))
+
+    def wrap(self, ptr: int, h: int, w: int, stride: int, dtype) -> "DevPlane":
+        """A DevPlane view of device memory this context does not own (e.g. a torch tensor's data_ptr)."""
+        return DevPlane(self, ptr, w, h, stride, np.dtype(dtype), own=False)
+
     # -- memory ---------------------------------------------------------------
     def empty(self, h: int, w: int, dtype, align_elems: int = 32) -> DevPlane:
         dtype = np.dtype(dtype)
