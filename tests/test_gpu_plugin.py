@@ -222,3 +222,27 @@ def test_concurrent_get_frame_threads(oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_second_clips_through_plugin(oracle):
+    """The optional second clips of the signatures: PlaneAverage clipb (+ a 32-bit integer clip),
+    Bilateral ref, EEDI3 sclip."""
+    a = fx.tiled_natural((96, 160), np.uint16, 0)
+    b = fx.tiled_natural((96, 160), np.uint16, 2)
+    ca, cb = vs.source([[a]], vs.GRAY16), vs.source([[b]], vs.GRAY16)
+    pr = ca.vszip.PlaneAverage(exclude=[-1], clipb=cb).get_frame(0).props
+    oa, od = oracle.plane_average(a, ref=b)
+    assert (pr["psmAvg"], pr["psmDiff"]) == (oa, od)
+    u32 = (a.astype(np.uint32) << 16) | b
+    p32 = vs.source([[u32]], vs.GRAY32).vszip.PlaneAverage(exclude=[]).get_frame(0).props
+    assert p32["psmAvg"] == oracle.plane_average(u32)[0]
+    with pytest.raises(vs.Error, match="exclude is not supported for 32-bit integer"):
+        vs.source([[u32]], vs.GRAY32).vszip.PlaneAverage(exclude=[0])
+    out = ca.vszip.Bilateral(ref=cb, sigmaS=2.0, sigmaR=0.05).get_frame(0)
+    prm = oracle.bilateral_params([2.0], [0.05])
+    want = oracle.bilateral_plane(a, prm["sigmaS"][0], prm["sigmaR"][0], prm["algorithm"][0], prm["radius"][0], prm["step"][0], prm["PBFICnum"][0], ref=b)
+    assert np.array_equal(out[0], want)
+    f = np.ascontiguousarray(fx.crop_rgbs()[1][:64, :200])
+    sc = np.ascontiguousarray(fx.crop_rgbs()[2][:128, :200])
+    e = vs.source([[f]], vs.GRAYS).vszip.EEDI3(field=1, dh=1, sclip=vs.source([[sc]], vs.GRAYS)).get_frame(0)
+    assert np.array_equal(e[0], oracle.eedi3(f, 1, dh=True, sclip=sc))
