@@ -216,6 +216,15 @@ int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const void *const *or
                      const void *prev1, const void *prev2, const int *width3, const int *height3,
                      const ptrdiff_t *stride3, int depth, int num_comps, unsigned frame_rate, int temporal,
                      uint64_t *wsse3);
+/* The same for a batch of frames in one launch (what a host that already holds several frames of
+ * the clip calls; frame f of the batch is exactly vszip_xpsnr_wsse on its own pointers):
+ * org3/rec3 hold nframes*num_comps plane pointers, frame-major; prev1/prev2 (arrays of nframes
+ * luma pointers, entries or the arrays themselves may be NULL) are per frame; every frame shares
+ * the geometry. wsse3 receives 3 values per frame. */
+int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, int nframes, const void *const *org3,
+                           const void *const *rec3, const void *const *prev1, const void *const *prev2,
+                           const int *width3, const int *height3, const ptrdiff_t *stride3, int depth,
+                           int num_comps, unsigned frame_rate, int temporal, uint64_t *wsse3);
 double vszip_xpsnr_value(uint64_t wsse, uint64_t width, uint64_t height, int depth);
 double vszip_xpsnr_average(double sum_wdist, double sum_xpsnr, uint64_t width, uint64_t height, int depth,
                            uint64_t num_frames);

@@ -58,3 +58,96 @@ def test_identical_is_inf(dev):
     d = [dev.upload(p) for p in org]
     assert dev.xpsnr_wsse(d, d) == [0, 0, 0]
     assert math.isinf(dev.lib.vszip_xpsnr_value(0, 352, 288, 8))
+
+
+def _rand_clip(rng, shapes, dtype, depth, n, full_range=False):
+    peak = np.iinfo(dtype).max if full_range else (1 << depth) - 1
+    frames = [[rng.integers(0, peak + 1, size=s, dtype=np.int64).astype(dtype) for s in shapes] for _ in range(n)]
+    recs = [[np.clip(p.astype(np.int64) + rng.integers(-9, 10, p.shape), 0, peak).astype(dtype) for p in fr] for fr in frames]
+    return frames, recs
+
+
+def _want(oracle, frames, recs, depth, fps, temporal=True):
+    return [oracle.xpsnr_wsse(frames[n], recs[n], frames[n - 1][0] if n >= 1 else None, frames[n - 2][0] if n >= 2 else None, depth=depth, frame_rate=fps,
+                              temporal=temporal) for n in range(len(frames))]
+
+
+# (luma shape, chroma subsampling (ssw, ssh) or None for Gray): plain 4:2:0, widths that are 2 mod 4, the
+# highds regime (> 2048x1152) with ragged last blocks, 4:4:4 / 4:2:2 / 4:1:1 chroma, a one-plane clip,
+# frames so small that the whole plane is one block (b < 4)
+_GEOMS = [((288, 352), (1, 1)), ((290, 354), (1, 1)), ((1156, 2054), (1, 1)), ((1200, 2100), (0, 0)), ((486, 720), (1, 0)), ((480, 704), (2, 0)),
+          ((240, 426), None), ((40, 44), (1, 1)), ((2160, 3840), (1, 1))]
+
+
+@pytest.mark.parametrize("geom", range(len(_GEOMS)))
+@pytest.mark.parametrize("dtype,depth", [(np.uint8, 8), (np.uint16, 10)])
+def test_batch_matches_oracle(dev, oracle, geom, dtype, depth):
+    """vszip_xpsnr_wsse_batch (strip kernel: one launch for the whole batch) == the oracle frame by
+    frame, with the frame table inline (3 frames) and in device memory (10 frames)."""
+    (h, w), ss = _GEOMS[geom]
+    shapes = [(h, w)] + ([] if ss is None else [(h >> ss[1], w >> ss[0])] * 2)
+    nf = 10 if h * w < 1e6 else 3
+    rng = np.random.default_rng(9100 + geom)
+    frames, recs = _rand_clip(rng, shapes, dtype, depth, nf)
+    fps = 60 if geom % 2 else 24
+    want = _want(oracle, frames, recs, depth, fps)
+    dfr = [[dev.upload(p) for p in fr] for fr in frames]
+    drc = [[dev.upload(p) for p in fr] for fr in recs]
+    p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(nf)]
+    p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(nf)]
+    assert dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=depth, frame_rate=fps) == want
+    assert dev.xpsnr_wsse_batch(dfr[:3], drc[:3], p1[:3], p2[:3], depth=depth, frame_rate=fps) == want[:3]
+
+
+def test_temporal_off_and_no_prev(dev, oracle):
+    rng = np.random.default_rng(5)
+    for shape in ((288, 352), (1200, 2100)):
+        shapes = [shape, (shape[0] // 2, shape[1] // 2), (shape[0] // 2, shape[1] // 2)]
+        frames, recs = _rand_clip(rng, shapes, np.uint8, 8, 2)
+        dfr = [[dev.upload(p) for p in fr] for fr in frames]
+        drc = [[dev.upload(p) for p in fr] for fr in recs]
+        want_off = [oracle.xpsnr_wsse(frames[n], recs[n], None, None, depth=8, frame_rate=24, temporal=False) for n in range(2)]
+        assert dev.xpsnr_wsse_batch(dfr, drc, None, None, depth=8, frame_rate=24, temporal=False) == want_off
+        # temporal on but no previous frames at all (frame 0 of a clip): the previous frame counts as zeros
+        want_np = [oracle.xpsnr_wsse(frames[n], recs[n], None, None, depth=8, frame_rate=60, temporal=True) for n in range(2)]
+        assert dev.xpsnr_wsse_batch(dfr, drc, None, None, depth=8, frame_rate=60, temporal=True) == want_np
+
+
+def test_block_kernels_agree(dev, oracle, monkeypatch):
+    """The one-workgroup-per-block kernels (planes that miss the strip kernel's alignment rules) and
+    the strip kernel give the same sums; an unaligned view takes the block kernels by itself."""
+    rng = np.random.default_rng(77)
+    shapes = [(486, 720), (243, 360), (243, 360)]
+    frames, recs = _rand_clip(rng, shapes, np.uint16, 10, 3, full_range=True)
+    want = _want(oracle, frames, recs, 10, 60)
+    dfr = [[dev.upload(p) for p in fr] for fr in frames]
+    drc = [[dev.upload(p) for p in fr] for fr in recs]
+    p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(3)]
+    p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(3)]
+    strip = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60)
+    monkeypatch.setenv("VSZIP_XPSNR_BLOCKS", "1")
+    block = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60)
+    monkeypatch.delenv("VSZIP_XPSNR_BLOCKS")
+    assert strip == block == want
+
+
+@pytest.mark.parametrize("shape", [(288, 352), (480, 640), (1080, 1920), (1200, 2100), (40, 44), (96, 160)])
+def test_device_weighting_is_the_host_weighting(dev, oracle, monkeypatch, shape):
+    """The f64 weighting (getWSSE :437-521) runs on the device by default; the host evaluation of
+    the same expressions (VSZIP_XPSNR_HOST_WEIGH) must give the same u64s, including the
+    <=640x480 weight smoothing."""
+    rng = np.random.default_rng(shape[0])
+    shapes = [shape, (shape[0] // 2, shape[1] // 2), (shape[0] // 2, shape[1] // 2)]
+    frames, recs = _rand_clip(rng, shapes, np.uint8, 8, 4)
+    # smooth content so that the block weights differ a lot (the smoothing step then matters)
+    for fr in frames:
+        fr[0][: shape[0] // 2] = fx.tiled_natural((shape[0] // 2, shape[1]), np.uint8, 1)
+    want = _want(oracle, frames, recs, 8, 24)
+    dfr = [[dev.upload(p) for p in fr] for fr in frames]
+    drc = [[dev.upload(p) for p in fr] for fr in recs]
+    p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(4)]
+    on_dev = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
+    monkeypatch.setenv("VSZIP_XPSNR_HOST_WEIGH", "1")
+    on_host = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
+    monkeypatch.delenv("VSZIP_XPSNR_HOST_WEIGH")
+    assert on_dev == on_host == want

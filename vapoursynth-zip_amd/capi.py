@@ -80,6 +80,8 @@ SYMBOLS = {
     "vszip_eedi3_mclip": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
     "vszip_xpsnr_wsse": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd), _i, _i, C.c_uint, _i,
                               C.POINTER(C.c_uint64)]),
+    "vszip_xpsnr_wsse_batch": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd), _i, _i,
+                                    C.c_uint, _i, C.POINTER(C.c_uint64)]),
     "vszip_xpsnr_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64, _i]),
     "vszip_xpsnr_average": (C.c_double, [C.c_double, C.c_double, C.c_uint64, C.c_uint64, _i, C.c_uint64]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -347,3 +349,18 @@ class Device:
         self.check(self.lib.vszip_xpsnr_wsse(self.ctx, org[0].dtype.itemsize, vp3(org), vp3(rec), prev1.ptr if prev1 else None, prev2.ptr if prev2 else None,
                                              w, h, st, depth, n, frame_rate, int(temporal), out))
         return [int(out[i]) for i in range(n)]
+
+    def xpsnr_wsse_batch(self, orgs, recs, prev1s=None, prev2s=None, depth=8, frame_rate=24, temporal=True):
+        """orgs / recs: one list of 1 or 3 DevPlanes per frame (same geometry); prev1s / prev2s: per
+        frame the luma DevPlane of frames n-1 / n-2 or None. -> [[wsse64 per plane] per frame]"""
+        nf, n = len(orgs), len(orgs[0])
+        flat = lambda ll: (C.c_void_p * (nf * n))(*[p.ptr for l in ll for p in l])
+        prev = lambda l: (C.c_void_p * nf)(*[(p.ptr if p is not None else None) for p in l]) if l is not None else None
+        o0 = orgs[0]
+        w = (C.c_int * 3)(*([p.w for p in o0] + [0] * (3 - n)))
+        h = (C.c_int * 3)(*([p.h for p in o0] + [0] * (3 - n)))
+        st = (C.c_ssize_t * 3)(*([p.stride for p in o0] + [0] * (3 - n)))
+        out = (C.c_uint64 * (3 * nf))()
+        self.check(self.lib.vszip_xpsnr_wsse_batch(self.ctx, o0[0].dtype.itemsize, nf, flat(orgs), flat(recs), prev(prev1s), prev(prev2s), w, h, st, depth, n,
+                                                   frame_rate, int(temporal), out))
+        return [[int(out[3 * f + i]) for i in range(n)] for f in range(nf)]

@@ -3,13 +3,23 @@
 // The pixel work is exact integer arithmetic per XPSNR block: squared error
 // (calcSquaredError :214-251), spatial activity (spatialAct :174-212, or highds :28-64 on
 // the 2x-decimated grid for frames larger than 2048x1152) and temporal activity
-// (tempDiff1/2 :111-170, diff1st/2nd :66-109). One 256-thread workgroup per luma block
-// (and per chroma block) reduces those to u64 sums. The few hundred per-block sums are
-// copied back and the f64 weighting (calcSquaredErrorAndWeight :315-357, the <=640x480
-// minimum smoothing and the weighted sums, getWSSE :437-521) runs on the host in the
-// reference's sequential block order, so wsse64 is identical to the reference's.
+// (tempDiff1/2 :111-170, diff1st/2nd :66-109), reduced to u64 sums per XPSNR block. The few
+// hundred per-block sums are copied back and the f64 weighting (calcSquaredErrorAndWeight
+// :315-357, the <=640x480 minimum smoothing and the weighted sums, getWSSE :437-521) runs on the
+// host in the reference's sequential block order, so wsse64 is identical to the reference's.
+//
+// Strip kernel (the path every VapourSynth frame takes): ONE launch covers the luma and chroma
+// planes of a whole batch of frames. A wave owns a strip of 64 lanes x 4 pixels x 8/16 rows inside one
+// block row; a lane reads its 4 pixels with one 4/8-byte load (+ two small halo loads on the
+// luma), the activity filters run separably down the rows (each row is read once per strip, the
+// row loop is fully unrolled so that its loads are all in flight together), and the lanes of one
+// XPSNR block are folded with a segmented wave reduction before one u64 atomic per block and
+// strip. Integer sums are order independent, so the atomics do not affect the result.
+// The older one-workgroup-per-block kernels below remain for planes that do not meet the strip
+// kernel's alignment rules (odd sizes, rows not a multiple of 4 samples).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -134,102 +144,441 @@ __global__ __launch_bounds__(256) void xpsnr_sse_kernel(const CArgs a) {
     if (threadIdx.x == 0) a.out[(size_t)blockIdx.y * a.nbx + blockIdx.x] = sse;
 }
 
+// ---- strip kernel -----------------------------------------------------------------------------
+
+struct XFrame {
+    const void *org[3], *rec[3], *p1, *p2;  // p1/p2: luma of frames n-1 / n-2 (NULL: absent)
+};
+constexpr int kInlineFrames = 8;  // batches up to this size travel in the kernel argument
+
+struct XGeo {     // strip decomposition of one plane
+    int w, h, stride;  // samples
+    int bx, by;        // XPSNR block size on this plane
+    int nbx;           // blocks across
+    int nsx;           // strips across (64 * vec samples each)
+    int segs;          // row segments per block row
+    int nstrips;       // nsx * segs * block rows
+    int vec;           // samples per lane on the SSE-only path (4, 2 or 1)
+    int out_off;       // u64 index of this plane's block sums in a frame's result
+};
+
+struct XStripArgs {
+    XFrame inl[kInlineFrames];
+    const XFrame *tab;  // non-NULL: the frames come from this device table instead of `inl`
+    uint64_t *out;
+    unsigned out_per_frame;
+    XGeo g[3];
+    int ncomp;
+    int luma_act;  // plane 0 carries the activity sums (b >= 4)
+    int bv;        // 1 or 2 (see XArgs::b_val)
+    int tmode;     // 0 none, 1 first order, 2 second order
+};
+
+constexpr int kRowsBv1 = 8, kRowsBv2 = 16, kRowsSse = 16;
+
+template <typename T, int N>
+__device__ __forceinline__ void load_px(const T *p, int v[N]) {
+    if constexpr (N == 1) {
+        v[0] = p[0];
+    } else if constexpr (sizeof(T) == 1 && N == 2) {
+        const uint32_t q = *reinterpret_cast<const uint16_t *>(p);
+        v[0] = q & 0xff;
+        v[1] = q >> 8;
+    } else if constexpr (sizeof(T) == 1 && N == 4) {
+        const uint32_t q = *reinterpret_cast<const uint32_t *>(p);
+        v[0] = q & 0xff;
+        v[1] = (q >> 8) & 0xff;
+        v[2] = (q >> 16) & 0xff;
+        v[3] = q >> 24;
+    } else if constexpr (sizeof(T) == 2 && N == 2) {
+        const uint32_t q = *reinterpret_cast<const uint32_t *>(p);
+        v[0] = q & 0xffff;
+        v[1] = q >> 16;
+    } else {
+        const uint2 q = *reinterpret_cast<const uint2 *>(p);
+        v[0] = q.x & 0xffff;
+        v[1] = q.x >> 16;
+        v[2] = q.y & 0xffff;
+        v[3] = q.y >> 16;
+    }
+}
+
+// Sum v over runs of equal `key` (runs are contiguous in lane order); valid in the first lane of
+// each run.
+template <typename A>
+__device__ __forceinline__ A seg_reduce(A v, int key, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int k2 = __shfl_down(key, d, 64);
+        const A v2 = __shfl_down(v, d, 64);
+        if (lane + d < 64 && k2 == key) v += v2;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void add_u64(uint64_t *p, uint64_t v) { atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
+
+// SSE of a strip of an SSE-only plane (chroma; every plane when b < 4): calcSquaredError :214-251
+template <typename T, int VEC>
+__device__ __forceinline__ void sse_strip(const XGeo &g, const T *org, const T *rec, uint64_t *out, int sx, int brow, int seg, int lane) {
+    const int ys = brow * g.by + seg * kRowsSse, ye = min(min(ys + kRowsSse, brow * g.by + g.by), g.h);
+    if (ys >= ye) return;
+    const int x0 = (sx * 64 + lane) * VEC;
+    const bool valid = x0 < g.w;
+    const int xl = valid ? x0 : 0;
+    uint64_t sse = 0;
+#pragma unroll
+    for (int i = 0; i < kRowsSse; ++i) {
+        const int y = min(ys + i, g.h - 1);
+        int o[VEC], r[VEC];
+        load_px<T, VEC>(org + (ptrdiff_t)y * g.stride + xl, o);
+        load_px<T, VEC>(rec + (ptrdiff_t)y * g.stride + xl, r);
+        if (ys + i < ye) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int e = o[j] - r[j];
+                const uint32_t ue = (uint32_t)abs(e);
+                if (x0 + j < g.w) sse += (uint64_t)(ue * ue);
+            }
+        }
+    }
+    const int key = valid ? x0 / g.bx : -1;
+    sse = seg_reduce(sse, key, lane);
+    const int up = __shfl_up(key, 1, 64);
+    if (valid && (lane == 0 || up != key)) add_u64(out + g.out_off + (size_t)brow * g.nbx + key, sse);
+}
+
+// One luma strip: SSE + spatial activity + temporal activity of a 256 x kRows window of one block
+// row. BV == 1: the 3x3 filter of spatialAct :174-212 as rows [-1,-2,-1] / [-2,12,-2] / [-1,-2,-1];
+// BV == 2: the 6x6 filter of highds :28-64 on even positions as rows A,B,C,C,B,A with
+// A = [0,-1,-1,-1,-1,0], B = [-1,-2,-3,-3,-2,-1], C = [-1,-3,12,12,-3,-1].
+template <typename T, int BV>
+__device__ __forceinline__ void luma_strip(const XStripArgs &a, const T *org, const T *rec, const T *p1, const T *p2, uint64_t *out, int sx, int brow, int seg,
+                                           int lane) {
+    constexpr int RS = BV == 1 ? kRowsBv1 : kRowsBv2;
+    const XGeo &g = a.g[0];
+    const int b = g.bx, w = g.w, h = g.h;
+    const ptrdiff_t o = g.stride;
+    const int oy = brow * b, bh = min(b, h - oy);
+    const int ys = oy + seg * RS, ye = min(ys + RS, oy + bh);
+    if (ys >= ye) return;
+    const int x0 = (sx * 64 + lane) * 4;
+    const bool valid = x0 < w;
+    const int xc = valid ? x0 : 0;                     // centre load position
+    const int xlft = max(xc - BV, 0);                  // left halo (BV samples ending at xc-1)
+    const int xrgt = min(xc + 4, w - BV);              // right halo (BV samples from xc+4)
+    const int key = valid ? x0 / b : -1;
+    const int ox = key * b, bw = min(b, w - ox);
+    // calcSquaredErrorAndWeight :283-286
+    const int x_act = ox > 0 ? 0 : BV, y_act = oy > 0 ? 0 : BV;
+    const int w_act = (ox + bw < w) ? bw : bw - BV, h_act = (oy + bh < h) ? bh : bh - BV;
+    bool mx[4];  // sample j of this lane lies in the block's activity columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xr = x0 + j - ox;
+        mx[j] = valid && x0 + j < w && xr >= x_act && xr < w_act && (BV == 1 || w_act > 12);
+    }
+    const int tmode = a.tmode;
+    const bool has1 = p1 != nullptr, has2 = p1 != nullptr && p2 != nullptr;
+    const int c1 = tmode == 1 ? 1 : 2;
+
+    uint64_t sse = 0;
+    uint32_t sa = 0, ta = 0;
+    if constexpr (BV == 1) {
+        int P[4] = {0, 0, 0, 0}, Pn[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < RS + 2; ++i) {
+            const int y = ys - 1 + i;
+            const T *row = org + (ptrdiff_t)min(max(y, 0), h - 1) * o;
+            int v[6];
+            load_px<T, 4>(row + xc, v + 1);
+            v[0] = row[xlft];
+            v[5] = row[xrgt];
+            const int yr = y - 1 - oy;  // the row completed by this iteration
+            const bool emit = i >= 2 && y - 1 < ye && yr >= y_act && yr < h_act;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int h1 = -(v[j] + 2 * v[j + 1] + v[j + 2]);
+                const int h0 = 12 * v[j + 1] - 2 * (v[j] + v[j + 2]);
+                const int f = P[j] + h1;
+                if (emit && mx[j]) sa += (uint32_t)abs(f);
+                P[j] = Pn[j] + h0;
+                Pn[j] = h1;
+            }
+            if (i >= 1 && i <= RS) {
+                const ptrdiff_t q = (ptrdiff_t)min(y, h - 1) * o + xc;
+                int r[4], t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+                load_px<T, 4>(rec + q, r);
+                if (tmode && has1) load_px<T, 4>(p1 + q, t1);
+                if (tmode == 2 && has2) load_px<T, 4>(p2 + q, t2);
+                if (y < ye) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!(valid && x0 + j < w)) continue;
+                        const uint32_t ue = (uint32_t)abs(v[j + 1] - r[j]);
+                        sse += (uint64_t)(ue * ue);
+                        if (tmode) ta += 2u * (uint32_t)abs(v[j + 1] - c1 * t1[j] + t2[j]);  // tempDiff1/2 :111-170
+                    }
+                }
+            }
+        }
+    } else {
+        int Pp[2] = {0, 0}, Pn[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < RS / 2 + 2; ++i) {
+            const int y = ys - 2 + 2 * i;  // rows y, y+1
+            int A[2][2], B[2][2], C[2][2], s4[2] = {0, 0};
+            int ctr[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const T *row = org + (ptrdiff_t)min(max(y + rr, 0), h - 1) * o;
+                int v[8];
+                load_px<T, 4>(row + xc, v + 2);
+                load_px<T, 2>(row + xlft, v);
+                load_px<T, 2>(row + xrgt, v + 6);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int *u = v + 2 * q;
+                    A[rr][q] = -(u[1] + u[2] + u[3] + u[4]);
+                    B[rr][q] = -(u[0] + u[5]) - 2 * (u[1] + u[4]) - 3 * (u[2] + u[3]);
+                    C[rr][q] = -(u[0] + u[5]) - 3 * (u[1] + u[4]) + 12 * (u[2] + u[3]);
+                    s4[q] += u[2] + u[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ctr[rr][j] = v[2 + j];
+            }
+            const int yr = y - 2 - oy;  // the row pair completed by this iteration
+            const bool emit = i >= 2 && y - 2 < ye && yr >= y_act && yr < h_act;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = Pp[q] + B[0][q] + A[1][q];
+                if (emit && mx[2 * q]) sa += (uint32_t)abs(f);
+                Pp[q] = Pn[q] + C[0][q] + C[1][q];
+                Pn[q] = A[0][q] + B[1][q];
+            }
+            if (i >= 1 && i <= RS / 2) {
+                int s1[2] = {0, 0}, s2[2] = {0, 0};
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const ptrdiff_t q = (ptrdiff_t)min(y + rr, h - 1) * o + xc;
+                    int r[4], t[4];
+                    load_px<T, 4>(rec + q, r);
+                    if (y < ye) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t ue = (uint32_t)abs(ctr[rr][j] - r[j]);
+                            if (valid && x0 + j < w) sse += (uint64_t)(ue * ue);
+                        }
+                    }
+                    if (tmode && has1) {
+                        load_px<T, 4>(p1 + q, t);
+                        s1[0] += t[0] + t[1];
+                        s1[1] += t[2] + t[3];
+                    }
+                    if (tmode == 2 && has2) {
+                        load_px<T, 4>(p2 + q, t);
+                        s2[0] += t[0] + t[1];
+                        s2[1] += t[2] + t[3];
+                    }
+                }
+                if (tmode && y < ye) {  // diff1st / diff2nd :66-109
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (valid && x0 + 2 * q < w) ta += 2u * (uint32_t)abs(s4[q] - c1 * s1[q] + s2[q]);
+                }
+            }
+        }
+    }
+    sse = seg_reduce(sse, key, lane);
+    sa = seg_reduce(sa, key, lane);
+    ta = seg_reduce(ta, key, lane);
+    const int up = __shfl_up(key, 1, 64);
+    if (valid && (lane == 0 || up != key)) {
+        uint64_t *q = out + ((size_t)brow * g.nbx + key) * 3;
+        add_u64(q, sse);
+        if (sa) add_u64(q + 1, sa);
+        if (ta) add_u64(q + 2, ta);
+    }
+}
+
+// ---- f64 weighting on the device --------------------------------------------------------------
+// getWSSE :437-521 for one frame per workgroup, from the block sums the kernels above leave in
+// device memory. IEEE f64 add / mul / div / sqrt are correctly rounded on gfx950 as on the host and
+// contraction is off, so evaluating the reference's expressions in the reference's order gives the
+// reference's bits: the per-block weights are independent (all threads), the <=640x480 smoothing
+// and the three weighted sums are sequential recurrences (one thread each, in block order).
+constexpr int kWeighMaxBlocks = 1536;  // 4 f64 arrays of this length in LDS
+
+struct WArgs {
+    const uint64_t *sums;  // [frame][total]
+    uint64_t *wsse;        // [frame][3]
+    unsigned total;
+    int w, h, b, w_blk, n_luma, b_val, temporal, num_comps, small;  // small: wh <= 640*480
+    unsigned coff[3], cn[3];
+    double sf, avg_act;
+};
+
+__global__ __launch_bounds__(256) void xpsnr_weigh_kernel(const WArgs a) {
+    __shared__ double W[kWeighMaxBlocks], P[3][kWeighMaxBlocks];
+    const uint64_t *res = a.sums + (size_t)blockIdx.x * a.total;
+    uint64_t *out = a.wsse + (size_t)blockIdx.x * 3;
+    const int tid = threadIdx.x;
+    if (a.b < 4) {
+        if (tid < 3) out[tid] = tid < a.num_comps ? res[a.coff[tid]] : 0;
+        return;
+    }
+    for (int idx = tid; idx < a.n_luma; idx += 256) {  // calcSquaredErrorAndWeight :268-357
+        const int x = (idx % a.w_blk) * a.b, y = (idx / a.w_blk) * a.b;
+        const int bw = min(a.b, a.w - x), bh = min(a.b, a.h - y);
+        const int x_act = x > 0 ? 0 : a.b_val, y_act = y > 0 ? 0 : a.b_val;
+        const int w_act = (x + bw < a.w) ? bw : bw - a.b_val, h_act = (y + bh < a.h) ? bh : bh - a.b_val;
+        const uint64_t *q = res + (size_t)idx * 3;
+        double ms_act = 1.0;
+        if (!(w_act <= x_act || h_act <= y_act)) {
+            ms_act = (double)q[1] / ((double)(w_act - x_act) * (double)(h_act - y_act));
+            if (a.temporal) ms_act += (double)q[2] / ((double)bw * (double)bh);
+            if (ms_act < a.sf) ms_act = a.sf;
+            ms_act *= ms_act;
+        }
+        W[idx] = 1.0 / sqrt(ms_act);
+    }
+    __syncthreads();
+    if (a.small && tid == 0) {  // :450-467, in block order
+        const int w_blk = a.w_blk;
+        for (int idx = 0; idx < a.n_luma; ++idx) {
+            const int x = (idx % w_blk) * a.b, y = (idx / w_blk) * a.b;
+            double prev;
+            if (x == 0)
+                prev = idx > 1 ? W[idx - 2] : 0;
+            else
+                prev = x > a.b ? fmax(W[idx - 2], W[idx]) : W[idx];
+            if (idx > w_blk) prev = fmax(prev, W[idx - 1 - w_blk]);
+            if (idx > 0 && W[idx - 1] > prev) W[idx - 1] = prev;
+            if ((x + a.b >= a.w) && (y + a.b >= a.h) && (idx > w_blk)) {
+                prev = fmax(W[idx - 1], W[idx - w_blk]);
+                if (W[idx] > prev) W[idx] = prev;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < a.n_luma; idx += 256) {
+        P[0][idx] = (double)res[(size_t)idx * 3] * W[idx];
+        for (int c = 1; c < a.num_comps; ++c)
+            if (idx < (int)a.cn[c]) P[c][idx] = (double)res[a.coff[c] + idx] * W[idx];
+    }
+    __syncthreads();
+    const int c = tid >> 6;
+    if ((tid & 63) == 0 && c < 3) {
+        uint64_t v = 0;
+        if (c < a.num_comps) {
+            const int n = c == 0 ? a.n_luma : (int)a.cn[c];
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) acc += P[c][i];
+            if (acc > 0.0) {
+                const double t = acc * a.avg_act + 0.5;
+                v = c == 0 ? (uint64_t)trunc(t) : (uint64_t)(t < 0 ? 0 : t);
+            }
+        }
+        out[c] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xpsnr_strip_kernel(const XStripArgs a) {
+    const int lane = threadIdx.x & 63;
+    int sid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int c = 0;
+    while (c < a.ncomp && sid >= a.g[c].nstrips) sid -= a.g[c++].nstrips;
+    if (c >= a.ncomp) return;
+    const XGeo &g = a.g[c];
+    const void *org, *rec, *p1, *p2;
+    if (a.tab) {
+        const XFrame *f = a.tab + blockIdx.y;
+        org = f->org[c], rec = f->rec[c], p1 = f->p1, p2 = f->p2;
+    } else {
+        const XFrame &f = a.inl[blockIdx.y];
+        org = f.org[c], rec = f.rec[c], p1 = f.p1, p2 = f.p2;
+    }
+    uint64_t *out = a.out + (size_t)blockIdx.y * a.out_per_frame;
+    const int sx = sid % g.nsx, t = sid / g.nsx;
+    const int brow = t / g.segs, seg = t - brow * g.segs;
+    const T *o = static_cast<const T *>(org), *r = static_cast<const T *>(rec);
+    if (c == 0 && a.luma_act) {
+        if (a.bv == 1)
+            luma_strip<T, 1>(a, o, r, static_cast<const T *>(p1), static_cast<const T *>(p2), out, sx, brow, seg, lane);
+        else
+            luma_strip<T, 2>(a, o, r, static_cast<const T *>(p1), static_cast<const T *>(p2), out, sx, brow, seg, lane);
+    } else if (g.vec == 4) {
+        sse_strip<T, 4>(g, o, r, out, sx, brow, seg, lane);
+    } else if (g.vec == 2) {
+        sse_strip<T, 2>(g, o, r, out, sx, brow, seg, lane);
+    } else {
+        sse_strip<T, 1>(g, o, r, out, sx, brow, seg, lane);
+    }
+}
+
 }  // namespace
 
-VSZIP_EXPORT int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const void *const *org3, const void *const *rec3, const void *prev1, const void *prev2,
-                                  const int *width3, const int *height3, const ptrdiff_t *stride3, int depth, int num_comps, unsigned frame_rate, int temporal,
-                                  uint64_t *wsse3) {
-    if (!ctx || !org3 || !rec3 || !width3 || !height3 || !stride3 || !wsse3 || num_comps < 1 || num_comps > 3) return VSZIP_ERR_ARG;
-    if (bytes_per_sample != 1 && bytes_per_sample != 2) return vszip_set_error(ctx, VSZIP_ERR_ARG, "XPSNR : only supports 8 or 10 bit clips");
-    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t w = (uint32_t)width3[0], h = (uint32_t)height3[0];
-    const uint32_t wh = w * h;
-    // getWSSE :389-398
-    const double r = (double)wh / (3840.0 * 2160.0);
-    const double bq = 32.0 * std::sqrt(r) + 0.5;
-    const uint32_t b = (uint32_t)(bq < 0 ? 0 : bq) * 4;
-    const uint32_t w_blk = b >= 4 ? (w + b - 1) / b : 0, h_blk = b >= 4 ? (h + b - 1) / b : 0;
-    const uint32_t sft = 1u << (2 * depth - 9);
-    const double avg_act = std::sqrt(16.0 * (double)sft / std::sqrt(std::max(0.00001, r)));
-    wsse3[0] = wsse3[1] = wsse3[2] = 0;
+// Geometry of one call: block sizes and the layout of a frame's device result.
+namespace {
 
+struct XPlan {
+    uint32_t w, h, wh, b, w_blk, h_blk;
+    double avg_act;
+    size_t n_luma, total;
+    size_t coff[3], cn[3];
+    uint32_t cbx[3], cby[3], cnbx[3], cnby[3];
+    int b_val, tmode;
+};
+
+int xpsnr_plan(vszip_ctx *ctx, const int *width3, const int *height3, int depth, int num_comps, unsigned frame_rate, int temporal, XPlan &p) {
+    p.w = (uint32_t)width3[0];
+    p.h = (uint32_t)height3[0];
+    p.wh = p.w * p.h;
+    // getWSSE :389-398
+    const double r = (double)p.wh / (3840.0 * 2160.0);
+    const double bq = 32.0 * std::sqrt(r) + 0.5;
+    p.b = (uint32_t)(bq < 0 ? 0 : bq) * 4;
+    p.w_blk = p.b >= 4 ? (p.w + p.b - 1) / p.b : 0;
+    p.h_blk = p.b >= 4 ? (p.h + p.b - 1) / p.b : 0;
+    const uint32_t sft = 1u << (2 * depth - 9);
+    p.avg_act = std::sqrt(16.0 * (double)sft / std::sqrt(std::max(0.00001, r)));
     // device result layout: luma [w_blk*h_blk][3], then per chroma plane its block SSEs
-    size_t n_luma = (size_t)w_blk * h_blk, total = n_luma * 3;
-    size_t coff[3] = {0, 0, 0}, cn[3] = {0, 0, 0};
-    uint32_t cbx[3] = {0, 0, 0}, cby[3] = {0, 0, 0}, cnbx[3] = {0, 0, 0}, cnby[3] = {0, 0, 0};
+    p.n_luma = (size_t)p.w_blk * p.h_blk;
+    p.total = p.n_luma * 3;
+    for (int c = 0; c < 3; ++c) p.coff[c] = p.cn[c] = p.cbx[c] = p.cby[c] = p.cnbx[c] = p.cnby[c] = 0;
     for (int c = 0; c < num_comps; ++c) {
         const uint32_t wp = (uint32_t)width3[c], hp = (uint32_t)height3[c];
-        if (b < 4) {
-            cbx[c] = wp;
-            cby[c] = hp;
+        if (p.b < 4) {
+            p.cbx[c] = wp;
+            p.cby[c] = hp;
         } else if (c > 0) {
-            cbx[c] = (b * wp) / w;
-            cby[c] = (b * hp) / h;
+            p.cbx[c] = (p.b * wp) / p.w;
+            p.cby[c] = (p.b * hp) / p.h;
         } else {
             continue;
         }
-        if (cbx[c] == 0 || cby[c] == 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "XPSNR : plane %d too small", c);
-        cnbx[c] = (wp + cbx[c] - 1) / cbx[c];
-        cnby[c] = (hp + cby[c] - 1) / cby[c];
-        coff[c] = total;
-        cn[c] = (size_t)cnbx[c] * cnby[c];
-        total += cn[c];
+        if (p.cbx[c] == 0 || p.cby[c] == 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "XPSNR : plane %d too small", c);
+        p.cnbx[c] = (wp + p.cbx[c] - 1) / p.cbx[c];
+        p.cnby[c] = (hp + p.cby[c] - 1) / p.cby[c];
+        p.coff[c] = p.total;
+        p.cn[c] = (size_t)p.cnbx[c] * p.cnby[c];
+        p.total += p.cn[c];
     }
-    int rc = vszip_ensure_scratch(ctx, total * sizeof(uint64_t));
-    if (rc != VSZIP_OK) return rc;
-    rc = vszip_ensure_scalars(ctx, total * sizeof(uint64_t));
-    if (rc != VSZIP_OK) return rc;
-    uint64_t *dev = static_cast<uint64_t *>(ctx->scratch);
+    p.b_val = ((uint64_t)p.w * p.h > 2048ull * 1152ull) ? 2 : 1;  // calcSquaredErrorAndWeight :279
+    p.tmode = temporal ? (frame_rate < 32 ? 1 : 2) : 0;
+    return VSZIP_OK;
+}
 
-    const int b_val = ((uint64_t)w * h > 2048ull * 1152ull) ? 2 : 1;  // calcSquaredErrorAndWeight :279
-    int tmode = 0;
-    if (temporal) tmode = frame_rate < 32 ? 1 : 2;
-    if (b >= 4) {
-        XArgs a;
-        a.org = org3[0];
-        a.rec = rec3[0];
-        a.p1 = temporal ? prev1 : nullptr;
-        a.p2 = (temporal && tmode == 2) ? prev2 : nullptr;
-        a.stride = (int)stride3[0];
-        a.w = (int)w;
-        a.h = (int)h;
-        a.b = (int)b;
-        a.w_blk = (int)w_blk;
-        a.h_blk = (int)h_blk;
-        a.b_val = b_val;
-        a.temporal = tmode;
-        a.out = dev;
-        if (bytes_per_sample == 1)
-            hipLaunchKernelGGL((xpsnr_luma_kernel<uint8_t>), dim3(w_blk, h_blk), dim3(256), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((xpsnr_luma_kernel<uint16_t>), dim3(w_blk, h_blk), dim3(256), 0, ctx->stream, a);
-    }
-    for (int c = 0; c < num_comps; ++c) {
-        if (cn[c] == 0) continue;
-        CArgs a;
-        a.org = org3[c];
-        a.rec = rec3[c];
-        a.stride = (int)stride3[c];
-        a.w = width3[c];
-        a.h = height3[c];
-        a.bx = (int)cbx[c];
-        a.by = (int)cby[c];
-        a.nbx = (int)cnbx[c];
-        a.out = dev + coff[c];
-        if (bytes_per_sample == 1)
-            hipLaunchKernelGGL((xpsnr_sse_kernel<uint8_t>), dim3(cnbx[c], cnby[c]), dim3(256), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((xpsnr_sse_kernel<uint16_t>), dim3(cnbx[c], cnby[c]), dim3(256), 0, ctx->stream, a);
-    }
-    VSZIP_HIP_CHECK(ctx, hipGetLastError());
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, dev, total * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t *res = static_cast<const uint64_t *>(ctx->scalars_host);
-
-    std::vector<double> weights(n_luma);
+// The f64 weighting of one frame's block sums, in the reference's block order (getWSSE :437-521).
+void xpsnr_weigh(const XPlan &p, const uint64_t *res, int depth, int num_comps, int temporal, uint64_t *wsse3) {
+    const uint32_t w = p.w, h = p.h, b = p.b, w_blk = p.w_blk;
+    const int b_val = p.b_val;
+    wsse3[0] = wsse3[1] = wsse3[2] = 0;
+    std::vector<double> weights(p.n_luma);
     if (b >= 4) {
         double wsse_luma = 0.0;
-        std::vector<double> sse_luma(n_luma);
+        std::vector<double> sse_luma(p.n_luma);
         size_t idx = 0;
         for (uint32_t y = 0; y < h; y += b) {
             const uint32_t bh = (y + b > h) ? (h - y) : b;
@@ -249,7 +598,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const vo
                     ms_act *= ms_act;
                 }
                 weights[idx] = 1.0 / std::sqrt(ms_act);
-                if (wh <= 640u * 480u) {  // :450-467
+                if (p.wh <= 640u * 480u) {  // :450-467
                     if (x == 0)
                         ms_act_prev = idx > 1 ? weights[idx - 2] : 0;
                     else
@@ -264,19 +613,202 @@ VSZIP_EXPORT int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const vo
             }
         }
         for (size_t i = 0; i < idx; ++i) wsse_luma += sse_luma[i] * weights[i];
-        wsse3[0] = wsse_luma <= 0.0 ? 0 : (uint64_t)std::trunc(wsse_luma * avg_act + 0.5);
+        wsse3[0] = wsse_luma <= 0.0 ? 0 : (uint64_t)std::trunc(wsse_luma * p.avg_act + 0.5);
     }
     for (int c = 0; c < num_comps; ++c) {
         if (b < 4) {
-            wsse3[c] = res[coff[c]];
+            wsse3[c] = res[p.coff[c]];
         } else if (c > 0) {
             double wsse_chroma = 0.0;
-            for (size_t i = 0; i < cn[c]; ++i) wsse_chroma += (double)res[coff[c] + i] * weights[i];
-            const double v = wsse_chroma * avg_act + 0.5;
+            for (size_t i = 0; i < p.cn[c]; ++i) wsse_chroma += (double)res[p.coff[c] + i] * weights[i];
+            const double v = wsse_chroma * p.avg_act + 0.5;
             wsse3[c] = wsse_chroma <= 0.0 ? 0 : (uint64_t)(v < 0 ? 0 : v);
         }
     }
+}
+
+// One workgroup per block: the launches of one frame into dev[0..total).
+template <typename T>
+void launch_block_kernels(vszip_ctx *ctx, const XPlan &p, const void *const *org3, const void *const *rec3, const void *prev1, const void *prev2,
+                          const int *width3, const int *height3, const ptrdiff_t *stride3, int num_comps, int temporal, uint64_t *dev) {
+    if (p.b >= 4) {
+        XArgs a;
+        a.org = org3[0];
+        a.rec = rec3[0];
+        a.p1 = temporal ? prev1 : nullptr;
+        a.p2 = (temporal && p.tmode == 2) ? prev2 : nullptr;
+        a.stride = (int)stride3[0];
+        a.w = (int)p.w;
+        a.h = (int)p.h;
+        a.b = (int)p.b;
+        a.w_blk = (int)p.w_blk;
+        a.h_blk = (int)p.h_blk;
+        a.b_val = p.b_val;
+        a.temporal = p.tmode;
+        a.out = dev;
+        hipLaunchKernelGGL((xpsnr_luma_kernel<T>), dim3(p.w_blk, p.h_blk), dim3(256), 0, ctx->stream, a);
+    }
+    for (int c = 0; c < num_comps; ++c) {
+        if (p.cn[c] == 0) continue;
+        CArgs a;
+        a.org = org3[c];
+        a.rec = rec3[c];
+        a.stride = (int)stride3[c];
+        a.w = width3[c];
+        a.h = height3[c];
+        a.bx = (int)p.cbx[c];
+        a.by = (int)p.cby[c];
+        a.nbx = (int)p.cnbx[c];
+        a.out = dev + p.coff[c];
+        hipLaunchKernelGGL((xpsnr_sse_kernel<T>), dim3(p.cnbx[c], p.cnby[c]), dim3(256), 0, ctx->stream, a);
+    }
+}
+
+bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, int nframes, const void *const *org3, const void *const *rec3,
+                                        const void *const *prev1, const void *const *prev2, const int *width3, const int *height3, const ptrdiff_t *stride3,
+                                        int depth, int num_comps, unsigned frame_rate, int temporal, uint64_t *wsse3) {
+    if (!ctx || !org3 || !rec3 || !width3 || !height3 || !stride3 || !wsse3 || num_comps < 1 || num_comps > 3 || nframes < 0) return VSZIP_ERR_ARG;
+    if (bytes_per_sample != 1 && bytes_per_sample != 2) return vszip_set_error(ctx, VSZIP_ERR_ARG, "XPSNR : only supports 8 or 10 bit clips");
+    if (nframes == 0) return VSZIP_OK;
+    if (nframes > 65535) return vszip_set_error(ctx, VSZIP_ERR_ARG, "XPSNR : at most 65535 frames per call");
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XPlan p;
+    int rc = xpsnr_plan(ctx, width3, height3, depth, num_comps, frame_rate, temporal, p);
+    if (rc != VSZIP_OK) return rc;
+
+    // strip kernel eligibility: even planes, rows that hold whole 4-sample groups, aligned bases
+    const size_t bps = (size_t)bytes_per_sample;
+    XStripArgs sa;
+    bool strips = (p.w % 2 == 0) && (p.h % 2 == 0) && getenv("VSZIP_XPSNR_BLOCKS") == nullptr;
+    size_t tab_bytes = 0;
+    if (strips) {
+        sa.ncomp = num_comps;
+        sa.luma_act = p.b >= 4;
+        sa.bv = p.b_val;
+        sa.tmode = p.tmode;
+        for (int c = 0; c < num_comps && strips; ++c) {
+            XGeo &g = sa.g[c];
+            g.w = width3[c];
+            g.h = height3[c];
+            g.stride = (int)stride3[c];
+            const bool luma = c == 0 && sa.luma_act;
+            g.bx = luma ? (int)p.b : (int)p.cbx[c];
+            g.by = luma ? (int)p.b : (int)p.cby[c];
+            g.nbx = luma ? (int)p.w_blk : (int)p.cnbx[c];
+            g.out_off = luma ? 0 : (int)p.coff[c];
+            auto fits = [&](int v) {
+                if (g.bx % v || stride3[c] % v || stride3[c] < (ptrdiff_t)((g.w + v - 1) / v * v)) return false;
+                for (int f = 0; f < nframes; ++f) {
+                    if (!aligned_to(org3[f * num_comps + c], v * bps) || !aligned_to(rec3[f * num_comps + c], v * bps)) return false;
+                    if (luma && ((prev1 && !aligned_to(prev1[f], v * bps)) || (prev2 && !aligned_to(prev2[f], v * bps)))) return false;
+                }
+                return true;
+            };
+            g.vec = luma ? 4 : (fits(4) ? 4 : fits(2) ? 2 : 1);
+            if (luma && !fits(4)) strips = false;
+            const int rs = luma ? (p.b_val == 1 ? kRowsBv1 : kRowsBv2) : kRowsSse;
+            const int nby = (g.h + g.by - 1) / g.by;
+            g.nsx = (g.w + 64 * g.vec - 1) / (64 * g.vec);
+            g.segs = (std::min(g.by, g.h) + rs - 1) / rs;
+            g.nstrips = g.nsx * g.segs * nby;
+        }
+        if (nframes > kInlineFrames) tab_bytes = ((size_t)nframes * sizeof(XFrame) + 255) & ~(size_t)255;
+    }
+
+    const size_t res_bytes = ((size_t)nframes * p.total * sizeof(uint64_t) + 255) & ~(size_t)255;
+    const size_t wsse_bytes = ((size_t)nframes * 3 * sizeof(uint64_t) + 255) & ~(size_t)255;
+    bool dev_weigh = p.n_luma <= (size_t)kWeighMaxBlocks && getenv("VSZIP_XPSNR_HOST_WEIGH") == nullptr;
+    for (int c = 1; c < num_comps; ++c) dev_weigh = dev_weigh && (p.b < 4 || p.cn[c] <= p.n_luma);
+    rc = vszip_ensure_scratch(ctx, res_bytes + wsse_bytes + tab_bytes);
+    if (rc != VSZIP_OK) return rc;
+    rc = vszip_ensure_scalars(ctx, std::max(dev_weigh ? wsse_bytes : res_bytes, tab_bytes));
+    if (rc != VSZIP_OK) return rc;
+    uint64_t *dev = static_cast<uint64_t *>(ctx->scratch);
+
+    if (strips) {
+        auto fill = [&](XFrame &x, int f) {
+            for (int c = 0; c < 3; ++c) {
+                x.org[c] = c < num_comps ? org3[f * num_comps + c] : nullptr;
+                x.rec[c] = c < num_comps ? rec3[f * num_comps + c] : nullptr;
+            }
+            x.p1 = (temporal && prev1) ? prev1[f] : nullptr;
+            x.p2 = (temporal && p.tmode == 2 && prev2) ? prev2[f] : nullptr;
+        };
+        sa.tab = nullptr;
+        if (nframes > kInlineFrames) {
+            XFrame *host = static_cast<XFrame *>(ctx->scalars_host);  // pinned
+            for (int f = 0; f < nframes; ++f) fill(host[f], f);
+            XFrame *tab_dev = reinterpret_cast<XFrame *>(reinterpret_cast<char *>(dev) + res_bytes + wsse_bytes);
+            VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, host, (size_t)nframes * sizeof(XFrame), hipMemcpyHostToDevice, ctx->stream));
+            sa.tab = tab_dev;
+        } else {
+            for (int f = 0; f < kInlineFrames; ++f) fill(sa.inl[f], std::min(f, nframes - 1));
+        }
+        sa.out = dev;
+        sa.out_per_frame = (unsigned)p.total;
+        int nstrips = 0;
+        for (int c = 0; c < num_comps; ++c) nstrips += sa.g[c].nstrips;
+        VSZIP_HIP_CHECK(ctx, hipMemsetAsync(dev, 0, (size_t)nframes * p.total * sizeof(uint64_t), ctx->stream));
+        {
+            vszip_probe_scope probe(ctx);
+            if (bytes_per_sample == 1)
+                hipLaunchKernelGGL((xpsnr_strip_kernel<uint8_t>), dim3((nstrips + 3) / 4, nframes), dim3(256), 0, ctx->stream, sa);
+            else
+                hipLaunchKernelGGL((xpsnr_strip_kernel<uint16_t>), dim3((nstrips + 3) / 4, nframes), dim3(256), 0, ctx->stream, sa);
+        }
+    } else {
+        for (int f = 0; f < nframes; ++f) {
+            const void *q1 = prev1 ? prev1[f] : nullptr, *q2 = prev2 ? prev2[f] : nullptr;
+            if (bytes_per_sample == 1)
+                launch_block_kernels<uint8_t>(ctx, p, org3 + f * num_comps, rec3 + f * num_comps, q1, q2, width3, height3, stride3, num_comps, temporal, dev + f * p.total);
+            else
+                launch_block_kernels<uint16_t>(ctx, p, org3 + f * num_comps, rec3 + f * num_comps, q1, q2, width3, height3, stride3, num_comps, temporal, dev + f * p.total);
+        }
+    }
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    if (strips && nframes > kInlineFrames) VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the pinned buffer held the frame table
+    if (dev_weigh) {
+        WArgs wa;
+        wa.sums = dev;
+        wa.wsse = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dev) + res_bytes);
+        wa.total = (unsigned)p.total;
+        wa.w = (int)p.w;
+        wa.h = (int)p.h;
+        wa.b = (int)p.b;
+        wa.w_blk = (int)p.w_blk;
+        wa.n_luma = (int)p.n_luma;
+        wa.b_val = p.b_val;
+        wa.temporal = temporal ? 1 : 0;
+        wa.num_comps = num_comps;
+        wa.small = p.wh <= 640u * 480u;
+        for (int c = 0; c < 3; ++c) {
+            wa.coff[c] = (unsigned)p.coff[c];
+            wa.cn[c] = (unsigned)p.cn[c];
+        }
+        wa.sf = (double)((size_t)1 << (depth - 6));
+        wa.avg_act = p.avg_act;
+        hipLaunchKernelGGL(xpsnr_weigh_kernel, dim3(nframes), dim3(256), 0, ctx->stream, wa);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, wa.wsse, (size_t)nframes * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        std::copy_n(static_cast<const uint64_t *>(ctx->scalars_host), (size_t)nframes * 3, wsse3);
+        return VSZIP_OK;
+    }
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, dev, (size_t)nframes * p.total * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t *res = static_cast<const uint64_t *>(ctx->scalars_host);
+    for (int f = 0; f < nframes; ++f) xpsnr_weigh(p, res + (size_t)f * p.total, depth, num_comps, temporal, wsse3 + (size_t)f * 3);
     return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const void *const *org3, const void *const *rec3, const void *prev1, const void *prev2,
+                                  const int *width3, const int *height3, const ptrdiff_t *stride3, int depth, int num_comps, unsigned frame_rate, int temporal,
+                                  uint64_t *wsse3) {
+    return vszip_xpsnr_wsse_batch(ctx, bytes_per_sample, 1, org3, rec3, &prev1, &prev2, width3, height3, stride3, depth, num_comps, frame_rate, temporal, wsse3);
 }
 
 // getFrameXPSNR :370-374 on sqrt(f64(wsse)) (src/vapoursynth/xpsnr.zig:84-86). Host only.
