@@ -31,6 +31,10 @@ struct vszip_ctx {
     bool probe_on = false;
     std::vector<hipEvent_t> probe_events;  // begin/end pairs
     size_t probe_used = 0;
+    // XPSNR block sums: a buffer of its own that the weighting kernel leaves zeroed for the next call
+    void *xpsnr_sums = nullptr;
+    size_t xpsnr_sums_bytes = 0;
+    bool xpsnr_clean = false;
     int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
 };
 

@@ -71,6 +71,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

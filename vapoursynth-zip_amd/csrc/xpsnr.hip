@@ -410,7 +410,7 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, const T *org, co
 constexpr int kWeighMaxBlocks = 1536;  // 4 f64 arrays of this length in LDS
 
 struct WArgs {
-    const uint64_t *sums;  // [frame][total]
+    uint64_t *sums;        // [frame][total]; left zeroed
     uint64_t *wsse;        // [frame][3]
     unsigned total;
     int w, h, b, w_blk, n_luma, b_val, temporal, num_comps, small;  // small: wh <= 640*480
@@ -420,11 +420,12 @@ struct WArgs {
 
 __global__ __launch_bounds__(256) void xpsnr_weigh_kernel(const WArgs a) {
     __shared__ double W[kWeighMaxBlocks], P[3][kWeighMaxBlocks];
-    const uint64_t *res = a.sums + (size_t)blockIdx.x * a.total;
+    uint64_t *res = a.sums + (size_t)blockIdx.x * a.total;
     uint64_t *out = a.wsse + (size_t)blockIdx.x * 3;
     const int tid = threadIdx.x;
     if (a.b < 4) {
         if (tid < 3) out[tid] = tid < a.num_comps ? res[a.coff[tid]] : 0;
+        if (tid < a.num_comps) res[a.coff[tid]] = 0;
         return;
     }
     for (int idx = tid; idx < a.n_luma; idx += 256) {  // calcSquaredErrorAndWeight :268-357
@@ -463,8 +464,12 @@ __global__ __launch_bounds__(256) void xpsnr_weigh_kernel(const WArgs a) {
     __syncthreads();
     for (int idx = tid; idx < a.n_luma; idx += 256) {
         P[0][idx] = (double)res[(size_t)idx * 3] * W[idx];
+        res[(size_t)idx * 3] = res[(size_t)idx * 3 + 1] = res[(size_t)idx * 3 + 2] = 0;
         for (int c = 1; c < a.num_comps; ++c)
-            if (idx < (int)a.cn[c]) P[c][idx] = (double)res[a.coff[c] + idx] * W[idx];
+            if (idx < (int)a.cn[c]) {
+                P[c][idx] = (double)res[a.coff[c] + idx] * W[idx];
+                res[a.coff[c] + idx] = 0;
+            }
     }
     __syncthreads();
     const int c = tid >> 6;
@@ -719,15 +724,36 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
         if (nframes > kInlineFrames) tab_bytes = ((size_t)nframes * sizeof(XFrame) + 255) & ~(size_t)255;
     }
 
-    const size_t res_bytes = ((size_t)nframes * p.total * sizeof(uint64_t) + 255) & ~(size_t)255;
-    const size_t wsse_bytes = ((size_t)nframes * 3 * sizeof(uint64_t) + 255) & ~(size_t)255;
+    const size_t res_bytes = (size_t)nframes * p.total * sizeof(uint64_t);
+    const size_t wsse_bytes = (size_t)nframes * 3 * sizeof(uint64_t);
     bool dev_weigh = p.n_luma <= (size_t)kWeighMaxBlocks && getenv("VSZIP_XPSNR_HOST_WEIGH") == nullptr;
     for (int c = 1; c < num_comps; ++c) dev_weigh = dev_weigh && (p.b < 4 || p.cn[c] <= p.n_luma);
-    rc = vszip_ensure_scratch(ctx, res_bytes + wsse_bytes + tab_bytes);
-    if (rc != VSZIP_OK) return rc;
+    if (tab_bytes) {
+        rc = vszip_ensure_scratch(ctx, tab_bytes);
+        if (rc != VSZIP_OK) return rc;
+    }
     rc = vszip_ensure_scalars(ctx, std::max(dev_weigh ? wsse_bytes : res_bytes, tab_bytes));
     if (rc != VSZIP_OK) return rc;
-    uint64_t *dev = static_cast<uint64_t *>(ctx->scratch);
+    // The block sums live in a buffer of their own: the strip kernel accumulates into it with
+    // atomics, the weighting kernel zeroes what it consumed, so a steady stream of calls never
+    // pays for a memset.
+    if (res_bytes > ctx->xpsnr_sums_bytes) {
+        if (ctx->xpsnr_sums) {
+            VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->xpsnr_sums);
+            ctx->xpsnr_sums = nullptr;
+            ctx->xpsnr_sums_bytes = 0;
+        }
+        const size_t want = std::max<size_t>(res_bytes * 2, 1 << 20);
+        if (hipMalloc(&ctx->xpsnr_sums, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "XPSNR : block sum buffer allocation failed");
+        ctx->xpsnr_sums_bytes = want;
+        ctx->xpsnr_clean = false;
+    }
+    uint64_t *dev = static_cast<uint64_t *>(ctx->xpsnr_sums);
+    if (!ctx->xpsnr_clean) {
+        VSZIP_HIP_CHECK(ctx, hipMemsetAsync(dev, 0, ctx->xpsnr_sums_bytes, ctx->stream));
+        ctx->xpsnr_clean = true;
+    }
 
     if (strips) {
         auto fill = [&](XFrame &x, int f) {
@@ -742,7 +768,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
         if (nframes > kInlineFrames) {
             XFrame *host = static_cast<XFrame *>(ctx->scalars_host);  // pinned
             for (int f = 0; f < nframes; ++f) fill(host[f], f);
-            XFrame *tab_dev = reinterpret_cast<XFrame *>(reinterpret_cast<char *>(dev) + res_bytes + wsse_bytes);
+            XFrame *tab_dev = static_cast<XFrame *>(ctx->scratch);
             VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, host, (size_t)nframes * sizeof(XFrame), hipMemcpyHostToDevice, ctx->stream));
             sa.tab = tab_dev;
         } else {
@@ -752,7 +778,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
         sa.out_per_frame = (unsigned)p.total;
         int nstrips = 0;
         for (int c = 0; c < num_comps; ++c) nstrips += sa.g[c].nstrips;
-        VSZIP_HIP_CHECK(ctx, hipMemsetAsync(dev, 0, (size_t)nframes * p.total * sizeof(uint64_t), ctx->stream));
+        ctx->xpsnr_clean = false;  // until the weighting kernel has consumed the sums
         {
             vszip_probe_scope probe(ctx);
             if (bytes_per_sample == 1)
@@ -770,11 +796,11 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
         }
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
-    if (strips && nframes > kInlineFrames) VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the pinned buffer held the frame table
     if (dev_weigh) {
         WArgs wa;
         wa.sums = dev;
-        wa.wsse = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dev) + res_bytes);
+        // results go straight into the pinned host buffer (device-visible): no copy command
+        VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&wa.wsse), ctx->scalars_host, 0));
         wa.total = (unsigned)p.total;
         wa.w = (int)p.w;
         wa.h = (int)p.h;
@@ -793,12 +819,13 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
         wa.avg_act = p.avg_act;
         hipLaunchKernelGGL(xpsnr_weigh_kernel, dim3(nframes), dim3(256), 0, ctx->stream, wa);
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
-        VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, wa.wsse, (size_t)nframes * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->xpsnr_clean = true;
         VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         std::copy_n(static_cast<const uint64_t *>(ctx->scalars_host), (size_t)nframes * 3, wsse3);
         return VSZIP_OK;
     }
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, dev, (size_t)nframes * p.total * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->xpsnr_clean = false;
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, dev, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t *res = static_cast<const uint64_t *>(ctx->scalars_host);
     for (int f = 0; f < nframes; ++f) xpsnr_weigh(p, res + (size_t)f * p.total, depth, num_comps, temporal, wsse3 + (size_t)f * 3);
