@@ -129,3 +129,21 @@ def test_vcheck_on_wide_lines(dev, oracle, w):
     for kw in (dict(vcheck=2), dict(vcheck=3, dh=True)):
         got = _gpu(dev, src, 1, **kw)
         assert np.array_equal(got, oracle.eedi3(src, 1, **kw)), kw
+
+
+@pytest.mark.parametrize("w", [5, 8, 17, 31, 43, 45, 63])
+@pytest.mark.parametrize("kw", [dict(), dict(hp=True), dict(mdis=40, nrad=3), dict(mdis=31, nrad=0, vcheck=3), dict(dh=True)],
+                         ids=["default", "hp", "mdis40", "mdis31", "dh"])
+def test_short_lines(dev, oracle, w, kw):
+    """Lines shorter than the direction reach 2*mdis+nrad: every direction the reference evaluates at
+    x is bounded by min(x, w-1-x), so the result stays defined; also the horizontal variant on a
+    short height."""
+    src = np.ascontiguousarray(fx.crop_rgbs()[0][40:72, 100:100 + w])
+    got = _gpu(dev, src, 1, **kw)
+    want = oracle.eedi3(src, 1, **kw)
+    assert np.array_equal(got, want), (w, kw, int((got != want).sum()))
+    if not kw.get("dh"):
+        srct = np.ascontiguousarray(src.T)
+        if srct.shape[1] % 2 == 0:
+            got = _gpu(dev, srct, 0, horizontal=True, **kw)
+            assert np.array_equal(got, oracle.eedi3(srct, 0, horizontal=True, **kw))

@@ -63,12 +63,14 @@ __device__ __forceinline__ int src_col(bool dh, int off, int n_src) {  // :102-1
     return dh ? reflect_row(off, 2 * n_src) / 2 : reflect_row(off, n_src);
 }
 
-// Column c of a mirror-padded row (mirrorPad :107-110 is reflect-101 on both sides for
-// every column the kernels touch when w >= 2*mdis + nrad + 2).
+// Column c of a mirror-padded row (mirrorPad :107-110): reflect-101 on both sides. Only columns
+// within nrad of the line take part in an unmasked cost (a direction u is evaluated at x only for
+// u <= min(x, w-1-x)), so on lines shorter than the staging reach the columns past a single
+// reflection are staged as clamped filler that nothing reads back.
 __device__ __forceinline__ float rowv(const float *row, int c, int w) {
     c = c < 0 ? -c : c;
     c = c >= w ? 2 * (w - 1) - c : c;
-    return row[c];
+    return row[min(max(c, 0), w - 1)];
 }
 
 // Single-wave workgroups: LDS traffic is ordered by a wave-level fence, no s_barrier.
@@ -1115,8 +1117,7 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
         g.n_src = horizontal ? s.w : s.h;
         g.n_dst = dh ? 2 * g.n_src : g.n_src;
         g.n_interp = dh ? g.n_src : g.n_src / 2;
-        if (g.L < 2 * up->mdis + up->nrad + (general ? 4 : 2))
-            return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines shorter than 2*mdis+nrad+%d not built yet", name, general ? 4 : 2);
+        if (g.L < up->nrad + 2) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines shorter than nrad+2 not built yet", name);
         if (horizontal) {
             g.srcT = fl;
             fl += (size_t)g.n_src * g.L;
