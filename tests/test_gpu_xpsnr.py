@@ -131,6 +131,29 @@ def test_block_kernels_agree(dev, oracle, monkeypatch):
     assert strip == block == want
 
 
+@pytest.mark.parametrize("shape,fps", [((290, 354), 24), ((290, 354), 60), ((1156, 2054), 24), ((1156, 2054), 60)])
+def test_packed_8bit_strip_agrees(dev, oracle, monkeypatch, shape, fps):
+    """8-bit clips take the packed-arithmetic strip (v_dot4 / v_sad_u8 / packed i16); the generic
+    strip on the same frames (VSZIP_XPSNR_UNPACKED) and the oracle give the same sums. Full-range
+    noise + extreme values so that every intermediate reaches its bound."""
+    rng = np.random.default_rng(shape[0] + fps)
+    shapes = [shape, (shape[0] // 2, shape[1] // 2), (shape[0] // 2, shape[1] // 2)]
+    frames, recs = _rand_clip(rng, shapes, np.uint8, 8, 3)
+    frames[1][0][::2, ::2] = 255
+    frames[1][0][1::2, 1::2] = 0
+    recs[1][0][:] = 255 - frames[1][0]
+    want = _want(oracle, frames, recs, 8, fps)
+    dfr = [[dev.upload(p) for p in fr] for fr in frames]
+    drc = [[dev.upload(p) for p in fr] for fr in recs]
+    p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(3)]
+    p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(3)]
+    packed = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps)
+    monkeypatch.setenv("VSZIP_XPSNR_UNPACKED", "1")
+    generic = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps)
+    monkeypatch.delenv("VSZIP_XPSNR_UNPACKED")
+    assert packed == generic == want
+
+
 @pytest.mark.parametrize("shape", [(288, 352), (480, 640), (1080, 1920), (1200, 2100), (40, 44), (96, 160)])
 def test_device_weighting_is_the_host_weighting(dev, oracle, monkeypatch, shape):
     """The f64 weighting (getWSSE :437-521) runs on the device by default; the host evaluation of

@@ -172,30 +172,45 @@ struct XStripArgs {
     int luma_act;  // plane 0 carries the activity sums (b >= 4)
     int bv;        // 1 or 2 (see XArgs::b_val)
     int tmode;     // 0 none, 1 first order, 2 second order
+    int packed;    // 8-bit samples: the packed-arithmetic strip (VSZIP_XPSNR_UNPACKED=1 selects the generic one)
 };
 
-constexpr int kRowsBv1 = 8, kRowsBv2 = 16, kRowsSse = 16;
+constexpr int kRowsBv1 = 8, kRowsBv2 = 8, kRowsSse = 16;
 
+// N samples as one register-sized load (the unit every strip load is made of) and their unpacking
 template <typename T, int N>
-__device__ __forceinline__ void load_px(const T *p, int v[N]) {
+struct Raw {
+    using type = uint32_t;
+};
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <>
+struct Raw<uint16_t, 4> {
+    using type = u32x2;
+};
+template <typename T>
+using GP = const T __attribute__((address_space(1))) *;  // a plane pointer, known to be global memory
+template <typename T, int N>
+__device__ __forceinline__ typename Raw<T, N>::type load_raw(GP<T> p) {
+    if constexpr (N == 1)
+        return (uint32_t)p[0];
+    else if constexpr (sizeof(T) * N == 2)
+        return (uint32_t) * (GP<uint16_t>)p;
+    else if constexpr (sizeof(T) * N == 4)
+        return *(GP<uint32_t>)p;
+    else
+        return *(GP<u32x2>)p;
+}
+template <typename T, int N>
+__device__ __forceinline__ void unpack(typename Raw<T, N>::type q, int v[N]) {
     if constexpr (N == 1) {
-        v[0] = p[0];
-    } else if constexpr (sizeof(T) == 1 && N == 2) {
-        const uint32_t q = *reinterpret_cast<const uint16_t *>(p);
-        v[0] = q & 0xff;
-        v[1] = q >> 8;
-    } else if constexpr (sizeof(T) == 1 && N == 4) {
-        const uint32_t q = *reinterpret_cast<const uint32_t *>(p);
-        v[0] = q & 0xff;
-        v[1] = (q >> 8) & 0xff;
-        v[2] = (q >> 16) & 0xff;
-        v[3] = q >> 24;
-    } else if constexpr (sizeof(T) == 2 && N == 2) {
-        const uint32_t q = *reinterpret_cast<const uint32_t *>(p);
+        v[0] = (int)q;
+    } else if constexpr (sizeof(T) == 1) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = (q >> (8 * j)) & 0xff;
+    } else if constexpr (N == 2) {
         v[0] = q & 0xffff;
         v[1] = q >> 16;
     } else {
-        const uint2 q = *reinterpret_cast<const uint2 *>(p);
         v[0] = q.x & 0xffff;
         v[1] = q.x >> 16;
         v[2] = q.y & 0xffff;
@@ -218,26 +233,35 @@ __device__ __forceinline__ A seg_reduce(A v, int key, int lane) {
 
 __device__ __forceinline__ void add_u64(uint64_t *p, uint64_t v) { atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 
+// All strip functions are written in two phases: every load of the strip first, into register
+// arrays, with clamped (always valid) addresses and no branch in between, so that they are all in
+// flight together; then the arithmetic. Row validity is applied in the second phase.
+
 // SSE of a strip of an SSE-only plane (chroma; every plane when b < 4): calcSquaredError :214-251
 template <typename T, int VEC>
-__device__ __forceinline__ void sse_strip(const XGeo &g, const T *org, const T *rec, uint64_t *out, int sx, int brow, int seg, int lane) {
+__device__ __forceinline__ void sse_strip(const XGeo &g, GP<T> org, GP<T> rec, uint64_t *out, int sx, int brow, int seg, int lane) {
     const int ys = brow * g.by + seg * kRowsSse, ye = min(min(ys + kRowsSse, brow * g.by + g.by), g.h);
     if (ys >= ye) return;
     const int x0 = (sx * 64 + lane) * VEC;
     const bool valid = x0 < g.w;
     const int xl = valid ? x0 : 0;
+    typename Raw<T, VEC>::type qo[kRowsSse], qr[kRowsSse];
+#pragma unroll
+    for (int i = 0; i < kRowsSse; ++i) {
+        const ptrdiff_t q = (ptrdiff_t)min(ys + i, g.h - 1) * g.stride + xl;
+        qo[i] = load_raw<T, VEC>(org + q);
+        qr[i] = load_raw<T, VEC>(rec + q);
+    }
     uint64_t sse = 0;
 #pragma unroll
     for (int i = 0; i < kRowsSse; ++i) {
-        const int y = min(ys + i, g.h - 1);
-        int o[VEC], r[VEC];
-        load_px<T, VEC>(org + (ptrdiff_t)y * g.stride + xl, o);
-        load_px<T, VEC>(rec + (ptrdiff_t)y * g.stride + xl, r);
         if (ys + i < ye) {
+            int o[VEC], r[VEC];
+            unpack<T, VEC>(qo[i], o);
+            unpack<T, VEC>(qr[i], r);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const int e = o[j] - r[j];
-                const uint32_t ue = (uint32_t)abs(e);
+                const uint32_t ue = (uint32_t)abs(o[j] - r[j]);
                 if (x0 + j < g.w) sse += (uint64_t)(ue * ue);
             }
         }
@@ -248,94 +272,129 @@ __device__ __forceinline__ void sse_strip(const XGeo &g, const T *org, const T *
     if (valid && (lane == 0 || up != key)) add_u64(out + g.out_off + (size_t)brow * g.nbx + key, sse);
 }
 
+// Geometry of one luma strip and of this lane's 4 samples in it.
+template <int BV>
+struct LumaLane {
+    int w, h, oy, ys, ye, x0, xc, xlft, xrgt, key, y_act, h_act;
+    bool valid;
+    bool mx[4];  // sample j lies in the activity columns of its block
+    __device__ __forceinline__ bool init(const XGeo &g, int RS, int sx, int brow, int seg, int lane) {
+        const int b = g.bx;
+        w = g.w;
+        h = g.h;
+        oy = brow * b;
+        const int bh = min(b, h - oy);
+        ys = oy + seg * RS;
+        ye = min(ys + RS, oy + bh);
+        if (ys >= ye) return false;
+        x0 = (sx * 64 + lane) * 4;
+        valid = x0 < w;
+        xc = valid ? x0 : 0;             // centre load position
+        xlft = max(xc - BV, 0);          // left halo (BV samples ending at xc-1)
+        xrgt = min(xc + 4, w - BV);      // right halo (BV samples from xc+4)
+        key = valid ? x0 / b : -1;
+        const int ox = key * b, bw = min(b, w - ox);
+        // calcSquaredErrorAndWeight :283-286
+        const int x_act = ox > 0 ? 0 : BV;
+        y_act = oy > 0 ? 0 : BV;
+        const int w_act = (ox + bw < w) ? bw : bw - BV;
+        h_act = (oy + bh < h) ? bh : bh - BV;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xr = x0 + j - ox;
+            mx[j] = valid && x0 + j < w && xr >= x_act && xr < w_act && (BV == 1 || w_act > 12);
+        }
+        return true;
+    }
+    __device__ __forceinline__ bool act_row(int y) const { return y - oy >= y_act && y - oy < h_act; }
+};
+
 // One luma strip: SSE + spatial activity + temporal activity of a 256 x kRows window of one block
 // row. BV == 1: the 3x3 filter of spatialAct :174-212 as rows [-1,-2,-1] / [-2,12,-2] / [-1,-2,-1];
 // BV == 2: the 6x6 filter of highds :28-64 on even positions as rows A,B,C,C,B,A with
 // A = [0,-1,-1,-1,-1,0], B = [-1,-2,-3,-3,-2,-1], C = [-1,-3,12,12,-3,-1].
 template <typename T, int BV>
-__device__ __forceinline__ void luma_strip(const XStripArgs &a, const T *org, const T *rec, const T *p1, const T *p2, uint64_t *out, int sx, int brow, int seg,
+__device__ __forceinline__ void luma_strip(const XStripArgs &a, GP<T> org, GP<T> rec, GP<T> p1, GP<T> p2, uint64_t *out, int sx, int brow, int seg,
                                            int lane) {
-    constexpr int RS = BV == 1 ? kRowsBv1 : kRowsBv2;
+    constexpr int RS = BV == 1 ? kRowsBv1 : kRowsBv2, NR = RS + 2 * BV;
     const XGeo &g = a.g[0];
-    const int b = g.bx, w = g.w, h = g.h;
+    LumaLane<BV> L;
+    if (!L.init(g, RS, sx, brow, seg, lane)) return;
     const ptrdiff_t o = g.stride;
-    const int oy = brow * b, bh = min(b, h - oy);
-    const int ys = oy + seg * RS, ye = min(ys + RS, oy + bh);
-    if (ys >= ye) return;
-    const int x0 = (sx * 64 + lane) * 4;
-    const bool valid = x0 < w;
-    const int xc = valid ? x0 : 0;                     // centre load position
-    const int xlft = max(xc - BV, 0);                  // left halo (BV samples ending at xc-1)
-    const int xrgt = min(xc + 4, w - BV);              // right halo (BV samples from xc+4)
-    const int key = valid ? x0 / b : -1;
-    const int ox = key * b, bw = min(b, w - ox);
-    // calcSquaredErrorAndWeight :283-286
-    const int x_act = ox > 0 ? 0 : BV, y_act = oy > 0 ? 0 : BV;
-    const int w_act = (ox + bw < w) ? bw : bw - BV, h_act = (oy + bh < h) ? bh : bh - BV;
-    bool mx[4];  // sample j of this lane lies in the block's activity columns
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int xr = x0 + j - ox;
-        mx[j] = valid && x0 + j < w && xr >= x_act && xr < w_act && (BV == 1 || w_act > 12);
-    }
+    const int w = L.w, h = L.h, ys = L.ys, ye = L.ye, x0 = L.x0;
+    const bool valid = L.valid;
     const int tmode = a.tmode;
     const bool has1 = p1 != nullptr, has2 = p1 != nullptr && p2 != nullptr;
     const int c1 = tmode == 1 ? 1 : 2;
+
+    typename Raw<T, 4>::type qc[NR], qr[RS], q1[RS], q2[RS];
+    uint32_t ql[NR], qg[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const GP<T> row = org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o;
+        qc[i] = load_raw<T, 4>(row + L.xc);
+        ql[i] = load_raw<T, BV>(row + L.xlft);
+        qg[i] = load_raw<T, BV>(row + L.xrgt);
+    }
+#pragma unroll
+    for (int i = 0; i < RS; ++i) qr[i] = load_raw<T, 4>(rec + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+    if (tmode && has1) {
+#pragma unroll
+        for (int i = 0; i < RS; ++i) q1[i] = load_raw<T, 4>(p1 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+    }
+    if (tmode == 2 && has2) {
+#pragma unroll
+        for (int i = 0; i < RS; ++i) q2[i] = load_raw<T, 4>(p2 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+    }
 
     uint64_t sse = 0;
     uint32_t sa = 0, ta = 0;
     if constexpr (BV == 1) {
         int P[4] = {0, 0, 0, 0}, Pn[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < RS + 2; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int y = ys - 1 + i;
-            const T *row = org + (ptrdiff_t)min(max(y, 0), h - 1) * o;
             int v[6];
-            load_px<T, 4>(row + xc, v + 1);
-            v[0] = row[xlft];
-            v[5] = row[xrgt];
-            const int yr = y - 1 - oy;  // the row completed by this iteration
-            const bool emit = i >= 2 && y - 1 < ye && yr >= y_act && yr < h_act;
+            unpack<T, 4>(qc[i], v + 1);
+            v[0] = (int)ql[i];
+            v[5] = (int)qg[i];
+            const bool emit = i >= 2 && y - 1 < ye && L.act_row(y - 1);  // the row completed by this iteration
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int h1 = -(v[j] + 2 * v[j + 1] + v[j + 2]);
                 const int h0 = 12 * v[j + 1] - 2 * (v[j] + v[j + 2]);
                 const int f = P[j] + h1;
-                if (emit && mx[j]) sa += (uint32_t)abs(f);
+                if (emit && L.mx[j]) sa += (uint32_t)abs(f);
                 P[j] = Pn[j] + h0;
                 Pn[j] = h1;
             }
-            if (i >= 1 && i <= RS) {
-                const ptrdiff_t q = (ptrdiff_t)min(y, h - 1) * o + xc;
+            if (i >= 1 && i <= RS && y < ye) {
                 int r[4], t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
-                load_px<T, 4>(rec + q, r);
-                if (tmode && has1) load_px<T, 4>(p1 + q, t1);
-                if (tmode == 2 && has2) load_px<T, 4>(p2 + q, t2);
-                if (y < ye) {
+                unpack<T, 4>(qr[i - 1], r);
+                if (tmode && has1) unpack<T, 4>(q1[i - 1], t1);
+                if (tmode == 2 && has2) unpack<T, 4>(q2[i - 1], t2);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!(valid && x0 + j < w)) continue;
-                        const uint32_t ue = (uint32_t)abs(v[j + 1] - r[j]);
-                        sse += (uint64_t)(ue * ue);
-                        if (tmode) ta += 2u * (uint32_t)abs(v[j + 1] - c1 * t1[j] + t2[j]);  // tempDiff1/2 :111-170
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    if (!(valid && x0 + j < w)) continue;
+                    const uint32_t ue = (uint32_t)abs(v[j + 1] - r[j]);
+                    sse += (uint64_t)(ue * ue);
+                    if (tmode) ta += 2u * (uint32_t)abs(v[j + 1] - c1 * t1[j] + t2[j]);  // tempDiff1/2 :111-170
                 }
             }
         }
     } else {
         int Pp[2] = {0, 0}, Pn[2] = {0, 0};
 #pragma unroll
-        for (int i = 0; i < RS / 2 + 2; ++i) {
+        for (int i = 0; i < NR / 2; ++i) {
             const int y = ys - 2 + 2 * i;  // rows y, y+1
             int A[2][2], B[2][2], C[2][2], s4[2] = {0, 0};
             int ctr[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const T *row = org + (ptrdiff_t)min(max(y + rr, 0), h - 1) * o;
                 int v[8];
-                load_px<T, 4>(row + xc, v + 2);
-                load_px<T, 2>(row + xlft, v);
-                load_px<T, 2>(row + xrgt, v + 6);
+                unpack<T, 4>(qc[2 * i + rr], v + 2);
+                unpack<T, 2>(ql[2 * i + rr], v);
+                unpack<T, 2>(qg[2 * i + rr], v + 6);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int *u = v + 2 * q;
@@ -347,41 +406,38 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, const T *org, co
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ctr[rr][j] = v[2 + j];
             }
-            const int yr = y - 2 - oy;  // the row pair completed by this iteration
-            const bool emit = i >= 2 && y - 2 < ye && yr >= y_act && yr < h_act;
+            const bool emit = i >= 2 && y - 2 < ye && L.act_row(y - 2);  // the row pair completed by this iteration
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int f = Pp[q] + B[0][q] + A[1][q];
-                if (emit && mx[2 * q]) sa += (uint32_t)abs(f);
+                if (emit && L.mx[2 * q]) sa += (uint32_t)abs(f);
                 Pp[q] = Pn[q] + C[0][q] + C[1][q];
                 Pn[q] = A[0][q] + B[1][q];
             }
-            if (i >= 1 && i <= RS / 2) {
+            if (i >= 1 && i <= RS / 2 && y < ye) {
                 int s1[2] = {0, 0}, s2[2] = {0, 0};
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    const ptrdiff_t q = (ptrdiff_t)min(y + rr, h - 1) * o + xc;
+                    const int k = 2 * (i - 1) + rr;
                     int r[4], t[4];
-                    load_px<T, 4>(rec + q, r);
-                    if (y < ye) {
+                    unpack<T, 4>(qr[k], r);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t ue = (uint32_t)abs(ctr[rr][j] - r[j]);
-                            if (valid && x0 + j < w) sse += (uint64_t)(ue * ue);
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t ue = (uint32_t)abs(ctr[rr][j] - r[j]);
+                        if (valid && x0 + j < w) sse += (uint64_t)(ue * ue);
                     }
                     if (tmode && has1) {
-                        load_px<T, 4>(p1 + q, t);
+                        unpack<T, 4>(q1[k], t);
                         s1[0] += t[0] + t[1];
                         s1[1] += t[2] + t[3];
                     }
                     if (tmode == 2 && has2) {
-                        load_px<T, 4>(p2 + q, t);
+                        unpack<T, 4>(q2[k], t);
                         s2[0] += t[0] + t[1];
                         s2[1] += t[2] + t[3];
                     }
                 }
-                if (tmode && y < ye) {  // diff1st / diff2nd :66-109
+                if (tmode) {  // diff1st / diff2nd :66-109
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         if (valid && x0 + 2 * q < w) ta += 2u * (uint32_t)abs(s4[q] - c1 * s1[q] + s2[q]);
@@ -389,12 +445,169 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, const T *org, co
             }
         }
     }
-    sse = seg_reduce(sse, key, lane);
-    sa = seg_reduce(sa, key, lane);
-    ta = seg_reduce(ta, key, lane);
-    const int up = __shfl_up(key, 1, 64);
-    if (valid && (lane == 0 || up != key)) {
-        uint64_t *q = out + ((size_t)brow * g.nbx + key) * 3;
+    sse = seg_reduce(sse, L.key, lane);
+    sa = seg_reduce(sa, L.key, lane);
+    ta = seg_reduce(ta, L.key, lane);
+    const int up = __shfl_up(L.key, 1, 64);
+    if (valid && (lane == 0 || up != L.key)) {
+        uint64_t *q = out + ((size_t)brow * g.nbx + L.key) * 3;
+        add_u64(q, sse);
+        if (sa) add_u64(q + 1, sa);
+        if (ta) add_u64(q + 2, ta);
+    }
+}
+
+// The same strip for 8-bit samples with the pixels kept packed: a lane's 4 pixels stay in one
+// register, the horizontal filters are v_dot4_u32_u8 against constant weight bytes (BV == 2) or
+// packed 16-bit arithmetic on pixel pairs (BV == 1), SSE is sum(o*o) + sum(r*r) - 2 sum(o*r) from
+// three dot products, the first-order temporal difference is v_sad_u8. Every intermediate is an
+// exact integer (|f| <= 3060 fits i16; a strip's dot-product sums stay below 2^23), so the sums
+// are the same numbers as luma_strip's.
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ uint32_t abs_dot2(v2s v, uint32_t mask, uint32_t acc) {  // acc + |v.lo| * mask.lo + |v.hi| * mask.hi
+    const v2s a = __builtin_elementwise_max(v, -v);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, mask), acc, false);
+}
+
+template <int BV>
+__device__ __forceinline__ void luma_strip_u8(const XStripArgs &a, GP<uint8_t> org, GP<uint8_t> rec, GP<uint8_t> p1, GP<uint8_t> p2, uint64_t *out, int sx,
+                                              int brow, int seg, int lane) {
+    constexpr int RS = BV == 1 ? kRowsBv1 : kRowsBv2, NR = RS + 2 * BV;
+    const XGeo &g = a.g[0];
+    LumaLane<BV> L;
+    if (!L.init(g, RS, sx, brow, seg, lane)) return;
+    const ptrdiff_t o = g.stride;
+    const int w = L.w, h = L.h, ys = L.ys, ye = L.ye, x0 = L.x0;
+    const bool valid = L.valid;
+    const uint32_t vm = !valid ? 0u : (x0 + 3 < w ? 0xffffffffu : 0x0000ffffu);  // bytes of this lane inside the plane (w is even)
+    const int tmode = a.tmode;
+    const bool has1 = p1 != nullptr, has2 = p1 != nullptr && p2 != nullptr;
+
+    uint32_t qc[NR], ql[NR], qg[NR], qr[RS], q1[RS], q2[RS];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const GP<uint8_t> row = org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o;
+        qc[i] = load_raw<uint8_t, 4>(row + L.xc);
+        ql[i] = load_raw<uint8_t, BV>(row + L.xlft);
+        qg[i] = load_raw<uint8_t, BV>(row + L.xrgt);
+    }
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+        qr[i] = load_raw<uint8_t, 4>(rec + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+        q1[i] = q2[i] = 0;
+    }
+    if (tmode && has1) {
+#pragma unroll
+        for (int i = 0; i < RS; ++i) q1[i] = load_raw<uint8_t, 4>(p1 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+    }
+    if (tmode == 2 && has2) {
+#pragma unroll
+        for (int i = 0; i < RS; ++i) q2[i] = load_raw<uint8_t, 4>(p2 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+    }
+
+    uint32_t oo = 0, rr2 = 0, orr = 0, sa = 0, ta = 0;
+    if constexpr (BV == 1) {
+        const uint32_t m01 = (L.mx[0] ? 1u : 0u) | (L.mx[1] ? 0x10000u : 0u), m23 = (L.mx[2] ? 1u : 0u) | (L.mx[3] ? 0x10000u : 0u);
+        const uint32_t t01 = (vm & 0xffu ? 1u : 0u) | (vm & 0xff00u ? 0x10000u : 0u);
+        const uint32_t t23 = (vm & 0xff0000u ? 1u : 0u) | (vm & 0xff000000u ? 0x10000u : 0u);
+        v2s P01 = {0, 0}, P23 = {0, 0}, N01 = {0, 0}, N23 = {0, 0};  // P: h0(y-1) - h1n(y-2); N: h1n(y-1), h1n = l + 2c + r
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int y = ys - 1 + i;
+            const uint32_t C = qc[i];
+            // pixel pairs as packed u16: centre (c0,c1) (c2,c3), left neighbours (l,c0) (c1,c2), right neighbours (c1,c2) (c3,r)
+            const v2s c01 = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c010c00u)), c23 = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c030c02u));
+            const v2s l01 = as_v2s(__builtin_amdgcn_perm(ql[i], C, 0x0c000c04u)), mid = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c020c01u));
+            const v2s r23 = as_v2s(__builtin_amdgcn_perm(qg[i], C, 0x0c040c03u));
+            const v2s s01 = l01 + mid, s23 = mid + r23;
+            const v2s n01 = c01 * (v2s){2, 2} + s01, n23 = c23 * (v2s){2, 2} + s23;
+            const v2s h01 = c01 * (v2s){12, 12} - s01 * (v2s){2, 2}, h23 = c23 * (v2s){12, 12} - s23 * (v2s){2, 2};
+            if (i >= 2 && y - 1 < ye && L.act_row(y - 1)) {
+                sa = abs_dot2(P01 - n01, m01, sa);
+                sa = abs_dot2(P23 - n23, m23, sa);
+            }
+            P01 = h01 - N01;
+            P23 = h23 - N23;
+            N01 = n01;
+            N23 = n23;
+            if (i >= 1 && i <= RS && y < ye) {
+                const uint32_t Cm = C & vm, Rm = qr[i - 1] & vm, T1 = q1[i - 1], T2 = q2[i - 1];
+                oo = dot4(Cm, Cm, oo);
+                rr2 = dot4(Rm, Rm, rr2);
+                orr = dot4(Cm, Rm, orr);
+                if (tmode == 1) {
+                    ta = __builtin_amdgcn_sad_u8(Cm, T1 & vm, ta);  // tempDiff1 :111-140
+                } else if (tmode == 2) {                             // tempDiff2 :142-170: |o - 2 p1 + p2|
+                    const v2s a01 = as_v2s(__builtin_amdgcn_perm(0u, T1, 0x0c010c00u)), a23 = as_v2s(__builtin_amdgcn_perm(0u, T1, 0x0c030c02u));
+                    const v2s b01 = as_v2s(__builtin_amdgcn_perm(0u, T2, 0x0c010c00u)), b23 = as_v2s(__builtin_amdgcn_perm(0u, T2, 0x0c030c02u));
+                    ta = abs_dot2(c01 - a01 * (v2s){2, 2} + b01, t01, ta);
+                    ta = abs_dot2(c23 - a23 * (v2s){2, 2} + b23, t23, ta);
+                }
+            }
+        }
+    } else {
+        int Pp[2] = {0, 0}, Pn[2] = {0, 0};
+        const bool tq[2] = {valid, valid && x0 + 2 < w};
+#pragma unroll
+        for (int i = 0; i < NR / 2; ++i) {
+            const int y = ys - 2 + 2 * i;
+            uint32_t An[2][2], Bn[2][2], s4[2] = {0, 0};
+            int Cs[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t C = qc[2 * i + r], LL = ql[2 * i + r], RR = qg[2 * i + r];
+                // position 0 sees (LL.b0, LL.b1, C.b0..b3), position 1 (C.b0..b3, RR.b0, RR.b1); weights are per byte, lowest first
+                An[r][0] = dot4(C, 0x00010101u, dot4(LL, 0x00000100u, 0));
+                Bn[r][0] = dot4(C, 0x01020303u, dot4(LL, 0x00000201u, 0));
+                Cs[r][0] = (int)dot4(C, 0x00000c0cu, 0) - (int)dot4(C, 0x01030000u, dot4(LL, 0x00000301u, 0));
+                An[r][1] = dot4(C, 0x01010100u, dot4(RR, 0x00000001u, 0));
+                Bn[r][1] = dot4(C, 0x03030201u, dot4(RR, 0x00000102u, 0));
+                Cs[r][1] = (int)dot4(C, 0x0c0c0000u, 0) - (int)dot4(C, 0x00000301u, dot4(RR, 0x00000103u, 0));
+                s4[0] = dot4(C, 0x00000101u, s4[0]);
+                s4[1] = dot4(C, 0x01010000u, s4[1]);
+            }
+            const bool emit = i >= 2 && y - 2 < ye && L.act_row(y - 2);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = Pp[q] - (int)Bn[0][q] - (int)An[1][q];
+                if (emit && L.mx[2 * q]) sa += (uint32_t)abs(f);
+                Pp[q] = Pn[q] + Cs[0][q] + Cs[1][q];
+                Pn[q] = -(int)An[0][q] - (int)Bn[1][q];
+            }
+            if (i >= 1 && i <= RS / 2 && y < ye) {
+                uint32_t s1[2] = {0, 0}, s2[2] = {0, 0};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = 2 * (i - 1) + r;
+                    const uint32_t Cm = qc[2 * i + r] & vm, Rm = qr[k] & vm;
+                    oo = dot4(Cm, Cm, oo);
+                    rr2 = dot4(Rm, Rm, rr2);
+                    orr = dot4(Cm, Rm, orr);
+                    s1[0] = dot4(q1[k], 0x00000101u, s1[0]);
+                    s1[1] = dot4(q1[k], 0x01010000u, s1[1]);
+                    s2[0] = dot4(q2[k], 0x00000101u, s2[0]);
+                    s2[1] = dot4(q2[k], 0x01010000u, s2[1]);
+                }
+                if (tmode) {  // diff1st / diff2nd :66-109
+                    const int c1 = tmode == 1 ? 1 : 2;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (tq[q]) ta += (uint32_t)abs((int)s4[q] - c1 * (int)s1[q] + (int)s2[q]);
+                }
+            }
+        }
+    }
+    uint64_t sse = (uint64_t)(oo + rr2 - 2u * orr);
+    ta *= 2u;
+    sse = seg_reduce(sse, L.key, lane);
+    sa = seg_reduce(sa, L.key, lane);
+    ta = seg_reduce(ta, L.key, lane);
+    const int up = __shfl_up(L.key, 1, 64);
+    if (valid && (lane == 0 || up != L.key)) {
+        uint64_t *q = out + ((size_t)brow * g.nbx + L.key) * 3;
         add_u64(q, sse);
         if (sa) add_u64(q + 1, sa);
         if (ta) add_u64(q + 2, ta);
@@ -491,7 +704,7 @@ __global__ __launch_bounds__(256) void xpsnr_weigh_kernel(const WArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void xpsnr_strip_kernel(const XStripArgs a) {
     const int lane = threadIdx.x & 63;
-    int sid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int sid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the strip geometry in SGPRs
     int c = 0;
     while (c < a.ncomp && sid >= a.g[c].nstrips) sid -= a.g[c++].nstrips;
     if (c >= a.ncomp) return;
@@ -507,12 +720,26 @@ __global__ __launch_bounds__(256) void xpsnr_strip_kernel(const XStripArgs a) {
     uint64_t *out = a.out + (size_t)blockIdx.y * a.out_per_frame;
     const int sx = sid % g.nsx, t = sid / g.nsx;
     const int brow = t / g.segs, seg = t - brow * g.segs;
-    const T *o = static_cast<const T *>(org), *r = static_cast<const T *>(rec);
+    // the plane pointers come out of a table: type them as global memory (global_load instead of
+    // flat_load, which would also tie up the LDS counter)
+    const GP<T> o = (GP<T>)org, r = (GP<T>)rec, t1 = (GP<T>)p1, t2 = (GP<T>)p2;
     if (c == 0 && a.luma_act) {
-        if (a.bv == 1)
-            luma_strip<T, 1>(a, o, r, static_cast<const T *>(p1), static_cast<const T *>(p2), out, sx, brow, seg, lane);
-        else
-            luma_strip<T, 2>(a, o, r, static_cast<const T *>(p1), static_cast<const T *>(p2), out, sx, brow, seg, lane);
+        if constexpr (sizeof(T) == 1) {
+            if (a.packed == 0) {
+                if (a.bv == 1)
+                    luma_strip<T, 1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+                else
+                    luma_strip<T, 2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+            } else if (a.bv == 1) {
+                luma_strip_u8<1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+            } else {
+                luma_strip_u8<2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+            }
+        } else if (a.bv == 1) {
+            luma_strip<T, 1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+        } else {
+            luma_strip<T, 2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+        }
     } else if (g.vec == 4) {
         sse_strip<T, 4>(g, o, r, out, sx, brow, seg, lane);
     } else if (g.vec == 2) {
@@ -695,6 +922,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
         sa.luma_act = p.b >= 4;
         sa.bv = p.b_val;
         sa.tmode = p.tmode;
+        sa.packed = getenv("VSZIP_XPSNR_UNPACKED") == nullptr;
         for (int c = 0; c < num_comps && strips; ++c) {
             XGeo &g = sa.g[c];
             g.w = width3[c];
