@@ -44,6 +44,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        from vszip_amd.capi import _share_torch_hip_runtime
+
+        _share_torch_hip_runtime()  # one HIP runtime per process (see capi.py)
         l = C.CDLL(str(LIB))
         vp, i, i64 = C.c_void_p, C.c_int, C.c_int64
         l.fakevs_load_plugin.argtypes = [C.c_char_p, C.c_char_p, i]

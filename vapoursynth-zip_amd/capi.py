@@ -91,6 +91,28 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.7 (same soname as the system one). Two HIP
+    runtimes in one process do not work (the second finds no device), and whichever is loaded
+    first wins the soname: when torch is installed but not imported yet, load ITS runtime first, so
+    that libvszip_hip.so and a later `import torch` share one — the same state as importing torch
+    before this module. Without torch installed the system runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")  # does not import torch
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.is_file():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """dlopen libvszip_hip.so and declare every exported entry point."""
     global _lib
@@ -100,6 +122,7 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python vapoursynth-zip_amd/build.py` "
                 "(there is no CPU fallback)"
             )
+        _share_torch_hip_runtime()
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export it

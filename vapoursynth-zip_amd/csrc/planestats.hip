@@ -517,8 +517,10 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     char *p = static_cast<char *>(ctx->scratch);
     prm.partial = reinterpret_cast<double *>(p);
     p += (size_t)blocks * 4 * sizeof(double);
-    prm.result = reinterpret_cast<double *>(p);
     p += (size_t)nplanes * 4 * sizeof(double);
+    // the final kernels write the per-plane results straight into the pinned host buffer
+    // (device-visible): the call ends with a synchronise, no copy command
+    VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&prm.result), ctx->scalars_host, 0));
     prm.hist = reinterpret_cast<uint32_t *>(p);
     p += (size_t)nplanes * 512 * sizeof(uint32_t);
     prm.bucket = reinterpret_cast<uint32_t *>(p);
@@ -526,8 +528,6 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
 }
 
 int fetch(vszip_ctx *ctx, const Launch &L, double *r0, double *r1, double *r2) {
-    const size_t bytes = (size_t)L.prm.nplanes * 4 * sizeof(double);
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, L.prm.result, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double *h = static_cast<const double *>(ctx->scalars_host);
     for (int i = 0; i < L.prm.nplanes; ++i) {

@@ -503,11 +503,10 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
     const size_t need = bytes_part + bytes_avg + bytes_tab + (size_t)npairs * f_pair * sizeof(float) + 1024;
     int rc = vszip_ensure_scratch(ctx, need);
     if (rc != VSZIP_OK) return rc;
-    rc = vszip_ensure_scalars(ctx, bytes_avg);
+    rc = vszip_ensure_scalars(ctx, std::max(bytes_avg, bytes_tab));
     if (rc != VSZIP_OK) return rc;
     char *base = static_cast<char *>(ctx->scratch);
     double *partial = reinterpret_cast<double *>(base);
-    double *avg_dev = reinterpret_cast<double *>(base + bytes_part);
     PairPtrs *tab_dev = reinterpret_cast<PairPtrs *>(base + bytes_part + bytes_avg);
     float *fbase = reinterpret_cast<float *>(base + bytes_part + bytes_avg + bytes_tab);
 
@@ -519,7 +518,8 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
         sw[s] = (sw[s - 1] + 1) / 2;
         sh[s] = (sh[s - 1] + 1) / 2;
     }
-    std::vector<PairPtrs> tab((size_t)kScales * npairs);
+    // staged in the pinned buffer (the final kernel overwrites it with the averages, later in stream order)
+    PairPtrs *tab = static_cast<PairPtrs *>(ctx->scalars_host);
     for (int pair = 0; pair < npairs; ++pair) {
         float *fxyb = fbase + (size_t)pair * f_pair;
         float *pyrA = fxyb + f_xyb;   // scales 1, 3
@@ -544,12 +544,12 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
             }
         }
     }
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab.data(), tab.size() * sizeof(PairPtrs), hipMemcpyHostToDevice, ctx->stream));
-    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `tab` is pageable host memory
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab, (size_t)kScales * npairs * sizeof(PairPtrs), hipMemcpyHostToDevice, ctx->stream));
 
     FinalArgs fin;
     fin.partial = partial;
-    fin.avg = avg_dev;
+    // the averages go straight into the pinned host buffer (device-visible): no copy command at the end
+    VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&fin.avg), ctx->scalars_host, 0));
     fin.max_tiles = tiles0;
     for (int i = 0; i < 18; ++i) {
         fin.ntiles[i] = 0;
@@ -597,7 +597,6 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
     }
     hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(64), 0, ctx->stream, fin);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, avg_dev, (size_t)npairs * 18 * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
     for (int pair = 0; pair < npairs; ++pair) scores[pair] = score_of(avg[pair]);
