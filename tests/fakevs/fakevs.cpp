@@ -12,7 +12,10 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../vapoursynth-zip_amd/plugin/VapourSynth4_min.h"
@@ -40,9 +43,47 @@ struct VSMap {
         return items.back().second;
     }
 };
+// Plane memory comes from a size-keyed pool, like VapourSynth's frame memory pool: a steady
+// pipeline recycles (already touched) buffers instead of mapping fresh pages per frame.
+struct PlanePool {
+    std::mutex mu;
+    std::multimap<size_t, uint8_t *> idle;
+    size_t idle_bytes = 0;
+    bool refill = true;  // tests: recycled planes are poisoned again; the throughput tool turns it off
+    uint8_t *take(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = idle.find(bytes);
+            if (it != idle.end()) {
+                uint8_t *p = it->second;
+                idle.erase(it);
+                idle_bytes -= bytes;
+                if (refill) memset(p, 0xA5, bytes);
+                return p;
+            }
+        }
+        void *mem = nullptr;
+        if (posix_memalign(&mem, 64, bytes)) abort();
+        memset(mem, 0xA5, bytes);  // fresh memory only: catches reads of never-written samples
+        return static_cast<uint8_t *>(mem);
+    }
+    void give(uint8_t *p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle_bytes + bytes > ((size_t)4 << 30)) {
+            free(p);
+            return;
+        }
+        idle.emplace(bytes, p);
+        idle_bytes += bytes;
+    }
+};
+static PlanePool g_planes;
 struct PlaneBuf {
     uint8_t *base = nullptr;
-    ~PlaneBuf() { free(base); }
+    size_t bytes = 0;
+    ~PlaneBuf() {
+        if (base) g_planes.give(base, bytes);
+    }
 };
 struct VSFrame {
     std::atomic<int> refs{1};
@@ -111,10 +152,8 @@ static VSFrame *frame_new(const VSVideoFormat *fmt, int w, int h, int extra_stri
         const int pw = plane_w(*fmt, w, p), ph = plane_h(*fmt, h, p);
         ptrdiff_t st = ((ptrdiff_t)pw * fmt->bytesPerSample + al - 1) / al * al + extra_stride;
         f->buf[p] = std::make_shared<PlaneBuf>();
-        void *mem = nullptr;
-        if (posix_memalign(&mem, 64, (size_t)st * ph + offset + 64)) abort();
-        memset(mem, 0xA5, (size_t)st * ph + offset + 64);
-        f->buf[p]->base = static_cast<uint8_t *>(mem);
+        f->buf[p]->bytes = (size_t)st * ph + offset + 64;
+        f->buf[p]->base = g_planes.take(f->buf[p]->bytes);
         f->ptr[p] = f->buf[p]->base + offset;
         f->stride[p] = st;
     }
@@ -610,6 +649,7 @@ DRV int fakevs_load_plugin(const char *path, char *err, int errlen) {
     return 0;
 }
 DRV void fakevs_set_alignment(int bytes) { g_core.frame_alignment = bytes; }
+DRV void fakevs_set_pool_refill(int on) { g_planes.refill = on != 0; }
 DRV int fakevs_plugin_info(const char *ns, char *id, int idlen, int *version, int *nfuncs) {
     VSPlugin *p = A(getPluginByNamespace)(ns, &g_core);
     if (!p) return -1;
@@ -669,6 +709,31 @@ DRV VSNode *fakevs_map_node(VSMap *m, const char *k) {
 }
 DRV const VSFrame *fakevs_get_frame(VSNode *n, int i, char *err, int errlen) { return A(getFrame)(i, n, err, errlen); }
 DRV void fakevs_frame_free(const VSFrame *f) { frame_unref(f); }
+// What a VapourSynth output loop does under fmParallel: `threads` workers pull `count` frames
+// (frame numbers first, first+1, ... modulo the clip length) and drop them. Returns the number of
+// failed frames; *seconds is the wall time of the whole pull.
+DRV int fakevs_pull(VSNode *n, int first, int count, int threads, double *seconds) {
+    std::atomic<int> next{0}, failed{0};
+    const int nframes = n->vi.numFrames;
+    auto work = [&] {
+        char err[256];
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= count) break;
+            const VSFrame *f = A(getFrame)((first + k) % nframes, n, err, (int)sizeof(err));
+            if (f)
+                frame_unref(f);
+            else
+                failed.fetch_add(1);
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return failed.load();
+}
 DRV uint8_t *fakevs_frame_plane(const VSFrame *f, int p, int *w, int *h, ptrdiff_t *stride) {
     *w = plane_w(f->fmt, f->w, p);
     *h = plane_h(f->fmt, f->h, p);

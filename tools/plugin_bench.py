@@ -1,0 +1,48 @@
+"""End-to-end throughput of the VapourSynth plugin (libvszip.so) through the VapourSynth-free host
+tests/fakevs: worker threads call getFrame like fmParallel does; every frame crosses PCIe both ways
+from/to ordinary (pageable) frame memory. Prints one JSON line per (filter, threads)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fixtures as fx  # noqa: E402
+from fakevs import fakevs as vs  # noqa: E402
+
+
+def clip_4k16(n):
+    base = [fx.splitmix64_plane(p, s, np.uint16) for p, s in enumerate([(2160, 3840), (1080, 1920), (1080, 1920)])]
+    return vs.source([[np.roll(p, 7 * f, axis=1) for p in base] for f in range(n)], vs.YUV420P16)
+
+
+def clip_1080p8(n):
+    base = [fx.tiled_natural(s, np.uint8, p) for p, s in enumerate([(1080, 1920), (540, 960), (540, 960)])]
+    return vs.source([[np.roll(p, 5 * f, axis=1) for p in base] for f in range(n)], vs.YUV420P8)
+
+
+def main():
+    threads = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "4", "8", "16", "32"])]
+    vs.lib().fakevs_set_pool_refill(0)  # a real host does not touch recycled frame memory
+    src4k = clip_4k16(16)
+    src1080 = clip_1080p8(16)
+    rec1080 = vs.source([[np.clip(p.astype(np.int16) + 2, 0, 255).astype(np.uint8) for p in [np.asarray(src1080.get_frame(f)[q]) for q in range(3)]] for f in range(16)],
+                        vs.YUV420P8)
+    legs = [
+        ("BoxBlur r=13 4K YUV420P16", src4k.vszip.BoxBlur(hradius=13, vradius=13), 25 * 2, 128),
+        ("Bilateral sigmaS=2 sigmaR=0.02 4K YUV420P16", src4k.vszip.Bilateral(sigmaS=2.0, sigmaR=0.02), 25 * 2, 64),
+        ("PlaneAverage 4K YUV420P16", src4k.vszip.PlaneAverage(exclude=[-1]), 25, 128),
+        ("XPSNR 1080p YUV420P8", src1080.vszip.XPSNR(rec1080), 3.1 * 2, 256),
+    ]
+    for name, clip, mb_per_frame, count in legs:
+        clip.pull(16, 8)  # warm-up: contexts, slabs, LUTs
+        for t in threads:
+            sec = clip.pull(count, t)
+            print(json.dumps({"filter": name, "threads": t, "frames_per_s": round(count / sec, 1), "pcie_GBps": round(count * mb_per_frame / 1e3 / sec, 2)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
