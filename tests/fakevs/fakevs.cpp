@@ -6,6 +6,7 @@
 // It is built against the same VapourSynth4_min.h as the plugin (see that header's note).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <chrono>
+#include <cmath>
 #include <thread>
 #include <vector>
 
@@ -478,7 +480,7 @@ static bool check_args(const std::string &fname, const std::string &sig, const V
         if (end == std::string::npos) end = sig.size();
         const std::string item = sig.substr(pos, end - pos);
         pos = end + 1;
-        if (item.empty()) continue;
+        if (item.empty() || item == "any") continue;
         std::vector<std::string> parts;
         size_t q = 0;
         while (true) {
@@ -513,7 +515,7 @@ static bool check_args(const std::string &fname, const std::string &sig, const V
         }
     }
     for (auto &kv : args->items) {
-        bool ok = false;
+        bool ok = sig.find(";any") != std::string::npos;  // e.g. std.SetFrameProps "clip:vnode;any"
         for (auto &k : known) ok = ok || k == kv.first;
         if (!ok) {
             A(mapSetError)(out, (fname + ": no argument named " + kv.first).c_str());
@@ -648,6 +650,134 @@ DRV int fakevs_load_plugin(const char *path, char *err, int errlen) {
     g_core.plugins.push_back(std::move(p));
     return 0;
 }
+// ---------------------------------------------------------------------------
+// Stand-ins for the two core functions the plugin delegates to (opt-in, tests only):
+// std.SetFrameProps and resize.Point as a plain depth conversion. They are NOT zimg: Point here
+// is round-to-nearest full-range scaling (limited-range YUV integer clips: a shift), evaluated
+// eagerly over the whole clip. They exist so that the plugin's delegation plumbing (which
+// function, which arguments, node ownership) runs in the test host; the arithmetic of the real
+// resize plugin stays outside this repository's parity claims.
+// ---------------------------------------------------------------------------
+static std::vector<std::string> g_standin_log;  // "std.SetFrameProps _Range=1", "resize.Point format=... dither_type=none"
+
+static VSNode *eager_clone(VSNode *src, const VSVideoFormat *fmt) {
+    VSNode *n = new VSNode();
+    n->vi = src->vi;
+    n->vi.format = *fmt;
+    n->name = "Standin";
+    return n;
+}
+
+static void VS_CC standin_set_frame_props(const VSMap *in, VSMap *out, void *, VSCore *, const VSAPI *) {
+    int err = 0;
+    VSNode *src = A(mapGetNode)(in, "clip", 0, &err);
+    VSNode *n = eager_clone(src, &src->vi.format);
+    std::string log = "std.SetFrameProps";
+    for (int i = 0; i < src->vi.numFrames; ++i) {
+        char e[256];
+        const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+        VSFrame *c = A(copyFrame)(f, &g_core);
+        frame_unref(f);
+        for (auto &kv : in->items) {
+            if (kv.first == "clip") continue;
+            if (kv.second.type == ptInt) {
+                A(mapSetInt)(&c->props, kv.first.c_str(), kv.second.i[0], maReplace);
+                if (i == 0) log += " " + kv.first + "=" + std::to_string(kv.second.i[0]);
+            }
+        }
+        n->frames.push_back(c);
+    }
+    g_standin_log.push_back(log);
+    node_unref(src);
+    A(mapSetNode)(out, "clip", n, maReplace);
+    node_unref(n);
+}
+
+static double sample_at(const VSFrame *f, int p, int x, int y) {
+    const uint8_t *row = f->ptr[p] + (ptrdiff_t)y * f->stride[p];
+    if (f->fmt.sampleType == stFloat) return f->fmt.bytesPerSample == 4 ? reinterpret_cast<const float *>(row)[x] : 0.0;
+    if (f->fmt.bytesPerSample == 1) return row[x];
+    if (f->fmt.bytesPerSample == 2) return reinterpret_cast<const uint16_t *>(row)[x];
+    return reinterpret_cast<const uint32_t *>(row)[x];
+}
+
+static void VS_CC standin_point(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *) {
+    int err = 0;
+    VSNode *src = A(mapGetNode)(in, "clip", 0, &err);
+    const int64_t id = A(mapGetInt)(in, "format", 0, &err);
+    VSVideoFormat fmt;
+    if (err || !A(getVideoFormatByID)(&fmt, (uint32_t)id, core) || fmt.sampleType != stInteger || fmt.bytesPerSample > 2) {
+        A(mapSetError)(out, "resize: stand-in supports integer 8..16 bit targets only");
+        node_unref(src);
+        return;
+    }
+    int e2 = 0;
+    const char *dither = A(mapGetData)(in, "dither_type", 0, &e2);
+    g_standin_log.push_back("resize.Point format=" + std::to_string(id) + (e2 ? "" : std::string(" dither_type=") + dither));
+    VSNode *n = eager_clone(src, &fmt);
+    const VSVideoFormat &sf = src->vi.format;
+    for (int i = 0; i < src->vi.numFrames; ++i) {
+        char e[256];
+        const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+        VSFrame *c = frame_new(&fmt, src->vi.width, src->vi.height);
+        map_copy(&f->props, &c->props);
+        int pe = 0;
+        const bool full = A(mapGetInt)(&f->props, "_Range", 0, &pe) == 1 && !pe;
+        for (int p = 0; p < fmt.numPlanes; ++p) {
+            const int pw = plane_w(fmt, c->w, p), ph = plane_h(fmt, c->h, p);
+            for (int y = 0; y < ph; ++y)
+                for (int x = 0; x < pw; ++x) {
+                    const double v = sample_at(f, p, x, y);
+                    double o;
+                    const double peak_out = (double)((1u << fmt.bitsPerSample) - 1);
+                    if (sf.sampleType == stFloat)
+                        o = v * peak_out;
+                    else if (full || sf.colorFamily == cfRGB)
+                        o = v * peak_out / (double)((1ull << sf.bitsPerSample) - 1);
+                    else
+                        o = fmt.bitsPerSample >= sf.bitsPerSample ? v * (double)(1u << (fmt.bitsPerSample - sf.bitsPerSample)) : v / (double)(1u << (sf.bitsPerSample - fmt.bitsPerSample));
+                    const long q = (long)std::floor(std::min(std::max(o, 0.0), peak_out) + 0.5);
+                    uint8_t *row = c->ptr[p] + (ptrdiff_t)y * c->stride[p];
+                    if (fmt.bytesPerSample == 1)
+                        row[x] = (uint8_t)q;
+                    else
+                        reinterpret_cast<uint16_t *>(row)[x] = (uint16_t)q;
+                }
+        }
+        frame_unref(f);
+        n->frames.push_back(c);
+    }
+    node_unref(src);
+    A(mapSetNode)(out, "clip", n, maReplace);
+    node_unref(n);
+}
+
+DRV void fakevs_enable_core_standins(int on) {
+    auto &pl = g_core.plugins;
+    for (size_t i = 0; i < pl.size();)
+        if (pl[i]->id == "com.vapoursynth.std" || pl[i]->id == "com.vapoursynth.resize")
+            pl.erase(pl.begin() + i);
+        else
+            ++i;
+    g_standin_log.clear();
+    if (!on) return;
+    auto st = std::make_unique<VSPlugin>();
+    st->id = "com.vapoursynth.std";
+    st->ns = "std";
+    st->funcs["SetFrameProps"] = Func{"clip:vnode;any", "clip:vnode;", standin_set_frame_props, nullptr};
+    pl.push_back(std::move(st));
+    auto rs = std::make_unique<VSPlugin>();
+    rs->id = "com.vapoursynth.resize";
+    rs->ns = "resize";
+    rs->funcs["Point"] = Func{"clip:vnode;format:int:opt;dither_type:data:opt;", "clip:vnode;", standin_point, nullptr};
+    pl.push_back(std::move(rs));
+}
+DRV int fakevs_standin_log(int i, char *buf, int len) {
+    if (i < 0 || i >= (int)g_standin_log.size()) return 0;
+    snprintf(buf, (size_t)len, "%s", g_standin_log[i].c_str());
+    return 1;
+}
+
 DRV void fakevs_set_alignment(int bytes) { g_core.frame_alignment = bytes; }
 DRV void fakevs_set_pool_refill(int on) { g_planes.refill = on != 0; }
 DRV int fakevs_plugin_info(const char *ns, char *id, int idlen, int *version, int *nfuncs) {

@@ -168,6 +168,21 @@ def source(frames, format_id, fps=(24, 1), extra_stride=0, offset=0, props=None)
     return Clip(node)
 
 
+def core_standins(on: bool):
+    """Register (or remove) the test host's stand-ins for std.SetFrameProps and resize.Point — the
+    two core functions the plugin delegates depth conversions to (fakevs.cpp explains what they
+    are and are not)."""
+    lib().fakevs_enable_core_standins(1 if on else 0)
+
+
+def standin_log():
+    out, buf, i = [], C.create_string_buffer(256), 0
+    while lib().fakevs_standin_log(i, buf, 256):
+        out.append(buf.value.decode())
+        i += 1
+    return out
+
+
 def blank(format_id, w, h, color, length=1, fps=(24, 1)) -> Clip:
     """std.BlankClip"""
     dt = _np_dtype(format_id)

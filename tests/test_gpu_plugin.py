@@ -246,3 +246,41 @@ def test_second_clips_through_plugin(oracle):
     sc = np.ascontiguousarray(fx.crop_rgbs()[2][:128, :200])
     e = vs.source([[f]], vs.GRAYS).vszip.EEDI3(field=1, dh=1, sclip=vs.source([[sc]], vs.GRAYS)).get_frame(0)
     assert np.array_equal(e[0], oracle.eedi3(f, 1, dh=True, sclip=sc))
+
+
+def test_depth_conversions_are_delegated_to_the_host(oracle):
+    """mclip that is not 8-bit Gray: std.SetFrameProps(_Range=1) + resize.Point(format=Gray8)
+    (src/vapoursynth/eedi3.zig:411-432); XPSNR clips of different depth: resize.Point with
+    dither_type=none on the shallower one (src/helper.zig:470-494, xpsnr.zig:163-169). The host
+    functions are the test host's stand-ins; what is checked is the delegation (calls, arguments,
+    ownership) and that the filter then runs on the converted clip."""
+    f = np.ascontiguousarray(fx.crop_rgbs()[1][:64, :200])
+    mask16 = np.zeros((64, 200), np.uint16)
+    mask16[10:30, 50:120] = 40000
+    mask16[40:50, 10:40] = 90
+    src = vs.source([[f]], vs.GRAYS)
+    with pytest.raises(vs.Error, match="needs the host's std and resize plugins"):
+        src.vszip.EEDI3(field=1, mclip=vs.source([[mask16]], vs.GRAY16))
+    y8 = fx.tiled_natural((96, 160), np.uint8, 0)
+    c8 = [fx.tiled_natural((48, 80), np.uint8, 1 + i) for i in range(2)]
+    ref8 = [[y8] + c8] * 2
+    dis10 = [[np.clip(p.astype(np.int32) * 4 + 5, 0, 1023).astype(np.uint16) for p in fr] for fr in ref8]
+    with pytest.raises(vs.Error, match="different bit depth need the host's resize plugin"):
+        vs.source(ref8, vs.YUV420P8).vszip.XPSNR(vs.source(dis10, vs.YUV420P10))
+    vs.core_standins(True)
+    try:
+        got = src.vszip.EEDI3(field=1, mclip=vs.source([[mask16]], vs.GRAY16)).get_frame(0)
+        assert vs.standin_log() == ["std.SetFrameProps _Range=1", f"resize.Point format={vs.GRAY8}"]
+        mask8 = np.floor(mask16.astype(np.float64) * 255 / 65535 + 0.5).astype(np.uint8)
+        assert np.array_equal(got[0], oracle.eedi3(f, 1, mclip=mask8))
+        assert not np.array_equal(got[0], oracle.eedi3(f, 1))  # the mask does gate something
+        vs.core_standins(True)  # clears the log
+        clip = vs.source(ref8, vs.YUV420P8).vszip.XPSNR(vs.source(dis10, vs.YUV420P10), verbose=0)
+        assert vs.standin_log() == [f"resize.Point format={vs.YUV420P10} dither_type=none"]
+        props = clip.get_frame(1).props
+        ref10 = [(p.astype(np.uint16) << 2) for p in ref8[0]]
+        w = oracle.xpsnr_wsse(ref10, dis10[0], ref10[0], None, depth=10, frame_rate=24, temporal=True)
+        assert props["XPSNR_Y"] == oracle.xpsnr_frame(w[0], 160, 96, 10)
+        assert props["XPSNR_U"] == oracle.xpsnr_frame(w[1], 80, 48, 10)
+    finally:
+        vs.core_standins(False)

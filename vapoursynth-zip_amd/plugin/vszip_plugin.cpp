@@ -689,6 +689,30 @@ struct SsimData {
     VSNode *node1, *node2;
 };
 
+// hz.bitDepth (helper.zig:470-494): depth conversion is the host's resize.Point with the given
+// dither, exactly like the reference. Consumes `node`; NULL (node freed) when the host has no
+// resize plugin or the conversion fails.
+VSNode *bit_depth(const Z &z, int bits, VSNode *node, const char *dither) {
+    const VSAPI *api = z.api;
+    const VSVideoInfo *vi = api->getVideoInfo(node);
+    if (vi->format.bitsPerSample == bits) return node;
+    VSPlugin *resize = api->getPluginByID("com.vapoursynth.resize", z.core);
+    if (!resize) {
+        api->freeNode(node);
+        return nullptr;
+    }
+    const uint32_t id = api->queryVideoFormatID(vi->format.colorFamily, vi->format.sampleType, bits, vi->format.subSamplingW, vi->format.subSamplingH, z.core);
+    VSMap *args = api->createMap();
+    api->mapConsumeNode(args, "clip", node, maReplace);
+    api->mapSetInt(args, "format", id, maReplace);
+    api->mapSetData(args, "dither_type", dither, -1, dtUtf8, maReplace);
+    VSMap *ret = api->invoke(resize, "Point", args);
+    VSNode *conv = z.getNode(ret, "clip");
+    api->freeMap(ret);
+    api->freeMap(args);
+    return conv;
+}
+
 // hz.toRGBS + sRGBtoLinearRGB (helper.zig:225-243, ssimulacra2.zig:132-162): delegated to the
 // host's resize/std plugins exactly like the reference; a host without them can only feed RGBS
 // clips that are already linear (_Transfer == 8).
@@ -929,12 +953,20 @@ void VS_CC xpsnrCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const 
     }
     d->node2 = z.getNode(in, "distorted");
     const VSVideoInfo *v2 = api->getVideoInfo(d->node2);
-    if (v1->format.bitsPerSample != v2->format.bitsPerSample) {
-        // hz.bitDepth (helper.zig:470-494) delegates to resize.Point; equal depths are required here
-        z.setError(out, "XPSNR : clips of different bit depth need the host's resize plugin; convert before calling");
-        api->freeNode(d->node1);
-        api->freeNode(d->node2);
-        return;
+    if (v1->format.bitsPerSample != v2->format.bitsPerSample) {  // xpsnr.zig:163-169: the shallower clip is raised to the deeper one
+        const int b1 = v1->format.bitsPerSample, b2 = v2->format.bitsPerSample;
+        if (b1 < b2)
+            d->node1 = bit_depth(z, b2, d->node1, "none");
+        else
+            d->node2 = bit_depth(z, b1, d->node2, "none");
+        if (!d->node1 || !d->node2) {
+            z.setError(out, "XPSNR : clips of different bit depth need the host's resize plugin; convert before calling");
+            if (d->node1) api->freeNode(d->node1);
+            if (d->node2) api->freeNode(d->node2);
+            return;
+        }
+        v1 = api->getVideoInfo(d->node1);
+        v2 = api->getVideoInfo(d->node2);
     }
     d->vi = v1;
     if (!compare_nodes(z, out, d->node1, d->node2, 0, "XPSNR")) return;
@@ -1113,8 +1145,35 @@ void eedi3_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *api, b
         if (mv->format.colorFamily != cfGray) return bail("%s: mclip must be Gray.", name);
         if (mv->width != d->vi.width || mv->height != d->vi.height) return bail("%s: mclip's dimensions don't match.", name);
         if (mv->numFrames != d->vi.numFrames) return bail("%s: mclip's number of frames doesn't match.", name);
-        // the reference converts other depths with std.SetFrameProps + resize.Point (:411-432); this build takes the 8-bit mask as is
-        if (mv->format.bitsPerSample != 8 || mv->format.sampleType != stInteger) return bail("%s: mclip must be 8-bit Gray in the MI355X build (convert it with resize.Point first).", name);
+        if (mv->format.bitsPerSample != 8 || mv->format.sampleType != stInteger) {
+            // :411-432: std.SetFrameProps(_Range=1) then resize.Point(format=Gray8), both the host's
+            VSPlugin *stdp = api->getPluginByID("com.vapoursynth.std", core), *resize = api->getPluginByID("com.vapoursynth.resize", core);
+            if (!stdp || !resize) return bail("%s: an mclip that is not 8-bit Gray needs the host's std and resize plugins (convert it with resize.Point first).", name);
+            VSMap *args = api->createMap();
+            api->mapConsumeNode(args, "clip", mclip, maReplace);
+            mclip = nullptr;  // ownership moved into `args`
+            api->mapSetInt(args, "_Range", 1, maReplace);
+            VSMap *ret = api->invoke(stdp, "SetFrameProps", args);
+            api->clearMap(args);
+            VSNode *ranged = z.getNode(ret, "clip");
+            api->freeMap(ret);
+            if (ranged) {
+                api->mapConsumeNode(args, "clip", ranged, maReplace);
+                api->mapSetInt(args, "format", pfGray8, maReplace);
+                ret = api->invoke(resize, "Point", args);
+                const char *err = api->mapGetError(ret);
+                if (err) {
+                    const std::string msg = err;
+                    api->freeMap(ret);
+                    api->freeMap(args);
+                    return bail("%s", msg.c_str());
+                }
+                mclip = z.getNode(ret, "clip");
+                api->freeMap(ret);
+            }
+            api->freeMap(args);
+            if (!mclip) return bail("%s: mclip conversion to 8-bit Gray failed.", name);
+        }
     }
     if (field > 1) {
         if (d->vi.numFrames > INT32_MAX / 2) return bail("%s: resulting clip is too long.", name);
