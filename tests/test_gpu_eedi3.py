@@ -121,9 +121,10 @@ def test_errors(dev):
         dev.eedi3([odd], 1)
 
 
-@pytest.mark.parametrize("w", [4097, 7680])
+@pytest.mark.parametrize("w", [4097, 7680, 8200, 16500])
 def test_vcheck_on_wide_lines(dev, oracle, w):
-    """Lines wider than the pipelined vcheck kernels serve (8K frames) take the wide-line kernel."""
+    """Lines wider than the pipelined vcheck kernels serve (8K frames) take the wide-line kernel;
+    beyond 8192 samples the blended line pair lives in global scratch instead of LDS."""
     rng = np.random.default_rng(w)
     src = rng.random((16, w)).astype(np.float32)
     for kw in (dict(vcheck=2), dict(vcheck=3, dh=True)):

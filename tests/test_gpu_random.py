@@ -179,3 +179,11 @@ def test_boxblur_rt_huge_radius(dev, oracle):
     s, d = dev.upload(p8), dev.empty(64, 2300, np.uint8)
     dev.boxblur([s], [d], 1030, 1, 0, 0)
     assert np.array_equal(dev.download(d), oracle.boxblur(p8, 1030, 1, 0, 0))
+
+
+def test_boxblur_rt_very_wide_rows(dev, oracle):
+    """Rows far wider than any video line (the ring kernel keeps three chunks, not the row, in LDS)."""
+    p = fx.splitmix64_plane(14, (24, 20000), np.uint16)
+    s, d = dev.upload(p), dev.empty(24, 20000, np.uint16)
+    dev.boxblur([s], [d], 30, 2, 9, 1)
+    assert np.array_equal(dev.download(d), oracle.boxblur(p, 30, 2, 9, 1))

@@ -464,6 +464,8 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                     hipLaunchKernelGGL((boxblur_rt_hring_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
                 } else {
                     const size_t lds = (size_t)((maxw + CH - 1) / CH) * CH * sizeof(uint32_t);
+                    if (lds > 64000)  // only the whole-row-prefix kernels keep a row in LDS; the ring kernel above serves any width
+                        return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: a horizontal radius of %d on rows longer than 15000 samples is not built", radius);
                     hipLaunchKernelGGL((boxblur_rt_hrow_kernel<T>), dim3(blocks), dim3(64), lds, ctx->stream, prm);
                 }
             } else if (aligned) {
@@ -489,6 +491,8 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                 }
                 hipLaunchKernelGGL((boxblur_rt_vband_kernel<T>), dim3(vb), dim3(64), 0, ctx->stream, vp);
             } else if (!vertical) {
+                if ((size_t)maxw * sizeof(uint32_t) > 64000)
+                    return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: rows longer than 16000 samples need 16-byte aligned planes on the RT integer path");
                 hipLaunchKernelGGL((boxblur_rt_hint_kernel<T>), dim3(blocks), dim3(256), (size_t)maxw * sizeof(uint32_t), ctx->stream, prm);
             } else {
                 hipLaunchKernelGGL((boxblur_rt_vint_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
@@ -515,8 +519,6 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
     for (int i = 0; i < nplanes; ++i) {
         off[i] = elems;
         elems += (size_t)((planes[i].w + 63) & ~63) * planes[i].h;
-        if (std::is_integral<T>::value && hb && (size_t)(planes[i].w + 1024) * sizeof(uint32_t) > 60000)
-            return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "BoxBlur: rows longer than 15000 samples not built yet on the RT integer path");
     }
     T *scratch[2] = {nullptr, nullptr};
     if (total > 1) {

@@ -663,6 +663,8 @@ struct VParams {
     int scstride[kMaxPlanesE];
     int field, dh, vcheck, hp;
     float vthresh2, rcp0, rcp1, rcp2;
+    float *gline;  // wide kernel, lines that do not fit LDS: 2 lines per plane in global memory (NULL: LDS)
+    int gline_pitch;
 };
 
 // vcheckLine (:915-1046), hp = false. Line pd blends against line pd-2 AS ALREADY BLENDED, so
@@ -886,9 +888,11 @@ __device__ __forceinline__ float vcheck_pixel(const VParams &prm, int L, int i, 
     return (1.0f - a) * dl[i] + a * cint;
 }
 
-// vcheckLine for very wide lines (4096 < L <= 8192, e.g. 8K frames): the chain without any
-// cross-line pipelining — every line prepares and resolves its pixels in column chunks of 1024,
-// the blended line is handed on through (dynamic) LDS. Correct first; not tuned.
+// vcheckLine for very wide lines (L > 4096, e.g. 8K frames): the chain without any cross-line
+// pipelining — every line prepares and resolves its pixels in column chunks of 1024, the blended
+// line is handed on through (dynamic) LDS, or through two lines of global scratch per plane when a
+// line pair does not fit LDS (L > 8192; a workgroup's own global writes are visible to it after
+// __syncthreads). Correct first; not tuned.
 __global__ __launch_bounds__(1024) void eedi3_vcheck_wide_kernel(const VParams prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     const EPlane pl = prm.p[blockIdx.x];
@@ -897,6 +901,10 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_wide_kernel(const VParams p
     const int L = pl.w;
     const int tid = threadIdx.x;
     float *prevl[2] = {reinterpret_cast<float *>(vsm), reinterpret_cast<float *>(vsm) + L};
+    if (prm.gline) {
+        prevl[0] = prm.gline + (size_t)blockIdx.x * 2 * prm.gline_pitch;
+        prevl[1] = prevl[0] + prm.gline_pitch;
+    }
     int cur = 0;
     bool have_prev = false;
     for (int off = 1; off + 1 < pl.n_interp; ++off) {
@@ -1132,7 +1140,13 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
         pb += (size_t)g.n_interp * g.L * tpitch;
         dm += (size_t)g.n_interp * g.L;
     }
-    const size_t bytes = fl * sizeof(float) + dm * sizeof(int) + pb + mb + 4096;
+    size_t bytes = (fl * sizeof(float) + dm * sizeof(int) + pb + mb + 4096 + 255) & ~(size_t)255;
+    const size_t gline_off = bytes;  // vcheck on lines wider than 8192: two lines per plane
+    {
+        int maxL = 0;
+        for (int i = 0; i < nplanes; ++i) maxL = std::max(maxL, geo[i].L);
+        if (up->vcheck > 0 && maxL > 8192) bytes += (size_t)nplanes * 2 * ((maxL + 63) & ~63) * sizeof(float);
+    }
     int rc = vszip_ensure_scratch(ctx, bytes);
     if (rc != VSZIP_OK) return rc;
     char *base = static_cast<char *>(ctx->scratch);
@@ -1245,16 +1259,17 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (up->vcheck > 0) {
-        for (int i = 0; i < nplanes; ++i)
-            if (geo[i].L > 8192) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: vcheck on lines longer than 8192 not built yet", name);
         int maxL = 0;
         for (int i = 0; i < nplanes; ++i) maxL = std::max(maxL, geo[i].L);
+        vp.gline = nullptr;
+        vp.gline_pitch = (maxL + 63) & ~63;
+        if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
         if (maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL"))
             hipLaunchKernelGGL(eedi3_vcheck_lds_kernel, dim3(nplanes), dim3(1024), (size_t)maxL * (7 * sizeof(float) + 4), ctx->stream, vp);
         else if (maxL <= 4096)
             hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
         else
-            hipLaunchKernelGGL(eedi3_vcheck_wide_kernel, dim3(nplanes), dim3(1024), (size_t)maxL * 2 * sizeof(float), ctx->stream, vp);
+            hipLaunchKernelGGL(eedi3_vcheck_wide_kernel, dim3(nplanes), dim3(1024), vp.gline ? 0 : (size_t)maxL * 2 * sizeof(float), ctx->stream, vp);
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (horizontal) {
