@@ -29,7 +29,7 @@ def test_average_matches_oracle(dev, oracle, dtype):
             a[::3, ::5] = 100
         else:
             a[::3, ::5] = 1.0
-        for excl in ([-1], [100, 7], [1]):
+        for excl in ([-1], [100, 7], [1], list(range(90, 130)) + [7, 7, 0, 1]):  # the last: 40+ values, duplicates
             da, db = dev.upload(a), dev.upload(b)
             avg, diff = dev.plane_average([da], excl, [db])
             oavg, odiff = oracle.plane_average(a, excl, b)

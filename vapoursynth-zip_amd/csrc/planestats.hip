@@ -28,11 +28,13 @@ struct PSPlane {
     int nblocks;
 };
 
+constexpr int kMaxExclude = 256;  // distinct exclude values per call (the list travels in the kernel argument)
+
 struct PSParams {
     PSPlane p[kMaxPlanesPS];
     int nplanes;
     int rows_per_block;
-    int32_t excl[8];
+    int32_t excl[kMaxExclude];
     int nexcl;
     double *partial;     // [total_blocks][4]: avg: sum, count, diff ; minmax: min, max, diff
     uint32_t *hist;      // [nplanes][2][256]
@@ -132,7 +134,8 @@ __device__ __forceinline__ int find_plane(const PSParams &prm, int b) {
 // ---- PlaneAverage ---------------------------------------------------------------
 // NEX: compile-time size of the exclude list (0, 1 or 8 entries; a list shorter than NEX is
 // padded with copies of its first entry by the host) — the common exclude=[-1] on an integer
-// clip can never match and compiles to no compare at all.
+// clip can never match and compiles to no compare at all. NEX < 0: a longer list, walked at run
+// time from the kernel argument (scalar loads).
 template <typename T, bool REF, int NEX>
 __global__ __launch_bounds__(kThreads) void average_kernel(const PSParams prm) {
     using S = Smp<T>;
@@ -161,6 +164,14 @@ __global__ __launch_bounds__(kThreads) void average_kernel(const PSParams prm) {
                     found = found || ((int32_t)v == ex[e]);
                 else
                     found = found || (S::f(v) == (float)ex[e]);
+            }
+            if constexpr (NEX < 0) {
+                for (int e = 0; e < prm.nexcl; ++e) {
+                    if constexpr (S::is_int)
+                        found = found || ((int32_t)v == prm.excl[e]);
+                    else
+                        found = found || (S::f(v) == (float)prm.excl[e]);
+                }
             }
             if (!found) {
                 if constexpr (S::is_int) acc += v; else acc += (double)S::f(v);
@@ -546,7 +557,7 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
     for (int i = 0; i < L.prm.nexcl; ++i)
         if (!Smp<T>::is_int || (L.prm.excl[i] >= 0 && L.prm.excl[i] <= (int32_t)L.prm.peak)) L.prm.excl[n++] = L.prm.excl[i];
     L.prm.nexcl = n;
-    const int nex = n == 0 ? 0 : (n == 1 ? 1 : 8);
+    const int nex = n == 0 ? 0 : (n == 1 ? 1 : (n <= 8 ? 8 : -1));
     for (int i = n; i < nex; ++i) L.prm.excl[i] = L.prm.excl[0];
     const dim3 grid(L.total_blocks), block(kThreads);
 #define VSZIP_AVG_LAUNCH(NEX)                                                                        \
@@ -560,8 +571,10 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
         VSZIP_AVG_LAUNCH(0);
     else if (nex == 1)
         VSZIP_AVG_LAUNCH(1);
-    else
+    else if (nex == 8)
         VSZIP_AVG_LAUNCH(8);
+    else
+        VSZIP_AVG_LAUNCH(-1);
 #undef VSZIP_AVG_LAUNCH
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (Smp<T>::is_int)
@@ -599,13 +612,19 @@ int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr) {
 
 VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
                                      double *avg, double *diff) {
-    if (nexclude < 0 || nexclude > 8) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneAverage: at most 8 exclude values");
+    if (nexclude < 0 || (nexclude > 0 && !exclude)) return VSZIP_ERR_ARG;
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
     Launch L;
     int rc = prepare(ctx, planes, nplanes, ref, L);
     if (rc != VSZIP_OK) return rc;
-    L.prm.nexcl = nexclude;
-    for (int i = 0; i < nexclude; ++i) L.prm.excl[i] = exclude[i];
+    L.prm.nexcl = 0;
+    for (int i = 0; i < nexclude; ++i) {  // distinct values only: membership is all the kernel tests
+        bool seen = false;
+        for (int k = 0; k < L.prm.nexcl; ++k) seen = seen || L.prm.excl[k] == exclude[i];
+        if (seen) continue;
+        if (L.prm.nexcl == kMaxExclude) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "PlaneAverage: more than %d distinct exclude values", kMaxExclude);
+        L.prm.excl[L.prm.nexcl++] = exclude[i];
+    }
     L.prm.peak = (float)(((uint64_t)1 << bits_per_sample) - 1);  // planeaverage.zig(vs):115
     switch (dtype) {
         case VSZIP_U8: rc = run_average<uint8_t>(ctx, L, ref); break;

@@ -668,7 +668,6 @@ void plane_stat_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *a
         d->key_a = pfx + "Avg";
         const int ne = std::max(0, api->mapNumElements(in, "exclude"));
         if (d->dt == VSZIP_U32 && ne > 0) return bail("PlaneAverage: exclude is not supported for 32-bit integer clips.");
-        if (ne > 8) return bail("PlaneAverage: more than 8 exclude values are not available in the MI355X build yet");
         for (int i = 0; i < ne; ++i) {
             const int64_t v = z.getInt(in, "exclude", 0, i);
             d->exclude.push_back((int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, v)));  // math.lossyCast(i32, ...)
