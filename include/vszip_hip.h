@@ -103,7 +103,7 @@ int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int npla
  * (src/filters/planeaverage.zig:26,47) called from src/vapoursynth/planeaverage.zig:55-61.
  * planes[i].ref != NULL on plane 0 selects the clipb variant for all planes.
  * `exclude` is the i32 list of the wrapper (:122-137; compared as @floatFromInt for
- * float clips), at most 8 values. bits_per_sample gives peak = 2^bits - 1 (:115).
+ * float clips), any length (up to 256 distinct values). bits_per_sample gives peak = 2^bits - 1 (:115).
  * Results are written to host arrays avg[nplanes] and (clipb) diff[nplanes]; the call
  * synchronises the stream. Integer planes are exact; float planes differ from the
  * reference's sequential f64 sum by rounding only.
