@@ -187,3 +187,20 @@ def test_boxblur_rt_very_wide_rows(dev, oracle):
     s, d = dev.upload(p), dev.empty(24, 20000, np.uint16)
     dev.boxblur([s], [d], 30, 2, 9, 1)
     assert np.array_equal(dev.download(d), oracle.boxblur(p, 30, 2, 9, 1))
+
+
+def test_more_planes_than_one_kernel_table(dev, oracle):
+    """Calls with more planes than a kernel-argument table holds (48) are split into batches inside
+    the library: plane statistics, EEDI3, Bilateral."""
+    rng = np.random.default_rng(4242)
+    planes = [rng.integers(0, 65536, size=(40 + i % 7, 72 + 8 * (i % 5)), dtype=np.uint16) for i in range(110)]
+    dp = [dev.upload(p) for p in planes]
+    avg, _ = dev.plane_average(dp, exclude=[-1])
+    mn, mx, _ = dev.plane_minmax(dp, 0.05, 0.05)
+    for i, p in enumerate(planes):
+        assert avg[i] == oracle.plane_average(p)[0]
+        assert (mn[i], mx[i]) == oracle.plane_minmax(p, 0.05, 0.05)[:2]
+    fl = [rng.random((24, 96 + 8 * (i % 3))).astype(np.float32) for i in range(60)]
+    outs = dev.eedi3([dev.upload(p) for p in fl], 1)
+    for i in (0, 47, 48, 59):
+        assert np.array_equal(dev.download(outs[i]), oracle.eedi3(fl[i], 1))

@@ -1081,9 +1081,24 @@ VSZIP_EXPORT int vszip_eedi3(vszip_ctx *ctx, const vszip_plane *planes, const fl
     return vszip_eedi3_mclip(ctx, planes, sclips, sclip_strides, nullptr, nullptr, nplanes, field, horizontal, up);
 }
 
+static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips, const ptrdiff_t *sclip_strides, const uint8_t *const *mclips,
+                       const ptrdiff_t *mclip_strides, int nplanes, int field, int horizontal, const vszip_eedi3_params *up);
+
+// Any number of planes per call: batches of kMaxPlanesE (the per-plane tables travel in the kernel arguments).
 VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips, const ptrdiff_t *sclip_strides,
                                    const uint8_t *const *mclips, const ptrdiff_t *mclip_strides, int nplanes, int field, int horizontal,
                                    const vszip_eedi3_params *up) {
+    if (!ctx || !planes || !up || nplanes <= 0) return VSZIP_ERR_ARG;
+    for (int o = 0; o < nplanes; o += kMaxPlanesE) {
+        const int rc = eedi3_batch(ctx, planes + o, sclips ? sclips + o : nullptr, sclip_strides ? sclip_strides + o : nullptr, mclips ? mclips + o : nullptr,
+                                   mclip_strides ? mclip_strides + o : nullptr, std::min(kMaxPlanesE, nplanes - o), field, horizontal, up);
+        if (rc != VSZIP_OK) return rc;
+    }
+    return VSZIP_OK;
+}
+
+static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *const *sclips, const ptrdiff_t *sclip_strides, const uint8_t *const *mclips,
+                       const ptrdiff_t *mclip_strides, int nplanes, int field, int horizontal, const vszip_eedi3_params *up) {
     if (!ctx || !planes || !up || nplanes <= 0 || nplanes > kMaxPlanesE) return VSZIP_ERR_ARG;
     const char *name = horizontal ? "EEDI3H" : "EEDI3";
     // createImpl :316-410

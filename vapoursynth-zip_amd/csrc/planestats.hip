@@ -610,8 +610,8 @@ int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr) {
 
 }  // namespace
 
-VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
-                                     double *avg, double *diff) {
+static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
+                               double *avg, double *diff) {
     if (nexclude < 0 || (nexclude > 0 && !exclude)) return VSZIP_ERR_ARG;
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
     Launch L;
@@ -641,8 +641,8 @@ VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plan
     return fetch(ctx, L, avg, ref ? diff : nullptr, nullptr);
 }
 
-VSZIP_EXPORT int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
-                                    double *vmin, double *vmax, double *diff) {
+static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
+                              double *vmin, double *vmax, double *diff) {
     if (minthr < 0 || minthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: minthr should be a float between 0.0 and 1.0");
     if (maxthr < 0 || maxthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: maxthr should be a float between 0.0 and 1.0");
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
@@ -664,4 +664,27 @@ VSZIP_EXPORT int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane
     }
     if (rc != VSZIP_OK) return rc;
     return fetch(ctx, L, vmin, vmax, ref ? diff : nullptr);
+}
+
+// Any number of planes per call: batches of kMaxPlanesPS (the per-plane table travels in the kernel argument).
+VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
+                                     double *avg, double *diff) {
+    if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
+    for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
+        const int rc = plane_average_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), exclude, nexclude, bits_per_sample, avg ? avg + o : nullptr,
+                                           diff ? diff + o : nullptr);
+        if (rc != VSZIP_OK) return rc;
+    }
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
+                                    double *vmin, double *vmax, double *diff) {
+    if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
+    for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
+        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, vmin ? vmin + o : nullptr,
+                                          vmax ? vmax + o : nullptr, diff ? diff + o : nullptr);
+        if (rc != VSZIP_OK) return rc;
+    }
+    return VSZIP_OK;
 }
