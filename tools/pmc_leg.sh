@@ -1,14 +1,13 @@
 #!/bin/bash
-# GPU box: PMC passes for the current build. usage: pmc.sh <tag> "<counters set 1>" "<set 2>" ...  (BENCH_ARGS for bench flags)
-tag=$1; shift
+# GPU box: PMC passes over one bench leg (tools/prof_legs.py). usage: pmc_leg.sh <leg> "<counter set 1>" "<set 2>" ...
+leg=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/pmc_$tag
-rm -rf $out; mkdir -p $out
+out=/tmp/pmc_leg; rm -rf $out; mkdir -p $out
 n=0
 for set in "$@"; do
   n=$((n+1))
-  rocprofv3 --pmc $set --output-format csv -d $out/set$n -- python3 $R/bench.py --no-cpu --no-others --steps 4 --warmup 1 $BENCH_ARGS > /dev/null 2> $out/set$n.err
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $out/set$n -- python3 $R/tools/prof_legs.py $leg > /dev/null 2> $out/set$n.err
 done
 python3 - <<PY
 import csv, glob, collections
@@ -20,5 +19,5 @@ for f in glob.glob("$out/set*/*/*counter_collection.csv"):
         agg[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for tag, d in agg.items():
     for k, v in sorted(d.items()):
-        print(f"{tag:40s} {k:28s} {sum(v)/len(v):16.1f}")
+        print(f"{tag:40s} {k:28s} {sum(v)/len(v):18.1f}")
 PY

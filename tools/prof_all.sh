@@ -1,0 +1,22 @@
+#!/bin/bash
+# GPU box: regenerate every rocprofv3 summary of the round in one call.
+# usage: bash tools/prof_all.sh <round tag, e.g. r01>
+# Each tag gets a --kernel-trace --stats run and three PMC passes (own runs: gpurun refuses
+# pmc + tracing in one). Summaries: python3 tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<tag>
+rt=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+prof() {
+  tag=$1; shift
+  out=$R/gpurun_out/prof_$tag
+  rm -rf $out; mkdir -p $out
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 "$@" > $out/bench_trace.json 2> $out/trace.err
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 "$@" > /dev/null 2> $out/pmc_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write -- python3 "$@" > /dev/null 2> $out/pmc_write.err
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_sq -- python3 "$@" > /dev/null 2> $out/pmc_sq.err
+}
+prof ${rt}_boxblur $R/bench.py --no-cpu --no-others --steps 20 --warmup 3
+prof ${rt}_bilateral $R/bench.py --no-cpu --no-others --workload bilateral --steps 10 --warmup 2
+prof ${rt}_ssimulacra2 $R/bench.py --no-cpu --no-others --workload ssimulacra2 --steps 5 --warmup 1
+prof ${rt}_legs $R/tools/prof_legs.py eedi3 xpsnr boxblur_other planestats
+ls $R/gpurun_out | grep prof_${rt}

@@ -98,17 +98,16 @@ template <int NRAD, int MD>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     constexpr int kRowW = kXB + 2 * (2 * MD + 3) + 16;  // staged columns per source row: block + reach 2*mdis + nrad each side (+16: see the cost phase)
     constexpr int kTbW = kXB + 2 * MD + 2 * 3 + 8;      // longest t_base span
-    constexpr int kPtW = (2 * MD + 1 + 3) & ~3;
     const float kFltMax09 = FLT_MAX * 0.9f;
     __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
-    __shared__ float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
+    __shared__ __attribute__((aligned(16))) float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
     __shared__ float ctile[2 * MD + 1][kXB + 1];
     __shared__ int fpt[kXB];
     float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[1];
-    // the back-pointer tile lives in the same LDS as tb/ws: those are dead once a block's costs
-    // are in ctile, and every phase change is fenced (fewer bytes per wave = more waves per CU)
-    static_assert(sizeof(tbws) >= (size_t)kXB * kPtW, "back-pointer tile must fit the t_base scratch");
-    int8_t (*ptile)[kPtW] = reinterpret_cast<int8_t (*)[kPtW]>(&tbws[0][0][0]);
+    // the backtrack's back-pointer tile ([direction][column] codes of one block) lives in the same
+    // LDS as tb/ws, which are dead by then (fewer bytes per wave = more waves per CU)
+    static_assert(sizeof(tbws) >= (size_t)kXB * (2 * MD + 1), "back-pointer tile must fit the t_base scratch");
+    uint8_t (*ptile)[kXB] = reinterpret_cast<uint8_t (*)[kXB]>(&tbws[0][0][0]);
 
     int pi = 0;
     const int gl = blockIdx.x;
@@ -126,12 +125,18 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const float *r1p = pl.src + (size_t)src_col(dh, line - 1, pl.n_src) * pl.sstride;
     const float *r1n = pl.src + (size_t)src_col(dh, line + 1, pl.n_src) * pl.sstride;
     const float *r3n = pl.src + (size_t)src_col(dh, line + 3, pl.n_src) * pl.sstride;
-    int8_t *pback = pl.pback + (size_t)off * w * tpitch;
+    // back-pointer codes of this line: [block][direction][64 columns], one byte each (0: stay, 1: from
+    // the direction below, 2: from the direction above); column 63 of a block is produced by the
+    // first step of the next block
+    uint8_t *pback = reinterpret_cast<uint8_t *>(pl.pback) + (size_t)off * ((w + kXB - 1) / kXB * kXB) * tpitch;
     float *out = pl.dst + (size_t)line * pl.dstride;
     int *dmap = pl.dmap + (size_t)off * w;
     const int reach = 2 * mdis + nrad, roww = kXB + 2 * reach;
 
     float pcost = kFltMax09;  // DP state of direction `lane` (inactive lanes stay at the sentinel)
+    uint32_t held[kXB / 4];   // back-pointer codes of the previous block, waiting for their last column
+#pragma unroll
+    for (int i = 0; i < kXB / 4; ++i) held[i] = 0;
     const int nblk = (w + kXB - 1) / kXB;
     for (int blk = 0; blk < nblk; ++blk) {
         const int xb = blk * kXB;
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 span[i] = kXB + max(u, max(0, two_u)) + nrad - jlo[i];  // t_base columns xb+jlo .. xb+63+jhi
                 span_max = max(span_max, span[i]);
             }
+#ifndef VSZIP_E3_ABL_NOTB
             for (int t = lane; t < span_max; t += 64) {
                 float val[kU];
 #pragma unroll
@@ -180,9 +186,11 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
                 for (int i = 0; i < kU; ++i) tb[i][t] = val[i];
             }
+#endif
             wave_fence();
             // window sums, accumulated from 0 in k order exactly like sw0/sw1/sw2 (:443-450): the
             // three sums of a pixel are the same function of t_base at x+u, x, x+2u
+#ifndef VSZIP_E3_ABL_NOWIN
             for (int t = lane + nrad; t < span_max - nrad; t += 64) {
                 float val[kU];
 #pragma unroll
@@ -195,7 +203,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
                 for (int i = 0; i < kU; ++i) ws[i][t] = val[i];
             }
+#endif
             wave_fence();
+#ifndef VSZIP_E3_ABL_NOCOST
             {
                 const int lxc = lx;  // lanes past the line end compute on staged (clamped) columns and store nothing
                 float val[kU];
@@ -213,46 +223,71 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                     for (int i = 0; i < kU; ++i) ctile[mdis + uu[i]][lane] = val[i];
                 }
             }
+#else
+            if (x < w) {
+#pragma unroll
+                for (int i = 0; i < kU; ++i) ctile[mdis + uu[i]][lane] = (float)abs(uu[i]);
+            }
+#endif
             wave_fence();  // tb / ws are rewritten by the next pass
         }
         wave_fence();
         // ---- DP phase, lanes = direction index ---------------------------------------
         const int xe = min(kXB, w - xb);
-        for (int xl = 0; xl < xe; ++xl) {
-            const int xx = xb + xl;
-            const float tc = lane < tpitch ? ctile[lane][xl] : 0.0f;
-            if (xx == 0) {
-                pcost = lane < tpitch ? tc : kFltMax09;  // :461-463
-                continue;
-            }
-            const float left = lane_below(pcost, kFltMax09);
-            float right = lane_above(pcost, kFltMax09);
-            if (lane >= tpitch - 1) right = kFltMax09;
-            const float left_cc = left + prm.gamma, right_cc = right + prm.gamma;
+        // The Viterbi recurrence is a dependent chain along x, so nothing in it may wait on memory:
+        // the costs of the block's 64 columns are read from LDS into registers up front, the 64 steps
+        // are unrolled, the back-pointer of a step is a 2-bit code packed into registers (16 of them
+        // per block) and written out — straight to global memory, 64 bytes per direction — only after
+        // the block; lanes past the last direction get an infinite cost, which pins them at the
+        // 0.9*FLT_MAX sentinel the reference gives a missing neighbour, so no step needs a lane mask.
+        // (With the cost read and the int8 store inside the loop every step waited out an LDS round
+        // trip: the DP phase was half of the kernel's time at 1/5 of its instructions.)
+        float tcv[kXB];
+#pragma unroll
+        for (int xl = 0; xl < kXB; ++xl) tcv[xl] = lane < tpitch ? ctile[lane][xl] : INFINITY;
+        uint32_t pk[kXB / 4];
+#pragma unroll
+        for (int i = 0; i < kXB / 4; ++i) pk[i] = 0;
+        auto dp_step = [&](float tc) -> uint32_t {
+            const float left_cc = lane_below(pcost, kFltMax09) + prm.gamma, right_cc = lane_above(pcost, kFltMax09) + prm.gamma;
             float bval = pcost;  // :536-548
-            int bd = 0;
+            uint32_t code = 0;
             if (left_cc < bval) {
                 bval = left_cc;
-                bd = -1;
+                code = 1;
             }
             if (right_cc < bval) {
                 bval = right_cc;
-                bd = 1;
+                code = 2;
             }
-            if (lane < tpitch) pcost = fminf(bval + tc, kFltMax09);
-            // back-pointer of column xx-1 (:472): stored at the tile row of xx-1
-            if (xl == 0) {
-                if (lane < tpitch) pback[(size_t)(xx - 1) * tpitch + lane] = (int8_t)bd;  // last row of the previous block
-            } else if (lane < tpitch) {  // a tile row is only as wide as the directions in use
-                ptile[xl - 1][lane] = (int8_t)bd;
+            pcost = fminf(bval + tc, kFltMax09);
+            return code;
+        };
+        auto store_block = [&](const uint32_t *q, int b) {  // 64 codes of direction `lane`, block b
+            if (lane < tpitch) {
+                uint4 *dst = reinterpret_cast<uint4 *>(pback + ((size_t)b * tpitch + lane) * kXB);
+#pragma unroll
+                for (int i = 0; i < kXB / 16; ++i) dst[i] = make_uint4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
             }
+        };
+        // step 0 completes the previous block (its column 63)
+        if (blk == 0) {
+            pcost = lane < tpitch ? tcv[0] : kFltMax09;  // :461-463
+        } else {
+            held[kXB / 4 - 1] |= dp_step(tcv[0]) << 24;
+            store_block(held, blk - 1);
         }
-        wave_fence();
-        // flush the block's back-pointers (rows xb .. xb+xe-2; row xb+xe-1 comes with the next block)
-        for (int t = lane; t < (xe - 1) * tpitch; t += 64) {
-            const int r = t / tpitch, c = t - r * tpitch;
-            pback[(size_t)(xb + r) * tpitch + c] = ptile[r][c];
+        if (xe == kXB) {
+#pragma unroll
+            for (int xl = 1; xl < kXB; ++xl) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
+        } else {
+#pragma unroll
+            for (int xl = 1; xl < kXB; ++xl)
+                if (xl < xe) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
         }
+#pragma unroll
+        for (int i = 0; i < kXB / 4; ++i) held[i] = pk[i];
+        if (blk == nblk - 1) store_block(held, blk);
     }
     __syncthreads();
     __threadfence_block();
@@ -263,19 +298,22 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         const int xb = blk * kXB;
         const int xe = min(kXB, w - xb);
         __syncthreads();
-        for (int t = lane; t < xe * tpitch; t += 64) {
-            const int r = t / tpitch, c = t - r * tpitch;
-            if (xb + r < w - 1) ptile[r][c] = pback[(size_t)(xb + r) * tpitch + c];
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(pback + (size_t)blk * tpitch * kXB);
+            uint4 *dst = reinterpret_cast<uint4 *>(&ptile[0][0]);
+            for (int t = lane; t < tpitch * (kXB / 16); t += 64) dst[t] = src[t];
         }
         __syncthreads();
         if (lane == 0) {
             int fp = carry;
             for (int xl = xe - 1; xl >= 0; --xl) {
                 const int xx = xb + xl;
-                if (xx == w - 1)
+                if (xx == w - 1) {
                     fp = 0;
-                else
-                    fp = fp + ptile[xl][mdis + fp];
+                } else {
+                    const int code = ptile[mdis + fp][xl];
+                    fp += code == 1 ? -1 : (code == 2 ? 1 : 0);
+                }
                 fpt[xl] = fp;
             }
         }
@@ -1152,7 +1190,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
             if (mclips && mclips[i]) mb += (((size_t)g.n_src * g.L) + 255) & ~(size_t)255;
         }
         lines += g.n_interp;
-        pb += (size_t)g.n_interp * g.L * tpitch;
+        pb += (size_t)g.n_interp * ((g.L + kXB - 1) / kXB * kXB) * tpitch;  // the line kernel stores whole 64-column blocks
         dm += (size_t)g.n_interp * g.L;
     }
     size_t bytes = (fl * sizeof(float) + dm * sizeof(int) + pb + mb + 4096 + 255) & ~(size_t)255;
@@ -1241,7 +1279,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         d.pback = pbase + pbo;
         d.line0 = line0;
         dmo += (size_t)g.n_interp * g.L;
-        pbo += (size_t)g.n_interp * g.L * tpitch;
+        pbo += (size_t)g.n_interp * ((g.L + kXB - 1) / kXB * kXB) * tpitch;
         line0 += g.n_interp;
         maxw = std::max(maxw, g.L);
         maxsrc = std::max(maxsrc, g.n_src);
