@@ -96,8 +96,13 @@ constexpr int kU = 4;  // directions per cost pass
 // 5 waves per CU, and the kernel is latency bound.
 template <int NRAD, int MD>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
-    constexpr int kRowW = kXB + 2 * (2 * MD + 3) + 16;  // staged columns per source row: block + reach 2*mdis + nrad each side (+16: see the cost phase)
-    constexpr int kTbW = kXB + 2 * MD + 2 * 3 + 8;      // longest t_base span
+    // The t_base and window-sum steps run a fixed number of 64-entry iterations (NIT, the longest
+    // span rounded up) with no guard — entries past a direction's span are computed from padding and
+    // never read — so that the compiler emits straight-line code (with `t < span` loops it vectorised
+    // them into prologue/body/remainder blocks that cost more instructions than the arithmetic).
+    constexpr int NIT = (kXB + 2 * MD + 2 * NRAD + 63) / 64;
+    constexpr int kRowW = 64 * NIT + 2 * MD + 4;  // staged columns per source row: block + reach 2*mdis + nrad each side, padded for the overshoot
+    constexpr int kTbW = 64 * NIT + 8;            // t_base / window-sum entries per direction
     const float kFltMax09 = FLT_MAX * 0.9f;
     __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
     __shared__ __attribute__((aligned(16))) float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
@@ -162,18 +167,17 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             // keep the LDS reads of all kU directions in flight together: a direction whose span is
             // shorter than the pass's longest simply computes a few entries nobody reads (rows[],
             // tb[] and ws[] are padded for the overshoot).
-            int uu[kU], jlo[kU], span[kU];
-            int span_max = 0;
+            int uu[kU], jlo[kU];
 #pragma unroll
             for (int i = 0; i < kU; ++i) {
                 const int u = min(ug + i, mdis), two_u = 2 * u;  // past +mdis: a duplicate of the last direction (same values, same slots)
                 uu[i] = u;
-                jlo[i] = min(u, min(0, two_u)) - nrad;
-                span[i] = kXB + max(u, max(0, two_u)) + nrad - jlo[i];  // t_base columns xb+jlo .. xb+63+jhi
-                span_max = max(span_max, span[i]);
+                jlo[i] = min(u, min(0, two_u)) - nrad;  // t_base columns xb+jlo .. xb+63+max(u, 0, 2u)+nrad are the ones read back
             }
 #ifndef VSZIP_E3_ABL_NOTB
-            for (int t = lane; t < span_max; t += 64) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int t = lane + 64 * it;
                 float val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
@@ -191,7 +195,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             // window sums, accumulated from 0 in k order exactly like sw0/sw1/sw2 (:443-450): the
             // three sums of a pixel are the same function of t_base at x+u, x, x+2u
 #ifndef VSZIP_E3_ABL_NOWIN
-            for (int t = lane + nrad; t < span_max - nrad; t += 64) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int t = lane + nrad + 64 * it;
                 float val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
