@@ -22,6 +22,7 @@
 // bit-identical to the CPU oracle (the discrete path makes anything less visible).
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -107,12 +108,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
     __shared__ __attribute__((aligned(16))) float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
     __shared__ float ctile[2 * MD + 1][kXB + 1];
-    __shared__ int fpt[kXB];
     float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[1];
-    // the backtrack's back-pointer tile ([direction][column] codes of one block) lives in the same
-    // LDS as tb/ws, which are dead by then (fewer bytes per wave = more waves per CU)
-    static_assert(sizeof(tbws) >= (size_t)kXB * (2 * MD + 1), "back-pointer tile must fit the t_base scratch");
-    uint8_t (*ptile)[kXB] = reinterpret_cast<uint8_t (*)[kXB]>(&tbws[0][0][0]);
 
     int pi = 0;
     const int gl = blockIdx.x;
@@ -299,35 +295,51 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     __threadfence_block();
 
     // ---- backtrack (:557-565) + output (:577-591), block by block from the right ------------
+    // fpath[x] = fpath[x+1] + bp[x][fpath[x+1]] is a scalar chain: the block's codes come back into
+    // registers (each lane its own direction's 64 bytes), a step is v_readlane of the word that holds
+    // column xl at lane mdis+fpath, a bit-field extract and a scalar add; the path goes to the
+    // path to the lane of its column with a select. No LDS and no barrier in the chain.
     int carry = 0;  // fpath of the first column of the block to the right
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int xb = blk * kXB;
         const int xe = min(kXB, w - xb);
-        __syncthreads();
+        uint32_t q[kXB / 4];
         {
-            const uint4 *src = reinterpret_cast<const uint4 *>(pback + (size_t)blk * tpitch * kXB);
-            uint4 *dst = reinterpret_cast<uint4 *>(&ptile[0][0]);
-            for (int t = lane; t < tpitch * (kXB / 16); t += 64) dst[t] = src[t];
-        }
-        __syncthreads();
-        if (lane == 0) {
-            int fp = carry;
-            for (int xl = xe - 1; xl >= 0; --xl) {
-                const int xx = xb + xl;
-                if (xx == w - 1) {
-                    fp = 0;
-                } else {
-                    const int code = ptile[mdis + fp][xl];
-                    fp += code == 1 ? -1 : (code == 2 ? 1 : 0);
-                }
-                fpt[xl] = fp;
+            const uint4 *src = reinterpret_cast<const uint4 *>(pback + ((size_t)blk * tpitch + min(lane, tpitch - 1)) * kXB);
+#pragma unroll
+            for (int i = 0; i < kXB / 16; ++i) {
+                const uint4 v = src[i];
+                q[4 * i] = v.x;
+                q[4 * i + 1] = v.y;
+                q[4 * i + 2] = v.z;
+                q[4 * i + 3] = v.w;
             }
         }
-        __syncthreads();
-        carry = fpt[0];
+        int fp = __builtin_amdgcn_readfirstlane(carry);
+        int fpv = 0;  // lane xl: fpath of column xb + xl
+        auto walk = [&](auto full) {
+#pragma unroll
+            for (int xl = kXB - 1; xl >= 0; --xl) {
+                if (decltype(full)::value || xl < xe) {
+                    if (!decltype(full)::value && xb + xl == w - 1) {
+                        fp = 0;
+                    } else {
+                        const int word = __builtin_amdgcn_readlane((int)q[xl >> 2], mdis + fp);
+                        // code 1: -1, code 2: +1 — bit arithmetic, so that the chain stays on the scalar unit
+                        fp += ((word >> (8 * (xl & 3) + 1)) & 1) - ((word >> (8 * (xl & 3))) & 1);
+                    }
+                    fpv = lane == xl ? fp : fpv;
+                }
+            }
+        };
+        if (xe == kXB && blk != nblk - 1)
+            walk(std::true_type{});
+        else
+            walk(std::false_type{});
+        carry = fp;
         if (lane < xe) {
             const int xx = xb + lane;
-            const int dir = fpt[lane], ad = abs(dir);
+            const int dir = fpv, ad = abs(dir);
             dmap[xx] = dir;
             float v;
             if (xx >= ad * 3 && xx + ad * 3 <= w - 1)
