@@ -1004,7 +1004,61 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_wide_kernel(const VParams p
 }
 
 constexpr int kVcLdsMaxL = 1920;
+// The per-line step is paced by instruction issue on ONE CU (PMC: 214 scalar + 126 vector
+// instructions per wave and line before this form), so the kernel is specialised on hp and the
+// vcheck mode, the pixel function is branch-free (a pixel that keeps cint gathers around itself and
+// is selected out at the end — no exec-mask regions), and the ring slots of the seven rows are
+// kept incrementally instead of as r % 7.
+template <bool HP, int VC>
+__device__ __forceinline__ float vcheck_pixel_bf(const VParams &prm, int L, int i, int dirc, int dirt, int dirb, float cint, const float *d1p, const float *d1n,
+                                                 const float *dl, const float *d2p, const float *d2n) {
+    const int maxoff = !HP ? abs(dirc) : (((dirc & 1) == 0) ? abs(dirc >> 1) : max(abs(dirc >> 1), abs((dirc + 1) >> 1)));
+    const bool act = dirc != 0 && !(max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) && !(i + maxoff >= L || i - maxoff < 0);
+    const int dsafe = act ? dirc : 0;
+    float it, ib, vt, vb;
+    int dabs;
+    if (HP && (dsafe & 1) != 0) {  // :969-985
+        const int d20 = dsafe >> 1, d21 = (dsafe + 1) >> 1;
+        const int ip0 = i + d20, ip1 = i + d21, im0 = i - d20, im1 = i - d21;
+        const float s2p = d2p[ip0] + d2p[ip1], s1p = d1p[ip0] + d1p[ip1], pa0 = dl[ip0] + dl[ip1], ps0 = dl[im0] + dl[im1];
+        const float s1n = d1n[im0] + d1n[im1], s2n = d2n[im0] + d2n[im1];
+        it = (s2p + ps0) * 0.25f;
+        vt = (fabsf(s2p - s1p) + fabsf(pa0 - s1p)) * 0.5f;
+        ib = (pa0 + s2n) * 0.25f;
+        vb = (fabsf(s2n - s1n) + fabsf(ps0 - s1n)) * 0.5f;
+        dabs = abs(dsafe) >> 1;
+    } else {
+        const int offh = HP ? dsafe >> 1 : dsafe;
+        const int ipd = i + offh, imd = i - offh;
+        const float d2p_i = d2p[ipd], dl_p = dl[ipd], d1p_p = d1p[ipd], dl_m = dl[imd], d2n_m = d2n[imd], d1n_m = d1n[imd];
+        it = (d2p_i + dl_m) * 0.5f;
+        ib = (dl_p + d2n_m) * 0.5f;
+        vt = fabsf(d2p_i - d1p_p) + fabsf(dl_p - d1p_p);
+        vb = fabsf(d2n_m - d1n_m) + fabsf(dl_m - d1n_m);
+        dabs = HP ? abs(dsafe) >> 1 : abs(dsafe);
+    }
+    const float dl_i = dl[i], d1p_i = d1p[i], d1n_i = d1n[i];
+    const float vc = fabsf(dl_i - d1p_i) + fabsf(dl_i - d1n_i);
+    const float e0 = fabsf(it - d1p_i), e1 = fabsf(ib - d1n_i), e2 = fabsf(vt - vc), e3 = fabsf(vb - vc);
+    float m0, m1;
+    if (VC == 1) {
+        m0 = fminf(e0, e1);
+        m1 = fminf(e2, e3);
+    } else if (VC == 2) {
+        m0 = (e0 + e1) * 0.5f;
+        m1 = (e2 + e3) * 0.5f;
+    } else {
+        m0 = fmaxf(e0, e1);
+        m1 = fmaxf(e2, e3);
+    }
+    const float a0 = m0 * prm.rcp0, a1 = m1 * prm.rcp1;
+    const float a2 = fmaxf((prm.vthresh2 - (float)dabs) * prm.rcp2, 0.0f);
+    const float a = fminf(fmaxf(a0, fmaxf(a1, a2)), 1.0f);
+    const float blended = (1.0f - a) * dl_i + a * cint;
+    return act ? blended : cint;
+}
 
+template <bool HP, int VC>
 __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams prm) {
     constexpr int C = 2;  // columns per thread: lines up to 2048 (LDS allows 1920)
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
@@ -1041,41 +1095,59 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams pr
         }
     }
     __syncthreads();
-    for (int off = first; off <= last; ++off) {
-        const int pd = prm.field + 2 * off;
-        const bool nxt = off + 1 <= last;
-        // the next line's two new rows and map row: coalesced loads, parked in registers
-        float n4[C], n5[C], sc[C];
-        int nd[C];
+    // The rows a line adds to the ring (pd+4, pd+5, the map row off+2, its sclip row) are loaded two
+    // lines ahead and parked in registers.
+    float a4[C], a5[C], asc[C], b4[C], b5[C], bsc[C];  // a*: for line off+1 (stored at the end of this iteration), b*: for line off+2
+    int ad[C], bd[C];
+    auto fetch = [&](int o, float *n4, float *n5, int *nd, float *sc) {  // new rows of line o (line o-1 stores them)
+        const int pdo = prm.field + 2 * o;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int i = tid + c * 1024;
             n4[c] = n5[c] = sc[c] = 0.0f;
             nd[c] = 0;
-            if (i < L) {
-                if (nxt) {
-                    if (pd + 4 < n_dst) n4[c] = pl.dst[(size_t)(pd + 4) * pl.dstride + i];
-                    if (pd + 5 < n_dst) n5[c] = pl.dst[(size_t)(pd + 5) * pl.dstride + i];
-                    nd[c] = pl.dmap[(size_t)(off + 2) * L + i];
-                }
-                if (scp) sc[c] = scp[(size_t)pd * scstride + i];
+            if (i < L && o <= last) {
+                if (pdo + 2 < n_dst) n4[c] = pl.dst[(size_t)(pdo + 2) * pl.dstride + i];
+                if (pdo + 3 < n_dst) n5[c] = pl.dst[(size_t)(pdo + 3) * pl.dstride + i];
+                nd[c] = pl.dmap[(size_t)(o + 1) * L + i];
+                if (scp) sc[c] = scp[(size_t)pdo * scstride + i];
             }
         }
-        const float *d1p = row(pd - 1), *d1n = row(pd + 1), *dl = row(pd), *d2p = row(pd - 2), *d2n = row(pd + 2);
-        const float *d3p = row(reflect_row(pd - 3, n_dst)), *d3n = row(reflect_row(pd + 3, n_dst));
+    };
+    float sc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int i = tid + c * 1024;
+        sc[c] = (scp && i < L) ? scp[(size_t)(prm.field + 2 * first) * scstride + i] : 0.0f;
+    }
+    fetch(first + 1, a4, a5, ad, asc);
+    int s0 = ((prm.field + 2 * first - 3) % 7 + 7) % 7;  // ring slot of row pd-3; row pd-3+k sits in slot (s0 + k) mod 7
+    auto slot = [&](int k) -> float * {
+        int q = s0 + k;
+        q = q >= 7 ? q - 7 : q;
+        return ring + q * L;
+    };
+    for (int off = first; off <= last; ++off) {
+        const int pd = prm.field + 2 * off;
+        const bool nxt = off + 1 <= last;
+        fetch(off + 2, b4, b5, bd, bsc);
+        const float *d2p = slot(1), *d1p = slot(2), *dl = slot(3), *d1n = slot(4), *d2n = slot(5);
+        // rows pd-3 / pd+3 reflect at the frame border (only the first / last line of the chain)
+        const float *d3p = pd - 3 >= 0 ? slot(0) : row(reflect_row(pd - 3, n_dst));
+        const float *d3n = pd + 3 < n_dst ? slot(6) : row(reflect_row(pd + 3, n_dst));
         const int8_t *dc = dmr(off), *dp = dmr(off - 1), *dn = dmr(off + 1);
         float res[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int i = tid + c * 1024;
-            if (i < L) {
-                const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
-                res[c] = vcheck_pixel(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
-            }
+            const int i = min(tid + c * 1024, L - 1);  // threads past the line compute on its last column and store nothing
+            const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
+            res[c] = vcheck_pixel_bf<HP, VC>(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
         }
         __syncthreads();  // every read of the un-blended line pd is done
-        float *dlw = row(pd);
         float *gout = pl.dst + (size_t)pd * pl.dstride;
+        float *r4 = slot(0), *r5 = slot(1);  // rows pd+4 / pd+5 take the slots of rows pd-3 / pd-2
+        float *dlw = slot(3);
+        int8_t *dnew = dmr(off + 2);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int i = tid + c * 1024;
@@ -1083,12 +1155,18 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams pr
                 dlw[i] = res[c];
                 gout[i] = res[c];
                 if (nxt) {
-                    if (pd + 4 < n_dst) row(pd + 4)[i] = n4[c];
-                    if (pd + 5 < n_dst) row(pd + 5)[i] = n5[c];
-                    dmr(off + 2)[i] = (int8_t)nd[c];
+                    if (pd + 4 < n_dst) r4[i] = a4[c];
+                    if (pd + 5 < n_dst) r5[i] = a5[c];
+                    dnew[i] = (int8_t)ad[c];
                 }
             }
+            sc[c] = asc[c];
+            a4[c] = b4[c];
+            a5[c] = b5[c];
+            ad[c] = bd[c];
+            asc[c] = bsc[c];
         }
+        s0 = s0 + 2 >= 7 ? s0 - 5 : s0 + 2;
         __syncthreads();
     }
 }
@@ -1336,7 +1414,23 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         vp.gline_pitch = (maxL + 63) & ~63;
         if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
         if (maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL"))
-            hipLaunchKernelGGL(eedi3_vcheck_lds_kernel, dim3(nplanes), dim3(1024), (size_t)maxL * (7 * sizeof(float) + 4), ctx->stream, vp);
+        {
+            const size_t lds = (size_t)maxL * (7 * sizeof(float) + 4);
+#define VSZIP_VC_LAUNCH(HPV)                                                                                                   \
+    do {                                                                                                                       \
+        if (up->vcheck == 1)                                                                                                   \
+            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 1>), dim3(nplanes), dim3(1024), lds, ctx->stream, vp);           \
+        else if (up->vcheck == 2)                                                                                              \
+            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 2>), dim3(nplanes), dim3(1024), lds, ctx->stream, vp);           \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 3>), dim3(nplanes), dim3(1024), lds, ctx->stream, vp);           \
+    } while (0)
+            if (hp)
+                VSZIP_VC_LAUNCH(true);
+            else
+                VSZIP_VC_LAUNCH(false);
+#undef VSZIP_VC_LAUNCH
+        }
         else if (maxL <= 4096)
             hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
         else
