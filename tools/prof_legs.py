@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Run single bench legs (eedi3 | xpsnr | planestats) for rocprofv3 --kernel-trace --stats."""
+import json
 import sys
 from pathlib import Path
 
@@ -15,10 +16,10 @@ dev = vszip_amd.Device(0)
 timed = bench.Timed(dev, dev.sync)
 for leg in sys.argv[1:]:
     if leg == "eedi3":
-        print(bench.eedi3_leg(dev, timed, True))
+        print(json.dumps(bench.eedi3_leg(dev, timed, True)))
     elif leg == "xpsnr":
-        print(bench.xpsnr_leg(dev, timed, True))
+        print(json.dumps(bench.xpsnr_leg(dev, timed, True)))
     elif leg == "boxblur_other":
-        print(bench.boxblur_other_paths_leg(dev, timed))
+        print(json.dumps(bench.boxblur_other_paths_leg(dev, timed)))
     elif leg == "planestats":
-        print(bench.planestats_leg(dev, timed))
+        print(json.dumps(bench.planestats_leg(dev, timed)))

@@ -47,12 +47,19 @@ def main():
     bench = None
     bj = src / "bench_trace.json"
     if bj.exists():
+        lines = []
         for line in bj.read_text().splitlines():
             if line.startswith("{"):
-                bench = json.loads(line)
+                try:
+                    lines.append(json.loads(line))
+                except json.JSONDecodeError:
+                    import ast
+
+                    lines.append(ast.literal_eval(line))  # tools/prof_legs.py printed dict reprs before it printed JSON
+        bench = lines[-1] if len(lines) == 1 else (lines or None)
     json.dump({"source": str(src), "bench_line_under_tracing": bench, "kernels": pmc}, open(f"{dst}_pmc.json", "w"), indent=1)
     with open(f"{dst}.md", "w") as o:
-        o.write(f"# {dst.name}: rocprofv3 summary\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu ...` (tools/prof.sh), PMC in separate passes.\n\n")
+        o.write(f"# {dst.name}: rocprofv3 summary\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu ...` or `... tools/prof_legs.py <legs>` (tools/prof_all.sh), PMC in separate passes.\n\n")
         o.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
         for r in rows:
             o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |\n")

@@ -690,8 +690,18 @@ __global__ __launch_bounds__(256) void xpsnr_weigh_kernel(const WArgs a) {
         uint64_t v = 0;
         if (c < a.num_comps) {
             const int n = c == 0 ? a.n_luma : (int)a.cn[c];
+            // a sequential f64 chain: the operands are fetched eight at a time ahead of the adds, so a
+            // step costs one add latency, not an LDS round trip
             double acc = 0.0;
-            for (int i = 0; i < n; ++i) acc += P[c][i];
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = P[c][i + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k];
+            }
+            for (; i < n; ++i) acc += P[c][i];
             if (acc > 0.0) {
                 const double t = acc * a.avg_act + 0.5;
                 v = c == 0 ? (uint64_t)trunc(t) : (uint64_t)(t < 0 ? 0 : t);
