@@ -362,11 +362,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 // ---------------------------------------------------------------------------
 constexpr int kGMaxMdis = 40;
 constexpr int kGXB = 32;                                      // columns per block
-constexpr int kGReach = 2 * kGMaxMdis + 3 + 2;                // 2*mdis + nrad, +2 for the half-pel taps
-constexpr int kGRowW = kGXB + 2 * kGReach;
-constexpr int kGTbMax = kGXB + 2 * kGMaxMdis + 2 * 3 + 8;
-constexpr int kGNS = 3;                                       // DP states per lane: 3 * 64 >= 4 * 40 + 1
-constexpr int kGTpMax = 4 * kGMaxMdis + 1;
+constexpr int kGNit = 2;                                      // 64-entry iterations of the t_base / window steps: spans reach 32 + 80 + 6
+constexpr int kGRowW = 64 * kGNit + 2 * kGMaxMdis + 8;        // block + reach each side, padded for the fixed-count overshoot
+constexpr int kGTbMax = 64 * kGNit + 8;
 
 struct GExtra {
     const uint8_t *mask[kMaxPlanesE];  // mclip rows (NULL: no mask), geometry of the (transposed) source plane
@@ -374,13 +372,17 @@ struct GExtra {
     int hp;
 };
 
-template <int NRAD, bool HP>
+// TPMAX: the most directions the instantiation serves (81: mdis <= 40, or hp with mdis <= 20; 161: hp
+// with mdis up to 40) — it sizes the cost tile, the back-pointer tile and the DP states per lane, i.e.
+// the LDS per wave: 20 KiB instead of 36 for the 81-direction geometries.
+template <int NRAD, bool HP, int TPMAX>
 __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams prm, const GExtra ex) {
+    constexpr int kGNS = (TPMAX + 63) / 64;  // DP states per lane
     const float kFltMax09 = FLT_MAX * 0.9f;
     __shared__ float rows[4][kGRowW];  // r3p, r1p, r1n, r3n
-    __shared__ float hrow[4][kGRowW];  // their half-pel rows (computeHpRow :602-617), HP only
+    __shared__ float hrow[HP ? 4 : 1][HP ? kGRowW : 1];  // their half-pel rows (computeHpRow :602-617), HP only
     __shared__ float tbm[kGTbMax], tbh[kGTbMax], wsm[kGTbMax], wsh[kGTbMax];
-    __shared__ float ctile[kGTpMax][kGXB + 1];
+    __shared__ float ctile[TPMAX][kGXB + 1];
     __shared__ int8_t ptile[kGXB][kGNS * 64];
     __shared__ int fpt[kGXB];
     __shared__ uint8_t bmt[kGXB];
@@ -468,14 +470,15 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
         for (int u = -cen; u <= cen; ++u) {
             if (!HP) {
                 const int two_u = 2 * u;
-                const int jlo = min(u, min(0, two_u)) - nrad, jhi = max(u, max(0, two_u)) + nrad;
-                const int span = kGXB + jhi - jlo;
-                for (int t = lane; t < span; t += 64) {
+                const int jlo = min(u, min(0, two_u)) - nrad;  // t_base columns xb+jlo .. xb+31+max(u, 0, 2u)+nrad are read back
+                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
+                    const int t = lane + 64 * it;  // fixed trip count, entries past the span are padding nobody reads
                     const int j = jlo + t + reach;
                     tbm[t] = fabsf(rows[0][j] - rows[1][j - two_u]) + fabsf(rows[1][j] - rows[2][j - two_u]) + fabsf(rows[2][j] - rows[3][j - two_u]);
                 }
                 __syncthreads();
-                for (int t = lane + nrad; t < span - nrad; t += 64) {
+                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
+                    const int t = lane + nrad + 64 * it;
                     float sw = 0.0f;
 #pragma unroll
                     for (int k = -nrad; k <= nrad; ++k) sw += tbm[t + k];
@@ -496,15 +499,16 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
                 const int uh = u >> 1;
                 const bool odd = (u & 1) != 0;
                 const int lo0 = odd ? -uh - 1 : -uh;
-                const int jlo = min(0, min(u, uh)) - nrad, jhi = max(0, max(u, uh)) + nrad;
-                const int span = kGXB + jhi - jlo;
-                for (int t = lane; t < span; t += 64) {
+                const int jlo = min(0, min(u, uh)) - nrad;  // columns xb+jlo .. xb+31+max(0, u, uh)+nrad are read back
+                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
+                    const int t = lane + 64 * it;  // fixed trip count, entries past the span are padding nobody reads
                     const int j = jlo + t + reach;
                     tbm[t] = fabsf(rows[0][j] - rows[1][j - u]) + fabsf(rows[1][j] - rows[2][j - u]) + fabsf(rows[2][j] - rows[3][j - u]);
                     if (odd) tbh[t] = fabsf(hrow[0][j] - hrow[1][j - u]) + fabsf(hrow[1][j] - hrow[2][j - u]) + fabsf(hrow[2][j] - hrow[3][j - u]);
                 }
                 __syncthreads();
-                for (int t = lane + nrad; t < span - nrad; t += 64) {
+                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
+                    const int t = lane + nrad + 64 * it;
                     float sm = 0.0f, sh = 0.0f;
 #pragma unroll
                     for (int k = -nrad; k <= nrad; ++k) {
@@ -1202,10 +1206,12 @@ __global__ void transpose_u8_kernel(const uint8_t *src, uint8_t *dst, int sstrid
 
 template <int NRAD>
 void launch_general(vszip_ctx *ctx, bool hp, unsigned lines, const EParams &ep, const GExtra &gx) {
-    if (hp)
-        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, true>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
+    if (hp && 4 * ep.mdis + 1 > 81)
+        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, true, 4 * kGMaxMdis + 1>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
+    else if (hp)
+        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, true, 81>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
     else
-        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, false>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
+        hipLaunchKernelGGL((eedi3_line_general_kernel<NRAD, false, 81>), dim3(lines), dim3(64), 0, ctx->stream, ep, gx);
 }
 
 }  // namespace
