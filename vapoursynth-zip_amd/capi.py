@@ -373,9 +373,9 @@ class Device:
                                              w, h, st, depth, n, frame_rate, int(temporal), out))
         return [int(out[i]) for i in range(n)]
 
-    def xpsnr_wsse_batch(self, orgs, recs, prev1s=None, prev2s=None, depth=8, frame_rate=24, temporal=True):
-        """orgs / recs: one list of 1 or 3 DevPlanes per frame (same geometry); prev1s / prev2s: per
-        frame the luma DevPlane of frames n-1 / n-2 or None. -> [[wsse64 per plane] per frame]"""
+    def xpsnr_batch_call(self, orgs, recs, prev1s=None, prev2s=None, depth=8, frame_rate=24, temporal=True):
+        """The argument marshalling of xpsnr_wsse_batch done once: returns run() -> [[wsse64 per plane] per
+        frame] (a host that keeps its frame pointers in C arrays pays none of it per call)."""
         nf, n = len(orgs), len(orgs[0])
         flat = lambda ll: (C.c_void_p * (nf * n))(*[p.ptr for l in ll for p in l])
         prev = lambda l: (C.c_void_p * nf)(*[(p.ptr if p is not None else None) for p in l]) if l is not None else None
@@ -384,6 +384,16 @@ class Device:
         h = (C.c_int * 3)(*([p.h for p in o0] + [0] * (3 - n)))
         st = (C.c_ssize_t * 3)(*([p.stride for p in o0] + [0] * (3 - n)))
         out = (C.c_uint64 * (3 * nf))()
-        self.check(self.lib.vszip_xpsnr_wsse_batch(self.ctx, o0[0].dtype.itemsize, nf, flat(orgs), flat(recs), prev(prev1s), prev(prev2s), w, h, st, depth, n,
-                                                   frame_rate, int(temporal), out))
-        return [[int(out[3 * f + i]) for i in range(n)] for f in range(nf)]
+        fo, fr, p1, p2 = flat(orgs), flat(recs), prev(prev1s), prev(prev2s)
+        bps, keep = o0[0].dtype.itemsize, (orgs, recs, prev1s, prev2s)
+
+        def run(_keep=keep):
+            self.check(self.lib.vszip_xpsnr_wsse_batch(self.ctx, bps, nf, fo, fr, p1, p2, w, h, st, depth, n, frame_rate, int(temporal), out))
+            return [[int(out[3 * f + i]) for i in range(n)] for f in range(nf)]
+
+        return run
+
+    def xpsnr_wsse_batch(self, orgs, recs, prev1s=None, prev2s=None, depth=8, frame_rate=24, temporal=True):
+        """orgs / recs: one list of 1 or 3 DevPlanes per frame (same geometry); prev1s / prev2s: per
+        frame the luma DevPlane of frames n-1 / n-2 or None. -> [[wsse64 per plane] per frame]"""
+        return self.xpsnr_batch_call(orgs, recs, prev1s, prev2s, depth, frame_rate, temporal)()
