@@ -174,3 +174,27 @@ def test_device_weighting_is_the_host_weighting(dev, oracle, monkeypatch, shape)
     on_host = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
     monkeypatch.delenv("VSZIP_XPSNR_HOST_WEIGH")
     assert on_dev == on_host == want
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_batch_random_geometries(dev, oracle, seed):
+    """Seeded random even sizes on both sides of the 2048x1152 switch (3x3 vs highds activity), both
+    depths, both temporal orders, 4:2:0 / 4:4:4 / 4:2:2: the strip kernel (and, for widths that are
+    2 mod 4 with an unpadded stride, the per-block kernels) against the oracle."""
+    rng = np.random.default_rng(31000 + seed)
+    big = seed % 3 == 0
+    h = int(rng.integers(600, 760)) * 2 if big else int(rng.integers(9, 420)) * 2
+    w = int(rng.integers(900, 1100)) * 2 if big else int(rng.integers(9, 640)) * 2
+    ssw, ssh = [(1, 1), (0, 0), (1, 0)][seed % 3]
+    dtype, depth = [(np.uint8, 8), (np.uint16, 10)][seed % 2]
+    shapes = [(h, w), (h >> ssh, w >> ssw), (h >> ssh, w >> ssw)]
+    nf = 3
+    frames, recs = _rand_clip(rng, shapes, dtype, depth, nf)
+    fps = 60 if seed % 4 < 2 else 24
+    want = _want(oracle, frames, recs, depth, fps)
+    pitch = 1 if seed % 5 == 0 else 256  # tight rows now and then: stride == width
+    dfr = [[dev.upload(p, pitch) for p in fr] for fr in frames]
+    drc = [[dev.upload(p, pitch) for p in fr] for fr in recs]
+    p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(nf)]
+    p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(nf)]
+    assert dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=depth, frame_rate=fps) == want, (seed, h, w, ssw, ssh, depth, fps, pitch)
