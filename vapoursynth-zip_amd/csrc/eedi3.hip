@@ -170,7 +170,6 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 uu[i] = u;
                 jlo[i] = min(u, min(0, two_u)) - nrad;  // t_base columns xb+jlo .. xb+63+max(u, 0, 2u)+nrad are the ones read back
             }
-#ifndef VSZIP_E3_ABL_NOTB
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int t = lane + 64 * it;
@@ -186,11 +185,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
                 for (int i = 0; i < kU; ++i) tb[i][t] = val[i];
             }
-#endif
             wave_fence();
             // window sums, accumulated from 0 in k order exactly like sw0/sw1/sw2 (:443-450): the
             // three sums of a pixel are the same function of t_base at x+u, x, x+2u
-#ifndef VSZIP_E3_ABL_NOWIN
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int t = lane + nrad + 64 * it;
@@ -205,9 +202,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
                 for (int i = 0; i < kU; ++i) ws[i][t] = val[i];
             }
-#endif
             wave_fence();
-#ifndef VSZIP_E3_ABL_NOCOST
             {
                 const int lxc = lx;  // lanes past the line end compute on staged (clamped) columns and store nothing
                 float val[kU];
@@ -225,12 +220,6 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                     for (int i = 0; i < kU; ++i) ctile[mdis + uu[i]][lane] = val[i];
                 }
             }
-#else
-            if (x < w) {
-#pragma unroll
-                for (int i = 0; i < kU; ++i) ctile[mdis + uu[i]][lane] = (float)abs(uu[i]);
-            }
-#endif
             wave_fence();  // tb / ws are rewritten by the next pass
         }
         wave_fence();
