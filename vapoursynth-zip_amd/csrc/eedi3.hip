@@ -1296,8 +1296,10 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     char *base = static_cast<char *>(ctx->scratch);
     float *fbase = reinterpret_cast<float *>(base);
     int *dbase = reinterpret_cast<int *>(base + fl * sizeof(float));
-    int8_t *pbase = reinterpret_cast<int8_t *>(base + fl * sizeof(float) + dm * sizeof(int));
-    uint8_t *mbase = reinterpret_cast<uint8_t *>(base + fl * sizeof(float) + dm * sizeof(int) + pb);
+    // the back-pointer area is written with 16-byte stores: keep it 256-byte aligned (the +4096 of `bytes` covers the padding)
+    const size_t pb_off = (fl * sizeof(float) + dm * sizeof(int) + 255) & ~(size_t)255;
+    int8_t *pbase = reinterpret_cast<int8_t *>(base + pb_off);
+    uint8_t *mbase = reinterpret_cast<uint8_t *>(base + pb_off + pb);
     GExtra gx;
     gx.hp = hp;
 
