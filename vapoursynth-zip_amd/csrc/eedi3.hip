@@ -372,8 +372,6 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
     __shared__ float hrow[HP ? 4 : 1][HP ? kGRowW : 1];  // their half-pel rows (computeHpRow :602-617), HP only
     __shared__ float tbm[kGTbMax], tbh[kGTbMax], wsm[kGTbMax], wsh[kGTbMax];
     __shared__ float ctile[TPMAX][kGXB + 1];
-    __shared__ int8_t ptile[kGXB][kGNS * 64];
-    __shared__ int fpt[kGXB];
     __shared__ uint8_t bmt[kGXB];
     __shared__ int any_mask;
 
@@ -394,7 +392,6 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
     const float *r1p = pl.src + (size_t)src_col(dh, line - 1, pl.n_src) * pl.sstride;
     const float *r1n = pl.src + (size_t)src_col(dh, line + 1, pl.n_src) * pl.sstride;
     const float *r3n = pl.src + (size_t)src_col(dh, line + 3, pl.n_src) * pl.sstride;
-    int8_t *pback = pl.pback + (size_t)off * w * tpitch;
     float *out = pl.dst + (size_t)line * pl.dstride;
     int *dmap = pl.dmap + (size_t)off * w;
     const uint8_t *maskp = ex.mask[pi] ? ex.mask[pi] + (size_t)(dh ? off : line) * ex.mstride[pi] : nullptr;
@@ -425,11 +422,16 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
 
     float pc[kGNS];  // DP states ui = lane + 64 * s (out-of-range states stay at the sentinel)
     int8_t lastbd[kGNS];
+    uint32_t held[kGNS][kGXB / 4];  // back-pointer bytes of the previous block, waiting for their last column
 #pragma unroll
     for (int s = 0; s < kGNS; ++s) {
         pc[s] = kFltMax09;
         lastbd[s] = 0;
+#pragma unroll
+        for (int i = 0; i < kGXB / 4; ++i) held[s][i] = 0;
     }
+    // back-pointers of this line: [block][direction][32 columns], one signed byte each
+    uint8_t *pbk = reinterpret_cast<uint8_t *>(pl.pback) + (size_t)off * ((w + kXB - 1) / kXB * kXB) * tpitch;
     const float g1 = HP ? prm.gamma * 0.5f : prm.gamma, g2 = prm.gamma;
     const int nvec = (tpitch / 8) * 8;
     const int nblk = (w + kGXB - 1) / kGXB;
@@ -521,138 +523,179 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
             }
         }
         // ---- DP phase --------------------------------------------------------------------
+        // As in eedi3_line_kernel the chain touches no memory: the block's costs (32 columns x kGNS
+        // states per lane) come into registers first, the steps are unrolled, a step's back-pointer
+        // (-2..2, one signed byte) is packed into registers and the block's 32 bytes per state go to
+        // global memory afterwards ([block][direction][32 columns]); the mask bits of the block's
+        // columns are one ballot.
         const int xe = min(kGXB, w - xb);
-        for (int xl = 0; xl < xe; ++xl) {
-            const int xx = xb + xl;
-            float tc[kGNS];
+        float tcv[kGNS][kGXB];
 #pragma unroll
-            for (int s = 0; s < kGNS; ++s) tc[s] = (lane + 64 * s < tpitch) ? ctile[lane + 64 * s][xl] : 0.0f;
-            if (xx == 0) {
+        for (int s2 = 0; s2 < kGNS; ++s2)
 #pragma unroll
-                for (int s = 0; s < kGNS; ++s) pc[s] = (lane + 64 * s < tpitch) ? tc[s] : kFltMax09;
-                continue;
-            }
-            const bool masked = maskp && !bmt[xl];
-            float pn[kGNS];
-            int8_t bdn[kGNS];
-            if (masked) {  // :474-484 / :785-795
+            for (int xl = 0; xl < kGXB; ++xl) tcv[s2][xl] = (lane + 64 * s2 < tpitch) ? ctile[min(lane + 64 * s2, tpitch - 1)][xl] : 0.0f;
+        const unsigned long long bmbits = maskp ? __ballot(lane < kGXB && bmt[lane & (kGXB - 1)] != 0) : ~0ull;
+        uint32_t pk[kGNS][kGXB / 4];
 #pragma unroll
-                for (int s = 0; s < kGNS; ++s) {
-                    const bool valid = lane + 64 * s < tpitch;
-                    pn[s] = xx == 1 ? (valid ? tc[s] : kFltMax09) : pc[s];
-                    bdn[s] = xx == 1 ? (int8_t)0 : lastbd[s];
+        for (int s2 = 0; s2 < kGNS; ++s2)
+#pragma unroll
+            for (int i = 0; i < kGXB / 4; ++i) pk[s2][i] = 0;
+        auto store_block = [&](uint32_t (*q)[kGXB / 4], int b2) {
+#pragma unroll
+            for (int s2 = 0; s2 < kGNS; ++s2) {
+                const int ui = lane + 64 * s2;
+                if (ui < tpitch) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(pbk + ((size_t)b2 * tpitch + ui) * kGXB);
+                    dst[0] = make_uint4(q[s2][0], q[s2][1], q[s2][2], q[s2][3]);
+                    dst[1] = make_uint4(q[s2][4], q[s2][5], q[s2][6], q[s2][7]);
                 }
-            } else {
+            }
+        };
 #pragma unroll
-                for (int s = 0; s < kGNS; ++s) {
-                    const int ui = lane + 64 * s;
-                    const bool valid = ui < tpitch;
-                    // neighbours ui-1, ui+1 (and ui-2, ui+2): DPP shift inside the lane group, readlane across it
-                    const float e_b1 = s > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s > 0 ? s - 1 : 0]), 63)) : kFltMax09;
-                    const float e_a1 = s < kGNS - 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s < kGNS - 1 ? s + 1 : s]), 0)) : kFltMax09;
-                    const float b1 = lane_below(pc[s], e_b1), a1 = lane_above(pc[s], e_a1);
-                    float bval;
-                    int bd;
-                    if (!HP) {
-                        const float left = b1 + g2, right = a1 + g2;  // :536-548
-                        bval = pc[s];
-                        bd = 0;
-                        if (left < bval) {
-                            bval = left;
-                            bd = -1;
-                        }
-                        if (right < bval) {
-                            bval = right;
-                            bd = 1;
+        for (int xl = 0; xl < kGXB; ++xl) {
+            if (xl < xe) {
+                const int xx = xb + xl;
+                float tc[kGNS];
+#pragma unroll
+                for (int s2 = 0; s2 < kGNS; ++s2) tc[s2] = tcv[s2][xl];
+                if (xx == 0) {
+#pragma unroll
+                    for (int s2 = 0; s2 < kGNS; ++s2) pc[s2] = (lane + 64 * s2 < tpitch) ? tc[s2] : kFltMax09;
+                } else {
+                    const bool masked = ((bmbits >> xl) & 1ull) == 0;
+                    float pn[kGNS];
+                    int8_t bdn[kGNS];
+                    if (masked) {  // :474-484 / :785-795
+#pragma unroll
+                        for (int s = 0; s < kGNS; ++s) {
+                            const bool valid = lane + 64 * s < tpitch;
+                            pn[s] = xx == 1 ? (valid ? tc[s] : kFltMax09) : pc[s];
+                            bdn[s] = xx == 1 ? (int8_t)0 : lastbd[s];
                         }
                     } else {
-                        const float e_b2 = s > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s > 0 ? s - 1 : 0]), 62)) : kFltMax09;
-                        const float e_a2 = s < kGNS - 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s < kGNS - 1 ? s + 1 : s]), 1)) : kFltMax09;
-                        const float b2 = lane_below(b1, e_b2), a2 = lane_above(a1, e_a2);
-                        const float c_m2 = b2 + g2, c_m1 = b1 + g1, c_0 = pc[s], c_p1 = a1 + g1, c_p2 = a2 + g2;
-                        if (ui < nvec) {  // vector body :806-832 starts from the -2 candidate
-                            bval = c_m2;
-                            bd = -2;
-                        } else {  // scalar tail :834-849 starts from the sentinel
-                            bval = kFltMax09;
-                            bd = 0;
-                            if (c_m2 < bval) {
-                                bval = c_m2;
-                                bd = -2;
+#pragma unroll
+                        for (int s = 0; s < kGNS; ++s) {
+                            const int ui = lane + 64 * s;
+                            const bool valid = ui < tpitch;
+                            // neighbours ui-1, ui+1 (and ui-2, ui+2): DPP shift inside the lane group, readlane across it
+                            const float e_b1 = s > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s > 0 ? s - 1 : 0]), 63)) : kFltMax09;
+                            const float e_a1 = s < kGNS - 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s < kGNS - 1 ? s + 1 : s]), 0)) : kFltMax09;
+                            const float b1 = lane_below(pc[s], e_b1), a1 = lane_above(pc[s], e_a1);
+                            float bval;
+                            int bd;
+                            if (!HP) {
+                                const float left = b1 + g2, right = a1 + g2;  // :536-548
+                                bval = pc[s];
+                                bd = 0;
+                                if (left < bval) {
+                                    bval = left;
+                                    bd = -1;
+                                }
+                                if (right < bval) {
+                                    bval = right;
+                                    bd = 1;
+                                }
+                            } else {
+                                const float e_b2 = s > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s > 0 ? s - 1 : 0]), 62)) : kFltMax09;
+                                const float e_a2 = s < kGNS - 1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pc[s < kGNS - 1 ? s + 1 : s]), 1)) : kFltMax09;
+                                const float b2 = lane_below(b1, e_b2), a2 = lane_above(a1, e_a2);
+                                const float c_m2 = b2 + g2, c_m1 = b1 + g1, c_0 = pc[s], c_p1 = a1 + g1, c_p2 = a2 + g2;
+                                if (ui < nvec) {  // vector body :806-832 starts from the -2 candidate
+                                    bval = c_m2;
+                                    bd = -2;
+                                } else {  // scalar tail :834-849 starts from the sentinel
+                                    bval = kFltMax09;
+                                    bd = 0;
+                                    if (c_m2 < bval) {
+                                        bval = c_m2;
+                                        bd = -2;
+                                    }
+                                }
+                                if (c_m1 < bval) {
+                                    bval = c_m1;
+                                    bd = -1;
+                                }
+                                if (c_0 < bval) {
+                                    bval = c_0;
+                                    bd = 0;
+                                }
+                                if (c_p1 < bval) {
+                                    bval = c_p1;
+                                    bd = 1;
+                                }
+                                if (c_p2 < bval) {
+                                    bval = c_p2;
+                                    bd = 2;
+                                }
                             }
-                        }
-                        if (c_m1 < bval) {
-                            bval = c_m1;
-                            bd = -1;
-                        }
-                        if (c_0 < bval) {
-                            bval = c_0;
-                            bd = 0;
-                        }
-                        if (c_p1 < bval) {
-                            bval = c_p1;
-                            bd = 1;
-                        }
-                        if (c_p2 < bval) {
-                            bval = c_p2;
-                            bd = 2;
+                            pn[s] = valid ? fminf(bval + tc[s], kFltMax09) : kFltMax09;
+                            bdn[s] = (int8_t)bd;
                         }
                     }
-                    pn[s] = valid ? fminf(bval + tc[s], kFltMax09) : kFltMax09;
-                    bdn[s] = (int8_t)bd;
-                }
-            }
 #pragma unroll
-            for (int s = 0; s < kGNS; ++s) {
-                pc[s] = pn[s];
-                lastbd[s] = bdn[s];
-                const int ui = lane + 64 * s;
-                if (ui < tpitch) {
-                    if (xl == 0)
-                        pback[(size_t)(xx - 1) * tpitch + ui] = bdn[s];
-                    else
-                        ptile[xl - 1][ui] = bdn[s];
+                    for (int s = 0; s < kGNS; ++s) {
+                        pc[s] = pn[s];
+                        lastbd[s] = bdn[s];
+                        // back-pointer of column xx-1: byte xl-1 of this block, or the last byte of the previous one
+                        const uint32_t byte = (uint32_t)(uint8_t)bdn[s];
+                        if (xl == 0)
+                            held[s][kGXB / 4 - 1] |= byte << 24;
+                        else
+                            pk[s][(xl - 1) >> 2] |= byte << (8 * ((xl - 1) & 3));
+                    }
                 }
             }
         }
-        __syncthreads();
-        for (int t = lane; t < (xe - 1) * tpitch; t += 64) {
-            const int r = t / tpitch, c = t - r * tpitch;
-            pback[(size_t)(xb + r) * tpitch + c] = ptile[r][c];
-        }
+        if (blk > 0) store_block(held, blk - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < kGNS; ++s2)
+#pragma unroll
+            for (int i = 0; i < kGXB / 4; ++i) held[s2][i] = pk[s2][i];
+        if (blk == nblk - 1) store_block(held, blk);
     }
     __syncthreads();
     __threadfence_block();
 
     // ---- backtrack + output --------------------------------------------------------------
+    // fpath as a scalar chain over register-held codes, like eedi3_line_kernel: state cen+fpath sits
+    // in lane (cen+fpath) & 63 of state group (cen+fpath) >> 6
     int carry = 0;
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int xb = blk * kGXB;
         const int xe = min(kGXB, w - xb);
         __syncthreads();
-        for (int t = lane; t < xe * tpitch; t += 64) {
-            const int r = t / tpitch, c = t - r * tpitch;
-            if (xb + r < w - 1) ptile[r][c] = pback[(size_t)(xb + r) * tpitch + c];
-        }
         if (maskp && lane < xe) bmt[lane] = bmask_at(xb + lane) ? 1 : 0;
+        uint32_t q[kGNS][kGXB / 4];
+#pragma unroll
+        for (int s2 = 0; s2 < kGNS; ++s2) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(pbk + ((size_t)blk * tpitch + min(lane + 64 * s2, tpitch - 1)) * kGXB);
+            const uint4 v0 = src[0], v1 = src[1];
+            q[s2][0] = v0.x, q[s2][1] = v0.y, q[s2][2] = v0.z, q[s2][3] = v0.w;
+            q[s2][4] = v1.x, q[s2][5] = v1.y, q[s2][6] = v1.z, q[s2][7] = v1.w;
+        }
         __syncthreads();
-        if (lane == 0) {
-            int fp = carry;
-            for (int xl = xe - 1; xl >= 0; --xl) {
-                const int xx = xb + xl;
-                if (xx == w - 1)
+        int fp = __builtin_amdgcn_readfirstlane(carry);
+        int fpv = 0;
+#pragma unroll
+        for (int xl = kGXB - 1; xl >= 0; --xl) {
+            if (xl < xe) {
+                if (xb + xl == w - 1) {
                     fp = 0;
-                else
-                    fp = fp + ptile[xl][cen + fp];
-                fpt[xl] = fp;
+                } else {
+                    const int ui = cen + fp, l = ui & 63, sg = ui >> 6;
+                    int word = __builtin_amdgcn_readlane((int)q[0][xl >> 2], l);
+                    if (kGNS > 1 && sg == 1) word = __builtin_amdgcn_readlane((int)q[kGNS > 1 ? 1 : 0][xl >> 2], l);
+                    if (kGNS > 2 && sg == 2) word = __builtin_amdgcn_readlane((int)q[kGNS > 2 ? 2 : 0][xl >> 2], l);
+                    fp += (int)(int8_t)((word >> (8 * (xl & 3))) & 0xff);
+                }
+                fpv = lane == xl ? fp : fpv;
             }
         }
-        __syncthreads();
-        carry = fpt[0];
+        carry = fp;
         if (lane < xe) {
             const int xx = xb + lane;
             const bool masked = maskp && !bmt[lane];
-            int dir = fpt[lane];
+            int dir = fpv;
             float v;
             if (!HP) {
                 if (masked) dir = 0;  // :566-569
