@@ -370,7 +370,8 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
     const float kFltMax09 = FLT_MAX * 0.9f;
     __shared__ float rows[4][kGRowW];  // r3p, r1p, r1n, r3n
     __shared__ float hrow[HP ? 4 : 1][HP ? kGRowW : 1];  // their half-pel rows (computeHpRow :602-617), HP only
-    __shared__ float tbm[kGTbMax], tbh[kGTbMax], wsm[kGTbMax], wsh[kGTbMax];
+    __shared__ float tbm[kGTbMax], tbh[kGTbMax], wsm[kGTbMax], wsh[kGTbMax];  // hp: one direction per pass
+    __shared__ float tbq[HP ? 1 : kU][HP ? 1 : kGTbMax], wsq[HP ? 1 : kU][HP ? 1 : kGTbMax];  // otherwise: kU directions per pass
     __shared__ float ctile[TPMAX][kGXB + 1];
     __shared__ uint8_t bmt[kGXB];
     __shared__ int any_mask;
@@ -458,32 +459,61 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
         const bool act = lane < kGXB && xb + lane < w;
         const int lx = lane + reach;
         // ---- cost phase ---------------------------------------------------------------
-        for (int u = -cen; u <= cen; ++u) {
-            if (!HP) {
-                const int two_u = 2 * u;
-                const int jlo = min(u, min(0, two_u)) - nrad;  // t_base columns xb+jlo .. xb+31+max(u, 0, 2u)+nrad are read back
-                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
+        if constexpr (!HP) {
+            // four directions per pass, like eedi3_line_kernel: independent LDS round trips in flight
+            for (int ug = -cen; ug <= cen; ug += kU) {
+                int uu[kU], jlo[kU];
+#pragma unroll
+                for (int i = 0; i < kU; ++i) {
+                    const int u = min(ug + i, cen);  // past +cen: a duplicate of the last direction (same values, same slots)
+                    uu[i] = u;
+                    jlo[i] = min(u, min(0, 2 * u)) - nrad;  // t_base columns xb+jlo .. xb+31+max(u, 0, 2u)+nrad are read back
+                }
+#pragma unroll
+                for (int it = 0; it < kGNit; ++it) {
                     const int t = lane + 64 * it;  // fixed trip count, entries past the span are padding nobody reads
-                    const int j = jlo + t + reach;
-                    tbm[t] = fabsf(rows[0][j] - rows[1][j - two_u]) + fabsf(rows[1][j] - rows[2][j - two_u]) + fabsf(rows[2][j] - rows[3][j - two_u]);
+                    float val[kU];
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        const int two_u = 2 * uu[i];
+                        const int j = jlo[i] + t + reach;
+                        val[i] = fabsf(rows[0][j] - rows[1][j - two_u]) + fabsf(rows[1][j] - rows[2][j - two_u]) + fabsf(rows[2][j] - rows[3][j - two_u]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) tbq[i][t] = val[i];
                 }
                 __syncthreads();
-                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
-                    const int t = lane + nrad + 64 * it;
-                    float sw = 0.0f;
 #pragma unroll
-                    for (int k = -nrad; k <= nrad; ++k) sw += tbm[t + k];
-                    wsm[t] = sw;
+                for (int it = 0; it < kGNit; ++it) {
+                    const int t = lane + nrad + 64 * it;
+                    float val[kU];
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        float sw = 0.0f;
+#pragma unroll
+                        for (int k = -nrad; k <= nrad; ++k) sw += tbq[i][t + k];
+                        val[i] = sw;
+                    }
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) wsq[i][t] = val[i];
                 }
                 __syncthreads();
                 if (act) {
-                    const int base = lane - jlo;
-                    const float sw1 = wsm[base], sw0 = wsm[base + u], sw2 = wsm[base + two_u];
-                    const float ip = (rows[1][lx + u] + rows[2][lx - u]) * 0.5f;
-                    const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
-                    ctile[cen + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        const int u = uu[i], two_u = 2 * u;
+                        const int base = lane - jlo[i];
+                        const float sw1 = wsq[i][base], sw0 = wsq[i][base + u], sw2 = wsq[i][base + two_u];
+                        const float ip = (rows[1][lx + u] + rows[2][lx - u]) * 0.5f;
+                        const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
+                        ctile[cen + u][lane] = prm.alpha * (sw0 + sw1 + sw2) + prm.beta * (float)abs(u) + prm.one_minus_ab * v;
+                    }
                 }
                 __syncthreads();
+            }
+        }
+        for (int u = -cen; HP && u <= cen; ++u) {
+            if (!HP) {
             } else {
                 // :659-702 — u in half pels; baseM pairs full-pel rows shifted by u, baseHp (odd u)
                 // pairs the half-pel rows; s1/s2 window baseM at x and x+u, s0 the u/2 neighbour
