@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct vszip_ctx vszip_ctx;
 
-/* sample types: helper.zig:59-108 DataType. U32 is accepted by vszip_plane_average only, like in
+/* sample types: helper.zig:59-108 DataType. U32 is accepted by vszip_plane_average and vszip_limiter only, like in
  * the reference (enable_u32, helper.zig:78), and without an exclude list (planeaverage.zig(vs):127). */
 enum vszip_dtype { VSZIP_U8 = 0, VSZIP_U16 = 1, VSZIP_F16 = 2, VSZIP_F32 = 3, VSZIP_U32 = 4 };
 
@@ -111,6 +111,16 @@ int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int npla
 int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
                         const int32_t *exclude, int nexclude, int bits_per_sample,
                         double *avg, double *diff);
+
+/*
+ * Limiter — replaces the getFrame bodies of LimiterRT / Limiter (src/vapoursynth/limiter.zig:28-96):
+ * dst = min(max(lo, x), hi) in the sample type, per plane. lo[i] / hi[i] are the bounds the wrapper
+ * resolved for planes[i] — the min/max arrays (u32 for integer clips, f32 for float clips), or the
+ * comptime range tables of src/filters/limiter.zig:66-91 (full / tv_range yuv / rgb per depth,
+ * yuvf / rgbf). dtype may be VSZIP_U32. Asynchronous on the context stream.
+ */
+int vszip_limiter(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const double *lo,
+                  const double *hi);
 
 /*
  * PlaneMinMax — replaces filter.minMax / minMaxRef / minMaxNoThr / minMaxNoThrRef

@@ -224,6 +224,28 @@ def xpsnr_wsse(org, rec, prv1=None, prv2=None, depth=8, frame_rate=24, temporal=
     return [int(out[i]) for i in range(n)]
 
 
+def limiter(src: np.ndarray, lo: float, hi: float) -> np.ndarray:
+    """vszip.Limiter on one plane: min(max(lo, x), hi) in the sample type."""
+    src = np.ascontiguousarray(src)
+    dst = np.empty_like(src)
+    sp, ss = _plane(src)
+    dp, ds = _plane(dst)
+    l = lib()
+    l.vszo_limiter.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, C.c_double, C.c_double]
+    assert l.vszo_limiter(dt_of(src), sp, dp, ss, ds, src.shape[1], src.shape[0], float(lo), float(hi)) == 0
+    return dst
+
+
+def limiter_default_range(is_float: bool, bits: int, yuv: bool, tv_range: bool):
+    """-> (lo[3], hi[3]) of vszip.Limiter without min/max arrays."""
+    lo, hi = (C.c_double * 3)(), (C.c_double * 3)()
+    l = lib()
+    l.vszo_limiter_default_range.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    l.vszo_limiter_default_range.restype = None
+    l.vszo_limiter_default_range(int(is_float), bits, int(yuv), int(tv_range), lo, hi)
+    return list(lo), list(hi)
+
+
 def xpsnr_frame(wsse: int, w: int, h: int, depth: int) -> float:
     return lib().vszo_xpsnr_frame(wsse, w, h, depth)
 

@@ -211,3 +211,50 @@ def test_xpsnr_magnitude(oracle):
     w = oracle.xpsnr_wsse([y], [d], depth=8, temporal=False)
     x = oracle.xpsnr_frame(w[0], 352, 288, 8)
     assert 35.0 < x < 60.0
+
+
+# ---- Limiter ---------------------------------------------------
+@pytest.mark.parametrize("key,lo,hi,planes", [
+    ("RGB24|full|max=[180,200,250],min=[20,20,100]", [20, 20, 100], [180, 200, 250], [0, 1, 2]),
+    ("RGB24|full|max=[180,200,250],min=[20,20,100],planes=[0,2]", [20, 20, 100], [180, 200, 250], [0, 2]),
+    ("RGB24|full|tv_range=1", None, None, [0, 1, 2]),
+])
+def test_limiter_golden_rgb24(oracle, key, lo, hi, planes):
+    g = fx.ref_goldens()["exact"]["limiter"][key]
+    if lo is None:  # the comptime tv_range table of an RGB clip (src/filters/limiter.zig:83)
+        lo, hi = oracle.limiter_default_range(False, 8, False, True)
+        assert (lo, hi) == ([16.0] * 3, [235.0] * 3)
+    src = fx.crop_rgb24()
+    for p in range(3):
+        out = oracle.limiter(src[p], lo[p], hi[p]) if p in planes else src[p]
+        _check(fx.plane_stats(out), g[f"p{p}"])
+
+
+def test_limiter_golden_gray8_and_rgbs(oracle):
+    g = fx.ref_goldens()["exact"]["limiter"]
+    _check(fx.plane_stats(oracle.limiter(fx.crop_gray8(), 50, 200)), g["GRAY8|full|max=[200],min=[50]"]["p0"])
+    lo, hi = [0.1, 0.1, 0.1], [0.7, 0.7, 0.99]
+    for p in range(3):
+        out = oracle.limiter(np.ascontiguousarray(fx.crop_rgbs()[p]), np.float32(lo[p]), np.float32(hi[p]))
+        _check(fx.plane_stats(out), g["RGBS|full|max=[0.7,0.7,0.99],min=[0.1,0.1,0.1]"][f"p{p}"])
+
+
+@pytest.mark.parametrize("key,lo,hi", [("GRAY16|full|max=[50000],min=[10000]", 10000, 50000), ("GRAY16|full|max=[30000],min=[0]", 0, 30000),
+                                        ("GRAY16|full|max=[65535],min=[30000]", 30000, 65535)])
+def test_limiter_soft_gray16(oracle, key, lo, hi):
+    g = fx.ref_goldens()["soft"]["limiter"][key]["p0"]
+    st = fx.plane_stats(oracle.limiter(fx.crop_gray16(), lo, hi))
+    assert st["avg"] == pytest.approx(g["avg"], rel=1e-7) and abs(st["min"] - g["min"]) <= 1 and abs(st["max"] - g["max"]) <= 1
+
+
+def test_limiter_default_tables(oracle):
+    """reference tests/test_limiter.py:96-127 (TV_RANGE table, mask, float default) and the u32 tables :150-191"""
+    assert oracle.limiter_default_range(False, 16, True, True) == ([4096.0] * 3, [60160.0, 61440.0, 61440.0])
+    assert oracle.limiter_default_range(False, 10, True, True) == ([64.0] * 3, [940.0, 960.0, 960.0])
+    assert oracle.limiter_default_range(False, 32, True, True) == ([268435456.0] * 3, [3942645760.0, 4026531840.0, 4026531840.0])
+    assert oracle.limiter_default_range(False, 32, False, True)[1] == [3942645760.0] * 3
+    assert oracle.limiter_default_range(False, 16, True, False) == ([0.0] * 3, [65535.0] * 3)
+    assert oracle.limiter_default_range(True, 32, True, True) == ([0.0, -0.5, -0.5], [1.0, 0.5, 0.5])
+    assert oracle.limiter_default_range(True, 32, False, True) == ([0.0] * 3, [1.0] * 3)  # mask / RGB / Gray
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (2, 1))
+    assert oracle.limiter(ramp, 10, 200)[0].tolist() == [min(max(x, 10), 200) for x in range(256)]

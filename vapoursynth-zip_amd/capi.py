@@ -84,6 +84,7 @@ SYMBOLS = {
                                     C.c_uint, _i, C.POINTER(C.c_uint64)]),
     "vszip_xpsnr_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64, _i]),
     "vszip_xpsnr_average": (C.c_double, [C.c_double, C.c_double, C.c_uint64, C.c_uint64, _i, C.c_uint64]),
+    "vszip_limiter": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -277,6 +278,12 @@ class Device:
         b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
         self.check(self.lib.vszip_plane_average(self.ctx, _NP2DT[srcs[0].dtype], table, n, ex, len(exclude), b, avg, diff))
         return list(avg), (list(diff) if refs is not None else None)
+
+    def limiter(self, srcs, dsts, lo, hi):
+        """dsts[i] = min(max(lo[i], srcs[i]), hi[i]) (vszip.Limiter with the bounds already resolved)."""
+        n = len(srcs)
+        table = self.plane_table(srcs, dsts)
+        self.check(self.lib.vszip_limiter(self.ctx, _NP2DT[srcs[0].dtype], table, n, (C.c_double * n)(*[float(v) for v in lo]), (C.c_double * n)(*[float(v) for v in hi])))
 
     def plane_minmax(self, srcs, minthr=0.0, maxthr=0.0, refs=None, bits=None):
         n = len(srcs)
