@@ -356,6 +356,24 @@ def planestats_leg(dev, timed, frames=16):
     return out
 
 
+def limiter_leg(dev, timed, frames=16):
+    """vszip.Limiter (tv_range bounds) on 3840x2160 YUV420P16: a streaming read + write, HBM roofline = both."""
+    base = make_frame(9, W4K, H4K)
+    srcs, dsts = [], []
+    for f in range(frames):
+        for p in base:
+            srcs.append(dev.upload(np.roll(p, f * 5, axis=1)))
+            dsts.append(dev.empty(p.shape[0], p.shape[1], p.dtype))
+    lo, hi = [4096.0] * len(srcs), [60160.0, 61440.0, 61440.0] * frames
+    dt, _, dom_ms, launches = timed.run(lambda: (dev.limiter(srcs, dsts, lo, hi), dev.sync()), 10, 2)
+    fb = 2 * sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K)) * frames
+    gbs = fb * 10 / (dom_ms * 1e-3) / 1e9
+    return {"limiter_4k": {"value": frames * 10 / dt, "unit": "frames/s",
+                           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                        "kernel": "limiter_kernel<u16>", "avg_launch_us": dom_ms * 1e3 / launches},
+                           "workload": f"vszip.Limiter tv_range: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
+
+
 def boxblur_other_paths_leg(dev, timed, frames=8):
     """The BoxBlur paths beside the headline one: the runtime path (radius > 22 or several passes,
     boxblur_runtime.zig) on 4K YUV420P16 and the compile-time float path on 4K YUV420PS."""
@@ -549,6 +567,10 @@ def main() -> int:
                 others.update(planestats_leg(dev, timed))
             except Exception as e:
                 others["plane_stats_4k"] = {"error": str(e)}
+            try:
+                others.update(limiter_leg(dev, timed))
+            except Exception as e:
+                others["limiter_4k"] = {"error": str(e)}
             try:
                 others["boxblur_4k_pcie"] = pcie_boxblur(vszip_amd, local_rank, a.radius)
             except Exception as e:  # the PCIe leg is informative only

@@ -120,6 +120,9 @@ class Frame:
     def __getitem__(self, p):
         return self.planes[p]
 
+    def __len__(self):
+        return len(self.planes)
+
 
 class Clip:
     def __init__(self, node):

@@ -284,3 +284,50 @@ def test_depth_conversions_are_delegated_to_the_host(oracle):
         assert props["XPSNR_U"] == oracle.xpsnr_frame(w[1], 80, 48, 10)
     finally:
         vs.core_standins(False)
+
+
+def test_limiter_through_plugin(oracle):
+    """reference tests/test_limiter.py: tv_range tables per format, mask, float default, integer default
+    no-op, tv_range == explicit min/max, planes subset, explicit min/max pixels, 32-bit tables."""
+    def stacked(fmt, dtype, peak, lo_val=0, chroma=False):
+        h, w = 32, 64
+        ssw, ssh = (fmt >> 8) & 0xFF, fmt & 0xFF
+        npl = 1 if (fmt >> 28) == vs.GRAY else 3
+        planes = []
+        for p in range(npl):
+            ph, pw = h >> (ssh if p else 0), w >> (ssw if p else 0)
+            a = np.empty((ph, pw), dtype)
+            a[: ph // 2] = peak if not (chroma and p) else 0.5
+            a[ph // 2:] = lo_val if not (chroma and p) else -0.5
+            planes.append(a)
+        return vs.source([planes], fmt), planes
+
+    def mm(clip):
+        f = clip.get_frame(0)
+        return [np.asarray(f[p]).min().item() for p in range(len(f))], [np.asarray(f[p]).max().item() for p in range(len(f))]
+
+    for fmt, dtype, peak, lo, hi in ((vs.YUV420P8, np.uint8, 255, [16, 16, 16], [235, 240, 240]), (vs.YUV420P10, np.uint16, 1023, [64, 64, 64], [940, 960, 960]),
+                                     (vs.YUV420P16, np.uint16, 65535, [4096] * 3, [60160, 61440, 61440]), (vs.RGB24, np.uint8, 255, [16] * 3, [235] * 3)):
+        src, planes = stacked(fmt, dtype, peak)
+        assert mm(src.vszip.Limiter(tv_range=True)) == (lo, hi), fmt
+        explicit = src.vszip.Limiter(min=lo, max=hi).get_frame(0)  # the comptime and the runtime path agree
+        tv = src.vszip.Limiter(tv_range=True).get_frame(0)
+        for p in range(3):
+            assert np.array_equal(explicit[p], tv[p])
+        out = src.vszip.Limiter().get_frame(0)  # integer default: full range, a no-op
+        for p in range(3):
+            assert np.array_equal(out[p], planes[p])
+    srcf, _ = stacked(vs.YUV420PS, np.float32, 2.0, -2.0)
+    assert mm(srcf.vszip.Limiter()) == ([0.0, -0.5, -0.5], [1.0, 0.5, 0.5])
+    assert mm(srcf.vszip.Limiter(tv_range=True, mask=True)) == ([0.0] * 3, [1.0] * 3)
+    src16, planes16 = stacked(vs.YUV420P16, np.uint16, 65535)
+    part = src16.vszip.Limiter(tv_range=True, planes=[0]).get_frame(0)
+    assert np.array_equal(part[1], planes16[1]) and np.array_equal(part[2], planes16[2]) and np.asarray(part[0]).min() == 4096
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (2, 1))
+    assert np.asarray(vs.source([[ramp]], vs.GRAY8).vszip.Limiter(min=[10], max=[200]).get_frame(0)[0])[0].tolist() == [min(max(x, 10), 200) for x in range(256)]
+    src32, _ = stacked(vs.GRAY32, np.uint32, 4294967295)
+    assert mm(src32.vszip.Limiter()) == ([0], [4294967295]) and mm(src32.vszip.Limiter(tv_range=True)) == ([268435456], [3942645760])
+    nat = [fx.tiled_natural((96, 160), np.uint16, p) for p in range(3)]
+    got = vs.source([nat], vs.YUV444P16).vszip.Limiter(min=[10000, 20000, 10000], max=[50000, 55000, 45000]).get_frame(0)
+    for p, (lo, hi) in enumerate(zip([10000, 20000, 10000], [50000, 55000, 45000])):
+        assert np.array_equal(got[p], oracle.limiter(nat[p], lo, hi))

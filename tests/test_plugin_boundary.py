@@ -13,6 +13,7 @@ SIGNATURES = {
     "BoxBlur": "clip:vnode;planes:int[]:opt;hradius:int:opt;hpasses:int:opt;vradius:int:opt;vpasses:int:opt",
     "EEDI3": "clip:vnode;field:int;dh:int:opt;alpha:float:opt;beta:float:opt;gamma:float:opt;nrad:int:opt;mdis:int:opt;hp:int:opt;vcheck:int:opt;"
              "vthresh0:float:opt;vthresh1:float:opt;vthresh2:float:opt;sclip:vnode:opt;mclip:vnode:opt;",
+    "Limiter": "clip:vnode;min:float[]:opt;max:float[]:opt;tv_range:int:opt;mask:int:opt;planes:int[]:opt;",  # src/vszip.zig:162
     "PlaneAverage": "clipa:vnode;exclude:int[];clipb:vnode:opt;planes:int[]:opt;prop:data:opt;",
     "PlaneMinMax": "clipa:vnode;minthr:float:opt;maxthr:float:opt;clipb:vnode:opt;planes:int[]:opt;prop:data:opt;",
     "SSIMULACRA2": "reference:vnode;distorted:vnode;",
@@ -144,3 +145,28 @@ def test_ssimulacra2_and_xpsnr_validation():
 def test_unknown_argument_rejected():
     with pytest.raises(vs.Error, match="no argument named"):
         _yuv().vszip.BoxBlur(radius=3)
+
+
+@pytest.mark.parametrize("args,msg", [  # reference tests/test_limiter.py:189-205
+    (dict(min=[0, 0, 0]), "min array is set but max array is not"),
+    (dict(max=[255, 255, 255]), "max array is set but min array is not"),
+    (dict(min=[0, 0], max=[255, 255, 255]), "min array must have the same number of elements as planes"),
+    (dict(min=[0, 0, 0], max=[255, 255]), "max array must have the same number of elements as planes"),
+    (dict(min=[-1, 0, 0], max=[255, 255, 255]), "min value must be greater than or equal to 0"),
+    (dict(min=[0, 0, 0], max=[255, 255, 256]), "max value must be less than or equal to peak value"),
+    (dict(min=[300, 0, 0], max=[255, 255, 255]), "min value must be less than or equal to peak value"),
+    (dict(min=[200, 0, 0], max=[100, 255, 255]), "min value must be less than or equal to max value"),
+    (dict(planes=[3]), "plane index out of range"),
+    (dict(planes=[-1]), "plane index out of range"),
+    (dict(planes=[0, 0]), "plane specified twice"),
+])
+def test_limiter_validation(args, msg):
+    with pytest.raises(vs.Error, match=msg):
+        _yuv().vszip.Limiter(**args)
+
+
+def test_limiter_32bit_explicit_bounds_are_unreachable():
+    """getPeakValue overflows for 32-bit integer clips (peak -1), so every explicit bound is above it
+    (reference tests/test_limiter.py:150-160)."""
+    with pytest.raises(vs.Error, match="min value must be less than or equal to peak value"):
+        vs.blank(vs.GRAY32, 64, 32, 0).vszip.Limiter(min=[0], max=[10])

@@ -21,5 +21,7 @@ for leg in sys.argv[1:]:
         print(json.dumps(bench.xpsnr_leg(dev, timed, True)))
     elif leg == "boxblur_other":
         print(json.dumps(bench.boxblur_other_paths_leg(dev, timed)))
+    elif leg == "limiter":
+        print(json.dumps(bench.limiter_leg(dev, timed)))
     elif leg == "planestats":
         print(json.dumps(bench.planestats_leg(dev, timed)))

@@ -688,6 +688,150 @@ struct SsimData {
     VSNode *node1, *node2;
 };
 
+// ---------------------------------------------------------------------------
+// Limiter (src/vapoursynth/limiter.zig, src/filters/limiter.zig) — SURVEY 8f rank 4
+// ---------------------------------------------------------------------------
+struct LimiterData {
+    VSNode *node;
+    const VSVideoInfo *vi;
+    int dt;
+    bool planes[3];
+    double lo[3], hi[3];  // resolved bounds: the min/max arrays or the comptime range table of the format
+};
+
+const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<LimiterData *>(inst);
+    Z z{api, core, fctx};
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->node, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *src = api->getFrameFilter(n, d->node, fctx);
+        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+        const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
+        const int pidx[3] = {0, 1, 2};
+        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
+        Gpu *g = gpu_for_frame(n);
+        if (!g) {
+            api->freeFrame(src);
+            return fail(z, nullptr, dst, "Limiter", "no MI355X device available (the plugin has no CPU fallback)");
+        }
+        std::vector<vszip_plane> tab;
+        std::vector<DPlane> outs;
+        std::vector<int> which;
+        std::vector<double> lo, hi;
+        for (int p = 0; p < vf->numPlanes; ++p) {
+            if (!d->planes[p]) continue;
+            DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps);
+            if (!s.ptr || !o.ptr) {
+                api->freeFrame(src);
+                return fail(z, g, dst, "Limiter", "device staging failed");
+            }
+            tab.push_back(mk_plane(s, &o, nullptr));
+            outs.push_back(o);
+            which.push_back(p);
+            lo.push_back(d->lo[p]);
+            hi.push_back(d->hi[p]);
+        }
+        int rc = tab.empty() ? VSZIP_OK : vszip_limiter(g->ctx, d->dt, tab.data(), (int)tab.size(), lo.data(), hi.data());
+        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
+            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
+        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        api->freeFrame(src);
+        if (rc != VSZIP_OK) return fail(z, g, dst, "Limiter", "GPU kernel failed");
+        return dst;
+    }
+    return nullptr;
+}
+
+void VS_CC limiterFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<LimiterData *>(inst);
+    api->freeNode(d->node);
+    delete d;
+}
+
+void VS_CC limiterCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) {
+    Z z{api, core, nullptr};
+    LimiterData d{};
+    d.node = z.getNode(in, "clip");
+    d.vi = api->getVideoInfo(d.node);
+    const VSVideoFormat &f = d.vi->format;
+    const int np = f.numPlanes;
+    const bool is_int = f.sampleType == stInteger;
+    // hz.getPeakValue(fmt, false, .FULL) :293-304 as f32; shl(i32, 1, 32) is 0, so a 32-bit clip has peak -1
+    const float peak = !is_int ? 1.0f : (f.bitsPerSample >= 32 ? -1.0f : (float)((1 << f.bitsPerSample) - 1));
+    d.planes[0] = d.planes[1] = d.planes[2] = true;
+    if (!get_planes(z, in, out, {d.node}, d.planes, np, "Limiter")) return;
+    auto bail = [&](const char *msg) {
+        z.setError(out, "%s", msg);
+        api->freeNode(d.node);
+    };
+    const int nmin = api->mapNumElements(in, "min"), nmax = api->mapNumElements(in, "max");
+    const bool has_min = nmin >= 0 && api->mapGetType(in, "min") != ptUnset, has_max = nmax >= 0 && api->mapGetType(in, "max") != ptUnset;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    if (has_min) {  // :123-151
+        if (nmin != np) return bail("Limiter: min array must have the same number of elements as planes.");
+        for (int i = 0; i < nmin; ++i) {
+            const double v = z.getFloat(in, "min", 0.0, i);
+            if (is_int) {
+                const int64_t t = (int64_t)std::trunc(v);
+                if (t < 0) return bail("Limiter: min value must be greater than or equal to 0.");
+                if (v > (double)peak) return bail("Limiter: min value must be less than or equal to peak value.");
+                mn[i] = (double)(uint32_t)t;
+            } else {
+                mn[i] = (double)(float)v;
+            }
+        }
+    }
+    if (has_max) {  // :153-181
+        if (nmax != np) return bail("Limiter: max array must have the same number of elements as planes.");
+        for (int i = 0; i < nmax; ++i) {
+            const double v = z.getFloat(in, "max", 0.0, i);
+            if (is_int) {
+                const int64_t t = (int64_t)std::trunc(v);
+                if (v > (double)peak) return bail("Limiter: max value must be less than or equal to peak value.");
+                if (t < 0) return bail("Limiter: max value must be greater than or equal to 0.");
+                mx[i] = (double)(uint32_t)t;
+            } else {
+                mx[i] = (double)(float)v;
+            }
+        }
+    }
+    if (has_min && !has_max) return bail("Limiter: min array is set but max array is not.");
+    if (!has_min && has_max) return bail("Limiter: max array is set but min array is not.");
+    if (has_min && has_max)
+        for (int p = 0; p < np; ++p)
+            if (mn[p] > mx[p]) return bail("Limiter: min value must be less than or equal to max value.");
+    // BPSType.select (helper.zig:25-56): integer 8/9/10/12/14/16/32 bits, float 16/32
+    if (is_int) {
+        const int b = f.bitsPerSample;
+        if (!(b == 8 || b == 9 || b == 10 || b == 12 || b == 14 || b == 16 || b == 32)) return bail("Limiter: not supported Int format.");
+        d.dt = b == 8 ? VSZIP_U8 : (b == 32 ? VSZIP_U32 : VSZIP_U16);
+    } else {
+        if (f.bitsPerSample != 16 && f.bitsPerSample != 32) return bail("Limiter: not supported Float format.");
+        d.dt = f.bitsPerSample == 16 ? VSZIP_F16 : VSZIP_F32;
+    }
+    const bool tv_range = z.getInt(in, "tv_range", 0) != 0, mask = z.getInt(in, "mask", 0) != 0;
+    const bool yuv = f.colorFamily == cfYUV && !mask;
+    for (int p = 0; p < 3; ++p) {
+        if (has_min) {  // LimiterRT
+            d.lo[p] = mn[p];
+            d.hi[p] = mx[p];
+        } else if (!is_int) {  // yuvf / rgbf, with or without tv_range (src/filters/limiter.zig:33-34,53-54,90-91)
+            d.lo[p] = (yuv && p > 0) ? -0.5 : 0.0;
+            d.hi[p] = (yuv && p > 0) ? 0.5 : 1.0;
+        } else if (tv_range) {  // yuvN / rgbN :74-88
+            d.lo[p] = (double)(16ull << (f.bitsPerSample - 8));
+            d.hi[p] = (double)(((yuv && p > 0) ? 240ull : 235ull) << (f.bitsPerSample - 8));
+        } else {  // fullN :66-72
+            d.lo[p] = 0.0;
+            d.hi[p] = (double)((1ull << f.bitsPerSample) - 1);
+        }
+    }
+    auto *data = new LimiterData(d);
+    VSFilterDependency deps[] = {{d.node, rpStrictSpatial}};
+    api->createVideoFilter(out, "Limiter", d.vi, limiterGetFrame, limiterFree, fmParallel, deps, 1, data, core);
+}
+
 // hz.bitDepth (helper.zig:470-494): depth conversion is the host's resize.Point with the given
 // dither, exactly like the reference. Consumes `node`; NULL (node freed) when the host has no
 // resize plugin or the conversion fails.
@@ -1211,6 +1355,7 @@ VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI
     vspapi->configPlugin("com.julek.vszip", "vszip", "VapourSynth Zig Image Process", VS_MAKE_VERSION(19, 0), VAPOURSYNTH_API_VERSION, 0, plugin);
     vspapi->registerFunction("Bilateral", "clip:vnode;ref:vnode:opt;sigmaS:float[]:opt;sigmaR:float[]:opt;planes:int[]:opt;algorithm:int[]:opt;PBFICnum:int[]:opt",
                              "clip:vnode;", bilateralCreate, nullptr, plugin);
+    vspapi->registerFunction("Limiter", "clip:vnode;min:float[]:opt;max:float[]:opt;tv_range:int:opt;mask:int:opt;planes:int[]:opt;", "clip:vnode;", limiterCreate, nullptr, plugin);
     vspapi->registerFunction("BoxBlur", "clip:vnode;planes:int[]:opt;hradius:int:opt;hpasses:int:opt;vradius:int:opt;vpasses:int:opt", "clip:vnode;", boxblurCreate, nullptr, plugin);
     vspapi->registerFunction("EEDI3", kEedi3Args, "clip:vnode;", eedi3Create, nullptr, plugin);
     vspapi->registerFunction("EEDI3H", kEedi3Args, "clip:vnode;", eedi3hCreate, nullptr, plugin);
