@@ -123,6 +123,19 @@ int vszip_limiter(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int npla
                   const double *hi);
 
 /*
+ * LimitFilter — replaces filter.process (src/filters/limit_filter.zig:3-34) called from
+ * LimitFilter(T, refb).getFrame (src/vapoursynth/limit_filter.zig:27-80). planes[i].src is the
+ * FILTERED clip's plane (`flt`), planes[i].ref the SOURCE clip's (`src`), planes[i].dst the output;
+ * refs[i] (may be NULL, as may the array) is the optional third clip the difference is taken
+ * against (default: the source), strides in elements. dark_thr / bright_thr are on the clip's own
+ * scale (the wrapper applies hz.scaleValue, src/helper.zig:312-336, to the 8-bit-scale arguments),
+ * elast as given; one value per plane. Asynchronous on the context stream.
+ */
+int vszip_limit_filter(vszip_ctx *ctx, int dtype, const vszip_plane *planes, const void *const *refs,
+                       const ptrdiff_t *ref_strides, int nplanes, const float *dark_thr,
+                       const float *bright_thr, const float *elast);
+
+/*
  * PlaneMinMax — replaces filter.minMax / minMaxRef / minMaxNoThr / minMaxNoThrRef
  * (src/filters/planeminmax.zig:72-133) called from src/vapoursynth/planeminmax.zig:60-77.
  * minthr == maxthr == 0 is the exact path; otherwise the histogram-percentile rule of

@@ -246,6 +246,29 @@ def limiter_default_range(is_float: bool, bits: int, yuv: bool, tv_range: bool):
     return list(lo), list(hi)
 
 
+def limit_filter(flt: np.ndarray, src: np.ndarray, ref: np.ndarray | None, dark_thr: float, bright_thr: float, elast: float) -> np.ndarray:
+    """vszip.LimitFilter on one plane; thresholds already on the clip's scale (scale_value_from_8bit)."""
+    flt, src = np.ascontiguousarray(flt), np.ascontiguousarray(src)
+    ref = np.ascontiguousarray(ref) if ref is not None else None
+    dst = np.empty_like(flt)
+    fp, fs = _plane(flt)
+    sp, ss = _plane(src)
+    rp, rs = _plane(ref) if ref is not None else (None, 0)
+    dp, ds = _plane(dst)
+    l = lib()
+    l.vszo_limit_filter.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_ssize_t] * 4 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    assert l.vszo_limit_filter(dt_of(flt), fp, sp, rp, dp, fs, ss, rs, ds, flt.shape[1], flt.shape[0], dark_thr, bright_thr, elast) == 0
+    return dst
+
+
+def scale_value_from_8bit(value: float, is_float: bool, bits: int, limited: bool) -> float:
+    """hz.scaleValue with its default options: an 8-bit-scale threshold carried to the clip's format."""
+    l = lib()
+    l.vszo_scale_value_from_8bit.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int]
+    l.vszo_scale_value_from_8bit.restype = C.c_float
+    return float(l.vszo_scale_value_from_8bit(value, int(is_float), bits, int(limited)))
+
+
 def xpsnr_frame(wsse: int, w: int, h: int, depth: int) -> float:
     return lib().vszo_xpsnr_frame(wsse, w, h, depth)
 

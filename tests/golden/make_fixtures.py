@@ -27,7 +27,7 @@ OUT = Path(__file__).resolve().parent
 
 REACHABLE_PREFIXES = ("RGB24|", "RGBS|", "GRAY8|")
 FILES = ["boxblur", "bilateral", "eedi3", "eedi3h", "planeaverage",
-         "planeminmax", "ssimulacra2", "limiter"]
+         "planeminmax", "ssimulacra2", "limiter", "limitfilter"]
 
 
 def main() -> int:

@@ -258,3 +258,40 @@ def test_limiter_default_tables(oracle):
     assert oracle.limiter_default_range(True, 32, False, True) == ([0.0] * 3, [1.0] * 3)  # mask / RGB / Gray
     ramp = np.tile(np.arange(256, dtype=np.uint8), (2, 1))
     assert oracle.limiter(ramp, 10, 200)[0].tolist() == [min(max(x, 10), 200) for x in range(256)]
+
+
+# ---- LimitFilter -------------------------------------------------
+# The reference's goldens are taken on flt = src.vszip.BoxBlur(hradius=2, vradius=2), LimitFilter(flt, src)
+# (the construction of tests/test_int_parity.py:158-167; confirmed by the goldens themselves: the
+# RGB24 key reproduces to every printed digit).
+def _limit_filter(oracle, planes, dark, bright, elast, is_float=False, which=(0, 1, 2)):
+    out = []
+    for p, s in enumerate(planes):
+        s = np.ascontiguousarray(s)
+        flt = oracle.boxblur(s, 2, 1, 2, 1)
+        if p not in which:
+            out.append(flt)  # unprocessed planes are copied from flt (newVideoFrame2 on flt)
+            continue
+        d = oracle.scale_value_from_8bit(dark, is_float, 32 if is_float else 8 * s.itemsize, False)
+        b = oracle.scale_value_from_8bit(bright, is_float, 32 if is_float else 8 * s.itemsize, False)
+        out.append(oracle.limit_filter(flt, s, None, d, b, elast))
+    return out
+
+
+def test_limit_filter_goldens(oracle):
+    g = fx.ref_goldens()["exact"]["limitfilter"]
+    for key, planes, args in (("RGB24|full|bright_thr=8,dark_thr=8,elast=3", list(fx.crop_rgb24()), dict(dark=8, bright=8, elast=3)),
+                              ("RGB24|full|bright_thr=8,dark_thr=8,planes=[0,2]", list(fx.crop_rgb24()), dict(dark=8, bright=8, elast=2, which=(0, 2))),
+                              ("GRAY8|full|bright_thr=4,dark_thr=4,elast=2", [fx.crop_gray8()], dict(dark=4, bright=4, elast=2)),
+                              ("RGBS|full|bright_thr=8,dark_thr=8,elast=3", list(fx.crop_rgbs()), dict(dark=8, bright=8, elast=3, is_float=True))):
+        out = _limit_filter(oracle, planes, **args)
+        for p in range(len(planes)):
+            _check(fx.plane_stats(out[p]), g[key][f"p{p}"])
+
+
+def test_scale_value(oracle):
+    """hz.scaleValue defaults (src/helper.zig:312-336): identity at 8 bit, x257 full range / x256-ish limited at 16 bit, /255 for float"""
+    assert oracle.scale_value_from_8bit(8, False, 8, True) == 8.0
+    assert oracle.scale_value_from_8bit(8, False, 16, False) == float(np.round(np.float32(8) * (np.float32(65535) / np.float32(255))))
+    assert oracle.scale_value_from_8bit(8, False, 16, True) == float(np.round(np.float32(8) * (np.float32(60160 - 4096) / np.float32(219))))
+    assert oracle.scale_value_from_8bit(8, True, 32, False) == float(np.float32(8) * (np.float32(1) / np.float32(255)))

@@ -85,6 +85,7 @@ SYMBOLS = {
     "vszip_xpsnr_value": (C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64, _i]),
     "vszip_xpsnr_average": (C.c_double, [C.c_double, C.c_double, C.c_uint64, C.c_uint64, _i, C.c_uint64]),
     "vszip_limiter": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vszip_limit_filter": (_i, [_vp, _i, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -284,6 +285,15 @@ class Device:
         n = len(srcs)
         table = self.plane_table(srcs, dsts)
         self.check(self.lib.vszip_limiter(self.ctx, _NP2DT[srcs[0].dtype], table, n, (C.c_double * n)(*[float(v) for v in lo]), (C.c_double * n)(*[float(v) for v in hi])))
+
+    def limit_filter(self, flts, srcs, dsts, dark_thr, bright_thr, elast, refs=None):
+        """vszip.LimitFilter per plane; thresholds already on the clip's scale. refs: optional third clip's planes."""
+        n = len(flts)
+        table = self.plane_table(flts, dsts, srcs)
+        fa = lambda v: (C.c_float * n)(*[float(x) for x in v])
+        rp = (C.c_void_p * n)(*[p.ptr for p in refs]) if refs is not None else None
+        rs = (C.c_ssize_t * n)(*[p.stride for p in refs]) if refs is not None else None
+        self.check(self.lib.vszip_limit_filter(self.ctx, _NP2DT[flts[0].dtype], table, rp, rs, n, fa(dark_thr), fa(bright_thr), fa(elast)))
 
     def plane_minmax(self, srcs, minthr=0.0, maxthr=0.0, refs=None, bits=None):
         n = len(srcs)
