@@ -374,6 +374,25 @@ def limiter_leg(dev, timed, frames=16):
                            "workload": f"vszip.Limiter tv_range: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
 
 
+def limit_filter_leg(dev, timed, frames=16):
+    """vszip.LimitFilter(flt, src) on 3840x2160 YUV420P16: two streams in, one out."""
+    base = make_frame(11, W4K, H4K)
+    flts, srcs, dsts = [], [], []
+    for f in range(frames):
+        for p in base:
+            srcs.append(dev.upload(np.roll(p, f * 5, axis=1)))
+            flts.append(dev.upload(np.roll(p, f * 5 + 1, axis=1)))
+            dsts.append(dev.empty(p.shape[0], p.shape[1], p.dtype))
+    n = len(srcs)
+    dt, _, dom_ms, launches = timed.run(lambda: (dev.limit_filter(flts, srcs, dsts, [2056.0] * n, [2056.0] * n, [3.0] * n), dev.sync()), 10, 2)
+    fb = 3 * sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K)) * frames
+    gbs = fb * 10 / (dom_ms * 1e-3) / 1e9
+    return {"limit_filter_4k": {"value": frames * 10 / dt, "unit": "frames/s",
+                                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                             "kernel": "limit_filter_kernel<u16>", "avg_launch_us": dom_ms * 1e3 / launches},
+                                "workload": f"vszip.LimitFilter dark_thr=bright_thr=8 elast=3: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
+
+
 def boxblur_other_paths_leg(dev, timed, frames=8):
     """The BoxBlur paths beside the headline one: the runtime path (radius > 22 or several passes,
     boxblur_runtime.zig) on 4K YUV420P16 and the compile-time float path on 4K YUV420PS."""
@@ -569,6 +588,7 @@ def main() -> int:
                 others["plane_stats_4k"] = {"error": str(e)}
             try:
                 others.update(limiter_leg(dev, timed))
+                others.update(limit_filter_leg(dev, timed))
             except Exception as e:
                 others["limiter_4k"] = {"error": str(e)}
             try:

@@ -238,12 +238,10 @@ class _Namespace:
         self._clip = clip
 
     def __getattr__(self, fn):
-        first = {"PlaneAverage": "clipa", "PlaneMinMax": "clipa", "SSIMULACRA2": "reference", "XPSNR": "reference"}.get(fn, "clip")
-
         def call(*args, **kw):
-            if self._clip is not None:
-                kw = {first: self._clip, **kw}
             names = signature(fn)
+            if self._clip is not None:
+                kw = {names[0]: self._clip, **kw}  # clip.vszip.F(...): the clip is the function's first argument
             for name, a in zip([n for n in names if n not in kw], args):
                 kw[name] = a
             return invoke(fn, **kw)

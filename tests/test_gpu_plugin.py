@@ -331,3 +331,41 @@ def test_limiter_through_plugin(oracle):
     got = vs.source([nat], vs.YUV444P16).vszip.Limiter(min=[10000, 20000, 10000], max=[50000, 55000, 45000]).get_frame(0)
     for p, (lo, hi) in enumerate(zip([10000, 20000, 10000], [50000, 55000, 45000])):
         assert np.array_equal(got[p], oracle.limiter(nat[p], lo, hi))
+
+
+def test_limit_filter_through_plugin(oracle):
+    """flt = BoxBlur(2,2) of src like the reference's own cases; thresholds arrive on the 8-bit scale
+    and are carried to the clip's depth / range by the wrapper (hz.scaleValue): identity at 8 bit, full
+    range for RGB, limited for YUV without a range prop, the _ColorRange prop when present; per-plane
+    arrays; the optional ref clip; planes subset copies from flt."""
+    src8 = list(fx.crop_rgb24()[:, :96, :160])
+    clip8 = vs.source([src8], vs.RGB24)
+    flt8 = clip8.vszip.BoxBlur(hradius=2, vradius=2)
+    out = flt8.vszip.LimitFilter(src=clip8, dark_thr=8, bright_thr=8, elast=3).get_frame(0)
+    for p in range(3):
+        want = oracle.limit_filter(oracle.boxblur(np.ascontiguousarray(src8[p]), 2, 1, 2, 1), src8[p], None, 8, 8, 3)
+        assert np.array_equal(out[p], want)
+    nat = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate([(96, 160), (48, 80), (48, 80)])]
+    for props, limited in ((None, True), ({"_ColorRange": 0}, False), ({"_ColorRange": 1}, True)):
+        c16 = vs.source([nat], vs.YUV420P16, props=props)
+        f16 = c16.vszip.BoxBlur(hradius=2, vradius=2)
+        r16 = c16.vszip.BoxBlur(hradius=4, vradius=4)
+        got = f16.vszip.LimitFilter(src=c16, ref=r16, dark_thr=[16, 4], bright_thr=[8, 2], elast=[4, 2]).get_frame(0)
+        for p in range(3):
+            dk = oracle.scale_value_from_8bit([16, 4, 4][p], False, 16, limited)
+            br = oracle.scale_value_from_8bit([8, 2, 2][p], False, 16, limited)
+            fl = oracle.boxblur(nat[p], 2, 1, 2, 1)
+            rf = oracle.boxblur(nat[p], 4, 1, 4, 1)
+            assert np.array_equal(got[p], oracle.limit_filter(fl, nat[p], rf, dk, br, [4, 2, 2][p])), (props, p)
+    c16 = vs.source([nat], vs.YUV420P16)
+    f16 = c16.vszip.BoxBlur(hradius=2, vradius=2)
+    part = f16.vszip.LimitFilter(src=c16, dark_thr=8, bright_thr=8, planes=[0]).get_frame(0)
+    flt_frame = f16.get_frame(0)
+    assert np.array_equal(part[1], flt_frame[1]) and np.array_equal(part[2], flt_frame[2]) and not np.array_equal(part[0], flt_frame[0])
+    srcf = [np.ascontiguousarray(p[:64, :128]) for p in fx.crop_rgbs()]
+    cf = vs.source([srcf], vs.RGBS)
+    ff = cf.vszip.BoxBlur(hradius=2, vradius=2)
+    gotf = ff.vszip.LimitFilter(src=cf, dark_thr=8, bright_thr=8, elast=3).get_frame(0)
+    t = oracle.scale_value_from_8bit(8, True, 32, False)
+    for p in range(3):
+        assert np.array_equal(gotf[p], oracle.limit_filter(oracle.boxblur(srcf[p], 2, 1, 2, 1), srcf[p], None, t, t, 3))

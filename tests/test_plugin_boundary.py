@@ -13,6 +13,7 @@ SIGNATURES = {
     "BoxBlur": "clip:vnode;planes:int[]:opt;hradius:int:opt;hpasses:int:opt;vradius:int:opt;vpasses:int:opt",
     "EEDI3": "clip:vnode;field:int;dh:int:opt;alpha:float:opt;beta:float:opt;gamma:float:opt;nrad:int:opt;mdis:int:opt;hp:int:opt;vcheck:int:opt;"
              "vthresh0:float:opt;vthresh1:float:opt;vthresh2:float:opt;sclip:vnode:opt;mclip:vnode:opt;",
+    "LimitFilter": "flt:vnode;src:vnode;ref:vnode:opt;dark_thr:float[]:opt;bright_thr:float[]:opt;elast:float[]:opt;planes:int[]:opt;",  # src/vszip.zig:154
     "Limiter": "clip:vnode;min:float[]:opt;max:float[]:opt;tv_range:int:opt;mask:int:opt;planes:int[]:opt;",  # src/vszip.zig:162
     "PlaneAverage": "clipa:vnode;exclude:int[];clipb:vnode:opt;planes:int[]:opt;prop:data:opt;",
     "PlaneMinMax": "clipa:vnode;minthr:float:opt;maxthr:float:opt;clipb:vnode:opt;planes:int[]:opt;prop:data:opt;",
@@ -170,3 +171,27 @@ def test_limiter_32bit_explicit_bounds_are_unreachable():
     (reference tests/test_limiter.py:150-160)."""
     with pytest.raises(vs.Error, match="min value must be less than or equal to peak value"):
         vs.blank(vs.GRAY32, 64, 32, 0).vszip.Limiter(min=[0], max=[10])
+
+
+@pytest.mark.parametrize("args,msg", [
+    (dict(dark_thr=[1, 2, 3, 4]), "dark_thr has too many elements"),
+    (dict(bright_thr=-1.0), "below minimum"),
+    (dict(dark_thr=256.0), "above maximum"),
+    (dict(elast=70000.0), "above maximum"),
+    (dict(planes=[3]), "plane index out of range"),
+    (dict(planes=[1, 1]), "plane specified twice"),
+])
+def test_limit_filter_validation(args, msg):
+    with pytest.raises(vs.Error, match=msg):
+        _yuv().vszip.LimitFilter(src=_yuv(), **args)
+
+
+def test_limit_filter_clip_mismatch():
+    with pytest.raises(vs.Error, match="same width and height"):
+        _yuv().vszip.LimitFilter(src=_yuv(w=48))
+    with pytest.raises(vs.Error, match="same bit depth"):
+        _yuv().vszip.LimitFilter(src=_yuv(vs.YUV420P10))
+    with pytest.raises(vs.Error, match="same length"):
+        _yuv(length=3).vszip.LimitFilter(src=_yuv(length=2))
+    with pytest.raises(vs.Error, match="same length"):
+        _yuv(length=3).vszip.LimitFilter(src=_yuv(length=3), ref=_yuv(length=2))

@@ -23,5 +23,6 @@ for leg in sys.argv[1:]:
         print(json.dumps(bench.boxblur_other_paths_leg(dev, timed)))
     elif leg == "limiter":
         print(json.dumps(bench.limiter_leg(dev, timed)))
+        print(json.dumps(bench.limit_filter_leg(dev, timed)))
     elif leg == "planestats":
         print(json.dumps(bench.planestats_leg(dev, timed)))

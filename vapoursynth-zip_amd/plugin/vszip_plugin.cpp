@@ -832,6 +832,173 @@ void VS_CC limiterCreate(const VSMap *in, VSMap *out, void *, VSCore *core, cons
     api->createVideoFilter(out, "Limiter", d.vi, limiterGetFrame, limiterFree, fmParallel, deps, 1, data, core);
 }
 
+// ---------------------------------------------------------------------------
+// LimitFilter (src/vapoursynth/limit_filter.zig, src/filters/limit_filter.zig) — SURVEY 8f rank 4
+// ---------------------------------------------------------------------------
+struct LimitFilterData {
+    VSNode *flt, *src, *ref;
+    const VSVideoInfo *vi;
+    int dt;
+    bool planes[3];
+    float dark[3], bright[3], elast[3];
+};
+
+// hz.getColorRange (helper.zig:261-279): frame 0's range prop, else RGB -> full, others -> limited.
+// The prop is read through the un-vendored vapoursynth-zig binding; both spellings are honoured here:
+// _Range (1 = full, 0 = limited) and the older _ColorRange (0 = full, 1 = limited).
+bool clip_is_limited_range(const Z &z, VSNode *node) {
+    char err[256];
+    const VSFrame *f0 = z.api->getFrame(0, node, err, sizeof err);
+    int limited = -1;
+    if (f0) {
+        const VSMap *props = z.api->getFramePropertiesRO(f0);
+        int e = 0;
+        const int64_t r = z.api->mapGetInt(props, "_Range", 0, &e);
+        if (!e) limited = r == 0;
+        if (limited < 0) {
+            e = 0;
+            const int64_t c = z.api->mapGetInt(props, "_ColorRange", 0, &e);
+            if (!e) limited = c == 1;
+        }
+        z.api->freeFrame(f0);
+    }
+    if (limited >= 0) return limited != 0;
+    return z.api->getVideoInfo(node)->format.colorFamily != cfRGB;
+}
+
+// hz.scaleValue(value, node, zapi, .{}) :312-336 — from the 8-bit integer luma scale to the clip's format
+float scale_value_from_8bit(const Z &z, float value, VSNode *target) {
+    const VSVideoFormat &fo = z.api->getVideoInfo(target)->format;
+    if (fo.bitsPerSample == 8) return value;
+    const bool limited = clip_is_limited_range(z, target), is_float = fo.sampleType == stFloat;
+    const int b = fo.bitsPerSample;
+    const float in_peak = limited ? 235.0f : 255.0f, in_low = limited ? 16.0f : 0.0f;
+    const float out_peak = is_float ? 1.0f : (limited ? (float)(235 << (b - 8)) : (float)((1 << b) - 1));
+    const float out_low = is_float ? 0.0f : (limited ? (float)(16 << (b - 8)) : 0.0f);
+    float out = value * ((out_peak - out_low) / (in_peak - in_low));
+    if (!is_float) out = std::fmax(std::fmin(std::round(out), (float)((1 << b) - 1)), 0.0f);
+    return out;
+}
+
+const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
+    auto *d = static_cast<LimitFilterData *>(inst);
+    Z z{api, core, fctx};
+    if (reason == arInitial) {
+        api->requestFrameFilter(n, d->flt, fctx);
+        api->requestFrameFilter(n, d->src, fctx);
+        if (d->ref) api->requestFrameFilter(n, d->ref, fctx);
+    } else if (reason == arAllFramesReady) {
+        const VSFrame *src = api->getFrameFilter(n, d->src, fctx), *flt = api->getFrameFilter(n, d->flt, fctx);
+        const VSFrame *ref = d->ref ? api->getFrameFilter(n, d->ref, fctx) : nullptr;
+        auto release = [&] {
+            api->freeFrame(src);
+            api->freeFrame(flt);
+            if (ref) api->freeFrame(ref);
+        };
+        const VSVideoFormat *vf = api->getVideoFrameFormat(flt);
+        const VSFrame *psrc[3] = {d->planes[0] ? nullptr : flt, d->planes[1] ? nullptr : flt, d->planes[2] ? nullptr : flt};
+        const int pidx[3] = {0, 1, 2};
+        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(flt, 0), api->getFrameHeight(flt, 0), psrc, pidx, flt, core);
+        Gpu *g = gpu_for_frame(n);
+        if (!g) {
+            release();
+            return fail(z, nullptr, dst, "LimitFilter", "no MI355X device available (the plugin has no CPU fallback)");
+        }
+        std::vector<vszip_plane> tab;
+        std::vector<DPlane> outs;
+        std::vector<int> which;
+        std::vector<const void *> refs;
+        std::vector<ptrdiff_t> rstr;
+        std::vector<float> dk, br, el;
+        for (int p = 0; p < vf->numPlanes; ++p) {
+            if (!d->planes[p]) continue;
+            DPlane f = z.upload(g, flt, p), s = z.upload(g, src, p), o = z.blank(g, f.w, f.h, f.bps);
+            DPlane r;
+            if (ref) r = z.upload(g, ref, p);
+            if (!f.ptr || !s.ptr || !o.ptr || (ref && !r.ptr)) {
+                release();
+                return fail(z, g, dst, "LimitFilter", "device staging failed");
+            }
+            tab.push_back(mk_plane(f, &o, &s));
+            outs.push_back(o);
+            which.push_back(p);
+            refs.push_back(ref ? r.ptr : nullptr);
+            rstr.push_back(ref ? r.stride : 0);
+            dk.push_back(d->dark[p]);
+            br.push_back(d->bright[p]);
+            el.push_back(d->elast[p]);
+        }
+        int rc = tab.empty() ? VSZIP_OK
+                             : vszip_limit_filter(g->ctx, d->dt, tab.data(), ref ? refs.data() : nullptr, ref ? rstr.data() : nullptr, (int)tab.size(), dk.data(),
+                                                  br.data(), el.data());
+        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
+            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
+        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        release();
+        if (rc != VSZIP_OK) return fail(z, g, dst, "LimitFilter", "GPU kernel failed");
+        return dst;
+    }
+    return nullptr;
+}
+
+void VS_CC limitFilterFree(void *inst, VSCore *, const VSAPI *api) {
+    auto *d = static_cast<LimitFilterData *>(inst);
+    api->freeNode(d->flt);
+    api->freeNode(d->src);
+    if (d->ref) api->freeNode(d->ref);
+    delete d;
+}
+
+void VS_CC limitFilterCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) {
+    Z z{api, core, nullptr};
+    LimitFilterData d{};
+    d.flt = z.getNode(in, "flt");
+    d.vi = api->getVideoInfo(d.flt);
+    if (!select_dtype(z, out, d.flt, d.vi, "LimitFilter", false, &d.dt)) return;
+    d.src = z.getNode(in, "src");
+    d.ref = z.getNode(in, "ref");
+    auto free_all = [&] {
+        api->freeNode(d.flt);
+        api->freeNode(d.src);
+        if (d.ref) api->freeNode(d.ref);
+    };
+    // hz.compareNodes(.SAME_LEN) over flt, src, ref (helper.zig:166-215): on a mismatch every node is released
+    for (VSNode *other : {d.src, d.ref}) {
+        if (!other) continue;
+        const VSVideoInfo *a = d.vi, *b = api->getVideoInfo(other);
+        const char *msg = nullptr;
+        if (!is_constant_format(b))
+            msg = "all input clips must have constant format.";
+        else if (a->width != b->width || a->height != b->height)
+            msg = "all input clips must have the same width and height.";
+        else if (a->format.colorFamily != b->format.colorFamily)
+            msg = "all input clips must have the same color family.";
+        else if (a->format.subSamplingW != b->format.subSamplingW || a->format.subSamplingH != b->format.subSamplingH)
+            msg = "all input clips must have the same subsampling.";
+        else if (a->format.bitsPerSample != b->format.bitsPerSample)
+            msg = "all input clips must have the same bit depth.";
+        else if (a->numFrames != b->numFrames)
+            msg = "all input clips must have the same length.";
+        if (msg) {
+            z.setError(out, "LimitFilter: %s", msg);
+            free_all();
+            return;
+        }
+    }
+    d.planes[0] = d.planes[1] = d.planes[2] = true;
+    if (!get_planes(z, in, out, {d.flt, d.src, d.ref}, d.planes, d.vi->format.numPlanes, "LimitFilter")) return;
+    if (!get_array3<float>(z, in, out, "dark_thr", "LimitFilter", 1.0f, 0.0f, 255.0f, true, d.dark, {d.flt, d.src, d.ref})) return;
+    if (!get_array3<float>(z, in, out, "bright_thr", "LimitFilter", 1.0f, 0.0f, 255.0f, true, d.bright, {d.flt, d.src, d.ref})) return;
+    if (!get_array3<float>(z, in, out, "elast", "LimitFilter", 2.0f, 0.0f, 65535.0f, true, d.elast, {d.flt, d.src, d.ref})) return;
+    for (int i = 0; i < 3; ++i) {  // :103-107
+        d.dark[i] = scale_value_from_8bit(z, d.dark[i], d.flt);
+        d.bright[i] = scale_value_from_8bit(z, d.bright[i], d.flt);
+    }
+    auto *data = new LimitFilterData(d);
+    VSFilterDependency deps[] = {{d.flt, rpStrictSpatial}, {d.src, rpStrictSpatial}, {d.ref, rpStrictSpatial}};
+    api->createVideoFilter(out, "LimitFilter", d.vi, limitFilterGetFrame, limitFilterFree, fmParallel, deps, d.ref ? 3 : 2, data, core);
+}
+
 // hz.bitDepth (helper.zig:470-494): depth conversion is the host's resize.Point with the given
 // dither, exactly like the reference. Consumes `node`; NULL (node freed) when the host has no
 // resize plugin or the conversion fails.
@@ -1355,6 +1522,7 @@ VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI
     vspapi->configPlugin("com.julek.vszip", "vszip", "VapourSynth Zig Image Process", VS_MAKE_VERSION(19, 0), VAPOURSYNTH_API_VERSION, 0, plugin);
     vspapi->registerFunction("Bilateral", "clip:vnode;ref:vnode:opt;sigmaS:float[]:opt;sigmaR:float[]:opt;planes:int[]:opt;algorithm:int[]:opt;PBFICnum:int[]:opt",
                              "clip:vnode;", bilateralCreate, nullptr, plugin);
+    vspapi->registerFunction("LimitFilter", "flt:vnode;src:vnode;ref:vnode:opt;dark_thr:float[]:opt;bright_thr:float[]:opt;elast:float[]:opt;planes:int[]:opt;", "clip:vnode;", limitFilterCreate, nullptr, plugin);
     vspapi->registerFunction("Limiter", "clip:vnode;min:float[]:opt;max:float[]:opt;tv_range:int:opt;mask:int:opt;planes:int[]:opt;", "clip:vnode;", limiterCreate, nullptr, plugin);
     vspapi->registerFunction("BoxBlur", "clip:vnode;planes:int[]:opt;hradius:int:opt;hpasses:int:opt;vradius:int:opt;vpasses:int:opt", "clip:vnode;", boxblurCreate, nullptr, plugin);
     vspapi->registerFunction("EEDI3", kEedi3Args, "clip:vnode;", eedi3Create, nullptr, plugin);
