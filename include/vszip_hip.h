@@ -136,6 +136,13 @@ int vszip_limit_filter(vszip_ctx *ctx, int dtype, const vszip_plane *planes, con
                        const float *bright_thr, const float *elast);
 
 /*
+ * AdaptiveBinarize — replaces the getFrame body of src/vapoursynth/adaptive_binarize.zig:26-73:
+ * 8-bit planes, dst = 255 where clip2 - clip >= c (compared in i16, c clamped to [-256, 256]
+ * :96-99), else 0. planes[i].src is `clip`'s plane, planes[i].ref `clip2`'s. Asynchronous.
+ */
+int vszip_adaptive_binarize(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int c);
+
+/*
  * PlaneMinMax — replaces filter.minMax / minMaxRef / minMaxNoThr / minMaxNoThrRef
  * (src/filters/planeminmax.zig:72-133) called from src/vapoursynth/planeminmax.zig:60-77.
  * minthr == maxthr == 0 is the exact path; otherwise the histogram-percentile rule of

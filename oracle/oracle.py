@@ -269,6 +269,16 @@ def scale_value_from_8bit(value: float, is_float: bool, bits: int, limited: bool
     return float(l.vszo_scale_value_from_8bit(value, int(is_float), bits, int(limited)))
 
 
+def adaptive_binarize(src: np.ndarray, src2: np.ndarray, c: int = 3) -> np.ndarray:
+    """vszip.AdaptiveBinarize on one u8 plane."""
+    src, src2 = np.ascontiguousarray(src, np.uint8), np.ascontiguousarray(src2, np.uint8)
+    dst = np.empty_like(src)
+    l = lib()
+    l.vszo_adaptive_binarize.argtypes = [C.c_void_p] * 3 + [C.c_ssize_t] * 3 + [C.c_int] * 3
+    assert l.vszo_adaptive_binarize(src.ctypes.data, src2.ctypes.data, dst.ctypes.data, src.strides[0], src2.strides[0], dst.strides[0], src.shape[1], src.shape[0], int(c)) == 0
+    return dst
+
+
 def xpsnr_frame(wsse: int, w: int, h: int, depth: int) -> float:
     return lib().vszo_xpsnr_frame(wsse, w, h, depth)
 

@@ -66,3 +66,15 @@ def test_many_planes_and_errors(dev, oracle):
         assert np.array_equal(out[i], oracle.limiter(planes[i], lo[i], hi[i]))
     with pytest.raises(vszip_amd.VszipError, match="min value must be less than or equal to max value"):
         _run(dev, planes[:1], [10], [5])
+
+
+def test_adaptive_binarize_matches_oracle(dev, oracle):
+    """vszip_adaptive_binarize (src/vapoursynth/adaptive_binarize.zig:26-73) on aligned and tight strides."""
+    for shape, align in (((61, 203), 1), ((128, 512), 32), ((5, 9), 1)):
+        a = fx.splitmix64_plane(31, shape, np.uint8)
+        b = fx.splitmix64_plane(32, shape, np.uint8)
+        for c in (3, 0, -5, 255, -255, 256, -256, 300):
+            da, db = dev.upload(a, align), dev.upload(b, align)
+            dd = dev.empty(shape[0], shape[1], np.uint8, align)
+            dev.adaptive_binarize([da], [db], [dd], c)
+            assert np.array_equal(dev.download(dd), oracle.adaptive_binarize(a, b, c)), (shape, c)

@@ -369,3 +369,20 @@ def test_limit_filter_through_plugin(oracle):
     t = oracle.scale_value_from_8bit(8, True, 32, False)
     for p in range(3):
         assert np.array_equal(gotf[p], oracle.limit_filter(oracle.boxblur(srcf[p], 2, 1, 2, 1), srcf[p], None, t, t, 3))
+
+
+def test_adaptive_binarize_through_plugin(oracle):
+    """255 where clip2 - clip >= c else 0 on every plane, c clamped to [-256, 256], output tagged full
+    range (reference tests/test_adaptive_binarize.py:58-70); clip2 here is vszip.BoxBlur(5, 5)."""
+    planes = [fx.tiled_natural(s, np.uint8, p) for p, s in enumerate([(98, 162), (49, 81), (49, 81)])]
+    src = vs.source([planes], vs.YUV420P8)
+    blur = src.vszip.BoxBlur(hradius=5, vradius=5)
+    bf = blur.get_frame(0)
+    for c in (3, 0, 12, -5, 1000, -1000):
+        out = src.vszip.AdaptiveBinarize(clip2=blur, c=c).get_frame(0)
+        for p in range(3):
+            assert np.array_equal(out[p], oracle.adaptive_binarize(planes[p], bf[p], c)), (c, p)
+            assert set(np.unique(out[p]).tolist()) <= {0, 255}
+        assert out.props["_ColorRange"] == 0
+    assert np.all(src.vszip.AdaptiveBinarize(clip2=blur, c=1000).get_frame(0)[0] == 0)
+    assert np.all(src.vszip.AdaptiveBinarize(clip2=blur, c=-1000).get_frame(0)[0] == 255)

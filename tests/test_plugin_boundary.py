@@ -9,6 +9,7 @@ from fakevs import fakevs as vs
 
 # src/vszip.zig:48,64,186,194,210,218 and src/vapoursynth/eedi3.zig:494 — byte-identical signatures
 SIGNATURES = {
+    "AdaptiveBinarize": "clip:vnode;clip2:vnode;c:int:opt;",  # src/vszip.zig:40
     "Bilateral": "clip:vnode;ref:vnode:opt;sigmaS:float[]:opt;sigmaR:float[]:opt;planes:int[]:opt;algorithm:int[]:opt;PBFICnum:int[]:opt",
     "BoxBlur": "clip:vnode;planes:int[]:opt;hradius:int:opt;hpasses:int:opt;vradius:int:opt;vpasses:int:opt",
     "EEDI3": "clip:vnode;field:int;dh:int:opt;alpha:float:opt;beta:float:opt;gamma:float:opt;nrad:int:opt;mdis:int:opt;hp:int:opt;vcheck:int:opt;"
@@ -195,3 +196,14 @@ def test_limit_filter_clip_mismatch():
         _yuv(length=3).vszip.LimitFilter(src=_yuv(length=2))
     with pytest.raises(vs.Error, match="same length"):
         _yuv(length=3).vszip.LimitFilter(src=_yuv(length=3), ref=_yuv(length=2))
+
+
+def test_adaptive_binarize_validation():
+    with pytest.raises(vs.Error, match="only 8 bit int format supported"):
+        _yuv(vs.YUV420P16).vszip.AdaptiveBinarize(clip2=_yuv(vs.YUV420P16))
+    with pytest.raises(vs.Error, match="clip2 is required"):
+        _yuv().vszip.AdaptiveBinarize()
+    with pytest.raises(vs.Error, match="same width and height"):
+        _yuv().vszip.AdaptiveBinarize(clip2=_yuv(w=48))
+    with pytest.raises(vs.Error, match="second clip has less frames"):
+        _yuv(length=3).vszip.AdaptiveBinarize(clip2=_yuv(length=2))

@@ -86,6 +86,7 @@ SYMBOLS = {
     "vszip_xpsnr_average": (C.c_double, [C.c_double, C.c_double, C.c_uint64, C.c_uint64, _i, C.c_uint64]),
     "vszip_limiter": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_limit_filter": (_i, [_vp, _i, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vszip_adaptive_binarize": (_i, [_vp, _PP, _i, _i]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -294,6 +295,10 @@ class Device:
         rp = (C.c_void_p * n)(*[p.ptr for p in refs]) if refs is not None else None
         rs = (C.c_ssize_t * n)(*[p.stride for p in refs]) if refs is not None else None
         self.check(self.lib.vszip_limit_filter(self.ctx, _NP2DT[flts[0].dtype], table, rp, rs, n, fa(dark_thr), fa(bright_thr), fa(elast)))
+
+    def adaptive_binarize(self, clips, clips2, dsts, c=3):
+        """dsts[i] = 255 where clips2[i] - clips[i] >= c else 0 (u8 planes)."""
+        self.check(self.lib.vszip_adaptive_binarize(self.ctx, self.plane_table(clips, dsts, clips2), len(clips), int(c)))
 
     def plane_minmax(self, srcs, minthr=0.0, maxthr=0.0, refs=None, bits=None):
         n = len(srcs)
