@@ -138,8 +138,11 @@ __global__ __launch_bounds__(64) void boxblur_rt_vint_kernel(const RParams prm) 
 template <typename T>
 struct RtVec {
     static constexpr int V = 16 / (int)sizeof(T);
-    static __device__ __forceinline__ void load(const T *p, uint32_t v[V]) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    // raw(): the 16-byte load alone, so that a caller can put several rows in flight before it
+    // unpacks the first (a vertical walk is otherwise one global round trip per row)
+    static __device__ __forceinline__ uint4 raw(const T *p) { return *reinterpret_cast<const uint4 *>(p); }
+    static __device__ __forceinline__ void load(const T *p, uint32_t v[V]) { unpack(raw(p), v); }
+    static __device__ __forceinline__ void unpack(const uint4 q, uint32_t v[V]) {
         const uint32_t d[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -202,13 +205,25 @@ __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm
     const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
     auto mrow = [&](int j) { return j < 0 ? -j - 1 : (j >= len ? 2 * len - 1 - j : j); };
 
+    // Rows are fetched kPf at a time (raw 16-byte loads, all issued before the first is unpacked): the
+    // walk down a band is a chain of dependent adds, not of memory round trips.
+    constexpr int kPf = 8;
     uint32_t e0[V], e[V], kk[V], t[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) e0[k] = 0;
-    for (int r = 0; r <= R; ++r) {  // E_0 = s[R] + 2 * sum_{i<R} s[i]
-        X::load(s + (size_t)r * ss, t);
+    for (int r0 = 0; r0 <= R; r0 += kPf) {  // E_0 = s[R] + 2 * sum_{i<R} s[i]
+        uint4 q[kPf];
 #pragma unroll
-        for (int k = 0; k < V; ++k) e0[k] += r < R ? 2u * t[k] : t[k];
+        for (int u = 0; u < kPf; ++u) q[u] = X::raw(s + (size_t)min(r0 + u, R) * ss);
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) {
+            const int r = r0 + u;
+            if (r <= R) {
+                X::unpack(q[u], t);
+#pragma unroll
+                for (int k = 0; k < V; ++k) e0[k] += r < R ? 2u * t[k] : t[k];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) kk[k] = 32768u + (uint32_t)(((uint64_t)e0[k] * invlo) >> 16);
@@ -218,23 +233,44 @@ __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) e[k] = 0;
-        for (int j = y0 - R; j <= y0 + R; ++j) {
-            X::load(s + (size_t)mrow(j) * ss, t);
+        for (int j0 = y0 - R; j0 <= y0 + R; j0 += kPf) {
+            uint4 q[kPf];
 #pragma unroll
-            for (int k = 0; k < V; ++k) e[k] += t[k];
+            for (int u = 0; u < kPf; ++u) q[u] = X::raw(s + (size_t)mrow(min(j0 + u, y0 + R)) * ss);
+#pragma unroll
+            for (int u = 0; u < kPf; ++u) {
+                if (j0 + u <= y0 + R) {
+                    X::unpack(q[u], t);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) e[k] += t[k];
+                }
+            }
         }
     }
-#pragma unroll 4
-    for (int i = y0; i < y1; ++i) {
-        uint32_t o[V], a[V], c[V];
-        X::load(s + (size_t)mrow(i + 1 + R) * ss, a);
-        X::load(s + (size_t)mrow(i - R) * ss, c);
+    constexpr int kPm = 4;  // output rows per chunk of the sliding part: 2 * kPm loads in flight
+    for (int i0 = y0; i0 < y1; i0 += kPm) {
+        uint4 qa[kPm], qc[kPm];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            o[k] = (uint32_t)(((uint64_t)e[k] * inv2 + kk[k]) >> 16);
-            e[k] += a[k] - c[k];
+        for (int u = 0; u < kPm; ++u) {
+            const int i = min(i0 + u, y1 - 1);
+            qa[u] = X::raw(s + (size_t)mrow(i + 1 + R) * ss);
+            qc[u] = X::raw(s + (size_t)mrow(i - R) * ss);
         }
-        X::store(d + (size_t)i * ds, o, nst);
+#pragma unroll
+        for (int u = 0; u < kPm; ++u) {
+            const int i = i0 + u;
+            if (i < y1) {
+                uint32_t o[V], a[V], c[V];
+                X::unpack(qa[u], a);
+                X::unpack(qc[u], c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    o[k] = (uint32_t)(((uint64_t)e[k] * inv2 + kk[k]) >> 16);
+                    e[k] += a[k] - c[k];
+                }
+                X::store(d + (size_t)i * ds, o, nst);
+            }
+        }
     }
 }
 
@@ -332,18 +368,19 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
     const int nch = (w + CH - 1) / CH;
     auto pidx = [&](uint32_t c) { return ((c / (uint32_t)CH) % 3u) * (uint32_t)CH + (c % (uint32_t)V) * 64u + (c % (uint32_t)CH) / (uint32_t)V; };
     uint32_t carry = 0;
-    auto prefix_chunk = [&](int ch) {
+    // the row is fetched one chunk ahead of its prefix (a load issued and scanned in the same step
+    // would put a global round trip on every chunk of the row's chain)
+    auto fetch = [&](int ch) -> uint4 {
+        const int x0 = ch * CH + lane * V;
+        return (ch < nch && x0 < w) ? X::raw(s + x0) : make_uint4(0, 0, 0, 0);  // [w, stride) is readable padding; masked below
+    };
+    auto prefix_chunk = [&](int ch, const uint4 q) {
         const int x0 = ch * CH + lane * V;
         uint32_t v[V];
-        if (x0 < w) {
-            X::load(s + x0, v);  // [w, stride) is readable padding; masked below
+        X::unpack(q, v);
 #pragma unroll
-            for (int k = 0; k < V; ++k)
-                if (x0 + k >= w) v[k] = 0;
-        } else {
-#pragma unroll
-            for (int k = 0; k < V; ++k) v[k] = 0;
-        }
+        for (int k = 0; k < V; ++k)
+            if (x0 + k >= w) v[k] = 0;
 #pragma unroll
         for (int k = 1; k < V; ++k) v[k] += v[k - 1];
         const uint32_t incl = wave_incl_scan_dpp(v[V - 1]);
@@ -353,8 +390,10 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
         for (int k = 0; k < V; ++k) slot[k * 64 + lane] = v[k] + base;
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     };
-    prefix_chunk(0);
-    if (nch > 1) prefix_chunk(1);
+    const uint4 q0 = fetch(0), q1 = fetch(1);
+    uint4 qn = fetch(2);  // raw samples of the chunk the loop scans next
+    prefix_chunk(0, q0);
+    if (nch > 1) prefix_chunk(1, q1);
     vszip_wave_fence();
     const uint32_t ksize = 2u * (uint32_t)R + 1u;
     const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
@@ -364,7 +403,9 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
     const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
     for (int ch = 0; ch < nch; ++ch) {
         if (ch >= 1 && ch + 1 < nch) {  // chunk ch+1 replaces chunk ch-2, which no window reaches any more
-            prefix_chunk(ch + 1);
+            const uint4 cur = qn;
+            qn = fetch(ch + 2);
+            prefix_chunk(ch + 1, cur);
             vszip_wave_fence();
         }
         const int x0 = ch * CH + lane * V;
