@@ -24,5 +24,9 @@ for leg in sys.argv[1:]:
     elif leg == "limiter":
         print(json.dumps(bench.limiter_leg(dev, timed)))
         print(json.dumps(bench.limit_filter_leg(dev, timed)))
+    elif leg == "pbfic":
+        import runpy
+
+        runpy.run_path(str(ROOT / "tools" / "pbfic_timing.py"))
     elif leg == "planestats":
         print(json.dumps(bench.planestats_leg(dev, timed)))

@@ -255,70 +255,82 @@ __global__ __launch_bounds__(256) void pbfic_wj_kernel(const PBArgs a) {
     a.wj[(size_t)(2 * k + 1) * plane + i] = wv * S::f(sv);
 }
 
+// One wave per 64 rows (lane = row in the recursion, lane = column while a 64 x 64 tile moves between
+// HBM and LDS, so HBM sees coalesced rows). The recursion along a row is inherently sequential; what
+// the kernel hides is everything else: the next tile is fetched into registers while the current one
+// is filtered, so the chain never waits for a global round trip, and a tile's LDS reads are issued
+// eight steps ahead of the adds.
+// DIR +1: causal pass, left to right (:413-424), the first sample passes through;
+// DIR -1: anticausal pass, right to left (:425-431), the last sample passes through.
+template <int DIR>
+__device__ __forceinline__ void pbfic_h_pass(float (*tile)[65], float *__restrict__ io, int y0, int rows, int w, int lane, float b, float b1, float b2, float b3) {
+    const int nchunk = (w + 63) / 64;
+    const int c_first = DIR > 0 ? 0 : nchunk - 1, c_last = DIR > 0 ? nchunk - 1 : 0;
+    float p1 = 0, p2 = 0, p3 = 0;
+    float nxt[64];
+    {
+        const int x0 = c_first * 64, cw = min(64, w - x0);
+#pragma unroll
+        for (int r = 0; r < 64; ++r) nxt[r] = lane < cw ? io[(size_t)(y0 + min(r, rows - 1)) * w + x0 + lane] : 0.0f;
+    }
+    for (int c = c_first;; c += DIR) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) tile[r][lane] = nxt[r];
+        __syncthreads();
+        if (c != c_last) {  // the next tile: in flight while this one is filtered (rows past the plane repeat the last one)
+            const int x0 = (c + DIR) * 64, cw = min(64, w - x0);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) nxt[r] = lane < cw ? io[(size_t)(y0 + min(r, rows - 1)) * w + x0 + lane] : 0.0f;
+        }
+        const int x0 = c * 64, cw = min(64, w - x0);
+        if (lane < rows) {
+            float *row = &tile[lane][0];
+            int i = DIR > 0 ? 0 : cw - 1;
+            if (c == c_first) {  // the pass's first sample
+                p1 = p2 = p3 = row[i];
+                i += DIR;
+            }
+            const int n = DIR > 0 ? cw - i : i + 1;
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[i + DIR * (k + u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float o = b * v[u] + b1 * p1 + b2 * p2 + b3 * p3;  // :417-423 / :427-430, the reference's operation order
+                    p3 = p2;
+                    p2 = p1;
+                    p1 = o;
+                    row[i + DIR * (k + u)] = o;
+                }
+            }
+            for (; k < n; ++k) {
+                const float o = b * row[i + DIR * k] + b1 * p1 + b2 * p2 + b3 * p3;
+                p3 = p2;
+                p2 = p1;
+                p1 = o;
+                row[i + DIR * k] = o;
+            }
+        }
+        __syncthreads();
+        if (lane < cw) {
+#pragma unroll 8
+            for (int r = 0; r < rows; ++r) io[(size_t)(y0 + r) * w + x0 + lane] = tile[r][lane];
+        }
+        __syncthreads();
+        if (c == c_last) break;
+    }
+}
+
 __global__ __launch_bounds__(64) void pbfic_rg_h_kernel(const PBArgs a) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x;
     const int y0 = blockIdx.x * 64;
-    const size_t plane = (size_t)a.w * a.h;
-    float *io = a.wj + (size_t)blockIdx.y * plane;
+    float *io = a.wj + (size_t)blockIdx.y * (size_t)a.w * a.h;
     const int rows = min(64, a.h - y0);
-    const int w = a.w, nchunk = (w + 63) / 64;
-    const float b = a.b, b1 = a.b1, b2 = a.b2, b3 = a.b3;
-    float p1 = 0, p2 = 0, p3 = 0;
-    // causal pass, left to right (:413-424): the first sample passes through
-    for (int c = 0; c < nchunk; ++c) {
-        const int x0 = c * 64, cw = min(64, w - x0);
-        for (int r = 0; r < rows; ++r)
-            if (lane < cw) tile[r][lane] = io[(size_t)(y0 + r) * w + x0 + lane];
-        __syncthreads();
-        if (lane < rows) {
-            for (int i = 0; i < cw; ++i) {
-                const float v = tile[lane][i];
-                float o;
-                if (x0 + i == 0) {
-                    p1 = p2 = p3 = v;
-                    o = v;
-                } else {
-                    o = b * v + b1 * p1 + b2 * p2 + b3 * p3;
-                    p3 = p2;
-                    p2 = p1;
-                    p1 = o;
-                }
-                tile[lane][i] = o;
-            }
-        }
-        __syncthreads();
-        for (int r = 0; r < rows; ++r)
-            if (lane < cw) io[(size_t)(y0 + r) * w + x0 + lane] = tile[r][lane];
-        __syncthreads();
-    }
-    // anticausal pass, right to left (:425-431): the last sample passes through
-    for (int c = nchunk - 1; c >= 0; --c) {
-        const int x0 = c * 64, cw = min(64, w - x0);
-        for (int r = 0; r < rows; ++r)
-            if (lane < cw) tile[r][lane] = io[(size_t)(y0 + r) * w + x0 + lane];
-        __syncthreads();
-        if (lane < rows) {
-            for (int i = cw - 1; i >= 0; --i) {
-                const float v = tile[lane][i];
-                float o;
-                if (x0 + i == w - 1) {
-                    p1 = p2 = p3 = v;
-                    o = v;
-                } else {
-                    o = b * v + b1 * p1 + b2 * p2 + b3 * p3;
-                    p3 = p2;
-                    p2 = p1;
-                    p1 = o;
-                }
-                tile[lane][i] = o;
-            }
-        }
-        __syncthreads();
-        for (int r = 0; r < rows; ++r)
-            if (lane < cw) io[(size_t)(y0 + r) * w + x0 + lane] = tile[r][lane];
-        __syncthreads();
-    }
+    pbfic_h_pass<1>(tile, io, y0, rows, a.w, lane, a.b, a.b1, a.b2, a.b3);
+    pbfic_h_pass<-1>(tile, io, y0, rows, a.w, lane, a.b, a.b1, a.b2, a.b3);
 }
 
 __global__ __launch_bounds__(256) void pbfic_rg_v_kernel(const PBArgs a) {
