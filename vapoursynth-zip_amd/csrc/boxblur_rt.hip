@@ -436,40 +436,133 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
     }
 }
 
-// ---- RT float: blurFloat verbatim (:43-79), one thread per line ------------------------------
-template <typename T>
-__device__ __forceinline__ void blur_float_line(const T *s, size_t ss, T *d, size_t ds, int len, int R) {
-    const float ksize = (float)(R * 2 + 1);
-    const float div = 1.0f / ksize;
-    float sum = (float)s[(size_t)R * ss];
-    for (int x = 0; x < R; ++x) sum += (float)s[(size_t)x * ss] * 2;
-    sum = sum * div;
-    int x = 0;
-    for (; x <= R; ++x) {
-        sum += ((float)s[(size_t)(R + x) * ss] - (float)s[(size_t)(R - x) * ss]) * div;
-        d[(size_t)x * ds] = (T)sum;
-    }
-    for (; x < len - R; ++x) {
-        sum += ((float)s[(size_t)(R + x) * ss] - (float)s[(size_t)(x - R - 1) * ss]) * div;
-        d[(size_t)x * ds] = (T)sum;
-    }
-    for (; x < len; ++x) {
-        sum += ((float)s[(size_t)(2 * len - R - x - 1) * ss] - (float)s[(size_t)(x - R - 1) * ss]) * div;
-        d[(size_t)x * ds] = (T)sum;
-    }
-}
+// ---- RT float: blurFloat (:43-79) — a running f32 sum per line, sequential by definition ------
+// Index of the sample entering / leaving the window at output x (the three loops of blurFloat :55-78
+// as one pair of functions: x <= R, R < x < len - R, x >= len - R).
+__device__ __forceinline__ int rtf_in(int x, int len, int R) { return (x > R && x >= len - R) ? 2 * len - R - x - 1 : R + x; }
+__device__ __forceinline__ int rtf_out(int x, int R) { return x <= R ? R - x : x - R - 1; }
 
-template <typename T, bool VERT>
-__global__ __launch_bounds__(64) void boxblur_rt_float_kernel(const RParams prm) {
+// Vertical float pass: lane = column (coalesced), the running sum walks down the rows. The samples
+// of kPf output rows (entering and leaving) are loaded before the first of them is added, so a step
+// of the chain is one f32 add, not a global round trip.
+template <typename T>
+__global__ __launch_bounds__(64) void boxblur_rt_float_v_kernel(const RParams prm) {
     const int b = blockIdx.x;
     const RPlane pl = prm.p[rt_find(prm, b)];
     const int i = (b - pl.block0) * 64 + threadIdx.x;
-    const T *s = static_cast<const T *>(pl.src);
-    T *d = static_cast<T *>(pl.dst);
-    if (VERT) {
-        if (i < pl.w) blur_float_line<T>(s + i, pl.sstride, d + i, pl.dstride, pl.h, prm.radius);
-    } else {
-        if (i < pl.h) blur_float_line<T>(s + (size_t)i * pl.sstride, 1, d + (size_t)i * pl.dstride, 1, pl.w, prm.radius);
+    if (i >= pl.w) return;
+    const T *s = static_cast<const T *>(pl.src) + i;
+    T *d = static_cast<T *>(pl.dst) + i;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    const int len = pl.h, R = prm.radius;
+    const float div = 1.0f / (float)(R * 2 + 1);
+    constexpr int kPf = 8;
+    float sum = 0.0f;
+    for (int x0 = 0; x0 <= R; x0 += kPf) {  // :47-49 — sum = s[R] + 2 * s[0] + 2 * s[1] + ..., in that order
+        float q[kPf];
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) q[u] = (float)s[(size_t)(x0 + u == 0 ? R : min(x0 + u - 1, R - 1 >= 0 ? R - 1 : 0)) * ss];
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) {
+            const int k = x0 + u;  // term k: k == 0 is s[R], k >= 1 is s[k-1] * 2
+            if (k == 0)
+                sum = q[u];
+            else if (k <= R)
+                sum += q[u] * 2;
+        }
+    }
+    sum = sum * div;
+    for (int x0 = 0; x0 < len; x0 += kPf) {
+        float qi[kPf], qo[kPf];
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) {
+            const int x = min(x0 + u, len - 1);
+            qi[u] = (float)s[(size_t)rtf_in(x, len, R) * ss];
+            qo[u] = (float)s[(size_t)rtf_out(x, R) * ss];
+        }
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) {
+            if (x0 + u < len) {
+                sum += (qi[u] - qo[u]) * div;
+                d[(size_t)(x0 + u) * ds] = (T)sum;
+            }
+        }
+    }
+}
+
+// Horizontal float pass: the running sum of a row is sequential, so lanes are rows — but a lane walking
+// its own row touches 64 cache lines per step. Instead the entering and the leaving samples of 64
+// output columns x 64 rows go through two LDS tiles (loaded with lane = column: coalesced), the chain
+// runs with lane = row on LDS, the results go back through the first tile; the next chunk's tiles are
+// fetched into registers while the current chunk is summed.
+template <typename T>
+__global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams prm) {
+    __shared__ float tin[64][65], tout[64][65];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int lane = threadIdx.x;
+    const int y0 = (b - pl.block0) * 64;
+    const int rows = min(64, pl.h - y0), len = pl.w, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y0 * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y0 * pl.dstride;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    const float div = 1.0f / (float)(R * 2 + 1);
+    // the initial sum (:47-50), lane = row, sequential over the first R + 1 samples of the row
+    float sum = 0.0f;
+    if (lane < rows) {
+        const T *row = s + (size_t)lane * ss;
+        sum = (float)row[R];
+        for (int x = 0; x < R; ++x) sum += (float)row[x] * 2;
+        sum = sum * div;
+    }
+    const int nchunk = (len + 63) / 64;
+    float ni[64], no[64];
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+        const int x = min(c * 64 + lane, len - 1);
+        const int ci = rtf_in(x, len, R), co = rtf_out(x, R);
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const T *row = s + (size_t)min(r, rows - 1) * ss;
+            ni[r] = (float)row[ci];
+            no[r] = (float)row[co];
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            tin[r][lane] = ni[r];
+            tout[r][lane] = no[r];
+        }
+        __syncthreads();
+        if (c + 1 < nchunk) fetch(c + 1);
+        const int x0 = c * 64, cw = min(64, len - x0);
+        if (lane < rows) {
+            int k = 0;
+            for (; k + 8 <= cw; k += 8) {
+                float a[8], o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a[u] = tin[lane][k + u];
+                    o[u] = tout[lane][k + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    sum += (a[u] - o[u]) * div;
+                    tin[lane][k + u] = sum;
+                }
+            }
+            for (; k < cw; ++k) {
+                sum += (tin[lane][k] - tout[lane][k]) * div;
+                tin[lane][k] = sum;
+            }
+        }
+        __syncthreads();
+        if (lane < cw) {
+#pragma unroll 8
+            for (int r = 0; r < rows; ++r) d[(size_t)r * ds + x0 + lane] = (T)tin[r][lane];
+        }
+        __syncthreads();
     }
 }
 
@@ -540,9 +633,9 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
             }
         } else {
             if (vertical)
-                hipLaunchKernelGGL((boxblur_rt_float_kernel<T, true>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+                hipLaunchKernelGGL((boxblur_rt_float_v_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
             else
-                hipLaunchKernelGGL((boxblur_rt_float_kernel<T, false>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+                hipLaunchKernelGGL((boxblur_rt_float_h_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
         }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
         done += n;
