@@ -400,7 +400,7 @@ def boxblur_other_paths_leg(dev, timed, frames=8):
     base16 = make_frame(3, W4K, H4K)
     basef = [(p.astype(np.float32) / 65535.0) for p in base16]
     for name, base, args, dt_ in (("boxblur_rt_r30_4k", base16, (30, 1, 30, 1), np.uint16), ("boxblur_rt_r5x3_4k", base16, (5, 3, 5, 3), np.uint16),
-                                  ("boxblur_ct_float_r13_4k", basef, (13, 1, 13, 1), np.float32)):
+                                  ("boxblur_ct_float_r13_4k", basef, (13, 1, 13, 1), np.float32), ("boxblur_rt_float_r5x3_4k", basef, (5, 3, 5, 3), np.float32)):
         srcs, dsts = [], []
         for f in range(frames):
             for p in base:
