@@ -370,8 +370,8 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
     const float kFltMax09 = FLT_MAX * 0.9f;
     __shared__ float rows[4][kGRowW];  // r3p, r1p, r1n, r3n
     __shared__ float hrow[HP ? 4 : 1][HP ? kGRowW : 1];  // their half-pel rows (computeHpRow :602-617), HP only
-    __shared__ float tbm[kGTbMax], tbh[kGTbMax], wsm[kGTbMax], wsh[kGTbMax];  // hp: one direction per pass
-    __shared__ float tbq[HP ? 1 : kU][HP ? 1 : kGTbMax], wsq[HP ? 1 : kU][HP ? 1 : kGTbMax];  // otherwise: kU directions per pass
+    __shared__ float tbq[kU][kGTbMax], wsq[kU][kGTbMax];  // t_base and window sums of the kU directions of a pass
+    __shared__ float tbhq[HP ? kU / 2 : 1][HP ? kGTbMax : 1], whq[HP ? kU / 2 : 1][HP ? kGTbMax : 1];  // hp: their half-pel twins (odd directions)
     __shared__ float ctile[TPMAX][kGXB + 1];
     __shared__ uint8_t bmt[kGXB];
     __shared__ int any_mask;
@@ -512,42 +512,73 @@ __global__ __launch_bounds__(64) void eedi3_line_general_kernel(const EParams pr
                 __syncthreads();
             }
         }
-        for (int u = -cen; HP && u <= cen; ++u) {
-            if (!HP) {
-            } else {
-                // :659-702 — u in half pels; baseM pairs full-pel rows shifted by u, baseHp (odd u)
-                // pairs the half-pel rows; s1/s2 window baseM at x and x+u, s0 the u/2 neighbour
-                const int uh = u >> 1;
-                const bool odd = (u & 1) != 0;
-                const int lo0 = odd ? -uh - 1 : -uh;
-                const int jlo = min(0, min(u, uh)) - nrad;  // columns xb+jlo .. xb+31+max(0, u, uh)+nrad are read back
-                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
+        if constexpr (HP) {
+            // :659-702 — u in half pels; baseM pairs full-pel rows shifted by u, baseHp (odd u) pairs the
+            // half-pel rows; s1/s2 window baseM at x and x+u, s0 the u/2 neighbour. Four directions per
+            // pass (-cen is even, so slots 1 and 3 are the odd ones and own the two half-pel arrays).
+            for (int ug = -cen; ug <= cen; ug += kU) {
+                int uu[kU], jlo[kU];
+#pragma unroll
+                for (int i = 0; i < kU; ++i) {
+                    const int u = min(ug + i, cen);  // past +cen: duplicates of the last (even) direction
+                    uu[i] = u;
+                    jlo[i] = min(0, min(u, u >> 1)) - nrad;  // columns xb+jlo .. xb+31+max(0, u, uh)+nrad are read back
+                }
+#pragma unroll
+                for (int it = 0; it < kGNit; ++it) {
                     const int t = lane + 64 * it;  // fixed trip count, entries past the span are padding nobody reads
-                    const int j = jlo + t + reach;
-                    tbm[t] = fabsf(rows[0][j] - rows[1][j - u]) + fabsf(rows[1][j] - rows[2][j - u]) + fabsf(rows[2][j] - rows[3][j - u]);
-                    if (odd) tbh[t] = fabsf(hrow[0][j] - hrow[1][j - u]) + fabsf(hrow[1][j] - hrow[2][j - u]) + fabsf(hrow[2][j] - hrow[3][j - u]);
+                    float vm[kU], vh[kU / 2];
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        const int u = uu[i], j = jlo[i] + t + reach;
+                        vm[i] = fabsf(rows[0][j] - rows[1][j - u]) + fabsf(rows[1][j] - rows[2][j - u]) + fabsf(rows[2][j] - rows[3][j - u]);
+                        if (i & 1) vh[i >> 1] = fabsf(hrow[0][j] - hrow[1][j - u]) + fabsf(hrow[1][j] - hrow[2][j - u]) + fabsf(hrow[2][j] - hrow[3][j - u]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        tbq[i][t] = vm[i];
+                        if (i & 1) tbhq[i >> 1][t] = vh[i >> 1];
+                    }
                 }
                 __syncthreads();
-                _Pragma("unroll") for (int it = 0; it < kGNit; ++it) {
-                    const int t = lane + nrad + 64 * it;
-                    float sm = 0.0f, sh = 0.0f;
 #pragma unroll
-                    for (int k = -nrad; k <= nrad; ++k) {
-                        sm += tbm[t + k];
-                        if (odd) sh += tbh[t + k];
+                for (int it = 0; it < kGNit; ++it) {
+                    const int t = lane + nrad + 64 * it;
+                    float sm[kU], sh[kU / 2];
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        float am = 0.0f, ah = 0.0f;
+#pragma unroll
+                        for (int k = -nrad; k <= nrad; ++k) {
+                            am += tbq[i][t + k];
+                            if (i & 1) ah += tbhq[i >> 1][t + k];
+                        }
+                        sm[i] = am;
+                        if (i & 1) sh[i >> 1] = ah;
                     }
-                    wsm[t] = sm;
-                    wsh[t] = sh;
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        wsq[i][t] = sm[i];
+                        if (i & 1) whq[i >> 1][t] = sh[i >> 1];
+                    }
                 }
                 __syncthreads();
                 if (act) {
-                    const int base = lane - jlo;
-                    const float s1 = wsm[base], s2 = wsm[base + u], s0 = odd ? wsh[base + uh] : wsm[base + uh];
-                    const float bq = odd ? hrow[1][lx + uh] : rows[1][lx + uh];
-                    const float cq = odd ? hrow[2][lx + lo0] : rows[2][lx + lo0];
-                    const float ip = (bq + cq) * 0.5f;
-                    const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
-                    ctile[cen + u][lane] = prm.alpha * (s0 + s1 + s2) + (prm.beta * (float)abs(u) * 0.5f) + prm.one_minus_ab * v;
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) {
+                        const int u = uu[i], uh = u >> 1;
+                        const bool odd = (u & 1) != 0;  // false for the duplicates in slots 1 / 3 of the last pass
+                        const int lo0 = odd ? -uh - 1 : -uh;
+                        const int base = lane - jlo[i];
+                        const float s1 = wsq[i][base], s2 = wsq[i][base + u];
+                        float s0 = wsq[i][base + uh];
+                        if ((i & 1) && odd) s0 = whq[i >> 1][base + uh];
+                        const float bq = odd ? hrow[1][lx + uh] : rows[1][lx + uh];
+                        const float cq = odd ? hrow[2][lx + lo0] : rows[2][lx + lo0];
+                        const float ip = (bq + cq) * 0.5f;
+                        const float v = fabsf(rows[1][lx] - ip) + fabsf(rows[2][lx] - ip);
+                        ctile[cen + u][lane] = prm.alpha * (s0 + s1 + s2) + (prm.beta * (float)abs(u) * 0.5f) + prm.one_minus_ab * v;
+                    }
                 }
                 __syncthreads();
             }
