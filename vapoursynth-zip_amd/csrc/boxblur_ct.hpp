@@ -607,7 +607,18 @@ struct RingWave {
         // A: vertical mean, rounded (:114-128; col carries the +r), wave-wide inclusive prefix
         uint32_t p[PX];
 #pragma unroll
-        for (int k = 0; k < PX; ++k) p[k] = __umulhi(col[k], G::MAGIC);
+        for (int k = 0; k < PX; ++k) {
+            if constexpr (sizeof(T) == 1) {
+                // 8-bit samples: col <= 255 k + r < 2^14, so floor(col / k) == (col * ceil(2^19 / k)) >> 19 exactly
+                // (error term col * (M k - 2^19) < 2^19 since M k - 2^19 < k) and the product fits 32 bits: a
+                // full-rate 24-bit multiply and a shift instead of the quarter-rate v_mul_hi_u32
+                constexpr uint32_t M19 = (uint32_t)(((1u << 19) + G::K - 1) / G::K);
+                static_assert((uint64_t)(255u * G::K + R) * (M19 * G::K - (1u << 19)) < (1u << 19), "8-bit divide-by-k shortcut must be exact");
+                p[k] = __umul24(col[k], M19) >> 19;
+            } else {
+                p[k] = __umulhi(col[k], G::MAGIC);
+            }
+        }
         if constexpr (GENERAL) {
             const uint32_t m = ld_ok ? 0xffffffffu : 0u;  // lanes outside the plane hold zeros
 #pragma unroll
