@@ -472,20 +472,30 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_v_kernel(const RParams pr
         }
     }
     sum = sum * div;
-    for (int x0 = 0; x0 < len; x0 += kPf) {
-        float qi[kPf], qo[kPf];
+    // two groups in flight: the samples of rows x0 + kPf .. are requested before rows x0 .. are summed
+    float qi[kPf], qo[kPf], ni[kPf], no[kPf];
+    auto fetch = [&](int x0, float *fi, float *fo) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kPf; ++u) {
             const int x = min(x0 + u, len - 1);
-            qi[u] = (float)s[(size_t)rtf_in(x, len, R) * ss];
-            qo[u] = (float)s[(size_t)rtf_out(x, R) * ss];
+            fi[u] = (float)s[(size_t)rtf_in(x, len, R) * ss];
+            fo[u] = (float)s[(size_t)rtf_out(x, R) * ss];
         }
+    };
+    fetch(0, qi, qo);
+    for (int x0 = 0; x0 < len; x0 += kPf) {
+        fetch(x0 + kPf, ni, no);
 #pragma unroll
         for (int u = 0; u < kPf; ++u) {
             if (x0 + u < len) {
                 sum += (qi[u] - qo[u]) * div;
                 d[(size_t)(x0 + u) * ds] = (T)sum;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) {
+            qi[u] = ni[u];
+            qo[u] = no[u];
         }
     }
 }
