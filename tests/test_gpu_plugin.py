@@ -386,3 +386,40 @@ def test_adaptive_binarize_through_plugin(oracle):
         assert out.props["_ColorRange"] == 0
     assert np.all(src.vszip.AdaptiveBinarize(clip2=blur, c=1000).get_frame(0)[0] == 0)
     assert np.all(src.vszip.AdaptiveBinarize(clip2=blur, c=-1000).get_frame(0)[0] == 255)
+
+
+def test_xpsnr_reference_behaviours(oracle):
+    """reference tests/test_xpsnr.py: the temporal order switches at exactly 32 fps (24 == 31; 32 agrees
+    on frame 0 only) :178-196; a width whose stride exceeds it :352-361; a clip so small that the block
+    size is 0 :364-369; the output frame is the distorted frame :254-257; verbose changes nothing :266-273."""
+    rng = np.random.default_rng(8)
+
+    def clip(w, h, n, fps, seed):
+        r = np.random.default_rng(seed)
+        shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+        frames = [[np.roll(fx.tiled_natural(s, np.uint8, p), 3 * f, axis=1) for p, s in enumerate(shapes)] for f in range(n)]
+        dist = [[np.clip(p.astype(np.int16) + r.integers(-4, 5, p.shape), 0, 255).astype(np.uint8) for p in fr] for fr in frames]
+        return frames, dist, vs.source(frames, vs.YUV420P8, fps=(fps, 1)), vs.source(dist, vs.YUV420P8, fps=(fps, 1))
+
+    def ys(fps):
+        fr, ds, a, b = clip(640, 360, 5, fps, 1)
+        out = a.vszip.XPSNR(b, verbose=0)
+        got = [out.get_frame(n).props["XPSNR_Y"] for n in range(5)]
+        for n in range(5):  # and each equals the oracle with the temporal order the fps selects
+            w = oracle.xpsnr_wsse(fr[n], ds[n], fr[n - 1][0] if n >= 1 else None, fr[n - 2][0] if n >= 2 else None, depth=8, frame_rate=fps, temporal=True)
+            assert got[n] == oracle.xpsnr_frame(w[0], 640, 360, 8)
+        return got
+
+    s24, s31, s32 = ys(24), ys(31), ys(32)
+    assert s24 == s31 and s32[0] == s31[0] and all(s32[n] != s31[n] for n in range(1, 5))
+    for w, h in ((100, 80), (32, 32)):
+        fr, ds, a, b = clip(w, h, 3, 24, w)
+        out = a.vszip.XPSNR(b, temporal=1, verbose=0)
+        quiet = [out.get_frame(n) for n in range(3)]
+        loud = [a.vszip.XPSNR(b, temporal=1).get_frame(n) for n in range(3)]
+        for n in range(3):
+            assert math.isfinite(quiet[n].props["XPSNR_Y"]) and quiet[n].props == loud[n].props
+            for p in range(3):
+                assert np.array_equal(quiet[n][p], ds[n][p])  # the distorted frame, passed through
+            wsse = oracle.xpsnr_wsse(fr[n], ds[n], fr[n - 1][0] if n >= 1 else None, None, depth=8, frame_rate=24, temporal=True)
+            assert quiet[n].props["XPSNR_U"] == oracle.xpsnr_frame(wsse[1], w // 2, h // 2, 8)
