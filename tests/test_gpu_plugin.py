@@ -423,3 +423,19 @@ def test_xpsnr_reference_behaviours(oracle):
                 assert np.array_equal(quiet[n][p], ds[n][p])  # the distorted frame, passed through
             wsse = oracle.xpsnr_wsse(fr[n], ds[n], fr[n - 1][0] if n >= 1 else None, None, depth=8, frame_rate=24, temporal=True)
             assert quiet[n].props["XPSNR_U"] == oracle.xpsnr_frame(wsse[1], w // 2, h // 2, 8)
+
+
+def test_ssimulacra2_monotone_and_output_clip(oracle):
+    """reference tests/test_ssimulacra2.py:79-100: more blur scores lower; the output clip is the RGBS reference."""
+    ref = [np.ascontiguousarray(p[:128, :192]) for p in fx.crop_rgbs()]
+    a = vs.source([ref], vs.RGBS, props={"_Transfer": 8})
+    s = []
+    for r in (0, 1, 3):
+        b = a if r == 0 else vs.source([[oracle.boxblur(p, r, 1, r, 1) for p in ref]], vs.RGBS, props={"_Transfer": 8})
+        out = a.vszip.SSIMULACRA2(b)
+        f = out.get_frame(0)
+        s.append(f.props["SSIMULACRA2"])
+        assert out.format_id == vs.RGBS and (out.width, out.height) == (192, 128)
+        for p in range(3):
+            assert np.array_equal(f[p], ref[p])
+    assert s[0] > s[1] > s[2] and s[0] > 99.9
