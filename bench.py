@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline bench: frames/s of the vszip hot path on MI355X, inputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload boxblur|bilateral|ssimulacra2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload boxblur|bilateral|ssimulacra2|pipeline]
                     [--frames F] [--no-cpu] [--no-others]
 
 Default workload (the JSON line's `value` and `roofline`): vszip.BoxBlur(hradius=vradius=13)
@@ -216,6 +216,60 @@ def setup_ssimulacra2(dev, w, h, pairs):
         r += [dev.upload(np.roll(x, p * 7, axis=1), 1) for x in ref]
         d += [dev.upload(np.roll(x, p * 7, axis=1), 1) for x in dis]
     return (lambda: dev.ssimulacra2(r, d)), (r, d)
+
+
+W8K, H8K = 7680, 4320
+
+
+def setup_pipeline(dev, w, h, frames):
+    """BASELINE config 5: Bilateral(sigmaS=2, sigmaR=2) -> BoxBlur(r=2) -> SSIMULACRA2(source, processed)
+    on RGBS frames; every intermediate plane stays in HBM, only the per-frame scores leave the device
+    (the chain tests/test_gpu_fullsize.py checks against the oracle stage by stage)."""
+    import fixtures as fx
+
+    k0 = np.float32(0.0404482362771082)  # sRGB -> linear, as the SSIMULACRA2 wrapper's input contract wants
+    base = []
+    for p in range(3):
+        v = np.ascontiguousarray(fx.tiled_natural((h, w), np.float32, p))
+        base.append(np.where(v <= k0, v / np.float32(12.92), ((v + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4)).astype(np.float32))
+    cfg = dev.bilateral_cfg([2], [2], yuv=False, ssw=0, ssh=0, hist_len=65536)
+    srcs, mid, outp, idx = [], [], [], []
+    for f in range(frames):
+        for i, plane in enumerate(base):
+            srcs.append(dev.upload(np.roll(plane, f * 19, axis=1), 1))
+            mid.append(dev.empty(h, w, np.float32, 1))
+            outp.append(dev.empty(h, w, np.float32, 1))
+            idx.append(i)
+    scores = []
+
+    def step():
+        dev.bilateral(srcs, mid, cfg, idx)
+        dev.boxblur(mid, outp, 2, 1, 2, 1)
+        scores[:] = dev.ssimulacra2(srcs, outp)
+
+    return step, (srcs, mid, outp, cfg), scores
+
+
+def pipeline_line(dev, timed, world, frames, steps, warmup, max_over_ranks, reduce_scalars):
+    step, keep, scores = setup_pipeline(dev, W8K, H8K, frames)
+    dt, region_ms, _, _ = timed.run(step, steps, warmup)
+    dt = max_over_ranks(dt)
+    frame_bytes = 3 * W8K * H8K * 4  # 398 131 200
+    # compulsory traffic per frame: source read by Bilateral and by SSIMULACRA2, the two intermediates written and read once
+    alg = 6 * frame_bytes
+    t0 = time.perf_counter()
+    tot = reduce_scalars(np.array([float(np.sum(scores)), float(len(scores))]))
+    reduce_ms = (time.perf_counter() - t0) * 1e3
+    res = {"value": world * frames * steps / dt, "unit": "frames/s", "ms_per_step": dt * 1e3 / steps, "frames_per_step_per_gpu": frames,
+           "stream_ms_per_frame": region_ms / (steps * frames),
+           "roofline": {"bound": "hbm", "achieved": alg * frames * steps / (region_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg * frames * steps / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "whole chain (bilateral_truncated + boxblur_ct + the SSIMULACRA2 kernels); algorithmic bytes = 6 x frame "
+                                  "(source read twice, each intermediate written and read once)"},
+           "clip_mean_score": {"value": float(tot[0] / tot[1]), "frames": int(tot[1]), "reduced_over_ranks": world, "allreduce_ms": reduce_ms},
+           "workload": "Bilateral(sigmaS=2,sigmaR=2) -> BoxBlur(r=2) -> SSIMULACRA2 on 7680x4320 RGBS, intermediates HBM-resident, per-clip mean score all-reduced"}
+    dev.bilateral_free(keep[3])
+    return res
 
 
 def eedi3_leg(dev, timed, no_cpu, frames=16):
@@ -465,7 +519,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (64 4K YUV420P16 frames = 192 planes = one BoxBlur launch)")
-    ap.add_argument("--workload", default="boxblur", choices=["boxblur", "bilateral", "ssimulacra2"])
+    ap.add_argument("--workload", default="boxblur", choices=["boxblur", "bilateral", "ssimulacra2", "pipeline"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")
     ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
@@ -514,9 +568,21 @@ def main() -> int:
             return float(t.item())
         return dt
 
+    def reduce_scalars(v):
+        return vszip_amd.cluster.allreduce_clip_scalars(v, device="cuda" if use_dist else None)
+
     F = a.frames
     out = None
-    if a.workload == "boxblur":
+    if a.workload == "pipeline":
+        nf = max(1, min(F // 16, 8))  # 64 -> 4 frames of 398 MB per step per GPU
+        res = pipeline_line(dev, timed, world, nf, a.steps, a.warmup, max_over_ranks, reduce_scalars)
+        out = {"metric": "frames/sec: Bilateral->BoxBlur->SSIMULACRA2 pipeline 7680x4320 RGBS", "value": res.pop("value"), "unit": res.pop("unit"),
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": res.pop("workload"), "frames_per_step_per_gpu": nf, "parallelism": f"frame-parallel x{world}",
+                          "clip_mean_score": res.pop("clip_mean_score")},
+               "roofline": res.pop("roofline")}
+    elif a.workload == "boxblur":
         step, keep = setup_boxblur(dev, rank, F, a.radius)
         dt, region_ms, dom_ms, launches = timed.run(step, a.steps, a.warmup)
         dt = max_over_ranks(dt)
@@ -591,6 +657,10 @@ def main() -> int:
                 others.update(limit_filter_leg(dev, timed))
             except Exception as e:
                 others["limiter_4k"] = {"error": str(e)}
+            try:
+                others["pipeline_8k_rgbs"] = pipeline_line(dev, timed, 1, 2, 3, 1, lambda t: t, reduce_scalars)
+            except Exception as e:
+                others["pipeline_8k_rgbs"] = {"error": str(e)}
             try:
                 others["boxblur_4k_pcie"] = pcie_boxblur(vszip_amd, local_rank, a.radius)
             except Exception as e:  # the PCIe leg is informative only
