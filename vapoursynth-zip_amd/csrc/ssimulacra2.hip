@@ -380,19 +380,52 @@ struct FinalArgs {
     int max_tiles;
 };
 
-__global__ __launch_bounds__(64) void ssim_final_kernel(const FinalArgs a) {
+constexpr int kFinThreads = 256, kFinUnroll = 4;
+
+// One block per (slot, pair). The tile partials are folded in a fixed order — thread t takes tiles
+// t, t+256, ... in four interleaved chains (so four loads are in flight per thread instead of one
+// dependent chain over n/64 round trips), then lanes, then the four waves — so the result is
+// reproducible run to run.
+__global__ __launch_bounds__(kFinThreads) void ssim_final_kernel(const FinalArgs a) {
+    __shared__ double sh[kFinThreads / 64][6];
     const int slot = blockIdx.x, pair = blockIdx.y;
     const int n = a.ntiles[slot];
-    const int lane = threadIdx.x;
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int t = lane; t < n; t += 64) {
-        const double *p = a.partial + (((size_t)pair * 18 + slot) * a.max_tiles + t) * 6;
+    const int tid = threadIdx.x;
+    const double *base = a.partial + ((size_t)pair * 18 + slot) * a.max_tiles * 6;
+    double acc[kFinUnroll][6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s[q] += p[q];
+    for (int u = 0; u < kFinUnroll; ++u)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[u][q] = 0.0;
+    for (int t0 = tid; t0 < n; t0 += kFinThreads * kFinUnroll) {
+        double v[kFinUnroll][6];
+#pragma unroll
+        for (int u = 0; u < kFinUnroll; ++u) {
+            const int t = t0 + u * kFinThreads;
+            const double *p = base + (size_t)min(t, n - 1) * 6;
+            const bool live = t < n;  // the clamped index keeps the load unconditional
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const double x = p[q];
+                v[u][q] = live ? x : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFinUnroll; ++u)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[u][q] += v[u][q];
     }
+    double s[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s[q] = wave_reduce_sum(s[q]);
-    if (lane == 0) {
+    for (int q = 0; q < 6; ++q) s[q] = wave_reduce_sum((acc[0][q] + acc[1][q]) + (acc[2][q] + acc[3][q]));
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sh[tid >> 6][q] = s[q];
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s[q] = (sh[0][q] + sh[1][q]) + (sh[2][q] + sh[3][q]);
         const double opp = a.one_per_pixels[slot];
         double *o = a.avg + ((size_t)pair * 18 + slot) * 6;
         o[0] = opp * s[0];
@@ -595,7 +628,7 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
             fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
         }
     }
-    hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(64), 0, ctx->stream, fin);
+    hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(kFinThreads), 0, ctx->stream, fin);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
