@@ -439,3 +439,30 @@ def test_ssimulacra2_monotone_and_output_clip(oracle):
         for p in range(3):
             assert np.array_equal(f[p], ref[p])
     assert s[0] > s[1] > s[2] and s[0] > 99.9
+
+
+def test_chained_filters_like_a_script(oracle):
+    """BASELINE config 5 written the way a .vpy script chains it — Bilateral -> BoxBlur ->
+    SSIMULACRA2(source, processed) — over a 3-frame clip: every frame's pixels equal the oracle's
+    chain bit for bit and every frame carries its own score."""
+    base = [np.ascontiguousarray(p) for p in fx.crop_rgbs()]
+    frames = [[np.ascontiguousarray(np.roll(p, 37 * f, axis=1)) for p in base] for f in range(3)]
+    src = vs.source(frames, vs.RGBS, props={"_Transfer": 8})
+    proc = src.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)
+    scored = src.vszip.SSIMULACRA2(proc)
+    prm = oracle.bilateral_params([2], [2], yuv=False, ssw=0, ssh=0)
+    scores = []
+    for n in (2, 0, 1):  # out of order, like a seeking host
+        want = []
+        for i, p in enumerate(frames[n]):
+            b = oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i])
+            want.append(oracle.boxblur(b, 2, 1, 2, 1))
+        got = proc.get_frame(n)
+        for i in range(3):
+            assert np.array_equal(got[i], want[i])
+        assert got.props["_Transfer"] == 8
+        s = scored.get_frame(n).props["SSIMULACRA2"]
+        assert s == pytest.approx(oracle.ssimulacra2(frames[n], want), abs=1e-7)
+        scores.append(s)
+    # a horizontal roll only moves the content across tile borders: the scores stay close, not equal
+    assert max(scores) - min(scores) < 5.0 and len(set(scores)) == 3
