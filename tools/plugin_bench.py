@@ -24,6 +24,20 @@ def clip_1080p8(n):
     return vs.source([[np.roll(p, 5 * f, axis=1) for p in base] for f in range(n)], vs.YUV420P8)
 
 
+def clip_1080ps(n):
+    base = [np.ascontiguousarray(fx.tiled_natural(s, np.float32, p)) for p, s in enumerate([(1080, 1920), (540, 960), (540, 960)])]
+    return vs.source([[np.roll(p, 5 * f, axis=1) for p in base] for f in range(n)], vs.YUV420PS)
+
+
+def clips_4k_rgbs(n):
+    base = [np.ascontiguousarray(fx.tiled_natural((2160, 3840), np.float32, p)) for p in range(3)]
+    rng = np.random.default_rng(1)
+    noise = rng.normal(0, 0.02, (2160, 3840)).astype(np.float32)
+    ref = [[np.roll(p, 9 * f, axis=1) for p in base] for f in range(n)]
+    dis = [[np.clip(p + noise, 0, 1) for p in fr] for fr in ref]
+    return vs.source(ref, vs.RGBS, props={"_Transfer": 8}), vs.source(dis, vs.RGBS, props={"_Transfer": 8})
+
+
 def main():
     threads = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "4", "8", "16", "32"])]
     vs.lib().fakevs_set_pool_refill(0)  # a real host does not touch recycled frame memory
@@ -31,12 +45,20 @@ def main():
     src1080 = clip_1080p8(16)
     rec1080 = vs.source([[np.clip(p.astype(np.int16) + 2, 0, 255).astype(np.uint8) for p in [np.asarray(src1080.get_frame(f)[q]) for q in range(3)]] for f in range(16)],
                         vs.YUV420P8)
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     legs = [
         ("BoxBlur r=13 4K YUV420P16", src4k.vszip.BoxBlur(hradius=13, vradius=13), 25 * 2, 128),
         ("Bilateral sigmaS=2 sigmaR=0.02 4K YUV420P16", src4k.vszip.Bilateral(sigmaS=2.0, sigmaR=0.02), 25 * 2, 64),
         ("PlaneAverage 4K YUV420P16", src4k.vszip.PlaneAverage(exclude=[-1]), 25, 128),
         ("XPSNR 1080p YUV420P8", src1080.vszip.XPSNR(rec1080), 3.1 * 2, 256),
     ]
+    if only is None or "eedi3" in only:
+        legs.append(("EEDI3 field=1 dh=1 1080p YUV420PS", clip_1080ps(8).vszip.EEDI3(field=1, dh=True), 12.4 + 24.9, 128))
+    if only is None or "ssimulacra2" in only:
+        ref, dis = clips_4k_rgbs(4)
+        legs.append(("SSIMULACRA2 4K RGBS (linear)", ref.vszip.SSIMULACRA2(dis), 199.1, 64))
+    if only is not None:
+        legs = [l for l in legs if any(o.lower() in l[0].lower() for o in only)]
     for name, clip, mb_per_frame, count in legs:
         clip.pull(16, 8)  # warm-up: contexts, slabs, LUTs
         for t in threads:

@@ -1312,8 +1312,13 @@ void VS_CC xpsnrFree(void *inst, VSCore *, const VSAPI *api) {
     if (d->verbose) {  // xpsnr.zig:114-128
         printf("XPSNR average, %llu frames  ", (unsigned long long)d->num_frames);
         const char ch[3] = {'y', 'u', 'v'};
-        for (int c = 0; c < d->num_comps; ++c)
-            printf("%c: %.4f  ", ch[c], vszip_xpsnr_average(d->sum_wdist[c], d->sum_xpsnr[c], d->width[c], d->height[c], d->depth, d->num_frames));
+        for (int c = 0; c < d->num_comps; ++c) {
+            const double v = vszip_xpsnr_average(d->sum_wdist[c], d->sum_xpsnr[c], d->width[c], d->height[c], d->depth, d->num_frames);
+            if (v != v)
+                printf("%c: nan  ", ch[c]);  // Zig's {d:.04} prints no sign for NaN (a clip freed before any frame: 0/0)
+            else
+                printf("%c: %.4f  ", ch[c], v);
+        }
         printf("\n");
         fflush(stdout);
     }
