@@ -49,6 +49,15 @@ void vszip_ctx_destroy(vszip_ctx *ctx);
 int vszip_ctx_set_stream(vszip_ctx *ctx, void *hip_stream);
 void *vszip_ctx_stream(vszip_ctx *ctx);
 int vszip_ctx_sync(vszip_ctx *ctx);
+/* How vszip_copy_h2d_2d / _d2h_2d move host memory. 0 (default): straight from/to the caller's pointers
+ * (right for pinned memory; pageable memory is pinned in place by the runtime, one copy at a time
+ * per process). 1: through the context's own pinned arena with CPU copies — the DMA is asynchronous
+ * and concurrent across contexts, D2H data reaches the caller's memory inside vszip_ctx_sync.
+ * Env VSZIP_STAGING=pinned selects 1 for every new context. */
+int vszip_ctx_set_staging(vszip_ctx *ctx, int mode);
+/* Error path of a caller that gives up on the current frame: drains the stream and forgets staged
+ * D2H copies that have not reached their destination yet (the destinations may then be freed). */
+int vszip_ctx_abort(vszip_ctx *ctx);
 const char *vszip_last_error(vszip_ctx *ctx);
 int vszip_abi_version(void);
 
@@ -58,7 +67,7 @@ int vszip_dev_free(vszip_ctx *ctx, void *dptr);
 int vszip_dev_memset(vszip_ctx *ctx, void *dptr, int value, size_t bytes);
 int vszip_host_alloc_pinned(vszip_ctx *ctx, size_t bytes, void **hptr);
 int vszip_host_free_pinned(vszip_ctx *ctx, void *hptr);
-/* pitches in BYTES; async on the context stream */
+/* pitches in BYTES; async on the context stream: a copy is complete when vszip_ctx_sync returns */
 int vszip_copy_h2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);
 int vszip_copy_d2h_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);
 int vszip_copy_d2d_2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows);

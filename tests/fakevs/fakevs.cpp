@@ -842,26 +842,40 @@ DRV void fakevs_frame_free(const VSFrame *f) { frame_unref(f); }
 // What a VapourSynth output loop does under fmParallel: `threads` workers pull `count` frames
 // (frame numbers first, first+1, ... modulo the clip length) and drop them. Returns the number of
 // failed frames; *seconds is the wall time of the whole pull.
-DRV int fakevs_pull(VSNode *n, int first, int count, int threads, double *seconds) {
-    std::atomic<int> next{0}, failed{0};
+DRV int fakevs_pull_warm(VSNode *n, int first, int count, int threads, int warm_per_thread, double *seconds);
+DRV int fakevs_pull(VSNode *n, int first, int count, int threads, double *seconds) { return fakevs_pull_warm(n, first, count, threads, 0, seconds); }
+// Same with a steady-state clock: VapourSynth's workers live as long as the core, so a filter's
+// per-thread state (here: the plugin's per-thread GPU contexts) is set up once per session. Every
+// worker first fetches `warm_per_thread` frames untimed, the workers meet, and the clock runs from
+// that point until the last timed frame is done (before the workers exit).
+DRV int fakevs_pull_warm(VSNode *n, int first, int count, int threads, int warm_per_thread, double *seconds) {
+    std::atomic<int> next{0}, failed{0}, arrived{0}, finished{0};
+    std::atomic<int64_t> t_begin{0}, t_end{0};
     const int nframes = n->vi.numFrames;
-    auto work = [&] {
+    auto now_ns = [] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto fetch = [&](int k, char *err, int errlen) {
+        const VSFrame *f = A(getFrame)((first + k) % nframes, n, err, errlen);
+        if (f)
+            frame_unref(f);
+        else
+            failed.fetch_add(1);
+    };
+    auto work = [&](int tid) {
         char err[256];
+        for (int w = 0; w < warm_per_thread; ++w) fetch(tid * warm_per_thread + w, err, (int)sizeof(err));
+        if (arrived.fetch_add(1) + 1 == threads) t_begin.store(now_ns());
+        while (t_begin.load() == 0) std::this_thread::yield();
         for (;;) {
             const int k = next.fetch_add(1);
             if (k >= count) break;
-            const VSFrame *f = A(getFrame)((first + k) % nframes, n, err, (int)sizeof(err));
-            if (f)
-                frame_unref(f);
-            else
-                failed.fetch_add(1);
+            fetch(k, err, (int)sizeof(err));
         }
+        if (finished.fetch_add(1) + 1 == threads) t_end.store(now_ns());
     };
-    const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
-    for (int t = 0; t < threads; ++t) pool.emplace_back(work);
+    for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
     for (auto &t : pool) t.join();
-    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (seconds) *seconds = (double)(t_end.load() - t_begin.load()) * 1e-9;
     return failed.load();
 }
 DRV uint8_t *fakevs_frame_plane(const VSFrame *f, int p, int *w, int *h, ptrdiff_t *stride) {

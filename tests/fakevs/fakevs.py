@@ -54,6 +54,7 @@ def lib():
         l.fakevs_source.argtypes = [C.c_uint32, i, i, i, i64, i64, i, i]
         l.fakevs_source_frame.restype = vp
         l.fakevs_pull.argtypes = [vp, i, i, i, C.POINTER(C.c_double)]
+        l.fakevs_pull_warm.argtypes = [vp, i, i, i, i, C.POINTER(C.c_double)]
         l.fakevs_source_frame.argtypes = [vp, i]
         l.fakevs_node_free.argtypes = [vp]
         l.fakevs_node_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_uint32), C.POINTER(i64), C.POINTER(i64)]
@@ -140,11 +141,13 @@ class Clip:
             raise Error(err.value.decode())
         return Frame(ptr, _np_dtype(self.format_id))
 
-    def pull(self, count, threads, first=0):
+    def pull(self, count, threads, first=0, warm_per_thread=0):
         """`threads` workers fetch `count` frames (numbers modulo the clip length) and drop them,
-        like VapourSynth's output loop under fmParallel. -> wall seconds"""
+        like VapourSynth's output loop under fmParallel. -> wall seconds. warm_per_thread > 0:
+        every worker first fetches that many frames untimed (VapourSynth's workers outlive a run,
+        so per-thread filter state is warm in steady state)."""
         sec = C.c_double()
-        failed = lib().fakevs_pull(self.node, first, count, threads, C.byref(sec))
+        failed = lib().fakevs_pull_warm(self.node, first, count, threads, warm_per_thread, C.byref(sec))
         if failed:
             raise Error(f"{failed} frames failed")
         return sec.value

@@ -466,3 +466,29 @@ def test_chained_filters_like_a_script(oracle):
         scores.append(s)
     # a horizontal roll only moves the content across tile borders: the scores stay close, not equal
     assert max(scores) - min(scores) < 5.0 and len(set(scores)) == 3
+
+
+def test_heavy_filters_switch_to_the_pinned_arena_under_load(oracle):
+    """Bilateral and EEDI3 stage through the context's pinned arena once four getFrame calls are
+    in flight (HeavyFrameScope); BoxBlur on the same worker threads keeps the direct copies. The
+    pixels must not depend on the staging mode: 16 workers pull a Bilateral -> BoxBlur chain and an
+    EEDI3 clip, and every frame equals the single-caller result."""
+    planes = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate([(216, 384), (108, 192), (108, 192)])]
+    frames = [[np.ascontiguousarray(np.roll(p, 3 * f, axis=1)) for p in planes] for f in range(12)]
+    chain = vs.source(frames, vs.YUV420P16).vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=3, vradius=3)
+    single = [[np.array(chain.get_frame(n)[p]) for p in range(3)] for n in range(12)]
+    chain.pull(96, 16, warm_per_thread=1)
+    import concurrent.futures as cf
+
+    with cf.ThreadPoolExecutor(16) as ex:
+        got = list(ex.map(lambda n: [np.array(chain.get_frame(n % 12)[p]) for p in range(3)], range(64)))
+    for n, fr in enumerate(got):
+        for p in range(3):
+            assert np.array_equal(fr[p], single[n % 12][p])
+    g = [np.ascontiguousarray(np.roll(fx.tiled_natural((120, 200), np.float32, 0), 5 * f, axis=1)) for f in range(8)]
+    e3 = vs.source([[x] for x in g], vs.GRAYS).vszip.EEDI3(field=1, dh=True)
+    want = [oracle.eedi3(x, 1, dh=True) for x in g]
+    with cf.ThreadPoolExecutor(16) as ex:
+        got = list(ex.map(lambda n: np.array(e3.get_frame(n % 8)[0]), range(48)))
+    for n, o in enumerate(got):
+        assert np.array_equal(o, want[n % 8])

@@ -57,6 +57,8 @@ SYMBOLS = {
     "vszip_ctx_set_stream": (_i, [_vp, _vp]),
     "vszip_ctx_stream": (_vp, [_vp]),
     "vszip_ctx_sync": (_i, [_vp]),
+    "vszip_ctx_set_staging": (_i, [_vp, _i]),
+    "vszip_ctx_abort": (_i, [_vp]),
     "vszip_last_error": (C.c_char_p, [_vp]),
     "vszip_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_dev_free": (_i, [_vp, _vp]),
@@ -185,6 +187,10 @@ class Device:
 
     def sync(self):
         self.check(self.lib.vszip_ctx_sync(self.ctx))
+
+    def set_staging(self, mode: int):
+        """0: host copies go straight from/to the caller's memory; 1: through the context's pinned arena."""
+        self.check(self.lib.vszip_ctx_set_staging(self.ctx, mode))
 
     def set_stream(self, hip_stream: int):
         """Enqueue on an externally owned hipStream_t (e.g. torch.cuda.Stream().cuda_stream)."""

@@ -35,6 +35,19 @@ struct vszip_ctx {
     void *xpsnr_sums = nullptr;
     size_t xpsnr_sums_bytes = 0;
     bool xpsnr_clean = false;
+    // Host staging (vszip_ctx_set_staging): 0 = copy straight from/to the caller's pointers (pinned
+    // callers, or pageable memory that the runtime pins in place), 1 = through this context's pinned
+    // arena with CPU copies — H2D: copy in, DMA asynchronously; D2H: DMA now, copy out in vszip_ctx_sync.
+    int staging = 0;
+    char *stage = nullptr;
+    size_t stage_bytes = 0, stage_used = 0;
+    struct PendingOut {
+        void *dst;
+        size_t dpitch;
+        const char *src;
+        size_t wb, rows;
+    };
+    std::vector<PendingOut> pending_out;
     int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
 };
 

@@ -1,6 +1,9 @@
 // Context, device memory, staging copies and timers behind include/vszip_hip.h.
 #include "common.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
         char buf[512];
@@ -60,6 +63,8 @@ VSZIP_EXPORT int vszip_ctx_create(int device, vszip_ctx **out) {
     c->own_stream = true;
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
+    const char *st = getenv("VSZIP_STAGING");
+    if (st) c->staging = (strcmp(st, "pinned") == 0 || strcmp(st, "1") == 0) ? 1 : 0;
     const char *sm = getenv("VSZIP_SCAN_MODE");
     if (sm) c->scan_mode = atoi(sm);
     *out = c;
@@ -74,6 +79,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->probe_events) (void)hipEventDestroy(e);
@@ -94,9 +100,30 @@ VSZIP_EXPORT int vszip_ctx_set_stream(vszip_ctx *ctx, void *hip_stream) {
 
 VSZIP_EXPORT void *vszip_ctx_stream(vszip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+static void flush_pending_out(vszip_ctx *ctx);
+
 VSZIP_EXPORT int vszip_ctx_sync(vszip_ctx *ctx) {
     if (!ctx) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->staging == 1) flush_pending_out(ctx);
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_ctx_abort(vszip_ctx *ctx) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pending_out.clear();  // the caller is about to release the destinations
+    ctx->stage_used = 0;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_ctx_set_staging(vszip_ctx *ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 1) return VSZIP_ERR_ARG;
+    if (mode != ctx->staging) {
+        VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        flush_pending_out(ctx);
+        ctx->staging = mode;
+    }
     return VSZIP_OK;
 }
 
@@ -133,9 +160,60 @@ VSZIP_EXPORT int vszip_host_free_pinned(vszip_ctx *ctx, void *hptr) {
     return VSZIP_OK;
 }
 
+static void copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows) {
+    if (dpitch == wb && spitch == wb) {
+        memcpy(dst, src, wb * rows);
+        return;
+    }
+    for (size_t y = 0; y < rows; ++y) memcpy(static_cast<char *>(dst) + y * dpitch, static_cast<const char *>(src) + y * spitch, wb);
+}
+
+// D2H copies staged through the arena land in the caller's memory here (after the stream drained).
+static void flush_pending_out(vszip_ctx *ctx) {
+    for (const auto &p : ctx->pending_out) copy_rows(p.dst, p.dpitch, p.src, p.wb, p.wb, p.rows);
+    ctx->pending_out.clear();
+    ctx->stage_used = 0;
+}
+
+// `bytes` of the pinned arena, valid until the next vszip_ctx_sync. A full arena drains the stream
+// first (everything staged so far has then been consumed) and grows.
+static int stage_take(vszip_ctx *ctx, size_t bytes, char **out) {
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->stage_used + need > ctx->stage_bytes) {
+        VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        flush_pending_out(ctx);
+        if (need > ctx->stage_bytes) {
+            if (ctx->stage) (void)hipHostFree(ctx->stage);
+            ctx->stage = nullptr;
+            ctx->stage_bytes = 0;
+            const size_t want = need * 2 > (size_t(64) << 20) ? need * 2 : (size_t(64) << 20);
+            void *p = nullptr;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipHostMalloc(%zu) failed", want);
+            ctx->stage = static_cast<char *>(p);
+            ctx->stage_bytes = want;
+        }
+    }
+    *out = ctx->stage + ctx->stage_used;
+    ctx->stage_used += need;
+    return VSZIP_OK;
+}
+
 static int copy2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows, hipMemcpyKind kind) {
     if (!ctx) return VSZIP_ERR_ARG;
     if (wb == 0 || rows == 0) return VSZIP_OK;
+    if (ctx->staging == 1 && kind != hipMemcpyDeviceToDevice) {
+        char *a = nullptr;
+        const int rc = stage_take(ctx, wb * rows, &a);
+        if (rc != VSZIP_OK) return rc;
+        if (kind == hipMemcpyHostToDevice) {
+            copy_rows(a, wb, src, spitch, wb, rows);
+            VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, a, wb, wb, rows, kind, ctx->stream));
+        } else {
+            VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(a, wb, src, spitch, wb, rows, kind, ctx->stream));
+            ctx->pending_out.push_back({dst, dpitch, a, wb, rows});
+        }
+        return VSZIP_OK;
+    }
     VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, wb, rows, kind, ctx->stream));
     return VSZIP_OK;
 }

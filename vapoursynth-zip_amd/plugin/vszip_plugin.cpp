@@ -11,6 +11,8 @@
 // context (stream + scratch) per worker thread and device, so getFrame stays re-entrant
 // (fmParallel) exactly like the reference's.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -76,10 +78,60 @@ int device_count() {
     return n;
 }
 
-Gpu *gpu_for_frame(int n) {
+// At most kGateDefault (x GPUs) getFrame calls work on the GPU at a time; further workers wait
+// here. VapourSynth starts one worker per hardware thread (256 on the MI355X hosts), and the
+// plugin's throughput peaks at 8-16 concurrent callers and falls to a third of that at 64 (the
+// runtime's pageable-copy path and the hardware queues are shared): profiles/r01_plugin_throughput.md.
+// The gate hands out SLOTS, and a slot owns the GPU contexts (stream, slab, scratch) its holder
+// uses — so a process has `limit` streams, one per hardware queue, however many workers the host
+// runs, instead of one context per worker thread. VSZIP_MAX_IN_FLIGHT overrides the limit
+// (0 = no gate, one context per worker thread).
+constexpr int kGateDefault = 16;
+struct GateState {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> free_slots;  // LIFO: a lightly loaded host keeps reusing the same warm contexts
+    std::vector<std::map<int, std::unique_ptr<Gpu>>> gpus;
+    int limit = -1;
+};
+GateState &gate_state() {
+    static GateState *st = new GateState();  // never destroyed: HIP may be gone at static-destruction time
+    return *st;
+}
+struct FrameGate {
+    int slot = -1;
+    FrameGate() {
+        GateState &st = gate_state();
+        std::unique_lock<std::mutex> lk(st.mu);
+        if (st.limit < 0) {
+            const char *e = getenv("VSZIP_MAX_IN_FLIGHT");
+            st.limit = e ? std::max(0, atoi(e)) : kGateDefault * std::max(1, device_count());
+            st.gpus.resize((size_t)st.limit);
+            for (int i = st.limit - 1; i >= 0; --i) st.free_slots.push_back(i);
+        }
+        if (st.limit == 0) return;
+        st.cv.wait(lk, [&] { return !st.free_slots.empty(); });
+        slot = st.free_slots.back();
+        st.free_slots.pop_back();
+    }
+    ~FrameGate() {
+        if (slot < 0) return;
+        GateState &st = gate_state();
+        {
+            std::lock_guard<std::mutex> lk(st.mu);
+            st.free_slots.push_back(slot);
+        }
+        st.cv.notify_one();
+    }
+    FrameGate(const FrameGate &) = delete;
+    FrameGate &operator=(const FrameGate &) = delete;
+};
+
+Gpu *gpu_for_frame(int n, const FrameGate &gate) {
     const int nd = device_count();
     if (nd <= 0) return nullptr;
-    thread_local std::map<int, std::unique_ptr<Gpu>> pool;
+    thread_local std::map<int, std::unique_ptr<Gpu>> own;
+    auto &pool = gate.slot >= 0 ? gate_state().gpus[(size_t)gate.slot] : own;  // a held slot is exclusive
     const int dev = ((n % nd) + nd) % nd;  // frame-index round-robin over the GPUs of the node
     auto &g = pool[dev];
     if (!g) {
@@ -93,6 +145,27 @@ Gpu *gpu_for_frame(int n) {
     g->reset();
     return g.get();
 }
+
+// Host staging policy (measured: profiles/r01_plugin_throughput.md). Link-bound filters copy straight
+// from/to the frame memory (the runtime pins it in place; fastest per byte, but the call blocks and
+// copies of one process take turns). Kernel-bound filters (Bilateral, EEDI3) go through the
+// context's pinned arena once several getFrame calls are in flight: their DMA is asynchronous, so
+// the streams of concurrent callers overlap kernels with copies. VSZIP_STAGING=direct|pinned
+// overrides (read by vszip_ctx_create).
+std::atomic<int> g_heavy_in_flight{0};
+struct HeavyFrameScope {
+    Gpu *g;
+    bool switched = false;
+    explicit HeavyFrameScope(Gpu *gpu) : g(gpu) {
+        static const bool forced = getenv("VSZIP_STAGING") != nullptr;
+        const int n = g_heavy_in_flight.fetch_add(1) + 1;
+        if (g && !forced && n >= 4) switched = vszip_ctx_set_staging(g->ctx, 1) == VSZIP_OK;
+    }
+    ~HeavyFrameScope() {
+        g_heavy_in_flight.fetch_sub(1);
+        if (switched) vszip_ctx_set_staging(g->ctx, 0);  // the thread's context is shared with the link-bound filters
+    }
+};
 
 struct DPlane {
     void *ptr = nullptr;
@@ -253,6 +326,7 @@ const VSFrame *fail(const Z &z, Gpu *g, VSFrame *dst, const char *name, const ch
     char buf[600];
     snprintf(buf, sizeof buf, "%s: %s%s%s", name, what, g ? " — " : "", g ? vszip_last_error(g->ctx) : "");
     z.api->setFilterError(buf, z.fctx);
+    if (g) vszip_ctx_abort(g->ctx);  // staged output copies must not land in a frame we free
     if (dst) z.api->freeFrame(dst);
     return nullptr;
 }
@@ -296,7 +370,8 @@ const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSF
         const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             api->freeFrame(src);
             return fail(z, nullptr, dst, "BoxBlur", "no MI355X device available (the plugin has no CPU fallback)");
@@ -431,7 +506,9 @@ const VSFrame *VS_CC bilateralGetFrame(int n, int reason, void *inst, void **, V
             if (ref) api->freeFrame(ref);
             return r;
         };
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
+        HeavyFrameScope heavy(g);
         if (!g) return done(fail(z, nullptr, dst, "Bilateral", "no MI355X device available (the plugin has no CPU fallback)"));
         vszip_bilateral_cfg *cfg;
         {
@@ -578,7 +655,8 @@ const VSFrame *VS_CC planeStatGetFrame(int n, int reason, void *inst, void **, V
             if (ref) api->freeFrame(ref);
             return r;
         };
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
         std::vector<vszip_plane> tab;
         const VSVideoFormat *vf = api->getVideoFrameFormat(src);
@@ -710,7 +788,8 @@ const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSF
         const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             api->freeFrame(src);
             return fail(z, nullptr, dst, "Limiter", "no MI355X device available (the plugin has no CPU fallback)");
@@ -899,7 +978,8 @@ const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **,
         const VSFrame *psrc[3] = {d->planes[0] ? nullptr : flt, d->planes[1] ? nullptr : flt, d->planes[2] ? nullptr : flt};
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(flt, 0), api->getFrameHeight(flt, 0), psrc, pidx, flt, core);
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             release();
             return fail(z, nullptr, dst, "LimitFilter", "no MI355X device available (the plugin has no CPU fallback)");
@@ -1022,7 +1102,8 @@ const VSFrame *VS_CC adaptiveBinarizeGetFrame(int n, int reason, void *inst, voi
             api->freeFrame(src);
             api->freeFrame(src2);
         };
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             release();
             return fail(z, nullptr, dst, "AdaptiveBinarize", "no MI355X device available (the plugin has no CPU fallback)");
@@ -1176,7 +1257,8 @@ const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFram
             api->freeFrame(s2);
             return r;
         };
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, "SSIMULACRA2", "no MI355X device available (the plugin has no CPU fallback)"));
         // all six planes at one common pitch
         const int w = api->getFrameWidth(s1, 0), h = api->getFrameHeight(s1, 0);
@@ -1271,7 +1353,8 @@ const VSFrame *VS_CC xpsnrGetFrame(int n, int reason, void *inst, void **, VSFra
             if (p2) api->freeFrame(p2);
             return r;
         };
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, "XPSNR", "no MI355X device available (the plugin has no CPU fallback)"));
         const void *o3[3] = {nullptr, nullptr, nullptr}, *r3[3] = {nullptr, nullptr, nullptr};
         ptrdiff_t st[3] = {0, 0, 0};
@@ -1434,7 +1517,9 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
         if (!e && fb == 1) field = 0;  // BOTTOM
         if (!e && fb == 2) field = 1;  // TOP
         if (d->field > 1) field = (n & 1) ^ field;
-        Gpu *g = gpu_for_frame(n);
+        FrameGate gate;
+        Gpu *g = gpu_for_frame(n, gate);
+        HeavyFrameScope heavy(g);
         if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
         std::vector<vszip_plane> tab;
         std::vector<DPlane> outs;
@@ -1602,6 +1687,13 @@ const char *kEedi3Args =
 // src/vszip.zig:35-223 — the seven hot-path filters of the pack, same id / namespace / signatures.
 // pluginVersion: zon.version "19.0.0" packed by vapoursynth-zig (un-vendored) — major only here.
 VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
+    // Every worker thread owns a HIP stream, and the runtime folds all streams of a process onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4), in which kernels of different streams run in
+    // order: with 16 workers, EEDI3's 2 ms vcheck chain of one frame holds up three other frames'
+    // kernels (0.8 k -> 1.6 k fps at 16 queues, profiles/r01_plugin_throughput.md). The runtime
+    // reads the variable when it initialises, i.e. at the first HIP call, which happens after this
+    // point in a VapourSynth process; a value the user has set is left alone.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     vspapi->configPlugin("com.julek.vszip", "vszip", "VapourSynth Zig Image Process", VS_MAKE_VERSION(19, 0), VAPOURSYNTH_API_VERSION, 0, plugin);
     vspapi->registerFunction("Bilateral", "clip:vnode;ref:vnode:opt;sigmaS:float[]:opt;sigmaR:float[]:opt;planes:int[]:opt;algorithm:int[]:opt;PBFICnum:int[]:opt",
                              "clip:vnode;", bilateralCreate, nullptr, plugin);
