@@ -78,66 +78,75 @@ int device_count() {
     return n;
 }
 
-// At most kGateDefault (x GPUs) getFrame calls work on the GPU at a time; further workers wait
+// At most kGateDefault getFrame calls per GPU work on that GPU at a time; further workers wait
 // here. VapourSynth starts one worker per hardware thread (256 on the MI355X hosts), and the
 // plugin's throughput peaks at 8-16 concurrent callers and falls to a third of that at 64 (the
 // runtime's pageable-copy path and the hardware queues are shared): profiles/r01_plugin_throughput.md.
 // The gate hands out SLOTS, and a slot owns the GPU contexts (stream, slab, scratch) its holder
-// uses — so a process has `limit` streams, one per hardware queue, however many workers the host
+// uses — so a process has `limit` streams per GPU, one per hardware queue, however many workers the host
 // runs, instead of one context per worker thread. VSZIP_MAX_IN_FLIGHT overrides the limit
 // (0 = no gate, one context per worker thread).
 constexpr int kGateDefault = 16;
+struct GateDevice {
+    std::vector<int> free_slots;  // LIFO: a lightly loaded host keeps reusing the same warm contexts
+    std::vector<std::unique_ptr<Gpu>> gpus;
+};
 struct GateState {
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<int> free_slots;  // LIFO: a lightly loaded host keeps reusing the same warm contexts
-    std::vector<std::map<int, std::unique_ptr<Gpu>>> gpus;
-    int limit = -1;
+    std::vector<GateDevice> dev;
+    int limit = -1;  // slots per device
 };
 GateState &gate_state() {
     static GateState *st = new GateState();  // never destroyed: HIP may be gone at static-destruction time
     return *st;
 }
+inline int device_of_frame(int n, int nd) { return ((n % nd) + nd) % nd; }  // frame-index round-robin over the GPUs of the node
 struct FrameGate {
-    int slot = -1;
-    FrameGate() {
+    int dev = -1, slot = -1;
+    explicit FrameGate(int n) {
+        const int nd = device_count();
+        if (nd <= 0) return;
+        dev = device_of_frame(n, nd);
         GateState &st = gate_state();
         std::unique_lock<std::mutex> lk(st.mu);
         if (st.limit < 0) {
             const char *e = getenv("VSZIP_MAX_IN_FLIGHT");
-            st.limit = e ? std::max(0, atoi(e)) : kGateDefault * std::max(1, device_count());
-            st.gpus.resize((size_t)st.limit);
-            for (int i = st.limit - 1; i >= 0; --i) st.free_slots.push_back(i);
+            st.limit = e ? std::max(0, atoi(e)) : kGateDefault;
+            st.dev.resize((size_t)nd);
+            for (auto &d : st.dev) {
+                d.gpus.resize((size_t)st.limit);
+                for (int i = st.limit - 1; i >= 0; --i) d.free_slots.push_back(i);
+            }
         }
         if (st.limit == 0) return;
-        st.cv.wait(lk, [&] { return !st.free_slots.empty(); });
-        slot = st.free_slots.back();
-        st.free_slots.pop_back();
+        GateDevice &d = st.dev[(size_t)dev];
+        st.cv.wait(lk, [&] { return !d.free_slots.empty(); });
+        slot = d.free_slots.back();
+        d.free_slots.pop_back();
     }
     ~FrameGate() {
         if (slot < 0) return;
         GateState &st = gate_state();
         {
             std::lock_guard<std::mutex> lk(st.mu);
-            st.free_slots.push_back(slot);
+            st.dev[(size_t)dev].free_slots.push_back(slot);
         }
-        st.cv.notify_one();
+        st.cv.notify_all();  // waiters of different devices share the condition variable
     }
     FrameGate(const FrameGate &) = delete;
     FrameGate &operator=(const FrameGate &) = delete;
 };
 
 Gpu *gpu_for_frame(int n, const FrameGate &gate) {
-    const int nd = device_count();
-    if (nd <= 0) return nullptr;
-    thread_local std::map<int, std::unique_ptr<Gpu>> own;
-    auto &pool = gate.slot >= 0 ? gate_state().gpus[(size_t)gate.slot] : own;  // a held slot is exclusive
-    const int dev = ((n % nd) + nd) % nd;  // frame-index round-robin over the GPUs of the node
-    auto &g = pool[dev];
+    (void)n;
+    if (gate.dev < 0) return nullptr;
+    thread_local std::map<int, std::unique_ptr<Gpu>> own;  // VSZIP_MAX_IN_FLIGHT=0: one context per worker thread
+    auto &g = gate.slot >= 0 ? gate_state().dev[(size_t)gate.dev].gpus[(size_t)gate.slot] : own[gate.dev];  // a held slot is exclusive
     if (!g) {
         g.reset(new Gpu());
-        g->device = dev;
-        if (vszip_ctx_create(dev, &g->ctx) != VSZIP_OK) {
+        g->device = gate.dev;
+        if (vszip_ctx_create(gate.dev, &g->ctx) != VSZIP_OK) {
             g.reset();
             return nullptr;
         }
@@ -370,7 +379,7 @@ const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSF
         const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             api->freeFrame(src);
@@ -506,7 +515,7 @@ const VSFrame *VS_CC bilateralGetFrame(int n, int reason, void *inst, void **, V
             if (ref) api->freeFrame(ref);
             return r;
         };
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         HeavyFrameScope heavy(g);
         if (!g) return done(fail(z, nullptr, dst, "Bilateral", "no MI355X device available (the plugin has no CPU fallback)"));
@@ -655,7 +664,7 @@ const VSFrame *VS_CC planeStatGetFrame(int n, int reason, void *inst, void **, V
             if (ref) api->freeFrame(ref);
             return r;
         };
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
         std::vector<vszip_plane> tab;
@@ -788,7 +797,7 @@ const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSF
         const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             api->freeFrame(src);
@@ -978,7 +987,7 @@ const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **,
         const VSFrame *psrc[3] = {d->planes[0] ? nullptr : flt, d->planes[1] ? nullptr : flt, d->planes[2] ? nullptr : flt};
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(flt, 0), api->getFrameHeight(flt, 0), psrc, pidx, flt, core);
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             release();
@@ -1102,7 +1111,7 @@ const VSFrame *VS_CC adaptiveBinarizeGetFrame(int n, int reason, void *inst, voi
             api->freeFrame(src);
             api->freeFrame(src2);
         };
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
             release();
@@ -1257,7 +1266,7 @@ const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFram
             api->freeFrame(s2);
             return r;
         };
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, "SSIMULACRA2", "no MI355X device available (the plugin has no CPU fallback)"));
         // all six planes at one common pitch
@@ -1353,7 +1362,7 @@ const VSFrame *VS_CC xpsnrGetFrame(int n, int reason, void *inst, void **, VSFra
             if (p2) api->freeFrame(p2);
             return r;
         };
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, "XPSNR", "no MI355X device available (the plugin has no CPU fallback)"));
         const void *o3[3] = {nullptr, nullptr, nullptr}, *r3[3] = {nullptr, nullptr, nullptr};
@@ -1517,7 +1526,7 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
         if (!e && fb == 1) field = 0;  // BOTTOM
         if (!e && fb == 2) field = 1;  // TOP
         if (d->field > 1) field = (n & 1) ^ field;
-        FrameGate gate;
+        FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         HeavyFrameScope heavy(g);
         if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
