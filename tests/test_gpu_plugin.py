@@ -492,3 +492,35 @@ def test_heavy_filters_switch_to_the_pinned_arena_under_load(oracle):
         got = list(ex.map(lambda n: np.array(e3.get_frame(n % 8)[0]), range(48)))
     for n, o in enumerate(got):
         assert np.array_equal(o, want[n % 8])
+
+
+def test_gate_with_fewer_slots_than_workers():
+    """VSZIP_MAX_IN_FLIGHT=2 with 16 workers on a Bilateral -> BoxBlur chain plus a metric: every
+    worker gets its turn (no deadlock, no failed frame), results equal the ungated single caller's.
+    Runs in a child process because the limit is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import fixtures as fx
+from fakevs import fakevs as vs
+planes = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate([(144, 256), (72, 128), (72, 128)])]
+frames = [[np.ascontiguousarray(np.roll(p, 3 * f, axis=1)) for p in planes] for f in range(8)]
+src = vs.source(frames, vs.YUV420P16)
+chain = src.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=3, vradius=3).vszip.PlaneAverage(exclude=[-1])
+single = [(np.array(chain.get_frame(n)[0]), chain.get_frame(n).props["psmAvg"]) for n in range(8)]
+chain.pull(128, 16)
+import concurrent.futures as cf
+with cf.ThreadPoolExecutor(16) as ex:
+    got = list(ex.map(lambda n: (np.array(chain.get_frame(n % 8)[0]), chain.get_frame(n % 8).props["psmAvg"]), range(64)))
+for n, (px, avg) in enumerate(got):
+    assert np.array_equal(px, single[n % 8][0]) and avg == single[n % 8][1]
+print("gate ok")
+'''
+    env = dict(os.environ, VSZIP_MAX_IN_FLIGHT="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gate ok" in r.stdout, r.stdout + r.stderr
