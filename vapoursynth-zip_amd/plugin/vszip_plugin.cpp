@@ -88,13 +88,13 @@ int device_count() {
 // (0 = no gate, one context per worker thread).
 constexpr int kGateDefault = 16;
 struct GateDevice {
+    std::condition_variable cv;   // waiters for a slot of this device (woken one at a time)
     std::vector<int> free_slots;  // LIFO: a lightly loaded host keeps reusing the same warm contexts
     std::vector<std::unique_ptr<Gpu>> gpus;
 };
 struct GateState {
     std::mutex mu;
-    std::condition_variable cv;
-    std::vector<GateDevice> dev;
+    std::vector<std::unique_ptr<GateDevice>> dev;
     int limit = -1;  // slots per device
 };
 GateState &gate_state() {
@@ -113,15 +113,15 @@ struct FrameGate {
         if (st.limit < 0) {
             const char *e = getenv("VSZIP_MAX_IN_FLIGHT");
             st.limit = e ? std::max(0, atoi(e)) : kGateDefault;
-            st.dev.resize((size_t)nd);
-            for (auto &d : st.dev) {
-                d.gpus.resize((size_t)st.limit);
-                for (int i = st.limit - 1; i >= 0; --i) d.free_slots.push_back(i);
+            for (int k = 0; k < nd; ++k) {
+                st.dev.emplace_back(new GateDevice());
+                st.dev.back()->gpus.resize((size_t)st.limit);
+                for (int i = st.limit - 1; i >= 0; --i) st.dev.back()->free_slots.push_back(i);
             }
         }
         if (st.limit == 0) return;
-        GateDevice &d = st.dev[(size_t)dev];
-        st.cv.wait(lk, [&] { return !d.free_slots.empty(); });
+        GateDevice &d = *st.dev[(size_t)dev];
+        d.cv.wait(lk, [&] { return !d.free_slots.empty(); });
         slot = d.free_slots.back();
         d.free_slots.pop_back();
     }
@@ -130,9 +130,9 @@ struct FrameGate {
         GateState &st = gate_state();
         {
             std::lock_guard<std::mutex> lk(st.mu);
-            st.dev[(size_t)dev].free_slots.push_back(slot);
+            st.dev[(size_t)dev]->free_slots.push_back(slot);
         }
-        st.cv.notify_all();  // waiters of different devices share the condition variable
+        st.dev[(size_t)dev]->cv.notify_one();
     }
     FrameGate(const FrameGate &) = delete;
     FrameGate &operator=(const FrameGate &) = delete;
@@ -142,7 +142,7 @@ Gpu *gpu_for_frame(int n, const FrameGate &gate) {
     (void)n;
     if (gate.dev < 0) return nullptr;
     thread_local std::map<int, std::unique_ptr<Gpu>> own;  // VSZIP_MAX_IN_FLIGHT=0: one context per worker thread
-    auto &g = gate.slot >= 0 ? gate_state().dev[(size_t)gate.dev].gpus[(size_t)gate.slot] : own[gate.dev];  // a held slot is exclusive
+    auto &g = gate.slot >= 0 ? gate_state().dev[(size_t)gate.dev]->gpus[(size_t)gate.slot] : own[gate.dev];  // a held slot is exclusive
     if (!g) {
         g.reset(new Gpu());
         g->device = gate.dev;
