@@ -245,11 +245,12 @@ static VSFrame *VS_CC A(newVideoFrame2)(const VSVideoFormat *fmt, int w, int h, 
     VSFrame *f = frame_new(fmt, w, h);
     if (propSrc) map_copy(&propSrc->props, &f->props);
     for (int p = 0; p < fmt->numPlanes; ++p) {
-        if (planeSrc && planeSrc[p]) {  // the real core shares the plane; a copy is observably the same
+        if (planeSrc && planeSrc[p]) {  // like the real core: the plane buffer is shared (copy on write)
             const VSFrame *s = planeSrc[p];
             const int sp = planes ? planes[p] : p;
-            const int pw = plane_w(*fmt, w, p) * fmt->bytesPerSample, ph = plane_h(*fmt, h, p);
-            for (int y = 0; y < ph; ++y) memcpy(f->ptr[p] + (size_t)y * f->stride[p], s->ptr[sp] + (size_t)y * s->stride[sp], pw);
+            f->buf[p] = s->buf[sp];
+            f->ptr[p] = s->ptr[sp];
+            f->stride[p] = s->stride[sp];
         }
     }
     return f;
@@ -259,12 +260,18 @@ static const VSFrame *VS_CC A(addFrameRef)(const VSFrame *f) {
     const_cast<VSFrame *>(f)->refs++;
     return f;
 }
+// Like the real core: the copy shares the plane buffers, and a plane is duplicated only when
+// someone asks for a write pointer to a buffer that is still shared (getWritePtr below).
 static VSFrame *VS_CC A(copyFrame)(const VSFrame *s, VSCore *) {
-    VSFrame *f = frame_new(&s->fmt, s->w, s->h);
+    VSFrame *f = new VSFrame();
+    f->fmt = s->fmt;
+    f->w = s->w;
+    f->h = s->h;
     map_copy(&s->props, &f->props);
     for (int p = 0; p < s->fmt.numPlanes; ++p) {
-        const int pw = plane_w(s->fmt, s->w, p) * s->fmt.bytesPerSample, ph = plane_h(s->fmt, s->h, p);
-        for (int y = 0; y < ph; ++y) memcpy(f->ptr[p] + (size_t)y * f->stride[p], s->ptr[p] + (size_t)y * s->stride[p], pw);
+        f->buf[p] = s->buf[p];
+        f->ptr[p] = s->ptr[p];
+        f->stride[p] = s->stride[p];
     }
     return f;
 }
@@ -272,7 +279,17 @@ static const VSMap *VS_CC A(getFramePropertiesRO)(const VSFrame *f) { return &f-
 static VSMap *VS_CC A(getFramePropertiesRW)(VSFrame *f) { return &f->props; }
 static ptrdiff_t VS_CC A(getStride)(const VSFrame *f, int p) { return f->stride[p]; }
 static const uint8_t *VS_CC A(getReadPtr)(const VSFrame *f, int p) { return f->ptr[p]; }
-static uint8_t *VS_CC A(getWritePtr)(VSFrame *f, int p) { return f->ptr[p]; }
+static uint8_t *VS_CC A(getWritePtr)(VSFrame *f, int p) {
+    if (f->buf[p] && f->buf[p].use_count() > 1) {  // copy on write
+        auto nb = std::make_shared<PlaneBuf>();
+        nb->bytes = f->buf[p]->bytes;
+        nb->base = g_planes.take(nb->bytes);
+        memcpy(nb->base, f->buf[p]->base, nb->bytes);
+        f->ptr[p] = nb->base + (f->ptr[p] - f->buf[p]->base);
+        f->buf[p] = nb;
+    }
+    return f->ptr[p];
+}
 static const VSVideoFormat *VS_CC A(getVideoFrameFormat)(const VSFrame *f) { return &f->fmt; }
 static int VS_CC A(getFrameType)(const VSFrame *) { return mtVideo; }
 static int VS_CC A(getFrameWidth)(const VSFrame *f, int p) { return plane_w(f->fmt, f->w, p); }
