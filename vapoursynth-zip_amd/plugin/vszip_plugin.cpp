@@ -80,13 +80,13 @@ int device_count() {
 
 // At most kGateDefault getFrame calls per GPU work on that GPU at a time; further workers wait
 // here. VapourSynth starts one worker per hardware thread (256 on the MI355X hosts), and the
-// plugin's throughput peaks at 8-16 concurrent callers and falls to a third of that at 64 (the
+// plugin's throughput peaks at 10-16 concurrent callers and falls to a third of that at 64 (the
 // runtime's pageable-copy path and the hardware queues are shared): profiles/r01_plugin_throughput.md.
 // The gate hands out SLOTS, and a slot owns the GPU contexts (stream, slab, scratch) its holder
 // uses — so a process has `limit` streams per GPU, one per hardware queue, however many workers the host
 // runs, instead of one context per worker thread. VSZIP_MAX_IN_FLIGHT overrides the limit
 // (0 = no gate, one context per worker thread).
-constexpr int kGateDefault = 16;
+constexpr int kGateDefault = 12;  // swept 6..24 at 32 workers: 12 is the best or within 5 % for every filter (EEDI3 1.6 k vs 1.1 k fps at 16)
 struct GateDevice {
     std::condition_variable cv;   // waiters for a slot of this device (woken one at a time)
     std::vector<int> free_slots;  // LIFO: a lightly loaded host keeps reusing the same warm contexts
