@@ -20,10 +20,30 @@ GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
 
 @lru_cache(maxsize=None)
 def crop_rgb24() -> np.ndarray:
-    a = np.load(GOLDEN_DIR / "crop_rgb24.npy")
-    assert a.shape == (3, 320, 640) and a.dtype == np.uint8
+    a = np.ascontiguousarray(_crop_rows322()[:, :320])
     a.setflags(write=False)
     return a
+
+
+@lru_cache(maxsize=None)
+def _crop_rows322() -> np.ndarray:
+    a = np.load(GOLDEN_DIR / "crop_rgb24.npy")
+    assert a.shape == (3, 322, 640) and a.dtype == np.uint8
+    return a
+
+
+def temporal_rgb24(n: int) -> np.ndarray:
+    """Frame n (0..2) of the reference's temporal fixture (tests/conftest.py:138-148): the crop
+    shifted down n rows."""
+    assert 0 <= n <= 2
+    return np.ascontiguousarray(_crop_rows322()[:, n:n + 320])
+
+
+def luma8(rgb: np.ndarray) -> np.ndarray:
+    """zimg RGB24 -> 8-bit limited-range BT.709 luma (exact): plane 0 of the reference's
+    GRAY8 and YUV4xxP8 fixtures."""
+    r, g, b = (rgb[i].astype(np.float64) for i in range(3))
+    return np.floor((0.2126 * r + 0.7152 * g + 0.0722 * b) * 219.0 / 255.0 + 16.0 + 0.5).astype(np.uint8)
 
 
 @lru_cache(maxsize=None)
@@ -35,9 +55,7 @@ def crop_rgbs() -> np.ndarray:
 
 @lru_cache(maxsize=None)
 def crop_gray8() -> np.ndarray:
-    r, g, b = (crop_rgb24()[i].astype(np.float64) for i in range(3))
-    y = np.floor((0.2126 * r + 0.7152 * g + 0.0722 * b) * 219.0 / 255.0 + 16.0 + 0.5)
-    a = y.astype(np.uint8)
+    a = luma8(crop_rgb24())
     a.setflags(write=False)
     return a
 
