@@ -10,9 +10,13 @@ over one batch of F = 64 synthetic frames already resident in HBM (F*3 = 192 pla
 The other two headline filters (Bilateral sigmaS=2 sigmaR=2, SSIMULACRA2 ref vs dist) are
 measured in the same run on their BASELINE configs and reported under "others", each beside
 the CPU oracle timed on this box's host cores.
-For N > 1 the driver starts one process per GPU through torch.distributed.run; frames shard
-across ranks with no data-path collective (weak scaling: every rank owns its own F frames);
-the only collective is the max-reduce of the timings.
+N > 1: one process per GPU over RCCL. Either the caller starts the ranks (python -m torch.distributed.run
+... bench.py --gpus N: RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N` starts them
+itself as CHILD processes before anything in this process has touched the GPU, relays rank 0's line
+and exits with the children's code. Frames shard across ranks with no data-path collective (weak
+scaling: every rank owns its own F frames); the collectives are the max-reduce of the timings and, outside
+the timed region, the per-clip XPSNR accumulators. Every N also reports the PCIe-fed rate (pinned host
+frames in and out, all ranks at once): config.pcie_fed_fps.
 Rank 0 prints ONE JSON line (DESIGN.md section "Measurement").
 """
 from __future__ import annotations
@@ -89,12 +93,12 @@ def _timed_pool(fn, cores: int, budget_s: float, unit_desc: str, t_single: float
             "sample": f"{n} x {unit_desc}, one per thread on {cores} threads, {dt:.1f}s"}
 
 
-def cpu_boxblur(budget_s=6.0):
+def cpu_boxblur(budget_s=6.0, w=W4K, h=H4K, blank=False):
     from oracle import oracle as orc
 
     orc.build()
     cores = os.cpu_count() or 1
-    frame = make_frame(0, W4K, H4K)
+    frame = [np.zeros(sh, np.uint16) for sh in yuv420_shapes(w, h)] if blank else make_frame(0, w, h)
 
     def one(_):
         for p in frame:
@@ -102,7 +106,7 @@ def cpu_boxblur(budget_s=6.0):
 
     t0 = time.perf_counter()
     one(0)
-    return _timed_pool(one, cores, budget_s, "3840x2160 YUV420P16 frame, BoxBlur r=13", time.perf_counter() - t0)
+    return _timed_pool(one, cores, budget_s, f"{w}x{h} YUV420P16 frame{' (BlankClip)' if blank else ''}, BoxBlur r=13", time.perf_counter() - t0)
 
 
 def cpu_bilateral(w, h, budget_s=6.0):
@@ -178,9 +182,29 @@ class Timed:
         region_ms = self.dev.timer_stop_ms()  # synchronises the stream
         self.barrier()
         dt = time.perf_counter() - t0
-        dom_ms, launches = self.dev.probe_read()
+        dom_ms, launches, each = self.dev.probe_read_each()
         self.dev.probe_enable(False)
+        self.each_ms = each
         return dt, region_ms, dom_ms, launches
+
+    def launch_stats(self, step, min_seconds=1.0, max_launches=20000):
+        """min / median / max duration of the dominant kernel's launches over at least `min_seconds` of
+        kernel time (the contract's K-step region can be a few ms; this sample is not part of `value`)."""
+        each = list(getattr(self, "each_ms", []))
+        while sum(each) < min_seconds * 1e3 and len(each) < max_launches:
+            self.dev.probe_enable(True)
+            for _ in range(64):
+                step()
+            _, _, e = self.dev.probe_read_each()
+            self.dev.probe_enable(False)
+            if not e:
+                break
+            each += e
+        if not each:
+            return None
+        a = np.sort(np.asarray(each, np.float64)) * 1e3
+        return {"min": float(a[0]), "median": float(a[len(a) // 2]), "max": float(a[-1]), "mean": float(a.mean()), "p10": float(a[len(a) // 10]),
+                "p90": float(a[(9 * len(a)) // 10]), "n": int(len(a)), "sample_s": float(a.sum() * 1e-6)}
 
 
 def setup_boxblur(dev, rank, frames, radius):
@@ -472,7 +496,7 @@ def boxblur_other_paths_leg(dev, timed, frames=8):
     return out
 
 
-def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, rounds: int = 12):
+def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, rounds: int = 12, barrier=None):
     """PCIe-inclusive BoxBlur rate, the path a VapourSynth host pays: every frame is copied from
     pinned host memory to the GPU, blurred, and copied back. `nctx` contexts (one stream each,
     like the plugin's per-worker contexts) keep H2D, kernels and D2H of different frames in flight."""
@@ -499,13 +523,15 @@ def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, round
             c[0].sync()
 
     one_round()
+    if barrier:
+        barrier()  # every rank starts its timed rounds together: the host links are shared
     t0 = time.perf_counter()
     for _ in range(rounds):
         one_round()
     dt = time.perf_counter() - t0
     fps = nctx * rounds / dt
     fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K))
-    res = {"value": fps, "unit": "frames/s", "host_to_host": True, "contexts": nctx,
+    res = {"value": fps, "unit": "frames/s", "host_to_host": True, "contexts": nctx, "rounds": rounds, "seconds": dt,
            "pcie_GBps_each_direction": fps * fb / 1e9,
            "workload": "vszip.BoxBlur r=13 3840x2160 YUV420P16, pinned host frame -> GPU -> pinned host frame (never the headline value)"}
     for c in ctxs:
@@ -513,17 +539,143 @@ def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, round
     return res
 
 
+def boxblur_1080p_leg(dev, timed, no_cpu, frames=64):
+    """BASELINE configs[0] — the reference README's own benchmark (README.md:34-44: BlankClip 1920x1080
+    YUV420P16, BoxBlur hradius=vradius=13, 1046 fps on an unstated CPU) — on HBM-resident frames, 64 per call."""
+    srcs, dsts = [], []
+    for f in range(frames):
+        for sh in yuv420_shapes(W1080, H1080):
+            srcs.append(dev.upload(np.zeros(sh, np.uint16)))
+            dsts.append(dev.empty(sh[0], sh[1], np.uint16))
+    table = dev.plane_table(srcs, dsts)
+    dt, _, dom_ms, launches = timed.run(lambda: dev.boxblur_table(np.uint16, table, RADIUS, 1, RADIUS, 1), 200, 5)
+    fb = 2 * sum(2 * sh[0] * sh[1] for sh in yuv420_shapes(W1080, H1080)) * frames
+    gbs = fb * launches / (dom_ms * 1e-3) / 1e9
+    res = {"value": frames * 200 / dt, "unit": "frames/s", "readme_reference_fps": 1046.11,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "boxblur_ct_ring_kernel<u16,13>", "avg_launch_us": dom_ms * 1e3 / launches},
+           "workload": f"vszip.BoxBlur hradius=vradius=13 on 1920x1080 YUV420P16 BlankClip (README bench), {frames} frames per call, HBM-resident"}
+    if not no_cpu:
+        res["cpu_baseline"] = cpu_boxblur(4.0, W1080, H1080, blank=True)
+    return res
+
+
+def bind_to_gpu_numa(local_rank: int):
+    """Best effort: run this rank's host threads (and first-touch its pinned buffers) on the NUMA node
+    the GPU hangs off — the PCIe-fed rate is limited by host memory placement."""
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(Path(f"/sys/bus/pci/devices/{bdf}/numa_node").read_text())
+        if node < 0:
+            return None
+        cpus = []
+        for part in Path(f"/sys/devices/system/node/node{node}/cpulist").read_text().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
+def xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev, frames_per_rank=8):
+    """The one real exchange of the design: XPSNR's per-clip accumulators {sum_wdist[3], sum_xpsnr[3], n}
+    (src/vapoursynth/xpsnr.zig:89-96) from actual vszip_xpsnr_wsse_batch output on each rank's frames
+    (frame n belongs to rank n mod world), SUM-all-reduced over RCCL, averaged with getAvgXPSNR
+    (src/filters/xpsnr.zig:359-368) and checked on rank 0 against a single-rank pass over the whole clip."""
+    import ctypes as C
+
+    import fixtures as fx
+    from vszip_amd import cluster
+
+    n_total = world * frames_per_rank
+    shapes = yuv420_shapes(W1080, H1080)
+    base = [fx.tiled_natural(sh, np.uint8, p) for p, sh in enumerate(shapes)]
+
+    def frame(n):
+        org = [np.roll(b, 5 * n, axis=1) for b in base]
+        rng = np.random.default_rng(1000 + n)
+        rec = [np.clip(o.astype(np.int16) + rng.integers(-3, 4, o.shape, dtype=np.int16), 0, 255).astype(np.uint8) for o in org]
+        return org, rec
+
+    def accumulate(frame_ids):
+        orgs, recs, p1 = [], [], []
+        for n in frame_ids:
+            o, r = frame(n)
+            orgs.append([dev.upload(x) for x in o])
+            recs.append([dev.upload(x) for x in r])
+            p1.append(dev.upload(frame(n - 1)[0][0]) if n > 0 else None)
+        wsse = dev.xpsnr_wsse_batch(orgs, recs, p1, None, depth=8, frame_rate=24, temporal=True)
+        acc = np.zeros(7)
+        for wf in wsse:
+            for c in range(3):
+                acc[c] += np.sqrt(float(wf[c]))
+                acc[3 + c] += dev.lib.vszip_xpsnr_value(C.c_uint64(wf[c]), shapes[c][1], shapes[c][0], 8)
+            acc[6] += 1
+        return acc
+
+    mine = list(cluster.frames_of_rank(n_total, rank, world))
+    t0 = time.perf_counter()
+    tot = cluster.allreduce_clip_scalars(accumulate(mine), device=coll_dev)
+    ms = (time.perf_counter() - t0) * 1e3
+    avg = cluster.xpsnr_clip_average(tot[0:3], tot[3:6], tot[6], [sh[1] for sh in shapes], [sh[0] for sh in shapes], 8, dev.lib)
+    res = {"avg_xpsnr_yuv": [float(v) for v in avg], "frames": int(tot[6]), "reduced_over_ranks": world, "ms": ms}
+    if rank == 0:
+        serial = accumulate(range(n_total)) if world > 1 else tot
+        res["max_rel_diff_vs_single_rank"] = float(np.max(np.abs(tot - serial) / np.maximum(np.abs(serial), 1e-300)))
+        res["matches_single_rank"] = bool(res["max_rel_diff_vs_single_rank"] <= 1e-12)
+    return res
+
+
+def launch_ranks(a, argv) -> int:
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks as child
+    processes (this process never initialises a GPU, so no process that has touched one is ever
+    replaced), relay rank 0's single JSON line and return the children's exit code."""
+    import socket
+    import subprocess
+
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    if a.dry_launch:
+        print(json.dumps({"dry_launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.lstrip().startswith("{")]
+    if lines:
+        print(lines[-1])
+    elif r.returncode == 0:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 3
+    return r.returncode
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000, help="timed steps (default: ~1.2 s of BoxBlur launches)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (64 4K YUV420P16 frames = 192 planes = one BoxBlur launch)")
     ap.add_argument("--workload", default="boxblur", choices=["boxblur", "bilateral", "ssimulacra2", "pipeline"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")
     ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="kernel time of the launch-duration sample (roofline.launch_us)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1: print the rank-launch command and exit (no GPU)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a, [x for x in sys.argv[1:] if x != "--dry-launch"])
+    if a.workload != "boxblur" and a.steps == 2000:
+        a.steps = 50  # the other workloads' steps are milliseconds, not 0.6 ms
 
     # stdout carries exactly ONE line, the JSON. Libraries that print to fd 1 (RCCL's version banner
     # does) are sent to stderr for the lifetime of the process; the JSON goes to the saved fd.
@@ -534,6 +686,9 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, a.gpus):
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
 
     # torch first: its bundled HIP runtime must be the one libvszip_hip.so binds to
     import torch
@@ -542,12 +697,24 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         return 2
+    # development only (1-GPU boxes): VSZIP_BENCH_SHARE_GPU=1 folds the ranks onto the visible devices and runs
+    # the collectives over gloo (RCCL refuses two ranks on one GPU) — exercises launch, sharding and reduce logic
+    share_gpu = os.environ.get("VSZIP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # VSZIP_BENCH_FORCE_DIST=1 (under torch.distributed.run with one process): run the RCCL path
     # — barrier, timing max-reduce, per-clip scalar all-reduce — even with a single rank
     use_dist = world > 1 or (os.environ.get("VSZIP_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
+    coll_dev = None if (share_gpu or not use_dist) else "cuda"
+    rccl_ranks = 0 if share_gpu else (dist.get_world_size() if use_dist else 1)
+    numa_node = bind_to_gpu_numa(local_rank)
 
     import vszip_amd
 
@@ -563,13 +730,13 @@ def main() -> int:
 
     def max_over_ranks(dt):
         if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev or "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return dt
 
     def reduce_scalars(v):
-        return vszip_amd.cluster.allreduce_clip_scalars(v, device="cuda" if use_dist else None)
+        return vszip_amd.cluster.allreduce_clip_scalars(v, device=coll_dev)
 
     F = a.frames
     out = None
@@ -596,6 +763,7 @@ def main() -> int:
             "value": world * F * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": "vszip.BoxBlur hradius=vradius=13, 3840x2160 YUV420P16, splitmix64 noise, HBM-resident",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -605,17 +773,44 @@ def main() -> int:
                          "whole_filter": {"note": "ring kernel + launch gaps, HIP events over the whole timed region",
                                           "avg_us": group_s * 1e6, "achieved": alg_bytes / group_s / 1e9, "frac": alg_bytes / group_s / 1e9 / HBM_PEAK_GBS}},
         }
+        if rank == 0:
+            st_ = timed.launch_stats(step, a.min_seconds)
+            if st_:
+                out["roofline"]["launch_us"] = st_
+                out["roofline"]["frac_median"] = alg_bytes / (st_["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        barrier()
         # Outside the timed region: the one collective of the design — a per-clip scalar (here the
         # mean luma of the blurred clip, PlaneAverage over every rank's frames) all-reduced over
         # RCCL, like XPSNR's / SSIMULACRA2's per-clip sums (vszip_amd.cluster).
         try:
             luma = keep[1][0::3]
             avgs, _ = dev.plane_average(luma[:48], exclude=[-1])
-            tot = vszip_amd.cluster.allreduce_clip_scalars(np.array([float(np.sum(avgs)), float(len(avgs))]), device="cuda" if use_dist else None)
+            tot = vszip_amd.cluster.allreduce_clip_scalars(np.array([float(np.sum(avgs)), float(len(avgs))]), device=coll_dev)
             out["config"]["clip_mean_luma"] = {"value": float(tot[0] / tot[1]), "frames": int(tot[1]), "reduced_over_ranks": world}
         except Exception as e:  # informative only
             out["config"]["clip_mean_luma"] = {"error": str(e)}
         del keep
+        # The exchange step on real data: XPSNR's per-clip accumulators over RCCL (all ranks take part)
+        try:
+            if not a.no_others:
+                out["config"]["xpsnr_clip"] = xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev)
+        except Exception as e:
+            out["config"]["xpsnr_clip"] = {"error": str(e)}
+        # PCIe-fed rate at this N: every rank feeds its GPU from pinned host frames at the same time
+        try:
+            if a.no_others:
+                raise KeyboardInterrupt
+            pc = pcie_boxblur(vszip_amd, local_rank, a.radius, barrier=barrier)
+            dt_p = max_over_ranks(pc["seconds"])
+            out["config"]["pcie_fed_fps"] = world * pc["contexts"] * pc["rounds"] / dt_p
+            out["config"]["pcie_fed"] = {"rank0_fps": pc["value"], "rank0_GBps_each_direction": pc["pcie_GBps_each_direction"], "contexts_per_gpu": pc["contexts"],
+                                         "rank0_numa_node": numa_node,
+                                         "note": "pinned host frame -> GPU -> pinned host frame, every rank at once (barrier, then the same number of rounds); "
+                                                 "whole-job frames / max-over-ranks time"}
+        except KeyboardInterrupt:
+            pass
+        except Exception as e:
+            out["config"]["pcie_fed"] = {"error": str(e)}
         if rank == 0 and world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_boxblur()
         if world == 1 and not a.no_others:
@@ -627,7 +822,7 @@ def main() -> int:
                 others[name] = {"value": nf * 10 / dt2, "unit": "frames/s", "kernel_ms_per_frame": kms / (10 * nf),
                                 "roofline": {"bound": "hbm", "achieved": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                             "kernel": "bilateral_truncated_kernel<u16>", "avg_launch_us": dms * 1e3 / nl},
+                                             "kernel": "bilateral_tiled_kernel<u16>", "avg_launch_us": dms * 1e3 / nl},
                                 "workload": f"vszip.Bilateral sigmaS=2 sigmaR=2 {w}x{h} YUV420P16 (natural content tiled), HBM-resident"}
                 if not a.no_cpu:
                     others[name]["cpu_baseline"] = cpu_bilateral(w, h, 5.0 if h < 2000 else 3.0)
@@ -662,9 +857,9 @@ def main() -> int:
             except Exception as e:
                 others["pipeline_8k_rgbs"] = {"error": str(e)}
             try:
-                others["boxblur_4k_pcie"] = pcie_boxblur(vszip_amd, local_rank, a.radius)
-            except Exception as e:  # the PCIe leg is informative only
-                others["boxblur_4k_pcie"] = {"error": str(e)}
+                others["boxblur_1080p"] = boxblur_1080p_leg(dev, timed, a.no_cpu)
+            except Exception as e:
+                others["boxblur_1080p"] = {"error": str(e)}
             out["others"] = others
     elif a.workload == "bilateral":
         step, keep = setup_bilateral(dev, W1080, H1080, F)
@@ -678,7 +873,7 @@ def main() -> int:
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "vszip.Bilateral sigmaS=2 sigmaR=2, 1920x1080 YUV420P16, natural content tiled", "frames_per_step_per_gpu": F},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": "bilateral_truncated_kernel<u16>"}}
+                            "kernel": "bilateral_tiled_kernel<u16>"}}
         if rank == 0 and world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_bilateral(W1080, H1080)
     else:

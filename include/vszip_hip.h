@@ -82,6 +82,8 @@ int vszip_timer_stop_ms(vszip_ctx *ctx, float *ms); /* synchronises */
  * aid for bench.py's roofline (the figure rocprofv3 --kernel-trace reports per kernel). */
 int vszip_probe_enable(vszip_ctx *ctx, int on);
 int vszip_probe_read(vszip_ctx *ctx, double *total_ms, int *launches);
+/* the same, also copying the first `cap` launch durations (ms, launch order) to each_ms */
+int vszip_probe_read_each(vszip_ctx *ctx, double *total_ms, int *launches, float *each_ms, int cap);
 
 /* One plane of one frame. Strides in elements of the sample type. */
 typedef struct vszip_plane {
@@ -211,6 +213,33 @@ int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *planes,
  */
 int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3,
                       ptrdiff_t stride, int w, int h, int npairs, double *scores);
+
+/*
+ * SSIMULACRA2 with its colour pre-stage on the device — additionally replaces, for the clips that
+ * need no resampler, what ssimulacraCreate hangs in front of the kernel on the host:
+ * hz.toRGBS (src/helper.zig:225-243: resize.Bicubic(format=RGBS, matrix_in=709|601)) and
+ * sRGBtoLinearRGB (src/vapoursynth/ssimulacra2.zig:132-162: std.SetFrameProp(_Transfer=13) +
+ * resize.Bicubic(transfer=LINEAR)), i.e. zimg's integer -> float conversion (full range for RGB,
+ * limited for Gray), Gray -> R = G = B, and the sRGB EOTF through zimg's approximate-gamma table
+ * (VapourSynth's resize default). The source planes are uploaded as they are (8/16-bit samples: a
+ * quarter / half of the RGBS bytes), the conversion is fused into the first SSIMULACRA2 pass.
+ *   family     VSZIP_CF_RGB (3 planes per frame) or VSZIP_CF_GRAY (1 plane per frame); YUV needs
+ *              zimg's chroma resampler and matrix and stays with the host's resize;
+ *   dtype/bits VSZIP_U8 (8), VSZIP_U16 (9..16) or VSZIP_F32 (f16 is rejected by the wrapper, :106-113);
+ *   limited    integer samples are limited range (zimg's default for Gray) or full (RGB);
+ *   linearize  0 when frame 0 carries _Transfer == LINEAR (:139-141), else 1.
+ * ref_planes / dis_planes: HOST arrays of npairs * (3 | 1) device plane pointers, same stride (elements).
+ */
+enum { VSZIP_CF_RGB = 0, VSZIP_CF_GRAY = 1 };
+typedef struct vszip_ssim_source {
+    int family, dtype, bits, limited, linearize;
+} vszip_ssim_source;
+int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *fmt, const void *const *ref_planes,
+                          const void *const *dis_planes, ptrdiff_t stride, int w, int h, int npairs, double *scores);
+/* The pre-stage alone: one frame's planes -> linear-light RGBS planes (dst3: R, G, B device pointers).
+ * Asynchronous on the context stream. */
+int vszip_to_rgbs_linear(vszip_ctx *ctx, const vszip_ssim_source *fmt, const void *const *src_planes, ptrdiff_t src_stride,
+                         float *const *dst3, ptrdiff_t dst_stride, int w, int h);
 
 /*
  * EEDI3 / EEDI3H — replaces processPlane (src/vapoursynth/eedi3.zig:26-140) with its kernels

@@ -61,6 +61,8 @@ def _declare(l: C.CDLL) -> None:
     l.vszo_bilateral_plane.restype = i
     l.vszo_ssimulacra2.argtypes = [C.POINTER(vp), C.POINTER(vp), pd, i, i, pdbl, pdbl]
     l.vszo_ssimulacra2.restype = dbl
+    l.vszo_ssim_set_vec.argtypes = [i]
+    l.vszo_ssim_set_vec.restype = i
     l.vszo_ssim_to_xyb.argtypes = [C.POINTER(vp), C.POINTER(vp), i, i]
     l.vszo_ssim_to_xyb.restype = None
     l.vszo_ssim_blur.argtypes = [vp, vp, i, i]
@@ -182,6 +184,11 @@ def ssimulacra2(ref, dis, want_parts: bool = False):
     a = np.zeros((6, 6)); e = np.zeros((6, 12))
     s = lib().vszo_ssimulacra2(_ptr3(ref), _ptr3(dis), w, w, h, a.ctypes.data_as(C.POINTER(C.c_double)), e.ctypes.data_as(C.POINTER(C.c_double)))
     return (s, a, e) if want_parts else s
+
+
+def ssim_set_vec(v: int) -> int:
+    """Test knob: the reference build's vec_size (8: x86_64_v3 / haswell, 16: znver4). Returns the previous value."""
+    return lib().vszo_ssim_set_vec(v)
 
 
 def ssim_to_xyb(rgb):

@@ -22,7 +22,11 @@
 
 namespace {
 
-constexpr int kVec = 8;
+// vec_size of the reference build: 8 for the x86_64_v3 / haswell wheels and the CI build, 16 for the
+// znver4 wheel (hatch_build.py:13-17). A test knob (vszo_ssim_set_vec) measures how far the other
+// build's score moves: tests/test_oracle_goldens.py::test_ssimulacra2_vec_size_sensitivity.
+constexpr int kVecMax = 16;
+static int kVec = 8;
 
 const double kWeight[108] = {
     0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0,
@@ -187,7 +191,7 @@ static void blur(const float* src, float* dst, int w, int h, std::vector<float>&
 }
 
 struct LaneSum {
-    double lane[kVec];
+    double lane[kVecMax];
     double tail;
     LaneSum() : tail(0.0) {
         for (double& l : lane) l = 0.0;
@@ -347,6 +351,11 @@ VSZO_API double vszo_ssimulacra2(const float* const ref[3], const float* const d
 }
 
 // Exposed pieces so the GPU tests can localise a mismatch.
+VSZO_API int vszo_ssim_set_vec(int v) {  // test knob: 8 (default) or 16; returns the previous value
+    const int old = kVec;
+    if (v == 8 || v == 16) kVec = v;
+    return old;
+}
 VSZO_API void vszo_ssim_to_xyb(const float* const src[3], float* const dst[3], int w, int h) { to_xyb(src, dst, w, w, w, h); }
 VSZO_API void vszo_ssim_blur(const float* src, float* dst, int w, int h) {
     std::vector<float> tmp;

@@ -74,3 +74,30 @@ def test_owner_rule_matches_plugin():
         for n in range(50):
             assert cluster.owner_of_frame(n, world) == n % world
             assert n in cluster.frames_of_rank(50, n % world, world)
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus N` must start N ranks itself (round 1: --gpus was parsed and ignored).
+    --dry-launch prints the child command instead of running it; no GPU needed."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["dry_launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(str(ROOT / "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "7", "--warmup", "1"]  # the ranks get the same arguments, minus --dry-launch
+
+
+def test_bench_rejects_world_size_mismatch():
+    """Started by an outer launcher with the wrong number of ranks, bench.py must not print an n_gpus it did not run."""
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""

@@ -1,0 +1,249 @@
+"""Cross-depth and f16/f32 agreement of the HIP kernels — the reference's structural statements about
+its 10/12-bit and half-float paths, for which no golden vector is reachable:
+  * tests/test_int_parity.py:38-56 — the same picture at 8, 10 and 16 bit, outputs normalised by the
+    format's peak, agree within 4 LSB of the lower depth (a hard-coded peak, a 16-bit overflow or a
+    depth-dependent scale would miss by orders of magnitude);
+  * tests/test_f16_parity.py:36-52 — an f16 clip and the byte-identical data widened to f32 give the
+    same result within 1e-3 (about two f16 ulps near 1.0).
+Inputs: the reference's own test crop (8 bit), carried to 10 / 16 bit the way zimg's Point conversion
+of a full-range clip does (round(v * peak / 255): x257 exactly at 16 bit). Through the C ABI."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+DEPTHS = (8, 10, 16)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    yield d
+    d.close()
+
+
+def peak(bits):
+    return (1 << bits) - 1
+
+
+def at_depth(p8: np.ndarray, bits: int) -> np.ndarray:
+    if bits == 8:
+        return np.ascontiguousarray(p8)
+    return np.floor(p8.astype(np.float64) * peak(bits) / 255.0 + 0.5).astype(np.uint16)
+
+
+def planes(bits):
+    return [at_depth(p, bits) for p in fx.crop_rgb24()]
+
+
+def assert_parity(results, lsb=4.0):
+    """results: {bits: [planes]} -> every lower depth against the highest, test_int_parity.py:38-56."""
+    hi = max(results)
+    for bits, outs in results.items():
+        if bits == hi:
+            continue
+        tol = lsb / peak(bits)
+        for i, (a, b) in enumerate(zip(outs, results[hi])):
+            d = np.abs(a.astype(np.float64) / peak(bits) - b.astype(np.float64) / peak(hi)).max()
+            assert d <= tol, f"{bits}-bit vs {hi}-bit, plane {i}: max|dnorm| = {d} > {tol} ({lsb} LSB)"
+
+
+def run_boxblur(dev, ps, **kw):
+    s = [dev.upload(p) for p in ps]
+    d = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in ps]
+    dev.boxblur(s, d, kw.get("hradius", 1), kw.get("hpasses", 1), kw.get("vradius", 1), kw.get("vpasses", 1))
+    return [dev.download(x) for x in d]
+
+
+def run_bilateral(dev, ps, sigmaS, sigmaR, bits=None, refs=None):
+    dt = ps[0].dtype
+    hist = (1 << (bits or 8 * dt.itemsize)) if dt.kind == "u" else 65536
+    cfg = dev.bilateral_cfg([sigmaS], [sigmaR], hist_len=hist)
+    s = [dev.upload(p) for p in ps]
+    d = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in ps]
+    r = [dev.upload(p) for p in refs] if refs is not None else None
+    dev.bilateral(s, d, cfg, [0] * len(ps), r, peak=float(hist - 1))
+    out = [dev.download(x) for x in d]
+    dev.bilateral_free(cfg)
+    return out
+
+
+def run_limiter(dev, ps, lo, hi):
+    s = [dev.upload(p) for p in ps]
+    d = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in ps]
+    dev.limiter(s, d, lo, hi)
+    return [dev.download(x) for x in d]
+
+
+def run_limit_filter(dev, flts, srcs, dark, bright, elast, refs=None):
+    f = [dev.upload(p) for p in flts]
+    s = [dev.upload(p) for p in srcs]
+    r = [dev.upload(p) for p in refs] if refs is not None else None
+    d = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in flts]
+    n = len(flts)
+    dev.limit_filter(f, s, d, [dark] * n, [bright] * n, [elast] * n, r)
+    return [dev.download(x) for x in d]
+
+
+# ---- integer depth parity ---------------------------------------------------------------------
+@pytest.mark.parametrize("args", [dict(hradius=3, vradius=3), dict(hradius=6, vradius=3, hpasses=2, vpasses=2), dict(hradius=13, vradius=13)],
+                         ids=["comptime", "runtime", "r13"])
+def test_int_parity_boxblur(dev, args):
+    """test_int_parity.py:96-110: the reciprocal depends on the radius only."""
+    assert_parity({b: run_boxblur(dev, planes(b), **args) for b in DEPTHS})
+
+
+@pytest.mark.parametrize("sig", [(2, 2), (2, 0.02)], ids=["smooth", "sharp_range"])
+def test_int_parity_bilateral(dev, sig):
+    """test_int_parity.py:73-93: sigmaR is a fraction of the peak taken from the clip's depth. The 10-bit
+    clip runs the kernel variant that keeps its whole 1024-entry range LUT in LDS, the 16-bit one gathers
+    from the 65536-entry table in L2."""
+    assert_parity({b: run_bilateral(dev, planes(b), sig[0], sig[1], bits=b) for b in DEPTHS})
+
+
+def test_int_parity_limiter(dev):
+    """test_int_parity.py:119-147: raw bounds scaled per depth; the tv_range tables 16 / 235 << (bits - 8)."""
+    res, tv = {}, {}
+    for b in DEPTHS:
+        ps = planes(b)
+        res[b] = run_limiter(dev, ps, [round(0.1 * peak(b))] * 3, [round(0.8 * peak(b))] * 3)
+        tv[b] = run_limiter(dev, ps, [16 << (b - 8)] * 3, [235 << (b - 8)] * 3)
+    assert_parity(res)
+    assert_parity(tv)
+
+
+def _limit_filter_at(dev, b, dark, bright, elast, with_ref):
+    src = planes(b)
+    flt = run_boxblur(dev, src, hradius=2, vradius=2)
+    ref = run_boxblur(dev, src, hradius=4, vradius=4) if with_ref else None
+    k = peak(b) / 255.0
+    return run_limit_filter(dev, flt, src, dark * k, bright * k, elast, ref)
+
+
+@pytest.mark.parametrize("dark,bright,elast", [(4, 4, 2), (16, 2, 4), (8, 16, 1.5)])
+def test_int_parity_limit_filter(dev, dark, bright, elast):
+    """test_int_parity.py:150-185: thresholds on the 8-bit scale, carried by peak / 255 (full range)."""
+    assert_parity({b: _limit_filter_at(dev, b, dark, bright, elast, False) for b in DEPTHS})
+
+
+def test_int_parity_limit_filter_ref(dev):
+    """test_int_parity.py:188-197: with a third clip the soft limit amplifies the per-depth blur differences of
+    BOTH flt and ref near the transition (~10 LSB), hence the reference's looser bound of 14 LSB."""
+    assert_parity({b: _limit_filter_at(dev, b, 8, 8, 3, True) for b in DEPTHS}, lsb=14.0)
+
+
+def test_int_parity_plane_average(dev):
+    """test_int_parity.py:262-302: psmAvg / psmDiff are peak-normalised; exclude values scaled per depth."""
+    avg, diff = {}, {}
+    for b in DEPTHS:
+        ps = planes(b)
+        s = [dev.upload(p) for p in ps]
+        r = [dev.upload(p) for p in run_boxblur(dev, ps, hradius=2, vradius=2)]
+        a, _ = dev.plane_average(s, [round(0.5 * peak(b)), round(0.7 * peak(b))], None, bits=b)
+        a2, d = dev.plane_average(s, [-1], r, bits=b)
+        avg[b], diff[b] = a, d
+    for b in (8, 10):
+        tol = 2.0 / peak(b)
+        for i in range(3):
+            assert abs(avg[b][i] - avg[16][i]) <= tol and abs(diff[b][i] - diff[16][i]) <= tol, (b, i, avg[b][i], avg[16][i], diff[b][i], diff[16][i])
+
+
+def test_int_parity_plane_minmax(dev):
+    """test_int_parity.py:330-365: the same threshold fraction selects the same normalised value (4 LSB);
+    psmDiff within 2e-3."""
+    res = {}
+    for b in DEPTHS:
+        ps = planes(b)
+        s = [dev.upload(p) for p in ps]
+        r = [dev.upload(p) for p in run_boxblur(dev, ps, hradius=1, vradius=1)]
+        mn, mx, df = dev.plane_minmax(s, 0.1, 0.1, r, bits=b)
+        res[b] = ([v / peak(b) for v in mn], [v / peak(b) for v in mx], df)
+    for b in (8, 10):
+        for i in range(3):
+            assert abs(res[b][0][i] - res[16][0][i]) <= 4.0 / peak(b)
+            assert abs(res[b][1][i] - res[16][1][i]) <= 4.0 / peak(b)
+            assert abs(res[b][2][i] - res[16][2][i]) <= 2e-3
+
+
+@pytest.mark.parametrize("temporal", [True, False])
+def test_int_parity_xpsnr(dev, temporal):
+    """test_int_parity.py:398-420: the dB score is peak-normalised, 8 vs 10 bit within 0.15 dB."""
+    out = {}
+    for b in (8, 10):
+        sc = []
+        for n in range(3):
+            conv = (lambda p: p) if b == 8 else (lambda p: (p.astype(np.uint16) << 2))
+            y = conv(fx.luma8(fx.temporal_rgb24(n)))
+            c = conv(np.ascontiguousarray(fx.temporal_rgb24(n)[1][::2, ::2]))
+            org = [y, c, c]
+            rec = run_boxblur(dev, org, hradius=2, vradius=2)
+            prv = conv(fx.luma8(fx.temporal_rgb24(n - 1))) if (temporal and n > 0) else None
+            d_org, d_rec = [dev.upload(p) for p in org], [dev.upload(p) for p in rec]
+            w = dev.xpsnr_wsse(d_org, d_rec, dev.upload(prv) if prv is not None else None, None, depth=b, frame_rate=30, temporal=temporal)
+            dims = [(640, 320), (320, 160), (320, 160)]
+            sc.append([10.0 * np.log10(dims[i][0] * dims[i][1] * float(peak(b)) ** 2 / float(w[i])) for i in range(3)])
+        out[b] = sc
+    for n in range(3):
+        for i in range(3):
+            assert abs(out[8][n][i] - out[10][n][i]) <= 0.15, (n, i, out[8][n][i], out[10][n][i])
+
+
+# ---- f16 vs the same data widened to f32 ----------------------------------------------------------
+def f16_pair():
+    h = [np.ascontiguousarray(p.astype(np.float16)) for p in fx.crop_rgbs()]
+    return h, [p.astype(np.float32) for p in h]
+
+
+def assert_f16(out16, out32, tol=1e-3):
+    for i, (a, b) in enumerate(zip(out16, out32)):
+        d = np.abs(a.astype(np.float32) - b).max()
+        assert d <= tol, f"plane {i}: max|f16 - f32| = {d} > {tol}"
+
+
+@pytest.mark.parametrize("args", [dict(hradius=3, vradius=3), dict(hradius=6, vradius=3, hpasses=2, vpasses=2), dict(hradius=30, vradius=30)],
+                         ids=["comptime", "runtime", "r30"])
+def test_f16_parity_boxblur(dev, args):
+    h, s = f16_pair()
+    assert_f16(run_boxblur(dev, h, **args), run_boxblur(dev, s, **args))
+
+
+@pytest.mark.parametrize("sig", [(2, 2), (2, 0.02)])
+def test_f16_parity_bilateral(dev, sig):
+    """test_f16_parity.py:60-90"""
+    h, s = f16_pair()
+    assert_f16(run_bilateral(dev, h, *sig), run_bilateral(dev, s, *sig))
+
+
+def test_f16_parity_bilateral_ref(dev):
+    """test_f16_parity.py:93-112: joint bilateral, ref = vszip.BoxBlur(5) built in f16 and widened."""
+    h, s = f16_pair()
+    r16 = run_boxblur(dev, h, hradius=5, vradius=5)
+    r32 = [p.astype(np.float32) for p in r16]
+    assert_f16(run_bilateral(dev, h, 2, 0.05, refs=r16), run_bilateral(dev, s, 2, 0.05, refs=r32))
+
+
+def test_f16_parity_limiter_and_limit_filter(dev):
+    h, s = f16_pair()
+    assert_f16(run_limiter(dev, h, [0.1] * 3, [0.8] * 3), run_limiter(dev, s, [0.1] * 3, [0.8] * 3))
+    f16 = run_boxblur(dev, h, hradius=2, vradius=2)
+    f32 = [p.astype(np.float32) for p in f16]
+    t = 8.0 / 255.0
+    assert_f16(run_limit_filter(dev, f16, h, t, t, 3.0), run_limit_filter(dev, f32, s, t, t, 3.0))
+
+
+def test_f16_parity_plane_stats(dev):
+    h, s = f16_pair()
+    dh, ds = [dev.upload(p) for p in h], [dev.upload(p) for p in s]
+    r16 = run_boxblur(dev, h, hradius=1, vradius=1)
+    rh, rs = [dev.upload(p) for p in r16], [dev.upload(p.astype(np.float32)) for p in r16]
+    a16, d16 = dev.plane_average(dh, [-1], rh)
+    a32, d32 = dev.plane_average(ds, [-1], rs)
+    m16, m32 = dev.plane_minmax(dh, 0.1, 0.1, rh), dev.plane_minmax(ds, 0.1, 0.1, rs)
+    for i in range(3):
+        assert abs(a16[i] - a32[i]) <= 1e-3 and abs(d16[i] - d32[i]) <= 1e-3
+        for k in range(3):
+            assert abs(m16[k][i] - m32[k][i]) <= 1e-3

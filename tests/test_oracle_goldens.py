@@ -73,6 +73,21 @@ def test_bilateral_soft_gray16(oracle, key, sS, sR, alg, num):
     assert abs(st["min"] - g["min"]) <= 1 and abs(st["max"] - g["max"]) <= 1
 
 
+def test_bilateral_soft_gray16_joint_ref(oracle):
+    """The joint path (`ref` clip, reference tests/test_bilateral.py:40-44: ref = std.BoxBlur(5,5) of the
+    source): GRAY16|full|sigmaR=0.05,sigmaS=2|ref on the approximate GRAY16 fixture."""
+    from oracle import vs_host as vh
+
+    g = fx.ref_goldens()["soft"]["bilateral"]["GRAY16|full|sigmaR=0.05,sigmaS=2|ref"]["p0"]
+    src = np.ascontiguousarray(fx.crop_gray16())
+    prm = oracle.bilateral_params([2], [0.05])
+    out = oracle.bilateral_plane(src, prm["sigmaS"][0], prm["sigmaR"][0], prm["algorithm"][0], prm["radius"][0], prm["step"][0], prm["PBFICnum"][0],
+                                 ref=vh.std_boxblur(src, 5, 5))
+    st = fx.plane_stats(out)
+    assert st["avg"] == pytest.approx(g["avg"], rel=1e-7)
+    assert abs(st["min"] - g["min"]) <= 1 and abs(st["max"] - g["max"]) <= 1
+
+
 # ---- EEDI3 / EEDI3H -----------------------------------------------------------
 def test_eedi3_golden_rgbs(oracle):
     g = fx.ref_goldens()["exact"]["eedi3"]["RGBS|full|field=1"]
@@ -179,6 +194,34 @@ def test_ssimulacra2_identical_is_100(oracle):
     assert oracle.ssimulacra2(c, c) == 100.0
     lin = [_srgb_to_linear(p) for p in fx.crop_rgbs()]
     assert oracle.ssimulacra2(lin, lin) > 99.9
+
+
+def test_ssimulacra2_vec_size_sensitivity(oracle):
+    """The oracle (and the HIP kernels) restate the reference as built with vec_size = 8 (x86_64_v3, the
+    CI build and the haswell wheel); the znver4 wheel has vec_size = 16 (hatch_build.py:13-17), which moves
+    the column where blurV stops fusing and the f64 lane-sum order. Measured on the reference's test crop
+    (RGB24, dist = std.BoxBlur(1,1), score 4.41): 3.5e-5 relative at 640x320 (the 40- and 20-column scales of
+    the pyramid have 8 resp. 4 tail columns under one build and 8 resp. 4 + 0 under the other — the deep scales
+    carry the large weights), 4.8e-5 at 631x313, 7e-8 at 13x7. I.e. the reference's own two wheels disagree
+    by ~4e-5 relative; anything below that is not a parity statement about "the" reference. Bound asserted:
+    1e-4 (the reference's own tolerance is rel=1e-3)."""
+    from oracle import vs_host as vh
+
+    ref8 = [np.ascontiguousarray(p) for p in fx.crop_rgb24()]
+    worst = {}
+    for name, crop in (("640x320", lambda p: p), ("631x313", lambda p: np.ascontiguousarray(p[:313, :631])), ("13x7", lambda p: np.ascontiguousarray(p[100:107, 200:213]))):
+        ref = [crop(p) for p in ref8]
+        lin_r = vh.to_linear_rgbs(ref, "RGB", 8)
+        lin_d = vh.to_linear_rgbs([vh.std_boxblur(p, 1, 1) for p in ref], "RGB", 8)
+        s8 = oracle.ssimulacra2(lin_r, lin_d)
+        try:
+            assert oracle.ssim_set_vec(16) == 8
+            s16 = oracle.ssimulacra2(lin_r, lin_d)
+        finally:
+            oracle.ssim_set_vec(8)
+        worst[name] = abs(s16 - s8) / max(abs(s8), 1e-30)
+    print("SSIMULACRA2 vec_size 8 vs 16, relative score change:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert 0 < max(worst.values()) <= 1e-4
 
 
 # The reference's golden keys for SSIMULACRA2 (RGBS / RGB24 / GRAY8, blur1 / blur3) are pinned in

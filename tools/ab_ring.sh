@@ -15,6 +15,6 @@ for round in $(seq 1 ${ROUNDS:-3}); do
     cp /tmp/ab_$n.so vapoursynth-zip_amd/libvszip_hip.so
     echo -n "[$cfg] "
     if [ $round = 1 ]; then python __graft_entry__.py --smoke 2>&1 | tail -1 | cut -c1-9 | tr '\n' ' '; fi
-    python bench.py --steps 30 --warmup 5 --no-cpu --no-others ${BENCH_ARGS} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'fps', round(d['roofline']['avg_launch_us'],1), 'us/launch', round(d['roofline']['frac'],3))"
+    python bench.py --steps 30 --warmup 5 --no-cpu --no-others ${BENCH_ARGS} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); l=d['roofline'].get('launch_us') or {}; print(round(d['value']), 'fps', round(d['roofline']['avg_launch_us'],1), 'us/launch', round(d['roofline']['frac'],3), '| >=1s sample: min', round(l.get('min',0),1), 'med', round(l.get('median',0),1), 'max', round(l.get('max',0),1), 'frac_med', round(d['roofline'].get('frac_median',0),3))"
   done
 done

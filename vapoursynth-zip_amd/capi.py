@@ -72,6 +72,7 @@ SYMBOLS = {
     "vszip_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "vszip_probe_enable": (_i, [_vp, _i]),
     "vszip_probe_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
+    "vszip_probe_read_each": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_float), _i]),
     "vszip_boxblur": (_i, [_vp, _i, _PP, _i, _i, _i, _i, _i]),
     "vszip_bilateral_derive": (_i, [C.POINTER(C.c_double), _i, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _i, _i,
                                     C.POINTER(C.c_int), C.POINTER(BilateralCfg)]),
@@ -252,6 +253,13 @@ class Device:
         ms, n = C.c_double(), C.c_int()
         self.check(self.lib.vszip_probe_read(self.ctx, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def probe_read_each(self, cap: int = 65536):
+        """(summed ms, launches, [per-launch ms]) — the per-launch durations in launch order."""
+        ms, n = C.c_double(), C.c_int()
+        each = (C.c_float * cap)()
+        self.check(self.lib.vszip_probe_read_each(self.ctx, C.byref(ms), C.byref(n), each, cap))
+        return ms.value, n.value, [each[i] for i in range(min(n.value, cap))]
 
     def timer_stop_ms(self) -> float:
         ms = C.c_float()

@@ -48,12 +48,14 @@ struct vszip_ctx {
         size_t wb, rows;
     };
     std::vector<PendingOut> pending_out;
+    void *ssim_lut = nullptr;  // SSIMULACRA2 colour pre-stage: cached conversion table (ssimulacra2.hip)
     int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
 };
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
 int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes);
 int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
+void vszip_ssim_release(vszip_ctx *ctx);  // frees ctx->ssim_lut
 // Bracket the launch of a filter's dominant kernel; no-ops unless the probe is enabled.
 void vszip_probe_mark(vszip_ctx *ctx);
 struct vszip_probe_scope {

@@ -77,6 +77,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
+    vszip_ssim_release(ctx);
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -259,7 +260,7 @@ VSZIP_EXPORT int vszip_probe_enable(vszip_ctx *ctx, int on) {
     return VSZIP_OK;
 }
 
-VSZIP_EXPORT int vszip_probe_read(vszip_ctx *ctx, double *total_ms, int *launches) {
+VSZIP_EXPORT int vszip_probe_read_each(vszip_ctx *ctx, double *total_ms, int *launches, float *each_ms, int cap) {
     if (!ctx || !total_ms || !launches) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0;
@@ -268,9 +269,14 @@ VSZIP_EXPORT int vszip_probe_read(vszip_ctx *ctx, double *total_ms, int *launche
         float ms = 0;
         VSZIP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->probe_events[2 * i], ctx->probe_events[2 * i + 1]));
         tot += ms;
+        if (each_ms && (int)i < cap) each_ms[i] = ms;
     }
     *total_ms = tot;
     *launches = (int)pairs;
     ctx->probe_used = 0;
     return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_probe_read(vszip_ctx *ctx, double *total_ms, int *launches) {
+    return vszip_probe_read_each(ctx, total_ms, launches, nullptr, 0);
 }

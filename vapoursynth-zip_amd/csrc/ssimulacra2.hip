@@ -1,7 +1,15 @@
 // vszip.SSIMULACRA2 on gfx950: the per-frame kernel of src/filters/ssimulacra2.zig
 // (`process`, :46-136) — two linear-light RGBS frames in, one f64 score out.
 //
-// Per scale s = 0..4 (scale 5 carries only pruned weights, :22-37, and is never built):
+// Scales 0 and 1 (94 % of the samples) come out of ONE pass over the source:
+//   ssim_pyr_kernel       a thread owns a 4x4 block of source samples of both frames: it converts them
+//                         to linear RGB (the colour pre-stage of hz.toRGBS + sRGBtoLinearRGB fused in:
+//                         integer / gamma sources go through a lookup table, see vszip_ssimulacra2_src),
+//                         writes the XYB planes scale 0 needs, box-filters to its 2x2 block of scale 1
+//                         (downscale :138-209) and writes that scale's XYB planes, box-filters once more
+//                         and writes its one sample of scale-2 linear RGB. The source is read once and
+//                         neither scale 0's nor scale 1's linear RGB pyramid ever exists in HBM.
+// Per scale s = 2..4 (scale 5 carries only pruned weights, :22-37, and is never built):
 //   ssim_xyb_down_kernel  reads the linear RGB of both frames at scale s once and writes
 //                         (a) the XYB planes scale s actually needs (toXYB :392-472 with the
 //                         VCL cbrt of src/vcl.zig:40-81) and (b) the 2x2-box-filtered linear
@@ -135,6 +143,166 @@ __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
                 if (xyb[1]) xyb[1][o] = Y;
                 if (need_b) xyb[2][o] = B;
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scales 0 + 1 + the scale-2 RGB in one pass, colour pre-stage included.
+// ---------------------------------------------------------------------------------------------
+enum { PYR_F32_LINEAR = 0, PYR_F32_GAMMA = 1, PYR_INT = 2 };
+
+struct PyrPair {
+    const void *src1[3], *src2[3];  // source planes of the two frames (Gray: [0] only)
+    float *x0a[3], *x0b[3];         // scale-0 XYB planes of frame 1 / 2 (NULL = pruned)
+    float *x1a[3], *x1b[3];         // scale-1 XYB planes
+    float *r2a[3], *r2b[3];         // scale-2 linear RGB
+};
+
+struct PyrArgs {
+    const PyrPair *tab;
+    const float *lut;   // PYR_INT: 2^bits entries indexed by the sample; PYR_F32_GAMMA: the 65537-entry transfer table
+    int lut_lds;        // PYR_INT: number of entries staged in LDS (0: gathered from global memory)
+    int sstride;        // source row pitch, elements
+    int w, h, w1, h1, w2, h2;
+    XybK k;
+};
+
+constexpr int kPyrLdsLut = 4096;  // integer clips up to 12 bit keep their whole table in LDS
+
+template <typename T, int MODE>
+__device__ __forceinline__ float pyr_linear(T v, const float *lut, const float *lds_lut, bool use_lds) {
+    if constexpr (MODE == PYR_F32_LINEAR) {
+        return (float)v;
+    } else if constexpr (MODE == PYR_F32_GAMMA) {
+        // zimg's approximate-gamma table: index rint(x * 32768 + 16384) over [-0.5, 1.5], clamped
+        float t = rintf(fmaf((float)v, 32768.0f, 16384.0f));
+        t = fminf(fmaxf(t, 0.0f), 65536.0f);
+        return lut[(int)t];
+    } else {
+        return use_lds ? lds_lut[(uint32_t)v] : lut[(uint32_t)v];
+    }
+}
+
+template <typename T, int MODE, bool GRAY>
+__global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
+    __shared__ float lds_lut[(MODE == PYR_INT) ? kPyrLdsLut : 1];
+    const bool use_lds = MODE == PYR_INT && a.lut_lds > 0;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < a.lut_lds; i += 256) lds_lut[i] = a.lut[i];
+        __syncthreads();
+    }
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = bx * 4, y0 = by * 4;
+    if (x0 >= a.w || y0 >= a.h) return;
+    const PyrPair pp = a.tab[blockIdx.z];
+    const bool full = x0 + 4 <= a.w && y0 + 4 <= a.h;
+    constexpr int NP = GRAY ? 1 : 3;
+#pragma unroll
+    for (int img = 0; img < 2; ++img) {
+        const void *const *src = img ? pp.src2 : pp.src1;
+        float *const *o0 = img ? pp.x0b : pp.x0a;
+        float *const *o1 = img ? pp.x1b : pp.x1a;
+        float *const *o2 = img ? pp.r2b : pp.r2a;
+        // 4x4 block -> linear RGB. Samples past the right / bottom edge take the edge sample, which is
+        // exactly the clamp of downscale (:186-200): min(2*ox + ix, w - 1).
+        float lin[3][4][4];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const T *pl = static_cast<const T *>(src[c]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T *row = pl + (size_t)min(y0 + r, a.h - 1) * a.sstride;
+                T v[4];
+                if (full && ((reinterpret_cast<uintptr_t>(row + x0) & (sizeof(T) * 4 - 1)) == 0)) {
+                    // one 4 / 8 / 16-byte load, unpacked with shifts (an array of T in a struct goes to scratch)
+                    if constexpr (sizeof(T) == 4) {
+                        const float4 q = *reinterpret_cast<const float4 *>(row + x0);
+                        v[0] = (T)q.x; v[1] = (T)q.y; v[2] = (T)q.z; v[3] = (T)q.w;
+                    } else if constexpr (sizeof(T) == 2) {
+                        const uint2 q = *reinterpret_cast<const uint2 *>(row + x0);
+                        v[0] = (T)(q.x & 0xffffu); v[1] = (T)(q.x >> 16); v[2] = (T)(q.y & 0xffffu); v[3] = (T)(q.y >> 16);
+                    } else {
+                        const uint32_t q = *reinterpret_cast<const uint32_t *>(row + x0);
+                        v[0] = (T)(q & 0xffu); v[1] = (T)((q >> 8) & 0xffu); v[2] = (T)((q >> 16) & 0xffu); v[3] = (T)(q >> 24);
+                    }
+                } else {
+                    v[0] = row[min(x0 + 0, a.w - 1)];
+                    v[1] = row[min(x0 + 1, a.w - 1)];
+                    v[2] = row[min(x0 + 2, a.w - 1)];
+                    v[3] = row[min(x0 + 3, a.w - 1)];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lin[c][r][i] = pyr_linear<T, MODE>(v[i], a.lut, lds_lut, use_lds);
+            }
+        }
+        if constexpr (GRAY) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lin[1][r][i] = lin[2][r][i] = lin[0][r][i];
+        }
+        // scale 0: XYB of the 16 samples
+        {
+            const bool nb = o0[2] != nullptr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (y0 + r >= a.h) break;
+                float X[4], Y[4], B[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    B[i] = 0.0f;
+                    to_xyb_px(a.k, lin[0][r][i], lin[1][r][i], lin[2][r][i], nb, X[i], Y[i], B[i]);
+                }
+                const size_t o = (size_t)(y0 + r) * a.w + x0;
+                const bool vec = full && (a.w & 3) == 0;
+                auto put = [&](float *pl, float v0, float v1, float v2, float v3) {
+                    if (!pl) return;
+                    if (vec) {
+                        *reinterpret_cast<float4 *>(pl + o) = make_float4(v0, v1, v2, v3);
+                    } else {
+                        pl[o] = v0;
+                        if (x0 + 1 < a.w) pl[o + 1] = v1;
+                        if (x0 + 2 < a.w) pl[o + 2] = v2;
+                        if (x0 + 3 < a.w) pl[o + 3] = v3;
+                    }
+                };
+                put(o0[0], X[0], X[1], X[2], X[3]);
+                put(o0[1], Y[0], Y[1], Y[2], Y[3]);
+                put(o0[2], B[0], B[1], B[2], B[3]);
+            }
+        }
+        // scale 1: 2x2 box of linear RGB, summed ((a+b)+c)+d (:186-200), then XYB
+        float l1[3][2][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    l1[c][j][i] = (((lin[c][2 * j][2 * i] + lin[c][2 * j][2 * i + 1]) + lin[c][2 * j + 1][2 * i]) + lin[c][2 * j + 1][2 * i + 1]) * 0.25f;
+        {
+            const bool nb = o1[2] != nullptr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int x = 2 * bx + i, y = 2 * by + j;
+                    if (x >= a.w1 || y >= a.h1) continue;
+                    float X, Y, B = 0.0f;
+                    to_xyb_px(a.k, l1[0][j][i], l1[1][j][i], l1[2][j][i], nb, X, Y, B);
+                    const size_t o = (size_t)y * a.w1 + x;
+                    if (o1[0]) o1[0][o] = X;
+                    if (o1[1]) o1[1][o] = Y;
+                    if (nb) o1[2][o] = B;
+                }
+        }
+        // scale 2: one sample; a missing scale-1 column / row takes its neighbour (the same clamp one level up)
+        if (bx < a.w2 && by < a.h2) {
+            const int i1 = (2 * bx + 1 < a.w1) ? 1 : 0, j1 = (2 * by + 1 < a.h1) ? 1 : 0;
+            const size_t o = (size_t)by * a.w2 + bx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o2[c][o] = (((l1[c][0][0] + l1[c][0][i1]) + l1[c][j1][0]) + l1[c][j1][i1]) * 0.25f;
+        }
     }
 }
 
@@ -518,32 +686,138 @@ double score_of(const double avg[18][6]) {  // ssimulacra2.zig:630-663; slot = s
 
 }  // namespace
 
-// Scratch per pair (floats): XYB planes of one scale (6 * w * h) + two RGB pyramids that
-// ping-pong (scale s+1 is written while scale s is read): 2 * 6 * (w/2+1)*(h/2+1).
-VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3, ptrdiff_t stride, int w, int h, int npairs, double *scores) {
-    if (!ctx || !ref3 || !dis3 || !scores || npairs <= 0 || w <= 0 || h <= 0) return VSZIP_ERR_ARG;
-    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    static const XybK kx = make_xyb_consts();
-    const size_t n0 = (size_t)w * h;
-    const int w1 = (w + 1) / 2, h1 = (h + 1) / 2;
-    const size_t n1 = (size_t)w1 * h1;
-    const int tiles0 = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
-    const size_t f_xyb = 6 * n0, f_pyrA = 6 * n1, f_pyrB = 6 * (((size_t)(w1 + 1) / 2) * ((h1 + 1) / 2));
-    const size_t f_pair = (f_xyb + f_pyrA + f_pyrB + 63) & ~(size_t)63;
-    const size_t bytes_part = ((size_t)npairs * 18 * tiles0 * 6 * sizeof(double) + 255) & ~(size_t)255;
-    const size_t bytes_avg = ((size_t)npairs * 18 * 6 * sizeof(double) + 255) & ~(size_t)255;
-    const size_t bytes_tab = ((size_t)kScales * npairs * sizeof(PairPtrs) + 255) & ~(size_t)255;
-    const size_t need = bytes_part + bytes_avg + bytes_tab + (size_t)npairs * f_pair * sizeof(float) + 1024;
-    int rc = vszip_ensure_scratch(ctx, need);
-    if (rc != VSZIP_OK) return rc;
-    rc = vszip_ensure_scalars(ctx, std::max(bytes_avg, bytes_tab));
-    if (rc != VSZIP_OK) return rc;
-    char *base = static_cast<char *>(ctx->scratch);
-    double *partial = reinterpret_cast<double *>(base);
-    PairPtrs *tab_dev = reinterpret_cast<PairPtrs *>(base + bytes_part + bytes_avg);
-    float *fbase = reinterpret_cast<float *>(base + bytes_part + bytes_avg + bytes_tab);
+// zimg's sRGB EOTF (constants of its colorspace/gamma.cpp) evaluated in f64, rounded to f32 — the entries of
+// its approximate-gamma table (VapourSynth's resize default approximate_gamma=1): 2^16 + 1 samples over
+// [-0.5, 1.5]. Restated from the published algorithm; pinned by the reference's SSIMULACRA2 goldens
+// (oracle/vs_host.py, tests/test_oracle_vs_host.py).
+static float srgb_eotf_f32(float xf) {
+    const double A = 1.055010718947587, B = 0.003041282560128;
+    const double x = (double)xf;
+    return (float)(x < 12.92 * B ? x / 12.92 : std::pow((std::max(x, 0.0) + (A - 1.0)) / A, 2.4));
+}
+static const std::vector<float> &srgb_table() {
+    static const std::vector<float> t = [] {
+        std::vector<float> v(65537);
+        for (int i = 0; i < 65537; ++i) v[i] = srgb_eotf_f32((float)i / 65536.0f * 2.0f - 0.5f);
+        return v;
+    }();
+    return t;
+}
+static float srgb_lookup(float x) {
+    float t = std::nearbyintf(x * 32768.0f + 16384.0f);
+    t = std::min(std::max(t, 0.0f), 65536.0f);
+    return srgb_table()[(int)t];
+}
 
-    // geometry of every scale + the plane pointers of every (scale, pair)
+namespace {
+
+struct SsimLutKey {
+    int mode, bits, limited, linearize;
+    bool operator==(const SsimLutKey &o) const { return mode == o.mode && bits == o.bits && limited == o.limited && linearize == o.linearize; }
+};
+
+// Device copy of the conversion table of one source format, cached in the context (a clip has one format).
+struct SsimLutCache {
+    SsimLutKey key{-1, 0, 0, 0};
+    float *dev = nullptr;
+    size_t entries = 0;
+};
+
+SsimLutCache *lut_cache_of(vszip_ctx *ctx) {
+    if (!ctx->ssim_lut) ctx->ssim_lut = new SsimLutCache();
+    return static_cast<SsimLutCache *>(ctx->ssim_lut);
+}
+
+template <typename T, int MODE>
+void launch_pyr(bool gray, dim3 grid, hipStream_t st, const PyrArgs &pa) {
+    if (gray)
+        hipLaunchKernelGGL((ssim_pyr_kernel<T, MODE, true>), grid, dim3(256), 0, st, pa);
+    else
+        hipLaunchKernelGGL((ssim_pyr_kernel<T, MODE, false>), grid, dim3(256), 0, st, pa);
+}
+
+}  // namespace
+
+void vszip_ssim_release(vszip_ctx *ctx) {
+    if (!ctx->ssim_lut) return;
+    SsimLutCache *c = static_cast<SsimLutCache *>(ctx->ssim_lut);
+    if (c->dev) (void)hipFree(c->dev);
+    delete c;
+    ctx->ssim_lut = nullptr;
+}
+
+// Validates the source format and makes its conversion table resident (cached in the context).
+static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_out, bool *gray_out, const float **lut_out, int *lds_out) {
+    const bool gray = fmt->family == VSZIP_CF_GRAY;
+    *gray_out = gray;
+    if (fmt->family != VSZIP_CF_RGB && !gray) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "SSIMULACRA2: colour family %d has no device pre-stage", fmt->family);
+    int &mode = *mode_out;
+    if (fmt->dtype == VSZIP_F32) {
+        mode = fmt->linearize ? PYR_F32_GAMMA : PYR_F32_LINEAR;
+    } else if (fmt->dtype == VSZIP_U8 || fmt->dtype == VSZIP_U16) {
+        mode = PYR_INT;
+        if (fmt->bits < 8 || fmt->bits > (fmt->dtype == VSZIP_U8 ? 8 : 16)) return vszip_set_error(ctx, VSZIP_ERR_ARG, "SSIMULACRA2: %d-bit samples in this container", fmt->bits);
+    } else {
+        return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "SSIMULACRA2: sample type %d", fmt->dtype);  // f16 is rejected by the wrapper (:106-113)
+    }
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+
+    // conversion table of this source format
+    const float *&lut_dev = *lut_out;
+    int &lut_lds = *lds_out;
+    lut_dev = nullptr;
+    lut_lds = 0;
+    if (mode != PYR_F32_LINEAR) {
+        SsimLutCache *lc = lut_cache_of(ctx);
+        const SsimLutKey key{mode, fmt->bits, fmt->limited, fmt->linearize};
+        if (!(lc->key == key)) {
+            std::vector<float> host;
+            if (mode == PYR_F32_GAMMA) {
+                host = srgb_table();
+            } else {
+                // zimg integer -> float: (v - offset) * f32(1 / range); then the transfer table
+                const int off = fmt->limited ? (16 << (fmt->bits - 8)) : 0;
+                const int rng = fmt->limited ? (219 << (fmt->bits - 8)) : ((1 << fmt->bits) - 1);
+                const float sc = (float)(1.0 / rng);
+                host.resize((size_t)1 << fmt->bits);
+                for (size_t v = 0; v < host.size(); ++v) {
+                    const float x = ((float)v - (float)off) * sc;
+                    host[v] = fmt->linearize ? srgb_lookup(x) : x;
+                }
+            }
+            if (lc->entries < host.size()) {
+                VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                if (lc->dev) (void)hipFree(lc->dev);
+                lc->dev = nullptr;
+                lc->entries = 0;
+                VSZIP_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&lc->dev), host.size() * sizeof(float)));
+                lc->entries = host.size();
+            }
+            VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a launch still reading the old table
+            VSZIP_HIP_CHECK(ctx, hipMemcpy(lc->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+            lc->key = key;
+        }
+        lut_dev = lc->dev;
+        if (mode == PYR_INT && ((size_t)1 << fmt->bits) <= (size_t)kPyrLdsLut) lut_lds = 1 << fmt->bits;
+    }
+
+    return VSZIP_OK;
+}
+
+// Scratch per pair (floats): the XYB planes scales 0 and 1 need (2 n0 + 4 n1: Y of scale 0; X, Y of
+// scale 1), the scale-2 linear RGB (6 n2), the XYB planes of one later scale at a time (6 n2) and the RGB
+// of scales 3 / 4 (6 n3 + 6 n4) — 130 MB per 4K pair.
+VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *fmt, const void *const *ref_planes, const void *const *dis_planes,
+                                       ptrdiff_t stride, int w, int h, int npairs, double *scores) {
+    if (!ctx || !fmt || !ref_planes || !dis_planes || !scores || npairs <= 0 || w <= 0 || h <= 0) return VSZIP_ERR_ARG;
+    int mode, lut_lds;
+    bool gray;
+    const float *lut_dev;
+    int rc = ssim_prepare(ctx, fmt, &mode, &gray, &lut_dev, &lut_lds);
+    if (rc != VSZIP_OK) return rc;
+    const int nsp = gray ? 1 : 3;
+    static const XybK kx = make_xyb_consts();
+
     int sw[kScales + 1], sh[kScales + 1];
     sw[0] = w;
     sh[0] = h;
@@ -551,33 +825,100 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
         sw[s] = (sw[s - 1] + 1) / 2;
         sh[s] = (sh[s - 1] + 1) / 2;
     }
-    // staged in the pinned buffer (the final kernel overwrites it with the averages, later in stream order)
+    size_t npx[kScales + 1];
+    for (int s = 0; s <= kScales; ++s) npx[s] = (size_t)sw[s] * sh[s];
+    int nneed[kScales];  // XYB planes a scale keeps
+    for (int s = 0; s < kScales; ++s) {
+        nneed[s] = 0;
+        for (int c = 0; c < 3; ++c) nneed[s] += skip_of(c, s).all() ? 0 : 1;
+    }
+    const int tiles0 = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
+    const size_t f_x0 = 2 * nneed[0] * npx[0], f_x1 = 2 * nneed[1] * npx[1], f_r2 = 6 * npx[2], f_xs = 6 * npx[2], f_r3 = 6 * npx[3], f_r4 = 6 * npx[4];
+    const size_t f_pair = (f_x0 + f_x1 + f_r2 + f_xs + f_r3 + f_r4 + 63) & ~(size_t)63;
+    const size_t bytes_part = ((size_t)npairs * 18 * tiles0 * 6 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t bytes_avg = ((size_t)npairs * 18 * 6 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t bytes_tab = ((size_t)kScales * npairs * sizeof(PairPtrs) + 255) & ~(size_t)255;
+    const size_t bytes_pyr = ((size_t)npairs * sizeof(PyrPair) + 255) & ~(size_t)255;
+    const size_t need = bytes_part + bytes_avg + bytes_tab + bytes_pyr + (size_t)npairs * f_pair * sizeof(float) + 1024;
+    rc = vszip_ensure_scratch(ctx, need);
+    if (rc != VSZIP_OK) return rc;
+    rc = vszip_ensure_scalars(ctx, std::max(bytes_avg, bytes_tab + bytes_pyr));
+    if (rc != VSZIP_OK) return rc;
+    char *base = static_cast<char *>(ctx->scratch);
+    double *partial = reinterpret_cast<double *>(base);
+    PairPtrs *tab_dev = reinterpret_cast<PairPtrs *>(base + bytes_part + bytes_avg);
+    PyrPair *pyr_dev = reinterpret_cast<PyrPair *>(base + bytes_part + bytes_avg + bytes_tab);
+    float *fbase = reinterpret_cast<float *>(base + bytes_part + bytes_avg + bytes_tab + bytes_pyr);
+
+    // plane pointers of every (scale, pair), staged in the pinned buffer (the final kernel overwrites it with the
+    // averages, later in stream order)
     PairPtrs *tab = static_cast<PairPtrs *>(ctx->scalars_host);
+    PyrPair *pyr = reinterpret_cast<PyrPair *>(static_cast<char *>(ctx->scalars_host) + bytes_tab);
+    std::memset(tab, 0, bytes_tab + bytes_pyr);
     for (int pair = 0; pair < npairs; ++pair) {
-        float *fxyb = fbase + (size_t)pair * f_pair;
-        float *pyrA = fxyb + f_xyb;   // scales 1, 3
-        float *pyrB = pyrA + f_pyrA;  // scales 2, 4
-        const float *cur1[3] = {ref3[pair * 3 + 0], ref3[pair * 3 + 1], ref3[pair * 3 + 2]};
-        const float *cur2[3] = {dis3[pair * 3 + 0], dis3[pair * 3 + 1], dis3[pair * 3 + 2]};
+        float *x0 = fbase + (size_t)pair * f_pair, *x1 = x0 + f_x0, *r2 = x1 + f_x1, *xs = r2 + f_r2, *r3 = xs + f_xs, *r4 = r3 + f_r3;
+        PyrPair &py = pyr[pair];
+        for (int c = 0; c < nsp; ++c) {
+            py.src1[c] = ref_planes[pair * nsp + c];
+            py.src2[c] = dis_planes[pair * nsp + c];
+        }
         for (int scale = 0; scale < kScales; ++scale) {
             PairPtrs &pp = tab[(size_t)scale * npairs + pair];
-            const size_t n = (size_t)sw[scale] * sh[scale], nn = (size_t)sw[scale + 1] * sh[scale + 1];
-            float *pyr = (scale & 1) ? pyrB : pyrA;
-            const bool last = scale == kScales - 1;
+            int k = 0;
             for (int c = 0; c < 3; ++c) {
-                pp.rgb1[c] = cur1[c];
-                pp.rgb2[c] = cur2[c];
                 const bool need_plane = !skip_of(c, scale).all();
-                pp.xyb1[c] = need_plane ? fxyb + (size_t)c * n : nullptr;
-                pp.xyb2[c] = need_plane ? fxyb + (size_t)(3 + c) * n : nullptr;
-                pp.next1[c] = last ? nullptr : pyr + (size_t)c * nn;
-                pp.next2[c] = last ? nullptr : pyr + (size_t)(3 + c) * nn;
-                cur1[c] = pp.next1[c];
-                cur2[c] = pp.next2[c];
+                float *xa = nullptr, *xb = nullptr;
+                if (need_plane) {
+                    float *xbase = scale == 0 ? x0 : (scale == 1 ? x1 : xs);
+                    xa = xbase + (size_t)k * npx[scale];
+                    xb = xbase + (size_t)(nneed[scale] + k) * npx[scale];
+                    ++k;
+                }
+                pp.xyb1[c] = xa;
+                pp.xyb2[c] = xb;
+                if (scale == 0) { py.x0a[c] = xa; py.x0b[c] = xb; }
+                if (scale == 1) { py.x1a[c] = xa; py.x1b[c] = xb; }
+                if (scale >= 2) {
+                    const float *cur = scale == 2 ? r2 : (scale == 3 ? r3 : r4);
+                    pp.rgb1[c] = cur + (size_t)c * npx[scale];
+                    pp.rgb2[c] = cur + (size_t)(3 + c) * npx[scale];
+                    float *nxt = scale == 2 ? r3 : (scale == 3 ? r4 : nullptr);
+                    pp.next1[c] = nxt ? nxt + (size_t)c * npx[scale + 1] : nullptr;
+                    pp.next2[c] = nxt ? nxt + (size_t)(3 + c) * npx[scale + 1] : nullptr;
+                }
             }
         }
+        for (int c = 0; c < 3; ++c) {
+            py.r2a[c] = r2 + (size_t)c * npx[2];
+            py.r2b[c] = r2 + (size_t)(3 + c) * npx[2];
+        }
     }
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab, (size_t)kScales * npairs * sizeof(PairPtrs), hipMemcpyHostToDevice, ctx->stream));
+    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab, bytes_tab + bytes_pyr, hipMemcpyHostToDevice, ctx->stream));
+
+    // scales 0 + 1 + the scale-2 RGB: one pass over the source
+    {
+        PyrArgs pa;
+        pa.tab = pyr_dev;
+        pa.lut = lut_dev;
+        pa.lut_lds = lut_lds;
+        pa.sstride = (int)stride;
+        pa.w = w;
+        pa.h = h;
+        pa.w1 = sw[1];
+        pa.h1 = sh[1];
+        pa.w2 = sw[2];
+        pa.h2 = sh[2];
+        pa.k = kx;
+        const dim3 grid((w + 255) / 256, (h + 15) / 16, npairs);
+        if (mode == PYR_F32_LINEAR)
+            launch_pyr<float, PYR_F32_LINEAR>(gray, grid, ctx->stream, pa);
+        else if (mode == PYR_F32_GAMMA)
+            launch_pyr<float, PYR_F32_GAMMA>(gray, grid, ctx->stream, pa);
+        else if (fmt->dtype == VSZIP_U8)
+            launch_pyr<uint8_t, PYR_INT>(gray, grid, ctx->stream, pa);
+        else
+            launch_pyr<uint16_t, PYR_INT>(gray, grid, ctx->stream, pa);
+    }
 
     FinalArgs fin;
     fin.partial = partial;
@@ -590,19 +931,21 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
     }
     for (int scale = 0; scale < kScales; ++scale) {
         const int cw = sw[scale], ch = sh[scale], nw = sw[scale + 1], nh = sh[scale + 1];
-        XybArgs xa;
-        xa.tab = tab_dev + (size_t)scale * npairs;
-        xa.stride = scale == 0 ? (int)stride : cw;
-        xa.w = cw;
-        xa.h = ch;
-        xa.nstride = nw;
-        xa.nw = nw;
-        xa.nh = nh;
-        xa.xstride = cw;
-        xa.k = kx;
-        hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, npairs), dim3(256), 0, ctx->stream, xa);
+        if (scale >= 2) {
+            XybArgs xa;
+            xa.tab = tab_dev + (size_t)scale * npairs;
+            xa.stride = cw;
+            xa.w = cw;
+            xa.h = ch;
+            xa.nstride = nw;
+            xa.nw = nw;
+            xa.nh = nh;
+            xa.xstride = cw;
+            xa.k = kx;
+            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, npairs), dim3(256), 0, ctx->stream, xa);
+        }
         MapsArgs ma;
-        ma.tab = xa.tab;
+        ma.tab = tab_dev + (size_t)scale * npairs;
         ma.nactive = 0;
         for (int c = 0; c < 3; ++c) {
             const Skip sk = skip_of(c, scale);
@@ -633,5 +976,61 @@ VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, con
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
     for (int pair = 0; pair < npairs; ++pair) scores[pair] = score_of(avg[pair]);
+    return VSZIP_OK;
+}
+
+// Linear-light RGBS in (the kernel contract of the reference, :46): the pre-stage is the identity.
+VSZIP_EXPORT int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *const *dis3, ptrdiff_t stride, int w, int h, int npairs, double *scores) {
+    const vszip_ssim_source fmt = {VSZIP_CF_RGB, VSZIP_F32, 32, 0, 0};
+    return vszip_ssimulacra2_src(ctx, &fmt, reinterpret_cast<const void *const *>(ref3), reinterpret_cast<const void *const *>(dis3), stride, w, h, npairs, scores);
+}
+
+// The pre-stage alone (hz.toRGBS + sRGBtoLinearRGB of one clip's frame): what the score is computed from, as
+// planes — for hosts that want the converted frame (the reference's output clip is the converted reference
+// clip, src/vapoursynth/ssimulacra2.zig:53) and for the tests.
+namespace {
+template <typename T, int MODE, bool GRAY>
+__global__ __launch_bounds__(256) void to_rgbs_kernel(const void *s0, const void *s1, const void *s2, float *d0, float *d1, float *d2, int sstride, int dstride, int w, int h,
+                                                      const float *lut) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const void *src[3] = {s0, s1, s2};
+    float *dst[3] = {d0, d1, d2};
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < (GRAY ? 1 : 3); ++c) v[c] = pyr_linear<T, MODE>(static_cast<const T *>(src[c])[(size_t)y * sstride + x], lut, nullptr, false);
+    if (GRAY) v[1] = v[2] = v[0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[c][(size_t)y * dstride + x] = v[c];
+}
+}  // namespace
+
+VSZIP_EXPORT int vszip_to_rgbs_linear(vszip_ctx *ctx, const vszip_ssim_source *fmt, const void *const *src_planes, ptrdiff_t src_stride, float *const *dst3, ptrdiff_t dst_stride,
+                                      int w, int h) {
+    if (!ctx || !fmt || !src_planes || !dst3 || w <= 0 || h <= 0) return VSZIP_ERR_ARG;
+    int mode, lut_lds;
+    bool gray;
+    const float *lut;
+    const int rc = ssim_prepare(ctx, fmt, &mode, &gray, &lut, &lut_lds);
+    if (rc != VSZIP_OK) return rc;
+    const dim3 grid((w + 255) / 256, h);
+    const void *s0 = src_planes[0], *s1 = gray ? nullptr : src_planes[1], *s2 = gray ? nullptr : src_planes[2];
+#define VSZIP_TO_RGBS(T, MODE)                                                                                                                              \
+    do {                                                                                                                                                    \
+        if (gray)                                                                                                                                           \
+            hipLaunchKernelGGL((to_rgbs_kernel<T, MODE, true>), grid, dim3(256), 0, ctx->stream, s0, s1, s2, dst3[0], dst3[1], dst3[2], (int)src_stride, (int)dst_stride, w, h, lut); \
+        else                                                                                                                                                \
+            hipLaunchKernelGGL((to_rgbs_kernel<T, MODE, false>), grid, dim3(256), 0, ctx->stream, s0, s1, s2, dst3[0], dst3[1], dst3[2], (int)src_stride, (int)dst_stride, w, h, lut); \
+    } while (0)
+    if (mode == PYR_F32_LINEAR)
+        VSZIP_TO_RGBS(float, PYR_F32_LINEAR);
+    else if (mode == PYR_F32_GAMMA)
+        VSZIP_TO_RGBS(float, PYR_F32_GAMMA);
+    else if (fmt->dtype == VSZIP_U8)
+        VSZIP_TO_RGBS(uint8_t, PYR_INT);
+    else
+        VSZIP_TO_RGBS(uint16_t, PYR_INT);
+#undef VSZIP_TO_RGBS
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
