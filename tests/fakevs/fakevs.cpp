@@ -769,6 +769,98 @@ static void VS_CC standin_point(const VSMap *in, VSMap *out, void *, VSCore *cor
     node_unref(n);
 }
 
+// resize.Bicubic as SSIMULACRA2's wrapper uses it (hz.toRGBS: format=RGBS, matrix_in=...; sRGBtoLinearRGB:
+// transfer=8 on a clip tagged _Transfer=13) and std.SetFrameProp(prop, intval) — for RGB / Gray clips only,
+// where zimg needs no resampler: integer -> float (full range for RGB, limited for Gray, _ColorRange
+// overrides), Gray -> R = G = B, and the sRGB EOTF through the approximate-gamma table. The same
+// restatement as oracle/vs_host.py (pinned there by the reference's goldens); TEST INFRASTRUCTURE.
+static const std::vector<float> &standin_srgb_table() {
+    static const std::vector<float> t = [] {
+        std::vector<float> v(65537);
+        const double A = 1.055010718947587, B = 0.003041282560128;
+        for (int i = 0; i < 65537; ++i) {
+            const double x = (double)((float)i / 65536.0f * 2.0f - 0.5f);
+            v[i] = (float)(x < 12.92 * B ? x / 12.92 : std::pow((std::max(x, 0.0) + (A - 1.0)) / A, 2.4));
+        }
+        return v;
+    }();
+    return t;
+}
+
+static void VS_CC standin_set_frame_prop(const VSMap *in, VSMap *out, void *, VSCore *, const VSAPI *) {
+    int err = 0;
+    VSNode *src = A(mapGetNode)(in, "clip", 0, &err);
+    const char *prop = A(mapGetData)(in, "prop", 0, &err);
+    const int64_t val = A(mapGetInt)(in, "intval", 0, &err);
+    VSNode *n = eager_clone(src, &src->vi.format);
+    for (int i = 0; i < src->vi.numFrames; ++i) {
+        char e[256];
+        const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+        VSFrame *c = A(copyFrame)(f, &g_core);
+        frame_unref(f);
+        A(mapSetInt)(&c->props, prop, val, maReplace);
+        n->frames.push_back(c);
+    }
+    g_standin_log.push_back(std::string("std.SetFrameProp ") + prop + "=" + std::to_string(val));
+    node_unref(src);
+    A(mapSetNode)(out, "clip", n, maReplace);
+    node_unref(n);
+}
+
+static void VS_CC standin_bicubic(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *) {
+    int err = 0, e_fmt = 0, e_tr = 0;
+    VSNode *src = A(mapGetNode)(in, "clip", 0, &err);
+    const int64_t id = A(mapGetInt)(in, "format", 0, &e_fmt);
+    const int64_t transfer = A(mapGetInt)(in, "transfer", 0, &e_tr);
+    const VSVideoFormat &sf = src->vi.format;
+    VSVideoFormat fmt = sf;
+    if (!e_fmt) A(getVideoFormatByID)(&fmt, (uint32_t)id, core);
+    const bool to_rgbs = !e_fmt && fmt.colorFamily == cfRGB && fmt.sampleType == stFloat && fmt.bytesPerSample == 4;
+    const bool lin = !e_tr && transfer == 8;
+    if ((sf.colorFamily != cfRGB && sf.colorFamily != cfGray) || sf.subSamplingW || sf.subSamplingH || (!to_rgbs && !lin) || (lin && !to_rgbs && !(sf.colorFamily == cfRGB && sf.sampleType == stFloat))) {
+        A(mapSetError)(out, "resize: stand-in converts RGB / Gray clips to RGBS and RGBS to linear light only");
+        node_unref(src);
+        return;
+    }
+    g_standin_log.push_back(std::string("resize.Bicubic") + (to_rgbs ? " format=RGBS" : "") + (lin ? " transfer=8" : ""));
+    VSNode *n = eager_clone(src, &fmt);
+    const std::vector<float> &tab = standin_srgb_table();
+    for (int i = 0; i < src->vi.numFrames; ++i) {
+        char e[256];
+        const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+        VSFrame *c = frame_new(&fmt, src->vi.width, src->vi.height);
+        map_copy(&f->props, &c->props);
+        int pe = 0;
+        const int64_t range = A(mapGetInt)(&f->props, "_ColorRange", 0, &pe);
+        const bool limited = sf.sampleType == stInteger && (pe ? sf.colorFamily == cfGray : range == 1);
+        const int b = sf.bitsPerSample;
+        const float off = limited ? (float)(16 << (b - 8)) : 0.0f;
+        const float sc = sf.sampleType == stInteger ? (float)(1.0 / (limited ? (219 << (b - 8)) : ((1 << b) - 1))) : 1.0f;
+        for (int p = 0; p < 3; ++p) {
+            const int sp = sf.colorFamily == cfGray ? 0 : p;
+            for (int y = 0; y < c->h; ++y) {
+                float *row = reinterpret_cast<float *>(c->ptr[p] + (ptrdiff_t)y * c->stride[p]);
+                for (int x = 0; x < c->w; ++x) {
+                    float v = (float)sample_at(f, sp, x, y);
+                    if (sf.sampleType == stInteger) v = (v - off) * sc;
+                    if (lin) {
+                        float t = std::nearbyintf(v * 32768.0f + 16384.0f);
+                        t = std::min(std::max(t, 0.0f), 65536.0f);
+                        v = tab[(size_t)t];
+                    }
+                    row[x] = v;
+                }
+            }
+        }
+        if (lin) A(mapSetInt)(&c->props, "_Transfer", 8, maReplace);
+        frame_unref(f);
+        n->frames.push_back(c);
+    }
+    node_unref(src);
+    A(mapSetNode)(out, "clip", n, maReplace);
+    node_unref(n);
+}
+
 DRV void fakevs_enable_core_standins(int on) {
     auto &pl = g_core.plugins;
     for (size_t i = 0; i < pl.size();)
@@ -782,11 +874,13 @@ DRV void fakevs_enable_core_standins(int on) {
     st->id = "com.vapoursynth.std";
     st->ns = "std";
     st->funcs["SetFrameProps"] = Func{"clip:vnode;any", "clip:vnode;", standin_set_frame_props, nullptr};
+    st->funcs["SetFrameProp"] = Func{"clip:vnode;prop:data;intval:int[]:opt;", "clip:vnode;", standin_set_frame_prop, nullptr};
     pl.push_back(std::move(st));
     auto rs = std::make_unique<VSPlugin>();
     rs->id = "com.vapoursynth.resize";
     rs->ns = "resize";
     rs->funcs["Point"] = Func{"clip:vnode;format:int:opt;dither_type:data:opt;", "clip:vnode;", standin_point, nullptr};
+    rs->funcs["Bicubic"] = Func{"clip:vnode;format:int:opt;matrix_in:int:opt;transfer:int:opt;", "clip:vnode;", standin_bicubic, nullptr};
     pl.push_back(std::move(rs));
 }
 DRV int fakevs_standin_log(int i, char *buf, int len) {

@@ -524,3 +524,75 @@ print("gate ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "gate ok" in r.stdout, r.stdout + r.stderr
+
+
+def _ssim_prestage_case(oracle):
+    from oracle import vs_host as vh
+
+    ref8 = [np.ascontiguousarray(p[:160, :256]) for p in fx.crop_rgb24()]
+    dis8 = [vh.std_boxblur(p, 1, 1) for p in ref8]
+    g8 = np.ascontiguousarray(fx.crop_gray8()[:160, :256])
+    want_rgb = oracle.ssimulacra2(vh.to_linear_rgbs(ref8, "RGB", 8), vh.to_linear_rgbs(dis8, "RGB", 8))
+    want_gray = oracle.ssimulacra2(vh.to_linear_rgbs([g8], "GRAY", 8), vh.to_linear_rgbs([vh.std_boxblur(g8, 3, 3)], "GRAY", 8))
+    return ref8, dis8, g8, want_rgb, want_gray
+
+
+def test_ssimulacra2_device_colour_prestage(oracle):
+    """RGB24 / Gray8 / gamma RGBS clips go to the GPU as they are; hz.toRGBS + sRGBtoLinearRGB
+    (src/helper.zig:225-243, src/vapoursynth/ssimulacra2.zig:132-162) run fused into the first SSIMULACRA2 pass.
+    The OUTPUT clip is still the host-converted reference (ssimulacra2.zig:53), here through the test host's
+    resize / std stand-ins (the same restatement as oracle/vs_host.py)."""
+    from oracle import vs_host as vh
+
+    ref8, dis8, g8, want_rgb, want_gray = _ssim_prestage_case(oracle)
+    vs.core_standins(True)
+    try:
+        a, b = vs.source([ref8], vs.RGB24), vs.source([dis8], vs.RGB24)
+        out = a.vszip.SSIMULACRA2(b)
+        f = out.get_frame(0)
+        assert f.props["SSIMULACRA2"] == pytest.approx(want_rgb, abs=1e-7)
+        assert out.format_id == vs.RGBS
+        lin = vh.to_linear_rgbs(ref8, "RGB", 8)
+        for p in range(3):
+            assert np.array_equal(np.asarray(f[p]).view(np.uint32), lin[p].view(np.uint32))
+        # only the reference went through the host's resize (format + transfer); the distorted clip never did
+        log = vs.standin_log()
+        assert sum("resize.Bicubic" in l for l in log) == 2, log
+        # Gray: limited range, R = G = B
+        ga, gb = vs.source([[g8]], vs.GRAY8), vs.source([[vh.std_boxblur(g8, 3, 3)]], vs.GRAY8)
+        assert ga.vszip.SSIMULACRA2(gb).get_frame(0).props["SSIMULACRA2"] == pytest.approx(want_gray, abs=1e-7)
+        # mixed formats: RGB24 reference against a gamma RGBS distorted clip (converted on the device one by one)
+        dis_f = [(p.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float32) for p in dis8]
+        c = vs.source([dis_f], vs.RGBS)
+        assert a.vszip.SSIMULACRA2(c).get_frame(0).props["SSIMULACRA2"] == pytest.approx(want_rgb, abs=1e-7)
+        # a distorted clip that is already linear needs no pre-stage at all
+        d = vs.source([vh.to_linear_rgbs(dis8, "RGB", 8)], vs.RGBS, props={"_Transfer": 8})
+        assert a.vszip.SSIMULACRA2(d).get_frame(0).props["SSIMULACRA2"] == pytest.approx(want_rgb, abs=1e-7)
+    finally:
+        vs.core_standins(False)
+
+
+def test_ssimulacra2_host_colour_switch(oracle, tmp_path):
+    """VSZIP_SSIM_HOST_COLOR=1 keeps the whole conversion on the host (the round-1 path): same score."""
+    import subprocess
+    import sys
+    import textwrap
+
+    ref8, dis8, _, want_rgb, _ = _ssim_prestage_case(oracle)
+    np.save(tmp_path / "ref.npy", np.stack(ref8))
+    np.save(tmp_path / "dis.npy", np.stack(dis8))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {str(vs.ROOT)!r}); sys.path.insert(0, {str(vs.ROOT / 'tests')!r})
+        from fakevs import fakevs as vs
+        vs.core_standins(True)
+        ref, dis = np.load({str(tmp_path / 'ref.npy')!r}), np.load({str(tmp_path / 'dis.npy')!r})
+        a, b = vs.source([list(ref)], vs.RGB24), vs.source([list(dis)], vs.RGB24)
+        print(repr(a.vszip.SSIMULACRA2(b).get_frame(0).props["SSIMULACRA2"]), sum("resize.Bicubic" in l for l in vs.standin_log()))
+    """)
+    import os
+
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, VSZIP_SSIM_HOST_COLOR="1"), timeout=600)
+    assert r.returncode == 0, r.stderr
+    score, nconv = r.stdout.strip().split()
+    assert float(score) == pytest.approx(want_rgb, abs=1e-7) and int(nconv) == 4  # both clips: format + transfer on the host

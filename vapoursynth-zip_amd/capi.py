@@ -42,6 +42,14 @@ class BilateralCfg(C.Structure):
     ]
 
 
+class SsimSource(C.Structure):
+    """vszip_ssim_source: family (0 RGB, 1 Gray), dtype, bits, limited, linearize."""
+    _fields_ = [("family", C.c_int32), ("dtype", C.c_int32), ("bits", C.c_int32), ("limited", C.c_int32), ("linearize", C.c_int32)]
+
+
+CF_RGB, CF_GRAY = 0, 1
+
+
 class Eedi3Params(C.Structure):
     _fields_ = [("dh", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float), ("nrad", C.c_int32), ("mdis", C.c_int32),
                 ("hp", C.c_int32), ("vcheck", C.c_int32), ("vthresh0", C.c_float), ("vthresh1", C.c_float), ("vthresh2", C.c_float)]
@@ -79,6 +87,8 @@ SYMBOLS = {
     "vszip_bilateral_luts": (_i, [_vp, C.POINTER(BilateralCfg), _i]),
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
     "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
+    "vszip_ssimulacra2_src": (_i, [_vp, C.POINTER(SsimSource), C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
+    "vszip_to_rgbs_linear": (_i, [_vp, C.POINTER(SsimSource), C.POINTER(_vp), _pd, C.POINTER(_vp), _pd, _i, _i]),
     "vszip_eedi3": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
     "vszip_eedi3_mclip": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
     "vszip_xpsnr_wsse": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_pd), _i, _i, C.c_uint, _i,
@@ -371,6 +381,38 @@ class Device:
         p0 = ref_planes[0]
         self.check(self.lib.vszip_ssimulacra2(self.ctx, r, d, p0.stride, p0.w, p0.h, n, out))
         return list(out)
+
+    @staticmethod
+    def ssim_source(family: str, dtype, bits=None, linearize=True, limited=None) -> SsimSource:
+        """family "RGB" | "GRAY"; integer samples: full range for RGB, limited for Gray (zimg's defaults) unless given."""
+        dt = np.dtype(dtype)
+        fam = CF_GRAY if family.upper() == "GRAY" else CF_RGB
+        b = bits if bits is not None else (32 if dt.kind == "f" else 8 * dt.itemsize)
+        lim = (fam == CF_GRAY) if limited is None else bool(limited)
+        return SsimSource(fam, _NP2DT[dt], b, int(lim and dt.kind != "f"), int(bool(linearize)))
+
+    def ssimulacra2_src(self, fmt: SsimSource, ref_planes, dis_planes):
+        """SSIMULACRA2 with the colour pre-stage on the device: ref_planes / dis_planes are flat lists of
+        npairs * (3 | 1) source DevPlanes in the clip's own sample type. -> scores[npairs]"""
+        per = 1 if fmt.family == CF_GRAY else 3
+        n = len(ref_planes) // per
+        r = (C.c_void_p * (per * n))(*[p.ptr for p in ref_planes])
+        d = (C.c_void_p * (per * n))(*[p.ptr for p in dis_planes])
+        out = (C.c_double * n)()
+        p0 = ref_planes[0]
+        self.check(self.lib.vszip_ssimulacra2_src(self.ctx, C.byref(fmt), r, d, p0.stride, p0.w, p0.h, n, out))
+        return list(out)
+
+    def to_rgbs_linear(self, fmt: SsimSource, planes):
+        """One frame's source planes -> [R, G, B] linear-light f32 DevPlanes (hz.toRGBS + sRGBtoLinearRGB)."""
+        p0 = planes[0]
+        dst = [self.empty(p0.h, p0.w, np.float32) for _ in range(3)]
+        per = 1 if fmt.family == CF_GRAY else 3
+        s = (C.c_void_p * per)(*[p.ptr for p in planes[:per]])
+        d = (C.c_void_p * 3)(*[p.ptr for p in dst])
+        self.check(self.lib.vszip_to_rgbs_linear(self.ctx, C.byref(fmt), s, p0.stride, d, dst[0].stride, p0.w, p0.h))
+        self.sync()
+        return dst
 
     def eedi3(self, srcs, field, dh=False, alpha=0.2, beta=0.25, gamma=20.0, nrad=2, mdis=20, hp=False, vcheck=2,
               vthresh0=32.0, vthresh1=64.0, vthresh2=4.0, sclips=None, horizontal=False, mclips=None):

@@ -183,6 +183,19 @@ __device__ __forceinline__ float pyr_linear(T v, const float *lut, const float *
     }
 }
 
+// four adjacent samples of one plane row: one 16-byte store, or the `left` (< 4) samples inside the plane
+__device__ __forceinline__ void pyr_put4(float *pl, size_t o, bool vec, int left, float v0, float v1, float v2, float v3) {
+    if (!pl) return;
+    if (vec) {
+        *reinterpret_cast<float4 *>(pl + o) = make_float4(v0, v1, v2, v3);
+    } else {
+        pl[o] = v0;
+        if (left > 1) pl[o + 1] = v1;
+        if (left > 2) pl[o + 2] = v2;
+        if (left > 3) pl[o + 3] = v3;
+    }
+}
+
 template <typename T, int MODE, bool GRAY>
 __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
     __shared__ float lds_lut[(MODE == PYR_INT) ? kPyrLdsLut : 1];
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
     const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int x0 = bx * 4, y0 = by * 4;
     if (x0 >= a.w || y0 >= a.h) return;
-    const PyrPair pp = a.tab[blockIdx.z];
+    const PyrPair &pp = a.tab[blockIdx.z];  // (a reference: a local copy indexed by `img` would be promoted to LDS)
     const bool full = x0 + 4 <= a.w && y0 + 4 <= a.h;
     constexpr int NP = GRAY ? 1 : 3;
 #pragma unroll
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
             const bool nb = o0[2] != nullptr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (y0 + r >= a.h) break;
+                if (y0 + r >= a.h) continue;  // (no break: the loop must stay fully unrolled, or `lin` leaves the registers)
                 float X[4], Y[4], B[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -255,20 +268,9 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
                 }
                 const size_t o = (size_t)(y0 + r) * a.w + x0;
                 const bool vec = full && (a.w & 3) == 0;
-                auto put = [&](float *pl, float v0, float v1, float v2, float v3) {
-                    if (!pl) return;
-                    if (vec) {
-                        *reinterpret_cast<float4 *>(pl + o) = make_float4(v0, v1, v2, v3);
-                    } else {
-                        pl[o] = v0;
-                        if (x0 + 1 < a.w) pl[o + 1] = v1;
-                        if (x0 + 2 < a.w) pl[o + 2] = v2;
-                        if (x0 + 3 < a.w) pl[o + 3] = v3;
-                    }
-                };
-                put(o0[0], X[0], X[1], X[2], X[3]);
-                put(o0[1], Y[0], Y[1], Y[2], Y[3]);
-                put(o0[2], B[0], B[1], B[2], B[3]);
+                pyr_put4(o0[0], o, vec, a.w - x0, X[0], X[1], X[2], X[3]);
+                pyr_put4(o0[1], o, vec, a.w - x0, Y[0], Y[1], Y[2], Y[3]);
+                pyr_put4(o0[2], o, vec, a.w - x0, B[0], B[1], B[2], B[3]);
             }
         }
         // scale 1: 2x2 box of linear RGB, summed ((a+b)+c)+d (:186-200), then XYB
@@ -298,10 +300,16 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
         }
         // scale 2: one sample; a missing scale-1 column / row takes its neighbour (the same clamp one level up)
         if (bx < a.w2 && by < a.h2) {
-            const int i1 = (2 * bx + 1 < a.w1) ? 1 : 0, j1 = (2 * by + 1 < a.h1) ? 1 : 0;
+            const bool i1 = 2 * bx + 1 < a.w1, j1 = 2 * by + 1 < a.h1;
             const size_t o = (size_t)by * a.w2 + bx;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o2[c][o] = (((l1[c][0][0] + l1[c][0][i1]) + l1[c][j1][0]) + l1[c][j1][i1]) * 0.25f;
+            for (int c = 0; c < 3; ++c) {
+                // selects, not l1[c][j1][i1]: a runtime index would move the array out of the registers
+                const float p00 = l1[c][0][0], p01 = i1 ? l1[c][0][1] : l1[c][0][0];
+                const float p10 = j1 ? l1[c][1][0] : l1[c][0][0];
+                const float p11 = j1 ? (i1 ? l1[c][1][1] : l1[c][1][0]) : p01;
+                o2[c][o] = (((p00 + p01) + p10) + p11) * 0.25f;
+            }
         }
     }
 }

@@ -772,7 +772,13 @@ void VS_CC planeMinMaxCreate(const VSMap *in, VSMap *out, void *, VSCore *core, 
 // SSIMULACRA2 — src/vapoursynth/ssimulacra2.zig
 // ===========================================================================
 struct SsimData {
-    VSNode *node1, *node2;
+    VSNode *node1, *node2;  // the linear-light RGBS clips the reference's filter is built on (host-converted where needed)
+    // Colour pre-stage on the device (vszip_ssimulacra2_src): the clip as the user passed it, when its format
+    // needs no resampler (RGB / Gray, 8..16-bit integer or f32). node1 stays the source of the OUTPUT frame
+    // (the reference returns the converted reference clip, src/vapoursynth/ssimulacra2.zig:53) and of the
+    // distorted planes when that clip is not eligible.
+    VSNode *raw1 = nullptr, *raw2 = nullptr;
+    vszip_ssim_source fmt1{}, fmt2{};
 };
 
 // ---------------------------------------------------------------------------
@@ -1252,37 +1258,119 @@ VSNode *to_linear_rgbs(const Z &z, VSNode *node, VSMap *out, bool *ok) {
     return node;
 }
 
+// Can the device pre-stage take this clip as it is? RGB / Gray, integer 8..16 bit or f32, constant format.
+// Range and transfer come from frame 0 like the reference's own probe (ssimulacra2.zig:134-141): _Transfer ==
+// LINEAR skips the EOTF; _ColorRange overrides zimg's defaults (RGB full, Gray limited).
+bool ssim_device_source(const Z &z, VSNode *node, vszip_ssim_source *fmt) {
+    static const bool host_color = [] { const char *e = getenv("VSZIP_SSIM_HOST_COLOR"); return e && atoi(e) != 0; }();
+    if (host_color) return false;
+    const VSAPI *api = z.api;
+    const VSVideoInfo *vi = api->getVideoInfo(node);
+    const VSVideoFormat &f = vi->format;
+    if (!is_constant_format(vi)) return false;
+    if (f.colorFamily != cfRGB && f.colorFamily != cfGray) return false;
+    if (f.subSamplingW || f.subSamplingH) return false;
+    int dt;
+    if (f.sampleType == stInteger && f.bitsPerSample >= 8 && f.bitsPerSample <= 16)
+        dt = f.bytesPerSample == 1 ? VSZIP_U8 : VSZIP_U16;
+    else if (f.sampleType == stFloat && f.bitsPerSample == 32)
+        dt = VSZIP_F32;
+    else
+        return false;
+    char err[256];
+    const VSFrame *f0 = api->getFrame(0, node, err, sizeof err);
+    if (!f0) return false;
+    int e1 = 0, e2 = 0;
+    const VSMap *props = api->getFramePropertiesRO(f0);
+    const int64_t transfer = api->mapGetInt(props, "_Transfer", 0, &e1);
+    const int64_t range = api->mapGetInt(props, "_ColorRange", 0, &e2);
+    api->freeFrame(f0);
+    fmt->family = f.colorFamily == cfGray ? VSZIP_CF_GRAY : VSZIP_CF_RGB;
+    fmt->dtype = dt;
+    fmt->bits = f.bitsPerSample;
+    fmt->limited = dt == VSZIP_F32 ? 0 : (e2 ? (f.colorFamily == cfGray ? 1 : 0) : (range == 1 ? 1 : 0));
+    fmt->linearize = (!e1 && transfer == 8) ? 0 : 1;
+    return true;
+}
+
 const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<SsimData *>(inst);
     Z z{api, core, fctx};
     if (reason == arInitial) {
         api->requestFrameFilter(n, d->node1, fctx);
-        api->requestFrameFilter(n, d->node2, fctx);
+        if (d->raw1) api->requestFrameFilter(n, d->raw1, fctx);
+        api->requestFrameFilter(n, d->raw2 ? d->raw2 : d->node2, fctx);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx), *s2 = api->getFrameFilter(n, d->node2, fctx);
+        const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx);
+        const VSFrame *r1 = d->raw1 ? api->getFrameFilter(n, d->raw1, fctx) : nullptr;
+        const VSFrame *s2 = api->getFrameFilter(n, d->raw2 ? d->raw2 : d->node2, fctx);
         VSFrame *dst = api->copyFrame(s1, core);
         auto done = [&](const VSFrame *r) {
             api->freeFrame(s1);
+            if (r1) api->freeFrame(r1);
             api->freeFrame(s2);
             return r;
         };
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, "SSIMULACRA2", "no MI355X device available (the plugin has no CPU fallback)"));
-        // all six planes at one common pitch
         const int w = api->getFrameWidth(s1, 0), h = api->getFrameHeight(s1, 0);
-        const size_t pitch = ((size_t)w * 4 + 255) & ~(size_t)255;
-        const float *r3[3], *d3[3];
-        for (int p = 0; p < 3; ++p) {
-            void *a = g->alloc(pitch * h), *b = g->alloc(pitch * h);
-            if (!a || !b || vszip_copy_h2d_2d(g->ctx, a, pitch, api->getReadPtr(s1, p), (size_t)api->getStride(s1, p), (size_t)w * 4, h) != VSZIP_OK ||
-                vszip_copy_h2d_2d(g->ctx, b, pitch, api->getReadPtr(s2, p), (size_t)api->getStride(s2, p), (size_t)w * 4, h) != VSZIP_OK)
-                return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
-            r3[p] = static_cast<const float *>(a);
-            d3[p] = static_cast<const float *>(b);
-        }
+        // one clip's planes at one common pitch (elements), as they are
+        auto stage = [&](const VSFrame *f, int nplanes, int bps, const void **out, ptrdiff_t *stride) {
+            const size_t pitch = ((size_t)w * bps + 255) & ~(size_t)255;
+            *stride = (ptrdiff_t)(pitch / bps);
+            for (int p = 0; p < nplanes; ++p) {
+                void *a = g->alloc(pitch * h);
+                if (!a || vszip_copy_h2d_2d(g->ctx, a, pitch, api->getReadPtr(f, p), (size_t)api->getStride(f, p), (size_t)w * bps, h) != VSZIP_OK) return false;
+                out[p] = a;
+            }
+            return true;
+        };
+        auto bps_of = [](const vszip_ssim_source &f) { return f.dtype == VSZIP_U8 ? 1 : (f.dtype == VSZIP_U16 ? 2 : 4); };
+        auto same = [](const vszip_ssim_source &a, const vszip_ssim_source &b) {
+            return a.family == b.family && a.dtype == b.dtype && a.bits == b.bits && a.limited == b.limited && a.linearize == b.linearize;
+        };
         double score = 0;
-        if (vszip_ssimulacra2(g->ctx, r3, d3, (ptrdiff_t)(pitch / 4), w, h, 1, &score) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "GPU kernel failed"));
+        int rc;
+        if (d->raw1 && d->raw2 && same(d->fmt1, d->fmt2)) {
+            // both clips in one source format: the conversion is fused into the first SSIMULACRA2 pass
+            const int np = d->fmt1.family == VSZIP_CF_GRAY ? 1 : 3;
+            const void *a3[3], *b3[3];
+            ptrdiff_t st1, st2;
+            if (!stage(r1, np, bps_of(d->fmt1), a3, &st1) || !stage(s2, np, bps_of(d->fmt2), b3, &st2)) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+            rc = vszip_ssimulacra2_src(g->ctx, &d->fmt1, a3, b3, st1, w, h, 1, &score);
+        } else {
+            // mixed formats: convert what can be converted on the device, upload the host's RGBS for the rest
+            const float *lin[2][3];
+            ptrdiff_t lstride = 0;
+            for (int k = 0; k < 2; ++k) {
+                const VSFrame *f = k ? s2 : (r1 ? r1 : s1);
+                const bool raw = k ? d->raw2 != nullptr : d->raw1 != nullptr;
+                const vszip_ssim_source &fm = k ? d->fmt2 : d->fmt1;
+                if (!raw) {
+                    const void *p3[3];
+                    ptrdiff_t st;
+                    if (!stage(f, 3, 4, p3, &st)) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+                    for (int p = 0; p < 3; ++p) lin[k][p] = static_cast<const float *>(p3[p]);
+                    lstride = st;
+                } else {
+                    const void *p3[3];
+                    ptrdiff_t st;
+                    float *o3[3];
+                    const size_t pitch = ((size_t)w * 4 + 255) & ~(size_t)255;
+                    if (!stage(f, fm.family == VSZIP_CF_GRAY ? 1 : 3, bps_of(fm), p3, &st)) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+                    for (int p = 0; p < 3; ++p) {
+                        o3[p] = static_cast<float *>(g->alloc(pitch * h));
+                        if (!o3[p]) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+                        lin[k][p] = o3[p];
+                    }
+                    lstride = (ptrdiff_t)(pitch / 4);
+                    if (vszip_to_rgbs_linear(g->ctx, &fm, p3, st, o3, lstride, w, h) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "colour pre-stage failed"));
+                }
+            }
+            rc = vszip_ssimulacra2(g->ctx, lin[0], lin[1], lstride, w, h, 1, &score);
+        }
+        if (rc != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "GPU kernel failed"));
         api->mapSetFloat(api->getFramePropertiesRW(dst), "SSIMULACRA2", score, maReplace);
         return done(dst);
     }
@@ -1293,6 +1381,8 @@ void VS_CC ssimFree(void *inst, VSCore *, const VSAPI *api) {
     auto *d = static_cast<SsimData *>(inst);
     api->freeNode(d->node1);
     api->freeNode(d->node2);
+    if (d->raw1) api->freeNode(d->raw1);
+    if (d->raw2) api->freeNode(d->raw2);
     delete d;
 }
 
@@ -1313,17 +1403,28 @@ void VS_CC ssimCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const V
         api->freeNode(d.node2);
         return;
     }
+    // The device pre-stage works on the clips as passed in. A clip that is already linear-light RGBS needs
+    // none (the host path below returns it unchanged, so it is what gets uploaded anyway).
+    auto is_linear_rgbs = [&](VSNode *nd, const vszip_ssim_source &f) { (void)nd; return f.family == VSZIP_CF_RGB && f.dtype == VSZIP_F32 && !f.linearize; };
+    if (ssim_device_source(z, d.node1, &d.fmt1) && !is_linear_rgbs(d.node1, d.fmt1)) d.raw1 = api->addNodeRef(d.node1);
+    if (ssim_device_source(z, d.node2, &d.fmt2) && !is_linear_rgbs(d.node2, d.fmt2)) d.raw2 = api->addNodeRef(d.node2);
     bool ok = true;
-    d.node1 = to_linear_rgbs(z, d.node1, out, &ok);
-    if (ok) d.node2 = to_linear_rgbs(z, d.node2, out, &ok);
+    d.node1 = to_linear_rgbs(z, d.node1, out, &ok);  // the output clip, and the score's input when raw1 is not set
+    if (ok && !d.raw2) d.node2 = to_linear_rgbs(z, d.node2, out, &ok);
     if (!ok) {
         if (d.node1) api->freeNode(d.node1);
         if (d.node2) api->freeNode(d.node2);
+        if (d.raw1) api->freeNode(d.raw1);
+        if (d.raw2) api->freeNode(d.raw2);
         return;
     }
     auto *data = new SsimData(d);
-    VSFilterDependency deps[] = {{d.node1, rpStrictSpatial}, {d.node2, rpStrictSpatial}};
-    api->createVideoFilter(out, "SSIMULACRA2", api->getVideoInfo(d.node1), ssimGetFrame, ssimFree, fmParallel, deps, 2, data, core);
+    VSFilterDependency deps[3];
+    int nd = 0;
+    deps[nd++] = {d.node1, rpStrictSpatial};
+    if (d.raw1) deps[nd++] = {d.raw1, rpStrictSpatial};
+    deps[nd++] = {d.raw2 ? d.raw2 : d.node2, rpStrictSpatial};
+    api->createVideoFilter(out, "SSIMULACRA2", api->getVideoInfo(d.node1), ssimGetFrame, ssimFree, fmParallel, deps, nd, data, core);
 }
 
 // ===========================================================================
