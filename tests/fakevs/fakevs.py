@@ -10,8 +10,11 @@ import numpy as np
 
 _DIR = Path(__file__).resolve().parent
 ROOT = _DIR.parents[1]
-LIB = _DIR / "libfakevs.so"
-PLUGIN = ROOT / "vapoursynth-zip_amd" / "libvszip.so"
+import os as _os
+
+# tests/test_sanitizers.py points these at the ASan/UBSan builds of tests/sanitize/_build
+LIB = Path(_os.environ.get("VSZIP_FAKEVS_LIB", _DIR / "libfakevs.so"))
+PLUGIN = Path(_os.environ.get("VSZIP_PLUGIN_LIB", ROOT / "vapoursynth-zip_amd" / "libvszip.so"))
 
 GRAY, RGB, YUV = 1, 2, 3
 INTEGER, FLOAT = 0, 1
@@ -46,7 +49,8 @@ def lib():
     if _lib is None:
         from vszip_amd.capi import _share_torch_hip_runtime
 
-        _share_torch_hip_runtime()  # one HIP runtime per process (see capi.py)
+        if "VSZIP_PLUGIN_LIB" not in _os.environ:  # (the sanitizer build links a GPU-less stub)
+            _share_torch_hip_runtime()  # one HIP runtime per process (see capi.py)
         l = C.CDLL(str(LIB))
         vp, i, i64 = C.c_void_p, C.c_int, C.c_int64
         l.fakevs_load_plugin.argtypes = [C.c_char_p, C.c_char_p, i]

@@ -1,0 +1,113 @@
+"""CPU-side sanitizer runs (the reference's CI builds Zig Debug = bounds/overflow checked,
+.github/workflows/test.yml:27): the plugin (1.8 k lines of C++ with manual freeFrame / freeNode on every error
+path), the test host and the oracle under AddressSanitizer + UndefinedBehaviorSanitizer. libvszip.so links a
+GPU-less stand-in for libvszip_hip.so (tests/sanitize/stub_hip.cpp: real allocations and copies in host memory,
+every filter entry point touches the extents of the planes it is handed and then fails), so staging, error and
+unwind paths run without a GPU. No GPU sanitizer exists on this pool; these are CPU builds only."""
+import os
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+SAN = ROOT / "tests" / "sanitize"
+
+
+def _runtime(name):
+    p = subprocess.run(["g++", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+    return p if p and os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.fixture(scope="module")
+def san_env():
+    asan = _runtime("libasan.so")
+    if not asan:
+        pytest.skip("g++ has no libasan")
+    r = subprocess.run(["make", "-C", str(SAN)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(["make", "-C", str(ROOT / "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1:exitcode=98",
+               VSZIP_FAKEVS_LIB=str(SAN / "_build" / "libfakevs.so"), VSZIP_PLUGIN_LIB=str(SAN / "_build" / "libvszip.so"),
+               VSZIP_ORACLE_LIB=str(ROOT / "oracle" / "_asan" / "liboracle_vszip.so"), PYTHONMALLOC="malloc")
+    return env
+
+
+def _clean(r):
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out and r.returncode not in (98, 99), out[-4000:]
+
+
+def test_plugin_boundary_suite_under_asan(san_env):
+    """tests/test_plugin_boundary.py (registration, create-time validation, error strings: the reference's
+    validation tests) against the instrumented plugin + host."""
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_plugin_boundary.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=san_env, cwd=str(ROOT), timeout=900)
+    _clean(r)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+
+
+SCENARIO = textwrap.dedent("""
+    import sys, numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+    from fakevs import fakevs as vs
+    rng = np.random.default_rng(0)
+    def yuv(dt, w=134, h=96, n=3, hi=255):
+        shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+        return [[(rng.random(s) * hi).astype(dt) for s in shapes] for _ in range(n)]
+    c8 = vs.source(yuv(np.uint8), vs.YUV420P8)
+    c16 = vs.source(yuv(np.uint16, hi=65535), vs.YUV420P16, extra_stride=24, offset=8)   # cropped-clip layout: pitch > width
+    cf = vs.source(yuv(np.float32, hi=1.0), vs.YUV420PS)
+    rgb = vs.source([[(rng.random((96, 134)) * 255).astype(np.uint8) for _ in range(3)] for _ in range(2)], vs.RGB24)
+    rgbs = vs.source([[rng.random((96, 134)).astype(np.float32) for _ in range(3)] for _ in range(2)], vs.RGBS, props={{"_Transfer": 8}})
+    g8 = vs.source([[(rng.random((96, 134)) * 255).astype(np.uint8)] for _ in range(2)], vs.GRAY8)
+    gs = vs.source([[rng.random((96, 134)).astype(np.float32)] for _ in range(2)], vs.GRAYS)
+    vs.core_standins(True)
+    clips = [
+        c16.vszip.BoxBlur(hradius=13, vradius=13), c8.vszip.BoxBlur(hradius=3, vradius=5, hpasses=2, planes=[0, 2]),
+        c16.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0), c16.vszip.Bilateral(ref=c16, sigmaS=3.0, sigmaR=0.02, planes=[0]),
+        c8.vszip.PlaneAverage(exclude=[-1]), c8.vszip.PlaneAverage(exclude=[3, 4], clipb=c8), c16.vszip.PlaneMinMax(minthr=0.1, maxthr=0.1, clipb=c16),
+        c8.vszip.XPSNR(c8), c8.vszip.XPSNR(c8, temporal=False), rgbs.vszip.SSIMULACRA2(rgbs), rgb.vszip.SSIMULACRA2(rgb), g8.vszip.SSIMULACRA2(g8),
+        rgb.vszip.SSIMULACRA2(rgbs), cf.vszip.EEDI3(field=1, dh=True), cf.vszip.EEDI3H(field=0), gs.vszip.EEDI3(field=1, sclip=gs, mclip=g8, vcheck=3),
+        c16.vszip.Limiter(tv_range=True), c16.vszip.LimitFilter(c16, dark_thr=8.0), c16.vszip.LimitFilter(c16, c16, elast=3.0), g8.vszip.AdaptiveBinarize(g8, c=3),
+    ]
+    failed = 0
+    for c in clips:
+        for n in range(2):
+            try:
+                c.get_frame(n)
+            except vs.Error as e:
+                failed += 1
+                assert any(s in str(e) for s in ("GPU kernel failed", "device staging failed", "LUT upload failed", "colour pre-stage failed")), str(e)
+    assert failed == 2 * len(clips), failed
+    # worker threads pulling frames at once (fmParallel): every frame fails, nothing may be touched after release
+    try:
+        clips[0].pull(12, 4)
+    except vs.Error:
+        pass
+    print("scenario ok", failed)
+""")
+
+
+@pytest.mark.parametrize("mode", ["kernel", "alloc", "copy"])
+def test_error_and_unwind_paths_under_asan(san_env, mode):
+    """Every filter's getFrame through staging, a failing kernel / allocation / copy, and the release of every
+    frame and device pointer it held."""
+    env = dict(san_env)
+    if mode != "kernel":
+        env["VSZIP_STUB_FAIL"] = mode
+    r = subprocess.run([sys.executable, "-c", SCENARIO.format(root=str(ROOT), tests=str(ROOT / "tests"))], capture_output=True, text=True, env=env, timeout=900)
+    _clean(r)
+    assert r.returncode == 0 and "scenario ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_oracle_under_asan(san_env):
+    """The CPU oracle (2 k lines of pointer arithmetic) on its golden tests, instrumented."""
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_oracle_goldens.py"), str(ROOT / "tests" / "test_oracle_boxblur.py"), "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", "not exhaustive and not closed_forms"], capture_output=True, text=True, env=san_env, cwd=str(ROOT), timeout=1800)
+    _clean(r)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

@@ -45,7 +45,7 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
     stamp = OBJ / "flags.txt"
     if not stamp.is_file() or stamp.read_text() != " ".join(flags):
         force = True
-    srcs = sorted(CSRC.glob("*.hip"))
+    srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.cpp"))  # *.cpp: device-free host code (also built by tests/sanitize)
     hdrs = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list((PKG.parent / "include").glob("*.h"))
     jobs = []
     for s in srcs:

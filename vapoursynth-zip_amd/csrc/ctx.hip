@@ -105,6 +105,7 @@ static void flush_pending_out(vszip_ctx *ctx);
 
 VSZIP_EXPORT int vszip_ctx_sync(vszip_ctx *ctx) {
     if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->staging == 1) flush_pending_out(ctx);
     return VSZIP_OK;
@@ -112,6 +113,7 @@ VSZIP_EXPORT int vszip_ctx_sync(vszip_ctx *ctx) {
 
 VSZIP_EXPORT int vszip_ctx_abort(vszip_ctx *ctx) {
     if (!ctx) return VSZIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pending_out.clear();  // the caller is about to release the destinations
     ctx->stage_used = 0;
@@ -139,6 +141,7 @@ VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
 
 VSZIP_EXPORT int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
     if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     VSZIP_HIP_CHECK(ctx, hipFree(dptr));
     return VSZIP_OK;
 }
@@ -151,6 +154,7 @@ VSZIP_EXPORT int vszip_dev_memset(vszip_ctx *ctx, void *dptr, int value, size_t 
 
 VSZIP_EXPORT int vszip_host_alloc_pinned(vszip_ctx *ctx, size_t bytes, void **hptr) {
     if (!ctx || !hptr) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     return VSZIP_OK;
 }
@@ -202,6 +206,9 @@ static int stage_take(vszip_ctx *ctx, size_t bytes, char **out) {
 static int copy2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wb, size_t rows, hipMemcpyKind kind) {
     if (!ctx) return VSZIP_ERR_ARG;
     if (wb == 0 || rows == 0) return VSZIP_OK;
+    // The calling thread's current device may be another one: the plugin picks the GPU per frame index and a
+    // worker thread serves frames of every GPU (pinned allocations and event/stream calls follow the current device).
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->staging == 1 && kind != hipMemcpyDeviceToDevice) {
         char *a = nullptr;
         const int rc = stage_take(ctx, wb * rows, &a);

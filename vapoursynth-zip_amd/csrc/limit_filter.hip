@@ -6,10 +6,23 @@
 
 #include "common.hpp"
 
+#ifndef VSZIP_STREAM_PLAIN_LOADS
+#define VSZIP_STREAM_LOAD(p) __builtin_nontemporal_load(p)  // every sample is read once
+#else
+#define VSZIP_STREAM_LOAD(p) (*(p))
+#endif
+
 namespace {
 
 constexpr int kMaxPlanesLF = 48;
-constexpr int kRowsPerBlockLF = 4;
+// Rows per workgroup, measured on 16 4K YUV420P16 frames (tools/ab_stream.sh, round 2): 1 row 0.42 of the HBM
+// peak (a workgroup's fixed cost — plane lookup, two half-filled passes over a 480-vector row — dominates),
+// 2 rows + non-temporal loads 0.68, 4 rows 0.67. (A pure copy gains from short-lived workgroups in address
+// order, profiles/r02_membw.md; with per-workgroup set-up in the way the gain is a few percent.)
+#ifndef VSZIP_STREAM_ROWS
+#define VSZIP_STREAM_ROWS 2
+#endif
+constexpr int kRowsPerBlockLF = VSZIP_STREAM_ROWS;
 
 struct LFPlane {
     const void *flt, *src, *ref;
@@ -84,8 +97,8 @@ __global__ __launch_bounds__(256) void limit_filter_kernel(const LFParams prm) {
         if (vec) {
             const int nv = pl.w / V;
             for (int i = threadIdx.x; i < nv; i += 256) {
-                const VecT fv = reinterpret_cast<const VecT *>(f)[i], sv = reinterpret_cast<const VecT *>(s)[i];
-                const VecT rv = q == s ? sv : reinterpret_cast<const VecT *>(q)[i];
+                const VecT fv = VSZIP_STREAM_LOAD(reinterpret_cast<const VecT *>(f) + i), sv = VSZIP_STREAM_LOAD(reinterpret_cast<const VecT *>(s) + i);
+                const VecT rv = q == s ? sv : VSZIP_STREAM_LOAD(reinterpret_cast<const VecT *>(q) + i);
                 VecT o;
 #pragma unroll
                 for (int k = 0; k < V; ++k) o[k] = limit_px<T>(fv[k], sv[k], rv[k], pl);

@@ -7,10 +7,23 @@
 
 #include "common.hpp"
 
+#ifndef VSZIP_STREAM_PLAIN_LOADS
+#define VSZIP_STREAM_LOAD(p) __builtin_nontemporal_load(p)  // every sample is read once
+#else
+#define VSZIP_STREAM_LOAD(p) (*(p))
+#endif
+
 namespace {
 
 constexpr int kMaxPlanesL = 48;
-constexpr int kRowsPerBlock = 4;
+// Rows per workgroup, measured on 16 4K YUV420P16 frames (tools/ab_stream.sh, round 2): 1 row 0.42 of the HBM
+// peak (a workgroup's fixed cost — plane lookup, two half-filled passes over a 480-vector row — dominates),
+// 2 rows + non-temporal loads 0.68, 4 rows 0.67. (A pure copy gains from short-lived workgroups in address
+// order, profiles/r02_membw.md; with per-workgroup set-up in the way the gain is a few percent.)
+#ifndef VSZIP_STREAM_ROWS
+#define VSZIP_STREAM_ROWS 2
+#endif
+constexpr int kRowsPerBlock = VSZIP_STREAM_ROWS;
 
 struct LPlane {
     const void *src;
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256) void limiter_kernel(const LParams prm) {
         if (vec) {
             const int nv = pl.w / V;
             for (int i = threadIdx.x; i < nv; i += 256) {
-                VecT v = reinterpret_cast<const VecT *>(s)[i];
+                VecT v = VSZIP_STREAM_LOAD(reinterpret_cast<const VecT *>(s) + i);
 #pragma unroll
                 for (int k = 0; k < V; ++k) v[k] = LOps<T>::f(v[k], pl);
                 __builtin_nontemporal_store(v, reinterpret_cast<VecT *>(d) + i);

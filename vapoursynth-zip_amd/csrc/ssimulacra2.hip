@@ -102,6 +102,45 @@ __device__ __forceinline__ void to_xyb_px(const XybK &k, float r, float g, float
     }
 }
 
+// Two samples per instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): element-wise IEEE operations in
+// the scalar forms' order, so every lane value equals vcl_cbrt / to_xyb_px of that sample.
+__device__ __forceinline__ v2f vcl_cbrt2(v2f x) {
+    const v2f one_third = {1.0f / 3.0f, 1.0f / 3.0f}, four_third = {4.0f / 3.0f, 4.0f / 3.0f};
+    const v2f xa = {fabsf(x.x), fabsf(x.y)};
+    const v2f xa3 = one_third * xa;
+    const uint32_t m0 = __float_as_uint(xa.x), m1 = __float_as_uint(xa.y);
+    v2f a = {__uint_as_float(0x54800000u - ((m0 >> 23) * 0x002AAAAAu)), __uint_as_float(0x54800000u - ((m1 >> 23) * 0x002AAAAAu))};
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const v2f a2 = a * a;
+        a = (four_third * a) - (xa3 * (a2 * a2));
+    }
+    const v2f a2 = a * a;
+    a = a + (one_third * (a - (xa * (a2 * a2))));
+    a = (a * a) * x;
+    return v2f{m0 <= 0x00800000u ? 0.0f : a.x, m1 <= 0x00800000u ? 0.0f : a.y};
+}
+
+__device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
+__device__ __forceinline__ v2f max0_2(v2f v) { return v2f{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f)}; }
+
+__device__ __forceinline__ void to_xyb_px2(const XybK &k, v2f r, v2f g, v2f b, bool need_b, v2f &X, v2f &Y, v2f &B) {
+    const v2f bias = splat2(k.bias), kd1 = splat2(k.kd1);
+    const v2f ox = __builtin_elementwise_fma(splat2(k.m[0]), r, __builtin_elementwise_fma(splat2(k.m[1]), g, __builtin_elementwise_fma(splat2(k.m[2]), b, bias)));
+    const v2f oy = __builtin_elementwise_fma(splat2(k.m[3]), r, __builtin_elementwise_fma(splat2(k.m[4]), g, __builtin_elementwise_fma(splat2(k.m[5]), b, bias)));
+    const v2f cx = vcl_cbrt2(max0_2(ox)) - kd1;
+    const v2f cy = vcl_cbrt2(max0_2(oy)) - kd1;
+    const v2f xv = splat2(0.5f) * (cx - cy);
+    const v2f yv = splat2(0.5f) * (cx + cy);
+    X = xv * splat2(14.0f) + splat2(0.42f);
+    Y = yv + splat2(0.01f);
+    if (need_b) {
+        const v2f oz = __builtin_elementwise_fma(splat2(k.m[6]), r, __builtin_elementwise_fma(splat2(k.m[7]), g, __builtin_elementwise_fma(splat2(k.m[8]), b, bias)));
+        const v2f cz = vcl_cbrt2(max0_2(oz)) - kd1;
+        B = (cz - yv) + splat2(0.55f);
+    }
+}
+
 // One thread per scale-(s+1) pixel = one 2x2 block of scale-s pixels.
 __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
     const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -254,23 +293,21 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lin[1][r][i] = lin[2][r][i] = lin[0][r][i];
         }
-        // scale 0: XYB of the 16 samples
+        // scale 0: XYB of the 16 samples, two per instruction; every value is computed, only the stores are guarded
         {
             const bool nb = o0[2] != nullptr;
+            const bool vec = full && (a.w & 3) == 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (y0 + r >= a.h) continue;  // (no break: the loop must stay fully unrolled, or `lin` leaves the registers)
-                float X[4], Y[4], B[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    B[i] = 0.0f;
-                    to_xyb_px(a.k, lin[0][r][i], lin[1][r][i], lin[2][r][i], nb, X[i], Y[i], B[i]);
+                v2f X01, Y01, B01 = {0.0f, 0.0f}, X23, Y23, B23 = {0.0f, 0.0f};
+                to_xyb_px2(a.k, v2f{lin[0][r][0], lin[0][r][1]}, v2f{lin[1][r][0], lin[1][r][1]}, v2f{lin[2][r][0], lin[2][r][1]}, nb, X01, Y01, B01);
+                to_xyb_px2(a.k, v2f{lin[0][r][2], lin[0][r][3]}, v2f{lin[1][r][2], lin[1][r][3]}, v2f{lin[2][r][2], lin[2][r][3]}, nb, X23, Y23, B23);
+                if (y0 + r < a.h) {
+                    const size_t o = (size_t)(y0 + r) * a.w + x0;
+                    pyr_put4(o0[0], o, vec, a.w - x0, X01.x, X01.y, X23.x, X23.y);
+                    pyr_put4(o0[1], o, vec, a.w - x0, Y01.x, Y01.y, Y23.x, Y23.y);
+                    pyr_put4(o0[2], o, vec, a.w - x0, B01.x, B01.y, B23.x, B23.y);
                 }
-                const size_t o = (size_t)(y0 + r) * a.w + x0;
-                const bool vec = full && (a.w & 3) == 0;
-                pyr_put4(o0[0], o, vec, a.w - x0, X[0], X[1], X[2], X[3]);
-                pyr_put4(o0[1], o, vec, a.w - x0, Y[0], Y[1], Y[2], Y[3]);
-                pyr_put4(o0[2], o, vec, a.w - x0, B[0], B[1], B[2], B[3]);
             }
         }
         // scale 1: 2x2 box of linear RGB, summed ((a+b)+c)+d (:186-200), then XYB
@@ -285,18 +322,18 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
         {
             const bool nb = o1[2] != nullptr;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int x = 2 * bx + i, y = 2 * by + j;
-                    if (x >= a.w1 || y >= a.h1) continue;
-                    float X, Y, B = 0.0f;
-                    to_xyb_px(a.k, l1[0][j][i], l1[1][j][i], l1[2][j][i], nb, X, Y, B);
+            for (int j = 0; j < 2; ++j) {
+                v2f X, Y, B = {0.0f, 0.0f};
+                to_xyb_px2(a.k, v2f{l1[0][j][0], l1[0][j][1]}, v2f{l1[1][j][0], l1[1][j][1]}, v2f{l1[2][j][0], l1[2][j][1]}, nb, X, Y, B);
+                const int x = 2 * bx, y = 2 * by + j;
+                if (y < a.h1) {
                     const size_t o = (size_t)y * a.w1 + x;
-                    if (o1[0]) o1[0][o] = X;
-                    if (o1[1]) o1[1][o] = Y;
-                    if (nb) o1[2][o] = B;
+                    const bool two = x + 1 < a.w1;
+                    if (o1[0]) { o1[0][o] = X.x; if (two) o1[0][o + 1] = X.y; }
+                    if (o1[1]) { o1[1][o] = Y.x; if (two) o1[1][o + 1] = Y.y; }
+                    if (nb) { o1[2][o] = B.x; if (two) o1[2][o + 1] = B.y; }
                 }
+            }
         }
         // scale 2: one sample; a missing scale-1 column / row takes its neighbour (the same clamp one level up)
         if (bx < a.w2 && by < a.h2) {
@@ -394,21 +431,18 @@ __device__ __forceinline__ void ssim_maps_tile_blocked(const MapsArgs &a, const 
         }
 #pragma unroll
         for (int o = 0; o < VR; ++o) {
-            float m1 = 0.0f, m2 = 0.0f, m12 = 0.0f, msq = 0.0f;
+            // (m1, m2) and (m12, msq) ride in one packed register pair each: v_pk_fma_f32, element-wise IEEE
+            v2f m = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < 9; ++k) {  // blurV vector body :318 (interior tiles lie left of the unfused tail)
-                const float kk = c_kernel[k];
-                m1 = fmaf(kk, p[o + k], m1);
-                m2 = fmaf(kk, q[o + k], m2);
-                if (do_ssim) {
-                    m12 = fmaf(kk, pq[o + k], m12);
-                    msq = fmaf(kk, sq[o + k], msq);
-                }
+                const v2f kk = {c_kernel[k], c_kernel[k]};
+                m = __builtin_elementwise_fma(kk, v2f{p[o + k], q[o + k]}, m);
+                if (do_ssim) ms = __builtin_elementwise_fma(kk, v2f{pq[o + k], sq[o + k]}, ms);
             }
-            vt[0][r0 + o][c] = m12;
-            vt[1][r0 + o][c] = msq;
-            vt[2][r0 + o][c] = m1;
-            vt[3][r0 + o][c] = m2;
+            vt[0][r0 + o][c] = ms.x;
+            vt[1][r0 + o][c] = ms.y;
+            vt[2][r0 + o][c] = m.x;
+            vt[3][r0 + o][c] = m.y;
         }
     }
     __syncthreads();

@@ -1076,23 +1076,4 @@ VSZIP_EXPORT int vszip_xpsnr_wsse(vszip_ctx *ctx, int bytes_per_sample, const vo
     return vszip_xpsnr_wsse_batch(ctx, bytes_per_sample, 1, org3, rec3, &prev1, &prev2, width3, height3, stride3, depth, num_comps, frame_rate, temporal, wsse3);
 }
 
-// getFrameXPSNR :370-374 on sqrt(f64(wsse)) (src/vapoursynth/xpsnr.zig:84-86). Host only.
-VSZIP_EXPORT double vszip_xpsnr_value(uint64_t wsse, uint64_t width, uint64_t height, int depth) {
-    const double sq = std::sqrt((double)wsse);
-    if (sq < 1) return INFINITY;
-    uint64_t maxerr = ((uint64_t)1 << depth) - 1;
-    maxerr *= maxerr;
-    return 10.0 * std::log10((double)(width * height * maxerr) / (sq * sq));
-}
-
-// getAvgXPSNR :359-368: the per-clip average printed by xpsnrFree. Host only.
-VSZIP_EXPORT double vszip_xpsnr_average(double sum_wdist, double sum_xpsnr, uint64_t width, uint64_t height, int depth, uint64_t num_frames) {
-    const double nf = (double)num_frames;
-    uint64_t maxerr = ((uint64_t)1 << depth) - 1;
-    maxerr *= maxerr;
-    if (sum_wdist >= nf) {
-        const double avg = sum_wdist / nf;
-        return 10.0 * std::log10((double)(width * height * maxerr) / (avg * avg));
-    }
-    return sum_xpsnr / nf;
-}
+// (vszip_xpsnr_value / vszip_xpsnr_average are device-free: host_params.cpp)

@@ -7,9 +7,10 @@
 // (src/vapoursynth/{boxblur,bilateral,ssimulacra2,xpsnr,eedi3,planeaverage,planeminmax}.zig and
 // src/helper.zig), written in C++ because no Zig toolchain exists in the build image. Every
 // getFrame stages the VSFrame planes to the GPU, calls the flat C ABI of include/vszip_hip.h and
-// stages the result back; frames shard over the visible GPUs by frame index (n mod #GPUs), one
-// context (stream + scratch) per worker thread and device, so getFrame stays re-entrant
-// (fmParallel) exactly like the reference's.
+// stages the result back; frames shard over the visible GPUs by frame index (n mod #GPUs). A gate
+// admits kGateDefault getFrame calls per GPU at a time and hands each a SLOT that owns the context
+// (stream, device slab, scratch) — so a process has that many streams per GPU however many worker
+// threads the host runs, and getFrame stays re-entrant (fmParallel) exactly like the reference's.
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -38,6 +39,19 @@ struct Gpu {
     char *slab = nullptr;
     size_t slab_size = 0, used = 0;
     std::vector<void *> retired;
+
+    Gpu() = default;
+    Gpu(const Gpu &) = delete;
+    Gpu &operator=(const Gpu &) = delete;
+    // Slot-owned contexts live for the process (GateState is never destroyed: HIP may be gone at static-destruction
+    // time). With VSZIP_MAX_IN_FLIGHT=0 a worker thread owns its contexts in thread-local storage, and those go when
+    // the thread exits — while the runtime is still up (thread-local destructors run before atexit handlers).
+    ~Gpu() {
+        if (!ctx) return;
+        for (void *p : retired) vszip_dev_free(ctx, p);
+        if (slab) vszip_dev_free(ctx, slab);
+        vszip_ctx_destroy(ctx);
+    }
 
     void reset() {
         used = 0;
@@ -382,8 +396,9 @@ const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSF
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
+            const VSFrame *failed = fail(z, nullptr, dst, "BoxBlur", "no MI355X device available (the plugin has no CPU fallback)");  // drain / abort the stream first: queued copies may still read src
             api->freeFrame(src);
-            return fail(z, nullptr, dst, "BoxBlur", "no MI355X device available (the plugin has no CPU fallback)");
+            return failed;
         }
         std::vector<vszip_plane> tab;
         std::vector<DPlane> outs;
@@ -392,8 +407,9 @@ const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSF
             if (!d->planes[p]) continue;
             DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps);
             if (!s.ptr || !o.ptr) {
+                const VSFrame *failed = fail(z, g, dst, "BoxBlur", "device staging failed");  // drain / abort the stream first: queued copies may still read src
                 api->freeFrame(src);
-                return fail(z, g, dst, "BoxBlur", "device staging failed");
+                return failed;
             }
             tab.push_back(mk_plane(s, &o, nullptr));
             outs.push_back(o);
@@ -403,9 +419,9 @@ const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSF
         for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
             if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        const VSFrame *result = rc != VSZIP_OK ? fail(z, g, dst, "BoxBlur", "GPU kernel failed") : dst;  // fail() aborts the stream before src goes
         api->freeFrame(src);
-        if (rc != VSZIP_OK) return fail(z, g, dst, "BoxBlur", "GPU kernel failed");
-        return dst;
+        return result;
     }
     return nullptr;
 }
@@ -524,9 +540,19 @@ const VSFrame *VS_CC bilateralGetFrame(int n, int reason, void *inst, void **, V
             std::lock_guard<std::mutex> lk(d->mu);
             auto &v = d->per_device[g->device];
             if (v.empty()) {
-                v.assign(d->cfg, d->cfg + 3);
-                for (int p = 0; p < 3; ++p)
-                    if (vszip_bilateral_luts(g->ctx, &v[p], d->hist_len) != VSZIP_OK) return done(fail(z, g, dst, "Bilateral", "LUT upload failed"));
+                // build the three configs aside and publish them only when every LUT is on the device: a failed
+                // upload must not leave a non-empty entry that later frames would take for a complete one
+                std::vector<vszip_bilateral_cfg> fresh(d->cfg, d->cfg + 3);
+                bool ok_luts = true;
+                for (int p = 0; p < 3 && ok_luts; ++p) ok_luts = vszip_bilateral_luts(g->ctx, &fresh[p], d->hist_len) == VSZIP_OK;
+                if (!ok_luts) {
+                    for (auto &c : fresh) {
+                        if (c.gs_lut) vszip_dev_free(g->ctx, c.gs_lut);
+                        if (c.gr_lut) vszip_dev_free(g->ctx, c.gr_lut);
+                    }
+                    return done(fail(z, g, dst, "Bilateral", "LUT upload failed"));
+                }
+                v = std::move(fresh);
             }
             cfg = v.data();
         }
@@ -806,8 +832,9 @@ const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSF
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
+            const VSFrame *failed = fail(z, nullptr, dst, "Limiter", "no MI355X device available (the plugin has no CPU fallback)");  // drain / abort the stream first: queued copies may still read src
             api->freeFrame(src);
-            return fail(z, nullptr, dst, "Limiter", "no MI355X device available (the plugin has no CPU fallback)");
+            return failed;
         }
         std::vector<vszip_plane> tab;
         std::vector<DPlane> outs;
@@ -817,8 +844,9 @@ const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSF
             if (!d->planes[p]) continue;
             DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps);
             if (!s.ptr || !o.ptr) {
+                const VSFrame *failed = fail(z, g, dst, "Limiter", "device staging failed");  // drain / abort the stream first: queued copies may still read src
                 api->freeFrame(src);
-                return fail(z, g, dst, "Limiter", "device staging failed");
+                return failed;
             }
             tab.push_back(mk_plane(s, &o, nullptr));
             outs.push_back(o);
@@ -830,9 +858,9 @@ const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSF
         for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
             if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        const VSFrame *result = rc != VSZIP_OK ? fail(z, g, dst, "Limiter", "GPU kernel failed") : dst;  // fail() aborts the stream before src goes
         api->freeFrame(src);
-        if (rc != VSZIP_OK) return fail(z, g, dst, "Limiter", "GPU kernel failed");
-        return dst;
+        return result;
     }
     return nullptr;
 }
@@ -996,8 +1024,9 @@ const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **,
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
+            const VSFrame *failed = fail(z, nullptr, dst, "LimitFilter", "no MI355X device available (the plugin has no CPU fallback)");  // abort the stream first: queued copies may still read the inputs
             release();
-            return fail(z, nullptr, dst, "LimitFilter", "no MI355X device available (the plugin has no CPU fallback)");
+            return failed;
         }
         std::vector<vszip_plane> tab;
         std::vector<DPlane> outs;
@@ -1011,8 +1040,9 @@ const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **,
             DPlane r;
             if (ref) r = z.upload(g, ref, p);
             if (!f.ptr || !s.ptr || !o.ptr || (ref && !r.ptr)) {
+                const VSFrame *failed = fail(z, g, dst, "LimitFilter", "device staging failed");  // abort the stream first: queued copies may still read the inputs
                 release();
-                return fail(z, g, dst, "LimitFilter", "device staging failed");
+                return failed;
             }
             tab.push_back(mk_plane(f, &o, &s));
             outs.push_back(o);
@@ -1029,9 +1059,9 @@ const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **,
         for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
             if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        const VSFrame *result = rc != VSZIP_OK ? fail(z, g, dst, "LimitFilter", "GPU kernel failed") : dst;
         release();
-        if (rc != VSZIP_OK) return fail(z, g, dst, "LimitFilter", "GPU kernel failed");
-        return dst;
+        return result;
     }
     return nullptr;
 }
@@ -1120,16 +1150,18 @@ const VSFrame *VS_CC adaptiveBinarizeGetFrame(int n, int reason, void *inst, voi
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) {
+            const VSFrame *failed = fail(z, nullptr, dst, "AdaptiveBinarize", "no MI355X device available (the plugin has no CPU fallback)");  // abort the stream first: queued copies may still read the inputs
             release();
-            return fail(z, nullptr, dst, "AdaptiveBinarize", "no MI355X device available (the plugin has no CPU fallback)");
+            return failed;
         }
         std::vector<vszip_plane> tab;
         std::vector<DPlane> outs;
         for (int p = 0; p < vf->numPlanes; ++p) {
             DPlane a = z.upload(g, src, p), b = z.upload(g, src2, p), o = z.blank(g, a.w, a.h, a.bps);
             if (!a.ptr || !b.ptr || !o.ptr) {
+                const VSFrame *failed = fail(z, g, dst, "AdaptiveBinarize", "device staging failed");  // abort the stream first: queued copies may still read the inputs
                 release();
-                return fail(z, g, dst, "AdaptiveBinarize", "device staging failed");
+                return failed;
             }
             tab.push_back(mk_plane(a, &o, &b));
             outs.push_back(o);
@@ -1138,8 +1170,12 @@ const VSFrame *VS_CC adaptiveBinarizeGetFrame(int n, int reason, void *inst, voi
         for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
             if (!z.download(g, outs[i], dst, (int)i)) rc = VSZIP_ERR_HIP;
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+        if (rc != VSZIP_OK) {
+            const VSFrame *failed = fail(z, g, dst, "AdaptiveBinarize", "GPU kernel failed");
+            release();
+            return failed;
+        }
         release();
-        if (rc != VSZIP_OK) return fail(z, g, dst, "AdaptiveBinarize", "GPU kernel failed");
         api->mapSetInt(api->getFramePropertiesRW(dst), "_ColorRange", 0, maReplace);  // setColorRange(.FULL) :70-71 (reference tests/test_adaptive_binarize.py:70)
         return dst;
     }
