@@ -796,6 +796,12 @@ static void VS_CC standin_set_frame_prop(const VSMap *in, VSMap *out, void *, VS
     for (int i = 0; i < src->vi.numFrames; ++i) {
         char e[256];
         const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+        if (!f) {  // the upstream filter failed: the stand-in is eager, so the error surfaces at create time
+            A(mapSetError)(out, e);
+            node_unref(src);
+            node_unref(n);
+            return;
+        }
         VSFrame *c = A(copyFrame)(f, &g_core);
         frame_unref(f);
         A(mapSetInt)(&c->props, prop, val, maReplace);
@@ -828,6 +834,12 @@ static void VS_CC standin_bicubic(const VSMap *in, VSMap *out, void *, VSCore *c
     for (int i = 0; i < src->vi.numFrames; ++i) {
         char e[256];
         const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+        if (!f) {
+            A(mapSetError)(out, e);
+            node_unref(src);
+            node_unref(n);
+            return;
+        }
         VSFrame *c = frame_new(&fmt, src->vi.width, src->vi.height);
         map_copy(&f->props, &c->props);
         int pe = 0;

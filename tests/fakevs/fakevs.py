@@ -185,6 +185,15 @@ def core_standins(on: bool):
     lib().fakevs_enable_core_standins(1 if on else 0)
 
 
+def fusion_stats():
+    """(getFrame calls that ran fused upstream vszip stages, stages run) since the plugin was loaded."""
+    lib()  # the plugin is loaded by now
+    pl = C.CDLL(str(PLUGIN))
+    a, b = C.c_long(), C.c_long()
+    pl.vszip_plugin_fusion_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def standin_log():
     out, buf, i = [], C.create_string_buffer(256), 0
     while lib().fakevs_standin_log(i, buf, 256):

@@ -596,3 +596,71 @@ def test_ssimulacra2_host_colour_switch(oracle, tmp_path):
     assert r.returncode == 0, r.stderr
     score, nconv = r.stdout.strip().split()
     assert float(score) == pytest.approx(want_rgb, abs=1e-7) and int(nconv) == 4  # both clips: format + transfer on the host
+
+
+def _materialize(clip, fmt, n):
+    """The clip's frames as a fresh source clip: a non-vszip node in between, i.e. the UNFUSED path."""
+    out = []
+    for i in range(n):
+        fr = clip.get_frame(i)
+        out.append([np.array(fr[p]) for p in range(3)])
+    return vs.source(out, fmt)
+
+
+def test_fused_chain_equals_unfused(oracle):
+    """SURVEY 8f rank 4, second half: chained vszip filters run as ONE getFrame — one upload of the root frame,
+    every stage's kernels on the device, one download. The fused result is bit-identical to the same chain
+    with every intermediate clip taken through host memory, including `planes` subsets (a plane an upstream
+    stage wrote and the last stage does not process must come back from the device, not from the root frame)."""
+    frames = [[fx.splitmix64_plane(10 * f + p, s, np.uint16) for p, s in enumerate([(120, 208), (60, 104), (60, 104)])] for f in range(3)]
+    src = vs.source(frames, vs.YUV420P16)
+    f0, s0 = vs.fusion_stats()
+    # fused: Bilateral (all planes) -> BoxBlur (luma only) -> Limiter (chroma only)
+    fused = src.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=3, vradius=3, planes=[0]).vszip.Limiter(min=[0, 20000, 20000], max=[65535, 40000, 40000], planes=[1, 2])
+    got = []
+    for n in (1, 0, 2):
+        fr = fused.get_frame(n)
+        got.append([np.array(fr[p]) for p in range(3)])
+    f1, s1 = vs.fusion_stats()
+    assert (f1 - f0, s1 - s0) == (3, 6)  # three getFrame calls, two upstream stages each
+    # unfused twin: every hop through host memory
+    a = _materialize(src.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05), vs.YUV420P16, 3)
+    b = _materialize(a.vszip.BoxBlur(hradius=3, vradius=3, planes=[0]), vs.YUV420P16, 3)
+    c = b.vszip.Limiter(min=[0, 20000, 20000], max=[65535, 40000, 40000], planes=[1, 2])
+    assert vs.fusion_stats() == (f1, s1)  # nothing fused here
+    for k, n in enumerate((1, 0, 2)):
+        want = c.get_frame(n)
+        for p in range(3):
+            assert np.array_equal(got[k][p], want[p]), (n, p)
+    # and against the oracle, stage by stage
+    prm = oracle.bilateral_params([2], [0.05], yuv=True, ssw=1, ssh=1)
+    for k, n in enumerate((1, 0, 2)):
+        bl = [oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i]) for i, p in enumerate(frames[n])]
+        want = [oracle.boxblur(bl[0], 3, 1, 3, 1), oracle.limiter(bl[1], 20000, 40000), oracle.limiter(bl[2], 20000, 40000)]
+        for p in range(3):
+            assert np.array_equal(got[k][p], want[p]), (n, p)
+    # the upstream instances still serve other consumers on their own
+    up = src.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05)
+    down = up.vszip.BoxBlur(hradius=3, vradius=3, planes=[0])
+    assert np.array_equal(np.array(up.get_frame(0)[1]), oracle.bilateral_plane(frames[0][1], prm["sigmaS"][1], prm["sigmaR"][1], prm["algorithm"][1], prm["radius"][1], prm["step"][1], prm["PBFICnum"][1]))
+    assert np.array_equal(np.array(down.get_frame(0)[0]), got[1][0])
+    # a joint-bilateral instance (ref clip) is not a fusable stage: its consumer takes the staged path
+    f2, s2 = vs.fusion_stats()
+    j = src.vszip.Bilateral(ref=src, sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=1, vradius=1)
+    j.get_frame(0)
+    assert vs.fusion_stats() == (f2, s2)
+
+
+def test_fused_pipeline_into_ssimulacra2(oracle):
+    """BASELINE config 5 through libvszip.so: SSIMULACRA2(src, src.Bilateral().BoxBlur()) uploads the source frame
+    ONCE (both inputs share the root), runs Bilateral and BoxBlur on the device and returns a score — the
+    processed frame never crosses the host link."""
+    base = [np.ascontiguousarray(p[:160, :256]) for p in fx.crop_rgbs()]
+    src = vs.source([base], vs.RGBS, props={"_Transfer": 8})
+    f0, s0 = vs.fusion_stats()
+    s = src.vszip.SSIMULACRA2(src.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)).get_frame(0).props["SSIMULACRA2"]
+    assert vs.fusion_stats() == (f0 + 1, s0 + 2)
+    prm = oracle.bilateral_params([2], [2], yuv=False, ssw=0, ssh=0)
+    want = [oracle.boxblur(oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i]), 2, 1, 2, 1)
+            for i, p in enumerate(base)]
+    assert s == pytest.approx(oracle.ssimulacra2(base, want), abs=1e-7)

@@ -74,6 +74,10 @@ SCENARIO = textwrap.dedent("""
         c8.vszip.XPSNR(c8), c8.vszip.XPSNR(c8, temporal=False), rgbs.vszip.SSIMULACRA2(rgbs), rgb.vszip.SSIMULACRA2(rgb), g8.vszip.SSIMULACRA2(g8),
         rgb.vszip.SSIMULACRA2(rgbs), cf.vszip.EEDI3(field=1, dh=True), cf.vszip.EEDI3H(field=0), gs.vszip.EEDI3(field=1, sclip=gs, mclip=g8, vcheck=3),
         c16.vszip.Limiter(tv_range=True), c16.vszip.LimitFilter(c16, dark_thr=8.0), c16.vszip.LimitFilter(c16, c16, elast=3.0), g8.vszip.AdaptiveBinarize(g8, c=3),
+        # fused chains (one getFrame runs the upstream stages): their unwind paths, and the references they hold
+        c16.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=3, vradius=3, planes=[0]).vszip.Limiter(tv_range=True, planes=[1, 2]),
+        rgbs.vszip.SSIMULACRA2(rgbs.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)),
+        rgb.vszip.SSIMULACRA2(rgb.vszip.BoxBlur(hradius=1, vradius=1)),
     ]
     failed = 0
     for c in clips:
@@ -89,6 +93,7 @@ SCENARIO = textwrap.dedent("""
         clips[0].pull(12, 4)
     except vs.Error:
         pass
+    del clips, c  # every filter instance is freed: chains release the upstream nodes they hold
     print("scenario ok", failed)
 """)
 

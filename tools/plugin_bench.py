@@ -38,6 +38,20 @@ def clips_4k_rgbs(n):
     return vs.source(ref, vs.RGBS, props={"_Transfer": 8}), vs.source(dis, vs.RGBS, props={"_Transfer": 8})
 
 
+def clips_4k_rgb24(n):
+    base = [fx.tiled_natural((2160, 3840), np.uint8, p) for p in range(3)]
+    rng = np.random.default_rng(1)
+    noise = rng.integers(-3, 4, (2160, 3840), dtype=np.int16)
+    ref = [[np.roll(p, 9 * f, axis=1) for p in base] for f in range(n)]
+    dis = [[np.clip(p.astype(np.int16) + noise, 0, 255).astype(np.uint8) for p in fr] for fr in ref]
+    return vs.source(ref, vs.RGB24), vs.source(dis, vs.RGB24)
+
+
+def clip_8k_rgbs(n):
+    base = [np.ascontiguousarray(fx.tiled_natural((4320, 7680), np.float32, p)) for p in range(3)]
+    return vs.source([[np.roll(p, 19 * f, axis=1) for p in base] for f in range(n)], vs.RGBS, props={"_Transfer": 8})
+
+
 def main():
     threads = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "4", "8", "16", "32"])]
     vs.lib().fakevs_set_pool_refill(0)  # a real host does not touch recycled frame memory
@@ -57,6 +71,16 @@ def main():
     if only is None or "ssimulacra2" in only:
         ref, dis = clips_4k_rgbs(4)
         legs.append(("SSIMULACRA2 4K RGBS (linear)", ref.vszip.SSIMULACRA2(dis), 199.1, 64))
+    if only is None or "ssimulacra2" in only:
+        # colour pre-stage on the device: the RGB24 planes go up as they are (50 MB per pair instead of 199);
+        # the output clip is the host-converted reference (the test host converts eagerly, outside the clock)
+        vs.core_standins(True)
+        r8, d8 = clips_4k_rgb24(4)
+        legs.append(("SSIMULACRA2 4K RGB24 (device colour pre-stage)", r8.vszip.SSIMULACRA2(d8), 49.8, 64))
+    if only is None or "pipeline" in only:
+        # BASELINE config 5 as a script writes it: three filter instances, fused into one getFrame by the plugin
+        src8k = clip_8k_rgbs(4)
+        legs.append(("Pipeline Bilateral->BoxBlur->SSIMULACRA2 8K RGBS (one getFrame per frame when fused)", src8k.vszip.SSIMULACRA2(src8k.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)), 398.1, 16))
     if only is not None:
         legs = [l for l in legs if any(o.lower() in l[0].lower() for o in only)]
     for name, clip, mb_per_frame, count in legs:

@@ -42,6 +42,9 @@ constexpr int kScales = 5;  // scales that carry a non-pruned weight
 constexpr int TW = 32, TH = 32, HALO = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
 constexpr int kVecW = 8;    // reference SIMD width baked into the FMA rule
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+#define VSZIP_GLOBAL __attribute__((address_space(1)))  // a pointer known to be global memory: global_load / global_store, not flat_*
 
 __constant__ float c_kernel[9] = {
     0.0076144188642501831054687500f, 0.0360749699175357818603515625f, 0.1095860823988914489746093750f,
@@ -201,6 +204,7 @@ struct PyrArgs {
     const PyrPair *tab;
     const float *lut;   // PYR_INT: 2^bits entries indexed by the sample; PYR_F32_GAMMA: the 65537-entry transfer table
     int lut_lds;        // PYR_INT: number of entries staged in LDS (0: gathered from global memory)
+    int vec_ok;         // every source plane base and the row pitch are aligned to 4 samples, and w % 4 == 0
     int sstride;        // source row pitch, elements
     int w, h, w1, h1, w2, h2;
     XybK k;
@@ -223,10 +227,10 @@ __device__ __forceinline__ float pyr_linear(T v, const float *lut, const float *
 }
 
 // four adjacent samples of one plane row: one 16-byte store, or the `left` (< 4) samples inside the plane
-__device__ __forceinline__ void pyr_put4(float *pl, size_t o, bool vec, int left, float v0, float v1, float v2, float v3) {
+__device__ __forceinline__ void pyr_put4(float __attribute__((address_space(1))) *pl, size_t o, bool vec, int left, float v0, float v1, float v2, float v3) {
     if (!pl) return;
     if (vec) {
-        *reinterpret_cast<float4 *>(pl + o) = make_float4(v0, v1, v2, v3);
+        *reinterpret_cast<v4f VSZIP_GLOBAL *>(pl + o) = v4f{v0, v1, v2, v3};
     } else {
         pl[o] = v0;
         if (left > 1) pl[o + 1] = v1;
@@ -235,58 +239,63 @@ __device__ __forceinline__ void pyr_put4(float *pl, size_t o, bool vec, int left
     }
 }
 
-template <typename T, int MODE, bool GRAY>
-__global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
-    __shared__ float lds_lut[(MODE == PYR_INT) ? kPyrLdsLut : 1];
-    const bool use_lds = MODE == PYR_INT && a.lut_lds > 0;
-    if (use_lds) {
-        for (int i = threadIdx.x; i < a.lut_lds; i += 256) lds_lut[i] = a.lut[i];
-        __syncthreads();
-    }
-    const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
+// The work of one thread. FAST is a property of the whole workgroup (every 4x4 block of it lies inside the
+// plane and every row start is aligned): loads and stores are then unconditional vector accesses — no divergent
+// branch around a memory instruction, so the compiler issues an image's 12 row loads back to back behind ONE
+// s_waitcnt (with a per-thread `if (full)` around each load it waited for every load separately: 12 dependent
+// round trips per image, 81 us per 4K pair instead of 50).
+struct PyrPtrs {  // one frame's plane pointers, held in (scalar) registers
+    const void *src[3];
+    float *o0[3], *o1[3], *o2[3];
+};
+
+template <typename T, int MODE, bool GRAY, bool FAST>
+__device__ __forceinline__ void pyr_image(const PyrArgs &a, const PyrPtrs &pp, const float *lds_lut, bool use_lds, int bx, int by) {
     const int x0 = bx * 4, y0 = by * 4;
-    if (x0 >= a.w || y0 >= a.h) return;
-    const PyrPair &pp = a.tab[blockIdx.z];  // (a reference: a local copy indexed by `img` would be promoted to LDS)
-    const bool full = x0 + 4 <= a.w && y0 + 4 <= a.h;
     constexpr int NP = GRAY ? 1 : 3;
-#pragma unroll
-    for (int img = 0; img < 2; ++img) {
-        const void *const *src = img ? pp.src2 : pp.src1;
-        float *const *o0 = img ? pp.x0b : pp.x0a;
-        float *const *o1 = img ? pp.x1b : pp.x1a;
-        float *const *o2 = img ? pp.r2b : pp.r2a;
+    {
+        // plane pointers read from a table are generic to the compiler (flat_load / flat_store): they are global memory
+        typedef const T __attribute__((address_space(1))) *GSrc;
+        typedef float __attribute__((address_space(1))) *GOut;
+        const GSrc src[3] = {(GSrc)pp.src[0], (GSrc)pp.src[1], (GSrc)pp.src[2]};
+        const GOut o0[3] = {(GOut)pp.o0[0], (GOut)pp.o0[1], (GOut)pp.o0[2]};
+        const GOut o1[3] = {(GOut)pp.o1[0], (GOut)pp.o1[1], (GOut)pp.o1[2]};
+        const GOut o2[3] = {(GOut)pp.o2[0], (GOut)pp.o2[1], (GOut)pp.o2[2]};
         // 4x4 block -> linear RGB. Samples past the right / bottom edge take the edge sample, which is
         // exactly the clamp of downscale (:186-200): min(2*ox + ix, w - 1).
-        float lin[3][4][4];
+        T raw[NP][4][4];
 #pragma unroll
         for (int c = 0; c < NP; ++c) {
-            const T *pl = static_cast<const T *>(src[c]);
+            const GSrc pl = src[c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const T *row = pl + (size_t)min(y0 + r, a.h - 1) * a.sstride;
-                T v[4];
-                if (full && ((reinterpret_cast<uintptr_t>(row + x0) & (sizeof(T) * 4 - 1)) == 0)) {
+                if constexpr (FAST) {
+                    const GSrc row = pl + (size_t)(y0 + r) * a.sstride + x0;
                     // one 4 / 8 / 16-byte load, unpacked with shifts (an array of T in a struct goes to scratch)
                     if constexpr (sizeof(T) == 4) {
-                        const float4 q = *reinterpret_cast<const float4 *>(row + x0);
-                        v[0] = (T)q.x; v[1] = (T)q.y; v[2] = (T)q.z; v[3] = (T)q.w;
+                        const v4f q = *reinterpret_cast<const v4f VSZIP_GLOBAL *>(row);
+                        raw[c][r][0] = (T)q.x; raw[c][r][1] = (T)q.y; raw[c][r][2] = (T)q.z; raw[c][r][3] = (T)q.w;
                     } else if constexpr (sizeof(T) == 2) {
-                        const uint2 q = *reinterpret_cast<const uint2 *>(row + x0);
-                        v[0] = (T)(q.x & 0xffffu); v[1] = (T)(q.x >> 16); v[2] = (T)(q.y & 0xffffu); v[3] = (T)(q.y >> 16);
+                        const v2u q = *reinterpret_cast<const v2u VSZIP_GLOBAL *>(row);
+                        raw[c][r][0] = (T)(q.x & 0xffffu); raw[c][r][1] = (T)(q.x >> 16); raw[c][r][2] = (T)(q.y & 0xffffu); raw[c][r][3] = (T)(q.y >> 16);
                     } else {
-                        const uint32_t q = *reinterpret_cast<const uint32_t *>(row + x0);
-                        v[0] = (T)(q & 0xffu); v[1] = (T)((q >> 8) & 0xffu); v[2] = (T)((q >> 16) & 0xffu); v[3] = (T)(q >> 24);
+                        const uint32_t q = *reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>(row);
+                        raw[c][r][0] = (T)(q & 0xffu); raw[c][r][1] = (T)((q >> 8) & 0xffu); raw[c][r][2] = (T)((q >> 16) & 0xffu); raw[c][r][3] = (T)(q >> 24);
                     }
                 } else {
-                    v[0] = row[min(x0 + 0, a.w - 1)];
-                    v[1] = row[min(x0 + 1, a.w - 1)];
-                    v[2] = row[min(x0 + 2, a.w - 1)];
-                    v[3] = row[min(x0 + 3, a.w - 1)];
-                }
+                    const GSrc row = pl + (size_t)min(y0 + r, a.h - 1) * a.sstride;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lin[c][r][i] = pyr_linear<T, MODE>(v[i], a.lut, lds_lut, use_lds);
+                    for (int i = 0; i < 4; ++i) raw[c][r][i] = row[min(x0 + i, a.w - 1)];
+                }
             }
         }
+        float lin[3][4][4];
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lin[c][r][i] = pyr_linear<T, MODE>(raw[c][r][i], a.lut, lds_lut, use_lds);
         if constexpr (GRAY) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -296,17 +305,16 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
         // scale 0: XYB of the 16 samples, two per instruction; every value is computed, only the stores are guarded
         {
             const bool nb = o0[2] != nullptr;
-            const bool vec = full && (a.w & 3) == 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v2f X01, Y01, B01 = {0.0f, 0.0f}, X23, Y23, B23 = {0.0f, 0.0f};
                 to_xyb_px2(a.k, v2f{lin[0][r][0], lin[0][r][1]}, v2f{lin[1][r][0], lin[1][r][1]}, v2f{lin[2][r][0], lin[2][r][1]}, nb, X01, Y01, B01);
                 to_xyb_px2(a.k, v2f{lin[0][r][2], lin[0][r][3]}, v2f{lin[1][r][2], lin[1][r][3]}, v2f{lin[2][r][2], lin[2][r][3]}, nb, X23, Y23, B23);
-                if (y0 + r < a.h) {
+                if (FAST || y0 + r < a.h) {
                     const size_t o = (size_t)(y0 + r) * a.w + x0;
-                    pyr_put4(o0[0], o, vec, a.w - x0, X01.x, X01.y, X23.x, X23.y);
-                    pyr_put4(o0[1], o, vec, a.w - x0, Y01.x, Y01.y, Y23.x, Y23.y);
-                    pyr_put4(o0[2], o, vec, a.w - x0, B01.x, B01.y, B23.x, B23.y);
+                    pyr_put4(o0[0], o, FAST, a.w - x0, X01.x, X01.y, X23.x, X23.y);
+                    pyr_put4(o0[1], o, FAST, a.w - x0, Y01.x, Y01.y, Y23.x, Y23.y);
+                    pyr_put4(o0[2], o, FAST, a.w - x0, B01.x, B01.y, B23.x, B23.y);
                 }
             }
         }
@@ -326,18 +334,25 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
                 v2f X, Y, B = {0.0f, 0.0f};
                 to_xyb_px2(a.k, v2f{l1[0][j][0], l1[0][j][1]}, v2f{l1[1][j][0], l1[1][j][1]}, v2f{l1[2][j][0], l1[2][j][1]}, nb, X, Y, B);
                 const int x = 2 * bx, y = 2 * by + j;
-                if (y < a.h1) {
+                if (FAST || y < a.h1) {
                     const size_t o = (size_t)y * a.w1 + x;
-                    const bool two = x + 1 < a.w1;
-                    if (o1[0]) { o1[0][o] = X.x; if (two) o1[0][o + 1] = X.y; }
-                    if (o1[1]) { o1[1][o] = Y.x; if (two) o1[1][o + 1] = Y.y; }
-                    if (nb) { o1[2][o] = B.x; if (two) o1[2][o + 1] = B.y; }
+                    const bool two = FAST || x + 1 < a.w1;
+                    if (FAST && (a.w1 & 1) == 0) {  // 8-byte stores: every row of scale 1 starts 8-byte aligned
+                        typedef v2f VSZIP_GLOBAL *G2;
+                        if (o1[0]) *reinterpret_cast<G2>(o1[0] + o) = X;
+                        if (o1[1]) *reinterpret_cast<G2>(o1[1] + o) = Y;
+                        if (nb) *reinterpret_cast<G2>(o1[2] + o) = B;
+                    } else {
+                        if (o1[0]) { o1[0][o] = X.x; if (two) o1[0][o + 1] = X.y; }
+                        if (o1[1]) { o1[1][o] = Y.x; if (two) o1[1][o + 1] = Y.y; }
+                        if (nb) { o1[2][o] = B.x; if (two) o1[2][o + 1] = B.y; }
+                    }
                 }
             }
         }
         // scale 2: one sample; a missing scale-1 column / row takes its neighbour (the same clamp one level up)
-        if (bx < a.w2 && by < a.h2) {
-            const bool i1 = 2 * bx + 1 < a.w1, j1 = 2 * by + 1 < a.h1;
+        if (FAST || (bx < a.w2 && by < a.h2)) {
+            const bool i1 = FAST || 2 * bx + 1 < a.w1, j1 = FAST || 2 * by + 1 < a.h1;
             const size_t o = (size_t)by * a.w2 + bx;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -348,6 +363,37 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
                 o2[c][o] = (((p00 + p01) + p10) + p11) * 0.25f;
             }
         }
+    }
+}
+
+template <typename T, int MODE, bool GRAY>
+__global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
+    __shared__ float lds_lut[(MODE == PYR_INT) ? kPyrLdsLut : 1];
+    const bool use_lds = MODE == PYR_INT && a.lut_lds > 0;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < a.lut_lds; i += 256) lds_lut[i] = a.lut[i];
+        __syncthreads();
+    }
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    // Both frames' plane pointers, read ONCE before any store (through the table in memory the compiler must
+    // assume that a store to an output plane changed them, and reloads — and waits for — a pointer before
+    // every access). Statically indexed copies: they live in SGPRs.
+    const PyrPair *__restrict__ tp = a.tab + blockIdx.z;
+    PyrPtrs f1, f2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f1.src[c] = tp->src1[c]; f1.o0[c] = tp->x0a[c]; f1.o1[c] = tp->x1a[c]; f1.o2[c] = tp->r2a[c];
+        f2.src[c] = tp->src2[c]; f2.o0[c] = tp->x0b[c]; f2.o1[c] = tp->x1b[c]; f2.o2[c] = tp->r2b[c];
+    }
+    // workgroup-uniform: the whole 256 x 16 sample block is inside the plane and the planes allow vector accesses
+    const bool fast = a.vec_ok && (int)(blockIdx.x + 1) * 256 <= a.w && (int)(blockIdx.y + 1) * 16 <= a.h;
+    if (fast) {
+        pyr_image<T, MODE, GRAY, true>(a, f1, lds_lut, use_lds, bx, by);
+        pyr_image<T, MODE, GRAY, true>(a, f2, lds_lut, use_lds, bx, by);
+    } else {
+        if (bx * 4 >= a.w || by * 4 >= a.h) return;
+        pyr_image<T, MODE, GRAY, false>(a, f1, lds_lut, use_lds, bx, by);
+        pyr_image<T, MODE, GRAY, false>(a, f2, lds_lut, use_lds, bx, by);
     }
 }
 
@@ -405,11 +451,30 @@ __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, floa
 __device__ __forceinline__ void ssim_maps_tile_blocked(const MapsArgs &a, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0,
                                                        float (*s1)[IW + 1], float (*s2)[IW + 1], float (*vt)[TH][IW + 1], double acc[6]) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const size_t o = (size_t)(y0 - HALO + r) * a.stride + (x0 - HALO + c);
-        s1[r][c] = im1[o];
-        s2[r][c] = im2[o];
+    {
+        // stage the 40 x 40 tile of both frames: all 14 loads of a thread in flight before the first LDS write
+        // (global address space: plane pointers read from the pair table are generic to the compiler — flat
+        // loads, each followed by a full s_waitcnt in the rolled loop)
+        const float VSZIP_GLOBAL *g1 = (const float VSZIP_GLOBAL *)im1, *g2 = (const float VSZIP_GLOBAL *)im2;
+        constexpr int NS = (IH * IW + 255) / 256;
+        float v1[NS], v2[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = min(tid + 256 * k, IH * IW - 1);
+            const int r = i / IW, c = i - r * IW;
+            const size_t o = (size_t)(y0 - HALO + r) * a.stride + (x0 - HALO + c);
+            v1[k] = g1[o];
+            v2[k] = g2[o];
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < IH * IW) {
+                const int r = i / IW, c = i - r * IW;
+                s1[r][c] = v1[k];
+                s2[r][c] = v2[k];
+            }
+        }
     }
     __syncthreads();
     constexpr int VR = 8;  // output rows per thread in the vertical pass
@@ -943,6 +1008,12 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         pa.tab = pyr_dev;
         pa.lut = lut_dev;
         pa.lut_lds = lut_lds;
+        {
+            const size_t bps = fmt->dtype == VSZIP_U8 ? 1 : (fmt->dtype == VSZIP_U16 ? 2 : 4);
+            uintptr_t bits = (uintptr_t)((size_t)stride * bps);
+            for (int i = 0; i < npairs * nsp; ++i) bits |= reinterpret_cast<uintptr_t>(ref_planes[i]) | reinterpret_cast<uintptr_t>(dis_planes[i]);
+            pa.vec_ok = (bits & (4 * bps - 1)) == 0 && (w & 3) == 0;  // (the XYB planes are dense: rows of w floats, 16-byte aligned when w % 4 == 0)
+        }
         pa.sstride = (int)stride;
         pa.w = w;
         pa.h = h;

@@ -373,61 +373,294 @@ vszip_plane mk_plane(const DPlane &s, const DPlane *d, const DPlane *r) {
 }
 
 // ===========================================================================
-// BoxBlur — src/vapoursynth/boxblur.zig
+// Fused vszip -> vszip chains (frames stay on the device between chained filters)
 // ===========================================================================
+// A .vpy script chains filters as separate instances: clip.vszip.Bilateral().vszip.BoxBlur() — and through the
+// plain plugin boundary every hop is a PCIe round trip. The pixel filters (BoxBlur, Bilateral without a `ref`
+// clip, Limiter) therefore register their OUTPUT node in a private side table at create time; a vszip filter
+// created on such a node does not request that node's frames but the frames of the chain's ROOT (the first
+// ancestor that is not a fusable vszip instance), uploads them once and runs the upstream stages' kernels
+// itself, on the device planes, before its own. One getFrame, one upload, k kernels, one download (none for
+// SSIMULACRA2: a score). Nothing is attached to frames (a frame-prop handle would survive std.CopyFrameProps
+// onto other pixels, and VapourSynth recycles frame memory); the upstream instances stay valid on their own for
+// any other consumer. The fused consumer holds a reference on every upstream node it runs, which keeps their
+// instance data (parameters, LUTs) alive. VSZIP_NO_FUSION=1 switches it off.
+enum StageKind { kStageBoxBlur = 0, kStageBilateral = 1, kStageLimiter = 2 };
+struct StageRef {
+    int kind;
+    VSNode *input;  // the instance's own input node (the instance owns that reference)
+    void *data;     // BoxBlurData / BilateralData / LimiterData of the instance
+};
+struct StageRegistry {
+    std::mutex mu;
+    std::map<VSNode *, StageRef> by_node;
+};
+StageRegistry &stage_registry() {
+    static StageRegistry *r = new StageRegistry();
+    return *r;
+}
+bool fusion_enabled() {
+    static const bool on = [] { const char *e = getenv("VSZIP_NO_FUSION"); return !(e && atoi(e) != 0); }();
+    return on;
+}
+// After createVideoFilter: remember which node is this instance's output. The key is not a reference (a
+// self-reference would keep the node alive for ever); the instance's free callback removes it.
+VSNode *register_stage(const VSAPI *api, VSMap *out, int kind, VSNode *input, void *data) {
+    int err = 0;
+    VSNode *self = api->mapGetNode(out, "clip", 0, &err);
+    if (err || !self) return nullptr;
+    api->freeNode(self);
+    StageRegistry &r = stage_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.by_node[self] = StageRef{kind, input, data};
+    return self;
+}
+void unregister_stage(VSNode *self) {
+    if (!self) return;
+    StageRegistry &r = stage_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.by_node.erase(self);
+}
+std::atomic<long> g_fused_frames{0}, g_fused_stages{0};  // diagnostics: getFrame calls that ran upstream stages, stages run
+void count_fused(size_t stages) {
+    if (!stages) return;
+    g_fused_frames.fetch_add(1);
+    g_fused_stages.fetch_add((long)stages);
+}
+struct Chain {
+    VSNode *root = nullptr;        // owned reference: where the frames are requested
+    std::vector<StageRef> stages;  // upstream stages, root first
+    std::vector<VSNode *> held;    // owned references on the fused upstream nodes
+    bool fused() const { return !stages.empty(); }
+};
+// node: borrowed. The returned chain owns its references (free_chain).
+Chain resolve_chain(const VSAPI *api, VSNode *node) {
+    Chain c;
+    VSNode *cur = node;
+    if (fusion_enabled()) {
+        StageRegistry &r = stage_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        for (;;) {
+            auto it = r.by_node.find(cur);
+            if (it == r.by_node.end()) break;
+            c.stages.insert(c.stages.begin(), it->second);
+            c.held.push_back(api->addNodeRef(cur));
+            cur = it->second.input;
+        }
+    }
+    c.root = api->addNodeRef(cur);
+    return c;
+}
+void free_chain(const VSAPI *api, Chain &c) {
+    if (c.root) api->freeNode(c.root);
+    for (VSNode *n : c.held) api->freeNode(n);
+    c.root = nullptr;
+    c.held.clear();
+    c.stages.clear();
+}
+
 struct BoxBlurData {
     VSNode *node;
     const VSVideoInfo *vi;
     int hradius, vradius, hpasses, vpasses, dt;
     bool planes[3];
+    Chain chain;
+    VSNode *self = nullptr;
 };
+struct BilateralData {
+    VSNode *node1, *node2;
+    const VSVideoInfo *vi;
+    vszip_bilateral_cfg cfg[3];
+    int dt, hist_len;
+    float peak;
+    std::mutex mu;
+    std::map<int, std::vector<vszip_bilateral_cfg>> per_device;  // LUTs live in device memory
+    Chain chain;
+    VSNode *self = nullptr;
+};
+struct LimiterData {
+    VSNode *node;
+    const VSVideoInfo *vi;
+    int dt;
+    bool planes[3];
+    double lo[3], hi[3];  // resolved bounds: the min/max arrays or the comptime range table of the format
+    Chain chain;
+    VSNode *self = nullptr;
+};
+
+// One filter instance's kernels on device planes: cur[p] is replaced by the stage's output for the planes it
+// processes (the others pass through untouched, which is what newVideoFrame2's plane copy gives the reference).
+// Returns a message on failure, nullptr on success.
+const char *stage_boxblur(const BoxBlurData *d, Gpu *g, const Z &z, int nplanes, DPlane cur[3], bool touched[3]) {
+    std::vector<vszip_plane> tab;
+    DPlane outs[3];
+    for (int p = 0; p < nplanes; ++p) {
+        if (!d->planes[p]) continue;
+        outs[p] = z.blank(g, cur[p].w, cur[p].h, cur[p].bps);
+        if (!outs[p].ptr) return "device staging failed";
+        tab.push_back(mk_plane(cur[p], &outs[p], nullptr));
+    }
+    if (tab.empty()) return nullptr;
+    if (vszip_boxblur(g->ctx, d->dt, tab.data(), (int)tab.size(), d->hradius, d->hpasses, d->vradius, d->vpasses) != VSZIP_OK) return "GPU kernel failed";
+    for (int p = 0; p < nplanes; ++p)
+        if (d->planes[p]) {
+            cur[p] = outs[p];
+            touched[p] = true;
+        }
+    return nullptr;
+}
+
+const char *stage_bilateral(BilateralData *d, Gpu *g, const Z &z, int nplanes, DPlane cur[3], const DPlane *ref, bool touched[3]) {
+    vszip_bilateral_cfg *cfg;
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        auto &v = d->per_device[g->device];
+        if (v.empty()) {
+            // build the three configs aside and publish them only when every LUT is on the device: a failed
+            // upload must not leave a non-empty entry that later frames would take for a complete one
+            std::vector<vszip_bilateral_cfg> fresh(d->cfg, d->cfg + 3);
+            bool ok_luts = true;
+            for (int p = 0; p < 3 && ok_luts; ++p) ok_luts = vszip_bilateral_luts(g->ctx, &fresh[p], d->hist_len) == VSZIP_OK;
+            if (!ok_luts) {
+                for (auto &c : fresh) {
+                    if (c.gs_lut) vszip_dev_free(g->ctx, c.gs_lut);
+                    if (c.gr_lut) vszip_dev_free(g->ctx, c.gr_lut);
+                }
+                return "LUT upload failed";
+            }
+            v = std::move(fresh);
+        }
+        cfg = v.data();
+    }
+    std::vector<vszip_plane> tab;
+    std::vector<const vszip_bilateral_cfg *> cfgs;
+    DPlane outs[3];
+    for (int p = 0; p < nplanes; ++p) {
+        if (!cfg[p].process) continue;
+        outs[p] = z.blank(g, cur[p].w, cur[p].h, cur[p].bps);
+        if (!outs[p].ptr) return "device staging failed";
+        tab.push_back(mk_plane(cur[p], &outs[p], ref ? &ref[p] : nullptr));
+        cfgs.push_back(&cfg[p]);
+    }
+    if (tab.empty()) return nullptr;
+    if (vszip_bilateral(g->ctx, d->dt, tab.data(), cfgs.data(), (int)tab.size(), d->peak) != VSZIP_OK) return "GPU kernel failed";
+    for (int p = 0; p < nplanes; ++p)
+        if (cfg[p].process) {
+            cur[p] = outs[p];
+            touched[p] = true;
+        }
+    return nullptr;
+}
+
+const char *stage_limiter(const LimiterData *d, Gpu *g, const Z &z, int nplanes, DPlane cur[3], bool touched[3]) {
+    std::vector<vszip_plane> tab;
+    std::vector<double> lo, hi;
+    DPlane outs[3];
+    for (int p = 0; p < nplanes; ++p) {
+        if (!d->planes[p]) continue;
+        outs[p] = z.blank(g, cur[p].w, cur[p].h, cur[p].bps);
+        if (!outs[p].ptr) return "device staging failed";
+        tab.push_back(mk_plane(cur[p], &outs[p], nullptr));
+        lo.push_back(d->lo[p]);
+        hi.push_back(d->hi[p]);
+    }
+    if (tab.empty()) return nullptr;
+    if (vszip_limiter(g->ctx, d->dt, tab.data(), (int)tab.size(), lo.data(), hi.data()) != VSZIP_OK) return "GPU kernel failed";
+    for (int p = 0; p < nplanes; ++p)
+        if (d->planes[p]) {
+            cur[p] = outs[p];
+            touched[p] = true;
+        }
+    return nullptr;
+}
+
+bool stage_processes(const StageRef &s, int p) {
+    switch (s.kind) {
+        case kStageBoxBlur: return static_cast<const BoxBlurData *>(s.data)->planes[p];
+        case kStageBilateral: return static_cast<const BilateralData *>(s.data)->cfg[p].process != 0;
+        default: return static_cast<const LimiterData *>(s.data)->planes[p];
+    }
+}
+const char *run_stage(const StageRef &s, Gpu *g, const Z &z, int nplanes, DPlane cur[3], bool touched[3]) {
+    switch (s.kind) {
+        case kStageBoxBlur: return stage_boxblur(static_cast<const BoxBlurData *>(s.data), g, z, nplanes, cur, touched);
+        case kStageBilateral: return stage_bilateral(static_cast<BilateralData *>(s.data), g, z, nplanes, cur, nullptr, touched);
+        default: return stage_limiter(static_cast<const LimiterData *>(s.data), g, z, nplanes, cur, touched);
+    }
+}
+
+// getFrame of a pixel filter (BoxBlur, Bilateral, Limiter): the frames of the chain's root are uploaded once, the
+// fused upstream stages and the filter's own stage (`self`) run on the device, and every plane some stage wrote is
+// copied back; planes nobody touched are copied from the root frame by newVideoFrame2, like the reference does.
+const VSFrame *pixel_filter_frame(int n, const Z &z, const Chain &chain, const StageRef &self, VSNode *joint_ref, const char *name, bool heavy) {
+    const VSAPI *api = z.api;
+    const VSFrame *src = api->getFrameFilter(n, chain.root, z.fctx);
+    const VSFrame *ref = joint_ref ? api->getFrameFilter(n, joint_ref, z.fctx) : nullptr;
+    const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+    const int np = vf->numPlanes;
+    bool need[3] = {false, false, false};
+    for (int p = 0; p < np; ++p) {
+        need[p] = stage_processes(self, p);
+        for (const StageRef &s : chain.stages) need[p] = need[p] || stage_processes(s, p);
+    }
+    const VSFrame *psrc[3];
+    const int pidx[3] = {0, 1, 2};
+    for (int p = 0; p < 3; ++p) psrc[p] = need[p] ? nullptr : src;
+    VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, z.core);
+    auto done = [&](const VSFrame *r) {  // (after fail(): the stream is drained before the inputs go)
+        api->freeFrame(src);
+        if (ref) api->freeFrame(ref);
+        return r;
+    };
+    FrameGate gate(n);
+    Gpu *g = gpu_for_frame(n, gate);
+    std::unique_ptr<HeavyFrameScope> hs;
+    if (heavy) hs.reset(new HeavyFrameScope(g));
+    if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
+    DPlane cur[3], rpl[3];
+    bool touched[3] = {false, false, false};
+    for (int p = 0; p < np; ++p) {
+        if (!need[p]) continue;
+        cur[p] = z.upload(g, src, p);
+        if (!cur[p].ptr) return done(fail(z, g, dst, name, "device staging failed"));
+        if (ref && stage_processes(self, p)) {
+            rpl[p] = z.upload(g, ref, p);
+            if (!rpl[p].ptr) return done(fail(z, g, dst, name, "device staging failed"));
+        }
+    }
+    const char *err = nullptr;
+    for (const StageRef &s : chain.stages)
+        if (!err) err = run_stage(s, g, z, np, cur, touched);
+    if (!err) err = self.kind == kStageBilateral ? stage_bilateral(static_cast<BilateralData *>(self.data), g, z, np, cur, ref ? rpl : nullptr, touched) : run_stage(self, g, z, np, cur, touched);
+    if (err) return done(fail(z, g, dst, name, err));
+    count_fused(chain.stages.size());
+    int rc = VSZIP_OK;
+    for (int p = 0; p < np && rc == VSZIP_OK; ++p)
+        if (need[p] && !z.download(g, cur[p], dst, p)) rc = VSZIP_ERR_HIP;  // (a needed plane no stage wrote: the uploaded copy, identical to the source)
+    if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
+    if (rc != VSZIP_OK) return done(fail(z, g, dst, name, "GPU kernel failed"));
+    return done(dst);
+}
+
+// ===========================================================================
+// BoxBlur — src/vapoursynth/boxblur.zig
+// ===========================================================================
 
 const VSFrame *VS_CC boxblurGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<BoxBlurData *>(inst);
     Z z{api, core, fctx};
     if (reason == arInitial) {
-        api->requestFrameFilter(n, d->node, fctx);
+        api->requestFrameFilter(n, d->chain.root, fctx);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *src = api->getFrameFilter(n, d->node, fctx);
-        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
-        const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
-        const int pidx[3] = {0, 1, 2};
-        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        FrameGate gate(n);
-        Gpu *g = gpu_for_frame(n, gate);
-        if (!g) {
-            const VSFrame *failed = fail(z, nullptr, dst, "BoxBlur", "no MI355X device available (the plugin has no CPU fallback)");  // drain / abort the stream first: queued copies may still read src
-            api->freeFrame(src);
-            return failed;
-        }
-        std::vector<vszip_plane> tab;
-        std::vector<DPlane> outs;
-        std::vector<int> which;
-        for (int p = 0; p < vf->numPlanes; ++p) {
-            if (!d->planes[p]) continue;
-            DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps);
-            if (!s.ptr || !o.ptr) {
-                const VSFrame *failed = fail(z, g, dst, "BoxBlur", "device staging failed");  // drain / abort the stream first: queued copies may still read src
-                api->freeFrame(src);
-                return failed;
-            }
-            tab.push_back(mk_plane(s, &o, nullptr));
-            outs.push_back(o);
-            which.push_back(p);
-        }
-        int rc = tab.empty() ? VSZIP_OK : vszip_boxblur(g->ctx, d->dt, tab.data(), (int)tab.size(), d->hradius, d->hpasses, d->vradius, d->vpasses);
-        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
-            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
-        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
-        const VSFrame *result = rc != VSZIP_OK ? fail(z, g, dst, "BoxBlur", "GPU kernel failed") : dst;  // fail() aborts the stream before src goes
-        api->freeFrame(src);
-        return result;
+        return pixel_filter_frame(n, z, d->chain, StageRef{kStageBoxBlur, d->node, d}, nullptr, "BoxBlur", false);
     }
     return nullptr;
 }
 
 void VS_CC boxblurFree(void *inst, VSCore *, const VSAPI *api) {
     auto *d = static_cast<BoxBlurData *>(inst);
+    unregister_stage(d->self);
+    free_chain(api, d->chain);
     api->freeNode(d->node);
     delete d;
 }
@@ -465,8 +698,10 @@ void VS_CC boxblurCreate(const VSMap *in, VSMap *out, void *, VSCore *core, cons
         }
     }
     auto *data = new BoxBlurData(d);
-    VSFilterDependency deps[] = {{d.node, rpStrictSpatial}};
+    data->chain = resolve_chain(api, d.node);  // frames come from the chain's root (== d.node when nothing upstream is a vszip stage)
+    VSFilterDependency deps[] = {{data->chain.root, rpStrictSpatial}};
     api->createVideoFilter(out, "BoxBlur", d.vi, boxblurGetFrame, boxblurFree, fmParallel, deps, 1, data, core);
+    data->self = register_stage(api, out, kStageBoxBlur, data->node, data);
 }
 
 // hz.getArray (helper.zig:340-404): up to 3 values, missing entries repeat the previous one
@@ -502,80 +737,15 @@ bool get_array3(const Z &z, const VSMap *in, VSMap *out, const char *key, const 
 // ===========================================================================
 // Bilateral — src/vapoursynth/bilateral.zig
 // ===========================================================================
-struct BilateralData {
-    VSNode *node1, *node2;
-    const VSVideoInfo *vi;
-    vszip_bilateral_cfg cfg[3];
-    int dt, hist_len;
-    float peak;
-    std::mutex mu;
-    std::map<int, std::vector<vszip_bilateral_cfg>> per_device;  // LUTs live in device memory
-};
 
 const VSFrame *VS_CC bilateralGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<BilateralData *>(inst);
     Z z{api, core, fctx};
     if (reason == arInitial) {
-        api->requestFrameFilter(n, d->node1, fctx);
+        api->requestFrameFilter(n, d->chain.root, fctx);
         if (d->node2) api->requestFrameFilter(n, d->node2, fctx);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *src = api->getFrameFilter(n, d->node1, fctx);
-        const VSFrame *ref = d->node2 ? api->getFrameFilter(n, d->node2, fctx) : nullptr;
-        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
-        const VSFrame *psrc[3];
-        const int pidx[3] = {0, 1, 2};
-        for (int p = 0; p < 3; ++p) psrc[p] = d->cfg[p].process ? nullptr : src;
-        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        auto done = [&](const VSFrame *r) {
-            api->freeFrame(src);
-            if (ref) api->freeFrame(ref);
-            return r;
-        };
-        FrameGate gate(n);
-        Gpu *g = gpu_for_frame(n, gate);
-        HeavyFrameScope heavy(g);
-        if (!g) return done(fail(z, nullptr, dst, "Bilateral", "no MI355X device available (the plugin has no CPU fallback)"));
-        vszip_bilateral_cfg *cfg;
-        {
-            std::lock_guard<std::mutex> lk(d->mu);
-            auto &v = d->per_device[g->device];
-            if (v.empty()) {
-                // build the three configs aside and publish them only when every LUT is on the device: a failed
-                // upload must not leave a non-empty entry that later frames would take for a complete one
-                std::vector<vszip_bilateral_cfg> fresh(d->cfg, d->cfg + 3);
-                bool ok_luts = true;
-                for (int p = 0; p < 3 && ok_luts; ++p) ok_luts = vszip_bilateral_luts(g->ctx, &fresh[p], d->hist_len) == VSZIP_OK;
-                if (!ok_luts) {
-                    for (auto &c : fresh) {
-                        if (c.gs_lut) vszip_dev_free(g->ctx, c.gs_lut);
-                        if (c.gr_lut) vszip_dev_free(g->ctx, c.gr_lut);
-                    }
-                    return done(fail(z, g, dst, "Bilateral", "LUT upload failed"));
-                }
-                v = std::move(fresh);
-            }
-            cfg = v.data();
-        }
-        std::vector<vszip_plane> tab;
-        std::vector<const vszip_bilateral_cfg *> cfgs;
-        std::vector<DPlane> outs;
-        std::vector<int> which;
-        for (int p = 0; p < vf->numPlanes; ++p) {
-            if (!cfg[p].process) continue;
-            DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps), r;
-            if (ref) r = z.upload(g, ref, p);
-            if (!s.ptr || !o.ptr || (ref && !r.ptr)) return done(fail(z, g, dst, "Bilateral", "device staging failed"));
-            tab.push_back(mk_plane(s, &o, ref ? &r : nullptr));
-            cfgs.push_back(&cfg[p]);
-            outs.push_back(o);
-            which.push_back(p);
-        }
-        int rc = tab.empty() ? VSZIP_OK : vszip_bilateral(g->ctx, d->dt, tab.data(), cfgs.data(), (int)tab.size(), d->peak);
-        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
-            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
-        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
-        if (rc != VSZIP_OK) return done(fail(z, g, dst, "Bilateral", "GPU kernel failed"));
-        return done(dst);
+        return pixel_filter_frame(n, z, d->chain, StageRef{kStageBilateral, d->node1, d}, d->node2, "Bilateral", true);
     }
     return nullptr;
 }
@@ -592,6 +762,8 @@ void VS_CC bilateralFree(void *inst, VSCore *, const VSAPI *api) {
             vszip_ctx_destroy(c);
         }
     }
+    unregister_stage(d->self);
+    free_chain(api, d->chain);
     api->freeNode(d->node1);
     if (d->node2) api->freeNode(d->node2);
     delete d;
@@ -651,9 +823,11 @@ void VS_CC bilateralCreate(const VSMap *in, VSMap *out, void *, VSCore *core, co
     d->node2 = z.getNode(in, "ref");
     if (d->node2 && !compare_nodes(z, out, d->node1, d->node2, 1, "Bilateral")) return;
     const int rp2 = (d->node2 && d->vi->numFrames <= api->getVideoInfo(d->node2)->numFrames) ? rpStrictSpatial : rpFrameReuseLastOnly;
-    VSFilterDependency deps[] = {{d->node1, rpStrictSpatial}, {d->node2, rp2}};
     BilateralData *raw = d.release();
+    raw->chain = resolve_chain(api, raw->node1);
+    VSFilterDependency deps[] = {{raw->chain.root, rpStrictSpatial}, {raw->node2, rp2}};
     api->createVideoFilter(out, "Bilateral", raw->vi, bilateralGetFrame, bilateralFree, fmParallel, deps, raw->node2 ? 2 : 1, raw, core);
+    if (!raw->node2) raw->self = register_stage(api, out, kStageBilateral, raw->node1, raw);  // a joint `ref` clip keeps the instance out of fused chains
 }
 
 // ===========================================================================
@@ -805,68 +979,30 @@ struct SsimData {
     // distorted planes when that clip is not eligible.
     VSNode *raw1 = nullptr, *raw2 = nullptr;
     vszip_ssim_source fmt1{}, fmt2{};
+    // raw clips that are the output of fusable vszip pixel filters (Bilateral -> BoxBlur -> SSIMULACRA2, BASELINE
+    // config 5): the frames of the chain's root are uploaded and the upstream stages run on the device
+    Chain c1, c2;
 };
 
 // ---------------------------------------------------------------------------
 // Limiter (src/vapoursynth/limiter.zig, src/filters/limiter.zig) — SURVEY 8f rank 4
 // ---------------------------------------------------------------------------
-struct LimiterData {
-    VSNode *node;
-    const VSVideoInfo *vi;
-    int dt;
-    bool planes[3];
-    double lo[3], hi[3];  // resolved bounds: the min/max arrays or the comptime range table of the format
-};
 
 const VSFrame *VS_CC limiterGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<LimiterData *>(inst);
     Z z{api, core, fctx};
     if (reason == arInitial) {
-        api->requestFrameFilter(n, d->node, fctx);
+        api->requestFrameFilter(n, d->chain.root, fctx);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *src = api->getFrameFilter(n, d->node, fctx);
-        const VSVideoFormat *vf = api->getVideoFrameFormat(src);
-        const VSFrame *psrc[3] = {d->planes[0] ? nullptr : src, d->planes[1] ? nullptr : src, d->planes[2] ? nullptr : src};
-        const int pidx[3] = {0, 1, 2};
-        VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(src, 0), api->getFrameHeight(src, 0), psrc, pidx, src, core);
-        FrameGate gate(n);
-        Gpu *g = gpu_for_frame(n, gate);
-        if (!g) {
-            const VSFrame *failed = fail(z, nullptr, dst, "Limiter", "no MI355X device available (the plugin has no CPU fallback)");  // drain / abort the stream first: queued copies may still read src
-            api->freeFrame(src);
-            return failed;
-        }
-        std::vector<vszip_plane> tab;
-        std::vector<DPlane> outs;
-        std::vector<int> which;
-        std::vector<double> lo, hi;
-        for (int p = 0; p < vf->numPlanes; ++p) {
-            if (!d->planes[p]) continue;
-            DPlane s = z.upload(g, src, p), o = z.blank(g, s.w, s.h, s.bps);
-            if (!s.ptr || !o.ptr) {
-                const VSFrame *failed = fail(z, g, dst, "Limiter", "device staging failed");  // drain / abort the stream first: queued copies may still read src
-                api->freeFrame(src);
-                return failed;
-            }
-            tab.push_back(mk_plane(s, &o, nullptr));
-            outs.push_back(o);
-            which.push_back(p);
-            lo.push_back(d->lo[p]);
-            hi.push_back(d->hi[p]);
-        }
-        int rc = tab.empty() ? VSZIP_OK : vszip_limiter(g->ctx, d->dt, tab.data(), (int)tab.size(), lo.data(), hi.data());
-        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
-            if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
-        if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
-        const VSFrame *result = rc != VSZIP_OK ? fail(z, g, dst, "Limiter", "GPU kernel failed") : dst;  // fail() aborts the stream before src goes
-        api->freeFrame(src);
-        return result;
+        return pixel_filter_frame(n, z, d->chain, StageRef{kStageLimiter, d->node, d}, nullptr, "Limiter", false);
     }
     return nullptr;
 }
 
 void VS_CC limiterFree(void *inst, VSCore *, const VSAPI *api) {
     auto *d = static_cast<LimiterData *>(inst);
+    unregister_stage(d->self);
+    free_chain(api, d->chain);
     api->freeNode(d->node);
     delete d;
 }
@@ -950,8 +1086,10 @@ void VS_CC limiterCreate(const VSMap *in, VSMap *out, void *, VSCore *core, cons
         }
     }
     auto *data = new LimiterData(d);
-    VSFilterDependency deps[] = {{d.node, rpStrictSpatial}};
+    data->chain = resolve_chain(api, d.node);
+    VSFilterDependency deps[] = {{data->chain.root, rpStrictSpatial}};
     api->createVideoFilter(out, "Limiter", d.vi, limiterGetFrame, limiterFree, fmParallel, deps, 1, data, core);
+    data->self = register_stage(api, out, kStageLimiter, data->node, data);
 }
 
 // ---------------------------------------------------------------------------
@@ -1313,8 +1451,12 @@ bool ssim_device_source(const Z &z, VSNode *node, vszip_ssim_source *fmt) {
         dt = VSZIP_F32;
     else
         return false;
+    // frame 0's properties, from the root of the clip's vszip chain (the pixel filters pass properties through;
+    // asking the filter node itself would run its kernels for a frame nobody wants)
+    Chain probe = resolve_chain(api, node);
     char err[256];
-    const VSFrame *f0 = api->getFrame(0, node, err, sizeof err);
+    const VSFrame *f0 = api->getFrame(0, probe.root, err, sizeof err);
+    free_chain(api, probe);
     if (!f0) return false;
     int e1 = 0, e2 = 0;
     const VSMap *props = api->getFramePropertiesRO(f0);
@@ -1332,76 +1474,93 @@ bool ssim_device_source(const Z &z, VSNode *node, vszip_ssim_source *fmt) {
 const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<SsimData *>(inst);
     Z z{api, core, fctx};
+    VSNode *in1 = d->raw1 ? d->c1.root : nullptr;            // reference planes for the score (nullptr: node1's RGBS frame)
+    VSNode *in2 = d->raw2 ? d->c2.root : d->node2;           // distorted planes
+    const bool shared_root = in1 && in1 == in2;               // e.g. SSIMULACRA2(src, src.Bilateral().BoxBlur()): one upload
     if (reason == arInitial) {
         api->requestFrameFilter(n, d->node1, fctx);
-        if (d->raw1) api->requestFrameFilter(n, d->raw1, fctx);
-        api->requestFrameFilter(n, d->raw2 ? d->raw2 : d->node2, fctx);
+        if (in1) api->requestFrameFilter(n, in1, fctx);
+        if (!shared_root) api->requestFrameFilter(n, in2, fctx);
     } else if (reason == arAllFramesReady) {
         const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx);
-        const VSFrame *r1 = d->raw1 ? api->getFrameFilter(n, d->raw1, fctx) : nullptr;
-        const VSFrame *s2 = api->getFrameFilter(n, d->raw2 ? d->raw2 : d->node2, fctx);
+        const VSFrame *r1 = in1 ? api->getFrameFilter(n, in1, fctx) : nullptr;
+        const VSFrame *s2 = shared_root ? nullptr : api->getFrameFilter(n, in2, fctx);
         VSFrame *dst = api->copyFrame(s1, core);
         auto done = [&](const VSFrame *r) {
             api->freeFrame(s1);
             if (r1) api->freeFrame(r1);
-            api->freeFrame(s2);
+            if (s2) api->freeFrame(s2);
             return r;
         };
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
         if (!g) return done(fail(z, nullptr, dst, "SSIMULACRA2", "no MI355X device available (the plugin has no CPU fallback)"));
         const int w = api->getFrameWidth(s1, 0), h = api->getFrameHeight(s1, 0);
-        // one clip's planes at one common pitch (elements), as they are
-        auto stage = [&](const VSFrame *f, int nplanes, int bps, const void **out, ptrdiff_t *stride) {
-            const size_t pitch = ((size_t)w * bps + 255) & ~(size_t)255;
-            *stride = (ptrdiff_t)(pitch / bps);
-            for (int p = 0; p < nplanes; ++p) {
-                void *a = g->alloc(pitch * h);
-                if (!a || vszip_copy_h2d_2d(g->ctx, a, pitch, api->getReadPtr(f, p), (size_t)api->getStride(f, p), (size_t)w * bps, h) != VSZIP_OK) return false;
-                out[p] = a;
-            }
-            return true;
-        };
-        auto bps_of = [](const vszip_ssim_source &f) { return f.dtype == VSZIP_U8 ? 1 : (f.dtype == VSZIP_U16 ? 2 : 4); };
         auto same = [](const vszip_ssim_source &a, const vszip_ssim_source &b) {
             return a.family == b.family && a.dtype == b.dtype && a.bits == b.bits && a.limited == b.limited && a.linearize == b.linearize;
         };
+        // one clip's planes on the device, as they are: upload (or take the other clip's upload of the same root
+        // frame), then the fused upstream stages
+        DPlane base1[3], cur1[3], cur2[3];
+        auto raw_planes = [&](const VSFrame *f, const DPlane *shared, const Chain &c, const vszip_ssim_source &fm, DPlane base[3], DPlane cur[3]) -> const char * {
+            const int np = fm.family == VSZIP_CF_GRAY ? 1 : 3;
+            bool touched[3] = {false, false, false};
+            for (int p = 0; p < np; ++p) {
+                base[p] = shared ? shared[p] : z.upload(g, f, p);
+                if (!base[p].ptr) return "device staging failed";
+                cur[p] = base[p];
+            }
+            for (const StageRef &st : c.stages)
+                if (const char *e = run_stage(st, g, z, np, cur, touched)) return e;
+            return nullptr;
+        };
+        auto host_rgbs = [&](const VSFrame *f, DPlane cur[3]) -> const char * {
+            for (int p = 0; p < 3; ++p) {
+                cur[p] = z.upload(g, f, p);
+                if (!cur[p].ptr) return "device staging failed";
+            }
+            return nullptr;
+        };
+        const char *err = nullptr;
+        DPlane base2[3];
+        err = d->raw1 ? raw_planes(r1, nullptr, d->c1, d->fmt1, base1, cur1) : host_rgbs(s1, cur1);
+        if (!err) err = d->raw2 ? raw_planes(s2, shared_root ? base1 : nullptr, d->c2, d->fmt2, base2, cur2) : host_rgbs(s2, cur2);
+        if (err) return done(fail(z, g, dst, "SSIMULACRA2", err));
+        count_fused((d->raw1 ? d->c1.stages.size() : 0) + (d->raw2 ? d->c2.stages.size() : 0));
         double score = 0;
         int rc;
         if (d->raw1 && d->raw2 && same(d->fmt1, d->fmt2)) {
             // both clips in one source format: the conversion is fused into the first SSIMULACRA2 pass
             const int np = d->fmt1.family == VSZIP_CF_GRAY ? 1 : 3;
-            const void *a3[3], *b3[3];
-            ptrdiff_t st1, st2;
-            if (!stage(r1, np, bps_of(d->fmt1), a3, &st1) || !stage(s2, np, bps_of(d->fmt2), b3, &st2)) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
-            rc = vszip_ssimulacra2_src(g->ctx, &d->fmt1, a3, b3, st1, w, h, 1, &score);
+            const void *a3[3] = {nullptr, nullptr, nullptr}, *b3[3] = {nullptr, nullptr, nullptr};
+            for (int p = 0; p < np; ++p) {
+                a3[p] = cur1[p].ptr;
+                b3[p] = cur2[p].ptr;
+            }
+            rc = vszip_ssimulacra2_src(g->ctx, &d->fmt1, a3, b3, cur1[0].stride, w, h, 1, &score);
         } else {
-            // mixed formats: convert what can be converted on the device, upload the host's RGBS for the rest
+            // mixed formats: convert what can be converted on the device, the host's RGBS for the rest
             const float *lin[2][3];
             ptrdiff_t lstride = 0;
             for (int k = 0; k < 2; ++k) {
-                const VSFrame *f = k ? s2 : (r1 ? r1 : s1);
                 const bool raw = k ? d->raw2 != nullptr : d->raw1 != nullptr;
                 const vszip_ssim_source &fm = k ? d->fmt2 : d->fmt1;
+                DPlane *cur = k ? cur2 : cur1;
                 if (!raw) {
-                    const void *p3[3];
-                    ptrdiff_t st;
-                    if (!stage(f, 3, 4, p3, &st)) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
-                    for (int p = 0; p < 3; ++p) lin[k][p] = static_cast<const float *>(p3[p]);
-                    lstride = st;
+                    for (int p = 0; p < 3; ++p) lin[k][p] = static_cast<const float *>(cur[p].ptr);
+                    lstride = cur[0].stride;
                 } else {
-                    const void *p3[3];
-                    ptrdiff_t st;
+                    const void *p3[3] = {cur[0].ptr, cur[1].ptr, cur[2].ptr};
                     float *o3[3];
-                    const size_t pitch = ((size_t)w * 4 + 255) & ~(size_t)255;
-                    if (!stage(f, fm.family == VSZIP_CF_GRAY ? 1 : 3, bps_of(fm), p3, &st)) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+                    DPlane o[3];
                     for (int p = 0; p < 3; ++p) {
-                        o3[p] = static_cast<float *>(g->alloc(pitch * h));
-                        if (!o3[p]) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+                        o[p] = z.blank(g, w, h, 4);
+                        if (!o[p].ptr) return done(fail(z, g, dst, "SSIMULACRA2", "device staging failed"));
+                        o3[p] = static_cast<float *>(o[p].ptr);
                         lin[k][p] = o3[p];
                     }
-                    lstride = (ptrdiff_t)(pitch / 4);
-                    if (vszip_to_rgbs_linear(g->ctx, &fm, p3, st, o3, lstride, w, h) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "colour pre-stage failed"));
+                    lstride = o[0].stride;
+                    if (vszip_to_rgbs_linear(g->ctx, &fm, p3, cur[0].stride, o3, lstride, w, h) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "colour pre-stage failed"));
                 }
             }
             rc = vszip_ssimulacra2(g->ctx, lin[0], lin[1], lstride, w, h, 1, &score);
@@ -1419,6 +1578,8 @@ void VS_CC ssimFree(void *inst, VSCore *, const VSAPI *api) {
     api->freeNode(d->node2);
     if (d->raw1) api->freeNode(d->raw1);
     if (d->raw2) api->freeNode(d->raw2);
+    free_chain(api, d->c1);
+    free_chain(api, d->c2);
     delete d;
 }
 
@@ -1441,9 +1602,16 @@ void VS_CC ssimCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const V
     }
     // The device pre-stage works on the clips as passed in. A clip that is already linear-light RGBS needs
     // none (the host path below returns it unchanged, so it is what gets uploaded anyway).
-    auto is_linear_rgbs = [&](VSNode *nd, const vszip_ssim_source &f) { (void)nd; return f.family == VSZIP_CF_RGB && f.dtype == VSZIP_F32 && !f.linearize; };
-    if (ssim_device_source(z, d.node1, &d.fmt1) && !is_linear_rgbs(d.node1, d.fmt1)) d.raw1 = api->addNodeRef(d.node1);
-    if (ssim_device_source(z, d.node2, &d.fmt2) && !is_linear_rgbs(d.node2, d.fmt2)) d.raw2 = api->addNodeRef(d.node2);
+    // ... unless it is the output of a fusable vszip chain: then taking it "raw" is what keeps its frames on the device.
+    auto wants_raw = [&](VSNode *nd, const vszip_ssim_source &f) {
+        if (!(f.family == VSZIP_CF_RGB && f.dtype == VSZIP_F32 && !f.linearize)) return true;
+        Chain c = resolve_chain(api, nd);
+        const bool fused = c.fused();
+        free_chain(api, c);
+        return fused;
+    };
+    if (ssim_device_source(z, d.node1, &d.fmt1) && wants_raw(d.node1, d.fmt1)) d.raw1 = api->addNodeRef(d.node1);
+    if (ssim_device_source(z, d.node2, &d.fmt2) && wants_raw(d.node2, d.fmt2)) d.raw2 = api->addNodeRef(d.node2);
     bool ok = true;
     d.node1 = to_linear_rgbs(z, d.node1, out, &ok);  // the output clip, and the score's input when raw1 is not set
     if (ok && !d.raw2) d.node2 = to_linear_rgbs(z, d.node2, out, &ok);
@@ -1455,11 +1623,14 @@ void VS_CC ssimCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const V
         return;
     }
     auto *data = new SsimData(d);
+    if (data->raw1) data->c1 = resolve_chain(api, data->raw1);
+    if (data->raw2) data->c2 = resolve_chain(api, data->raw2);
     VSFilterDependency deps[3];
     int nd = 0;
     deps[nd++] = {d.node1, rpStrictSpatial};
-    if (d.raw1) deps[nd++] = {d.raw1, rpStrictSpatial};
-    deps[nd++] = {d.raw2 ? d.raw2 : d.node2, rpStrictSpatial};
+    if (data->raw1) deps[nd++] = {data->c1.root, rpStrictSpatial};
+    VSNode *in2 = data->raw2 ? data->c2.root : d.node2;
+    if (!(data->raw1 && data->c1.root == in2)) deps[nd++] = {in2, rpStrictSpatial};
     api->createVideoFilter(out, "SSIMULACRA2", api->getVideoInfo(d.node1), ssimGetFrame, ssimFree, fmParallel, deps, nd, data, core);
 }
 
@@ -1832,6 +2003,12 @@ const char *kEedi3Args =
 
 // src/vszip.zig:35-223 — the seven hot-path filters of the pack, same id / namespace / signatures.
 // pluginVersion: zon.version "19.0.0" packed by vapoursynth-zig (un-vendored) — major only here.
+// Diagnostics for tests and tools: how many getFrame calls ran fused upstream stages, and how many stages.
+extern "C" __attribute__((visibility("default"))) void vszip_plugin_fusion_stats(long *frames, long *stages) {
+    if (frames) *frames = g_fused_frames.load();
+    if (stages) *stages = g_fused_stages.load();
+}
+
 VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
     // Every worker thread owns a HIP stream, and the runtime folds all streams of a process onto
     // GPU_MAX_HW_QUEUES hardware queues (default 4), in which kernels of different streams run in
