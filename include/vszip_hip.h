@@ -204,6 +204,32 @@ int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *planes,
                     const vszip_bilateral_cfg *const *cfgs, int nplanes, float peak);
 
 /*
+ * Chained pixel filters on resident planes (frames stay on the device between
+ * chained vszip filters). Every filter entry point takes device pointers, so a host may simply call them one
+ * after another on one context; vszip_chain_run does that for the frame-in / frame-out filters in ONE call and
+ * owns the intermediate planes: upload once (vszip_copy_h2d_2d), vszip_chain_run, download once. What the
+ * reference does as separate filter instances with a host frame in between — clip.vszip.Bilateral().vszip.BoxBlur()
+ * = bilateralGetFrame (src/vapoursynth/bilateral.zig) feeding BoxBlur's getFrame (src/vapoursynth/boxblur.zig:29-50).
+ *   stages[s].process[k]  whether stage s filters plane slot k (0..2: Y/U/V or R/G/B); other planes pass through,
+ *                         as the reference's newVideoFrame2 plane copy does;
+ *   planes[i]             src = resident input, dst = where the chain's result goes; plane_slot[i] in 0..2 picks
+ *                         the per-plane parameters (a table may hold the planes of many frames).
+ * libvszip.so applies the same scheme across filter INSTANCES: a vszip filter created on the output of another
+ * vszip pixel filter runs that filter's kernels itself on its own upload ("Fused chains").
+ */
+enum { VSZIP_STAGE_BOXBLUR = 0, VSZIP_STAGE_BILATERAL = 1, VSZIP_STAGE_LIMITER = 2 };
+typedef struct vszip_chain_stage {
+    int32_t kind;
+    int32_t process[3];
+    int32_t hradius, hpasses, vradius, vpasses; /* BoxBlur */
+    const struct vszip_bilateral_cfg *bilateral[3]; /* Bilateral: per plane slot, LUTs resident (vszip_bilateral_luts) */
+    float peak;                                     /* Bilateral: as vszip_bilateral */
+    double lo[3], hi[3];                            /* Limiter: resolved bounds per plane slot */
+} vszip_chain_stage;
+int vszip_chain_run(vszip_ctx *ctx, int dtype, const vszip_chain_stage *stages, int nstages,
+                    const vszip_plane *planes, const int *plane_slot, int nplanes);
+
+/*
  * SSIMULACRA2 — replaces filter_ssim.process (src/filters/ssimulacra2.zig:46) called from
  * ssimulacra2GetFrame (src/vapoursynth/ssimulacra2.zig:40-66). Inputs are linear-light
  * RGBS planes (what hz.toRGBS + sRGBtoLinearRGB hand to the kernel, :115-118): ref3 / dis3

@@ -159,6 +159,12 @@ EXP int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *pl, const 
     for (int i = 0; i < n; ++i) (void)*(volatile const int *)&cfgs[i]->radius;
     return kernel_failed(ctx, "Bilateral");
 }
+EXP int vszip_chain_run(vszip_ctx *ctx, int dtype, const vszip_chain_stage *st, int ns, const vszip_plane *pl, const int *slot, int n) {
+    touch_table(pl, n, bps_of(dtype));
+    for (int i = 0; i < n; ++i) (void)*(volatile const int *)&slot[i];
+    for (int s = 0; s < ns; ++s) (void)*(volatile const int *)&st[s].kind;
+    return kernel_failed(ctx, "chain");
+}
 EXP int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *r, const float *const *d, ptrdiff_t stride, int w, int h, int np, double *scores) {
     for (int i = 0; i < 3 * np; ++i) {
         touch(r[i], stride, w, h, 4, false);

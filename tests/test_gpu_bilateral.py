@@ -128,3 +128,24 @@ def test_errors(dev):
     src = np.zeros((5, 5), np.uint8)
     with pytest.raises(vszip_amd.VszipError, match="plane too small"):
         _gpu(dev, [src], 2, 2)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.float16])
+@pytest.mark.parametrize("sig", [(2, 2), (3, 0.2), (1, 0.5)])
+def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
+    """16-bit / float clips: the kernel that keeps the whole 65536-entry range LUT packed in LDS (exact:
+    bits = base[i >> 6] - delta[i]) against the kernel that gathers it from global memory, and both against
+    the oracle; joint `ref` clip and an odd shape included. Steep tables (small sigmaR) do not pack and take
+    the gathered path by themselves — covered by test_matches_oracle's (3, 0.02) and (0.8, 0.05) cases."""
+    sS, sR = sig
+    for shape, joint in [((120, 200), False), ((67, 131), False), ((96, 160), True)]:
+        src = fx.tiled_natural(shape, dtype, 1)
+        refs = [np.ascontiguousarray(np.roll(src, 3, axis=1))] if joint else None
+        (a,), cfgs = _gpu(dev, [src], sS, sR, refs=refs, algorithm=[2])
+        monkeypatch.setenv("VSZIP_BILATERAL_NO_LDS16", "1")
+        (b,), _ = _gpu(dev, [src], sS, sR, refs=refs, algorithm=[2])
+        monkeypatch.delenv("VSZIP_BILATERAL_NO_LDS16")
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (dtype, sig, shape, joint)
+        c = cfgs[0]
+        want = oracle.bilateral_plane(src, c[0], c[1], c[2], c[3], c[4], c[5], ref=refs[0] if joint else None)
+        assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (dtype, sig, shape, joint)

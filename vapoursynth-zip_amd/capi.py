@@ -42,6 +42,15 @@ class BilateralCfg(C.Structure):
     ]
 
 
+class ChainStage(C.Structure):
+    """vszip_chain_stage"""
+    _fields_ = [("kind", C.c_int32), ("process", C.c_int32 * 3), ("hradius", C.c_int32), ("hpasses", C.c_int32), ("vradius", C.c_int32), ("vpasses", C.c_int32),
+                ("bilateral", C.POINTER(BilateralCfg) * 3), ("peak", C.c_float), ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+
+
+STAGE_BOXBLUR, STAGE_BILATERAL, STAGE_LIMITER = 0, 1, 2
+
+
 class SsimSource(C.Structure):
     """vszip_ssim_source: family (0 RGB, 1 Gray), dtype, bits, limited, linearize."""
     _fields_ = [("family", C.c_int32), ("dtype", C.c_int32), ("bits", C.c_int32), ("limited", C.c_int32), ("linearize", C.c_int32)]
@@ -87,6 +96,7 @@ SYMBOLS = {
     "vszip_bilateral_luts": (_i, [_vp, C.POINTER(BilateralCfg), _i]),
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
     "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
+    "vszip_chain_run": (_i, [_vp, _i, C.POINTER(ChainStage), _i, _PP, C.POINTER(C.c_int), _i]),
     "vszip_ssimulacra2_src": (_i, [_vp, C.POINTER(SsimSource), C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
     "vszip_to_rgbs_linear": (_i, [_vp, C.POINTER(SsimSource), C.POINTER(_vp), _pd, C.POINTER(_vp), _pd, _i, _i]),
     "vszip_eedi3": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
@@ -381,6 +391,31 @@ class Device:
         p0 = ref_planes[0]
         self.check(self.lib.vszip_ssimulacra2(self.ctx, r, d, p0.stride, p0.w, p0.h, n, out))
         return list(out)
+
+    def chain_run(self, stages, srcs, dsts, plane_slot):
+        """stages: list of dicts — {"boxblur": (hr, hp, vr, vp)} | {"bilateral": cfg, "peak": p} | {"limiter": (lo3, hi3)}, each with
+        an optional "planes": (bool, bool, bool). One call: every stage on the resident planes, intermediates owned by the context."""
+        arr = (ChainStage * len(stages))()
+        for st, d in zip(arr, stages):
+            pr = d.get("planes", (True, True, True))
+            for k in range(3):
+                st.process[k] = int(bool(pr[k]))
+            if "boxblur" in d:
+                st.kind = STAGE_BOXBLUR
+                st.hradius, st.hpasses, st.vradius, st.vpasses = d["boxblur"]
+            elif "bilateral" in d:
+                st.kind = STAGE_BILATERAL
+                for k in range(3):
+                    st.bilateral[k] = C.pointer(d["bilateral"][k])
+                    st.process[k] = int(bool(pr[k]) and bool(d["bilateral"][k].process))
+                st.peak = d["peak"]
+            else:
+                st.kind = STAGE_LIMITER
+                for k in range(3):
+                    st.lo[k], st.hi[k] = d["limiter"][0][k], d["limiter"][1][k]
+        n = len(srcs)
+        slots = (C.c_int * n)(*plane_slot)
+        self.check(self.lib.vszip_chain_run(self.ctx, _NP2DT[srcs[0].dtype], arr, len(stages), self.plane_table(srcs, dsts), slots, n))
 
     @staticmethod
     def ssim_source(family: str, dtype, bits=None, linearize=True, limited=None) -> SsimSource:

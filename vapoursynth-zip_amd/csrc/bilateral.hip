@@ -18,8 +18,12 @@
 // for 16-bit and float input, too large for LDS) is gathered through L1/L2, where
 // natural content keeps the low-difference end hot.
 // bilateral_truncated_kernel (any radius): one thread per pixel, taps as cached loads.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "common.hpp"
@@ -57,7 +61,8 @@ template <>
 struct BSmp<uint16_t> {
     static constexpr bool is_int = true;
     static __device__ __forceinline__ float f(uint16_t v) { return (float)v; }
-    static __device__ __forceinline__ uint32_t ridx(uint16_t a, uint16_t b) { return a > b ? (uint32_t)(a - b) : (uint32_t)(b - a); }
+    // |a - b| in one instruction: v_sad_u16 sums the absolute differences of the two 16-bit halves (upper halves are 0)
+    static __device__ __forceinline__ uint32_t ridx(uint16_t a, uint16_t b) { return __builtin_amdgcn_sad_u16((uint32_t)a, (uint32_t)b, 0u); }
 };
 template <>
 struct BSmp<float> {
@@ -161,6 +166,143 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParam
             dst[(size_t)y * pl.dstride + x] = (T)truncf(v);
         } else {
             dst[(size_t)y * pl.dstride + x] = (T)q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit / float clips: the WHOLE 65536-entry range LUT in LDS, in an exact compressed form.
+// gr_lut is monotone non-increasing in the index, and so are the bit patterns of its (non-negative) f32
+// entries: bits(gr[i]) = base[i >> 6] - delta[i] with base = the block's first entry (u32 x 1024 = 4 KiB) and
+// delta a u16 (128 KiB) reproduces every bit whenever no 64-entry block spans more than 65535 ulps —
+// vszip_bilateral_luts verifies all 65536 entries and registers the table only then (steep small-sigmaR tables
+// keep the gathered path). 132 KiB of a CU's 160 KiB: one persistent 1024-thread workgroup per CU walks the
+// tiles. Measured (tools/lds_gather_probe.hip, per 64-lane lookup and CU): 38 / 68 / 198 cycles for the gather
+// from L1/L2 on natural / edgy / uniform index distributions against 14 / 15 / 18 for the two LDS reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int kL16Rows = 16;                       // thread rows of the workgroup: 64 x 16 = 1024 threads
+constexpr int kL16TileH = 64;                      // output rows per tile (4 per wave)
+constexpr int kL16LutBytes = 4096 + 131072;        // base + delta
+constexpr int kL16MaxLds = 160 * 1024;
+constexpr int kL16MaxStage = 6;                    // staged samples per thread and clip: tiles up to 1024 * 6 samples
+
+// CR / CS > 0: every plane of the launch has this radius / step (the BASELINE's luma 3 / 2 and chroma 2 / 1):
+// the tap loops unroll and every LDS offset becomes an immediate; 0 = read them from the plane table.
+template <typename T, bool JOINT, int CR, int CS>
+__global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BLParams prm, const int nblocks) {
+    using S = BSmp<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *sbase = reinterpret_cast<uint32_t *>(smem);
+    uint16_t *sdelta = reinterpret_cast<uint16_t *>(smem + 4096);
+    T *tiles = reinterpret_cast<T *>(smem + kL16LutBytes);
+    const int lx = (int)threadIdx.x, tyi = (int)threadIdx.y, tid = tyi * kBX + lx;
+    constexpr int NT = kBX * kL16Rows;
+    {
+        // the planes of one launch share one range LUT (the host groups them by table)
+        const uint32_t *gb = reinterpret_cast<const uint32_t *>(prm.p[0].gr + 65536);
+        const uint4 *gd = reinterpret_cast<const uint4 *>(gb + 1024);
+        sbase[tid] = gb[tid];
+        for (int i = tid; i < 65536 / 8; i += NT) reinterpret_cast<uint4 *>(sdelta)[i] = gd[i];
+    }
+    auto lut = [&](uint32_t i) { return __uint_as_float(sbase[i >> 6] - (uint32_t)sdelta[i]); };
+    // Only ONE workgroup fits a CU, so nothing else hides a tile's global loads: the next tile is fetched into
+    // registers while this one is filtered, and the two LDS tile buffers alternate (one barrier per tile).
+    const int tile_elems_max = prm.lut_offset;  // (reused field) samples of the largest tile of the launch, per clip
+    T pre_r[kL16MaxStage], pre_s[JOINT ? kL16MaxStage : 1];
+    int pi = 0;
+    auto plane_of = [&](int b) {
+        while (pi + 1 < prm.nplanes && b >= prm.p[pi + 1].block0) ++pi;  // tiles are visited in increasing order
+        return pi;
+    };
+    auto fetch = [&](int b) {
+        const BLPlane &pl = prm.p[plane_of(b)];
+        const int lb = b - pl.block0;
+        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH;
+        const int r = CR > 0 ? CR : pl.radius, tw = kBX + 2 * r, n = tw * (kL16TileH + 2 * r);
+        const T *src = static_cast<const T *>(pl.src), *ref = static_cast<const T *>(pl.ref);
+#pragma unroll
+        for (int k = 0; k < kL16MaxStage; ++k) {
+            const int i = min(tid + k * NT, n - 1);
+            const int t = i / tw, c = i - t * tw;
+            const int gy = min(max(y0 - r + t, 0), pl.h - 1), gx = min(max(x0 - r + c, 0), pl.w - 1);
+            pre_r[k] = ref[(size_t)gy * pl.rstride + gx];
+            if constexpr (JOINT) pre_s[k] = src[(size_t)gy * pl.sstride + gx];
+        }
+    };
+    int b = blockIdx.x, buf = 0;
+    if (b < nblocks) fetch(b);
+#pragma unroll 1
+    for (; b < nblocks; b += gridDim.x, buf ^= 1) {
+        const BLPlane &pl = prm.p[plane_of(b)];
+        const int lb = b - pl.block0;
+        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH;
+        const int r = CR > 0 ? CR : pl.radius;
+        const int tw = kBX + 2 * r, th = kL16TileH + 2 * r, n = tw * th;
+        T *tr = tiles + (size_t)buf * tile_elems_max * (JOINT ? 2 : 1);
+        T *ts = JOINT ? tr + tile_elems_max : tr;
+#pragma unroll
+        for (int k = 0; k < kL16MaxStage; ++k) {
+            const int i = tid + k * NT;
+            if (i < n) {
+                tr[i] = pre_r[k];
+                if constexpr (JOINT) ts[i] = pre_s[k];
+            }
+        }
+        __syncthreads();  // (also: the LUT is in place the first time; the other buffer's readers finished a tile ago)
+        const int pi_here = pi;
+        if (b + (int)gridDim.x < nblocks) fetch(b + gridDim.x);  // in flight while this tile is filtered
+        const BLPlane &pc = prm.p[pi_here];
+        const int x = x0 + lx;
+        if (x < pc.w) {
+            T *dst = static_cast<T *>(pc.dst);
+            const float *gs = pc.gs;
+            const int radius2 = r + 1, step = CS > 0 ? CS : pc.step;
+            const float w0 = gs[0] * lut(0);
+            // one (yy, xx) quadrant set: 4 diagonal taps, the reference's operation order (:236-264)
+            auto taps = [&](const T cx, int c0, int yy, int xx, float swei, float &wsum, float &sum) {
+                const int oa = c0 - yy * tw, ob = c0 + yy * tw;
+                const T ra1 = tr[oa + xx], ra2 = tr[ob + xx], ra3 = tr[oa - xx], ra4 = tr[ob - xx];
+                const float rw1 = lut(S::ridx(cx, ra1));
+                const float rw2 = lut(S::ridx(cx, ra2));
+                const float rw3 = lut(S::ridx(cx, ra3));
+                const float rw4 = lut(S::ridx(cx, ra4));
+                wsum += swei * (rw1 + rw2 + rw3 + rw4);
+                if constexpr (JOINT)
+                    sum += swei * (S::f(ts[oa + xx]) * rw1 + S::f(ts[ob + xx]) * rw2 + S::f(ts[oa - xx]) * rw3 + S::f(ts[ob - xx]) * rw4);
+                else
+                    sum += swei * (S::f(ra1) * rw1 + S::f(ra2) * rw2 + S::f(ra3) * rw3 + S::f(ra4) * rw4);
+            };
+            float sw[CR > 0 ? (CR + 1) * (CR + 1) : 1];
+            if constexpr (CR > 0) {
+#pragma unroll
+                for (int i = 0; i < (CR + 1) * (CR + 1); ++i) sw[i] = gs[i];
+            }
+#pragma unroll 1
+            for (int k = 0; k < kL16TileH / kL16Rows; ++k) {
+                const int ly = tyi + kL16Rows * k;
+                const int y = y0 + ly;
+                if (y >= pc.h) break;
+                const int c0 = (ly + r) * tw + lx + r;
+                const T cx = tr[c0];
+                float wsum = w0;
+                float sum = S::f(ts[c0]) * wsum;
+                if constexpr (CR > 0 && CS > 0) {
+#pragma unroll
+                    for (int yy = 1; yy <= CR; yy += CS)
+#pragma unroll
+                        for (int xx = 1; xx <= CR; xx += CS) taps(cx, c0, yy, xx, sw[yy * (CR + 1) + xx], wsum, sum);
+                } else {
+                    for (int yy = 1; yy < radius2; yy += step)
+                        for (int xx = 1; xx < radius2; xx += step) taps(cx, c0, yy, xx, gs[yy * radius2 + xx], wsum, sum);
+                }
+                const float q = __fdiv_rn(sum, wsum);
+                if constexpr (S::is_int) {
+                    const float v = fminf(fmaxf(q + 0.5f, 0.0f), prm.peak);  // finalize :30-36
+                    dst[(size_t)y * pc.dstride + x] = (T)truncf(v);
+                } else {
+                    dst[(size_t)y * pc.dstride + x] = (T)q;
+                }
+            }
         }
     }
 }
@@ -471,6 +613,46 @@ int run_pbfic(vszip_ctx *ctx, const vszip_plane &s, const vszip_bilateral_cfg &c
     return VSZIP_OK;
 }
 
+// Range LUTs whose packed form (see bilateral_lds16_kernel) was verified exact and uploaded behind the f32 table
+// in the same device allocation: keyed by the gr_lut pointer, dropped when the pointer is freed.
+struct PackedLuts {
+    std::mutex mu;
+    std::set<const void *> exact;
+};
+PackedLuts &packed_luts() {
+    static PackedLuts *p = new PackedLuts();
+    return *p;
+}
+bool lut_is_packed(const void *gr) {
+    PackedLuts &p = packed_luts();
+    std::lock_guard<std::mutex> lk(p.mu);
+    return p.exact.count(gr) != 0;
+}
+
+template <typename T, bool JOINT, int CR, int CS>
+int launch_lds16_k(vszip_ctx *ctx, const BLParams &prm, int blocks, size_t lds) {
+    const dim3 grid(std::min(blocks, 256)), block(kBX, kL16Rows);
+    VSZIP_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bilateral_lds16_kernel<T, JOINT, CR, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((bilateral_lds16_kernel<T, JOINT, CR, CS>), grid, block, lds, ctx->stream, prm, blocks);
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    return VSZIP_OK;
+}
+
+template <typename T>
+int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_radius) {
+    const int tile_elems = (kBX + 2 * max_radius) * (kL16TileH + 2 * max_radius);
+    prm.lut_offset = tile_elems;  // (the field is free in this kernel: samples of the largest tile, per clip)
+    const size_t lds = kL16LutBytes + (size_t)2 * tile_elems * sizeof(T) * (joint ? 2 : 1);
+    int r = prm.p[0].radius, st = prm.p[0].step;
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (prm.p[i].radius != r || prm.p[i].step != st) r = st = 0;
+    vszip_probe_scope probe(ctx);
+    if (!joint && r == 3 && st == 2) return launch_lds16_k<T, false, 3, 2>(ctx, prm, blocks, lds);  // sigmaS = 2 luma (BASELINE)
+    if (!joint && r == 2 && st == 1) return launch_lds16_k<T, false, 2, 1>(ctx, prm, blocks, lds);  // sigmaS = 1: its 4:2:0 chroma
+    if (!joint && r == 3 && st == 1) return launch_lds16_k<T, false, 3, 1>(ctx, prm, blocks, lds);  // sigmaS = 1.5
+    return joint ? launch_lds16_k<T, true, 0, 0>(ctx, prm, blocks, lds) : launch_lds16_k<T, false, 0, 0>(ctx, prm, blocks, lds);
+}
+
 template <typename T>
 int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled, bool joint, int max_radius) {
     {
@@ -505,6 +687,13 @@ int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled
 
 // (vszip_bilateral_derive — bilateralCreate's per-plane derivation — is device-free: host_params.cpp)
 
+// vszip_dev_free forgets a packed range LUT with its allocation
+void vszip_bilateral_forget_lut(const void *dptr) {
+    PackedLuts &pl = packed_luts();
+    std::lock_guard<std::mutex> lk(pl.mu);
+    pl.exact.erase(dptr);
+}
+
 // LUTs exactly as bilateral.zig:306-339 computes them (f64 exp on the host, cast to f32),
 // uploaded to device memory owned by the caller (vszip_dev_free).
 VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, int hist_len) {
@@ -521,9 +710,40 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
         gr[i] = (float)(std::exp(x * x / -2) / (std::sqrt(2.0 * M_PI) * cfg->sigmaR));
     }
     for (const float up = gr[upper]; (int)i < hist_len; ++i) gr[i] = up;
+    // 65536-entry tables: the exact packed form for bilateral_lds16_kernel (base[i >> 6] - delta[i]), kept behind
+    // the f32 table in the same allocation when every entry round-trips
+    std::vector<uint32_t> pbase;
+    std::vector<uint16_t> pdelta;
+    bool packed = hist_len == 65536 && !getenv("VSZIP_BILATERAL_NO_LDS16");
+    if (packed) {
+        pbase.resize(1024);
+        pdelta.resize(65536);
+        for (int b = 0; b < 1024 && packed; ++b) {
+            uint32_t hi;
+            std::memcpy(&hi, &gr[(size_t)b * 64], 4);
+            pbase[b] = hi;
+            for (int j = 0; j < 64; ++j) {
+                uint32_t v;
+                std::memcpy(&v, &gr[(size_t)b * 64 + j], 4);
+                if (v > hi || hi - v > 65535u || (v >> 31)) {
+                    packed = false;
+                    break;
+                }
+                pdelta[(size_t)b * 64 + j] = (uint16_t)(hi - v);
+            }
+        }
+    }
     void *d = nullptr;
-    if (hipMalloc(&d, gr.size() * sizeof(float)) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: range LUT allocation failed");
-    VSZIP_HIP_CHECK(ctx, hipMemcpy(d, gr.data(), gr.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t gr_bytes = gr.size() * sizeof(float);
+    if (hipMalloc(&d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0)) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: range LUT allocation failed");
+    VSZIP_HIP_CHECK(ctx, hipMemcpy(d, gr.data(), gr_bytes, hipMemcpyHostToDevice));
+    if (packed) {
+        VSZIP_HIP_CHECK(ctx, hipMemcpy(static_cast<char *>(d) + gr_bytes, pbase.data(), 4096, hipMemcpyHostToDevice));
+        VSZIP_HIP_CHECK(ctx, hipMemcpy(static_cast<char *>(d) + gr_bytes + 4096, pdelta.data(), 131072, hipMemcpyHostToDevice));
+        PackedLuts &pl = packed_luts();
+        std::lock_guard<std::mutex> lk(pl.mu);
+        pl.exact.insert(d);
+    }
     cfg->gr_lut = static_cast<float *>(d);
     if (cfg->algorithm == 2) {
         const int up2 = cfg->radius + 1;
@@ -606,6 +826,44 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         }
         prm.nplanes = n;
         int rc;
+        // 16-bit / float clips whose range LUTs are all registered in packed form: one persistent launch per
+        // distinct table, the whole table in LDS
+        bool lds16 = tiled && dtype != VSZIP_U8 && prm.lut_len == 65536;
+        {
+            const size_t bps = dtype == VSZIP_F32 ? 4 : 2;
+            const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (kL16TileH + 2 * max_radius);
+            lds16 = lds16 && tile_elems <= (size_t)kBX * kL16Rows * kL16MaxStage && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
+            for (int i = 0; i < n && lds16; ++i) lds16 = lut_is_packed(prm.p[i].gr);
+        }
+        if (lds16) {
+            std::vector<const float *> tables;
+            for (int i = 0; i < n; ++i)
+                if (std::find(tables.begin(), tables.end(), prm.p[i].gr) == tables.end()) tables.push_back(prm.p[i].gr);
+            rc = VSZIP_OK;
+            for (const float *tbl : tables) {
+                BLParams q;
+                q.peak = prm.peak;
+                q.lut_len = prm.lut_len;
+                q.lut_offset = 0;
+                q.nplanes = 0;
+                int qb = 0;
+                for (int i = 0; i < n; ++i) {
+                    if (prm.p[i].gr != tbl) continue;
+                    BLPlane &dp = q.p[q.nplanes++];
+                    dp = prm.p[i];
+                    dp.block0 = qb;
+                    qb += dp.nbx * ((dp.h + kL16TileH - 1) / kL16TileH);
+                }
+                switch (dtype) {
+                    case VSZIP_U16: rc = launch_lds16<uint16_t>(ctx, q, qb, joint, max_radius); break;
+                    case VSZIP_F16: rc = launch_lds16<_Float16>(ctx, q, qb, joint, max_radius); break;
+                    default: rc = launch_lds16<float>(ctx, q, qb, joint, max_radius); break;
+                }
+                if (rc != VSZIP_OK) return rc;
+            }
+            done += n;
+            continue;
+        }
         switch (dtype) {
             case VSZIP_U8: rc = launch_truncated<uint8_t>(ctx, prm, blocks, tiled, joint, max_radius); break;
             case VSZIP_U16: rc = launch_truncated<uint16_t>(ctx, prm, blocks, tiled, joint, max_radius); break;

@@ -48,6 +48,8 @@ struct vszip_ctx {
         size_t wb, rows;
     };
     std::vector<PendingOut> pending_out;
+    void *chain_buf = nullptr;  // vszip_chain_run: intermediate planes (grow-only)
+    size_t chain_bytes = 0;
     void *ssim_lut = nullptr;  // SSIMULACRA2 colour pre-stage: cached conversion table (ssimulacra2.hip)
     int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
 };
@@ -56,6 +58,8 @@ int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
 int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes);
 int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
 void vszip_ssim_release(vszip_ctx *ctx);  // frees ctx->ssim_lut
+void vszip_chain_release(vszip_ctx *ctx);  // frees ctx->chain_buf
+void vszip_bilateral_forget_lut(const void *dptr);  // vszip_dev_free: a packed range LUT goes with its allocation
 // Bracket the launch of a filter's dominant kernel; no-ops unless the probe is enabled.
 void vszip_probe_mark(vszip_ctx *ctx);
 struct vszip_probe_scope {

@@ -78,6 +78,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
     vszip_ssim_release(ctx);
+    vszip_chain_release(ctx);
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -142,6 +143,7 @@ VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
 VSZIP_EXPORT int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
     if (!ctx) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    vszip_bilateral_forget_lut(dptr);
     VSZIP_HIP_CHECK(ctx, hipFree(dptr));
     return VSZIP_OK;
 }
