@@ -664,3 +664,33 @@ def test_fused_pipeline_into_ssimulacra2(oracle):
     want = [oracle.boxblur(oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i]), 2, 1, 2, 1)
             for i, p in enumerate(base)]
     assert s == pytest.approx(oracle.ssimulacra2(base, want), abs=1e-7)
+
+
+def test_frames_shard_over_devices_like_one_device(oracle):
+    """frame n runs on GPU n mod #GPUs (vszip_plugin.cpp device_of_frame), with per-device slots,
+    contexts and Bilateral LUTs. On a multi-GPU host every frame must equal the single-device result; a worker
+    thread serves frames of every GPU, so the C ABI sets the device itself in its copy / sync paths."""
+    import ctypes as C
+
+    import vszip_amd
+
+    n_dev = 0
+    lib = vszip_amd.capi.load()
+    for d in range(16):
+        ctx = C.c_void_p()
+        if lib.vszip_ctx_create(d, C.byref(ctx)) != 0:
+            break
+        lib.vszip_ctx_destroy(ctx)
+        n_dev += 1
+    if n_dev < 2:
+        pytest.skip("one visible GPU: the n mod #GPUs path needs a multi-GPU host")
+    frames = [_yuv420p16(seed=7 * f) for f in range(2 * n_dev)]
+    src = vs.source(frames, vs.YUV420P16)
+    out = src.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=5, vradius=5)
+    prm = oracle.bilateral_params([2], [0.05], yuv=True, ssw=1, ssh=1)
+    out.pull(len(frames), 4)  # several workers, every device
+    for n in range(len(frames)):
+        got = out.get_frame(n)
+        for i, p in enumerate(frames[n]):
+            b = oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i])
+            assert np.array_equal(got[i], oracle.boxblur(b, 5, 1, 5, 1)), (n, i)
