@@ -180,6 +180,7 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParam
 // tiles. Measured (tools/lds_gather_probe.hip, per 64-lane lookup and CU): 38 / 68 / 198 cycles for the gather
 // from L1/L2 on natural / edgy / uniform index distributions against 14 / 15 / 18 for the two LDS reads.
 // ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kL16Rows = 16;                       // thread rows of the workgroup: 64 x 16 = 1024 threads
 constexpr int kL16TileH = 64;                      // output rows per tile (4 per wave)
 constexpr int kL16LutBytes = 4096 + 131072;        // base + delta
@@ -191,10 +192,12 @@ constexpr int kL16MaxStage = 6;                    // staged samples per thread 
 template <typename T, bool JOINT, int CR, int CS>
 __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BLParams prm, const int nblocks) {
     using S = BSmp<T>;
+    // the LUT is a STATIC allocation (addresses fold into the ds_read offsets); the tile buffers follow it
+    __shared__ __attribute__((aligned(16))) struct { uint32_t base[1024]; uint16_t delta[65536]; } slut;
+    uint32_t *sbase = slut.base;
+    uint16_t *sdelta = slut.delta;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *sbase = reinterpret_cast<uint32_t *>(smem);
-    uint16_t *sdelta = reinterpret_cast<uint16_t *>(smem + 4096);
-    T *tiles = reinterpret_cast<T *>(smem + kL16LutBytes);
+    T *tiles = reinterpret_cast<T *>(smem);
     const int lx = (int)threadIdx.x, tyi = (int)threadIdx.y, tid = tyi * kBX + lx;
     constexpr int NT = kBX * kL16Rows;
     {
@@ -277,30 +280,71 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
 #pragma unroll
                 for (int i = 0; i < (CR + 1) * (CR + 1); ++i) sw[i] = gs[i];
             }
-#pragma unroll 1
-            for (int k = 0; k < kL16TileH / kL16Rows; ++k) {
-                const int ly = tyi + kL16Rows * k;
-                const int y = y0 + ly;
-                if (y >= pc.h) break;
-                const int c0 = (ly + r) * tw + lx + r;
-                const T cx = tr[c0];
-                float wsum = w0;
-                float sum = S::f(ts[c0]) * wsum;
-                if constexpr (CR > 0 && CS > 0) {
-#pragma unroll
-                    for (int yy = 1; yy <= CR; yy += CS)
-#pragma unroll
-                        for (int xx = 1; xx <= CR; xx += CS) taps(cx, c0, yy, xx, sw[yy * (CR + 1) + xx], wsum, sum);
-                } else {
-                    for (int yy = 1; yy < radius2; yy += step)
-                        for (int xx = 1; xx < radius2; xx += step) taps(cx, c0, yy, xx, gs[yy * radius2 + xx], wsum, sum);
-                }
+            auto finish = [&](float sum, float wsum, int y) {
                 const float q = __fdiv_rn(sum, wsum);
                 if constexpr (S::is_int) {
                     const float v = fminf(fmaxf(q + 0.5f, 0.0f), prm.peak);  // finalize :30-36
                     dst[(size_t)y * pc.dstride + x] = (T)truncf(v);
                 } else {
                     dst[(size_t)y * pc.dstride + x] = (T)q;
+                }
+            };
+            if constexpr (CR > 0 && CS > 0) {
+                // Two output rows per pass: the lookups stay per sample, the weight arithmetic of the pair runs as
+                // packed f32 (v_pk_mul / v_pk_add: IEEE per element, so the reference's operation order holds).
+                auto taps2 = [&](const T cxa, const T cxb, int ca, int cb, int yy, int xx, float swei, v2f &wsum, v2f &sum) {
+                    const int oa = -yy * tw, ob = yy * tw;
+                    const T a1 = tr[ca + oa + xx], a2 = tr[ca + ob + xx], a3 = tr[ca + oa - xx], a4 = tr[ca + ob - xx];
+                    const T b1 = tr[cb + oa + xx], b2 = tr[cb + ob + xx], b3 = tr[cb + oa - xx], b4 = tr[cb + ob - xx];
+                    const v2f rw1 = {lut(S::ridx(cxa, a1)), lut(S::ridx(cxb, b1))};
+                    const v2f rw2 = {lut(S::ridx(cxa, a2)), lut(S::ridx(cxb, b2))};
+                    const v2f rw3 = {lut(S::ridx(cxa, a3)), lut(S::ridx(cxb, b3))};
+                    const v2f rw4 = {lut(S::ridx(cxa, a4)), lut(S::ridx(cxb, b4))};
+                    const v2f sv = {swei, swei};
+                    wsum += sv * (rw1 + rw2 + rw3 + rw4);
+                    v2f f1, f2, f3, f4;
+                    if constexpr (JOINT) {
+                        f1 = v2f{S::f(ts[ca + oa + xx]), S::f(ts[cb + oa + xx])};
+                        f2 = v2f{S::f(ts[ca + ob + xx]), S::f(ts[cb + ob + xx])};
+                        f3 = v2f{S::f(ts[ca + oa - xx]), S::f(ts[cb + oa - xx])};
+                        f4 = v2f{S::f(ts[ca + ob - xx]), S::f(ts[cb + ob - xx])};
+                    } else {
+                        f1 = v2f{S::f(a1), S::f(b1)};
+                        f2 = v2f{S::f(a2), S::f(b2)};
+                        f3 = v2f{S::f(a3), S::f(b3)};
+                        f4 = v2f{S::f(a4), S::f(b4)};
+                    }
+                    sum += sv * (f1 * rw1 + f2 * rw2 + f3 * rw3 + f4 * rw4);
+                };
+#pragma unroll 1
+                for (int k = 0; k < kL16TileH / kL16Rows; k += 2) {
+                    const int lya = tyi + kL16Rows * k, lyb = lya + kL16Rows;
+                    const int ya = y0 + lya, yb = y0 + lyb;
+                    if (ya >= pc.h) break;
+                    const int ca = (lya + r) * tw + lx + r, cb = (lyb + r) * tw + lx + r;
+                    const T cxa = tr[ca], cxb = tr[cb];
+                    v2f wsum = {w0, w0};
+                    v2f sum = v2f{S::f(ts[ca]), S::f(ts[cb])} * wsum;
+#pragma unroll
+                    for (int yy = 1; yy <= CR; yy += CS)
+#pragma unroll
+                        for (int xx = 1; xx <= CR; xx += CS) taps2(cxa, cxb, ca, cb, yy, xx, sw[yy * (CR + 1) + xx], wsum, sum);
+                    finish(sum.x, wsum.x, ya);
+                    if (yb < pc.h) finish(sum.y, wsum.y, yb);
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < kL16TileH / kL16Rows; ++k) {
+                    const int ly = tyi + kL16Rows * k;
+                    const int y = y0 + ly;
+                    if (y >= pc.h) break;
+                    const int c0 = (ly + r) * tw + lx + r;
+                    const T cx = tr[c0];
+                    float wsum = w0;
+                    float sum = S::f(ts[c0]) * wsum;
+                    for (int yy = 1; yy < radius2; yy += step)
+                        for (int xx = 1; xx < radius2; xx += step) taps(cx, c0, yy, xx, gs[yy * radius2 + xx], wsum, sum);
+                    finish(sum, wsum, y);
                 }
             }
         }
@@ -642,7 +686,7 @@ template <typename T>
 int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_radius) {
     const int tile_elems = (kBX + 2 * max_radius) * (kL16TileH + 2 * max_radius);
     prm.lut_offset = tile_elems;  // (the field is free in this kernel: samples of the largest tile, per clip)
-    const size_t lds = kL16LutBytes + (size_t)2 * tile_elems * sizeof(T) * (joint ? 2 : 1);
+    const size_t lds = (size_t)2 * tile_elems * sizeof(T) * (joint ? 2 : 1);  // dynamic part; the LUT is static
     int r = prm.p[0].radius, st = prm.p[0].step;
     for (int i = 1; i < prm.nplanes; ++i)
         if (prm.p[i].radius != r || prm.p[i].step != st) r = st = 0;
