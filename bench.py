@@ -56,7 +56,16 @@ def natural_frame(w: int, h: int):
     """Natural-content YUV420P16-shaped planes: the reference test picture tiled."""
     import fixtures as fx
 
-    return [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate(yuv420_shapes(w, h))]
+    planes = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate(yuv420_shapes(w, h))]
+    content = os.environ.get("VSZIP_BENCH_CONTENT", "")  # development: how content-sensitive a kernel is
+    if content:
+        rng = np.random.default_rng(5)
+        if content == "noise":  # full-range white noise: the worst case of every data-dependent lookup
+            planes = [rng.integers(0, 65536, p.shape, dtype=np.uint16) for p in planes]
+        else:  # "grain<sigma>": the picture plus Gaussian grain of that many 16-bit LSB
+            sigma = float(content.replace("grain", "") or 300)
+            planes = [np.clip(p + rng.normal(0, sigma, p.shape), 0, 65535).astype(np.uint16) for p in planes]
+    return planes
 
 
 def _lin(v):

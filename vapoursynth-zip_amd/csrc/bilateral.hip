@@ -181,6 +181,17 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParam
 // from L1/L2 on natural / edgy / uniform index distributions against 14 / 15 / 18 for the two LDS reads.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
+// The LDS pipeline is this kernel's limit, so part of the lookups goes to the f32 table in global memory: the
+// vector-memory pipeline (L1/L2) runs beside it. How many pays depends on the content - smooth pictures keep the
+// touched part of the table in L1, heavy grain does not. Measured (1080p YUV420P16, k fps) at 0 / 2 / 3 / 4 / 6 / 8
+// of every 16 lookups: natural 37.7 / 40.0 / 41.4 / 42.5 / 39.2 / 33.2; + grain sigma 1500 LSB 35.8 / 38.2 / 38.9 /
+// 34.4 / 25.8 / 20.6; full-range white noise 33.8 / 35.6 / 27.1 / 21.4 / 15.1 / 11.6. 3 wins or ties on everything
+// a camera produces; a per-wave choice between 4 and 2 from the previous pass's gradients was slower than either
+// (two copies of the loop, 39.2 natural).
+#ifndef VSZIP_L16_SPLIT
+#define VSZIP_L16_SPLIT 3
+#endif
+constexpr int kL16Split = VSZIP_L16_SPLIT;
 constexpr int kL16Rows = 16;                       // thread rows of the workgroup: 64 x 16 = 1024 threads
 constexpr int kL16TileH = 64;                      // output rows per tile (4 per wave)
 constexpr int kL16LutBytes = 4096 + 131072;        // base + delta
@@ -261,6 +272,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
             const float *gs = pc.gs;
             const int radius2 = r + 1, step = CS > 0 ? CS : pc.step;
             const float w0 = gs[0] * lut(0);
+            [[maybe_unused]] const float *__restrict__ grg = prm.p[0].gr;
             // one (yy, xx) quadrant set: 4 diagonal taps, the reference's operation order (:236-264)
             auto taps = [&](const T cx, int c0, int yy, int xx, float swei, float &wsum, float &sum) {
                 const int oa = c0 - yy * tw, ob = c0 + yy * tw;
@@ -292,14 +304,17 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
             if constexpr (CR > 0 && CS > 0) {
                 // Two output rows per pass: the lookups stay per sample, the weight arithmetic of the pair runs as
                 // packed f32 (v_pk_mul / v_pk_add: IEEE per element, so the reference's operation order holds).
-                auto taps2 = [&](const T cxa, const T cxb, int ca, int cb, int yy, int xx, float swei, v2f &wsum, v2f &sum) {
+                auto taps2 = [&](const T cxa, const T cxb, int ca, int cb, int yy, int xx, int ng, float swei, v2f &wsum, v2f &sum) {
                     const int oa = -yy * tw, ob = yy * tw;
                     const T a1 = tr[ca + oa + xx], a2 = tr[ca + ob + xx], a3 = tr[ca + oa - xx], a4 = tr[ca + ob - xx];
                     const T b1 = tr[cb + oa + xx], b2 = tr[cb + ob + xx], b3 = tr[cb + oa - xx], b4 = tr[cb + ob - xx];
-                    const v2f rw1 = {lut(S::ridx(cxa, a1)), lut(S::ridx(cxb, b1))};
-                    const v2f rw2 = {lut(S::ridx(cxa, a2)), lut(S::ridx(cxb, b2))};
-                    const v2f rw3 = {lut(S::ridx(cxa, a3)), lut(S::ridx(cxb, b3))};
-                    const v2f rw4 = {lut(S::ridx(cxa, a4)), lut(S::ridx(cxb, b4))};
+                    // ng of the 4 lookups go to the f32 table in global memory (L1/L2): the vector-memory pipeline
+                    // runs beside the LDS one, which is this kernel's limit
+                    auto look = [&](uint32_t i, bool global) { return global ? grg[i] : lut(i); };
+                    const v2f rw1 = {look(S::ridx(cxa, a1), ng > 3), look(S::ridx(cxb, b1), ng > 3)};
+                    const v2f rw2 = {look(S::ridx(cxa, a2), ng > 2), look(S::ridx(cxb, b2), ng > 2)};
+                    const v2f rw3 = {look(S::ridx(cxa, a3), ng > 1), look(S::ridx(cxb, b3), ng > 1)};
+                    const v2f rw4 = {look(S::ridx(cxa, a4), ng > 0), look(S::ridx(cxb, b4), ng > 0)};
                     const v2f sv = {swei, swei};
                     wsum += sv * (rw1 + rw2 + rw3 + rw4);
                     v2f f1, f2, f3, f4;
@@ -325,10 +340,14 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
                     const T cxa = tr[ca], cxb = tr[cb];
                     v2f wsum = {w0, w0};
                     v2f sum = v2f{S::f(ts[ca]), S::f(ts[cb])} * wsum;
+                    int call = 0;
 #pragma unroll
                     for (int yy = 1; yy <= CR; yy += CS)
 #pragma unroll
-                        for (int xx = 1; xx <= CR; xx += CS) taps2(cxa, cxb, ca, cb, yy, xx, sw[yy * (CR + 1) + xx], wsum, sum);
+                        for (int xx = 1; xx <= CR; xx += CS, ++call) {
+                            const int ng = (kL16Split * (call + 1)) / 4 - (kL16Split * call) / 4;  // spread evenly over the tap sets
+                            taps2(cxa, cxb, ca, cb, yy, xx, ng, sw[yy * (CR + 1) + xx], wsum, sum);
+                        }
                     finish(sum.x, wsum.x, ya);
                     if (yb < pc.h) finish(sum.y, wsum.y, yb);
                 }
