@@ -116,6 +116,29 @@ def test_ct_float_matches_oracle(dev, oracle, dtype, r):
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, r, shape)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("r", [1, 3, 4, 5, 8, 12, 13, 16, 17, 18])
+def test_ct_float_ring_interior_and_border_strips(dev, oracle, dtype, r):
+    """Planes large enough for the register-ring kernel (interior) + the tile kernel (four border strips):
+    several column tiles and bands, widths that leave a ragged right strip; r = 18 stays on the tile kernel."""
+    for shape in [(333, 777), (150, 1300)]:
+        src = fx.splitmix64_plane(90 + r, shape, dtype)
+        got = _run(dev, src, r, 1, r, 1)
+        want = oracle.boxblur(src, r, 1, r, 1)
+        bad = got.view(np.uint8) != want.view(np.uint8)
+        assert not bad.any(), (dtype, r, shape, np.argwhere(bad)[:4].tolist())
+
+
+def test_ct_float_ring_batch_yuv420(dev, oracle):
+    shapes = [(432, 768), (216, 384), (216, 384)] * 2
+    srcs = [fx.splitmix64_plane(140 + i, s, np.float32) for i, s in enumerate(shapes)]
+    ds = [dev.upload(a) for a in srcs]
+    dd = [dev.empty(a.shape[0], a.shape[1], a.dtype) for a in srcs]
+    dev.boxblur(ds, dd, 13, 1, 13, 1)
+    for a, d in zip(srcs, dd):
+        assert np.array_equal(dev.download(d).view(np.uint8), oracle.boxblur(a, 13, 1, 13, 1).view(np.uint8))
+
+
 RT_CASES = [(23, 1, 23, 1), (40, 1, 40, 1), (4, 1, 9, 1), (9, 1, 4, 1), (5, 3, 5, 3), (5, 1, 5, 2), (5, 2, 5, 1), (0, 0, 7, 1), (7, 1, 0, 0), (6, 2, 3, 3)]
 
 

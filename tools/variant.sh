@@ -1,0 +1,14 @@
+#!/bin/bash
+# Container: build a variant of libvszip_hip.so with ONE source recompiled under extra flags.
+#   tools/variant.sh <name> <source stem> "<extra flags>"   ->  tools/ab/<name>.so   (travels with gpurun, git-ignored)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; stem=$2; extra=$3
+python vapoursynth-zip_amd/build.py > /dev/null
+mkdir -p tools/ab /tmp/variant_$name
+B=vapoursynth-zip_amd/csrc/_build
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
+  $extra -c vapoursynth-zip_amd/csrc/$stem.hip -o /tmp/variant_$name/$stem.o
+objs=$(ls $B/*.o | grep -v "/$stem.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/$name.so $objs /tmp/variant_$name/$stem.o
+echo tools/ab/$name.so

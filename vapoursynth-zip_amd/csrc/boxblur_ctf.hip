@@ -9,6 +9,10 @@
 // unroll, and tiles that touch no plane border use compile-time tap offsets (the mirror index
 // arithmetic costs more than the taps themselves) and are register blocked (8 outputs per
 // work item share their 8 + 2r loads).
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
 #include "common.hpp"
 
 namespace {
@@ -19,6 +23,7 @@ struct FPlane {
     const void *src;
     void *dst;
     int sstride, dstride, w, h;
+    int rx0, ry0, rx1, ry1;  // the rectangle of the plane this entry tiles (the whole plane, or one border strip beside the ring kernel's interior)
     int block0, nbx;
 };
 struct FParams {
@@ -47,12 +52,12 @@ __global__ __launch_bounds__(256) void boxblur_ct_float_kernel(const FParams prm
     const FPlane pl = prm.p[pi];
     const int lb = b - pl.block0;
     const int w = pl.w, h = pl.h;
-    const int x0 = (lb % pl.nbx) * FTW, y0 = (lb / pl.nbx) * FTH;
+    const int x0 = pl.rx0 + (lb % pl.nbx) * FTW, y0 = pl.ry0 + (lb / pl.nbx) * FTH;
     const T *src = static_cast<const T *>(pl.src);
     T *dst = static_cast<T *>(pl.dst);
     const float div = 1.0f / (float)K;  // :39
     const int tid = threadIdx.x;
-    const bool interior = x0 >= R && y0 >= R && x0 + FTW + R <= w && y0 + FTH + R <= h;
+    const bool interior = x0 >= R && y0 >= R && x0 + FTW + R <= w && y0 + FTH + R <= h && x0 + FTW <= pl.rx1 && y0 + FTH <= pl.ry1;
     if (interior) {
         for (int i = tid; i < IH * IW; i += 256) {
             const int r = i / IW, c = i - r * IW;
@@ -93,27 +98,291 @@ __global__ __launch_bounds__(256) void boxblur_ct_float_kernel(const FParams prm
         }
         return;
     }
+    // border tiles (and partial ones): only the rows / columns the tile's outputs tap are staged, and the
+    // mirrored tap indices (boxblur_comptime.zig:50-70) are tabulated once per tile
+    __shared__ short rtap[FTH][K], ctap[FTW][K];
+    const int th = min(FTH, pl.ry1 - y0), tw = min(FTW, pl.rx1 - x0);
     const int cx0 = max(x0 - R, 0), cy0 = max(y0 - R, 0);
-    const int cw = min(x0 + FTW + R, w) - cx0, ch = min(y0 + FTH + R, h) - cy0;
-    for (int i = tid; i < ch * cw; i += 256) {
-        const int r = i / cw, c = i - r * cw;
-        tile[r][c] = (float)src[(size_t)(cy0 + r) * pl.sstride + cx0 + c];
+    const int cw = min(x0 + tw + R, w) - cx0, ch = min(y0 + th + R, h) - cy0;
+    for (int i0 = tid; i0 < ch * cw; i0 += 4 * 256) {  // 4 loads in flight per work item
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * 256, ch * cw - 1);
+            const int r = i / cw, c = i - r * cw;
+            v[u] = src[(size_t)(cy0 + r) * pl.sstride + cx0 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * 256, ch * cw - 1);
+            const int r = i / cw, c = i - r * cw;
+            tile[r][c] = (float)v[u];
+        }
+    }
+    // an axis whose taps meet no border on this tile runs the register-blocked pass with compile-time offsets
+    // (a strip beside the ring kernel's interior mirrors on one axis only)
+    constexpr int NBE = 8;
+    const bool vplain = y0 >= R && y0 + th + R <= h && th == FTH;
+    const bool hplain = x0 >= R && x0 + tw + R <= w && tw == FTW;
+    if (!vplain)
+        for (int i = tid; i < th * K; i += 256) rtap[i / K][i % K] = (short)(ct_tap(i % K, y0 + i / K, R, h) - cy0);
+    if (!hplain)
+        for (int i = tid; i < tw * K; i += 256) ctap[i / K][i % K] = (short)(ct_tap(i % K, x0 + i / K, R, w) - cx0);
+    __syncthreads();
+    if (vplain) {  // tile rows are y0 - R .. y0 + FTH + R - 1
+        for (int i = tid; i < (FTH / NBE) * cw; i += 256) {
+            const int c = i % cw, r0 = (i / cw) * NBE;
+            float v[NBE + 2 * R];
+#pragma unroll
+            for (int j = 0; j < NBE + 2 * R; ++j) v[j] = tile[r0 + j][c];
+#pragma unroll
+            for (int o = 0; o < NBE; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = acc + div * v[o + k];
+                vt[r0 + o][c] = (float)(T)acc;
+            }
+        }
+    } else {
+        for (int i = tid; i < th * cw; i += 256) {
+            const int r = i / cw, c = i - r * cw;
+            float acc = 0.0f;
+#pragma unroll 9
+            for (int k = 0; k < K; ++k) acc = acc + div * tile[rtap[r][k]][c];
+            vt[r][c] = (float)(T)acc;
+        }
     }
     __syncthreads();
-    const int th = min(FTH, h - y0), tw = min(FTW, w - x0);
-    for (int i = tid; i < th * cw; i += 256) {
-        const int r = i / cw, c = i - r * cw;
-        float acc = 0.0f;
-        for (int k = 0; k < K; ++k) acc = acc + div * tile[ct_tap(k, y0 + r, R, h) - cy0][c];
-        vt[r][c] = (float)(T)acc;
+    if (hplain) {  // vt columns are x0 - R .. x0 + FTW + R - 1
+        for (int i = tid; i < th * (FTW / NBE); i += 256) {
+            const int r = i / (FTW / NBE), c0 = (i % (FTW / NBE)) * NBE;
+            float v[NBE + 2 * R];
+#pragma unroll
+            for (int j = 0; j < NBE + 2 * R; ++j) v[j] = vt[r][c0 + j];
+            T *drow = dst + (size_t)(y0 + r) * pl.dstride + x0 + c0;
+#pragma unroll
+            for (int o = 0; o < NBE; ++o) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sum += div * v[o + k];
+                drow[o] = (T)sum;
+            }
+        }
+    } else {
+        for (int i = tid; i < th * tw; i += 256) {
+            const int r = i / tw, c = i - r * tw;
+            float sum = 0.0f;
+#pragma unroll 9
+            for (int k = 0; k < K; ++k) sum += div * vt[r][ctap[c][k]];
+            dst[(size_t)(y0 + r) * pl.dstride + x0 + c] = (T)sum;
+        }
     }
-    __syncthreads();
-    for (int i = tid; i < th * tw; i += 256) {
-        const int r = i / tw, c = i - r * tw;
-        float sum = 0.0f;
-        for (int k = 0; k < K; ++k) sum += div * vt[r][ct_tap(k, x0 + c, R, w) - cx0];
-        dst[(size_t)(y0 + r) * pl.dstride + x0 + c] = (T)sum;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// boxblur_ctf_ring_kernel<T, R>: the part of a plane whose taps meet no border (rows [ya, yb), whole column
+// tiles whose halo is real data). One wave walks a 256-column tile down a band of rows, 4 pixels per lane
+// (one 16-byte load per row for f32):
+//   * the 2r+1 window rows stay in registers as PRODUCTS div * v (the reference multiplies every tap by div
+//     before adding, :176; the product is the same for every output row that taps it), in a ring of
+//     2r+1+D slots whose row loop is unrolled over one ring period, so every slot index is a compile-time
+//     constant; rows are fetched D steps ahead into the slot that just left the window;
+//   * each step sums its 2r+1 slots IN TAP ORDER (unfused adds: bit-identical to vBlurFloat :161-190),
+//     rounds to T like the reference's tmp row, and parks div * tmp in 1 KiB of LDS laid out
+//     [pixel-in-lane][lane] (conflict-free both ways);
+//   * every output lane reads its 4 + 2r neighbours back and sums them in tap order (hBlurFloat :192-263).
+// The rest of the plane (four border strips) goes through boxblur_ct_float_kernel.
+// ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+
+#ifndef VSZIP_FR_ST_AUX
+#define VSZIP_FR_ST_AUX 2
+#endif
+#ifndef VSZIP_FRD
+#define VSZIP_FRD 8
+#endif
+constexpr int kFRD = VSZIP_FRD;    // rows in flight ahead of the window
+constexpr int kFRPx = 4;           // pixels per lane and row
+constexpr int kFRCopy = kFRPx * 64 + 16;  // floats of the LDS row
+constexpr int kFRMaxR = 17;         // larger radii: the ring (2r+1+D rows x 4 registers) no longer fits the register file with useful occupancy
+
+template <int R>
+struct FRGeom {
+    static constexpr int K = 2 * R + 1, NR = K + kFRD;
+    static constexpr int HL = ((R + kFRPx - 1) / kFRPx) * kFRPx;  // halo columns each side, whole lanes
+    static constexpr int OUT_LANES = 64 - 2 * (HL / kFRPx);
+    static constexpr int TWO = OUT_LANES * kFRPx;                 // output columns per tile
+};
+
+struct FRPlane {
+    const void *src;
+    void *dst;
+    int sstride, dstride;
+    int ya, yb;          // interior rows [ya, yb)
+    int xb;              // interior columns [HL, xb)
+    int ntx, nbands, nperiods;
+    int block0;
+};
+struct FRParams {
+    FRPlane p[kMaxPlanesF];
+    int nplanes, nblocks;
+};
+
+template <typename T>
+struct FRow;
+template <>
+struct FRow<float> {
+#ifdef VSZIP_FR_LD_NT
+    static __device__ __forceinline__ void load(v4f &slot, const float *p) { slot = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)); }
+#else
+    static __device__ __forceinline__ void load(v4f &slot, const float *p) { slot = *reinterpret_cast<const v4f *>(p); }
+#endif
+    static __device__ __forceinline__ void to_products(v4f &slot, float div) { slot = div * slot; }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rd, uint32_t vo, uint32_t so, v4f v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rd, vo, so, VSZIP_FR_ST_AUX);  // aux 2 = nt
     }
+    static __device__ __forceinline__ v4f narrow(v4f v) { return v; }
+};
+template <>
+struct FRow<_Float16> {
+    // the 8 loaded bytes wait in the slot's first two registers until the row enters the window
+    static __device__ __forceinline__ void load(v4f &slot, const _Float16 *p) {
+        const v2u r = *reinterpret_cast<const v2u *>(p);
+        slot.x = __uint_as_float(r.x);
+        slot.y = __uint_as_float(r.y);
+    }
+    static __device__ __forceinline__ void to_products(v4f &slot, float div) {
+        v2u r = {__float_as_uint(slot.x), __float_as_uint(slot.y)};
+        const v4h h = __builtin_bit_cast(v4h, r);
+        slot = div * v4f{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rd, uint32_t vo, uint32_t so, v4f v) {
+        const v4h h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, h), rd, vo, so, VSZIP_FR_ST_AUX);
+    }
+    static __device__ __forceinline__ v4f narrow(v4f v) {  // tmp row is stored as T (:186)
+        return v4f{(float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w};
+    }
+};
+
+// The wave's state. Ring slots are addressed by template parameters (a period of NR steps is a fold
+// expression), so every slot index is a compile-time constant whatever the optimizer's unroll budget.
+template <typename T, int R>
+struct FRWave {
+    using G = FRGeom<R>;
+    static constexpr int K = G::K, NR = G::NR, PXL = kFRPx;
+    v4f ring[NR];  // slot of row rho = (rho - (y0 - R)) mod NR
+    const T *sp;
+    size_t ss;
+    __amdgpu_buffer_rsrc_t rd;  // stores go through a buffer descriptor: halo lanes carry an out-of-range offset and the
+    uint32_t sdoff, drow;       // hardware drops them, so a row is ONE unconditional store (no branch for the wait counters to be pessimistic about)
+    float *pw;
+    float div;
+    int last_row;
+
+    template <int J>
+    __device__ __forceinline__ void preload(int y0) {
+        FRow<T>::load(ring[J], sp + (size_t)min(y0 - R + J, last_row) * ss);
+    }
+    template <int... J>
+    __device__ __forceinline__ void preload_all(int y0, std::integer_sequence<int, J...>) {
+        (preload<J>(y0), ...);
+    }
+    template <int... J>
+    __device__ __forceinline__ void products_all(std::integer_sequence<int, J...>) {
+        (FRow<T>::to_products(ring[J], div), ...);
+    }
+    template <int S, int... Kk>
+    __device__ __forceinline__ v4f window_sum(std::integer_sequence<int, Kk...>) {
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        ((acc = acc + ring[(S + Kk) % NR]), ...);  // tap order, unfused (:176)
+        return acc;
+    }
+    // output row y + S: its window is slots S .. S + K - 1 (mod NR)
+    template <int S>
+    __device__ __forceinline__ void step(int y) {
+        FRow<T>::to_products(ring[(S + K - 1) % NR], div);  // row y + S + R arrived D steps ago
+        FRow<T>::load(ring[(S + NR - 1) % NR], sp + (size_t)min(y + S + R + kFRD, last_row) * ss);
+        const v4f acc = window_sum<S>(std::make_integer_sequence<int, K>{});
+        const v4f ph = div * FRow<T>::narrow(acc);
+        pw[0 * 64] = ph.x;
+        pw[1 * 64] = ph.y;
+        pw[2 * 64] = ph.z;
+        pw[3 * 64] = ph.w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            // outputs (0,1) and (2,3) accumulate as packed pairs of neighbouring columns: pr[j] = (q[j], q[j+1]),
+            // q[j] = column j - R relative to this lane's first one
+            v2f pr[PXL + 2 * R - 1];
+#pragma unroll
+            for (int j = 0; j < PXL + 2 * R - 1; ++j) {
+                auto at = [&](int jj) {
+                    const int c = jj - R;
+                    const int k = ((c % PXL) + PXL) % PXL;  // pixel-in-lane of that column
+                    return pw[k * 64 + (c - k) / PXL];      // ... of its owner lane
+                };
+                pr[j] = v2f{at(j), at(j + 1)};
+            }
+            v2f o01 = {0.0f, 0.0f}, o23 = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                o01 = o01 + pr[k];
+                o23 = o23 + pr[k + 2];
+            }
+            FRow<T>::store(rd, sdoff, (uint32_t)(y + S) * drow, v4f{o01.x, o01.y, o23.x, o23.y});
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);  // a step is a scheduling region: the row load stays D steps ahead of its use
+    }
+    template <int... S>
+    __device__ __forceinline__ void period(int y, std::integer_sequence<int, S...>) {
+        (step<S>(y), ...);
+    }
+};
+
+template <typename T, int R>
+__global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm) {
+    using W = FRWave<T, R>;
+    using G = FRGeom<R>;
+    constexpr int K = G::K, NR = G::NR, PXL = kFRPx;
+    __shared__ float P[kFRCopy];  // div * tmp of the current row, [pixel-in-lane][lane], 8 floats of slack either side
+    const int chunk = (prm.nblocks + 7) >> 3;  // XCD-aware: blocks b and b+8 share an XCD
+    const int b = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (b >= prm.nblocks) return;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const FRPlane &pl = prm.p[pi];
+    const int lb = b - pl.block0;
+    const int tx = lb % pl.ntx, by = lb / pl.ntx;
+    const int p0 = (int)((long)by * pl.nperiods / pl.nbands), p1 = (int)((long)(by + 1) * pl.nperiods / pl.nbands);
+    const int band_rows = (p1 - p0) * NR;
+    const int y0 = min(pl.ya + p0 * NR, pl.yb - band_rows);  // the last band is shifted up to end at yb (rewrites identical values)
+    const int lane = threadIdx.x;
+    // this lane's first column (always inside the plane); the last tile is shifted left to end at xb
+    const int cx = min(tx * G::TWO, pl.xb - G::HL - G::TWO) + lane * PXL;
+    W st;
+    st.sp = static_cast<const T *>(pl.src) + cx;
+    st.ss = (size_t)pl.sstride;
+    st.drow = (uint32_t)pl.dstride * (uint32_t)sizeof(T);
+    st.rd = __builtin_amdgcn_make_buffer_rsrc(pl.dst, 0, (int)((uint32_t)(pl.yb + R) * st.drow), 0x00020000);
+    const bool is_out = lane >= G::HL / PXL && lane < G::HL / PXL + G::OUT_LANES;
+    st.sdoff = is_out ? (uint32_t)cx * (uint32_t)sizeof(T) : 0xfffffff0u;
+    st.div = 1.0f / (float)K;  // :39
+    st.last_row = pl.yb + R - 1;  // rows fetched past it are never summed
+    st.pw = P + 8 + lane;
+    st.preload_all(y0, std::make_integer_sequence<int, NR - 1>{});
+    st.products_all(std::make_integer_sequence<int, K - 1>{});
+#pragma unroll 1
+    for (int y = y0; y < y0 + band_rows; y += NR) st.period(y, std::make_integer_sequence<int, NR>{});
 }
 
 template <typename T, int R>
@@ -130,32 +399,126 @@ struct FloatDispatch<T, 0> {
     static void launch(vszip_ctx *, int, int, const FParams &) {}
 };
 
+template <typename T, int R>
+struct RingDispatch {
+    static void launch(vszip_ctx *ctx, int r, int blocks, const FRParams &prm) {
+        if (r == R)
+            hipLaunchKernelGGL((boxblur_ctf_ring_kernel<T, R>), dim3(((blocks + 7) / 8) * 8), dim3(64), 0, ctx->stream, prm);
+        else
+            RingDispatch<T, R - 1>::launch(ctx, r, blocks, prm);
+    }
+    static void geom(int r, int &k, int &nr, int &hl, int &two) {
+        if (r == R) {
+            k = FRGeom<R>::K, nr = FRGeom<R>::NR, hl = FRGeom<R>::HL, two = FRGeom<R>::TWO;
+        } else {
+            RingDispatch<T, R - 1>::geom(r, k, nr, hl, two);
+        }
+    }
+};
+template <typename T>
+struct RingDispatch<T, 0> {
+    static void launch(vszip_ctx *, int, int, const FRParams &) {}
+    static void geom(int, int &, int &, int &, int &) {}
+};
+
+// Interior of a plane for the ring kernel: columns [HL, xb) (xb the last multiple of 4 that leaves HL columns of
+// real halo), rows [R, h - R); false when the plane is too small or not 16-byte (f16: 8-byte) aligned - the tile
+// kernel then takes all of it.
+template <typename T>
+bool ring_interior(const vszip_plane &s, int radius, int nr, int hl, int two, int &ntx, int &xb) {
+    constexpr uintptr_t VB = sizeof(T) * kFRPx;
+    if (radius > kFRMaxR || std::getenv("VSZIP_BOXBLUR_NO_FLOAT_RING")) return false;
+    if ((reinterpret_cast<uintptr_t>(s.src) | reinterpret_cast<uintptr_t>(s.dst) | (uintptr_t)(s.src_stride * sizeof(T)) | (uintptr_t)(s.dst_stride * sizeof(T))) & (VB - 1)) return false;
+    xb = ((s.w - hl) / kFRPx) * kFRPx;
+    ntx = (xb - hl + two - 1) / two;
+    if ((uint64_t)s.dst_stride * s.h * sizeof(T) >= (1ull << 32)) return false;  // 32-bit store offsets
+    return xb - hl >= two && s.h - 2 * radius >= nr;
+}
+
 template <typename T>
 int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int radius) {
     if (radius < 1 || radius > 22) return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: CT float radius out of range");
-    int done = 0;
-    while (done < nplanes) {
-        FParams prm;
-        const int n = std::min(kMaxPlanesF, nplanes - done);
-        prm.nplanes = n;
-        int blocks = 0;
-        for (int i = 0; i < n; ++i) {
-            const vszip_plane &s = planes[done + i];
-            FPlane &d = prm.p[i];
+    int K = 0, NR = 0, HL = 0, TWO = 0;
+    RingDispatch<T, kFRMaxR>::geom(radius, K, NR, HL, TWO);
+    vszip_probe_scope probe(ctx);
+    // 1. interiors: one ring launch per kMaxPlanesF planes
+    long interior_px = 0;
+    for (int i = 0; i < nplanes; ++i) {
+        int ntx, xb;
+        if (ring_interior<T>(planes[i], radius, NR, HL, TWO, ntx, xb)) interior_px += (long)(xb - HL) * (planes[i].h - 2 * radius);
+    }
+    // rows per band: one resident round (2 waves per SIMD = 2048 waves) over the whole call when there is that
+    // much work, a band at least two ring periods - every band re-reads 2r rows
+    int band_rows = std::max(2 * NR, 1);
+    while (interior_px > 0 && interior_px / ((long)TWO * band_rows) > 2048 && band_rows < 16 * NR) band_rows += NR;
+    for (int done = 0; done < nplanes;) {
+        FRParams prm;
+        int n = 0, blocks = 0;
+        for (; done < nplanes && n < kMaxPlanesF; ++done) {
+            const vszip_plane &s = planes[done];
+            int ntx, xb;
+            if (!ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) continue;
+            const int ya = radius, yb = s.h - radius;
+            FRPlane &d = prm.p[n++];
             d.src = s.src;
             d.dst = s.dst;
             d.sstride = (int)s.src_stride;
             d.dstride = (int)s.dst_stride;
-            d.w = s.w;
-            d.h = s.h;
+            d.ya = ya;
+            d.yb = yb;
+            d.xb = xb;
+            d.ntx = ntx;
+            d.nperiods = (yb - ya + NR - 1) / NR;
+            d.nbands = std::max(1, std::min(d.nperiods, (yb - ya + band_rows - 1) / band_rows));
             d.block0 = blocks;
-            d.nbx = (s.w + FTW - 1) / FTW;
-            blocks += d.nbx * ((s.h + FTH - 1) / FTH);
+            blocks += d.ntx * d.nbands;
         }
-        FloatDispatch<T, 22>::launch(ctx, radius, blocks, prm);
-        VSZIP_HIP_CHECK(ctx, hipGetLastError());
-        done += n;
+        if (n) {
+            prm.nplanes = n;
+            prm.nblocks = blocks;
+            RingDispatch<T, kFRMaxR>::launch(ctx, radius, blocks, prm);
+            VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        }
     }
+    // 2. everything else (border strips, or whole planes) through the tile kernel
+    FParams prm;
+    int n = 0, blocks = 0;
+    auto flush = [&]() {
+        if (!n) return;
+        prm.nplanes = n;
+        FloatDispatch<T, 22>::launch(ctx, radius, blocks, prm);
+        n = blocks = 0;
+    };
+    auto add_rect = [&](const vszip_plane &s, int rx0, int ry0, int rx1, int ry1) {
+        if (rx1 <= rx0 || ry1 <= ry0) return;
+        if (n == kMaxPlanesF) flush();
+        FPlane &d = prm.p[n++];
+        d.src = s.src;
+        d.dst = s.dst;
+        d.sstride = (int)s.src_stride;
+        d.dstride = (int)s.dst_stride;
+        d.w = s.w;
+        d.h = s.h;
+        d.rx0 = rx0, d.ry0 = ry0, d.rx1 = rx1, d.ry1 = ry1;
+        d.block0 = blocks;
+        d.nbx = (rx1 - rx0 + FTW - 1) / FTW;
+        blocks += d.nbx * ((ry1 - ry0 + FTH - 1) / FTH);
+    };
+    for (int i = 0; i < nplanes; ++i) {
+        const vszip_plane &s = planes[i];
+        int ntx, xb;
+        if (ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) {
+            const int ya = radius, yb = s.h - radius;
+            add_rect(s, 0, 0, s.w, ya);       // top
+            add_rect(s, 0, yb, s.w, s.h);     // bottom
+            add_rect(s, 0, ya, HL, yb);       // left
+            add_rect(s, xb, ya, s.w, yb);     // right
+        } else {
+            add_rect(s, 0, 0, s.w, s.h);
+        }
+    }
+    flush();
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
 
