@@ -199,21 +199,24 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;
 
 #ifndef VSZIP_FR_ST_AUX
 #define VSZIP_FR_ST_AUX 2
 #endif
 #ifndef VSZIP_FRD
-#define VSZIP_FRD 8
+#define VSZIP_FRD 7
 #endif
 constexpr int kFRD = VSZIP_FRD;    // rows in flight ahead of the window
 constexpr int kFRPx = 4;           // pixels per lane and row
-constexpr int kFRCopy = kFRPx * 64 + 16;  // floats of the LDS row
+constexpr int kFRPix = 256, kFRRowB = 128;  // LDS: [pixel-in-lane] blocks of 256 floats, row A at +0, row B at +128, 8 floats of slack before lane 0
+constexpr int kFRLds = kFRPx * kFRPix + 16;
 constexpr int kFRMaxR = 17;         // larger radii: the ring (2r+1+D rows x 4 registers) no longer fits the register file with useful occupancy
 
 template <int R>
 struct FRGeom {
-    static constexpr int K = 2 * R + 1, NR = K + kFRD;
+    static constexpr int K = 2 * R + 1, NR = K + kFRD;  // NR even: rows are processed in pairs
+    static_assert((K + kFRD) % 2 == 0, "ring period must be even");
     static constexpr int HL = ((R + kFRPx - 1) / kFRPx) * kFRPx;  // halo columns each side, whole lanes
     static constexpr int OUT_LANES = 64 - 2 * (HL / kFRPx);
     static constexpr int TWO = OUT_LANES * kFRPx;                 // output columns per tile
@@ -282,6 +285,10 @@ struct FRWave {
     __amdgpu_buffer_rsrc_t rd;  // stores go through a buffer descriptor: halo lanes carry an out-of-range offset and the
     uint32_t sdoff, drow;       // hardware drops them, so a row is ONE unconditional store (no branch for the wait counters to be pessimistic about)
     float *pw;
+    // LDS address of each neighbour lane's column block, kept opaque to the optimizer: with the lane offset folded
+    // into the instruction it pairs reads of neighbouring lanes instead of rows A / B
+    static constexpr int NBH = (R + PXL - 1) / PXL + 1;
+    const lds_float *nb[2 * NBH + 1];
     float div;
     int last_row;
 
@@ -303,47 +310,56 @@ struct FRWave {
         ((acc = acc + ring[(S + Kk) % NR]), ...);  // tap order, unfused (:176)
         return acc;
     }
-    // output row y + S: its window is slots S .. S + K - 1 (mod NR)
+    // vertical pass of output row y + S (window = slots S .. S + K - 1 mod NR); div * tmp goes to LDS row A or B
     template <int S>
-    __device__ __forceinline__ void step(int y) {
+    __device__ __forceinline__ void vstep(int y) {
         FRow<T>::to_products(ring[(S + K - 1) % NR], div);  // row y + S + R arrived D steps ago
         FRow<T>::load(ring[(S + NR - 1) % NR], sp + (size_t)min(y + S + R + kFRD, last_row) * ss);
         const v4f acc = window_sum<S>(std::make_integer_sequence<int, K>{});
         const v4f ph = div * FRow<T>::narrow(acc);
-        pw[0 * 64] = ph.x;
-        pw[1 * 64] = ph.y;
-        pw[2 * 64] = ph.z;
-        pw[3 * 64] = ph.w;
+        float *p = pw + (S & 1) * kFRRowB;
+        p[0 * kFRPix] = ph.x;
+        p[1 * kFRPix] = ph.y;
+        p[2 * kFRPix] = ph.z;
+        p[3 * kFRPix] = ph.w;
+    }
+    // Two output rows per horizontal pass: the packed accumulators pair ROW A with ROW B of one column, and
+    // that pair (qA[j], qB[j]) is two LDS words 128 floats apart - one two-address read, already in an aligned
+    // register pair (pairing neighbouring columns of one row needs 45 register moves per row instead).
+    template <int S>
+    __device__ __forceinline__ void step2(int y) {
+        vstep<S>(y);
+        vstep<S + 1>(y);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            // outputs (0,1) and (2,3) accumulate as packed pairs of neighbouring columns: pr[j] = (q[j], q[j+1]),
-            // q[j] = column j - R relative to this lane's first one
-            v2f pr[PXL + 2 * R - 1];
+        v2f q[PXL + 2 * R];  // q[j] = column j - R relative to this lane's first one, rows A and B
 #pragma unroll
-            for (int j = 0; j < PXL + 2 * R - 1; ++j) {
-                auto at = [&](int jj) {
-                    const int c = jj - R;
-                    const int k = ((c % PXL) + PXL) % PXL;  // pixel-in-lane of that column
-                    return pw[k * 64 + (c - k) / PXL];      // ... of its owner lane
-                };
-                pr[j] = v2f{at(j), at(j + 1)};
-            }
-            v2f o01 = {0.0f, 0.0f}, o23 = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                o01 = o01 + pr[k];
-                o23 = o23 + pr[k + 2];
-            }
-            FRow<T>::store(rd, sdoff, (uint32_t)(y + S) * drow, v4f{o01.x, o01.y, o23.x, o23.y});
+        for (int j = 0; j < PXL + 2 * R; ++j) {
+            const int c = j - R;
+            const int k = ((c % PXL) + PXL) % PXL;         // pixel-in-lane of that column
+            const lds_float *p = nb[(c - k) / PXL + NBH];  // ... of its owner lane
+            q[j] = v2f{p[k * kFRPix], p[k * kFRPix + kFRRowB]};
         }
+        v2f o[PXL];
+#pragma unroll
+        for (int e = 0; e < PXL; ++e) {
+            o[e] = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) o[e] = o[e] + q[e + k];  // tap order, unfused (:232)
+        }
+        FRow<T>::store(rd, sdoff, (uint32_t)(y + S) * drow, v4f{o[0].x, o[1].x, o[2].x, o[3].x});
+        FRow<T>::store(rd, sdoff, (uint32_t)(y + S + 1) * drow, v4f{o[0].y, o[1].y, o[2].y, o[3].y});
+        // gfx940+ reads the data registers of a 16-byte store over the following cycles (a VALU write to them needs 2
+        // wait states); the hazard recogniser counts the two zero-size barriers below as those wait states, and
+        // without real ones the last lanes of every 16 stored the NEXT row pair's first LDS reads
+        asm volatile("s_nop 3");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);  // a step is a scheduling region: the row load stays D steps ahead of its use
+        __builtin_amdgcn_sched_barrier(0);  // a row pair is a scheduling region: the row loads stay D steps ahead of their use
     }
-    template <int... S>
-    __device__ __forceinline__ void period(int y, std::integer_sequence<int, S...>) {
-        (step<S>(y), ...);
+    template <int... S2>
+    __device__ __forceinline__ void period(int y, std::integer_sequence<int, S2...>) {
+        (step2<2 * S2>(y), ...);
     }
 };
 
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     using W = FRWave<T, R>;
     using G = FRGeom<R>;
     constexpr int K = G::K, NR = G::NR, PXL = kFRPx;
-    __shared__ float P[kFRCopy];  // div * tmp of the current row, [pixel-in-lane][lane], 8 floats of slack either side
+    __shared__ float P[kFRLds];  // div * tmp of the current two rows, [pixel-in-lane][row A | row B][lane]
     const int chunk = (prm.nblocks + 7) >> 3;  // XCD-aware: blocks b and b+8 share an XCD
     const int b = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (b >= prm.nblocks) return;
@@ -379,10 +395,16 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     st.div = 1.0f / (float)K;  // :39
     st.last_row = pl.yb + R - 1;  // rows fetched past it are never summed
     st.pw = P + 8 + lane;
+#pragma unroll
+    for (int i = 0; i < 2 * W::NBH + 1; ++i) {
+        const lds_float *b = (const lds_float *)P + 8 + lane + (i - W::NBH);
+        asm volatile("" : "+v"(b));
+        st.nb[i] = b;
+    }
     st.preload_all(y0, std::make_integer_sequence<int, NR - 1>{});
     st.products_all(std::make_integer_sequence<int, K - 1>{});
 #pragma unroll 1
-    for (int y = y0; y < y0 + band_rows; y += NR) st.period(y, std::make_integer_sequence<int, NR>{});
+    for (int y = y0; y < y0 + band_rows; y += NR) st.period(y, std::make_integer_sequence<int, NR / 2>{});
 }
 
 template <typename T, int R>
