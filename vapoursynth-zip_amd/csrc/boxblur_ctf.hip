@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <utility>
+#include <vector>
 
 #include "common.hpp"
 
@@ -228,7 +229,7 @@ struct FRPlane {
     int sstride, dstride;
     int ya, yb;          // interior rows [ya, yb)
     int xb;              // interior columns [HL, xb)
-    int ntx, nbands, nperiods;
+    int ntx, nbands;
     int block0;
 };
 struct FRParams {
@@ -294,7 +295,7 @@ struct FRWave {
 
     template <int J>
     __device__ __forceinline__ void preload(int y0) {
-        FRow<T>::load(ring[J], sp + (size_t)min(y0 - R + J, last_row) * ss);
+        FRow<T>::load(ring[J], sp + (size_t)min(abs(y0 - R + J), last_row) * ss);  // rows above the plane: reflect-101 (:54)
     }
     template <int... J>
     __device__ __forceinline__ void preload_all(int y0, std::integer_sequence<int, J...>) {
@@ -327,7 +328,8 @@ struct FRWave {
     // that pair (qA[j], qB[j]) is two LDS words 128 floats apart - one two-address read, already in an aligned
     // register pair (pairing neighbouring columns of one row needs 45 register moves per row instead).
     template <int S>
-    __device__ __forceinline__ void step2(int y) {
+    __device__ __forceinline__ bool step2(int y, int yend) {
+        if (y + S >= yend) return false;  // (uniform) a band may end inside a ring period
         vstep<S>(y);
         vstep<S + 1>(y);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -356,10 +358,11 @@ struct FRWave {
         asm volatile("s_nop 3");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);  // a row pair is a scheduling region: the row loads stay D steps ahead of their use
+        return true;
     }
     template <int... S2>
-    __device__ __forceinline__ void period(int y, std::integer_sequence<int, S2...>) {
-        (step2<2 * S2>(y), ...);
+    __device__ __forceinline__ void period(int y, int yend, std::integer_sequence<int, S2...>) {
+        (void)(step2<2 * S2>(y, yend) && ...);
     }
 };
 
@@ -379,9 +382,10 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     const FRPlane &pl = prm.p[pi];
     const int lb = b - pl.block0;
     const int tx = lb % pl.ntx, by = lb / pl.ntx;
-    const int p0 = (int)((long)by * pl.nperiods / pl.nbands), p1 = (int)((long)(by + 1) * pl.nperiods / pl.nbands);
-    const int band_rows = (p1 - p0) * NR;
-    const int y0 = min(pl.ya + p0 * NR, pl.yb - band_rows);  // the last band is shifted up to end at yb (rewrites identical values)
+    // bands split the plane's row PAIRS evenly (an odd row count makes the last band compute row yb as well: it
+    // belongs to the bottom strip, whose kernel runs afterwards)
+    const int npairs = (pl.yb - pl.ya + 1) / 2;
+    const int y0 = pl.ya + 2 * (int)((long)by * npairs / pl.nbands), y1 = pl.ya + 2 * (int)((long)(by + 1) * npairs / pl.nbands);
     const int lane = threadIdx.x;
     // this lane's first column (always inside the plane); the last tile is shifted left to end at xb
     const int cx = min(tx * G::TWO, pl.xb - G::HL - G::TWO) + lane * PXL;
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     st.preload_all(y0, std::make_integer_sequence<int, NR - 1>{});
     st.products_all(std::make_integer_sequence<int, K - 1>{});
 #pragma unroll 1
-    for (int y = y0; y < y0 + band_rows; y += NR) st.period(y, std::make_integer_sequence<int, NR / 2>{});
+    for (int y = y0; y < y1; y += NR) st.period(y, y1, std::make_integer_sequence<int, NR / 2>{});
 }
 
 template <typename T, int R>
@@ -436,11 +440,23 @@ struct RingDispatch {
             RingDispatch<T, R - 1>::geom(r, k, nr, hl, two);
         }
     }
+    // waves one resident round holds: what the register count of this radius leaves per CU, times the CUs
+    static int round_waves(int r, int cus) {
+        if (r != R) return RingDispatch<T, R - 1>::round_waves(r, cus);
+        static int per_cu = 0;  // (benign race: every thread computes the same value)
+        if (!per_cu) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, boxblur_ctf_ring_kernel<T, R>, 64, 0) != hipSuccess || n < 1) n = 8;
+            per_cu = n;
+        }
+        return per_cu * cus;
+    }
 };
 template <typename T>
 struct RingDispatch<T, 0> {
     static void launch(vszip_ctx *, int, int, const FRParams &) {}
     static void geom(int, int &, int &, int &, int &) {}
+    static int round_waves(int, int) { return 2048; }
 };
 
 // Interior of a plane for the ring kernel: columns [HL, xb) (xb the last multiple of 4 that leaves HL columns of
@@ -464,34 +480,47 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
     RingDispatch<T, kFRMaxR>::geom(radius, K, NR, HL, TWO);
     vszip_probe_scope probe(ctx);
     // 1. interiors: one ring launch per kMaxPlanesF planes
-    long interior_px = 0;
+    // bands per plane: the call's waves must fit ONE resident round (r = 13: 2 waves per SIMD = 2048; one wave
+    // more starts a second round and the launch takes twice as long). Greedy: the planes with
+    // the most rows per band get one more band each while the round has room; a band is at least two ring periods
+    // (every band re-reads 2r rows).
+    const long round = RingDispatch<T, kFRMaxR>::round_waves(radius, ctx->num_cus > 0 ? ctx->num_cus : 256);
+    std::vector<int> nb(nplanes, 0), ntxs(nplanes, 0), xbs(nplanes, 0);
+    long waves = 0;
     for (int i = 0; i < nplanes; ++i) {
-        int ntx, xb;
-        if (ring_interior<T>(planes[i], radius, NR, HL, TWO, ntx, xb)) interior_px += (long)(xb - HL) * (planes[i].h - 2 * radius);
+        if (!ring_interior<T>(planes[i], radius, NR, HL, TWO, ntxs[i], xbs[i])) continue;
+        nb[i] = 1;
+        waves += ntxs[i];
     }
-    // rows per band: one resident round (2 waves per SIMD = 2048 waves) over the whole call when there is that
-    // much work, a band at least two ring periods - every band re-reads 2r rows
-    int band_rows = std::max(2 * NR, 1);
-    while (interior_px > 0 && interior_px / ((long)TWO * band_rows) > 2048 && band_rows < 16 * NR) band_rows += NR;
+    for (;;) {
+        int worst = 0;
+        for (int i = 0; i < nplanes; ++i)
+            if (nb[i]) worst = std::max(worst, (planes[i].h - radius + nb[i] - 1) / nb[i]);
+        if (worst == 0 || worst < 4 * NR) break;  // (worst == 0: no plane takes the ring kernel)
+        long extra = 0;
+        for (int i = 0; i < nplanes; ++i)
+            if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) extra += ntxs[i];
+        if (waves + extra > round) break;
+        for (int i = 0; i < nplanes; ++i)
+            if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) ++nb[i];
+        waves += extra;
+    }
     for (int done = 0; done < nplanes;) {
         FRParams prm;
         int n = 0, blocks = 0;
         for (; done < nplanes && n < kMaxPlanesF; ++done) {
             const vszip_plane &s = planes[done];
-            int ntx, xb;
-            if (!ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) continue;
-            const int ya = radius, yb = s.h - radius;
+            if (!nb[done]) continue;
             FRPlane &d = prm.p[n++];
             d.src = s.src;
             d.dst = s.dst;
             d.sstride = (int)s.src_stride;
             d.dstride = (int)s.dst_stride;
-            d.ya = ya;
-            d.yb = yb;
-            d.xb = xb;
-            d.ntx = ntx;
-            d.nperiods = (yb - ya + NR - 1) / NR;
-            d.nbands = std::max(1, std::min(d.nperiods, (yb - ya + band_rows - 1) / band_rows));
+            d.ya = 0;  // (the ring kernel mirrors the top rows itself)
+            d.yb = s.h - radius;
+            d.xb = xbs[done];
+            d.ntx = ntxs[done];
+            d.nbands = nb[done];
             d.block0 = blocks;
             blocks += d.ntx * d.nbands;
         }
@@ -530,8 +559,7 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
         const vszip_plane &s = planes[i];
         int ntx, xb;
         if (ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) {
-            const int ya = radius, yb = s.h - radius;
-            add_rect(s, 0, 0, s.w, ya);       // top
+            const int ya = 0, yb = s.h - radius;  // (the ring kernel mirrors the top rows itself)
             add_rect(s, 0, yb, s.w, s.h);     // bottom
             add_rect(s, 0, ya, HL, yb);       // left
             add_rect(s, xb, ya, s.w, yb);     // right

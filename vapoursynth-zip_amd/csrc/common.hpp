@@ -15,6 +15,7 @@
 
 struct vszip_ctx {
     int device = 0;
+    int num_cus = 0;  // compute units of `device` (0: unknown)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

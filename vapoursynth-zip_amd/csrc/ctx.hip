@@ -56,6 +56,7 @@ VSZIP_EXPORT int vszip_ctx_create(int device, vszip_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return VSZIP_ERR_HIP;
     vszip_ctx *c = new vszip_ctx();
     c->device = device;
+    (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return VSZIP_ERR_HIP;
