@@ -212,7 +212,7 @@ constexpr int kFRD = VSZIP_FRD;    // rows in flight ahead of the window
 constexpr int kFRPx = 4;           // pixels per lane and row
 constexpr int kFRPix = 256, kFRRowB = 128;  // LDS: [pixel-in-lane] blocks of 256 floats, row A at +0, row B at +128, 8 floats of slack before lane 0
 constexpr int kFRLds = kFRPx * kFRPix + 16;
-constexpr int kFRMaxR = 17;         // larger radii: the ring (2r+1+D rows x 4 registers) no longer fits the register file with useful occupancy
+constexpr int kFRMaxR = 22;         // larger radii: the ring (2r+1+D rows x 4 registers) no longer fits the register file with useful occupancy
 
 template <int R>
 struct FRGeom {
