@@ -97,15 +97,16 @@ constexpr int kU = 4;  // directions per cost pass
 // 5 waves per CU, and the kernel is latency bound.
 template <int NRAD, int MD>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
-    // The t_base and window-sum steps run a fixed number of 64-entry iterations (NIT, the longest
-    // span rounded up) with no guard — entries past a direction's span are computed from padding and
-    // never read — so that the compiler emits straight-line code (with `t < span` loops it vectorised
-    // them into prologue/body/remainder blocks that cost more instructions than the arithmetic).
-    constexpr int NIT = (kXB + 2 * MD + 2 * NRAD + 63) / 64;
-    constexpr int kRowW = 64 * NIT + 2 * MD + 4;  // staged columns per source row: block + reach 2*mdis + nrad each side, padded for the overshoot
-    constexpr int kTbW = 64 * NIT + 8;            // t_base / window-sum entries per direction
+    // The t_base and window-sum steps run a fixed number of 128-entry iterations (NIT2: every lane owns two
+    // neighbouring entries, and the kU directions of a pass share ONE first column, so the span is the longest
+    // of the pass) with no guard — entries past a direction's span are computed from padding and never read —
+    // so that the compiler emits straight-line code (with `t < span` loops it vectorised them into
+    // prologue/body/remainder blocks that cost more instructions than the arithmetic).
+    constexpr int NIT2 = (kXB + 2 * MD + 2 * NRAD + 2 * (kU - 1) + 127) / 128;
+    constexpr int kRowW = 128 * NIT2 + 2 * MD + 8;  // staged columns per source row: block + reach 2*mdis + nrad each side, padded for the overshoot
+    constexpr int kTbW = 128 * NIT2 + 8;            // t_base / window-sum entries per direction
     const float kFltMax09 = FLT_MAX * 0.9f;
-    __shared__ float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
+    __shared__ __attribute__((aligned(16))) float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
     __shared__ __attribute__((aligned(16))) float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
     __shared__ float ctile[2 * MD + 1][kXB + 1];
     float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[1];
@@ -163,53 +164,76 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             // keep the LDS reads of all kU directions in flight together: a direction whose span is
             // shorter than the pass's longest simply computes a few entries nobody reads (rows[],
             // tb[] and ws[] are padded for the overshoot).
-            int uu[kU], jlo[kU];
+            // The LDS pipeline is this kernel's limit (4 SIMDs share it: 1.45 x the VALU time before this
+            // layout), so the pass moves as few LDS bytes as the data flow allows: the kU directions start
+            // their t_base at ONE column (the unshifted taps r3p[j], r1p[j], r1n[j] are then read once for all
+            // of them), every lane owns two neighbouring entries (8-byte reads), and a window sum reads its
+            // 2*nrad+2 inputs once for both of its outputs.
+            int uu[kU];
 #pragma unroll
-            for (int i = 0; i < kU; ++i) {
-                const int u = min(ug + i, mdis), two_u = 2 * u;  // past +mdis: a duplicate of the last direction (same values, same slots)
-                uu[i] = u;
-                jlo[i] = min(u, min(0, two_u)) - nrad;  // t_base columns xb+jlo .. xb+63+max(u, 0, 2u)+nrad are the ones read back
-            }
+            for (int i = 0; i < kU; ++i) uu[i] = min(ug + i, mdis);  // past +mdis: a duplicate of the last direction (same values, same slots)
+            // t_base columns xb+jlo .. are the ones read back; direction u needs them from min(u, 0, 2u) - nrad on,
+            // the pass's smallest u sets the common start (even distance to the staged rows: 8-byte aligned pairs)
+            const int jlo = min(0, 2 * ug) - nrad;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int t = lane + 64 * it;
-                float val[kU];
+            for (int it = 0; it < NIT2; ++it) {
+                const int t = 2 * lane + 128 * it;
+                const int j = jlo + t + reach;  // rows[] index of column xb + jlo + t (even)
+                const float2 a = *reinterpret_cast<const float2 *>(&rows[0][j]);
+                const float2 c = *reinterpret_cast<const float2 *>(&rows[1][j]);
+                const float2 e = *reinterpret_cast<const float2 *>(&rows[2][j]);
+                float2 val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
                     const int two_u = 2 * uu[i];
-                    const int j = jlo[i] + t + reach;  // rows[] index of column xb + jlo + t
-                    const float a = rows[0][j], b = rows[1][j - two_u], c = rows[1][j];
-                    const float d = rows[2][j - two_u], e = rows[2][j], f = rows[3][j - two_u];
-                    val[i] = fabsf(a - b) + fabsf(c - d) + fabsf(e - f);  // :415-425
+                    const float2 b = *reinterpret_cast<const float2 *>(&rows[1][j - two_u]);
+                    const float2 d = *reinterpret_cast<const float2 *>(&rows[2][j - two_u]);
+                    const float2 f = *reinterpret_cast<const float2 *>(&rows[3][j - two_u]);
+                    val[i].x = fabsf(a.x - b.x) + fabsf(c.x - d.x) + fabsf(e.x - f.x);  // :415-425
+                    val[i].y = fabsf(a.y - b.y) + fabsf(c.y - d.y) + fabsf(e.y - f.y);
                 }
 #pragma unroll
-                for (int i = 0; i < kU; ++i) tb[i][t] = val[i];
+                for (int i = 0; i < kU; ++i) *reinterpret_cast<float2 *>(&tb[i][t]) = val[i];
             }
             wave_fence();
             // window sums, accumulated from 0 in k order exactly like sw0/sw1/sw2 (:443-450): the
             // three sums of a pixel are the same function of t_base at x+u, x, x+2u
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int t = lane + nrad + 64 * it;
-                float val[kU];
+            for (int it = 0; it < NIT2; ++it) {
+                const int t = 2 * lane + 128 * it;  // inputs tb[t .. t + 2*nrad + 1], outputs ws[t + nrad], ws[t + nrad + 1]
+                float2 val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
-                    float sw = 0.0f;
+                    float v[2 * NRAD + 2];
 #pragma unroll
-                    for (int k = -nrad; k <= nrad; ++k) sw += tb[i][t + k];
-                    val[i] = sw;
+                    for (int m = 0; m <= NRAD; ++m) {
+                        const float2 p = *reinterpret_cast<const float2 *>(&tb[i][t + 2 * m]);
+                        v[2 * m] = p.x;
+                        v[2 * m + 1] = p.y;
+                    }
+                    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k <= 2 * NRAD; ++k) {
+                        s0 += v[k];
+                        s1 += v[k + 1];
+                    }
+                    val[i].x = s0;
+                    val[i].y = s1;
                 }
 #pragma unroll
-                for (int i = 0; i < kU; ++i) ws[i][t] = val[i];
+                for (int i = 0; i < kU; ++i) {
+                    ws[i][t + nrad] = val[i].x;
+                    ws[i][t + nrad + 1] = val[i].y;
+                }
             }
             wave_fence();
             {
                 const int lxc = lx;  // lanes past the line end compute on staged (clamped) columns and store nothing
+                const int base = lane - jlo;  // tb/ws index of column x
                 float val[kU];
 #pragma unroll
                 for (int i = 0; i < kU; ++i) {
                     const int u = uu[i], two_u = 2 * u;
-                    const int base = (lxc - reach) - jlo[i];  // tb/ws index of the column
                     const float sw1 = ws[i][base], sw0 = ws[i][base + u], sw2 = ws[i][base + two_u];
                     const float ip = (rows[1][lxc + u] + rows[2][lxc - u]) * 0.5f;
                     const float v = fabsf(rows[1][lxc] - ip) + fabsf(rows[2][lxc] - ip);
