@@ -449,7 +449,7 @@ __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, floa
 // row — 12 loads per map instead of 36. Every output still accumulates its 9 taps in tap order
 // with the same fused / unfused operations, so the f32 maps are unchanged.
 __device__ __forceinline__ void ssim_maps_tile_blocked(const MapsArgs &a, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0,
-                                                       float (*s1)[IW + 1], float (*s2)[IW + 1], float (*vt)[TH][IW + 1], double acc[6]) {
+                                                       float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
     const int tid = threadIdx.x;
     {
         // stage the 40 x 40 tile of both frames: all 14 loads of a thread in flight before the first LDS write
@@ -504,39 +504,28 @@ __device__ __forceinline__ void ssim_maps_tile_blocked(const MapsArgs &a, const 
                 m = __builtin_elementwise_fma(kk, v2f{p[o + k], q[o + k]}, m);
                 if (do_ssim) ms = __builtin_elementwise_fma(kk, v2f{pq[o + k], sq[o + k]}, ms);
             }
-            vt[0][r0 + o][c] = ms.x;
-            vt[1][r0 + o][c] = ms.y;
-            vt[2][r0 + o][c] = m.x;
-            vt[3][r0 + o][c] = m.y;
+            vt[r0 + o][c] = v4f{ms.x, ms.y, m.x, m.y};
         }
     }
     __syncthreads();
     constexpr int HC = 4;  // adjacent outputs per thread in the horizontal pass: 32 rows x 8 strips = 256 threads
     {
         const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
-        float t2[HC + 8], t3[HC + 8], t0[HC + 8], t1[HC + 8];
+        // one 16-byte LDS read per column; (mu1, mu2) and (b12, bsq) accumulate as packed pairs (v_pk_mul_f32 +
+        // v_pk_add_f32: unfused and element-wise IEEE, blurH :276)
+        v4f t[HC + 8];
 #pragma unroll
-        for (int j = 0; j < HC + 8; ++j) {
-            t2[j] = vt[2][r][xs + j];
-            t3[j] = vt[3][r][xs + j];
-            if (do_ssim) {
-                t0[j] = vt[0][r][xs + j];
-                t1[j] = vt[1][r][xs + j];
-            }
-        }
+        for (int j = 0; j < HC + 8; ++j) t[j] = vt[r][xs + j];
 #pragma unroll
         for (int o = 0; o < HC; ++o) {
-            float mu1 = 0.0f, mu2 = 0.0f, b12 = 0.0f, bsq = 0.0f;
+            v2f mu = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {  // blurH :276, unfused
-                const float kk = c_kernel[k];
-                mu1 += kk * t2[o + k];
-                mu2 += kk * t3[o + k];
-                if (do_ssim) {
-                    b12 += kk * t0[o + k];
-                    bsq += kk * t1[o + k];
-                }
+            for (int k = 0; k < 9; ++k) {
+                const v2f kk = {c_kernel[k], c_kernel[k]};
+                mu = mu + kk * v2f{t[o + k].z, t[o + k].w};
+                if (do_ssim) bs = bs + kk * v2f{t[o + k].x, t[o + k].y};
             }
+            const float mu1 = mu.x, mu2 = mu.y, b12 = bs.x, bsq = bs.y;
             maps_pixel(mu1, mu2, b12, bsq, s1[r + HALO][xs + o + HALO], s2[r + HALO][xs + o + HALO], do_ssim, do_edge, acc);
         }
     }
@@ -546,7 +535,7 @@ __device__ __forceinline__ void ssim_maps_tile_blocked(const MapsArgs &a, const 
 // split, so every tap offset is a compile-time constant and the index arithmetic folds away.
 template <bool INTERIOR>
 __device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0,
-                                               float (*s1)[IW + 1], float (*s2)[IW + 1], float (*vt)[TH][IW + 1], double acc[6]) {
+                                               float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
     const int w = a.w, h = a.h;
     const int cx0 = INTERIOR ? x0 - HALO : max(x0 - HALO, 0), cy0 = INTERIOR ? y0 - HALO : max(y0 - HALO, 0);  // real coords of LDS (0,0)
     const int cw = INTERIOR ? IW : min(x0 + TW + HALO, w) - cx0, ch = INTERIOR ? IH : min(y0 + TH + HALO, h) - cy0;
@@ -586,10 +575,7 @@ __device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *i
                 if (do_ssim) ms = ms + kk * (a * b2);
             }
         }
-        vt[0][r][c] = ms.x;
-        vt[1][r][c] = ms.y;
-        vt[2][r][c] = m.x;
-        vt[3][r][c] = m.y;
+        vt[r][c] = v4f{ms.x, ms.y, m.x, m.y};
     }
     __syncthreads();
 
@@ -603,12 +589,9 @@ __device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *i
         for (int k = 0; k < 9; ++k) {
             const int cc = INTERIOR ? c + k : tap_index(k, x, w) - cx0;
             const v2f kk = {c_kernel[k], c_kernel[k]};
-            const v2f v23 = {vt[2][r][cc], vt[3][r][cc]};
-            mu = mu + kk * v23;
-            if (do_ssim) {
-                const v2f v01 = {vt[0][r][cc], vt[1][r][cc]};
-                bs = bs + kk * v01;
-            }
+            const v4f t = vt[r][cc];
+            mu = mu + kk * v2f{t.z, t.w};
+            if (do_ssim) bs = bs + kk * v2f{t.x, t.y};
         }
         maps_pixel(mu.x, mu.y, bs.x, bs.y, s1[y0 + r - cy0][x - cx0], s2[y0 + r - cy0][x - cx0], do_ssim, do_edge, acc);
     }
@@ -616,7 +599,7 @@ __device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *i
 
 __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
     __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];  // XYB tile of both frames
-    __shared__ float vt[4][TH][IW + 1];               // vertical pass of the 4 maps
+    __shared__ v4f vt[TH][IW + 1];                    // vertical pass of the 4 maps, interleaved: (b12, bsq, mu1, mu2) of a pixel in one 16-byte word
     __shared__ double red[4][6];
 
     const int ps = blockIdx.z % a.nactive, pair = blockIdx.z / a.nactive;
