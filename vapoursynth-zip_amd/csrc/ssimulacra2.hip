@@ -405,6 +405,7 @@ struct MapsArgs {
     int nactive;
     int stride, w, h;
     int tiles_x, tiles_y;
+    int tpb;          // tiles (along x) per block
     double *partial;  // [pair][slot][tile][6]
     int max_tiles;
 };
@@ -448,35 +449,39 @@ __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, floa
 // per input row instead of once per tap. Horizontal pass: a thread owns 4 adjacent outputs of a
 // row — 12 loads per map instead of 36. Every output still accumulates its 9 taps in tap order
 // with the same fused / unfused operations, so the f32 maps are unchanged.
-__device__ __forceinline__ void ssim_maps_tile_blocked(const MapsArgs &a, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0,
-                                                       float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
+constexpr int kMapsNS = (IH * IW + 255) / 256;  // staged samples per thread and frame
+
+// the 40 x 40 input tile of both frames: all 14 loads of a thread in flight before anything waits on them
+// (global address space: plane pointers read from the pair table are generic to the compiler — flat
+// loads, each followed by a full s_waitcnt in the rolled loop)
+__device__ __forceinline__ void ssim_maps_fetch(const MapsArgs &a, const float *im1, const float *im2, int x0, int y0, float v1[kMapsNS], float v2[kMapsNS]) {
+    const float VSZIP_GLOBAL *g1 = (const float VSZIP_GLOBAL *)im1, *g2 = (const float VSZIP_GLOBAL *)im2;
     const int tid = threadIdx.x;
-    {
-        // stage the 40 x 40 tile of both frames: all 14 loads of a thread in flight before the first LDS write
-        // (global address space: plane pointers read from the pair table are generic to the compiler — flat
-        // loads, each followed by a full s_waitcnt in the rolled loop)
-        const float VSZIP_GLOBAL *g1 = (const float VSZIP_GLOBAL *)im1, *g2 = (const float VSZIP_GLOBAL *)im2;
-        constexpr int NS = (IH * IW + 255) / 256;
-        float v1[NS], v2[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int i = min(tid + 256 * k, IH * IW - 1);
+    for (int k = 0; k < kMapsNS; ++k) {
+        const int i = min(tid + 256 * k, IH * IW - 1);
+        const int r = i / IW, c = i - r * IW;
+        const size_t o = (size_t)(y0 - HALO + r) * a.stride + (x0 - HALO + c);
+        v1[k] = g1[o];
+        v2[k] = g2[o];
+    }
+}
+__device__ __forceinline__ void ssim_maps_park(const float v1[kMapsNS], const float v2[kMapsNS], float (*s1)[IW + 1], float (*s2)[IW + 1]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kMapsNS; ++k) {
+        const int i = tid + 256 * k;
+        if (i < IH * IW) {
             const int r = i / IW, c = i - r * IW;
-            const size_t o = (size_t)(y0 - HALO + r) * a.stride + (x0 - HALO + c);
-            v1[k] = g1[o];
-            v2[k] = g2[o];
-        }
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int i = tid + 256 * k;
-            if (i < IH * IW) {
-                const int r = i / IW, c = i - r * IW;
-                s1[r][c] = v1[k];
-                s2[r][c] = v2[k];
-            }
+            s1[r][c] = v1[k];
+            s2[r][c] = v2[k];
         }
     }
-    __syncthreads();
+}
+
+// interior tile whose inputs are already in s1 / s2
+__device__ __forceinline__ void ssim_maps_tile_blocked(bool do_ssim, bool do_edge, float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
+    const int tid = threadIdx.x;
     constexpr int VR = 8;  // output rows per thread in the vertical pass
     if (tid < IW * (TH / VR)) {
         const int c = tid % IW, r0 = (tid / IW) * VR;
@@ -606,27 +611,43 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
     const PairPtrs &pp = a.tab[pair];
     const float *im1 = pp.xyb1[a.plane[ps]], *im2 = pp.xyb2[a.plane[ps]];
     const int w = a.w, h = a.h;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int y0 = blockIdx.y * TH;
     const bool do_ssim = a.flags[ps] & 1, do_edge = a.flags[ps] & 2;
     const int tid = threadIdx.x;
-    const bool interior = x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h;
-
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (interior)
-        ssim_maps_tile_blocked(a, im1, im2, do_ssim, do_edge, x0, y0, s1, s2, vt, acc);
-    else
-        ssim_maps_tile<false>(a, im1, im2, do_ssim, do_edge, x0, y0, s1, s2, vt, acc);
+    auto is_interior = [&](int x0) { return x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h; };
+    // A block walks a.tpb neighbouring tiles: the first scale's planes stream from HBM and with one tile per
+    // block nothing hid that latency (its launch cost twice as much per pixel as the cached scales), so the next
+    // interior tile's inputs are fetched into registers while this one is filtered.
+    const int tx0 = blockIdx.x * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
+    float v1[kMapsNS], v2[kMapsNS];
+    bool fetched = false;
+    for (int tx = tx0; tx < tx1; ++tx) {
+        const int x0 = tx * TW;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (is_interior(x0)) {
+            if (!fetched) ssim_maps_fetch(a, im1, im2, x0, y0, v1, v2);
+            ssim_maps_park(v1, v2, s1, s2);
+            __syncthreads();
+            fetched = tx + 1 < tx1 && is_interior(x0 + TW);
+            if (fetched) ssim_maps_fetch(a, im1, im2, x0 + TW, y0, v1, v2);
+            ssim_maps_tile_blocked(do_ssim, do_edge, s1, s2, vt, acc);
+        } else {
+            fetched = false;
+            ssim_maps_tile<false>(a, im1, im2, do_ssim, do_edge, x0, y0, s1, s2, vt, acc);
+        }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) acc[q] = wave_reduce_sum(acc[q]);
-    if ((tid & 63) == 0) {
+        for (int q = 0; q < 6; ++q) acc[q] = wave_reduce_sum(acc[q]);
+        if ((tid & 63) == 0) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
-    }
-    __syncthreads();
-    if (tid < 6) {
-        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        const int tile = blockIdx.y * a.tiles_x + blockIdx.x;
-        a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
+            for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
+        }
+        __syncthreads();
+        if (tid < 6) {
+            const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            const int tile = blockIdx.y * a.tiles_x + tx;
+            a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
+        }
+        __syncthreads();  // s1 / s2 / vt / red are rewritten by the next tile
     }
 }
 
@@ -1060,7 +1081,8 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         ma.max_tiles = tiles0;
         if (ma.nactive > 0) {
             vszip_probe_scope probe(ctx);
-            hipLaunchKernelGGL(ssim_maps_kernel, dim3(ma.tiles_x, ma.tiles_y, ma.nactive * npairs), dim3(256), 0, ctx->stream, ma);
+            ma.tpb = ma.tiles_x >= 32 ? 4 : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
+            hipLaunchKernelGGL(ssim_maps_kernel, dim3((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * npairs), dim3(256), 0, ctx->stream, ma);
         }
         for (int k = 0; k < ma.nactive; ++k) {
             fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
