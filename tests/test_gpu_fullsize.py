@@ -50,6 +50,18 @@ def test_boxblur_r13_4k_yuv420p16(dev, oracle, content):
         assert np.array_equal(g, oracle.boxblur(p, 13, 1, 13, 1))
 
 
+@pytest.mark.parametrize("dtype,r", [(np.float32, 13), (np.float16, 13), (np.float32, 22), (np.float32, 3)])
+def test_boxblur_ct_float_4k_yuv420(dev, oracle, dtype, r):
+    """The float CT path at 4K (register-ring kernel over several column tiles and bands that end inside a ring
+    period, the bottom / left / right strips through the tile kernel): every byte equals the oracle's."""
+    planes = [fx.splitmix64_plane(0x5A170100 + p, s, dtype) for p, s in enumerate(_yuv420((H4K, W4K)))]
+    got, _ = _boxblur(dev, planes, r, 1, r, 1)
+    for g, p in zip(got, planes):
+        want = oracle.boxblur(p, r, 1, r, 1)
+        bad = g.view(np.uint8) != want.view(np.uint8)
+        assert not bad.any(), (dtype, r, p.shape, np.argwhere(bad)[:3].tolist())
+
+
 def test_boxblur_pass_composition_4k(dev):
     """BoxBlur(h=7, hpasses=2) == BoxBlur(h=7) o BoxBlur(h=7) and BoxBlur(4, 9) == v9 o h4 (reference
     tests/test_boxblur.py:86-101), exact, on a 4K u16 plane."""
