@@ -228,7 +228,7 @@ struct FRPlane {
     void *dst;
     int sstride, dstride;
     int ya, yb;          // interior rows [ya, yb)
-    int xb;              // interior columns [HL, xb)
+    int xb;              // interior columns [0, xb)
     int ntx, nbands;
     int block0;
 };
@@ -285,7 +285,12 @@ struct FRWave {
     size_t ss;
     __amdgpu_buffer_rsrc_t rd;  // stores go through a buffer descriptor: halo lanes carry an out-of-range offset and the
     uint32_t sdoff, drow;       // hardware drops them, so a row is ONE unconditional store (no branch for the wait counters to be pessimistic about)
-    float *pw;
+    float *pw, *lds0;  // this lane's LDS slot of row A, pixel 0; the LDS row itself (lane 0's slot)
+    // first column tile of a plane: columns left of 0 are reflect-101 padding (:204-206) and the vertical pass is per
+    // column, so their LDS entries are copies of this row's own entries of columns 1 .. HL - halo lanes fetch them
+    // there (msrc[e]: LDS index of the mirror image of this lane's e-th column; mirror_lane: a halo lane of tile 0)
+    bool left_tile, mirror_lane;
+    int msrc[PXL];
     // LDS address of each neighbour lane's column block, kept opaque to the optimizer: with the lane offset folded
     // into the instruction it pairs reads of neighbouring lanes instead of rows A / B
     static constexpr int NBH = (R + PXL - 1) / PXL + 1;
@@ -335,6 +340,24 @@ struct FRWave {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (left_tile) {  // (uniform)
+            if (mirror_lane) {
+                float a[PXL], bb[PXL];
+#pragma unroll
+                for (int e = 0; e < PXL; ++e) {
+                    a[e] = lds0[msrc[e]];
+                    bb[e] = lds0[msrc[e] + kFRRowB];
+                }
+#pragma unroll
+                for (int e = 0; e < PXL; ++e) {
+                    pw[e * kFRPix] = a[e];
+                    pw[e * kFRPix + kFRRowB] = bb[e];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         v2f q[PXL + 2 * R];  // q[j] = column j - R relative to this lane's first one, rows A and B
 #pragma unroll
         for (int j = 0; j < PXL + 2 * R; ++j) {
@@ -387,15 +410,25 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     const int npairs = (pl.yb - pl.ya + 1) / 2;
     const int y0 = pl.ya + 2 * (int)((long)by * npairs / pl.nbands), y1 = pl.ya + 2 * (int)((long)(by + 1) * npairs / pl.nbands);
     const int lane = threadIdx.x;
-    // this lane's first column (always inside the plane); the last tile is shifted left to end at xb
-    const int cx = min(tx * G::TWO, pl.xb - G::HL - G::TWO) + lane * PXL;
+    // this lane's first column; the last tile is shifted left to end at xb, the first one starts HL columns left of
+    // the plane (its halo lanes hold the reflect-101 images of columns 1 .. HL)
+    const int cx = min(tx * G::TWO, pl.xb - G::TWO) - G::HL + lane * PXL;
     W st;
-    st.sp = static_cast<const T *>(pl.src) + cx;
+    st.left_tile = tx == 0;
+    st.mirror_lane = cx < 0;
+#pragma unroll
+    for (int e = 0; e < PXL; ++e) {
+        const int j = -(cx + e);            // mirror image of virtual column cx + e (reflect-101: -j -> j)
+        const int pcol = max(j, 0) + G::HL;  // its position in the tile
+        st.msrc[e] = 8 + (pcol % PXL) * kFRPix + pcol / PXL;
+    }
+    st.lds0 = P;
+    st.sp = static_cast<const T *>(pl.src) + max(cx, 0);  // (halo lanes of the first tile load columns they overwrite in LDS)
     st.ss = (size_t)pl.sstride;
     st.drow = (uint32_t)pl.dstride * (uint32_t)sizeof(T);
     st.rd = __builtin_amdgcn_make_buffer_rsrc(pl.dst, 0, (int)((uint32_t)(pl.yb + R) * st.drow), 0x00020000);
     const bool is_out = lane >= G::HL / PXL && lane < G::HL / PXL + G::OUT_LANES;
-    st.sdoff = is_out ? (uint32_t)cx * (uint32_t)sizeof(T) : 0xfffffff0u;
+    st.sdoff = is_out ? (uint32_t)cx * (uint32_t)sizeof(T) : 0xfffffff0u;  // (output lanes: cx >= 0)
     st.div = 1.0f / (float)K;  // :39
     st.last_row = pl.yb + R - 1;  // rows fetched past it are never summed
     st.pw = P + 8 + lane;
@@ -459,7 +492,7 @@ struct RingDispatch<T, 0> {
     static int round_waves(int, int) { return 2048; }
 };
 
-// Interior of a plane for the ring kernel: columns [HL, xb) (xb the last multiple of 4 that leaves HL columns of
+// Interior of a plane for the ring kernel: columns [0, xb) (xb the last multiple of 4 that leaves HL columns of
 // real halo), rows [R, h - R); false when the plane is too small or not 16-byte (f16: 8-byte) aligned - the tile
 // kernel then takes all of it.
 template <typename T>
@@ -468,9 +501,9 @@ bool ring_interior(const vszip_plane &s, int radius, int nr, int hl, int two, in
     if (radius > kFRMaxR || std::getenv("VSZIP_BOXBLUR_NO_FLOAT_RING")) return false;
     if ((reinterpret_cast<uintptr_t>(s.src) | reinterpret_cast<uintptr_t>(s.dst) | (uintptr_t)(s.src_stride * sizeof(T)) | (uintptr_t)(s.dst_stride * sizeof(T))) & (VB - 1)) return false;
     xb = ((s.w - hl) / kFRPx) * kFRPx;
-    ntx = (xb - hl + two - 1) / two;
+    ntx = (xb + two - 1) / two;
     if ((uint64_t)s.dst_stride * s.h * sizeof(T) >= (1ull << 32)) return false;  // 32-bit store offsets
-    return xb - hl >= two && s.h - 2 * radius >= nr;
+    return xb >= two + hl && s.h - 2 * radius >= nr;
 }
 
 template <typename T>
@@ -561,7 +594,6 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
         if (ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) {
             const int ya = 0, yb = s.h - radius;  // (the ring kernel mirrors the top rows itself)
             add_rect(s, 0, yb, s.w, s.h);     // bottom
-            add_rect(s, 0, ya, HL, yb);       // left
             add_rect(s, xb, ya, s.w, yb);     // right
         } else {
             add_rect(s, 0, 0, s.w, s.h);
