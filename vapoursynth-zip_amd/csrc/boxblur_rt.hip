@@ -436,6 +436,15 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
     }
 }
 
+#ifndef VSZIP_RTF_PF
+#define VSZIP_RTF_PF 32
+#endif
+#ifndef VSZIP_RTF_LW
+#define VSZIP_RTF_LW 64
+#endif
+#ifndef VSZIP_RTF_RB
+#define VSZIP_RTF_RB 16
+#endif
 // ---- RT float: blurFloat (:43-79) — a running f32 sum per line, sequential by definition ------
 // Index of the sample entering / leaving the window at output x (the three loops of blurFloat :55-78
 // as one pair of functions: x <= R, R < x < len - R, x >= len - R).
@@ -449,14 +458,21 @@ template <typename T>
 __global__ __launch_bounds__(64) void boxblur_rt_float_v_kernel(const RParams prm) {
     const int b = blockIdx.x;
     const RPlane pl = prm.p[rt_find(prm, b)];
-    const int i = (b - pl.block0) * 64 + threadIdx.x;
-    if (i >= pl.w) return;
+    // kLW columns per wave. Measured on 8 4K YUV420PS frames, 3+3 passes of r = 5 (k fps): 64 -> 5.9, 32 -> 5.2,
+    // 16 -> 3.6; a variant with 16-byte loads (4 columns per lane, a quarter of the waves) 5.6: the pass is bound by
+    // the number of row requests in flight, not by a wave's chain.
+    constexpr int kLW = VSZIP_RTF_LW;
+    const int i = (b - pl.block0) * kLW + threadIdx.x;
+    if ((int)threadIdx.x >= kLW || i >= pl.w) return;
     const T *s = static_cast<const T *>(pl.src) + i;
     T *d = static_cast<T *>(pl.dst) + i;
     const size_t ss = pl.sstride, ds = pl.dstride;
     const int len = pl.h, R = prm.radius;
     const float div = 1.0f / (float)(R * 2 + 1);
-    constexpr int kPf = 8;
+    // columns are the only parallelism a running sum leaves (one wave per 64 columns: about one wave per SIMD on
+    // 8 4K frames), so the chain must never wait on memory: 2 x kPf rows (entering + leaving) are in flight per
+    // wave while the previous kPf are summed - 8 rows left the launch latency bound at 1.2 TB/s
+    constexpr int kPf = VSZIP_RTF_PF;
     float sum = 0.0f;
     for (int x0 = 0; x0 <= R; x0 += kPf) {  // :47-49 — sum = s[R] + 2 * s[0] + 2 * s[1] + ..., in that order
         float q[kPf];
@@ -507,12 +523,16 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_v_kernel(const RParams pr
 // fetched into registers while the current chunk is summed.
 template <typename T>
 __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams prm) {
-    __shared__ float tin[64][65], tout[64][65];
+    // RB rows per wave: rows are the only parallelism of this pass, and a wave's time is the latency of its chain
+    // (LDS round trips, not lane work), so fewer rows per wave = more waves in flight = proportionally faster until
+    // HBM saturates (64 rows: 544 waves on 8 4K frames, half the SIMDs idle)
+    constexpr int RB = VSZIP_RTF_RB;
+    __shared__ float tin[RB][65], tout[RB][65];
     const int b = blockIdx.x;
     const RPlane pl = prm.p[rt_find(prm, b)];
     const int lane = threadIdx.x;
-    const int y0 = (b - pl.block0) * 64;
-    const int rows = min(64, pl.h - y0), len = pl.w, R = prm.radius;
+    const int y0 = (b - pl.block0) * RB;
+    const int rows = min(RB, pl.h - y0), len = pl.w, R = prm.radius;
     const T *s = static_cast<const T *>(pl.src) + (size_t)y0 * pl.sstride;
     T *d = static_cast<T *>(pl.dst) + (size_t)y0 * pl.dstride;
     const size_t ss = pl.sstride, ds = pl.dstride;
@@ -526,12 +546,12 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
         sum = sum * div;
     }
     const int nchunk = (len + 63) / 64;
-    float ni[64], no[64];
+    float ni[RB], no[RB];
     auto fetch = [&](int c) __attribute__((always_inline)) {
         const int x = min(c * 64 + lane, len - 1);
         const int ci = rtf_in(x, len, R), co = rtf_out(x, R);
 #pragma unroll
-        for (int r = 0; r < 64; ++r) {
+        for (int r = 0; r < RB; ++r) {
             const T *row = s + (size_t)min(r, rows - 1) * ss;
             ni[r] = (float)row[ci];
             no[r] = (float)row[co];
@@ -540,7 +560,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
     fetch(0);
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-        for (int r = 0; r < 64; ++r) {
+        for (int r = 0; r < RB; ++r) {
             tin[r][lane] = ni[r];
             tout[r][lane] = no[r];
         }
@@ -591,6 +611,10 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
             prm.p[i].block0 = blocks;
             if (is_int && !vertical)
                 blocks += prm.p[i].h;
+            else if (!is_int && !vertical)
+                blocks += (prm.p[i].h + VSZIP_RTF_RB - 1) / VSZIP_RTF_RB;
+            else if (!is_int)
+                blocks += (prm.p[i].w + VSZIP_RTF_LW - 1) / VSZIP_RTF_LW;
             else
                 blocks += ((vertical ? prm.p[i].w : prm.p[i].h) + 63) / 64;
             maxw = std::max(maxw, prm.p[i].w);
