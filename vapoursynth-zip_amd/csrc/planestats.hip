@@ -567,14 +567,17 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
         else                                                                                         \
             hipLaunchKernelGGL((average_kernel<T, false, NEX>), grid, block, 0, ctx->stream, L.prm); \
     } while (0)
-    if (nex == 0)
-        VSZIP_AVG_LAUNCH(0);
-    else if (nex == 1)
-        VSZIP_AVG_LAUNCH(1);
-    else if (nex == 8)
-        VSZIP_AVG_LAUNCH(8);
-    else
-        VSZIP_AVG_LAUNCH(-1);
+    {
+        vszip_probe_scope probe(ctx);  // the plane reader (the final kernels and the copy-back are not it)
+        if (nex == 0)
+            VSZIP_AVG_LAUNCH(0);
+        else if (nex == 1)
+            VSZIP_AVG_LAUNCH(1);
+        else if (nex == 8)
+            VSZIP_AVG_LAUNCH(8);
+        else
+            VSZIP_AVG_LAUNCH(-1);
+    }
 #undef VSZIP_AVG_LAUNCH
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (Smp<T>::is_int)
@@ -590,11 +593,17 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
     constexpr int is_int = Smp<T>::is_int ? 1 : 0;
     constexpr int wide = sizeof(T) > 1 ? 1 : 0;
     if (no_thr) {
-        hipLaunchKernelGGL((minmax_kernel<T, REF>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+        {
+            vszip_probe_scope probe(ctx);
+            hipLaunchKernelGGL((minmax_kernel<T, REF>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+        }
         hipLaunchKernelGGL(minmax_final_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, is_int);
     } else {
         VSZIP_HIP_CHECK(ctx, hipMemsetAsync(L.prm.hist, 0, (size_t)L.prm.nplanes * 512 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL((hist_kernel<T, REF, 0>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+        {
+            vszip_probe_scope probe(ctx);
+            hipLaunchKernelGGL((hist_kernel<T, REF, 0>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+        }
         hipLaunchKernelGGL(bucket_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, wide);
         if (wide) hipLaunchKernelGGL((hist_kernel<T, false, 1>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
         hipLaunchKernelGGL(thr_final_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, wide, is_int);
