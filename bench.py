@@ -548,21 +548,28 @@ def pcie_boxblur(vszip_amd, device_index: int, radius: int, nctx: int = 4, round
         ctxs.append((d, hin, hout, dsrc, ddst, d.plane_table(dsrc, ddst)))
 
     def one_round():
+        # a context waits for ITS previous frame only (like a worker thread that owns it), so the other contexts'
+        # copies and kernels stay in flight across rounds; the clock stops after every context has drained
         for d, hin, hout, dsrc, ddst, table in ctxs:
+            d.sync()
             for a, dp in zip(hin, dsrc):
                 d.copy_in(dp, a)
             d.boxblur_table(np.uint16, table, radius, 1, radius, 1)
             for a, dp in zip(hout, ddst):
                 d.copy_out(a, dp)
+
+    def drain():
         for c in ctxs:
             c[0].sync()
 
     one_round()
+    drain()
     if barrier:
         barrier()  # every rank starts its timed rounds together: the host links are shared
     t0 = time.perf_counter()
     for _ in range(rounds):
         one_round()
+    drain()
     dt = time.perf_counter() - t0
     fps = nctx * rounds / dt
     fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K))
