@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -193,10 +194,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #endif
 constexpr int kL16Split = VSZIP_L16_SPLIT;
 constexpr int kL16Rows = 16;                       // thread rows of the workgroup: 64 x 16 = 1024 threads
-constexpr int kL16TileH = 64;                      // output rows per tile (4 per wave)
+// output rows per tile: 64 (4 per wave) for 2-byte samples; f32 tiles are half as high so that two of them still fit
+// beside the table (2 x 70 x 38 x 4 B at radius 3)
+template <typename T>
+constexpr int kL16TileH = sizeof(T) == 4 ? 32 : 64;
 constexpr int kL16LutBytes = 4096 + 131072;        // base + delta
 constexpr int kL16MaxLds = 160 * 1024;
-constexpr int kL16MaxStage = 6;                    // staged samples per thread and clip: tiles up to 1024 * 6 samples
+// staged samples per thread and clip: tiles up to 1024 * kL16MaxStage samples
+template <typename T>
+constexpr int kL16MaxStage = sizeof(T) == 4 ? 4 : 6;
 
 // CR / CS > 0: every plane of the launch has this radius / step (the BASELINE's luma 3 / 2 and chroma 2 / 1):
 // the tap loops unroll and every LDS offset becomes an immediate; 0 = read them from the plane table.
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     // Only ONE workgroup fits a CU, so nothing else hides a tile's global loads: the next tile is fetched into
     // registers while this one is filtered, and the two LDS tile buffers alternate (one barrier per tile).
     const int tile_elems_max = prm.lut_offset;  // (reused field) samples of the largest tile of the launch, per clip
-    T pre_r[kL16MaxStage], pre_s[JOINT ? kL16MaxStage : 1];
+    T pre_r[kL16MaxStage<T>], pre_s[JOINT ? kL16MaxStage<T> : 1];
     int pi = 0;
     auto plane_of = [&](int b) {
         while (pi + 1 < prm.nplanes && b >= prm.p[pi + 1].block0) ++pi;  // tiles are visited in increasing order
@@ -231,11 +237,11 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     auto fetch = [&](int b) {
         const BLPlane &pl = prm.p[plane_of(b)];
         const int lb = b - pl.block0;
-        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH;
-        const int r = CR > 0 ? CR : pl.radius, tw = kBX + 2 * r, n = tw * (kL16TileH + 2 * r);
+        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH<T>;
+        const int r = CR > 0 ? CR : pl.radius, tw = kBX + 2 * r, n = tw * (kL16TileH<T> + 2 * r);
         const T *src = static_cast<const T *>(pl.src), *ref = static_cast<const T *>(pl.ref);
 #pragma unroll
-        for (int k = 0; k < kL16MaxStage; ++k) {
+        for (int k = 0; k < kL16MaxStage<T>; ++k) {
             const int i = min(tid + k * NT, n - 1);
             const int t = i / tw, c = i - t * tw;
             const int gy = min(max(y0 - r + t, 0), pl.h - 1), gx = min(max(x0 - r + c, 0), pl.w - 1);
@@ -249,13 +255,13 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     for (; b < nblocks; b += gridDim.x, buf ^= 1) {
         const BLPlane &pl = prm.p[plane_of(b)];
         const int lb = b - pl.block0;
-        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH;
+        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH<T>;
         const int r = CR > 0 ? CR : pl.radius;
-        const int tw = kBX + 2 * r, th = kL16TileH + 2 * r, n = tw * th;
+        const int tw = kBX + 2 * r, th = kL16TileH<T> + 2 * r, n = tw * th;
         T *tr = tiles + (size_t)buf * tile_elems_max * (JOINT ? 2 : 1);
         T *ts = JOINT ? tr + tile_elems_max : tr;
 #pragma unroll
-        for (int k = 0; k < kL16MaxStage; ++k) {
+        for (int k = 0; k < kL16MaxStage<T>; ++k) {
             const int i = tid + k * NT;
             if (i < n) {
                 tr[i] = pre_r[k];
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
                     sum += sv * (f1 * rw1 + f2 * rw2 + f3 * rw3 + f4 * rw4);
                 };
 #pragma unroll 1
-                for (int k = 0; k < kL16TileH / kL16Rows; k += 2) {
+                for (int k = 0; k < kL16TileH<T> / kL16Rows; k += 2) {
                     const int lya = tyi + kL16Rows * k, lyb = lya + kL16Rows;
                     const int ya = y0 + lya, yb = y0 + lyb;
                     if (ya >= pc.h) break;
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
                 }
             } else {
 #pragma unroll 1
-                for (int k = 0; k < kL16TileH / kL16Rows; ++k) {
+                for (int k = 0; k < kL16TileH<T> / kL16Rows; ++k) {
                     const int ly = tyi + kL16Rows * k;
                     const int y = y0 + ly;
                     if (y >= pc.h) break;
@@ -680,16 +686,19 @@ int run_pbfic(vszip_ctx *ctx, const vszip_plane &s, const vszip_bilateral_cfg &c
 // in the same device allocation: keyed by the gr_lut pointer, dropped when the pointer is freed.
 struct PackedLuts {
     std::mutex mu;
-    std::set<const void *> exact;
+    std::map<const void *, uint64_t> exact;  // pointer -> content key (the bits of sigmaR: length and peak are fixed for these tables)
 };
 PackedLuts &packed_luts() {
     static PackedLuts *p = new PackedLuts();
     return *p;
 }
-bool lut_is_packed(const void *gr) {
+bool lut_is_packed(const void *gr, uint64_t *key = nullptr) {
     PackedLuts &p = packed_luts();
     std::lock_guard<std::mutex> lk(p.mu);
-    return p.exact.count(gr) != 0;
+    const auto it = p.exact.find(gr);
+    if (it == p.exact.end()) return false;
+    if (key) *key = it->second;
+    return true;
 }
 
 template <typename T, bool JOINT, int CR, int CS>
@@ -703,7 +712,7 @@ int launch_lds16_k(vszip_ctx *ctx, const BLParams &prm, int blocks, size_t lds) 
 
 template <typename T>
 int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_radius) {
-    const int tile_elems = (kBX + 2 * max_radius) * (kL16TileH + 2 * max_radius);
+    const int tile_elems = (kBX + 2 * max_radius) * (kL16TileH<T> + 2 * max_radius);
     prm.lut_offset = tile_elems;  // (the field is free in this kernel: samples of the largest tile, per clip)
     const size_t lds = (size_t)2 * tile_elems * sizeof(T) * (joint ? 2 : 1);  // dynamic part; the LUT is static
     int r = prm.p[0].radius, st = prm.p[0].step;
@@ -805,7 +814,9 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
         VSZIP_HIP_CHECK(ctx, hipMemcpy(static_cast<char *>(d) + gr_bytes + 4096, pdelta.data(), 131072, hipMemcpyHostToDevice));
         PackedLuts &pl = packed_luts();
         std::lock_guard<std::mutex> lk(pl.mu);
-        pl.exact.insert(d);
+        uint64_t key;
+        std::memcpy(&key, &cfg->sigmaR, sizeof key);
+        pl.exact[d] = key;
     }
     cfg->gr_lut = static_cast<float *>(d);
     if (cfg->algorithm == 2) {
@@ -894,16 +905,24 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         bool lds16 = tiled && dtype != VSZIP_U8 && prm.lut_len == 65536;
         {
             const size_t bps = dtype == VSZIP_F32 ? 4 : 2;
-            const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (kL16TileH + 2 * max_radius);
-            lds16 = lds16 && tile_elems <= (size_t)kBX * kL16Rows * kL16MaxStage && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
+            const int tile_h = dtype == VSZIP_F32 ? kL16TileH<float> : kL16TileH<uint16_t>;
+            const int stages = dtype == VSZIP_F32 ? kL16MaxStage<float> : kL16MaxStage<uint16_t>;
+            const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (tile_h + 2 * max_radius);
+            lds16 = lds16 && tile_elems <= (size_t)kBX * kL16Rows * stages && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
             for (int i = 0; i < n && lds16; ++i) lds16 = lut_is_packed(prm.p[i].gr);
         }
         if (lds16) {
-            std::vector<const float *> tables;
-            for (int i = 0; i < n; ++i)
-                if (std::find(tables.begin(), tables.end(), prm.p[i].gr) == tables.end()) tables.push_back(prm.p[i].gr);
+            // planes whose tables have the same content and the same radius / step (the planes of an RGB clip, the
+            // chroma planes of a YUV one) share a launch, whichever allocation each of them points at
+            std::vector<uint64_t> keys(n), tables;
+            for (int i = 0; i < n; ++i) {
+                lut_is_packed(prm.p[i].gr, &keys[i]);
+                // ... and the same radius / step: the launch then takes the kernel with compile-time taps
+                keys[i] = keys[i] * 1000003u + (uint64_t)prm.p[i].radius * 64u + (uint64_t)prm.p[i].step;
+                if (std::find(tables.begin(), tables.end(), keys[i]) == tables.end()) tables.push_back(keys[i]);
+            }
             rc = VSZIP_OK;
-            for (const float *tbl : tables) {
+            for (const uint64_t tbl : tables) {
                 BLParams q;
                 q.peak = prm.peak;
                 q.lut_len = prm.lut_len;
@@ -911,11 +930,12 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 q.nplanes = 0;
                 int qb = 0;
                 for (int i = 0; i < n; ++i) {
-                    if (prm.p[i].gr != tbl) continue;
+                    if (keys[i] != tbl) continue;
                     BLPlane &dp = q.p[q.nplanes++];
                     dp = prm.p[i];
                     dp.block0 = qb;
-                    qb += dp.nbx * ((dp.h + kL16TileH - 1) / kL16TileH);
+                    const int tile_h = dtype == VSZIP_F32 ? kL16TileH<float> : kL16TileH<uint16_t>;
+                    qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
                 }
                 switch (dtype) {
                     case VSZIP_U16: rc = launch_lds16<uint16_t>(ctx, q, qb, joint, max_radius); break;
