@@ -194,15 +194,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #endif
 constexpr int kL16Split = VSZIP_L16_SPLIT;
 constexpr int kL16Rows = 16;                       // thread rows of the workgroup: 64 x 16 = 1024 threads
-// output rows per tile: 64 (4 per wave) for 2-byte samples; f32 tiles are half as high so that two of them still fit
-// beside the table (2 x 70 x 38 x 4 B at radius 3)
-template <typename T>
-constexpr int kL16TileH = sizeof(T) == 4 ? 32 : 64;
+// output rows per tile: 64 (4 per wave) for 2-byte samples; f32 tiles, and the tile pairs of a joint (`ref`) clip,
+// are half as high so that two buffers of them still fit beside the table (2 x 70 x 38 x 4 B at radius 3)
+template <typename T, bool JOINT>
+constexpr int kL16TileH = (sizeof(T) == 4 || JOINT) ? 32 : 64;
 constexpr int kL16LutBytes = 4096 + 131072;        // base + delta
 constexpr int kL16MaxLds = 160 * 1024;
 // staged samples per thread and clip: tiles up to 1024 * kL16MaxStage samples
-template <typename T>
-constexpr int kL16MaxStage = sizeof(T) == 4 ? 4 : 6;
+template <typename T, bool JOINT>
+constexpr int kL16MaxStage = (sizeof(T) == 4 || JOINT) ? 4 : 6;
 
 // CR / CS > 0: every plane of the launch has this radius / step (the BASELINE's luma 3 / 2 and chroma 2 / 1):
 // the tap loops unroll and every LDS offset becomes an immediate; 0 = read them from the plane table.
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     // Only ONE workgroup fits a CU, so nothing else hides a tile's global loads: the next tile is fetched into
     // registers while this one is filtered, and the two LDS tile buffers alternate (one barrier per tile).
     const int tile_elems_max = prm.lut_offset;  // (reused field) samples of the largest tile of the launch, per clip
-    T pre_r[kL16MaxStage<T>], pre_s[JOINT ? kL16MaxStage<T> : 1];
+    T pre_r[kL16MaxStage<T, JOINT>], pre_s[JOINT ? kL16MaxStage<T, JOINT> : 1];
     int pi = 0;
     auto plane_of = [&](int b) {
         while (pi + 1 < prm.nplanes && b >= prm.p[pi + 1].block0) ++pi;  // tiles are visited in increasing order
@@ -237,11 +237,11 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     auto fetch = [&](int b) {
         const BLPlane &pl = prm.p[plane_of(b)];
         const int lb = b - pl.block0;
-        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH<T>;
-        const int r = CR > 0 ? CR : pl.radius, tw = kBX + 2 * r, n = tw * (kL16TileH<T> + 2 * r);
+        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH<T, JOINT>;
+        const int r = CR > 0 ? CR : pl.radius, tw = kBX + 2 * r, n = tw * (kL16TileH<T, JOINT> + 2 * r);
         const T *src = static_cast<const T *>(pl.src), *ref = static_cast<const T *>(pl.ref);
 #pragma unroll
-        for (int k = 0; k < kL16MaxStage<T>; ++k) {
+        for (int k = 0; k < kL16MaxStage<T, JOINT>; ++k) {
             const int i = min(tid + k * NT, n - 1);
             const int t = i / tw, c = i - t * tw;
             const int gy = min(max(y0 - r + t, 0), pl.h - 1), gx = min(max(x0 - r + c, 0), pl.w - 1);
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     for (; b < nblocks; b += gridDim.x, buf ^= 1) {
         const BLPlane &pl = prm.p[plane_of(b)];
         const int lb = b - pl.block0;
-        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH<T>;
+        const int x0 = (lb % pl.nbx) * kBX, y0 = (lb / pl.nbx) * kL16TileH<T, JOINT>;
         const int r = CR > 0 ? CR : pl.radius;
-        const int tw = kBX + 2 * r, th = kL16TileH<T> + 2 * r, n = tw * th;
+        const int tw = kBX + 2 * r, th = kL16TileH<T, JOINT> + 2 * r, n = tw * th;
         T *tr = tiles + (size_t)buf * tile_elems_max * (JOINT ? 2 : 1);
         T *ts = JOINT ? tr + tile_elems_max : tr;
 #pragma unroll
-        for (int k = 0; k < kL16MaxStage<T>; ++k) {
+        for (int k = 0; k < kL16MaxStage<T, JOINT>; ++k) {
             const int i = tid + k * NT;
             if (i < n) {
                 tr[i] = pre_r[k];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
                     sum += sv * (f1 * rw1 + f2 * rw2 + f3 * rw3 + f4 * rw4);
                 };
 #pragma unroll 1
-                for (int k = 0; k < kL16TileH<T> / kL16Rows; k += 2) {
+                for (int k = 0; k < kL16TileH<T, JOINT> / kL16Rows; k += 2) {
                     const int lya = tyi + kL16Rows * k, lyb = lya + kL16Rows;
                     const int ya = y0 + lya, yb = y0 + lyb;
                     if (ya >= pc.h) break;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
                 }
             } else {
 #pragma unroll 1
-                for (int k = 0; k < kL16TileH<T> / kL16Rows; ++k) {
+                for (int k = 0; k < kL16TileH<T, JOINT> / kL16Rows; ++k) {
                     const int ly = tyi + kL16Rows * k;
                     const int y = y0 + ly;
                     if (y >= pc.h) break;
@@ -712,7 +712,7 @@ int launch_lds16_k(vszip_ctx *ctx, const BLParams &prm, int blocks, size_t lds) 
 
 template <typename T>
 int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_radius) {
-    const int tile_elems = (kBX + 2 * max_radius) * (kL16TileH<T> + 2 * max_radius);
+    const int tile_elems = (kBX + 2 * max_radius) * ((joint ? kL16TileH<T, true> : kL16TileH<T, false>) + 2 * max_radius);
     prm.lut_offset = tile_elems;  // (the field is free in this kernel: samples of the largest tile, per clip)
     const size_t lds = (size_t)2 * tile_elems * sizeof(T) * (joint ? 2 : 1);  // dynamic part; the LUT is static
     int r = prm.p[0].radius, st = prm.p[0].step;
@@ -722,6 +722,8 @@ int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_r
     if (!joint && r == 3 && st == 2) return launch_lds16_k<T, false, 3, 2>(ctx, prm, blocks, lds);  // sigmaS = 2 luma (BASELINE)
     if (!joint && r == 2 && st == 1) return launch_lds16_k<T, false, 2, 1>(ctx, prm, blocks, lds);  // sigmaS = 1: its 4:2:0 chroma
     if (!joint && r == 3 && st == 1) return launch_lds16_k<T, false, 3, 1>(ctx, prm, blocks, lds);  // sigmaS = 1.5
+    if (joint && r == 3 && st == 2) return launch_lds16_k<T, true, 3, 2>(ctx, prm, blocks, lds);
+    if (joint && r == 2 && st == 1) return launch_lds16_k<T, true, 2, 1>(ctx, prm, blocks, lds);
     return joint ? launch_lds16_k<T, true, 0, 0>(ctx, prm, blocks, lds) : launch_lds16_k<T, false, 0, 0>(ctx, prm, blocks, lds);
 }
 
@@ -905,8 +907,8 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         bool lds16 = tiled && dtype != VSZIP_U8 && prm.lut_len == 65536;
         {
             const size_t bps = dtype == VSZIP_F32 ? 4 : 2;
-            const int tile_h = dtype == VSZIP_F32 ? kL16TileH<float> : kL16TileH<uint16_t>;
-            const int stages = dtype == VSZIP_F32 ? kL16MaxStage<float> : kL16MaxStage<uint16_t>;
+            const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64;  // kL16TileH
+            const int stages = (dtype == VSZIP_F32 || joint) ? 4 : 6;     // kL16MaxStage
             const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (tile_h + 2 * max_radius);
             lds16 = lds16 && tile_elems <= (size_t)kBX * kL16Rows * stages && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
             for (int i = 0; i < n && lds16; ++i) lds16 = lut_is_packed(prm.p[i].gr);
@@ -934,7 +936,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     BLPlane &dp = q.p[q.nplanes++];
                     dp = prm.p[i];
                     dp.block0 = qb;
-                    const int tile_h = dtype == VSZIP_F32 ? kL16TileH<float> : kL16TileH<uint16_t>;
+                    const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64;
                     qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
                 }
                 switch (dtype) {
