@@ -515,7 +515,7 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
     // 1. interiors: one ring launch per kMaxPlanesF planes
     // bands per plane: the call's waves must fit ONE resident round (r = 13: 2 waves per SIMD = 2048; one wave
     // more starts a second round and the launch takes twice as long). Greedy: the planes with
-    // the most rows per band get one more band each while the round has room; a band is at least two ring periods
+    // the most rows per band get one more band each while the round has room; a band is at least one ring period
     // (every band re-reads 2r rows).
     const long round = RingDispatch<T, kFRMaxR>::round_waves(radius, ctx->num_cus > 0 ? ctx->num_cus : 256);
     std::vector<int> nb(nplanes, 0), ntxs(nplanes, 0), xbs(nplanes, 0);
@@ -529,7 +529,7 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
         int worst = 0;
         for (int i = 0; i < nplanes; ++i)
             if (nb[i]) worst = std::max(worst, (planes[i].h - radius + nb[i] - 1) / nb[i]);
-        if (worst == 0 || worst < 4 * NR) break;  // (worst == 0: no plane takes the ring kernel)
+        if (worst == 0 || worst < 2 * NR) break;  // (worst == 0: no plane takes the ring kernel)
         long extra = 0;
         for (int i = 0; i < nplanes; ++i)
             if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) extra += ntxs[i];
