@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int kMaxPlanesBL = 48;
+constexpr int kMaxPlanesBL = 192;  // planes per launch (64 YUV frames): the persistent kernels pay their table load and their tail once per launch
 
 struct BLPlane {
     const void *src, *ref;
