@@ -431,6 +431,9 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
            "kernel_us_per_call": (dom_ms / launches * 1e3) if launches else None,
            "kernel_hbm_frac": (batch * fb / (dom_ms / launches * 1e-3) / 8e12) if launches else None,
            "per_frame_calls": {"workers": workers, "frames_per_s": multi, "single_caller_frames_per_s": single},
+           "roofline": ({"bound": "hbm", "achieved": batch * fb / (dom_ms / launches * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": batch * fb / (dom_ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "xpsnr_strip_kernel<u8>",
+                         "avg_launch_us": dom_ms / launches * 1e3} if launches else None),
            "workload": f"vszip.XPSNR getWSSE, 1920x1080 YUV420P8 org vs rec, temporal, {batch} frames per call; per_frame_calls: one synchronising call per frame, "
                        f"{workers} host threads with a context each"}
     if not no_cpu:
