@@ -116,3 +116,59 @@ def test_oracle_under_asan(san_env):
                         "-p", "no:cacheprovider", "-k", "not exhaustive and not closed_forms"], capture_output=True, text=True, env=san_env, cwd=str(ROOT), timeout=1800)
     _clean(r)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+
+
+SUCCESS = textwrap.dedent("""
+    import sys, numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+    from fakevs import fakevs as vs
+    rng = np.random.default_rng(0)
+    def yuv(dt, w=134, h=96, n=6, hi=255):
+        shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+        return [[(rng.random(s) * hi).astype(dt) for s in shapes] for _ in range(n)]
+    c8 = vs.source(yuv(np.uint8), vs.YUV420P8)
+    c16 = vs.source(yuv(np.uint16, hi=65535), vs.YUV420P16, extra_stride=24, offset=8)
+    cf = vs.source(yuv(np.float32, hi=1.0), vs.YUV420PS)
+    rgb = vs.source([[(rng.random((96, 134)) * 255).astype(np.uint8) for _ in range(3)] for _ in range(6)], vs.RGB24)
+    rgbs = vs.source([[rng.random((96, 134)).astype(np.float32) for _ in range(3)] for _ in range(6)], vs.RGBS, props={{"_Transfer": 8}})
+    vs.core_standins(True)
+    clips = [
+        c16.vszip.BoxBlur(hradius=13, vradius=13), c16.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0), c8.vszip.PlaneAverage(exclude=[-1]),
+        c16.vszip.PlaneMinMax(minthr=0.1, maxthr=0.1, clipb=c16), c8.vszip.XPSNR(c8), rgb.vszip.SSIMULACRA2(rgb), cf.vszip.EEDI3(field=1, dh=True),
+        c16.vszip.LimitFilter(c16, dark_thr=8.0),
+        c16.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=3, vradius=3, planes=[0]).vszip.Limiter(tv_range=True, planes=[1, 2]),
+        rgbs.vszip.SSIMULACRA2(rgbs.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)),
+    ]
+    for c in clips:
+        c.get_frame(0)              # every filter's success path once, single threaded
+        c.pull(6, {threads})        # ... and from worker threads at once (fmParallel): contexts, the per-GPU gate, the stage registry
+    del clips, c
+    print("success ok")
+""")
+
+
+def test_success_paths_under_asan(san_env):
+    """The stub's kernels SUCCEED (VSZIP_STUB_FAIL=none): download, frame properties, fused chains and the release of
+    every frame / node / device pointer on the good path, single threaded and from 4 worker threads."""
+    env = dict(san_env, VSZIP_STUB_FAIL="none")
+    r = subprocess.run([sys.executable, "-c", SUCCESS.format(root=str(ROOT), tests=str(ROOT / "tests"), threads=4)], capture_output=True, text=True, env=env, timeout=900)
+    _clean(r)
+    assert r.returncode == 0 and "success ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_worker_threads_under_tsan():
+    """Race detection: the plugin, the stub device library and the test host built with
+    -fsanitize=thread; 8 worker threads pull frames of every filter kind at once (shared per-instance state:
+    context pools, the per-GPU gate, LUT caches, the fusion registry, XPSNR's accumulators)."""
+    tsan = _runtime("libtsan.so")
+    if not tsan:
+        pytest.skip("g++ has no libtsan")
+    r = subprocess.run(["make", "-C", str(SAN), "tsan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=tsan, TSAN_OPTIONS="halt_on_error=0:exitcode=97:report_signal_unsafe=0", VSZIP_STUB_FAIL="none",
+               VSZIP_FAKEVS_LIB=str(SAN / "_build_tsan" / "libfakevs.so"), VSZIP_PLUGIN_LIB=str(SAN / "_build_tsan" / "libvszip.so"))
+    r = subprocess.run([sys.executable, "-c", SUCCESS.format(root=str(ROOT), tests=str(ROOT / "tests"), threads=8)], capture_output=True, text=True, env=env, timeout=1800)
+    out = r.stdout + r.stderr
+    assert "ThreadSanitizer" not in out and r.returncode != 97, out[-6000:]
+    assert r.returncode == 0 and "success ok" in r.stdout, out[-3000:]
