@@ -95,7 +95,9 @@ constexpr int kU = 4;  // directions per cost pass
 // largest mdis the instantiation serves (20: the default and below, 31: one DP state per lane) and
 // sizes the LDS arrays — the default geometry takes 20 KiB per wave instead of 29, i.e. 7 instead of
 // 5 waves per CU, and the kernel is latency bound.
-template <int NRAD, int MD>
+// FIXED: mdis == MD (the default 20): the direction loop unrolls and every LDS offset of a pass is an immediate
+// (with a runtime mdis a quarter of the cost phase's instructions are address arithmetic).
+template <int NRAD, int MD, bool FIXED>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     // The t_base and window-sum steps run a fixed number of 128-entry iterations (NIT2: every lane owns two
     // neighbouring entries, and the kU directions of a pass share ONE first column, so the span is the longest
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const int off = gl - pl.line0;              // interpolated-line index within the plane
     const int line = prm.field + 2 * off;       // destination line
     constexpr int nrad = NRAD;
-    const int w = pl.w, mdis = prm.mdis, tpitch = 2 * mdis + 1;
+    const int w = pl.w, mdis = FIXED ? MD : prm.mdis, tpitch = 2 * mdis + 1;
     const int lane = threadIdx.x;
     const bool dh = prm.dh != 0;
     const float *r3p = pl.src + (size_t)src_col(dh, line - 3, pl.n_src) * pl.sstride;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         // The three steps of a direction (t_base -> window sums -> cost) are a chain of LDS
         // round trips; one direction at a time leaves the wave waiting on LDS latency most of
         // the time, so kU directions go through each step together (independent work in flight).
-        for (int ug = -mdis; ug <= mdis; ug += kU) {
+        auto cost_pass = [&](const int ug) __attribute__((always_inline)) {
             // Everything below is branch-free across the kU directions, so that the compiler can
             // keep the LDS reads of all kU directions in flight together: a direction whose span is
             // shorter than the pass's longest simply computes a few entries nobody reads (rows[],
@@ -245,6 +247,12 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 }
             }
             wave_fence();  // tb / ws are rewritten by the next pass
+        };
+        if constexpr (FIXED) {
+#pragma unroll
+            for (int ug = -MD; ug <= MD; ug += kU) cost_pass(ug);
+        } else {
+            for (int ug = -mdis; ug <= mdis; ug += kU) cost_pass(ug);
         }
         wave_fence();
         // ---- DP phase, lanes = direction index ---------------------------------------
@@ -264,7 +272,11 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
         for (int i = 0; i < kXB / 4; ++i) pk[i] = 0;
         auto dp_step = [&](float tc) -> uint32_t {
-            const float left_cc = lane_below(pcost, kFltMax09) + prm.gamma, right_cc = lane_above(pcost, kFltMax09) + prm.gamma;
+            // A lane without a neighbour (direction -mdis has none below) receives ITS OWN cost instead of the
+            // reference's 0.9*FLT_MAX sentinel: own + gamma < own is as false as sentinel + gamma < own (gamma >= 0 is
+            // validated), and it saves loading the sentinel into the DPP destination before every shift. (Lane 63's
+            // "above" is irrelevant: lanes past the last direction are pinned at the sentinel by their infinite cost.)
+            const float left_cc = lane_below(pcost, pcost) + prm.gamma, right_cc = lane_above(pcost, pcost) + prm.gamma;
             float bval = pcost;  // :536-548
             uint32_t code = 0;
             if (left_cc < bval) {
@@ -1346,6 +1358,7 @@ VSZIP_EXPORT int vszip_eedi3_mclip(vszip_ctx *ctx, const vszip_plane *planes, co
                                    const uint8_t *const *mclips, const ptrdiff_t *mclip_strides, int nplanes, int field, int horizontal,
                                    const vszip_eedi3_params *up) {
     if (!ctx || !planes || !up || nplanes <= 0) return VSZIP_ERR_ARG;
+    if (!(up->gamma >= 0.0f)) return vszip_set_error(ctx, VSZIP_ERR_ARG, "EEDI3: gamma must be greater than or equal to 0.0.");  // eedi3.zig:368 (the DP kernels rely on it)
     for (int o = 0; o < nplanes; o += kMaxPlanesE) {
         const int rc = eedi3_batch(ctx, planes + o, sclips ? sclips + o : nullptr, sclip_strides ? sclip_strides + o : nullptr, mclips ? mclips + o : nullptr,
                                    mclip_strides ? mclip_strides + o : nullptr, std::min(kMaxPlanesE, nplanes - o), field, horizontal, up);
@@ -1518,10 +1531,12 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         const dim3 lgrid((unsigned)lines), lblock(64);
 #define VSZIP_E3_LAUNCH(N)                                                                        \
     do {                                                                                          \
-        if (up->mdis <= 20)                                                                       \
-            hipLaunchKernelGGL((eedi3_line_kernel<N, 20>), lgrid, lblock, 0, ctx->stream, ep);    \
+        if (up->mdis == 20 && !getenv("VSZIP_EEDI3_NO_FIXED"))                                    \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true>), lgrid, lblock, 0, ctx->stream, ep); \
+        else if (up->mdis <= 20)                                                                  \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, false>), lgrid, lblock, 0, ctx->stream, ep); \
         else                                                                                      \
-            hipLaunchKernelGGL((eedi3_line_kernel<N, kMaxMdis>), lgrid, lblock, 0, ctx->stream, ep); \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, kMaxMdis, false>), lgrid, lblock, 0, ctx->stream, ep); \
     } while (0)
         switch (up->nrad) {
             case 0: VSZIP_E3_LAUNCH(0); break;
