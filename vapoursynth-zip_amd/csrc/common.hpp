@@ -19,6 +19,12 @@ struct vszip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second stream for kernels that run BESIDE the main stream's (EEDI3: the line kernel of the short planes next to the
+    // vertical-consistency chains of the tall ones); its CU mask leaves `aux_reserved` CUs to the main stream, created on
+    // first use; aux_fork / aux_join order the two
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    int aux_reserved = 0;  // CUs the aux stream's mask leaves free for the main stream's kernels
     std::string err;
     // grow-only device scratch (filters that need intermediates) and a small
     // pinned + device pair for returning scalars

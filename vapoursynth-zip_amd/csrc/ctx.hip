@@ -83,6 +83,12 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+    }
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->probe_events) (void)hipEventDestroy(e);

@@ -49,6 +49,7 @@ struct EParams {
     int field, dh;
     int mdis, nrad;
     float alpha, beta, gamma, one_minus_ab;
+    int line_base;  // first global line id of this launch (a call may launch its tall and its short planes separately)
 };
 
 __device__ __forceinline__ int reflect_row(int y, int h) {  // eedi3.zig:88-96
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[1];
 
     int pi = 0;
-    const int gl = blockIdx.x;
+    const int gl = prm.line_base + (int)blockIdx.x;
 #pragma unroll 1
     for (int i = 1; i < prm.nplanes; ++i)
         if (gl >= prm.p[i].line0) pi = i;
@@ -854,6 +855,7 @@ struct VParams {
     float vthresh2, rcp0, rcp1, rcp2;
     float *gline;  // wide kernel, lines that do not fit LDS: 2 lines per plane in global memory (NULL: LDS)
     int gline_pitch;
+    int plane_base;  // first plane slot of this launch (eedi3_vcheck_lds_kernel)
 };
 
 // vcheckLine (:915-1046), hp = false. Line pd blends against line pd-2 AS ALREADY BLENDED, so
@@ -1195,9 +1197,10 @@ template <bool HP, int VC>
 __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams prm) {
     constexpr int C = 2;  // columns per thread: lines up to 2048 (LDS allows 1920)
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
-    const EPlane pl = prm.p[blockIdx.x];
-    const float *scp = prm.scp[blockIdx.x];
-    const int scstride = prm.scstride[blockIdx.x];
+    const int pslot = prm.plane_base + (int)blockIdx.x;
+    const EPlane pl = prm.p[pslot];
+    const float *scp = prm.scp[pslot];
+    const int scstride = prm.scstride[pslot];
     const int L = pl.w, n_dst = pl.n_dst;
     const int tid = threadIdx.x;
     float *ring = reinterpret_cast<float *>(vsm);
@@ -1468,10 +1471,27 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     size_t dmo = 0, pbo = 0;
     int line0 = 0, maxw = 0, maxsrc = 0;
     const dim3 tb(kTT, 8);
-    for (int i = 0; i < nplanes; ++i) {
+    // Plane slots: the tall planes of the call first (the luma planes of a subsampled clip). The vertical-consistency
+    // pass is a sequential chain per plane, as long as the plane is tall and busy on one CU per plane only; with the
+    // tall planes' lines interpolated first their chains run on a second stream BESIDE the line kernel of the short
+    // planes, and only the short planes' (half as long) chains remain after it.
+    std::vector<int> order(nplanes);
+    int ntall = 0, lines_tall = 0;
+    {
+        int max_interp = 0;
+        for (int i = 0; i < nplanes; ++i) max_interp = std::max(max_interp, geo[i].n_interp);
+        for (int i = 0; i < nplanes; ++i)
+            if (4 * geo[i].n_interp >= 3 * max_interp) order[ntall++] = i;
+        int k = ntall;
+        for (int i = 0; i < nplanes; ++i)
+            if (4 * geo[i].n_interp < 3 * max_interp) order[k++] = i;
+    }
+    for (int slot = 0; slot < nplanes; ++slot) {
+        const int i = order[slot];
         const vszip_plane &s = planes[i];
         const Geo &g = geo[i];
-        EPlane &d = ep.p[i];
+        EPlane &d = ep.p[slot];
+        if (slot == ntall) lines_tall = line0;
         if (horizontal) {
             float *srcT = fbase + g.srcT;
             hipLaunchKernelGGL(transpose_kernel, dim3((s.w + kTT - 1) / kTT, (s.h + kTT - 1) / kTT), tb, 0, ctx->stream, static_cast<const float *>(s.src), srcT,
@@ -1479,31 +1499,31 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
             d.src = srcT;
             d.dst = fbase + g.dstT;
             d.sstride = d.dstride = g.L;
-            vp.scp[i] = nullptr;
-            vp.scstride[i] = g.L;
+            vp.scp[slot] = nullptr;
+            vp.scstride[slot] = g.L;
             if (up->vcheck > 0 && sclips && sclips[i]) {
                 float *scT = fbase + g.scT;
                 hipLaunchKernelGGL(transpose_kernel, dim3((g.n_dst + kTT - 1) / kTT, (s.h + kTT - 1) / kTT), tb, 0, ctx->stream, sclips[i], scT,
                                    (int)sclip_strides[i], g.L, g.n_dst, s.h);
-                vp.scp[i] = scT;
+                vp.scp[slot] = scT;
             }
-            gx.mask[i] = nullptr;
-            gx.mstride[i] = g.L;
+            gx.mask[slot] = nullptr;
+            gx.mstride[slot] = g.L;
             if (mclips && mclips[i]) {  // mask has the source plane's geometry (w x h) -> transposed: w lines of h
                 uint8_t *mT = mbase + g.mT;
                 hipLaunchKernelGGL(transpose_u8_kernel, dim3((s.w + kTT - 1) / kTT, (s.h + kTT - 1) / kTT), tb, 0, ctx->stream, mclips[i], mT, (int)mclip_strides[i], g.L,
                                    s.w, s.h);
-                gx.mask[i] = mT;
+                gx.mask[slot] = mT;
             }
         } else {
-            gx.mask[i] = mclips ? mclips[i] : nullptr;
-            gx.mstride[i] = (mclips && mclips[i]) ? (int)mclip_strides[i] : 0;
+            gx.mask[slot] = mclips ? mclips[i] : nullptr;
+            gx.mstride[slot] = (mclips && mclips[i]) ? (int)mclip_strides[i] : 0;
             d.src = static_cast<const float *>(s.src);
             d.dst = static_cast<float *>(s.dst);
             d.sstride = (int)s.src_stride;
             d.dstride = (int)s.dst_stride;
-            vp.scp[i] = (up->vcheck > 0 && sclips) ? sclips[i] : nullptr;
-            vp.scstride[i] = (sclips && sclip_strides) ? (int)sclip_strides[i] : 0;
+            vp.scp[slot] = (up->vcheck > 0 && sclips) ? sclips[i] : nullptr;
+            vp.scstride[slot] = (sclips && sclip_strides) ? (int)sclip_strides[i] : 0;
         }
         d.w = g.L;
         d.n_src = g.n_src;
@@ -1517,8 +1537,65 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         line0 += g.n_interp;
         maxw = std::max(maxw, g.L);
         maxsrc = std::max(maxsrc, g.n_src);
-        vp.p[i] = d;
+        vp.p[slot] = d;
     }
+    if (ntall == nplanes) lines_tall = line0;
+    int maxL = 0;
+    for (int i = 0; i < nplanes; ++i) maxL = std::max(maxL, geo[i].L);
+    vp.gline = nullptr;
+    vp.gline_pitch = (maxL + 63) & ~63;
+    if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
+    const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL");
+    auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
+        const size_t lds = (size_t)maxL * (7 * sizeof(float) + 4);
+        vp.plane_base = first;
+#define VSZIP_VC_LAUNCH(HPV)                                                                                      \
+    do {                                                                                                          \
+        if (up->vcheck == 1)                                                                                      \
+            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 1>), dim3(count), dim3(1024), lds, st, vp);         \
+        else if (up->vcheck == 2)                                                                                 \
+            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 2>), dim3(count), dim3(1024), lds, st, vp);         \
+        else                                                                                                      \
+            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 3>), dim3(count), dim3(1024), lds, st, vp);         \
+    } while (0)
+        if (hp)
+            VSZIP_VC_LAUNCH(true);
+        else
+            VSZIP_VC_LAUNCH(false);
+#undef VSZIP_VC_LAUNCH
+    };
+    // two plane heights in the call, the tuned line kernel and the LDS chain kernel: overlap (see `order` above).
+    // The chains need a whole CU's worth of LDS each; beside a full line-kernel launch they would never find one
+    // (freed wave slots go to the next line wave), so the short planes' line kernel runs on a stream whose CU mask
+    // leaves one CU per chain free.
+    bool split = !general && vc_lds && ntall > 0 && ntall < nplanes && ntall <= 64 && !getenv("VSZIP_EEDI3_NO_OVERLAP");
+    if (split) {
+        const int reserve = std::min(64, (ntall + 7) & ~7), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        if (ctx->aux_stream && ctx->aux_reserved != reserve) {
+            (void)hipStreamSynchronize(ctx->aux_stream);
+            (void)hipStreamDestroy(ctx->aux_stream);
+            ctx->aux_stream = nullptr;
+        }
+        if (!ctx->aux_stream) {
+            std::vector<uint32_t> mask((cus + 31) / 32, 0xffffffffu);
+            for (int b = 0; b < reserve; ++b) mask[b / 32] &= ~(1u << (b % 32));  // the runtime spreads consecutive bits over the XCDs
+            if (cus % 32) mask.back() &= (1u << (cus % 32)) - 1;
+            bool ok = hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (ok && !ctx->aux_fork) ok = hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                ctx->aux_stream = nullptr;
+                split = false;
+            }
+            ctx->aux_reserved = reserve;
+        }
+    }
+    if (!split) {
+        ntall = nplanes;  // one group: the launches below cover every line / plane at once
+        lines_tall = (int)lines;
+    }
+    ep.line_base = 0;
+    vp.plane_base = 0;
     hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);
     if (general) {
         switch (up->nrad) {
@@ -1528,53 +1605,54 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
             default: launch_general<3>(ctx, hp, (unsigned)lines, ep, gx); break;
         }
     } else {
-        const dim3 lgrid((unsigned)lines), lblock(64);
+        const dim3 lblock(64);
 #define VSZIP_E3_LAUNCH(N)                                                                        \
     do {                                                                                          \
         if (up->mdis == 20 && !getenv("VSZIP_EEDI3_NO_FIXED"))                                    \
-            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true>), lgrid, lblock, 0, ctx->stream, ep); \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true>), lgrid, lblock, 0, lst, ep);      \
         else if (up->mdis <= 20)                                                                  \
-            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, false>), lgrid, lblock, 0, ctx->stream, ep); \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, false>), lgrid, lblock, 0, lst, ep);     \
         else                                                                                      \
-            hipLaunchKernelGGL((eedi3_line_kernel<N, kMaxMdis, false>), lgrid, lblock, 0, ctx->stream, ep); \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, kMaxMdis, false>), lgrid, lblock, 0, lst, ep); \
     } while (0)
-        switch (up->nrad) {
-            case 0: VSZIP_E3_LAUNCH(0); break;
-            case 1: VSZIP_E3_LAUNCH(1); break;
-            case 2: VSZIP_E3_LAUNCH(2); break;
-            default: VSZIP_E3_LAUNCH(3); break;
+        auto launch_lines = [&](hipStream_t lst, int first, int count) {
+            const dim3 lgrid((unsigned)count);
+            ep.line_base = first;
+            switch (up->nrad) {
+                case 0: VSZIP_E3_LAUNCH(0); break;
+                case 1: VSZIP_E3_LAUNCH(1); break;
+                case 2: VSZIP_E3_LAUNCH(2); break;
+                default: VSZIP_E3_LAUNCH(3); break;
+            }
+        };
+        launch_lines(ctx->stream, 0, lines_tall);
+        if (split) {
+            // the tall planes' lines are done: the short planes' lines go to the masked stream, the tall planes' chains
+            // start here at once on the CUs it leaves free
+            VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->aux_fork, ctx->stream));
+            VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+            launch_lines(ctx->aux_stream, lines_tall, (int)lines - lines_tall);
+            VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+            launch_vcheck_lds(ctx->stream, 0, ntall);
+            VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+        } else if ((int)lines > lines_tall) {
+            launch_lines(ctx->stream, lines_tall, (int)lines - lines_tall);
         }
 #undef VSZIP_E3_LAUNCH
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     if (up->vcheck > 0) {
-        int maxL = 0;
-        for (int i = 0; i < nplanes; ++i) maxL = std::max(maxL, geo[i].L);
-        vp.gline = nullptr;
-        vp.gline_pitch = (maxL + 63) & ~63;
-        if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
-        if (maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL"))
-        {
-            const size_t lds = (size_t)maxL * (7 * sizeof(float) + 4);
-#define VSZIP_VC_LAUNCH(HPV)                                                                                                   \
-    do {                                                                                                                       \
-        if (up->vcheck == 1)                                                                                                   \
-            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 1>), dim3(nplanes), dim3(1024), lds, ctx->stream, vp);           \
-        else if (up->vcheck == 2)                                                                                              \
-            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 2>), dim3(nplanes), dim3(1024), lds, ctx->stream, vp);           \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 3>), dim3(nplanes), dim3(1024), lds, ctx->stream, vp);           \
-    } while (0)
-            if (hp)
-                VSZIP_VC_LAUNCH(true);
-            else
-                VSZIP_VC_LAUNCH(false);
-#undef VSZIP_VC_LAUNCH
-        }
-        else if (maxL <= 4096)
+        if (vc_lds) {
+            if (split) {
+                launch_vcheck_lds(ctx->stream, ntall, nplanes - ntall);  // (the tall planes' chains were launched beside the line kernel)
+            } else {
+                launch_vcheck_lds(ctx->stream, 0, nplanes);
+            }
+        } else if (maxL <= 4096) {
             hipLaunchKernelGGL(eedi3_vcheck_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, vp);
-        else
+        } else {
             hipLaunchKernelGGL(eedi3_vcheck_wide_kernel, dim3(nplanes), dim3(1024), vp.gline ? 0 : (size_t)maxL * 2 * sizeof(float), ctx->stream, vp);
+        }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
     }
     if (horizontal) {
