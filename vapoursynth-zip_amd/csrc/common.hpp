@@ -25,6 +25,9 @@ struct vszip_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     int aux_reserved = 0;  // CUs the aux stream's mask leaves free for the main stream's kernels
+    // plain second stream (SSIMULACRA2: the small scales' launch-bound kernels beside the large scales' maps kernels)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     std::string err;
     // grow-only device scratch (filters that need intermediates) and a small
     // pinned + device pair for returning scalars

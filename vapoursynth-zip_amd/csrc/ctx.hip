@@ -87,6 +87,12 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
     }
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
     if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
     if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -1046,8 +1046,25 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         fin.ntiles[i] = 0;
         fin.one_per_pixels[i] = 0;
     }
+    // Scales 2.. are a chain of small, launch-bound kernels (a sixteenth of the samples and less) that depends only on
+    // the pyramid pass: it runs on a second stream beside the two large maps launches instead of after them.
+    bool side = kScales > 2 && !getenv("VSZIP_SSIM_ONE_STREAM");
+    if (side && !ctx->side_stream) {
+        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->side_stream = nullptr;
+            side = false;
+        }
+    }
+    if (side) {
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    }
     for (int scale = 0; scale < kScales; ++scale) {
         const int cw = sw[scale], ch = sh[scale], nw = sw[scale + 1], nh = sh[scale + 1];
+        const bool on_side = side && scale >= 2;
+        hipStream_t st = on_side ? ctx->side_stream : ctx->stream;
         if (scale >= 2) {
             XybArgs xa;
             xa.tab = tab_dev + (size_t)scale * npairs;
@@ -1059,7 +1076,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
             xa.nh = nh;
             xa.xstride = cw;
             xa.k = kx;
-            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, npairs), dim3(256), 0, ctx->stream, xa);
+            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, npairs), dim3(256), 0, st, xa);
         }
         MapsArgs ma;
         ma.tab = tab_dev + (size_t)scale * npairs;
@@ -1080,14 +1097,23 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         ma.partial = partial;
         ma.max_tiles = tiles0;
         if (ma.nactive > 0) {
-            vszip_probe_scope probe(ctx);
             ma.tpb = ma.tiles_x >= 32 ? 4 : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
-            hipLaunchKernelGGL(ssim_maps_kernel, dim3((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * npairs), dim3(256), 0, ctx->stream, ma);
+            const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * npairs);
+            if (on_side) {
+                hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
+            } else {
+                vszip_probe_scope probe(ctx);  // (HIP events on the main stream: the side stream's launches are not probed)
+                hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
+            }
         }
         for (int k = 0; k < ma.nactive; ++k) {
             fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
             fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
         }
+    }
+    if (side) {
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
     }
     hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(kFinThreads), 0, ctx->stream, fin);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
