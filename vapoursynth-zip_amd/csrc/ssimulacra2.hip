@@ -1006,10 +1006,12 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     }
     VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab, bytes_tab + bytes_pyr, hipMemcpyHostToDevice, ctx->stream));
 
+    // the pipeline of pairs [p0, p0 + cnt) on `main_st`: pyramid pass, per-scale maps, final reduction
+    auto run_pairs = [&](int p0, int cnt, hipStream_t main_st, bool allow_side, hipEvent_t after_pyr) -> int {
     // scales 0 + 1 + the scale-2 RGB: one pass over the source
     {
         PyrArgs pa;
-        pa.tab = pyr_dev;
+        pa.tab = pyr_dev + p0;
         pa.lut = lut_dev;
         pa.lut_lds = lut_lds;
         {
@@ -1026,21 +1028,23 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         pa.w2 = sw[2];
         pa.h2 = sh[2];
         pa.k = kx;
-        const dim3 grid((w + 255) / 256, (h + 15) / 16, npairs);
+        const dim3 grid((w + 255) / 256, (h + 15) / 16, cnt);
         if (mode == PYR_F32_LINEAR)
-            launch_pyr<float, PYR_F32_LINEAR>(gray, grid, ctx->stream, pa);
+            launch_pyr<float, PYR_F32_LINEAR>(gray, grid, main_st, pa);
         else if (mode == PYR_F32_GAMMA)
-            launch_pyr<float, PYR_F32_GAMMA>(gray, grid, ctx->stream, pa);
+            launch_pyr<float, PYR_F32_GAMMA>(gray, grid, main_st, pa);
         else if (fmt->dtype == VSZIP_U8)
-            launch_pyr<uint8_t, PYR_INT>(gray, grid, ctx->stream, pa);
+            launch_pyr<uint8_t, PYR_INT>(gray, grid, main_st, pa);
         else
-            launch_pyr<uint16_t, PYR_INT>(gray, grid, ctx->stream, pa);
+            launch_pyr<uint16_t, PYR_INT>(gray, grid, main_st, pa);
+        if (after_pyr) VSZIP_HIP_CHECK(ctx, hipEventRecord(after_pyr, main_st));
     }
 
     FinalArgs fin;
-    fin.partial = partial;
+    fin.partial = partial + (size_t)p0 * 18 * tiles0 * 6;
     // the averages go straight into the pinned host buffer (device-visible): no copy command at the end
     VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&fin.avg), ctx->scalars_host, 0));
+    fin.avg += (size_t)p0 * 18 * 6;
     fin.max_tiles = tiles0;
     for (int i = 0; i < 18; ++i) {
         fin.ntiles[i] = 0;
@@ -1048,7 +1052,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     }
     // Scales 2.. are a chain of small, launch-bound kernels (a sixteenth of the samples and less) that depends only on
     // the pyramid pass: it runs on a second stream beside the two large maps launches instead of after them.
-    bool side = kScales > 2 && !getenv("VSZIP_SSIM_ONE_STREAM");
+    bool side = allow_side && kScales > 2 && !getenv("VSZIP_SSIM_ONE_STREAM");
     if (side && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
@@ -1058,16 +1062,16 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         }
     }
     if (side) {
-        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, main_st));
         VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
     }
     for (int scale = 0; scale < kScales; ++scale) {
         const int cw = sw[scale], ch = sh[scale], nw = sw[scale + 1], nh = sh[scale + 1];
         const bool on_side = side && scale >= 2;
-        hipStream_t st = on_side ? ctx->side_stream : ctx->stream;
+        hipStream_t st = on_side ? ctx->side_stream : main_st;
         if (scale >= 2) {
             XybArgs xa;
-            xa.tab = tab_dev + (size_t)scale * npairs;
+            xa.tab = tab_dev + (size_t)scale * npairs + p0;
             xa.stride = cw;
             xa.w = cw;
             xa.h = ch;
@@ -1076,10 +1080,10 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
             xa.nh = nh;
             xa.xstride = cw;
             xa.k = kx;
-            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, npairs), dim3(256), 0, st, xa);
+            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, cnt), dim3(256), 0, st, xa);
         }
         MapsArgs ma;
-        ma.tab = tab_dev + (size_t)scale * npairs;
+        ma.tab = tab_dev + (size_t)scale * npairs + p0;
         ma.nactive = 0;
         for (int c = 0; c < 3; ++c) {
             const Skip sk = skip_of(c, scale);
@@ -1094,16 +1098,20 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         ma.h = ch;
         ma.tiles_x = (cw + TW - 1) / TW;
         ma.tiles_y = (ch + TH - 1) / TH;
-        ma.partial = partial;
+        ma.partial = partial + (size_t)p0 * 18 * tiles0 * 6;
         ma.max_tiles = tiles0;
         if (ma.nactive > 0) {
             ma.tpb = ma.tiles_x >= 32 ? 4 : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
-            const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * npairs);
+            const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * cnt);
             if (on_side) {
                 hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
             } else {
-                vszip_probe_scope probe(ctx);  // (HIP events on the main stream: the side stream's launches are not probed)
-                hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
+                if (main_st == ctx->stream) {
+                    vszip_probe_scope probe(ctx);  // (HIP events on the context's stream: other streams' launches are not probed)
+                    hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
+                } else {
+                    hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
+                }
             }
         }
         for (int k = 0; k < ma.nactive; ++k) {
@@ -1113,10 +1121,36 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     }
     if (side) {
         VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
-        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(main_st, ctx->side_join, 0));
     }
-    hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(kFinThreads), 0, ctx->stream, fin);
+    hipLaunchKernelGGL(ssim_final_kernel, dim3(18, cnt), dim3(kFinThreads), 0, main_st, fin);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    return VSZIP_OK;
+    };
+    // Two halves, staggered: the pyramid pass is HBM bound and the maps kernels are issue bound, so the second half's
+    // pyramid pass runs (on the second stream) beside the first half's maps instead of before them.
+    bool halves = npairs >= 4 && !getenv("VSZIP_SSIM_ONE_STREAM") && !getenv("VSZIP_SSIM_NO_HALVES");
+    if (halves && !ctx->side_stream) {
+        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->side_stream = nullptr;
+            halves = false;
+        }
+    }
+    if (halves) {
+        const int n1 = npairs / 2;
+        rc = run_pairs(0, n1, ctx->stream, false, ctx->side_fork);  // (the fork also orders the pointer-table upload before the second stream)
+        if (rc != VSZIP_OK) return rc;
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+        rc = run_pairs(n1, npairs - n1, ctx->side_stream, false, nullptr);
+        if (rc != VSZIP_OK) return rc;
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    } else {
+        rc = run_pairs(0, npairs, ctx->stream, true, nullptr);
+        if (rc != VSZIP_OK) return rc;
+    }
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
     for (int pair = 0; pair < npairs; ++pair) scores[pair] = score_of(avg[pair]);
