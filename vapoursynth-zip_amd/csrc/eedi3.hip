@@ -844,7 +844,16 @@ __global__ void eedi3_copy_kernel(const EParams prm) {
     }
     const float *s = pl.src + (size_t)k * pl.sstride;
     float *d = pl.dst + (size_t)dl * pl.dstride;
-    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < pl.w; x += gridDim.x * blockDim.x) d[x] = s[x];
+    // 16 bytes per lane where the rows allow it (every VapourSynth frame): a quarter of the instructions per byte
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        const int n4 = pl.w >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(s);
+        float4 *d4 = reinterpret_cast<float4 *>(d);
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n4; x += gridDim.x * blockDim.x) d4[x] = s4[x];
+        for (int x = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; x < pl.w; x += gridDim.x * blockDim.x) d[x] = s[x];
+    } else {
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < pl.w; x += gridDim.x * blockDim.x) d[x] = s[x];
+    }
 }
 
 struct VParams {
@@ -1596,7 +1605,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     }
     ep.line_base = 0;
     vp.plane_base = 0;
-    hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);
+    hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw / 4 + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);  // (grid-stride rows: any x grid serves)
     if (general) {
         switch (up->nrad) {
             case 0: launch_general<0>(ctx, hp, (unsigned)lines, ep, gx); break;
