@@ -64,3 +64,18 @@ def test_identical_is_exactly_100(dev):
     assert _gpu(dev, c, c)[0] == 100.0
     lin = [_lin(np.ascontiguousarray(p)) for p in fx.crop_rgbs()]
     assert _gpu(dev, lin, lin)[0] > 99.9
+
+
+def test_batched_calls_equal_single_pair_calls(dev):
+    """A call of 4 or more pairs runs as two staggered halves on two streams (and smaller ones put the small scales on
+    a side stream): every score must be the bits a one-pair call gives, whatever the split (5 pairs: 2 + 3)."""
+    shape = (270, 480)
+    pairs = [_pair(shape, 20 + i, sigma=0.01 * (i + 1)) for i in range(5)]
+    single = [_gpu(dev, r, d)[0] for r, d in pairs]
+    rr = [dev.upload(np.ascontiguousarray(p), 1) for r, _ in pairs for p in r]
+    dd = [dev.upload(np.ascontiguousarray(p), 1) for _, d in pairs for p in d]
+    for n in (5, 4, 3, 2):
+        got = dev.ssimulacra2(rr[: 3 * n], dd[: 3 * n])
+        assert [float(x).hex() for x in got] == [float(x).hex() for x in single[:n]], n
+    again = dev.ssimulacra2(rr, dd)  # run-to-run: the fixed-order reductions give identical bits
+    assert [float(x).hex() for x in again] == [float(x).hex() for x in single]
