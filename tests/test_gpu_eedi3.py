@@ -148,3 +148,23 @@ def test_short_lines(dev, oracle, w, kw):
         if srct.shape[1] % 2 == 0:
             got = _gpu(dev, srct, 0, horizontal=True, **kw)
             assert np.array_equal(got, oracle.eedi3(srct, 0, horizontal=True, **kw))
+
+
+@pytest.mark.parametrize("kw", [dict(dh=True), dict(), dict(horizontal=True), dict(vcheck=3, nrad=1)], ids=["dh", "plain", "eedi3h", "vcheck3"])
+def test_two_plane_heights_overlap_equals_sequential_and_oracle(dev, oracle, kw, monkeypatch):
+    """YUV 4:2:0 batches: the tall planes' vertical-consistency chains run beside the short planes' line kernel (second,
+    CU-masked stream; plane slots reordered tall-first). Same bits as the sequential order, and as the oracle, with the
+    planes handed over in frame order (Y, U, V, Y, U, V)."""
+    shapes = [(96, 160), (48, 80), (48, 80)] * 2
+    planes = [np.ascontiguousarray(fx.tiled_natural(s, np.float32, i % 3)) + np.float32(0.01 * (i // 3)) for i, s in enumerate(shapes)]
+    srcs = [dev.upload(p) for p in planes]
+    a = [dev.download(d) for d in dev.eedi3(srcs, 1, **kw)]
+    monkeypatch.setenv("VSZIP_EEDI3_NO_OVERLAP", "1")
+    b = [dev.download(d) for d in dev.eedi3(srcs, 1, **kw)]
+    monkeypatch.delenv("VSZIP_EEDI3_NO_OVERLAP")
+    okw = {k: v for k, v in kw.items() if k != "horizontal"}
+    for p, x, y in zip(planes, a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        # EEDI3H == T . EEDI3 . T (src/vapoursynth/eedi3.zig:220-246)
+        want = np.ascontiguousarray(oracle.eedi3(np.ascontiguousarray(p.T), 1, **okw).T) if kw.get("horizontal") else oracle.eedi3(p, 1, **okw)
+        assert np.array_equal(x.view(np.uint32), want.view(np.uint32))
