@@ -149,3 +149,33 @@ def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
         c = cfgs[0]
         want = oracle.bilateral_plane(src, c[0], c[1], c[2], c[3], c[4], c[5], ref=refs[0] if joint else None)
         assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (dtype, sig, shape, joint)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_large_yuv420_batches_cross_the_launch_table(dev, oracle, dtype):
+    """70 frames of YUV 4:2:0 in one call = 210 planes: more than one launch table (192 planes), luma and chroma with
+    different radius / step (two launches per table, planes grouped by range-table content), every plane against the
+    oracle."""
+    shapes = [(64, 96), (32, 48), (32, 48)]
+    base = [fx.tiled_natural(s, dtype, i) for i, s in enumerate(shapes)]
+    hist = 65536
+    cfg = dev.bilateral_cfg([2], [2], yuv=True, ssw=1, ssh=1, hist_len=hist)
+    planes, idx = [], []
+    for f in range(70):
+        for i, p in enumerate(base):
+            planes.append(np.ascontiguousarray(np.roll(p, f, axis=1)))
+            idx.append(i)
+    srcs = [dev.upload(p) for p in planes]
+    dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+    dev.bilateral(srcs, dsts, cfg, idx)
+    want = {}
+    for k in (0, 1, 2, 70 * 3 - 3, 70 * 3 - 2, 70 * 3 - 1, 191, 192, 193, 100):
+        c = cfg[idx[k]]
+        w = oracle.bilateral_plane(planes[k], c.sigmaS, c.sigmaR, c.algorithm, c.radius, c.step, c.pbficnum)
+        assert np.array_equal(dev.download(dsts[k]).view(np.uint8), w.view(np.uint8)), k
+    # whole-batch check: away from the left / right borders the filter commutes with the roll that made frame f
+    first = [dev.download(dsts[i]) for i in range(3)]
+    for k in range(0, 210, 7):
+        f, i = divmod(k, 3)
+        assert np.array_equal(np.roll(first[i], f, axis=1)[:, 8 + f:-8].view(np.uint8), dev.download(dsts[k])[:, 8 + f:-8].view(np.uint8)), k
+    dev.bilateral_free(cfg)
