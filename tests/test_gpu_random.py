@@ -78,6 +78,24 @@ def test_boxblur_float_random(dev, oracle, seed):
     assert np.array_equal(dev.download(d).view(np.uint8), oracle.boxblur(p, r, 1, r, 1).view(np.uint8)), (seed, r, h, w)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_boxblur_float_ring_random(dev, oracle, seed):
+    """Planes large enough for the float register-ring kernel, in batches of mixed sizes: column-tile counts, bands that
+    end inside a ring period, ragged right strips, odd row counts, one call over all of them."""
+    rng = np.random.default_rng(2500 + seed)
+    dtype = [np.float32, np.float16][seed % 2]
+    r = int(rng.integers(1, 23))
+    planes = [_plane(rng, (int(rng.integers(2 * r + 40, 700)), int(rng.integers(270, 1500))), dtype) for _ in range(int(rng.integers(1, 5)))]
+    if seed % 3 == 0:
+        planes.append(_plane(rng, (int(rng.integers(2 * r + 1, 60)), int(rng.integers(2 * r + 1, 200))), dtype))  # one that stays on the tile kernel
+    srcs = [dev.upload(p) for p in planes]
+    dsts = [dev.empty(p.shape[0], p.shape[1], dtype) for p in planes]
+    dev.boxblur(srcs, dsts, r, 1, r, 1)
+    for i, p in enumerate(planes):
+        bad = dev.download(dsts[i]).view(np.uint8) != oracle.boxblur(p, r, 1, r, 1).view(np.uint8)
+        assert not bad.any(), (seed, r, p.shape, np.argwhere(bad)[:3].tolist())
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_bilateral_random(dev, oracle, seed):
     rng = np.random.default_rng(3000 + seed)
