@@ -319,7 +319,7 @@ def pipeline_line(dev, timed, world, frames, steps, warmup, max_over_ranks, redu
            "stream_ms_per_frame": region_ms / (steps * frames),
            "roofline": {"bound": "hbm", "achieved": alg * frames * steps / (region_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg * frames * steps / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "whole chain (bilateral_truncated + boxblur_ct + the SSIMULACRA2 kernels); algorithmic bytes = 6 x frame "
+                        "kernel": "whole chain (bilateral_lds16<f32> + boxblur_ctf_ring + the SSIMULACRA2 kernels); algorithmic bytes = 6 x frame "
                                   "(source read twice, each intermediate written and read once)"},
            "clip_mean_score": {"value": float(tot[0] / tot[1]), "frames": int(tot[1]), "reduced_over_ranks": world, "allreduce_ms": reduce_ms},
            "workload": "Bilateral(sigmaS=2,sigmaR=2) -> BoxBlur(r=2) -> SSIMULACRA2 on 7680x4320 RGBS, intermediates HBM-resident, per-clip mean score all-reduced"}
