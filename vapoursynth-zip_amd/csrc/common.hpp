@@ -72,6 +72,8 @@ void vszip_chain_release(vszip_ctx *ctx);  // frees ctx->chain_buf
 void vszip_bilateral_forget_lut(const void *dptr);  // vszip_dev_free: a packed range LUT goes with its allocation
 // Bracket the launch of a filter's dominant kernel; no-ops unless the probe is enabled.
 void vszip_probe_mark(vszip_ctx *ctx);
+void vszip_aux_register(vszip_ctx *ctx);  // ctx.hip: the context owns a CU-masked stream (destroyed at exit if still alive)
+
 struct vszip_probe_scope {
     vszip_ctx *c;
     explicit vszip_probe_scope(vszip_ctx *ctx) : c(ctx) { if (c->probe_on) vszip_probe_mark(c); }

@@ -3,6 +3,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
@@ -48,6 +50,34 @@ int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes) {
 
 VSZIP_EXPORT int vszip_abi_version(void) { return VSZIP_ABI_VERSION; }
 
+// Streams created with a CU mask must be gone before the process tears the runtime down: with rocprofv3 attached
+// a live one crashes the tool's finaliser (SIGSEGV inside __cxa_finalize, after the outputs are written). Contexts
+// that own one are listed here and an atexit handler - registered after the runtime's and the profiler's own, so it
+// runs before them - destroys what the host left alive.
+static std::mutex g_aux_mu;
+static std::set<vszip_ctx *> g_aux_ctxs;
+static void vszip_aux_atexit() {
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    for (vszip_ctx *c : g_aux_ctxs)
+        if (c->aux_stream) {
+            (void)hipSetDevice(c->device);
+            (void)hipStreamSynchronize(c->aux_stream);
+            (void)hipStreamDestroy(c->aux_stream);
+            c->aux_stream = nullptr;
+        }
+    g_aux_ctxs.clear();
+}
+void vszip_aux_register(vszip_ctx *ctx) {
+    static std::once_flag once;
+    std::call_once(once, [] { std::atexit(vszip_aux_atexit); });
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    g_aux_ctxs.insert(ctx);
+}
+static void vszip_aux_forget(vszip_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    g_aux_ctxs.erase(ctx);
+}
+
 VSZIP_EXPORT int vszip_ctx_create(int device, vszip_ctx **out) {
     if (!out) return VSZIP_ERR_ARG;
     *out = nullptr;
@@ -83,6 +113,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    vszip_aux_forget(ctx);
     if (ctx->aux_stream) {
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);

@@ -1597,6 +1597,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
                 split = false;
             }
             ctx->aux_reserved = reserve;
+            if (split) vszip_aux_register(ctx);
         }
     }
     if (!split) {
