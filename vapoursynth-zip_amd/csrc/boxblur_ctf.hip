@@ -210,6 +210,7 @@ typedef __attribute__((address_space(3))) float lds_float;
 #endif
 constexpr int kFRD = VSZIP_FRD;    // rows in flight ahead of the window
 constexpr int kFRPx = 4;           // pixels per lane and row
+constexpr uint32_t kFROob = 0xfffffff0u;  // store offset of a lane / row that must not be written (the buffer descriptor drops it)
 constexpr int kFRPix = 256, kFRRowB = 128;  // LDS: [pixel-in-lane] blocks of 256 floats, row A at +0, row B at +128, 8 floats of slack before lane 0
 constexpr int kFRLds = kFRPx * kFRPix + 16;
 constexpr int kFRMaxR = 22;         // larger radii: the ring (2r+1+D rows x 4 registers) no longer fits the register file with useful occupancy
@@ -227,7 +228,9 @@ struct FRPlane {
     const void *src;
     void *dst;
     int sstride, dstride;
-    int ya, yb;          // interior rows [ya, yb)
+    int ya, yb;          // rows of the main loops [ya, yb): yb = h - R, or h - NB when the kernel also does the bottom rows
+    int h;
+    int ylast;           // > 0: first row of the last band, which ends on a ring-period boundary and then does the bottom NB rows
     int xb;              // interior columns [0, xb)
     int ntx, nbands;
     int block0;
@@ -247,8 +250,10 @@ struct FRow<float> {
     static __device__ __forceinline__ void load(v4f &slot, const float *p) { slot = *reinterpret_cast<const v4f *>(p); }
 #endif
     static __device__ __forceinline__ void to_products(v4f &slot, float div) { slot = div * slot; }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rd, uint32_t vo, uint32_t so, v4f v) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rd, vo, so, VSZIP_FR_ST_AUX);  // aux 2 = nt
+    typedef v4u raw_t;
+    static __device__ __forceinline__ raw_t pack(v4f v) { return __builtin_bit_cast(v4u, v); }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rd, uint32_t vo, uint32_t so, raw_t v) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rd, vo, so, VSZIP_FR_ST_AUX);  // aux 2 = nt
     }
     static __device__ __forceinline__ v4f narrow(v4f v) { return v; }
 };
@@ -265,9 +270,13 @@ struct FRow<_Float16> {
         const v4h h = __builtin_bit_cast(v4h, r);
         slot = div * v4f{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rd, uint32_t vo, uint32_t so, v4f v) {
+    typedef v2u raw_t;
+    static __device__ __forceinline__ raw_t pack(v4f v) {
         const v4h h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, h), rd, vo, so, VSZIP_FR_ST_AUX);
+        return __builtin_bit_cast(v2u, h);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rd, uint32_t vo, uint32_t so, raw_t v) {
+        __builtin_amdgcn_raw_buffer_store_b64(v, rd, vo, so, VSZIP_FR_ST_AUX);
     }
     static __device__ __forceinline__ v4f narrow(v4f v) {  // tmp row is stored as T (:186)
         return v4f{(float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w};
@@ -297,6 +306,7 @@ struct FRWave {
     const lds_float *nb[2 * NBH + 1];
     float div;
     int last_row;
+    int ystop;  // rows from here on are computed by the main loop's pairs but not stored
 
     template <int J>
     __device__ __forceinline__ void preload(int y0) {
@@ -316,27 +326,27 @@ struct FRWave {
         ((acc = acc + ring[(S + Kk) % NR]), ...);  // tap order, unfused (:176)
         return acc;
     }
-    // vertical pass of output row y + S (window = slots S .. S + K - 1 mod NR); div * tmp goes to LDS row A or B
-    template <int S>
-    __device__ __forceinline__ void vstep(int y) {
-        FRow<T>::to_products(ring[(S + K - 1) % NR], div);  // row y + S + R arrived D steps ago
-        FRow<T>::load(ring[(S + NR - 1) % NR], sp + (size_t)min(y + S + R + kFRD, last_row) * ss);
-        const v4f acc = window_sum<S>(std::make_integer_sequence<int, K>{});
+    // div * tmp of one output row goes to LDS row A (par 0) or B (par 1)
+    __device__ __forceinline__ void put_row(v4f acc, int par) {
         const v4f ph = div * FRow<T>::narrow(acc);
-        float *p = pw + (S & 1) * kFRRowB;
+        float *p = pw + par * kFRRowB;
         p[0 * kFRPix] = ph.x;
         p[1 * kFRPix] = ph.y;
         p[2 * kFRPix] = ph.z;
         p[3 * kFRPix] = ph.w;
     }
-    // Two output rows per horizontal pass: the packed accumulators pair ROW A with ROW B of one column, and
-    // that pair (qA[j], qB[j]) is two LDS words 128 floats apart - one two-address read, already in an aligned
-    // register pair (pairing neighbouring columns of one row needs 45 register moves per row instead).
+    // vertical pass of output row y + S (window = slots S .. S + K - 1 mod NR)
     template <int S>
-    __device__ __forceinline__ bool step2(int y, int yend) {
-        if (y + S >= yend) return false;  // (uniform) a band may end inside a ring period
-        vstep<S>(y);
-        vstep<S + 1>(y);
+    __device__ __forceinline__ void vstep(int y) {
+        FRow<T>::to_products(ring[(S + K - 1) % NR], div);  // row y + S + R arrived D steps ago
+        FRow<T>::load(ring[(S + NR - 1) % NR], sp + (size_t)min(y + S + R + kFRD, last_row) * ss);
+        put_row(window_sum<S>(std::make_integer_sequence<int, K>{}), S & 1);
+    }
+    // Two output rows per horizontal pass (rows ya, ya + 1, already parked in LDS rows A / B): the packed
+    // accumulators pair ROW A with ROW B of one column, and that pair (qA[j], qB[j]) is two LDS words 128 floats
+    // apart - one two-address read, already in an aligned register pair (pairing neighbouring columns of one row needs
+    // 45 register moves per row instead). Rows from `ystop` on are computed but not stored.
+    __device__ __forceinline__ void hpass(int ya_row) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -373,15 +383,57 @@ struct FRWave {
 #pragma unroll
             for (int k = 0; k < K; ++k) o[e] = o[e] + q[e + k];  // tap order, unfused (:232)
         }
-        FRow<T>::store(rd, sdoff, (uint32_t)(y + S) * drow, v4f{o[0].x, o[1].x, o[2].x, o[3].x});
-        FRow<T>::store(rd, sdoff, (uint32_t)(y + S + 1) * drow, v4f{o[0].y, o[1].y, o[2].y, o[3].y});
-        // gfx940+ reads the data registers of a 16-byte store over the following cycles (a VALU write to them needs 2
-        // wait states); the hazard recogniser counts the two zero-size barriers below as those wait states, and
-        // without real ones the last lanes of every 16 stored the NEXT row pair's first LDS reads
+        // gfx950 reads the data registers of a 16-byte buffer store over the following cycles; a VALU write to them needs
+        // 2 wait states, and the compiler's hazard recogniser does not provide them for stores whose soffset is an SGPR
+        // (it assumes the hazard away there) - the last lanes of every 16 then store whatever was written next. So: both
+        // rows' data are assembled in registers of their own FIRST (the empty asm pins them), then the two stores issue
+        // back to back, then real wait states, and nothing is scheduled across.
+        typename FRow<T>::raw_t ta = FRow<T>::pack(v4f{o[0].x, o[1].x, o[2].x, o[3].x}), tb = FRow<T>::pack(v4f{o[0].y, o[1].y, o[2].y, o[3].y});
+        uint32_t va = ya_row < ystop ? sdoff : kFROob, vb = ya_row + 1 < ystop ? sdoff : kFROob;  // (the second offset's select landed in the first store's data register)
+        asm volatile("" : "+v"(ta), "+v"(tb), "+v"(va), "+v"(vb));
+        __builtin_amdgcn_sched_barrier(0);
+        FRow<T>::store(rd, va, (uint32_t)ya_row * drow, ta);
+        FRow<T>::store(rd, vb, (uint32_t)(ya_row + 1) * drow, tb);
         asm volatile("s_nop 3");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);  // a row pair is a scheduling region: the row loads stay D steps ahead of their use
+    }
+    template <int S>
+    __device__ __forceinline__ bool step2(int y, int yend) {
+        if (y + S >= yend) return false;  // (uniform) a band may end inside a ring period
+        vstep<S>(y);
+        vstep<S + 1>(y);
+        hpass(y + S);
         return true;
+    }
+
+    // The last NB rows of the plane (NB = R or R + 1, even): taps past the bottom edge mirror about the CURRENT row
+    // (boxblur_comptime.zig:61-66), so output row h - NB + J with d = NB - 1 - J rows below it sums rows i - R .. h - 1
+    // and then i - 1, i - 2, .., i - (R - d). All of them sit in the ring when the band's main loop has ended on a
+    // period boundary (row y_f = h - NB - 1 at step NR - 1: row y_f - R + k in slot (NR - 1 + k) mod NR), which makes
+    // every slot of every sequence a compile-time constant.
+    static constexpr int NB = (R % 2 == 0) ? R : R + 1;
+    template <int J, int Kk>
+    static constexpr int bottom_slot() {
+        constexpr int d = NB - 1 - J;
+        return Kk <= R + d ? (J + Kk) % NR : (R + J - (Kk - R - d) + NR) % NR;
+    }
+    template <int J, int... Kk>
+    __device__ __forceinline__ v4f bottom_sum(std::integer_sequence<int, Kk...>) {
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        ((acc = acc + ring[bottom_slot<J, Kk>()]), ...);
+        return acc;
+    }
+    template <int P2>
+    __device__ __forceinline__ void bottom_pair(int yb0) {
+        put_row(bottom_sum<2 * P2>(std::make_integer_sequence<int, K>{}), 0);
+        put_row(bottom_sum<2 * P2 + 1>(std::make_integer_sequence<int, K>{}), 1);
+        hpass(yb0 + 2 * P2);
+    }
+    template <int... P2>
+    __device__ __forceinline__ void bottom_rows(int yb0, std::integer_sequence<int, P2...>) {
+        if constexpr (NB == R + 1) FRow<T>::to_products(ring[(NR - 1 + K) % NR], div);  // row h - 1 was fetched ahead of the last window
+        (bottom_pair<P2>(yb0), ...);
     }
     template <int... S2>
     __device__ __forceinline__ void period(int y, int yend, std::integer_sequence<int, S2...>) {
@@ -405,10 +457,17 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     const FRPlane &pl = prm.p[pi];
     const int lb = b - pl.block0;
     const int tx = lb % pl.ntx, by = lb / pl.ntx;
-    // bands split the plane's row PAIRS evenly (an odd row count makes the last band compute row yb as well: it
-    // belongs to the bottom strip, whose kernel runs afterwards)
-    const int npairs = (pl.yb - pl.ya + 1) / 2;
-    const int y0 = pl.ya + 2 * (int)((long)by * npairs / pl.nbands), y1 = pl.ya + 2 * (int)((long)(by + 1) * npairs / pl.nbands);
+    // Bands split the plane's row PAIRS evenly. Without the bottom rows (ylast == 0) an odd row count makes the last band
+    // compute row yb as well - it belongs to the bottom strip, whose kernel runs afterwards. With them, the last band
+    // is [ylast, yb) - a whole number of ring periods - and the others share [ya, ylast) (an odd count there makes the band
+    // before the last one compute row ylast too: the same bits as the last band's).
+    const bool bottom = pl.ylast > 0;
+    const int nb_even = bottom ? pl.nbands - 1 : pl.nbands;
+    const int y_even_end = bottom ? pl.ylast : pl.yb;
+    const int npairs = (y_even_end - pl.ya + 1) / 2;
+    const bool last_band = bottom && by == pl.nbands - 1;
+    const int y0 = last_band ? pl.ylast : pl.ya + 2 * (int)((long)by * npairs / nb_even);
+    const int y1 = last_band ? pl.yb : pl.ya + 2 * (int)((long)(by + 1) * npairs / nb_even);
     const int lane = threadIdx.x;
     // this lane's first column; the last tile is shifted left to end at xb, the first one starts HL columns left of
     // the plane (its halo lanes hold the reflect-101 images of columns 1 .. HL)
@@ -426,11 +485,12 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     st.sp = static_cast<const T *>(pl.src) + max(cx, 0);  // (halo lanes of the first tile load columns they overwrite in LDS)
     st.ss = (size_t)pl.sstride;
     st.drow = (uint32_t)pl.dstride * (uint32_t)sizeof(T);
-    st.rd = __builtin_amdgcn_make_buffer_rsrc(pl.dst, 0, (int)((uint32_t)(pl.yb + R) * st.drow), 0x00020000);
+    st.rd = __builtin_amdgcn_make_buffer_rsrc(pl.dst, 0, (int)((uint32_t)pl.h * st.drow), 0x00020000);
     const bool is_out = lane >= G::HL / PXL && lane < G::HL / PXL + G::OUT_LANES;
-    st.sdoff = is_out ? (uint32_t)cx * (uint32_t)sizeof(T) : 0xfffffff0u;  // (output lanes: cx >= 0)
+    st.sdoff = is_out ? (uint32_t)cx * (uint32_t)sizeof(T) : kFROob;  // (output lanes: cx >= 0)
     st.div = 1.0f / (float)K;  // :39
-    st.last_row = pl.yb + R - 1;  // rows fetched past it are never summed
+    st.last_row = pl.h - 1;  // rows fetched past it are never summed
+    st.ystop = bottom ? pl.yb : 0x7fffffff;  // (with the bottom rows in the kernel a main-loop pair must not write into them)
     st.pw = P + 8 + lane;
 #pragma unroll
     for (int i = 0; i < 2 * W::NBH + 1; ++i) {
@@ -442,6 +502,10 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     st.products_all(std::make_integer_sequence<int, K - 1>{});
 #pragma unroll 1
     for (int y = y0; y < y1; y += NR) st.period(y, y1, std::make_integer_sequence<int, NR / 2>{});
+    if (last_band) {  // (uniform)
+        st.ystop = pl.h;
+        st.bottom_rows(pl.yb, std::make_integer_sequence<int, W::NB / 2>{});
+    }
 }
 
 template <typename T, int R>
@@ -538,6 +602,19 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
             if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) ++nb[i];
         waves += extra;
     }
+    // Bottom rows inside the ring kernel: needs a last band of a whole number of ring periods ending at h - NB and at
+    // least one band before it (otherwise the bottom strip goes through the tile kernel as the right one does)
+    const int NB = (radius % 2 == 0) ? radius : radius + 1;
+    std::vector<int> ylasts(nplanes, 0);
+    if (!getenv("VSZIP_BOXBLUR_FLOAT_BOTTOM_STRIP"))
+        for (int i = 0; i < nplanes; ++i) {
+            if (nb[i] < 2) continue;
+            const int main_rows = planes[i].h - NB;
+            int m = (std::max(planes[i].h / nb[i] - NB, NR) + NR / 2) / NR;  // the last band also does the NB bottom rows: about as many rows as the others in all
+            m = std::max(1, std::min(m, (main_rows - 2 * (nb[i] - 1)) / NR));
+            if (m < 1 || main_rows - m * NR < 2 * (nb[i] - 1)) continue;
+            ylasts[i] = main_rows - m * NR;
+        }
     for (int done = 0; done < nplanes;) {
         FRParams prm;
         int n = 0, blocks = 0;
@@ -549,8 +626,11 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
             d.dst = s.dst;
             d.sstride = (int)s.src_stride;
             d.dstride = (int)s.dst_stride;
+            d.h = s.h;
             d.ya = 0;  // (the ring kernel mirrors the top rows itself)
             d.yb = s.h - radius;
+            d.ylast = ylasts[done];
+            if (d.ylast > 0) d.yb = s.h - NB;  // ... and the bottom rows, behind a last band that is a whole number of ring periods
             d.xb = xbs[done];
             d.ntx = ntxs[done];
             d.nbands = nb[done];
@@ -592,9 +672,13 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
         const vszip_plane &s = planes[i];
         int ntx, xb;
         if (ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) {
-            const int ya = 0, yb = s.h - radius;  // (the ring kernel mirrors the top rows itself)
-            add_rect(s, 0, yb, s.w, s.h);     // bottom
-            add_rect(s, xb, ya, s.w, yb);     // right
+            if (ylasts[i] > 0) {
+                add_rect(s, xb, 0, s.w, s.h);  // right (the ring kernel does the top, left and bottom edges itself)
+            } else {
+                const int yb = s.h - radius;
+                add_rect(s, 0, yb, s.w, s.h);  // bottom
+                add_rect(s, xb, 0, s.w, yb);   // right
+            }
         } else {
             add_rect(s, 0, 0, s.w, s.h);
         }
