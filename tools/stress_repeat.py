@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""GPU box: run the same BoxBlur / Bilateral / SSIMULACRA2 / EEDI3 launches many times and compare every output with the
+first run's, bit for bit - timing-dependent hardware hazards and stream races show up as rare mismatches."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
+import torch  # noqa: F401
+import bench
+import fixtures as fx
+import vszip_amd
+
+dev = vszip_amd.Device(0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+bad_total = 0
+
+
+def planes_of(dtype, w, h, frames, seed):
+    base = [fx.splitmix64_plane(seed + p, s, dtype) for p, s in enumerate(bench.yuv420_shapes(w, h))]
+    return [np.roll(p, f, axis=1) for f in range(frames) for p in base]
+
+
+def repeat(name, run, outs, n=N):
+    global bad_total
+    run()
+    dev.sync()
+    first = [dev.download(o).copy() for o in outs]
+    bad = 0
+    for it in range(n):
+        run()
+        dev.sync()
+        for k in range(it % 3, len(outs), 3):  # a third of the planes per iteration
+            if not np.array_equal(dev.download(outs[k]).view(np.uint8), first[k].view(np.uint8)):
+                bad += 1
+    print(f"{name}: {n} runs, mismatching planes {bad}", flush=True)
+    bad_total += bad
+
+
+for dtype, r, frames in [(np.uint16, 13, 16), (np.uint8, 13, 16), (np.uint16, 5, 16), (np.float32, 3, 4), (np.float32, 13, 4), (np.float16, 7, 4), (np.float32, 22, 4)]:
+    pl = planes_of(dtype, bench.W4K, bench.H4K, frames, 7)
+    srcs = [dev.upload(p) for p in pl]
+    dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in pl]
+    table = dev.plane_table(srcs, dsts)
+    repeat(f"boxblur {np.dtype(dtype).name} r={r} x{frames} 4K", lambda: dev.boxblur_table(dtype, table, r, 1, r, 1), dsts)
+    del srcs, dsts, table
+
+pl = planes_of(np.uint16, bench.W1080, bench.H1080, 16, 11)
+srcs = [dev.upload(p) for p in pl]
+dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in pl]
+cfg = dev.bilateral_cfg([2], [2], yuv=True, ssw=1, ssh=1, hist_len=65536)
+idx = [i % 3 for i in range(len(pl))]
+repeat("bilateral u16 1080p x16", lambda: dev.bilateral(srcs, dsts, cfg, idx), dsts)
+
+plf = [np.ascontiguousarray(fx.tiled_natural(s, np.float32, i % 3)) for i, s in enumerate(bench.yuv420_shapes(bench.W1080, bench.H1080) * 4)]
+fs = [dev.upload(p) for p in plf]
+outs = dev.eedi3(fs, 1, dh=True)
+table = dev.plane_table(fs, outs)
+prm = bench._eedi3_params()
+repeat("eedi3 1080p YUV420PS x4 (two plane heights: overlap path)", lambda: dev.check(dev.lib.vszip_eedi3(dev.ctx, table, None, None, len(fs), 1, 0, prm)), outs, n=max(10, N // 3))
+
+ref = [np.ascontiguousarray(fx.tiled_natural((1080, 1920), np.float32, p)) for p in range(3)]
+rng = np.random.default_rng(3)
+rr, dd = [], []
+for i in range(6):
+    rr += [dev.upload(p) for p in ref]
+    dd += [dev.upload(np.clip(p + rng.normal(0, 0.01 * (i + 1), p.shape).astype(np.float32), 0, 1).astype(np.float32)) for p in ref]
+first = dev.ssimulacra2(rr, dd)
+bad = sum(1 for _ in range(N) if [float(x).hex() for x in dev.ssimulacra2(rr, dd)] != [float(x).hex() for x in first])
+print(f"ssimulacra2 1080p x6 pairs (halves on two streams): {N} runs, mismatching calls {bad}")
+bad_total += bad
+print("TOTAL MISMATCHES", bad_total)
+sys.exit(1 if bad_total else 0)
