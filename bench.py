@@ -509,15 +509,19 @@ def limit_filter_leg(dev, timed, frames=16):
                                 "workload": f"vszip.LimitFilter dark_thr=bright_thr=8 elast=3: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
 
 
-def boxblur_other_paths_leg(dev, timed, frames=8):
+def boxblur_other_paths_leg(dev, timed, frames_in=8):
     """The BoxBlur paths beside the headline one: the runtime path (radius > 22 or several passes,
     boxblur_runtime.zig) on 4K YUV420P16 and the compile-time float path on 4K YUV420PS."""
     out = {}
     base16 = make_frame(3, W4K, H4K)
     basef = [(p.astype(np.float32) / 65535.0) for p in base16]
+    fmt_names = {'uint16': 'YUV420P16', 'float32': 'YUV420PS', 'uint8': 'YUV420P8'}
+    base8 = [(p >> 8).astype(np.uint8) for p in base16]
     for name, base, args, dt_ in (("boxblur_rt_r30_4k", base16, (30, 1, 30, 1), np.uint16), ("boxblur_rt_r5x3_4k", base16, (5, 3, 5, 3), np.uint16),
-                                  ("boxblur_ct_float_r13_4k", basef, (13, 1, 13, 1), np.float32), ("boxblur_rt_float_r5x3_4k", basef, (5, 3, 5, 3), np.float32)):
+                                  ("boxblur_ct_float_r13_4k", basef, (13, 1, 13, 1), np.float32), ("boxblur_rt_float_r5x3_4k", basef, (5, 3, 5, 3), np.float32),
+                                  ("boxblur_ct_u8_r13_4k", base8, (13, 1, 13, 1), np.uint8)):
         srcs, dsts = [], []
+        frames = 64 if dt_ == np.uint8 else frames_in
         for f in range(frames):
             for p in base:
                 srcs.append(dev.upload(np.roll(p, f + 1, axis=1)))
@@ -529,7 +533,7 @@ def boxblur_other_paths_leg(dev, timed, frames=8):
         out[name] = {"value": frames * 5 / dt, "unit": "frames/s",
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                   "note": "algorithmic bytes = one read + one write of the frame, whatever the number of passes"},
-                     "workload": f"vszip.BoxBlur hradius={args[0]} hpasses={args[1]} vradius={args[2]} vpasses={args[3]}, 3840x2160 {'YUV420P16' if dt_ == np.uint16 else 'YUV420PS'}, HBM-resident"}
+                     "workload": f"vszip.BoxBlur hradius={args[0]} hpasses={args[1]} vradius={args[2]} vpasses={args[3]}, 3840x2160 {fmt_names[np.dtype(dt_).name]}, {frames} frames per call, HBM-resident"}
         del srcs, dsts
     return out
 

@@ -8,6 +8,7 @@
 // VSZIP_ERR_HIP — the plugin must turn that into a filter error and release everything it holds.
 // VSZIP_STUB_FAIL=alloc|copy makes allocations / copies fail instead, =none makes every filter succeed. The device-free entry points come from
 // the product's own csrc/host_params.cpp, compiled alongside.
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -22,14 +23,17 @@
 struct vszip_ctx {
     std::string err;
     int staging = 0;
+    int device = 0;
     std::vector<void *> live;  // allocations not yet freed: destroy() asserts the plugin returned them... or reports
 };
 
+static std::atomic<long> g_calls[16];  // filter calls per fake device
 static bool fail_mode(const char *what) {
     const char *e = getenv("VSZIP_STUB_FAIL");
     return e && strcmp(e, what) == 0;
 }
 static int kernel_failed(vszip_ctx *ctx, const char *name) {
+    if (ctx) g_calls[ctx->device].fetch_add(1);
     // VSZIP_STUB_FAIL=none: the "kernel" succeeds (outputs keep whatever the staging left there), so every filter's
     // SUCCESS path - download, frame properties, release of every reference - runs under the sanitizer as well
     if (fail_mode("none")) return VSZIP_OK;
@@ -56,11 +60,23 @@ static void touch_table(const vszip_plane *pl, int n, int bps) {
     }
 }
 
+// VSZIP_STUB_DEVICES=N: N fake devices (default one). With more than one, BoxBlur's "kernel" stamps the device index
+// of the context it ran on into the first sample of every destination plane and the per-device call counters below
+// count filter calls, so a test can see which GPU the plugin sent each frame to (frame-index round-robin,
+// vszip_plugin.cpp device_of_frame) without a multi-GPU box.
+static int stub_devices() {
+    const char *e = getenv("VSZIP_STUB_DEVICES");
+    const int n = e ? atoi(e) : 1;
+    return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+EXP long vszip_stub_device_calls(int device) { return device >= 0 && device < 16 ? g_calls[device].load() : -1; }
+
 EXP int vszip_ctx_create(int device, vszip_ctx **out) {
     if (!out) return VSZIP_ERR_ARG;
     *out = nullptr;
-    if (device != 0) return VSZIP_ERR_HIP;  // one fake device
+    if (device < 0 || device >= stub_devices()) return VSZIP_ERR_HIP;
     *out = new vszip_ctx();
+    (*out)->device = device;
     return VSZIP_OK;
 }
 EXP void vszip_ctx_destroy(vszip_ctx *ctx) { delete ctx; }
@@ -118,6 +134,9 @@ EXP int vszip_probe_read(vszip_ctx *ctx, double *t, int *n) { return vszip_probe
 
 EXP int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *pl, int n, int, int, int, int) {
     touch_table(pl, n, bps_of(dtype));
+    if (ctx && stub_devices() > 1 && fail_mode("none"))
+        for (int i = 0; i < n; ++i)
+            if (pl[i].dst && pl[i].w > 0 && pl[i].h > 0) memset(pl[i].dst, 0, (size_t)bps_of(dtype)), *(unsigned char *)pl[i].dst = (unsigned char)ctx->device;
     return kernel_failed(ctx, "BoxBlur");
 }
 EXP int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *pl, int n, const int32_t *ex, int nex, int, double *avg, double *diff) {

@@ -172,3 +172,38 @@ def test_worker_threads_under_tsan():
     out = r.stdout + r.stderr
     assert "ThreadSanitizer" not in out and r.returncode != 97, out[-6000:]
     assert r.returncode == 0 and "success ok" in r.stdout, out[-3000:]
+
+
+ROUND_ROBIN = textwrap.dedent("""
+    import ctypes, os, sys, numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+    from fakevs import fakevs as vs
+    rng = np.random.default_rng(1)
+    n = 12
+    frames = [[(rng.random(s) * 60000).astype(np.uint16) + 1000 for s in ((64, 96), (32, 48), (32, 48))] for _ in range(n)]
+    clip = vs.source(frames, vs.YUV420P16)
+    out = clip.vszip.BoxBlur(hradius=2, vradius=2)
+    # the stub stamps the device index of the context a frame's BoxBlur ran on into every plane's first sample
+    for i in range(n):
+        f = out.get_frame(i)
+        stamps = [int(f[p][0, 0]) for p in range(3)]
+        assert stamps == [i % 3] * 3, (i, stamps)
+    stub = ctypes.CDLL(os.path.join(os.path.dirname(os.environ["VSZIP_PLUGIN_LIB"]), "libvszip_hip.so"))
+    stub.vszip_stub_device_calls.restype = ctypes.c_long
+    calls = [stub.vszip_stub_device_calls(d) for d in range(4)]
+    assert calls == [4, 4, 4, 0], calls
+    out.pull(2 * n, 6)  # and from six worker threads at once: three gates, three sets of slot contexts
+    calls = [stub.vszip_stub_device_calls(d) for d in range(4)]
+    assert calls == [12, 12, 12, 0], calls
+    print("round robin ok")
+""")
+
+
+def test_frames_round_robin_over_three_devices(san_env):
+    """Multi-GPU through the plugin: frame n runs on GPU n mod G, every GPU with its own gate
+    slots and contexts. The stub library offers three fake devices and says which one each frame ran on; 12 frames from
+    6 worker threads, under ASan."""
+    env = dict(san_env, VSZIP_STUB_FAIL="none", VSZIP_STUB_DEVICES="3")
+    r = subprocess.run([sys.executable, "-c", ROUND_ROBIN.format(root=str(ROOT), tests=str(ROOT / "tests"))], capture_output=True, text=True, env=env, timeout=600)
+    _clean(r)
+    assert r.returncode == 0 and "round robin ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
