@@ -152,6 +152,29 @@ def test_rt_matches_oracle(dev, oracle, dtype, case):
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, case, shape)
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("r", [23, 30, 63, 64, 100, 250])
+def test_rt_horizontal_mirror_extended_rows(dev, oracle, dtype, r, monkeypatch):
+    """The horizontal RT pass on rows that are whole lane groups: the prefix runs over the mirror-extended row (halo
+    lanes hold reversed real groups), every window a two-term difference. Widths from one chunk to several, with halos that
+    fill less / more than a chunk, saturated rows (the 32-bit scale must not overflow), several passes; against the oracle
+    and against the clamped-terms kernel (VSZIP_RT_NO_VIRT)."""
+    V = 16 // np.dtype(dtype).itemsize
+    for w in (2 * r + 1, 512, 1040, 1920 + 2 * V):  # (the filter needs 2 r < width)
+        w = (max(w, 2 * r + 1) + V - 1) // V * V
+        for passes in (1, 2):
+            src = fx.splitmix64_plane(300 + r, (9, w), dtype)
+            src[3] = np.iinfo(dtype).max
+            src[4, : w // 2] = 0
+            got = _run(dev, src, r, passes, 0, 0)
+            want = oracle.boxblur(src, r, passes, 0, 0)
+            assert np.array_equal(got, want), (dtype, r, w, passes, np.argwhere(got != want)[:4].tolist())
+            monkeypatch.setenv("VSZIP_RT_NO_VIRT", "1")
+            alt = _run(dev, src, r, passes, 0, 0)
+            monkeypatch.delenv("VSZIP_RT_NO_VIRT")
+            assert np.array_equal(got, alt), (dtype, r, w, passes)
+
+
 def test_rt_reference_golden_rgbs(dev):
     """RGBS|full|hpasses=2,hradius=6,vpasses=3,vradius=3 and RGBS|full|hradius=2,vradius=2 (reference goldens)."""
     g = fx.ref_goldens()["exact"]["boxblur"]

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm
             }
         }
     }
+    const bool mul24 = (uint64_t)(sizeof(T) == 1 ? 255u : 65535u) * ksize < (1u << 24);
     constexpr int kPm = 4;  // output rows per chunk of the sliding part: 2 * kPm loads in flight
     for (int i0 = y0; i0 < y1; i0 += kPm) {
         uint4 qa[kPm], qc[kPm];
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm
                 X::unpack(qc[u], c);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    o[k] = (uint32_t)(((uint64_t)e[k] * inv2 + kk[k]) >> 16);
+                    // the 16.16 value is the window mean + 0.5: 32 bits hold it (a 24-bit multiply while the window sum is below 2^24)
+                    o[k] = ((mul24 ? (uint32_t)__umul24(e[k], inv2) : e[k] * inv2) + kk[k]) >> 16;
                     e[k] += a[k] - c[k];
                 }
                 X::store(d + (size_t)i * ds, o, nst);
@@ -349,15 +351,27 @@ __global__ __launch_bounds__(64) void boxblur_rt_hrow_kernel(const RParams prm) 
 
 
 // Horizontal, single pass (radius < one chunk of 64 * V columns): the prefix lives in a ring of
-// three chunks in LDS instead of the whole row — 6 KiB (u16) per wave instead of 4 bytes per
-// column, so 3x the waves per CU — and the row is read once: chunk c+1 is prefixed while chunk c
+// four chunks in LDS instead of the whole row — 8 KiB (u16) per wave instead of 4 bytes per
+// column, so more waves per CU — and the row is read once: chunk c+1 is prefixed while chunk c
 // is emitted from the chunks c-1, c, c+1 that its windows (and the mirror terms at the row ends)
-// can reach.
-template <typename T>
+// can reach. Four slots, not three: the slot of a column is then two bits of its index, and the
+// LDS address of "column x + r" / "column x - r - 1" of a lane is a per-lane constant that moves by
+// one chunk per step — an add and a mask per access instead of a division by three.
+//
+// VIRT (every row a whole number of lane groups, both halos narrower than the row): the prefix runs over the
+// VIRTUAL row [mirror image of columns 0..HL-1 | the row | mirror image of the last HR columns] (blurInt's
+// implicit padding: -k -> k-1, w-1+k -> w-k; a halo lane loads the real group it mirrors and reverses it in
+// registers), so every window — at the row ends too — is the same two-term prefix difference. Without it the two end
+// chunks of a row (a third of a 4K frame's chunks) evaluate five clamped terms per pixel: 190 VALU instructions per
+// chunk on average against about 100.
+template <typename T, bool VIRT>
 __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm) {
     using X = RtVec<T>;
     constexpr int V = X::V, CH = 64 * V;
-    __shared__ __attribute__((aligned(16))) uint32_t P[3 * CH];
+    constexpr uint32_t kRing = 4u * CH;
+    constexpr int LV = V == 8 ? 3 : 4, LCH = LV + 6;
+    static_assert((1 << LV) == V && (1 << LCH) == CH, "chunk geometry");
+    __shared__ __attribute__((aligned(16))) uint32_t P[kRing];
     const int b = blockIdx.x;
     const RPlane pl = prm.p[rt_find(prm, b)];
     const int y = b - pl.block0;
@@ -365,33 +379,63 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
     const T *s = static_cast<const T *>(pl.src) + (size_t)y * pl.sstride;
     T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
     const int lane = threadIdx.x;
-    const int nch = (w + CH - 1) / CH;
-    auto pidx = [&](uint32_t c) { return ((c / (uint32_t)CH) % 3u) * (uint32_t)CH + (c % (uint32_t)V) * 64u + (c % (uint32_t)CH) / (uint32_t)V; };
+    // virtual row: HL mirrored columns, the row, HR mirrored columns (both 0 without VIRT)
+    const int HL = VIRT ? ((R + V) / V) * V : 0, HR = VIRT ? ((R + V - 1) / V) * V : 0;
+    const int vw = HL + w + HR;
+    const int nch = (vw + CH - 1) / CH;
+    // column c -> [slot = chunk & 3][pixel-in-lane][lane]: conflict-free for a fixed pixel index
+    auto pidx = [&](uint32_t c) { return (c & (kRing - 1u) & ~(uint32_t)(CH - 1)) | ((c & (uint32_t)(V - 1)) << 6) | ((c & (uint32_t)(CH - 1)) >> LV); };
     uint32_t carry = 0;
     // the row is fetched one chunk ahead of its prefix (a load issued and scanned in the same step
     // would put a global round trip on every chunk of the row's chain)
     auto fetch = [&](int ch) -> uint4 {
-        const int x0 = ch * CH + lane * V;
-        return (ch < nch && x0 < w) ? X::raw(s + x0) : make_uint4(0, 0, 0, 0);  // [w, stride) is readable padding; masked below
+        const int v0 = ch * CH + lane * V;
+        if (ch >= nch || v0 >= vw) return make_uint4(0, 0, 0, 0);  // (without VIRT: [w, stride) is readable padding; masked below)
+        int g = v0 - HL;
+        if constexpr (VIRT) g = g < 0 ? -g - V : (g >= w ? 2 * w - g - V : g);
+        return X::raw(s + g);
     };
-    auto prefix_chunk = [&](int ch, const uint4 q) {
+    auto prefix_chunk = [&](int ch, uint4 q) {
         const int x0 = ch * CH + lane * V;
+        if constexpr (VIRT) {
+            if (ch * CH < HL || ch * CH + CH > HL + w) {  // (wave-uniform: the chunk holds halo lanes)
+                const int c0 = x0 - HL;
+                if (c0 < 0 || c0 >= w) {  // mirrored lanes: pixel order reversed
+                    const uint4 o = q;
+                    if constexpr (sizeof(T) == 2) {
+                        q.x = __builtin_amdgcn_alignbit(o.w, o.w, 16);
+                        q.y = __builtin_amdgcn_alignbit(o.z, o.z, 16);
+                        q.z = __builtin_amdgcn_alignbit(o.y, o.y, 16);
+                        q.w = __builtin_amdgcn_alignbit(o.x, o.x, 16);
+                    } else {
+                        q.x = __builtin_amdgcn_perm(o.w, o.w, 0x00010203u);
+                        q.y = __builtin_amdgcn_perm(o.z, o.z, 0x00010203u);
+                        q.z = __builtin_amdgcn_perm(o.y, o.y, 0x00010203u);
+                        q.w = __builtin_amdgcn_perm(o.x, o.x, 0x00010203u);
+                    }
+                }
+            }
+        }
         uint32_t v[V];
         X::unpack(q, v);
+        if constexpr (!VIRT) {
+            if (ch * CH + CH > w) {  // (wave-uniform: only the last chunk holds columns past the row)
 #pragma unroll
-        for (int k = 0; k < V; ++k)
-            if (x0 + k >= w) v[k] = 0;
+                for (int k = 0; k < V; ++k)
+                    if (x0 + k >= w) v[k] = 0;
+            }
+        }
 #pragma unroll
         for (int k = 1; k < V; ++k) v[k] += v[k - 1];
         const uint32_t incl = wave_incl_scan_dpp(v[V - 1]);
         const uint32_t base = carry + incl - v[V - 1];
-        uint32_t *slot = P + (ch % 3) * CH;
+        uint32_t *slot = P + (ch & 3) * CH;
 #pragma unroll
         for (int k = 0; k < V; ++k) slot[k * 64 + lane] = v[k] + base;
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     };
     const uint4 q0 = fetch(0), q1 = fetch(1);
-    uint4 qn = fetch(2);  // raw samples of the chunk the loop scans next
+    uint4 qn = fetch(2);  // raw samples of the chunk the loop scans next (fetching four chunks ahead instead of one: -3 %)
     prefix_chunk(0, q0);
     if (nch > 1) prefix_chunk(1, q1);
     vszip_wave_fence();
@@ -399,26 +443,40 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
     const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
     const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
     auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : P[pidx((uint32_t)min(c, w - 1))]; };
-    const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2*sum_{x<r} srcp[x]; r < CH: chunks 0 / 1
+    // srcp[r] + 2*sum_{x<r} srcp[x] (r < CH: chunks 0 / 1); real prefix Q(c) = virtual prefix at c + HL minus the left halo's sum
+    uint32_t e0;
+    if constexpr (VIRT)
+        e0 = P[pidx((uint32_t)(R + HL))] + P[pidx((uint32_t)(R - 1 + HL))] - 2u * P[pidx((uint32_t)(HL - 1))];
+    else
+        e0 = Q(R) + Q(R - 1);
     const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
+    // (e * inv2 + kr) >> 16 in 32 bits: the 16.16 value is the window mean + 0.5, at most 65535.5 * 65536 (blurInt
+    // :24-40); a 24-bit multiply serves while the window sum itself stays below 2^24
+    constexpr uint32_t kPeak = sizeof(T) == 1 ? 255u : 65535u;
+    const bool mul24 = (uint64_t)kPeak * ksize < (1u << 24);
+    auto scale = [&](uint32_t e) -> uint32_t { return ((mul24 ? (uint32_t)__umul24(e, inv2) : e * inv2) + kr) >> 16; };
+    // LDS addresses of this lane's window ends in chunk 0's frame; chunk ch adds ch * CH, modulo the ring
+    uint32_t a_hi[V], a_lo[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        a_hi[k] = pidx((uint32_t)(lane * V + k + R));
+        a_lo[k] = pidx((uint32_t)(lane * V + k - R - 1) + kRing);
+    }
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch >= 1 && ch + 1 < nch) {  // chunk ch+1 replaces chunk ch-2, which no window reaches any more
+        if (ch >= 1 && ch + 1 < nch) {  // chunk ch+1 takes the slot of chunk ch-3, which no window reaches any more
             const uint4 cur = qn;
             qn = fetch(ch + 2);
             prefix_chunk(ch + 1, cur);
             vszip_wave_fence();
         }
-        const int x0 = ch * CH + lane * V;
-        const bool inner = ch * CH - R - 1 >= 0 && ch * CH + CH - 1 + R <= w - 1;
-        if (x0 < w) {
+        const int x0 = ch * CH + lane * V - HL;  // real column of this lane's group
+        const bool inner = VIRT || (ch * CH - R - 1 >= 0 && ch * CH + CH - 1 + R <= w - 1);
+        if (x0 >= 0 && x0 < w) {
             uint32_t o[V];
             if (inner) {
+                const uint32_t adv = (uint32_t)ch << LCH;
 #pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    const uint32_t x = (uint32_t)(x0 + k);
-                    const uint32_t e = P[pidx(x + (uint32_t)R)] - P[pidx(x - (uint32_t)R - 1u)];
-                    o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
-                }
+                for (int k = 0; k < V; ++k) o[k] = scale(P[(a_hi[k] + adv) & (kRing - 1u)] - P[(a_lo[k] + adv) & (kRing - 1u)]);
             } else {
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
@@ -427,7 +485,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
                     uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
                     if (x - R - 1 < -1) e += Q(R - x - 1);
                     if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
-                    o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+                    o[k] = scale(e);
                 }
             }
             X::store(d + x0, o, min(V, w - x0));
@@ -629,7 +687,13 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
             if (aligned && !vertical) {
                 constexpr int CH = 64 * RtVec<T>::V;
                 if (radius < CH - 1 && !getenv("VSZIP_RT_HROW")) {
-                    hipLaunchKernelGGL((boxblur_rt_hring_kernel<T>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+                    // virtual (mirror-extended) rows when every row is whole lane groups and wider than its halos
+                    bool virt = !getenv("VSZIP_RT_NO_VIRT");
+                    for (int i = 0; i < n; ++i) virt = virt && prm.p[i].w % RtVec<T>::V == 0 && prm.p[i].w >= radius + 1 + RtVec<T>::V;
+                    if (virt)
+                        hipLaunchKernelGGL((boxblur_rt_hring_kernel<T, true>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
+                    else
+                        hipLaunchKernelGGL((boxblur_rt_hring_kernel<T, false>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
                 } else {
                     const size_t lds = (size_t)((maxw + CH - 1) / CH) * CH * sizeof(uint32_t);
                     if (lds > 64000)  // only the whole-row-prefix kernels keep a row in LDS; the ring kernel above serves any width
