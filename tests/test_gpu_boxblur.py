@@ -139,6 +139,19 @@ def test_ct_float_ring_batch_yuv420(dev, oracle):
         assert np.array_equal(dev.download(d).view(np.uint8), oracle.boxblur(a, 13, 1, 13, 1).view(np.uint8))
 
 
+def test_ct_ring_batch_wider_than_one_block_table(dev, oracle):
+    """192 planes of 40 x 15360 u16 need 12288 (plane, band, column tile) blocks — more than one launch's block table
+    (8192): the batch is split over launches instead of failing. Every plane against the oracle's result (one content,
+    so one oracle run) — a plane skipped or done twice with another plane's geometry would differ."""
+    src = fx.splitmix64_plane(77, (40, 15360), np.uint16)
+    want = oracle.boxblur(src, 13, 1, 13, 1)
+    s = dev.upload(src)
+    dsts = [dev.empty(40, 15360, np.uint16) for _ in range(192)]
+    dev.boxblur([s] * 192, dsts, 13, 1, 13, 1)
+    for i, d in enumerate(dsts):
+        assert np.array_equal(dev.download(d), want), i
+
+
 RT_CASES = [(23, 1, 23, 1), (40, 1, 40, 1), (4, 1, 9, 1), (9, 1, 4, 1), (5, 3, 5, 3), (5, 1, 5, 2), (5, 2, 5, 1), (0, 0, 7, 1), (7, 1, 0, 0), (6, 2, 3, 3)]
 
 

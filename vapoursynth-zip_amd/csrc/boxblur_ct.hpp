@@ -884,8 +884,7 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         }
         if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-        prm.nplanes = n;
-        int blocks = 0;
+        int blocks = 0, fit = n;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
             BBPlane &d = prm.p[i];
@@ -899,10 +898,15 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             d.nbands = bands_for(s.h, d.nperiods, target);
             d.ntx = (s.w + G::TWO - 1) / G::TWO;
             d.block0 = blocks;
-            if (blocks + d.ntx * d.nbands > kRingMaxBlocks) return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: launch table overflow (%d blocks)", blocks + d.ntx * d.nbands);
+            if (blocks + d.ntx * d.nbands > kRingMaxBlocks) {  // very wide planes: the rest of the batch goes into the next launch
+                if (i == 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: launch table overflow (%d blocks)", blocks + d.ntx * d.nbands);
+                fit = i;
+                break;
+            }
             for (int k = 0; k < d.ntx * d.nbands; ++k) prm.plane_of_block[blocks + k] = (uint8_t)i;
             blocks += d.ntx * d.nbands;
         }
+        prm.nplanes = fit;
         prm.nblocks = blocks;
         const dim3 grid(((blocks + 7) / 8) * 8);
         {
@@ -913,7 +917,7 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
                 hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
         }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
-        done += n;
+        done += fit;
     }
     return VSZIP_OK;
 }
