@@ -291,3 +291,230 @@ def test_float_no_thr_exact_minmax(vs):
     g[7, 9] = np.float32(1.987654321)
     p = _clip(vs, vs.GRAYS, [g]).vszip.PlaneMinMax().get_frame(0).props
     assert p["psmMin"] == float(g.min()) and p["psmMax"] == float(g.max())
+
+
+def _two_tone(vs, fmt, lo, hi):
+    dt = np.uint16 if fmt == vs.GRAY16 else np.float32
+    return _clip(vs, fmt, [np.concatenate([np.full((32, 64), lo, dt), np.full((32, 64), hi, dt)], axis=0)])
+
+
+def test_matches_std_planestats(vs):
+    """test_planeaverage.py:108-113 — with a never-matching exclude value this is the plain plane mean (exact: the sum of
+    16-bit samples is an integer)."""
+    g = _gray(vs, vs.GRAY16)
+    ours = _clip(vs, vs.GRAY16, [g]).vszip.PlaneAverage(exclude=[-1]).get_frame(0).props["psmAvg"]
+    assert ours == pytest.approx(float(g.astype(np.float64).mean()) / 65535.0, rel=1e-12)
+
+
+def test_exclude_exact(vs):
+    """test_planeaverage.py:116-121"""
+    src = _two_tone(vs, vs.GRAY16, 1000, 3000)
+    assert src.vszip.PlaneAverage(exclude=[1000]).get_frame(0).props["psmAvg"] == 3000 / 65535
+    assert src.vszip.PlaneAverage(exclude=[3000]).get_frame(0).props["psmAvg"] == 1000 / 65535
+    assert src.vszip.PlaneAverage(exclude=[1000, 3000]).get_frame(0).props["psmAvg"] == 0.0
+
+
+def test_exclude_float_clip(vs):
+    """test_planeaverage.py:124-126"""
+    assert _two_tone(vs, vs.GRAYS, 3.0, 1.0).vszip.PlaneAverage(exclude=[3]).get_frame(0).props["psmAvg"] == 1.0
+
+
+def test_clipb_diff_matches_std(vs):
+    """test_planeaverage.py:129-133 — psmDiff is the mean absolute difference over the peak."""
+    g = _gray(vs, vs.GRAY16)
+    b = np.ascontiguousarray(np.roll(g, 3, axis=1))
+    p = _clip(vs, vs.GRAY16, [g]).vszip.PlaneAverage(exclude=[-1], clipb=_clip(vs, vs.GRAY16, [b])).get_frame(0).props
+    assert p["psmDiff"] == pytest.approx(float(np.abs(g.astype(np.float64) - b).mean()) / 65535.0, rel=1e-12)
+
+
+def test_planes_and_prop_rename(vs):
+    """test_planeaverage.py:136-146"""
+    src = vs.blank(vs.YUV420P16, 64, 32, [6777, 32768, 0])
+    out = src.vszip.PlaneAverage(exclude=[300, 5000]).vszip.PlaneAverage(exclude=[300, 5000], prop="avg_test")
+    p = out.get_frame(0).props
+    assert p["psmAvg"] == 0.10341039139391164  # 6777 / 65535
+    assert p["avg_testAvg"] == p["psmAvg"]
+    multi = src.vszip.PlaneAverage(exclude=[-1], planes=[0, 1, 2]).get_frame(0).props["psmAvg"]
+    assert multi == [6777 / 65535, 32768 / 65535, 0.0]
+
+
+def test_planeaverage_errors(vs):
+    """test_planeaverage.py:149-175"""
+    with pytest.raises(vs.Error, match="32-bit integer"):
+        vs.blank(vs.GRAY32, 64, 32, 123456).vszip.PlaneAverage(exclude=[-1])
+    src = _clip(vs, vs.YUV420P16, _yuv(vs))
+    with pytest.raises(vs.Error, match="plane index out of range"):
+        src.vszip.PlaneAverage(exclude=[-1], planes=[3])
+    with pytest.raises(vs.Error, match="plane specified twice"):
+        src.vszip.PlaneAverage(exclude=[-1], planes=[0, 0])
+    with pytest.raises(vs.Error, match="exclude"):
+        src.vszip.PlaneAverage()
+    with pytest.raises(vs.Error, match="second clip has less frames than input clip"):
+        vs.blank(vs.GRAY8, 64, 32, 0, length=5).vszip.PlaneAverage(exclude=[-1], clipb=vs.blank(vs.GRAY8, 64, 32, 0, length=3))
+
+
+# ---- EEDI3: reference tests/test_eedi3.py, "behavioral contract" ------------------------------------------------------
+
+
+@pytest.fixture(scope="module")
+def grays(vs):
+    g = _gray(vs, vs.GRAYS)
+    h, w = (g.shape[0] // 2) * 2, (g.shape[1] // 2) * 2
+    return _clip(vs, vs.GRAYS, [g[:h, :w]]), np.ascontiguousarray(g[:h, :w])
+
+
+def _y(clip, n=0):
+    return clip.get_frame(n)[0]
+
+
+def test_eedi3_geometry(vs, grays):
+    """:89-110 — field doubles the height with dh, keeps the size without; field 2 doubles the frame count; EEDI3H
+    doubles the width."""
+    c, g = grays
+    h, w = g.shape
+    out = c.vszip.EEDI3(field=1, dh=True)
+    assert (out.width, out.height) == (w, h * 2)
+    out = c.vszip.EEDI3(field=1)
+    assert (out.width, out.height) == (w, h)
+    four = vs.source([[g]] * 4, vs.GRAYS)
+    assert four.vszip.EEDI3(field=2).num_frames == 8
+    out = c.vszip.EEDI3H(field=1, dh=True)
+    assert (out.width, out.height) == (w * 2, h)
+
+
+def test_eedi3h_matches_transpose_eedi3(vs, grays):
+    """:113-120 — EEDI3H is bit-exact to Transpose -> EEDI3 -> Transpose for every option combination."""
+    c, g = grays
+    t = _clip(vs, vs.GRAYS, [np.ascontiguousarray(g.T)])
+    for kw in (dict(field=1), dict(field=0, vcheck=0), dict(field=1, dh=True), dict(field=1, hp=True, vcheck=3), dict(field=1, nrad=3, mdis=40)):
+        assert np.array_equal(_y(c.vszip.EEDI3H(**kw)), _y(t.vszip.EEDI3(**kw)).T), kw
+
+
+def test_all_planes_processed(vs, grays):
+    """:123-126"""
+    _, g = grays
+    planes = [g, np.ascontiguousarray(np.roll(g, 7, axis=1)) - np.float32(0.5), np.ascontiguousarray(np.roll(g, 9, axis=0)) - np.float32(0.5)]
+    out = _clip(vs, vs.YUV444PS, planes).vszip.EEDI3(field=1).get_frame(0)
+    for p in range(3):
+        assert not np.array_equal(out[p], planes[p])
+
+
+def test_options_change_the_output(vs, grays):
+    """:129-143 — a larger mdis, hp (half-pel steps are implemented, unlike eedi3m) and vcheck each change the result."""
+    c, _ = grays
+    assert not np.array_equal(_y(c.vszip.EEDI3(field=1, mdis=1)), _y(c.vszip.EEDI3(field=1, mdis=40)))
+    assert not np.array_equal(_y(c.vszip.EEDI3(field=1, hp=True)), _y(c.vszip.EEDI3(field=1, hp=False)))
+    assert not np.array_equal(_y(c.vszip.EEDI3(field=1, vcheck=0)), _y(c.vszip.EEDI3(field=1, vcheck=3)))
+
+
+def test_float_output_is_finite(vs, grays):
+    """:146-152 — the 4-tap cubic overshoots the nominal range and is not clamped; nothing blows up."""
+    _, g = grays
+    planes = [g, g - np.float32(0.5), np.float32(0.5) - g]
+    out = _clip(vs, vs.YUV444PS, planes).vszip.EEDI3(field=1).get_frame(0)
+    for p in range(3):
+        assert -2.0 < float(out[p].min()) <= float(out[p].max()) < 2.0
+
+
+def test_eedi3_stride_handling(vs, grays):
+    """:155-161 — odd width (cropped by 19 columns, offset plane pointer) against the repacked clip."""
+    _, g = grays
+    cropped = np.ascontiguousarray(g[:, 19:])
+    a = _clip(vs, vs.GRAYS, [cropped], extra_stride=19 * 4 + 64, offset=19 * 4).vszip.EEDI3(field=1, mdis=10)
+    b = _clip(vs, vs.GRAYS, [cropped]).vszip.EEDI3(field=1, mdis=10)
+    assert np.array_equal(_y(a), _y(b))
+
+
+def test_sclip_and_mclip_change_the_output(vs, grays):
+    """:163-186 — a custom sclip changes the vcheck blend; an edge mask differs from an empty mask (plain cubic); a
+    float Gray mask is converted internally and runs."""
+    c, g = grays
+    blurred = c.vszip.BoxBlur(hradius=4, vradius=4)
+    assert not np.array_equal(_y(c.vszip.EEDI3(field=1, vcheck=3, sclip=blurred)), _y(c.vszip.EEDI3(field=1, vcheck=3)))
+    gy, gx = np.gradient(g.astype(np.float64))
+    edge = ((np.hypot(gx, gy) > 0.05) * 255).astype(np.uint8)
+    masked = c.vszip.EEDI3(field=1, mclip=_clip(vs, vs.GRAY8, [edge]))
+    cubic = c.vszip.EEDI3(field=1, mclip=vs.blank(vs.GRAY8, g.shape[1], g.shape[0], 0))
+    assert not np.array_equal(_y(masked), _y(cubic))
+    vs.core_standins(True)  # (a float mask goes through the host's resize; the test host has a stand-in)
+    try:
+        c.vszip.EEDI3(field=1, mclip=_clip(vs, vs.GRAYS, [(edge / 255).astype(np.float32)])).get_frame(0)
+    finally:
+        vs.core_standins(False)
+
+
+def test_eedi3_rejections(vs, grays):
+    """:191-246"""
+    c, g = grays
+    with pytest.raises(vs.Error, match="32-bit float"):
+        _clip(vs, vs.GRAY16, [_gray(vs, vs.GRAY16)]).vszip.EEDI3(field=1).get_frame(0)
+    with pytest.raises(vs.Error, match="height must be mod 2"):
+        _clip(vs, vs.GRAYS, [g[:-1]]).vszip.EEDI3(field=1).get_frame(0)
+    with pytest.raises(vs.Error, match="width must be mod 2"):
+        _clip(vs, vs.GRAYS, [g[:, :-1]]).vszip.EEDI3H(field=1).get_frame(0)
+    yuv = _clip(vs, vs.YUV444PS, [g, g - np.float32(0.5), g - np.float32(0.5)])
+    with pytest.raises(vs.Error, match="mclip must be Gray"):
+        yuv.vszip.EEDI3(field=1, mclip=yuv).get_frame(0)
+    wide = np.pad(g, ((0, 0), (0, 2)))
+    with pytest.raises(vs.Error, match="mclip's dimensions"):
+        c.vszip.EEDI3(field=1, mclip=_clip(vs, vs.GRAY8, [(wide > 0.1).astype(np.uint8)])).get_frame(0)
+    with pytest.raises(vs.Error, match="sclip"):
+        c.vszip.EEDI3(field=1, vcheck=2, sclip=_clip(vs, vs.GRAYS, [wide])).get_frame(0)
+
+
+@pytest.mark.parametrize("fmt", ["GRAYS", "YUV420PS", "YUV422PS", "YUV444PS", "RGBS"])
+def test_all_float_formats_run(vs, grays, fmt):
+    """:249-251"""
+    _, g = grays
+    fid = {"YUV422PS": vs.fmt_id(vs.YUV, vs.FLOAT, 32, 1, 0)}.get(fmt) or getattr(vs, fmt)
+    ssw, ssh = (fid >> 8) & 0xFF, fid & 0xFF
+    n = 1 if fmt == "GRAYS" else 3
+    planes = [np.ascontiguousarray(g if p == 0 else g[:: 1 << ssh, :: 1 << ssw]) for p in range(n)]
+    _clip(vs, fid, planes).vszip.EEDI3(field=1).get_frame(0)
+
+
+# ---- Limiter: reference tests/test_limiter.py -------------------------------------------------------------------------
+
+
+def _stacked(vs, fid):
+    """top half all-peak, bottom half all-floor (floor is -2 for float)"""
+    is_float = (fid >> 24) & 0xF == vs.FLOAT
+    bits = (fid >> 16) & 0xFF
+    peak, floor = (2.0, -2.0) if is_float else ((1 << bits) - 1, 0)
+    dt = np.float32 if is_float else (np.uint8 if bits <= 8 else np.uint16)
+    ssw, ssh = (fid >> 8) & 0xFF, fid & 0xFF
+    planes = []
+    for p in range(3):
+        h, w = 64 >> (ssh if p else 0), 64 >> (ssw if p else 0)
+        planes.append(np.concatenate([np.full((h // 2, w), peak, dt), np.full((h // 2, w), floor, dt)], axis=0))
+    return _clip(vs, fid, planes), planes
+
+
+def _min_max(frame):
+    return [p.min().item() for p in frame.planes], [p.max().item() for p in frame.planes]
+
+
+TV_RANGE = [(8, [16, 16, 16], [235, 240, 240]), (9, [32, 32, 32], [470, 480, 480]), (10, [64, 64, 64], [940, 960, 960]),
+            (12, [256, 256, 256], [3760, 3840, 3840]), (14, [1024, 1024, 1024], [15040, 15360, 15360]), (16, [4096, 4096, 4096], [60160, 61440, 61440]),
+            (32, [0.0, -0.5, -0.5], [1.0, 0.5, 0.5])]
+
+
+@pytest.mark.parametrize(("bits", "lo", "hi"), TV_RANGE)
+def test_tv_range(vs, bits, lo, hi):
+    """:112-115 — YUV420P8/9/10/12/14/16 and YUV420PS"""
+    fid = vs.fmt_id(vs.YUV, vs.FLOAT if bits == 32 else vs.INTEGER, bits, 1, 1)
+    src, _ = _stacked(vs, fid)
+    assert _min_max(src.vszip.Limiter(tv_range=True).get_frame(0)) == (lo, hi)
+    if bits <= 10:  # :133-137 — the compile-time tv_range path and the runtime min / max path agree
+        a, b = src.vszip.Limiter(tv_range=True).get_frame(0), src.vszip.Limiter(min=lo, max=hi).get_frame(0)
+        assert all(np.array_equal(a[p], b[p]) for p in range(3))
+
+
+def test_limiter_defaults(vs):
+    """:118-130 — mask clamps float chroma to 0..1; float default clamps to the full range; integer default is a no-op."""
+    src, _ = _stacked(vs, vs.YUV420PS)
+    assert _min_max(src.vszip.Limiter(tv_range=True, mask=True).get_frame(0)) == ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    assert _min_max(src.vszip.Limiter().get_frame(0)) == ([0.0, -0.5, -0.5], [1.0, 0.5, 0.5])
+    src16, planes = _stacked(vs, vs.YUV420P16)
+    out = src16.vszip.Limiter().get_frame(0)
+    assert all(np.array_equal(out[p], planes[p]) for p in range(3))
