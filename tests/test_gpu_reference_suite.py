@@ -518,3 +518,40 @@ def test_limiter_defaults(vs):
     src16, planes = _stacked(vs, vs.YUV420P16)
     out = src16.vszip.Limiter().get_frame(0)
     assert all(np.array_equal(out[p], planes[p]) for p in range(3))
+
+
+# ---- AdaptiveBinarize: reference tests/test_adaptive_binarize.py ------------------------------------------------------
+
+
+def test_output_is_binary_and_full_range(vs):
+    """:64-68"""
+    g = _gray(vs, vs.GRAY8)
+    src = _clip(vs, vs.GRAY8, [g])
+    f = src.vszip.AdaptiveBinarize(src.vszip.BoxBlur(hradius=5, vradius=5)).get_frame(0)
+    assert set(np.unique(f[0]).tolist()) <= {0, 255} and len(np.unique(f[0])) == 2
+    assert f.props["_ColorRange"] == 0  # RANGE_FULL
+
+
+@pytest.mark.parametrize("c", [0, 3, 10])
+def test_threshold_rule_exact(vs, c):
+    """:71-82 — out = 255 where src <= clip2 - c, else 0 (OpenCV ADAPTIVE_THRESH_MEAN_C with THRESH_BINARY_INV), on a
+    0..255 ramp against a constant 128."""
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (2, 1))
+    out = _clip(vs, vs.GRAY8, [ramp]).vszip.AdaptiveBinarize(vs.blank(vs.GRAY8, 256, 2, 128), c=c).get_frame(0)[0]
+    assert out[0].tolist() == [255 if x <= 128 - c else 0 for x in range(256)]
+
+
+def test_higher_c_is_stricter(vs):
+    """:85-90"""
+    src = _clip(vs, vs.GRAY8, [_gray(vs, vs.GRAY8)])
+    blur = src.vszip.BoxBlur(hradius=5, vradius=5)
+    a3 = src.vszip.AdaptiveBinarize(blur, c=3).get_frame(0)[0].mean()
+    a10 = src.vszip.AdaptiveBinarize(blur, c=10).get_frame(0)[0].mean()
+    assert a10 < a3
+
+
+def test_non_8bit_error(vs):
+    """:93-96"""
+    src16 = _clip(vs, vs.GRAY16, [_gray(vs, vs.GRAY16)])
+    with pytest.raises(vs.Error, match="only 8 bit int format supported"):
+        src16.vszip.AdaptiveBinarize(src16)
