@@ -713,6 +713,7 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                 }
                 int band = std::max(64, 4 * radius);
                 while (band < maxh && colgroups * ((maxh + band - 1) / band) > 16384) band *= 2;
+                if (const char *e = getenv("VSZIP_RT_VBAND")) band = std::max(8, atoi(e));  // development sweep knob
                 vp.band = band;
                 int vb = 0;
                 for (int i = 0; i < n; ++i) {
