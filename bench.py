@@ -345,7 +345,12 @@ def eedi3_leg(dev, timed, no_cpu, frames=16):
 
     dt, _, _, _ = timed.run(step, 5, 1)
     lines = sum(s[0] for s in yuv420_shapes(W1080, H1080))  # one interpolated line per source line (dh)
-    res = {"value": frames * 5 / dt, "unit": "frames/s", "interpolated_lines_per_s": frames * 5 * lines / dt,
+    fb = 3 * sum(p.nbytes for p in base)  # one read of the frame, one write of the double-height frame
+    gbs = fb * frames * 5 / dt / 1e9
+    res = {"value": frames * 5 / dt, "unit": "frames/s", "interpolated_lines_per_s": frames * 5 * lines / dt, "frames_per_call": frames,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "note": "not an HBM-bound filter: 41 directions x a 5-tap window per pixel and a dynamic programme along every line "
+                                "(eedi3_line_kernel: VALU about 80 % busy, DESIGN.md 3.5); the fraction is reported for completeness"},
            "workload": "vszip.EEDI3 field=1 dh=1 (defaults: mdis 20, nrad 2, vcheck 2), 1920x1080 YUV420PS -> 1920x2160, HBM-resident"}
     if not no_cpu:
         from oracle import oracle as orc
@@ -918,7 +923,11 @@ def main() -> int:
                 del keep
             st, keep = setup_ssimulacra2(dev, W4K, H4K, 16)
             dt3, kms, _, _ = timed.run(st, 5, 1)
+            ss_gbs = 2 * 3 * W4K * H4K * 4 * 16 * 5 / dt3 / 1e9  # algorithmic bytes: the two RGBS input frames
             others["ssimulacra2_4k"] = {"value": 16 * 5 / dt3, "unit": "pairs/s", "ms_per_pair": dt3 * 1e3 / 80, "pairs_per_call": 16,
+                                        "roofline": {"bound": "hbm", "achieved": ss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ss_gbs / HBM_PEAK_GBS, "traffic": None,
+                                                     "note": "whole pipeline on the two input frames; ssim_maps_kernel (65 % of a pair) is issue bound: "
+                                                             "about 230 instructions per plane-pixel, a quarter of them f64 (DESIGN.md 3.4)"},
                                         "workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS (linear), HBM-resident; includes the scalar D2H + sync"}
             if not a.no_cpu:
                 others["ssimulacra2_4k"]["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K, 6.0)
