@@ -256,51 +256,48 @@ class Arena:
             pass
 
 
-def setup_boxblur(dev, rank, frames, radius, tries=None):
-    """The headline batch: `frames` 4K YUV420P16 frames, sources in one arena, destinations in another.
+def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=None):
+    """`host_planes` (a list of 2-D arrays, one per plane of the batch) in a source arena, a destination arena of the
+    same geometry, and the BoxBlur launch `args` on them — with the PLACEMENT of both arenas probed.
 
-    WHERE an arena lies in VRAM decides how fast the ring kernel runs on it: the identical launch on identical layouts
+    WHERE an arena lies in VRAM decides how fast the ring kernels run on it: the identical launch on identical layouts
     takes 565-595 us on some allocations and 640-680 us on most (profiles/r02_notes.md, tools/slab_ballast.py: walking
-    through VRAM in 1.6 GiB arenas, the fast ones are those that straddle a 32 GiB step of the address space — two or
-    three in every 32 GiB; streaming kernels do not care, the ring kernel's hundreds of lock-step write streams do).
-    Neither the virtual layout inside the arena, nor a physically contiguous allocation, nor the pairing of source and
-    destination controls it, so the placement is probed before the timed region: `tries` candidate arenas are
-    allocated one after another (all held, so each lies further into VRAM), the launch is timed with each as the
-    destination, the fastest is kept; the remaining candidates are then tried as the source arena (a smaller effect);
-    everything else is freed. Every candidate's time is reported in config.placement.
-    VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as a caller who does not care gets)."""
+    through VRAM in 1.6 GiB arenas, the fast ones are those that straddle a 32 GiB step of the address space; streaming
+    kernels do not care, the ring kernel's hundreds of lock-step write streams do). Neither the virtual layout inside
+    the arena, nor a physically contiguous allocation, nor the pairing of source and destination controls it, so the
+    placement is probed before any timed region: `tries` candidate arenas are allocated one after another (all held, so
+    each lies further into VRAM), the launch is timed with each as the destination, the fastest is kept; the remaining
+    candidates are then tried as the source arena (a smaller effect); everything else is freed. Returns (step, keep,
+    info): info lists every candidate's time. VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as
+    a caller who does not care gets)."""
     if tries is None:
-        tries = max(1, int(os.environ.get("VSZIP_BENCH_PLACEMENT_TRIES", "40")))
-    base = make_frame(rank, W4K, H4K)
-    shapes = [p.shape for p in base] * frames
-
-    # the probe launches use the neighbouring radius: the same access shape, but another instance of the kernel template,
-    # so that the rocprofv3 statistics of the measured kernel (boxblur_ct_ring_kernel<u16, 13>) hold the timed launches only
-    probe_r = radius - 1 if radius > 1 else radius + 1
+        tries = 40
+    if os.environ.get("VSZIP_BENCH_PLACEMENT_TRIES"):
+        tries = max(1, min(tries, int(os.environ["VSZIP_BENCH_PLACEMENT_TRIES"])))
+    shapes = [p.shape for p in host_planes]
+    probe_args = probe_args or args
+    isz = np.dtype(dtype).itemsize
 
     def launch_us(src, dst, n=10):
         table = dev.plane_table(src.planes, dst.planes)
         for _ in range(2):
-            dev.boxblur_table(np.uint16, table, probe_r, 1, probe_r, 1)
+            dev.boxblur_table(dtype, table, *probe_args)
         dev.sync()
         t0 = time.perf_counter()
         for _ in range(n):
-            dev.boxblur_table(np.uint16, table, probe_r, 1, probe_r, 1)
+            dev.boxblur_table(dtype, table, *probe_args)
         dev.sync()
         return (time.perf_counter() - t0) / n * 1e6
 
-    src = Arena(dev, shapes, np.uint16, 1000 * rank + 1)
-    for f in range(frames):
-        for i, plane in enumerate(base):
-            # distinct content per frame: noise rolled by the frame index
-            a = np.ascontiguousarray(np.roll(plane, f * 17 + 1, axis=1))
-            d = src.planes[f * 3 + i]
-            dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * a.itemsize, a.ctypes.data, a.strides[0], a.shape[1] * a.itemsize, a.shape[0]))
+    src = Arena(dev, shapes, dtype, seed + 1)
+    for a, d in zip(host_planes, src.planes):
+        a = np.ascontiguousarray(a)
+        dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * isz, a.ctypes.data, a.strides[0], a.shape[1] * isz, a.shape[0]))
     dev.sync()
     cands = []
     for k in range(tries):
         try:
-            cands.append(Arena(dev, shapes, np.uint16, 1000 * rank + 100 + k))
+            cands.append(Arena(dev, shapes, dtype, seed + 100 + k))
         except Exception:  # VRAM exhausted (a smaller or shared device): probe what fits
             if not cands:
                 raise
@@ -311,7 +308,7 @@ def setup_boxblur(dev, rank, frames, radius, tries=None):
     src_us = [min(dst_us)] if tries > 1 else [None]
     for cand in cands:  # the other candidates as the source arena (a device-to-device copy of the first one)
         for a_, b_ in zip(src.planes, cand.planes):
-            dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * 2, a_.ptr, a_.stride * 2, a_.w * 2, a_.h))
+            dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
         dev.sync()
         t = launch_us(cand, dst)
         src_us.append(t)
@@ -322,11 +319,22 @@ def setup_boxblur(dev, rank, frames, radius, tries=None):
             cand.free()
     table = dev.plane_table(src.planes, dst.planes)
     r1 = lambda v: None if v is None else round(v, 1)
-    info = {"tries": tries, "destination_candidates_us": [r1(v) for v in dst_us], "source_candidates_us": [r1(v) for v in src_us],
-            "probe_radius": probe_r,
-            "note": "launch time of the same batch (at the neighbouring radius) on candidate arenas, in allocation order (10 launches each, wall clock); the fastest placement "
-                    "is kept and the rest freed before the timed region, see setup_boxblur; tries = 1: first allocation"}
-    return (lambda: dev.boxblur_table(np.uint16, table, radius, 1, radius, 1)), (src, dst, info)
+    info = {"tries": tries, "destination_candidates_us": [r1(v) for v in dst_us], "source_candidates_us": [r1(v) for v in src_us], "probe_args": list(probe_args),
+            "note": "launch time of the batch on candidate arenas, in allocation order (10 launches each, wall clock); the fastest placement "
+                    "is kept and the rest freed before the timed region, see placed_batch; tries = 1: first allocation"}
+    return (lambda: dev.boxblur_table(dtype, table, *args)), (src, dst, info), info
+
+
+def setup_boxblur(dev, rank, frames, radius, tries=None):
+    """The headline batch: `frames` 4K YUV420P16 frames (distinct content per frame: noise rolled by the frame index),
+    placement probed (placed_batch). The probe launches use the neighbouring radius: the same access shape, but another
+    instance of the kernel template, so that the rocprofv3 statistics of the measured kernel
+    (boxblur_ct_ring_kernel<u16, 13>) hold the timed launches only."""
+    base = make_frame(rank, W4K, H4K)
+    planes = [np.roll(plane, f * 17 + 1, axis=1) for f in range(frames) for plane in base]
+    probe_r = radius - 1 if radius > 1 else radius + 1
+    step, keep, _ = placed_batch(dev, planes, np.uint16, (radius, 1, radius, 1), 1000 * rank, tries, (probe_r, 1, probe_r, 1))
+    return step, keep
 
 
 def setup_bilateral(dev, w, h, frames):
@@ -621,18 +629,26 @@ def boxblur_other_paths_leg(dev, timed, frames_in=8):
                                   ("boxblur_ct_u8_r13_4k", base8, (13, 1, 13, 1), np.uint8)):
         srcs, dsts = [], []
         frames = 64 if dt_ == np.uint8 else frames_in
-        for f in range(frames):
-            for p in base:
-                srcs.append(dev.upload(np.roll(p, f + 1, axis=1)))
-                dsts.append(dev.empty(p.shape[0], p.shape[1], p.dtype))
-        table = dev.plane_table(srcs, dsts)
-        dt, kms, _, _ = timed.run(lambda: dev.boxblur_table(dt_, table, *args), 5, 1)
+        placement = None
+        if name.startswith("boxblur_ct_"):  # the ring kernels: placement probed like the headline's
+            step, keep_, placement = placed_batch(dev, [np.roll(p, f + 1, axis=1) for f in range(frames) for p in base], dt_, args, 8000, 24)
+        else:
+            for f in range(frames):
+                for p in base:
+                    srcs.append(dev.upload(np.roll(p, f + 1, axis=1)))
+                    dsts.append(dev.empty(p.shape[0], p.shape[1], p.dtype))
+            table = dev.plane_table(srcs, dsts)
+            step = lambda: dev.boxblur_table(dt_, table, *args)
+        dt, kms, _, _ = timed.run(step, 5, 1)
         fb = 2 * sum(p.nbytes for p in base) * frames
         gbs = fb * 5 / (kms * 1e-3) / 1e9
         out[name] = {"value": frames * 5 / dt, "unit": "frames/s",
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                   "note": "algorithmic bytes = one read + one write of the frame, whatever the number of passes"},
                      "workload": f"vszip.BoxBlur hradius={args[0]} hpasses={args[1]} vradius={args[2]} vpasses={args[3]}, 3840x2160 {fmt_names[np.dtype(dt_).name]}, {frames} frames per call, HBM-resident"}
+        if placement:
+            out[name]["placement"] = placement
+            del keep_
         del srcs, dsts
     return out
 
@@ -730,19 +746,17 @@ def plugin_legs():
 def boxblur_1080p_leg(dev, timed, no_cpu, frames=64):
     """BASELINE configs[0] — the reference README's own benchmark (README.md:34-44: BlankClip 1920x1080
     YUV420P16, BoxBlur hradius=vradius=13, 1046 fps on an unstated CPU) — on HBM-resident frames, 64 per call."""
-    srcs, dsts = [], []
-    for f in range(frames):
-        for sh in yuv420_shapes(W1080, H1080):
-            srcs.append(dev.upload(np.zeros(sh, np.uint16)))
-            dsts.append(dev.empty(sh[0], sh[1], np.uint16))
-    table = dev.plane_table(srcs, dsts)
-    dt, _, dom_ms, launches = timed.run(lambda: dev.boxblur_table(np.uint16, table, RADIUS, 1, RADIUS, 1), 200, 5)
+    planes = [np.zeros(sh, np.uint16) for _ in range(frames) for sh in yuv420_shapes(W1080, H1080)]
+    step, keep, placement = placed_batch(dev, planes, np.uint16, (RADIUS, 1, RADIUS, 1), 7000, 24)
+    dt, _, dom_ms, launches = timed.run(step, 200, 5)
     fb = 2 * sum(2 * sh[0] * sh[1] for sh in yuv420_shapes(W1080, H1080)) * frames
     gbs = fb * launches / (dom_ms * 1e-3) / 1e9
     res = {"value": frames * 200 / dt, "unit": "frames/s", "readme_reference_fps": 1046.11,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "boxblur_ct_ring_kernel<u16,13>", "avg_launch_us": dom_ms * 1e3 / launches},
+           "placement": placement,
            "workload": f"vszip.BoxBlur hradius=vradius=13 on 1920x1080 YUV420P16 BlankClip (README bench), {frames} frames per call, HBM-resident"}
+    del keep
     if not no_cpu:
         res["cpu_baseline"] = cpu_boxblur(4.0, W1080, H1080, blank=True)
     return res
