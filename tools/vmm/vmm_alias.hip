@@ -35,14 +35,16 @@ EXP int vmm_create(int device, size_t bytes, void **handle) {
     return 0;
 }
 
-// a new virtual range (aligned as asked, optionally at a requested address) backed by that physical memory
-EXP int vmm_map(int device, void *handle, size_t bytes, size_t alignment, void *want, void **va) {
+// a new virtual range backed by that physical memory; `skew` bytes (a multiple of the granularity) shift the mapping
+// inside a larger reservation, so that virtual and physical addresses disagree modulo 2 MiB (small PTE fragments only)
+EXP int vmm_map(int device, void *handle, size_t bytes, size_t alignment, size_t skew, void **va) {
     void *p = nullptr;
-    hipError_t e = hipMemAddressReserve(&p, bytes, alignment, want, 0);
+    hipError_t e = hipMemAddressReserve(&p, bytes + skew, alignment, nullptr, 0);
     if (e != hipSuccess) {
         fprintf(stderr, "hipMemAddressReserve: %s\n", hipGetErrorString(e));
         return (int)e;
     }
+    p = (char *)p + skew;
     e = hipMemMap(p, bytes, 0, (hipMemGenericAllocationHandle_t)handle, 0);
     if (e != hipSuccess) {
         fprintf(stderr, "hipMemMap: %s\n", hipGetErrorString(e));
