@@ -261,17 +261,17 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
     same geometry, and the BoxBlur launch `args` on them — with the PLACEMENT of both arenas probed.
 
     WHERE an arena lies in VRAM decides how fast the ring kernels run on it: the identical launch on identical layouts
-    takes 565-595 us on some allocations and 640-680 us on most (profiles/r02_notes.md, tools/slab_ballast.py: walking
-    through VRAM in 1.6 GiB arenas, the fast ones are those that straddle a 32 GiB step of the address space; streaming
-    kernels do not care, the ring kernel's hundreds of lock-step write streams do). Neither the virtual layout inside
-    the arena, nor a physically contiguous allocation, nor the pairing of source and destination controls it, so the
+    takes 565-595 us on some allocations and 640-680 us on most (profiles/r02_notes.md, tools/slab_*.py, vmm_alias.py: it
+    follows the PHYSICAL memory behind the planes — every virtual alias of one physical arena gives the same time, page
+    table fragments do not matter; streaming kernels do not care, the ring kernels' hundreds of concurrent row streams
+    do; devices differ in how many of their placements are fast). Nothing user space can see or request controls it, so the
     placement is probed before any timed region: `tries` candidate arenas are allocated one after another (all held, so
-    each lies further into VRAM), the launch is timed with each as the destination, the fastest is kept; the remaining
-    candidates are then tried as the source arena (a smaller effect); everything else is freed. Returns (step, keep,
-    info): info lists every candidate's time. VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as
+    each lies further into VRAM), the launch is timed with each as the destination, then with each as the source of the
+    best destination, then once more with each as the destination of the best source; the fastest pair is kept,
+    everything else is freed. Returns (step, keep, info): info lists every candidate's time. VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as
     a caller who does not care gets)."""
     if tries is None:
-        tries = 40
+        tries = 64
     if os.environ.get("VSZIP_BENCH_PLACEMENT_TRIES"):
         tries = max(1, min(tries, int(os.environ["VSZIP_BENCH_PLACEMENT_TRIES"])))
     shapes = [p.shape for p in host_planes]
@@ -303,25 +303,44 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
                 raise
             break
     tries = len(cands)
-    dst_us = [launch_us(src, c) for c in cands] if tries > 1 else [None]
-    dst = cands.pop(int(np.argmin(dst_us)) if tries > 1 else 0)
-    src_us = [min(dst_us)] if tries > 1 else [None]
-    for cand in cands:  # the other candidates as the source arena (a device-to-device copy of the first one)
-        for a_, b_ in zip(src.planes, cand.planes):
-            dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
-        dev.sync()
-        t = launch_us(cand, dst)
-        src_us.append(t)
-        if t < min(src_us[:-1]):
+    dst_us, src_us, dst2_us = [None], [None], []
+    dst = cands[0]
+    if tries > 1:
+        # 1: every candidate as the destination of the first source arena
+        dst_us = [launch_us(src, c) for c in cands]
+        dst = cands[int(np.argmin(dst_us))]
+        # 2: every other candidate as the source (a device-to-device copy of the first one) of that destination
+        src_us, best_src = [min(dst_us)], src
+        for cand in cands:
+            if cand is dst:
+                continue
+            for a_, b_ in zip(src.planes, cand.planes):
+                dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
+            dev.sync()
+            src_us.append(launch_us(cand, dst))
+            if src_us[-1] < min(src_us[:-1]):
+                best_src = cand
+        # 3: the destination once more, against the chosen source (source and destination effects are not independent)
+        best = min(src_us)
+        for cand in cands:
+            if cand is dst or cand is best_src:
+                continue
+            dst2_us.append(launch_us(best_src, cand))
+            if dst2_us[-1] < best:
+                best, dst = dst2_us[-1], cand
+        if best_src is not src:
             src.free()
-            src = cand
-        else:
+            src = best_src
+    for cand in cands:
+        if cand is not dst and cand is not src:
             cand.free()
     table = dev.plane_table(src.planes, dst.planes)
     r1 = lambda v: None if v is None else round(v, 1)
-    info = {"tries": tries, "destination_candidates_us": [r1(v) for v in dst_us], "source_candidates_us": [r1(v) for v in src_us], "probe_args": list(probe_args),
-            "note": "launch time of the batch on candidate arenas, in allocation order (10 launches each, wall clock); the fastest placement "
-                    "is kept and the rest freed before the timed region, see placed_batch; tries = 1: first allocation"}
+    info = {"tries": tries, "destination_candidates_us": [r1(v) for v in dst_us], "source_candidates_us": [r1(v) for v in src_us],
+            "destination_candidates_second_pass_us": [r1(v) for v in dst2_us], "probe_args": list(probe_args),
+            "note": "launch time of the batch on candidate arenas, in allocation order (10 launches each, wall clock): every candidate as the destination, "
+                    "then as the source of the best destination, then as the destination of the best source; the fastest pair is kept and the rest "
+                    "freed before the timed region, see placed_batch; tries = 1: first allocation"}
     return (lambda: dev.boxblur_table(dtype, table, *args)), (src, dst, info), info
 
 
