@@ -26,13 +26,21 @@ def short(name: str) -> str:
 def main():
     src, dst = Path(sys.argv[1]), Path(sys.argv[2])
     dst.parent.mkdir(parents=True, exist_ok=True)
-    stats = glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv"))
+    import os
+
+    # gpurun MERGES into gpurun_out/: an earlier call's files (other process ids) may still lie beside the new ones
+    stats = sorted(glob.glob(str(src / "trace" / "*" / "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     rows = []
     if stats:
         shutil.copy(stats[0], f"{dst}_kernel_stats.csv")
         rows = list(csv.DictReader(open(stats[0])))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    newest = {}
     for f in glob.glob(str(src / "pmc_*" / "*" / "*counter_collection.csv")):
+        d = os.path.dirname(f)
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     pmc = {}
