@@ -223,26 +223,43 @@ class Timed:
 
 
 class Arena:
-    """One device allocation holding a batch of planes: plane k starts on a 2 MiB boundary plus a pseudo-random multiple
+    """A batch of planes inside one device allocation: plane k starts on a 2 MiB boundary plus a pseudo-random multiple
     of 256 B below 1 MiB (planes that start on identical offsets inside their pages collide more often)."""
 
-    def __init__(self, dev, shapes, dtype, seed):
+    def __init__(self, dev, shapes, dtype, seed, ptr=None):
         import ctypes as C
-
-        from vszip_amd.capi import DevPlane
 
         rng = np.random.default_rng(seed)
         isz = np.dtype(dtype).itemsize
-        offs, total = [], 0
+        self.offs, total = [], 0
         for h, w in shapes:
             total = (total + (2 << 20) - 1) // (2 << 20) * (2 << 20)
             o = total + int(rng.integers(0, 4096)) * 256
-            offs.append(o)
+            self.offs.append(o)
             total = o + h * w * isz
-        p = C.c_void_p()
-        dev.check(dev.lib.vszip_dev_alloc(dev.ctx, total + 256, C.byref(p)))
-        self.dev, self.ptr, self.nbytes = dev, p.value, total
-        self.planes = [DevPlane(dev, p.value + o, w, h, w, dtype, own=False) for o, (h, w) in zip(offs, shapes)]
+        self.dev, self.shapes, self.dtype, self.nbytes, self.ptr, self.planes = dev, shapes, dtype, total + 256, 0, []
+        if ptr is None:
+            p = C.c_void_p()
+            dev.check(dev.lib.vszip_dev_alloc(dev.ctx, self.nbytes, C.byref(p)))
+            ptr = p.value
+        self.bind(ptr)
+
+    def bind(self, ptr):
+        from vszip_amd.capi import DevPlane
+
+        self.ptr = ptr
+        self.planes = [DevPlane(self.dev, ptr + o, w, h, w, self.dtype, own=False) for o, (h, w) in zip(self.offs, self.shapes)]
+        return self
+
+    def view(self, ptr):
+        """the same layout on another allocation (not owned)"""
+        v = Arena.__new__(Arena)
+        v.dev, v.shapes, v.dtype, v.nbytes, v.offs = self.dev, self.shapes, self.dtype, self.nbytes, self.offs
+        v.ptr = 0  # a view never frees
+        from vszip_amd.capi import DevPlane
+
+        v.planes = [DevPlane(self.dev, ptr + o, w, h, w, self.dtype, own=False) for o, (h, w) in zip(self.offs, self.shapes)]
+        return v
 
     def free(self):
         if self.ptr:
@@ -258,18 +275,19 @@ class Arena:
 
 def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=None):
     """`host_planes` (a list of 2-D arrays, one per plane of the batch) in a source arena, a destination arena of the
-    same geometry, and the BoxBlur launch `args` on them — with the PLACEMENT of both arenas probed.
+    same geometry, and the BoxBlur launch `args` on them — with the PLACEMENT of both arenas probed
+    (vszip_dev_alloc_probed, include/vszip_hip.h).
 
     WHERE an arena lies in VRAM decides how fast the ring kernels run on it: the identical launch on identical layouts
     takes 565-595 us on some allocations and 640-680 us on most (profiles/r02_notes.md, tools/slab_*.py, vmm_alias.py: it
     follows the PHYSICAL memory behind the planes — every virtual alias of one physical arena gives the same time, page
     table fragments do not matter; streaming kernels do not care, the ring kernels' hundreds of concurrent row streams
-    do; devices differ in how many of their placements are fast). Nothing user space can see or request controls it, so the
-    placement is probed before any timed region: `tries` candidate arenas are allocated one after another (all held, so
-    each lies further into VRAM), the launch is timed with each as the destination, then with each as the source of the
-    best destination, then once more with each as the destination of the best source; the fastest pair is kept,
-    everything else is freed. Returns (step, keep, info): info lists every candidate's time. VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as
-    a caller who does not care gets)."""
+    do; devices differ in how many of their placements are fast). Nothing user space can see or request controls it, so
+    the placement is probed before any timed region, in three walks of `tries` candidate allocations each (all
+    candidates of a walk are held until it ends, so each lies elsewhere): the destination arena against the first
+    source arena, then the source arena against that destination, then the destination once more against the chosen
+    source (the two effects are not independent). Returns (step, keep, info): info lists every candidate's time.
+    VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as a caller who does not care gets)."""
     if tries is None:
         tries = 64
     if os.environ.get("VSZIP_BENCH_PLACEMENT_TRIES"):
@@ -289,58 +307,51 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
         dev.sync()
         return (time.perf_counter() - t0) / n * 1e6
 
+    def copy_planes(a_arena, b_arena):
+        for a_, b_ in zip(a_arena.planes, b_arena.planes):
+            dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
+        dev.sync()
+
     src = Arena(dev, shapes, dtype, seed + 1)
     for a, d in zip(host_planes, src.planes):
         a = np.ascontiguousarray(a)
         dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * isz, a.ctypes.data, a.strides[0], a.shape[1] * isz, a.shape[0]))
     dev.sync()
-    cands = []
-    for k in range(tries):
-        try:
-            cands.append(Arena(dev, shapes, dtype, seed + 100 + k))
-        except Exception:  # VRAM exhausted (a smaller or shared device): probe what fits
-            if not cands:
-                raise
-            break
-    tries = len(cands)
-    dst_us, src_us, dst2_us = [None], [None], []
-    dst = cands[0]
-    if tries > 1:
-        # 1: every candidate as the destination of the first source arena
-        dst_us = [launch_us(src, c) for c in cands]
-        dst = cands[int(np.argmin(dst_us))]
-        # 2: every other candidate as the source (a device-to-device copy of the first one) of that destination
-        src_us, best_src = [min(dst_us)], src
-        for cand in cands:
-            if cand is dst:
-                continue
-            for a_, b_ in zip(src.planes, cand.planes):
-                dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
-            dev.sync()
-            src_us.append(launch_us(cand, dst))
-            if src_us[-1] < min(src_us[:-1]):
-                best_src = cand
-        # 3: the destination once more, against the chosen source (source and destination effects are not independent)
-        best = min(src_us)
-        for cand in cands:
-            if cand is dst or cand is best_src:
-                continue
-            dst2_us.append(launch_us(best_src, cand))
-            if dst2_us[-1] < best:
-                best, dst = dst2_us[-1], cand
-        if best_src is not src:
+    lay = Arena(dev, shapes, dtype, seed + 2, ptr=0)  # the destination layout (bound to an allocation below)
+    if tries <= 1:
+        dst, dst_us, src_us, dst2_us = Arena(dev, shapes, dtype, seed + 2), [None], [None], []
+    else:
+        # 1: the destination arena, every candidate against the first source arena
+        ptr, best, dst_us = dev.alloc_probed(lay.nbytes, tries, lambda p: launch_us(src, lay.view(p)))
+        dst = lay.bind(ptr)
+        # 2: the source arena (a device-to-device copy of the first one) against that destination
+        def as_source(p):
+            cand = src.view(p)
+            copy_planes(src, cand)
+            return launch_us(cand, dst)
+
+        ptr, best_s, src_us = dev.alloc_probed(src.nbytes, tries, as_source)
+        src_us = [best] + src_us
+        if best_s < best:
             src.free()
-            src = best_src
-    for cand in cands:
-        if cand is not dst and cand is not src:
-            cand.free()
+            src.bind(ptr)
+            best = best_s
+        else:
+            dev.lib.vszip_dev_free(dev.ctx, ptr)
+        # 3: the destination once more, against the chosen source
+        ptr, best_d, dst2_us = dev.alloc_probed(lay.nbytes, tries, lambda p: launch_us(src, lay.view(p)))
+        if best_d < best:
+            dst.free()
+            dst.bind(ptr)
+        else:
+            dev.lib.vszip_dev_free(dev.ctx, ptr)
     table = dev.plane_table(src.planes, dst.planes)
     r1 = lambda v: None if v is None else round(v, 1)
     info = {"tries": tries, "destination_candidates_us": [r1(v) for v in dst_us], "source_candidates_us": [r1(v) for v in src_us],
             "destination_candidates_second_pass_us": [r1(v) for v in dst2_us], "probe_args": list(probe_args),
-            "note": "launch time of the batch on candidate arenas, in allocation order (10 launches each, wall clock): every candidate as the destination, "
-                    "then as the source of the best destination, then as the destination of the best source; the fastest pair is kept and the rest "
-                    "freed before the timed region, see placed_batch; tries = 1: first allocation"}
+            "note": "vszip_dev_alloc_probed: launch time of the batch on candidate allocations, in allocation order (10 launches each, wall clock): the destination "
+                    "arena, then the source arena against the best destination, then the destination again against the best source; the fastest pair is kept "
+                    "and the rest freed before the timed region, see placed_batch; tries = 1: first allocation"}
     return (lambda: dev.boxblur_table(dtype, table, *args)), (src, dst, info), info
 
 

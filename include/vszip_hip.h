@@ -64,6 +64,15 @@ int vszip_abi_version(void);
 /* ---- device memory + staging (replaces nothing: the reference is host-only) */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
 int vszip_dev_free(vszip_ctx *ctx, void *dptr);
+/* Device memory whose PLACEMENT in VRAM is chosen by measurement. The BoxBlur ring kernels (hundreds of concurrent row
+ * streams) run 15-20 % faster or slower depending on which physical memory holds a resident batch — nothing user space
+ * can see or request predicts it (profiles/r02_notes.md). Up to `tries` allocations of `bytes` are made
+ * one after another and all held meanwhile (so each lies elsewhere); `probe(user, ptr)` is called once for each and
+ * returns a cost (e.g. the seconds the caller's launch took with its planes in `ptr`); the allocation with the lowest
+ * cost is returned in *dptr (free it with vszip_dev_free), its cost in *best_cost (may be NULL), the others are freed.
+ * Stops early, with what it has, when the device runs out of memory. tries <= 1 or probe == NULL: plain vszip_dev_alloc. */
+typedef double (*vszip_placement_probe)(void *user, void *dptr);
+int vszip_dev_alloc_probed(vszip_ctx *ctx, size_t bytes, int tries, vszip_placement_probe probe, void *user, void **dptr, double *best_cost);
 int vszip_dev_memset(vszip_ctx *ctx, void *dptr, int value, size_t bytes);
 int vszip_host_alloc_pinned(vszip_ctx *ctx, size_t bytes, void **hptr);
 int vszip_host_free_pinned(vszip_ctx *ctx, void *hptr);

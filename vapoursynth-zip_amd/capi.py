@@ -79,6 +79,7 @@ SYMBOLS = {
     "vszip_last_error": (C.c_char_p, [_vp]),
     "vszip_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_dev_free": (_i, [_vp, _vp]),
+    "vszip_dev_alloc_probed": (_i, [_vp, _sz, _i, C.c_void_p, _vp, C.POINTER(_vp), C.POINTER(C.c_double)]),
     "vszip_dev_memset": (_i, [_vp, _vp, _i, _sz]),
     "vszip_host_alloc_pinned": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_host_free_pinned": (_i, [_vp, _vp]),
@@ -228,6 +229,21 @@ class Device:
         p = C.c_void_p()
         self.check(self.lib.vszip_dev_alloc(self.ctx, stride * h * dtype.itemsize + 256, C.byref(p)))
         return DevPlane(self, p.value, w, h, stride, dtype)
+
+    def alloc_probed(self, nbytes: int, tries: int, probe) -> tuple:
+        """vszip_dev_alloc_probed: `probe(ptr) -> cost` is called for each of up to `tries` candidate allocations;
+        -> (pointer of the cheapest, its cost, the costs of all candidates in allocation order)."""
+        costs = []
+
+        def cb(_user, ptr):
+            c = float(probe(ptr))
+            costs.append(c)
+            return c
+
+        fn = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p)(cb)
+        p, best = C.c_void_p(), C.c_double()
+        self.check(self.lib.vszip_dev_alloc_probed(self.ctx, nbytes, tries, C.cast(fn, C.c_void_p), None, C.byref(p), C.byref(best)))
+        return p.value, best.value, costs
 
     def upload(self, a: np.ndarray, align_elems: int = 32) -> DevPlane:
         assert a.ndim == 2 and a.strides[1] == a.itemsize

@@ -1,4 +1,6 @@
 // Context, device memory, staging copies and timers behind include/vszip_hip.h.
+#include <vector>
+
 #include "common.hpp"
 
 #include <cstdlib>
@@ -181,6 +183,37 @@ VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_dev_alloc_probed(vszip_ctx *ctx, size_t bytes, int tries, vszip_placement_probe probe, void *user, void **dptr, double *best_cost) {
+    if (!ctx || !dptr) return VSZIP_ERR_ARG;
+    if (tries <= 1 || !probe) {
+        if (best_cost) *best_cost = 0.0;
+        return vszip_dev_alloc(ctx, bytes, dptr);
+    }
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    std::vector<void *> held;  // every candidate stays allocated until the walk is over: the next one lies elsewhere
+    void *best = nullptr;
+    double cost = 0.0;
+    for (int k = 0; k < tries; ++k) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+            (void)hipGetLastError();  // out of memory: choose among what fitted
+            break;
+        }
+        held.push_back(p);
+        const double c = probe(user, p);
+        if (!best || c < cost) {
+            best = p;
+            cost = c;
+        }
+    }
+    for (void *p : held)
+        if (p != best) (void)hipFree(p);
+    if (!best) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    *dptr = best;
+    if (best_cost) *best_cost = cost;
     return VSZIP_OK;
 }
 
