@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: the ring kernel's store cache policy (buffer_store aux bits) on a SLOW and on a FAST placement of the
+"""GPU box: variants of the ring kernel (store / load cache policy, prefetch depth ...) on a SLOW and on a FAST placement of the
 destination arena, all inside one process: variant libraries (tools/variant.sh, -DVSZIP_ST_AUX=n) are loaded side by
 side and run on the same arenas."""
 import ctypes as C
