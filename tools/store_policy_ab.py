@@ -18,29 +18,37 @@ import bench
 import vszip_amd
 
 dev = vszip_amd.Device(0)
+import os
+
 frames, radius = 64, 13
+DT = np.uint8 if os.environ.get("AB_U8") else np.uint16  # AB_U8=1: the 8-bit kernel on YUV420P8
 base = bench.make_frame(0, bench.W4K, bench.H4K)
+if DT == np.uint8:
+    base = [(p >> 8).astype(np.uint8) for p in base]
 planes = [np.roll(p, f * 17 + 1, axis=1) for f in range(frames) for p in base]
 shapes = [p.shape for p in planes]
-src = bench.Arena(dev, shapes, np.uint16, 1)
+src = bench.Arena(dev, shapes, DT, 1)
 for a, d in zip(planes, src.planes):
     a = np.ascontiguousarray(a)
-    dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * 2, a.ctypes.data, a.strides[0], a.shape[1] * 2, a.shape[0]))
+    dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * a.itemsize, a.ctypes.data, a.strides[0], a.shape[1] * a.itemsize, a.shape[0]))
 dev.sync()
+
+
+CODE = 0 if DT == np.uint8 else 1
 
 
 def run(lib, ctx, table, n=40):
     for _ in range(5):
-        assert lib.vszip_boxblur(ctx, 1, table, len(table), radius, 1, radius, 1) == 0
+        assert lib.vszip_boxblur(ctx, CODE, table, len(table), radius, 1, radius, 1) == 0
     lib.vszip_ctx_sync(ctx)
     t0 = time.perf_counter()
     for _ in range(n):
-        lib.vszip_boxblur(ctx, 1, table, len(table), radius, 1, radius, 1)
+        lib.vszip_boxblur(ctx, CODE, table, len(table), radius, 1, radius, 1)
     lib.vszip_ctx_sync(ctx)
     return (time.perf_counter() - t0) / n * 1e6
 
 
-cands = [bench.Arena(dev, shapes, np.uint16, 100 + k) for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30)]
+cands = [bench.Arena(dev, shapes, DT, 100 + k) for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30)]
 times = [run(dev.lib, dev.ctx, dev.plane_table(src.planes, c.planes), 10) for c in cands]
 order = np.argsort(times)
 picks = {"fast": cands[order[0]], "median": cands[order[len(order) // 2]], "slow": cands[order[-1]]}
