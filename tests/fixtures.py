@@ -5,7 +5,9 @@ tests/conftest.py:72-77); the derived formats restate what zimg does for the
 only conversions that are reproducible without zimg:
   RGBS  = v * f32(1/255)                       (exact)
   GRAY8 = limited-range BT.709 luma, f64, +0.5 floor   (exact)
-  GRAY16 / GRAYS luma                          (approximate, soft checks only)
+  GRAY16 / GRAYS / GRAYH luma, YUV4xxP8/P16/PS  (exact since round 3: oracle/vs_host.py restates zimg's
+                                               matrix and chroma resampler; the plane sums of the reference's
+                                               planeaverage.json goldens match to the last unit)
 """
 from __future__ import annotations
 
@@ -62,22 +64,52 @@ def crop_gray8() -> np.ndarray:
 
 @lru_cache(maxsize=None)
 def crop_grays() -> np.ndarray:
-    """Approximate zimg RGB24 -> GRAYS (matrix=1); soft checks only."""
-    f = np.float32
-    r, g, b = (crop_rgbs()[i] for i in range(3))
-    y = ((f(0.2126) * r + f(0.7152) * g) + f(0.0722) * b).astype(np.float32)
+    """zimg RGB24 -> GRAYS (matrix=1): the FMA-chain luma (oracle/vs_host.py); planeaverage.json
+    `GRAYS|full|exclude=[-1]` reproduces to every digit."""
+    from oracle import vs_host as vh
+
+    y = vh.rgb24_to_yuv(crop_rgb24(), sample="f32", gray=True)[0]
     y.setflags(write=False)
     return y
 
 
 @lru_cache(maxsize=None)
 def crop_gray16() -> np.ndarray:
-    """Approximate zimg RGB24 -> GRAY16 limited range; soft checks only."""
-    f = np.float32
-    y = np.floor(crop_grays() * f(56064.0) + f(4096.0) + f(0.5))
-    a = y.astype(np.uint16)
+    """zimg RGB24 -> GRAY16 limited range; the plane sum equals planeaverage.json `GRAY16|full|exclude=[-1]`."""
+    from oracle import vs_host as vh
+
+    a = vh.rgb24_to_yuv(crop_rgb24(), 16, gray=True)[0]
     a.setflags(write=False)
     return a
+
+
+@lru_cache(maxsize=None)
+def crop_yuv(bits: int = 8, ssw: int = 1, ssh: int = 1, sample: str = "int", temporal: int = 0) -> tuple:
+    """The reference's YUV fixtures (tests/conftest.py:88-102: resize.Bilinear(format=YUV..., matrix=1) of the
+    RGB24 crop; `temporal` = frame n of the 3-frame shifted clip)."""
+    from oracle import vs_host as vh
+
+    planes = vh.rgb24_to_yuv(temporal_rgb24(temporal), bits, ssw, ssh, sample=sample)
+    for p in planes:
+        p.setflags(write=False)
+    return tuple(planes)
+
+
+def yuv_geometry(planes, geometry: str, ssw: int = 1, ssh: int = 1) -> list:
+    """reference tests/conftest.py:108-122 on a subsampled clip: `odd` crops the subsampling modulus off the
+    right / bottom, `tiny` is CropAbs(13 - 13 % wmod, 7 - 7 % hmod, left=200, top=100)."""
+    if geometry == "full":
+        return [np.ascontiguousarray(p) for p in planes]
+    wm, hm = 1 << ssw, 1 << ssh
+    y, u, v = planes
+    if geometry == "odd":
+        return [np.ascontiguousarray(y[:-hm, :-wm]), np.ascontiguousarray(u[:-1, :-1]), np.ascontiguousarray(v[:-1, :-1])]
+    if geometry == "tiny":
+        tw, th = 13 - 13 % wm, 7 - 7 % hm
+        cw, ch = tw >> ssw, th >> ssh
+        return [np.ascontiguousarray(y[100:100 + th, 200:200 + tw]), np.ascontiguousarray(u[100 >> ssh:(100 >> ssh) + ch, 200 >> ssw:(200 >> ssw) + cw]),
+                np.ascontiguousarray(v[100 >> ssh:(100 >> ssh) + ch, 200 >> ssw:(200 >> ssw) + cw])]
+    raise ValueError(geometry)
 
 
 @lru_cache(maxsize=None)

@@ -28,6 +28,9 @@ REF = Path("/root/reference/tests")
 OUT = Path(__file__).resolve().parent
 
 REACHABLE_PREFIXES = ("RGB24|", "RGBS|", "GRAY8|")
+# round 3: oracle/vs_host.py restates zimg's matrix + chroma resampler exactly enough (plane sums of
+# planeaverage.json match to the last unit), so the YUV keys and the 16-bit / float Gray keys are reachable too
+YUV_PREFIXES = ("YUV420P8|", "YUV420P16|", "YUV444P16|", "YUV444PS|", "YUV420PS|", "YUV420P10|", "GRAYH|")
 FILES = ["boxblur", "bilateral", "eedi3", "eedi3h", "planeaverage",
          "planeminmax", "ssimulacra2", "limiter", "limitfilter", "adaptive_binarize"]
 # XPSNR accepts YUV only, but XPSNR_Y depends on the luma planes alone and the luma of the
@@ -56,6 +59,10 @@ def main() -> int:
     for name in FILES:
         data = json.loads((REF / "goldens" / f"{name}.json").read_text())
         soft[name] = {k: v for k, v in data.items() if k.startswith(("GRAY16|", "GRAYS|"))}
+    yuv = {}
+    for name in FILES + ["xpsnr"]:
+        data = json.loads((REF / "goldens" / f"{name}.json").read_text())
+        yuv[name] = {k: v for k, v in data.items() if k.startswith(YUV_PREFIXES)}
     # plane 0 of a YUV420P8 clip is the GRAY8 fixture (same limited-range BT.709 luma; the golden's
     # avg[0] equals the GRAY8 average to every digit), so the luma entries of YUV keys are reachable
     pa = json.loads((REF / "goldens" / "planeaverage.json").read_text())
@@ -65,7 +72,7 @@ def main() -> int:
     extra["xpsnr_Y"] = {k: v["Y"] for k, v in xp.items() if k.startswith(("YUV420P8|", "YUV420P10|"))}
     # x+k distortions: chroma SSE is k^2 per sample whatever the chroma content -> U/V reachable as well
     extra["xpsnr_UV"] = {k: {"U": v["U"], "V": v["V"]} for k, v in xp.items() if k.startswith("YUV420P8|") and ("|bright|" in k or "|shift|" in k)}
-    (OUT / "ref_goldens.json").write_text(json.dumps({"exact": out, "soft": soft, "luma_of_yuv": extra}, indent=1, sort_keys=True) + "\n")
+    (OUT / "ref_goldens.json").write_text(json.dumps({"exact": out, "soft": soft, "luma_of_yuv": extra, "yuv": yuv}, indent=1, sort_keys=True) + "\n")
     print("wrote", OUT / "crop_rgb24.npy", planar.shape, "and ref_goldens.json")
     return 0
 
