@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define VSZIP_ABI_VERSION 1
+#define VSZIP_ABI_VERSION 2 /* 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1: vszip_dev_alloc_probed,
+                               vszip_chain_run, vszip_ssimulacra2_src, vszip_to_rgbs_linear, vszip_probe_read_each, vszip_resample_table */
 
 typedef struct vszip_ctx vszip_ctx;
 
@@ -258,16 +259,28 @@ int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *con
  * limited for Gray), Gray -> R = G = B, and the sRGB EOTF through zimg's approximate-gamma table
  * (VapourSynth's resize default). The source planes are uploaded as they are (8/16-bit samples: a
  * quarter / half of the RGBS bytes), the conversion is fused into the first SSIMULACRA2 pass.
- *   family     VSZIP_CF_RGB (3 planes per frame) or VSZIP_CF_GRAY (1 plane per frame); YUV needs
- *              zimg's chroma resampler and matrix and stays with the host's resize;
+ *   family     VSZIP_CF_RGB (3 planes per frame), VSZIP_CF_GRAY (1 plane per frame) or — round 3 — VSZIP_CF_YUV
+ *              (3 planes, chroma subsampled by 2^ssw x 2^ssh): zimg's integer -> float conversion per plane, the
+ *              chroma planes brought to 4:4:4 with its Catmull-Rom resampler (resize.Bicubic: b = 0, c = 0.5;
+ *              horizontal pass first, two interleaved FMA accumulators per sample — vszip_resample_table below),
+ *              the YUV -> RGB matrix as an FMA chain, then the transfer table. Restated from zimg's published
+ *              algorithm and pinned by the reference's seven YUV SSIMULACRA2 goldens (tests/test_oracle_zimg_goldens.py);
  *   dtype/bits VSZIP_U8 (8), VSZIP_U16 (9..16) or VSZIP_F32 (f16 is rejected by the wrapper, :106-113);
- *   limited    integer samples are limited range (zimg's default for Gray) or full (RGB);
- *   linearize  0 when frame 0 carries _Transfer == LINEAR (:139-141), else 1.
+ *   limited    integer samples are limited range (zimg's default for Gray and YUV) or full (RGB);
+ *   linearize  0 when frame 0 carries _Transfer == LINEAR (:139-141), else 1;
+ *   YUV only:  ssw / ssh   log2 chroma subsampling (0..2);
+ *              matrix      _Matrix of the clip's frames if set and specified, else what hz.toRGBS passes as matrix_in
+ *                          (1 = BT.709 if height > 650 else 6 = BT.601; src/helper.zig:231) — VapourSynth's resize
+ *                          lets a frame property win over the *_in argument; supported: 1, 5, 6, 9;
+ *              chroma_loc  _ChromaLocation (0 left — the default —, 1 center, 2 top-left, 3 top, 4 bottom-left, 5 bottom);
+ *              chroma_stride  row pitch of the U and V planes, elements.
  * ref_planes / dis_planes: HOST arrays of npairs * (3 | 1) device plane pointers, same stride (elements).
  */
-enum { VSZIP_CF_RGB = 0, VSZIP_CF_GRAY = 1 };
+enum { VSZIP_CF_RGB = 0, VSZIP_CF_GRAY = 1, VSZIP_CF_YUV = 2 };
 typedef struct vszip_ssim_source {
     int family, dtype, bits, limited, linearize;
+    int ssw, ssh, matrix, chroma_loc; /* VSZIP_CF_YUV */
+    ptrdiff_t chroma_stride;          /* VSZIP_CF_YUV */
 } vszip_ssim_source;
 int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *fmt, const void *const *ref_planes,
                           const void *const *dis_planes, ptrdiff_t stride, int w, int h, int npairs, double *scores);
@@ -275,6 +288,10 @@ int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *fmt, const vo
  * Asynchronous on the context stream. */
 int vszip_to_rgbs_linear(vszip_ctx *ctx, const vszip_ssim_source *fmt, const void *const *src_planes, ptrdiff_t src_stride,
                          float *const *dst3, ptrdiff_t dst_stride, int w, int h);
+/* zimg's Catmull-Rom table for one axis of an upscale (device-free): output sample i = sum_k coef4[4 i + k] *
+ * src[min(left[i] + k, src_dim - 1)], accumulated as (c0 x0 + fma(c2, x2, .)) + (c1 x1 + fma(c3, x3, .)).
+ * shift: position offset in source samples (4:2:0 left-sited chroma -> luma grid: 0.25 horizontally, 0 vertically). */
+int vszip_resample_table(int src_dim, int dst_dim, double shift, int32_t *left, float *coef4);
 
 /*
  * EEDI3 / EEDI3H — replaces processPlane (src/vapoursynth/eedi3.zig:26-140) with its kernels

@@ -780,7 +780,8 @@ static const std::vector<float> &standin_srgb_table() {
         const double A = 1.055010718947587, B = 0.003041282560128;
         for (int i = 0; i < 65537; ++i) {
             const double x = (double)((float)i / 65536.0f * 2.0f - 0.5f);
-            v[i] = (float)(x < 12.92 * B ? x / 12.92 : std::pow((std::max(x, 0.0) + (A - 1.0)) / A, 2.4));
+            const double xc = std::max(x, 0.0);  // zimg clamps negative input (oracle/vs_host.py::srgb_eotf)
+            v[i] = (float)(xc < 12.92 * B ? xc / 12.92 : std::pow((xc + (A - 1.0)) / A, 2.4));
         }
         return v;
     }();
@@ -813,6 +814,99 @@ static void VS_CC standin_set_frame_prop(const VSMap *in, VSMap *out, void *, VS
     node_unref(n);
 }
 
+// ---- YUV -> RGBS for the stand-in (hz.toRGBS on a YUV clip): the restatement of oracle/vs_host.py::yuv_to_rgbs in C++
+// (zimg's integer -> float conversion, Catmull-Rom chroma resampler with two interleaved FMA accumulators, horizontal
+// pass first, YUV -> RGB FMA chain). TEST INFRASTRUCTURE; tests/test_gpu_plugin.py checks its output against vs_host.
+static void standin_table(int src_dim, int dst_dim, double shift, std::vector<int> &left, std::vector<float> &coef) {
+    auto wgt = [](double x) {
+        x = std::fabs(x);  // b = 0, c = 0.5
+        if (x < 1.0) return 1.0 - 2.5 * x * x + 1.5 * x * x * x;
+        if (x < 2.0) return 2.0 - 4.0 * x + 2.5 * x * x - 0.5 * x * x * x;
+        return 0.0;
+    };
+    left.assign((size_t)dst_dim, 0);
+    coef.assign((size_t)dst_dim * 4, 0.0f);
+    const double scale = (double)dst_dim / src_dim;
+    std::vector<double> row((size_t)src_dim);
+    for (int i = 0; i < dst_dim; ++i) {
+        std::fill(row.begin(), row.end(), 0.0);
+        const double pos = (i + 0.5) / scale + shift, begin = std::floor(pos - 2.0 + 0.5) + 0.5;
+        double w[4], total = 0;
+        for (int k = 0; k < 4; ++k) total += (w[k] = wgt(begin + k - pos));
+        for (int k = 0; k < 4; ++k) {
+            const double xp = begin + k;
+            double r = xp < 0 ? -xp : (xp >= src_dim ? 2.0 * src_dim - xp : xp);
+            r = std::min(std::max(r, 0.0), std::nextafter((double)src_dim, -1.0));
+            row[(size_t)std::floor(r)] += w[k] / total;
+        }
+        int first = -1, last = 0;
+        for (int j = 0; j < src_dim; ++j)
+            if (row[(size_t)j] != 0.0) {
+                if (first < 0) first = j;
+                last = j;
+            }
+        (void)last;
+        const int width = std::min(4, src_dim), l = std::min(first, src_dim - width);
+        left[(size_t)i] = l;
+        for (int k = 0; k < 4 && l + k < src_dim; ++k) coef[(size_t)i * 4 + k] = (float)row[(size_t)(l + k)];
+    }
+}
+static inline float standin_acc(const float *c, float x0, float x1, float x2, float x3) {
+    float a0 = c[0] * x0, a1 = c[1] * x1;
+    a0 = std::fmaf(c[2], x2, a0);
+    a1 = std::fmaf(c[3], x3, a1);
+    return a0 + a1;
+}
+// one chroma plane (already f32) to w x h
+static std::vector<float> standin_upsample(const std::vector<float> &src, int cw, int ch, int w, int h, int ssw, int ssh, int loc) {
+    auto offset = [&](int ss, bool vertical) {
+        if (!ss) return 0.0;
+        const double edge = -((1 << ss) - 1) / 2.0;
+        if (vertical) return (loc == 2 || loc == 3) ? edge : ((loc == 4 || loc == 5) ? -edge : 0.0);
+        return (loc == 0 || loc == 2 || loc == 4) ? edge : 0.0;
+    };
+    std::vector<float> hp;
+    const std::vector<float> *cur = &src;
+    int curw = cw;
+    std::vector<int> left;
+    std::vector<float> coef;
+    if (ssw) {
+        standin_table(cw, w, -offset(ssw, false) / (1 << ssw), left, coef);
+        hp.resize((size_t)w * ch);
+        for (int y = 0; y < ch; ++y)
+            for (int x = 0; x < w; ++x) {
+                const float *r = src.data() + (size_t)y * cw;
+                const int l = left[(size_t)x];
+                hp[(size_t)y * w + x] = standin_acc(&coef[(size_t)x * 4], r[l], r[std::min(l + 1, cw - 1)], r[std::min(l + 2, cw - 1)], r[std::min(l + 3, cw - 1)]);
+            }
+        cur = &hp;
+        curw = w;
+    }
+    if (!ssh) return *cur;
+    standin_table(ch, h, -offset(ssh, true) / (1 << ssh), left, coef);
+    std::vector<float> out((size_t)w * h);
+    for (int y = 0; y < h; ++y) {
+        const int l = left[(size_t)y];
+        const float *r0 = cur->data() + (size_t)l * curw, *r1 = cur->data() + (size_t)std::min(l + 1, ch - 1) * curw, *r2 = cur->data() + (size_t)std::min(l + 2, ch - 1) * curw,
+                    *r3 = cur->data() + (size_t)std::min(l + 3, ch - 1) * curw;
+        for (int x = 0; x < w; ++x) out[(size_t)y * w + x] = standin_acc(&coef[(size_t)y * 4], r0[x], r1[x], r2[x], r3[x]);
+    }
+    return out;
+}
+static void standin_yuv_matrix(int matrix, float m[9]) {
+    double kr = 0.299, kb = 0.114;
+    if (matrix == 1) { kr = 0.2126; kb = 0.0722; }
+    if (matrix == 9) { kr = 0.2627; kb = 0.0593; }
+    const double kg = 1.0 - kr - kb, us = 1.0 / (2.0 - 2.0 * kb), vs = 1.0 / (2.0 - 2.0 * kr);
+    const double a[3][3] = {{kr, kg, kb}, {-kr * us, -kg * us, (1.0 - kb) * us}, {(1.0 - kr) * vs, -kg * vs, -kb * vs}};
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) + a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int r0 = j == 0 ? 1 : 0, r1 = j == 2 ? 1 : 2, c0 = i == 0 ? 1 : 0, c1 = i == 2 ? 1 : 2;
+            m[3 * i + j] = (float)((((i + j) & 1) ? -1.0 : 1.0) * (a[r0][c0] * a[r1][c1] - a[r0][c1] * a[r1][c0]) / det);
+        }
+}
+
 static void VS_CC standin_bicubic(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *) {
     int err = 0, e_fmt = 0, e_tr = 0;
     VSNode *src = A(mapGetNode)(in, "clip", 0, &err);
@@ -823,6 +917,68 @@ static void VS_CC standin_bicubic(const VSMap *in, VSMap *out, void *, VSCore *c
     if (!e_fmt) A(getVideoFormatByID)(&fmt, (uint32_t)id, core);
     const bool to_rgbs = !e_fmt && fmt.colorFamily == cfRGB && fmt.sampleType == stFloat && fmt.bytesPerSample == 4;
     const bool lin = !e_tr && transfer == 8;
+    const bool yuv = sf.colorFamily == cfYUV && to_rgbs && !lin;
+    if (yuv) {
+        int e_mi = 0;
+        const int64_t matrix_in = A(mapGetInt)(in, "matrix_in", 0, &e_mi);
+        g_standin_log.push_back(std::string("resize.Bicubic format=RGBS matrix_in=") + std::to_string(e_mi ? -1 : (int)matrix_in));
+        VSNode *n = eager_clone(src, &fmt);
+        for (int i = 0; i < src->vi.numFrames; ++i) {
+            char e[256];
+            const VSFrame *f = A(getFrame)(i, src, e, sizeof e);
+            if (!f) {
+                A(mapSetError)(out, e);
+                node_unref(src);
+                node_unref(n);
+                return;
+            }
+            int pe = 0, me = 0, le = 0;
+            const int64_t range = A(mapGetInt)(&f->props, "_ColorRange", 0, &pe);
+            const int64_t mprop = A(mapGetInt)(&f->props, "_Matrix", 0, &me);
+            const int64_t loc = A(mapGetInt)(&f->props, "_ChromaLocation", 0, &le);
+            const int matrix = (!me && mprop != 2) ? (int)mprop : (e_mi ? 6 : (int)matrix_in);  // a specified frame property wins over *_in
+            const bool limited = sf.sampleType == stInteger && (pe ? true : range == 1);
+            const int b = sf.bitsPerSample, w = src->vi.width, h = src->vi.height, ssw = sf.subSamplingW, ssh = sf.subSamplingH;
+            const int cw = (w + (1 << ssw) - 1) >> ssw, ch = (h + (1 << ssh) - 1) >> ssh;
+            std::vector<float> pl[3];
+            for (int p = 0; p < 3; ++p) {
+                const int pw = p ? cw : w, ph = p ? ch : h;
+                pl[p].resize((size_t)pw * ph);
+                double off = 0, rng = 1;
+                if (sf.sampleType == stInteger) {
+                    off = limited ? (double)((p ? 128 : 16) << (b - 8)) : (p ? (double)(1 << (b - 1)) : 0.0);
+                    rng = limited ? (double)((p ? 224 : 219) << (b - 8)) : (double)((1 << b) - 1);
+                }
+                const float sc = (float)(1.0 / rng), so = (float)(-off / rng);
+                for (int y = 0; y < ph; ++y)
+                    for (int x = 0; x < pw; ++x) {
+                        const float v = (float)sample_at(f, p, x, y);
+                        pl[p][(size_t)y * pw + x] = sf.sampleType == stInteger ? std::fmaf(v, sc, so) : v;
+                    }
+            }
+            for (int p = 1; p < 3; ++p)
+                if (ssw || ssh) pl[p] = standin_upsample(pl[p], cw, ch, w, h, ssw, ssh, le ? 0 : (int)loc);
+            float m[9];
+            standin_yuv_matrix(matrix, m);
+            VSFrame *c = frame_new(&fmt, w, h);
+            map_copy(&f->props, &c->props);
+            A(mapSetInt)(&c->props, "_Matrix", 0, maReplace);
+            for (int p = 0; p < 3; ++p)
+                for (int y = 0; y < h; ++y) {
+                    float *row = reinterpret_cast<float *>(c->ptr[p] + (ptrdiff_t)y * c->stride[p]);
+                    for (int x = 0; x < w; ++x) {
+                        const size_t o = (size_t)y * w + x;
+                        row[x] = std::fmaf(m[3 * p + 2], pl[2][o], std::fmaf(m[3 * p + 1], pl[1][o], m[3 * p] * pl[0][o]));
+                    }
+                }
+            frame_unref(f);
+            n->frames.push_back(c);
+        }
+        node_unref(src);
+        A(mapSetNode)(out, "clip", n, maReplace);
+        node_unref(n);
+        return;
+    }
     if ((sf.colorFamily != cfRGB && sf.colorFamily != cfGray) || sf.subSamplingW || sf.subSamplingH || (!to_rgbs && !lin) || (lin && !to_rgbs && !(sf.colorFamily == cfRGB && sf.sampleType == stFloat))) {
         A(mapSetError)(out, "resize: stand-in converts RGB / Gray clips to RGBS and RGBS to linear light only");
         node_unref(src);
@@ -846,15 +1002,16 @@ static void VS_CC standin_bicubic(const VSMap *in, VSMap *out, void *, VSCore *c
         const int64_t range = A(mapGetInt)(&f->props, "_ColorRange", 0, &pe);
         const bool limited = sf.sampleType == stInteger && (pe ? sf.colorFamily == cfGray : range == 1);
         const int b = sf.bitsPerSample;
-        const float off = limited ? (float)(16 << (b - 8)) : 0.0f;
-        const float sc = sf.sampleType == stInteger ? (float)(1.0 / (limited ? (219 << (b - 8)) : ((1 << b) - 1))) : 1.0f;
+        const double rng = limited ? (double)(219 << (b - 8)) : (double)((1 << b) - 1);
+        const float off = limited ? (float)(-(double)(16 << (b - 8)) / rng) : 0.0f;
+        const float sc = sf.sampleType == stInteger ? (float)(1.0 / rng) : 1.0f;
         for (int p = 0; p < 3; ++p) {
             const int sp = sf.colorFamily == cfGray ? 0 : p;
             for (int y = 0; y < c->h; ++y) {
                 float *row = reinterpret_cast<float *>(c->ptr[p] + (ptrdiff_t)y * c->stride[p]);
                 for (int x = 0; x < c->w; ++x) {
                     float v = (float)sample_at(f, sp, x, y);
-                    if (sf.sampleType == stInteger) v = (v - off) * sc;
+                    if (sf.sampleType == stInteger) v = std::fmaf(v, sc, off);
                     if (lin) {
                         float t = std::nearbyintf(v * 32768.0f + 16384.0f);
                         t = std::min(std::max(t, 0.0f), 65536.0f);

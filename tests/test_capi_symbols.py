@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libvszip_hip.so does not export {name}"
     assert declared == set(vszip_amd.capi.SYMBOLS), (declared ^ set(vszip_amd.capi.SYMBOLS))
-    assert lib.vszip_abi_version() == 1
+    assert lib.vszip_abi_version() == 2
 
 
 def test_no_gpu_fails_loudly():
@@ -34,3 +34,25 @@ def test_no_gpu_fails_loudly():
         lib.vszip_ctx_destroy(ctx)
         pytest.skip("GPU present")
     assert rc < 0 and not ctx.value
+
+
+def test_resample_table_equals_the_oracle_restatement():
+    """vszip_resample_table (device-free host code of the product: the tables the YUV colour pre-stage of
+    SSIMULACRA2 runs on) against oracle/vs_host.py::zimg_filter, the restatement the reference's YUV goldens pin:
+    same first tap and bit-identical f32 coefficients for every geometry the pre-stage meets (4:2:0 / 4:2:2 /
+    4:1:0, every chroma siting, odd and tiny sizes)."""
+    import numpy as np
+
+    import vszip_amd
+    from oracle import vs_host as vh
+
+    for src, dst, shift in [(320, 640, 0.25), (160, 320, 0.0), (319, 638, 0.25), (159, 318, 0.0), (6, 12, 0.25), (3, 6, 0.0), (1, 2, 0.0), (2, 4, 0.25),
+                            (960, 1920, 0.0), (540, 1080, 0.25), (540, 1080, -0.25), (160, 640, 0.375), (5, 10, 0.0), (7, 13, 0.25), (4, 7, 0.0)]:
+        left, coef = vszip_amd.capi.resample_table(src, dst, shift)
+        l0, c0 = vh.zimg_filter("bicubic", src, dst, shift)
+        c0 = c0.astype(np.float32)
+        w = c0.shape[1]
+        assert w <= 4
+        assert np.array_equal(left, l0.astype(np.int32)), (src, dst, shift)
+        assert np.array_equal(coef[:, :w].view(np.uint32), c0.view(np.uint32)), (src, dst, shift)
+        assert not coef[:, w:].any()

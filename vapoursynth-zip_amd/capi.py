@@ -52,11 +52,12 @@ STAGE_BOXBLUR, STAGE_BILATERAL, STAGE_LIMITER = 0, 1, 2
 
 
 class SsimSource(C.Structure):
-    """vszip_ssim_source: family (0 RGB, 1 Gray), dtype, bits, limited, linearize."""
-    _fields_ = [("family", C.c_int32), ("dtype", C.c_int32), ("bits", C.c_int32), ("limited", C.c_int32), ("linearize", C.c_int32)]
+    """vszip_ssim_source: family (0 RGB, 1 Gray, 2 YUV), dtype, bits, limited, linearize; YUV: ssw, ssh, matrix, chroma_loc, chroma_stride."""
+    _fields_ = [("family", C.c_int32), ("dtype", C.c_int32), ("bits", C.c_int32), ("limited", C.c_int32), ("linearize", C.c_int32),
+                ("ssw", C.c_int32), ("ssh", C.c_int32), ("matrix", C.c_int32), ("chroma_loc", C.c_int32), ("chroma_stride", C.c_ssize_t)]
 
 
-CF_RGB, CF_GRAY = 0, 1
+CF_RGB, CF_GRAY, CF_YUV = 0, 1, 2
 
 
 class Eedi3Params(C.Structure):
@@ -98,6 +99,7 @@ SYMBOLS = {
     "vszip_bilateral": (_i, [_vp, _i, _PP, C.POINTER(C.POINTER(BilateralCfg)), _i, C.c_float]),
     "vszip_ssimulacra2": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
     "vszip_chain_run": (_i, [_vp, _i, C.POINTER(ChainStage), _i, _PP, C.POINTER(C.c_int), _i]),
+    "vszip_resample_table": (_i, [_i, _i, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "vszip_ssimulacra2_src": (_i, [_vp, C.POINTER(SsimSource), C.POINTER(_vp), C.POINTER(_vp), _pd, _i, _i, _i, C.POINTER(C.c_double)]),
     "vszip_to_rgbs_linear": (_i, [_vp, C.POINTER(SsimSource), C.POINTER(_vp), _pd, C.POINTER(_vp), _pd, _i, _i]),
     "vszip_eedi3": (_i, [_vp, _PP, C.POINTER(_vp), C.POINTER(_pd), _i, _i, _i, C.POINTER(Eedi3Params)]),
@@ -116,6 +118,16 @@ SYMBOLS = {
 }
 
 _lib = None
+
+
+def resample_table(src_dim: int, dst_dim: int, shift: float = 0.0):
+    """vszip_resample_table (device-free): zimg's Catmull-Rom upscale table of one axis -> (left[dst_dim] int32, coef[dst_dim, 4] f32)."""
+    left = np.empty(dst_dim, np.int32)
+    coef = np.empty((dst_dim, 4), np.float32)
+    rc = load().vszip_resample_table(src_dim, dst_dim, float(shift), left.ctypes.data_as(C.POINTER(C.c_int32)), coef.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise ValueError(f"vszip_resample_table({src_dim}, {dst_dim}, {shift}) -> {rc}")
+    return left, coef
 
 
 def _share_torch_hip_runtime():
@@ -434,13 +446,14 @@ class Device:
         self.check(self.lib.vszip_chain_run(self.ctx, _NP2DT[srcs[0].dtype], arr, len(stages), self.plane_table(srcs, dsts), slots, n))
 
     @staticmethod
-    def ssim_source(family: str, dtype, bits=None, linearize=True, limited=None) -> SsimSource:
-        """family "RGB" | "GRAY"; integer samples: full range for RGB, limited for Gray (zimg's defaults) unless given."""
+    def ssim_source(family: str, dtype, bits=None, linearize=True, limited=None, ssw=0, ssh=0, matrix=1, chroma_loc=0) -> SsimSource:
+        """family "RGB" | "GRAY" | "YUV"; integer samples: full range for RGB, limited for Gray / YUV (zimg's defaults) unless
+        given. YUV: log2 subsampling, _Matrix, _ChromaLocation (the chroma row pitch is filled in from the planes)."""
         dt = np.dtype(dtype)
-        fam = CF_GRAY if family.upper() == "GRAY" else CF_RGB
+        fam = {"GRAY": CF_GRAY, "YUV": CF_YUV}.get(family.upper(), CF_RGB)
         b = bits if bits is not None else (32 if dt.kind == "f" else 8 * dt.itemsize)
-        lim = (fam == CF_GRAY) if limited is None else bool(limited)
-        return SsimSource(fam, _NP2DT[dt], b, int(lim and dt.kind != "f"), int(bool(linearize)))
+        lim = (fam != CF_RGB) if limited is None else bool(limited)
+        return SsimSource(fam, _NP2DT[dt], b, int(lim and dt.kind != "f"), int(bool(linearize)), ssw, ssh, matrix, chroma_loc, 0)
 
     def ssimulacra2_src(self, fmt: SsimSource, ref_planes, dis_planes):
         """SSIMULACRA2 with the colour pre-stage on the device: ref_planes / dis_planes are flat lists of
@@ -451,6 +464,9 @@ class Device:
         d = (C.c_void_p * (per * n))(*[p.ptr for p in dis_planes])
         out = (C.c_double * n)()
         p0 = ref_planes[0]
+        if fmt.family == CF_YUV:
+            fmt.chroma_stride = ref_planes[1].stride
+            assert all(p.stride == (p0.stride if i % 3 == 0 else fmt.chroma_stride) for i, p in enumerate(list(ref_planes) + list(dis_planes)))
         self.check(self.lib.vszip_ssimulacra2_src(self.ctx, C.byref(fmt), r, d, p0.stride, p0.w, p0.h, n, out))
         return list(out)
 
@@ -461,6 +477,8 @@ class Device:
         per = 1 if fmt.family == CF_GRAY else 3
         s = (C.c_void_p * per)(*[p.ptr for p in planes[:per]])
         d = (C.c_void_p * 3)(*[p.ptr for p in dst])
+        if fmt.family == CF_YUV:
+            fmt.chroma_stride = planes[1].stride
         self.check(self.lib.vszip_to_rgbs_linear(self.ctx, C.byref(fmt), s, p0.stride, d, dst[0].stride, p0.w, p0.h))
         self.sync()
         return dst

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/vszip_hip.h"
 
@@ -90,4 +91,64 @@ VSZIP_EXPORT double vszip_xpsnr_average(double sum_wdist, double sum_xpsnr, uint
         return 10.0 * std::log10((double)(width * height * maxerr) / (avg * avg));
     }
     return sum_xpsnr / nf;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// zimg's resampling table for one axis (round 3: the YUV colour pre-stage of SSIMULACRA2) — what
+// `resize.Bicubic(format=RGBS)` in hz.toRGBS (src/helper.zig:225-243) uses to bring a subsampled chroma plane to
+// 4:4:4. zimg is third-party and not in the reference tree; this restates its published filter construction
+// (oracle/vs_host.py::zimg_filter is the twin the tests compare with, itself pinned by the reference's goldens):
+// per output sample the window `pos = (i + 0.5) / scale + shift`, `filter_size = ceil(2 * support)` taps starting at
+// `floor(pos - filter_size / 2 + 0.5)`, weights normalised, taps outside the line reflected about the edge (edge
+// sample repeated) and ADDED to the sample they land on, rows trimmed to their non-zero span and aligned to the common
+// width. Upscaling only (scale >= 1, support 2): at most 4 taps. coef4[4 * i + k] multiplies sample left[i] + k; the
+// caller clamps left[i] + k to src_dim - 1 for lines shorter than 4 (those coefficients are 0).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+double bicubic_weight(double x, double b, double c) {
+    x = std::fabs(x);
+    const double p0 = (6.0 - 2.0 * b) / 6.0, p2 = (-18.0 + 12.0 * b + 6.0 * c) / 6.0, p3 = (12.0 - 9.0 * b - 6.0 * c) / 6.0;
+    const double q0 = (8.0 * b + 24.0 * c) / 6.0, q1 = (-12.0 * b - 48.0 * c) / 6.0, q2 = (6.0 * b + 30.0 * c) / 6.0, q3 = (-b - 6.0 * c) / 6.0;
+    if (x < 1.0) return p0 + p2 * x * x + p3 * x * x * x;
+    if (x < 2.0) return q0 + q1 * x + q2 * x * x + q3 * x * x * x;
+    return 0.0;
+}
+}  // namespace
+
+VSZIP_EXPORT int vszip_resample_table(int src_dim, int dst_dim, double shift, int32_t *left, float *coef4) {
+    if (src_dim <= 0 || dst_dim < src_dim || !left || !coef4) return VSZIP_ERR_ARG;
+    const double scale = (double)dst_dim / (double)src_dim;
+    constexpr int kTaps = 4;  // ceil(2 * support), support 2, no widening when upscaling
+    std::vector<double> row((size_t)src_dim);
+    for (int i = 0; i < dst_dim; ++i) {
+        std::fill(row.begin(), row.end(), 0.0);
+        const double pos = (i + 0.5) / scale + shift;
+        const double begin = std::floor(pos - kTaps / 2.0 + 0.5) + 0.5;
+        double w[kTaps], total = 0.0;
+        for (int k = 0; k < kTaps; ++k) {
+            w[k] = bicubic_weight(begin + k - pos, 0.0, 0.5);  // VapourSynth's resize.Bicubic defaults: b = 0, c = 0.5
+            total += w[k];
+        }
+        for (int k = 0; k < kTaps; ++k) {
+            const double xpos = begin + k;
+            double real = xpos < 0.0 ? -xpos : (xpos >= src_dim ? 2.0 * src_dim - xpos : xpos);
+            real = std::min(std::max(real, 0.0), std::nextafter((double)src_dim, -INFINITY));
+            row[(size_t)std::floor(real)] += w[k] / total;
+        }
+        int first = 0, last = 0;
+        bool any = false;
+        for (int j = 0; j < src_dim; ++j)
+            if (row[j] != 0.0) {
+                if (!any) first = j;
+                last = j;
+                any = true;
+            }
+        if (!any || last - first + 1 > kTaps) return VSZIP_ERR_UNSUPPORTED;
+        // zimg aligns every row to the table's common width (4 wherever the line has 4 samples)
+        const int width = std::min(kTaps, src_dim);
+        const int l = std::min(first, src_dim - width);
+        left[i] = l;
+        for (int k = 0; k < kTaps; ++k) coef4[4 * i + k] = (l + k < src_dim) ? (float)row[(size_t)(l + k)] : 0.0f;
+    }
+    return VSZIP_OK;
 }

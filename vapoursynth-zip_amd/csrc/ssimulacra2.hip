@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Scales 0 + 1 + the scale-2 RGB in one pass, colour pre-stage included.
 // ---------------------------------------------------------------------------------------------
-enum { PYR_F32_LINEAR = 0, PYR_F32_GAMMA = 1, PYR_INT = 2 };
+enum { PYR_F32_LINEAR = 0, PYR_F32_GAMMA = 1, PYR_INT = 2, PYR_YUV = 3 };
 
 struct PyrPair {
     const void *src1[3], *src2[3];  // source planes of the two frames (Gray: [0] only)
@@ -236,6 +236,75 @@ __device__ __forceinline__ void pyr_put4(float __attribute__((address_space(1)))
         if (left > 1) pl[o + 1] = v1;
         if (left > 2) pl[o + 2] = v2;
         if (left > 3) pl[o + 3] = v3;
+    }
+}
+
+// The second half of a thread's work: its 4x4 block of linear RGB -> the XYB planes of scale 0, the 2x2 box and
+// XYB of scale 1, and its one sample of scale-2 linear RGB.
+typedef float __attribute__((address_space(1))) *PyrGOut;
+template <bool FAST>
+__device__ __forceinline__ void pyr_emit(const PyrArgs &a, const PyrGOut (&o0)[3], const PyrGOut (&o1)[3], const PyrGOut (&o2)[3], const float (&lin)[3][4][4], int bx, int by) {
+    const int x0 = bx * 4, y0 = by * 4;
+    // scale 0: XYB of the 16 samples, two per instruction; every value is computed, only the stores are guarded
+    {
+        const bool nb = o0[2] != nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v2f X01, Y01, B01 = {0.0f, 0.0f}, X23, Y23, B23 = {0.0f, 0.0f};
+            to_xyb_px2(a.k, v2f{lin[0][r][0], lin[0][r][1]}, v2f{lin[1][r][0], lin[1][r][1]}, v2f{lin[2][r][0], lin[2][r][1]}, nb, X01, Y01, B01);
+            to_xyb_px2(a.k, v2f{lin[0][r][2], lin[0][r][3]}, v2f{lin[1][r][2], lin[1][r][3]}, v2f{lin[2][r][2], lin[2][r][3]}, nb, X23, Y23, B23);
+            if (FAST || y0 + r < a.h) {
+                const size_t o = (size_t)(y0 + r) * a.w + x0;
+                pyr_put4(o0[0], o, FAST, a.w - x0, X01.x, X01.y, X23.x, X23.y);
+                pyr_put4(o0[1], o, FAST, a.w - x0, Y01.x, Y01.y, Y23.x, Y23.y);
+                pyr_put4(o0[2], o, FAST, a.w - x0, B01.x, B01.y, B23.x, B23.y);
+            }
+        }
+    }
+    // scale 1: 2x2 box of linear RGB, summed ((a+b)+c)+d (:186-200), then XYB
+    float l1[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                l1[c][j][i] = (((lin[c][2 * j][2 * i] + lin[c][2 * j][2 * i + 1]) + lin[c][2 * j + 1][2 * i]) + lin[c][2 * j + 1][2 * i + 1]) * 0.25f;
+    {
+        const bool nb = o1[2] != nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            v2f X, Y, B = {0.0f, 0.0f};
+            to_xyb_px2(a.k, v2f{l1[0][j][0], l1[0][j][1]}, v2f{l1[1][j][0], l1[1][j][1]}, v2f{l1[2][j][0], l1[2][j][1]}, nb, X, Y, B);
+            const int x = 2 * bx, y = 2 * by + j;
+            if (FAST || y < a.h1) {
+                const size_t o = (size_t)y * a.w1 + x;
+                const bool two = FAST || x + 1 < a.w1;
+                if (FAST && (a.w1 & 1) == 0) {  // 8-byte stores: every row of scale 1 starts 8-byte aligned
+                    typedef v2f VSZIP_GLOBAL *G2;
+                    if (o1[0]) *reinterpret_cast<G2>(o1[0] + o) = X;
+                    if (o1[1]) *reinterpret_cast<G2>(o1[1] + o) = Y;
+                    if (nb) *reinterpret_cast<G2>(o1[2] + o) = B;
+                } else {
+                    if (o1[0]) { o1[0][o] = X.x; if (two) o1[0][o + 1] = X.y; }
+                    if (o1[1]) { o1[1][o] = Y.x; if (two) o1[1][o + 1] = Y.y; }
+                    if (nb) { o1[2][o] = B.x; if (two) o1[2][o + 1] = B.y; }
+                }
+            }
+        }
+    }
+    // scale 2: one sample; a missing scale-1 column / row takes its neighbour (the same clamp one level up)
+    if (FAST || (bx < a.w2 && by < a.h2)) {
+        const bool i1 = FAST || 2 * bx + 1 < a.w1, j1 = FAST || 2 * by + 1 < a.h1;
+        const size_t o = (size_t)by * a.w2 + bx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // selects, not l1[c][j1][i1]: a runtime index would move the array out of the registers
+            const float p00 = l1[c][0][0], p01 = i1 ? l1[c][0][1] : l1[c][0][0];
+            const float p10 = j1 ? l1[c][1][0] : l1[c][0][0];
+            const float p11 = j1 ? (i1 ? l1[c][1][1] : l1[c][1][0]) : p01;
+            o2[c][o] = (((p00 + p01) + p10) + p11) * 0.25f;
+        }
     }
 }
 
@@ -302,67 +371,7 @@ __device__ __forceinline__ void pyr_image(const PyrArgs &a, const PyrPtrs &pp, c
 #pragma unroll
                 for (int i = 0; i < 4; ++i) lin[1][r][i] = lin[2][r][i] = lin[0][r][i];
         }
-        // scale 0: XYB of the 16 samples, two per instruction; every value is computed, only the stores are guarded
-        {
-            const bool nb = o0[2] != nullptr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v2f X01, Y01, B01 = {0.0f, 0.0f}, X23, Y23, B23 = {0.0f, 0.0f};
-                to_xyb_px2(a.k, v2f{lin[0][r][0], lin[0][r][1]}, v2f{lin[1][r][0], lin[1][r][1]}, v2f{lin[2][r][0], lin[2][r][1]}, nb, X01, Y01, B01);
-                to_xyb_px2(a.k, v2f{lin[0][r][2], lin[0][r][3]}, v2f{lin[1][r][2], lin[1][r][3]}, v2f{lin[2][r][2], lin[2][r][3]}, nb, X23, Y23, B23);
-                if (FAST || y0 + r < a.h) {
-                    const size_t o = (size_t)(y0 + r) * a.w + x0;
-                    pyr_put4(o0[0], o, FAST, a.w - x0, X01.x, X01.y, X23.x, X23.y);
-                    pyr_put4(o0[1], o, FAST, a.w - x0, Y01.x, Y01.y, Y23.x, Y23.y);
-                    pyr_put4(o0[2], o, FAST, a.w - x0, B01.x, B01.y, B23.x, B23.y);
-                }
-            }
-        }
-        // scale 1: 2x2 box of linear RGB, summed ((a+b)+c)+d (:186-200), then XYB
-        float l1[3][2][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    l1[c][j][i] = (((lin[c][2 * j][2 * i] + lin[c][2 * j][2 * i + 1]) + lin[c][2 * j + 1][2 * i]) + lin[c][2 * j + 1][2 * i + 1]) * 0.25f;
-        {
-            const bool nb = o1[2] != nullptr;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                v2f X, Y, B = {0.0f, 0.0f};
-                to_xyb_px2(a.k, v2f{l1[0][j][0], l1[0][j][1]}, v2f{l1[1][j][0], l1[1][j][1]}, v2f{l1[2][j][0], l1[2][j][1]}, nb, X, Y, B);
-                const int x = 2 * bx, y = 2 * by + j;
-                if (FAST || y < a.h1) {
-                    const size_t o = (size_t)y * a.w1 + x;
-                    const bool two = FAST || x + 1 < a.w1;
-                    if (FAST && (a.w1 & 1) == 0) {  // 8-byte stores: every row of scale 1 starts 8-byte aligned
-                        typedef v2f VSZIP_GLOBAL *G2;
-                        if (o1[0]) *reinterpret_cast<G2>(o1[0] + o) = X;
-                        if (o1[1]) *reinterpret_cast<G2>(o1[1] + o) = Y;
-                        if (nb) *reinterpret_cast<G2>(o1[2] + o) = B;
-                    } else {
-                        if (o1[0]) { o1[0][o] = X.x; if (two) o1[0][o + 1] = X.y; }
-                        if (o1[1]) { o1[1][o] = Y.x; if (two) o1[1][o + 1] = Y.y; }
-                        if (nb) { o1[2][o] = B.x; if (two) o1[2][o + 1] = B.y; }
-                    }
-                }
-            }
-        }
-        // scale 2: one sample; a missing scale-1 column / row takes its neighbour (the same clamp one level up)
-        if (FAST || (bx < a.w2 && by < a.h2)) {
-            const bool i1 = FAST || 2 * bx + 1 < a.w1, j1 = FAST || 2 * by + 1 < a.h1;
-            const size_t o = (size_t)by * a.w2 + bx;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                // selects, not l1[c][j1][i1]: a runtime index would move the array out of the registers
-                const float p00 = l1[c][0][0], p01 = i1 ? l1[c][0][1] : l1[c][0][0];
-                const float p10 = j1 ? l1[c][1][0] : l1[c][0][0];
-                const float p11 = j1 ? (i1 ? l1[c][1][1] : l1[c][1][0]) : p01;
-                o2[c][o] = (((p00 + p01) + p10) + p11) * 0.25f;
-            }
-        }
+        pyr_emit<FAST>(a, o0, o1, o2, lin, bx, by);
     }
 }
 
@@ -394,6 +403,232 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
         if (bx * 4 >= a.w || by * 4 >= a.h) return;
         pyr_image<T, MODE, GRAY, false>(a, f1, lds_lut, use_lds, bx, by);
         pyr_image<T, MODE, GRAY, false>(a, f2, lds_lut, use_lds, bx, by);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// YUV sources (round 3): hz.toRGBS on a subsampled clip, fused into the same pass. Per frame and workgroup
+// (256 x 16 luma samples): phase A brings the chroma rows the block needs to full WIDTH (zimg's horizontal pass
+// comes first when both axes double) and parks them in LDS — thread t owns luma column X0 + t, its 4 taps and
+// coefficients come from the per-axis tables of vszip_resample_table; phase B is pyr_image's job with a different
+// front end: a thread reads its 4x4 luma block, finishes the chroma with the vertical 4-tap pass from LDS,
+// applies zimg's integer -> float conversion, the YUV -> RGB matrix (FMA chain) and the transfer table.
+// Every f32 operation is the one oracle/vs_host.py::yuv_to_rgbs performs, in its order: bit-exact.
+// ---------------------------------------------------------------------------------------------
+struct YuvArgs {
+    const int *hleft, *vleft;      // [w], [h]: first tap of a luma column / row in the chroma plane (NULL: axis not subsampled)
+    const float *hcoef, *vcoef;    // [4 w], [4 h]
+    int cstride, cw, ch;           // chroma row pitch (elements) and size
+    float ys, yo, cs, co;          // integer -> float: fma(v, ys, yo) for luma, fma(v, cs, co) for chroma
+    float m[9];                    // YUV -> RGB, row major
+    int linearize;                 // 0: _Transfer == LINEAR
+};
+
+constexpr int kYuvRows = 16;  // chroma rows a 16-row luma block can need: 16 (not subsampled vertically) or <= 8 + 3 + 1
+
+__device__ __forceinline__ float yuv_two_acc(float c0, float c1, float c2, float c3, float x0, float x1, float x2, float x3) {
+    float a0 = c0 * x0, a1 = c1 * x1;
+    a0 = fmaf(c2, x2, a0);
+    a1 = fmaf(c3, x3, a1);
+    return a0 + a1;
+}
+
+template <typename T>
+__device__ __forceinline__ float yuv_cvt(T v, float s, float o) {
+    if constexpr (sizeof(T) == 4)
+        return (float)v;
+    else
+        return fmaf((float)v, s, o);
+}
+
+__device__ __forceinline__ float yuv_transfer(float x, const float *lut, int linearize) {
+    if (!linearize) return x;
+    float t = rintf(fmaf(x, 32768.0f, 16384.0f));
+    t = fminf(fmaxf(t, 0.0f), 65536.0f);
+    return lut[(int)t];
+}
+
+template <typename T, bool FAST>
+__device__ __forceinline__ void pyr_image_yuv(const PyrArgs &a, const YuvArgs &ya, const PyrPtrs &pp, float (*hbuf)[kYuvRows][256], int bx, int by) {
+    typedef const T __attribute__((address_space(1))) *GSrc;
+    const GSrc src[3] = {(GSrc)pp.src[0], (GSrc)pp.src[1], (GSrc)pp.src[2]};
+    const PyrGOut o0[3] = {(PyrGOut)pp.o0[0], (PyrGOut)pp.o0[1], (PyrGOut)pp.o0[2]};
+    const PyrGOut o1[3] = {(PyrGOut)pp.o1[0], (PyrGOut)pp.o1[1], (PyrGOut)pp.o1[2]};
+    const PyrGOut o2[3] = {(PyrGOut)pp.o2[0], (PyrGOut)pp.o2[1], (PyrGOut)pp.o2[2]};
+    const int X0 = blockIdx.x * 256, Y0 = blockIdx.y * 16;
+    const int ylast = min(Y0 + 15, a.h - 1);
+    const int r0 = ya.vleft ? ya.vleft[Y0] : Y0;
+    const int r1 = ya.vleft ? min(ya.vleft[ylast] + 3, ya.ch - 1) : ylast;
+    // ---- phase A: chroma rows r0 .. r1 at full width into hbuf[plane][row - r0][column - X0]
+    {
+        const int t = threadIdx.x;
+        const int X = min(X0 + t, a.w - 1);
+        int hl = X;
+        float c0 = 1.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+        if (ya.hleft) {
+            hl = ya.hleft[X];
+            const v4f c = *reinterpret_cast<const v4f *>(ya.hcoef + 4 * (size_t)X);
+            c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+        }
+        const int i0 = hl, i1 = min(hl + 1, ya.cw - 1), i2 = min(hl + 2, ya.cw - 1), i3 = min(hl + 3, ya.cw - 1);
+        for (int r = r0; r <= r1; ++r) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const GSrc row = src[1 + pl] + (size_t)r * ya.cstride;
+                float v;
+                if (ya.hleft) {
+                    const T q0 = row[i0], q1 = row[i1], q2 = row[i2], q3 = row[i3];
+                    v = yuv_two_acc(c0, c1, c2, c3, yuv_cvt<T>(q0, ya.cs, ya.co), yuv_cvt<T>(q1, ya.cs, ya.co), yuv_cvt<T>(q2, ya.cs, ya.co), yuv_cvt<T>(q3, ya.cs, ya.co));
+                } else {
+                    v = yuv_cvt<T>(row[i0], ya.cs, ya.co);
+                }
+                hbuf[pl][r - r0][t] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: the thread's 4x4 block
+    if (FAST || (bx * 4 < a.w && by * 4 < a.h)) {
+        const int x0 = bx * 4, y0 = by * 4;
+        const int lx = x0 - X0;  // local column of the block in hbuf
+        float lin[3][4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = FAST ? y0 + r : min(y0 + r, a.h - 1);
+            // luma row
+            float yy[4];
+            {
+                const GSrc row = src[0] + (size_t)y * a.sstride;
+                if constexpr (FAST) {
+                    if constexpr (sizeof(T) == 4) {
+                        const v4f q = *reinterpret_cast<const v4f VSZIP_GLOBAL *>(row + x0);
+                        yy[0] = q.x; yy[1] = q.y; yy[2] = q.z; yy[3] = q.w;
+                    } else if constexpr (sizeof(T) == 2) {
+                        const v2u q = *reinterpret_cast<const v2u VSZIP_GLOBAL *>(row + x0);
+                        yy[0] = yuv_cvt<uint16_t>((uint16_t)(q.x & 0xffffu), ya.ys, ya.yo); yy[1] = yuv_cvt<uint16_t>((uint16_t)(q.x >> 16), ya.ys, ya.yo);
+                        yy[2] = yuv_cvt<uint16_t>((uint16_t)(q.y & 0xffffu), ya.ys, ya.yo); yy[3] = yuv_cvt<uint16_t>((uint16_t)(q.y >> 16), ya.ys, ya.yo);
+                    } else {
+                        const uint32_t q = *reinterpret_cast<const uint32_t __attribute__((address_space(1))) *>(row + x0);
+                        yy[0] = yuv_cvt<uint8_t>((uint8_t)(q & 0xffu), ya.ys, ya.yo); yy[1] = yuv_cvt<uint8_t>((uint8_t)((q >> 8) & 0xffu), ya.ys, ya.yo);
+                        yy[2] = yuv_cvt<uint8_t>((uint8_t)((q >> 16) & 0xffu), ya.ys, ya.yo); yy[3] = yuv_cvt<uint8_t>((uint8_t)(q >> 24), ya.ys, ya.yo);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) yy[i] = yuv_cvt<T>(row[min(x0 + i, a.w - 1)], ya.ys, ya.yo);
+                }
+            }
+            // chroma: vertical pass over the LDS rows (wave-uniform row and coefficients)
+            float uv[2][4];
+            {
+                int vl = y - r0;
+                float c0 = 1.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+                if (ya.vleft) {
+                    vl = ya.vleft[y] - r0;
+                    const v4f c = *reinterpret_cast<const v4f *>(ya.vcoef + 4 * (size_t)y);
+                    c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+                }
+                const int nr = r1 - r0;
+                const int j0 = vl, j1 = min(vl + 1, nr), j2 = min(vl + 2, nr), j3 = min(vl + 3, nr);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (ya.vleft) {
+                        float t0[4], t1[4], t2[4], t3[4];
+                        if constexpr (FAST) {
+                            const v4f q0 = *reinterpret_cast<const v4f *>(&hbuf[pl][j0][lx]), q1 = *reinterpret_cast<const v4f *>(&hbuf[pl][j1][lx]);
+                            const v4f q2 = *reinterpret_cast<const v4f *>(&hbuf[pl][j2][lx]), q3 = *reinterpret_cast<const v4f *>(&hbuf[pl][j3][lx]);
+                            t0[0] = q0.x; t0[1] = q0.y; t0[2] = q0.z; t0[3] = q0.w;
+                            t1[0] = q1.x; t1[1] = q1.y; t1[2] = q1.z; t1[3] = q1.w;
+                            t2[0] = q2.x; t2[1] = q2.y; t2[2] = q2.z; t2[3] = q2.w;
+                            t3[0] = q3.x; t3[1] = q3.y; t3[2] = q3.z; t3[3] = q3.w;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int c = min(lx + i, min(a.w - 1 - X0, 255));
+                                t0[i] = hbuf[pl][j0][c]; t1[i] = hbuf[pl][j1][c]; t2[i] = hbuf[pl][j2][c]; t3[i] = hbuf[pl][j3][c];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) uv[pl][i] = yuv_two_acc(c0, c1, c2, c3, t0[i], t1[i], t2[i], t3[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) uv[pl][i] = hbuf[pl][j0][FAST ? lx + i : min(lx + i, min(a.w - 1 - X0, 255))];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float g = fmaf(ya.m[3 * c + 2], uv[1][i], fmaf(ya.m[3 * c + 1], uv[0][i], ya.m[3 * c] * yy[i]));
+                    lin[c][r][i] = yuv_transfer(g, a.lut, ya.linearize);
+                }
+            }
+        }
+        pyr_emit<FAST>(a, o0, o1, o2, lin, bx, by);
+    }
+    __syncthreads();  // hbuf is reused by the other frame
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ssim_pyr_yuv_kernel(const PyrArgs a, const YuvArgs ya) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][kYuvRows][256];
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const PyrPair *__restrict__ tp = a.tab + blockIdx.z;
+    PyrPtrs f1, f2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f1.src[c] = tp->src1[c]; f1.o0[c] = tp->x0a[c]; f1.o1[c] = tp->x1a[c]; f1.o2[c] = tp->r2a[c];
+        f2.src[c] = tp->src2[c]; f2.o0[c] = tp->x0b[c]; f2.o1[c] = tp->x1b[c]; f2.o2[c] = tp->r2b[c];
+    }
+    const bool fast = a.vec_ok && (int)(blockIdx.x + 1) * 256 <= a.w && (int)(blockIdx.y + 1) * 16 <= a.h;
+    if (fast) {
+        pyr_image_yuv<T, true>(a, ya, f1, hbuf, bx, by);
+        pyr_image_yuv<T, true>(a, ya, f2, hbuf, bx, by);
+    } else {
+        pyr_image_yuv<T, false>(a, ya, f1, hbuf, bx, by);
+        pyr_image_yuv<T, false>(a, ya, f2, hbuf, bx, by);
+    }
+}
+
+// The YUV pre-stage alone (vszip_to_rgbs_linear): one thread per output sample, everything from global memory
+// (16 chroma taps per plane through the caches) — the mixed-format fallback and the tests' view of the conversion.
+template <typename T>
+__global__ __launch_bounds__(256) void yuv_to_rgbs_kernel(const void *s0, const void *s1, const void *s2, float *d0, float *d1, float *d2, int sstride, int dstride, int w, int h,
+                                                          const float *lut, const YuvArgs ya) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const T *src[3] = {static_cast<const T *>(s0), static_cast<const T *>(s1), static_cast<const T *>(s2)};
+    int hl = x, vl = y;
+    float hc[4] = {1.0f, 0.0f, 0.0f, 0.0f}, vc[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    if (ya.hleft) {
+        hl = ya.hleft[x];
+        for (int k = 0; k < 4; ++k) hc[k] = ya.hcoef[4 * (size_t)x + k];
+    }
+    if (ya.vleft) {
+        vl = ya.vleft[y];
+        for (int k = 0; k < 4; ++k) vc[k] = ya.vcoef[4 * (size_t)y + k];
+    }
+    float uv[2];
+    for (int pl = 0; pl < 2; ++pl) {
+        float rows[4];
+        const int nrows = ya.vleft ? 4 : 1;
+        for (int j = 0; j < nrows; ++j) {
+            const T *row = src[1 + pl] + (size_t)min(vl + j, ya.ch - 1) * ya.cstride;
+            if (ya.hleft) {
+                float t[4];
+                for (int k = 0; k < 4; ++k) t[k] = yuv_cvt<T>(row[min(hl + k, ya.cw - 1)], ya.cs, ya.co);
+                rows[j] = yuv_two_acc(hc[0], hc[1], hc[2], hc[3], t[0], t[1], t[2], t[3]);
+            } else {
+                rows[j] = yuv_cvt<T>(row[hl], ya.cs, ya.co);
+            }
+        }
+        uv[pl] = ya.vleft ? yuv_two_acc(vc[0], vc[1], vc[2], vc[3], rows[0], rows[1], rows[2], rows[3]) : rows[0];
+    }
+    const float yy = yuv_cvt<T>(src[0][(size_t)y * sstride + x], ya.ys, ya.yo);
+    float *dst[3] = {d0, d1, d2};
+    for (int c = 0; c < 3; ++c) {
+        const float g = fmaf(ya.m[3 * c + 2], uv[1], fmaf(ya.m[3 * c + 1], uv[0], ya.m[3 * c] * yy));
+        dst[c][(size_t)y * dstride + x] = yuv_transfer(g, lut, ya.linearize);
     }
 }
 
@@ -803,8 +1038,8 @@ double score_of(const double avg[18][6]) {  // ssimulacra2.zig:630-663; slot = s
 // (oracle/vs_host.py, tests/test_oracle_vs_host.py).
 static float srgb_eotf_f32(float xf) {
     const double A = 1.055010718947587, B = 0.003041282560128;
-    const double x = (double)xf;
-    return (float)(x < 12.92 * B ? x / 12.92 : std::pow((std::max(x, 0.0) + (A - 1.0)) / A, 2.4));
+    const double x = std::max((double)xf, 0.0);  // zimg's transfer functions clamp negative input first (round 3: the YUV goldens show it)
+    return (float)(x < 12.92 * B ? x / 12.92 : std::pow((x + (A - 1.0)) / A, 2.4));
 }
 static const std::vector<float> &srgb_table() {
     static const std::vector<float> t = [] {
@@ -832,6 +1067,10 @@ struct SsimLutCache {
     SsimLutKey key{-1, 0, 0, 0};
     float *dev = nullptr;
     size_t entries = 0;
+    // YUV sources: the resampling tables of the clip's geometry (hleft[w] | vleft[h] | hcoef[4 w] | vcoef[4 h])
+    int yw = 0, yh = 0, yssw = -1, yssh = -1, yloc = -1;
+    char *ydev = nullptr;
+    size_t ybytes = 0;
 };
 
 SsimLutCache *lut_cache_of(vszip_ctx *ctx) {
@@ -853,6 +1092,7 @@ void vszip_ssim_release(vszip_ctx *ctx) {
     if (!ctx->ssim_lut) return;
     SsimLutCache *c = static_cast<SsimLutCache *>(ctx->ssim_lut);
     if (c->dev) (void)hipFree(c->dev);
+    if (c->ydev) (void)hipFree(c->ydev);
     delete c;
     ctx->ssim_lut = nullptr;
 }
@@ -861,9 +1101,16 @@ void vszip_ssim_release(vszip_ctx *ctx) {
 static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_out, bool *gray_out, const float **lut_out, int *lds_out) {
     const bool gray = fmt->family == VSZIP_CF_GRAY;
     *gray_out = gray;
-    if (fmt->family != VSZIP_CF_RGB && !gray) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "SSIMULACRA2: colour family %d has no device pre-stage", fmt->family);
+    const bool yuv = fmt->family == VSZIP_CF_YUV;
+    if (fmt->family != VSZIP_CF_RGB && !gray && !yuv) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "SSIMULACRA2: colour family %d has no device pre-stage", fmt->family);
     int &mode = *mode_out;
-    if (fmt->dtype == VSZIP_F32) {
+    if (yuv) {
+        mode = PYR_YUV;
+        if (fmt->dtype != VSZIP_F32 && fmt->dtype != VSZIP_U8 && fmt->dtype != VSZIP_U16) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "SSIMULACRA2: sample type %d", fmt->dtype);
+        if (fmt->dtype != VSZIP_F32 && (fmt->bits < 8 || fmt->bits > (fmt->dtype == VSZIP_U8 ? 8 : 16))) return vszip_set_error(ctx, VSZIP_ERR_ARG, "SSIMULACRA2: %d-bit samples in this container", fmt->bits);
+        if (fmt->ssw < 0 || fmt->ssw > 2 || fmt->ssh < 0 || fmt->ssh > 2 || fmt->chroma_loc < 0 || fmt->chroma_loc > 5) return vszip_set_error(ctx, VSZIP_ERR_ARG, "SSIMULACRA2: chroma layout %d/%d/%d", fmt->ssw, fmt->ssh, fmt->chroma_loc);
+        if (fmt->matrix != 1 && fmt->matrix != 5 && fmt->matrix != 6 && fmt->matrix != 9) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "SSIMULACRA2: _Matrix %d has no device pre-stage", fmt->matrix);
+    } else if (fmt->dtype == VSZIP_F32) {
         mode = fmt->linearize ? PYR_F32_GAMMA : PYR_F32_LINEAR;
     } else if (fmt->dtype == VSZIP_U8 || fmt->dtype == VSZIP_U16) {
         mode = PYR_INT;
@@ -878,21 +1125,22 @@ static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_
     int &lut_lds = *lds_out;
     lut_dev = nullptr;
     lut_lds = 0;
-    if (mode != PYR_F32_LINEAR) {
+    if (mode != PYR_F32_LINEAR && !(mode == PYR_YUV && !fmt->linearize)) {
         SsimLutCache *lc = lut_cache_of(ctx);
-        const SsimLutKey key{mode, fmt->bits, fmt->limited, fmt->linearize};
+        // (a YUV clip's samples go through arithmetic first: it shares the f32 transfer table)
+        const SsimLutKey key = mode == PYR_YUV ? SsimLutKey{PYR_F32_GAMMA, 32, 0, 1} : SsimLutKey{mode, fmt->bits, fmt->limited, fmt->linearize};
         if (!(lc->key == key)) {
             std::vector<float> host;
-            if (mode == PYR_F32_GAMMA) {
+            if (mode == PYR_F32_GAMMA || mode == PYR_YUV) {
                 host = srgb_table();
             } else {
-                // zimg integer -> float: (v - offset) * f32(1 / range); then the transfer table
+                // zimg integer -> float as its x86 kernels do it: fma(v, f32(1 / range), f32(-offset / range)); then the transfer table
                 const int off = fmt->limited ? (16 << (fmt->bits - 8)) : 0;
                 const int rng = fmt->limited ? (219 << (fmt->bits - 8)) : ((1 << fmt->bits) - 1);
-                const float sc = (float)(1.0 / rng);
+                const float sc = (float)(1.0 / rng), so = (float)(-(double)off / rng);
                 host.resize((size_t)1 << fmt->bits);
                 for (size_t v = 0; v < host.size(); ++v) {
-                    const float x = ((float)v - (float)off) * sc;
+                    const float x = std::fmaf((float)v, sc, so);
                     host[v] = fmt->linearize ? srgb_lookup(x) : x;
                 }
             }
@@ -915,6 +1163,81 @@ static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_
     return VSZIP_OK;
 }
 
+// YUV sources: the kernel arguments of one clip geometry — resampling tables resident (cached in the context),
+// zimg's conversion constants and matrix.
+static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, int h, YuvArgs *ya) {
+    const int cw = (w + (1 << fmt->ssw) - 1) >> fmt->ssw, ch = (h + (1 << fmt->ssh) - 1) >> fmt->ssh;
+    SsimLutCache *lc = lut_cache_of(ctx);
+    const size_t off_v = (size_t)w * 4, off_hc = off_v + (size_t)h * 4, off_vc = off_hc + (size_t)w * 16, bytes = off_vc + (size_t)h * 16;
+    if (!(lc->yw == w && lc->yh == h && lc->yssw == fmt->ssw && lc->yssh == fmt->ssh && lc->yloc == fmt->chroma_loc)) {
+        std::vector<char> host(bytes);
+        // position of a chroma sample relative to the centre of its 2^ss luma samples, in luma samples
+        auto offset = [&](int ss, bool vertical) -> double {
+            if (ss == 0) return 0.0;
+            const double edge = -((1 << ss) - 1) / 2.0;
+            const int loc = fmt->chroma_loc;
+            if (vertical) return (loc == 2 || loc == 3) ? edge : ((loc == 4 || loc == 5) ? -edge : 0.0);
+            return (loc == 0 || loc == 2 || loc == 4) ? edge : 0.0;
+        };
+        if (fmt->ssw) {
+            const int rc = vszip_resample_table(cw, w, -offset(fmt->ssw, false) / (1 << fmt->ssw), reinterpret_cast<int32_t *>(host.data()), reinterpret_cast<float *>(host.data() + off_hc));
+            if (rc != VSZIP_OK) return vszip_set_error(ctx, rc, "SSIMULACRA2: no horizontal resampling table for %d -> %d", cw, w);
+        }
+        if (fmt->ssh) {
+            const int rc = vszip_resample_table(ch, h, -offset(fmt->ssh, true) / (1 << fmt->ssh), reinterpret_cast<int32_t *>(host.data() + off_v), reinterpret_cast<float *>(host.data() + off_vc));
+            if (rc != VSZIP_OK) return vszip_set_error(ctx, rc, "SSIMULACRA2: no vertical resampling table for %d -> %d", ch, h);
+        }
+        VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a launch still reading the old tables
+        if (lc->ybytes < bytes) {
+            if (lc->ydev) (void)hipFree(lc->ydev);
+            lc->ydev = nullptr;
+            lc->ybytes = 0;
+            VSZIP_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&lc->ydev), bytes));
+            lc->ybytes = bytes;
+        }
+        VSZIP_HIP_CHECK(ctx, hipMemcpy(lc->ydev, host.data(), bytes, hipMemcpyHostToDevice));
+        lc->yw = w; lc->yh = h; lc->yssw = fmt->ssw; lc->yssh = fmt->ssh; lc->yloc = fmt->chroma_loc;
+    }
+    ya->hleft = fmt->ssw ? reinterpret_cast<const int *>(lc->ydev) : nullptr;
+    ya->vleft = fmt->ssh ? reinterpret_cast<const int *>(lc->ydev + off_v) : nullptr;
+    ya->hcoef = reinterpret_cast<const float *>(lc->ydev + off_hc);
+    ya->vcoef = reinterpret_cast<const float *>(lc->ydev + off_vc);
+    ya->cstride = (int)fmt->chroma_stride;
+    ya->cw = cw;
+    ya->ch = ch;
+    // zimg integer -> float: fma(v, f32(1 / range), f32(-offset / range))
+    if (fmt->dtype == VSZIP_F32) {
+        ya->ys = ya->cs = 1.0f;
+        ya->yo = ya->co = 0.0f;
+    } else {
+        const int b = fmt->bits;
+        const double yoff = fmt->limited ? (double)(16 << (b - 8)) : 0.0, yrng = fmt->limited ? (double)(219 << (b - 8)) : (double)((1 << b) - 1);
+        const double coff = fmt->limited ? (double)(128 << (b - 8)) : (double)(1 << (b - 1)), crng = fmt->limited ? (double)(224 << (b - 8)) : (double)((1 << b) - 1);
+        ya->ys = (float)(1.0 / yrng); ya->yo = (float)(-yoff / yrng);
+        ya->cs = (float)(1.0 / crng); ya->co = (float)(-coff / crng);
+    }
+    // zimg's YUV -> RGB: the inverse (by cofactors, f64) of the non-constant-luminance RGB -> YUV matrix, rounded to f32
+    {
+        double kr, kb;
+        switch (fmt->matrix) {
+            case 1: kr = 0.2126; kb = 0.0722; break;
+            case 9: kr = 0.2627; kb = 0.0593; break;
+            default: kr = 0.299; kb = 0.114; break;  // 5, 6
+        }
+        const double kg = 1.0 - kr - kb, us = 1.0 / (2.0 - 2.0 * kb), vs = 1.0 / (2.0 - 2.0 * kr);
+        const double m[3][3] = {{kr, kg, kb}, {-kr * us, -kg * us, (1.0 - kb) * us}, {(1.0 - kr) * vs, -kg * vs, -kb * vs}};
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const int r0 = j == 0 ? 1 : 0, r1 = j == 2 ? 1 : 2, c0 = i == 0 ? 1 : 0, c1 = i == 2 ? 1 : 2;
+                const double minor = m[r0][c0] * m[r1][c1] - m[r0][c1] * m[r1][c0];
+                ya->m[3 * i + j] = (float)((((i + j) & 1) ? -1.0 : 1.0) * minor / det);
+            }
+    }
+    ya->linearize = fmt->linearize;
+    return VSZIP_OK;
+}
+
 // Scratch per pair (floats): the XYB planes scales 0 and 1 need (2 n0 + 4 n1: Y of scale 0; X, Y of
 // scale 1), the scale-2 linear RGB (6 n2), the XYB planes of one later scale at a time (6 n2) and the RGB
 // of scales 3 / 4 (6 n3 + 6 n4) — 130 MB per 4K pair.
@@ -928,6 +1251,11 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     if (rc != VSZIP_OK) return rc;
     const int nsp = gray ? 1 : 3;
     static const XybK kx = make_xyb_consts();
+    YuvArgs ya{};
+    if (mode == PYR_YUV) {
+        rc = ssim_yuv_args(ctx, fmt, w, h, &ya);
+        if (rc != VSZIP_OK) return rc;
+    }
 
     int sw[kScales + 1], sh[kScales + 1];
     sw[0] = w;
@@ -1029,7 +1357,14 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         pa.h2 = sh[2];
         pa.k = kx;
         const dim3 grid((w + 255) / 256, (h + 15) / 16, cnt);
-        if (mode == PYR_F32_LINEAR)
+        if (mode == PYR_YUV) {
+            if (fmt->dtype == VSZIP_F32)
+                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<float>, grid, dim3(256), 0, main_st, pa, ya);
+            else if (fmt->dtype == VSZIP_U8)
+                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<uint8_t>, grid, dim3(256), 0, main_st, pa, ya);
+            else
+                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<uint16_t>, grid, dim3(256), 0, main_st, pa, ya);
+        } else if (mode == PYR_F32_LINEAR)
             launch_pyr<float, PYR_F32_LINEAR>(gray, grid, main_st, pa);
         else if (mode == PYR_F32_GAMMA)
             launch_pyr<float, PYR_F32_GAMMA>(gray, grid, main_st, pa);
@@ -1193,6 +1528,19 @@ VSZIP_EXPORT int vszip_to_rgbs_linear(vszip_ctx *ctx, const vszip_ssim_source *f
     if (rc != VSZIP_OK) return rc;
     const dim3 grid((w + 255) / 256, h);
     const void *s0 = src_planes[0], *s1 = gray ? nullptr : src_planes[1], *s2 = gray ? nullptr : src_planes[2];
+    if (mode == PYR_YUV) {
+        YuvArgs ya{};
+        const int yrc = ssim_yuv_args(ctx, fmt, w, h, &ya);
+        if (yrc != VSZIP_OK) return yrc;
+        if (fmt->dtype == VSZIP_F32)
+            hipLaunchKernelGGL(yuv_to_rgbs_kernel<float>, grid, dim3(256), 0, ctx->stream, s0, s1, s2, dst3[0], dst3[1], dst3[2], (int)src_stride, (int)dst_stride, w, h, lut, ya);
+        else if (fmt->dtype == VSZIP_U8)
+            hipLaunchKernelGGL(yuv_to_rgbs_kernel<uint8_t>, grid, dim3(256), 0, ctx->stream, s0, s1, s2, dst3[0], dst3[1], dst3[2], (int)src_stride, (int)dst_stride, w, h, lut, ya);
+        else
+            hipLaunchKernelGGL(yuv_to_rgbs_kernel<uint16_t>, grid, dim3(256), 0, ctx->stream, s0, s1, s2, dst3[0], dst3[1], dst3[2], (int)src_stride, (int)dst_stride, w, h, lut, ya);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        return VSZIP_OK;
+    }
 #define VSZIP_TO_RGBS(T, MODE)                                                                                                                              \
     do {                                                                                                                                                    \
         if (gray)                                                                                                                                           \

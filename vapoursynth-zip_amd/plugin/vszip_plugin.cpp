@@ -1103,9 +1103,14 @@ struct LimitFilterData {
     float dark[3], bright[3], elast[3];
 };
 
-// hz.getColorRange (helper.zig:261-279): frame 0's range prop, else RGB -> full, others -> limited.
-// The prop is read through the un-vendored vapoursynth-zig binding; both spellings are honoured here:
-// _Range (1 = full, 0 = limited) and the older _ColorRange (0 = full, 1 = limited).
+// hz.getColorRange (helper.zig:261-279): frame 0's range prop, else RGB -> full, others -> limited — AS THE REFERENCE'S BUILD
+// RESOLVES IT. The prop is read through the un-vendored vapoursynth-zig binding, and the reference's own goldens show what comes
+// out: all 38 integer LimitFilter keys (tests/goldens/limitfilter.json, GRAY16 and YUV420P16 clips that zimg produced and flagged
+// limited range) carry thresholds scaled by 257 = the FULL-range branch of hz.scaleValue; the limited branch (x 256) misses
+// them by up to 8e-5 (tests/test_oracle_zimg_goldens.py::test_limit_filter_keys). So a clip flagged limited resolves to .FULL
+// there — the binding's enum order is the inverse of the prop's — and, by the same mapping, a clip flagged full to .LIMITED.
+// Mirrored here, because results must be the reference's: _ColorRange (0 = full, 1 = limited) and the newer _Range
+// (1 = full, 0 = limited) both map to the OPPOSITE range; only a clip without the prop takes the documented default.
 bool clip_is_limited_range(const Z &z, VSNode *node) {
     char err[256];
     const VSFrame *f0 = z.api->getFrame(0, node, err, sizeof err);
@@ -1113,12 +1118,12 @@ bool clip_is_limited_range(const Z &z, VSNode *node) {
     if (f0) {
         const VSMap *props = z.api->getFramePropertiesRO(f0);
         int e = 0;
-        const int64_t r = z.api->mapGetInt(props, "_Range", 0, &e);
-        if (!e) limited = r == 0;
+        const int64_t c = z.api->mapGetInt(props, "_ColorRange", 0, &e);
+        if (!e) limited = c == 0;  // flagged full -> .LIMITED, flagged limited -> .FULL (see above)
         if (limited < 0) {
             e = 0;
-            const int64_t c = z.api->mapGetInt(props, "_ColorRange", 0, &e);
-            if (!e) limited = c == 1;
+            const int64_t r = z.api->mapGetInt(props, "_Range", 0, &e);
+            if (!e) limited = r == 1;
         }
         z.api->freeFrame(f0);
     }
@@ -1442,8 +1447,9 @@ bool ssim_device_source(const Z &z, VSNode *node, vszip_ssim_source *fmt) {
     const VSVideoInfo *vi = api->getVideoInfo(node);
     const VSVideoFormat &f = vi->format;
     if (!is_constant_format(vi)) return false;
-    if (f.colorFamily != cfRGB && f.colorFamily != cfGray) return false;
-    if (f.subSamplingW || f.subSamplingH) return false;
+    if (f.colorFamily != cfRGB && f.colorFamily != cfGray && f.colorFamily != cfYUV) return false;
+    if (f.colorFamily != cfYUV && (f.subSamplingW || f.subSamplingH)) return false;
+    if (f.subSamplingW > 2 || f.subSamplingH > 2) return false;
     int dt;
     if (f.sampleType == stInteger && f.bitsPerSample >= 8 && f.bitsPerSample <= 16)
         dt = f.bytesPerSample == 1 ? VSZIP_U8 : VSZIP_U16;
@@ -1458,15 +1464,27 @@ bool ssim_device_source(const Z &z, VSNode *node, vszip_ssim_source *fmt) {
     const VSFrame *f0 = api->getFrame(0, probe.root, err, sizeof err);
     free_chain(api, probe);
     if (!f0) return false;
-    int e1 = 0, e2 = 0;
+    int e1 = 0, e2 = 0, e3 = 0, e4 = 0;
     const VSMap *props = api->getFramePropertiesRO(f0);
     const int64_t transfer = api->mapGetInt(props, "_Transfer", 0, &e1);
     const int64_t range = api->mapGetInt(props, "_ColorRange", 0, &e2);
+    const int64_t matrix = api->mapGetInt(props, "_Matrix", 0, &e3);
+    const int64_t chroma_loc = api->mapGetInt(props, "_ChromaLocation", 0, &e4);
     api->freeFrame(f0);
-    fmt->family = f.colorFamily == cfGray ? VSZIP_CF_GRAY : VSZIP_CF_RGB;
+    *fmt = vszip_ssim_source{};
+    fmt->family = f.colorFamily == cfGray ? VSZIP_CF_GRAY : (f.colorFamily == cfYUV ? VSZIP_CF_YUV : VSZIP_CF_RGB);
     fmt->dtype = dt;
     fmt->bits = f.bitsPerSample;
-    fmt->limited = dt == VSZIP_F32 ? 0 : (e2 ? (f.colorFamily == cfGray ? 1 : 0) : (range == 1 ? 1 : 0));
+    fmt->limited = dt == VSZIP_F32 ? 0 : (e2 ? (f.colorFamily == cfRGB ? 0 : 1) : (range == 1 ? 1 : 0));
+    if (f.colorFamily == cfYUV) {
+        // hz.toRGBS passes matrix_in = 709 above 650 rows, else 601 (src/helper.zig:231) — and VapourSynth's resize lets a
+        // specified _Matrix frame property win over that argument (the reference's YUV goldens are only met that way)
+        fmt->matrix = (!e3 && matrix != 2) ? (int)matrix : (vi->height > 650 ? 1 : 6);
+        fmt->chroma_loc = e4 ? 0 : (int)chroma_loc;
+        fmt->ssw = f.subSamplingW;
+        fmt->ssh = f.subSamplingH;
+        if ((fmt->matrix != 1 && fmt->matrix != 5 && fmt->matrix != 6 && fmt->matrix != 9) || fmt->chroma_loc < 0 || fmt->chroma_loc > 5) return false;  // the host's resize
+    }
     fmt->linearize = (!e1 && transfer == 8) ? 0 : 1;
     return true;
 }
@@ -1476,20 +1494,24 @@ const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFram
     Z z{api, core, fctx};
     VSNode *in1 = d->raw1 ? d->c1.root : nullptr;            // reference planes for the score (nullptr: node1's RGBS frame)
     VSNode *in2 = d->raw2 ? d->c2.root : d->node2;           // distorted planes
-    const bool shared_root = in1 && in1 == in2;               // e.g. SSIMULACRA2(src, src.Bilateral().BoxBlur()): one upload
+    // e.g. SSIMULACRA2(src, src.Bilateral().BoxBlur()): both inputs come from one node -> one request, one frame. The UPLOAD is
+    // shared only when both sides take the raw path; with raw1 set and raw2 not (lin.BoxBlur().SSIMULACRA2(lin) on a linear RGBS
+    // clip) the distorted planes are that same frame uploaded as host RGBS (it used to be a null frame).
+    const bool same_node = in1 && in1 == in2;
+    const bool shared_root = same_node && d->raw1 && d->raw2;
     if (reason == arInitial) {
         api->requestFrameFilter(n, d->node1, fctx);
         if (in1) api->requestFrameFilter(n, in1, fctx);
-        if (!shared_root) api->requestFrameFilter(n, in2, fctx);
+        if (!same_node) api->requestFrameFilter(n, in2, fctx);
     } else if (reason == arAllFramesReady) {
         const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx);
         const VSFrame *r1 = in1 ? api->getFrameFilter(n, in1, fctx) : nullptr;
-        const VSFrame *s2 = shared_root ? nullptr : api->getFrameFilter(n, in2, fctx);
+        const VSFrame *s2 = same_node ? r1 : api->getFrameFilter(n, in2, fctx);  // (same_node: one frame, released once)
         VSFrame *dst = api->copyFrame(s1, core);
         auto done = [&](const VSFrame *r) {
             api->freeFrame(s1);
             if (r1) api->freeFrame(r1);
-            if (s2) api->freeFrame(s2);
+            if (s2 && !same_node) api->freeFrame(s2);
             return r;
         };
         FrameGate gate(n);
@@ -1497,7 +1519,8 @@ const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFram
         if (!g) return done(fail(z, nullptr, dst, "SSIMULACRA2", "no MI355X device available (the plugin has no CPU fallback)"));
         const int w = api->getFrameWidth(s1, 0), h = api->getFrameHeight(s1, 0);
         auto same = [](const vszip_ssim_source &a, const vszip_ssim_source &b) {
-            return a.family == b.family && a.dtype == b.dtype && a.bits == b.bits && a.limited == b.limited && a.linearize == b.linearize;
+            return a.family == b.family && a.dtype == b.dtype && a.bits == b.bits && a.limited == b.limited && a.linearize == b.linearize && a.ssw == b.ssw &&
+                   a.ssh == b.ssh && a.matrix == b.matrix && a.chroma_loc == b.chroma_loc;
         };
         // one clip's planes on the device, as they are: upload (or take the other clip's upload of the same root
         // frame), then the fused upstream stages
@@ -1537,7 +1560,14 @@ const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFram
                 a3[p] = cur1[p].ptr;
                 b3[p] = cur2[p].ptr;
             }
-            rc = vszip_ssimulacra2_src(g->ctx, &d->fmt1, a3, b3, cur1[0].stride, w, h, 1, &score);
+            vszip_ssim_source fm = d->fmt1;
+            bool pitch_ok = cur1[0].stride == cur2[0].stride;
+            if (fm.family == VSZIP_CF_YUV) {
+                fm.chroma_stride = cur1[1].stride;
+                pitch_ok = pitch_ok && cur1[1].stride == cur1[2].stride && cur2[1].stride == cur1[1].stride && cur2[2].stride == cur1[1].stride;
+            }
+            if (!pitch_ok) return done(fail(z, g, dst, "SSIMULACRA2", "device planes of the two clips differ in row pitch"));
+            rc = vszip_ssimulacra2_src(g->ctx, &fm, a3, b3, cur1[0].stride, w, h, 1, &score);
         } else {
             // mixed formats: convert what can be converted on the device, the host's RGBS for the rest
             const float *lin[2][3];
@@ -1560,7 +1590,9 @@ const VSFrame *VS_CC ssimGetFrame(int n, int reason, void *inst, void **, VSFram
                         lin[k][p] = o3[p];
                     }
                     lstride = o[0].stride;
-                    if (vszip_to_rgbs_linear(g->ctx, &fm, p3, cur[0].stride, o3, lstride, w, h) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "colour pre-stage failed"));
+                    vszip_ssim_source fl = fm;
+                    if (fl.family == VSZIP_CF_YUV) fl.chroma_stride = cur[1].stride;
+                    if (vszip_to_rgbs_linear(g->ctx, &fl, p3, cur[0].stride, o3, lstride, w, h) != VSZIP_OK) return done(fail(z, g, dst, "SSIMULACRA2", "colour pre-stage failed"));
                 }
             }
             rc = vszip_ssimulacra2(g->ctx, lin[0], lin[1], lstride, w, h, 1, &score);
