@@ -1002,7 +1002,7 @@ static void VS_CC standin_bicubic(const VSMap *in, VSMap *out, void *, VSCore *c
         const int64_t range = A(mapGetInt)(&f->props, "_ColorRange", 0, &pe);
         const bool limited = sf.sampleType == stInteger && (pe ? sf.colorFamily == cfGray : range == 1);
         const int b = sf.bitsPerSample;
-        const double rng = limited ? (double)(219 << (b - 8)) : (double)((1 << b) - 1);
+        const double rng = sf.sampleType != stInteger ? 1.0 : (limited ? (double)(219 << (b - 8)) : (double)((1 << b) - 1));
         const float off = limited ? (float)(-(double)(16 << (b - 8)) / rng) : 0.0f;
         const float sc = sf.sampleType == stInteger ? (float)(1.0 / rng) : 1.0f;
         for (int p = 0; p < 3; ++p) {

@@ -205,14 +205,19 @@ EXP int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *r, const float *co
 EXP int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *f, const void *const *r, const void *const *d, ptrdiff_t stride, int w, int h, int np, double *scores) {
     const int per = f->family == VSZIP_CF_GRAY ? 1 : 3;
     for (int i = 0; i < per * np; ++i) {
-        touch(r[i], stride, w, h, bps_of(f->dtype), false);
-        touch(d[i], stride, w, h, bps_of(f->dtype), false);
+        const bool chroma = f->family == VSZIP_CF_YUV && i % 3 != 0;  // a subsampled plane has its own pitch and size
+        const int pw = chroma ? (w + (1 << f->ssw) - 1) >> f->ssw : w, ph = chroma ? (h + (1 << f->ssh) - 1) >> f->ssh : h;
+        touch(r[i], chroma ? f->chroma_stride : stride, pw, ph, bps_of(f->dtype), false);
+        touch(d[i], chroma ? f->chroma_stride : stride, pw, ph, bps_of(f->dtype), false);
     }
     for (int i = 0; i < np; ++i) scores[i] = 0;
     return kernel_failed(ctx, "SSIMULACRA2");
 }
 EXP int vszip_to_rgbs_linear(vszip_ctx *ctx, const vszip_ssim_source *f, const void *const *s, ptrdiff_t ss, float *const *d3, ptrdiff_t ds, int w, int h) {
-    for (int i = 0; i < (f->family == VSZIP_CF_GRAY ? 1 : 3); ++i) touch(s[i], ss, w, h, bps_of(f->dtype), false);
+    for (int i = 0; i < (f->family == VSZIP_CF_GRAY ? 1 : 3); ++i) {
+        const bool chroma = f->family == VSZIP_CF_YUV && i != 0;
+        touch(s[i], chroma ? f->chroma_stride : ss, chroma ? (w + (1 << f->ssw) - 1) >> f->ssw : w, chroma ? (h + (1 << f->ssh) - 1) >> f->ssh : h, bps_of(f->dtype), false);
+    }
     for (int i = 0; i < 3; ++i) touch(d3[i], ds, w, h, 4, true);
     return kernel_failed(ctx, "to_rgbs_linear");
 }

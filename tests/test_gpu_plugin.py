@@ -336,8 +336,10 @@ def test_limiter_through_plugin(oracle):
 def test_limit_filter_through_plugin(oracle):
     """flt = BoxBlur(2,2) of src like the reference's own cases; thresholds arrive on the 8-bit scale
     and are carried to the clip's depth / range by the wrapper (hz.scaleValue): identity at 8 bit, full
-    range for RGB, limited for YUV without a range prop, the _ColorRange prop when present; per-plane
-    arrays; the optional ref clip; planes subset copies from flt."""
+    range for RGB, limited for YUV without a range prop; WITH a range prop the reference's build resolves the
+    opposite range (its 38 integer LimitFilter goldens on zimg's limited-flagged clips carry full-range thresholds:
+    tests/test_oracle_zimg_goldens.py::test_limit_filter_keys), mirrored by the plugin; per-plane arrays; the
+    optional ref clip; planes subset copies from flt."""
     src8 = list(fx.crop_rgb24()[:, :96, :160])
     clip8 = vs.source([src8], vs.RGB24)
     flt8 = clip8.vszip.BoxBlur(hradius=2, vradius=2)
@@ -346,7 +348,7 @@ def test_limit_filter_through_plugin(oracle):
         want = oracle.limit_filter(oracle.boxblur(np.ascontiguousarray(src8[p]), 2, 1, 2, 1), src8[p], None, 8, 8, 3)
         assert np.array_equal(out[p], want)
     nat = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate([(96, 160), (48, 80), (48, 80)])]
-    for props, limited in ((None, True), ({"_ColorRange": 0}, False), ({"_ColorRange": 1}, True)):
+    for props, limited in ((None, True), ({"_ColorRange": 0}, True), ({"_ColorRange": 1}, False), ({"_Range": 0}, False)):
         c16 = vs.source([nat], vs.YUV420P16, props=props)
         f16 = c16.vszip.BoxBlur(hradius=2, vradius=2)
         r16 = c16.vszip.BoxBlur(hradius=4, vradius=4)
@@ -664,6 +666,65 @@ def test_fused_pipeline_into_ssimulacra2(oracle):
     want = [oracle.boxblur(oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i]), 2, 1, 2, 1)
             for i, p in enumerate(base)]
     assert s == pytest.approx(oracle.ssimulacra2(base, want), abs=1e-7)
+
+
+def test_ssimulacra2_yuv_sources_on_the_device(oracle):
+    """SURVEY 8f rank 1, the YUV half (round 3): a YUV clip goes to the GPU as it is — 12 MB per 4K YUV420P8 frame instead
+    of 100 MB of RGBS — and hz.toRGBS's chroma upsampling + matrix + sRGBtoLinearRGB run fused into the first pass. The
+    output clip is still the host-converted reference (ssimulacra2.zig:53), here through the test host's stand-in (which
+    must agree with oracle/vs_host.py bit for bit). `_Matrix` of the frames wins over toRGBS's matrix_in = 601 / 709."""
+    from oracle import vs_host as vh
+
+    vs.core_standins(True)
+    try:
+        for fmt_id, bits in ((vs.YUV420P8, 8), (vs.YUV420P16, 16)):
+            ref = [np.ascontiguousarray(p[:80, :128] if i else p[:160, :256]) for i, p in enumerate(fx.crop_yuv(bits))]
+            dis = [vh.std_boxblur(p, 1, 1) for p in ref]
+            props = {"_Matrix": 1, "_ColorRange": 1, "_ChromaLocation": 0}
+            a, b = vs.source([ref], fmt_id, props=props), vs.source([dis], fmt_id, props=props)
+            out = a.vszip.SSIMULACRA2(b)
+            f = out.get_frame(0)
+            lin_r, lin_d = vh.yuv_to_linear_rgbs(ref, bits, 1, 1, 1, 0), vh.yuv_to_linear_rgbs(dis, bits, 1, 1, 1, 0)
+            assert f.props["SSIMULACRA2"] == pytest.approx(oracle.ssimulacra2(lin_r, lin_d), abs=1e-7)
+            assert out.format_id == vs.RGBS
+            for p in range(3):
+                assert np.array_equal(np.asarray(f[p]).view(np.uint32), lin_r[p].view(np.uint32)), (bits, p)
+            # only the reference went through the host's resize (format, then transfer); the distorted clip never did
+            assert sum("resize.Bicubic" in l for l in vs.standin_log()) == 2, vs.standin_log()
+            vs.core_standins(True)  # (clears the log)
+        # no _Matrix on the frames: toRGBS's own choice — BT.601 for a clip of <= 650 rows (src/helper.zig:231)
+        ref = [np.ascontiguousarray(p[:80, :128] if i else p[:160, :256]) for i, p in enumerate(fx.crop_yuv(8))]
+        dis = [vh.std_boxblur(p, 2, 2) for p in ref]
+        a, b = vs.source([ref], vs.YUV420P8), vs.source([dis], vs.YUV420P8)
+        want = oracle.ssimulacra2(vh.yuv_to_linear_rgbs(ref, 8, 1, 1, 6, 0), vh.yuv_to_linear_rgbs(dis, 8, 1, 1, 6, 0))
+        assert a.vszip.SSIMULACRA2(b).get_frame(0).props["SSIMULACRA2"] == pytest.approx(want, abs=1e-7)
+        # mixed: YUV420P8 reference against the same picture as RGB24 (converted on the device one by one)
+        rgb = [np.ascontiguousarray(p[:160, :256]) for p in fx.crop_rgb24()]
+        c = vs.source([rgb], vs.RGB24)
+        want = oracle.ssimulacra2(vh.yuv_to_linear_rgbs(ref, 8, 1, 1, 6, 0), vh.to_linear_rgbs(rgb, "RGB", 8))
+        assert a.vszip.SSIMULACRA2(c).get_frame(0).props["SSIMULACRA2"] == pytest.approx(want, abs=1e-7)
+        # a vszip chain on the YUV clip stays on the device: one upload of the 4:2:0 planes, BoxBlur there, score
+        f0, s0 = vs.fusion_stats()
+        got = a.vszip.SSIMULACRA2(a.vszip.BoxBlur(hradius=2, vradius=2)).get_frame(0).props["SSIMULACRA2"]
+        assert vs.fusion_stats() == (f0 + 1, s0 + 1)
+        blur = [oracle.boxblur(p, 2, 1, 2, 1) for p in ref]
+        assert got == pytest.approx(oracle.ssimulacra2(vh.yuv_to_linear_rgbs(ref, 8, 1, 1, 6, 0), vh.yuv_to_linear_rgbs(blur, 8, 1, 1, 6, 0)), abs=1e-7)
+    finally:
+        vs.core_standins(False)
+
+
+def test_ssimulacra2_fused_reference_against_its_own_linear_root(oracle):
+    """lin.vszip.BoxBlur().vszip.SSIMULACRA2(lin) on a linear RGBS clip — the reference is a fused chain
+    whose root IS the distorted clip, and the distorted clip needs no pre-stage (raw1 set, raw2 not). Both inputs are one
+    node: requested once, and the distorted planes are that frame's own upload (it used to be a null frame)."""
+    base = [np.ascontiguousarray(p[:96, :160]) for p in fx.crop_rgbs()]
+    lin = vs.source([base], vs.RGBS, props={"_Transfer": 8})
+    blur = [oracle.boxblur(p, 2, 1, 2, 1) for p in base]
+    s = lin.vszip.BoxBlur(hradius=2, vradius=2).vszip.SSIMULACRA2(lin).get_frame(0).props["SSIMULACRA2"]
+    assert s == pytest.approx(oracle.ssimulacra2(blur, base), abs=1e-7)
+    # and the mirrored order (which always worked)
+    s2 = lin.vszip.SSIMULACRA2(lin.vszip.BoxBlur(hradius=2, vradius=2)).get_frame(0).props["SSIMULACRA2"]
+    assert s2 == pytest.approx(oracle.ssimulacra2(base, blur), abs=1e-7)
 
 
 def test_frames_shard_over_devices_like_one_device(oracle):

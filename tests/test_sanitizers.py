@@ -78,6 +78,8 @@ SCENARIO = textwrap.dedent("""
         c16.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=3, vradius=3, planes=[0]).vszip.Limiter(tv_range=True, planes=[1, 2]),
         rgbs.vszip.SSIMULACRA2(rgbs.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)),
         rgb.vszip.SSIMULACRA2(rgb.vszip.BoxBlur(hradius=1, vradius=1)),
+        # YUV sources take the device pre-stage; a fused reference whose root IS the (linear RGBS) distorted clip (ADVICE r2)
+        c8.vszip.SSIMULACRA2(c8), c16.vszip.SSIMULACRA2(c16.vszip.BoxBlur(hradius=1, vradius=1)), rgbs.vszip.BoxBlur(hradius=2, vradius=2).vszip.SSIMULACRA2(rgbs),
     ]
     failed = 0
     for c in clips:
@@ -138,6 +140,8 @@ SUCCESS = textwrap.dedent("""
         c16.vszip.LimitFilter(c16, dark_thr=8.0),
         c16.vszip.Bilateral(sigmaS=2.0, sigmaR=0.05).vszip.BoxBlur(hradius=3, vradius=3, planes=[0]).vszip.Limiter(tv_range=True, planes=[1, 2]),
         rgbs.vszip.SSIMULACRA2(rgbs.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)),
+        # ADVICE r2 (high): the fused reference's root is the distorted clip itself, which takes the host-RGBS path
+        rgbs.vszip.BoxBlur(hradius=2, vradius=2).vszip.SSIMULACRA2(rgbs), c8.vszip.SSIMULACRA2(c8.vszip.BoxBlur(hradius=1, vradius=1)),
     ]
     for c in clips:
         c.get_frame(0)              # every filter's success path once, single threaded

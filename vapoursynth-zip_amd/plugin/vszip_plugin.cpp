@@ -1405,7 +1405,11 @@ VSNode *to_linear_rgbs(const Z &z, VSNode *node, VSMap *out, bool *ok) {
         }
     }
     char err[256];
-    const VSFrame *f0 = api->getFrame(0, node, err, sizeof err);
+    // frame 0's _Transfer (ssimulacra2.zig:134-141) — read at the root of the clip's vszip chain: the pixel filters pass
+    // frame properties through, and asking the filter node itself would run its kernels for a frame nobody wants
+    Chain probe = resolve_chain(api, node);
+    const VSFrame *f0 = api->getFrame(0, probe.root, err, sizeof err);
+    free_chain(api, probe);
     int64_t transfer = 2;  // unspecified
     if (f0) {
         int e = 0;
@@ -1428,12 +1432,22 @@ VSNode *to_linear_rgbs(const Z &z, VSNode *node, VSMap *out, bool *ok) {
     node = z.getNode(ret, "clip");
     api->freeMap(ret);
     api->clearMap(args);
+    if (!node) {  // the host's std refused (e.g. an upstream filter that fails at create time)
+        api->freeMap(args);
+        z.setError(out, "SSIMULACRA2 : tagging the clip as sRGB failed");
+        *ok = false;
+        return nullptr;
+    }
     api->mapConsumeNode(args, "clip", node, maReplace);
     api->mapSetInt(args, "transfer", 8, maReplace);
     ret = api->invoke(resize, "Bicubic", args);
     node = z.getNode(ret, "clip");
     api->freeMap(ret);
     api->freeMap(args);
+    if (!node) {
+        z.setError(out, "SSIMULACRA2 : conversion to linear light failed");
+        *ok = false;
+    }
     return node;
 }
 
