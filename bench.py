@@ -231,12 +231,13 @@ class Arena:
 
         rng = np.random.default_rng(seed)
         isz = np.dtype(dtype).itemsize
+        spacing = int(float(os.environ.get("VSZIP_BENCH_PLANE_SPACING_MIB", "0")) * (1 << 20))  # extra distance between consecutive planes
         self.offs, total = [], 0
         for h, w in shapes:
             total = (total + (2 << 20) - 1) // (2 << 20) * (2 << 20)
             o = total + int(rng.integers(0, 4096)) * 256
             self.offs.append(o)
-            total = o + h * w * isz
+            total = o + h * w * isz + spacing
         self.dev, self.shapes, self.dtype, self.nbytes, self.ptr, self.planes = dev, shapes, dtype, total + 256, 0, []
         if ptr is None:
             p = C.c_void_p()
@@ -879,6 +880,25 @@ def boxblur_1080p_5pass_leg(dev, timed, no_cpu, frames=32):
     return res
 
 
+def pcie_path(local_rank: int):
+    """The GPU's PCIe endpoint and every bridge above it with the link each negotiated (sysfs): the PCIe-fed rate is 1.10 k
+    4K-YUV420P16 frames/s on some boxes of the pool and 1.8 k on others, whatever the process does (tools/pcie_ab.py)."""
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        dev = Path(f"/sys/bus/pci/devices/{bdf}").resolve()
+        out = []
+        while dev.name != "" and (dev / "current_link_speed").exists() and len(out) < 8:
+            rd = lambda n: (dev / n).read_text().strip() if (dev / n).exists() else None
+            out.append({"bdf": dev.name, "speed": rd("current_link_speed"), "width": rd("current_link_width"), "max_speed": rd("max_link_speed"), "max_width": rd("max_link_width")})
+            dev = dev.parent
+        return out
+    except Exception as e:
+        return [{"error": str(e)}]
+
+
 def bind_to_gpu_numa(local_rank: int):
     """Best effort: run this rank's host threads (and first-touch its pinned buffers) on the NUMA node
     the GPU hangs off — the PCIe-fed rate is limited by host memory placement."""
@@ -1134,7 +1154,7 @@ def main() -> int:
             dt_p = max_over_ranks(pc["seconds"])
             out["config"]["pcie_fed_fps"] = world * pc["contexts"] * pc["rounds"] / dt_p
             out["config"]["pcie_fed"] = {"rank0_fps": pc["value"], "rank0_GBps_each_direction": pc["pcie_GBps_each_direction"], "contexts_per_gpu": pc["contexts"],
-                                         "rank0_numa_node": numa_node,
+                                         "rank0_numa_node": numa_node, "rank0_pcie_path": pcie_path(local_rank),
                                          "note": "pinned host frame -> GPU -> pinned host frame, every rank at once (barrier, then the same number of rounds); "
                                                  "whole-job frames / max-over-ranks time"}
         except KeyboardInterrupt:

@@ -25,6 +25,7 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -373,6 +374,165 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 3 — 16-bit clips, no `ref`, compile-time taps: bilateral_walk16_kernel<CR, CS>.
+// The LDS16 kernel above is bound by the LDS pipeline: 16 taps x {tile read, base[i >> 6], delta[i]} = 45 lane
+// operations per pixel. Two facts remove two thirds of them:
+//   (1) the range weight is symmetric — gr[|c - n|] for the tap c -> n is the one for n -> c — so a pixel looks up
+//       only its 8 DOWNWARD taps and receives the 8 upward ones from the pixels above, which computed them as their
+//       downward taps yy rows earlier: same f32 bits, and the accumulation order swei * (rw1 + rw2 + rw3 + rw4) is
+//       untouched, so the result stays bit-exact;
+//   (2) a wave that walks DOWN a strip of columns (lane = column) keeps the 2 CR + 1 rows it needs in registers:
+//       neighbour samples and the handed-down weights cross lanes with DPP wave shifts (VALU), not through LDS.
+// LDS traffic is the 16 table reads per pixel and nothing else (no tile, no barrier after the table is loaded);
+// the 1024-thread workgroup (one per CU: the packed table leaves room for no second one) is 16 independent waves.
+// A wave covers 64 columns of which the inner 64 - 2 CR are outputs (the outer ones only feed their neighbours);
+// columns and rows outside the plane are the clamped samples of truncatedEdges (:281-289), held by the halo lanes
+// and the rows above / below, which makes the handed-down weights of the border pixels come out right by the same
+// rule (a virtual pixel's downward tap onto a real one is that pixel's upward tap onto the clamped position).
+// Rings of R rows per column set (own column and the four tap columns) and of yy rows per handed-down weight are
+// register arrays addressed by template parameters: the row loop is unrolled over one ring period R.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float walk_shr1(float v) {  // lane i takes lane i - 1 (wave_shr:1; lane 0 reads 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float walk_shl1(float v) {  // lane i takes lane i + 1 (wave_shl:1; lane 63 reads 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+// {value of lane i - T0, value of lane i - T1} / {lane i + T0, lane i + T1}: T0 = 1, T1 = 2 or 3, chained single shifts
+template <int T1>
+__device__ __forceinline__ v2f walk_left_pair(float a, float b) {  // a travels T0 = 1 lane, b travels T1 lanes
+    float y = walk_shr1(b);
+#pragma unroll
+    for (int k = 1; k < T1; ++k) y = walk_shr1(y);
+    return v2f{walk_shr1(a), y};
+}
+template <int T1>
+__device__ __forceinline__ v2f walk_right_pair(float a, float b) {
+    float y = walk_shl1(b);
+#pragma unroll
+    for (int k = 1; k < T1; ++k) y = walk_shl1(y);
+    return v2f{walk_shl1(a), y};
+}
+
+constexpr int kWalkBand = 126;  // output rows per strip (a multiple of both ring periods keeps the tail short)
+
+template <int CR, int CS>
+struct WalkState {
+    static constexpr int T0 = 1, T1 = 1 + CS;      // the two tap distances per axis (CR = 3, CS = 2: 1, 3; CR = 2, CS = 1: 1, 2)
+    static constexpr int R = CR == 3 ? 9 : 6;      // ring period: >= 2 CR + 1 rows, a multiple of T0 and T1
+    float sc[R];                                   // the lane's own column, as f32 (exact)
+    v2f sl[R], sr[R];                              // the tap columns as pairs over the tap distance: {x - T0, x - T1}, {x + T0, x + T1}
+    v2f ha0[T0], hb0[T0];                          // handed-down weights of the yy = T0 taps: a = from the pixels at x - xx (rw3), b = from x + xx (rw1)
+    v2f ha1[T1], hb1[T1];                          // ... of the yy = T1 taps
+};
+
+template <int CR, int CS, int P>
+__device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t *sbase, const uint16_t *sdelta, const v2f (&sw)[2], float w0, float peak,
+                                           uint32_t &pend, const uint16_t *__restrict__ colp, int rstride, int next_row, bool math, bool store,
+                                           uint16_t *__restrict__ dstp) {
+    using W = WalkState<CR, CS>;
+    constexpr int R = W::R, T0 = W::T0, T1 = W::T1;
+    // 1: the row loaded a step ago enters the rings (slot P), with its shifted copies
+    const float v = (float)pend;
+    st.sc[P] = v;
+    st.sl[P] = walk_left_pair<T1>(v, v);
+    st.sr[P] = walk_right_pair<T1>(v, v);
+    // 2: the next row's load is in flight during the arithmetic
+    pend = colp[(size_t)next_row * rstride];
+    if (!math) return;
+    // 3: the row CR above the newest one. Pairs run over the tap distance xx (v_pk_* : IEEE per element, the reference's order)
+    constexpr int C = (P - CR + R) % R;
+    const float c = st.sc[C];
+    auto lut = [&](float n) {
+        const uint32_t i = (uint32_t)fabsf(c - n);  // |c - n|: exact in f32 for 16-bit samples
+        return __uint_as_float(sbase[i >> 6] - (uint32_t)sdelta[i]);
+    };
+    float wsum = w0, sum = c * w0;
+    auto sets = [&](const v2f swv, const v2f n1, const v2f n2, const v2f n3, const v2f n4, v2f &ha, v2f &hb) {
+        const v2f rw2 = {lut(n2.x), lut(n2.y)}, rw4 = {lut(n4.x), lut(n4.y)};  // the downward taps (+yy, +xx), (+yy, -xx)
+        const v2f rw1 = hb, rw3 = ha;  // handed down: (-yy, +xx) is the (+yy, -xx) tap of the pixel at x + xx, (-yy, -xx) the (+yy, +xx) tap of the one at x - xx
+        ha = walk_left_pair<T1>(rw2.x, rw2.y);   // what the pixels yy rows below take from their left / right neighbours
+        hb = walk_right_pair<T1>(rw4.x, rw4.y);
+        const v2f wi = swv * (rw1 + rw2 + rw3 + rw4);
+        const v2f si = swv * (n1 * rw1 + n2 * rw2 + n3 * rw3 + n4 * rw4);
+        wsum += wi.x;
+        sum += si.x;
+        wsum += wi.y;
+        sum += si.y;
+    };
+    {
+        constexpr int up = (C - T0 + R) % R, dn = (C + T0) % R, sl = P % T0;
+        sets(sw[0], st.sr[up], st.sr[dn], st.sl[up], st.sl[dn], st.ha0[sl], st.hb0[sl]);
+    }
+    {
+        constexpr int up = (C - T1 + R) % R, dn = (C + T1) % R, sl = P % T1;
+        sets(sw[1], st.sr[up], st.sr[dn], st.sl[up], st.sl[dn], st.ha1[sl], st.hb1[sl]);
+    }
+    if (store) {
+        const float q = __fdiv_rn(sum, wsum);
+        *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
+    }
+}
+
+template <int CR, int CS, int... P>
+__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const uint32_t *sbase, const uint16_t *sdelta, const v2f (&sw)[2], float w0, float peak, uint32_t &pend,
+                                             const uint16_t *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, uint16_t *__restrict__ dcol,
+                                             int dstride, std::integer_sequence<int, P...>) {
+    // step t handles the new row ys + t and the output row ys + t - CR; rows are clamped into the plane (replicate padding)
+    (walk_step<CR, CS, P>(st, sbase, sdelta, sw, w0, peak, pend, colp, rstride, min(max(ys + t0 + P + 1, 0), h - 1), t0 + P >= 2 * CR,
+                          lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1, dcol + (size_t)max(ys + t0 + P - CR, 0) * dstride),
+     ...);
+}
+
+template <int CR, int CS>
+__global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips) {
+    using W = WalkState<CR, CS>;
+    __shared__ __attribute__((aligned(16))) struct { uint32_t base[1024]; uint16_t delta[65536]; } slut;
+    const int tid = (int)threadIdx.x;
+    {
+        const uint32_t *gb = reinterpret_cast<const uint32_t *>(prm.p[0].gr + 65536);
+        const uint4 *gd = reinterpret_cast<const uint4 *>(gb + 1024);
+        slut.base[tid] = gb[tid];
+        for (int i = tid; i < 65536 / 8; i += 1024) reinterpret_cast<uint4 *>(slut.delta)[i] = gd[i];
+    }
+    __syncthreads();  // the only barrier: from here on the 16 waves are independent
+    const int lane = tid & 63;
+    const int wave0 = (int)blockIdx.x * 16 + (tid >> 6), nwaves = (int)gridDim.x * 16;
+    constexpr int WOUT = 64 - 2 * CR;
+    int pi = 0;
+#pragma unroll 1
+    for (int sidx = wave0; sidx < nstrips; sidx += nwaves) {
+        while (pi + 1 < prm.nplanes && sidx >= prm.p[pi + 1].block0) ++pi;  // strips are visited in increasing order
+        const BLPlane &pl = prm.p[pi];
+        const float *gs = pl.gs;  // (planes of one launch share the range table, radius and step — not necessarily sigmaS)
+        const v2f sw[2] = {{gs[W::T0 * (CR + 1) + W::T0], gs[W::T0 * (CR + 1) + W::T1]}, {gs[W::T1 * (CR + 1) + W::T0], gs[W::T1 * (CR + 1) + W::T1]}};
+        const float w0 = gs[0] * __uint_as_float(slut.base[0] - (uint32_t)slut.delta[0]);
+        const int ls = sidx - pl.block0;
+        const int X0 = (ls % pl.nbx) * WOUT, y0 = (ls / pl.nbx) * kWalkBand, y1 = min(y0 + kWalkBand, pl.h);
+        const int col = X0 - CR + lane;
+        const uint16_t *colp = static_cast<const uint16_t *>(pl.src) + min(max(col, 0), pl.w - 1);
+        uint16_t *dcol = static_cast<uint16_t *>(pl.dst) + min(max(col, 0), pl.w - 1);
+        const bool lane_out = lane >= CR && lane < 64 - CR && col < pl.w;
+        W st;
+#pragma unroll
+        for (int b = 0; b < W::R; ++b) {
+            st.sc[b] = 0.0f;
+            st.sl[b] = st.sr[b] = v2f{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int b = 0; b < W::T0; ++b) st.ha0[b] = st.hb0[b] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int b = 0; b < W::T1; ++b) st.ha1[b] = st.hb1[b] = v2f{0.0f, 0.0f};
+        const int ys = y0 - 2 * CR;  // first row needed: the weights handed to row y0 come from rows y0 - CR .., which tap rows down to y0 - 2 CR
+        uint32_t pend = colp[(size_t)min(max(ys, 0), pl.h - 1) * pl.sstride];
+        const int steps = (y1 - y0) + 3 * CR;
+#pragma unroll 1
+        for (int t0 = 0; t0 < steps; t0 += W::R)
+            walk_period<CR, CS>(st, slut.base, slut.delta, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, std::make_integer_sequence<int, W::R>{});
     }
 }
 
@@ -727,6 +887,23 @@ int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_r
     return joint ? launch_lds16_k<T, true, 0, 0>(ctx, prm, blocks, lds) : launch_lds16_k<T, false, 0, 0>(ctx, prm, blocks, lds);
 }
 
+// The column-walking kernel: strips of 64 - 2 CR output columns x kWalkBand rows; prm.p[i].block0 / nbx are re-based on strips.
+template <int CR, int CS>
+int launch_walk16(vszip_ctx *ctx, BLParams prm) {
+    int strips = 0;
+    for (int i = 0; i < prm.nplanes; ++i) {
+        BLPlane &p = prm.p[i];
+        p.block0 = strips;
+        p.nbx = (p.w + (64 - 2 * CR) - 1) / (64 - 2 * CR);
+        strips += p.nbx * ((p.h + kWalkBand - 1) / kWalkBand);
+    }
+    const int grid = std::min((strips + 15) / 16, 256);
+    vszip_probe_scope probe(ctx);
+    hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips);
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    return VSZIP_OK;
+}
+
 template <typename T>
 int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled, bool joint, int max_radius) {
     {
@@ -938,6 +1115,22 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     dp.block0 = qb;
                     const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64;
                     qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
+                }
+                static const bool no_walk = getenv("VSZIP_BILATERAL_NO_WALK") != nullptr;
+                if (dtype == VSZIP_U16 && !joint && !no_walk && q.nplanes > 0) {
+                    int r = q.p[0].radius, st = q.p[0].step;
+                    for (int i = 1; i < q.nplanes; ++i)
+                        if (q.p[i].radius != r || q.p[i].step != st) r = st = 0;
+                    if (r == 3 && st == 2) {
+                        rc = launch_walk16<3, 2>(ctx, q);
+                        if (rc != VSZIP_OK) return rc;
+                        continue;
+                    }
+                    if (r == 2 && st == 1) {
+                        rc = launch_walk16<2, 1>(ctx, q);
+                        if (rc != VSZIP_OK) return rc;
+                        continue;
+                    }
                 }
                 switch (dtype) {
                     case VSZIP_U16: rc = launch_lds16<uint16_t>(ctx, q, qb, joint, max_radius); break;
