@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(x)                                                                      \
@@ -27,6 +28,7 @@
 struct Stream {
     long long src, dst;  // byte offsets of the stream's first row segment
     int stride, rows;
+    int dstride, unused;
 };
 
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(64) void ring_copy(const char *sbase, char *dbase, 
     for (int r = 0; r < s.rows; ++r) {
         v4u b = a;
         if (r + 1 < s.rows) a = *reinterpret_cast<const v4u *>(sp + (size_t)(r + 1) * s.stride);
-        __builtin_nontemporal_store(b, reinterpret_cast<v4u *>(dp + (size_t)r * s.stride));
+        __builtin_nontemporal_store(b, reinterpret_cast<v4u *>(dp + (size_t)r * s.dstride));
     }
 }
 
@@ -66,20 +68,27 @@ int main(int argc, char **argv) {
     const long long Dmax = 64 * MiB;
     const long long small_bytes = total + 192 * (1 * MiB + 7 * 65536) + 4 * MiB;  // room for every D <= 1 MiB (and the odd multiples)
     const long long big_bytes = total + (long long)nplanes * Dmax + 4 * MiB;      // one arena for the large strides
+    long long pad = 0;  // extra bytes per DESTINATION row (a padded row pitch); planes then start (h * pad) further apart
     auto make_streams = [&](long long D, std::vector<Stream> &out) {
         out.clear();
+        long long shift = 0;
         for (int k = 0; k < nplanes; ++k) {
             const Pl &p = pls[k % 3];
             const int band_rows = p.h / p.bands;
+            const long long dstride = p.stride + (k % 3 == 0 ? pad : pad / 2);
             for (int b = 0; b < p.bands; ++b)
                 for (int t = 0; t < p.tiles; ++t) {
                     Stream s;
                     s.src = pbase[k] + (long long)b * band_rows * p.stride + t * 960;
-                    s.dst = pbase[k] + (long long)k * D + (long long)b * band_rows * p.stride + t * 960;
+                    s.dst = pbase[k] + shift + (long long)k * D + (long long)b * band_rows * dstride + t * 960;
                     s.stride = p.stride;
+                    s.dstride = (int)dstride;
+                    s.unused = 0;
                     s.rows = band_rows;
                     out.push_back(s);
                 }
+            shift += (dstride - p.stride) * p.h;
+            shift = (shift + 2 * MiB - 1) / (2 * MiB) * (2 * MiB);
         }
     };
     char *src;
@@ -107,6 +116,39 @@ int main(int argc, char **argv) {
         return ms * 1e3 / n;
     };
     printf("streams %d, bytes moved per launch %.3f GB (read + write), arena %.2f GiB\n", nstreams, 2.0 * frames * 24883200 / 1e9, small_bytes / 1073741824.0);
+    if (argc > 2 && std::string(argv[2]) == "pitch") {
+        // the same walk with a padded DESTINATION row pitch instead of a plane lattice (luma pad, chroma half of it)
+        const std::vector<long long> pads = {0, 64, 128, 256, 512, 768, 1024, 1280, 2048, 4096, 512 + 7680};
+        printf("arena");
+        for (long long pd : pads) printf(" %8lld", pd);
+        printf("   (destination pitch pad, bytes)\n");
+        for (int a = 0; a < narena; ++a) {
+            char *d;
+            // room for the largest pad: every luma row + 8192 B, every chroma row + 4096 B, and a 2 MiB round-up per plane
+            const long long pitch_bytes = total + 64LL * 2160 * 8192 + 128LL * 1080 * 4096 + 192LL * 2 * MiB + 8 * MiB;
+            if (hipMalloc(&d, pitch_bytes) != hipSuccess) break;
+            {
+                pad = pads.back();
+                make_streams(0, hs);
+                long long hi = 0;
+                for (const Stream &q : hs) hi = std::max(hi, q.dst + (long long)(q.rows - 1) * q.dstride + 960);
+                pad = 0;
+                if (hi > pitch_bytes) {
+                    fprintf(stderr, "layout %lld exceeds the arena %lld\n", hi, pitch_bytes);
+                    return 2;
+                }
+            }
+            printf("%5d", a);
+            for (long long pd : pads) {
+                pad = pd;
+                printf(" %8.1f", time_us(d, 0));
+            }
+            pad = 0;
+            printf("\n");
+            fflush(stdout);
+        }
+        return 0;
+    }
     // 1: the walk — every candidate arena with D = 0 and the small lattices
     std::vector<char *> arenas;
     std::vector<double> base_us;
