@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../vapoursynth-zip_amd/plugin/VapourSynth4_min.h"
+#include "../../vapoursynth-zip_amd/plugin/vsapi_layout_check.h"
 
 struct Prop {
     int type = ptUnset;

@@ -85,7 +85,7 @@ def build_plugin(force: bool = False) -> None:
     """libvszip.so (the VapourSynth plugin: plain C++ over the C ABI, linked to libvszip_hip.so
     next to it) and the VapourSynth-free test host tests/fakevs/libfakevs.so."""
     psrc = PKG / "plugin" / "vszip_plugin.cpp"
-    pdeps = [psrc, PKG / "plugin" / "VapourSynth4_min.h", PKG.parent / "include" / "vszip_hip.h"]
+    pdeps = [psrc, PKG / "plugin" / "VapourSynth4_min.h", PKG / "plugin" / "vsapi_layout_check.h", PKG.parent / "include" / "vszip_hip.h"]
     if force or _stale(PLUGIN, pdeps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-o", str(PLUGIN), str(psrc),
                "-L" + str(PKG), "-lvszip_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]

@@ -418,7 +418,7 @@ __device__ __forceinline__ v2f walk_right_pair(float a, float b) {
     return v2f{walk_shl1(a), y};
 }
 
-constexpr int kWalkBand = 126;  // output rows per strip (a multiple of both ring periods keeps the tail short)
+constexpr int kWalkBand = 108;  // output rows per strip: a multiple of both ring periods, and 1080 / 540 / 2160 rows split into whole bands
 
 template <int CR, int CS>
 struct WalkState {
@@ -432,8 +432,7 @@ struct WalkState {
 
 template <int CR, int CS, int P>
 __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t *sbase, const uint16_t *sdelta, const v2f (&sw)[2], float w0, float peak,
-                                           uint32_t &pend, const uint16_t *__restrict__ colp, int rstride, int next_row, bool math, bool store,
-                                           uint16_t *__restrict__ dstp) {
+                                           uint32_t &pend, const uint16_t *__restrict__ nextp, uint16_t *__restrict__ dstp) {
     using W = WalkState<CR, CS>;
     constexpr int R = W::R, T0 = W::T0, T1 = W::T1;
     // 1: the row loaded a step ago enters the rings (slot P), with its shifted copies
@@ -442,8 +441,7 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t 
     st.sl[P] = walk_left_pair<T1>(v, v);
     st.sr[P] = walk_right_pair<T1>(v, v);
     // 2: the next row's load is in flight during the arithmetic
-    pend = colp[(size_t)next_row * rstride];
-    if (!math) return;
+    pend = *nextp;
     // 3: the row CR above the newest one. Pairs run over the tap distance xx (v_pk_* : IEEE per element, the reference's order)
     constexpr int C = (P - CR + R) % R;
     const float c = st.sc[C];
@@ -472,24 +470,24 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t 
         constexpr int up = (C - T1 + R) % R, dn = (C + T1) % R, sl = P % T1;
         sets(sw[1], st.sr[up], st.sr[dn], st.sl[up], st.sl[dn], st.ha1[sl], st.hb1[sl]);
     }
-    if (store) {
-        const float q = __fdiv_rn(sum, wsum);
-        *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
-    }
+    // No branch anywhere in a step (a period of R steps is ONE basic block: the scheduler may start a step's loads and table
+    // reads under the previous step's arithmetic): rows and lanes that produce no output store to a dummy line instead.
+    const float q = __fdiv_rn(sum, wsum);
+    *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
 }
 
 template <int CR, int CS, int... P>
 __device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const uint32_t *sbase, const uint16_t *sdelta, const v2f (&sw)[2], float w0, float peak, uint32_t &pend,
                                              const uint16_t *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, uint16_t *__restrict__ dcol,
-                                             int dstride, std::integer_sequence<int, P...>) {
+                                             int dstride, uint16_t *__restrict__ dummy, std::integer_sequence<int, P...>) {
     // step t handles the new row ys + t and the output row ys + t - CR; rows are clamped into the plane (replicate padding)
-    (walk_step<CR, CS, P>(st, sbase, sdelta, sw, w0, peak, pend, colp, rstride, min(max(ys + t0 + P + 1, 0), h - 1), t0 + P >= 2 * CR,
-                          lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1, dcol + (size_t)max(ys + t0 + P - CR, 0) * dstride),
+    (walk_step<CR, CS, P>(st, sbase, sdelta, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
+                          (lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1) ? dcol + (size_t)(ys + t0 + P - CR) * dstride : dummy),
      ...);
 }
 
 template <int CR, int CS>
-__global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips) {
+__global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips, int *__restrict__ next_strip) {
     using W = WalkState<CR, CS>;
     __shared__ __attribute__((aligned(16))) struct { uint32_t base[1024]; uint16_t delta[65536]; } slut;
     const int tid = (int)threadIdx.x;
@@ -501,12 +499,19 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
     }
     __syncthreads();  // the only barrier: from here on the 16 waves are independent
     const int lane = tid & 63;
-    const int wave0 = (int)blockIdx.x * 16 + (tid >> 6), nwaves = (int)gridDim.x * 16;
     constexpr int WOUT = 64 - 2 * CR;
+    // strips are handed out dynamically (one atomic per strip, lane 0): a plane's strips differ in length (the last band) and
+    // 19 584 luma strips do not divide by 4 096 waves; the counter is zeroed by the host before the launch
+    auto grab = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_strip, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    uint16_t *dummy = reinterpret_cast<uint16_t *>(next_strip + 64) + lane;  // 128 B behind the counter's line: what the halo lanes / rows "store"
     int pi = 0;
 #pragma unroll 1
-    for (int sidx = wave0; sidx < nstrips; sidx += nwaves) {
-        while (pi + 1 < prm.nplanes && sidx >= prm.p[pi + 1].block0) ++pi;  // strips are visited in increasing order
+    for (int sidx = grab(); sidx < nstrips; sidx = grab()) {
+        while (pi + 1 < prm.nplanes && sidx >= prm.p[pi + 1].block0) ++pi;  // a wave's strips come in increasing order
         const BLPlane &pl = prm.p[pi];
         const float *gs = pl.gs;  // (planes of one launch share the range table, radius and step — not necessarily sigmaS)
         const v2f sw[2] = {{gs[W::T0 * (CR + 1) + W::T0], gs[W::T0 * (CR + 1) + W::T1]}, {gs[W::T1 * (CR + 1) + W::T0], gs[W::T1 * (CR + 1) + W::T1]}};
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         const int steps = (y1 - y0) + 3 * CR;
 #pragma unroll 1
         for (int t0 = 0; t0 < steps; t0 += W::R)
-            walk_period<CR, CS>(st, slut.base, slut.delta, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, std::make_integer_sequence<int, W::R>{});
+            walk_period<CR, CS>(st, slut.base, slut.delta, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
     }
 }
 
@@ -898,8 +903,12 @@ int launch_walk16(vszip_ctx *ctx, BLParams prm) {
         strips += p.nbx * ((p.h + kWalkBand - 1) / kWalkBand);
     }
     const int grid = std::min((strips + 15) / 16, 256);
+    int rcs = vszip_ensure_scratch(ctx, 512);  // the strip counter, and the dummy store line 256 B behind it
+    if (rcs != VSZIP_OK) return rcs;
+    int *counter = static_cast<int *>(ctx->scratch);
+    VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
     vszip_probe_scope probe(ctx);
-    hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips);
+    hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }

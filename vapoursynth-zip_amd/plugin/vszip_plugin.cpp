@@ -27,6 +27,7 @@
 
 #include "../../include/vszip_hip.h"
 #include "VapourSynth4_min.h"
+#include "vsapi_layout_check.h"
 
 namespace {
 
