@@ -151,6 +151,40 @@ def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
         assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (dtype, sig, shape, joint)
 
 
+@pytest.mark.parametrize("sig", [(2, 2), (1, 2), (2, 1.0), (2, 0.3)])
+@pytest.mark.parametrize("content", ["natural", "noise", "edges"])
+def test_walk16_paths_agree(dev, oracle, sig, content, monkeypatch):
+    """Round 3: 16-bit clips without `ref` whose taps are the BASELINE's (radius 3 / step 2, radius 2 / step 1) take the
+    column-walking kernel — each pixel looks up only its 8 downward taps and receives the 8 upward ones from the pixels above
+    (the range weight is symmetric), neighbours cross lanes with DPP shifts. Both of its table forms (FINE: 4-entry blocks with
+    u8 deltas, for gentle tables such as sigmaR = 2; COARSE: the LDS16 form) against the tile kernel and the oracle, byte for
+    byte: natural content, full-range white noise (every table entry, every weight handed down differs) and hard edges;
+    strips narrower / wider than a wave's 58 / 60 output columns, bands that end inside a ring period, planes barely
+    larger than the taps."""
+    sS, sR = sig
+    for shape in [(120, 200), (67, 131), (7, 9), (230, 58), (109, 117), (8, 64)]:
+        if content == "natural":
+            src = fx.tiled_natural(shape, np.uint16, 1)
+        elif content == "noise":
+            src = fx.splitmix64_plane(5 + shape[0], shape, np.uint16)
+        else:
+            src = np.where((np.add.outer(np.arange(shape[0]) // 5, np.arange(shape[1]) // 7) & 1) == 0, 0, 65535).astype(np.uint16)
+        (a,), cfgs = _gpu(dev, [src], sS, sR, algorithm=[2])
+        c = cfgs[0]
+        if min(shape) <= 2 * c[3]:
+            continue  # the wrapper rejects planes not larger than the taps
+        monkeypatch.setenv("VSZIP_BILATERAL_NO_FINE", "1")
+        (b,), _ = _gpu(dev, [src], sS, sR, algorithm=[2])
+        monkeypatch.delenv("VSZIP_BILATERAL_NO_FINE")
+        monkeypatch.setenv("VSZIP_BILATERAL_NO_WALK", "1")
+        (t,), _ = _gpu(dev, [src], sS, sR, algorithm=[2])
+        monkeypatch.delenv("VSZIP_BILATERAL_NO_WALK")
+        want = oracle.bilateral_plane(src, c[0], c[1], c[2], c[3], c[4], c[5])
+        assert np.array_equal(a, want), (sig, content, shape, int((a != want).sum()))
+        assert np.array_equal(b, want), (sig, content, shape, "coarse")
+        assert np.array_equal(t, want), (sig, content, shape, "tile kernel")
+
+
 @pytest.mark.parametrize("dtype", [np.uint16, np.float32])
 def test_large_yuv420_batches_cross_the_launch_table(dev, oracle, dtype):
     """70 frames of YUV 4:2:0 in one call = 210 planes: more than one launch table (192 planes), luma and chroma with

@@ -201,6 +201,7 @@ template <typename T, bool JOINT>
 constexpr int kL16TileH = (sizeof(T) == 4 || JOINT) ? 32 : 64;
 constexpr int kL16LutBytes = 4096 + 131072;        // base + delta
 constexpr int kL16MaxLds = 160 * 1024;
+constexpr int kWalkFineBytes = 65536 + 65536;      // the 4-entry-block form of the table: base4 u32 x 16384 + delta8 u8 x 65536
 // staged samples per thread and clip: tiles up to 1024 * kL16MaxStage samples
 template <typename T, bool JOINT>
 constexpr int kL16MaxStage = (sizeof(T) == 4 || JOINT) ? 4 : 6;
@@ -430,8 +431,25 @@ struct WalkState {
     v2f ha1[T1], hb1[T1];                          // ... of the yy = T1 taps
 };
 
-template <int CR, int CS, int P>
-__device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t *sbase, const uint16_t *sdelta, const v2f (&sw)[2], float w0, float peak,
+// The table in LDS: COARSE = base[i >> 6] (u32 x 1024) - delta[i] (u16), any table that packs; FINE = base4[i >> 2] (u32 x 16384) - delta8[i] (u8),
+// gentle tables only — its byte offsets are i & ~3 and i: one VALU instruction of address arithmetic per lookup instead of three.
+template <bool FINE>
+struct WalkLut;
+template <>
+struct WalkLut<false> {
+    uint32_t base[1024];
+    uint16_t delta[65536];
+    __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(base[i >> 6] - (uint32_t)delta[i]); }
+};
+template <>
+struct WalkLut<true> {
+    uint32_t base[16384];
+    uint8_t delta[65536];
+    __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(base[i >> 2] - (uint32_t)delta[i]); }
+};
+
+template <int CR, int CS, int P, bool FINE>
+__device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak,
                                            uint32_t &pend, const uint16_t *__restrict__ nextp, uint16_t *__restrict__ dstp) {
     using W = WalkState<CR, CS>;
     constexpr int R = W::R, T0 = W::T0, T1 = W::T1;
@@ -446,8 +464,7 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t 
     constexpr int C = (P - CR + R) % R;
     const float c = st.sc[C];
     auto lut = [&](float n) {
-        const uint32_t i = (uint32_t)fabsf(c - n);  // |c - n|: exact in f32 for 16-bit samples
-        return __uint_as_float(sbase[i >> 6] - (uint32_t)sdelta[i]);
+        return tab.at((uint32_t)fabsf(c - n));  // |c - n|: exact in f32 for 16-bit samples
     };
     float wsum = w0, sum = c * w0;
     auto sets = [&](const v2f swv, const v2f n1, const v2f n2, const v2f n3, const v2f n4, v2f &ha, v2f &hb) {
@@ -476,26 +493,25 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const uint32_t 
     *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
 }
 
-template <int CR, int CS, int... P>
-__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const uint32_t *sbase, const uint16_t *sdelta, const v2f (&sw)[2], float w0, float peak, uint32_t &pend,
+template <int CR, int CS, bool FINE, int... P>
+__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak, uint32_t &pend,
                                              const uint16_t *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, uint16_t *__restrict__ dcol,
                                              int dstride, uint16_t *__restrict__ dummy, std::integer_sequence<int, P...>) {
     // step t handles the new row ys + t and the output row ys + t - CR; rows are clamped into the plane (replicate padding)
-    (walk_step<CR, CS, P>(st, sbase, sdelta, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
+    (walk_step<CR, CS, P, FINE>(st, tab, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
                           (lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1) ? dcol + (size_t)(ys + t0 + P - CR) * dstride : dummy),
      ...);
 }
 
-template <int CR, int CS>
+template <int CR, int CS, bool FINE>
 __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips, int *__restrict__ next_strip) {
     using W = WalkState<CR, CS>;
-    __shared__ __attribute__((aligned(16))) struct { uint32_t base[1024]; uint16_t delta[65536]; } slut;
+    __shared__ __attribute__((aligned(16))) WalkLut<FINE> slut;
     const int tid = (int)threadIdx.x;
     {
-        const uint32_t *gb = reinterpret_cast<const uint32_t *>(prm.p[0].gr + 65536);
-        const uint4 *gd = reinterpret_cast<const uint4 *>(gb + 1024);
-        slut.base[tid] = gb[tid];
-        for (int i = tid; i < 65536 / 8; i += 1024) reinterpret_cast<uint4 *>(slut.delta)[i] = gd[i];
+        // the packed forms lie behind the f32 table: COARSE (4 + 128 KiB), then FINE (64 + 64 KiB)
+        const uint4 *g = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(prm.p[0].gr + 65536) + (FINE ? kL16LutBytes : 0));
+        for (int i = tid; i < (int)(sizeof(WalkLut<FINE>) / 16); i += 1024) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
     }
     __syncthreads();  // the only barrier: from here on the 16 waves are independent
     const int lane = tid & 63;
@@ -515,7 +531,7 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         const BLPlane &pl = prm.p[pi];
         const float *gs = pl.gs;  // (planes of one launch share the range table, radius and step — not necessarily sigmaS)
         const v2f sw[2] = {{gs[W::T0 * (CR + 1) + W::T0], gs[W::T0 * (CR + 1) + W::T1]}, {gs[W::T1 * (CR + 1) + W::T0], gs[W::T1 * (CR + 1) + W::T1]}};
-        const float w0 = gs[0] * __uint_as_float(slut.base[0] - (uint32_t)slut.delta[0]);
+        const float w0 = gs[0] * slut.at(0);
         const int ls = sidx - pl.block0;
         const int X0 = (ls % pl.nbx) * WOUT, y0 = (ls / pl.nbx) * kWalkBand, y1 = min(y0 + kWalkBand, pl.h);
         const int col = X0 - CR + lane;
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         const int steps = (y1 - y0) + 3 * CR;
 #pragma unroll 1
         for (int t0 = 0; t0 < steps; t0 += W::R)
-            walk_period<CR, CS>(st, slut.base, slut.delta, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
+            walk_period<CR, CS, FINE>(st, slut, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
     }
 }
 
@@ -852,17 +868,19 @@ int run_pbfic(vszip_ctx *ctx, const vszip_plane &s, const vszip_bilateral_cfg &c
 struct PackedLuts {
     std::mutex mu;
     std::map<const void *, uint64_t> exact;  // pointer -> content key (the bits of sigmaR: length and peak are fixed for these tables)
+    std::set<const void *> fine;             // ... whose 4-entry-block form (bilateral_walk16_kernel, FINE) is exact as well and stored behind the first
 };
 PackedLuts &packed_luts() {
     static PackedLuts *p = new PackedLuts();
     return *p;
 }
-bool lut_is_packed(const void *gr, uint64_t *key = nullptr) {
+bool lut_is_packed(const void *gr, uint64_t *key = nullptr, bool *fine = nullptr) {
     PackedLuts &p = packed_luts();
     std::lock_guard<std::mutex> lk(p.mu);
     const auto it = p.exact.find(gr);
     if (it == p.exact.end()) return false;
     if (key) *key = it->second;
+    if (fine) *fine = p.fine.count(gr) != 0;
     return true;
 }
 
@@ -894,7 +912,7 @@ int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_r
 
 // The column-walking kernel: strips of 64 - 2 CR output columns x kWalkBand rows; prm.p[i].block0 / nbx are re-based on strips.
 template <int CR, int CS>
-int launch_walk16(vszip_ctx *ctx, BLParams prm) {
+int launch_walk16(vszip_ctx *ctx, BLParams prm, bool fine) {
     int strips = 0;
     for (int i = 0; i < prm.nplanes; ++i) {
         BLPlane &p = prm.p[i];
@@ -908,7 +926,10 @@ int launch_walk16(vszip_ctx *ctx, BLParams prm) {
     int *counter = static_cast<int *>(ctx->scratch);
     VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
     vszip_probe_scope probe(ctx);
-    hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+    if (fine)
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, true>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+    else
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, false>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
@@ -952,6 +973,7 @@ void vszip_bilateral_forget_lut(const void *dptr) {
     PackedLuts &pl = packed_luts();
     std::lock_guard<std::mutex> lk(pl.mu);
     pl.exact.erase(dptr);
+    pl.fine.erase(dptr);
 }
 
 // LUTs exactly as bilateral.zig:306-339 computes them (f64 exp on the host, cast to f32),
@@ -993,18 +1015,55 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
             }
         }
     }
+    // ... and the FINE form for gentle tables (sigmaR around 1.5 and up, the BASELINE's 2 among them): blocks of FOUR entries,
+    // bits(gr[i]) = base4[i >> 2] - delta8[i] with a u8 delta (64 + 64 KiB) — the byte offsets of both reads are i itself and
+    // i & ~3, no shift: two VALU instructions fewer per lookup in bilateral_walk16_kernel
+    std::vector<uint32_t> fbase;
+    std::vector<uint8_t> fdelta;
+    bool fine = packed;
+    if (fine) {
+        fbase.resize(16384);
+        fdelta.resize(65536);
+        for (int b = 0; b < 16384 && fine; ++b) {
+            uint32_t hi;
+            std::memcpy(&hi, &gr[(size_t)b * 4], 4);
+            fbase[b] = hi;
+            for (int j = 0; j < 4; ++j) {
+                uint32_t v;
+                std::memcpy(&v, &gr[(size_t)b * 4 + j], 4);
+                if (v > hi || hi - v > 255u) {
+                    fine = false;
+                    break;
+                }
+                fdelta[(size_t)b * 4 + j] = (uint8_t)(hi - v);
+            }
+        }
+    }
     void *d = nullptr;
     const size_t gr_bytes = gr.size() * sizeof(float);
-    if (hipMalloc(&d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0)) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: range LUT allocation failed");
-    VSZIP_HIP_CHECK(ctx, hipMemcpy(d, gr.data(), gr_bytes, hipMemcpyHostToDevice));
-    if (packed) {
-        VSZIP_HIP_CHECK(ctx, hipMemcpy(static_cast<char *>(d) + gr_bytes, pbase.data(), 4096, hipMemcpyHostToDevice));
-        VSZIP_HIP_CHECK(ctx, hipMemcpy(static_cast<char *>(d) + gr_bytes + 4096, pdelta.data(), 131072, hipMemcpyHostToDevice));
+    if (hipMalloc(&d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0) + (fine ? (size_t)kWalkFineBytes : 0)) != hipSuccess)
+        return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: range LUT allocation failed");
+    auto upload = [&](size_t off, const void *src, size_t n) { return hipMemcpy(static_cast<char *>(d) + off, src, n, hipMemcpyHostToDevice) == hipSuccess; };
+    bool up_ok = upload(0, gr.data(), gr_bytes);
+    if (packed) up_ok = up_ok && upload(gr_bytes, pbase.data(), 4096) && upload(gr_bytes + 4096, pdelta.data(), 131072);
+    if (fine) up_ok = up_ok && upload(gr_bytes + kL16LutBytes, fbase.data(), 65536) && upload(gr_bytes + kL16LutBytes + 65536, fdelta.data(), 65536);
+    if (!up_ok) {
+        (void)hipGetLastError();
+        (void)hipFree(d);  // (the allocation leaked on a failed upload)
+        return vszip_set_error(ctx, VSZIP_ERR_HIP, "Bilateral: range LUT upload failed");
+    }
+    {
         PackedLuts &pl = packed_luts();
         std::lock_guard<std::mutex> lk(pl.mu);
-        uint64_t key;
-        std::memcpy(&key, &cfg->sigmaR, sizeof key);
-        pl.exact[d] = key;
+        // the registry is keyed by the raw pointer: an address reused after a free that bypassed vszip_dev_free must not keep a stale entry
+        pl.exact.erase(d);
+        pl.fine.erase(d);
+        if (packed) {
+            uint64_t key;
+            std::memcpy(&key, &cfg->sigmaR, sizeof key);
+            pl.exact[d] = key;
+            if (fine) pl.fine.insert(d);
+        }
     }
     cfg->gr_lut = static_cast<float *>(d);
     if (cfg->algorithm == 2) {
@@ -1102,15 +1161,22 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         if (lds16) {
             // planes whose tables have the same content and the same radius / step (the planes of an RGB clip, the
             // chroma planes of a YUV one) share a launch, whichever allocation each of them points at
-            std::vector<uint64_t> keys(n), tables;
+            // (compared field by field — table content = the bits of sigmaR, radius, step —, not through a hash: ADVICE r2)
+            struct GroupKey {
+                uint64_t table;
+                int radius, step;
+                bool operator==(const GroupKey &o) const { return table == o.table && radius == o.radius && step == o.step; }
+            };
+            std::vector<GroupKey> keys(n), tables;
             for (int i = 0; i < n; ++i) {
-                lut_is_packed(prm.p[i].gr, &keys[i]);
+                lut_is_packed(prm.p[i].gr, &keys[i].table);
                 // ... and the same radius / step: the launch then takes the kernel with compile-time taps
-                keys[i] = keys[i] * 1000003u + (uint64_t)prm.p[i].radius * 64u + (uint64_t)prm.p[i].step;
+                keys[i].radius = prm.p[i].radius;
+                keys[i].step = prm.p[i].step;
                 if (std::find(tables.begin(), tables.end(), keys[i]) == tables.end()) tables.push_back(keys[i]);
             }
             rc = VSZIP_OK;
-            for (const uint64_t tbl : tables) {
+            for (const GroupKey &tbl : tables) {
                 BLParams q;
                 q.peak = prm.peak;
                 q.lut_len = prm.lut_len;
@@ -1118,25 +1184,28 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 q.nplanes = 0;
                 int qb = 0;
                 for (int i = 0; i < n; ++i) {
-                    if (keys[i] != tbl) continue;
+                    if (!(keys[i] == tbl)) continue;
                     BLPlane &dp = q.p[q.nplanes++];
                     dp = prm.p[i];
                     dp.block0 = qb;
                     const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64;
                     qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
                 }
-                static const bool no_walk = getenv("VSZIP_BILATERAL_NO_WALK") != nullptr;
+                const bool no_walk = getenv("VSZIP_BILATERAL_NO_WALK") != nullptr;  // (read per call: the tests switch paths inside one process)
                 if (dtype == VSZIP_U16 && !joint && !no_walk && q.nplanes > 0) {
                     int r = q.p[0].radius, st = q.p[0].step;
                     for (int i = 1; i < q.nplanes; ++i)
                         if (q.p[i].radius != r || q.p[i].step != st) r = st = 0;
+                    const bool no_fine = getenv("VSZIP_BILATERAL_NO_FINE") != nullptr;
+                    bool fine = !no_fine;
+                    for (int i = 0; i < q.nplanes && fine; ++i) lut_is_packed(q.p[i].gr, nullptr, &fine);
                     if (r == 3 && st == 2) {
-                        rc = launch_walk16<3, 2>(ctx, q);
+                        rc = launch_walk16<3, 2>(ctx, q, fine);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
                     if (r == 2 && st == 1) {
-                        rc = launch_walk16<2, 1>(ctx, q);
+                        rc = launch_walk16<2, 1>(ctx, q, fine);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
