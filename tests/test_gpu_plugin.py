@@ -653,6 +653,74 @@ def test_fused_chain_equals_unfused(oracle):
     assert vs.fusion_stats() == (f2, s2)
 
 
+def test_fused_two_input_and_metric_sinks(oracle):
+    """Round 3: create-time fusion reaches the two-input filter and the metric sinks.
+      * LimitFilter(src.vszip.BoxBlur(2,2), src) — the reference's own canonical construction (tests/test_int_parity.py:158-167):
+        ONE upload of src (flt and src share the root), BoxBlur + LimitFilter on the device, one download; with a `planes` subset
+        the planes LimitFilter does not process come back as flt's device planes; a `ref` chain of the same root as well;
+      * PlaneAverage / PlaneMinMax on a pixel chain: the statistics read the chain's planes on the device, the output frame
+        carries them (the reference returns clipa's frame), clipb may be another chain of the same root;
+      * XPSNR(src, src.vszip.BoxBlur(..)): the distorted clip's chain runs on the device, src is requested and uploaded once.
+    Every fused result is bit-identical to its unfused twin (every hop through host memory); vszip_plugin_fusion_stats counts them."""
+    frames = [[fx.tiled_natural(s, np.uint16, p) if f == 0 else fx.splitmix64_plane(10 * f + p, s, np.uint16) for p, s in enumerate([(96, 160), (48, 80), (48, 80)])] for f in range(3)]
+    src = vs.source(frames, vs.YUV420P16)
+    same = lambda a, b: all(np.array_equal(np.array(a[p]), np.array(b[p])) for p in range(3))
+
+    # ---- LimitFilter
+    f0, s0 = vs.fusion_stats()
+    fused = src.vszip.BoxBlur(hradius=2, vradius=2).vszip.LimitFilter(src, dark_thr=8, bright_thr=8, elast=3)
+    got = [fused.get_frame(n) for n in range(3)]
+    assert vs.fusion_stats() == (f0 + 3, s0 + 3)
+    flt = _materialize(src.vszip.BoxBlur(hradius=2, vradius=2), vs.YUV420P16, 3)
+    twin = flt.vszip.LimitFilter(_materialize(src, vs.YUV420P16, 3), dark_thr=8, bright_thr=8, elast=3)
+    f1, s1 = vs.fusion_stats()
+    for n in range(3):
+        assert same(got[n], twin.get_frame(n)), n
+    assert vs.fusion_stats() == (f1, s1)
+    # a planes subset (unprocessed planes are flt's: from the device) and a `ref` chain of the same root
+    part = src.vszip.BoxBlur(hradius=2, vradius=2).vszip.LimitFilter(src, ref=src.vszip.BoxBlur(hradius=4, vradius=4), dark_thr=[16, 4], bright_thr=[8, 2], planes=[0])
+    ptwin = flt.vszip.LimitFilter(_materialize(src, vs.YUV420P16, 3), ref=_materialize(src.vszip.BoxBlur(hradius=4, vradius=4), vs.YUV420P16, 3),
+                                  dark_thr=[16, 4], bright_thr=[8, 2], planes=[0])
+    assert same(part.get_frame(1), ptwin.get_frame(1))
+    # against the oracle (thresholds: the reference's build scales a clip without a range prop as limited)
+    fr = part.get_frame(1)
+    for p in range(3):
+        fl = oracle.boxblur(frames[1][p], 2, 1, 2, 1)
+        if p == 0:
+            dk, br = oracle.scale_value_from_8bit(16, False, 16, True), oracle.scale_value_from_8bit(8, False, 16, True)
+            fl = oracle.limit_filter(fl, frames[1][p], oracle.boxblur(frames[1][p], 4, 1, 4, 1), dk, br, 2.0)
+        assert np.array_equal(np.array(fr[p]), fl), p
+
+    # ---- PlaneAverage / PlaneMinMax as sinks
+    f2, s2 = vs.fusion_stats()
+    chain = src.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=3, vradius=3, planes=[0])
+    pa = chain.vszip.PlaneAverage(exclude=[-1], planes=[0, 1, 2], clipb=src.vszip.BoxBlur(hradius=1, vradius=1))
+    pm = chain.vszip.PlaneMinMax(minthr=0.1, maxthr=0.1, planes=[0, 1, 2], clipb=src)
+    ga, gm = pa.get_frame(0), pm.get_frame(0)
+    assert vs.fusion_stats() == (f2 + 2, s2 + 3 + 2)
+    mat = _materialize(chain, vs.YUV420P16, 3)
+    ta = mat.vszip.PlaneAverage(exclude=[-1], planes=[0, 1, 2], clipb=_materialize(src.vszip.BoxBlur(hradius=1, vradius=1), vs.YUV420P16, 3)).get_frame(0)
+    tm = mat.vszip.PlaneMinMax(minthr=0.1, maxthr=0.1, planes=[0, 1, 2], clipb=_materialize(src, vs.YUV420P16, 3)).get_frame(0)
+    assert same(ga, ta) and same(gm, tm)  # the output frames carry the chain's pixels
+    for k in ("psmAvg", "psmDiff"):
+        assert ga.props[k] == ta.props[k], k
+    for k in ("psmMin", "psmMax", "psmDiff"):
+        assert gm.props[k] == tm.props[k], k
+
+    # ---- XPSNR with a fused distorted clip of the reference's own root
+    s8 = vs.source([[(p >> 8).astype(np.uint8) for p in fr_] for fr_ in frames], vs.YUV420P8)
+    f3, s3 = vs.fusion_stats()
+    xp = s8.vszip.XPSNR(s8.vszip.BoxBlur(hradius=2, vradius=2), verbose=False)
+    gx = [xp.get_frame(n) for n in range(3)]
+    assert vs.fusion_stats() == (f3 + 3, s3 + 3)
+    tx = s8.vszip.XPSNR(_materialize(s8.vszip.BoxBlur(hradius=2, vradius=2), vs.YUV420P8, 3), verbose=False)
+    for n in range(3):
+        want = tx.get_frame(n)
+        assert same(gx[n], want), n
+        for k in ("XPSNR_Y", "XPSNR_U", "XPSNR_V"):
+            assert gx[n].props[k] == want.props[k], (n, k)
+
+
 def test_fused_pipeline_into_ssimulacra2(oracle):
     """BASELINE config 5 through libvszip.so: SSIMULACRA2(src, src.Bilateral().BoxBlur()) uploads the source frame
     ONCE (both inputs share the root), runs Bilateral and BoxBlur on the device and returns a score — the

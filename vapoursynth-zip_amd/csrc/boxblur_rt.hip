@@ -29,6 +29,7 @@ struct RParams {
     RPlane p[kMaxPlanesRT];
     int nplanes;
     int radius;
+    int keep;  // the output is the next pass's input: plain stores (it stays in L2 / the Infinity Cache); 0: streamed out with the nt hint
 };
 
 __device__ __forceinline__ int rt_find(const RParams &prm, int b) {
@@ -152,7 +153,7 @@ struct RtVec {
                 v[k] = (d[k >> 2] >> ((k & 3) * 8)) & 0xffu;
         }
     }
-    static __device__ __forceinline__ void store(T *p, const uint32_t v[V], int n) {
+    static __device__ __forceinline__ void store(T *p, const uint32_t v[V], int n, int keep = 0) {
         if (n >= V) {
             uint32_t d[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -164,7 +165,10 @@ struct RtVec {
             }
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 q = {d[0], d[1], d[2], d[3]};
-            __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(p));  // streamed output: keep it out of L2
+            if (keep)
+                *reinterpret_cast<u32x4 *>(p) = q;  // an intermediate pass: the next pass reads it back from cache
+            else
+                __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(p));  // streamed output: keep it out of L2
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k)
@@ -177,6 +181,7 @@ struct RVParams {
     RPlane p[kMaxPlanesRT];
     int ncg[kMaxPlanesRT];  // column groups (64 lanes x V columns) per plane
     int nplanes, radius, band;
+    int keep;
 };
 
 // Vertical: lane = V adjacent columns, one wave per (column group, band of rows). E_0 and the
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm
                     o[k] = ((mul24 ? (uint32_t)__umul24(e[k], inv2) : e[k] * inv2) + kk[k]) >> 16;
                     e[k] += a[k] - c[k];
                 }
-                X::store(d + (size_t)i * ds, o, nst);
+                X::store(d + (size_t)i * ds, o, nst, prm.keep);
             }
         }
     }
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hrow_kernel(const RParams prm) 
                 o[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
             }
         }
-        X::store(d + x0, o, min(V, w - x0));
+        X::store(d + x0, o, min(V, w - x0), prm.keep);
     }
 }
 
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
                     o[k] = scale(e);
                 }
             }
-            X::store(d + x0, o, min(V, w - x0));
+            X::store(d + x0, o, min(V, w - x0), prm.keep);
         }
         vszip_wave_fence();  // the next iteration overwrites a ring slot
     }
@@ -654,8 +659,123 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3 — several integer passes along one axis in ONE kernel (blur_passes, boxblur_runtime.zig:81-119): a 256-thread
+// workgroup owns a row; a thread keeps its 16 contiguous samples in REGISTERS across the passes. Per pass: in-thread
+// prefix, DPP wave scan, the four wave totals through LDS, the row's prefix parked in LDS laid out [sample-in-thread][thread]
+// (conflict free both ways), then every output is the difference of two prefix entries plus the two mirror terms of blurInt
+// (:24-40) at the row ends — the closed form of the single-pass kernels, so the bits are theirs. HBM sees the row once
+// in and once out whatever the number of passes (the per-pass kernels: one round trip per pass). Two barriers per pass; the
+// prefix is double buffered. Rows up to 4096 samples; the vertical passes run through it on transposed planes.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHmNT = 256, kHmEPT = 16, kHmMaxW = kHmNT * kHmEPT;
+
 template <typename T>
-int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool vertical) {
+__global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams prm, const int passes) {
+    __shared__ uint32_t P[2][kHmMaxW];
+    __shared__ uint32_t wtot[2][4];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int y = b - pl.block0;
+    const int w = pl.w, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = tid * kHmEPT;
+    uint32_t v[kHmEPT];
+    {
+        // 16 samples = one (u8) or two (u16) 16-byte loads; [w, stride) is readable padding, masked here
+        constexpr int V = RtVec<T>::V;
+#pragma unroll
+        for (int g = 0; g < kHmEPT / V; ++g) {
+            uint32_t t[V];
+            if (x0 + g * V < w) {
+                RtVec<T>::load(s + x0 + g * V, t);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) t[k] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[g * V + k] = (x0 + g * V + k < w) ? t[k] : 0u;
+        }
+    }
+    const uint32_t ksize = 2u * (uint32_t)R + 1u;
+    const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    for (int pass = 0; pass < passes; ++pass) {
+        uint32_t *Pb = P[pass & 1];
+        uint32_t p[kHmEPT];
+        p[0] = v[0];
+#pragma unroll
+        for (int k = 1; k < kHmEPT; ++k) p[k] = p[k - 1] + v[k];
+        const uint32_t incl = wave_incl_scan_dpp(p[kHmEPT - 1]);
+        if (lane == 63) wtot[pass & 1][wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - p[kHmEPT - 1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < wave) base += wtot[pass & 1][q];
+#pragma unroll
+        for (int k = 0; k < kHmEPT; ++k) Pb[k * kHmNT + tid] = p[k] + base;
+        __syncthreads();
+        auto at = [&](uint32_t c) { return Pb[(c & (uint32_t)(kHmEPT - 1)) * kHmNT + (c >> 4)]; };
+        auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : at((uint32_t)min(c, w - 1)); };
+        const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2 * sum_{x<r} srcp[x]
+        const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
+        // a thread whose 16 windows stay inside the row needs no mirror term
+        const bool inner = x0 - R - 1 >= 0 && x0 + kHmEPT - 1 + R <= w - 1;
+        if (inner) {
+#pragma unroll
+            for (int k = 0; k < kHmEPT; ++k) {
+                const uint32_t x = (uint32_t)(x0 + k);
+                const uint32_t e = at(x + (uint32_t)R) - at(x - (uint32_t)R - 1u);
+                v[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kHmEPT; ++k) {
+                const int x = x0 + k;
+                uint32_t o = 0;
+                if (x < w) {
+                    // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
+                    uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
+                    if (x - R - 1 < -1) e += Q(R - x - 1);
+                    if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
+                    o = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
+                }
+                v[k] = o;
+            }
+        }
+    }
+    {
+        constexpr int V = RtVec<T>::V;
+#pragma unroll
+        for (int g = 0; g < kHmEPT / V; ++g)
+            if (x0 + g * V < w) RtVec<T>::store(d + x0 + g * V, v + g * V, min(V, w - (x0 + g * V)), prm.keep);
+    }
+}
+
+// 64 x 64 tiles through LDS: dst[x][y] = src[y][x] (integer planes; the vertical passes of the fused path)
+template <typename T>
+__global__ __launch_bounds__(256) void rt_transpose_kernel(const RParams prm) {
+    __shared__ T tile[64][64 + 2];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int lb = b - pl.block0;
+    const int nbx = (pl.w + 63) / 64;
+    const int bx = (lb % nbx) * 64, by = (lb / nbx) * 64;
+    const T *s = static_cast<const T *>(pl.src);
+    T *d = static_cast<T *>(pl.dst);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4)
+        if (by + r < pl.h && bx + tx < pl.w) tile[r][tx] = s[(size_t)(by + r) * pl.sstride + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4)
+        if (bx + r < pl.w && by + tx < pl.h) d[(size_t)(bx + r) * pl.dstride + by + tx] = tile[tx][r];
+}
+
+template <typename T>
+int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool vertical, bool keep) {
     constexpr bool is_int = std::is_integral<T>::value;
     size_t done = 0;
     while (done < pl.size()) {
@@ -663,6 +783,7 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
         const int n = (int)std::min<size_t>(kMaxPlanesRT, pl.size() - done);
         prm.nplanes = n;
         prm.radius = radius;
+        prm.keep = keep ? 1 : 0;
         int blocks = 0, maxw = 0;
         for (int i = 0; i < n; ++i) {
             prm.p[i] = pl[done + i];
@@ -704,6 +825,7 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                 RVParams vp;
                 vp.nplanes = n;
                 vp.radius = radius;
+                vp.keep = keep ? 1 : 0;
                 // bands: enough waves to fill the chip, long enough that the 3r+2 warm-up rows stay a fraction
                 long colgroups = 0;
                 int maxh = 0;
@@ -753,40 +875,177 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
         off[i] = elems;
         elems += (size_t)((planes[i].w + 63) & ~63) * planes[i].h;
     }
-    T *scratch[2] = {nullptr, nullptr};
-    if (total > 1) {
-        int rc = vszip_ensure_scratch(ctx, 2 * elems * sizeof(T) + 256);
-        if (rc != VSZIP_OK) return rc;
-        scratch[0] = static_cast<T *>(ctx->scratch);
-        scratch[1] = scratch[0] + elems;
+    // Integer planes with >= 2 passes on an axis: the fused kernel keeps a row in registers across that axis's passes
+    // (horizontal directly; vertical, from 3 passes on, between two transposes: four HBM round trips for any 5 + 5 instead of ten).
+    if constexpr (std::is_integral<T>::value) {
+        bool ok = !getenv("VSZIP_RT_NO_FUSED") && total > 1;
+        const bool fuse_h = hb && hpasses >= 2, fuse_v = vb && vpasses >= 3;
+        ok = ok && (fuse_h || fuse_v);
+        for (int i = 0; i < nplanes && ok; ++i) {
+            const vszip_plane &q = planes[i];
+            ok = (((reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.src_stride * sizeof(T)) | (uintptr_t)((size_t)q.dst_stride * sizeof(T))) & 15) == 0) &&
+                 (size_t)q.src_stride >= (size_t)((q.w + RtVec<T>::V - 1) / RtVec<T>::V) * RtVec<T>::V;
+            if (fuse_h) ok = ok && q.w <= kHmMaxW && hradius < q.w;
+            if (fuse_v) ok = ok && q.h <= kHmMaxW && vradius < q.h;
+        }
+        if (ok) {
+            // scratch: two buffers that hold a plane set in either orientation (rows padded to 64 samples)
+            std::vector<size_t> poff(nplanes);
+            size_t pe = 0;
+            for (int i = 0; i < nplanes; ++i) {
+                poff[i] = pe;
+                pe += std::max((size_t)((planes[i].w + 63) & ~63) * planes[i].h, (size_t)((planes[i].h + 63) & ~63) * planes[i].w);
+            }
+            int rc = vszip_ensure_scratch(ctx, 2 * pe * sizeof(T) + 256);
+            if (rc != VSZIP_OK) return rc;
+            T *buf[2] = {static_cast<T *>(ctx->scratch), static_cast<T *>(ctx->scratch) + pe};
+            struct Cur { const void *ptr; int stride, w, h; };
+            std::vector<Cur> cur(nplanes);
+            for (int i = 0; i < nplanes; ++i) cur[i] = Cur{planes[i].src, (int)planes[i].src_stride, planes[i].w, planes[i].h};
+            int which = 0;
+            // one step over all planes: kind 0 = fused passes along the rows, 1 = transpose; `to_dst`: into the caller's planes
+            auto step = [&](int kind, int radius, int npass, bool to_dst) -> int {
+                size_t done = 0;
+                while (done < (size_t)nplanes) {
+                    RParams prm;
+                    const int n = (int)std::min<size_t>(kMaxPlanesRT, nplanes - done);
+                    prm.nplanes = n;
+                    prm.radius = radius;
+                    prm.keep = to_dst ? 0 : 1;
+                    int blocks = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const int gi = (int)done + i;
+                        RPlane &r = prm.p[i];
+                        r.src = cur[gi].ptr;
+                        r.sstride = cur[gi].stride;
+                        r.w = cur[gi].w;
+                        r.h = cur[gi].h;
+                        const int ow = kind == 1 ? cur[gi].h : cur[gi].w;
+                        if (to_dst) {
+                            r.dst = planes[gi].dst;
+                            r.dstride = (int)planes[gi].dst_stride;
+                        } else {
+                            r.dst = buf[which] + poff[gi];
+                            r.dstride = (ow + 63) & ~63;
+                        }
+                        r.block0 = blocks;
+                        blocks += kind == 1 ? ((r.w + 63) / 64) * ((r.h + 63) / 64) : r.h;
+                    }
+                    if (kind == 1)
+                        hipLaunchKernelGGL((rt_transpose_kernel<T>), dim3(blocks), dim3(256), 0, ctx->stream, prm);
+                    else
+                        hipLaunchKernelGGL((boxblur_rt_hmulti_kernel<T>), dim3(blocks), dim3(kHmNT), 0, ctx->stream, prm, npass);
+                    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+                    for (int i = 0; i < n; ++i) {
+                        const int gi = (int)done + i;
+                        const RPlane &r = prm.p[i];
+                        cur[gi] = kind == 1 ? Cur{r.dst, r.dstride, r.h, r.w} : Cur{r.dst, r.dstride, r.w, r.h};
+                    }
+                    done += n;
+                }
+                which ^= 1;
+                return VSZIP_OK;
+            };
+            // the per-pass kernels on the current planes (an axis the fused kernel does not take), into scratch or the caller's planes
+            auto per_pass = [&](int radius, int npass, bool vertical, bool last_axis) -> int {
+                for (int p = 0; p < npass; ++p) {
+                    const bool to_dst = last_axis && p == npass - 1;
+                    std::vector<RPlane> v(nplanes);
+                    for (int i = 0; i < nplanes; ++i) {
+                        v[i].src = cur[i].ptr;
+                        v[i].sstride = cur[i].stride;
+                        v[i].w = cur[i].w;
+                        v[i].h = cur[i].h;
+                        v[i].dst = to_dst ? planes[i].dst : static_cast<void *>(buf[which] + poff[i]);
+                        v[i].dstride = to_dst ? (int)planes[i].dst_stride : ((cur[i].w + 63) & ~63);
+                    }
+                    const int prc = launch_pass<T>(ctx, v, radius, vertical, !to_dst);
+                    if (prc != VSZIP_OK) return prc;
+                    for (int i = 0; i < nplanes; ++i) cur[i] = Cur{v[i].dst, v[i].dstride, v[i].w, v[i].h};
+                    which ^= 1;
+                }
+                return VSZIP_OK;
+            };
+            if (hb) {
+                rc = fuse_h ? step(0, hradius, hpasses, !vb) : per_pass(hradius, hpasses, false, !vb);
+                if (rc != VSZIP_OK) return rc;
+            }
+            if (vb) {
+                if (fuse_v) {
+                    if ((rc = step(1, 0, 0, false)) != VSZIP_OK) return rc;
+                    if ((rc = step(0, vradius, vpasses, false)) != VSZIP_OK) return rc;
+                    if ((rc = step(1, 0, 0, true)) != VSZIP_OK) return rc;
+                } else if ((rc = per_pass(vradius, vpasses, true, true)) != VSZIP_OK) {
+                    return rc;
+                }
+            }
+            return VSZIP_OK;
+        }
     }
-    std::vector<RPlane> cur(nplanes);
-    for (int i = 0; i < nplanes; ++i) {
-        cur[i].src = planes[i].src;
-        cur[i].sstride = (int)planes[i].src_stride;
-        cur[i].w = planes[i].w;
-        cur[i].h = planes[i].h;
-    }
-    int which = 0;
-    for (int p = 0; p < total; ++p) {
-        const bool vertical = p >= (hb ? hpasses : 0);
-        const bool last = p == total - 1;
-        for (int i = 0; i < nplanes; ++i) {
-            if (last) {
-                cur[i].dst = planes[i].dst;
-                cur[i].dstride = (int)planes[i].dst_stride;
-            } else {
-                cur[i].dst = scratch[which] + off[i];
-                cur[i].dstride = (planes[i].w + 63) & ~63;
+    // Several passes: the planes go through ALL passes in groups small enough that a pass's output is still in the Infinity
+    // Cache (256 MiB, memory side) when the next pass reads it — a line stays resident while everything touched between its two
+    // uses fits (MI355X_MICROARCH.md, Infinity Cache): about three group sizes here, so groups of <= 48 MB. HBM then sees the
+    // first read and the last write; the passes in between run cache to cache (their stores drop the nt hint). One pass, or
+    // VSZIP_RT_GROUP_MB=0: one group.
+    // (measured, round 3: 4K YUV420P16 3 + 3 passes of r = 5, groups of 24 / 48 / 96 MB: 8.4 k / 12.8 k / 13.6 k fps against 13.5 k in one
+    // group — the passes are not HBM-bound enough for residency to beat the smaller launches; the default is ONE group)
+    size_t group_bytes = ~(size_t)0;
+    if (const char *e = getenv("VSZIP_RT_GROUP_MB")) group_bytes = atoi(e) > 0 ? (size_t)atoi(e) << 20 : ~(size_t)0;
+    int g0 = 0;
+    while (g0 < nplanes) {
+        int g1 = g0;
+        size_t bytes = 0, elems_g = 0;
+        while (g1 < nplanes && (g1 == g0 || bytes + (size_t)planes[g1].w * planes[g1].h * sizeof(T) <= group_bytes)) {
+            bytes += (size_t)planes[g1].w * planes[g1].h * sizeof(T);
+            elems_g += (size_t)((planes[g1].w + 63) & ~63) * planes[g1].h;
+            ++g1;
+        }
+        const int ng = g1 - g0;
+        T *scratch[2] = {nullptr, nullptr};
+        std::vector<size_t> goff(ng);
+        {
+            size_t e = 0;
+            for (int i = 0; i < ng; ++i) {
+                goff[i] = e;
+                e += (size_t)((planes[g0 + i].w + 63) & ~63) * planes[g0 + i].h;
             }
         }
-        int rc = launch_pass<T>(ctx, cur, vertical ? vradius : hradius, vertical);
-        if (rc != VSZIP_OK) return rc;
-        for (int i = 0; i < nplanes; ++i) {
-            cur[i].src = cur[i].dst;
-            cur[i].sstride = cur[i].dstride;
+        if (total > 1) {
+            // (grow-only scratch sized for the largest group seen; every group reuses the same two buffers)
+            int rc = vszip_ensure_scratch(ctx, 2 * elems_g * sizeof(T) + 256);
+            if (rc != VSZIP_OK) return rc;
+            scratch[0] = static_cast<T *>(ctx->scratch);
+            scratch[1] = scratch[0] + elems_g;
         }
-        which ^= 1;
+        std::vector<RPlane> cur(ng);
+        for (int i = 0; i < ng; ++i) {
+            cur[i].src = planes[g0 + i].src;
+            cur[i].sstride = (int)planes[g0 + i].src_stride;
+            cur[i].w = planes[g0 + i].w;
+            cur[i].h = planes[g0 + i].h;
+        }
+        int which = 0;
+        for (int p = 0; p < total; ++p) {
+            const bool vertical = p >= (hb ? hpasses : 0);
+            const bool last = p == total - 1;
+            for (int i = 0; i < ng; ++i) {
+                if (last) {
+                    cur[i].dst = planes[g0 + i].dst;
+                    cur[i].dstride = (int)planes[g0 + i].dst_stride;
+                } else {
+                    cur[i].dst = scratch[which] + goff[i];
+                    cur[i].dstride = (planes[g0 + i].w + 63) & ~63;
+                }
+            }
+            int rc = launch_pass<T>(ctx, cur, vertical ? vradius : hradius, vertical, !last);
+            if (rc != VSZIP_OK) return rc;
+            for (int i = 0; i < ng; ++i) {
+                cur[i].src = cur[i].dst;
+                cur[i].sstride = cur[i].dstride;
+            }
+            which ^= 1;
+        }
+        g0 = g1;
     }
     return VSZIP_OK;
 }

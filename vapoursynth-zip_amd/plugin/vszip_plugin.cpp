@@ -590,6 +590,76 @@ const char *run_stage(const StageRef &s, Gpu *g, const Z &z, int nplanes, DPlane
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused INPUTS of multi-clip and metric filters (round 3: LimitFilter, PlaneAverage / PlaneMinMax, XPSNR): each input clip
+// is resolved to its chain at create time; per frame the distinct ROOT frames are requested once, each needed root plane
+// is uploaded once (two inputs with one root — LimitFilter(src.vszip.BoxBlur(2,2), src), the reference's own canonical
+// construction, tests/test_int_parity.py:158-167 — share it) and every input's upstream stages run on the device.
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedInput {
+    const Chain *chain = nullptr;   // resolved at create time (owned by the instance data)
+    const VSFrame *frame = nullptr; // this frame's root frame (shared between inputs of one root; released once)
+    DPlane cur[3];                  // the input's planes on the device after its stages
+    bool touched[3] = {false, false, false};
+    bool stage_touches(int p) const {
+        for (const StageRef &s : chain->stages)
+            if (stage_processes(s, p)) return true;
+        return false;
+    }
+};
+// arInitial: every distinct root once
+void request_fused_inputs(const VSAPI *api, int n, VSFrameContext *fctx, FusedInput *in, int k) {
+    for (int i = 0; i < k; ++i) {
+        if (!in[i].chain) continue;
+        bool seen = false;
+        for (int j = 0; j < i; ++j) seen = seen || (in[j].chain && in[j].chain->root == in[i].chain->root);
+        if (!seen) api->requestFrameFilter(n, in[i].chain->root, fctx);
+    }
+}
+void fetch_fused_inputs(const VSAPI *api, int n, VSFrameContext *fctx, FusedInput *in, int k) {
+    for (int i = 0; i < k; ++i) {
+        if (!in[i].chain) continue;
+        for (int j = 0; j < i && !in[i].frame; ++j)
+            if (in[j].chain && in[j].chain->root == in[i].chain->root) in[i].frame = in[j].frame;
+        if (!in[i].frame) in[i].frame = api->getFrameFilter(n, in[i].chain->root, fctx);
+    }
+}
+void release_fused_inputs(const VSAPI *api, FusedInput *in, int k) {
+    for (int i = 0; i < k; ++i) {
+        if (!in[i].frame) continue;
+        bool shared = false;
+        for (int j = 0; j < i; ++j) shared = shared || in[j].frame == in[i].frame;
+        if (!shared) api->freeFrame(in[i].frame);
+    }
+    for (int i = 0; i < k; ++i) in[i].frame = nullptr;
+}
+// Uploads (once per root frame and plane) and runs the stages. need[i][p]: the consumer reads plane p of input i; planes an
+// input's stages process are staged as well (a stage works on its own plane set). nullptr on success.
+const char *stage_fused_inputs(const Z &z, Gpu *g, FusedInput *in, int k, const bool (*need)[3], int nplanes) {
+    size_t stages_run = 0;
+    for (int i = 0; i < k; ++i) {
+        if (!in[i].chain) continue;
+        for (int p = 0; p < nplanes; ++p) {
+            if (!need[i][p] && !in[i].stage_touches(p)) continue;
+            for (int j = 0; j < i && !in[i].cur[p].ptr; ++j)  // the same root frame's plane, uploaded for an earlier input: its BASE (not its stage output)
+                if (in[j].frame == in[i].frame && in[j].cur[p].ptr && !in[j].touched[p]) in[i].cur[p] = in[j].cur[p];
+            if (!in[i].cur[p].ptr) in[i].cur[p] = z.upload(g, in[i].frame, p);
+            if (!in[i].cur[p].ptr) return "device staging failed";
+        }
+    }
+    // stages after ALL uploads: an input's stage output must not be mistaken for the shared base of a later input
+    for (int i = 0; i < k; ++i) {
+        if (!in[i].chain) continue;
+        for (const StageRef &st : in[i].chain->stages) {
+            // a stage allocates fresh outputs (cur[p] is replaced, the shared base stays intact)
+            if (const char *e = run_stage(st, g, z, nplanes, in[i].cur, in[i].touched)) return e;
+            ++stages_run;
+        }
+    }
+    count_fused(stages_run);
+    return nullptr;
+}
+
 // getFrame of a pixel filter (BoxBlur, Bilateral, Limiter): the frames of the chain's root are uploaded once, the
 // fused upstream stages and the filter's own stage (`self`) run on the device, and every plane some stage wrote is
 // copied back; planes nobody touched are copied from the root frame by newVideoFrame2, like the reference does.
@@ -843,26 +913,29 @@ struct PlaneStatData {
     float minthr, maxthr;
     std::string key_a, key_b, key_d;  // Avg | Min, Max, Diff
     bool minmax;
+    Chain ca, cb;  // round 3: a metric sink of a vszip pixel chain takes the chain's planes on the device (no second upload)
 };
 
 const VSFrame *VS_CC planeStatGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<PlaneStatData *>(inst);
     Z z{api, core, fctx};
     const char *name = d->minmax ? "PlaneMinMax" : "PlaneAverage";
+    FusedInput in[2];
+    in[0].chain = &d->ca;
+    in[1].chain = d->node2 ? &d->cb : nullptr;
     if (reason == arInitial) {
-        api->requestFrameFilter(n, d->node1, fctx);
-        if (d->node2) api->requestFrameFilter(n, d->node2, fctx);
+        request_fused_inputs(api, n, fctx, in, 2);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *src = api->getFrameFilter(n, d->node1, fctx);
-        const VSFrame *ref = d->node2 ? api->getFrameFilter(n, d->node2, fctx) : nullptr;
+        fetch_fused_inputs(api, n, fctx, in, 2);
+        const VSFrame *src = in[0].frame;  // clipa's ROOT frame: the output is clipa's frame (:copyFrame) = this one with the chain's planes
+        const bool ref = d->node2 != nullptr;
         VSFrame *dst = api->copyFrame(src, core);
         VSMap *props = api->getFramePropertiesRW(dst);
         api->mapDeleteKey(props, d->key_d.c_str());
         api->mapDeleteKey(props, d->key_a.c_str());
         if (d->minmax) api->mapDeleteKey(props, d->key_b.c_str());
         auto done = [&](const VSFrame *r) {
-            api->freeFrame(src);
-            if (ref) api->freeFrame(ref);
+            release_fused_inputs(api, in, 2);
             return r;
         };
         FrameGate gate(n);
@@ -870,13 +943,17 @@ const VSFrame *VS_CC planeStatGetFrame(int n, int reason, void *inst, void **, V
         if (!g) return done(fail(z, nullptr, dst, name, "no MI355X device available (the plugin has no CPU fallback)"));
         std::vector<vszip_plane> tab;
         const VSVideoFormat *vf = api->getVideoFrameFormat(src);
+        bool need[2][3];
+        for (int p = 0; p < 3; ++p) need[0][p] = need[1][p] = p < vf->numPlanes && d->planes[p];
+        for (int p = 0; p < 3; ++p) need[1][p] = need[1][p] && ref;
+        if (const char *e = stage_fused_inputs(z, g, in, 2, need, vf->numPlanes)) return done(fail(z, g, dst, name, e));
         for (int p = 0; p < vf->numPlanes; ++p) {
             if (!d->planes[p]) continue;
-            DPlane s = z.upload(g, src, p), r;
-            if (ref) r = z.upload(g, ref, p);
-            if (!s.ptr || (ref && !r.ptr)) return done(fail(z, g, dst, name, "device staging failed"));
-            tab.push_back(mk_plane(s, nullptr, ref ? &r : nullptr));
+            tab.push_back(mk_plane(in[0].cur[p], nullptr, ref ? &in[1].cur[p] : nullptr));
         }
+        // the output frame carries clipa's pixels: planes its upstream stages wrote come back from the device
+        for (int p = 0; p < vf->numPlanes; ++p)
+            if (in[0].touched[p] && !z.download(g, in[0].cur[p], dst, p)) return done(fail(z, g, dst, name, "GPU kernel failed"));
         const int np = (int)tab.size();
         std::vector<double> a(np), b(np), df(np);
         int rc = VSZIP_OK;
@@ -910,6 +987,8 @@ const VSFrame *VS_CC planeStatGetFrame(int n, int reason, void *inst, void **, V
 
 void VS_CC planeStatFree(void *inst, VSCore *, const VSAPI *api) {
     auto *d = static_cast<PlaneStatData *>(inst);
+    free_chain(api, d->ca);
+    free_chain(api, d->cb);
     if (d->node2) api->freeNode(d->node2);
     api->freeNode(d->node1);
     delete d;
@@ -962,9 +1041,13 @@ void plane_stat_create(const VSMap *in, VSMap *out, VSCore *core, const VSAPI *a
         }
     }
     const int rp2 = (d->node2 && d->vi->numFrames <= api->getVideoInfo(d->node2)->numFrames) ? rpStrictSpatial : rpFrameReuseLastOnly;
-    VSFilterDependency deps[] = {{d->node1, rpStrictSpatial}, {d->node2, rp2}};
     PlaneStatData *raw = d.release();
-    api->createVideoFilter(out, name, raw->vi, planeStatGetFrame, planeStatFree, fmParallel, deps, raw->node2 ? 2 : 1, raw, core);
+    raw->ca = resolve_chain(api, raw->node1);
+    if (raw->node2) raw->cb = resolve_chain(api, raw->node2);
+    VSFilterDependency deps[2] = {{raw->ca.root, rpStrictSpatial}, {nullptr, rp2}};
+    int nd = 1;
+    if (raw->node2 && raw->cb.root != raw->ca.root) deps[nd++] = {raw->cb.root, rp2};
+    api->createVideoFilter(out, name, raw->vi, planeStatGetFrame, planeStatFree, fmParallel, deps, nd, raw, core);
 }
 void VS_CC planeAverageCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { plane_stat_create(in, out, core, api, false); }
 void VS_CC planeMinMaxCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const VSAPI *api) { plane_stat_create(in, out, core, api, true); }
@@ -1102,6 +1185,7 @@ struct LimitFilterData {
     int dt;
     bool planes[3];
     float dark[3], bright[3], elast[3];
+    Chain cflt, csrc, cref;  // each input resolved to its vszip chain (round 3): LimitFilter(src.vszip.BoxBlur(2,2), src) is one upload
 };
 
 // hz.getColorRange (helper.zig:261-279): frame 0's range prop, else RGB -> full, others -> limited — AS THE REFERENCE'S BUILD
@@ -1149,69 +1233,82 @@ float scale_value_from_8bit(const Z &z, float value, VSNode *target) {
 const VSFrame *VS_CC limitFilterGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<LimitFilterData *>(inst);
     Z z{api, core, fctx};
+    FusedInput in[3];
+    in[0].chain = &d->cflt;
+    in[1].chain = &d->csrc;
+    in[2].chain = d->ref ? &d->cref : nullptr;
     if (reason == arInitial) {
-        api->requestFrameFilter(n, d->flt, fctx);
-        api->requestFrameFilter(n, d->src, fctx);
-        if (d->ref) api->requestFrameFilter(n, d->ref, fctx);
+        request_fused_inputs(api, n, fctx, in, 3);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *src = api->getFrameFilter(n, d->src, fctx), *flt = api->getFrameFilter(n, d->flt, fctx);
-        const VSFrame *ref = d->ref ? api->getFrameFilter(n, d->ref, fctx) : nullptr;
-        auto release = [&] {
-            api->freeFrame(src);
-            api->freeFrame(flt);
-            if (ref) api->freeFrame(ref);
-        };
+        fetch_fused_inputs(api, n, fctx, in, 3);
+        const VSFrame *flt = in[0].frame;  // flt's ROOT frame: format and frame properties are flt's (the pixel filters pass both through)
         const VSVideoFormat *vf = api->getVideoFrameFormat(flt);
-        const VSFrame *psrc[3] = {d->planes[0] ? nullptr : flt, d->planes[1] ? nullptr : flt, d->planes[2] ? nullptr : flt};
+        const int np = vf->numPlanes;
+        // planes LimitFilter does not process are flt's (newVideoFrame2 on flt, :42): the root frame's plane where no upstream
+        // stage touched it, the device plane otherwise
+        bool flt_dev[3] = {false, false, false};
+        const VSFrame *psrc[3];
+        for (int p = 0; p < 3; ++p) {
+            flt_dev[p] = p < np && !d->planes[p] && in[0].stage_touches(p);
+            psrc[p] = (p < np && (d->planes[p] || flt_dev[p])) ? nullptr : flt;
+        }
         const int pidx[3] = {0, 1, 2};
         VSFrame *dst = api->newVideoFrame2(vf, api->getFrameWidth(flt, 0), api->getFrameHeight(flt, 0), psrc, pidx, flt, core);
         FrameGate gate(n);
         Gpu *g = gpu_for_frame(n, gate);
-        if (!g) {
-            const VSFrame *failed = fail(z, nullptr, dst, "LimitFilter", "no MI355X device available (the plugin has no CPU fallback)");  // abort the stream first: queued copies may still read the inputs
-            release();
+        auto bail = [&](const char *msg) {
+            const VSFrame *failed = fail(z, g, dst, "LimitFilter", msg);  // abort the stream first: queued copies may still read the inputs
+            release_fused_inputs(api, in, 3);
             return failed;
+        };
+        if (!g) return bail("no MI355X device available (the plugin has no CPU fallback)");
+        bool need[3][3];
+        for (int p = 0; p < 3; ++p) {
+            need[0][p] = p < np && (d->planes[p] || flt_dev[p]);
+            need[1][p] = p < np && d->planes[p];
+            need[2][p] = p < np && d->planes[p] && d->ref;
         }
+        if (const char *e = stage_fused_inputs(z, g, in, 3, need, np)) return bail(e);
         std::vector<vszip_plane> tab;
         std::vector<DPlane> outs;
         std::vector<int> which;
         std::vector<const void *> refs;
         std::vector<ptrdiff_t> rstr;
         std::vector<float> dk, br, el;
-        for (int p = 0; p < vf->numPlanes; ++p) {
+        for (int p = 0; p < np; ++p) {
             if (!d->planes[p]) continue;
-            DPlane f = z.upload(g, flt, p), s = z.upload(g, src, p), o = z.blank(g, f.w, f.h, f.bps);
-            DPlane r;
-            if (ref) r = z.upload(g, ref, p);
-            if (!f.ptr || !s.ptr || !o.ptr || (ref && !r.ptr)) {
-                const VSFrame *failed = fail(z, g, dst, "LimitFilter", "device staging failed");  // abort the stream first: queued copies may still read the inputs
-                release();
-                return failed;
-            }
-            tab.push_back(mk_plane(f, &o, &s));
+            const DPlane &f = in[0].cur[p], &sp = in[1].cur[p];
+            DPlane o = z.blank(g, f.w, f.h, f.bps);
+            if (!o.ptr) return bail("device staging failed");
+            tab.push_back(mk_plane(f, &o, &sp));
             outs.push_back(o);
             which.push_back(p);
-            refs.push_back(ref ? r.ptr : nullptr);
-            rstr.push_back(ref ? r.stride : 0);
+            refs.push_back(d->ref ? in[2].cur[p].ptr : nullptr);
+            rstr.push_back(d->ref ? in[2].cur[p].stride : 0);
             dk.push_back(d->dark[p]);
             br.push_back(d->bright[p]);
             el.push_back(d->elast[p]);
         }
         int rc = tab.empty() ? VSZIP_OK
-                             : vszip_limit_filter(g->ctx, d->dt, tab.data(), ref ? refs.data() : nullptr, ref ? rstr.data() : nullptr, (int)tab.size(), dk.data(),
+                             : vszip_limit_filter(g->ctx, d->dt, tab.data(), d->ref ? refs.data() : nullptr, d->ref ? rstr.data() : nullptr, (int)tab.size(), dk.data(),
                                                   br.data(), el.data());
         for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
             if (!z.download(g, outs[i], dst, which[i])) rc = VSZIP_ERR_HIP;
+        for (int p = 0; rc == VSZIP_OK && p < np; ++p)
+            if (flt_dev[p] && !z.download(g, in[0].cur[p], dst, p)) rc = VSZIP_ERR_HIP;
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
-        const VSFrame *result = rc != VSZIP_OK ? fail(z, g, dst, "LimitFilter", "GPU kernel failed") : dst;
-        release();
-        return result;
+        if (rc != VSZIP_OK) return bail("GPU kernel failed");
+        release_fused_inputs(api, in, 3);
+        return dst;
     }
     return nullptr;
 }
 
 void VS_CC limitFilterFree(void *inst, VSCore *, const VSAPI *api) {
     auto *d = static_cast<LimitFilterData *>(inst);
+    free_chain(api, d->cflt);
+    free_chain(api, d->csrc);
+    free_chain(api, d->cref);
     api->freeNode(d->flt);
     api->freeNode(d->src);
     if (d->ref) api->freeNode(d->ref);
@@ -1264,8 +1361,20 @@ void VS_CC limitFilterCreate(const VSMap *in, VSMap *out, void *, VSCore *core, 
         d.bright[i] = scale_value_from_8bit(z, d.bright[i], d.flt);
     }
     auto *data = new LimitFilterData(d);
-    VSFilterDependency deps[] = {{d.flt, rpStrictSpatial}, {d.src, rpStrictSpatial}, {d.ref, rpStrictSpatial}};
-    api->createVideoFilter(out, "LimitFilter", d.vi, limitFilterGetFrame, limitFilterFree, fmParallel, deps, d.ref ? 3 : 2, data, core);
+    data->cflt = resolve_chain(api, data->flt);
+    data->csrc = resolve_chain(api, data->src);
+    if (data->ref) data->cref = resolve_chain(api, data->ref);
+    // dependencies: the distinct roots (the nodes the frames are requested from)
+    VSFilterDependency deps[3];
+    int nd = 0;
+    const Chain *chains[3] = {&data->cflt, &data->csrc, data->ref ? &data->cref : nullptr};
+    for (const Chain *c : chains) {
+        if (!c) continue;
+        bool seen = false;
+        for (int i = 0; i < nd; ++i) seen = seen || deps[i].source == c->root;
+        if (!seen) deps[nd++] = {c->root, rpStrictSpatial};
+    }
+    api->createVideoFilter(out, "LimitFilter", d.vi, limitFilterGetFrame, limitFilterFree, fmParallel, deps, nd, data, core);
 }
 
 // ---------------------------------------------------------------------------
@@ -1694,25 +1803,31 @@ struct XpsnrData {
     std::mutex mu;
     uint64_t num_frames = 0;
     double sum_wdist[3] = {0, 0, 0}, sum_xpsnr[3] = {0, 0, 0};
+    // round 3: the DISTORTED clip as the output of a vszip pixel chain — XPSNR(src, src.vszip.BoxBlur(..)) — runs that chain on
+    // the device; when its root is the reference clip itself the frame is requested and uploaded once. The reference clip is
+    // never taken through a chain (its frames n - 1, n - 2 would need the chain three times): c1 has no stages.
+    Chain c1, c2;
 };
 
 const VSFrame *VS_CC xpsnrGetFrame(int n, int reason, void *inst, void **, VSFrameContext *fctx, VSCore *core, const VSAPI *api) {
     auto *d = static_cast<XpsnrData *>(inst);
     Z z{api, core, fctx};
     const bool want1 = d->temporal && n > 0, want2 = d->temporal && d->frame_rate >= 32 && n > 1;
+    FusedInput in[2];
+    in[0].chain = &d->c1;
+    in[1].chain = &d->c2;
     if (reason == arInitial) {
-        api->requestFrameFilter(n, d->node1, fctx);
-        api->requestFrameFilter(n, d->node2, fctx);
+        request_fused_inputs(api, n, fctx, in, 2);
         if (want1) api->requestFrameFilter(n - 1, d->node1, fctx);
         if (want2) api->requestFrameFilter(n - 2, d->node1, fctx);
     } else if (reason == arAllFramesReady) {
-        const VSFrame *s1 = api->getFrameFilter(n, d->node1, fctx), *s2 = api->getFrameFilter(n, d->node2, fctx);
+        fetch_fused_inputs(api, n, fctx, in, 2);
+        const VSFrame *s2 = in[1].frame;  // the distorted clip's ROOT frame: the output is the distorted frame (:copyFrame) = this one with the chain's planes
         const VSFrame *p1 = want1 ? api->getFrameFilter(n - 1, d->node1, fctx) : nullptr;
         const VSFrame *p2 = want2 ? api->getFrameFilter(n - 2, d->node1, fctx) : nullptr;
         VSFrame *dst = api->copyFrame(s2, core);
         auto done = [&](const VSFrame *r) {
-            api->freeFrame(s1);
-            api->freeFrame(s2);
+            release_fused_inputs(api, in, 2);
             if (p1) api->freeFrame(p1);
             if (p2) api->freeFrame(p2);
             return r;
@@ -1722,12 +1837,15 @@ const VSFrame *VS_CC xpsnrGetFrame(int n, int reason, void *inst, void **, VSFra
         if (!g) return done(fail(z, nullptr, dst, "XPSNR", "no MI355X device available (the plugin has no CPU fallback)"));
         const void *o3[3] = {nullptr, nullptr, nullptr}, *r3[3] = {nullptr, nullptr, nullptr};
         ptrdiff_t st[3] = {0, 0, 0};
+        bool need[2][3];
+        for (int c = 0; c < 3; ++c) need[0][c] = need[1][c] = c < d->num_comps;
+        if (const char *e = stage_fused_inputs(z, g, in, 2, need, d->num_comps)) return done(fail(z, g, dst, "XPSNR", e));
         for (int c = 0; c < d->num_comps; ++c) {
-            DPlane a = z.upload(g, s1, c), b = z.upload(g, s2, c);
-            if (!a.ptr || !b.ptr) return done(fail(z, g, dst, "XPSNR", "device staging failed"));
-            o3[c] = a.ptr;
-            r3[c] = b.ptr;
-            st[c] = a.stride;  // same geometry and bit depth => same pitch
+            o3[c] = in[0].cur[c].ptr;
+            r3[c] = in[1].cur[c].ptr;
+            st[c] = in[0].cur[c].stride;
+            if (in[1].cur[c].stride != st[c]) return done(fail(z, g, dst, "XPSNR", "device planes of the two clips differ in row pitch"));
+            if (in[1].touched[c] && !z.download(g, in[1].cur[c], dst, c)) return done(fail(z, g, dst, "XPSNR", "GPU kernel failed"));
         }
         DPlane q1, q2;
         if (p1) q1 = z.upload(g, p1, 0);
@@ -1769,6 +1887,8 @@ void VS_CC xpsnrFree(void *inst, VSCore *, const VSAPI *api) {
         printf("\n");
         fflush(stdout);
     }
+    free_chain(api, d->c1);
+    free_chain(api, d->c2);
     api->freeNode(d->node1);
     api->freeNode(d->node2);
     delete d;
@@ -1819,9 +1939,13 @@ void VS_CC xpsnrCreate(const VSMap *in, VSMap *out, void *, VSCore *core, const 
         d->width[c] = c < d->num_comps ? (v1->width >> (c ? v1->format.subSamplingW : 0)) : 0;
         d->height[c] = c < d->num_comps ? (v1->height >> (c ? v1->format.subSamplingH : 0)) : 0;
     }
-    VSFilterDependency deps[] = {{d->node1, rpGeneral}, {d->node2, rpStrictSpatial}};
     XpsnrData *raw = d.release();
-    api->createVideoFilter(out, "XPSNR", raw->vi, xpsnrGetFrame, xpsnrFree, fmParallel, deps, 2, raw, core);
+    raw->c1.root = api->addNodeRef(raw->node1);  // no stages by construction (see XpsnrData)
+    raw->c2 = resolve_chain(api, raw->node2);
+    VSFilterDependency deps[2] = {{raw->node1, rpGeneral}, {nullptr, rpStrictSpatial}};
+    int nd = 1;
+    if (raw->c2.root != raw->node1) deps[nd++] = {raw->c2.root, rpStrictSpatial};
+    api->createVideoFilter(out, "XPSNR", raw->vi, xpsnrGetFrame, xpsnrFree, fmParallel, deps, nd, raw, core);
 }
 
 // ===========================================================================
