@@ -220,3 +220,27 @@ def test_torch_tensors_on_a_torch_stream(oracle):
     got = dst.cpu().numpy().view(np.uint16)
     assert np.array_equal(got, oracle.boxblur(src_np, 13, 1, 13, 1))
     d.close()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_rt_fused_multipass_equals_per_pass(dev, oracle, dtype, monkeypatch):
+    """Round 3: the opt-in fused multi-pass kernel (VSZIP_RT_FUSED=1: a row stays in registers across the passes of an axis, the
+    vertical axis runs between two transposes) against the per-pass kernels and the oracle, bit for bit: 2 .. 5 passes, radii up to
+    the fused kernel's 119, widths that are / are not whole thread groups, YUV 4:2:0 batches."""
+    for shapes, args in [([(72, 208), (36, 104), (36, 104)], (5, 3, 5, 3)), ([(64, 4096)], (13, 5, 0, 0)), ([(300, 96)], (0, 0, 13, 5)),
+                         ([(135, 250), (67, 125)], (7, 2, 9, 4)), ([(260, 300)], (119, 2, 100, 3)), ([(40, 33), (33, 40)], (3, 4, 2, 3))]:
+        planes = [fx.splitmix64_plane(3 + i, sh, dtype) for i, sh in enumerate(shapes)]
+        def run():
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+            dev.boxblur(srcs, dsts, *args)
+            return [dev.download(d) for d in dsts]
+
+        base = run()
+        monkeypatch.setenv("VSZIP_RT_FUSED", "1")
+        fused = run()
+        monkeypatch.delenv("VSZIP_RT_FUSED")
+        for p, a, b in zip(planes, base, fused):
+            want = oracle.boxblur(p, *args)
+            assert np.array_equal(b, want), (shapes, args, int((b != want).sum()))
+            assert np.array_equal(a, want)

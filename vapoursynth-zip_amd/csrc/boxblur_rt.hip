@@ -669,10 +669,17 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
 // prefix is double buffered. Rows up to 4096 samples; the vertical passes run through it on transposed planes.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHmNT = 256, kHmEPT = 16, kHmMaxW = kHmNT * kHmEPT;
+constexpr int kHmMaxR = 119;                                   // halo entries fit the padding of the prefix array
+constexpr int kHmCols = kHmNT + (2 * kHmMaxR + 2 + 15) / 16;   // columns of the [16][cols] prefix array: (w + 2 R + 2) / 16 entries per row
 
 template <typename T>
 __global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams prm, const int passes) {
-    __shared__ uint32_t P[2][kHmMaxW];
+    // The prefix of the MIRROR-EXTENDED row (blurInt's taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k, :24-40), minus
+    // the left halo's sum (which cancels in every difference): PV(j) = Preal(j) inside the row, -Preal(m - 2) at j = -m, and
+    // 2 Preal(w-1) - Preal(w-1-m) at j = w-1+m. With it every output is ONE difference PV(x + R) - PV(x - R - 1): no thread
+    // takes a border path. Entry j lives at [(j + R + 1) & 15][(j + R + 1) >> 4]: a thread's 16 entries and a wave's reads of
+    // "x + R" / "x - R - 1" are both conflict free.
+    __shared__ uint32_t P[2][16 * kHmCols];
     __shared__ uint32_t wtot[2][4];
     const int b = blockIdx.x;
     const RPlane pl = prm.p[rt_find(prm, b)];
@@ -702,49 +709,45 @@ __global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams 
     const uint32_t ksize = 2u * (uint32_t)R + 1u;
     const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
     const uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    const uint32_t off = (uint32_t)R + 1u;  // virtual index = real index + off
+    auto slot = [&](uint32_t jv) { return (jv & 15u) * (uint32_t)kHmCols + (jv >> 4); };
+    // per-thread constants of the two reads of output k: virtual indices x0 + k + 2 R + 1 and x0 + k
     for (int pass = 0; pass < passes; ++pass) {
         uint32_t *Pb = P[pass & 1];
-        uint32_t p[kHmEPT];
-        p[0] = v[0];
 #pragma unroll
-        for (int k = 1; k < kHmEPT; ++k) p[k] = p[k - 1] + v[k];
-        const uint32_t incl = wave_incl_scan_dpp(p[kHmEPT - 1]);
+        for (int k = 1; k < kHmEPT; ++k) v[k] += v[k - 1];  // in place: the thread's inclusive prefix
+        const uint32_t incl = wave_incl_scan_dpp(v[kHmEPT - 1]);
         if (lane == 63) wtot[pass & 1][wave] = incl;
         __syncthreads();
-        uint32_t base = incl - p[kHmEPT - 1];
+        uint32_t base = incl - v[kHmEPT - 1];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (q < wave) base += wtot[pass & 1][q];
+        if (x0 < w) {
 #pragma unroll
-        for (int k = 0; k < kHmEPT; ++k) Pb[k * kHmNT + tid] = p[k] + base;
+            for (int k = 0; k < kHmEPT; ++k) Pb[slot((uint32_t)(x0 + k) + off)] = v[k] + base;  // (entries past w - 1 repeat Preal(w-1): harmless, rewritten below)
+        }
         __syncthreads();
-        auto at = [&](uint32_t c) { return Pb[(c & (uint32_t)(kHmEPT - 1)) * kHmNT + (c >> 4)]; };
-        auto Q = [&](int c) -> uint32_t { return c < 0 ? 0u : at((uint32_t)min(c, w - 1)); };
-        const uint32_t e0 = Q(R) + Q(R - 1);  // srcp[r] + 2 * sum_{x<r} srcp[x]
+        // the 2 R + 1 halo entries, one per thread: left j = -m (m = 1 .. R + 1), right j = w - 1 + m (m = 1 .. R)
+        {
+            const uint32_t last = Pb[slot((uint32_t)(w - 1) + off)];
+            if (tid <= R) {
+                const int m = tid + 1;
+                Pb[slot(off - (uint32_t)m)] = m >= 2 ? 0u - Pb[slot((uint32_t)(m - 2) + off)] : 0u;
+            } else if (tid <= 2 * R) {
+                const int m = tid - R;
+                Pb[slot((uint32_t)(w - 1 + m) + off)] = 2u * last - Pb[slot((uint32_t)(w - 1 - m) + off)];
+            }
+        }
+        __syncthreads();
+        const uint32_t e0 = Pb[slot((uint32_t)R + off)] + Pb[slot((uint32_t)(R - 1) + off)];  // srcp[r] + 2 * sum_{x<r} srcp[x]
         const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
-        // a thread whose 16 windows stay inside the row needs no mirror term
-        const bool inner = x0 - R - 1 >= 0 && x0 + kHmEPT - 1 + R <= w - 1;
-        if (inner) {
 #pragma unroll
-            for (int k = 0; k < kHmEPT; ++k) {
-                const uint32_t x = (uint32_t)(x0 + k);
-                const uint32_t e = at(x + (uint32_t)R) - at(x - (uint32_t)R - 1u);
-                v[k] = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kHmEPT; ++k) {
-                const int x = x0 + k;
-                uint32_t o = 0;
-                if (x < w) {
-                    // blurInt :24-40: taps left of 0 mirror as -k -> k-1, right of w-1 as w-1+k -> w-k
-                    uint32_t e = Q(min(x + R, w - 1)) - Q(x - R - 1);
-                    if (x - R - 1 < -1) e += Q(R - x - 1);
-                    if (x + R > w - 1) e += Q(w - 1) - Q(2 * w - 2 - x - R);
-                    o = (uint32_t)(((uint64_t)e * inv2 + kr) >> 16);
-                }
-                v[k] = o;
-            }
+        for (int k = 0; k < kHmEPT; ++k) {
+            const uint32_t x = (uint32_t)(x0 + k);
+            const uint32_t e = Pb[slot(x + (uint32_t)R + off)] - Pb[slot(x + off - (uint32_t)R - 1u)];
+            // the 16.16 value is the window mean + 0.5: 32 bits hold it (proved exhaustively in tests/test_oracle_boxblur.py)
+            v[k] = (x0 + k < w) ? (e * inv2 + kr) >> 16 : 0u;
         }
     }
     {
@@ -875,18 +878,24 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
         off[i] = elems;
         elems += (size_t)((planes[i].w + 63) & ~63) * planes[i].h;
     }
-    // Integer planes with >= 2 passes on an axis: the fused kernel keeps a row in registers across that axis's passes
-    // (horizontal directly; vertical, from 3 passes on, between two transposes: four HBM round trips for any 5 + 5 instead of ten).
+    // Integer planes with >= 2 passes on an axis, OPT-IN (VSZIP_RT_FUSED=1): the fused kernel keeps a row in registers across that
+    // axis's passes (horizontal directly; vertical, from 3 passes on, between two transposes: four HBM round trips for any 5 + 5
+    // instead of ten). Bit-exact (tests/test_gpu_boxblur.py::test_rt_fused_multipass_equals_per_pass) — and measured SLOWER than
+    // the per-pass kernels, which is why it is not the default: 5 fused passes of r = 13 on 16 1080p YUV420P16 frames take 511 us
+    // against 5 x 65 us separately. The per-pass kernels are not HBM-bound but issue-bound (about 12 instructions per sample and
+    // pass at 4.3 TB/s effective); a kernel that keeps the row on chip needs about 19 (the whole row's prefix has to go through
+    // LDS with three barriers per pass), so saving the round trips buys nothing. The README's 5 + 5-pass benchmark therefore stays
+    // at ten round trips (profiles/r03_notes.md).
     if constexpr (std::is_integral<T>::value) {
-        bool ok = !getenv("VSZIP_RT_NO_FUSED") && total > 1;
+        bool ok = getenv("VSZIP_RT_FUSED") != nullptr && total > 1;
         const bool fuse_h = hb && hpasses >= 2, fuse_v = vb && vpasses >= 3;
         ok = ok && (fuse_h || fuse_v);
         for (int i = 0; i < nplanes && ok; ++i) {
             const vszip_plane &q = planes[i];
             ok = (((reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.src_stride * sizeof(T)) | (uintptr_t)((size_t)q.dst_stride * sizeof(T))) & 15) == 0) &&
                  (size_t)q.src_stride >= (size_t)((q.w + RtVec<T>::V - 1) / RtVec<T>::V) * RtVec<T>::V;
-            if (fuse_h) ok = ok && q.w <= kHmMaxW && hradius < q.w;
-            if (fuse_v) ok = ok && q.h <= kHmMaxW && vradius < q.h;
+            if (fuse_h) ok = ok && q.w <= kHmMaxW && 2 * hradius < q.w && hradius <= kHmMaxR;
+            if (fuse_v) ok = ok && q.h <= kHmMaxW && 2 * vradius < q.h && vradius <= kHmMaxR;
         }
         if (ok) {
             // scratch: two buffers that hold a plane set in either orientation (rows padded to 64 samples)
