@@ -653,6 +653,24 @@ __device__ __forceinline__ int tap_index(int k, int i, int n) {
     return (dist_from_end < k - HALO) ? (i - min(k - HALO - dist_from_end, i)) : (i - HALO + k);
 }
 
+// a / b in f64 for the two quotients of maps_pixel, whose denominators are finite and far from the exponent limits (>= 1, or a
+// variance term + 0.0009): v_rcp_f64 refined by two Newton steps and one residual correction of the quotient — the result is
+// within one unit in the last place of the IEEE quotient (mostly equal to it) at about half the instructions of the
+// v_div_scale / v_div_fmas / v_div_fixup sequence, which carries the range handling these operands never need. The maps kernel
+// is issue bound and the two f64 divisions were a quarter of a pixel's instructions. The pooled f64 sums move by ~1e-16
+// relative (the pooling ORDER already differs from the reference's by ~1e-15); -DVSZIP_SSIM_IEEE_DIV restores the IEEE sequence.
+__device__ __forceinline__ double maps_div(double a, double b) {
+#ifdef VSZIP_SSIM_IEEE_DIV
+    return a / b;
+#else
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+#endif
+}
+
 // ssimMap (:511-523) and edgeMap (:585-603) of one pixel, accumulated in f64
 __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, float bsq, float v1, float v2, bool do_ssim, bool do_edge, double acc[6]) {
     if (do_ssim) {
@@ -660,14 +678,14 @@ __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, floa
         const double num_m = (double)fmaf(md, -md, 1.0f);
         const double num_s = (double)fmaf(b12 - m12, 2.0f, 0.0009f);
         const double denom_s = (double)(bsq - 2.0f * b12 - m11 - m22 + 0.0009f);
-        const double d1 = fmax(1.0 - ((num_m * num_s) / denom_s), 0.0);
+        const double d1 = fmax(1.0 - maps_div(num_m * num_s, denom_s), 0.0);
         double t = d1 * d1;
         acc[0] += d1;
         acc[1] += t * t;
     }
     if (do_edge) {
         const double n2 = (double)fabsf(v2 - mu2), n1 = (double)fabsf(v1 - mu1);
-        const double d1 = (1.0 + n2) / (1.0 + n1) - 1.0;
+        const double d1 = maps_div(1.0 + n2, 1.0 + n1) - 1.0;
         const double art = fmax(d1, 0.0), det = fmax(-d1, 0.0);
         double t = art * art;
         acc[2] += art;
@@ -717,14 +735,21 @@ __device__ __forceinline__ void ssim_maps_park(const float v1[kMapsNS], const fl
 // interior tile whose inputs are already in s1 / s2
 __device__ __forceinline__ void ssim_maps_tile_blocked(bool do_ssim, bool do_edge, float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
     const int tid = threadIdx.x;
-    constexpr int VR = 8;  // output rows per thread in the vertical pass
-    if (tid < IW * (TH / VR)) {
+#ifndef VSZIP_SSIM_VR
+#define VSZIP_SSIM_VR 8
+#endif
+    // output rows per thread in the vertical pass: 8 -> 40 columns x 4 row groups = 160 of the 256 threads. 6 rows (240 threads) was
+    // measured in round 3 (tools/variant.sh, interleaved A/B on one device): 4.94-4.99 k pairs/s against 5.49-5.55 k — the shorter
+    // per-thread chains do not pay for the 25 % more tap loads and the clamped last group.
+    constexpr int VR = VSZIP_SSIM_VR;
+    if (tid < IW * ((TH + VR - 1) / VR)) {
         const int c = tid % IW, r0 = (tid / IW) * VR;
         float p[VR + 8], q[VR + 8], pq[VR + 8], sq[VR + 8];
 #pragma unroll
         for (int j = 0; j < VR + 8; ++j) {
-            p[j] = s1[r0 + j][c];
-            q[j] = s2[r0 + j][c];
+            const int rr = min(r0 + j, IH - 1);  // (the last group owns 2 rows: its other taps read the last row, their outputs are not stored)
+            p[j] = s1[rr][c];
+            q[j] = s2[rr][c];
         }
         if (do_ssim) {
 #pragma unroll
@@ -744,7 +769,7 @@ __device__ __forceinline__ void ssim_maps_tile_blocked(bool do_ssim, bool do_edg
                 m = __builtin_elementwise_fma(kk, v2f{p[o + k], q[o + k]}, m);
                 if (do_ssim) ms = __builtin_elementwise_fma(kk, v2f{pq[o + k], sq[o + k]}, ms);
             }
-            vt[r0 + o][c] = v4f{ms.x, ms.y, m.x, m.y};
+            if (r0 + o < TH) vt[r0 + o][c] = v4f{ms.x, ms.y, m.x, m.y};
         }
     }
     __syncthreads();
