@@ -14,9 +14,11 @@ prof() {
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 "$@" > /dev/null 2> $out/pmc_fetch.err
   timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write -- python3 "$@" > /dev/null 2> $out/pmc_write.err
   timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_sq -- python3 "$@" > /dev/null 2> $out/pmc_sq.err
+  # round 3: what the non-HBM legs are bound by — LDS-array cycles (with the conflict share) and VALU issue cycles against the clock
+  timeout 600 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_lds -- python3 "$@" > /dev/null 2> $out/pmc_lds.err
 }
 prof ${rt}_boxblur $R/bench.py --no-cpu --no-others --steps 50 --warmup 3 --min-seconds 0.1
 prof ${rt}_bilateral $R/bench.py --no-cpu --no-others --workload bilateral --steps 10 --warmup 2
 prof ${rt}_ssimulacra2 $R/bench.py --no-cpu --no-others --workload ssimulacra2 --steps 5 --warmup 1
-prof ${rt}_legs $R/tools/prof_legs.py eedi3 xpsnr boxblur_other planestats
+prof ${rt}_legs $R/tools/prof_legs.py eedi3 xpsnr boxblur_other planestats ssim_yuv
 ls $R/gpurun_out | grep prof_${rt}

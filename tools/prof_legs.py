@@ -28,5 +28,10 @@ for leg in sys.argv[1:]:
         import runpy
 
         runpy.run_path(str(ROOT / "tools" / "pbfic_timing.py"))
+    elif leg == "ssim_yuv":
+        st, keep = bench.setup_ssimulacra2_yuv420p8(dev, bench.W4K, bench.H4K, 16)
+        dt, _, _, _ = timed.run(st, 5, 1)
+        print(json.dumps({"ssimulacra2_4k_yuv420p8_pairs_s": 16 * 5 / dt}))
+        del keep
     elif leg == "planestats":
         print(json.dumps(bench.planestats_leg(dev, timed)))
