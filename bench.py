@@ -168,6 +168,35 @@ def profile_traffic(kernel_prefix: str, frames: int):
     return best
 
 
+def limit_from_profile(name: str, kernel_sub: str):
+    """What bounds a leg that HBM does not: issue and LDS-array busy fractions of its dominant kernel, from the committed PMC
+    passes of the same workload (profiles/r*_<name>_pmc.json, tools/prof_all.sh: separate --pmc runs) — REPLAYED, not measured in
+    this run. cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs); VALU busy = SQ_ACTIVE_INST_VALU x 4 (the SQ counts in
+    quad-cycles) / 1024 SIMDs / cycles; LDS array busy = SQ_LDS_IDX_ACTIVE / 256 CUs / cycles (MI355X_MICROARCH.md, LDS:
+    SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones)."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob(f"r*_{name}_pmc.json")):
+        try:
+            for k, m in json.loads(f.read_text())["kernels"].items():
+                if kernel_sub in k and "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+                    best = (f.name, k, m)
+        except Exception:
+            continue
+    if not best:
+        return None
+    fname, k, m = best
+    cycles = m["GRBM_GUI_ACTIVE"] / 8.0
+    valu = m["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cycles
+    out = {"kernel": k, "valu_busy_frac": valu, "source": f"profiles/{fname} (replayed; formulas in bench.limit_from_profile)"}
+    if "SQ_LDS_IDX_ACTIVE" in m:
+        out["lds_array_busy_frac"] = m["SQ_LDS_IDX_ACTIVE"] / 256.0 / cycles
+        if m["SQ_LDS_IDX_ACTIVE"] > 0 and "SQ_LDS_BANK_CONFLICT" in m:
+            out["lds_bank_conflict_share"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
+    out["bound"] = "lds" if out.get("lds_array_busy_frac", 0) > valu else "valu"
+    out["frac"] = max(valu, out.get("lds_array_busy_frac", 0))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # GPU workloads
 # ---------------------------------------------------------------------------
@@ -525,6 +554,11 @@ def eedi3_leg(dev, timed, no_cpu, frames=16):
                         "note": "not an HBM-bound filter: 41 directions x a 5-tap window per pixel and a dynamic programme along every line "
                                 "(eedi3_line_kernel: VALU about 80 % busy, DESIGN.md 3.5); the fraction is reported for completeness"},
            "workload": "vszip.EEDI3 field=1 dh=1 (defaults: mdis 20, nrad 2, vcheck 2), 1920x1080 YUV420PS -> 1920x2160, HBM-resident"}
+    # about 1.7 kflop per interpolated pixel x 3.11 Mpx = 5.4 GFLOP per frame against the 157.3 TFLOPS fp32 vector peak
+    tf = 5.4e9 * frames * 5 / dt / 1e12
+    res["limit"] = {"bound": "fp32_vector", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                    "note": "5.4 GFLOP per 1080p frame (SURVEY 8d); the Viterbi chain and the vertical-consistency chain are serial, so the fraction is a lower bound on "
+                            "how busy the vector units are (eedi3_line_kernel: about 80 % VALU issue utilisation, DESIGN.md 3.5)"}
     if not no_cpu:
         from oracle import oracle as orc
 
@@ -1174,6 +1208,8 @@ def main() -> int:
                                              "frac": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                              "kernel": "bilateral_lds16_kernel<u16> (range LUT packed in LDS)", "avg_launch_us": dms * 1e3 / nl},
                                 "workload": f"vszip.Bilateral sigmaS=2 sigmaR=2 {w}x{h} YUV420P16 (natural content tiled), HBM-resident"}
+                others[name]["roofline"]["kernel"] = "bilateral_walk16_kernel<3,2> + <2,1> (symmetric weights looked up once, table in LDS)"
+                others[name]["limit"] = limit_from_profile("bilateral", "bilateral_walk16_kernel<3")
                 if not a.no_cpu:
                     others[name]["cpu_baseline"] = cpu_bilateral(w, h, 5.0 if h < 2000 else 3.0)
                 del keep
@@ -1185,6 +1221,7 @@ def main() -> int:
                                                      "note": "whole pipeline on the two input frames; ssim_maps_kernel (65 % of a pair) is issue bound: "
                                                              "about 230 instructions per plane-pixel, a quarter of them f64 (DESIGN.md 3.4)"},
                                         "workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS (linear), HBM-resident; includes the scalar D2H + sync"}
+            others["ssimulacra2_4k"]["limit"] = limit_from_profile("ssimulacra2", "ssim_maps_kernel")
             if not a.no_cpu:
                 others["ssimulacra2_4k"]["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K, 6.0)
             del keep

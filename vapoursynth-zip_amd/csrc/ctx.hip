@@ -56,8 +56,18 @@ VSZIP_EXPORT int vszip_abi_version(void) { return VSZIP_ABI_VERSION; }
 // a live one crashes the tool's finaliser (SIGSEGV inside __cxa_finalize, after the outputs are written). Contexts
 // that own one are listed here and an atexit handler - registered after the runtime's and the profiler's own, so it
 // runs before them - destroys what the host left alive.
-static std::mutex g_aux_mu;
-static std::set<vszip_ctx *> g_aux_ctxs;
+// (heap objects that are never destroyed: a vszip_ctx_destroy from a late finaliser, after static destruction, must still
+// find a live mutex and set - ADVICE r2; packed_luts() in bilateral.hip does the same)
+static std::mutex &g_aux_mu_ref() {
+    static std::mutex *m = new std::mutex();
+    return *m;
+}
+static std::set<vszip_ctx *> &g_aux_ctxs_ref() {
+    static std::set<vszip_ctx *> *s = new std::set<vszip_ctx *>();
+    return *s;
+}
+#define g_aux_mu g_aux_mu_ref()
+#define g_aux_ctxs g_aux_ctxs_ref()
 static void vszip_aux_atexit() {
     std::lock_guard<std::mutex> lk(g_aux_mu);
     for (vszip_ctx *c : g_aux_ctxs)

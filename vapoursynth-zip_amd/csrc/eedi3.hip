@@ -1593,6 +1593,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
             if (ok && !ctx->aux_fork) ok = hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming) == hipSuccess;
             if (!ok) {
                 (void)hipGetLastError();
+                if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);  // the stream exists when only the events failed (it leaked, and the create was retried every call)
                 ctx->aux_stream = nullptr;
                 split = false;
             }
@@ -1639,12 +1640,19 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         if (split) {
             // the tall planes' lines are done: the short planes' lines go to the masked stream, the tall planes' chains
             // start here at once on the CUs it leaves free
+            // Any failure between the fork and the join must not leave the masked stream running kernels on the context's scratch
+            // that the main stream no longer waits for (the next call may grow or free it): drain it before returning.
+            auto forked = [&](hipError_t e) -> bool {
+                if (e == hipSuccess) return true;
+                (void)hipStreamSynchronize(ctx->aux_stream);
+                return false;
+            };
             VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->aux_fork, ctx->stream));
             VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
             launch_lines(ctx->aux_stream, lines_tall, (int)lines - lines_tall);
-            VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->aux_join, ctx->aux_stream));
+            if (!forked(hipEventRecord(ctx->aux_join, ctx->aux_stream))) return vszip_set_error(ctx, VSZIP_ERR_HIP, "%s: joining the second stream failed", name);
             launch_vcheck_lds(ctx->stream, 0, ntall);
-            VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+            if (!forked(hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0))) return vszip_set_error(ctx, VSZIP_ERR_HIP, "%s: joining the second stream failed", name);
         } else if ((int)lines > lines_tall) {
             launch_lines(ctx->stream, lines_tall, (int)lines - lines_tall);
         }
