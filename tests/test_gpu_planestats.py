@@ -97,3 +97,37 @@ def test_average_u32(dev, oracle):
     assert dev.plane_average([dev.upload(full)])[0][0] == oracle.plane_average(full)[0]
     with pytest.raises(vszip_amd.VszipError, match="exclude is not supported"):
         dev.plane_average([dev.upload(a)], exclude=[3])
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.float16])
+def test_minmax_single_read_and_its_second_sweep(dev, oracle, dtype, monkeypatch):
+    """Round 3: the opt-in single-read path (VSZIP_MINMAX_SINGLE_READ=1) — a sample of every 16th row predicts a range of values
+    around each threshold, one sweep counts what lies below the ranges and builds their histograms; planes whose sample misleads are
+    flagged and go through the two histogram sweeps. Same answers as the default two sweeps, and as the oracle."""
+    shape = (203, 331)
+    nat = fx.tiled_natural(shape, dtype)
+    # the sampled rows (8, 24, 40, ...) say "dark", the plane is bright: the prediction misses, the second sweep runs
+    lie = fx.tiled_natural(shape, dtype)
+    if np.dtype(dtype).kind == "u":
+        lie = (lie // 4 + 40000).astype(dtype)
+        lie[8::16, :] = (np.arange(shape[1]) % 300).astype(dtype)
+    else:
+        lie = (lie * 0.2 + 0.7).astype(dtype)
+        lie[8::16, :] = (np.arange(shape[1]) % 300 / 4000).astype(dtype)
+    flat = np.full(shape, 1234 if np.dtype(dtype).kind == "u" else 0.25, dtype)
+    short = fx.splitmix64_plane(9, (5, 77), dtype)  # no sampled row at all
+    planes = [nat, lie, flat, short, nat[:, :64].copy()]
+    refs = [fx.splitmix64_plane(40 + i, p.shape, dtype) for i, p in enumerate(planes)]
+    ds, dr = [dev.upload(p) for p in planes], [dev.upload(r) for r in refs]
+    for thr in [(0.0, 0.0), (0.02, 0.02), (0.3, 0.1), (0.06, 0.9), (1.0, 1.0)]:
+        monkeypatch.delenv("VSZIP_MINMAX_SINGLE_READ", raising=False)
+        mn, mx, df = dev.plane_minmax(ds, thr[0], thr[1], dr)
+        monkeypatch.setenv("VSZIP_MINMAX_SINGLE_READ", "1")
+        mn2, mx2, df2 = dev.plane_minmax(ds, thr[0], thr[1], dr)
+        mn3, mx3, _ = dev.plane_minmax(ds, thr[0], thr[1])  # (without a reference clip: the other instantiation)
+        assert list(mn3) == list(mn2) and list(mx3) == list(mx2), thr
+        assert list(mn) == list(mn2) and list(mx) == list(mx2) and list(df) == list(df2), thr
+        for i, p in enumerate(planes):
+            omn, omx, odf = oracle.plane_minmax(p, thr[0], thr[1], refs[i])
+            assert (mn[i], mx[i]) == (omn, omx), (dtype, thr, i)
+            assert df[i] == (odf if np.dtype(dtype).kind == "u" else pytest.approx(odf, rel=1e-12))

@@ -21,4 +21,13 @@ prof ${rt}_boxblur $R/bench.py --no-cpu --no-others --steps 50 --warmup 3 --min-
 prof ${rt}_bilateral $R/bench.py --no-cpu --no-others --workload bilateral --steps 10 --warmup 2
 prof ${rt}_ssimulacra2 $R/bench.py --no-cpu --no-others --workload ssimulacra2 --steps 5 --warmup 1
 prof ${rt}_legs $R/tools/prof_legs.py eedi3 xpsnr boxblur_other planestats ssim_yuv
-ls $R/gpurun_out | grep prof_${rt}
+# the raw outputs exceed what gpurun copies back (64 MiB): summarise here, keep the summaries and the stderr of each pass
+mkdir -p $R/gpurun_out/sum_${rt}
+for n in boxblur bilateral ssimulacra2 legs; do
+  o=$n; [ $n = legs ] && o=other_filters
+  python3 $R/tools/summarize_prof.py $R/gpurun_out/prof_${rt}_$n $R/gpurun_out/sum_${rt}/${rt}_$o
+  mkdir -p $R/gpurun_out/sum_${rt}/err_$n
+  cp $R/gpurun_out/prof_${rt}_$n/*.err $R/gpurun_out/prof_${rt}_$n/bench_trace.json $R/gpurun_out/sum_${rt}/err_$n/ 2>/dev/null
+  rm -rf $R/gpurun_out/prof_${rt}_$n
+done
+ls -la $R/gpurun_out/sum_${rt}

@@ -1422,7 +1422,12 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         g.n_src = horizontal ? s.w : s.h;
         g.n_dst = dh ? 2 * g.n_src : g.n_src;
         g.n_interp = dh ? g.n_src : g.n_src / 2;
-        if (g.L < up->nrad + 2) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines shorter than nrad+2 not built yet", name);
+        // The reference has no such check, and no defined result either: mirrorPad (src/filters/eedi3.zig:107-116) fills columns past one
+        // reflection from what the rotating scratch row held before (uninitialised memory on a frame's first lines), and below nrad+2
+        // samples the window sums that decide the path read them.
+        if (g.L < up->nrad + 2)
+            return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s: lines of %d samples are shorter than nrad+2 = %d; the reference's padded rows are undefined there", name, g.L,
+                                   up->nrad + 2);
         if (horizontal) {
             g.srcT = fl;
             fl += (size_t)g.n_src * g.L;

@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxPlanesPS = 48;
+constexpr int kHistWords = 4096, kBucketWords = 16, kSampleStep = 16;  // thresholded PlaneMinMax: table sizes; every 16th row is sampled
 
 struct PSPlane {
     const void *src;
@@ -37,8 +38,10 @@ struct PSParams {
     int32_t excl[kMaxExclude];
     int nexcl;
     double *partial;     // [total_blocks][4]: avg: sum, count, diff ; minmax: min, max, diff
-    uint32_t *hist;      // [nplanes][2][256]
-    uint32_t *bucket;    // [nplanes][8]: lo bucket, count below it, hi bucket, count above it
+    uint32_t *hist;      // [nplanes][kHistWords]: [0..255] high byte (first sweep) / low byte of the low bucket (second sweep), [256..511] low byte of the
+                         // high bucket, [512..] round 3: the histograms of the two candidate RANGES of the single-read path
+    uint32_t *bucket;    // [nplanes][kBucketWords]: see locate_buckets
+    uint32_t *shist;     // [nplanes][256]: high-byte histogram of the row SAMPLE (single-read path)
     double *result;      // [nplanes][4]
     float minthr, maxthr;
     float peak;
@@ -317,60 +320,43 @@ __global__ __launch_bounds__(64) void minmax_final_kernel(const PSParams prm, in
 }
 
 // ---- PlaneMinMax, thresholded: two-level radix histogram ----------------------------------
-// LEVEL 0: histogram of idx >> 8 (u8: idx itself, in level 0 only), + the abs-diff sum.
-// LEVEL 1: histogram of idx & 255 restricted to the low and the high threshold bucket.
-template <typename T, bool REF, int LEVEL>
-__global__ __launch_bounds__(kThreads) void hist_kernel(const PSParams prm) {
+// second sweep (16-bit / float): histogram of idx & 255 restricted to the low and the high threshold bucket. kb workgroups per plane, rows
+// interleaved; the workgroups of a plane the single-read path answered return at once.
+constexpr int kRefineCopies = 8;  // (same-address queues: 8-bit pictures carried in 16 bits put a whole bucket into ONE low-byte bin)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void hist_refine_kernel(const PSParams prm, int kb) {
     using S = Smp<T>;
-    __shared__ uint32_t h0[256], h1[256];
-    __shared__ double shd[8];
-    const int b = blockIdx.x;
-    const int pi = find_plane(prm, b);
+    const int pi = blockIdx.x / kb, part = blockIdx.x - pi * kb;
+    const uint32_t *bk = prm.bucket + pi * kBucketWords;
+    if (!bk[4]) return;  // workgroup-uniform
+    __shared__ uint32_t h0[256 * kRefineCopies], h1[256 * kRefineCopies];
     const PSPlane pl = prm.p[pi];
-    h0[threadIdx.x] = 0;
-    h1[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 256 * kRefineCopies; i += kThreads) {
+        h0[i] = 0;
+        h1[i] = 0;
+    }
     __syncthreads();
-    const int y0 = (b - pl.block0) * prm.rows_per_block;
-    const int y1 = min(y0 + prm.rows_per_block, pl.h);
+    const uint32_t blo = bk[0], bhi = bk[2];
+    const int copy = threadIdx.x & (kRefineCopies - 1);
     const T *src = static_cast<const T *>(pl.src);
-    const T *ref = static_cast<const T *>(pl.ref);
-    constexpr bool wide = sizeof(T) > 1;
-    uint32_t blo = 0, bhi = 0;
-    if (LEVEL == 1) {
-        blo = prm.bucket[pi * 8 + 0];
-        bhi = prm.bucket[pi * 8 + 2];
-    }
-    double dacc = 0;
-    for (int y = y0; y < y1; ++y) {
+    for (int y = part; y < pl.h; y += kb) {
         const T *s = src + (size_t)y * pl.sstride;
-        const T *r = (REF && LEVEL == 0) ? ref + (size_t)y * pl.rstride : nullptr;
-        if (LEVEL == 0) {
-            row_apply<T, REF>(s, r, pl.w, [&](T sv, T rv) {
-                const uint32_t idx = S::idx(sv);
-                atomicAdd(&h0[wide ? (idx >> 8) : idx], 1u);
-                if constexpr (REF) {
-                    if constexpr (S::is_int)
-                        dacc += fabs((double)S::f(sv) - (double)S::f(rv));
-                    else
-                        dacc += (double)S::f((T)fabsf((float)(T)(sv - rv)));
-                }
-            });
-        } else {
-            row_apply<T, false>(s, s, pl.w, [&](T sv, T) {
-                const uint32_t idx = S::idx(sv);
-                if ((idx >> 8) == blo) atomicAdd(&h0[idx & 255u], 1u);
-                if ((idx >> 8) == bhi) atomicAdd(&h1[idx & 255u], 1u);
-            });
-        }
+        row_apply<T, false>(s, s, pl.w, [&](T sv, T) {
+            const uint32_t idx = S::idx(sv);
+            if ((idx >> 8) == blo) atomicAdd(&h0[(idx & 255u) * kRefineCopies + copy], 1u);
+            if ((idx >> 8) == bhi) atomicAdd(&h1[(idx & 255u) * kRefineCopies + copy], 1u);
+        });
     }
     __syncthreads();
-    uint32_t *g = prm.hist + (size_t)pi * 512;
-    if (h0[threadIdx.x]) atomicAdd(&g[threadIdx.x], h0[threadIdx.x]);
-    if (LEVEL == 1 && h1[threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h1[threadIdx.x]);
-    if (LEVEL == 0) {
-        const double dtot = REF ? block_sum<double>(dacc, shd) : 0.0;
-        if (threadIdx.x == 0) prm.partial[(size_t)b * 4 + 2] = dtot;
+    uint32_t *g = prm.hist + (size_t)pi * kHistWords;
+    uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+    for (int k = 0; k < kRefineCopies; ++k) {
+        c0 += h0[threadIdx.x * kRefineCopies + k];
+        c1 += h1[threadIdx.x * kRefineCopies + k];
     }
+    if (c0) atomicAdd(&g[threadIdx.x], c0);
+    if (c1) atomicAdd(&g[256 + threadIdx.x], c1);
 }
 
 // After level 0: locate the buckets (planeminmax.zig:43-57: count > trunc(total * thr)
@@ -387,7 +373,7 @@ __device__ __forceinline__ void scan_bins(const uint32_t *g, int nb, bool from_t
     for (int k = 0; k < 4; ++k) {
         const int idx = lane * 4 + k;
         const int bin = from_top ? nb - 1 - idx : idx;
-        v[k] = idx < nb ? g[bin] : 0u;
+        v[k] = idx < nb ? __hip_atomic_load(&g[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // (may be called in the kernel that built the table)
         run += v[k];
         loc[k] = run;
     }
@@ -418,62 +404,49 @@ __device__ __forceinline__ void scan_bins(const uint32_t *g, int nb, bool from_t
     }
 }
 
-__global__ __launch_bounds__(64) void bucket_kernel(const PSParams prm, int wide) {
-    const int pi = blockIdx.x;
+// ---- the steps after a sweep, one wave per plane (device functions: the sweep runs them in the last workgroup to finish a plane) ----
+// bucket words of a plane: [0] lo bucket, [1] count below it, [2] hi bucket, [3] count above it, [4] the histogram sweeps are needed,
+// [7] sweep ticket, [8] / [9] first value of the low / high candidate range (single-read path), [10] quantile-sweep ticket,
+// [11] result written, [12] samples below the low range, [13] samples below the END of the high range, [15] sample ticket.
+// st[] holds words 0..4 in LDS for the wave that runs the steps.
+//
+// Hand-over inside a kernel (tables built by all workgroups, read by the last one) without a device-scope fence: on this chip such a
+// fence writes back and invalidates the XCD's L2, and one per workgroup made the sweep 20x slower. Everything the last workgroup
+// reads was written with agent-scope atomics (histogram adds, atomic stores of the partial sums), each wave waits for its own to
+// complete before the workgroup barrier that precedes the ticket add, and the reads are agent-scope atomic loads. Values handed to a
+// LATER kernel (bucket words, zeroed tables, results) are plain stores: the kernel boundary orders them.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// locate the two buckets in the high-byte (u8: the only) histogram
+__device__ __forceinline__ void locate_buckets(const PSParams &prm, int pi, int wide, uint32_t *st /* LDS, 8 words */) {
     const PSPlane pl = prm.p[pi];
-    uint32_t *g = prm.hist + (size_t)pi * 512;
+    uint32_t *g = prm.hist + (size_t)pi * kHistWords;
     const double total = (double)((uint32_t)pl.w * (uint32_t)pl.h);
     const uint32_t totalmin = (uint32_t)trunc(total * (double)prm.minthr);
     const uint32_t totalmax = (uint32_t)trunc(total * (double)prm.maxthr);
     const int nb = wide ? (prm.hist_size >> 8) : prm.hist_size;  // <= 256
-    uint32_t *bk = prm.bucket + pi * 8;
+    uint32_t *bk = prm.bucket + pi * kBucketWords;
     // planeminmax.zig:43-57: count > trunc(total * thr), scanning up from 0 / down from the peak
-    scan_bins(g, nb, false, totalmin, &bk[0], &bk[1]);
-    scan_bins(g, nb, true, totalmax, &bk[2], &bk[3]);
-    __syncthreads();
+    scan_bins(g, nb, false, totalmin, &st[0], &st[1]);
+    scan_bins(g, nb, true, totalmax, &st[2], &st[3]);
+    if (threadIdx.x == 0) st[4] = wide ? 1u : 0u;
+    wave_lds_fence();
+    if (threadIdx.x < 5) bk[threadIdx.x] = st[threadIdx.x];
     if (wide)
-        for (int u = threadIdx.x; u < 512; u += 64) g[u] = 0u;  // level 1 reuses the table
+        for (int u = threadIdx.x; u < 512; u += 64) g[u] = 0u;  // the second sweep reuses the table
 }
 
-__global__ __launch_bounds__(64) void thr_final_kernel(const PSParams prm, int wide, int is_int) {
-    const int pi = blockIdx.x;
+__device__ __forceinline__ void write_result(const PSParams &prm, int pi, int is_int, uint32_t retmin, uint32_t retmax) {
     const PSPlane pl = prm.p[pi];
     double d = 0;
-    for (int b = threadIdx.x; b < pl.nblocks; b += 64) d += prm.partial[(size_t)(pl.block0 + b) * 4 + 2];
+    for (int b = threadIdx.x; b < pl.nblocks; b += 64) d += __hip_atomic_load(&prm.partial[(size_t)(pl.block0 + b) * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     d = wave_reduce_sum(d);
     if (threadIdx.x != 0) return;
-    const uint32_t *g = prm.hist + (size_t)pi * 512;
-    const uint32_t *bk = prm.bucket + pi * 8;
     const double total = (double)((uint32_t)pl.w * (uint32_t)pl.h);
-    const uint32_t totalmin = (uint32_t)trunc(total * (double)prm.minthr);
-    const uint32_t totalmax = (uint32_t)trunc(total * (double)prm.maxthr);
-    const uint32_t peak = (uint32_t)prm.hist_size - 1;
-    uint32_t retmin = peak, retmax = 0;  // the reference's `else` values when no bin qualifies
-    if (wide) {
-        if (bk[0] != 0xffffffffu) {
-            uint32_t count = bk[1];
-            for (int u = 0; u < 256; ++u) {
-                count += g[u];
-                if (count > totalmin) {
-                    retmin = (bk[0] << 8) | (uint32_t)u;
-                    break;
-                }
-            }
-        }
-        if (bk[2] != 0xffffffffu) {
-            uint32_t count = bk[3];
-            for (int u = 255; u >= 0; --u) {
-                count += g[256 + u];
-                if (count > totalmax) {
-                    retmax = (bk[2] << 8) | (uint32_t)u;
-                    break;
-                }
-            }
-        }
-    } else {
-        if (bk[0] != 0xffffffffu) retmin = bk[0];
-        if (bk[2] != 0xffffffffu) retmax = bk[2];
-    }
     double *res = prm.result + (size_t)pi * 4;
     if (is_int) {
         res[0] = retmin;
@@ -483,6 +456,327 @@ __global__ __launch_bounds__(64) void thr_final_kernel(const PSParams prm, int w
         res[0] = (double)((float)retmin / 65535.0f);  // planeminmax.zig:63-64
         res[1] = (double)((float)retmax / 65535.0f);
         res[2] = d / total;
+    }
+    prm.bucket[pi * kBucketWords + 11] = 1u;
+}
+
+// the plane's results from the bucket words (st[], LDS) and the low-byte histograms of the second sweep (planeminmax.zig:43-64)
+__device__ __forceinline__ void finish_plane(const PSParams &prm, int pi, int wide, int is_int, const uint32_t *st, uint32_t *fine /* LDS, 4 words */) {
+    const PSPlane pl = prm.p[pi];
+    const uint32_t *g = prm.hist + (size_t)pi * kHistWords;
+    const double total = (double)((uint32_t)pl.w * (uint32_t)pl.h);
+    const uint32_t totalmin = (uint32_t)trunc(total * (double)prm.minthr);
+    const uint32_t totalmax = (uint32_t)trunc(total * (double)prm.maxthr);
+    const uint32_t peak = (uint32_t)prm.hist_size - 1;
+    uint32_t retmin = peak, retmax = 0;  // the reference's `else` values when no bin qualifies
+    if (wide) {
+        // "count (starting at the bins before the bucket) + bins of the bucket > thr": the same wave scan with the threshold reduced by that start
+        if (threadIdx.x < 4) fine[threadIdx.x] = 0xffffffffu;
+        wave_lds_fence();
+        if (st[0] != 0xffffffffu) scan_bins(g, 256, false, totalmin - st[1], &fine[0], &fine[1]);  // (wave-uniform conditions)
+        if (st[2] != 0xffffffffu) scan_bins(g + 256, 256, true, totalmax - st[3], &fine[2], &fine[3]);
+        wave_lds_fence();
+        if (fine[0] != 0xffffffffu) retmin = (st[0] << 8) | fine[0];
+        if (fine[2] != 0xffffffffu) retmax = (st[2] << 8) | fine[2];
+    } else {
+        if (st[0] != 0xffffffffu) retmin = st[0];
+        if (st[2] != 0xffffffffu) retmax = st[2];
+    }
+    write_result(prm, pi, is_int, retmin, retmax);
+}
+
+__global__ __launch_bounds__(64) void thr_final_kernel(const PSParams prm, int wide, int is_int) {
+    __shared__ uint32_t st[8], fine[4];
+    const uint32_t *bk = prm.bucket + blockIdx.x * kBucketWords;
+    if (bk[11]) return;  // a sweep's last workgroup has written this plane
+    if (threadIdx.x < 8) st[threadIdx.x] = bk[threadIdx.x];
+    wave_lds_fence();
+    finish_plane(prm, blockIdx.x, wide, is_int, st, fine);
+}
+
+// ---- round 3: ONE read of the plane for 16-bit / float clips ------------------------------------------------------------------
+// The two-level radix reads every plane twice: the low-byte histograms it needs are those of the two buckets the thresholds fall
+// into, known only after a full sweep. A row SAMPLE (every 16th row: 6 % of the bytes) predicts them instead: its high-byte
+// histogram is scanned like the real one (thresholds scaled to the sample), and each threshold gets a candidate RANGE of values, the
+// predicted bucket and two on either side (5 x 256 values). The single sweep then needs no full histogram at all — per plane
+//   * how many samples lie below the low range, and how many below the end of the high range (two compares and adds per sample,
+//     no LDS atomic: the plain histogram sweep is bound by its one ds_add per sample),
+//   * the exact histograms of the two ranges (LDS atomics for the few samples inside them),
+// and the last workgroup to finish the plane finds the two answers inside the ranges by the reference's own rule (the running count
+// starts at the samples below the range). When an answer lies outside its range — the sampled quantile was more than two 8-bit
+// levels off — the plane is flagged and goes through the two histogram sweeps; their workgroups return at once for every other plane.
+// Results are identical either way (tests/test_gpu_planestats.py::test_minmax_single_read_and_its_second_sweep forces both).
+constexpr int kCandHalf = 2, kRange = (2 * kCandHalf + 1) * 256, kRangeCopies = 4;
+// LDS histogram adds that survive real pictures: neighbouring samples of a picture share their high byte, so 64 lanes x 8 samples
+// would queue on one or two LDS words (measured: the histogram sweep took 3x as long on the test picture as on noise). The table is
+// kept in kCopies interleaved copies (lane & 15: sixteen neighbouring banks), which divides the queue by sixteen. (Merging the runs
+// of equal bins inside a lane first was tried and is worse: at ~16 VALU instructions per sample a sweep runs at the memory rate, and
+// the merge alone costs 8.)
+constexpr int kCopies = 16;
+static_assert(512 + 2 * kRange <= kHistWords, "range tables");
+
+constexpr int kSampleBlocks = 32;  // workgroups per plane in the sample pass
+template <typename T>
+__global__ __launch_bounds__(kThreads) void hist_sample_kernel(const PSParams prm) {
+    using S = Smp<T>;
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ uint32_t h[256 * kCopies];
+    __shared__ uint32_t tmp[4];
+    __shared__ int last;
+    const int pi = blockIdx.x / kSampleBlocks, part = blockIdx.x % kSampleBlocks;
+    const PSPlane pl = prm.p[pi];
+    for (int i = threadIdx.x; i < 256 * kCopies; i += kThreads) h[i] = 0;
+    __syncthreads();
+    const T *src = static_cast<const T *>(pl.src);
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ((size_t)pl.sstride * sizeof(T)) % 16 == 0;
+    const int nv = vec ? pl.w / V : 0;
+    const int copy = threadIdx.x & (kCopies - 1);
+    for (int y = kSampleStep / 2 + kSampleStep * part; y < pl.h; y += kSampleStep * kSampleBlocks) {
+        const T *s = src + (size_t)y * pl.sstride;
+        for (int i = threadIdx.x; i < nv; i += kThreads) {
+            union {
+                uint4 q;
+                T e[V];
+            } a;
+            a.q = reinterpret_cast<const uint4 *>(s)[i];
+#pragma unroll
+            for (int k = 0; k < V; ++k) atomicAdd(&h[(S::idx(a.e[k]) >> 8) * kCopies + copy], 1u);
+        }
+        for (int x = nv * V + (int)threadIdx.x; x < pl.w; x += kThreads) atomicAdd(&h[(S::idx(s[x]) >> 8) * kCopies + copy], 1u);
+    }
+    __syncthreads();
+    uint32_t *g = prm.shist + (size_t)pi * 256;
+    uint32_t *bk = prm.bucket + pi * kBucketWords;
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) c += h[threadIdx.x * kCopies + k];
+        if (c) atomicAdd(&g[threadIdx.x], c);
+    }
+    // the plane's last workgroup turns the sample histogram into the candidate ranges (no fence: see "Hand-over inside a kernel")
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&bk[15], 1u) == (uint32_t)kSampleBlocks - 1;
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    const int rows = pl.h > kSampleStep / 2 ? (pl.h - kSampleStep / 2 - 1) / kSampleStep + 1 : 0;
+    const double total = (double)((uint32_t)pl.w * (uint32_t)rows);
+    const int nb = prm.hist_size >> 8;
+    scan_bins(g, nb, false, (uint32_t)trunc(total * (double)prm.minthr), &tmp[0], &tmp[1]);
+    scan_bins(g, nb, true, (uint32_t)trunc(total * (double)prm.maxthr), &tmp[2], &tmp[3]);
+    wave_lds_fence();
+    if (threadIdx.x == 0) {
+        // Nothing in the sample exceeds a threshold (thr = 1, or a plane too short to be sampled): an empty range that everything lies below
+        // (low side) / whose end everything lies at or above (high side); the sweep's last workgroup then either knows that no value
+        // qualifies or flags the plane.
+        bk[8] = tmp[0] == 0xffffffffu ? 0x10000u : (uint32_t)max((int)tmp[0] - kCandHalf, 0) << 8;
+        bk[9] = tmp[2] == 0xffffffffu ? (uint32_t)-kRange : (uint32_t)max((int)tmp[2] - kCandHalf, 0) << 8;
+    }
+}
+
+// One threshold of the single-read path in the sweep's last workgroup: the reference's scan with the running count started at `start`
+// (the samples before the range in scan order), over the range's kRange bins in chunks of 256. found: 0 = the answer lies outside.
+__device__ __forceinline__ uint32_t range_scan(const uint32_t *tab, bool from_top, uint32_t start, uint32_t thr, uint32_t *fine, int *found) {
+    uint32_t run = start, ans = 0;
+    *found = 0;
+    if (start > thr) return 0;  // the count already exceeds the threshold before the range: the answer lies before it
+    for (int c = 0; c < kRange / 256; ++c) {
+        const int chunk = from_top ? kRange / 256 - 1 - c : c;
+        wave_lds_fence();
+        scan_bins(tab + chunk * 256, 256, from_top, thr - run, &fine[0], &fine[1]);
+        wave_lds_fence();
+        if (fine[0] != 0xffffffffu) {
+            ans = (uint32_t)chunk * 256u + fine[0];
+            *found = 1;
+            break;
+        }
+        run += fine[1];  // the chunk's total
+    }
+    return ans;
+}
+
+// The sweeps. MODE 0: histogram of idx >> 8 (u8: idx itself — one level is all it needs) for the two-level radix; with `flagged` only
+// the planes the single-read path could not answer. MODE 1: the single-read path's counts and range histograms. Both: the abs-diff sum.
+// Persistent workgroups of 512 threads, each over a contiguous range of the call's 8-row units (flushing its tables where the range
+// crosses into the next plane): the tables reach global memory once per workgroup and plane, not once per unit. The last workgroup to
+// finish a plane runs the steps that follow the sweep.
+constexpr int kSweepThreads = 512;  // 2 waves per SIMD and workgroup; the plain variants hold 3 workgroups per CU, the ones with a reference clip 2
+template <typename T, bool REF, int MODE>
+__global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParams prm, int units_total, int flagged) {
+    using S = Smp<T>;
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr bool wide = sizeof(T) > 1;
+    constexpr int kTab = MODE == 0 ? 256 * kCopies : 2 * kRange * kRangeCopies;
+    __shared__ uint32_t tab[kTab];  // MODE 0: the histogram's copies; MODE 1: the low range's bins, then the high range's (kRangeCopies interleaved copies each)
+    __shared__ double shd[kSweepThreads / 64];
+    __shared__ uint32_t shc[2][kSweepThreads / 64];
+    __shared__ uint32_t st[8], fine[4];
+    __shared__ int last;
+    const int tid = threadIdx.x, copy = tid & (kCopies - 1), rcopy = tid & (kRangeCopies - 1);
+    const int u1 = (int)((long)(blockIdx.x + 1) * units_total / gridDim.x);
+    int u = (int)((long)blockIdx.x * units_total / gridDim.x);
+    while (u < u1) {  // one turn per plane the range touches (workgroup-uniform)
+        const int pi = find_plane(prm, u);
+        const PSPlane pl = prm.p[pi];
+        const int ue = min(u1, pl.block0 + pl.nblocks);
+        uint32_t *bk = prm.bucket + pi * kBucketWords;
+        if (MODE == 0 && flagged && !bk[4]) {
+            u = ue;
+            continue;
+        }
+        for (int i = tid; i < kTab; i += kSweepThreads) tab[i] = 0;
+        __syncthreads();
+        const uint32_t lo_start = MODE == 1 ? bk[8] : 0u, hi_start = MODE == 1 ? bk[9] : 0u;
+        const int y0 = (u - pl.block0) * prm.rows_per_block;
+        const int nrows = min((ue - pl.block0) * prm.rows_per_block, pl.h) - y0;
+        const T *src = static_cast<const T *>(pl.src) + (size_t)y0 * pl.sstride;
+        const T *ref = REF ? static_cast<const T *>(pl.ref) + (size_t)y0 * pl.rstride : nullptr;
+        const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ((size_t)pl.sstride * sizeof(T)) % 16 == 0 &&
+                         (!REF || ((reinterpret_cast<uintptr_t>(ref) & 15) == 0 && ((size_t)pl.rstride * sizeof(T)) % 16 == 0));
+        const int nv = vec ? pl.w / V : 0;
+        double dacc = 0;
+        uint32_t below_lo = 0, below_hi_end = 0;  // MODE 1: samples below the low range / below the END of the high range
+        auto one = [&](T sv, T rv) {
+            const uint32_t idx = S::idx(sv);
+            if constexpr (MODE == 0) {
+                atomicAdd(&tab[(wide ? idx >> 8 : idx) * kCopies + copy], 1u);
+            } else {
+                // idx and the range starts are below 2^17: the sign bit of the difference is the borrow
+                const uint32_t dl = idx - lo_start, eh = idx - hi_start - (uint32_t)kRange;
+                below_lo += dl >> 31;
+                below_hi_end += eh >> 31;
+                if (dl < (uint32_t)kRange) atomicAdd(&tab[dl * kRangeCopies + rcopy], 1u);
+                if (eh + (uint32_t)kRange < (uint32_t)kRange) atomicAdd(&tab[(eh + 2u * kRange) * kRangeCopies + rcopy], 1u);
+            }
+            if constexpr (REF) {
+                if constexpr (S::is_int)
+                    dacc += fabs((double)S::f(sv) - (double)S::f(rv));
+                else
+                    dacc += (double)S::f((T)fabsf((float)(T)(sv - rv)));
+            }
+        };
+        if (nv > 0) {
+            // the range's 16-byte vectors, rows flattened (a 4K row has 480 of them, fewer than the workgroup has lanes); a lane's next vector
+            // lies kSweepThreads further: (ry, vx) advance by a quotient and a remainder instead of a division per step. Two loads in flight.
+            union Vec {
+                uint4 q;
+                T e[V];
+            };
+            const int qs = kSweepThreads / nv, rs = kSweepThreads - qs * nv;
+            int ry = tid / nv, vx = tid - ry * nv;
+            auto advance = [&]() {
+                ry += qs;
+                vx += rs;
+                if (vx >= nv) {
+                    vx -= nv;
+                    ++ry;
+                }
+            };
+            auto fetch = [&](Vec &a, Vec &b) {
+                a.q = reinterpret_cast<const uint4 *>(src + (size_t)ry * pl.sstride)[vx];
+                if constexpr (REF) b.q = reinterpret_cast<const uint4 *>(ref + (size_t)ry * pl.rstride)[vx];
+            };
+            auto tally = [&](const Vec &a, const Vec &b) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) one(a.e[k], REF ? b.e[k] : a.e[k]);
+            };
+            while (ry < nrows) {  // (not workgroup-uniform: no barriers inside)
+                Vec a0, b0, a1, b1;
+                fetch(a0, b0);
+                advance();
+                const bool two = ry < nrows;
+                if (two) {
+                    fetch(a1, b1);
+                    advance();
+                }
+                tally(a0, b0);
+                if (two) tally(a1, b1);
+            }
+        }
+        const int x0 = nv * V, tw = pl.w - x0;  // the columns past the last whole vector (all of them on unaligned planes)
+        if (tw > 0) {
+            const int total = nrows * tw;
+            for (int i = tid; i < total; i += kSweepThreads) {
+                const int ry = i / tw, x = x0 + i - ry * tw;
+                one(src[(size_t)ry * pl.sstride + x], REF ? ref[(size_t)ry * pl.rstride + x] : T(0));
+            }
+        }
+        __syncthreads();
+        uint32_t *g = prm.hist + (size_t)pi * kHistWords;
+        if constexpr (MODE == 0) {
+            if (tid < 256) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 0; k < kCopies; ++k) c += tab[tid * kCopies + k];
+                if (c) atomicAdd(&g[tid], c);
+            }
+        } else {
+            for (int i = tid; i < 2 * kRange; i += kSweepThreads) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 0; k < kRangeCopies; ++k) c += tab[i * kRangeCopies + k];
+                if (c) atomicAdd(&g[512 + i], c);
+            }
+            const uint32_t wl = wave_reduce_sum(below_lo), wh = wave_reduce_sum(below_hi_end);
+            if ((tid & 63) == 0) {
+                shc[0][tid >> 6] = wl;
+                shc[1][tid >> 6] = wh;
+            }
+        }
+        // the abs-diff sum of the range goes into its first unit's slot, the other units' slots are zero
+        if constexpr (REF) {
+            const double w = wave_reduce_sum(dacc);
+            if ((tid & 63) == 0) shd[tid >> 6] = w;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if constexpr (MODE == 1) {
+                uint32_t cl = 0, ch = 0;
+                for (int i = 0; i < kSweepThreads / 64; ++i) {
+                    cl += shc[0][i];
+                    ch += shc[1][i];
+                }
+                if (cl) atomicAdd(&bk[12], cl);
+                if (ch) atomicAdd(&bk[13], ch);
+            }
+        }
+        if (!(MODE == 0 && flagged)) {  // (the flagged planes' sums were written by the single sweep)
+            if (tid == 0) {
+                double dtot = 0;
+                if constexpr (REF)
+                    for (int i = 0; i < kSweepThreads / 64; ++i) dtot += shd[i];
+                __hip_atomic_store(&prm.partial[(size_t)u * 4 + 2], dtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int k = u + 1 + tid; k < ue; k += kSweepThreads) __hip_atomic_store(&prm.partial[(size_t)k * 4 + 2], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ticket: units of the plane done so far (no fence: see "Hand-over inside a kernel")
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) last = atomicAdd(&bk[MODE == 0 ? 7 : 10], (uint32_t)(ue - u)) + (uint32_t)(ue - u) == (uint32_t)pl.nblocks;
+        __syncthreads();
+        if (last && tid < 64) {
+            if constexpr (MODE == 0) {
+                locate_buckets(prm, pi, wide ? 1 : 0, st);
+                if (!wide) finish_plane(prm, pi, 0, S::is_int ? 1 : 0, st, fine);
+            } else {
+                const uint32_t total = (uint32_t)pl.w * (uint32_t)pl.h;
+                const uint32_t totalmin = (uint32_t)trunc((double)total * (double)prm.minthr);
+                const uint32_t totalmax = (uint32_t)trunc((double)total * (double)prm.maxthr);
+                const uint32_t nlo = __hip_atomic_load(&bk[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t nhi = total - __hip_atomic_load(&bk[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // samples at or above the high range's end
+                const uint32_t peak = (uint32_t)prm.hist_size - 1;
+                uint32_t retmin = peak, retmax = 0;  // the reference's `else` values: the count never exceeds a threshold >= total
+                int okl = 1, okh = 1;
+                if (totalmin < total) retmin = lo_start + range_scan(g + 512, false, nlo, totalmin, fine, &okl);
+                if (totalmax < total) retmax = hi_start + range_scan(g + 512 + kRange, true, nhi, totalmax, fine, &okh);
+                if (okl && okh)
+                    write_result(prm, pi, S::is_int ? 1 : 0, retmin, retmax);
+                else if (tid == 0)
+                    bk[4] = 1u;  // the two histogram sweeps answer this plane
+            }
+        }
+        __syncthreads();
+        u = ue;
     }
 }
 
@@ -496,8 +790,6 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     if (nplanes > kMaxPlanesPS) return vszip_set_error(ctx, VSZIP_ERR_ARG, "at most %d planes per call", kMaxPlanesPS);
     PSParams &prm = L.prm;
     prm.nplanes = nplanes;
-    long px = 0;
-    for (int i = 0; i < nplanes; ++i) px += (long)planes[i].w * planes[i].h;
     int rows = 8;
     for (int i = 0; i < nplanes; ++i) {
         const vszip_plane &s = planes[i];
@@ -520,7 +812,7 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     }
     L.total_blocks = blocks;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const size_t need = (size_t)blocks * 4 * sizeof(double) + (size_t)nplanes * (512 + 8) * sizeof(uint32_t) + (size_t)nplanes * 4 * sizeof(double) + 256;
+    const size_t need = (size_t)blocks * 4 * sizeof(double) + (size_t)nplanes * (kHistWords + kBucketWords + 256) * sizeof(uint32_t) + (size_t)nplanes * 4 * sizeof(double) + 256;
     int rc = vszip_ensure_scratch(ctx, need);
     if (rc != VSZIP_OK) return rc;
     rc = vszip_ensure_scalars(ctx, (size_t)nplanes * 4 * sizeof(double));
@@ -533,8 +825,10 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     // (device-visible): the call ends with a synchronise, no copy command
     VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&prm.result), ctx->scalars_host, 0));
     prm.hist = reinterpret_cast<uint32_t *>(p);
-    p += (size_t)nplanes * 512 * sizeof(uint32_t);
+    p += (size_t)nplanes * kHistWords * sizeof(uint32_t);
     prm.bucket = reinterpret_cast<uint32_t *>(p);
+    p += (size_t)nplanes * kBucketWords * sizeof(uint32_t);
+    prm.shist = reinterpret_cast<uint32_t *>(p);
     return VSZIP_OK;
 }
 
@@ -599,14 +893,29 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
         }
         hipLaunchKernelGGL(minmax_final_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, is_int);
     } else {
-        VSZIP_HIP_CHECK(ctx, hipMemsetAsync(L.prm.hist, 0, (size_t)L.prm.nplanes * 512 * sizeof(uint32_t), ctx->stream));
-        {
-            vszip_probe_scope probe(ctx);
-            hipLaunchKernelGGL((hist_kernel<T, REF, 0>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
+        // hist, bucket and shist are contiguous: one memset
+        VSZIP_HIP_CHECK(ctx, hipMemsetAsync(L.prm.hist, 0, (size_t)L.prm.nplanes * (kHistWords + kBucketWords + 256) * sizeof(uint32_t), ctx->stream));
+        const int single = wide && getenv("VSZIP_MINMAX_SINGLE_READ") ? 1 : 0;  // opt-in: measured slower than the two sweeps on two of three contents
+        const int grid = std::min(L.total_blocks, (REF ? 2 : 3) * 256), grid0 = std::min(L.total_blocks, 3 * 256);
+        if constexpr (wide != 0) {
+            if (single) {
+                hipLaunchKernelGGL((hist_sample_kernel<T>), dim3(L.prm.nplanes * kSampleBlocks), dim3(kThreads), 0, ctx->stream, L.prm);
+                vszip_probe_scope probe(ctx);
+                hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 1>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
+            }
         }
-        hipLaunchKernelGGL(bucket_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, wide);
-        if (wide) hipLaunchKernelGGL((hist_kernel<T, false, 1>), dim3(L.total_blocks), dim3(kThreads), 0, ctx->stream, L.prm);
-        hipLaunchKernelGGL(thr_final_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, wide, is_int);
+        // the two-level radix: every plane (8-bit clips, VSZIP_MINMAX_TWO_SWEEPS), or the planes the single sweep flagged (the others' workgroups return at once)
+        if (single) {
+            hipLaunchKernelGGL((hist_sweep_kernel<T, false, 0>), dim3(std::min(grid0, 256)), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 1);
+        } else {
+            vszip_probe_scope probe(ctx);
+            hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 0>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
+        }
+        if constexpr (wide != 0) {
+            const int kb = std::min(128, std::max(8, 4096 / L.prm.nplanes));  // workgroups per plane of the second sweep
+            hipLaunchKernelGGL((hist_refine_kernel<T>), dim3(L.prm.nplanes * kb), dim3(kThreads), 0, ctx->stream, L.prm, kb);
+        }
+        hipLaunchKernelGGL(thr_final_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, wide, is_int);  // (planes not written yet)
     }
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
