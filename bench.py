@@ -1206,7 +1206,7 @@ def main() -> int:
                 others[name] = {"value": nf * 10 / dt2, "unit": "frames/s", "kernel_ms_per_frame": kms / (10 * nf), "frames_per_call": nf,
                                 "roofline": {"bound": "hbm", "achieved": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                             "kernel": "bilateral_lds16_kernel<u16> (range LUT packed in LDS)", "avg_launch_us": dms * 1e3 / nl},
+                                             "kernel": "bilateral_walk16_kernel<3,2> luma + <2,1> chroma (column-walking waves, exact range LUT packed in LDS)", "avg_launch_us": dms * 1e3 / nl},
                                 "workload": f"vszip.Bilateral sigmaS=2 sigmaR=2 {w}x{h} YUV420P16 (natural content tiled), HBM-resident"}
                 others[name]["roofline"]["kernel"] = "bilateral_walk16_kernel<3,2> + <2,1> (symmetric weights looked up once, table in LDS)"
                 others[name]["limit"] = limit_from_profile("bilateral", "bilateral_walk16_kernel<3")
@@ -1291,7 +1291,7 @@ def main() -> int:
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "vszip.Bilateral sigmaS=2 sigmaR=2, 1920x1080 YUV420P16, natural content tiled", "frames_per_step_per_gpu": F},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": "bilateral_lds16_kernel<u16> (range LUT packed in LDS)"}}
+                            "kernel": "bilateral_walk16_kernel<3,2> luma + <2,1> chroma (column-walking waves, exact range LUT packed in LDS)"}}
         if rank == 0 and world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_bilateral(W1080, H1080)
     else:
