@@ -654,17 +654,16 @@ __device__ __forceinline__ int tap_index(int k, int i, int n) {
 }
 
 // a / b in f64 for the two quotients of maps_pixel, whose denominators are finite and far from the exponent limits (>= 1, or a
-// variance term + 0.0009): v_rcp_f64 refined by two Newton steps and one residual correction of the quotient — the result is
-// within one unit in the last place of the IEEE quotient (mostly equal to it) at about half the instructions of the
-// v_div_scale / v_div_fmas / v_div_fixup sequence, which carries the range handling these operands never need. The maps kernel
-// is issue bound and the two f64 divisions were a quarter of a pixel's instructions. The pooled f64 sums move by ~1e-16
-// relative (the pooling ORDER already differs from the reference's by ~1e-15); -DVSZIP_SSIM_IEEE_DIV restores the IEEE sequence.
+// variance term + 0.0009): v_rcp_f64 refined by ONE Newton step and one residual correction of the quotient, 6 instructions against
+// the 12 of the v_div_scale / v_div_fmas / v_div_fixup sequence, which carries the range handling these operands never need. The maps
+// kernel is issue bound and its f64 instructions (half rate) are more than half of its VALU cycles. tools/div_probe.hip compares the
+// forms with the IEEE quotient on 16.7 M operand pairs of the kernel's ranges: one Newton step and two both give the IEEE quotient on
+// EVERY pair (round 3 first used two), none leaves up to 18 units in the last place. -DVSZIP_SSIM_IEEE_DIV restores the IEEE sequence.
 __device__ __forceinline__ double maps_div(double a, double b) {
 #ifdef VSZIP_SSIM_IEEE_DIV
     return a / b;
 #else
     double r = __builtin_amdgcn_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
     r = fma(fma(-b, r, 1.0), r, r);
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
