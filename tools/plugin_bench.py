@@ -77,6 +77,20 @@ def main():
         vs.core_standins(True)
         r8, d8 = clips_4k_rgb24(4)
         legs.append(("SSIMULACRA2 4K RGB24 (device colour pre-stage)", r8.vszip.SSIMULACRA2(d8), 49.8, 64))
+    if only is None or "ssimulacra2" in only:
+        # round 3: YUV420P8 clips, chroma upsampling + matrix + EOTF on the device (24.9 MB per pair)
+        import bench
+
+        yref, ydis = bench.yuv420p8_pair(3840, 2160)
+        props = {"_Matrix": 1, "_ColorRange": 1, "_ChromaLocation": 0}
+        ya = vs.source([[np.roll(p, 8 * f, axis=1) for p in yref] for f in range(4)], vs.YUV420P8, props=props)
+        yb = vs.source([[np.roll(p, 8 * f, axis=1) for p in ydis] for f in range(4)], vs.YUV420P8, props=props)
+        legs.append(("SSIMULACRA2 4K YUV420P8 (device colour pre-stage)", ya.vszip.SSIMULACRA2(yb), 24.9, 96))
+    if only is None or "limitfilter" in only:
+        # round 3: the reference's canonical LimitFilter construction, a vszip chain with a two-input sink (tests/test_int_parity.py:158-167):
+        # fused = one upload of src, BoxBlur + LimitFilter on the device, one download
+        legs.append(("LimitFilter(flt=src.BoxBlur(2,2), src) 4K YUV420P16 (fused chain)", src4k.vszip.BoxBlur(hradius=2, vradius=2).vszip.LimitFilter(src=src4k, dark_thr=8, bright_thr=8, elast=3), 25 * 2, 96))
+        legs.append(("PlaneMinMax(BoxBlur(2,2), minthr=maxthr=0.1) 4K YUV420P16 (fused metric sink)", src4k.vszip.BoxBlur(hradius=2, vradius=2).vszip.PlaneMinMax(minthr=0.1, maxthr=0.1), 25, 96))
     if only is None or "pipeline" in only:
         # BASELINE config 5 as a script writes it: three filter instances, fused into one getFrame by the plugin
         src8k = clip_8k_rgbs(4)
