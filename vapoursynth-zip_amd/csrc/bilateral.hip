@@ -419,7 +419,12 @@ __device__ __forceinline__ v2f walk_right_pair(float a, float b) {
     return v2f{walk_shl1(a), y};
 }
 
-constexpr int kWalkBand = 108;  // output rows per strip: a multiple of both ring periods, and 1080 / 540 / 2160 rows split into whole bands
+#ifndef VSZIP_WALK_BAND
+#define VSZIP_WALK_BAND 270
+#endif
+constexpr int kWalkBand = VSZIP_WALK_BAND;  // output rows per strip: a multiple of both ring periods, and 1080 / 540 / 2160 rows split into whole bands.
+// 270: a strip pays its 2 CR rows of ring warm-up once per band — 108 / 180 / 270 / 360 / 540 rows measured 69.4 / 68-69 / 72.3 / 62 / 54.9 k fps at 1080p
+// (interleaved A/B on one device; longer bands leave too few strips to balance 4096 waves)
 
 template <int CR, int CS>
 struct WalkState {

@@ -1582,7 +1582,12 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     // The chains need a whole CU's worth of LDS each; beside a full line-kernel launch they would never find one
     // (freed wave slots go to the next line wave), so the short planes' line kernel runs on a stream whose CU mask
     // leaves one CU per chain free.
-    bool split = !general && vc_lds && ntall > 0 && ntall < nplanes && ntall <= 64 && !getenv("VSZIP_EEDI3_NO_OVERLAP");
+    // Only for calls of 12 frames and more (tools/eedi3_overlap_ab.py, 1080p YUV420PS, frames per call: with / without — 1: 306 / 401 fps,
+    // 2: 576 / 706, 4: 993 / 1119, 8: 1607 / 1630, 16: 2308 / 2170): below that the masked stream's launches and events cost more than the
+    // overlap returns, and the plugin's one-frame calls from twelve contexts at once lost half their rate to it (757 against 1599 fps).
+    // (VSZIP_EEDI3_FORCE_OVERLAP=1: from one tall plane on — the parity tests run small batches through this path)
+    const int min_tall = getenv("VSZIP_EEDI3_FORCE_OVERLAP") ? 1 : 12;
+    bool split = !general && vc_lds && ntall >= min_tall && ntall < nplanes && ntall <= 64 && !getenv("VSZIP_EEDI3_NO_OVERLAP");
     if (split) {
         const int reserve = std::min(64, (ntall + 7) & ~7), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
         if (ctx->aux_stream && ctx->aux_reserved != reserve) {
