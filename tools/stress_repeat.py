@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: run the same BoxBlur / Bilateral / SSIMULACRA2 / EEDI3 launches many times and compare every output with the
 first run's, bit for bit - timing-dependent hardware hazards and stream races show up as rare mismatches."""
+import os
 import sys
 from pathlib import Path
 
@@ -58,6 +59,7 @@ fs = [dev.upload(p) for p in plf]
 outs = dev.eedi3(fs, 1, dh=True)
 table = dev.plane_table(fs, outs)
 prm = bench._eedi3_params()
+os.environ["VSZIP_EEDI3_FORCE_OVERLAP"] = "1"  # (the library forks the second stream from 12 frames per call on)
 repeat("eedi3 1080p YUV420PS x4 (two plane heights: overlap path)", lambda: dev.check(dev.lib.vszip_eedi3(dev.ctx, table, None, None, len(fs), 1, 0, prm)), outs, n=max(10, N // 3))
 
 ref = [np.ascontiguousarray(fx.tiled_natural((1080, 1920), np.float32, p)) for p in range(3)]
