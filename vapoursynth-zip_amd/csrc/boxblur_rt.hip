@@ -190,7 +190,9 @@ struct RVParams {
 // RING (round 3): the leaving row is the one that entered 2R + 1 steps earlier. Re-reading it from memory made the pass fetch 2.2x its
 // input from HBM (PMC: 444 MB per 199 MB launch — 3 000 waves x (2R + 1) KiB outlive the L2s); the wave now keeps its last 2R + 2 raw row
 // vectors in LDS ([slot = row mod D][lane], 16 bytes per lane: conflict free, and private to the lane — no barrier) and takes the
-// leaving row from there. D KiB per wave: used while it leaves five waves a CU (R <= 15), else the re-reading form.
+// leaving row from there. D KiB per wave: used up to R = 8 (18 KiB: eight waves a CU) — at R = 13 (28 KiB: five waves) the README's 5 + 5-pass
+// bench lost 11 % to it (22.1 k -> 19.6 k fps in an interleaved A/B, tools/rt_ring_ab.py) — else the re-reading form.
+constexpr int kVRingMaxR = 8;
 template <typename T, bool RING>
 __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm) {
     using X = RtVec<T>;
@@ -878,7 +880,8 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                     vp.ncg[i] = (prm.p[i].w + 64 * RtVec<T>::V - 1) / (64 * RtVec<T>::V);
                     vb += vp.ncg[i] * ((prm.p[i].h + band - 1) / band);
                 }
-                if (radius <= 15 && !getenv("VSZIP_RT_NO_VRING"))
+                const char *vr = getenv("VSZIP_RT_VRING_MAXR");  // development: the largest radius that takes the ring
+                if (radius <= (vr ? atoi(vr) : kVRingMaxR) && !getenv("VSZIP_RT_NO_VRING"))
                     hipLaunchKernelGGL((boxblur_rt_vband_kernel<T, true>), dim3(vb), dim3(64), (size_t)(2 * radius + 2) * 64 * sizeof(uint4), ctx->stream, vp);
                 else
                     hipLaunchKernelGGL((boxblur_rt_vband_kernel<T, false>), dim3(vb), dim3(64), 0, ctx->stream, vp);
