@@ -160,6 +160,44 @@ def test_success_paths_under_asan(san_env):
     assert r.returncode == 0 and "success ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+RANDOM_GRAPHS = textwrap.dedent("""
+    import sys, numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+    from fakevs import fakevs as vs
+    import test_gpu_plugin_random as g
+    n = 0
+    for seed in range({graphs}):
+        rng = np.random.default_rng(77000 + seed)
+        sink = ["pixel", "limitfilter", "average", "minmax", "xpsnr", "ssim"][seed % 6]
+        fmt = vs.YUV420P8 if sink == "xpsnr" else (vs.RGBS if sink == "ssim" else vs.YUV420P16)
+        props = {{"_Transfer": 8}} if fmt == vs.RGBS else None
+        ra = vs.source(g._frames(rng, fmt), fmt, props=props)
+        rb = vs.source(g._frames(rng, fmt), fmt, props=props) if rng.integers(0, 3) == 0 else ra
+        a = g._chain(ra, [g._stage(rng) for _ in range(int(rng.integers(1, 4)))], fmt, True)
+        b = g._chain(rb, [g._stage(rng) for _ in range(int(rng.integers(0, 3)))], fmt, True)
+        if sink == "pixel": c = a.vszip.BoxBlur(hradius=2, vradius=2)
+        elif sink == "limitfilter": c = a.vszip.LimitFilter(b, dark_thr=8, ref=g._chain(ra, [g._stage(rng)], fmt, True))
+        elif sink == "average": c = a.vszip.PlaneAverage(exclude=[-1], planes=[0, 1, 2], clipb=b)
+        elif sink == "minmax": c = a.vszip.PlaneMinMax(minthr=0.1, maxthr=0.1, planes=[0, 1, 2], clipb=b)
+        elif sink == "ssim": c = a.vszip.SSIMULACRA2(b)
+        else: c = b.vszip.XPSNR(a, verbose=False)
+        c.get_frame(0)
+        c.pull(g.NFR, 3)
+        del a, b, c, ra, rb
+        n += 1
+    print("graphs ok", n)
+""")
+
+
+def test_random_filter_graphs_under_asan(san_env):
+    """The seeded random scripts of tests/test_gpu_plugin_random.py (fused side only) against the stub with succeeding kernels: the
+    fusion registry, the multi-input staging and every release on graphs nobody wrote by hand, single threaded and from 3 workers."""
+    env = dict(san_env, VSZIP_STUB_FAIL="none")
+    r = subprocess.run([sys.executable, "-c", RANDOM_GRAPHS.format(root=str(ROOT), tests=str(ROOT / "tests"), graphs=48)], capture_output=True, text=True, env=env, timeout=1200)
+    _clean(r)
+    assert r.returncode == 0 and "graphs ok 48" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_worker_threads_under_tsan():
     """Race detection: the plugin, the stub device library and the test host built with
     -fsanitize=thread; 8 worker threads pull frames of every filter kind at once (shared per-instance state:
