@@ -26,6 +26,7 @@
 #include <mutex>
 #include <set>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -453,9 +454,9 @@ struct WalkLut<true> {
     __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(base[i >> 2] - (uint32_t)delta[i]); }
 };
 
-template <int CR, int CS, int P, bool FINE>
+template <int CR, int CS, int P, bool FINE, typename T>
 __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak,
-                                           uint32_t &pend, const uint16_t *__restrict__ nextp, uint16_t *__restrict__ dstp) {
+                                           T &pend, const T *__restrict__ nextp, T *__restrict__ dstp) {
     using W = WalkState<CR, CS>;
     constexpr int R = W::R, T0 = W::T0, T1 = W::T1;
     // 1: the row loaded a step ago enters the rings (slot P), with its shifted copies
@@ -469,7 +470,10 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     constexpr int C = (P - CR + R) % R;
     const float c = st.sc[C];
     auto lut = [&](float n) {
-        return tab.at((uint32_t)fabsf(c - n));  // |c - n|: exact in f32 for 16-bit samples
+        if constexpr (std::is_same<T, uint16_t>::value)
+            return tab.at((uint32_t)fabsf(c - n));  // |c - n|: exact in f32 for 16-bit samples
+        else
+            return tab.at((uint32_t)truncf(fminf(1.0f, fabsf(c - n)) * 65535.0f + 0.5f));  // bilateral.zig:15-22 (|c - n| == |n - c|: the same entry both ways)
     };
     float wsum = w0, sum = c * w0;
     auto sets = [&](const v2f swv, const v2f n1, const v2f n2, const v2f n3, const v2f n4, v2f &ha, v2f &hb) {
@@ -495,20 +499,25 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     // No branch anywhere in a step (a period of R steps is ONE basic block: the scheduler may start a step's loads and table
     // reads under the previous step's arithmetic): rows and lanes that produce no output store to a dummy line instead.
     const float q = __fdiv_rn(sum, wsum);
-    *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
+    if constexpr (std::is_same<T, uint16_t>::value)
+        *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
+    else
+        *dstp = q;
 }
 
-template <int CR, int CS, bool FINE, int... P>
-__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak, uint32_t &pend,
-                                             const uint16_t *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, uint16_t *__restrict__ dcol,
-                                             int dstride, uint16_t *__restrict__ dummy, std::integer_sequence<int, P...>) {
+template <int CR, int CS, bool FINE, typename T, int... P>
+__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak, T &pend,
+                                             const T *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, T *__restrict__ dcol,
+                                             int dstride, T *__restrict__ dummy, std::integer_sequence<int, P...>) {
     // step t handles the new row ys + t and the output row ys + t - CR; rows are clamped into the plane (replicate padding)
-    (walk_step<CR, CS, P, FINE>(st, tab, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
+    (walk_step<CR, CS, P, FINE, T>(st, tab, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
                           (lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1) ? dcol + (size_t)(ys + t0 + P - CR) * dstride : dummy),
      ...);
 }
 
-template <int CR, int CS, bool FINE>
+// (T last: 16-bit integer samples, or — round 3, the 8K RGBS pipeline's Bilateral stage — f32 samples: the same walk, the table index
+// and the finish of the float path)
+template <int CR, int CS, bool FINE, typename T = uint16_t>
 __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips, int *__restrict__ next_strip) {
     using W = WalkState<CR, CS>;
     __shared__ __attribute__((aligned(16))) WalkLut<FINE> slut;
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         if (lane == 0) v = atomicAdd(next_strip, 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    uint16_t *dummy = reinterpret_cast<uint16_t *>(next_strip + 64) + lane;  // 128 B behind the counter's line: what the halo lanes / rows "store"
+    T *dummy = reinterpret_cast<T *>(next_strip + 64) + lane;  // 256 B behind the counter: what the halo lanes / rows "store"
     int pi = 0;
 #pragma unroll 1
     for (int sidx = grab(); sidx < nstrips; sidx = grab()) {
@@ -540,8 +549,8 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         const int ls = sidx - pl.block0;
         const int X0 = (ls % pl.nbx) * WOUT, y0 = (ls / pl.nbx) * kWalkBand, y1 = min(y0 + kWalkBand, pl.h);
         const int col = X0 - CR + lane;
-        const uint16_t *colp = static_cast<const uint16_t *>(pl.src) + min(max(col, 0), pl.w - 1);
-        uint16_t *dcol = static_cast<uint16_t *>(pl.dst) + min(max(col, 0), pl.w - 1);
+        const T *colp = static_cast<const T *>(pl.src) + min(max(col, 0), pl.w - 1);
+        T *dcol = static_cast<T *>(pl.dst) + min(max(col, 0), pl.w - 1);
         const bool lane_out = lane >= CR && lane < 64 - CR && col < pl.w;
         W st;
 #pragma unroll
@@ -554,11 +563,11 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
 #pragma unroll
         for (int b = 0; b < W::T1; ++b) st.ha1[b] = st.hb1[b] = v2f{0.0f, 0.0f};
         const int ys = y0 - 2 * CR;  // first row needed: the weights handed to row y0 come from rows y0 - CR .., which tap rows down to y0 - 2 CR
-        uint32_t pend = colp[(size_t)min(max(ys, 0), pl.h - 1) * pl.sstride];
+        T pend = colp[(size_t)min(max(ys, 0), pl.h - 1) * pl.sstride];
         const int steps = (y1 - y0) + 3 * CR;
 #pragma unroll 1
         for (int t0 = 0; t0 < steps; t0 += W::R)
-            walk_period<CR, CS, FINE>(st, slut, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
+            walk_period<CR, CS, FINE, T>(st, slut, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
     }
 }
 
@@ -916,7 +925,7 @@ int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_r
 }
 
 // The column-walking kernel: strips of 64 - 2 CR output columns x kWalkBand rows; prm.p[i].block0 / nbx are re-based on strips.
-template <int CR, int CS>
+template <int CR, int CS, typename T = uint16_t>
 int launch_walk16(vszip_ctx *ctx, BLParams prm, bool fine) {
     int strips = 0;
     for (int i = 0; i < prm.nplanes; ++i) {
@@ -932,9 +941,9 @@ int launch_walk16(vszip_ctx *ctx, BLParams prm, bool fine) {
     VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
     vszip_probe_scope probe(ctx);
     if (fine)
-        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, true>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, true, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     else
-        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, false>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, false, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
@@ -1197,7 +1206,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
                 }
                 const bool no_walk = getenv("VSZIP_BILATERAL_NO_WALK") != nullptr;  // (read per call: the tests switch paths inside one process)
-                if (dtype == VSZIP_U16 && !joint && !no_walk && q.nplanes > 0) {
+                if ((dtype == VSZIP_U16 || dtype == VSZIP_F32) && !joint && !no_walk && q.nplanes > 0) {
                     int r = q.p[0].radius, st = q.p[0].step;
                     for (int i = 1; i < q.nplanes; ++i)
                         if (q.p[i].radius != r || q.p[i].step != st) r = st = 0;
@@ -1205,12 +1214,12 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     bool fine = !no_fine;
                     for (int i = 0; i < q.nplanes && fine; ++i) lut_is_packed(q.p[i].gr, nullptr, &fine);
                     if (r == 3 && st == 2) {
-                        rc = launch_walk16<3, 2>(ctx, q, fine);
+                        rc = dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, fine) : launch_walk16<3, 2, float>(ctx, q, fine);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
                     if (r == 2 && st == 1) {
-                        rc = launch_walk16<2, 1>(ctx, q, fine);
+                        rc = dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, fine) : launch_walk16<2, 1, float>(ctx, q, fine);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
