@@ -50,6 +50,7 @@ struct BLParams {
     int nplanes;
     float peak;
     int lut_len, lut_offset;  // tiled kernel with the range LUT in LDS: entries, byte offset behind the tiles
+    int lut_upper;            // walk kernel, PLATEAU form: the table is constant from this entry on (gaussianFunctionRangeLUTGeneration's `upper`)
 };
 
 template <typename T>
@@ -437,25 +438,34 @@ struct WalkState {
     v2f ha1[T1], hb1[T1];                          // ... of the yy = T1 taps
 };
 
-// The table in LDS: COARSE = base[i >> 6] (u32 x 1024) - delta[i] (u16), any table that packs; FINE = base4[i >> 2] (u32 x 16384) - delta8[i] (u8),
-// gentle tables only — its byte offsets are i & ~3 and i: one VALU instruction of address arithmetic per lookup instead of three.
-template <bool FINE>
+// The table in LDS. COARSE (0) = base[i >> 6] (u32 x 1024) - delta[i] (u16), any table that packs; FINE (1) = base4[i >> 2] (u32 x 16384) -
+// delta8[i] (u8), gentle tables only — its byte offsets are i & ~3 and i: one VALU instruction of address arithmetic per lookup instead of three.
+// PLATEAU (2, round 3): the table as it is, up to the entry where the reference stops computing it (`upper` = trunc(sigmaR * 8 * 65535 + 0.5),
+// bilateral.zig:316-334: every entry beyond repeats gr[upper]) — the STEEP tables of the filter's usual sigmaR (0.01 ... 0.06; default 0.02),
+// which neither packed form holds and which had to be gathered through L2: one LDS read and a v_min per lookup, up to 32 768 entries.
+constexpr int kWalkPlateauMax = 32768;
+template <int FORM>
 struct WalkLut;
 template <>
-struct WalkLut<false> {
+struct WalkLut<0> {
     uint32_t base[1024];
     uint16_t delta[65536];
-    __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(base[i >> 6] - (uint32_t)delta[i]); }
+    __device__ __forceinline__ float at(uint32_t i, uint32_t) const { return __uint_as_float(base[i >> 6] - (uint32_t)delta[i]); }
 };
 template <>
-struct WalkLut<true> {
+struct WalkLut<1> {
     uint32_t base[16384];
     uint8_t delta[65536];
-    __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(base[i >> 2] - (uint32_t)delta[i]); }
+    __device__ __forceinline__ float at(uint32_t i, uint32_t) const { return __uint_as_float(base[i >> 2] - (uint32_t)delta[i]); }
+};
+template <>
+struct WalkLut<2> {
+    float t[kWalkPlateauMax];
+    __device__ __forceinline__ float at(uint32_t i, uint32_t upper) const { return t[min(i, upper)]; }
 };
 
-template <int CR, int CS, int P, bool FINE, typename T>
-__device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak,
+template <int CR, int CS, int P, int FINE, typename T>
+__device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const uint32_t upper, const v2f (&sw)[2], float w0, float peak,
                                            T &pend, const T *__restrict__ nextp, T *__restrict__ dstp) {
     using W = WalkState<CR, CS>;
     constexpr int R = W::R, T0 = W::T0, T1 = W::T1;
@@ -471,9 +481,9 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     const float c = st.sc[C];
     auto lut = [&](float n) {
         if constexpr (std::is_same<T, uint16_t>::value)
-            return tab.at((uint32_t)fabsf(c - n));  // |c - n|: exact in f32 for 16-bit samples
+            return tab.at((uint32_t)fabsf(c - n), upper);  // |c - n|: exact in f32 for 16-bit samples
         else
-            return tab.at((uint32_t)truncf(fminf(1.0f, fabsf(c - n)) * 65535.0f + 0.5f));  // bilateral.zig:15-22 (|c - n| == |n - c|: the same entry both ways)
+            return tab.at((uint32_t)truncf(fminf(1.0f, fabsf(c - n)) * 65535.0f + 0.5f), upper);  // bilateral.zig:15-22 (|c - n| == |n - c|: the same entry both ways)
     };
     float wsum = w0, sum = c * w0;
     auto sets = [&](const v2f swv, const v2f n1, const v2f n2, const v2f n3, const v2f n4, v2f &ha, v2f &hb) {
@@ -505,24 +515,29 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
         *dstp = q;
 }
 
-template <int CR, int CS, bool FINE, typename T, int... P>
-__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const v2f (&sw)[2], float w0, float peak, T &pend,
+template <int CR, int CS, int FINE, typename T, int... P>
+__device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const uint32_t upper, const v2f (&sw)[2], float w0, float peak, T &pend,
                                              const T *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, T *__restrict__ dcol,
                                              int dstride, T *__restrict__ dummy, std::integer_sequence<int, P...>) {
     // step t handles the new row ys + t and the output row ys + t - CR; rows are clamped into the plane (replicate padding)
-    (walk_step<CR, CS, P, FINE, T>(st, tab, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
+    (walk_step<CR, CS, P, FINE, T>(st, tab, upper, sw, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
                           (lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1) ? dcol + (size_t)(ys + t0 + P - CR) * dstride : dummy),
      ...);
 }
 
 // (T last: 16-bit integer samples, or — round 3, the 8K RGBS pipeline's Bilateral stage — f32 samples: the same walk, the table index
 // and the finish of the float path)
-template <int CR, int CS, bool FINE, typename T = uint16_t>
+template <int CR, int CS, int FINE, typename T = uint16_t>
 __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips, int *__restrict__ next_strip) {
     using W = WalkState<CR, CS>;
     __shared__ __attribute__((aligned(16))) WalkLut<FINE> slut;
     const int tid = (int)threadIdx.x;
-    {
+    const uint32_t upper = (uint32_t)prm.lut_upper;
+    if constexpr (FINE == 2) {
+        // the f32 table itself, up to its plateau
+        const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr);
+        for (int i = tid; i < ((int)upper + 4) / 4; i += 1024) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
+    } else {
         // the packed forms lie behind the f32 table: COARSE (4 + 128 KiB), then FINE (64 + 64 KiB)
         const uint4 *g = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(prm.p[0].gr + 65536) + (FINE ? kL16LutBytes : 0));
         for (int i = tid; i < (int)(sizeof(WalkLut<FINE>) / 16); i += 1024) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         const BLPlane &pl = prm.p[pi];
         const float *gs = pl.gs;  // (planes of one launch share the range table, radius and step — not necessarily sigmaS)
         const v2f sw[2] = {{gs[W::T0 * (CR + 1) + W::T0], gs[W::T0 * (CR + 1) + W::T1]}, {gs[W::T1 * (CR + 1) + W::T0], gs[W::T1 * (CR + 1) + W::T1]}};
-        const float w0 = gs[0] * slut.at(0);
+        const float w0 = gs[0] * slut.at(0, upper);
         const int ls = sidx - pl.block0;
         const int X0 = (ls % pl.nbx) * WOUT, y0 = (ls / pl.nbx) * kWalkBand, y1 = min(y0 + kWalkBand, pl.h);
         const int col = X0 - CR + lane;
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         const int steps = (y1 - y0) + 3 * CR;
 #pragma unroll 1
         for (int t0 = 0; t0 < steps; t0 += W::R)
-            walk_period<CR, CS, FINE, T>(st, slut, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
+            walk_period<CR, CS, FINE, T>(st, slut, upper, sw, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
     }
 }
 
@@ -883,6 +898,7 @@ struct PackedLuts {
     std::mutex mu;
     std::map<const void *, uint64_t> exact;  // pointer -> content key (the bits of sigmaR: length and peak are fixed for these tables)
     std::set<const void *> fine;             // ... whose 4-entry-block form (bilateral_walk16_kernel, FINE) is exact as well and stored behind the first
+    std::map<const void *, std::pair<uint64_t, uint32_t>> plateau;  // 65536-entry tables that are constant from `upper` <= kWalkPlateauMax - 1 on: pointer -> (content key, upper)
 };
 PackedLuts &packed_luts() {
     static PackedLuts *p = new PackedLuts();
@@ -895,6 +911,16 @@ bool lut_is_packed(const void *gr, uint64_t *key = nullptr, bool *fine = nullptr
     if (it == p.exact.end()) return false;
     if (key) *key = it->second;
     if (fine) *fine = p.fine.count(gr) != 0;
+    return true;
+}
+
+bool lut_plateau(const void *gr, uint64_t *key, uint32_t *upper) {
+    PackedLuts &p = packed_luts();
+    std::lock_guard<std::mutex> lk(p.mu);
+    const auto it = p.plateau.find(gr);
+    if (it == p.plateau.end()) return false;
+    *key = it->second.first;
+    *upper = it->second.second;
     return true;
 }
 
@@ -926,7 +952,7 @@ int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_r
 
 // The column-walking kernel: strips of 64 - 2 CR output columns x kWalkBand rows; prm.p[i].block0 / nbx are re-based on strips.
 template <int CR, int CS, typename T = uint16_t>
-int launch_walk16(vszip_ctx *ctx, BLParams prm, bool fine) {
+int launch_walk16(vszip_ctx *ctx, BLParams prm, int form) {  // form: 0 COARSE, 1 FINE, 2 PLATEAU (prm.lut_upper)
     int strips = 0;
     for (int i = 0; i < prm.nplanes; ++i) {
         BLPlane &p = prm.p[i];
@@ -940,10 +966,12 @@ int launch_walk16(vszip_ctx *ctx, BLParams prm, bool fine) {
     int *counter = static_cast<int *>(ctx->scratch);
     VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
     vszip_probe_scope probe(ctx);
-    if (fine)
-        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, true, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+    if (form == 2)
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, 2, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+    else if (form == 1)
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, 1, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     else
-        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, false, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, 0, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
@@ -988,6 +1016,7 @@ void vszip_bilateral_forget_lut(const void *dptr) {
     std::lock_guard<std::mutex> lk(pl.mu);
     pl.exact.erase(dptr);
     pl.fine.erase(dptr);
+    pl.plateau.erase(dptr);
 }
 
 // LUTs exactly as bilateral.zig:306-339 computes them (f64 exp on the host, cast to f32),
@@ -1072,6 +1101,12 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
         // the registry is keyed by the raw pointer: an address reused after a free that bypassed vszip_dev_free must not keep a stale entry
         pl.exact.erase(d);
         pl.fine.erase(d);
+        pl.plateau.erase(d);
+        if (hist_len == 65536 && upper + 1 <= (uint32_t)kWalkPlateauMax) {
+            uint64_t key;
+            std::memcpy(&key, &cfg->sigmaR, sizeof key);
+            pl.plateau[d] = {key, upper};
+        }
         if (packed) {
             uint64_t key;
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
@@ -1160,6 +1195,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             blocks += d.nbx * ((s.h + rows_per_block - 1) / rows_per_block);
         }
         prm.nplanes = n;
+        const int taken = n;  // planes this turn of the loop consumes (n shrinks when the walk kernel takes some of them)
         int rc;
         // 16-bit / float clips whose range LUTs are all registered in packed form: one persistent launch per
         // distinct table, the whole table in LDS
@@ -1171,6 +1207,55 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (tile_h + 2 * max_radius);
             lds16 = lds16 && tile_elems <= (size_t)kBX * kL16Rows * stages && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
             for (int i = 0; i < n && lds16; ++i) lds16 = lut_is_packed(prm.p[i].gr);
+        }
+        // Steep tables (the filter's usual sigmaR) with the BASELINE's tap shapes: the walk kernel with the table's computed part in LDS
+        // (PLATEAU form), one launch per distinct (table, taps)
+        if (!lds16 && tiled && !joint && (dtype == VSZIP_U16 || dtype == VSZIP_F32) && prm.lut_len == 65536 && !getenv("VSZIP_BILATERAL_NO_WALK")) {
+            struct PKey {
+                uint64_t table;
+                uint32_t upper;
+                int radius, step;
+                bool operator==(const PKey &o) const { return table == o.table && upper == o.upper && radius == o.radius && step == o.step; }
+            };
+            std::vector<PKey> keys(n), groups;
+            std::vector<char> walk(n, 0);
+            for (int i = 0; i < n; ++i) {
+                keys[i].radius = prm.p[i].radius;
+                keys[i].step = prm.p[i].step;
+                walk[i] = lut_plateau(prm.p[i].gr, &keys[i].table, &keys[i].upper) && ((keys[i].radius == 3 && keys[i].step == 2) || (keys[i].radius == 2 && keys[i].step == 1));
+                if (walk[i] && std::find(groups.begin(), groups.end(), keys[i]) == groups.end()) groups.push_back(keys[i]);
+            }
+            for (const PKey &g : groups) {
+                BLParams q;
+                q.peak = prm.peak;
+                q.lut_len = prm.lut_len;
+                q.lut_offset = 0;
+                q.lut_upper = (int)g.upper;
+                q.nplanes = 0;
+                for (int i = 0; i < n; ++i)
+                    if (walk[i] && keys[i] == g) q.p[q.nplanes++] = prm.p[i];
+                if (g.radius == 3)
+                    rc = dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, 2) : launch_walk16<3, 2, float>(ctx, q, 2);
+                else
+                    rc = dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, 2) : launch_walk16<2, 1, float>(ctx, q, 2);
+                if (rc != VSZIP_OK) return rc;
+            }
+            // planes with other tap shapes (sigmaS = 1's chroma: radius 1; sigmaS = 3's luma: radius 5) stay with the tile kernel below
+            int m = 0, nb = 0;
+            for (int i = 0; i < n; ++i) {
+                if (walk[i]) continue;
+                BLPlane d = prm.p[i];
+                d.block0 = nb;
+                nb += d.nbx * ((d.h + rows_per_block - 1) / rows_per_block);
+                prm.p[m++] = d;
+            }
+            if (m == 0) {
+                done += taken;
+                continue;
+            }
+            n = m;
+            prm.nplanes = m;
+            blocks = nb;
         }
         if (lds16) {
             // planes whose tables have the same content and the same radius / step (the planes of an RGB clip, the
@@ -1195,6 +1280,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 q.peak = prm.peak;
                 q.lut_len = prm.lut_len;
                 q.lut_offset = 0;
+                q.lut_upper = 0;
                 q.nplanes = 0;
                 int qb = 0;
                 for (int i = 0; i < n; ++i) {
@@ -1214,12 +1300,12 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     bool fine = !no_fine;
                     for (int i = 0; i < q.nplanes && fine; ++i) lut_is_packed(q.p[i].gr, nullptr, &fine);
                     if (r == 3 && st == 2) {
-                        rc = dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, fine) : launch_walk16<3, 2, float>(ctx, q, fine);
+                        rc = dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, fine ? 1 : 0) : launch_walk16<3, 2, float>(ctx, q, fine ? 1 : 0);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
                     if (r == 2 && st == 1) {
-                        rc = dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, fine) : launch_walk16<2, 1, float>(ctx, q, fine);
+                        rc = dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, fine ? 1 : 0) : launch_walk16<2, 1, float>(ctx, q, fine ? 1 : 0);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
@@ -1231,7 +1317,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 }
                 if (rc != VSZIP_OK) return rc;
             }
-            done += n;
+            done += taken;
             continue;
         }
         switch (dtype) {
@@ -1242,7 +1328,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: not supported Int format.");
         }
         if (rc != VSZIP_OK) return rc;
-        done += n;
+        done += taken;
     }
     return VSZIP_OK;
 }
