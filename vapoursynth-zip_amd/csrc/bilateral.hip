@@ -210,7 +210,9 @@ constexpr int kL16MaxStage = (sizeof(T) == 4 || JOINT) ? 4 : 6;
 
 // CR / CS > 0: every plane of the launch has this radius / step (the BASELINE's luma 3 / 2 and chroma 2 / 1):
 // the tap loops unroll and every LDS offset becomes an immediate; 0 = read them from the plane table.
-template <typename T, bool JOINT, int CR, int CS>
+// PLAT (round 3): the table is a steep one kept AS IT IS up to prm.lut_upper, where the reference stops computing it (see WalkLut<2> below) —
+// for the tap shapes the walk kernel does not have (the filter's default sigmaS = 3: radius 5) and for `ref` clips.
+template <typename T, bool JOINT, int CR, int CS, bool PLAT = false>
 __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BLParams prm, const int nblocks) {
     using S = BSmp<T>;
     // the LUT is a STATIC allocation (addresses fold into the ds_read offsets); the tile buffers follow it
@@ -221,14 +223,24 @@ __global__ __launch_bounds__(kBX *kL16Rows) void bilateral_lds16_kernel(const BL
     T *tiles = reinterpret_cast<T *>(smem);
     const int lx = (int)threadIdx.x, tyi = (int)threadIdx.y, tid = tyi * kBX + lx;
     constexpr int NT = kBX * kL16Rows;
-    {
+    const float *splain = reinterpret_cast<const float *>(&slut);  // PLAT: the same 132 KiB hold up to 32 768 plain entries
+    const uint32_t upper = (uint32_t)prm.lut_upper;
+    if constexpr (PLAT) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr);
+        for (int i = tid; i < ((int)upper + 4) / 4; i += NT) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
+    } else {
         // the planes of one launch share one range LUT (the host groups them by table)
         const uint32_t *gb = reinterpret_cast<const uint32_t *>(prm.p[0].gr + 65536);
         const uint4 *gd = reinterpret_cast<const uint4 *>(gb + 1024);
         sbase[tid] = gb[tid];
         for (int i = tid; i < 65536 / 8; i += NT) reinterpret_cast<uint4 *>(sdelta)[i] = gd[i];
     }
-    auto lut = [&](uint32_t i) { return __uint_as_float(sbase[i >> 6] - (uint32_t)sdelta[i]); };
+    auto lut = [&](uint32_t i) {
+        if constexpr (PLAT)
+            return splain[min(i, upper)];
+        else
+            return __uint_as_float(sbase[i >> 6] - (uint32_t)sdelta[i]);
+    };
     // Only ONE workgroup fits a CU, so nothing else hides a tile's global loads: the next tile is fetched into
     // registers while this one is filtered, and the two LDS tile buffers alternate (one barrier per tile).
     const int tile_elems_max = prm.lut_offset;  // (reused field) samples of the largest tile of the launch, per clip
@@ -924,20 +936,24 @@ bool lut_plateau(const void *gr, uint64_t *key, uint32_t *upper) {
     return true;
 }
 
-template <typename T, bool JOINT, int CR, int CS>
+template <typename T, bool JOINT, int CR, int CS, bool PLAT = false>
 int launch_lds16_k(vszip_ctx *ctx, const BLParams &prm, int blocks, size_t lds) {
     const dim3 grid(std::min(blocks, 256)), block(kBX, kL16Rows);
-    VSZIP_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bilateral_lds16_kernel<T, JOINT, CR, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((bilateral_lds16_kernel<T, JOINT, CR, CS>), grid, block, lds, ctx->stream, prm, blocks);
+    VSZIP_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bilateral_lds16_kernel<T, JOINT, CR, CS, PLAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((bilateral_lds16_kernel<T, JOINT, CR, CS, PLAT>), grid, block, lds, ctx->stream, prm, blocks);
     VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
 
 template <typename T>
-int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_radius) {
+int launch_lds16(vszip_ctx *ctx, BLParams prm, int blocks, bool joint, int max_radius, bool plateau = false) {
     const int tile_elems = (kBX + 2 * max_radius) * ((joint ? kL16TileH<T, true> : kL16TileH<T, false>) + 2 * max_radius);
     prm.lut_offset = tile_elems;  // (the field is free in this kernel: samples of the largest tile, per clip)
     const size_t lds = (size_t)2 * tile_elems * sizeof(T) * (joint ? 2 : 1);  // dynamic part; the LUT is static
+    if (plateau) {  // (prm.lut_upper set by the caller) run-time taps only: the walk kernel has the compile-time shapes
+        vszip_probe_scope probe(ctx);
+        return joint ? launch_lds16_k<T, true, 0, 0, true>(ctx, prm, blocks, lds) : launch_lds16_k<T, false, 0, 0, true>(ctx, prm, blocks, lds);
+    }
     int r = prm.p[0].radius, st = prm.p[0].step;
     for (int i = 1; i < prm.nplanes; ++i)
         if (prm.p[i].radius != r || prm.p[i].step != st) r = st = 0;
@@ -1256,6 +1272,44 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             n = m;
             prm.nplanes = m;
             blocks = nb;
+        }
+        // ... and steep tables with any other taps (or a `ref` clip): the persistent tile kernel with the same PLATEAU table in LDS
+        if (!lds16 && tiled && dtype != VSZIP_U8 && prm.lut_len == 65536 && !getenv("VSZIP_BILATERAL_NO_LDS16")) {
+            const size_t bps = dtype == VSZIP_F32 ? 4 : 2;
+            const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64, stages = (dtype == VSZIP_F32 || joint) ? 4 : 6;
+            const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (tile_h + 2 * max_radius);
+            bool ok = tile_elems <= (size_t)kBX * kL16Rows * stages && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
+            std::vector<std::pair<uint64_t, uint32_t>> keys(n), groups;
+            for (int i = 0; i < n && ok; ++i) {
+                ok = lut_plateau(prm.p[i].gr, &keys[i].first, &keys[i].second);
+                if (ok && std::find(groups.begin(), groups.end(), keys[i]) == groups.end()) groups.push_back(keys[i]);
+            }
+            if (ok) {
+                for (const auto &g : groups) {
+                    BLParams q;
+                    q.peak = prm.peak;
+                    q.lut_len = prm.lut_len;
+                    q.lut_offset = 0;
+                    q.lut_upper = (int)g.second;
+                    q.nplanes = 0;
+                    int qb = 0;
+                    for (int i = 0; i < n; ++i) {
+                        if (!(keys[i] == g)) continue;
+                        BLPlane &dp = q.p[q.nplanes++];
+                        dp = prm.p[i];
+                        dp.block0 = qb;
+                        qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
+                    }
+                    switch (dtype) {
+                        case VSZIP_U16: rc = launch_lds16<uint16_t>(ctx, q, qb, joint, max_radius, true); break;
+                        case VSZIP_F16: rc = launch_lds16<_Float16>(ctx, q, qb, joint, max_radius, true); break;
+                        default: rc = launch_lds16<float>(ctx, q, qb, joint, max_radius, true); break;
+                    }
+                    if (rc != VSZIP_OK) return rc;
+                }
+                done += taken;
+                continue;
+            }
         }
         if (lds16) {
             // planes whose tables have the same content and the same radius / step (the planes of an RGB clip, the
