@@ -412,9 +412,11 @@ def setup_boxblur(dev, rank, frames, radius, tries=None):
     return step, keep
 
 
-def setup_bilateral(dev, w, h, frames, sigma_s=2, sigma_r=2):
+def setup_bilateral(dev, w, h, frames, sigma_s=2, sigma_r=2, eight_bit=False):
     base = natural_frame(w, h)
-    cfg = dev.bilateral_cfg([sigma_s], [sigma_r], yuv=True, ssw=1, ssh=1, hist_len=65536)
+    if eight_bit:  # YUV420P8: the picture's own 8-bit samples
+        base = [(p >> 8).astype(np.uint8) for p in base]
+    cfg = dev.bilateral_cfg([sigma_s], [sigma_r], yuv=True, ssw=1, ssh=1, hist_len=256 if eight_bit else 65536)
     srcs, dsts, idx = [], [], []
     for f in range(frames):
         for i, plane in enumerate(base):
@@ -422,6 +424,8 @@ def setup_bilateral(dev, w, h, frames, sigma_s=2, sigma_r=2):
             dsts.append(dev.empty(plane.shape[0], plane.shape[1], plane.dtype))
             idx.append(i)
     keep = (srcs, dsts, cfg)
+    if eight_bit:
+        return (lambda: dev.bilateral(srcs, dsts, cfg, idx, peak=255.0)), keep
     return (lambda: dev.bilateral(srcs, dsts, cfg, idx)), keep
 
 
@@ -1215,15 +1219,15 @@ def main() -> int:
                 del keep
             # round 3: the same filter at the range sigma people use it with (the BASELINE's sigmaR = 2 is a gentle table; the filter's
             # default is 0.02, a steep one) and at the filter's default spatial sigma (3: luma radius 5, three tap distances)
-            for name, (ss, sr) in {"bilateral_1080p_sigmaR0p02": (2, 0.02), "bilateral_1080p_defaults": (3, 0.02)}.items():
-                st, keep = setup_bilateral(dev, W1080, H1080, 64, ss, sr)
+            for name, (ss, sr, b8) in {"bilateral_1080p_sigmaR0p02": (2, 0.02, False), "bilateral_1080p_defaults": (3, 0.02, False), "bilateral_1080p_yuv420p8": (2, 2, True)}.items():
+                st, keep = setup_bilateral(dev, W1080, H1080, 64, ss, sr, b8)
                 dt2, kms, _, _ = timed.run(st, 10, 2)
-                fb2 = sum(2 * s_[0] * s_[1] for s_ in yuv420_shapes(W1080, H1080))
+                fb2 = sum((1 if b8 else 2) * s_[0] * s_[1] for s_ in yuv420_shapes(W1080, H1080))
                 gb = 2 * fb2 * 64 * 10 / dt2 / 1e9
                 others[name] = {"value": 64 * 10 / dt2, "unit": "frames/s", "frames_per_call": 64,
                                 "roofline": {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
                                              "note": "whole call; the range table's computed part (up to the reference's `upper` cut) held as it is in LDS (DESIGN.md 3.3, PLATEAU form)"},
-                                "workload": f"vszip.Bilateral sigmaS={ss} sigmaR={sr} 1920x1080 YUV420P16 (natural content tiled), 64 frames per call, HBM-resident"}
+                                "workload": f"vszip.Bilateral sigmaS={ss} sigmaR={sr} 1920x1080 {'YUV420P8' if b8 else 'YUV420P16'} (natural content tiled), 64 frames per call, HBM-resident"}
                 del keep
             st, keep = setup_ssimulacra2(dev, W4K, H4K, 16)
             dt3, kms, _, _ = timed.run(st, 5, 1)
@@ -1285,7 +1289,7 @@ def main() -> int:
             out["others"] = others
             # the metric string's other two filters (and EEDI3) as scalars, so that they survive into the driver's record
             for key, leg in (("bilateral_1080p_fps", "bilateral_1080p"), ("bilateral_4k_fps", "bilateral_4k"), ("ssimulacra2_4k_pairs_s", "ssimulacra2_4k"),
-                             ("bilateral_1080p_sigmaR0p02_fps", "bilateral_1080p_sigmaR0p02"), ("bilateral_1080p_defaults_fps", "bilateral_1080p_defaults"), ("ssimulacra2_4k_yuv420p8_pairs_s", "ssimulacra2_4k_yuv420p8"), ("eedi3_1080p_fps", "eedi3_1080p"), ("xpsnr_1080p_fps", "xpsnr_1080p"),
+                             ("bilateral_1080p_sigmaR0p02_fps", "bilateral_1080p_sigmaR0p02"), ("bilateral_1080p_defaults_fps", "bilateral_1080p_defaults"), ("bilateral_1080p_yuv420p8_fps", "bilateral_1080p_yuv420p8"), ("ssimulacra2_4k_yuv420p8_pairs_s", "ssimulacra2_4k_yuv420p8"), ("eedi3_1080p_fps", "eedi3_1080p"), ("xpsnr_1080p_fps", "xpsnr_1080p"),
                              ("boxblur_1080p_fps", "boxblur_1080p"), ("boxblur_1080p_5pass_fps", "boxblur_1080p_5pass"), ("pipeline_8k_fps", "pipeline_8k_rgbs"),
                              ("plugin_ssimulacra2_4k_yuv420p8_pairs_s", "plugin_ssimulacra2_4k_yuv420p8"), ("plugin_ssimulacra2_4k_rgb24_pairs_s", "plugin_ssimulacra2_4k_rgb24")):
                 v = others.get(leg, {}).get("value")

@@ -151,7 +151,7 @@ def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
         assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (dtype, sig, shape, joint)
 
 
-@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize("sig", [(2, 2), (1, 2), (2, 1.0), (2, 0.3), (2, 0.02), (1, 0.05), (2, 0.0625), (2, 0.004)])
 @pytest.mark.parametrize("content", ["natural", "noise", "edges"])
 def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
@@ -159,7 +159,7 @@ def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
     column-walking kernel — each pixel looks up only its 8 downward taps and receives the 8 upward ones from the pixels above
     (the range weight is symmetric), neighbours cross lanes with DPP shifts. Both of its table forms (FINE: 4-entry blocks with
     u8 deltas, for gentle tables such as sigmaR = 2; COARSE: the LDS16 form; PLATEAU: the computed part of a STEEP table as it is —
-    sigmaR <= 0.0625, the filter's usual range, default 0.02) against the tile kernel and the oracle, byte for
+    sigmaR <= 0.0625, the filter's usual range, default 0.02 — and the whole table of 8-bit clips) against the tile kernel and the oracle, byte for
     byte: natural content, full-range white noise (every table entry, every weight handed down differs) and hard edges;
     strips narrower / wider than a wave's 58 / 60 output columns, bands that end inside a ring period, planes barely
     larger than the taps."""
@@ -170,7 +170,7 @@ def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
         elif content == "noise":
             src = fx.splitmix64_plane(5 + shape[0], shape, dtype)
         else:
-            src = np.where((np.add.outer(np.arange(shape[0]) // 5, np.arange(shape[1]) // 7) & 1) == 0, 0, 65535 if dtype == np.uint16 else 1).astype(dtype)
+            src = np.where((np.add.outer(np.arange(shape[0]) // 5, np.arange(shape[1]) // 7) & 1) == 0, 0, {np.uint8: 255, np.uint16: 65535}.get(dtype, 1)).astype(dtype)
         (a,), cfgs = _gpu(dev, [src], sS, sR, algorithm=[2])
         c = cfgs[0]
         if min(shape) <= 2 * c[3]:

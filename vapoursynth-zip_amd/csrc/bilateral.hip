@@ -492,8 +492,8 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     constexpr int C = (P - CR + R) % R;
     const float c = st.sc[C];
     auto lut = [&](float n) {
-        if constexpr (std::is_same<T, uint16_t>::value)
-            return tab.at((uint32_t)fabsf(c - n), upper);  // |c - n|: exact in f32 for 16-bit samples
+        if constexpr (!std::is_same<T, float>::value)
+            return tab.at((uint32_t)fabsf(c - n), upper);  // |c - n|: exact in f32 for 8- / 16-bit samples
         else
             return tab.at((uint32_t)truncf(fminf(1.0f, fabsf(c - n)) * 65535.0f + 0.5f), upper);  // bilateral.zig:15-22 (|c - n| == |n - c|: the same entry both ways)
     };
@@ -521,8 +521,8 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     // No branch anywhere in a step (a period of R steps is ONE basic block: the scheduler may start a step's loads and table
     // reads under the previous step's arithmetic): rows and lanes that produce no output store to a dummy line instead.
     const float q = __fdiv_rn(sum, wsum);
-    if constexpr (std::is_same<T, uint16_t>::value)
-        *dstp = (uint16_t)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
+    if constexpr (!std::is_same<T, float>::value)
+        *dstp = (T)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));  // finalize :30-36
     else
         *dstp = q;
 }
@@ -537,8 +537,8 @@ __device__ __forceinline__ void walk_period(WalkState<CR, CS> &st, const WalkLut
      ...);
 }
 
-// (T last: 16-bit integer samples, or — round 3, the 8K RGBS pipeline's Bilateral stage — f32 samples: the same walk, the table index
-// and the finish of the float path)
+// (T last: 8- / 16-bit integer samples — 8-bit clips and 10- / 12-bit ones in 16-bit containers through the PLATEAU form, their whole table —
+// or, the 8K RGBS pipeline's Bilateral stage, f32 samples: the same walk, the table index and the finish of the float path)
 template <int CR, int CS, int FINE, typename T = uint16_t>
 __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams prm, const int nstrips, int *__restrict__ next_strip) {
     using W = WalkState<CR, CS>;
@@ -1118,7 +1118,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
         pl.exact.erase(d);
         pl.fine.erase(d);
         pl.plateau.erase(d);
-        if (hist_len == 65536 && upper + 1 <= (uint32_t)kWalkPlateauMax) {
+        if (hist_len % 4 == 0 && upper + 1 <= (uint32_t)kWalkPlateauMax) {  // (8- / 10- / 12-bit clips: the whole table is that short)
             uint64_t key;
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
             pl.plateau[d] = {key, upper};
@@ -1226,7 +1226,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         }
         // Steep tables (the filter's usual sigmaR) with the BASELINE's tap shapes: the walk kernel with the table's computed part in LDS
         // (PLATEAU form), one launch per distinct (table, taps)
-        if (!lds16 && tiled && !joint && (dtype == VSZIP_U16 || dtype == VSZIP_F32) && prm.lut_len == 65536 && !getenv("VSZIP_BILATERAL_NO_WALK")) {
+        if (!lds16 && tiled && !joint && (dtype == VSZIP_U8 || dtype == VSZIP_U16 || dtype == VSZIP_F32) && !getenv("VSZIP_BILATERAL_NO_WALK")) {
             struct PKey {
                 uint64_t table;
                 uint32_t upper;
@@ -1251,9 +1251,9 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 for (int i = 0; i < n; ++i)
                     if (walk[i] && keys[i] == g) q.p[q.nplanes++] = prm.p[i];
                 if (g.radius == 3)
-                    rc = dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, 2) : launch_walk16<3, 2, float>(ctx, q, 2);
+                    rc = dtype == VSZIP_U8 ? launch_walk16<3, 2, uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, 2) : launch_walk16<3, 2, float>(ctx, q, 2));
                 else
-                    rc = dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, 2) : launch_walk16<2, 1, float>(ctx, q, 2);
+                    rc = dtype == VSZIP_U8 ? launch_walk16<2, 1, uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, 2) : launch_walk16<2, 1, float>(ctx, q, 2));
                 if (rc != VSZIP_OK) return rc;
             }
             // planes with other tap shapes (sigmaS = 1's chroma: radius 1; sigmaS = 3's luma: radius 5) stay with the tile kernel below
