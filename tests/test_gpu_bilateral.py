@@ -152,7 +152,7 @@ def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
-@pytest.mark.parametrize("sig", [(2, 2), (1, 2), (2, 1.0), (2, 0.3), (2, 0.02), (1, 0.05), (2, 0.0625), (2, 0.004)])
+@pytest.mark.parametrize("sig", [(2, 2), (1, 2), (2, 1.0), (2, 0.3), (2, 0.02), (1, 0.05), (2, 0.0625), (2, 0.004), (3, 0.02), (3, 2), (3, 1.0)])
 @pytest.mark.parametrize("content", ["natural", "noise", "edges"])
 def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
     """Round 3: 16-bit clips without `ref` whose taps are the BASELINE's (radius 3 / step 2, radius 2 / step 1) take the
@@ -161,7 +161,8 @@ def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
     u8 deltas, for gentle tables such as sigmaR = 2; COARSE: the LDS16 form; PLATEAU: the computed part of a STEEP table as it is —
     sigmaR <= 0.0625, the filter's usual range, default 0.02 — and the whole table of 8-bit clips) against the tile kernel and the oracle, byte for
     byte: natural content, full-range white noise (every table entry, every weight handed down differs) and hard edges;
-    strips narrower / wider than a wave's 58 / 60 output columns, bands that end inside a ring period, planes barely
+    the filter's default sigmaS = 3 (radius 5, step 2: three tap distances, bilateral_walk36_kernel) in all three table forms;
+    strips narrower / wider than a wave's 54 / 58 / 60 output columns, bands that end inside a ring period, planes barely
     larger than the taps."""
     sS, sR = sig
     for shape in [(120, 200), (67, 131), (7, 9), (230, 58), (109, 117), (8, 64)]:
@@ -171,10 +172,14 @@ def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
             src = fx.splitmix64_plane(5 + shape[0], shape, dtype)
         else:
             src = np.where((np.add.outer(np.arange(shape[0]) // 5, np.arange(shape[1]) // 7) & 1) == 0, 0, {np.uint8: 255, np.uint16: 65535}.get(dtype, 1)).astype(dtype)
-        (a,), cfgs = _gpu(dev, [src], sS, sR, algorithm=[2])
+        import vszip_amd
+
+        try:
+            (a,), cfgs = _gpu(dev, [src], sS, sR, algorithm=[2])
+        except vszip_amd.VszipError as e:
+            assert "plane too small" in str(e)  # planes not larger than the taps are rejected (bilateral.zig(vs):206-209)
+            continue
         c = cfgs[0]
-        if min(shape) <= 2 * c[3]:
-            continue  # the wrapper rejects planes not larger than the taps
         monkeypatch.setenv("VSZIP_BILATERAL_NO_FINE", "1")
         (b,), _ = _gpu(dev, [src], sS, sR, algorithm=[2])
         monkeypatch.delenv("VSZIP_BILATERAL_NO_FINE")

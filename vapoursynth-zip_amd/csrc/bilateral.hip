@@ -598,6 +598,177 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same walk for the filter's DEFAULT spatial sigma (sigmaS = 3: radius 5, step 2 — tap distances 1, 3, 5, nine (yy, xx) sets, 36
+// taps of which a pixel looks up 18): bilateral_walk36_kernel. The third distance rides beside the packed pair as a scalar; rings of 15
+// rows (a multiple of all three distances, >= 2 * 5 + 1); 512-thread workgroups — the state is about 200 registers.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ float walk_shr(float v) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v = walk_shr1(v);
+    return v;
+}
+template <int N>
+__device__ __forceinline__ float walk_shl(float v) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v = walk_shl1(v);
+    return v;
+}
+struct Walk3State {
+    static constexpr int CR = 5, T0 = 1, T1 = 3, T2 = 5, R = 15;
+    float sc[R];
+    v2f sl[R], sr[R];   // {x -+ 1, x -+ 3}
+    float slz[R], srz[R];  // x -+ 5
+    v2f ha0[T0], hb0[T0], ha1[T1], hb1[T1], ha2[T2], hb2[T2];
+    float haz0[T0], hbz0[T0], haz1[T1], hbz1[T1], haz2[T2], hbz2[T2];
+};
+
+template <int P, int FORM, typename T>
+__device__ __forceinline__ void walk3_step(Walk3State &st, const WalkLut<FORM> &tab, const uint32_t upper, const v2f (&sw)[3], const float (&swz)[3], float w0, float peak,
+                                            T &pend, const T *__restrict__ nextp, T *__restrict__ dstp) {
+    using W = Walk3State;
+    constexpr int R = W::R, CR = W::CR, T0 = W::T0, T1 = W::T1, T2 = W::T2;
+    const float v = (float)pend;
+    st.sc[P] = v;
+    {
+        const float l1 = walk_shr1(v), l3 = walk_shr<2>(l1), r1 = walk_shl1(v), r3 = walk_shl<2>(r1);
+        st.sl[P] = v2f{l1, l3};
+        st.sr[P] = v2f{r1, r3};
+        st.slz[P] = walk_shr<2>(l3);
+        st.srz[P] = walk_shl<2>(r3);
+    }
+    pend = *nextp;
+    constexpr int C = (P - CR + R) % R;
+    const float c = st.sc[C];
+    auto lut = [&](float n) {
+        if constexpr (!std::is_same<T, float>::value)
+            return tab.at((uint32_t)fabsf(c - n), upper);
+        else
+            return tab.at((uint32_t)truncf(fminf(1.0f, fabsf(c - n)) * 65535.0f + 0.5f), upper);
+    };
+    float wsum = w0, sum = c * w0;
+    // one yy: the three xx sets in the reference's order (1, 3, 5); handed-down weights as in walk_step
+    auto sets = [&](const v2f swv, const float swq, const v2f n1, const v2f n2, const v2f n3, const v2f n4, const float n1z, const float n2z, const float n3z, const float n4z, v2f &ha,
+                    v2f &hb, float &haz, float &hbz) {
+        const v2f rw2 = {lut(n2.x), lut(n2.y)}, rw4 = {lut(n4.x), lut(n4.y)};
+        const float rw2z = lut(n2z), rw4z = lut(n4z);
+        const v2f rw1 = hb, rw3 = ha;
+        const float rw1z = hbz, rw3z = haz;
+        ha = v2f{walk_shr1(rw2.x), walk_shr<T1>(rw2.y)};
+        hb = v2f{walk_shl1(rw4.x), walk_shl<T1>(rw4.y)};
+        haz = walk_shr<T2>(rw2z);
+        hbz = walk_shl<T2>(rw4z);
+        const v2f wi = swv * (rw1 + rw2 + rw3 + rw4);
+        const v2f si = swv * (n1 * rw1 + n2 * rw2 + n3 * rw3 + n4 * rw4);
+        const float wiz = swq * (rw1z + rw2z + rw3z + rw4z);
+        const float siz = swq * (n1z * rw1z + n2z * rw2z + n3z * rw3z + n4z * rw4z);
+        wsum += wi.x;
+        sum += si.x;
+        wsum += wi.y;
+        sum += si.y;
+        wsum += wiz;
+        sum += siz;
+    };
+    {
+        constexpr int up = (C - T0 + R) % R, dn = (C + T0) % R, sl = P % T0;
+        sets(sw[0], swz[0], st.sr[up], st.sr[dn], st.sl[up], st.sl[dn], st.srz[up], st.srz[dn], st.slz[up], st.slz[dn], st.ha0[sl], st.hb0[sl], st.haz0[sl], st.hbz0[sl]);
+    }
+    {
+        constexpr int up = (C - T1 + R) % R, dn = (C + T1) % R, sl = P % T1;
+        sets(sw[1], swz[1], st.sr[up], st.sr[dn], st.sl[up], st.sl[dn], st.srz[up], st.srz[dn], st.slz[up], st.slz[dn], st.ha1[sl], st.hb1[sl], st.haz1[sl], st.hbz1[sl]);
+    }
+    {
+        constexpr int up = (C - T2 + R) % R, dn = (C + T2) % R, sl = P % T2;
+        sets(sw[2], swz[2], st.sr[up], st.sr[dn], st.sl[up], st.sl[dn], st.srz[up], st.srz[dn], st.slz[up], st.slz[dn], st.ha2[sl], st.hb2[sl], st.haz2[sl], st.hbz2[sl]);
+    }
+    const float q = __fdiv_rn(sum, wsum);
+    if constexpr (!std::is_same<T, float>::value)
+        *dstp = (T)truncf(fminf(fmaxf(q + 0.5f, 0.0f), peak));
+    else
+        *dstp = q;
+}
+
+template <int FORM, typename T, int... P>
+__device__ __forceinline__ void walk3_period(Walk3State &st, const WalkLut<FORM> &tab, const uint32_t upper, const v2f (&sw)[3], const float (&swz)[3], float w0, float peak, T &pend,
+                                              const T *__restrict__ colp, int rstride, int h, int ys, int t0, int y0, int y1, bool lane_out, T *__restrict__ dcol, int dstride,
+                                              T *__restrict__ dummy, std::integer_sequence<int, P...>) {
+    constexpr int CR = Walk3State::CR;
+    (walk3_step<P, FORM, T>(st, tab, upper, sw, swz, w0, peak, pend, colp + (size_t)min(max(ys + t0 + P + 1, 0), h - 1) * rstride,
+                            (lane_out && ys + t0 + P - CR >= y0 && ys + t0 + P - CR < y1) ? dcol + (size_t)(ys + t0 + P - CR) * dstride : dummy),
+     ...);
+}
+
+template <int FORM, typename T>
+__global__ __launch_bounds__(512) void bilateral_walk36_kernel(const BLParams prm, const int nstrips, int *__restrict__ next_strip) {
+    using W = Walk3State;
+    constexpr int CR = W::CR;
+    __shared__ __attribute__((aligned(16))) WalkLut<FORM> slut;
+    const int tid = (int)threadIdx.x;
+    const uint32_t upper = (uint32_t)prm.lut_upper;
+    if constexpr (FORM == 2) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr);
+        for (int i = tid; i < ((int)upper + 4) / 4; i += 512) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
+    } else {
+        const uint4 *g = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(prm.p[0].gr + 65536) + (FORM ? kL16LutBytes : 0));
+        for (int i = tid; i < (int)(sizeof(WalkLut<FORM>) / 16); i += 512) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    constexpr int WOUT = 64 - 2 * CR;
+    auto grab = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_strip, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    T *dummy = reinterpret_cast<T *>(next_strip + 64) + lane;
+    int pi = 0;
+#pragma unroll 1
+    for (int sidx = grab(); sidx < nstrips; sidx = grab()) {
+        while (pi + 1 < prm.nplanes && sidx >= prm.p[pi + 1].block0) ++pi;
+        const BLPlane &pl = prm.p[pi];
+        const float *gs = pl.gs;
+        constexpr int G = CR + 1;
+        const v2f sw[3] = {{gs[1 * G + 1], gs[1 * G + 3]}, {gs[3 * G + 1], gs[3 * G + 3]}, {gs[5 * G + 1], gs[5 * G + 3]}};
+        const float swz[3] = {gs[1 * G + 5], gs[3 * G + 5], gs[5 * G + 5]};
+        const float w0 = gs[0] * slut.at(0, upper);
+        const int ls = sidx - pl.block0;
+        const int X0 = (ls % pl.nbx) * WOUT, y0 = (ls / pl.nbx) * kWalkBand, y1 = min(y0 + kWalkBand, pl.h);
+        const int col = X0 - CR + lane;
+        const T *colp = static_cast<const T *>(pl.src) + min(max(col, 0), pl.w - 1);
+        T *dcol = static_cast<T *>(pl.dst) + min(max(col, 0), pl.w - 1);
+        const bool lane_out = lane >= CR && lane < 64 - CR && col < pl.w;
+        W st;
+#pragma unroll
+        for (int b = 0; b < W::R; ++b) {
+            st.sc[b] = 0.0f;
+            st.sl[b] = st.sr[b] = v2f{0.0f, 0.0f};
+            st.slz[b] = st.srz[b] = 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < W::T0; ++b) {
+            st.ha0[b] = st.hb0[b] = v2f{0.0f, 0.0f};
+            st.haz0[b] = st.hbz0[b] = 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < W::T1; ++b) {
+            st.ha1[b] = st.hb1[b] = v2f{0.0f, 0.0f};
+            st.haz1[b] = st.hbz1[b] = 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < W::T2; ++b) {
+            st.ha2[b] = st.hb2[b] = v2f{0.0f, 0.0f};
+            st.haz2[b] = st.hbz2[b] = 0.0f;
+        }
+        const int ys = y0 - 2 * CR;
+        T pend = colp[(size_t)min(max(ys, 0), pl.h - 1) * pl.sstride];
+        const int steps = (y1 - y0) + 3 * CR;
+#pragma unroll 1
+        for (int t0 = 0; t0 < steps; t0 += W::R)
+            walk3_period<FORM, T>(st, slut, upper, sw, swz, w0, prm.peak, pend, colp, pl.sstride, pl.h, ys, t0, y0, y1, lane_out, dcol, pl.dstride, dummy, std::make_integer_sequence<int, W::R>{});
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBX *kBY) void bilateral_truncated_kernel(const BLParams prm) {
     using S = BSmp<T>;
@@ -992,6 +1163,33 @@ int launch_walk16(vszip_ctx *ctx, BLParams prm, int form) {  // form: 0 COARSE, 
     return VSZIP_OK;
 }
 
+// ... and the three-distance walk (radius 5, step 2): 54 output columns per wave, 8 waves per workgroup
+template <typename T>
+int launch_walk36(vszip_ctx *ctx, BLParams prm, int form) {
+    constexpr int CR = 5;
+    int strips = 0;
+    for (int i = 0; i < prm.nplanes; ++i) {
+        BLPlane &p = prm.p[i];
+        p.block0 = strips;
+        p.nbx = (p.w + (64 - 2 * CR) - 1) / (64 - 2 * CR);
+        strips += p.nbx * ((p.h + kWalkBand - 1) / kWalkBand);
+    }
+    const int grid = std::min((strips + 7) / 8, 256);
+    int rcs = vszip_ensure_scratch(ctx, 512);
+    if (rcs != VSZIP_OK) return rcs;
+    int *counter = static_cast<int *>(ctx->scratch);
+    VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    vszip_probe_scope probe(ctx);
+    if (form == 2)
+        hipLaunchKernelGGL((bilateral_walk36_kernel<2, T>), dim3(grid), dim3(512), 0, ctx->stream, prm, strips, counter);
+    else if (form == 1)
+        hipLaunchKernelGGL((bilateral_walk36_kernel<1, T>), dim3(grid), dim3(512), 0, ctx->stream, prm, strips, counter);
+    else
+        hipLaunchKernelGGL((bilateral_walk36_kernel<0, T>), dim3(grid), dim3(512), 0, ctx->stream, prm, strips, counter);
+    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+    return VSZIP_OK;
+}
+
 template <typename T>
 int launch_truncated(vszip_ctx *ctx, const BLParams &prm, int blocks, bool tiled, bool joint, int max_radius) {
     {
@@ -1238,7 +1436,8 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             for (int i = 0; i < n; ++i) {
                 keys[i].radius = prm.p[i].radius;
                 keys[i].step = prm.p[i].step;
-                walk[i] = lut_plateau(prm.p[i].gr, &keys[i].table, &keys[i].upper) && ((keys[i].radius == 3 && keys[i].step == 2) || (keys[i].radius == 2 && keys[i].step == 1));
+                walk[i] = lut_plateau(prm.p[i].gr, &keys[i].table, &keys[i].upper) &&
+                          ((keys[i].radius == 3 && keys[i].step == 2) || (keys[i].radius == 2 && keys[i].step == 1) || (keys[i].radius == 5 && keys[i].step == 2 && !getenv("VSZIP_BILATERAL_NO_WALK36")));
                 if (walk[i] && std::find(groups.begin(), groups.end(), keys[i]) == groups.end()) groups.push_back(keys[i]);
             }
             for (const PKey &g : groups) {
@@ -1250,7 +1449,9 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 q.nplanes = 0;
                 for (int i = 0; i < n; ++i)
                     if (walk[i] && keys[i] == g) q.p[q.nplanes++] = prm.p[i];
-                if (g.radius == 3)
+                if (g.radius == 5)
+                    rc = dtype == VSZIP_U8 ? launch_walk36<uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk36<uint16_t>(ctx, q, 2) : launch_walk36<float>(ctx, q, 2));
+                else if (g.radius == 3)
                     rc = dtype == VSZIP_U8 ? launch_walk16<3, 2, uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, 2) : launch_walk16<3, 2, float>(ctx, q, 2));
                 else
                     rc = dtype == VSZIP_U8 ? launch_walk16<2, 1, uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, 2) : launch_walk16<2, 1, float>(ctx, q, 2));
@@ -1360,6 +1561,11 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     }
                     if (r == 2 && st == 1) {
                         rc = dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, fine ? 1 : 0) : launch_walk16<2, 1, float>(ctx, q, fine ? 1 : 0);
+                        if (rc != VSZIP_OK) return rc;
+                        continue;
+                    }
+                    if (r == 5 && st == 2 && !getenv("VSZIP_BILATERAL_NO_WALK36")) {  // sigmaS = 3, the filter's default
+                        rc = dtype == VSZIP_U16 ? launch_walk36<uint16_t>(ctx, q, fine ? 1 : 0) : launch_walk36<float>(ctx, q, fine ? 1 : 0);
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
