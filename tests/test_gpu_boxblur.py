@@ -244,3 +244,45 @@ def test_rt_fused_multipass_equals_per_pass(dev, oracle, dtype, monkeypatch):
             want = oracle.boxblur(p, *args)
             assert np.array_equal(b, want), (shapes, args, int((b != want).sum()))
             assert np.array_equal(a, want)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
+    """Round 3: BoxBlur(hradius <= 8, hpasses >= 2) — how scripts approximate a Gaussian — runs ALL horizontal passes in one launch (a wave keeps
+    its row in LDS: boxblur_rt_hsmall_kernel) and two vertical passes in one launch as well (a chain of stages with LDS rings, the plane's first
+    rows run first for the stages' E_0 constants: boxblur_rt_vsmall_kernel; three and four stages with VSZIP_RT_VSMALL_MAX). Against the oracle
+    and the one-launch-per-pass kernels, bit for bit: every radius 1 .. 8, widths that are not whole 8-sample groups, planes barely taller
+    than the chain's reach, bands that start at the top / inside it / below it, the bottom rows' mirrored windows."""
+    cases = [([(72, 208), (36, 104), (36, 104)], (1, 2, 1, 2)), ([(300, 333)], (2, 3, 2, 2)), ([(64, 4096)], (3, 4, 0, 0)), ([(700, 96)], (0, 0, 4, 2)),
+             ([(135, 251), (67, 125)], (5, 2, 6, 2)), ([(533, 130)], (7, 3, 8, 2)), ([(40, 35), (35, 40)], (8, 2, 8, 2)), ([(290, 640)], (1, 4, 1, 2)),
+             ([(19, 40)], (2, 2, 2, 2)), ([(1080, 520)], (2, 2, 3, 2))]
+    for shapes, args in cases:
+        planes = [fx.splitmix64_plane(11 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
+
+        def run():
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+            dev.boxblur(srcs, dsts, *args)
+            return [dev.download(d) for d in dsts]
+
+        got = run()
+        monkeypatch.setenv("VSZIP_RT_NO_HSMALL", "1")
+        monkeypatch.setenv("VSZIP_RT_NO_VSMALL", "1")
+        per_pass = run()
+        monkeypatch.delenv("VSZIP_RT_NO_HSMALL")
+        monkeypatch.delenv("VSZIP_RT_NO_VSMALL")
+        for p, a, b in zip(planes, got, per_pass):
+            want = oracle.boxblur(p, *args)
+            assert np.array_equal(a, want), (shapes, args, int((a != want).sum()))
+            assert np.array_equal(b, want), (shapes, args, "per pass")
+    # three and four vertical stages (not the default: measured slower than a launch per pass)
+    monkeypatch.setenv("VSZIP_RT_VSMALL_MAX", "4")
+    for shapes, args in [([(300, 333)], (2, 2, 2, 3)), ([(521, 96), (260, 48)], (0, 0, 3, 4)), ([(70, 520)], (1, 2, 1, 4)), ([(1080, 512)], (0, 0, 2, 3))]:
+        planes = [fx.splitmix64_plane(17 + i, sh, dtype) for i, sh in enumerate(shapes)]
+        srcs = [dev.upload(p) for p in planes]
+        dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+        dev.boxblur(srcs, dsts, *args)
+        for p, d in zip(planes, dsts):
+            want = oracle.boxblur(p, *args)
+            got = dev.download(d)
+            assert np.array_equal(got, want), (shapes, args, int((got != want).sum()))

@@ -175,6 +175,30 @@ struct RtVec {
                 if (k < n) p[k] = (T)v[k];
         }
     }
+    // eight values (hsmall: a lane's group of eight samples, for 8-bit clips half a 16-byte vector)
+    static __device__ __forceinline__ void store8(T *p, const uint32_t v[8], int n, int keep = 0) {
+        if (n >= 8) {
+            if constexpr (sizeof(T) == 2) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 q = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+                if (keep)
+                    *reinterpret_cast<u32x4 *>(p) = q;
+                else
+                    __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(p));
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 q = {v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24), v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24)};
+                if (keep)
+                    *reinterpret_cast<u32x2 *>(p) = q;
+                else
+                    __builtin_nontemporal_store(q, reinterpret_cast<u32x2 *>(p));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < n) p[k] = (T)v[k];
+        }
+    }
 };
 
 struct RVParams {
@@ -792,6 +816,270 @@ __global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams 
 }
 
 // 64 x 64 tiles through LDS: dst[x][y] = src[y][x] (integer planes; the vertical passes of the fused path)
+// ---------------------------------------------------------------------------------------------
+// Several HORIZONTAL passes of a SMALL radius in one launch (round 3): BoxBlur(hradius = 1..8, hpasses >= 2) is how scripts approximate a
+// Gaussian, and each pass used to be a kernel of its own — the same ~100 us per 8 4K frames whatever the radius. One wave owns a row, keeps it
+// in LDS as u16 (two buffers, ping-pong, R mirrored samples on either side so that every window is the same sum) and runs the passes on it:
+// a lane takes 8 adjacent samples at a time (three 16-byte LDS reads: the vector and its neighbours), sums the first window directly and
+// slides it — blurInt's closed form (:10-41, see RtVec above): dst[x] = (inv2 * E_x + 32768 + ((E_0 * invlo) >> 16)) >> 16 with E_0 read from
+// the row's first R + 1 samples of the pass's own input, which are right there. One read and one write of the plane for all passes.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHsMaxR = 8, kHsMaxW = 8192;
+template <typename T, int R>
+__global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm, const int npass, const int pitch /* u16 elements per LDS buffer */) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hs[];
+    const int b = blockIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int y = b - pl.block0, w = pl.w, lane = (int)threadIdx.x;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y * pl.dstride;
+    constexpr uint32_t ksize = 2u * R + 1u;
+    constexpr uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+    constexpr uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
+    const int nv = (w + 7) / 8;  // 8-sample groups of the row; sample x lives at element 8 + x of a buffer
+    // stage the row (u16 in LDS whatever the clip's sample size)
+    for (int v = lane; v < nv; v += 64) {
+        const int x0 = 8 * v;
+        uint32_t e[8];
+        if (x0 + 8 <= w) {
+            if constexpr (sizeof(T) == 2) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(s + x0);
+                *reinterpret_cast<uint4 *>(hs + 8 + x0) = q;
+                continue;
+            } else {
+                const uint2 q = *reinterpret_cast<const uint2 *>(s + x0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = ((k < 4 ? q.x : q.y) >> (8 * (k & 3))) & 0xffu;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = x0 + k < w ? (uint32_t)s[x0 + k] : 0u;
+        }
+        uint4 o;
+        o.x = e[0] | (e[1] << 16);
+        o.y = e[2] | (e[3] << 16);
+        o.z = e[4] | (e[5] << 16);
+        o.w = e[6] | (e[7] << 16);
+        *reinterpret_cast<uint4 *>(hs + 8 + x0) = o;
+    }
+    vszip_wave_fence();
+    uint16_t *cur = hs, *nxt = hs + pitch;
+    for (int pass = 0; pass < npass; ++pass) {
+        // blurInt's implicit padding: -k -> k - 1, w - 1 + k -> w - k
+        if (lane < R) {
+            cur[8 - 1 - lane] = cur[8 + min(lane, w - 1)];
+            cur[8 + w + lane] = cur[8 + max(w - 1 - lane, 0)];
+        }
+        vszip_wave_fence();
+        uint32_t e0 = cur[8 + min(R, w - 1)];
+#pragma unroll
+        for (int i = 0; i < R; ++i) e0 += 2u * cur[8 + min(i, w - 1)];
+        const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
+        const bool last = pass == npass - 1;
+        for (int v = lane; v < nv; v += 64) {
+            const int x0 = 8 * v;
+            const uint4 qa = *reinterpret_cast<const uint4 *>(cur + x0), qb = *reinterpret_cast<const uint4 *>(cur + 8 + x0), qc = *reinterpret_cast<const uint4 *>(cur + 16 + x0);
+            uint32_t t[24];
+            const uint32_t dw[12] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+            for (int k = 0; k < 24; ++k) t[k] = (dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;  // t[8 + i] = sample x0 + i
+            uint32_t e = 0, o[8];
+#pragma unroll
+            for (int k = -R; k <= R; ++k) e += t[8 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                o[k] = (__umul24(e, inv2) + kr) >> 16;  // (e < 2^21 here: the 24-bit multiply is exact, the 16.16 value fits 32 bits)
+                if (k < 7) e += t[8 + k + 1 + R] - t[8 + k - R];
+            }
+            if (!last) {
+                uint4 q;
+                q.x = o[0] | (o[1] << 16);
+                q.y = o[2] | (o[3] << 16);
+                q.z = o[4] | (o[5] << 16);
+                q.w = o[6] | (o[7] << 16);
+                *reinterpret_cast<uint4 *>(nxt + 8 + x0) = q;
+            } else {
+                RtVec<T>::store8(d + x0, o, min(8, w - x0), prm.keep);
+            }
+        }
+        vszip_wave_fence();
+        uint16_t *sw = cur;
+        cur = nxt;
+        nxt = sw;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ... and several VERTICAL passes of a small radius in one launch: boxblur_rt_vsmall_kernel<T, P>. A wave owns 64 x 8 columns and a band of
+// output rows and pushes every input row through a chain of P stages; stage k keeps the last 2R + 2 rows of ITS input in an LDS ring (lane-
+// private: no barrier), slides its window sum and hands each output row straight to stage k + 1 — the last stage stores. Every stage is
+// blurInt's closed form on a column (see RtVec above): E_0 = s[R] + 2 * sum_{i<R} s[i] at the top, then E += entering - leaving, rows beyond
+// the plane mirrored (-k -> k - 1, len - 1 + k -> len - k) out of the ring; dst[i] = (inv2 * E_i + 32768 + ((E_0 * invlo) >> 16)) >> 16, the
+// E_0 of a stage being that of ITS input's first rows. A band that does not start at the top first runs the plane's first P * R + 1 rows
+// through the chain for those constants, then warms the windows up from P * R rows above its first output row.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int P>
+struct VsCtx {
+    uint32_t e[P][8], kk[P][8];
+    int cnt[P], pos[P];  // rows received; ring slot of the newest row (-1: none yet)
+    uint4 *ring;  // LDS, this lane's column of [stage][slot][lane]
+    T *d;
+    size_t ds;
+    int R, D, len, y0, y1, nst, keep;
+    uint32_t inv2, invlo;
+    bool top;        // the chain runs from the plane's first row (E_0 sums, constants computed on the way)
+    bool store_on;   // the last stage's rows go to memory
+};
+__device__ __forceinline__ void vs_unpack(const uint4 q, uint32_t v[8]) {
+    const uint32_t dw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (dw[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+}
+__device__ __forceinline__ uint4 vs_pack(const uint32_t v[8]) { return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)); }
+
+// a row of stage K's input arrives (rows arrive in order; r = its index): compile-time recursion down the chain
+template <typename T, int P, int K>
+__device__ __forceinline__ void vs_feed(VsCtx<T, P> &c, const uint32_t (&x)[8], const int r) {
+    const uint4 q = vs_pack(x);
+    const int R = c.R, D = c.D, len = c.len;
+    auto slot = [&](int row) -> uint4 & { return c.ring[((size_t)K * D + (row % D)) * 64]; };  // (a division: only for the mirrored rows at the plane's ends)
+    // rows arrive in order: the newest row's slot advances by one, and the slot after it holds the row 2R + 1 older — the one that leaves
+    int ps = c.pos[K] < 0 ? r % D : (c.pos[K] + 1 == D ? 0 : c.pos[K] + 1);
+    c.pos[K] = ps;
+    c.ring[((size_t)K * D + ps) * 64] = q;
+    const int pl = ps + 1 == D ? 0 : ps + 1;
+    const int cnt = ++c.cnt[K];
+    const int need = c.top ? R + 1 : 2 * R + 1;
+    if (cnt <= need) {
+        const uint32_t wgt = (c.top && cnt <= R) ? 2u : 1u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c.e[K][i] += wgt * x[i];
+        if (cnt < need) return;
+        if (c.top) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c.kk[K][i] = 32768u + (uint32_t)(((uint64_t)c.e[K][i] * c.invlo) >> 16);
+        }
+    } else {
+        const int lr = r - 2 * R - 1;  // the row that leaves the window (mirrored at the top)
+        uint32_t l[8];
+        vs_unpack(lr < 0 ? slot(-lr - 1) : c.ring[((size_t)K * D + pl) * 64], l);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c.e[K][i] += x[i] - l[i];
+    }
+    // the output row r - R, and after the input's last row the R rows that remain (entering rows mirrored at the bottom)
+    for (int i = r - R;; ++i) {
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__umul24(c.e[K][j], c.inv2) + c.kk[K][j]) >> 16;  // (radius <= 8: the window sum is below 2^21)
+        if constexpr (K + 1 < P) {
+            vs_feed<T, P, K + 1>(c, o, i);
+        } else {
+            if (c.store_on && i >= c.y0 && i < c.y1) RtVec<T>::store8(c.d + (size_t)i * c.ds, o, c.nst, c.keep);
+        }
+        if (r != len - 1 || i == len - 1) break;
+        uint32_t a[8], l[8];
+        vs_unpack(slot(2 * len - 1 - (i + 1 + R)), a);
+        vs_unpack(slot(i - R), l);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c.e[K][j] += a[j] - l[j];
+    }
+}
+
+template <typename T, int P>
+__global__ __launch_bounds__(64) void boxblur_rt_vsmall_kernel(const RVParams prm) {
+    extern __shared__ __attribute__((aligned(16))) uint4 vsr[];  // [stage][slot][lane]
+    int pi = 0;
+    const int b = blockIdx.x;
+    for (int i = 1; i < prm.nplanes; ++i)
+        if (b >= prm.p[i].block0) pi = i;
+    const RPlane pl = prm.p[pi];
+    const int lb = b - pl.block0, ncg = prm.ncg[pi], lane = (int)threadIdx.x;
+    const int x0 = ((lb % ncg) * 64 + lane) * 8;
+    if (x0 >= pl.w) return;
+    const int len = pl.h, R = prm.radius;
+    const T *s = static_cast<const T *>(pl.src) + x0;
+    const size_t ss = pl.sstride;
+    VsCtx<T, P> c;
+    c.ring = vsr + lane;
+    c.d = static_cast<T *>(pl.dst) + x0;
+    c.ds = pl.dstride;
+    c.R = R;
+    c.D = 2 * R + 2;
+    c.len = len;
+    // bands of prm.band rows, the last one takes the remainder as well (half a band to a band and a half): a band must not start within R rows
+    // of the bottom — its windows' warm-up sums real rows only
+    const int nb = max(1, (len + prm.band / 2) / prm.band), bi = lb / ncg;
+    c.y0 = bi * prm.band;
+    c.y1 = bi == nb - 1 ? len : c.y0 + prm.band;
+    c.nst = min(8, pl.w - x0);
+    c.keep = prm.keep;
+    {
+        const uint32_t ksize = 2u * (uint32_t)R + 1u;
+        const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+        c.inv2 = (uint32_t)(inv >> 16);
+        c.invlo = (uint32_t)(inv & 0xffffu);
+    }
+    auto load = [&](int row) -> uint4 {  // 8 samples of an input row, as packed u16
+        if constexpr (sizeof(T) == 2) {
+            return *reinterpret_cast<const uint4 *>(s + (size_t)row * ss);
+        } else {
+            const uint2 q = *reinterpret_cast<const uint2 *>(s + (size_t)row * ss);
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = ((i < 4 ? q.x : q.y) >> (8 * (i & 3))) & 0xffu;
+            return vs_pack(v);
+        }
+    };
+    auto reset = [&]() {
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            c.cnt[k] = 0;
+            c.pos[k] = -1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c.e[k][i] = 0;
+        }
+    };
+    auto run = [&](int r0, int r1) {  // input rows r0 .. r1 through the chain, eight loads in flight
+        constexpr int kPf = 8;
+        uint4 *stg = vsr + (size_t)P * c.D * 64 + lane;  // eight rows parked in LDS behind the rings: the chain below is one copy of code, not eight
+#pragma unroll 1
+        for (int rb = r0; rb <= r1; rb += kPf) {
+            {
+                uint4 q[kPf];
+#pragma unroll
+                for (int u = 0; u < kPf; ++u) q[u] = load(min(rb + u, r1));
+#pragma unroll
+                for (int u = 0; u < kPf; ++u) stg[u * 64] = q[u];
+            }
+#pragma unroll 1
+            for (int u = 0; u < kPf && rb + u <= r1; ++u) {
+                uint32_t x[8];
+                vs_unpack(stg[u * 64], x);
+                vs_feed<T, P, 0>(c, x, rb + u);
+            }
+        }
+    };
+    const int reach = P * R;
+    reset();
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c.kk[k][i] = 0;
+    c.top = true;
+    c.store_on = false;
+    if (c.y0 - reach > 0) {
+        // the constants first: the plane's top rows until the last stage has seen its E_0 (its first output needs input rows 0 .. P * R)
+        run(0, min(reach, len - 1));
+        reset();
+        c.top = false;
+        c.store_on = true;
+        run(c.y0 - reach, min(c.y1 - 1 + reach, len - 1));
+    } else {
+        c.store_on = true;
+        run(0, min(c.y1 - 1 + reach, len - 1));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rt_transpose_kernel(const RParams prm) {
     __shared__ T tile[64][64 + 2];
@@ -808,6 +1096,101 @@ __global__ __launch_bounds__(256) void rt_transpose_kernel(const RParams prm) {
     __syncthreads();
     for (int r = ty; r < 64; r += 4)
         if (bx + r < pl.w && by + tx < pl.h) d[(size_t)(bx + r) * pl.dstride + by + tx] = tile[tx][r];
+}
+
+// all horizontal passes of a small radius in one launch (boxblur_rt_hsmall_kernel); false: the planes do not qualify
+template <typename T>
+bool hsmall_ok(const std::vector<RPlane> &pl, int radius, int npass) {
+    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || radius < 1 || radius > kHsMaxR || getenv("VSZIP_RT_NO_HSMALL")) return false;
+    for (const RPlane &q : pl) {
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) | (uintptr_t)((size_t)q.dstride * sizeof(T));
+        if ((bits & 15) != 0 || q.w <= 2 * radius || q.w > kHsMaxW || q.sstride < ((q.w + 7) / 8) * 8 || q.dstride < ((q.w + 7) / 8) * 8) return false;
+    }
+    return true;
+}
+template <typename T>
+int launch_hsmall(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool keep) {
+    size_t done = 0;
+    while (done < pl.size()) {
+        RParams prm;
+        const int n = (int)std::min<size_t>(kMaxPlanesRT, pl.size() - done);
+        prm.nplanes = n;
+        prm.radius = radius;
+        prm.keep = keep ? 1 : 0;
+        int blocks = 0, maxw = 0;
+        for (int i = 0; i < n; ++i) {
+            prm.p[i] = pl[done + i];
+            prm.p[i].block0 = blocks;
+            blocks += prm.p[i].h;
+            maxw = std::max(maxw, prm.p[i].w);
+        }
+        const int pitch = ((maxw + 7) / 8) * 8 + 32;  // 8 samples of left halo room, the row in whole groups, a group of right halo room, slack for the last group's reads
+        const size_t lds = (size_t)2 * pitch * sizeof(uint16_t);
+#define VSZIP_HS(RR) case RR: hipLaunchKernelGGL((boxblur_rt_hsmall_kernel<T, RR>), dim3(blocks), dim3(64), lds, ctx->stream, prm, npass, pitch); break
+        switch (radius) {
+            VSZIP_HS(1); VSZIP_HS(2); VSZIP_HS(3); VSZIP_HS(4); VSZIP_HS(5); VSZIP_HS(6); VSZIP_HS(7);
+            default: hipLaunchKernelGGL((boxblur_rt_hsmall_kernel<T, 8>), dim3(blocks), dim3(64), lds, ctx->stream, prm, npass, pitch); break;
+        }
+#undef VSZIP_HS
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
+}
+
+// all vertical passes of a small radius in one launch (boxblur_rt_vsmall_kernel); false: the planes do not qualify
+template <typename T>
+bool vsmall_ok(const std::vector<RPlane> &pl, int radius, int npass) {
+    // Measured (tools/boxblur_radii_probe.py, 1080p, 64 frames per call, against one launch per pass): two passes 93.3 k -> 107.7 k fps (u16), 105 k -> 108 k
+    // (u8); three passes 68 k -> 66.5 k (u16), 79 k -> 65 k (u8) — the chain's rings and registers leave 6 waves a CU at three stages. Hence two passes
+    // only (VSZIP_RT_VSMALL_MAX=3 / 4 for experiments).
+    const char *mx = getenv("VSZIP_RT_VSMALL_MAX");
+    const int max_pass = mx ? std::min(4, std::max(2, atoi(mx))) : 2;
+    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || npass > max_pass || radius < 1 || radius > kHsMaxR || getenv("VSZIP_RT_NO_VSMALL")) return false;
+    if ((size_t)npass * (2 * radius + 2) * 1024 > 40 * 1024) return false;  // the rings: four waves a CU at least
+    for (const RPlane &q : pl) {
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) | (uintptr_t)((size_t)q.dstride * sizeof(T));
+        if ((bits & 15) != 0 || q.h <= 2 * npass * radius + 2 || q.sstride < ((q.w + 7) / 8) * 8 || q.dstride < ((q.w + 7) / 8) * 8) return false;
+    }
+    return true;
+}
+template <typename T>
+int launch_vsmall(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool keep) {
+    size_t done = 0;
+    while (done < pl.size()) {
+        RVParams vp;
+        const int n = (int)std::min<size_t>(kMaxPlanesRT, pl.size() - done);
+        vp.nplanes = n;
+        vp.radius = radius;
+        vp.keep = keep ? 1 : 0;
+        long colgroups = 0;
+        int maxh = 0;
+        for (int i = 0; i < n; ++i) {
+            colgroups += (pl[done + i].w + 511) / 512;
+            maxh = std::max(maxh, pl[done + i].h);
+        }
+        // bands: a band pays 2 * passes * radius + 1 extra rows (constants, warm-up); shorter ones only while the launch would not fill the chip
+        int band = 256;
+        while (band > 64 && colgroups * ((maxh + band - 1) / band) < 2048) band /= 2;
+        vp.band = band;
+        int vb = 0;
+        for (int i = 0; i < n; ++i) {
+            vp.p[i] = pl[done + i];
+            vp.p[i].block0 = vb;
+            vp.ncg[i] = (vp.p[i].w + 511) / 512;
+            vb += vp.ncg[i] * std::max(1, (vp.p[i].h + band / 2) / band);  // (the last band takes the remainder: see the kernel)
+        }
+        const size_t lds = ((size_t)npass * (2 * radius + 2) + 8) * 64 * sizeof(uint4);  // the stages' rings + eight parked input rows
+        if (npass == 2)
+            hipLaunchKernelGGL((boxblur_rt_vsmall_kernel<T, 2>), dim3(vb), dim3(64), lds, ctx->stream, vp);
+        else if (npass == 3)
+            hipLaunchKernelGGL((boxblur_rt_vsmall_kernel<T, 3>), dim3(vb), dim3(64), lds, ctx->stream, vp);
+        else
+            hipLaunchKernelGGL((boxblur_rt_vsmall_kernel<T, 4>), dim3(vb), dim3(64), lds, ctx->stream, vp);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
 }
 
 template <typename T>
@@ -1073,7 +1456,13 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
         int which = 0;
         for (int p = 0; p < total; ++p) {
             const bool vertical = p >= (hb ? hpasses : 0);
-            const bool last = p == total - 1;
+            // every horizontal pass of a small radius at once (round 3): the step then stands for hpasses passes
+            int span = 1;
+            if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) {
+                if (p == 0 && hb && hpasses >= 2) span = hpasses;
+                if (vertical && p == (hb ? hpasses : 0) && vpasses >= 2) span = vpasses;
+            }
+            const bool last = p + span - 1 == total - 1;
             for (int i = 0; i < ng; ++i) {
                 if (last) {
                     cur[i].dst = planes[g0 + i].dst;
@@ -1083,7 +1472,28 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
                     cur[i].dstride = (planes[g0 + i].w + 63) & ~63;
                 }
             }
-            int rc = launch_pass<T>(ctx, cur, vertical ? vradius : hradius, vertical, !last);
+            int rc;
+            if (span > 1 && !vertical && hsmall_ok<T>(cur, hradius, hpasses)) {
+                if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_hsmall<T>(ctx, cur, hradius, hpasses, !last);
+                else rc = VSZIP_ERR_ARG;
+                p += span - 1;
+            } else if (span > 1 && vertical && vsmall_ok<T>(cur, vradius, vpasses)) {
+                if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_vsmall<T>(ctx, cur, vradius, vpasses, !last);
+                else rc = VSZIP_ERR_ARG;
+                p += span - 1;
+            } else {
+                if (span > 1) {  // (the planes do not qualify: back to one pass per launch; this one is not the last)
+                    span = 1;
+                    for (int i = 0; i < ng; ++i) {
+                        if (total > 1) {
+                            cur[i].dst = scratch[which] + goff[i];
+                            cur[i].dstride = (planes[g0 + i].w + 63) & ~63;
+                        }
+                    }
+                }
+                const bool last1 = p == total - 1;
+                rc = launch_pass<T>(ctx, cur, vertical ? vradius : hradius, vertical, !last1);
+            }
             if (rc != VSZIP_OK) return rc;
             for (int i = 0; i < ng; ++i) {
                 cur[i].src = cur[i].dst;
