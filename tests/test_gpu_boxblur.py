@@ -248,14 +248,16 @@ def test_rt_fused_multipass_equals_per_pass(dev, oracle, dtype, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
 def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
-    """Round 3: BoxBlur(hradius <= 8, hpasses >= 2) — how scripts approximate a Gaussian — runs ALL horizontal passes in one launch (a wave keeps
+    """Round 3: BoxBlur(hradius <= 16, hpasses >= 2) — how scripts approximate a Gaussian — runs ALL horizontal passes in one launch (a wave keeps
     its row in LDS: boxblur_rt_hsmall_kernel) and two vertical passes in one launch as well (a chain of stages with LDS rings, the plane's first
     rows run first for the stages' E_0 constants: boxblur_rt_vsmall_kernel; three and four stages with VSZIP_RT_VSMALL_MAX). Against the oracle
-    and the one-launch-per-pass kernels, bit for bit: every radius 1 .. 8, widths that are not whole 8-sample groups, planes barely taller
+    and the one-launch-per-pass kernels, bit for bit: radii 1 .. 16 (vertical chain: 1 .. 8), widths that are not whole 8-sample groups, planes barely taller
     than the chain's reach, bands that start at the top / inside it / below it, the bottom rows' mirrored windows."""
     cases = [([(72, 208), (36, 104), (36, 104)], (1, 2, 1, 2)), ([(300, 333)], (2, 3, 2, 2)), ([(64, 4096)], (3, 4, 0, 0)), ([(700, 96)], (0, 0, 4, 2)),
              ([(135, 251), (67, 125)], (5, 2, 6, 2)), ([(533, 130)], (7, 3, 8, 2)), ([(40, 35), (35, 40)], (8, 2, 8, 2)), ([(290, 640)], (1, 4, 1, 2)),
-             ([(19, 40)], (2, 2, 2, 2)), ([(1080, 520)], (2, 2, 3, 2))]
+             ([(19, 40)], (2, 2, 2, 2)), ([(1080, 520)], (2, 2, 3, 2)),
+             # radii 9 .. 16: the horizontal kernel reads two neighbour groups on either side (13 x 5 passes is the reference README's third benchmark)
+             ([(72, 300), (36, 150)], (13, 5, 13, 5)), ([(90, 257)], (16, 2, 9, 2)), ([(64, 333)], (11, 3, 0, 0)), ([(50, 35)], (9, 4, 1, 2)), ([(40, 4104)], (12, 2, 0, 0))]
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(11 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
 

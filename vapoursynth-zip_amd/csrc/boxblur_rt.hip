@@ -824,7 +824,8 @@ __global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams 
 // slides it — blurInt's closed form (:10-41, see RtVec above): dst[x] = (inv2 * E_x + 32768 + ((E_0 * invlo) >> 16)) >> 16 with E_0 read from
 // the row's first R + 1 samples of the pass's own input, which are right there. One read and one write of the plane for all passes.
 // ---------------------------------------------------------------------------------------------
-constexpr int kHsMaxR = 8, kHsMaxW = 8192;
+constexpr int kHsMaxR = 16, kHsMaxW = 8192, kHsHalo = 16;  // (radius 13 x 5 passes is the reference README's third benchmark)
+constexpr int kVsMaxR = 8;
 template <typename T, int R>
 __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm, const int npass, const int pitch /* u16 elements per LDS buffer */) {
     extern __shared__ __attribute__((aligned(16))) uint16_t hs[];
@@ -836,7 +837,8 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
     constexpr uint32_t ksize = 2u * R + 1u;
     constexpr uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
     constexpr uint32_t inv2 = (uint32_t)(inv >> 16), invlo = (uint32_t)(inv & 0xffffu);
-    const int nv = (w + 7) / 8;  // 8-sample groups of the row; sample x lives at element 8 + x of a buffer
+    constexpr int H = kHsHalo, G = (R + 7) / 8, NT = 8 * (2 * G + 1);  // groups of halo reach; samples a lane unpacks per group of outputs
+    const int nv = (w + 7) / 8;  // 8-sample groups of the row; sample x lives at element H + x of a buffer
     // stage the row (u16 in LDS whatever the clip's sample size)
     for (int v = lane; v < nv; v += 64) {
         const int x0 = 8 * v;
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
         if (x0 + 8 <= w) {
             if constexpr (sizeof(T) == 2) {
                 const uint4 q = *reinterpret_cast<const uint4 *>(s + x0);
-                *reinterpret_cast<uint4 *>(hs + 8 + x0) = q;
+                *reinterpret_cast<uint4 *>(hs + H + x0) = q;
                 continue;
             } else {
                 const uint2 q = *reinterpret_cast<const uint2 *>(s + x0);
@@ -860,36 +862,39 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
         o.y = e[2] | (e[3] << 16);
         o.z = e[4] | (e[5] << 16);
         o.w = e[6] | (e[7] << 16);
-        *reinterpret_cast<uint4 *>(hs + 8 + x0) = o;
+        *reinterpret_cast<uint4 *>(hs + H + x0) = o;
     }
     vszip_wave_fence();
     uint16_t *cur = hs, *nxt = hs + pitch;
     for (int pass = 0; pass < npass; ++pass) {
         // blurInt's implicit padding: -k -> k - 1, w - 1 + k -> w - k
         if (lane < R) {
-            cur[8 - 1 - lane] = cur[8 + min(lane, w - 1)];
-            cur[8 + w + lane] = cur[8 + max(w - 1 - lane, 0)];
+            cur[H - 1 - lane] = cur[H + min(lane, w - 1)];
+            cur[H + w + lane] = cur[H + max(w - 1 - lane, 0)];
         }
         vszip_wave_fence();
-        uint32_t e0 = cur[8 + min(R, w - 1)];
+        uint32_t e0 = cur[H + min(R, w - 1)];
 #pragma unroll
-        for (int i = 0; i < R; ++i) e0 += 2u * cur[8 + min(i, w - 1)];
+        for (int i = 0; i < R; ++i) e0 += 2u * cur[H + min(i, w - 1)];
         const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
         const bool last = pass == npass - 1;
         for (int v = lane; v < nv; v += 64) {
             const int x0 = 8 * v;
-            const uint4 qa = *reinterpret_cast<const uint4 *>(cur + x0), qb = *reinterpret_cast<const uint4 *>(cur + 8 + x0), qc = *reinterpret_cast<const uint4 *>(cur + 16 + x0);
-            uint32_t t[24];
-            const uint32_t dw[12] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
+            uint32_t t[NT];  // t[8 G + i] = sample x0 + i: the group and G groups on either side (three 16-byte reads for R <= 8, five beyond)
 #pragma unroll
-            for (int k = 0; k < 24; ++k) t[k] = (dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;  // t[8 + i] = sample x0 + i
+            for (int g = 0; g < 2 * G + 1; ++g) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(cur + H + x0 + 8 * (g - G));
+                const uint32_t dw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[8 * g + k] = (dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            }
             uint32_t e = 0, o[8];
 #pragma unroll
-            for (int k = -R; k <= R; ++k) e += t[8 + k];
+            for (int k = -R; k <= R; ++k) e += t[8 * G + k];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                o[k] = (__umul24(e, inv2) + kr) >> 16;  // (e < 2^21 here: the 24-bit multiply is exact, the 16.16 value fits 32 bits)
-                if (k < 7) e += t[8 + k + 1 + R] - t[8 + k - R];
+                o[k] = (__umul24(e, inv2) + kr) >> 16;  // (e < 2^22 here: the 24-bit multiply is exact, the 16.16 value fits 32 bits)
+                if (k < 7) e += t[8 * G + k + 1 + R] - t[8 * G + k - R];
             }
             if (!last) {
                 uint4 q;
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
                 q.y = o[2] | (o[3] << 16);
                 q.z = o[4] | (o[5] << 16);
                 q.w = o[6] | (o[7] << 16);
-                *reinterpret_cast<uint4 *>(nxt + 8 + x0) = q;
+                *reinterpret_cast<uint4 *>(nxt + H + x0) = q;
             } else {
                 RtVec<T>::store8(d + x0, o, min(8, w - x0), prm.keep);
             }
@@ -1124,12 +1129,13 @@ int launch_hsmall(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int
             blocks += prm.p[i].h;
             maxw = std::max(maxw, prm.p[i].w);
         }
-        const int pitch = ((maxw + 7) / 8) * 8 + 32;  // 8 samples of left halo room, the row in whole groups, a group of right halo room, slack for the last group's reads
+        const int pitch = ((maxw + 7) / 8) * 8 + 2 * kHsHalo + 16;  // halo room on the left, the row in whole groups, halo room on the right, slack for the last group's reads
         const size_t lds = (size_t)2 * pitch * sizeof(uint16_t);
 #define VSZIP_HS(RR) case RR: hipLaunchKernelGGL((boxblur_rt_hsmall_kernel<T, RR>), dim3(blocks), dim3(64), lds, ctx->stream, prm, npass, pitch); break
         switch (radius) {
-            VSZIP_HS(1); VSZIP_HS(2); VSZIP_HS(3); VSZIP_HS(4); VSZIP_HS(5); VSZIP_HS(6); VSZIP_HS(7);
-            default: hipLaunchKernelGGL((boxblur_rt_hsmall_kernel<T, 8>), dim3(blocks), dim3(64), lds, ctx->stream, prm, npass, pitch); break;
+            VSZIP_HS(1); VSZIP_HS(2); VSZIP_HS(3); VSZIP_HS(4); VSZIP_HS(5); VSZIP_HS(6); VSZIP_HS(7); VSZIP_HS(8);
+            VSZIP_HS(9); VSZIP_HS(10); VSZIP_HS(11); VSZIP_HS(12); VSZIP_HS(13); VSZIP_HS(14); VSZIP_HS(15);
+            default: hipLaunchKernelGGL((boxblur_rt_hsmall_kernel<T, 16>), dim3(blocks), dim3(64), lds, ctx->stream, prm, npass, pitch); break;
         }
 #undef VSZIP_HS
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
@@ -1146,7 +1152,7 @@ bool vsmall_ok(const std::vector<RPlane> &pl, int radius, int npass) {
     // only (VSZIP_RT_VSMALL_MAX=3 / 4 for experiments).
     const char *mx = getenv("VSZIP_RT_VSMALL_MAX");
     const int max_pass = mx ? std::min(4, std::max(2, atoi(mx))) : 2;
-    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || npass > max_pass || radius < 1 || radius > kHsMaxR || getenv("VSZIP_RT_NO_VSMALL")) return false;
+    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || npass > max_pass || radius < 1 || radius > kVsMaxR || getenv("VSZIP_RT_NO_VSMALL")) return false;
     if ((size_t)npass * (2 * radius + 2) * 1024 > 40 * 1024) return false;  // the rings: four waves a CU at least
     for (const RPlane &q : pl) {
         const uintptr_t bits = reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) | (uintptr_t)((size_t)q.dstride * sizeof(T));
