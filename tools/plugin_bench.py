@@ -66,6 +66,11 @@ def main():
         ("PlaneAverage 4K YUV420P16", src4k.vszip.PlaneAverage(exclude=[-1]), 25, 128),
         ("XPSNR 1080p YUV420P8", src1080.vszip.XPSNR(rec1080), 3.1 * 2, 256),
     ]
+    if only is None or "1080p" in only:
+        # round 3: what most scripts run — 1080p YUV420P8 (3.1 MB per frame each way)
+        legs.append(("BoxBlur r=2 1080p YUV420P8", src1080.vszip.BoxBlur(hradius=2, vradius=2), 3.1 * 2, 512))
+        legs.append(("BoxBlur r=1 2+2 passes 1080p YUV420P8", src1080.vszip.BoxBlur(hradius=1, hpasses=2, vradius=1, vpasses=2), 3.1 * 2, 512))
+        legs.append(("Bilateral defaults (sigmaS=3 sigmaR=0.02) 1080p YUV420P8", src1080.vszip.Bilateral(), 3.1 * 2, 512))
     if only is None or "eedi3" in only:
         legs.append(("EEDI3 field=1 dh=1 1080p YUV420PS", clip_1080ps(8).vszip.EEDI3(field=1, dh=True), 12.4 + 24.9, 128))
     if only is None or "ssimulacra2" in only:
