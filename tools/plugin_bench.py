@@ -71,6 +71,12 @@ def main():
         legs.append(("BoxBlur r=2 1080p YUV420P8", src1080.vszip.BoxBlur(hradius=2, vradius=2), 3.1 * 2, 512))
         legs.append(("BoxBlur r=1 2+2 passes 1080p YUV420P8", src1080.vszip.BoxBlur(hradius=1, hpasses=2, vradius=1, vpasses=2), 3.1 * 2, 512))
         legs.append(("Bilateral defaults (sigmaS=3 sigmaR=0.02) 1080p YUV420P8", src1080.vszip.Bilateral(), 3.1 * 2, 512))
+        vs.core_standins(True)
+        p8 = {"_Matrix": 1, "_ColorRange": 1, "_ChromaLocation": 0}
+        fr = [[np.asarray(src1080.get_frame(f)[q]) for q in range(3)] for f in range(8)]
+        ya8 = vs.source(fr, vs.YUV420P8, props=p8)
+        yb8 = vs.source([[np.clip(p.astype(np.int16) + 2, 0, 255).astype(np.uint8) for p in f] for f in fr], vs.YUV420P8, props=p8)
+        legs.append(("SSIMULACRA2 1080p YUV420P8 (device colour pre-stage)", ya8.vszip.SSIMULACRA2(yb8), 6.2, 512))
     if only is None or "eedi3" in only:
         legs.append(("EEDI3 field=1 dh=1 1080p YUV420PS", clip_1080ps(8).vszip.EEDI3(field=1, dh=True), 12.4 + 24.9, 128))
     if only is None or "ssimulacra2" in only:
