@@ -8,7 +8,7 @@ import numpy as np, bench, vszip_amd
 dev = vszip_amd.Device(0)
 base = bench.natural_frame(1920, 1080)
 F = 64
-for sS, sR in ((2, 2), (2, 0.02), (3, 0.02), (3, 2), (1, 0.02)):
+for sS, sR in ((2, 2), (2, 0.02), (3, 0.02), (3, 2), (1, 0.02), (2, 0.1), (2, 0.3), (2, 0.5)):
     cfg = dev.bilateral_cfg([sS], [sR], yuv=True, ssw=1, ssh=1, hist_len=65536)
     srcs, dsts, idx = [], [], []
     for f in range(F):
