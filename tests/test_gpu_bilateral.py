@@ -152,14 +152,15 @@ def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
-@pytest.mark.parametrize("sig", [(2, 2), (1, 2), (2, 1.0), (2, 0.3), (2, 0.02), (1, 0.05), (2, 0.0625), (2, 0.004), (3, 0.02), (3, 2), (3, 1.0)])
+@pytest.mark.parametrize("sig", [(2, 2), (1, 2), (2, 1.0), (2, 0.3), (2, 0.02), (1, 0.05), (2, 0.0625), (2, 0.004), (3, 0.02), (3, 2), (3, 1.0), (2, 0.1), (2, 0.3), (1, 0.2), (3, 0.15), (2, 0.07), (2, 0.41)])
 @pytest.mark.parametrize("content", ["natural", "noise", "edges"])
 def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
     """Round 3: 16-bit clips without `ref` whose taps are the BASELINE's (radius 3 / step 2, radius 2 / step 1) take the
     column-walking kernel — each pixel looks up only its 8 downward taps and receives the 8 upward ones from the pixels above
     (the range weight is symmetric), neighbours cross lanes with DPP shifts. Both of its table forms (FINE: 4-entry blocks with
     u8 deltas, for gentle tables such as sigmaR = 2; COARSE: the LDS16 form; PLATEAU: the computed part of a STEEP table as it is —
-    sigmaR <= 0.0625, the filter's usual range, default 0.02 — and the whole table of 8-bit clips) against the tile kernel and the oracle, byte for
+    sigmaR <= 0.0625, the filter's usual range, default 0.02 — and the whole table of 8-bit clips; CUBIC: what lies between, 0.0625 < sigmaR < 0.42,
+    a cubic per 128 entries + a correction byte per entry) against the tile kernel and the oracle, byte for
     byte: natural content, full-range white noise (every table entry, every weight handed down differs) and hard edges;
     the filter's default sigmaS = 3 (radius 5, step 2: three tap distances, bilateral_walk36_kernel) in all three table forms;
     strips narrower / wider than a wave's 54 / 58 / 60 output columns, bands that end inside a ring period, planes barely

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_tiled_kernel(const BLParam
 // from L1/L2 on natural / edgy / uniform index distributions against 14 / 15 / 18 for the two LDS reads.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 // The LDS pipeline is this kernel's limit, so part of the lookups goes to the f32 table in global memory: the
 // vector-memory pipeline (L1/L2) runs beside it. How many pays depends on the content - smooth pictures keep the
 // touched part of the table in L1, heavy grain does not. Measured (1080p YUV420P16, k fps) at 0 / 2 / 3 / 4 / 6 / 8
@@ -475,6 +476,23 @@ struct WalkLut<2> {
     float t[kWalkPlateauMax];
     __device__ __forceinline__ float at(uint32_t i, uint32_t upper) const { return t[min(i, upper)]; }
 };
+// CUBIC (3, round 3): what lies between — 0.0625 < sigmaR < 0.42: more than 32 768 computed entries, too steep for 16-bit deltas. The table is smooth
+// (a Gaussian), so it is restated as a cubic per 128 entries, evaluated with three FMAs exactly as the host evaluates it when it builds the form, plus a
+// signed byte per entry with the difference of the bit patterns, bits(table[i]) - bits(cubic(i)): the sum IS the entry (the host checks every entry up to
+// `upper` and that every difference fits the byte). 8 + 64 KiB of LDS, a 16-byte and a 1-byte read and five VALU instructions more per lookup than PLATEAU.
+constexpr int kCubicSeg = 512, kCubicBytes = kCubicSeg * 16 + 65536;
+template <>
+struct WalkLut<3> {
+    v4f coef[kCubicSeg];
+    int8_t corr[65536];
+    __device__ __forceinline__ float at(uint32_t i, uint32_t upper) const {
+        const uint32_t j = min(i, upper);
+        const v4f c = coef[j >> 7];
+        const float t = (float)(j & 127u);
+        const float a = fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
+        return __int_as_float(__float_as_int(a) + (int)corr[j]);
+    }
+};
 
 template <int CR, int CS, int P, int FINE, typename T>
 __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<FINE> &tab, const uint32_t upper, const v2f (&sw)[2], float w0, float peak,
@@ -549,6 +567,9 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         // the f32 table itself, up to its plateau
         const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr);
         for (int i = tid; i < ((int)upper + 4) / 4; i += 1024) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
+    } else if constexpr (FINE == 3) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr + 65536);  // the cubic form lies behind the f32 table
+        for (int i = tid; i < kCubicBytes / 16; i += 1024) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
     } else {
         // the packed forms lie behind the f32 table: COARSE (4 + 128 KiB), then FINE (64 + 64 KiB)
         const uint4 *g = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(prm.p[0].gr + 65536) + (FINE ? kL16LutBytes : 0));
@@ -709,6 +730,9 @@ __global__ __launch_bounds__(512) void bilateral_walk36_kernel(const BLParams pr
     if constexpr (FORM == 2) {
         const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr);
         for (int i = tid; i < ((int)upper + 4) / 4; i += 512) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
+    } else if constexpr (FORM == 3) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(prm.p[0].gr + 65536);
+        for (int i = tid; i < kCubicBytes / 16; i += 512) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
     } else {
         const uint4 *g = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(prm.p[0].gr + 65536) + (FORM ? kL16LutBytes : 0));
         for (int i = tid; i < (int)(sizeof(WalkLut<FORM>) / 16); i += 512) reinterpret_cast<uint4 *>(&slut)[i] = g[i];
@@ -1082,6 +1106,7 @@ struct PackedLuts {
     std::map<const void *, uint64_t> exact;  // pointer -> content key (the bits of sigmaR: length and peak are fixed for these tables)
     std::set<const void *> fine;             // ... whose 4-entry-block form (bilateral_walk16_kernel, FINE) is exact as well and stored behind the first
     std::map<const void *, std::pair<uint64_t, uint32_t>> plateau;  // 65536-entry tables that are constant from `upper` <= kWalkPlateauMax - 1 on: pointer -> (content key, upper)
+    std::map<const void *, std::pair<uint64_t, uint32_t>> cubic;    // tables stored in the CUBIC form behind the f32 table: pointer -> (content key, upper)
 };
 PackedLuts &packed_luts() {
     static PackedLuts *p = new PackedLuts();
@@ -1097,14 +1122,20 @@ bool lut_is_packed(const void *gr, uint64_t *key = nullptr, bool *fine = nullptr
     return true;
 }
 
-bool lut_plateau(const void *gr, uint64_t *key, uint32_t *upper) {
+// the LDS form of a table no packed form holds: 2 = PLATEAU, 3 = CUBIC, 0 = none
+int lut_plateau(const void *gr, uint64_t *key, uint32_t *upper) {
     PackedLuts &p = packed_luts();
     std::lock_guard<std::mutex> lk(p.mu);
-    const auto it = p.plateau.find(gr);
-    if (it == p.plateau.end()) return false;
+    auto it = p.plateau.find(gr);
+    int form = 2;
+    if (it == p.plateau.end()) {
+        it = p.cubic.find(gr);
+        form = 3;
+        if (it == p.cubic.end()) return 0;
+    }
     *key = it->second.first;
     *upper = it->second.second;
-    return true;
+    return form;
 }
 
 template <typename T, bool JOINT, int CR, int CS, bool PLAT = false>
@@ -1153,7 +1184,9 @@ int launch_walk16(vszip_ctx *ctx, BLParams prm, int form) {  // form: 0 COARSE, 
     int *counter = static_cast<int *>(ctx->scratch);
     VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
     vszip_probe_scope probe(ctx);
-    if (form == 2)
+    if (form == 3)
+        hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, 3, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
+    else if (form == 2)
         hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, 2, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
     else if (form == 1)
         hipLaunchKernelGGL((bilateral_walk16_kernel<CR, CS, 1, T>), dim3(grid), dim3(1024), 0, ctx->stream, prm, strips, counter);
@@ -1180,7 +1213,9 @@ int launch_walk36(vszip_ctx *ctx, BLParams prm, int form) {
     int *counter = static_cast<int *>(ctx->scratch);
     VSZIP_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
     vszip_probe_scope probe(ctx);
-    if (form == 2)
+    if (form == 3)
+        hipLaunchKernelGGL((bilateral_walk36_kernel<3, T>), dim3(grid), dim3(512), 0, ctx->stream, prm, strips, counter);
+    else if (form == 2)
         hipLaunchKernelGGL((bilateral_walk36_kernel<2, T>), dim3(grid), dim3(512), 0, ctx->stream, prm, strips, counter);
     else if (form == 1)
         hipLaunchKernelGGL((bilateral_walk36_kernel<1, T>), dim3(grid), dim3(512), 0, ctx->stream, prm, strips, counter);
@@ -1231,6 +1266,7 @@ void vszip_bilateral_forget_lut(const void *dptr) {
     pl.exact.erase(dptr);
     pl.fine.erase(dptr);
     pl.plateau.erase(dptr);
+    pl.cubic.erase(dptr);
 }
 
 // LUTs exactly as bilateral.zig:306-339 computes them (f64 exp on the host, cast to f32),
@@ -1296,14 +1332,77 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
             }
         }
     }
+    // ... and the CUBIC form for what neither a packed form nor the PLATEAU form holds (walk kernels, WalkLut<3>): least-squares cubic per 128 entries,
+    // evaluated here with the kernel's three FMAs, + the difference of the bit patterns per entry
+    std::vector<float> ccoef;
+    std::vector<int8_t> ccorr;
+    bool cubic = hist_len == 65536 && !packed && upper + 1 > (uint32_t)kWalkPlateauMax && !getenv("VSZIP_BILATERAL_NO_CUBIC");
+    if (cubic) {
+        ccoef.assign((size_t)kCubicSeg * 4, 0.0f);
+        ccorr.assign(65536, 0);
+        for (int sg = 0; sg < kCubicSeg && cubic; ++sg) {
+            double A[4][5] = {};
+            int n = 0;
+            for (int t = 0; t < 128; ++t) {
+                const uint32_t idx = (uint32_t)sg * 128 + t;
+                if (idx > upper) break;
+                const double z = t / 128.0, y = (double)gr[idx];
+                double pw[7] = {1, z, z * z, z * z * z, 0, 0, 0};
+                pw[4] = pw[3] * z;
+                pw[5] = pw[4] * z;
+                pw[6] = pw[5] * z;
+                for (int a = 0; a < 4; ++a) {
+                    for (int b = 0; b < 4; ++b) A[a][b] += pw[a + b];
+                    A[a][4] += pw[a] * y;
+                }
+                ++n;
+            }
+            if (n == 0) break;
+            const int deg = n >= 8 ? 4 : (n >= 2 ? 2 : 1);
+            for (int a = 0; a < deg; ++a) {  // Gauss-Jordan with pivoting
+                int pv = a;
+                for (int b = a + 1; b < deg; ++b)
+                    if (std::fabs(A[b][a]) > std::fabs(A[pv][a])) pv = b;
+                for (int c = 0; c < 5; ++c) std::swap(A[a][c], A[pv][c]);
+                for (int b = 0; b < deg; ++b) {
+                    if (b == a) continue;
+                    const double f = A[b][a] / A[a][a];
+                    for (int c = a; c < 5; ++c) A[b][c] -= f * A[a][c];
+                }
+            }
+            double cz[4] = {0, 0, 0, 0};
+            for (int a = 0; a < deg; ++a) cz[a] = A[a][4] / A[a][a];
+            float *c = &ccoef[(size_t)sg * 4];
+            c[0] = (float)cz[0];
+            c[1] = (float)(cz[1] / 128.0);
+            c[2] = (float)(cz[2] / (128.0 * 128.0));
+            c[3] = (float)(cz[3] / (128.0 * 128.0 * 128.0));
+            for (int t = 0; t < 128; ++t) {
+                const uint32_t idx = (uint32_t)sg * 128 + t;
+                if (idx > upper) break;
+                const float tt = (float)t;
+                const float a = std::fmaf(std::fmaf(std::fmaf(c[3], tt, c[2]), tt, c[1]), tt, c[0]);
+                int32_t ba, bt;
+                std::memcpy(&ba, &a, 4);
+                std::memcpy(&bt, &gr[idx], 4);
+                const long df = (long)bt - (long)ba;
+                if (df < -128 || df > 127 || !(a > 0.0f)) {
+                    cubic = false;
+                    break;
+                }
+                ccorr[idx] = (int8_t)df;
+            }
+        }
+    }
     void *d = nullptr;
     const size_t gr_bytes = gr.size() * sizeof(float);
-    if (hipMalloc(&d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0) + (fine ? (size_t)kWalkFineBytes : 0)) != hipSuccess)
+    if (hipMalloc(&d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0) + (fine ? (size_t)kWalkFineBytes : 0) + (cubic ? (size_t)kCubicBytes : 0)) != hipSuccess)
         return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: range LUT allocation failed");
     auto upload = [&](size_t off, const void *src, size_t n) { return hipMemcpy(static_cast<char *>(d) + off, src, n, hipMemcpyHostToDevice) == hipSuccess; };
     bool up_ok = upload(0, gr.data(), gr_bytes);
     if (packed) up_ok = up_ok && upload(gr_bytes, pbase.data(), 4096) && upload(gr_bytes + 4096, pdelta.data(), 131072);
     if (fine) up_ok = up_ok && upload(gr_bytes + kL16LutBytes, fbase.data(), 65536) && upload(gr_bytes + kL16LutBytes + 65536, fdelta.data(), 65536);
+    if (cubic) up_ok = up_ok && upload(gr_bytes, ccoef.data(), (size_t)kCubicSeg * 16) && upload(gr_bytes + (size_t)kCubicSeg * 16, ccorr.data(), 65536);  // (never beside a packed form)
     if (!up_ok) {
         (void)hipGetLastError();
         (void)hipFree(d);  // (the allocation leaked on a failed upload)
@@ -1316,6 +1415,12 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
         pl.exact.erase(d);
         pl.fine.erase(d);
         pl.plateau.erase(d);
+        pl.cubic.erase(d);
+        if (cubic) {
+            uint64_t key;
+            std::memcpy(&key, &cfg->sigmaR, sizeof key);
+            pl.cubic[d] = {key, upper};
+        }
         if (hist_len % 4 == 0 && upper + 1 <= (uint32_t)kWalkPlateauMax) {  // (8- / 10- / 12-bit clips: the whole table is that short)
             uint64_t key;
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
@@ -1428,15 +1533,16 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             struct PKey {
                 uint64_t table;
                 uint32_t upper;
-                int radius, step;
-                bool operator==(const PKey &o) const { return table == o.table && upper == o.upper && radius == o.radius && step == o.step; }
+                int radius, step, form;
+                bool operator==(const PKey &o) const { return table == o.table && upper == o.upper && radius == o.radius && step == o.step && form == o.form; }
             };
             std::vector<PKey> keys(n), groups;
             std::vector<char> walk(n, 0);
             for (int i = 0; i < n; ++i) {
                 keys[i].radius = prm.p[i].radius;
                 keys[i].step = prm.p[i].step;
-                walk[i] = lut_plateau(prm.p[i].gr, &keys[i].table, &keys[i].upper) &&
+                keys[i].form = lut_plateau(prm.p[i].gr, &keys[i].table, &keys[i].upper);
+                walk[i] = keys[i].form != 0 &&
                           ((keys[i].radius == 3 && keys[i].step == 2) || (keys[i].radius == 2 && keys[i].step == 1) || (keys[i].radius == 5 && keys[i].step == 2 && !getenv("VSZIP_BILATERAL_NO_WALK36")));
                 if (walk[i] && std::find(groups.begin(), groups.end(), keys[i]) == groups.end()) groups.push_back(keys[i]);
             }
@@ -1449,12 +1555,13 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 q.nplanes = 0;
                 for (int i = 0; i < n; ++i)
                     if (walk[i] && keys[i] == g) q.p[q.nplanes++] = prm.p[i];
+                const int f = g.form;
                 if (g.radius == 5)
-                    rc = dtype == VSZIP_U8 ? launch_walk36<uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk36<uint16_t>(ctx, q, 2) : launch_walk36<float>(ctx, q, 2));
+                    rc = dtype == VSZIP_U8 ? launch_walk36<uint8_t>(ctx, q, f) : (dtype == VSZIP_U16 ? launch_walk36<uint16_t>(ctx, q, f) : launch_walk36<float>(ctx, q, f));
                 else if (g.radius == 3)
-                    rc = dtype == VSZIP_U8 ? launch_walk16<3, 2, uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, 2) : launch_walk16<3, 2, float>(ctx, q, 2));
+                    rc = dtype == VSZIP_U8 ? launch_walk16<3, 2, uint8_t>(ctx, q, f) : (dtype == VSZIP_U16 ? launch_walk16<3, 2, uint16_t>(ctx, q, f) : launch_walk16<3, 2, float>(ctx, q, f));
                 else
-                    rc = dtype == VSZIP_U8 ? launch_walk16<2, 1, uint8_t>(ctx, q, 2) : (dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, 2) : launch_walk16<2, 1, float>(ctx, q, 2));
+                    rc = dtype == VSZIP_U8 ? launch_walk16<2, 1, uint8_t>(ctx, q, f) : (dtype == VSZIP_U16 ? launch_walk16<2, 1, uint16_t>(ctx, q, f) : launch_walk16<2, 1, float>(ctx, q, f));
                 if (rc != VSZIP_OK) return rc;
             }
             // planes with other tap shapes (sigmaS = 1's chroma: radius 1; sigmaS = 3's luma: radius 5) stay with the tile kernel below
@@ -1482,7 +1589,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             bool ok = tile_elems <= (size_t)kBX * kL16Rows * stages && kL16LutBytes + 2 * tile_elems * bps * (joint ? 2 : 1) <= (size_t)kL16MaxLds;
             std::vector<std::pair<uint64_t, uint32_t>> keys(n), groups;
             for (int i = 0; i < n && ok; ++i) {
-                ok = lut_plateau(prm.p[i].gr, &keys[i].first, &keys[i].second);
+                ok = lut_plateau(prm.p[i].gr, &keys[i].first, &keys[i].second) == 2;  // (the tile kernel has the plain form only)
                 if (ok && std::find(groups.begin(), groups.end(), keys[i]) == groups.end()) groups.push_back(keys[i]);
             }
             if (ok) {
