@@ -1336,7 +1336,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
     // evaluated here with the kernel's three FMAs, + the difference of the bit patterns per entry
     std::vector<float> ccoef;
     std::vector<int8_t> ccorr;
-    bool cubic = hist_len == 65536 && !packed && upper + 1 > (uint32_t)kWalkPlateauMax && !getenv("VSZIP_BILATERAL_NO_CUBIC");
+    bool cubic = hist_len == 65536 && !packed && upper + 1 > (uint32_t)kWalkPlateauMax && !getenv("VSZIP_BILATERAL_NO_CUBIC") && !getenv("VSZIP_BILATERAL_NO_LDS16");
     if (cubic) {
         ccoef.assign((size_t)kCubicSeg * 4, 0.0f);
         ccorr.assign(65536, 0);
@@ -1421,7 +1421,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
             pl.cubic[d] = {key, upper};
         }
-        if (hist_len % 4 == 0 && upper + 1 <= (uint32_t)kWalkPlateauMax) {  // (8- / 10- / 12-bit clips: the whole table is that short)
+        if (hist_len % 4 == 0 && upper + 1 <= (uint32_t)kWalkPlateauMax && !getenv("VSZIP_BILATERAL_NO_LDS16")) {  // (8- / 10- / 12-bit clips: the whole table is that short)
             uint64_t key;
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
             pl.plateau[d] = {key, upper};
