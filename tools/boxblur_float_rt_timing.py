@@ -12,16 +12,16 @@ import fixtures as fx
 import vszip_amd
 
 dev = vszip_amd.Device(0)
-frames = 4
+frames = int(os.environ.get("FRAMES", "8"))
 planes = [fx.tiled_natural(s, np.float32, p) for p, s in enumerate([(2160, 3840), (1080, 1920), (1080, 1920)])]
 srcs = [dev.upload(np.roll(p, f, axis=1)) for f in range(frames) for p in planes]
 dsts = [dev.empty(p.shape[0], p.shape[1], np.float32) for f in range(frames) for p in planes]
-for args in ((30, 1, 30, 1), (5, 3, 5, 3), (13, 1, 13, 1)):
+for args in ((30, 1, 30, 1), (5, 3, 5, 3), (5, 3, 0, 0), (0, 0, 5, 3), (2, 2, 2, 2), (13, 5, 13, 5), (13, 1, 13, 1)):
     dev.boxblur(srcs, dsts, *args)
     dev.sync()
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(10):
         dev.boxblur(srcs, dsts, *args)
     dev.sync()
-    print(f"float BoxBlur {args}: {3 * frames / (time.perf_counter() - t0):8.1f} frames/s (4K YUV420PS, {frames} frames per call)", flush=True)
+    print(f"float BoxBlur {args}: {10 * frames / (time.perf_counter() - t0):8.1f} frames/s (4K YUV420PS, {frames} frames per call)", flush=True)
 dev.close()

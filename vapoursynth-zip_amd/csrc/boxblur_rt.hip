@@ -716,6 +716,347 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
     }
 }
 
+// ---- RT float, several passes along one axis in ONE kernel ------------------------------------------------------------------------------
+// blurFloat's running sum is sequential along its line, but the PASSES of blur_passes (boxblur_runtime.zig:81-119) pipeline: stage k's output x
+// needs stage k-1's outputs x - R - 1 ... x + R only, so P stages run in lock step, stage k trailing stage k-1 by R samples, each with its own
+// running sum and the last 2 R + 2 outputs of its producer in a lane-private LDS ring (slot = sample index % D). A line is then read once and
+// written once for all P passes. At tick t the source sample t enters ring 0 and stage k = 1 ... P produces its output x = t - k R:
+//   x == 0          the initial sum of :47-50 from its producer's samples 0 ... R (all there: the producer is at R)
+//   every x         sum += (in - out) * div with the three index ranges of :55-78 (rtf_in / rtf_out above)
+// Away from the line ends the entering sample is what the previous stage produced in this very tick (a register) and the leaving one sits in the
+// slot after the one just written (`fast`); the first (P + 1) R and the last P R ticks take `tick`, which indexes the rings by sample number.
+// Every stage performs the per-pass kernel's operations on the per-pass kernel's values (an f16 plane's stage output is rounded to f16 before the
+// next stage sees it), so the bits are those of P launches. Lines of at least 2 R + 2 samples.
+template <typename T, int P, int LS /* lanes per ring row */>
+struct FChain {
+    float sum[P];
+    float carry[P];  // what the source (0) / stage k produced at the previous tick: the next stage's entering sample at this one
+    float *ring;     // this lane's column of [D][P][LS]: sample y of ring j (0: the source, k: stage k's output) sits in slot (y + j L) % D, so that at
+                     // tick t every ring's newest sample t - j L is in slot t % D and every stage's leaving sample in slot (t + 1) % D
+    int D, R, L, len;
+    float div;
+    __device__ __forceinline__ void init(float *lane_ring, int radius, int length) {
+        ring = lane_ring;
+        R = radius;
+        L = radius + 1;
+        D = 2 * radius + 3;
+        len = length;
+        div = 1.0f / (float)(radius * 2 + 1);
+#pragma unroll
+        for (int k = 0; k < P; ++k) sum[k] = carry[k] = 0.0f;
+    }
+    __device__ __forceinline__ int ticks() const { return len + P * L; }
+    __device__ __forceinline__ int lag() const { return P * L; }
+    __device__ __forceinline__ float *at(int j, int y) const { return ring + (((y + j * L) % D) * P + j) * LS; }
+    __device__ __forceinline__ bool tick(const int t, const float v, float &out) {
+        if (t < len) *at(0, t) = v;
+        carry[0] = v;
+        bool has = false;
+#pragma unroll
+        for (int k = 1; k <= P; ++k) {
+            const int x = t - k * L;
+            if (x >= 0 && x < len) {
+                if (x == 0) {
+                    float s = *at(k - 1, R);
+                    for (int j = 0; j < R; ++j) s += *at(k - 1, j) * 2;
+                    sum[k - 1] = s * div;
+                }
+                const float a = *at(k - 1, rtf_in(x, len, R)), o = *at(k - 1, rtf_out(x, R));
+                sum[k - 1] += (a - o) * div;
+                const float r = (float)(T)sum[k - 1];
+                if (k < P) {
+                    *at(k, x) = r;
+                    carry[k] = r;
+                } else {
+                    out = r;
+                    has = true;
+                }
+            }
+        }
+        return has;
+    }
+    // U ticks t ... t + U - 1 away from the line ends; c = t % D. Two things make a tick cheap. (1) The leaving samples of all U ticks are read before
+    // the first tick writes: they were produced 2 R + 2 ticks before their tick, so none is written inside a group of U <= 4 (the compiler cannot
+    // move a ring read above the ring write of the stage before on its own: it cannot know the slots differ), and one slot address per tick serves
+    // all rings (the layout above; the ring index is an immediate offset). (2) A stage trails its producer by R + 1, not R: its entering sample is what
+    // the producer made at the PREVIOUS tick (`carry`), so the P stages of a tick do not depend on one another — a wave is alone on its SIMD here
+    // (columns / rows are the only parallelism) and P dependent sub-mul-add triples per tick were most of its time.
+    template <int U>
+    __device__ __forceinline__ void fast(const int c, const float *v, float *out) {
+        if (c + U < D) {  // no slot of the group wraps: one address, the slots are immediate offsets as well
+            float *pw[U + 1];
+            float *base = ring + c * (P * LS);
+#pragma unroll
+            for (int u = 0; u <= U; ++u) pw[u] = base + u * (P * LS);
+            fast_at<U>(pw, v, out);
+        } else {
+            float *pw[U + 1];
+#pragma unroll
+            for (int u = 0; u <= U; ++u) {
+                int sl = c + u;
+                if (sl >= D) sl -= D;
+                pw[u] = ring + sl * (P * LS);
+            }
+            fast_at<U>(pw, v, out);
+        }
+    }
+    template <int U>
+    __device__ __forceinline__ void fast_at(float *const *pw, const float *v, float *out) {
+        float o[U][P];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) o[u][k] = pw[u + 1][k * LS];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float na[P + 1];
+            na[0] = v[u];
+#pragma unroll
+            for (int k = 1; k <= P; ++k) {
+                sum[k - 1] += (carry[k - 1] - o[u][k - 1]) * div;
+                na[k] = (float)(T)sum[k - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                pw[u][k * LS] = na[k];
+                carry[k] = na[k];
+            }
+            out[u] = na[P];
+        }
+    }
+    // every stage away from its line's ends at ticks t ... t + u - 1
+    __device__ __forceinline__ bool interior(int t, int u) const { return t > P * L + R && t + u <= len; }
+    __device__ __forceinline__ int first_interior() const { return P * L + R + 1; }
+};
+
+// One-wave workgroups: LDS operations of a wave execute in order, so a hand-over between lanes needs the compiler to keep the order and nothing else —
+// __syncthreads() would also wait for every load and store in flight (s_waitcnt vmcnt(0)): the end of all prefetching.
+__device__ __forceinline__ void fc_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kFcPf = 32;
+// Vertical: lane = column, the plane's rows are the ticks. Columns are the only parallelism a running sum leaves (about one wave per SIMD on 8 4K frames),
+// so what counts is a wave's own time per tick, and a wave hides the memory latency itself: three register sets of kFcPf rows rotate — one is summed
+// while two are in flight. One load instruction fetches FOUR rows (16 lanes x 4 samples each) and one store writes four, through LDS both ways: with a
+// load and a store per row the 64 memory operations s_waitcnt can count (vmcnt is 6 bits, stores included) were one group — no lookahead at all.
+template <typename T, int P>
+__global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RParams prm) {
+    extern __shared__ float fc_lds[];  // [D][P][64] rings, [kFcPf][64] parked rows (the chain takes its group's rows by a running index), [8][64] outputs
+    typedef T Raw __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int i0 = (b - pl.block0) * 64, i = i0 + lane;
+    const bool ok = i < pl.w;
+    const int qrow = lane >> 4, qcol = 4 * (lane & 15);
+    const int vcol = min(i0 + qcol, ((pl.w + 3) & ~3) - 4);  // (a lane group past the row's end re-reads the last one: its columns are never stored)
+    const T *sv = static_cast<const T *>(pl.src) + vcol;
+    T *d = static_cast<T *>(pl.dst) + min(i, pl.w - 1);
+    T *dv = static_cast<T *>(pl.dst) + i0 + qcol;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    const int len = pl.h;
+    FChain<T, P, 64> ch;
+    ch.init(fc_lds + lane, prm.radius, len);
+    const int D = ch.D;
+    float *park = fc_lds + P * D * 64, *otile = park + kFcPf * 64;
+    const int total = ch.ticks(), lag = ch.lag();
+    auto fetch = [&](int t0, Raw *f) __attribute__((always_inline)) {
+        if (t0 < len) {
+#pragma unroll
+            for (int j = 0; j < kFcPf / 4; ++j) f[j] = *reinterpret_cast<const Raw *>(sv + (size_t)min(t0 + 4 * j + qrow, len - 1) * ss);
+        }
+    };
+    const int tlo = ch.first_interior();
+    const bool deep = 2 * prm.radius + 2 >= 8;  // groups of 8 ticks: their leaving samples are all older than the group
+    auto run = [&](int t0, const Raw *q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kFcPf / 4; ++j) *reinterpret_cast<f32x4 *>(park + (4 * j + qrow) * 64 + qcol) = __builtin_convertvector(q[j], f32x4);
+        fc_wave_sync();
+        const int ne = min(kFcPf, total - t0);
+        const int e1 = min(ne, max(0, tlo - t0)), e2 = min(ne, len - t0);  // [e1, e2): every stage away from the line's ends
+        int u0 = 0;
+        for (; u0 < e1; ++u0) {
+            float r;
+            if (ch.tick(t0 + u0, park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+        }
+        int c = (t0 + u0) % D;
+        if (deep) {
+            for (; u0 + 8 <= e2; u0 += 8) {
+                float v[8], r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = park[(u0 + u) * 64 + lane];
+                ch.template fast<8>(c, v, r);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) otile[u * 64 + lane] = r[u];
+                fc_wave_sync();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 o4 = *reinterpret_cast<const f32x4 *>(otile + (4 * h + qrow) * 64 + qcol);
+                    const Raw w4 = __builtin_convertvector(o4, Raw);
+                    T *dp = dv + (size_t)(t0 + u0 - lag + 4 * h + qrow) * ds;
+                    if (i0 + qcol + 3 < pl.w) {
+                        *reinterpret_cast<Raw *>(dp) = w4;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (i0 + qcol + e < pl.w) dp[e] = w4[e];
+                    }
+                }
+                fc_wave_sync();
+                c += 8;
+                if (c >= D) c -= D;
+            }
+        }
+        for (; u0 + 4 <= e2; u0 += 4) {
+            float v[4], r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = park[(u0 + u) * 64 + lane];
+            ch.template fast<4>(c, v, r);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) otile[u * 64 + lane] = r[u];
+            fc_wave_sync();
+            const f32x4 o4 = *reinterpret_cast<const f32x4 *>(otile + qrow * 64 + qcol);
+            const Raw w4 = __builtin_convertvector(o4, Raw);
+            T *dp = dv + (size_t)(t0 + u0 - lag + qrow) * ds;
+            if (i0 + qcol + 3 < pl.w) {
+                *reinterpret_cast<Raw *>(dp) = w4;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + qcol + e < pl.w) dp[e] = w4[e];
+            }
+            fc_wave_sync();
+            c += 4;
+            if (c >= D) c -= D;
+        }
+        for (; u0 < e2; ++u0) {
+            float v = park[u0 * 64 + lane], r;
+            ch.template fast<1>(c, &v, &r);
+            if (ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            c = c + 1 == D ? 0 : c + 1;
+        }
+        for (; u0 < ne; ++u0) {
+            float r;
+            if (ch.tick(t0 + u0, park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+        }
+        fc_wave_sync();
+    };
+    Raw b0[kFcPf / 4], b1[kFcPf / 4], b2[kFcPf / 4];
+    fetch(0, b0);
+    fetch(kFcPf, b1);
+    for (int t0 = 0; t0 < total; t0 += 3 * kFcPf) {
+        fetch(t0 + 2 * kFcPf, b2);
+        run(t0, b0);
+        if (t0 + kFcPf >= total) break;
+        fetch(t0 + 3 * kFcPf, b0);
+        run(t0 + kFcPf, b1);
+        if (t0 + 2 * kFcPf >= total) break;
+        fetch(t0 + 4 * kFcPf, b1);
+        run(t0 + 2 * kFcPf, b2);
+    }
+}
+
+// Horizontal: lane = row for the chain, lane = column for memory: 64 source columns of the wave's 64 rows enter through one LDS tile, the last stage's
+// outputs leave through another, flushed whenever its 64 columns are complete. All 64 lanes carry a row (the per-pass kernel takes 16 rows a wave for
+// more waves; here a wave's time is the line's ticks times the cost of a tick whatever its row count, and a SIMD runs two waves no faster than one).
+constexpr int kFcRB = 64;
+template <typename T, int P>
+__global__ __launch_bounds__(64) void boxblur_rt_float_hchain_kernel(const RParams prm) {
+    constexpr int RB = kFcRB;
+    extern __shared__ float fc_lds[];  // [D][P][RB] rings
+    __shared__ float tin[RB][65], tout[RB][65];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int y0 = (b - pl.block0) * RB;
+    const int rows = min(RB, pl.h - y0), len = pl.w;
+    const T *s = static_cast<const T *>(pl.src) + (size_t)y0 * pl.sstride;
+    T *d = static_cast<T *>(pl.dst) + (size_t)y0 * pl.dstride;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    FChain<T, P, RB> ch;
+    ch.init(fc_lds + lane, prm.radius, len);
+    const int D = ch.D;
+    const int total = ch.ticks(), lag = ch.lag(), tlo = ch.first_interior();
+    const bool deep = 2 * prm.radius + 2 >= 8;  // groups of 8 ticks: their leaving samples are all older than the group
+    const int nchunk = (total + 63) / 64;
+    float ni[RB];
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+        const int x = min(c * 64 + lane, len - 1);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) ni[r] = (float)s[(size_t)min(r, rows - 1) * ss + x];
+    };
+    fetch(0);
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) tin[r][lane] = ni[r];
+        fc_wave_sync();
+        if ((c + 1) * 64 < len) fetch(c + 1);
+        const int t0 = c * 64, kmax = min(64, total - t0);
+        int k = 0;
+        while (k < kmax) {
+            const int xp = t0 + k - lag;                      // the column the last stage produces at tick t0 + k
+            const int kend = min(kmax, k + 64 - (xp & 63));  // up to the end of its 64-column tile
+            if (lane < rows) {
+                int kk = k;
+                const int e1 = min(kend, max(k, tlo - t0)), e2 = min(kend, len - t0);  // [e1, e2): every stage away from the line's ends
+                for (; kk < e1; ++kk) {
+                    float r;
+                    if (ch.tick(t0 + kk, tin[lane][kk], r)) tout[lane][(t0 + kk - lag) & 63] = r;
+                }
+                int cc = (t0 + kk) % D;
+                if (deep) {
+                    for (; kk + 8 <= e2; kk += 8) {
+                        float v[8], r[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = tin[lane][kk + u];
+                        ch.template fast<8>(cc, v, r);
+                        float *to = &tout[lane][(t0 + kk - lag) & 63];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) to[u] = r[u];
+                        cc += 8;
+                        if (cc >= D) cc -= D;
+                    }
+                }
+                for (; kk + 4 <= e2; kk += 4) {
+                    float v[4], r[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = tin[lane][kk + u];
+                    ch.template fast<4>(cc, v, r);
+                    float *to = &tout[lane][(t0 + kk - lag) & 63];  // (a segment ends with its output tile: the four do not wrap)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) to[u] = r[u];
+                    cc += 4;
+                    if (cc >= D) cc -= D;
+                }
+                for (; kk < e2; ++kk) {
+                    float v = tin[lane][kk], r;
+                    ch.template fast<1>(cc, &v, &r);
+                    tout[lane][(t0 + kk - lag) & 63] = r;
+                    cc = cc + 1 == D ? 0 : cc + 1;
+                }
+                for (; kk < kend; ++kk) {
+                    float r;
+                    if (ch.tick(t0 + kk, tin[lane][kk], r)) tout[lane][(t0 + kk - lag) & 63] = r;
+                }
+            }
+            fc_wave_sync();
+            const int xl = t0 + kend - 1 - lag;
+            if (xl >= 0 && ((xl & 63) == 63 || xl == len - 1)) {
+                const int x = (xl & ~63) + lane;
+                if (x < len) {
+#pragma unroll 8
+                    for (int r = 0; r < rows; ++r) d[(size_t)r * ds + x] = (T)tout[r][lane];
+                }
+                fc_wave_sync();
+            }
+            k = kend;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Round 3 — several integer passes along one axis in ONE kernel (blur_passes, boxblur_runtime.zig:81-119): a 256-thread
 // workgroup owns a row; a thread keeps its 16 contiguous samples in REGISTERS across the passes. Per pass: in-thread
@@ -1293,6 +1634,60 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
     return VSZIP_OK;
 }
 
+// The float chain kernels: 2 ... 5 passes, lines of at least 2 R + 2 samples, rings within one workgroup's LDS.
+constexpr int kFcMaxPass = 5;
+template <typename T>
+bool fchain_ok(const std::vector<RPlane> &pl, int radius, int npass, bool vertical) {
+    if (getenv("VSZIP_RT_NO_FCHAIN") || npass < 2 || npass > kFcMaxPass) return false;
+    const size_t lds = vertical ? ((size_t)npass * (2 * radius + 3) + kFcPf + 8) * 64 * sizeof(float) : (size_t)npass * (2 * radius + 3) * kFcRB * sizeof(float);
+    if (lds > (vertical ? 48 : 30) * 1024) return false;  // (the horizontal kernel also holds two 64 x 64 tiles)
+    for (const RPlane &q : pl) {
+        if ((vertical ? q.h : q.w) < 2 * radius + 2) return false;
+        if (vertical) {  // rows go four samples a lane
+            const uintptr_t bits = reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) | (uintptr_t)((size_t)q.dstride * sizeof(T));
+            if ((bits & (4 * sizeof(T) - 1)) != 0 || q.sstride < ((q.w + 3) & ~3) || q.w < 4) return false;
+        }
+    }
+    return true;
+}
+
+template <typename T>
+int launch_fchain(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool vertical, bool keep) {
+    size_t done = 0;
+    while (done < pl.size()) {
+        RParams prm;
+        const int n = (int)std::min<size_t>(kMaxPlanesRT, pl.size() - done);
+        prm.nplanes = n;
+        prm.radius = radius;
+        prm.keep = keep ? 1 : 0;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            prm.p[i] = pl[done + i];
+            prm.p[i].block0 = blocks;
+            blocks += vertical ? (prm.p[i].w + 63) / 64 : (prm.p[i].h + kFcRB - 1) / kFcRB;
+        }
+        const int D = 2 * radius + 3;
+        const size_t lds = vertical ? ((size_t)npass * D + kFcPf + 8) * 64 * sizeof(float) : (size_t)npass * D * kFcRB * sizeof(float);
+#define VSZIP_FC_LAUNCH(PP)                                                                                                        \
+    case PP:                                                                                                                       \
+        if (vertical)                                                                                                              \
+            hipLaunchKernelGGL((boxblur_rt_float_vchain_kernel<T, PP>), dim3(blocks), dim3(64), lds, ctx->stream, prm);           \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((boxblur_rt_float_hchain_kernel<T, PP>), dim3(blocks), dim3(64), lds, ctx->stream, prm);           \
+        break;
+        switch (npass) {
+            VSZIP_FC_LAUNCH(2)
+            VSZIP_FC_LAUNCH(3)
+            VSZIP_FC_LAUNCH(4)
+            VSZIP_FC_LAUNCH(5)
+        }
+#undef VSZIP_FC_LAUNCH
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
+    }
+    return VSZIP_OK;
+}
+
 template <typename T>
 int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses) {
     // boxblur.zig:85-112: hpasses horizontal passes, then vpasses vertical passes
@@ -1464,7 +1859,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
             const bool vertical = p >= (hb ? hpasses : 0);
             // every horizontal pass of a small radius at once (round 3): the step then stands for hpasses passes
             int span = 1;
-            if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) {
+            if constexpr (!std::is_integral<T>::value || sizeof(T) <= 2) {
                 if (p == 0 && hb && hpasses >= 2) span = hpasses;
                 if (vertical && p == (hb ? hpasses : 0) && vpasses >= 2) span = vpasses;
             }
@@ -1479,7 +1874,11 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
                 }
             }
             int rc;
-            if (span > 1 && !vertical && hsmall_ok<T>(cur, hradius, hpasses)) {
+            if (!std::is_integral<T>::value && span > 1 && fchain_ok<T>(cur, vertical ? vradius : hradius, span, vertical)) {
+                if constexpr (!std::is_integral<T>::value) rc = launch_fchain<T>(ctx, cur, vertical ? vradius : hradius, span, vertical, !last);
+                else rc = VSZIP_ERR_ARG;
+                p += span - 1;
+            } else if (span > 1 && !vertical && hsmall_ok<T>(cur, hradius, hpasses)) {
                 if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_hsmall<T>(ctx, cur, hradius, hpasses, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
