@@ -565,6 +565,14 @@ __global__ __launch_bounds__(64) void boxblur_rt_hring_kernel(const RParams prm)
 #ifndef VSZIP_RTF_RB
 #define VSZIP_RTF_RB 16
 #endif
+// One-wave workgroups: LDS operations of a wave execute in order, so a hand-over between lanes needs the compiler to keep the order and nothing else —
+// __syncthreads() would also wait for every load and store in flight (s_waitcnt vmcnt(0)): the end of all prefetching.
+__device__ __forceinline__ void fc_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- RT float: blurFloat (:43-79) — a running f32 sum per line, sequential by definition ------
 // Index of the sample entering / leaving the window at output x (the three loops of blurFloat :55-78
 // as one pair of functions: x <= R, R < x < len - R, x >= len - R).
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
             tin[r][lane] = ni[r];
             tout[r][lane] = no[r];
         }
-        __syncthreads();
+        fc_wave_sync();
         if (c + 1 < nchunk) fetch(c + 1);
         const int x0 = c * 64, cw = min(64, len - x0);
         if (lane < rows) {
@@ -707,12 +715,12 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
                 tin[lane][k] = sum;
             }
         }
-        __syncthreads();
+        fc_wave_sync();
         if (lane < cw) {
 #pragma unroll 8
             for (int r = 0; r < rows; ++r) d[(size_t)r * ds + x0 + lane] = (T)tin[r][lane];
         }
-        __syncthreads();
+        fc_wave_sync();
     }
 }
 
@@ -829,14 +837,6 @@ struct FChain {
     __device__ __forceinline__ bool interior(int t, int u) const { return t > P * L + R && t + u <= len; }
     __device__ __forceinline__ int first_interior() const { return P * L + R + 1; }
 };
-
-// One-wave workgroups: LDS operations of a wave execute in order, so a hand-over between lanes needs the compiler to keep the order and nothing else —
-// __syncthreads() would also wait for every load and store in flight (s_waitcnt vmcnt(0)): the end of all prefetching.
-__device__ __forceinline__ void fc_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 constexpr int kFcPf = 32;
 // Vertical: lane = column, the plane's rows are the ticks. Columns are the only parallelism a running sum leaves (about one wave per SIMD on 8 4K frames),
