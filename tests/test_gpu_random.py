@@ -82,6 +82,44 @@ def test_boxblur_float_random(dev, oracle, seed):
     assert np.array_equal(dev.download(d).view(np.uint8), oracle.boxblur(p, r, 1, r, 1).view(np.uint8)), (seed, r, h, w)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_boxblur_float_runtime_passes_random(dev, oracle, seed):
+    """The runtime float path: 1 ... 6 passes on either axis (2 ... 5 take the pass-chain kernels, 1 and 6 a launch per pass), radii up to 30, f32 and f16,
+    batches of planes of mixed sizes, lines from barely 2 R + 2 samples to several prefetch groups / tiles; the pass chain against a launch per pass as well."""
+    rng = np.random.default_rng(SEED_BASE + 2300 + seed)
+    dtype = [np.float32, np.float16][seed % 2]
+    hr, vr = int(rng.integers(1, 31)), int(rng.integers(1, 31))
+    if seed % 3 == 0:
+        hr, vr = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    hp, vp = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    if seed % 4 == 1:
+        hr = 0  # vertical passes only
+    if seed % 4 == 3:
+        vr = 0
+    planes = []
+    for _ in range(int(rng.integers(1, 4))):
+        h = int(rng.integers(2 * vr + 2, 2 * vr + 3 + [6, 80, 400][int(rng.integers(0, 3))]))
+        w = int(rng.integers(2 * hr + 2, 2 * hr + 3 + [6, 80, 400][int(rng.integers(0, 3))]))
+        planes.append(_plane(rng, (h, w), dtype))
+
+    def run():
+        srcs = [dev.upload(p) for p in planes]
+        dsts = [dev.empty(p.shape[0], p.shape[1], dtype) for p in planes]
+        dev.boxblur(srcs, dsts, hr, hp, vr, vp)
+        return [dev.download(d) for d in dsts]
+
+    got = run()
+    os.environ["VSZIP_RT_NO_FCHAIN"] = "1"
+    try:
+        per_pass = run()
+    finally:
+        del os.environ["VSZIP_RT_NO_FCHAIN"]
+    for p, a, b in zip(planes, got, per_pass):
+        want = oracle.boxblur(p, hr, hp, vr, vp)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (seed, (hr, hp, vr, vp), p.shape, "chain vs per pass", np.argwhere(a != b)[:3].tolist())
+        assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (seed, (hr, hp, vr, vp), p.shape, np.argwhere(a != want)[:3].tolist())
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_boxblur_float_ring_random(dev, oracle, seed):
     """Planes large enough for the float register-ring kernel, in batches of mixed sizes: column-tile counts, bands that
