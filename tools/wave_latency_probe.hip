@@ -1,5 +1,5 @@
 // GPU box: what ONE wave alone on its SIMD pays per instruction — dependent f32 adds, independent f32 adds, an LDS write -> read round trip,
-// SALU adds — in ns (HIP events around 1 workgroup x 64 threads, and around 1024 such workgroups: one per SIMD).
+// independent f64 FMAs — in ns (HIP events around 1 workgroup x 64 threads, and around 1024 such workgroups: one per SIMD).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/wave_latency_probe.bin tools/wave_latency_probe.hip && tools/wave_latency_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,13 +40,18 @@ __global__ void lds_rt(float *out, float a) {
     }
     out[threadIdx.x + blockIdx.x * 64] = x;
 }
-__global__ void salu(float *out, int a) {
-    int s = a;
+__global__ void indep_fma64(float *out, float a) {
+    double x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3, b = a;
     for (int i = 0; i < N; ++i) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) asm volatile("s_add_i32 %0, %0, %1" : "+s"(s) : "s"(a));
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x0) : "v"(b));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x1) : "v"(b));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x2) : "v"(b));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x3) : "v"(b));
+        }
     }
-    out[threadIdx.x + blockIdx.x * 64] = s;
+    out[threadIdx.x + blockIdx.x * 64] = (float)(x0 + x1 + x2 + x3);
 }
 template <typename F>
 static void run(const char *name, F f, int blocks, double ops) {
@@ -58,12 +63,12 @@ static void run(const char *name, F f, int blocks, double ops) {
     printf("%-28s %5d waves: %7.2f ns per op\n", name, blocks, ms * 1e6 / ops);
 }
 int main() {
-    float *out; hipMalloc(&out, 4096 * 64 * 4);
-    for (int blocks : {1, 1024, 2048}) {
+    float *out; hipMalloc(&out, 8192 * 64 * 4);
+    for (int blocks : {1, 1024, 2048, 4096, 8192}) {
         run("dependent v_add_f32", [&](int b) { dep_add<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
         run("4 independent v_add_f32", [&](int b) { indep_add<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
         run("LDS write->read round trip", [&](int b) { lds_rt<<<b, 64>>>(out, 1.0f); }, blocks, 4.0 * N);
-        run("s_add_i32 (dependent)", [&](int b) { salu<<<b, 64>>>(out, 1); }, blocks, 16.0 * N);
+        run("4 independent v_fma_f64", [&](int b) { indep_fma64<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
     }
     return 0;
 }
