@@ -134,13 +134,13 @@ def test_rt_float_pass_chain_kernels(dev, oracle, dtype, monkeypatch):
     """Round 3: float planes with 2 ... 5 passes on an axis run them in ONE launch per axis (a chain of running sums, each stage R samples
     behind its producer: boxblur_rt_float_vchain_kernel / _hchain_kernel). Bit for bit the one-launch-per-pass kernels and the oracle: lines
     barely longer than 2 R + 2, lines shorter than one prefetch group / tile, widths and heights that are not whole tiles, line lengths around
-    the multiples of 64 and of the prefetch depth, radii whose ring wraps at every phase, f16 planes (every stage rounds to f16), six passes
-    (falls back to a launch per pass), lines too short for the chain (fall back as well)."""
+    the multiples of 64 and of the prefetch depth, radii whose ring wraps at every phase, f16 planes (every stage rounds to f16), more than five
+    passes (6 = 3 + 3, 7 = 4 + 3, 11 = 5 + 5 + ... chained launches), lines too short for the chain (a launch per pass)."""
     cases = [([(72, 208), (36, 104), (36, 104)], (1, 2, 1, 2)), ([(300, 333)], (2, 3, 2, 2)), ([(70, 1100)], (3, 4, 0, 0)), ([(700, 96)], (0, 0, 4, 2)),
              ([(135, 251), (67, 125)], (5, 3, 5, 3)), ([(233, 130)], (7, 3, 8, 5)), ([(40, 35), (35, 40)], (8, 2, 8, 2)), ([(90, 640)], (1, 5, 1, 4)),
              ([(19, 40)], (2, 2, 2, 2)), ([(18, 18)], (8, 2, 8, 3)), ([(64, 64)], (3, 3, 3, 3)), ([(65, 63)], (4, 2, 2, 5)), ([(128, 129)], (6, 3, 6, 2)),
              ([(81, 257)], (30, 2, 25, 2)), ([(150, 191)], (13, 5, 13, 5)), ([(48, 48)], (2, 6, 2, 6)), ([(16, 300)], (9, 2, 9, 2)), ([(33, 17)], (1, 3, 1, 3)),
-             ([(100, 200)], (5, 3, 0, 0)), ([(100, 200)], (0, 0, 5, 3)), ([(97, 1)], (0, 0, 3, 2)), ([(1, 97)], (3, 2, 0, 0))]
+             ([(100, 200)], (5, 3, 0, 0)), ([(100, 200)], (0, 0, 5, 3)), ([(60, 90)], (1, 11, 1, 7)), ([(70, 333)], (3, 8, 0, 0)), ([(200, 40)], (0, 0, 2, 12)), ([(97, 1)], (0, 0, 3, 2)), ([(1, 97)], (3, 2, 0, 0))]
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(31 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
 

@@ -1859,7 +1859,11 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
             const bool vertical = p >= (hb ? hpasses : 0);
             // every horizontal pass of a small radius at once (round 3): the step then stands for hpasses passes
             int span = 1;
-            if constexpr (!std::is_integral<T>::value || sizeof(T) <= 2) {
+            if constexpr (!std::is_integral<T>::value) {
+                // float: what is left of this axis's passes in chains of up to kFcMaxPass stages (6 = 3 + 3 rather than 5 + 1: a lone pass is a launch of its own)
+                const int rem = vertical ? total - p : hpasses - p;
+                if (rem >= 2) span = rem <= kFcMaxPass ? rem : (rem - kFcMaxPass == 1 ? kFcMaxPass - 1 : kFcMaxPass);
+            } else if constexpr (sizeof(T) <= 2) {
                 if (p == 0 && hb && hpasses >= 2) span = hpasses;
                 if (vertical && p == (hb ? hpasses : 0) && vpasses >= 2) span = vpasses;
             }
