@@ -295,7 +295,10 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
              ([(135, 251), (67, 125)], (5, 2, 6, 2)), ([(533, 130)], (7, 3, 8, 2)), ([(40, 35), (35, 40)], (8, 2, 8, 2)), ([(290, 640)], (1, 4, 1, 2)),
              ([(19, 40)], (2, 2, 2, 2)), ([(1080, 520)], (2, 2, 3, 2)),
              # radii 9 .. 16: the horizontal kernel reads two neighbour groups on either side (13 x 5 passes is the reference README's third benchmark)
-             ([(72, 300), (36, 150)], (13, 5, 13, 5)), ([(90, 257)], (16, 2, 9, 2)), ([(64, 333)], (11, 3, 0, 0)), ([(50, 35)], (9, 4, 1, 2)), ([(40, 4104)], (12, 2, 0, 0))]
+             ([(72, 300), (36, 150)], (13, 5, 13, 5)), ([(90, 257)], (16, 2, 9, 2)), ([(64, 333)], (11, 3, 0, 0)), ([(50, 35)], (9, 4, 1, 2)), ([(40, 4104)], (12, 2, 0, 0)),
+             # the vertical pass chain (3 ... 5 stages, more passes in several chains; radii to 30; lines of 2 R + 2 rows up; widths that are not whole 4-sample groups)
+             ([(200, 70)], (0, 0, 2, 3)), ([(333, 131)], (0, 0, 5, 3)), ([(64, 64)], (0, 0, 3, 4)), ([(96, 35)], (0, 0, 1, 5)), ([(130, 200), (65, 100)], (2, 2, 3, 7)),
+             ([(62, 48)], (0, 0, 30, 2)), ([(150, 41)], (0, 0, 22, 3)), ([(28, 260)], (0, 0, 13, 2)), ([(300, 5)], (0, 0, 4, 6)), ([(45, 3)], (0, 0, 2, 3)), ([(1080, 36)], (0, 0, 13, 5))]
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(11 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
 
@@ -306,15 +309,23 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
             return [dev.download(d) for d in dsts]
 
         got = run()
+        monkeypatch.setenv("VSZIP_RT_ICHAIN_ALL", "1")  # the vertical pass chain wherever it can run (8-bit planes take it from five passes on only)
+        chain_all = run()
+        monkeypatch.setenv("VSZIP_RT_NO_VSMALL", "1")   # ... and for two passes of a small radius too
+        chain_2 = run()
+        monkeypatch.delenv("VSZIP_RT_ICHAIN_ALL")
         monkeypatch.setenv("VSZIP_RT_NO_HSMALL", "1")
-        monkeypatch.setenv("VSZIP_RT_NO_VSMALL", "1")
+        monkeypatch.setenv("VSZIP_RT_NO_ICHAIN", "1")
         per_pass = run()
         monkeypatch.delenv("VSZIP_RT_NO_HSMALL")
         monkeypatch.delenv("VSZIP_RT_NO_VSMALL")
-        for p, a, b in zip(planes, got, per_pass):
+        monkeypatch.delenv("VSZIP_RT_NO_ICHAIN")
+        for p, a, b, c, c2 in zip(planes, got, per_pass, chain_all, chain_2):
             want = oracle.boxblur(p, *args)
             assert np.array_equal(a, want), (shapes, args, int((a != want).sum()))
             assert np.array_equal(b, want), (shapes, args, "per pass")
+            assert np.array_equal(c, want), (shapes, args, "pass chain", int((c != want).sum()), np.argwhere(c != want)[:3].tolist())
+            assert np.array_equal(c2, want), (shapes, args, "pass chain, two stages", int((c2 != want).sum()))
     # three and four vertical stages (not the default: measured slower than a launch per pass)
     monkeypatch.setenv("VSZIP_RT_VSMALL_MAX", "4")
     for shapes, args in [([(300, 333)], (2, 2, 2, 3)), ([(521, 96), (260, 48)], (0, 0, 3, 4)), ([(70, 520)], (1, 2, 1, 4)), ([(1080, 512)], (0, 0, 2, 3))]:

@@ -120,6 +120,44 @@ def test_boxblur_float_runtime_passes_random(dev, oracle, seed):
         assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (seed, (hr, hp, vr, vp), p.shape, np.argwhere(a != want)[:3].tolist())
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_boxblur_int_runtime_passes_random(dev, oracle, seed):
+    """The runtime integer path with several passes: whatever the library picks (all horizontal passes in one launch, two vertical stages, the vertical pass
+    chain, a launch per pass), the vertical pass chain forced wherever it can run, and a launch per pass — all three the oracle's bits. u8 / u16, radii to 30,
+    1 ... 7 passes, batches of planes of mixed sizes, widths that are not whole sample groups, lines from 2 R + 2 samples up."""
+    rng = np.random.default_rng(SEED_BASE + 2400 + seed)
+    dtype = [np.uint16, np.uint8][seed % 2]
+    hr, vr = int(rng.integers(1, 31)), int(rng.integers(1, 31))
+    if seed % 3 == 0:
+        hr, vr = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    hp, vp = int(rng.integers(1, 8)), int(rng.integers(2, 8))
+    if seed % 4 == 1:
+        hr = 0
+    planes = []
+    for _ in range(int(rng.integers(1, 4))):
+        h = int(rng.integers(2 * vr + 2, 2 * vr + 3 + [6, 80, 400][int(rng.integers(0, 3))]))
+        w = int(rng.integers(2 * hr + 2, 2 * hr + 3 + [6, 80, 400][int(rng.integers(0, 3))]))
+        planes.append(_plane(rng, (h, w), dtype))
+
+    def run(env):
+        for k in env:
+            os.environ[k] = "1"
+        try:
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], dtype) for p in planes]
+            dev.boxblur(srcs, dsts, hr, hp, vr, vp)
+            return [dev.download(d) for d in dsts]
+        finally:
+            for k in env:
+                del os.environ[k]
+
+    outs = {"default": run([]), "chain": run(["VSZIP_RT_ICHAIN_ALL", "VSZIP_RT_NO_VSMALL"]), "per pass": run(["VSZIP_RT_NO_ICHAIN", "VSZIP_RT_NO_VSMALL", "VSZIP_RT_NO_HSMALL"])}
+    for i, p in enumerate(planes):
+        want = oracle.boxblur(p, hr, hp, vr, vp)
+        for name, o in outs.items():
+            assert np.array_equal(o[i], want), (seed, name, (hr, hp, vr, vp), p.shape, np.argwhere(o[i] != want)[:3].tolist())
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_boxblur_float_ring_random(dev, oracle, seed):
     """Planes large enough for the float register-ring kernel, in batches of mixed sizes: column-tile counts, bands that

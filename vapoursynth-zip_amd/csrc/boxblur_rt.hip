@@ -735,29 +735,76 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_h_kernel(const RParams pr
 // slot after the one just written (`fast`); the first (P + 1) R and the last P R ticks take `tick`, which indexes the rings by sample number.
 // Every stage performs the per-pass kernel's operations on the per-pass kernel's values (an f16 plane's stage output is rounded to f16 before the
 // next stage sees it), so the bits are those of P launches. Lines of at least 2 R + 2 samples.
+// What a stage computes, float (blurFloat :43-79) or integer (blurInt :10-41 in the closed form of the per-pass kernels above: dst = (inv2 * E + 32768 +
+// ((E_0 * invlo) >> 16)) >> 16 with E the window sum; E_0, the stage's first window sum, is what its initial sum is). E: a sample in LDS, V: in registers, S: the sum.
+template <typename T>
+struct FcArithF {
+    using E = float;
+    using V = float;
+    using S = float;
+    float div;
+    __device__ __forceinline__ void setup(int R) { div = 1.0f / (float)(R * 2 + 1); }
+    __device__ __forceinline__ void start(S &sum, uint32_t &, V s) const { sum = s * div; }
+    __device__ __forceinline__ V step(S &sum, uint32_t, V a, V o) const {
+        sum += (a - o) * div;
+        return (float)(T)sum;
+    }
+};
+template <typename T>
+struct FcArithI {
+    using E = uint16_t;
+    using V = uint32_t;
+    using S = uint32_t;
+    uint32_t inv2, invlo;
+    __device__ __forceinline__ void setup(int R) {
+        const uint32_t ksize = 2u * (uint32_t)R + 1u;
+        const uint64_t inv = ((1ull << 32) + (uint64_t)R) / ksize;
+        inv2 = (uint32_t)(inv >> 16);
+        invlo = (uint32_t)(inv & 0xffffu);
+    }
+    __device__ __forceinline__ void start(S &sum, uint32_t &kk, V s) const {
+        sum = s;
+        kk = 32768u + (uint32_t)(((uint64_t)s * invlo) >> 16);
+    }
+    __device__ __forceinline__ V step(S &sum, uint32_t kk, V a, V o) const {
+        sum += a - o;
+        return ((uint32_t)__umul24(sum, inv2) + kk) >> 16;  // (the window sum of a chain radius is below 2^24: R <= 127)
+    }
+};
+template <typename T>
+using FcArith = typename std::conditional<std::is_integral<T>::value, FcArithI<T>, FcArithF<T>>::type;
+
 template <typename T, int P, int LS /* lanes per ring row */>
 struct FChain {
-    float sum[P];
-    float carry[P];  // what the source (0) / stage k produced at the previous tick: the next stage's entering sample at this one
-    float *ring;     // this lane's column of [D][P][LS]: sample y of ring j (0: the source, k: stage k's output) sits in slot (y + j L) % D, so that at
+    using A = FcArith<T>;
+    using E = typename A::E;
+    using V = typename A::V;
+    A ar;
+    typename A::S sum[P];
+    uint32_t kk[P];  // (integer stages: 32768 + ((E_0 * invlo) >> 16))
+    V carry[P];      // what the source (0) / stage k produced at the previous tick: the next stage's entering sample at this one
+    E *ring;         // this lane's column of [D][P][LS]: sample y of ring j (0: the source, k: stage k's output) sits in slot (y + j L) % D, so that at
                      // tick t every ring's newest sample t - j L is in slot t % D and every stage's leaving sample in slot (t + 1) % D
     int D, R, L, len;
-    float div;
-    __device__ __forceinline__ void init(float *lane_ring, int radius, int length) {
+    __device__ __forceinline__ void init(E *lane_ring, int radius, int length) {
         ring = lane_ring;
         R = radius;
         L = radius + 1;
         D = 2 * radius + 3;
         len = length;
-        div = 1.0f / (float)(radius * 2 + 1);
+        ar.setup(radius);
 #pragma unroll
-        for (int k = 0; k < P; ++k) sum[k] = carry[k] = 0.0f;
+        for (int k = 0; k < P; ++k) {
+            sum[k] = 0;
+            carry[k] = 0;
+            kk[k] = 0;
+        }
     }
     __device__ __forceinline__ int ticks() const { return len + P * L; }
     __device__ __forceinline__ int lag() const { return P * L; }
-    __device__ __forceinline__ float *at(int j, int y) const { return ring + (((y + j * L) % D) * P + j) * LS; }
-    __device__ __forceinline__ bool tick(const int t, const float v, float &out) {
-        if (t < len) *at(0, t) = v;
+    __device__ __forceinline__ E *at(int j, int y) const { return ring + (((y + j * L) % D) * P + j) * LS; }
+    __device__ __forceinline__ bool tick(const int t, const V v, V &out) {
+        if (t < len) *at(0, t) = (E)v;
         carry[0] = v;
         bool has = false;
 #pragma unroll
@@ -765,15 +812,14 @@ struct FChain {
             const int x = t - k * L;
             if (x >= 0 && x < len) {
                 if (x == 0) {
-                    float s = *at(k - 1, R);
-                    for (int j = 0; j < R; ++j) s += *at(k - 1, j) * 2;
-                    sum[k - 1] = s * div;
+                    V s = (V)*at(k - 1, R);
+                    for (int j = 0; j < R; ++j) s += (V)*at(k - 1, j) * 2;
+                    ar.start(sum[k - 1], kk[k - 1], s);
                 }
-                const float a = *at(k - 1, rtf_in(x, len, R)), o = *at(k - 1, rtf_out(x, R));
-                sum[k - 1] += (a - o) * div;
-                const float r = (float)(T)sum[k - 1];
+                const V a = (V)*at(k - 1, rtf_in(x, len, R)), o = (V)*at(k - 1, rtf_out(x, R));
+                const V r = ar.step(sum[k - 1], kk[k - 1], a, o);
                 if (k < P) {
-                    *at(k, x) = r;
+                    *at(k, x) = (E)r;
                     carry[k] = r;
                 } else {
                     out = r;
@@ -790,15 +836,15 @@ struct FChain {
     // the producer made at the PREVIOUS tick (`carry`), so the P stages of a tick do not depend on one another — a wave is alone on its SIMD here
     // (columns / rows are the only parallelism) and P dependent sub-mul-add triples per tick were most of its time.
     template <int U>
-    __device__ __forceinline__ void fast(const int c, const float *v, float *out) {
+    __device__ __forceinline__ void fast(const int c, const V *v, V *out) {
         if (c + U < D) {  // no slot of the group wraps: one address, the slots are immediate offsets as well
-            float *pw[U + 1];
-            float *base = ring + c * (P * LS);
+            E *pw[U + 1];
+            E *base = ring + c * (P * LS);
 #pragma unroll
             for (int u = 0; u <= U; ++u) pw[u] = base + u * (P * LS);
             fast_at<U>(pw, v, out);
         } else {
-            float *pw[U + 1];
+            E *pw[U + 1];
 #pragma unroll
             for (int u = 0; u <= U; ++u) {
                 int sl = c + u;
@@ -809,25 +855,22 @@ struct FChain {
         }
     }
     template <int U>
-    __device__ __forceinline__ void fast_at(float *const *pw, const float *v, float *out) {
-        float o[U][P];
+    __device__ __forceinline__ void fast_at(E *const *pw, const V *v, V *out) {
+        V o[U][P];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int k = 0; k < P; ++k) o[u][k] = pw[u + 1][k * LS];
+            for (int k = 0; k < P; ++k) o[u][k] = (V)pw[u + 1][k * LS];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float na[P + 1];
+            V na[P + 1];
             na[0] = v[u];
 #pragma unroll
-            for (int k = 1; k <= P; ++k) {
-                sum[k - 1] += (carry[k - 1] - o[u][k - 1]) * div;
-                na[k] = (float)(T)sum[k - 1];
-            }
+            for (int k = 1; k <= P; ++k) na[k] = ar.step(sum[k - 1], kk[k - 1], carry[k - 1], o[u][k - 1]);
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                pw[u][k * LS] = na[k];
+                pw[u][k * LS] = (E)na[k];
                 carry[k] = na[k];
             }
             out[u] = na[P];
@@ -845,9 +888,13 @@ constexpr int kFcPf = 32;
 // load and a store per row the 64 memory operations s_waitcnt can count (vmcnt is 6 bits, stores included) were one group — no lookahead at all.
 template <typename T, int P>
 __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RParams prm) {
-    extern __shared__ float fc_lds[];  // [D][P][64] rings, [kFcPf][64] parked rows (the chain takes its group's rows by a running index), [8][64] outputs
+    using CH = FChain<T, P, 64>;
+    using E = typename CH::E;  // float planes: f32 in LDS; integer planes (the same chain with blurInt's closed form as the stage): u16
+    using V = typename CH::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fc_lds_raw[];  // [D][P][64] rings, [kFcPf][64] parked rows (the chain takes its group's rows by a running index), [8][64] outputs
+    E *fc_lds = reinterpret_cast<E *>(fc_lds_raw);
     typedef T Raw __attribute__((ext_vector_type(4)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef E f32x4 __attribute__((ext_vector_type(4)));  // (four LDS samples)
     const int b = blockIdx.x, lane = threadIdx.x;
     const RPlane pl = prm.p[rt_find(prm, b)];
     const int i0 = (b - pl.block0) * 64, i = i0 + lane;
@@ -859,10 +906,10 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
     T *dv = static_cast<T *>(pl.dst) + i0 + qcol;
     const size_t ss = pl.sstride, ds = pl.dstride;
     const int len = pl.h;
-    FChain<T, P, 64> ch;
+    CH ch;
     ch.init(fc_lds + lane, prm.radius, len);
     const int D = ch.D;
-    float *park = fc_lds + P * D * 64, *otile = park + kFcPf * 64;
+    E *park = fc_lds + P * D * 64, *otile = park + kFcPf * 64;
     const int total = ch.ticks(), lag = ch.lag();
     auto fetch = [&](int t0, Raw *f) __attribute__((always_inline)) {
         if (t0 < len) {
@@ -880,18 +927,18 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
         const int e1 = min(ne, max(0, tlo - t0)), e2 = min(ne, len - t0);  // [e1, e2): every stage away from the line's ends
         int u0 = 0;
         for (; u0 < e1; ++u0) {
-            float r;
-            if (ch.tick(t0 + u0, park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            V r;
+            if (ch.tick(t0 + u0, (V)park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
         }
         int c = (t0 + u0) % D;
         if (deep) {
             for (; u0 + 8 <= e2; u0 += 8) {
-                float v[8], r[8];
+                V v[8], r[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = park[(u0 + u) * 64 + lane];
+                for (int u = 0; u < 8; ++u) v[u] = (V)park[(u0 + u) * 64 + lane];
                 ch.template fast<8>(c, v, r);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) otile[u * 64 + lane] = r[u];
+                for (int u = 0; u < 8; ++u) otile[u * 64 + lane] = (E)r[u];
                 fc_wave_sync();
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -912,12 +959,12 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
             }
         }
         for (; u0 + 4 <= e2; u0 += 4) {
-            float v[4], r[4];
+            V v[4], r[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = park[(u0 + u) * 64 + lane];
+            for (int u = 0; u < 4; ++u) v[u] = (V)park[(u0 + u) * 64 + lane];
             ch.template fast<4>(c, v, r);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) otile[u * 64 + lane] = r[u];
+            for (int u = 0; u < 4; ++u) otile[u * 64 + lane] = (E)r[u];
             fc_wave_sync();
             const f32x4 o4 = *reinterpret_cast<const f32x4 *>(otile + qrow * 64 + qcol);
             const Raw w4 = __builtin_convertvector(o4, Raw);
@@ -934,14 +981,14 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
             if (c >= D) c -= D;
         }
         for (; u0 < e2; ++u0) {
-            float v = park[u0 * 64 + lane], r;
+            V v = (V)park[u0 * 64 + lane], r;
             ch.template fast<1>(c, &v, &r);
             if (ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
             c = c + 1 == D ? 0 : c + 1;
         }
         for (; u0 < ne; ++u0) {
-            float r;
-            if (ch.tick(t0 + u0, park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            V r;
+            if (ch.tick(t0 + u0, (V)park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
         }
         fc_wave_sync();
     };
@@ -977,7 +1024,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_hchain_kernel(const RPara
     T *d = static_cast<T *>(pl.dst) + (size_t)y0 * pl.dstride;
     const size_t ss = pl.sstride, ds = pl.dstride;
     FChain<T, P, RB> ch;
-    ch.init(fc_lds + lane, prm.radius, len);
+    ch.init(fc_lds + lane, prm.radius, len);  // (float planes only: E = V = float)
     const int D = ch.D;
     const int total = ch.ticks(), lag = ch.lag(), tlo = ch.first_interior();
     const bool deep = 2 * prm.radius + 2 >= 8;  // groups of 8 ticks: their leaving samples are all older than the group
@@ -1638,8 +1685,14 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
 constexpr int kFcMaxPass = 5;
 template <typename T>
 bool fchain_ok(const std::vector<RPlane> &pl, int radius, int npass, bool vertical) {
-    if (getenv("VSZIP_RT_NO_FCHAIN") || npass < 2 || npass > kFcMaxPass) return false;
-    const size_t lds = vertical ? ((size_t)npass * (2 * radius + 3) + kFcPf + 8) * 64 * sizeof(float) : (size_t)npass * (2 * radius + 3) * kFcRB * sizeof(float);
+    constexpr bool is_int = std::is_integral<T>::value;
+    if (getenv(is_int ? "VSZIP_RT_NO_ICHAIN" : "VSZIP_RT_NO_FCHAIN") || npass < 2 || npass > kFcMaxPass) return false;
+    if (is_int && (!vertical || sizeof(T) > 2 || radius > 127)) return false;  // integer planes: the vertical chain only (the horizontal passes have boxblur_rt_hsmall_kernel)
+    // 8-bit planes: the per-pass kernel moves 16 samples a lane and wins up to four passes and at larger radii (1080p, 64 frames per call, chain against a launch per pass:
+    // r = 2 x 3 passes -11 %, 13 x 2 -19 %, 2 x 4 even, 3 x 5 +16 %; 16-bit planes: +12 ... +55 % throughout — tools/boxblur_radii_probe.py). VSZIP_RT_ICHAIN_ALL=1: every case (tests).
+    if (is_int && sizeof(T) == 1 && !(npass >= 5 && radius <= 8) && !getenv("VSZIP_RT_ICHAIN_ALL")) return false;
+    const size_t esz = sizeof(typename FcArith<T>::E);
+    const size_t lds = vertical ? ((size_t)npass * (2 * radius + 3) + kFcPf + 8) * 64 * esz : (size_t)npass * (2 * radius + 3) * kFcRB * sizeof(float);
     if (lds > (vertical ? 48 : 30) * 1024) return false;  // (the horizontal kernel also holds two 64 x 64 tiles)
     for (const RPlane &q : pl) {
         if ((vertical ? q.h : q.w) < 2 * radius + 2) return false;
@@ -1667,13 +1720,15 @@ int launch_fchain(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int
             blocks += vertical ? (prm.p[i].w + 63) / 64 : (prm.p[i].h + kFcRB - 1) / kFcRB;
         }
         const int D = 2 * radius + 3;
-        const size_t lds = vertical ? ((size_t)npass * D + kFcPf + 8) * 64 * sizeof(float) : (size_t)npass * D * kFcRB * sizeof(float);
+        const size_t lds = vertical ? ((size_t)npass * D + kFcPf + 8) * 64 * sizeof(typename FcArith<T>::E) : (size_t)npass * D * kFcRB * sizeof(float);
 #define VSZIP_FC_LAUNCH(PP)                                                                                                        \
     case PP:                                                                                                                       \
-        if (vertical)                                                                                                              \
+        if (vertical) {                                                                                                            \
             hipLaunchKernelGGL((boxblur_rt_float_vchain_kernel<T, PP>), dim3(blocks), dim3(64), lds, ctx->stream, prm);           \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((boxblur_rt_float_hchain_kernel<T, PP>), dim3(blocks), dim3(64), lds, ctx->stream, prm);           \
+        } else {                                                                                                                   \
+            if constexpr (!std::is_integral<T>::value)                                                                             \
+                hipLaunchKernelGGL((boxblur_rt_float_hchain_kernel<T, PP>), dim3(blocks), dim3(64), lds, ctx->stream, prm);       \
+        }                                                                                                                          \
         break;
         switch (npass) {
             VSZIP_FC_LAUNCH(2)
@@ -1865,7 +1920,10 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
                 if (rem >= 2) span = rem <= kFcMaxPass ? rem : (rem - kFcMaxPass == 1 ? kFcMaxPass - 1 : kFcMaxPass);
             } else if constexpr (sizeof(T) <= 2) {
                 if (p == 0 && hb && hpasses >= 2) span = hpasses;
-                if (vertical && p == (hb ? hpasses : 0) && vpasses >= 2) span = vpasses;
+                if (vertical) {  // what is left of the vertical passes, in chains of up to kFcMaxPass stages
+                    const int rem = total - p;
+                    if (rem >= 2) span = rem <= kFcMaxPass ? rem : (rem - kFcMaxPass == 1 ? kFcMaxPass - 1 : kFcMaxPass);
+                }
             }
             const bool last = p + span - 1 == total - 1;
             for (int i = 0; i < ng; ++i) {
@@ -1882,12 +1940,17 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
                 if constexpr (!std::is_integral<T>::value) rc = launch_fchain<T>(ctx, cur, vertical ? vradius : hradius, span, vertical, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
+            } else if (std::is_integral<T>::value && span > 1 && vertical && !vsmall_ok<T>(cur, vradius, span) && fchain_ok<T>(cur, vradius, span, true)) {
+                // integer planes, vertical passes the two-stage small-radius kernel does not take: the pass chain (one column a lane, the stages' rings in LDS)
+                if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_fchain<T>(ctx, cur, vradius, span, true, !last);
+                else rc = VSZIP_ERR_ARG;
+                p += span - 1;
             } else if (span > 1 && !vertical && hsmall_ok<T>(cur, hradius, hpasses)) {
                 if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_hsmall<T>(ctx, cur, hradius, hpasses, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
-            } else if (span > 1 && vertical && vsmall_ok<T>(cur, vradius, vpasses)) {
-                if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_vsmall<T>(ctx, cur, vradius, vpasses, !last);
+            } else if (span > 1 && vertical && vsmall_ok<T>(cur, vradius, span)) {
+                if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_vsmall<T>(ctx, cur, vradius, span, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
             } else {
