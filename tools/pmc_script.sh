@@ -15,9 +15,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$out/set*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        tag = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:44]
+        tag = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:64]
         agg[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for tag, d in agg.items():
     for k, v in sorted(d.items()):
-        print(f"{tag:44s} {k:24s} {sum(v)/len(v):16.1f}")
+        print(f"{tag:64s} {k:24s} {sum(v)/len(v):16.1f}")
 PY

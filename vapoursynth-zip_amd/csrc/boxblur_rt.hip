@@ -768,7 +768,11 @@ struct FcArithI {
     }
     __device__ __forceinline__ V step(S &sum, uint32_t kk, V a, V o) const {
         sum += a - o;
-        return ((uint32_t)__umul24(sum, inv2) + kk) >> 16;  // (the window sum of a chain radius is below 2^24: R <= 127)
+        // the window sum of a chain radius is below 2^24 (R <= 127) and inv2 below 2^16: one full-rate 24-bit multiply-add (left to itself the compiler forms
+        // v_mad_u64_u32 out of the multiply and the add: a quarter-rate 64-bit instruction per stage and tick)
+        uint32_t m;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(m) : "v"(sum), "v"(inv2), "v"(kk));
+        return m >> 16;
     }
 };
 template <typename T>
@@ -802,24 +806,48 @@ struct FChain {
     }
     __device__ __forceinline__ int ticks() const { return len + P * L; }
     __device__ __forceinline__ int lag() const { return P * L; }
-    __device__ __forceinline__ E *at(int j, int y) const { return ring + (((y + j * L) % D) * P + j) * LS; }
-    __device__ __forceinline__ bool tick(const int t, const V v, V &out) {
-        if (t < len) *at(0, t) = (E)v;
+    // sample y of ring j at tick t (c = t % D): the ring's newest sample t - j L is in slot c, y sits t - j L - y slots before it — 0 ... D - 1 for every sample a tick touches
+    __device__ __forceinline__ E *at(int j, int y, int t, int c) const {
+        int sl = c - (t - j * L - y);
+        if (sl < 0) sl += D;
+        return ring + (sl * P + j) * LS;
+    }
+    // One tick near a line end (any stage may be starting, mirroring or finished); c = t % D. All ring reads of the tick come before its writes, as in `fast`: a stage's
+    // inputs were produced at earlier ticks.
+    __device__ __forceinline__ bool tick(const int t, const int c, const V v, V &out) {
+        V a[P], o[P];
+        bool act[P];
+        const E *pn = ring + (c + 1 == D ? 0 : c + 1) * (P * LS);  // the slot of every ring's leaving sample, for the stages that are away from their ends
+#pragma unroll
+        for (int k = 1; k <= P; ++k) {
+            const int x = t - k * L;
+            act[k - 1] = x >= 0 && x < len;
+            a[k - 1] = o[k - 1] = 0;
+            if (act[k - 1]) {
+                if (x > R && x < len - R) {  // (the stages start L ticks apart and an end lasts R + 1 ticks: at most one stage of a tick is not here)
+                    a[k - 1] = carry[k - 1];
+                    o[k - 1] = (V)pn[(k - 1) * LS];
+                } else {
+                    if (x == 0) {
+                        V s = (V)*at(k - 1, R, t, c);
+                        for (int j = 0; j < R; ++j) s += (V)*at(k - 1, j, t, c) * 2;
+                        ar.start(sum[k - 1], kk[k - 1], s);
+                    }
+                    a[k - 1] = (V)*at(k - 1, rtf_in(x, len, R), t, c);
+                    o[k - 1] = (V)*at(k - 1, rtf_out(x, R), t, c);
+                }
+            }
+        }
+        E *pc = ring + c * (P * LS);  // every ring's newest sample: what this tick writes
+        if (t < len) pc[0] = (E)v;
         carry[0] = v;
         bool has = false;
 #pragma unroll
         for (int k = 1; k <= P; ++k) {
-            const int x = t - k * L;
-            if (x >= 0 && x < len) {
-                if (x == 0) {
-                    V s = (V)*at(k - 1, R);
-                    for (int j = 0; j < R; ++j) s += (V)*at(k - 1, j) * 2;
-                    ar.start(sum[k - 1], kk[k - 1], s);
-                }
-                const V a = (V)*at(k - 1, rtf_in(x, len, R)), o = (V)*at(k - 1, rtf_out(x, R));
-                const V r = ar.step(sum[k - 1], kk[k - 1], a, o);
+            if (act[k - 1]) {
+                const V r = ar.step(sum[k - 1], kk[k - 1], a[k - 1], o[k - 1]);
                 if (k < P) {
-                    *at(k, x) = (E)r;
+                    pc[k * LS] = (E)r;
                     carry[k] = r;
                 } else {
                     out = r;
@@ -926,11 +954,12 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
         const int ne = min(kFcPf, total - t0);
         const int e1 = min(ne, max(0, tlo - t0)), e2 = min(ne, len - t0);  // [e1, e2): every stage away from the line's ends
         int u0 = 0;
+        int c = t0 % D;
         for (; u0 < e1; ++u0) {
             V r;
-            if (ch.tick(t0 + u0, (V)park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            if (ch.tick(t0 + u0, c, (V)park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            c = c + 1 == D ? 0 : c + 1;
         }
-        int c = (t0 + u0) % D;
         if (deep) {
             for (; u0 + 8 <= e2; u0 += 8) {
                 V v[8], r[8];
@@ -988,7 +1017,8 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
         }
         for (; u0 < ne; ++u0) {
             V r;
-            if (ch.tick(t0 + u0, (V)park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            if (ch.tick(t0 + u0, c, (V)park[u0 * 64 + lane], r) && ok) d[(size_t)(t0 + u0 - lag) * ds] = (T)r;
+            c = c + 1 == D ? 0 : c + 1;
         }
         fc_wave_sync();
     };
@@ -1049,11 +1079,12 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_hchain_kernel(const RPara
             if (lane < rows) {
                 int kk = k;
                 const int e1 = min(kend, max(k, tlo - t0)), e2 = min(kend, len - t0);  // [e1, e2): every stage away from the line's ends
+                int cc = (t0 + kk) % D;
                 for (; kk < e1; ++kk) {
                     float r;
-                    if (ch.tick(t0 + kk, tin[lane][kk], r)) tout[lane][(t0 + kk - lag) & 63] = r;
+                    if (ch.tick(t0 + kk, cc, tin[lane][kk], r)) tout[lane][(t0 + kk - lag) & 63] = r;
+                    cc = cc + 1 == D ? 0 : cc + 1;
                 }
-                int cc = (t0 + kk) % D;
                 if (deep) {
                     for (; kk + 8 <= e2; kk += 8) {
                         float v[8], r[8];
@@ -1086,7 +1117,8 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_hchain_kernel(const RPara
                 }
                 for (; kk < kend; ++kk) {
                     float r;
-                    if (ch.tick(t0 + kk, tin[lane][kk], r)) tout[lane][(t0 + kk - lag) & 63] = r;
+                    if (ch.tick(t0 + kk, cc, tin[lane][kk], r)) tout[lane][(t0 + kk - lag) & 63] = r;
+                    cc = cc + 1 == D ? 0 : cc + 1;
                 }
             }
             fc_wave_sync();
