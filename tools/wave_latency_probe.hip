@@ -25,6 +25,34 @@ __global__ void indep_add(float *out, float a) {
     }
     out[threadIdx.x + blockIdx.x * 64] = x0 + x1 + x2 + x3;
 }
+__global__ void indep_add_e64(float *out, float a) {  // the same adds in the 8-byte VOP3 encoding
+    float x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3;
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(x0) : "v"(a));
+            asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(x1) : "v"(a));
+            asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(x2) : "v"(a));
+            asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(x3) : "v"(a));
+        }
+    }
+    out[threadIdx.x + blockIdx.x * 64] = x0 + x1 + x2 + x3;
+}
+__global__ void lds_indep(float *out, float a) {  // LDS reads nobody waits for until the end of the group: the issue cost of a DS instruction
+    __shared__ float t[64 * 17];
+    for (int k = threadIdx.x; k < 64 * 17; k += 64) t[k] = a;
+    float acc = 0;
+    const float *p = t + threadIdx.x;
+    for (int i = 0; i < N; ++i) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[u]) : "v"((uint32_t)(threadIdx.x * 4)), "n"(u * 256));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    out[threadIdx.x + blockIdx.x * 64] = acc + p[0];
+}
 __global__ void lds_rt(float *out, float a) {
     __shared__ float t[128];
     float x = threadIdx.x;
@@ -67,6 +95,8 @@ int main() {
     for (int blocks : {1, 1024, 2048, 4096, 8192}) {
         run("dependent v_add_f32", [&](int b) { dep_add<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
         run("4 independent v_add_f32", [&](int b) { indep_add<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
+        run("4 independent v_add_f32_e64", [&](int b) { indep_add_e64<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
+        run("16 ds_read_b32 + 16 adds", [&](int b) { lds_indep<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
         run("LDS write->read round trip", [&](int b) { lds_rt<<<b, 64>>>(out, 1.0f); }, blocks, 4.0 * N);
         run("4 independent v_fma_f64", [&](int b) { indep_fma64<<<b, 64>>>(out, 1.0f); }, blocks, 16.0 * N);
     }
