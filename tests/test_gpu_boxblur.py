@@ -309,7 +309,10 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
             return [dev.download(d) for d in dsts]
 
         got = run()
-        monkeypatch.setenv("VSZIP_RT_ICHAIN_ALL", "1")  # the vertical pass chain wherever it can run (8-bit planes take it from five passes on only)
+        monkeypatch.setenv("VSZIP_RT_VSMALL", "1")  # two vertical stages in one launch (opt-in since the end of round 3)
+        vsm = run()
+        monkeypatch.delenv("VSZIP_RT_VSMALL")
+        monkeypatch.setenv("VSZIP_RT_ICHAIN_ALL", "1")  # the vertical pass chain wherever it can run (by default: 3+ passes, batches of 900+ column groups, 8-bit planes from five passes on)
         chain_all = run()
         monkeypatch.setenv("VSZIP_RT_NO_VSMALL", "1")   # ... and for two passes of a small radius too
         chain_2 = run()
@@ -320,13 +323,15 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
         monkeypatch.delenv("VSZIP_RT_NO_HSMALL")
         monkeypatch.delenv("VSZIP_RT_NO_VSMALL")
         monkeypatch.delenv("VSZIP_RT_NO_ICHAIN")
-        for p, a, b, c, c2 in zip(planes, got, per_pass, chain_all, chain_2):
+        for p, a, b, c, c2, v in zip(planes, got, per_pass, chain_all, chain_2, vsm):
             want = oracle.boxblur(p, *args)
             assert np.array_equal(a, want), (shapes, args, int((a != want).sum()))
+            assert np.array_equal(v, want), (shapes, args, "two vertical stages", int((v != want).sum()))
             assert np.array_equal(b, want), (shapes, args, "per pass")
             assert np.array_equal(c, want), (shapes, args, "pass chain", int((c != want).sum()), np.argwhere(c != want)[:3].tolist())
             assert np.array_equal(c2, want), (shapes, args, "pass chain, two stages", int((c2 != want).sum()))
     # three and four vertical stages (not the default: measured slower than a launch per pass)
+    monkeypatch.setenv("VSZIP_RT_VSMALL", "1")
     monkeypatch.setenv("VSZIP_RT_VSMALL_MAX", "4")
     for shapes, args in [([(300, 333)], (2, 2, 2, 3)), ([(521, 96), (260, 48)], (0, 0, 3, 4)), ([(70, 520)], (1, 2, 1, 4)), ([(1080, 512)], (0, 0, 2, 3))]:
         planes = [fx.splitmix64_plane(17 + i, sh, dtype) for i, sh in enumerate(shapes)]

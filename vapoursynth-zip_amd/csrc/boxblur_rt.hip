@@ -1570,6 +1570,10 @@ bool vsmall_ok(const std::vector<RPlane> &pl, int radius, int npass) {
     // Measured (tools/boxblur_radii_probe.py, 1080p, 64 frames per call, against one launch per pass): two passes 93.3 k -> 107.7 k fps (u16), 105 k -> 108 k
     // (u8); three passes 68 k -> 66.5 k (u16), 79 k -> 65 k (u8) — the chain's rings and registers leave 6 waves a CU at three stages. Hence two passes
     // only (VSZIP_RT_VSMALL_MAX=3 / 4 for experiments).
+    // End of round 3: OPT-IN (VSZIP_RT_VSMALL=1). The per-pass kernel's LDS ring with its software pipeline (later that round) overtook it: two vertical passes, 1080p, 64 / 16 / 4
+    // frames per call, two launches against this kernel: u8 r = 1 179 k / 191 k / 60 k fps against 156 k / 160 k / 48 k, u16 147 k / 167 k / 68 k against 153 k / 160 k / 49 k; from r = 3 on
+    // this kernel falls to 64 - 105 k (its rings leave few waves a CU) where two launches stay at 137 - 180 k (tools/boxblur_radii_probe.py).
+    if (!getenv("VSZIP_RT_VSMALL")) return false;
     const char *mx = getenv("VSZIP_RT_VSMALL_MAX");
     const int max_pass = mx ? std::min(4, std::max(2, atoi(mx))) : 2;
     if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || npass > max_pass || radius < 1 || radius > kVsMaxR || getenv("VSZIP_RT_NO_VSMALL")) return false;
@@ -1723,6 +1727,15 @@ bool fchain_ok(const std::vector<RPlane> &pl, int radius, int npass, bool vertic
     // 8-bit planes: the per-pass kernel moves 16 samples a lane and wins up to four passes and at larger radii (1080p, 64 frames per call, chain against a launch per pass:
     // r = 2 x 3 passes -11 %, 13 x 2 -19 %, 2 x 4 even, 3 x 5 +16 %; 16-bit planes: +12 ... +55 % throughout — tools/boxblur_radii_probe.py). VSZIP_RT_ICHAIN_ALL=1: every case (tests).
     if (is_int && sizeof(T) == 1 && !(npass >= 5 && radius <= 8) && !getenv("VSZIP_RT_ICHAIN_ALL")) return false;
+    if (is_int && !getenv("VSZIP_RT_ICHAIN_ALL")) {
+        // Two passes: two launches of the per-pass kernel are as fast (u16, r >= 3: the chain +3 ... 8 % at 64 frames) and do not mind small calls. And the chain is as slow as its
+        // longest column (a wave per 64 columns, ~0.1 us a tick): with fewer waves than SIMDs — a plugin context submits ONE frame per call — the per-pass kernels, which
+        // cut a plane into bands, are several times faster (4 1080p frames, three passes: ~110 us against 3 x 25 us).
+        if (npass < 3) return false;
+        long waves = 0;
+        for (const RPlane &q : pl) waves += (q.w + 63) / 64;
+        if (waves < 900) return false;
+    }
     const size_t esz = sizeof(typename FcArith<T>::E);
     const size_t lds = vertical ? ((size_t)npass * (2 * radius + 3) + kFcPf + 8) * 64 * esz : (size_t)npass * (2 * radius + 3) * kFcRB * sizeof(float);
     if (lds > (vertical ? 48 : 30) * 1024) return false;  // (the horizontal kernel also holds two 64 x 64 tiles)
