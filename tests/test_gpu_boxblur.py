@@ -141,6 +141,7 @@ def test_rt_float_pass_chain_kernels(dev, oracle, dtype, monkeypatch):
              ([(19, 40)], (2, 2, 2, 2)), ([(18, 18)], (8, 2, 8, 3)), ([(64, 64)], (3, 3, 3, 3)), ([(65, 63)], (4, 2, 2, 5)), ([(128, 129)], (6, 3, 6, 2)),
              ([(81, 257)], (30, 2, 25, 2)), ([(150, 191)], (13, 5, 13, 5)), ([(48, 48)], (2, 6, 2, 6)), ([(16, 300)], (9, 2, 9, 2)), ([(33, 17)], (1, 3, 1, 3)),
              ([(100, 200)], (5, 3, 0, 0)), ([(100, 200)], (0, 0, 5, 3)), ([(60, 90)], (1, 11, 1, 7)), ([(70, 333)], (3, 8, 0, 0)), ([(200, 40)], (0, 0, 2, 12)), ([(97, 1)], (0, 0, 3, 2)), ([(1, 97)], (3, 2, 0, 0))]
+    monkeypatch.setenv("VSZIP_RT_FCHAIN_ALL", "1")  # (the horizontal chain is for calls of 12 000+ rows by default)
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(31 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
 

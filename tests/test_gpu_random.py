@@ -108,16 +108,22 @@ def test_boxblur_float_runtime_passes_random(dev, oracle, seed):
         dev.boxblur(srcs, dsts, hr, hp, vr, vp)
         return [dev.download(d) for d in dsts]
 
-    got = run()
+    dflt = run()  # (small calls: the vertical chain, the horizontal passes a launch each)
+    os.environ["VSZIP_RT_FCHAIN_ALL"] = "1"
+    try:
+        got = run()
+    finally:
+        del os.environ["VSZIP_RT_FCHAIN_ALL"]
     os.environ["VSZIP_RT_NO_FCHAIN"] = "1"
     try:
         per_pass = run()
     finally:
         del os.environ["VSZIP_RT_NO_FCHAIN"]
-    for p, a, b in zip(planes, got, per_pass):
+    for p, a, b, c in zip(planes, got, per_pass, dflt):
         want = oracle.boxblur(p, hr, hp, vr, vp)
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (seed, (hr, hp, vr, vp), p.shape, "chain vs per pass", np.argwhere(a != b)[:3].tolist())
         assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (seed, (hr, hp, vr, vp), p.shape, np.argwhere(a != want)[:3].tolist())
+        assert np.array_equal(c.view(np.uint8), want.view(np.uint8)), (seed, (hr, hp, vr, vp), p.shape, "default paths")
 
 
 @pytest.mark.parametrize("seed", range(12))

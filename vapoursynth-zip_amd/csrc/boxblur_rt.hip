@@ -1736,6 +1736,13 @@ bool fchain_ok(const std::vector<RPlane> &pl, int radius, int npass, bool vertic
         for (const RPlane &q : pl) waves += (q.w + 63) / 64;
         if (waves < 900) return false;
     }
+    if (!is_int && !vertical && !getenv("VSZIP_RT_FCHAIN_ALL")) {
+        // The horizontal chain carries 64 rows a wave and costs what a row's ticks cost however few waves there are; the per-pass kernel (16 rows a wave) is faster on small calls:
+        // 4K YUV420PS, 3 passes of r = 5, 1 / 2 / 4 frames per call: chain 2.5 k / 5.0 k / 9.7 k fps, a launch per pass 3.0 k / 5.7 k / 9.2 k. (The vertical chain wins from one frame on.)
+        long rows = 0;
+        for (const RPlane &q : pl) rows += q.h;
+        if (rows < 12000) return false;
+    }
     const size_t esz = sizeof(typename FcArith<T>::E);
     const size_t lds = vertical ? ((size_t)npass * (2 * radius + 3) + kFcPf + 8) * 64 * esz : (size_t)npass * (2 * radius + 3) * kFcRB * sizeof(float);
     if (lds > (vertical ? 48 : 30) * 1024) return false;  // (the horizontal kernel also holds two 64 x 64 tiles)
