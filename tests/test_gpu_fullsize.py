@@ -50,6 +50,28 @@ def test_boxblur_r13_4k_yuv420p16(dev, oracle, content):
         assert np.array_equal(g, oracle.boxblur(p, 13, 1, 13, 1))
 
 
+@pytest.mark.parametrize("dtype,args,frames,shape", [(np.uint16, (13, 5, 13, 5), 16, (H1080, W1080)), (np.uint16, (5, 3, 5, 3), 8, (H4K, W4K)), (np.uint8, (3, 2, 3, 6), 16, (H1080, W1080)),
+                                                     (np.float32, (5, 3, 5, 3), 8, (H4K, W4K)), (np.float16, (2, 2, 2, 2), 4, (H4K, W4K))])
+def test_boxblur_runtime_passes_batches_take_the_pass_chains(dev, oracle, dtype, args, frames, shape, monkeypatch):
+    """Calls large enough for the pass-chain kernels' own conditions (900+ column groups for integer planes' vertical passes, 12 000+ rows for float planes' horizontal
+    ones) — the sizes the bench legs run at: the default paths bit-identical to one launch per pass on every plane of the batch, and to the oracle on the first frame."""
+    import os
+
+    base = [fx.tiled_natural(s, dtype, p) for p, s in enumerate(_yuv420(shape))]
+    planes = [np.ascontiguousarray(np.roll(p, 7 * f, axis=1)) for f in range(frames) for p in base]
+    got, _ = _boxblur(dev, planes, *args)
+    for k in ("VSZIP_RT_NO_FCHAIN", "VSZIP_RT_NO_ICHAIN"):
+        monkeypatch.setenv(k, "1")
+    per_pass, _ = _boxblur(dev, planes, *args)
+    for k in ("VSZIP_RT_NO_FCHAIN", "VSZIP_RT_NO_ICHAIN"):
+        monkeypatch.delenv(k)
+    assert "VSZIP_RT_NO_ICHAIN" not in os.environ
+    for i, (a, b) in enumerate(zip(got, per_pass)):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (i, args, np.argwhere(a != b)[:3].tolist())
+    for a, p in zip(got[:3], planes[:3]):
+        assert np.array_equal(a.view(np.uint8), oracle.boxblur(p, *args).view(np.uint8))
+
+
 @pytest.mark.parametrize("dtype,r", [(np.float32, 13), (np.float16, 13), (np.float32, 22), (np.float32, 3)])
 def test_boxblur_ct_float_4k_yuv420(dev, oracle, dtype, r):
     """The float CT path at 4K (register-ring kernel over several column tiles and bands that end inside a ring
