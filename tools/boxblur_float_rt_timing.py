@@ -13,7 +13,8 @@ import vszip_amd
 
 dev = vszip_amd.Device(0)
 frames = int(os.environ.get("FRAMES", "8"))
-planes = [fx.tiled_natural(s, np.float32, p) for p, s in enumerate([(2160, 3840), (1080, 1920), (1080, 1920)])]
+H = int(os.environ.get("HEIGHT", "2160"))  # 2160: 4K, 1080: 1080p
+planes = [fx.tiled_natural(s, np.float32, p) for p, s in enumerate([(H, H * 16 // 9), (H // 2, H * 8 // 9), (H // 2, H * 8 // 9)])]
 srcs = [dev.upload(np.roll(p, f, axis=1)) for f in range(frames) for p in planes]
 dsts = [dev.empty(p.shape[0], p.shape[1], np.float32) for f in range(frames) for p in planes]
 for args in ((30, 1, 30, 1), (5, 3, 5, 3), (5, 3, 0, 0), (0, 0, 5, 3), (2, 2, 2, 2), (13, 5, 13, 5), (13, 1, 13, 1)):
@@ -23,5 +24,5 @@ for args in ((30, 1, 30, 1), (5, 3, 5, 3), (5, 3, 0, 0), (0, 0, 5, 3), (2, 2, 2,
     for _ in range(10):
         dev.boxblur(srcs, dsts, *args)
     dev.sync()
-    print(f"float BoxBlur {args}: {10 * frames / (time.perf_counter() - t0):8.1f} frames/s (4K YUV420PS, {frames} frames per call)", flush=True)
+    print(f"float BoxBlur {args}: {10 * frames / (time.perf_counter() - t0):8.1f} frames/s ({H}p YUV420PS, {frames} frames per call)", flush=True)
 dev.close()
