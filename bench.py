@@ -1311,6 +1311,7 @@ def main() -> int:
             for key, leg in (("bilateral_1080p_fps", "bilateral_1080p"), ("bilateral_4k_fps", "bilateral_4k"), ("ssimulacra2_4k_pairs_s", "ssimulacra2_4k"),
                              ("bilateral_1080p_sigmaR0p02_fps", "bilateral_1080p_sigmaR0p02"), ("bilateral_1080p_defaults_fps", "bilateral_1080p_defaults"), ("bilateral_1080p_yuv420p8_fps", "bilateral_1080p_yuv420p8"), ("ssimulacra2_4k_yuv420p8_pairs_s", "ssimulacra2_4k_yuv420p8"), ("eedi3_1080p_fps", "eedi3_1080p"), ("xpsnr_1080p_fps", "xpsnr_1080p"),
                              ("boxblur_1080p_fps", "boxblur_1080p"), ("boxblur_1080p_5pass_fps", "boxblur_1080p_5pass"), ("boxblur_1080p_r1x2_yuv420p8_fps", "boxblur_1080p_r1x2_yuv420p8"), ("pipeline_8k_fps", "pipeline_8k_rgbs"),
+                             ("boxblur_rt_float_r5x3_4k_fps", "boxblur_rt_float_r5x3_4k"), ("boxblur_rt_r5x3_4k_fps", "boxblur_rt_r5x3_4k"),
                              ("plugin_ssimulacra2_4k_yuv420p8_pairs_s", "plugin_ssimulacra2_4k_yuv420p8"), ("plugin_ssimulacra2_4k_rgb24_pairs_s", "plugin_ssimulacra2_4k_rgb24")):
                 v = others.get(leg, {}).get("value")
                 if isinstance(v, (int, float)):
