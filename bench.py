@@ -317,11 +317,13 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
     candidates of a walk are held until it ends, so each lies elsewhere): the destination arena against the first
     source arena, then the source arena against that destination, then the destination once more against the chosen
     source (the two effects are not independent). Returns (step, keep, info): info lists every candidate's time.
-    VSZIP_BENCH_PLACEMENT_TRIES=1 disables the probing (first allocation, as a caller who does not care gets)."""
+    tries = 1 (the default since round 4: the headline is what a plain allocation gets) does no probing;
+    VSZIP_BENCH_PLACEMENT_TRIES=N overrides; the default run measures the probed placement as a side scalar only
+    (config.probed_frac)."""
     if tries is None:
-        tries = 64
+        tries = 1  # round 4: every leg's `value` / `frac` is measured on plain vszip_dev_alloc arenas — what a caller gets
     if os.environ.get("VSZIP_BENCH_PLACEMENT_TRIES"):
-        tries = max(1, min(tries, int(os.environ["VSZIP_BENCH_PLACEMENT_TRIES"])))
+        tries = max(1, int(os.environ["VSZIP_BENCH_PLACEMENT_TRIES"]))
     shapes = [p.shape for p in host_planes]
     probe_args = probe_args or args
     isz = np.dtype(dtype).itemsize
@@ -740,7 +742,7 @@ def boxblur_other_paths_leg(dev, timed, frames_in=8):
         frames = 64 if dt_ == np.uint8 else frames_in
         placement = None
         if name.startswith("boxblur_ct_"):  # the ring kernels: placement probed like the headline's
-            step, keep_, placement = placed_batch(dev, [np.roll(p, f + 1, axis=1) for f in range(frames) for p in base], dt_, args, 8000, 24)
+            step, keep_, placement = placed_batch(dev, [np.roll(p, f + 1, axis=1) for f in range(frames) for p in base], dt_, args, 8000)
         else:
             for f in range(frames):
                 for p in base:
@@ -868,7 +870,7 @@ def boxblur_1080p_leg(dev, timed, no_cpu, frames=64):
     """BASELINE configs[0] — the reference README's own benchmark (README.md:34-44: BlankClip 1920x1080
     YUV420P16, BoxBlur hradius=vradius=13, 1046 fps on an unstated CPU) — on HBM-resident frames, 64 per call."""
     planes = [np.zeros(sh, np.uint16) for _ in range(frames) for sh in yuv420_shapes(W1080, H1080)]
-    step, keep, placement = placed_batch(dev, planes, np.uint16, (RADIUS, 1, RADIUS, 1), 7000, 24)
+    step, keep, placement = placed_batch(dev, planes, np.uint16, (RADIUS, 1, RADIUS, 1), 7000)
     dt, _, dom_ms, launches = timed.run(step, 200, 5)
     fb = 2 * sum(2 * sh[0] * sh[1] for sh in yuv420_shapes(W1080, H1080)) * frames
     gbs = fb * launches / (dom_ms * 1e-3) / 1e9
@@ -1026,6 +1028,119 @@ def xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev, frames_per_rank=8):
     return res
 
 
+# ---------------------------------------------------------------------------
+# The ONE stdout line. The driver keeps the last 8 KB of stdout and parses the JSON from it, so the line
+# must fit that window whole (round 3's 23 KB line left the driver with `parsed: null`). The line carries the
+# contract keys, `config` (workload + scalars), `roofline`, `cpu_baseline` and per `others` leg value / unit /
+# frac (+ limit); every other field goes to the sidecar file named in the line's `detail`.
+# ---------------------------------------------------------------------------
+LINE_MAX_BYTES = 7600
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rccl_ranks")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_us", "launches", "algorithmic_bytes_per_launch", "frac_median")
+
+
+def _sig(v, digits=6):
+    """floats to 6 significant digits (no NaN / Infinity tokens: they are not JSON)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        if v == int(v) and abs(v) < 2.0 ** 53:
+            return int(v) if abs(v) >= 1e6 else v  # byte counts stay exact
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return _sig(float(v), digits)
+    return str(v)
+
+
+def _scalar(v):
+    return v is None or isinstance(v, (bool, int, float, str))
+
+
+def compact_leg(leg: dict) -> dict:
+    """one `others` leg on the line: value, unit, frac (of its roofline), limit.bound / limit.frac, error"""
+    if not isinstance(leg, dict):
+        return {"error": str(leg)[:120]}
+    if "error" in leg:
+        return {"error": str(leg["error"])[:120]}
+    o = {k: leg[k] for k in ("value", "unit") if k in leg}
+    rf = leg.get("roofline")
+    if isinstance(rf, dict) and isinstance(rf.get("frac"), (int, float)):
+        o["frac"] = rf["frac"]
+    lim = leg.get("limit")
+    if isinstance(lim, dict) and "bound" in lim and "frac" in lim:
+        o["limit"] = {"bound": lim["bound"], "frac": lim["frac"]}
+    return o
+
+
+def compact_line(full: dict, detail_name: str | None = None) -> dict:
+    """The dict that is printed: see the section comment. `full` is untouched (it is what the sidecar holds)."""
+    line = {k: full[k] for k in CONTRACT_KEYS if k in full}
+    cfg = {}
+    for k, v in full.get("config", {}).items():
+        if _scalar(v):
+            cfg[k] = v if not isinstance(v, str) or len(v) <= 200 else v[:200]
+        elif isinstance(v, dict):  # small all-scalar records stay (clip sums); anything with prose or nesting is detail
+            flat = {a: b for a, b in v.items() if _scalar(b) and not (isinstance(b, str) and len(b) > 60)}
+            lists = {a: b for a, b in v.items() if isinstance(b, (list, tuple)) and len(b) <= 4 and all(_scalar(x) for x in b)}
+            flat.update(lists)
+            if flat and len(json.dumps(_sig(flat))) <= 260:
+                cfg[k] = flat
+    line["config"] = cfg
+    rf = full.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k: rf[k] for k in ROOFLINE_KEYS if k in rf}
+        ts = line["roofline"].get("traffic_source")
+        if isinstance(ts, str) and len(ts) > 80:
+            line["roofline"]["traffic_source"] = "replayed from profiles/ (PMC passes of this command)" if "replayed" in ts else ts[:80]
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = full["cpu_baseline"]
+    if isinstance(full.get("others"), dict):
+        line["others"] = {k: compact_leg(v) for k, v in full["others"].items()}
+    if detail_name:
+        line["detail"] = detail_name
+    line = _sig(line)
+    # hard bound: shed the least important parts until the line fits
+    for shed in ("limit", "unit", "others"):
+        if len(json.dumps(line)) <= LINE_MAX_BYTES:
+            break
+        if shed == "others":
+            line.pop("others", None)
+        else:
+            for leg in line.get("others", {}).values():
+                leg.pop(shed, None)
+    return line
+
+
+def emit_line(full: dict, stream, detail_path: Path | None = None) -> str:
+    """writes the sidecar (everything) and ONE compact line to `stream`; returns the line"""
+    name = None
+    if detail_path is not None:
+        try:
+            detail_path.write_text(json.dumps(_sig(full, 9), indent=1) + "\n")
+            name = detail_path.name
+        except OSError as e:  # a read-only checkout must not cost the line
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+    s_ = json.dumps(compact_line(full, name))
+    assert len(s_) < 8000, len(s_)
+    stream.write(s_ + "\n")
+    stream.flush()
+    return s_
+
+
+def detail_path_default() -> Path:
+    """bench_detail.json next to bench.py (VSZIP_BENCH_DETAIL overrides); also mirrored into gpurun_out/ when that exists"""
+    return Path(os.environ.get("VSZIP_BENCH_DETAIL") or (ROOT / "bench_detail.json"))
+
+
+
 def launch_ranks(a, argv) -> int:
     """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks as child
     processes (this process never initialises a GPU, so no process that has touched one is ever
@@ -1174,7 +1289,9 @@ def main() -> int:
         # probe gets — libvszip.so's slabs are not probed: its BoxBlur is PCIe-bound long before this matters).
         pl_info = keep[2]
         out["config"]["placement_tries"] = pl_info["tries"]
-        out["config"]["probed_frac"] = achieved / HBM_PEAK_GBS
+        out["config"]["placement_policy"] = "plain vszip_dev_alloc (first allocation)" if pl_info["tries"] <= 1 else f"best of 3 x {pl_info['tries']} probed arenas"
+        if pl_info["tries"] > 1:
+            out["config"]["probed_frac"] = achieved / HBM_PEAK_GBS
         if pl_info.get("first_allocation_us"):
             out["config"]["first_allocation_frac"] = alg_bytes / (pl_info["first_allocation_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             out["config"]["first_allocation_launch_us"] = pl_info["first_allocation_us"]
@@ -1197,6 +1314,17 @@ def main() -> int:
         except Exception as e:  # informative only
             out["config"]["clip_mean_luma"] = {"error": str(e)}
         del keep
+        # Side scalar only (never `value`): the same launch with the placement of both arenas searched (24 candidates a walk)
+        if rank == 0 and world == 1 and not a.no_others and pl_info["tries"] <= 1 and a.radius == RADIUS:
+            try:
+                step_p, keep_p = setup_boxblur(dev, rank, F, a.radius, tries=24)
+                _, _, dom_p, n_p = timed.run(step_p, 200, 5)
+                out["config"]["probed_frac"] = alg_bytes / (dom_p * 1e-3 / n_p) / 1e9 / HBM_PEAK_GBS
+                out["config"]["probed_launch_us"] = dom_p * 1e3 / n_p
+                out["config"]["probed_placement"] = keep_p[2]
+                del step_p, keep_p
+            except Exception as e:
+                out["config"]["probed_placement"] = {"error": str(e)}
         # The exchange step on real data: XPSNR's per-clip accumulators over RCCL (all ranks take part)
         try:
             if not a.no_others:
@@ -1348,8 +1476,12 @@ def main() -> int:
             out["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K)
 
     if rank == 0:
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+        emit_line(out, json_out, detail_path_default())
+        try:  # gpurun merges gpurun_out/ back: keep a copy of the full record there
+            if (ROOT / "gpurun_out").is_dir():
+                (ROOT / "gpurun_out" / "bench_detail.json").write_text(detail_path_default().read_text())
+        except OSError:
+            pass
     if use_dist:
         dist.destroy_process_group()
     dev.close()
