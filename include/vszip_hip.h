@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define VSZIP_ABI_VERSION 2 /* 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1: vszip_dev_alloc_probed,
+#define VSZIP_ABI_VERSION 3 /* 3 (round 4): vszip_ctx_set_option / _get_option, vszip_dev_trim, vszip_dev_placement_info, vszip_dev_probe_region
+                               added; vszip_dev_alloc places large requests (below); 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1: vszip_dev_alloc_probed,
                                vszip_chain_run, vszip_ssimulacra2_src, vszip_to_rgbs_linear, vszip_probe_read_each, vszip_resample_table */
 
 typedef struct vszip_ctx vszip_ctx;
@@ -56,6 +57,12 @@ int vszip_ctx_sync(vszip_ctx *ctx);
  * and concurrent across contexts, D2H data reaches the caller's memory inside vszip_ctx_sync.
  * Env VSZIP_STAGING=pinned selects 1 for every new context. */
 int vszip_ctx_set_staging(vszip_ctx *ctx, int mode);
+/* Options. Every switch of the library (vapoursynth-zip_amd/csrc/options.inc lists them with their defaults) is read from the
+ * environment ONCE, when the context is created, under the name given here (e.g. "VSZIP_PLACEMENT", "VSZIP_STAGING",
+ * "VSZIP_RT_NO_ICHAIN"); these two change / read one on a live context. Flags are 0 / 1. VSZIP_ERR_ARG: no such option;
+ * VSZIP_ERR_UNSUPPORTED: a development variant that this build does not contain (-DVSZIP_DEV_VARIANTS). */
+int vszip_ctx_set_option(vszip_ctx *ctx, const char *name, int value);
+int vszip_ctx_get_option(vszip_ctx *ctx, const char *name, int *value);
 /* Error path of a caller that gives up on the current frame: drains the stream and forgets staged
  * D2H copies that have not reached their destination yet (the destinations may then be freed). */
 int vszip_ctx_abort(vszip_ctx *ctx);
@@ -63,7 +70,23 @@ const char *vszip_last_error(vszip_ctx *ctx);
 int vszip_abi_version(void);
 
 /* ---- device memory + staging (replaces nothing: the reference is host-only) */
+/* vszip_dev_alloc. Requests of VSZIP_PLACEMENT_MIN_MIB (512) or more are PLACED: kernels with hundreds of concurrent row
+ * streams (the BoxBlur ring kernels) run 15-20 % faster or slower depending on which physical memory holds a resident batch, and
+ * nothing user space can see or request predicts it (profiles/r03_placement.md). The allocator walks candidate
+ * allocations of the requested size (all held meanwhile, so each lies elsewhere), classifies each with a 2 ms copy in the ring
+ * kernel's access shape, returns the fastest, keeps up to VSZIP_PLACEMENT_PARK_GIB (24) of further fast regions PARKED for the
+ * requests that follow and frees the rest. The walk stops once three fast regions are in hand, holds at most
+ * VSZIP_PLACEMENT_WALK_GIB (64) meanwhile and ends early when the device is full. vszip_dev_free parks a placed region again;
+ * parked memory returns to the driver when any allocation of the library would otherwise fail, in vszip_dev_trim and in
+ * vszip_ctx_destroy. VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc / hipFree. */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
+/* give every parked region back to the driver; *freed_bytes (may be NULL) = how much that was */
+int vszip_dev_trim(vszip_ctx *ctx, size_t *freed_bytes);
+/* What the allocator knows (any pointer may be NULL): the probe rate of the placed allocation `dptr` (bytes / s moved by the
+ * classification copy; 0 = not a placed allocation), the parked regions and their bytes, walks done and candidates probed so far. */
+int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed);
+/* the classification copy on a caller's region (overwrites its contents): bytes / s */
+int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, double *bytes_per_second);
 int vszip_dev_free(vszip_ctx *ctx, void *dptr);
 /* Device memory whose PLACEMENT in VRAM is chosen by measurement. The BoxBlur ring kernels (hundreds of concurrent row
  * streams) run 15-20 % faster or slower depending on which physical memory holds a resident batch — nothing user space
@@ -268,7 +291,10 @@ int vszip_ssimulacra2(vszip_ctx *ctx, const float *const *ref3, const float *con
  *   dtype/bits VSZIP_U8 (8), VSZIP_U16 (9..16) or VSZIP_F32 (f16 is rejected by the wrapper, :106-113);
  *   limited    integer samples are limited range (zimg's default for Gray and YUV) or full (RGB);
  *   linearize  0 when frame 0 carries _Transfer == LINEAR (:139-141), else 1;
- *   YUV only:  ssw / ssh   log2 chroma subsampling (0..2);
+ *   YUV only:  ssw / ssh   log2 chroma subsampling (0..2). A sited chroma plane (chroma_loc != center) lies half a LUMA
+ *                          sample off the centre of its 2^ss luma samples whatever ss — zimg's rule (0.5 / 2^ss chroma
+ *                          samples); ss = 2 (4:1:0, 4:1:1) is not covered by any reference golden, and libvszip.so
+ *                          leaves such clips to the host's resize;
  *              matrix      _Matrix of the clip's frames if set and specified, else what hz.toRGBS passes as matrix_in
  *                          (1 = BT.709 if height > 650 else 6 = BT.601; src/helper.zig:231) — VapourSynth's resize
  *                          lets a frame property win over the *_in argument; supported: 1, 5, 6, 9;

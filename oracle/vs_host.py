@@ -361,11 +361,15 @@ def resize_plane(p: np.ndarray, dst_w: int, dst_h: int, kind: str, shift_w: floa
 
 
 def chroma_offset(loc: int, ss: int, vertical: bool) -> float:
-    """Position of a chroma sample relative to the centre of its 2^ss luma samples, in luma samples.
-    `_ChromaLocation`: 0 left, 1 center, 2 top-left, 3 top, 4 bottom-left, 5 bottom."""
+    """Position of a sited chroma sample relative to the centre of its 2^ss luma samples, in luma samples.
+    `_ChromaLocation`: 0 left, 1 center, 2 top-left, 3 top, 4 bottom-left, 5 bottom.
+    zimg's rule (graphbuilder's chroma shift: raw siting shift -/+0.5, scaled by 1 / 2^ss into chroma samples):
+    half a luma sample for every ss > 0 — NOT the geometric (2^ss - 1) / 2. The two agree at ss = 1, which is all
+    the reference's goldens cover (YUV420P8 / P16); zimg's source is not in the reference tree, so ss = 2 is
+    restated from its published behaviour and unpinned."""
     if ss == 0:
         return 0.0
-    edge = -((1 << ss) - 1) / 2.0
+    edge = -0.5
     if vertical:
         return edge if loc in (2, 3) else (-edge if loc in (4, 5) else 0.0)
     return edge if loc in (0, 2, 4) else 0.0

@@ -19,3 +19,13 @@ def oracle():
 
     orc.build()
     return orc
+
+
+@pytest.fixture(autouse=True)
+def _restore_context_options(request):
+    """options a test set on a (module-scoped) Device go back to what they were, also when the test failed"""
+    yield
+    for name in ("dev", "dev_shfl"):
+        d = request.node.funcargs.get(name) if hasattr(request.node, "funcargs") else None
+        if d is not None and hasattr(d, "restore_options"):
+            d.restore_options()

@@ -165,3 +165,29 @@ def tiled_natural(shape, dtype, plane: int = 0) -> np.ndarray:
     if dtype == np.uint16:
         return (t.astype(np.uint16) * np.uint16(257)).astype(np.uint16)
     return (t.astype(np.float32) * np.float32(1.0 / 255.0)).astype(dtype)
+
+
+def has_dev_variants(dev) -> bool:
+    """does libvszip_hip.so contain the development variants (built with -DVSZIP_DEV_VARIANTS)?"""
+    from vszip_amd.capi import VszipError
+
+    try:
+        dev.get_option("VSZIP_RT_FUSED")
+        return True
+    except VszipError as e:
+        if e.code == -3:
+            return False
+        raise
+
+
+def set_dev_option(dev, name: str, value: int):
+    """set an option that only a -DVSZIP_DEV_VARIANTS build has; the default build skips the test"""
+    import pytest
+    from vszip_amd.capi import VszipError
+
+    try:
+        dev.set_option(name, value)
+    except VszipError as e:
+        if e.code == -3:
+            pytest.skip(f"{name}: development variant, not in the default build")
+        raise

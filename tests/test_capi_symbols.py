@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libvszip_hip.so does not export {name}"
     assert declared == set(vszip_amd.capi.SYMBOLS), (declared ^ set(vszip_amd.capi.SYMBOLS))
-    assert lib.vszip_abi_version() == 2
+    assert lib.vszip_abi_version() == 3
 
 
 def test_no_gpu_fails_loudly():
@@ -56,3 +56,24 @@ def test_resample_table_equals_the_oracle_restatement():
         assert np.array_equal(left, l0.astype(np.int32)), (src, dst, shift)
         assert np.array_equal(coef[:, :w].view(np.uint32), c0.view(np.uint32)), (src, dst, shift)
         assert not coef[:, w:].any()
+
+
+def test_the_environment_is_read_in_one_place():
+    """every switch is parsed once, in vszip_ctx_create (ctx.hip, from csrc/options.inc); no dispatch calls getenv."""
+    import re
+    from pathlib import Path
+
+    csrc = Path(__file__).resolve().parents[1] / "vapoursynth-zip_amd" / "csrc"
+    hits = {}
+    for f in sorted(csrc.glob("*")):
+        if f.suffix in (".hip", ".hpp", ".cpp", ".inc", ".h"):
+            n = len(re.findall(r"\bgetenv\s*\(", f.read_text()))
+            if n:
+                hits[f.name] = n
+    assert hits == {"ctx.hip": 1}, hits
+    # every option line names a VSZIP_ variable exactly once
+    names = re.findall(r'VSZIP_(?:DEV_)?OPT\(\w+, "(VSZIP_[A-Z0-9_]+)"', (csrc / "options.inc").read_text())
+    assert len(names) == len(set(names)) >= 40
+    # the default build does not define the development variants
+    build = (csrc.parent / "build.py").read_text()
+    assert "VSZIP_DEV_VARIANTS" not in build.split("FLAGS = [")[1].split("]")[0]

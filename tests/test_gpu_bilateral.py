@@ -142,9 +142,9 @@ def test_lds16_path_equals_gathered_path(dev, oracle, dtype, sig, monkeypatch):
         src = fx.tiled_natural(shape, dtype, 1)
         refs = [np.ascontiguousarray(np.roll(src, 3, axis=1))] if joint else None
         (a,), cfgs = _gpu(dev, [src], sS, sR, refs=refs, algorithm=[2])
-        monkeypatch.setenv("VSZIP_BILATERAL_NO_LDS16", "1")
+        dev.set_option("VSZIP_BILATERAL_NO_LDS16", 1)
         (b,), _ = _gpu(dev, [src], sS, sR, refs=refs, algorithm=[2])
-        monkeypatch.delenv("VSZIP_BILATERAL_NO_LDS16")
+        dev.set_option("VSZIP_BILATERAL_NO_LDS16", 0)
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (dtype, sig, shape, joint)
         c = cfgs[0]
         want = oracle.bilateral_plane(src, c[0], c[1], c[2], c[3], c[4], c[5], ref=refs[0] if joint else None)
@@ -181,12 +181,12 @@ def test_walk16_paths_agree(dev, oracle, sig, content, dtype, monkeypatch):
             assert "plane too small" in str(e)  # planes not larger than the taps are rejected (bilateral.zig(vs):206-209)
             continue
         c = cfgs[0]
-        monkeypatch.setenv("VSZIP_BILATERAL_NO_FINE", "1")
+        dev.set_option("VSZIP_BILATERAL_NO_FINE", 1)
         (b,), _ = _gpu(dev, [src], sS, sR, algorithm=[2])
-        monkeypatch.delenv("VSZIP_BILATERAL_NO_FINE")
-        monkeypatch.setenv("VSZIP_BILATERAL_NO_WALK", "1")
+        dev.set_option("VSZIP_BILATERAL_NO_FINE", 0)
+        dev.set_option("VSZIP_BILATERAL_NO_WALK", 1)
         (t,), _ = _gpu(dev, [src], sS, sR, algorithm=[2])
-        monkeypatch.delenv("VSZIP_BILATERAL_NO_WALK")
+        dev.set_option("VSZIP_BILATERAL_NO_WALK", 0)
         want = oracle.bilateral_plane(src, c[0], c[1], c[2], c[3], c[4], c[5])
         # (f32 planes, round 3: the 8K RGBS pipeline's Bilateral stage takes the walk kernel too; compared as bit patterns)
         assert np.array_equal(a.view(np.uint8), want.view(np.uint8)), (sig, content, shape, dtype, int((a != want).sum()))

@@ -26,11 +26,9 @@ def dev():
 def dev_shfl():
     import vszip_amd
 
-    os.environ["VSZIP_SCAN_MODE"] = "1"
-    try:
-        d = vszip_amd.Device(0)
-    finally:
-        del os.environ["VSZIP_SCAN_MODE"]
+    d = vszip_amd.Device(0)
+    d.set_option("VSZIP_SCAN_MODE", 1)
+    d._opt_saved.clear()  # (this context keeps it: conftest's restore leaves it alone)
     yield d
     d.close()
 
@@ -141,7 +139,7 @@ def test_rt_float_pass_chain_kernels(dev, oracle, dtype, monkeypatch):
              ([(19, 40)], (2, 2, 2, 2)), ([(18, 18)], (8, 2, 8, 3)), ([(64, 64)], (3, 3, 3, 3)), ([(65, 63)], (4, 2, 2, 5)), ([(128, 129)], (6, 3, 6, 2)),
              ([(81, 257)], (30, 2, 25, 2)), ([(150, 191)], (13, 5, 13, 5)), ([(48, 48)], (2, 6, 2, 6)), ([(16, 300)], (9, 2, 9, 2)), ([(33, 17)], (1, 3, 1, 3)),
              ([(100, 200)], (5, 3, 0, 0)), ([(100, 200)], (0, 0, 5, 3)), ([(60, 90)], (1, 11, 1, 7)), ([(70, 333)], (3, 8, 0, 0)), ([(200, 40)], (0, 0, 2, 12)), ([(97, 1)], (0, 0, 3, 2)), ([(1, 97)], (3, 2, 0, 0))]
-    monkeypatch.setenv("VSZIP_RT_FCHAIN_ALL", "1")  # (the horizontal chain is for calls of 12 000+ rows by default)
+    dev.set_option("VSZIP_RT_FCHAIN_ALL", 1)  # (the horizontal chain is for calls of 12 000+ rows by default)
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(31 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
 
@@ -154,14 +152,14 @@ def test_rt_float_pass_chain_kernels(dev, oracle, dtype, monkeypatch):
         try:
             got = run()
         except Exception as e:  # (a radius the filter refuses for this plane: the same error either way)
-            monkeypatch.setenv("VSZIP_RT_NO_FCHAIN", "1")
+            dev.set_option("VSZIP_RT_NO_FCHAIN", 1)
             with pytest.raises(type(e)):
                 run()
-            monkeypatch.delenv("VSZIP_RT_NO_FCHAIN")
+            dev.set_option("VSZIP_RT_NO_FCHAIN", 0)
             continue
-        monkeypatch.setenv("VSZIP_RT_NO_FCHAIN", "1")
+        dev.set_option("VSZIP_RT_NO_FCHAIN", 1)
         per_pass = run()
-        monkeypatch.delenv("VSZIP_RT_NO_FCHAIN")
+        dev.set_option("VSZIP_RT_NO_FCHAIN", 0)
         for p, a, b in zip(planes, got, per_pass):
             want = oracle.boxblur(p, *args)
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (shapes, args, int((a != b).sum()), np.argwhere(a != b)[:4].tolist())
@@ -221,9 +219,9 @@ def test_rt_horizontal_mirror_extended_rows(dev, oracle, dtype, r, monkeypatch):
             got = _run(dev, src, r, passes, 0, 0)
             want = oracle.boxblur(src, r, passes, 0, 0)
             assert np.array_equal(got, want), (dtype, r, w, passes, np.argwhere(got != want)[:4].tolist())
-            monkeypatch.setenv("VSZIP_RT_NO_VIRT", "1")
+            dev.set_option("VSZIP_RT_NO_VIRT", 1)
             alt = _run(dev, src, r, passes, 0, 0)
-            monkeypatch.delenv("VSZIP_RT_NO_VIRT")
+            dev.set_option("VSZIP_RT_NO_VIRT", 0)
             assert np.array_equal(got, alt), (dtype, r, w, passes)
 
 
@@ -276,9 +274,9 @@ def test_rt_fused_multipass_equals_per_pass(dev, oracle, dtype, monkeypatch):
             return [dev.download(d) for d in dsts]
 
         base = run()
-        monkeypatch.setenv("VSZIP_RT_FUSED", "1")
+        fx.set_dev_option(dev, "VSZIP_RT_FUSED", 1)
         fused = run()
-        monkeypatch.delenv("VSZIP_RT_FUSED")
+        fx.set_dev_option(dev, "VSZIP_RT_FUSED", 0)
         for p, a, b in zip(planes, base, fused):
             want = oracle.boxblur(p, *args)
             assert np.array_equal(b, want), (shapes, args, int((b != want).sum()))
@@ -300,6 +298,7 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
              # the vertical pass chain (3 ... 5 stages, more passes in several chains; radii to 30; lines of 2 R + 2 rows up; widths that are not whole 4-sample groups)
              ([(200, 70)], (0, 0, 2, 3)), ([(333, 131)], (0, 0, 5, 3)), ([(64, 64)], (0, 0, 3, 4)), ([(96, 35)], (0, 0, 1, 5)), ([(130, 200), (65, 100)], (2, 2, 3, 7)),
              ([(62, 48)], (0, 0, 30, 2)), ([(150, 41)], (0, 0, 22, 3)), ([(28, 260)], (0, 0, 13, 2)), ([(300, 5)], (0, 0, 4, 6)), ([(45, 3)], (0, 0, 2, 3)), ([(1080, 36)], (0, 0, 13, 5))]
+    dev_variants = fx.has_dev_variants(dev)
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(11 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
 
@@ -310,20 +309,18 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
             return [dev.download(d) for d in dsts]
 
         got = run()
-        monkeypatch.setenv("VSZIP_RT_VSMALL", "1")  # two vertical stages in one launch (opt-in since the end of round 3)
-        vsm = run()
-        monkeypatch.delenv("VSZIP_RT_VSMALL")
-        monkeypatch.setenv("VSZIP_RT_ICHAIN_ALL", "1")  # the vertical pass chain wherever it can run (by default: 3+ passes, batches of 900+ column groups, 8-bit planes from five passes on)
-        chain_all = run()
-        monkeypatch.setenv("VSZIP_RT_NO_VSMALL", "1")   # ... and for two passes of a small radius too
-        chain_2 = run()
-        monkeypatch.delenv("VSZIP_RT_ICHAIN_ALL")
-        monkeypatch.setenv("VSZIP_RT_NO_HSMALL", "1")
-        monkeypatch.setenv("VSZIP_RT_NO_ICHAIN", "1")
-        per_pass = run()
-        monkeypatch.delenv("VSZIP_RT_NO_HSMALL")
-        monkeypatch.delenv("VSZIP_RT_NO_VSMALL")
-        monkeypatch.delenv("VSZIP_RT_NO_ICHAIN")
+        vsm = got
+        if dev_variants:
+            with dev.options(VSZIP_RT_VSMALL=1):  # two vertical stages in one launch (a development variant since round 4)
+                vsm = run()
+        with dev.options(VSZIP_RT_ICHAIN_ALL=1):  # the vertical pass chain wherever it can run (by default: 3+ passes, batches of 900+ column groups, 8-bit planes from five passes on)
+            chain_all = run()
+            chain_2 = chain_all
+            if dev_variants:
+                with dev.options(VSZIP_RT_NO_VSMALL=1):  # ... and for two passes of a small radius too
+                    chain_2 = run()
+        with dev.options(VSZIP_RT_NO_HSMALL=1, VSZIP_RT_NO_ICHAIN=1):
+            per_pass = run()
         for p, a, b, c, c2, v in zip(planes, got, per_pass, chain_all, chain_2, vsm):
             want = oracle.boxblur(p, *args)
             assert np.array_equal(a, want), (shapes, args, int((a != want).sum()))
@@ -332,8 +329,10 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
             assert np.array_equal(c, want), (shapes, args, "pass chain", int((c != want).sum()), np.argwhere(c != want)[:3].tolist())
             assert np.array_equal(c2, want), (shapes, args, "pass chain, two stages", int((c2 != want).sum()))
     # three and four vertical stages (not the default: measured slower than a launch per pass)
-    monkeypatch.setenv("VSZIP_RT_VSMALL", "1")
-    monkeypatch.setenv("VSZIP_RT_VSMALL_MAX", "4")
+    if not dev_variants:
+        return
+    fx.set_dev_option(dev, "VSZIP_RT_VSMALL", 1)
+    fx.set_dev_option(dev, "VSZIP_RT_VSMALL_MAX", 4)
     for shapes, args in [([(300, 333)], (2, 2, 2, 3)), ([(521, 96), (260, 48)], (0, 0, 3, 4)), ([(70, 520)], (1, 2, 1, 4)), ([(1080, 512)], (0, 0, 2, 3))]:
         planes = [fx.splitmix64_plane(17 + i, sh, dtype) for i, sh in enumerate(shapes)]
         srcs = [dev.upload(p) for p in planes]

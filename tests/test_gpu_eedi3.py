@@ -158,12 +158,12 @@ def test_two_plane_heights_overlap_equals_sequential_and_oracle(dev, oracle, kw,
     shapes = [(96, 160), (48, 80), (48, 80)] * 2
     planes = [np.ascontiguousarray(fx.tiled_natural(s, np.float32, i % 3)) + np.float32(0.01 * (i // 3)) for i, s in enumerate(shapes)]
     srcs = [dev.upload(p) for p in planes]
-    monkeypatch.setenv("VSZIP_EEDI3_FORCE_OVERLAP", "1")  # (the library overlaps from 12 frames per call on: below that it does not pay)
+    dev.set_option("VSZIP_EEDI3_FORCE_OVERLAP", 1)  # (the library overlaps from 12 frames per call on: below that it does not pay)
     a = [dev.download(d) for d in dev.eedi3(srcs, 1, **kw)]
-    monkeypatch.delenv("VSZIP_EEDI3_FORCE_OVERLAP")
-    monkeypatch.setenv("VSZIP_EEDI3_NO_OVERLAP", "1")
+    dev.set_option("VSZIP_EEDI3_FORCE_OVERLAP", 0)
+    dev.set_option("VSZIP_EEDI3_NO_OVERLAP", 1)
     b = [dev.download(d) for d in dev.eedi3(srcs, 1, **kw)]
-    monkeypatch.delenv("VSZIP_EEDI3_NO_OVERLAP")
+    dev.set_option("VSZIP_EEDI3_NO_OVERLAP", 0)
     okw = {k: v for k, v in kw.items() if k != "horizontal"}
     for p, x, y in zip(planes, a, b):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))

@@ -60,12 +60,9 @@ def test_boxblur_runtime_passes_batches_take_the_pass_chains(dev, oracle, dtype,
     base = [fx.tiled_natural(s, dtype, p) for p, s in enumerate(_yuv420(shape))]
     planes = [np.ascontiguousarray(np.roll(p, 7 * f, axis=1)) for f in range(frames) for p in base]
     got, _ = _boxblur(dev, planes, *args)
-    for k in ("VSZIP_RT_NO_FCHAIN", "VSZIP_RT_NO_ICHAIN"):
-        monkeypatch.setenv(k, "1")
-    per_pass, _ = _boxblur(dev, planes, *args)
-    for k in ("VSZIP_RT_NO_FCHAIN", "VSZIP_RT_NO_ICHAIN"):
-        monkeypatch.delenv(k)
-    assert "VSZIP_RT_NO_ICHAIN" not in os.environ
+    with dev.options(VSZIP_RT_NO_FCHAIN=1, VSZIP_RT_NO_ICHAIN=1):
+        per_pass, _ = _boxblur(dev, planes, *args)
+    assert dev.get_option("VSZIP_RT_NO_ICHAIN") == 0 and "VSZIP_RT_NO_ICHAIN" not in os.environ
     for i, (a, b) in enumerate(zip(got, per_pass)):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (i, args, np.argwhere(a != b)[:3].tolist())
     for a, p in zip(got[:3], planes[:3]):

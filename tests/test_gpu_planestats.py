@@ -120,9 +120,9 @@ def test_minmax_single_read_and_its_second_sweep(dev, oracle, dtype, monkeypatch
     refs = [fx.splitmix64_plane(40 + i, p.shape, dtype) for i, p in enumerate(planes)]
     ds, dr = [dev.upload(p) for p in planes], [dev.upload(r) for r in refs]
     for thr in [(0.0, 0.0), (0.02, 0.02), (0.3, 0.1), (0.06, 0.9), (1.0, 1.0)]:
-        monkeypatch.delenv("VSZIP_MINMAX_SINGLE_READ", raising=False)
+        fx.set_dev_option(dev, "VSZIP_MINMAX_SINGLE_READ", 0)
         mn, mx, df = dev.plane_minmax(ds, thr[0], thr[1], dr)
-        monkeypatch.setenv("VSZIP_MINMAX_SINGLE_READ", "1")
+        fx.set_dev_option(dev, "VSZIP_MINMAX_SINGLE_READ", 1)
         mn2, mx2, df2 = dev.plane_minmax(ds, thr[0], thr[1], dr)
         mn3, mx3, _ = dev.plane_minmax(ds, thr[0], thr[1])  # (without a reference clip: the other instantiation)
         assert list(mn3) == list(mn2) and list(mx3) == list(mx2), thr

@@ -348,7 +348,7 @@ def test_limit_filter_through_plugin(oracle):
         want = oracle.limit_filter(oracle.boxblur(np.ascontiguousarray(src8[p]), 2, 1, 2, 1), src8[p], None, 8, 8, 3)
         assert np.array_equal(out[p], want)
     nat = [fx.tiled_natural(s, np.uint16, p) for p, s in enumerate([(96, 160), (48, 80), (48, 80)])]
-    for props, limited in ((None, True), ({"_ColorRange": 0}, True), ({"_ColorRange": 1}, False), ({"_Range": 0}, False)):
+    for props, limited in ((None, True), ({"_ColorRange": 0}, True), ({"_ColorRange": 1}, False), ({"_Range": 0}, True), ({"_Range": 1}, True)):
         c16 = vs.source([nat], vs.YUV420P16, props=props)
         f16 = c16.vszip.BoxBlur(hradius=2, vradius=2)
         r16 = c16.vszip.BoxBlur(hradius=4, vradius=4)

@@ -125,9 +125,9 @@ def test_block_kernels_agree(dev, oracle, monkeypatch):
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(3)]
     p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(3)]
     strip = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60)
-    monkeypatch.setenv("VSZIP_XPSNR_BLOCKS", "1")
+    dev.set_option("VSZIP_XPSNR_BLOCKS", 1)
     block = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60)
-    monkeypatch.delenv("VSZIP_XPSNR_BLOCKS")
+    dev.set_option("VSZIP_XPSNR_BLOCKS", 0)
     assert strip == block == want
 
 
@@ -148,9 +148,9 @@ def test_packed_8bit_strip_agrees(dev, oracle, monkeypatch, shape, fps):
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(3)]
     p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(3)]
     packed = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps)
-    monkeypatch.setenv("VSZIP_XPSNR_UNPACKED", "1")
+    dev.set_option("VSZIP_XPSNR_UNPACKED", 1)
     generic = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps)
-    monkeypatch.delenv("VSZIP_XPSNR_UNPACKED")
+    dev.set_option("VSZIP_XPSNR_UNPACKED", 0)
     assert packed == generic == want
 
 
@@ -170,9 +170,9 @@ def test_device_weighting_is_the_host_weighting(dev, oracle, monkeypatch, shape)
     drc = [[dev.upload(p) for p in fr] for fr in recs]
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(4)]
     on_dev = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
-    monkeypatch.setenv("VSZIP_XPSNR_HOST_WEIGH", "1")
+    dev.set_option("VSZIP_XPSNR_HOST_WEIGH", 1)
     on_host = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
-    monkeypatch.delenv("VSZIP_XPSNR_HOST_WEIGH")
+    dev.set_option("VSZIP_XPSNR_HOST_WEIGH", 0)
     assert on_dev == on_host == want
 
 

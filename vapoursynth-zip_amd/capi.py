@@ -77,6 +77,11 @@ SYMBOLS = {
     "vszip_ctx_sync": (_i, [_vp]),
     "vszip_ctx_set_staging": (_i, [_vp, _i]),
     "vszip_ctx_abort": (_i, [_vp]),
+    "vszip_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "vszip_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
+    "vszip_dev_trim": (_i, [_vp, C.POINTER(_sz)]),
+    "vszip_dev_placement_info": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i)]),
+    "vszip_dev_probe_region": (_i, [_vp, _vp, _sz, C.POINTER(C.c_double)]),
     "vszip_last_error": (C.c_char_p, [_vp]),
     "vszip_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_dev_free": (_i, [_vp, _vp]),
@@ -225,6 +230,63 @@ class Device:
     def set_staging(self, mode: int):
         """0: host copies go straight from/to the caller's memory; 1: through the context's pinned arena."""
         self.check(self.lib.vszip_ctx_set_staging(self.ctx, mode))
+
+    def set_option(self, name: str, value: int = 1):
+        """vszip_ctx_set_option: one switch of csrc/options.inc on this context, by its environment name.
+        VszipError with code VSZIP_ERR_UNSUPPORTED for a development variant a default build does not contain."""
+        saved = self.__dict__.setdefault("_opt_saved", {})
+        if name not in saved:
+            try:
+                saved[name] = self.get_option(name)
+            except VszipError:
+                pass
+        self.check(self.lib.vszip_ctx_set_option(self.ctx, name.encode(), int(value)))
+
+    def restore_options(self, keep=()):
+        """every option set through set_option back to its value before the first set (tests)"""
+        for k, v in list(self.__dict__.get("_opt_saved", {}).items()):
+            if k not in keep:
+                self.lib.vszip_ctx_set_option(self.ctx, k.encode(), int(v))
+                del self._opt_saved[k]
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        self.check(self.lib.vszip_ctx_get_option(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """`with dev.options(VSZIP_RT_NO_ICHAIN=1): ...` — set, run, restore (the path-agreement tests)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+
+        return scope()
+
+    def trim(self) -> int:
+        """vszip_dev_trim: parked placement regions back to the driver; -> bytes freed"""
+        n = C.c_size_t()
+        self.check(self.lib.vszip_dev_trim(self.ctx, C.byref(n)))
+        return n.value
+
+    def placement_info(self, ptr: int = 0) -> dict:
+        """vszip_dev_placement_info: probe rate of a placed allocation (0: not placed), parked regions / bytes, walks, probed"""
+        bps, nreg, nby, walks, probed = C.c_double(), C.c_int(), C.c_size_t(), C.c_int(), C.c_int()
+        self.check(self.lib.vszip_dev_placement_info(self.ctx, C.c_void_p(ptr), C.byref(bps), C.byref(nreg), C.byref(nby), C.byref(walks), C.byref(probed)))
+        return {"bytes_per_second": bps.value, "parked_regions": nreg.value, "parked_bytes": nby.value, "walks": walks.value, "probed": probed.value}
+
+    def probe_region(self, ptr: int, nbytes: int) -> float:
+        bps = C.c_double()
+        self.check(self.lib.vszip_dev_probe_region(self.ctx, C.c_void_p(ptr), nbytes, C.byref(bps)))
+        return bps.value
 
     def set_stream(self, hip_stream: int):
         """Enqueue on an externally owned hipStream_t (e.g. torch.cuda.Stream().cuda_stream)."""

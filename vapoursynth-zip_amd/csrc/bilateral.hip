@@ -1289,7 +1289,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
     // the f32 table in the same allocation when every entry round-trips
     std::vector<uint32_t> pbase;
     std::vector<uint16_t> pdelta;
-    bool packed = hist_len == 65536 && !getenv("VSZIP_BILATERAL_NO_LDS16");
+    bool packed = hist_len == 65536 && !ctx->opt.bilateral_no_lds16;
     if (packed) {
         pbase.resize(1024);
         pdelta.resize(65536);
@@ -1336,7 +1336,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
     // evaluated here with the kernel's three FMAs, + the difference of the bit patterns per entry
     std::vector<float> ccoef;
     std::vector<int8_t> ccorr;
-    bool cubic = hist_len == 65536 && !packed && upper + 1 > (uint32_t)kWalkPlateauMax && !getenv("VSZIP_BILATERAL_NO_CUBIC") && !getenv("VSZIP_BILATERAL_NO_LDS16");
+    bool cubic = hist_len == 65536 && !packed && upper + 1 > (uint32_t)kWalkPlateauMax && !ctx->opt.bilateral_no_cubic && !ctx->opt.bilateral_no_lds16;
     if (cubic) {
         ccoef.assign((size_t)kCubicSeg * 4, 0.0f);
         ccorr.assign(65536, 0);
@@ -1396,7 +1396,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
     }
     void *d = nullptr;
     const size_t gr_bytes = gr.size() * sizeof(float);
-    if (hipMalloc(&d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0) + (fine ? (size_t)kWalkFineBytes : 0) + (cubic ? (size_t)kCubicBytes : 0)) != hipSuccess)
+    if (vszip_hip_malloc(ctx, &d, gr_bytes + (packed ? (size_t)kL16LutBytes : 0) + (fine ? (size_t)kWalkFineBytes : 0) + (cubic ? (size_t)kCubicBytes : 0)) != hipSuccess)
         return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: range LUT allocation failed");
     auto upload = [&](size_t off, const void *src, size_t n) { return hipMemcpy(static_cast<char *>(d) + off, src, n, hipMemcpyHostToDevice) == hipSuccess; };
     bool up_ok = upload(0, gr.data(), gr_bytes);
@@ -1421,7 +1421,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
             pl.cubic[d] = {key, upper};
         }
-        if (hist_len % 4 == 0 && upper + 1 <= (uint32_t)kWalkPlateauMax && !getenv("VSZIP_BILATERAL_NO_LDS16")) {  // (8- / 10- / 12-bit clips: the whole table is that short)
+        if (hist_len % 4 == 0 && upper + 1 <= (uint32_t)kWalkPlateauMax && !ctx->opt.bilateral_no_lds16) {  // (8- / 10- / 12-bit clips: the whole table is that short)
             uint64_t key;
             std::memcpy(&key, &cfg->sigmaR, sizeof key);
             pl.plateau[d] = {key, upper};
@@ -1439,7 +1439,7 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
         std::vector<float> gs((size_t)up2 * up2);
         for (int y = 0; y < up2; ++y)
             for (int x = 0; x < up2; ++x) gs[(size_t)y * up2 + x] = (float)std::exp((double)(x * x + y * y) / (cfg->sigmaS * cfg->sigmaS * -2.0));
-        if (hipMalloc(&d, gs.size() * sizeof(float)) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: spatial LUT allocation failed");
+        if (vszip_hip_malloc(ctx, &d, gs.size() * sizeof(float)) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "Bilateral: spatial LUT allocation failed");
         VSZIP_HIP_CHECK(ctx, hipMemcpy(d, gs.data(), gs.size() * sizeof(float), hipMemcpyHostToDevice));
         cfg->gs_lut = static_cast<float *>(d);
     }
@@ -1458,7 +1458,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         int n = 0, blocks = 0;
         // one launch group: the tiled kernel when every radius fits its LDS tile; `joint` if any
         // plane of the group brings a separate ref clip
-        bool tiled = !getenv("VSZIP_BILATERAL_UNTILED"), joint = false;
+        bool tiled = !ctx->opt.bilateral_untiled, joint = false;
         int max_radius = 0;
         // algorithm 1 planes run one by one (each is its own set of launches)
         if (cfgs[done] && cfgs[done]->process && cfgs[done]->algorithm == 1) {
@@ -1529,7 +1529,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         }
         // Steep tables (the filter's usual sigmaR) with the BASELINE's tap shapes: the walk kernel with the table's computed part in LDS
         // (PLATEAU form), one launch per distinct (table, taps)
-        if (!lds16 && tiled && !joint && (dtype == VSZIP_U8 || dtype == VSZIP_U16 || dtype == VSZIP_F32) && !getenv("VSZIP_BILATERAL_NO_WALK")) {
+        if (!lds16 && tiled && !joint && (dtype == VSZIP_U8 || dtype == VSZIP_U16 || dtype == VSZIP_F32) && !ctx->opt.bilateral_no_walk) {
             struct PKey {
                 uint64_t table;
                 uint32_t upper;
@@ -1543,7 +1543,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                 keys[i].step = prm.p[i].step;
                 keys[i].form = lut_plateau(prm.p[i].gr, &keys[i].table, &keys[i].upper);
                 walk[i] = keys[i].form != 0 &&
-                          ((keys[i].radius == 3 && keys[i].step == 2) || (keys[i].radius == 2 && keys[i].step == 1) || (keys[i].radius == 5 && keys[i].step == 2 && !getenv("VSZIP_BILATERAL_NO_WALK36")));
+                          ((keys[i].radius == 3 && keys[i].step == 2) || (keys[i].radius == 2 && keys[i].step == 1) || (keys[i].radius == 5 && keys[i].step == 2 && !ctx->opt.bilateral_no_walk36));
                 if (walk[i] && std::find(groups.begin(), groups.end(), keys[i]) == groups.end()) groups.push_back(keys[i]);
             }
             for (const PKey &g : groups) {
@@ -1582,7 +1582,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
             blocks = nb;
         }
         // ... and steep tables with any other taps (or a `ref` clip): the persistent tile kernel with the same PLATEAU table in LDS
-        if (!lds16 && tiled && dtype != VSZIP_U8 && prm.lut_len == 65536 && !getenv("VSZIP_BILATERAL_NO_LDS16")) {
+        if (!lds16 && tiled && dtype != VSZIP_U8 && prm.lut_len == 65536 && !ctx->opt.bilateral_no_lds16) {
             const size_t bps = dtype == VSZIP_F32 ? 4 : 2;
             const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64, stages = (dtype == VSZIP_F32 || joint) ? 4 : 6;
             const size_t tile_elems = (size_t)(kBX + 2 * max_radius) * (tile_h + 2 * max_radius);
@@ -1653,12 +1653,12 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                     const int tile_h = (dtype == VSZIP_F32 || joint) ? 32 : 64;
                     qb += dp.nbx * ((dp.h + tile_h - 1) / tile_h);
                 }
-                const bool no_walk = getenv("VSZIP_BILATERAL_NO_WALK") != nullptr;  // (read per call: the tests switch paths inside one process)
+                const bool no_walk = ctx->opt.bilateral_no_walk != 0;
                 if ((dtype == VSZIP_U16 || dtype == VSZIP_F32) && !joint && !no_walk && q.nplanes > 0) {
                     int r = q.p[0].radius, st = q.p[0].step;
                     for (int i = 1; i < q.nplanes; ++i)
                         if (q.p[i].radius != r || q.p[i].step != st) r = st = 0;
-                    const bool no_fine = getenv("VSZIP_BILATERAL_NO_FINE") != nullptr;
+                    const bool no_fine = ctx->opt.bilateral_no_fine != 0;
                     bool fine = !no_fine;
                     for (int i = 0; i < q.nplanes && fine; ++i) lut_is_packed(q.p[i].gr, nullptr, &fine);
                     if (r == 3 && st == 2) {
@@ -1671,7 +1671,7 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
                         if (rc != VSZIP_OK) return rc;
                         continue;
                     }
-                    if (r == 5 && st == 2 && !getenv("VSZIP_BILATERAL_NO_WALK36")) {  // sigmaS = 3, the filter's default
+                    if (r == 5 && st == 2 && !ctx->opt.bilateral_no_walk36) {  // sigmaS = 3, the filter's default
                         rc = dtype == VSZIP_U16 ? launch_walk36<uint16_t>(ctx, q, fine ? 1 : 0) : launch_walk36<float>(ctx, q, fine ? 1 : 0);
                         if (rc != VSZIP_OK) return rc;
                         continue;

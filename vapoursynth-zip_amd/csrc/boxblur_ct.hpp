@@ -882,7 +882,7 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
                 target = t;
             }
         }
-        if (const char *e = getenv("VSZIP_RING_PERIODS")) target = std::max(1, atoi(e));  // development sweep knob
+        if (ctx->opt.ring_periods > 0) target = ctx->opt.ring_periods;  // development sweep knob (-DVSZIP_DEV_VARIANTS)
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         int blocks = 0, fit = n;
         for (int i = 0; i < n; ++i) {

@@ -560,9 +560,9 @@ struct RingDispatch<T, 0> {
 // real halo), rows [R, h - R); false when the plane is too small or not 16-byte (f16: 8-byte) aligned - the tile
 // kernel then takes all of it.
 template <typename T>
-bool ring_interior(const vszip_plane &s, int radius, int nr, int hl, int two, int &ntx, int &xb) {
+bool ring_interior(const vszip_ctx *ctx, const vszip_plane &s, int radius, int nr, int hl, int two, int &ntx, int &xb) {
     constexpr uintptr_t VB = sizeof(T) * kFRPx;
-    if (radius > kFRMaxR || std::getenv("VSZIP_BOXBLUR_NO_FLOAT_RING")) return false;
+    if (radius > kFRMaxR || ctx->opt.boxblur_no_float_ring) return false;
     if ((reinterpret_cast<uintptr_t>(s.src) | reinterpret_cast<uintptr_t>(s.dst) | (uintptr_t)(s.src_stride * sizeof(T)) | (uintptr_t)(s.dst_stride * sizeof(T))) & (VB - 1)) return false;
     xb = ((s.w - hl) / kFRPx) * kFRPx;
     ntx = (xb + two - 1) / two;
@@ -585,7 +585,7 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
     std::vector<int> nb(nplanes, 0), ntxs(nplanes, 0), xbs(nplanes, 0);
     long waves = 0;
     for (int i = 0; i < nplanes; ++i) {
-        if (!ring_interior<T>(planes[i], radius, NR, HL, TWO, ntxs[i], xbs[i])) continue;
+        if (!ring_interior<T>(ctx, planes[i], radius, NR, HL, TWO, ntxs[i], xbs[i])) continue;
         nb[i] = 1;
         waves += ntxs[i];
     }
@@ -606,7 +606,7 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
     // least one band before it (otherwise the bottom strip goes through the tile kernel as the right one does)
     const int NB = (radius % 2 == 0) ? radius : radius + 1;
     std::vector<int> ylasts(nplanes, 0);
-    if (!getenv("VSZIP_BOXBLUR_FLOAT_BOTTOM_STRIP"))
+    if (!ctx->opt.boxblur_float_bottom_strip)
         for (int i = 0; i < nplanes; ++i) {
             if (nb[i] < 2) continue;
             const int main_rows = planes[i].h - NB;
@@ -671,7 +671,7 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
     for (int i = 0; i < nplanes; ++i) {
         const vszip_plane &s = planes[i];
         int ntx, xb;
-        if (ring_interior<T>(s, radius, NR, HL, TWO, ntx, xb)) {
+        if (ring_interior<T>(ctx, s, radius, NR, HL, TWO, ntx, xb)) {
             if (ylasts[i] > 0) {
                 add_rect(s, xb, 0, s.w, s.h);  // right (the ring kernel does the top, left and bottom edges itself)
             } else {

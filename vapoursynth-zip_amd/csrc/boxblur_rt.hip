@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_hchain_kernel(const RPara
     }
 }
 
+#ifdef VSZIP_DEV_VARIANTS  // measured slower than what the default build runs (options.inc)
 // ---------------------------------------------------------------------------------------------
 // Round 3 — several integer passes along one axis in ONE kernel (blur_passes, boxblur_runtime.zig:81-119): a 256-thread
 // workgroup owns a row; a thread keeps its 16 contiguous samples in REGISTERS across the passes. Per pass: in-thread
@@ -1236,6 +1237,7 @@ __global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams 
 }
 
 // 64 x 64 tiles through LDS: dst[x][y] = src[y][x] (integer planes; the vertical passes of the fused path)
+#endif  // VSZIP_DEV_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // Several HORIZONTAL passes of a SMALL radius in one launch (round 3): BoxBlur(hradius = 1..8, hpasses >= 2) is how scripts approximate a
 // Gaussian, and each pass used to be a kernel of its own — the same ~100 us per 8 4K frames whatever the radius. One wave owns a row, keeps it
@@ -1245,7 +1247,7 @@ __global__ __launch_bounds__(kHmNT) void boxblur_rt_hmulti_kernel(const RParams 
 // the row's first R + 1 samples of the pass's own input, which are right there. One read and one write of the plane for all passes.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHsMaxR = 16, kHsMaxW = 8192, kHsHalo = 16;  // (radius 13 x 5 passes is the reference README's third benchmark)
-constexpr int kVsMaxR = 8;
+[[maybe_unused]] constexpr int kVsMaxR = 8;
 template <typename T, int R>
 __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm, const int npass, const int pitch /* u16 elements per LDS buffer */) {
     extern __shared__ __attribute__((aligned(16))) uint16_t hs[];
@@ -1334,6 +1336,7 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
     }
 }
 
+#ifdef VSZIP_DEV_VARIANTS  // measured slower than what the default build runs (options.inc)
 // ---------------------------------------------------------------------------------------------
 // ... and several VERTICAL passes of a small radius in one launch: boxblur_rt_vsmall_kernel<T, P>. A wave owns 64 x 8 columns and a band of
 // output rows and pushes every input row through a chain of P stages; stage k keeps the last 2R + 2 rows of ITS input in an LDS ring (lane-
@@ -1523,10 +1526,11 @@ __global__ __launch_bounds__(256) void rt_transpose_kernel(const RParams prm) {
         if (bx + r < pl.w && by + tx < pl.h) d[(size_t)(bx + r) * pl.dstride + by + tx] = tile[tx][r];
 }
 
+#endif  // VSZIP_DEV_VARIANTS
 // all horizontal passes of a small radius in one launch (boxblur_rt_hsmall_kernel); false: the planes do not qualify
 template <typename T>
-bool hsmall_ok(const std::vector<RPlane> &pl, int radius, int npass) {
-    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || radius < 1 || radius > kHsMaxR || getenv("VSZIP_RT_NO_HSMALL")) return false;
+bool hsmall_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass) {
+    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || radius < 1 || radius > kHsMaxR || ctx->opt.rt_no_hsmall) return false;
     for (const RPlane &q : pl) {
         const uintptr_t bits = reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) | (uintptr_t)((size_t)q.dstride * sizeof(T));
         if ((bits & 15) != 0 || q.w <= 2 * radius || q.w > kHsMaxW || q.sstride < ((q.w + 7) / 8) * 8 || q.dstride < ((q.w + 7) / 8) * 8) return false;
@@ -1564,19 +1568,19 @@ int launch_hsmall(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int
     return VSZIP_OK;
 }
 
+#ifdef VSZIP_DEV_VARIANTS  // measured slower than what the default build runs (options.inc)
 // all vertical passes of a small radius in one launch (boxblur_rt_vsmall_kernel); false: the planes do not qualify
 template <typename T>
-bool vsmall_ok(const std::vector<RPlane> &pl, int radius, int npass) {
+bool vsmall_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass) {
     // Measured (tools/boxblur_radii_probe.py, 1080p, 64 frames per call, against one launch per pass): two passes 93.3 k -> 107.7 k fps (u16), 105 k -> 108 k
     // (u8); three passes 68 k -> 66.5 k (u16), 79 k -> 65 k (u8) — the chain's rings and registers leave 6 waves a CU at three stages. Hence two passes
     // only (VSZIP_RT_VSMALL_MAX=3 / 4 for experiments).
     // End of round 3: OPT-IN (VSZIP_RT_VSMALL=1). The per-pass kernel's LDS ring with its software pipeline (later that round) overtook it: two vertical passes, 1080p, 64 / 16 / 4
     // frames per call, two launches against this kernel: u8 r = 1 179 k / 191 k / 60 k fps against 156 k / 160 k / 48 k, u16 147 k / 167 k / 68 k against 153 k / 160 k / 49 k; from r = 3 on
     // this kernel falls to 64 - 105 k (its rings leave few waves a CU) where two launches stay at 137 - 180 k (tools/boxblur_radii_probe.py).
-    if (!getenv("VSZIP_RT_VSMALL")) return false;
-    const char *mx = getenv("VSZIP_RT_VSMALL_MAX");
-    const int max_pass = mx ? std::min(4, std::max(2, atoi(mx))) : 2;
-    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || npass > max_pass || radius < 1 || radius > kVsMaxR || getenv("VSZIP_RT_NO_VSMALL")) return false;
+    if (!ctx->opt.rt_vsmall) return false;
+    const int max_pass = std::min(4, std::max(2, (int)ctx->opt.rt_vsmall_max));
+    if (!std::is_integral<T>::value || sizeof(T) > 2 || npass < 2 || npass > max_pass || radius < 1 || radius > kVsMaxR || ctx->opt.rt_no_vsmall) return false;
     if ((size_t)npass * (2 * radius + 2) * 1024 > 40 * 1024) return false;  // the rings: four waves a CU at least
     for (const RPlane &q : pl) {
         const uintptr_t bits = reinterpret_cast<uintptr_t>(q.src) | reinterpret_cast<uintptr_t>(q.dst) | (uintptr_t)((size_t)q.sstride * sizeof(T)) | (uintptr_t)((size_t)q.dstride * sizeof(T));
@@ -1623,6 +1627,12 @@ int launch_vsmall(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int
     return VSZIP_OK;
 }
 
+#else
+template <typename T>
+bool vsmall_ok(const vszip_ctx *, const std::vector<RPlane> &, int, int) { return false; }
+template <typename T>
+int launch_vsmall(vszip_ctx *ctx, const std::vector<RPlane> &, int, int, bool) { return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "boxblur_rt_vsmall_kernel is a development variant"); }
+#endif  // VSZIP_DEV_VARIANTS
 template <typename T>
 int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool vertical, bool keep) {
     constexpr bool is_int = std::is_integral<T>::value;
@@ -1656,9 +1666,9 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
             }
             if (aligned && !vertical) {
                 constexpr int CH = 64 * RtVec<T>::V;
-                if (radius < CH - 1 && !getenv("VSZIP_RT_HROW")) {
+                if (radius < CH - 1 && !ctx->opt.rt_hrow) {
                     // virtual (mirror-extended) rows when every row is whole lane groups and wider than its halos
-                    bool virt = !getenv("VSZIP_RT_NO_VIRT");
+                    bool virt = !ctx->opt.rt_no_virt;
                     for (int i = 0; i < n; ++i) virt = virt && prm.p[i].w % RtVec<T>::V == 0 && prm.p[i].w >= radius + 1 + RtVec<T>::V;
                     if (virt)
                         hipLaunchKernelGGL((boxblur_rt_hring_kernel<T, true>), dim3(blocks), dim3(64), 0, ctx->stream, prm);
@@ -1684,7 +1694,7 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                 }
                 int band = std::max(64, 4 * radius);
                 while (band < maxh && colgroups * ((maxh + band - 1) / band) > 16384) band *= 2;
-                if (const char *e = getenv("VSZIP_RT_VBAND")) band = std::max(8, atoi(e));  // development sweep knob
+                if (ctx->opt.rt_vband > 0) band = std::max(8, (int)ctx->opt.rt_vband);  // development sweep knob (-DVSZIP_DEV_VARIANTS)
                 vp.band = band;
                 int vb = 0;
                 for (int i = 0; i < n; ++i) {
@@ -1693,8 +1703,7 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
                     vp.ncg[i] = (prm.p[i].w + 64 * RtVec<T>::V - 1) / (64 * RtVec<T>::V);
                     vb += vp.ncg[i] * ((prm.p[i].h + band - 1) / band);
                 }
-                const char *vr = getenv("VSZIP_RT_VRING_MAXR");  // development: the largest radius that takes the ring
-                if (radius <= (vr ? atoi(vr) : kVRingMaxR) && !getenv("VSZIP_RT_NO_VRING"))
+                if (radius <= (ctx->opt.rt_vring_maxr > 0 ? (int)ctx->opt.rt_vring_maxr : kVRingMaxR) && !ctx->opt.rt_no_vring)
                     hipLaunchKernelGGL((boxblur_rt_vband_kernel<T, true>), dim3(vb), dim3(64), (size_t)(2 * radius + 2) * 64 * sizeof(uint4), ctx->stream, vp);
                 else
                     hipLaunchKernelGGL((boxblur_rt_vband_kernel<T, false>), dim3(vb), dim3(64), 0, ctx->stream, vp);
@@ -1720,14 +1729,14 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
 // The float chain kernels: 2 ... 5 passes, lines of at least 2 R + 2 samples, rings within one workgroup's LDS.
 constexpr int kFcMaxPass = 5;
 template <typename T>
-bool fchain_ok(const std::vector<RPlane> &pl, int radius, int npass, bool vertical) {
+bool fchain_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool vertical) {
     constexpr bool is_int = std::is_integral<T>::value;
-    if (getenv(is_int ? "VSZIP_RT_NO_ICHAIN" : "VSZIP_RT_NO_FCHAIN") || npass < 2 || npass > kFcMaxPass) return false;
+    if ((is_int ? ctx->opt.rt_no_ichain : ctx->opt.rt_no_fchain) || npass < 2 || npass > kFcMaxPass) return false;
     if (is_int && (!vertical || sizeof(T) > 2 || radius > 127)) return false;  // integer planes: the vertical chain only (the horizontal passes have boxblur_rt_hsmall_kernel)
     // 8-bit planes: the per-pass kernel moves 16 samples a lane and wins up to four passes and at larger radii (1080p, 64 frames per call, chain against a launch per pass:
     // r = 2 x 3 passes -11 %, 13 x 2 -19 %, 2 x 4 even, 3 x 5 +16 %; 16-bit planes: +12 ... +55 % throughout — tools/boxblur_radii_probe.py). VSZIP_RT_ICHAIN_ALL=1: every case (tests).
-    if (is_int && sizeof(T) == 1 && !(npass >= 5 && radius <= 8) && !getenv("VSZIP_RT_ICHAIN_ALL")) return false;
-    if (is_int && !getenv("VSZIP_RT_ICHAIN_ALL")) {
+    if (is_int && sizeof(T) == 1 && !(npass >= 5 && radius <= 8) && !ctx->opt.rt_ichain_all) return false;
+    if (is_int && !ctx->opt.rt_ichain_all) {
         // Two passes: two launches of the per-pass kernel are as fast (u16, r >= 3: the chain +3 ... 8 % at 64 frames) and do not mind small calls. And the chain is as slow as its
         // longest column (a wave per 64 columns, ~0.1 us a tick): with fewer waves than SIMDs — a plugin context submits ONE frame per call — the per-pass kernels, which
         // cut a plane into bands, are several times faster (4 1080p frames, three passes: ~110 us against 3 x 25 us).
@@ -1736,7 +1745,7 @@ bool fchain_ok(const std::vector<RPlane> &pl, int radius, int npass, bool vertic
         for (const RPlane &q : pl) waves += (q.w + 63) / 64;
         if (waves < 900) return false;
     }
-    if (!is_int && !vertical && !getenv("VSZIP_RT_FCHAIN_ALL")) {
+    if (!is_int && !vertical && !ctx->opt.rt_fchain_all) {
         // The horizontal chain carries 64 rows a wave and costs what a row's ticks cost however few waves there are; the per-pass kernel (16 rows a wave) is faster on small calls:
         // 4K YUV420PS, 3 passes of r = 5, 1 / 2 / 4 frames per call: chain 2.5 k / 5.0 k / 9.7 k fps, a launch per pass 3.0 k / 5.7 k / 9.2 k. (The vertical chain wins from one frame on.)
         long rows = 0;
@@ -1806,6 +1815,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
         off[i] = elems;
         elems += (size_t)((planes[i].w + 63) & ~63) * planes[i].h;
     }
+#ifdef VSZIP_DEV_VARIANTS  // measured slower than what the default build runs (options.inc)
     // Integer planes with >= 2 passes on an axis, OPT-IN (VSZIP_RT_FUSED=1): the fused kernel keeps a row in registers across that
     // axis's passes (horizontal directly; vertical, from 3 passes on, between two transposes: four HBM round trips for any 5 + 5
     // instead of ten). Bit-exact (tests/test_gpu_boxblur.py::test_rt_fused_multipass_equals_per_pass) — and measured SLOWER than
@@ -1815,7 +1825,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
     // LDS with three barriers per pass), so saving the round trips buys nothing. The README's 5 + 5-pass benchmark therefore stays
     // at ten round trips (profiles/r03_notes.md).
     if constexpr (std::is_integral<T>::value) {
-        bool ok = getenv("VSZIP_RT_FUSED") != nullptr && total > 1;
+        bool ok = ctx->opt.rt_fused && total > 1;
         const bool fuse_h = hb && hpasses >= 2, fuse_v = vb && vpasses >= 3;
         ok = ok && (fuse_h || fuse_v);
         for (int i = 0; i < nplanes && ok; ++i) {
@@ -1919,6 +1929,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
             return VSZIP_OK;
         }
     }
+#endif  // VSZIP_DEV_VARIANTS
     // Several passes: the planes go through ALL passes in groups small enough that a pass's output is still in the Infinity
     // Cache (256 MiB, memory side) when the next pass reads it — a line stays resident while everything touched between its two
     // uses fits (MI355X_MICROARCH.md, Infinity Cache): about three group sizes here, so groups of <= 48 MB. HBM then sees the
@@ -1927,7 +1938,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
     // (measured, round 3: 4K YUV420P16 3 + 3 passes of r = 5, groups of 24 / 48 / 96 MB: 8.4 k / 12.8 k / 13.6 k fps against 13.5 k in one
     // group — the passes are not HBM-bound enough for residency to beat the smaller launches; the default is ONE group)
     size_t group_bytes = ~(size_t)0;
-    if (const char *e = getenv("VSZIP_RT_GROUP_MB")) group_bytes = atoi(e) > 0 ? (size_t)atoi(e) << 20 : ~(size_t)0;
+    if (ctx->opt.rt_group_mb > 0) group_bytes = (size_t)ctx->opt.rt_group_mb << 20;  // (-DVSZIP_DEV_VARIANTS)
     int g0 = 0;
     while (g0 < nplanes) {
         int g1 = g0;
@@ -1988,20 +1999,20 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
                 }
             }
             int rc;
-            if (!std::is_integral<T>::value && span > 1 && fchain_ok<T>(cur, vertical ? vradius : hradius, span, vertical)) {
+            if (!std::is_integral<T>::value && span > 1 && fchain_ok<T>(ctx, cur, vertical ? vradius : hradius, span, vertical)) {
                 if constexpr (!std::is_integral<T>::value) rc = launch_fchain<T>(ctx, cur, vertical ? vradius : hradius, span, vertical, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
-            } else if (std::is_integral<T>::value && span > 1 && vertical && !vsmall_ok<T>(cur, vradius, span) && fchain_ok<T>(cur, vradius, span, true)) {
+            } else if (std::is_integral<T>::value && span > 1 && vertical && !vsmall_ok<T>(ctx, cur, vradius, span) && fchain_ok<T>(ctx, cur, vradius, span, true)) {
                 // integer planes, vertical passes the two-stage small-radius kernel does not take: the pass chain (one column a lane, the stages' rings in LDS)
                 if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_fchain<T>(ctx, cur, vradius, span, true, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
-            } else if (span > 1 && !vertical && hsmall_ok<T>(cur, hradius, hpasses)) {
+            } else if (span > 1 && !vertical && hsmall_ok<T>(ctx, cur, hradius, hpasses)) {
                 if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_hsmall<T>(ctx, cur, hradius, hpasses, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;
-            } else if (span > 1 && vertical && vsmall_ok<T>(cur, vradius, span)) {
+            } else if (span > 1 && vertical && vsmall_ok<T>(ctx, cur, vradius, span)) {
                 if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) rc = launch_vsmall<T>(ctx, cur, vradius, span, !last);
                 else rc = VSZIP_ERR_ARG;
                 p += span - 1;

@@ -19,7 +19,7 @@ static int ensure_chain_buf(vszip_ctx *ctx, size_t bytes) {
         ctx->chain_bytes = 0;
     }
     const size_t want = bytes + (bytes >> 3) + 4096;
-    if (hipMalloc(&ctx->chain_buf, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "chain buffer allocation of %zu bytes failed", want);
+    if (vszip_hip_malloc(ctx, &ctx->chain_buf, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "chain buffer allocation of %zu bytes failed", want);
     ctx->chain_bytes = want;
     return VSZIP_OK;
 }

@@ -13,7 +13,21 @@
 
 #define VSZIP_EXPORT extern "C" __attribute__((visibility("default")))
 
+// csrc/options.inc: every switch, parsed once per context (ctx.hip)
+struct vszip_options {
+#define VSZIP_OPT(field, env, def) int field = def;
+#ifdef VSZIP_DEV_VARIANTS
+#define VSZIP_DEV_OPT(field, env, def) int field = def;
+#else
+#define VSZIP_DEV_OPT(field, env, def) static constexpr int field = def;
+#endif
+#include "options.inc"
+#undef VSZIP_OPT
+#undef VSZIP_DEV_OPT
+};
+
 struct vszip_ctx {
+    vszip_options opt;
     int device = 0;
     int num_cus = 0;  // compute units of `device` (0: unknown)
     hipStream_t stream = nullptr;
@@ -48,7 +62,7 @@ struct vszip_ctx {
     // Host staging (vszip_ctx_set_staging): 0 = copy straight from/to the caller's pointers (pinned
     // callers, or pageable memory that the runtime pins in place), 1 = through this context's pinned
     // arena with CPU copies — H2D: copy in, DMA asynchronously; D2H: DMA now, copy out in vszip_ctx_sync.
-    int staging = 0;
+    int &staging = opt.staging;
     char *stage = nullptr;
     size_t stage_bytes = 0, stage_used = 0;
     struct PendingOut {
@@ -61,11 +75,20 @@ struct vszip_ctx {
     void *chain_buf = nullptr;  // vszip_chain_run: intermediate planes (grow-only)
     size_t chain_bytes = 0;
     void *ssim_lut = nullptr;  // SSIMULACRA2 colour pre-stage: cached conversion table (ssimulacra2.hip)
-    int scan_mode = 0;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
+    int &scan_mode = opt.scan_mode;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
+    // placed allocations (ctx.hip): classified regions that are not in use, and the probe cost of the ones that are
+    struct Region {
+        void *ptr;
+        size_t bytes;
+        double cost;  // probe seconds per byte moved; smaller is faster
+    };
+    std::vector<Region> parked, placed;
+    int placement_walks = 0, placement_probed = 0;
 };
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
 int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes);
+hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes);  // hipMalloc; parked placement regions are released before it fails (ctx.hip)
 int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
 void vszip_ssim_release(vszip_ctx *ctx);  // frees ctx->ssim_lut
 void vszip_chain_release(vszip_ctx *ctx);  // frees ctx->chain_buf

@@ -5,8 +5,13 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <set>
+
+namespace {
+size_t trim_parked(vszip_ctx *ctx);
+}
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
@@ -29,7 +34,7 @@ int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes) {
         ctx->scratch_bytes = 0;
     }
     const size_t want = bytes + (bytes >> 3) + 4096;
-    if (hipMalloc(&ctx->scratch, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "scratch allocation of %zu bytes failed", want);
+    if (vszip_hip_malloc(ctx, &ctx->scratch, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "scratch allocation of %zu bytes failed", want);
     ctx->scratch_bytes = want;
     return VSZIP_OK;
 }
@@ -44,13 +49,71 @@ int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes) {
         ctx->scalars_bytes = 0;
     }
     const size_t want = (bytes + 4095) & ~(size_t)4095;
-    if (hipMalloc(&ctx->scalars_dev, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "scalar buffer allocation failed");
+    if (vszip_hip_malloc(ctx, &ctx->scalars_dev, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "scalar buffer allocation failed");
     if (hipHostMalloc(&ctx->scalars_host, want, hipHostMallocDefault) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "pinned scalar buffer allocation failed");
     ctx->scalars_bytes = want;
     return VSZIP_OK;
 }
 
 VSZIP_EXPORT int vszip_abi_version(void) { return VSZIP_ABI_VERSION; }
+
+// ---- options (csrc/options.inc): the environment is read HERE, once per context, and nowhere else in csrc/ ----
+namespace {
+struct OptionDesc {
+    const char *env;
+    int vszip_options::*field;  // nullptr: a development variant this build does not contain
+};
+const OptionDesc kOptions[] = {
+#define VSZIP_OPT(f, env, def) {env, &vszip_options::f},
+#ifdef VSZIP_DEV_VARIANTS
+#define VSZIP_DEV_OPT(f, env, def) {env, &vszip_options::f},
+#else
+#define VSZIP_DEV_OPT(f, env, def) {env, nullptr},
+#endif
+#include "options.inc"
+#undef VSZIP_OPT
+#undef VSZIP_DEV_OPT
+};
+
+// flags: "" / "0" off, any other text on; integers as they are ("pinned" is VSZIP_STAGING's historical spelling of 1)
+int option_value(const char *text) {
+    if (!text || !*text) return 0;
+    char *end = nullptr;
+    const long v = strtol(text, &end, 10);
+    if (end != text && *end == 0) return (int)v;
+    return 1;
+}
+
+void options_from_env(vszip_options *o) {
+    for (const OptionDesc &d : kOptions) {
+        if (!d.field) continue;
+        if (const char *e = getenv(d.env)) o->*d.field = option_value(e);
+    }
+}
+}  // namespace
+
+VSZIP_EXPORT int vszip_ctx_set_option(vszip_ctx *ctx, const char *name, int value) {
+    if (!ctx || !name) return VSZIP_ERR_ARG;
+    for (const OptionDesc &d : kOptions)
+        if (strcmp(d.env, name) == 0) {
+            if (!d.field) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s is a development variant: build with -DVSZIP_DEV_VARIANTS", name);
+            if (d.field == &vszip_options::staging) return vszip_ctx_set_staging(ctx, value);  // (drains what is staged first)
+            ctx->opt.*d.field = value;
+            return VSZIP_OK;
+        }
+    return vszip_set_error(ctx, VSZIP_ERR_ARG, "unknown option %s", name);
+}
+
+VSZIP_EXPORT int vszip_ctx_get_option(vszip_ctx *ctx, const char *name, int *value) {
+    if (!ctx || !name || !value) return VSZIP_ERR_ARG;
+    for (const OptionDesc &d : kOptions)
+        if (strcmp(d.env, name) == 0) {
+            if (!d.field) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s is a development variant: build with -DVSZIP_DEV_VARIANTS", name);
+            *value = ctx->opt.*d.field;
+            return VSZIP_OK;
+        }
+    return vszip_set_error(ctx, VSZIP_ERR_ARG, "unknown option %s", name);
+}
 
 // Streams created with a CU mask must be gone before the process tears the runtime down: with rocprofv3 attached
 // a live one crashes the tool's finaliser (SIGSEGV inside __cxa_finalize, after the outputs are written). Contexts
@@ -106,10 +169,7 @@ VSZIP_EXPORT int vszip_ctx_create(int device, vszip_ctx **out) {
     c->own_stream = true;
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
-    const char *st = getenv("VSZIP_STAGING");
-    if (st) c->staging = (strcmp(st, "pinned") == 0 || strcmp(st, "1") == 0) ? 1 : 0;
-    const char *sm = getenv("VSZIP_SCAN_MODE");
-    if (sm) c->scan_mode = atoi(sm);
+    options_from_env(&c->opt);
     *out = c;
     return VSZIP_OK;
 }
@@ -118,6 +178,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    trim_parked(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
     vszip_ssim_release(ctx);
@@ -189,10 +250,203 @@ VSZIP_EXPORT int vszip_ctx_set_staging(vszip_ctx *ctx, int mode) {
 
 VSZIP_EXPORT const char *vszip_last_error(vszip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// ---- placed allocations -------------------------------------------------------------------------------------
+// WHERE a resident batch lies in VRAM decides how fast kernels with many concurrent row streams run on it: the BoxBlur
+// ring kernel's 64-frame 4K launch takes 545-565 us with its planes in some physical regions and 640-680 us in others
+// (a property of the physical memory, in runs of ~10 GiB; no layout user space can choose changes it, streaming
+// kernels do not see it: profiles/r03_placement.md). Round 3 searched for a fast region in bench.py; since round 4 the
+// allocator does it for every caller: a request of VSZIP_PLACEMENT_MIN_MIB or more is served from a walk over candidate
+// allocations of that size (all held meanwhile, so each lies elsewhere), each classified by placement_probe_kernel — the
+// ring kernel's access shape without its arithmetic — in about 2 ms. The fastest is returned, the next best stay PARKED
+// (allocated, classified, not in use) up to VSZIP_PLACEMENT_PARK_GIB for the requests that follow (a batch is a source
+// and a destination arena), the rest are freed. vszip_dev_free parks a placed region again instead of freeing it.
+// Parked memory goes back to the driver when an allocation fails, in vszip_dev_trim and in vszip_ctx_destroy.
+// Bounded: the walk holds at most VSZIP_PLACEMENT_WALK_GIB and stops as soon as enough regions of the fast class have
+// turned up; VSZIP_PLACEMENT=0 turns all of it off (plain hipMalloc).
+namespace {
+
+typedef unsigned int pv4u __attribute__((ext_vector_type(4)));
+
+// One wave per (band, tile): moves a 960-byte column tile down `band_rows` rows of a 7680-byte-pitch view of the region,
+// reading its own band and writing the band half a region away (every tile is read once and written once per launch).
+__global__ __launch_bounds__(64) void placement_probe_kernel(char *base, int bands, int band_rows) {
+    constexpr long long kPitch = 7680;
+    const int b = blockIdx.x >> 3, t = blockIdx.x & 7, lane = threadIdx.x;
+    if (lane >= 60) return;
+    const int wb = b + bands / 2 < bands ? b + bands / 2 : b + bands / 2 - bands;
+    const char *sp = base + (long long)b * band_rows * kPitch + t * 960 + lane * 16;
+    char *dp = base + (long long)wb * band_rows * kPitch + t * 960 + lane * 16;
+    pv4u a = *reinterpret_cast<const pv4u *>(sp);
+    for (int r = 0; r < band_rows; ++r) {
+        const pv4u v = a;
+        if (r + 1 < band_rows) a = *reinterpret_cast<const pv4u *>(sp + (long long)(r + 1) * kPitch);
+        __builtin_nontemporal_store(v, reinterpret_cast<pv4u *>(dp + (long long)r * kPitch));
+    }
+}
+
+constexpr size_t kProbeSpan = (size_t)2 << 30;  // at most this much of a region is probed (its first 2 GiB)
+constexpr double kFastBytesPerSec = 5.45e12;     // placement_probe_kernel: fast regions move 5.6-5.8 TB/s, slow ones 4.9-5.1
+
+// seconds per byte moved by the probe on [ptr, ptr + bytes); < 0: could not measure
+double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes) {
+    const size_t span = std::min(bytes, kProbeSpan);
+    const long long rows = (long long)(span / 7680);
+    // ~3072 streams like the ring kernel's launch: 384 bands x 8 tiles, bands of 64 ... 540 rows
+    int band_rows = (int)std::min<long long>(540, std::max<long long>(64, rows / 384));
+    const int bands = (int)(rows / band_rows);
+    if (bands < 2) return -1.0;
+    const dim3 grid(bands * 8);
+    hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), bands, band_rows);
+    if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) return -1.0;
+    const int n = 2;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), bands, band_rows);
+    float ms = 0;
+    if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess || hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0;
+    }
+    const double moved = 2.0 * n * (double)bands * band_rows * 8 * 960;
+    return ms * 1e-3 / moved;
+}
+
+void park_region(vszip_ctx *ctx, const vszip_ctx::Region &r) {
+    ctx->parked.push_back(r);
+    // over the cap: the slowest go back to the driver
+    const size_t cap = (size_t)std::max(0, ctx->opt.placement_park_gib) << 30;
+    size_t total = 0;
+    for (const auto &q : ctx->parked) total += q.bytes;
+    while (total > cap && !ctx->parked.empty()) {
+        size_t worst = 0;
+        for (size_t i = 1; i < ctx->parked.size(); ++i)
+            if (ctx->parked[i].cost > ctx->parked[worst].cost) worst = i;
+        total -= ctx->parked[worst].bytes;
+        (void)hipFree(ctx->parked[worst].ptr);
+        ctx->parked.erase(ctx->parked.begin() + worst);
+    }
+}
+
+size_t trim_parked(vszip_ctx *ctx) {
+    size_t freed = 0;
+    for (const auto &q : ctx->parked) {
+        (void)hipFree(q.ptr);
+        freed += q.bytes;
+    }
+    ctx->parked.clear();
+    return freed;
+}
+
+}  // namespace
+
+// hipMalloc that gives parked memory back to the driver before it reports failure (every allocation of the library)
+hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !ctx->parked.empty()) {
+        (void)hipGetLastError();
+        trim_parked(ctx);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+namespace {
+
+int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
+    // 1: a parked region of a fitting size (the fastest one)
+    int pick = -1;
+    for (size_t i = 0; i < ctx->parked.size(); ++i) {
+        const auto &r = ctx->parked[i];
+        if (r.bytes >= bytes && r.bytes / 2 <= bytes && (pick < 0 || r.cost < ctx->parked[pick].cost)) pick = (int)i;
+    }
+    const double fast_cost = 1.0 / kFastBytesPerSec;
+    if (pick >= 0 && ctx->parked[pick].cost <= fast_cost) {
+        ctx->placed.push_back(ctx->parked[pick]);
+        *dptr = ctx->parked[pick].ptr;
+        ctx->parked.erase(ctx->parked.begin() + pick);
+        return VSZIP_OK;
+    }
+    // 2: walk. Everything stays allocated until the walk ends; it ends when three regions of the fast class are in hand (the one
+    // to return and two to park: a batch is two arenas, and the next batch's walk should not start from nothing), when the
+    // walk budget is used, or when the device is full.
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t budget = (size_t)std::max(1, ctx->opt.placement_walk_gib) << 30;
+    const int max_cand = (int)std::min<size_t>(64, std::max<size_t>(1, budget / bytes));
+    std::vector<vszip_ctx::Region> cand;
+    if (pick >= 0) {  // a parked region of the slow class competes with what the walk finds
+        cand.push_back(ctx->parked[pick]);
+        ctx->parked.erase(ctx->parked.begin() + pick);
+    }
+    int fast = 0;
+    for (int k = 0; k < max_cand && fast < 3; ++k) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        double c = probe_region(ctx, p, bytes);
+        if (c < 0) c = 1.0;  // unmeasurable: last choice
+        cand.push_back({p, bytes, c});
+        if (c <= fast_cost) ++fast;
+    }
+    if (cand.empty()) {
+        void *p = nullptr;
+        if (vszip_hip_malloc(ctx, &p, bytes) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+        *dptr = p;
+        return VSZIP_OK;
+    }
+    std::sort(cand.begin(), cand.end(), [](const vszip_ctx::Region &a, const vszip_ctx::Region &b) { return a.cost < b.cost; });
+    *dptr = cand[0].ptr;
+    ctx->placed.push_back(cand[0]);
+    ctx->placement_walks += 1;
+    ctx->placement_probed += (int)cand.size();
+    // the slow ones are freed FIRST (in one go, after the walk), then the fast ones are parked
+    for (size_t i = 1; i < cand.size(); ++i)
+        if (cand[i].cost > fast_cost) (void)hipFree(cand[i].ptr);
+    for (size_t i = 1; i < cand.size(); ++i)
+        if (cand[i].cost <= fast_cost) park_region(ctx, cand[i]);
+    return VSZIP_OK;
+}
+
+}  // namespace
+
 VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    if (ctx->opt.placement && bytes >= ((size_t)std::max(1, ctx->opt.placement_min_mib) << 20)) return placed_alloc(ctx, bytes, dptr);
+    if (vszip_hip_malloc(ctx, dptr, bytes ? bytes : 1) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_dev_trim(vszip_ctx *ctx, size_t *freed_bytes) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t f = trim_parked(ctx);
+    if (freed_bytes) *freed_bytes = f;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed) {
+    if (!ctx) return VSZIP_ERR_ARG;
+    if (bytes_per_second) {
+        *bytes_per_second = 0.0;
+        for (const auto &r : ctx->placed)
+            if (r.ptr == dptr && r.cost > 0) *bytes_per_second = 1.0 / r.cost;
+    }
+    if (parked_regions) *parked_regions = (int)ctx->parked.size();
+    if (parked_bytes) {
+        *parked_bytes = 0;
+        for (const auto &r : ctx->parked) *parked_bytes += r.bytes;
+    }
+    if (walks) *walks = ctx->placement_walks;
+    if (probed) *probed = ctx->placement_probed;
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, double *bytes_per_second) {
+    if (!ctx || !dptr || !bytes_per_second) return VSZIP_ERR_ARG;
+    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const double c = probe_region(ctx, dptr, bytes);
+    if (c <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "region of %zu bytes is too small to probe", bytes);
+    *bytes_per_second = 1.0 / c;
     return VSZIP_OK;
 }
 
@@ -231,6 +485,17 @@ VSZIP_EXPORT int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
     if (!ctx) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     vszip_bilateral_forget_lut(dptr);
+    for (size_t i = 0; i < ctx->placed.size(); ++i)
+        if (ctx->placed[i].ptr == dptr) {  // a classified region: kept for the next request of its size
+            const vszip_ctx::Region r = ctx->placed[i];
+            ctx->placed.erase(ctx->placed.begin() + i);
+            VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (like hipFree: nothing in flight may still use it when it is handed out again)
+            if (ctx->opt.placement) {
+                park_region(ctx, r);
+                return VSZIP_OK;
+            }
+            break;
+        }
     VSZIP_HIP_CHECK(ctx, hipFree(dptr));
     return VSZIP_OK;
 }

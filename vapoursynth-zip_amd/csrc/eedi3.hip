@@ -1559,7 +1559,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     vp.gline = nullptr;
     vp.gline_pitch = (maxL + 63) & ~63;
     if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
-    const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !getenv("VSZIP_VCHECK_GLOBAL");
+    const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !ctx->opt.vcheck_global;
     auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
         const size_t lds = (size_t)maxL * (7 * sizeof(float) + 4);
         vp.plane_base = first;
@@ -1586,8 +1586,8 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     // 2: 576 / 706, 4: 993 / 1119, 8: 1607 / 1630, 16: 2308 / 2170): below that the masked stream's launches and events cost more than the
     // overlap returns, and the plugin's one-frame calls from twelve contexts at once lost half their rate to it (757 against 1599 fps).
     // (VSZIP_EEDI3_FORCE_OVERLAP=1: from one tall plane on — the parity tests run small batches through this path)
-    const int min_tall = getenv("VSZIP_EEDI3_FORCE_OVERLAP") ? 1 : 12;
-    bool split = !general && vc_lds && ntall >= min_tall && ntall < nplanes && ntall <= 64 && !getenv("VSZIP_EEDI3_NO_OVERLAP");
+    const int min_tall = ctx->opt.eedi3_force_overlap ? 1 : 12;
+    bool split = !general && vc_lds && ntall >= min_tall && ntall < nplanes && ntall <= 64 && !ctx->opt.eedi3_no_overlap;
     if (split) {
         const int reserve = std::min(64, (ntall + 7) & ~7), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
         if (ctx->aux_stream && ctx->aux_reserved != reserve) {
@@ -1629,7 +1629,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         const dim3 lblock(64);
 #define VSZIP_E3_LAUNCH(N)                                                                        \
     do {                                                                                          \
-        if (up->mdis == 20 && !getenv("VSZIP_EEDI3_NO_FIXED"))                                    \
+        if (up->mdis == 20 && !ctx->opt.eedi3_no_fixed)                                    \
             hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true>), lgrid, lblock, 0, lst, ep);      \
         else if (up->mdis <= 20)                                                                  \
             hipLaunchKernelGGL((eedi3_line_kernel<N, 20, false>), lgrid, lblock, 0, lst, ep);     \

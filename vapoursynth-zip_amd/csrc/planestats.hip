@@ -18,7 +18,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxPlanesPS = 48;
-constexpr int kHistWords = 4096, kBucketWords = 16, kSampleStep = 16;  // thresholded PlaneMinMax: table sizes; every 16th row is sampled
+constexpr int kHistWords = 4096, kBucketWords = 16;
+[[maybe_unused]] constexpr int kSampleStep = 16;  // thresholded PlaneMinMax: table sizes; every 16th row is sampled
 
 struct PSPlane {
     const void *src;
@@ -415,6 +416,11 @@ __device__ __forceinline__ void scan_bins(const uint32_t *g, int nb, bool from_t
 // reads was written with agent-scope atomics (histogram adds, atomic stores of the partial sums), each wave waits for its own to
 // complete before the workgroup barrier that precedes the ticket add, and the reads are agent-scope atomic loads. Values handed to a
 // LATER kernel (bucket words, zeroed tables, results) are plain stores: the kernel boundary orders them.
+// THE RULE: inside the last workgroup's steps (locate_buckets, finish_plane, write_result, range_scan, scan_bins) every read of
+// hist[], bucket[] words 12 / 13 and partial[] MUST be __hip_atomic_load(..., __HIP_MEMORY_SCOPE_AGENT) — a plain load may hit a stale line
+// of this XCD's L2. The words the steps WRITE and a later kernel reads (bk[0..4], bk[8], bk[9], bk[11], results) are plain.
+// tests/test_gpu_planestats.py::test_handover_many_planes_many_xcds runs enough planes that every plane's last workgroup
+// reads tables built on all eight XCDs, many times over, and compares every plane with the oracle.
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -515,6 +521,7 @@ constexpr int kCandHalf = 2, kRange = (2 * kCandHalf + 1) * 256, kRangeCopies = 
 constexpr int kCopies = 16;
 static_assert(512 + 2 * kRange <= kHistWords, "range tables");
 
+#ifdef VSZIP_DEV_VARIANTS
 constexpr int kSampleBlocks = 32;  // workgroups per plane in the sample pass
 template <typename T>
 __global__ __launch_bounds__(kThreads) void hist_sample_kernel(const PSParams prm) {
@@ -573,6 +580,8 @@ __global__ __launch_bounds__(kThreads) void hist_sample_kernel(const PSParams pr
         bk[9] = tmp[2] == 0xffffffffu ? (uint32_t)-kRange : (uint32_t)max((int)tmp[2] - kCandHalf, 0) << 8;
     }
 }
+
+#endif  // VSZIP_DEV_VARIANTS
 
 // One threshold of the single-read path in the sweep's last workgroup: the reference's scan with the running count started at `start`
 // (the samples before the range in scan order), over the range's kRange bins in chunks of 256. found: 0 = the answer lies outside.
@@ -895,8 +904,9 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
     } else {
         // hist, bucket and shist are contiguous: one memset
         VSZIP_HIP_CHECK(ctx, hipMemsetAsync(L.prm.hist, 0, (size_t)L.prm.nplanes * (kHistWords + kBucketWords + 256) * sizeof(uint32_t), ctx->stream));
-        const int single = wide && getenv("VSZIP_MINMAX_SINGLE_READ") ? 1 : 0;  // opt-in: measured slower than the two sweeps on two of three contents
+        const int single = wide && ctx->opt.minmax_single_read ? 1 : 0;  // opt-in: measured slower than the two sweeps on two of three contents
         const int grid = std::min(L.total_blocks, (REF ? 2 : 3) * 256), grid0 = std::min(L.total_blocks, 3 * 256);
+#ifdef VSZIP_DEV_VARIANTS  // the single-read path (hist_sample_kernel + MODE 1 sweep): measured slower, not in the default build
         if constexpr (wide != 0) {
             if (single) {
                 hipLaunchKernelGGL((hist_sample_kernel<T>), dim3(L.prm.nplanes * kSampleBlocks), dim3(kThreads), 0, ctx->stream, L.prm);
@@ -904,10 +914,14 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
                 hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 1>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
             }
         }
-        // the two-level radix: every plane (8-bit clips, VSZIP_MINMAX_TWO_SWEEPS), or the planes the single sweep flagged (the others' workgroups return at once)
+        // the two-level radix: every plane (8-bit clips), or the planes the single sweep flagged (the others' workgroups return at once)
         if (single) {
             hipLaunchKernelGGL((hist_sweep_kernel<T, false, 0>), dim3(std::min(grid0, 256)), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 1);
-        } else {
+        } else
+#endif
+        {
+            (void)single;
+            (void)grid0;
             vszip_probe_scope probe(ctx);
             hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 0>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
         }

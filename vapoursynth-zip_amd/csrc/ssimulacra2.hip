@@ -1173,7 +1173,7 @@ static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_
                 if (lc->dev) (void)hipFree(lc->dev);
                 lc->dev = nullptr;
                 lc->entries = 0;
-                VSZIP_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&lc->dev), host.size() * sizeof(float)));
+                VSZIP_HIP_CHECK(ctx, vszip_hip_malloc(ctx, reinterpret_cast<void **>(&lc->dev), host.size() * sizeof(float)));
                 lc->entries = host.size();
             }
             VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a launch still reading the old table
@@ -1195,10 +1195,14 @@ static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, in
     const size_t off_v = (size_t)w * 4, off_hc = off_v + (size_t)h * 4, off_vc = off_hc + (size_t)w * 16, bytes = off_vc + (size_t)h * 16;
     if (!(lc->yw == w && lc->yh == h && lc->yssw == fmt->ssw && lc->yssh == fmt->ssh && lc->yloc == fmt->chroma_loc)) {
         std::vector<char> host(bytes);
-        // position of a chroma sample relative to the centre of its 2^ss luma samples, in luma samples
+        // Position of a sited chroma sample relative to the centre of its 2^ss luma samples, in luma samples, by zimg's
+        // rule (graphbuilder: the raw siting shift is -/+0.5 whatever the subsampling, scaled by 1 / 2^ss into chroma
+        // samples): half a luma sample for every ss > 0. At ss = 1 this is also the geometric co-sited position; at
+        // ss = 2 (4:1:0 / 4:1:1) zimg's rule and the geometric one (1.5 luma samples) differ and the reference's
+        // resize.Bicubic is zimg. No reference golden covers ss = 2: the plugin keeps those clips on the host resize.
         auto offset = [&](int ss, bool vertical) -> double {
             if (ss == 0) return 0.0;
-            const double edge = -((1 << ss) - 1) / 2.0;
+            const double edge = -0.5;
             const int loc = fmt->chroma_loc;
             if (vertical) return (loc == 2 || loc == 3) ? edge : ((loc == 4 || loc == 5) ? -edge : 0.0);
             return (loc == 0 || loc == 2 || loc == 4) ? edge : 0.0;
@@ -1216,7 +1220,7 @@ static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, in
             if (lc->ydev) (void)hipFree(lc->ydev);
             lc->ydev = nullptr;
             lc->ybytes = 0;
-            VSZIP_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void **>(&lc->ydev), bytes));
+            VSZIP_HIP_CHECK(ctx, vszip_hip_malloc(ctx, reinterpret_cast<void **>(&lc->ydev), bytes));
             lc->ybytes = bytes;
         }
         VSZIP_HIP_CHECK(ctx, hipMemcpy(lc->ydev, host.data(), bytes, hipMemcpyHostToDevice));
@@ -1411,7 +1415,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     }
     // Scales 2.. are a chain of small, launch-bound kernels (a sixteenth of the samples and less) that depends only on
     // the pyramid pass: it runs on a second stream beside the two large maps launches instead of after them.
-    bool side = allow_side && kScales > 2 && !getenv("VSZIP_SSIM_ONE_STREAM");
+    bool side = allow_side && kScales > 2 && !ctx->opt.ssim_one_stream;
     if (side && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
@@ -1488,7 +1492,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     };
     // Two halves, staggered: the pyramid pass is HBM bound and the maps kernels are issue bound, so the second half's
     // pyramid pass runs (on the second stream) beside the first half's maps instead of before them.
-    bool halves = npairs >= 4 && !getenv("VSZIP_SSIM_ONE_STREAM") && !getenv("VSZIP_SSIM_NO_HALVES");
+    bool halves = npairs >= 4 && !ctx->opt.ssim_one_stream && !ctx->opt.ssim_no_halves;
     if (halves && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {

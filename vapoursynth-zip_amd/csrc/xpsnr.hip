@@ -925,14 +925,14 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
     // strip kernel eligibility: even planes, rows that hold whole 4-sample groups, aligned bases
     const size_t bps = (size_t)bytes_per_sample;
     XStripArgs sa;
-    bool strips = (p.w % 2 == 0) && (p.h % 2 == 0) && getenv("VSZIP_XPSNR_BLOCKS") == nullptr;
+    bool strips = (p.w % 2 == 0) && (p.h % 2 == 0) && !ctx->opt.xpsnr_blocks;
     size_t tab_bytes = 0;
     if (strips) {
         sa.ncomp = num_comps;
         sa.luma_act = p.b >= 4;
         sa.bv = p.b_val;
         sa.tmode = p.tmode;
-        sa.packed = getenv("VSZIP_XPSNR_UNPACKED") == nullptr;
+        sa.packed = !ctx->opt.xpsnr_unpacked;
         for (int c = 0; c < num_comps && strips; ++c) {
             XGeo &g = sa.g[c];
             g.w = width3[c];
@@ -964,7 +964,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
 
     const size_t res_bytes = (size_t)nframes * p.total * sizeof(uint64_t);
     const size_t wsse_bytes = (size_t)nframes * 3 * sizeof(uint64_t);
-    bool dev_weigh = p.n_luma <= (size_t)kWeighMaxBlocks && getenv("VSZIP_XPSNR_HOST_WEIGH") == nullptr;
+    bool dev_weigh = p.n_luma <= (size_t)kWeighMaxBlocks && !ctx->opt.xpsnr_host_weigh;
     for (int c = 1; c < num_comps; ++c) dev_weigh = dev_weigh && (p.b < 4 || p.cn[c] <= p.n_luma);
     if (tab_bytes) {
         rc = vszip_ensure_scratch(ctx, tab_bytes);
@@ -983,7 +983,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
             ctx->xpsnr_sums_bytes = 0;
         }
         const size_t want = std::max<size_t>(res_bytes * 2, 1 << 20);
-        if (hipMalloc(&ctx->xpsnr_sums, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "XPSNR : block sum buffer allocation failed");
+        if (vszip_hip_malloc(ctx, &ctx->xpsnr_sums, want) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "XPSNR : block sum buffer allocation failed");
         ctx->xpsnr_sums_bytes = want;
         ctx->xpsnr_clean = false;
     }

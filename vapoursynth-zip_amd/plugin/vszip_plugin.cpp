@@ -1194,8 +1194,10 @@ struct LimitFilterData {
 // limited range) carry thresholds scaled by 257 = the FULL-range branch of hz.scaleValue; the limited branch (x 256) misses
 // them by up to 8e-5 (tests/test_oracle_zimg_goldens.py::test_limit_filter_keys). So a clip flagged limited resolves to .FULL
 // there — the binding's enum order is the inverse of the prop's — and, by the same mapping, a clip flagged full to .LIMITED.
-// Mirrored here, because results must be the reference's: _ColorRange (0 = full, 1 = limited) and the newer _Range
-// (1 = full, 0 = limited) both map to the OPPOSITE range; only a clip without the prop takes the documented default.
+// Mirrored here, because results must be the reference's: _ColorRange (0 = full, 1 = limited) maps to the OPPOSITE range.
+// That is all the goldens back. The newer _Range prop is NOT read: the inversion is evidence that the binding turns
+// _ColorRange into its enum, and nothing shows it reading _Range at all, so a clip that carries only _Range takes the
+// family default like a clip without any range prop (no golden covers this branch either way).
 bool clip_is_limited_range(const Z &z, VSNode *node) {
     char err[256];
     const VSFrame *f0 = z.api->getFrame(0, node, err, sizeof err);
@@ -1205,11 +1207,6 @@ bool clip_is_limited_range(const Z &z, VSNode *node) {
         int e = 0;
         const int64_t c = z.api->mapGetInt(props, "_ColorRange", 0, &e);
         if (!e) limited = c == 0;  // flagged full -> .LIMITED, flagged limited -> .FULL (see above)
-        if (limited < 0) {
-            e = 0;
-            const int64_t r = z.api->mapGetInt(props, "_Range", 0, &e);
-            if (!e) limited = r == 1;
-        }
         z.api->freeFrame(f0);
     }
     if (limited >= 0) return limited != 0;
@@ -1573,7 +1570,9 @@ bool ssim_device_source(const Z &z, VSNode *node, vszip_ssim_source *fmt) {
     if (!is_constant_format(vi)) return false;
     if (f.colorFamily != cfRGB && f.colorFamily != cfGray && f.colorFamily != cfYUV) return false;
     if (f.colorFamily != cfYUV && (f.subSamplingW || f.subSamplingH)) return false;
-    if (f.subSamplingW > 2 || f.subSamplingH > 2) return false;
+    // 4:1:0 / 4:1:1 stay on the host's resize: no reference golden pins zimg's chroma siting at ss = 2; the
+    // C ABI takes them (vszip_ssim_source.ssw / ssh up to 2) with zimg's rule as far as it is published
+    if (f.subSamplingW > 1 || f.subSamplingH > 1) return false;
     int dt;
     if (f.sampleType == stInteger && f.bitsPerSample >= 8 && f.bitsPerSample <= 16)
         dt = f.bytesPerSample == 1 ? VSZIP_U8 : VSZIP_U16;
