@@ -75,18 +75,23 @@ int vszip_abi_version(void);
  * nothing user space can see or request predicts it (profiles/r03_placement.md). The allocator walks candidate
  * allocations of the requested size (all held meanwhile, so each lies elsewhere), classifies each with a 2 ms copy in the ring
  * kernel's access shape, returns the fastest, keeps up to VSZIP_PLACEMENT_PARK_GIB (24) of further fast regions PARKED for the
- * requests that follow and frees the rest. The walk stops once three fast regions are in hand, holds at most
- * VSZIP_PLACEMENT_WALK_GIB (64) meanwhile and ends early when the device is full. vszip_dev_free parks a placed region again;
+ * requests that follow and frees the rest. The walk stops at the first fast region, holds at most VSZIP_PLACEMENT_WALK_GIB (64)
+ * meanwhile, gives up after VSZIP_PLACEMENT_WALK_MS (2000: memory the device has not handed out before is cleared on first use,
+ * about 50-90 ms per GiB) and ends early when the device is full; a walk that meets no fast region is the context's last. vszip_dev_free parks a placed region again;
  * parked memory returns to the driver when any allocation of the library would otherwise fail, in vszip_dev_trim and in
  * vszip_ctx_destroy. VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc / hipFree. */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
 /* give every parked region back to the driver; *freed_bytes (may be NULL) = how much that was */
 int vszip_dev_trim(vszip_ctx *ctx, size_t *freed_bytes);
 /* What the allocator knows (any pointer may be NULL): the probe rate of the placed allocation `dptr` (bytes / s moved by the
- * classification copy; 0 = not a placed allocation), the parked regions and their bytes, walks done and candidates probed so far. */
-int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed);
-/* the classification copy on a caller's region (overwrites its contents): bytes / s */
-int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, double *bytes_per_second);
+ * classification copy; 0 = not a placed allocation), the parked regions and their bytes, walks done and candidates probed so far,
+ * how long the last walk took, and whether a walk has used its whole budget without meeting a fast region (then this context
+ * searches no more: later requests take a parked region or a plain allocation). */
+int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed, double *last_walk_ms,
+                             int *exhausted);
+/* the classification copy on a caller's region (overwrites its contents): bytes / s. `from` == NULL: tiles are read and written
+ * inside the region; else they are read from `from` (another region of at least `bytes`, not modified) — a source / destination pair. */
+int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, const void *from, double *bytes_per_second);
 int vszip_dev_free(vszip_ctx *ctx, void *dptr);
 /* Device memory whose PLACEMENT in VRAM is chosen by measurement. The BoxBlur ring kernels (hundreds of concurrent row
  * streams) run 15-20 % faster or slower depending on which physical memory holds a resident batch — nothing user space

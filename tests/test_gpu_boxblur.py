@@ -342,3 +342,37 @@ def test_rt_small_radius_multipass_kernels(dev, oracle, dtype, monkeypatch):
             want = oracle.boxblur(p, *args)
             got = dev.download(d)
             assert np.array_equal(got, want), (shapes, args, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_rt_integer_chain_in_bands(dev, oracle, dtype):
+    """Round 4: the integer vertical pass chain cut into bands of rows (boxblur_rt_ichain_kernel: zeroed rings P R rows above a band, the stages' E_0
+    constants from a table that a first launch fills, the plane's ends as the mirror-extended source). Exact under any segmentation: against the oracle,
+    the unbanded chain and one launch per pass — heights that leave a one-row last band, planes barely taller than the mirror extension needs, bands of
+    different counts for luma and chroma, widths that are not whole 4-sample groups, saturated and zero rows, radii to 30, 2 ... 7 passes."""
+    cases = [([(1080, 36)], (0, 0, 13, 5)), ([(541, 130), (270, 65), (270, 65)], (0, 0, 5, 3)), ([(400, 70)], (0, 0, 2, 3)), ([(385, 64)], (0, 0, 3, 4)),
+             ([(257, 33)], (0, 0, 1, 5)), ([(900, 48)], (0, 0, 30, 2)), ([(700, 41)], (0, 0, 22, 3)), ([(513, 260)], (2, 2, 13, 2)), ([(640, 5)], (0, 0, 4, 6)),
+             ([(300, 3)], (0, 0, 2, 7)), ([(1081, 20)], (1, 2, 13, 5)), ([(136, 50)], (0, 0, 9, 3)), ([(2160, 64), (1080, 32)], (0, 0, 5, 3))]
+    for shapes, args in cases:
+        planes = [fx.splitmix64_plane(41 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
+        planes[0][3] = np.iinfo(dtype).max
+        planes[0][-2] = 0
+        planes[0][planes[0].shape[0] // 2, :] = np.iinfo(dtype).max
+
+        def run():
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+            dev.boxblur(srcs, dsts, *args)
+            return [dev.download(d) for d in dsts]
+
+        with dev.options(VSZIP_RT_ICHAIN_ALL=1):
+            banded = run()
+            with dev.options(VSZIP_RT_NO_BANDED=1):
+                whole = run()
+        with dev.options(VSZIP_RT_NO_ICHAIN=1):
+            per_pass = run()
+        for p, a, b, c in zip(planes, banded, whole, per_pass):
+            want = oracle.boxblur(p, *args)
+            assert np.array_equal(a, want), (dtype, shapes, args, "banded", int((a != want).sum()), np.argwhere(a != want)[:4].tolist())
+            assert np.array_equal(b, want), (dtype, shapes, args, "whole columns")
+            assert np.array_equal(c, want), (dtype, shapes, args, "per pass")

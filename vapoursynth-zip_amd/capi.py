@@ -80,8 +80,8 @@ SYMBOLS = {
     "vszip_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "vszip_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "vszip_dev_trim": (_i, [_vp, C.POINTER(_sz)]),
-    "vszip_dev_placement_info": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i)]),
-    "vszip_dev_probe_region": (_i, [_vp, _vp, _sz, C.POINTER(C.c_double)]),
+    "vszip_dev_placement_info": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "vszip_dev_probe_region": (_i, [_vp, _vp, _sz, _vp, C.POINTER(C.c_double)]),
     "vszip_last_error": (C.c_char_p, [_vp]),
     "vszip_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_dev_free": (_i, [_vp, _vp]),
@@ -279,13 +279,14 @@ class Device:
 
     def placement_info(self, ptr: int = 0) -> dict:
         """vszip_dev_placement_info: probe rate of a placed allocation (0: not placed), parked regions / bytes, walks, probed"""
-        bps, nreg, nby, walks, probed = C.c_double(), C.c_int(), C.c_size_t(), C.c_int(), C.c_int()
-        self.check(self.lib.vszip_dev_placement_info(self.ctx, C.c_void_p(ptr), C.byref(bps), C.byref(nreg), C.byref(nby), C.byref(walks), C.byref(probed)))
-        return {"bytes_per_second": bps.value, "parked_regions": nreg.value, "parked_bytes": nby.value, "walks": walks.value, "probed": probed.value}
+        bps, nreg, nby, walks, probed, ms, exh = C.c_double(), C.c_int(), C.c_size_t(), C.c_int(), C.c_int(), C.c_double(), C.c_int()
+        self.check(self.lib.vszip_dev_placement_info(self.ctx, C.c_void_p(ptr), C.byref(bps), C.byref(nreg), C.byref(nby), C.byref(walks), C.byref(probed), C.byref(ms), C.byref(exh)))
+        return {"bytes_per_second": bps.value, "parked_regions": nreg.value, "parked_bytes": nby.value, "walks": walks.value, "probed": probed.value,
+                "last_walk_ms": ms.value, "exhausted": bool(exh.value)}
 
-    def probe_region(self, ptr: int, nbytes: int) -> float:
+    def probe_region(self, ptr: int, nbytes: int, src: int = 0) -> float:
         bps = C.c_double()
-        self.check(self.lib.vszip_dev_probe_region(self.ctx, C.c_void_p(ptr), nbytes, C.byref(bps)))
+        self.check(self.lib.vszip_dev_probe_region(self.ctx, C.c_void_p(ptr), nbytes, C.c_void_p(src) if src else None, C.byref(bps)))
         return bps.value
 
     def set_stream(self, hip_stream: int):

@@ -24,6 +24,7 @@ struct RPlane {
     void *dst;
     int sstride, dstride, w, h;
     int block0;
+    int aux;  // banded integer chain: this plane's first entry in the E_0 table (u32 units)
 };
 struct RParams {
     RPlane p[kMaxPlanesRT];
@@ -1037,6 +1038,181 @@ __global__ __launch_bounds__(64) void boxblur_rt_float_vchain_kernel(const RPara
     }
 }
 
+// ---- the integer vertical chain in BANDS (round 4) -----------------------------------------------------------------------------------------
+// The chain above walks a whole column per lane: a 16-frame 1080p call is 960 waves on 1 024 SIMDs, each alone with its latencies (~30 ns per stage
+// and tick), and the P (2R + 1) ticks at a plane's top and bottom run the generic `tick` (0.44 us each). blurInt's closed form (:10-41) makes the
+// passes EXACT under any segmentation of the rows:
+//   * a stage's output is a function of its input's window SUM and of one constant per line, K = 32768 + ((E_0 * invlo) >> 16), E_0 = the stage's
+//     first window sum. With K known a stage needs no start: its running sum is a sliding sum of whatever sits in its ring, so a band can begin with
+//     zeroed rings and sums P R rows above its first output row — what entered before the true samples (zeros, and the outputs computed from them)
+//     leaves every window again, bit for bit (integer adds): stage k is exact k (2R + 1) ticks after the band's first source row, the last stage at
+//     the band's first output row.
+//   * the plane's ends need no special ticks either: blurInt's padding is the edge-duplicating mirror (-k -> k - 1, len - 1 + k -> len - k) of EVERY
+//     stage's input, and a symmetric window over a mirrored input gives a mirrored output (same sum, same K), so feeding the chain the mirror-extended
+//     SOURCE rows (P R virtual rows on either side) makes every stage's virtual outputs the mirror of its real ones — exactly the padding the next
+//     stage wants.
+// So: boxblur_rt_ichain_kernel<T, P, 1> runs the plane's first P (R + 1) + 1 ticks through the generic chain once per column and leaves the P
+// constants in a table (no stores); <T, P, 2> runs one band of rows per wave — every tick a fast one — with the constants from the table. Waves
+// per call: column groups x bands (4 096 aimed at), against column groups alone.
+template <typename T, int P, int MODE /* 1: E_0 constants of the P stages, 2: one band of output rows */>
+__global__ __launch_bounds__(64) void boxblur_rt_ichain_kernel(const RParams prm, uint32_t *__restrict__ kk_tab, const int band_rows) {
+    using CH = FChain<T, P, 64>;
+    using E = typename CH::E;
+    using V = typename CH::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fc_lds_raw[];  // [D][P][64] rings, [kFcPf][64] parked rows, [8][64] outputs
+    E *fc_lds = reinterpret_cast<E *>(fc_lds_raw);
+    typedef T Raw __attribute__((ext_vector_type(4)));
+    typedef E e4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const RPlane pl = prm.p[rt_find(prm, b)];
+    const int ncg = (pl.w + 63) / 64;
+    const int lb = b - pl.block0;
+    const int cg = MODE == 2 ? lb % ncg : lb, band = MODE == 2 ? lb / ncg : 0;
+    const int i0 = cg * 64, i = i0 + lane;
+    const int qrow = lane >> 4, qcol = 4 * (lane & 15);
+    const int vcol = min(i0 + qcol, ((pl.w + 3) & ~3) - 4);
+    const T *sv = static_cast<const T *>(pl.src) + vcol;
+    T *dv = static_cast<T *>(pl.dst) + i0 + qcol;
+    const size_t ss = pl.sstride, ds = pl.dstride;
+    const int len = pl.h, R = prm.radius;
+    const int wpad = ncg * 64;
+    uint32_t *kt = kk_tab + pl.aux + i;  // stage k's constant of column i: kt[k * wpad]
+    CH ch;
+    ch.init(fc_lds + lane, R, len);
+    const int D = ch.D, L = ch.L;
+    E *park = fc_lds + P * D * 64, *otile = park + kFcPf * 64;
+    // source row of (virtual) tick t: blurInt's mirror on either side
+    auto src_row = [&](int t) __attribute__((always_inline)) {
+        int r = t < 0 ? -t - 1 : t;
+        r = r >= len ? 2 * len - 1 - r : r;
+        return min(max(r, 0), len - 1);
+    };
+    if constexpr (MODE == 1) {
+        const int total = P * L + 1;  // stage P starts (and its constant is known) at tick P L
+        auto fetch = [&](int t0, Raw *f) __attribute__((always_inline)) {
+            if (t0 < min(len, total)) {
+#pragma unroll
+                for (int j = 0; j < kFcPf / 4; ++j) f[j] = *reinterpret_cast<const Raw *>(sv + (size_t)min(t0 + 4 * j + qrow, len - 1) * ss);
+            }
+        };
+        auto run1 = [&](int tb, const Raw *q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < kFcPf / 4; ++j) *reinterpret_cast<e4 *>(park + (4 * j + qrow) * 64 + qcol) = __builtin_convertvector(q[j], e4);
+            fc_wave_sync();
+            const int ne = min(kFcPf, total - tb);
+            int c = tb % D;
+            for (int u = 0; u < ne; ++u) {
+                V r;
+                (void)ch.tick(tb + u, c, (V)park[u * 64 + lane], r);
+                c = c + 1 == D ? 0 : c + 1;
+            }
+            fc_wave_sync();
+        };
+        Raw b0[kFcPf / 4], b1[kFcPf / 4];
+        fetch(0, b0);
+        for (int t0 = 0; t0 < total; t0 += 2 * kFcPf) {
+            fetch(t0 + kFcPf, b1);
+            run1(t0, b0);
+            if (t0 + kFcPf >= total) break;
+            fetch(t0 + 2 * kFcPf, b0);
+            run1(t0 + kFcPf, b1);
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) kt[(size_t)k * wpad] = ch.kk[k];
+    } else {
+        const int nb = (len + band_rows - 1) / band_rows;
+        const int y0 = band * band_rows, y1 = band == nb - 1 ? len : y0 + band_rows;
+        const int lag = P * L;
+        const int ts = y0 - P * R, te = y1 + lag;  // ticks [ts, te): source rows from P R above the band; the last stage's row y1 - 1 leaves at tick y1 - 1 + lag
+        // zeroed rings, sums and carries + the constants: every tick is a fast one
+        for (int k = 0; k < P * D; ++k) fc_lds[k * 64 + lane] = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) ch.kk[k] = kt[(size_t)k * wpad];
+        fc_wave_sync();
+        auto fetch = [&](int t0, Raw *f) __attribute__((always_inline)) {
+            if (t0 < te) {
+#pragma unroll
+                for (int j = 0; j < kFcPf / 4; ++j) f[j] = *reinterpret_cast<const Raw *>(sv + (size_t)src_row(t0 + 4 * j + qrow) * ss);
+            }
+        };
+        const bool deep = 2 * R + 2 >= 8;
+        const bool full4 = i0 + qcol + 3 < pl.w;
+        auto put4 = [&](int row, const e4 o4) __attribute__((always_inline)) {
+            if (row < y0 || row >= y1) return;
+            const Raw w4 = __builtin_convertvector(o4, Raw);
+            T *dp = dv + (size_t)row * ds;
+            if (full4) {
+                if (prm.keep)
+                    *reinterpret_cast<Raw *>(dp) = w4;
+                else
+                    __builtin_nontemporal_store(w4, reinterpret_cast<Raw *>(dp));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + qcol + e < pl.w) dp[e] = w4[e];
+            }
+        };
+        auto run = [&](int t0, const Raw *q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < kFcPf / 4; ++j) *reinterpret_cast<e4 *>(park + (4 * j + qrow) * 64 + qcol) = __builtin_convertvector(q[j], e4);
+            fc_wave_sync();
+            const int ne = min(kFcPf, te - t0);
+            int c = (t0 - ts) % D;  // (any phase: the rings only need consistent slots)
+            int u0 = 0;
+            if (deep) {
+                for (; u0 + 8 <= ne; u0 += 8) {
+                    V v[8], r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = (V)park[(u0 + u) * 64 + lane];
+                    ch.template fast<8>(c, v, r);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) otile[u * 64 + lane] = (E)r[u];
+                    fc_wave_sync();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) put4(t0 + u0 - lag + 4 * h + qrow, *reinterpret_cast<const e4 *>(otile + (4 * h + qrow) * 64 + qcol));
+                    fc_wave_sync();
+                    c += 8;
+                    if (c >= D) c -= D;
+                }
+            }
+            for (; u0 + 4 <= ne; u0 += 4) {
+                V v[4], r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (V)park[(u0 + u) * 64 + lane];
+                ch.template fast<4>(c, v, r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) otile[u * 64 + lane] = (E)r[u];
+                fc_wave_sync();
+                put4(t0 + u0 - lag + qrow, *reinterpret_cast<const e4 *>(otile + qrow * 64 + qcol));
+                fc_wave_sync();
+                c += 4;
+                if (c >= D) c -= D;
+            }
+            for (; u0 < ne; ++u0) {
+                V v = (V)park[u0 * 64 + lane], r;
+                ch.template fast<1>(c, &v, &r);
+                const int row = t0 + u0 - lag;
+                if (row >= y0 && row < y1 && i < pl.w) static_cast<T *>(pl.dst)[(size_t)row * ds + i] = (T)r;
+                c = c + 1 == D ? 0 : c + 1;
+            }
+            fc_wave_sync();
+        };
+        Raw b0[kFcPf / 4], b1[kFcPf / 4], b2[kFcPf / 4];
+        fetch(ts, b0);
+        fetch(ts + kFcPf, b1);
+        for (int t0 = ts; t0 < te; t0 += 3 * kFcPf) {
+            fetch(t0 + 2 * kFcPf, b2);
+            run(t0, b0);
+            if (t0 + kFcPf >= te) break;
+            fetch(t0 + 3 * kFcPf, b0);
+            run(t0 + kFcPf, b1);
+            if (t0 + 2 * kFcPf >= te) break;
+            fetch(t0 + 4 * kFcPf, b1);
+            run(t0 + 2 * kFcPf, b2);
+        }
+    }
+}
+
 // Horizontal: lane = row for the chain, lane = column for memory: 64 source columns of the wave's 64 rows enter through one LDS tile, the last stage's
 // outputs leave through another, flushed whenever its 64 columns are complete. All 64 lanes carry a row (the per-pass kernel takes 16 rows a wave for
 // more waves; here a wave's time is the line's ticks times the cost of a tick whatever its row count, and a SIMD runs two waves no faster than one).
@@ -1729,7 +1905,7 @@ int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool 
 // The float chain kernels: 2 ... 5 passes, lines of at least 2 R + 2 samples, rings within one workgroup's LDS.
 constexpr int kFcMaxPass = 5;
 template <typename T>
-bool fchain_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool vertical) {
+bool fchain_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool vertical, int bands = 1) {
     constexpr bool is_int = std::is_integral<T>::value;
     if ((is_int ? ctx->opt.rt_no_ichain : ctx->opt.rt_no_fchain) || npass < 2 || npass > kFcMaxPass) return false;
     if (is_int && (!vertical || sizeof(T) > 2 || radius > 127)) return false;  // integer planes: the vertical chain only (the horizontal passes have boxblur_rt_hsmall_kernel)
@@ -1743,7 +1919,7 @@ bool fchain_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, 
         if (npass < 3) return false;
         long waves = 0;
         for (const RPlane &q : pl) waves += (q.w + 63) / 64;
-        if (waves < 900) return false;
+        if (waves * bands < 900) return false;  // (the banded form multiplies the waves: a one-frame call qualifies with eight bands)
     }
     if (!is_int && !vertical && !ctx->opt.rt_fchain_all) {
         // The horizontal chain carries 64 rows a wave and costs what a row's ticks cost however few waves there are; the per-pass kernel (16 rows a wave) is faster on small calls:
@@ -1802,6 +1978,76 @@ int launch_fchain(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int
         done += n;
     }
     return VSZIP_OK;
+}
+
+// The banded integer vertical chain (boxblur_rt_ichain_kernel): the planes qualify when the unbanded chain does, are tall enough for the mirror
+// extension (P (R + 1) + 1 rows) and for at least two bands of 2 P (2R + 1) rows — below that a band's warm-up is more than its rows.
+constexpr int kIcTargetWaves = 4096;
+template <typename T>
+int ichain_band_rows(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass) {
+    if (!std::is_integral<T>::value || sizeof(T) > 2 || ctx->opt.rt_no_banded) return 0;
+    long colgroups = 0;
+    int maxh = 0, minh = 1 << 30;
+    for (const RPlane &q : pl) {
+        colgroups += (q.w + 63) / 64;
+        maxh = std::max(maxh, q.h);
+        minh = std::min(minh, q.h);
+    }
+    if (minh < npass * (radius + 1) + 1) return 0;
+    const int warm = npass * (2 * radius + 1);
+    int nb = (int)std::min<long>((kIcTargetWaves + colgroups - 1) / colgroups, maxh / std::max(64, warm));
+    if (nb < 2) return 0;
+    return (maxh + nb - 1) / nb;
+}
+template <typename T>
+size_t ichain_table_bytes(const std::vector<RPlane> &pl) {
+    size_t e = 0;
+    for (const RPlane &q : pl) e += (size_t)((q.w + 63) & ~63) * kFcMaxPass;
+    return e * sizeof(uint32_t);
+}
+template <typename T>
+int launch_ichain_banded(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass, bool keep, int band_rows, uint32_t *kk_tab) {
+    if constexpr (std::is_integral<T>::value && sizeof(T) <= 2) {
+        size_t done = 0, kk_off = 0;
+        while (done < pl.size()) {
+            RParams prm, pe0;
+            const int n = (int)std::min<size_t>(kMaxPlanesRT, pl.size() - done);
+            prm.nplanes = pe0.nplanes = n;
+            prm.radius = pe0.radius = radius;
+            prm.keep = pe0.keep = keep ? 1 : 0;
+            int blocks = 0, blocks0 = 0;
+            for (int i = 0; i < n; ++i) {
+                prm.p[i] = pl[done + i];
+                const int ncg = (prm.p[i].w + 63) / 64;
+                prm.p[i].aux = (int)kk_off;
+                kk_off += (size_t)ncg * 64 * kFcMaxPass;
+                pe0.p[i] = prm.p[i];
+                prm.p[i].block0 = blocks;
+                pe0.p[i].block0 = blocks0;
+                blocks += ncg * ((prm.p[i].h + band_rows - 1) / band_rows);
+                blocks0 += ncg;
+            }
+            const int D = 2 * radius + 3;
+            const size_t lds = ((size_t)npass * D + kFcPf + 8) * 64 * sizeof(uint16_t);
+#define VSZIP_IC_LAUNCH(PP)                                                                                                              \
+    case PP:                                                                                                                             \
+        hipLaunchKernelGGL((boxblur_rt_ichain_kernel<T, PP, 1>), dim3(blocks0), dim3(64), lds, ctx->stream, pe0, kk_tab, band_rows);     \
+        hipLaunchKernelGGL((boxblur_rt_ichain_kernel<T, PP, 2>), dim3(blocks), dim3(64), lds, ctx->stream, prm, kk_tab, band_rows);      \
+        break;
+            switch (npass) {
+                VSZIP_IC_LAUNCH(2)
+                VSZIP_IC_LAUNCH(3)
+                VSZIP_IC_LAUNCH(4)
+                VSZIP_IC_LAUNCH(5)
+            }
+#undef VSZIP_IC_LAUNCH
+            VSZIP_HIP_CHECK(ctx, hipGetLastError());
+            done += n;
+        }
+        return VSZIP_OK;
+    } else {
+        return VSZIP_ERR_ARG;
+    }
 }
 
 template <typename T>
@@ -1950,6 +2196,7 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
         }
         const int ng = g1 - g0;
         T *scratch[2] = {nullptr, nullptr};
+        uint32_t *kk_tab = nullptr;  // the banded integer chain's per-column constants
         std::vector<size_t> goff(ng);
         {
             size_t e = 0;
@@ -1960,10 +2207,15 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
         }
         if (total > 1) {
             // (grow-only scratch sized for the largest group seen; every group reuses the same two buffers)
-            int rc = vszip_ensure_scratch(ctx, 2 * elems_g * sizeof(T) + 256);
+            const size_t planes_bytes = (2 * elems_g * sizeof(T) + 255) & ~(size_t)255;
+            size_t tab_bytes = 0;
+            if (std::is_integral<T>::value && vb && vpasses >= 2)
+                for (int i = 0; i < ng; ++i) tab_bytes += (size_t)((planes[g0 + i].w + 63) & ~63) * kFcMaxPass * sizeof(uint32_t);
+            int rc = vszip_ensure_scratch(ctx, planes_bytes + tab_bytes + 256);
             if (rc != VSZIP_OK) return rc;
             scratch[0] = static_cast<T *>(ctx->scratch);
             scratch[1] = scratch[0] + elems_g;
+            kk_tab = reinterpret_cast<uint32_t *>(static_cast<char *>(ctx->scratch) + planes_bytes);
         }
         std::vector<RPlane> cur(ng);
         for (int i = 0; i < ng; ++i) {
@@ -2002,6 +2254,11 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
             if (!std::is_integral<T>::value && span > 1 && fchain_ok<T>(ctx, cur, vertical ? vradius : hradius, span, vertical)) {
                 if constexpr (!std::is_integral<T>::value) rc = launch_fchain<T>(ctx, cur, vertical ? vradius : hradius, span, vertical, !last);
                 else rc = VSZIP_ERR_ARG;
+                p += span - 1;
+            } else if (const int br = (std::is_integral<T>::value && span > 1 && vertical && kk_tab && !vsmall_ok<T>(ctx, cur, vradius, span)) ? ichain_band_rows<T>(ctx, cur, vradius, span) : 0;
+                       br > 0 && fchain_ok<T>(ctx, cur, vradius, span, true, (cur[0].h + br - 1) / br)) {
+                // integer planes: the chain in bands of rows (exact under any segmentation: see boxblur_rt_ichain_kernel)
+                rc = launch_ichain_banded<T>(ctx, cur, vradius, span, !last, br, kk_tab);
                 p += span - 1;
             } else if (std::is_integral<T>::value && span > 1 && vertical && !vsmall_ok<T>(ctx, cur, vradius, span) && fchain_ok<T>(ctx, cur, vradius, span, true)) {
                 // integer planes, vertical passes the two-stage small-radius kernel does not take: the pass chain (one column a lane, the stages' rings in LDS)

@@ -84,6 +84,8 @@ struct vszip_ctx {
     };
     std::vector<Region> parked, placed;
     int placement_walks = 0, placement_probed = 0;
+    double placement_last_walk_ms = 0.0;
+    bool placement_exhausted = false;  // a walk used its budget without finding a fast region: no further walks in this context
 };
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);

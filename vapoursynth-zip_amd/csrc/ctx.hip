@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <set>
 
@@ -269,12 +270,13 @@ typedef unsigned int pv4u __attribute__((ext_vector_type(4)));
 
 // One wave per (band, tile): moves a 960-byte column tile down `band_rows` rows of a 7680-byte-pitch view of the region,
 // reading its own band and writing the band half a region away (every tile is read once and written once per launch).
-__global__ __launch_bounds__(64) void placement_probe_kernel(char *base, int bands, int band_rows) {
+// `from` != nullptr: the tiles are read from that region instead (a source arena allocated earlier) — the pair a batch will be.
+__global__ __launch_bounds__(64) void placement_probe_kernel(char *base, const char *from, int bands, int band_rows) {
     constexpr long long kPitch = 7680;
     const int b = blockIdx.x >> 3, t = blockIdx.x & 7, lane = threadIdx.x;
     if (lane >= 60) return;
-    const int wb = b + bands / 2 < bands ? b + bands / 2 : b + bands / 2 - bands;
-    const char *sp = base + (long long)b * band_rows * kPitch + t * 960 + lane * 16;
+    const int wb = from ? b : (b + bands / 2 < bands ? b + bands / 2 : b + bands / 2 - bands);
+    const char *sp = (from ? from : base) + (long long)b * band_rows * kPitch + t * 960 + lane * 16;
     char *dp = base + (long long)wb * band_rows * kPitch + t * 960 + lane * 16;
     pv4u a = *reinterpret_cast<const pv4u *>(sp);
     for (int r = 0; r < band_rows; ++r) {
@@ -285,10 +287,12 @@ __global__ __launch_bounds__(64) void placement_probe_kernel(char *base, int ban
 }
 
 constexpr size_t kProbeSpan = (size_t)2 << 30;  // at most this much of a region is probed (its first 2 GiB)
-constexpr double kFastBytesPerSec = 5.45e12;     // placement_probe_kernel: fast regions move 5.6-5.8 TB/s, slow ones 4.9-5.1
+constexpr double kFastBytesPerSec = 5.3e12;      // placement_probe_kernel: fast regions move 5.5-5.85 TB/s, slow ones 4.6-4.85 (gpurun_out/r4_pool_probe.txt)
+constexpr size_t kPlacedGranule = (size_t)64 << 20;  // placed requests are rounded up to this: arenas of nearly equal size share parked regions
 
 // seconds per byte moved by the probe on [ptr, ptr + bytes); < 0: could not measure
-double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes) {
+double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from = nullptr, size_t from_bytes = 0) {
+    if (from && from_bytes < bytes) bytes = from_bytes;
     const size_t span = std::min(bytes, kProbeSpan);
     const long long rows = (long long)(span / 7680);
     // ~3072 streams like the ring kernel's launch: 384 bands x 8 tiles, bands of 64 ... 540 rows
@@ -296,10 +300,11 @@ double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes) {
     const int bands = (int)(rows / band_rows);
     if (bands < 2) return -1.0;
     const dim3 grid(bands * 8);
-    hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), bands, band_rows);
+    const char *fr = static_cast<const char *>(from);
+    hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), fr, bands, band_rows);
     if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) return -1.0;
     const int n = 2;
-    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), bands, band_rows);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), fr, bands, band_rows);
     float ms = 0;
     if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess || hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) {
         (void)hipGetLastError();
@@ -351,6 +356,7 @@ hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes) {
 namespace {
 
 int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
+    bytes = (bytes + kPlacedGranule - 1) / kPlacedGranule * kPlacedGranule;
     // 1: a parked region of a fitting size (the fastest one)
     int pick = -1;
     for (size_t i = 0; i < ctx->parked.size(); ++i) {
@@ -364,19 +370,29 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         ctx->parked.erase(ctx->parked.begin() + pick);
         return VSZIP_OK;
     }
-    // 2: walk. Everything stays allocated until the walk ends; it ends when three regions of the fast class are in hand (the one
-    // to return and two to park: a batch is two arenas, and the next batch's walk should not start from nothing), when the
-    // walk budget is used, or when the device is full.
+    if (ctx->placement_exhausted) {  // an earlier walk used its whole budget without meeting a fast region: this device's next tens of GiB are slow, no more searching
+        if (pick >= 0) {
+            ctx->placed.push_back(ctx->parked[pick]);
+            *dptr = ctx->parked[pick].ptr;
+            ctx->parked.erase(ctx->parked.begin() + pick);
+            return VSZIP_OK;
+        }
+        if (vszip_hip_malloc(ctx, dptr, bytes) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+        return VSZIP_OK;
+    }
+    // 2: walk. Everything stays allocated until the walk ends; it ends with the first region of the fast class, when the walk's
+    // budget (bytes held, wall time: memory the device has not handed out before is cleared on first use, ~50 ms per GiB) is
+    // used, or when the device is full. Slow regions freed here come back first in the next walk and cost 2.5 ms each then.
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const size_t budget = (size_t)std::max(1, ctx->opt.placement_walk_gib) << 30;
     const int max_cand = (int)std::min<size_t>(64, std::max<size_t>(1, budget / bytes));
+    const auto t_start = std::chrono::steady_clock::now();
     std::vector<vszip_ctx::Region> cand;
     if (pick >= 0) {  // a parked region of the slow class competes with what the walk finds
         cand.push_back(ctx->parked[pick]);
         ctx->parked.erase(ctx->parked.begin() + pick);
     }
-    int fast = 0;
-    for (int k = 0; k < max_cand && fast < 3; ++k) {
+    for (int k = 0; k < max_cand; ++k) {
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -385,7 +401,9 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         double c = probe_region(ctx, p, bytes);
         if (c < 0) c = 1.0;  // unmeasurable: last choice
         cand.push_back({p, bytes, c});
-        if (c <= fast_cost) ++fast;
+        if (c <= fast_cost) break;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        if (ms > (double)std::max(1, ctx->opt.placement_walk_ms)) break;
     }
     if (cand.empty()) {
         void *p = nullptr;
@@ -398,6 +416,8 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     ctx->placed.push_back(cand[0]);
     ctx->placement_walks += 1;
     ctx->placement_probed += (int)cand.size();
+    ctx->placement_last_walk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    if (cand[0].cost > fast_cost) ctx->placement_exhausted = true;
     // the slow ones are freed FIRST (in one go, after the walk), then the fast ones are parked
     for (size_t i = 1; i < cand.size(); ++i)
         if (cand[i].cost > fast_cost) (void)hipFree(cand[i].ptr);
@@ -424,7 +444,8 @@ VSZIP_EXPORT int vszip_dev_trim(vszip_ctx *ctx, size_t *freed_bytes) {
     return VSZIP_OK;
 }
 
-VSZIP_EXPORT int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed) {
+VSZIP_EXPORT int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed, double *last_walk_ms,
+                                          int *exhausted) {
     if (!ctx) return VSZIP_ERR_ARG;
     if (bytes_per_second) {
         *bytes_per_second = 0.0;
@@ -438,13 +459,15 @@ VSZIP_EXPORT int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, doub
     }
     if (walks) *walks = ctx->placement_walks;
     if (probed) *probed = ctx->placement_probed;
+    if (last_walk_ms) *last_walk_ms = ctx->placement_last_walk_ms;
+    if (exhausted) *exhausted = ctx->placement_exhausted ? 1 : 0;
     return VSZIP_OK;
 }
 
-VSZIP_EXPORT int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, double *bytes_per_second) {
+VSZIP_EXPORT int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, const void *from, double *bytes_per_second) {
     if (!ctx || !dptr || !bytes_per_second) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const double c = probe_region(ctx, dptr, bytes);
+    const double c = probe_region(ctx, dptr, bytes, from, bytes);
     if (c <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "region of %zu bytes is too small to probe", bytes);
     *bytes_per_second = 1.0 / c;
     return VSZIP_OK;
