@@ -353,14 +353,18 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
             dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
         dev.sync()
 
+    t_alloc = time.perf_counter()
     src = Arena(dev, shapes, dtype, seed + 1)
+    t_alloc = time.perf_counter() - t_alloc
     for a, d in zip(host_planes, src.planes):
         a = np.ascontiguousarray(a)
         dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * isz, a.ctypes.data, a.strides[0], a.shape[1] * isz, a.shape[0]))
     dev.sync()
     lay = Arena(dev, shapes, dtype, seed + 2, ptr=0)  # the destination layout (bound to an allocation below)
     if tries <= 1:
+        t0_ = time.perf_counter()
         dst, dst_us, src_us, dst2_us = Arena(dev, shapes, dtype, seed + 2), [None], [None], []
+        t_alloc += time.perf_counter() - t0_
         first["us"] = launch_us(src, dst, n=20, with_args=args)
     else:
         # 1: the destination arena, every candidate against the first source arena
@@ -392,7 +396,7 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
         v = sorted(x for x in v if x is not None)
         return None if not v else {"n": len(v), "min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
 
-    info = {"tries": tries, "first_allocation_us": None if "us" not in first else round(first["us"], 1),
+    info = {"tries": tries, "alloc_seconds": round(t_alloc, 3), "first_allocation_us": None if "us" not in first else round(first["us"], 1),
             "destination_candidates_us": summary(dst_us), "source_candidates_us": summary(src_us),
             "destination_candidates_second_pass_us": summary(dst2_us), "probe_args": list(probe_args),
             "note": "vszip_dev_alloc_probed: launch time of the batch on candidate allocations (10 launches each, wall clock, min / median / max over the "
@@ -668,7 +672,7 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
     return res
 
 
-def planestats_leg(dev, timed, frames=16):
+def planestats_leg(dev, timed, frames=64):
     """PlaneAverage / PlaneMinMax on 3840x2160 YUV420P16: single-pass readers, HBM roofline = bytes read once."""
     base = make_frame(7, W4K, H4K)
     planes = []
@@ -685,8 +689,9 @@ def planestats_leg(dev, timed, frames=16):
         out[name] = {"value": frames * 10 / dt, "unit": "frames/s",
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                   "kernel": "the plane reader (average_kernel / minmax_kernel / hist_kernel pass 0)", "avg_launch_us": dom_ms * 1e3 / max(launches, 1),
-                                  "whole_call": {"note": "all kernels of the call + the scalar D2H + sync", "achieved": whole, "frac": whole / HBM_PEAK_GBS}},
-                     "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call (48 planes), HBM-resident; value includes the scalar D2H + sync"}
+                                  "whole_call": {"note": "all kernels of the call + the scalars' way to the host + the one sync", "achieved": whole, "frac": whole / HBM_PEAK_GBS}},
+                     "whole_call_frac": whole / HBM_PEAK_GBS,
+                     "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call ({3 * frames} planes in groups of 48 queued back to back, one sync), HBM-resident; value includes the sync"}
     return out
 
 
@@ -1074,6 +1079,8 @@ def compact_leg(leg: dict) -> dict:
     rf = leg.get("roofline")
     if isinstance(rf, dict) and isinstance(rf.get("frac"), (int, float)):
         o["frac"] = rf["frac"]
+    if isinstance(leg.get("whole_call_frac"), (int, float)):
+        o["whole_call_frac"] = leg["whole_call_frac"]
     lim = leg.get("limit")
     if isinstance(lim, dict) and "bound" in lim and "frac" in lim:
         o["limit"] = {"bound": lim["bound"], "frac": lim["frac"]}
@@ -1289,7 +1296,19 @@ def main() -> int:
         # probe gets — libvszip.so's slabs are not probed: its BoxBlur is PCIe-bound long before this matters).
         pl_info = keep[2]
         out["config"]["placement_tries"] = pl_info["tries"]
-        out["config"]["placement_policy"] = "plain vszip_dev_alloc (first allocation)" if pl_info["tries"] <= 1 else f"best of 3 x {pl_info['tries']} probed arenas"
+        out["config"]["placement_policy"] = ("vszip_dev_alloc (the library places requests of 512 MiB and more: include/vszip_hip.h)" if pl_info["tries"] <= 1
+                                             else f"best of 3 x {pl_info['tries']} probed arenas")
+        try:  # what the allocator did for the two arenas of the headline batch
+            pi_s, pi_d = dev.placement_info(keep[0].ptr), dev.placement_info(keep[1].ptr)
+            out["config"]["placement_src_probe_TBps"] = pi_s["bytes_per_second"] / 1e12
+            out["config"]["placement_dst_probe_TBps"] = pi_d["bytes_per_second"] / 1e12
+            out["config"]["placement_walks"] = pi_d["walks"]
+            out["config"]["placement_candidates_probed"] = pi_d["probed"]
+            out["config"]["placement_last_walk_ms"] = pi_d["last_walk_ms"]
+            out["config"]["placement_exhausted"] = pi_d["exhausted"]
+            out["config"]["placement_seconds"] = keep[2].get("alloc_seconds")
+        except Exception as e:
+            out["config"]["placement_error"] = str(e)[:100]
         if pl_info["tries"] > 1:
             out["config"]["probed_frac"] = achieved / HBM_PEAK_GBS
         if pl_info.get("first_allocation_us"):
@@ -1314,17 +1333,17 @@ def main() -> int:
         except Exception as e:  # informative only
             out["config"]["clip_mean_luma"] = {"error": str(e)}
         del keep
-        # Side scalar only (never `value`): the same launch with the placement of both arenas searched (24 candidates a walk)
+        # Side scalar only (never `value`): the same launch on arenas the allocator did NOT place (VSZIP_PLACEMENT=0: plain hipMalloc)
         if rank == 0 and world == 1 and not a.no_others and pl_info["tries"] <= 1 and a.radius == RADIUS:
             try:
-                step_p, keep_p = setup_boxblur(dev, rank, F, a.radius, tries=24)
+                with dev.options(VSZIP_PLACEMENT=0):
+                    step_p, keep_p = setup_boxblur(dev, rank, F, a.radius)
                 _, _, dom_p, n_p = timed.run(step_p, 200, 5)
-                out["config"]["probed_frac"] = alg_bytes / (dom_p * 1e-3 / n_p) / 1e9 / HBM_PEAK_GBS
-                out["config"]["probed_launch_us"] = dom_p * 1e3 / n_p
-                out["config"]["probed_placement"] = keep_p[2]
+                out["config"]["unplaced_frac"] = alg_bytes / (dom_p * 1e-3 / n_p) / 1e9 / HBM_PEAK_GBS
+                out["config"]["unplaced_launch_us"] = dom_p * 1e3 / n_p
                 del step_p, keep_p
             except Exception as e:
-                out["config"]["probed_placement"] = {"error": str(e)}
+                out["config"]["unplaced_error"] = str(e)[:100]
         # The exchange step on real data: XPSNR's per-clip accumulators over RCCL (all ranks take part)
         try:
             if not a.no_others:

@@ -26,8 +26,8 @@
 extern "C" {
 #endif
 
-#define VSZIP_ABI_VERSION 3 /* 3 (round 4): vszip_ctx_set_option / _get_option, vszip_dev_trim, vszip_dev_placement_info, vszip_dev_probe_region
-                               added; vszip_dev_alloc places large requests (below); 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1: vszip_dev_alloc_probed,
+#define VSZIP_ABI_VERSION 3 /* 3 (round 4): vszip_ctx_set_option / _get_option, vszip_dev_trim, vszip_dev_placement_info, vszip_dev_probe_region,
+                               vszip_plane_average_async, vszip_plane_minmax_async added; vszip_dev_alloc places large requests (below); 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1: vszip_dev_alloc_probed,
                                vszip_chain_run, vszip_ssimulacra2_src, vszip_to_rgbs_linear, vszip_probe_read_each, vszip_resample_table */
 
 typedef struct vszip_ctx vszip_ctx;
@@ -160,6 +160,12 @@ int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int npla
 int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
                         const int32_t *exclude, int nexclude, int bits_per_sample,
                         double *avg, double *diff);
+/* The same without the synchronise (round 4): the per-plane results are written by the kernels straight into the caller's PINNED
+ * host array `pinned_results` (vszip_host_alloc_pinned; nplanes x 4 doubles: [i][0] = avg, [i][1] = diff for the clipb variant)
+ * and are valid after the caller's next vszip_ctx_sync — a host that reads several statistics of a frame queues them all and
+ * waits once. */
+int vszip_plane_average_async(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
+                              const int32_t *exclude, int nexclude, int bits_per_sample, double *pinned_results);
 
 /*
  * Limiter — replaces the getFrame bodies of LimiterRT / Limiter (src/vapoursynth/limiter.zig:28-96):
@@ -201,6 +207,9 @@ int vszip_adaptive_binarize(vszip_ctx *ctx, const vszip_plane *planes, int nplan
 int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
                        float minthr, float maxthr, int bits_per_sample,
                        double *vmin, double *vmax, double *diff);
+/* ... and without the synchronise: pinned_results[i][0] = min, [i][1] = max, [i][2] = diff (see vszip_plane_average_async) */
+int vszip_plane_minmax_async(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
+                             float minthr, float maxthr, int bits_per_sample, double *pinned_results);
 
 /*
  * Bilateral — replaces filter.bilateral (src/filters/bilateral.zig:81) and the create-time

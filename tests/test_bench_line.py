@@ -60,7 +60,7 @@ def test_line_fits_the_drivers_tail_and_parses(full, tmp_path):
     # every leg: value / unit / frac / limit only
     assert set(d["others"]) == set(full["others"])
     for name, leg in d["others"].items():
-        assert set(leg) <= {"value", "unit", "frac", "limit", "error"}, name
+        assert set(leg) <= {"value", "unit", "frac", "whole_call_frac", "limit", "error"}, name
         assert "value" in leg or "error" in leg, name
     assert d["others"]["bilateral_1080p"]["limit"]["bound"] in ("valu", "lds")
     assert d["detail"] == "bench_detail.json"

@@ -131,3 +131,55 @@ def test_minmax_single_read_and_its_second_sweep(dev, oracle, dtype, monkeypatch
             omn, omx, odf = oracle.plane_minmax(p, thr[0], thr[1], refs[i])
             assert (mn[i], mx[i]) == (omn, omx), (dtype, thr, i)
             assert df[i] == (odf if np.dtype(dtype).kind == "u" else pytest.approx(odf, rel=1e-12))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_many_planes_one_call_and_the_async_entry_points(dev, oracle, dtype):
+    """Round 4: a call of more than 48 planes is queued as groups back to back with ONE synchronise at the end (results of every group in their own entries of
+    the pinned array), and vszip_plane_average_async / _minmax_async write into the caller's pinned array and do not synchronise at all. 130 planes of
+    three sizes (three groups), every plane against the oracle; the async results equal the synchronous ones to the bit."""
+    shapes = [(96, 160), (48, 80), (37, 53)]
+    planes = [fx.splitmix64_plane(100 + i, shapes[i % 3], dtype) if i % 5 else fx.tiled_natural(shapes[i % 3], dtype, i % 3) for i in range(130)]
+    refs = [fx.splitmix64_plane(900 + i, p.shape, dtype) for i, p in enumerate(planes)]
+    ds, dr = [dev.upload(p) for p in planes], [dev.upload(r) for r in refs]
+    is_int = np.dtype(dtype).kind == "u"
+    avg, diff = dev.plane_average(ds, [-1, 7], dr)
+    mn, mx, df = dev.plane_minmax(ds, 0.05, 0.1, dr)
+    mn0, mx0, _ = dev.plane_minmax(ds)
+    for i, p in enumerate(planes):
+        oa, od = oracle.plane_average(p, [-1, 7], refs[i])
+        omn, omx, odf = oracle.plane_minmax(p, 0.05, 0.1, refs[i])
+        assert (mn[i], mx[i]) == (omn, omx), (dtype, i)
+        assert (mn0[i], mx0[i]) == oracle.plane_minmax(p, 0.0, 0.0)[:2], (dtype, i)
+        if is_int:
+            assert (avg[i], diff[i], df[i]) == (oa, od, odf), (dtype, i)
+        else:
+            assert avg[i] == pytest.approx(oa, rel=1e-12) and diff[i] == pytest.approx(od, rel=1e-12) and df[i] == pytest.approx(odf, rel=1e-12)
+    ra = dev.pinned_array((130, 4), np.float64)
+    rm = dev.pinned_array((130, 4), np.float64)
+    ra[...] = -1.0
+    rm[...] = -1.0
+    dev.plane_average_async(ds, ra, [-1, 7], dr)
+    dev.plane_minmax_async(ds, rm, 0.05, 0.1, dr)  # queued behind the first: both reuse the context's scratch tables in stream order
+    dev.sync()
+    assert list(ra[:, 0]) == avg and list(ra[:, 1]) == diff
+    assert list(rm[:, 0]) == mn and list(rm[:, 1]) == mx and list(rm[:, 2]) == df
+    import vszip_amd
+
+    with pytest.raises(vszip_amd.VszipError, match="pinned"):
+        dev.plane_average_async(ds[:2], np.zeros((2, 4)), [-1])
+
+
+def test_handover_many_planes_many_xcds(dev, oracle):
+    """The last-workgroup hand-over of the thresholded PlaneMinMax (hist_sweep_kernel: tables built by all workgroups, read by the one whose ticket
+    comes last — agent-scope atomics, no fence: planestats.hip "Hand-over inside a kernel"): 48 planes per launch, each swept by workgroups on
+    all eight XCDs, twenty rounds on changing content; every plane of every round against the oracle."""
+    shape = (540, 960)
+    for rnd in range(20):
+        planes = [np.roll(fx.tiled_natural(shape, np.uint16, i % 3), 37 * rnd + 11 * i, axis=1) ^ np.uint16(rnd * 257 + i) for i in range(48)]
+        ds = [dev.upload(p) for p in planes]
+        thr = [(0.02, 0.02), (0.3, 0.1), (0.06, 0.9)][rnd % 3]
+        mn, mx, _ = dev.plane_minmax(ds, *thr)
+        for i in range(0, 48, 5 if rnd else 1):
+            omn, omx, _ = oracle.plane_minmax(planes[i], thr[0], thr[1], None)
+            assert (mn[i], mx[i]) == (omn, omx), (rnd, i, thr)

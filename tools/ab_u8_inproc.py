@@ -32,7 +32,7 @@ def main():
     args = sys.argv[1:]
     dt = np.uint16 if "--u16" in args else np.uint8
     names = [a for a in args if not a.startswith("--")] or ["base"]
-    radius = 13
+    radius = next((int(a.split("=")[1]) for a in args if a.startswith("--radius=")), 13)
     dev0 = device_of("base")
     base = [fx.splitmix64_plane(p, s, dt) for p, s in enumerate(bench.yuv420_shapes(bench.W4K, bench.H4K))]
     srcs, dsts = [], []

@@ -120,6 +120,8 @@ SYMBOLS = {
     "vszip_adaptive_binarize": (_i, [_vp, _PP, _i, _i]),
     "vszip_plane_average": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_plane_minmax": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vszip_plane_average_async": (_i, [_vp, _i, _PP, _i, C.POINTER(C.c_int32), _i, _i, _vp]),
+    "vszip_plane_minmax_async": (_i, [_vp, _i, _PP, _i, C.c_float, C.c_float, _i, _vp]),
 }
 
 _lib = None
@@ -405,6 +407,21 @@ class Device:
         b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
         self.check(self.lib.vszip_plane_average(self.ctx, _NP2DT[srcs[0].dtype], table, n, ex, len(exclude), b, avg, diff))
         return list(avg), (list(diff) if refs is not None else None)
+
+    def plane_average_async(self, srcs, results, exclude=(), refs=None, bits=None):
+        """vszip_plane_average_async: `results` is a pinned_array((len(srcs), 4), float64); valid after the next sync()"""
+        n = len(srcs)
+        table = self.plane_table(srcs, None, refs)
+        ex = (C.c_int32 * max(1, len(exclude)))(*exclude)
+        b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
+        self.check(self.lib.vszip_plane_average_async(self.ctx, _NP2DT[srcs[0].dtype], table, n, ex, len(exclude), b, results.ctypes.data))
+
+    def plane_minmax_async(self, srcs, results, minthr=0.0, maxthr=0.0, refs=None, bits=None):
+        """vszip_plane_minmax_async: results[i] = (min, max, diff, -), pinned; valid after the next sync()"""
+        n = len(srcs)
+        table = self.plane_table(srcs, None, refs)
+        b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
+        self.check(self.lib.vszip_plane_minmax_async(self.ctx, _NP2DT[srcs[0].dtype], table, n, minthr, maxthr, b, results.ctypes.data))
 
     def limiter(self, srcs, dsts, lo, hi):
         """dsts[i] = min(max(lo[i], srcs[i]), hi[i]) (vszip.Limiter with the bounds already resolved)."""

@@ -56,7 +56,10 @@ namespace {
 #ifndef VSZIP_LD_AUX
 #define VSZIP_LD_AUX 0
 #endif
-constexpr int kStoreAux = VSZIP_ST_AUX, kLoadAux = VSZIP_LD_AUX;
+#ifndef VSZIP_ST8_AUX
+#define VSZIP_ST8_AUX 0
+#endif
+constexpr int kStoreAux = VSZIP_ST_AUX, kLoadAux = VSZIP_LD_AUX, kStoreAux8 = VSZIP_ST8_AUX;
 typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t U32x2 __attribute__((ext_vector_type(2)));
 
@@ -345,7 +348,10 @@ struct RingGeom {
 #ifdef VSZIP_RING_WPE
     static constexpr int WPE = VSZIP_RING_WPE;
 #else
-    static constexpr int WPE = tier(est_vgprs(D));
+    // 8-bit planes (2 VGPRs a slot) fit four waves per SIMD at every radius — and run 4-10 % faster with THREE (168 VGPRs, 3 072 waves per launch instead
+    // of 4 096: r = 2 / 5 / 13 / 20 on 64 4K YUV420P8 frames 415 -> 387, 413 -> 384, 452 -> 412, 447 -> 440 us, interleaved A/B in one process,
+    // gpurun_out/r4_u8_ab*.txt; two waves lose again: 451 / 486 us at r = 13 / 20). The prefetch depth does not matter (D = 1 ... 9: 452 ... 429 us at four waves).
+    static constexpr int WPE = SLOT_VGPRS == 2 ? (tier(est_vgprs(D)) > 3 ? 3 : tier(est_vgprs(D))) : tier(est_vgprs(D));
 #endif
     static_assert(NR % KL == 0, "K-column ring must divide the period");
     static constexpr uint32_t MAGIC = (uint32_t)(((1ull << 32) + K - 1) / K);  // ceil(2^32 / k): mulhi(n, MAGIC) == n / k
@@ -538,7 +544,11 @@ struct RingWave {
 #pragma unroll
         for (int k = 0; k < PX; ++k) t[k] = __umul24(e[k], INV2) + kr;
         if constexpr (!GENERAL) {
+#ifdef VSZIP_DIAG_NO_STORE  // (timing diagnostics only: one lane of the wave stores)
+            const uint32_t vo = (live && lane == 8) ? sdoff : kOOB;
+#else
             const uint32_t vo = live ? sdoff : kOOB;
+#endif
             if constexpr (sizeof(T) == 2) {
                 U32x4 v;
                 v.x = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u);
@@ -554,7 +564,7 @@ struct RingWave {
                 const uint32_t a3 = __builtin_amdgcn_perm(t[7], t[6], 0x0c0c0602u);
                 v.x = a0 | (a1 << 16);
                 v.y = a2 | (a3 << 16);
-                __builtin_amdgcn_raw_buffer_store_b64(v, rd, vo, row_off_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v, rd, vo, row_off_bytes, kStoreAux8);
             }
         } else {
             T *q = reinterpret_cast<T *>(dstb + (row_off_bytes + doff));
@@ -642,7 +652,11 @@ struct RingWave {
             unpack8(ring[S], sb);
 #pragma unroll
             for (int k = 0; k < PX; ++k) col[k] += a[k] - sb[k];
+#ifdef VSZIP_DIAG_NO_LOAD  // (timing diagnostics only: the ring keeps what the band's fill put there)
+            if (next_off == 0xffffffffu) ring[S] = fetch_off(next_off);
+#else
             ring[S] = fetch_off(next_off);
+#endif
             // advance the refill row: plain bands just step down one row
 
         }
@@ -651,8 +665,10 @@ struct RingWave {
         {
             constexpr int J = S % G::KL;
             kcol += kn[J] - ko[J];
+#ifndef VSZIP_DIAG_NO_KCOL  // (timing diagnostics only: wrong results)
             kn[J] = fetch_px(kn_off);
             ko[J] = fetch_px(ko_off);
+#endif
 
         }
 

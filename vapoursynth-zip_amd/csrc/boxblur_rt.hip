@@ -1911,15 +1911,15 @@ bool fchain_ok(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, 
     if (is_int && (!vertical || sizeof(T) > 2 || radius > 127)) return false;  // integer planes: the vertical chain only (the horizontal passes have boxblur_rt_hsmall_kernel)
     // 8-bit planes: the per-pass kernel moves 16 samples a lane and wins up to four passes and at larger radii (1080p, 64 frames per call, chain against a launch per pass:
     // r = 2 x 3 passes -11 %, 13 x 2 -19 %, 2 x 4 even, 3 x 5 +16 %; 16-bit planes: +12 ... +55 % throughout — tools/boxblur_radii_probe.py). VSZIP_RT_ICHAIN_ALL=1: every case (tests).
-    if (is_int && sizeof(T) == 1 && !(npass >= 5 && radius <= 8) && !ctx->opt.rt_ichain_all) return false;
-    if (is_int && !ctx->opt.rt_ichain_all) {
+    if (is_int && bands < 2 && sizeof(T) == 1 && !(npass >= 5 && radius <= 8) && !ctx->opt.rt_ichain_all) return false;
+    if (is_int && bands < 2 && !ctx->opt.rt_ichain_all) {
         // Two passes: two launches of the per-pass kernel are as fast (u16, r >= 3: the chain +3 ... 8 % at 64 frames) and do not mind small calls. And the chain is as slow as its
         // longest column (a wave per 64 columns, ~0.1 us a tick): with fewer waves than SIMDs — a plugin context submits ONE frame per call — the per-pass kernels, which
         // cut a plane into bands, are several times faster (4 1080p frames, three passes: ~110 us against 3 x 25 us).
         if (npass < 3) return false;
         long waves = 0;
         for (const RPlane &q : pl) waves += (q.w + 63) / 64;
-        if (waves * bands < 900) return false;  // (the banded form multiplies the waves: a one-frame call qualifies with eight bands)
+        if (waves < 900) return false;
     }
     if (!is_int && !vertical && !ctx->opt.rt_fchain_all) {
         // The horizontal chain carries 64 rows a wave and costs what a row's ticks cost however few waves there are; the per-pass kernel (16 rows a wave) is faster on small calls:
@@ -1982,22 +1982,62 @@ int launch_fchain(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int
 
 // The banded integer vertical chain (boxblur_rt_ichain_kernel): the planes qualify when the unbanded chain does, are tall enough for the mirror
 // extension (P (R + 1) + 1 rows) and for at least two bands of 2 P (2R + 1) rows — below that a band's warm-up is more than its rows.
-constexpr int kIcTargetWaves = 4096;
+// How many bands: a cost model fitted to tools/rt_band_sweep.py (gpurun_out/r4_rt_band_sweep.txt: 12 workloads x 8 band counts). A wave's time is its ticks — the band's rows
+// + P (2R + 1) warm-up + P (R + 1) drain — times the tick's latency, which grows with the waves sharing a SIMD (about +36 % per extra wave: LDS hand-overs and the
+// loop-carried sums leave gaps that a second wave fills only partly); the rings' LDS bounds the resident waves (five stages of r = 13: 23.7 KB a wave, six waves a CU),
+// beyond which waves queue. T(nb) = max(longest wave, all wave-ticks / resident waves) x slow(waves per SIMD); the band count with the smallest T wins, 1 = no bands
+// (the callers then choose between the whole-column chain and a launch per pass as before).
 template <typename T>
 int ichain_band_rows(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, int npass) {
     if (!std::is_integral<T>::value || sizeof(T) > 2 || ctx->opt.rt_no_banded) return 0;
-    long colgroups = 0;
     int maxh = 0, minh = 1 << 30;
     for (const RPlane &q : pl) {
-        colgroups += (q.w + 63) / 64;
         maxh = std::max(maxh, q.h);
         minh = std::min(minh, q.h);
     }
-    if (minh < npass * (radius + 1) + 1) return 0;
-    const int warm = npass * (2 * radius + 1);
-    int nb = (int)std::min<long>((kIcTargetWaves + colgroups - 1) / colgroups, maxh / std::max(64, warm));
-    if (nb < 2) return 0;
-    return (maxh + nb - 1) / nb;
+    if (minh < npass * (radius + 1) + 1) return 0;  // (the mirror extension reflects once)
+    if (ctx->opt.rt_ichain_bands > 0) {  // (tests and sweeps: any band count)
+        const int nb = std::min(ctx->opt.rt_ichain_bands, std::max(1, maxh / 8));
+        return nb < 2 ? 0 : (maxh + nb - 1) / nb;
+    }
+    const int warm = npass * (2 * radius + 1), drain = npass * (radius + 1);
+    const size_t lds = ((size_t)npass * (2 * radius + 3) + kFcPf + 8) * 64 * sizeof(uint16_t);
+    const double cap = 256.0 * std::min<double>(16.0, std::floor(160.0 * 1024 / (double)lds));
+    auto cost = [&](int nb) {
+        const int br = (maxh + nb - 1) / nb;
+        double total = 0, waves = 0, longest = 0;
+        for (const RPlane &q : pl) {
+            const int ncg = (q.w + 63) / 64;
+            if (nb == 1) {  // whole columns: the generic ticks at both ends cost about three fast ones
+                const double t = q.h + drain + 2.0 * warm;
+                total += ncg * t;
+                waves += ncg;
+                longest = std::max(longest, t);
+                continue;
+            }
+            const int nbp = (q.h + br - 1) / br;
+            for (int b = 0; b < nbp; ++b) {
+                const double t = std::min(br, q.h - b * br) + warm + drain;
+                total += ncg * t;
+                longest = std::max(longest, t);
+            }
+            waves += (double)ncg * nbp;
+        }
+        const double conc = std::min(waves, cap), w = conc / 1024.0;
+        const double slow = 1.0 + 0.36 * std::max(0.0, w - 1.0);
+        return std::max(longest, total / conc) * slow + (nb > 1 ? 2.0 * drain : 0.0);  // (+ the launch that fills the table of constants)
+    };
+    int best_nb = 1;
+    double best = cost(1);
+    for (int nb : {2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32}) {
+        if ((maxh + nb - 1) / nb < 32) break;
+        const double c = cost(nb);
+        if (c < best * 0.97) {  // (a band count has to earn its extra launch)
+            best = c;
+            best_nb = nb;
+        }
+    }
+    return best_nb < 2 ? 0 : (maxh + best_nb - 1) / best_nb;
 }
 template <typename T>
 size_t ichain_table_bytes(const std::vector<RPlane> &pl) {

@@ -794,7 +794,7 @@ struct Launch {
     int total_blocks = 0;
 };
 
-int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_ref, Launch &L) {
+int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_ref, Launch &L, double *result_dev) {
     if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
     if (nplanes > kMaxPlanesPS) return vszip_set_error(ctx, VSZIP_ERR_ARG, "at most %d planes per call", kMaxPlanesPS);
     PSParams &prm = L.prm;
@@ -824,15 +824,14 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     const size_t need = (size_t)blocks * 4 * sizeof(double) + (size_t)nplanes * (kHistWords + kBucketWords + 256) * sizeof(uint32_t) + (size_t)nplanes * 4 * sizeof(double) + 256;
     int rc = vszip_ensure_scratch(ctx, need);
     if (rc != VSZIP_OK) return rc;
-    rc = vszip_ensure_scalars(ctx, (size_t)nplanes * 4 * sizeof(double));
-    if (rc != VSZIP_OK) return rc;
     char *p = static_cast<char *>(ctx->scratch);
     prm.partial = reinterpret_cast<double *>(p);
     p += (size_t)blocks * 4 * sizeof(double);
     p += (size_t)nplanes * 4 * sizeof(double);
-    // the final kernels write the per-plane results straight into the pinned host buffer
-    // (device-visible): the call ends with a synchronise, no copy command
-    VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&prm.result), ctx->scalars_host, 0));
+    // the final kernels write the per-plane results ([plane][4] doubles) straight into pinned host memory (device-visible):
+    // the context's own buffer (the calls that return values: one synchronise at the end, no copy command) or the caller's
+    // (the _async calls: no synchronise at all)
+    prm.result = result_dev;
     prm.hist = reinterpret_cast<uint32_t *>(p);
     p += (size_t)nplanes * kHistWords * sizeof(uint32_t);
     prm.bucket = reinterpret_cast<uint32_t *>(p);
@@ -841,10 +840,25 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     return VSZIP_OK;
 }
 
-int fetch(vszip_ctx *ctx, const Launch &L, double *r0, double *r1, double *r2) {
-    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const double *h = static_cast<const double *>(ctx->scalars_host);
-    for (int i = 0; i < L.prm.nplanes; ++i) {
+// the context's pinned result buffer for `nplanes` planes: host and device views
+int result_buffer(vszip_ctx *ctx, int nplanes, double **host, double **dev) {
+    const int rc = vszip_ensure_scalars(ctx, (size_t)nplanes * 4 * sizeof(double));
+    if (rc != VSZIP_OK) return rc;
+    *host = static_cast<double *>(ctx->scalars_host);
+    VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(dev), ctx->scalars_host, 0));
+    return VSZIP_OK;
+}
+// a caller's pinned array as the kernels see it
+int caller_buffer(vszip_ctx *ctx, double *pinned, double **dev) {
+    if (!pinned) return vszip_set_error(ctx, VSZIP_ERR_ARG, "the result array is NULL");
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(dev), pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return vszip_set_error(ctx, VSZIP_ERR_ARG, "the result array must be pinned host memory (vszip_host_alloc_pinned)");
+    }
+    return VSZIP_OK;
+}
+int fetch(vszip_ctx *ctx, int nplanes, const double *h, double *r0, double *r1, double *r2) {
+    for (int i = 0; i < nplanes; ++i) {
         if (r0) r0[i] = h[i * 4 + 0];
         if (r1) r1[i] = h[i * 4 + 1];
         if (r2) r2[i] = h[i * 4 + 2];
@@ -943,11 +957,11 @@ int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr) {
 }  // namespace
 
 static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
-                               double *avg, double *diff) {
+                               double *result_dev) {
     if (nexclude < 0 || (nexclude > 0 && !exclude)) return VSZIP_ERR_ARG;
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
     Launch L;
-    int rc = prepare(ctx, planes, nplanes, ref, L);
+    int rc = prepare(ctx, planes, nplanes, ref, L, result_dev);
     if (rc != VSZIP_OK) return rc;
     L.prm.nexcl = 0;
     for (int i = 0; i < nexclude; ++i) {  // distinct values only: membership is all the kernel tests
@@ -969,17 +983,16 @@ static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *pla
             break;
         default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneAverage: not supported Int format.");
     }
-    if (rc != VSZIP_OK) return rc;
-    return fetch(ctx, L, avg, ref ? diff : nullptr, nullptr);
+    return rc;
 }
 
 static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
-                              double *vmin, double *vmax, double *diff) {
+                              double *result_dev) {
     if (minthr < 0 || minthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: minthr should be a float between 0.0 and 1.0");
     if (maxthr < 0 || maxthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: maxthr should be a float between 0.0 and 1.0");
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
     Launch L;
-    int rc = prepare(ctx, planes, nplanes, ref, L);
+    int rc = prepare(ctx, planes, nplanes, ref, L, result_dev);
     if (rc != VSZIP_OK) return rc;
     const bool is_float = dtype == VSZIP_F16 || dtype == VSZIP_F32;
     L.prm.minthr = minthr;
@@ -994,29 +1007,65 @@ static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *plan
         case VSZIP_F32: rc = run_minmax<float>(ctx, L, ref, no_thr); break;
         default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: not supported Int format.");
     }
-    if (rc != VSZIP_OK) return rc;
-    return fetch(ctx, L, vmin, vmax, ref ? diff : nullptr);
+    return rc;
 }
 
 // Any number of planes per call: batches of kMaxPlanesPS (the per-plane table travels in the kernel argument).
-VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
-                                     double *avg, double *diff) {
-    if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
+// Every group of kMaxPlanesPS planes is queued without waiting for the one before (their results land in different entries of the
+// result array; the scratch tables are reused in stream order): a 64-frame call is four groups and ONE synchronise.
+static int plane_average_queue(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample, double *result_dev) {
     for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
-        const int rc = plane_average_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), exclude, nexclude, bits_per_sample, avg ? avg + o : nullptr,
-                                           diff ? diff + o : nullptr);
+        const int rc = plane_average_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), exclude, nexclude, bits_per_sample, result_dev + (size_t)o * 4);
         if (rc != VSZIP_OK) return rc;
     }
     return VSZIP_OK;
+}
+static int plane_minmax_queue(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample, double *result_dev) {
+    for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
+        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, result_dev + (size_t)o * 4);
+        if (rc != VSZIP_OK) return rc;
+    }
+    return VSZIP_OK;
+}
+
+VSZIP_EXPORT int vszip_plane_average(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
+                                     double *avg, double *diff) {
+    if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
+    double *host = nullptr, *dev = nullptr;
+    int rc = result_buffer(ctx, nplanes, &host, &dev);
+    if (rc != VSZIP_OK) return rc;
+    rc = plane_average_queue(ctx, dtype, planes, nplanes, exclude, nexclude, bits_per_sample, dev);
+    if (rc != VSZIP_OK) return rc;
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return fetch(ctx, nplanes, host, avg, planes[0].ref ? diff : nullptr, nullptr);
+}
+
+VSZIP_EXPORT int vszip_plane_average_async(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
+                                           double *pinned_results) {
+    if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
+    double *dev = nullptr;
+    const int rc = caller_buffer(ctx, pinned_results, &dev);
+    if (rc != VSZIP_OK) return rc;
+    return plane_average_queue(ctx, dtype, planes, nplanes, exclude, nexclude, bits_per_sample, dev);
 }
 
 VSZIP_EXPORT int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
                                     double *vmin, double *vmax, double *diff) {
     if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
-    for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
-        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, vmin ? vmin + o : nullptr,
-                                          vmax ? vmax + o : nullptr, diff ? diff + o : nullptr);
-        if (rc != VSZIP_OK) return rc;
-    }
-    return VSZIP_OK;
+    double *host = nullptr, *dev = nullptr;
+    int rc = result_buffer(ctx, nplanes, &host, &dev);
+    if (rc != VSZIP_OK) return rc;
+    rc = plane_minmax_queue(ctx, dtype, planes, nplanes, minthr, maxthr, bits_per_sample, dev);
+    if (rc != VSZIP_OK) return rc;
+    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return fetch(ctx, nplanes, host, vmin, vmax, planes[0].ref ? diff : nullptr);
+}
+
+VSZIP_EXPORT int vszip_plane_minmax_async(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
+                                          double *pinned_results) {
+    if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
+    double *dev = nullptr;
+    const int rc = caller_buffer(ctx, pinned_results, &dev);
+    if (rc != VSZIP_OK) return rc;
+    return plane_minmax_queue(ctx, dtype, planes, nplanes, minthr, maxthr, bits_per_sample, dev);
 }
