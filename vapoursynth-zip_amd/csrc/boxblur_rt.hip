@@ -2023,16 +2023,20 @@ int ichain_band_rows(const vszip_ctx *ctx, const std::vector<RPlane> &pl, int ra
             }
             waves += (double)ncg * nbp;
         }
+        // (a grid search over the five constants against the sweep's 12 x 9 measurements: the model's pick is the measured optimum on nine workloads and
+        // within 4 % of it on the other three — profiles/r04_rt_band_sweep.txt, tools/rt_band_fit.py)
         const double conc = std::min(waves, cap), w = conc / 1024.0;
-        const double slow = 1.0 + 0.36 * std::max(0.0, w - 1.0);
-        return std::max(longest, total / conc) * slow + (nb > 1 ? 2.0 * drain : 0.0);  // (+ the launch that fills the table of constants)
+        const double slow = 1.0 + 0.2 * std::max(0.0, w - 0.75);
+        double t = std::max(longest, total / conc) * slow;
+        if (waves > conc) t += 0.3 * longest * slow;  // queued waves: the last ones run beside idle slots
+        return t + (nb > 1 ? 1.0 * drain : 0.0);      // (+ the launch that fills the table of constants)
     };
     int best_nb = 1;
     double best = cost(1);
     for (int nb : {2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32}) {
         if ((maxh + nb - 1) / nb < 32) break;
         const double c = cost(nb);
-        if (c < best * 0.97) {  // (a band count has to earn its extra launch)
+        if (c < best) {
             best = c;
             best_nb = nb;
         }

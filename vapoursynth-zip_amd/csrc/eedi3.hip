@@ -249,12 +249,16 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             }
             wave_fence();  // tb / ws are rewritten by the next pass
         };
+#ifdef VSZIP_E3_DIAG_ONE_PASS  // (timing diagnostics only, tools/variant.sh: ONE of the eleven direction passes - wrong results)
+        cost_pass(0);
+#else
         if constexpr (FIXED) {
 #pragma unroll
             for (int ug = -MD; ug <= MD; ug += kU) cost_pass(ug);
         } else {
             for (int ug = -mdis; ug <= mdis; ug += kU) cost_pass(ug);
         }
+#endif
         wave_fence();
         // ---- DP phase, lanes = direction index ---------------------------------------
         const int xe = min(kXB, w - xb);
@@ -305,10 +309,18 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             held[kXB / 4 - 1] |= dp_step(tcv[0]) << 24;
             store_block(held, blk - 1);
         }
+#ifdef VSZIP_E3_DIAG_NO_DP  // (timing diagnostics only: four of the 64 Viterbi steps of a block - wrong results)
+        if (xe == kXB) {
+#pragma unroll
+            for (int xl = 1; xl < 5; ++xl) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
+        } else
+#else
         if (xe == kXB) {
 #pragma unroll
             for (int xl = 1; xl < kXB; ++xl) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
-        } else {
+        } else
+#endif
+        {
 #pragma unroll
             for (int xl = 1; xl < kXB; ++xl)
                 if (xl < xe) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));

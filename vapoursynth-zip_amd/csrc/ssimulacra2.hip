@@ -910,6 +910,143 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
     }
 }
 
+// ---- round 4: the maps kernel per TERM SET, register-lean ------------------------------------------------------------------------------
+// skip_table (ssimulacra2.zig:22-37) fixes per (scale, plane) whether ssimMap runs and whether edgeMap runs (edgeMap computes artifact AND detail loss
+// whenever either counts, :124): three term sets — S+E (scale 0's Y plane: 56 % of the maps time at 4K), S, E. ssim_maps_kernel above serves them all
+// with run-time flags and 167 VGPRs (three waves a SIMD; capped at 128 it spills). ssim_maps_ts_kernel<SSIM, EDGE> is the same arithmetic with the
+// flags compile-time and the two blur passes split so that the live state is half as large:
+//   * vertical: the (mu1, mu2) taps first — 2 x 16 staged samples in registers — and their 8 outputs stored as the .zw halves of vt; then p, q are
+//     overwritten by p q and (p + q)^2 and the (b12, bsq) taps follow into the .xy halves (the generic kernel holds all four 16-sample arrays);
+//   * horizontal: the .zw halves of 12 columns give mu1 / mu2 of the thread's 4 outputs, then the .xy halves give b12 / bsq (12 x 8-byte reads twice
+//     instead of 12 x 16-byte once: LDS has the room, the generic kernel's array is at 0.38);
+//   * the E set loads and blurs the two means only; the S set skips edgeMap's division and its four f64 sums.
+// Every output accumulates its nine taps in tap order with the same fused (vertical, :318) / unfused (horizontal, :276) operations, so the f32 maps and
+// therefore the f64 sums are those of the generic kernel (tests/test_gpu_ssimulacra2.py::test_maps_term_set_kernels_match_the_generic_one: partial sums
+// equal to the last bit).
+template <bool SSIM, bool EDGE>
+__device__ __forceinline__ void ssim_maps_tile_ts(float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
+    const int tid = threadIdx.x;
+    constexpr int VR = 8;
+    if (tid < IW * ((TH + VR - 1) / VR)) {
+        const int c = tid % IW, r0 = (tid / IW) * VR;
+        float p[VR + 8], q[VR + 8];
+#pragma unroll
+        for (int j = 0; j < VR + 8; ++j) {
+            const int rr = min(r0 + j, IH - 1);
+            p[j] = s1[rr][c];
+            q[j] = s2[rr][c];
+        }
+#pragma unroll
+        for (int o = 0; o < VR; ++o) {
+            v2f m = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m = __builtin_elementwise_fma(v2f{c_kernel[k], c_kernel[k]}, v2f{p[o + k], q[o + k]}, m);
+            if (r0 + o < TH) *reinterpret_cast<v2f *>(&reinterpret_cast<float *>(&vt[r0 + o][c])[2]) = m;
+        }
+        if constexpr (SSIM) {
+#pragma unroll
+            for (int j = 0; j < VR + 8; ++j) {
+                const float pp = p[j], qq = q[j], sum = pp + qq;
+                p[j] = pp * qq;
+                q[j] = sum * sum;
+            }
+#pragma unroll
+            for (int o = 0; o < VR; ++o) {
+                v2f ms = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) ms = __builtin_elementwise_fma(v2f{c_kernel[k], c_kernel[k]}, v2f{p[o + k], q[o + k]}, ms);
+                if (r0 + o < TH) *reinterpret_cast<v2f *>(&vt[r0 + o][c]) = ms;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int HC = 4;
+    {
+        const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
+        v2f mu[HC], bs[HC];
+        {
+            v2f t[HC + 8];
+#pragma unroll
+            for (int j = 0; j < HC + 8; ++j) t[j] = *reinterpret_cast<const v2f *>(&reinterpret_cast<const float *>(&vt[r][xs + j])[2]);
+#pragma unroll
+            for (int o = 0; o < HC; ++o) {
+                v2f a = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a = a + v2f{c_kernel[k], c_kernel[k]} * t[o + k];
+                mu[o] = a;
+            }
+        }
+        if constexpr (SSIM) {
+            v2f t[HC + 8];
+#pragma unroll
+            for (int j = 0; j < HC + 8; ++j) t[j] = *reinterpret_cast<const v2f *>(&vt[r][xs + j]);
+#pragma unroll
+            for (int o = 0; o < HC; ++o) {
+                v2f a = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a = a + v2f{c_kernel[k], c_kernel[k]} * t[o + k];
+                bs[o] = a;
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < HC; ++o) bs[o] = v2f{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int o = 0; o < HC; ++o)
+            maps_pixel(mu[o].x, mu[o].y, bs[o].x, bs[o].y, EDGE ? s1[r + HALO][xs + o + HALO] : 0.0f, EDGE ? s2[r + HALO][xs + o + HALO] : 0.0f, SSIM, EDGE, acc);
+    }
+}
+
+#ifndef VSZIP_SSIM_TS_WPE
+#define VSZIP_SSIM_TS_WPE 4
+#endif
+template <bool SSIM, bool EDGE>
+__global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(const MapsArgs a) {
+    __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];
+    __shared__ v4f vt[TH][IW + 1];
+    __shared__ double red[4][6];
+    const int ps = blockIdx.z % a.nactive, pair = blockIdx.z / a.nactive;
+    const PairPtrs &pp = a.tab[pair];
+    const float *im1 = pp.xyb1[a.plane[ps]], *im2 = pp.xyb2[a.plane[ps]];
+    const int w = a.w, h = a.h;
+    const int y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+    auto is_interior = [&](int x0) { return x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h; };
+    const int tx0 = blockIdx.x * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
+    float v1[kMapsNS], v2[kMapsNS];
+    bool fetched = false;
+    for (int tx = tx0; tx < tx1; ++tx) {
+        const int x0 = tx * TW;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (is_interior(x0)) {
+            if (!fetched) ssim_maps_fetch(a, im1, im2, x0, y0, v1, v2);
+            ssim_maps_park(v1, v2, s1, s2);
+            __syncthreads();
+            fetched = tx + 1 < tx1 && is_interior(x0 + TW);
+            if (fetched) ssim_maps_fetch(a, im1, im2, x0 + TW, y0, v1, v2);
+            ssim_maps_tile_ts<SSIM, EDGE>(s1, s2, vt, acc);
+        } else {
+            fetched = false;
+            ssim_maps_tile<false>(a, im1, im2, SSIM, EDGE, x0, y0, s1, s2, vt, acc);
+        }
+        // (the sums a term set does not have stay exact zeros: the final kernel reads all six)
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            if ((q < 2 && SSIM) || (q >= 2 && EDGE)) acc[q] = wave_reduce_sum(acc[q]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
+        }
+        __syncthreads();
+        if (tid < 6) {
+            const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            const int tile = blockIdx.y * a.tiles_x + tx;
+            a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
 struct FinalArgs {
     const double *partial;  // [pair][slot][tile][6]
     double *avg;  // [pair][18 slots][6]: ssim avg, ssim 4th-root, art avg, art 4th-root, det avg, det 4th-root
@@ -1466,15 +1603,37 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         if (ma.nactive > 0) {
             ma.tpb = ma.tiles_x >= 32 ? 4 : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
             const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * cnt);
-            if (on_side) {
-                hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
-            } else {
-                if (main_st == ctx->stream) {
-                    vszip_probe_scope probe(ctx);  // (HIP events on the context's stream: other streams' launches are not probed)
+            // one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>), or the one generic kernel (VSZIP_SSIM_GENERIC_MAPS=1)
+            auto launch_maps = [&]() {
+                if (ctx->opt.ssim_generic_maps) {
                     hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
-                } else {
-                    hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
+                    return;
                 }
+                for (int fl = 3; fl >= 1; --fl) {
+                    MapsArgs mt = ma;
+                    mt.nactive = 0;
+                    for (int k = 0; k < ma.nactive; ++k)
+                        if (ma.flags[k] == fl) {
+                            mt.plane[mt.nactive] = ma.plane[k];
+                            mt.flags[mt.nactive] = fl;
+                            mt.slot[mt.nactive] = ma.slot[k];
+                            ++mt.nactive;
+                        }
+                    if (mt.nactive == 0) continue;
+                    const dim3 g(mgrid.x, mgrid.y, mt.nactive * cnt);
+                    if (fl == 3)
+                        hipLaunchKernelGGL((ssim_maps_ts_kernel<true, true>), g, dim3(256), 0, st, mt);
+                    else if (fl == 1)
+                        hipLaunchKernelGGL((ssim_maps_ts_kernel<true, false>), g, dim3(256), 0, st, mt);
+                    else
+                        hipLaunchKernelGGL((ssim_maps_ts_kernel<false, true>), g, dim3(256), 0, st, mt);
+                }
+            };
+            if (!on_side && main_st == ctx->stream) {
+                vszip_probe_scope probe(ctx);  // (HIP events on the context's stream: other streams' launches are not probed)
+                launch_maps();
+            } else {
+                launch_maps();
             }
         }
         for (int k = 0; k < ma.nactive; ++k) {
