@@ -212,11 +212,14 @@ class Timed:
         # Clocks and power state first: the first launches after idle run up to 10 % slower (rocprofv3: 624 us
         # against 563 us in steady state). Untimed, like the W warm-up steps that follow.
         t_pre = time.perf_counter()
+        ncalls = 0
         while self.prewarm_s > 0 and time.perf_counter() - t_pre < self.prewarm_s:
             step()
             self.dev.sync()
+            ncalls += 1
         for _ in range(warmup):
             step()
+        self.calls = getattr(self, "calls", 0) + ncalls + warmup + steps  # every call of `step` a profiler sees (tools/roofline_check.py)
         self.barrier()
         self.dev.probe_enable(True)
         t0 = time.perf_counter()
@@ -531,6 +534,7 @@ def pipeline_line(dev, timed, world, frames, steps, warmup, max_over_ranks, redu
            "stream_ms_per_frame": region_ms / (steps * frames),
            "roofline": {"bound": "hbm", "achieved": alg * frames * steps / (region_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg * frames * steps / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "alg_bytes_per_call": alg * frames, "basis": "stream",
                         "kernel": "whole chain (bilateral_lds16<f32> + boxblur_ctf_ring + the SSIMULACRA2 kernels); algorithmic bytes = 6 x frame "
                                   "(source read twice, each intermediate written and read once)"},
            "clip_mean_score": {"value": float(tot[0] / tot[1]), "frames": int(tot[1]), "reduced_over_ranks": world, "allreduce_ms": reduce_ms},
@@ -561,6 +565,7 @@ def eedi3_leg(dev, timed, no_cpu, frames=16):
     gbs = fb * frames * 5 / dt / 1e9
     res = {"value": frames * 5 / dt, "unit": "frames/s", "interpolated_lines_per_s": frames * 5 * lines / dt, "frames_per_call": frames,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "alg_bytes_per_call": fb * frames, "basis": "wall",
                         "note": "not an HBM-bound filter: 41 directions x a 5-tap window per pixel and a dynamic programme along every line "
                                 "(eedi3_line_kernel: VALU about 80 % busy, DESIGN.md 3.5); the fraction is reported for completeness"},
            "workload": "vszip.EEDI3 field=1 dh=1 (defaults: mdis 20, nrad 2, vcheck 2), 1920x1080 YUV420PS -> 1920x2160, HBM-resident"}
@@ -592,7 +597,7 @@ def _eedi3_params():
     return C.byref(Eedi3Params(1, 0.2, 0.25, 20.0, 2, 20, 0, 2, 32.0, 64.0, 4.0))
 
 
-def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
+def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64, per_frame=True):
     """XPSNR (getWSSE) on 1920x1080 YUV420P8 with temporal weighting. `value` is the batched entry
     point (vszip_xpsnr_wsse_batch: `batch` frames per launch, one result copy). Per frame, every call
     synchronises (the result is a host scalar), so one caller is latency bound; `per_frame_calls` is
@@ -615,6 +620,12 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
     batch_call = dev.xpsnr_batch_call(dorg, drec, p1s, p2s, depth=8, frame_rate=24)  # pointer arrays built once, like a C host's
     dtb, _, dom_ms, launches = timed.run(batch_call, 10, 2)
     batched = batch * 10 / dtb
+    fb = 2 * sum(s[0] * s[1] for s in yuv420_shapes(W1080, H1080)) + W1080 * H1080  # org + rec + the previous luma
+    if not per_frame:  # (tools/roofline_check.sh: the batch call alone, so that a profile's xpsnr_strip_kernel rows are 64-frame launches only)
+        return {"value": batched, "unit": "frames/s", "frames_per_call": batch,
+                "roofline": {"bound": "hbm", "achieved": batch * fb / (dom_ms / launches * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": batch * fb / (dom_ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "xpsnr_strip_kernel<u8>",
+                             "alg_bytes_per_call": batch * fb, "basis": "dominant kernel", "kernel_match": "xpsnr_strip_kernel", "avg_launch_us": dom_ms / launches * 1e3}}
 
     def step():
         for f in range(frames):
@@ -625,7 +636,6 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
     for _ in range(5):
         step()
     dt = time.perf_counter() - t0
-    fb = 2 * sum(s[0] * s[1] for s in yuv420_shapes(W1080, H1080)) + W1080 * H1080  # org + rec + the previous luma
     single = frames * 5 / dt
 
     # the same frames from `workers` threads, one context each (device memory is shared)
@@ -655,6 +665,7 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
            "per_frame_calls": {"workers": workers, "frames_per_s": multi, "single_caller_frames_per_s": single},
            "roofline": ({"bound": "hbm", "achieved": batch * fb / (dom_ms / launches * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": batch * fb / (dom_ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "xpsnr_strip_kernel<u8>",
+                         "alg_bytes_per_call": batch * fb, "basis": "dominant kernel", "kernel_match": "xpsnr_strip_kernel",
                          "avg_launch_us": dom_ms / launches * 1e3} if launches else None),
            "workload": f"vszip.XPSNR getWSSE, 1920x1080 YUV420P8 org vs rec, temporal, {batch} frames per call; per_frame_calls: one synchronising call per frame, "
                        f"{workers} host threads with a context each"}
@@ -672,7 +683,7 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64):
     return res
 
 
-def planestats_leg(dev, timed, frames=64):
+def planestats_leg(dev, timed, frames=64, only=None):
     """PlaneAverage / PlaneMinMax on 3840x2160 YUV420P16: single-pass readers, HBM roofline = bytes read once."""
     base = make_frame(7, W4K, H4K)
     planes = []
@@ -683,12 +694,16 @@ def planestats_leg(dev, timed, frames=64):
     for name, fn in (("plane_average_4k", lambda: dev.plane_average(planes, exclude=[-1])),
                      ("plane_minmax_4k", lambda: dev.plane_minmax(planes)),
                      ("plane_minmax_thr_4k", lambda: dev.plane_minmax(planes, 0.1, 0.1))):
+        if only and name != only:
+            continue
         dt, region_ms, dom_ms, launches = timed.run(fn, 10, 2)
         gbs = fb * 10 / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         whole = fb * 10 / (region_ms * 1e-3) / 1e9
         out[name] = {"value": frames * 10 / dt, "unit": "frames/s",
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                   "kernel": "the plane reader (average_kernel / minmax_kernel / hist_kernel pass 0)", "avg_launch_us": dom_ms * 1e3 / max(launches, 1),
+                                  "alg_bytes_per_call": fb, "basis": "dominant kernel",
+                                  "kernel_match": {"plane_average_4k": "average_kernel", "plane_minmax_4k": "minmax_kernel", "plane_minmax_thr_4k": "hist_sweep_kernel"}[name],
                                   "whole_call": {"note": "all kernels of the call + the scalars' way to the host + the one sync", "achieved": whole, "frac": whole / HBM_PEAK_GBS}},
                      "whole_call_frac": whole / HBM_PEAK_GBS,
                      "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call ({3 * frames} planes in groups of 48 queued back to back, one sync), HBM-resident; value includes the sync"}
@@ -709,7 +724,8 @@ def limiter_leg(dev, timed, frames=16):
     gbs = fb * 10 / (dom_ms * 1e-3) / 1e9
     return {"limiter_4k": {"value": frames * 10 / dt, "unit": "frames/s",
                            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                        "kernel": "limiter_kernel<u16>", "avg_launch_us": dom_ms * 1e3 / launches},
+                                        "kernel": "limiter_kernel<u16>", "avg_launch_us": dom_ms * 1e3 / launches,
+                                        "alg_bytes_per_call": fb, "basis": "dominant kernel", "kernel_match": "limiter_kernel"},
                            "workload": f"vszip.Limiter tv_range: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
 
 
@@ -728,11 +744,12 @@ def limit_filter_leg(dev, timed, frames=16):
     gbs = fb * 10 / (dom_ms * 1e-3) / 1e9
     return {"limit_filter_4k": {"value": frames * 10 / dt, "unit": "frames/s",
                                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                             "kernel": "limit_filter_kernel<u16>", "avg_launch_us": dom_ms * 1e3 / launches},
+                                             "kernel": "limit_filter_kernel<u16>", "avg_launch_us": dom_ms * 1e3 / launches,
+                                             "alg_bytes_per_call": fb, "basis": "dominant kernel", "kernel_match": "limit_filter_kernel"},
                                 "workload": f"vszip.LimitFilter dark_thr=bright_thr=8 elast=3: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
 
 
-def boxblur_other_paths_leg(dev, timed, frames_in=8):
+def boxblur_other_paths_leg(dev, timed, frames_in=8, only=None):
     """The BoxBlur paths beside the headline one: the runtime path (radius > 22 or several passes,
     boxblur_runtime.zig) on 4K YUV420P16 and the compile-time float path on 4K YUV420PS."""
     out = {}
@@ -743,6 +760,8 @@ def boxblur_other_paths_leg(dev, timed, frames_in=8):
     for name, base, args, dt_ in (("boxblur_rt_r30_4k", base16, (30, 1, 30, 1), np.uint16), ("boxblur_rt_r5x3_4k", base16, (5, 3, 5, 3), np.uint16),
                                   ("boxblur_ct_float_r13_4k", basef, (13, 1, 13, 1), np.float32), ("boxblur_rt_float_r5x3_4k", basef, (5, 3, 5, 3), np.float32),
                                   ("boxblur_ct_u8_r13_4k", base8, (13, 1, 13, 1), np.uint8)):
+        if only and name != only:
+            continue
         srcs, dsts = [], []
         frames = 64 if dt_ == np.uint8 else frames_in
         placement = None
@@ -760,6 +779,7 @@ def boxblur_other_paths_leg(dev, timed, frames_in=8):
         gbs = fb * 5 / (kms * 1e-3) / 1e9
         out[name] = {"value": frames * 5 / dt, "unit": "frames/s",
                      "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                  "alg_bytes_per_call": fb, "basis": "stream",
                                   "note": "algorithmic bytes = one read + one write of the frame, whatever the number of passes"},
                      "workload": f"vszip.BoxBlur hradius={args[0]} hpasses={args[1]} vradius={args[2]} vpasses={args[3]}, 3840x2160 {fmt_names[np.dtype(dt_).name]}, {frames} frames per call, HBM-resident"}
         if placement:
@@ -881,7 +901,8 @@ def boxblur_1080p_leg(dev, timed, no_cpu, frames=64):
     gbs = fb * launches / (dom_ms * 1e-3) / 1e9
     res = {"value": frames * 200 / dt, "unit": "frames/s", "readme_reference_fps": 1046.11,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "boxblur_ct_ring_kernel<u16,13>", "avg_launch_us": dom_ms * 1e3 / launches},
+                        "kernel": "boxblur_ct_ring_kernel<u16,13>", "avg_launch_us": dom_ms * 1e3 / launches,
+                        "alg_bytes_per_call": fb, "basis": "dominant kernel", "kernel_match": "boxblur_ct_ring_kernel"},
            "placement": placement,
            "workload": f"vszip.BoxBlur hradius=vradius=13 on 1920x1080 YUV420P16 BlankClip (README bench), {frames} frames per call, HBM-resident"}
     del keep
@@ -905,7 +926,8 @@ def boxblur_gauss_leg(dev, timed, frames=64):
     gbs = fb * 10 / (kms * 1e-3) / 1e9
     return {"value": frames * 10 / dt, "unit": "frames/s",
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "boxblur_rt_hsmall_kernel<u8,1> + boxblur_rt_vsmall_kernel<u8,2>", "note": "algorithmic bytes = one read + one write of the frame"},
+                         "kernel": "boxblur_rt_hsmall_kernel<u8,1> + boxblur_rt_ichain_kernel<u8,2,1|2> (the vertical passes in bands)", "alg_bytes_per_call": fb, "basis": "stream",
+                         "note": "algorithmic bytes = one read + one write of the frame"},
             "workload": f"vszip.BoxBlur hradius=1 hpasses=2 vradius=1 vpasses=2 on 1920x1080 YUV420P8 (natural content tiled), {frames} frames per call, HBM-resident"}
 
 
@@ -925,7 +947,8 @@ def boxblur_1080p_5pass_leg(dev, timed, no_cpu, frames=32):
     gbs = fb * 20 / (kms * 1e-3) / 1e9
     res = {"value": frames * 20 / dt, "unit": "frames/s", "readme_reference_fps": 367.01,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "boxblur_rt_* (5 horizontal + 5 vertical passes)",
+                        "kernel": "boxblur_rt_hsmall_kernel<u16,13> (5 horizontal passes) + boxblur_rt_ichain_kernel<u16,5,1|2> (5 vertical passes in bands)",
+                        "alg_bytes_per_call": fb, "basis": "stream",
                         "note": "algorithmic bytes = one read + one write of the frame; every pass that goes through HBM divides the fraction"},
            "workload": f"vszip.BoxBlur hradius=13 hpasses=5 vradius=13 vpasses=5 on 1920x1080 YUV420P16 BlankClip (README bench 3), {frames} frames per call, HBM-resident"}
     if not no_cpu:
@@ -1376,7 +1399,8 @@ def main() -> int:
                 others[name] = {"value": nf * 10 / dt2, "unit": "frames/s", "kernel_ms_per_frame": kms / (10 * nf), "frames_per_call": nf,
                                 "roofline": {"bound": "hbm", "achieved": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": 2 * fb2 * nf * 10 / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                             "kernel": "bilateral_walk16_kernel<3,2> luma + <2,1> chroma (column-walking waves, exact range LUT packed in LDS)", "avg_launch_us": dms * 1e3 / nl},
+                                             "kernel": "bilateral_walk16_kernel<3,2> luma + <2,1> chroma (column-walking waves, exact range LUT packed in LDS)", "avg_launch_us": dms * 1e3 / nl,
+                                             "alg_bytes_per_call": 2 * fb2 * nf, "basis": "dominant kernel", "kernel_match": "bilateral_walk16_kernel"},
                                 "workload": f"vszip.Bilateral sigmaS=2 sigmaR=2 {w}x{h} YUV420P16 (natural content tiled), HBM-resident"}
                 others[name]["roofline"]["kernel"] = "bilateral_walk16_kernel<3,2> + <2,1> (symmetric weights looked up once, table in LDS)"
                 others[name]["limit"] = limit_from_profile("bilateral", "bilateral_walk16_kernel<3")
@@ -1392,6 +1416,7 @@ def main() -> int:
                 gb = 2 * fb2 * 64 * 10 / dt2 / 1e9
                 others[name] = {"value": 64 * 10 / dt2, "unit": "frames/s", "frames_per_call": 64,
                                 "roofline": {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
+                                             "alg_bytes_per_call": 2 * fb2 * 64, "basis": "wall",
                                              "note": "whole call; the range table's computed part (up to the reference's `upper` cut) held as it is in LDS (DESIGN.md 3.3, PLATEAU form)"},
                                 "workload": f"vszip.Bilateral sigmaS={ss} sigmaR={sr} 1920x1080 {'YUV420P8' if b8 else 'YUV420P16'} (natural content tiled), 64 frames per call, HBM-resident"}
                 del keep
@@ -1400,6 +1425,7 @@ def main() -> int:
             ss_gbs = 2 * 3 * W4K * H4K * 4 * 16 * 5 / dt3 / 1e9  # algorithmic bytes: the two RGBS input frames
             others["ssimulacra2_4k"] = {"value": 16 * 5 / dt3, "unit": "pairs/s", "ms_per_pair": dt3 * 1e3 / 80, "pairs_per_call": 16,
                                         "roofline": {"bound": "hbm", "achieved": ss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ss_gbs / HBM_PEAK_GBS, "traffic": None,
+                                                     "alg_bytes_per_call": 2 * 3 * W4K * H4K * 4 * 16, "basis": "wall",
                                                      "note": "whole pipeline on the two input frames; ssim_maps_kernel (65 % of a pair) is issue bound: "
                                                              "about 230 instructions per plane-pixel, a quarter of them f64 (DESIGN.md 3.4)"},
                                         "workload": "vszip.SSIMULACRA2 ref vs dist, 3840x2160 RGBS (linear), HBM-resident; includes the scalar D2H + sync"}

@@ -643,6 +643,7 @@ struct MapsArgs {
     int tpb;          // tiles (along x) per block
     double *partial;  // [pair][slot][tile][6]
     int max_tiles;
+    int gx, gy, nblk;  // ssim_maps_ts_kernel: the logical (x, y, plane-pair) grid, launched as one dimension of ceil(nblk / 8) * 8 blocks
 };
 
 // the asymmetric mirror of blur (:254,260,357,364): reflect-101 at the start,
@@ -1005,14 +1006,21 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
     __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];
     __shared__ v4f vt[TH][IW + 1];
     __shared__ double red[4][6];
-    const int ps = blockIdx.z % a.nactive, pair = blockIdx.z / a.nactive;
+    // XCD-aware order: workgroup i runs on XCD i % 8, so the logical blocks are dealt out in eight contiguous chunks — an XCD walks a band of tile
+    // rows of one plane, and the 8-row / 8-column halo a tile shares with its neighbours is in that XCD's L2 (with the plain 3-D grid every
+    // neighbour sat on another XCD and the halo came from memory again)
+    const int chunk = (a.nblk + 7) >> 3;
+    const int lb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (lb >= a.nblk) return;
+    const int bx = lb % a.gx, by = (lb / a.gx) % a.gy, bz = lb / (a.gx * a.gy);
+    const int ps = bz % a.nactive, pair = bz / a.nactive;
     const PairPtrs &pp = a.tab[pair];
     const float *im1 = pp.xyb1[a.plane[ps]], *im2 = pp.xyb2[a.plane[ps]];
     const int w = a.w, h = a.h;
-    const int y0 = blockIdx.y * TH;
+    const int y0 = by * TH;
     const int tid = threadIdx.x;
     auto is_interior = [&](int x0) { return x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h; };
-    const int tx0 = blockIdx.x * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
+    const int tx0 = bx * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
     float v1[kMapsNS], v2[kMapsNS];
     bool fetched = false;
     for (int tx = tx0; tx < tx1; ++tx) {
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
         __syncthreads();
         if (tid < 6) {
             const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-            const int tile = blockIdx.y * a.tiles_x + tx;
+            const int tile = by * a.tiles_x + tx;
             a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
         }
         __syncthreads();
@@ -1620,7 +1628,10 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
                             ++mt.nactive;
                         }
                     if (mt.nactive == 0) continue;
-                    const dim3 g(mgrid.x, mgrid.y, mt.nactive * cnt);
+                    mt.gx = (int)mgrid.x;
+                    mt.gy = (int)mgrid.y;
+                    mt.nblk = mt.gx * mt.gy * mt.nactive * cnt;
+                    const dim3 g((unsigned)(((mt.nblk + 7) / 8) * 8));
                     if (fl == 3)
                         hipLaunchKernelGGL((ssim_maps_ts_kernel<true, true>), g, dim3(256), 0, st, mt);
                     else if (fl == 1)
