@@ -368,7 +368,8 @@ def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=Non
         t0_ = time.perf_counter()
         dst, dst_us, src_us, dst2_us = Arena(dev, shapes, dtype, seed + 2), [None], [None], []
         t_alloc += time.perf_counter() - t0_
-        first["us"] = launch_us(src, dst, n=20, with_args=args)
+        if not os.environ.get("VSZIP_BENCH_NO_FIRST_US"):  # (tools/prof_legs.py: a profile of the leg should hold the timed launches only)
+            first["us"] = launch_us(src, dst, n=20, with_args=args)
     else:
         # 1: the destination arena, every candidate against the first source arena
         ptr, best, dst_us = dev.alloc_probed(lay.nbytes, tries, first_candidate)
@@ -710,7 +711,7 @@ def planestats_leg(dev, timed, frames=64, only=None):
     return out
 
 
-def limiter_leg(dev, timed, frames=16):
+def limiter_leg(dev, timed, frames=64):
     """vszip.Limiter (tv_range bounds) on 3840x2160 YUV420P16: a streaming read + write, HBM roofline = both."""
     base = make_frame(9, W4K, H4K)
     srcs, dsts = [], []
@@ -729,7 +730,7 @@ def limiter_leg(dev, timed, frames=16):
                            "workload": f"vszip.Limiter tv_range: {frames} x 3840x2160 YUV420P16 per call, HBM-resident"}}
 
 
-def limit_filter_leg(dev, timed, frames=16):
+def limit_filter_leg(dev, timed, frames=64):
     """vszip.LimitFilter(flt, src) on 3840x2160 YUV420P16: two streams in, one out."""
     base = make_frame(11, W4K, H4K)
     flts, srcs, dsts = [], [], []

@@ -89,6 +89,7 @@ EXP int vszip_ctx_set_staging(vszip_ctx *ctx, int mode) {
     return VSZIP_OK;
 }
 EXP int vszip_ctx_abort(vszip_ctx *ctx) { return ctx ? VSZIP_OK : VSZIP_ERR_ARG; }
+EXP int vszip_ctx_set_option(vszip_ctx *ctx, const char *name, int) { return ctx && name ? VSZIP_OK : VSZIP_ERR_ARG; }
 EXP const char *vszip_last_error(vszip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 EXP int vszip_abi_version(void) { return VSZIP_ABI_VERSION; }
 

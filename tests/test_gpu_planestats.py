@@ -135,11 +135,11 @@ def test_minmax_single_read_and_its_second_sweep(dev, oracle, dtype, monkeypatch
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 def test_many_planes_one_call_and_the_async_entry_points(dev, oracle, dtype):
-    """Round 4: a call of more than 48 planes is queued as groups back to back with ONE synchronise at the end (results of every group in their own entries of
-    the pinned array), and vszip_plane_average_async / _minmax_async write into the caller's pinned array and do not synchronise at all. 130 planes of
-    three sizes (three groups), every plane against the oracle; the async results equal the synchronous ones to the bit."""
+    """Round 4: a call of more than 192 planes is queued as groups back to back with ONE synchronise at the end (results of every group in their own entries of
+    the pinned array), and vszip_plane_average_async / _minmax_async write into the caller's pinned array and do not synchronise at all. 400 planes of
+    three sizes (three groups: 192 + 192 + 16), every plane against the oracle; the async results equal the synchronous ones to the bit."""
     shapes = [(96, 160), (48, 80), (37, 53)]
-    planes = [fx.splitmix64_plane(100 + i, shapes[i % 3], dtype) if i % 5 else fx.tiled_natural(shapes[i % 3], dtype, i % 3) for i in range(130)]
+    planes = [fx.splitmix64_plane(100 + i, shapes[i % 3], dtype) if i % 5 else fx.tiled_natural(shapes[i % 3], dtype, i % 3) for i in range(400)]
     refs = [fx.splitmix64_plane(900 + i, p.shape, dtype) for i, p in enumerate(planes)]
     ds, dr = [dev.upload(p) for p in planes], [dev.upload(r) for r in refs]
     is_int = np.dtype(dtype).kind == "u"
@@ -155,8 +155,8 @@ def test_many_planes_one_call_and_the_async_entry_points(dev, oracle, dtype):
             assert (avg[i], diff[i], df[i]) == (oa, od, odf), (dtype, i)
         else:
             assert avg[i] == pytest.approx(oa, rel=1e-12) and diff[i] == pytest.approx(od, rel=1e-12) and df[i] == pytest.approx(odf, rel=1e-12)
-    ra = dev.pinned_array((130, 4), np.float64)
-    rm = dev.pinned_array((130, 4), np.float64)
+    ra = dev.pinned_array((400, 4), np.float64)
+    rm = dev.pinned_array((400, 4), np.float64)
     ra[...] = -1.0
     rm[...] = -1.0
     dev.plane_average_async(ds, ra, [-1, 7], dr)

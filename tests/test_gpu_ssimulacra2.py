@@ -84,8 +84,8 @@ def test_batched_calls_equal_single_pair_calls(dev):
 @pytest.mark.parametrize("shape", [(320, 640), (319, 639), (97, 171), (540, 960), (1080, 1920)])
 def test_maps_term_set_kernels_match_the_generic_one(dev, oracle, shape):
     """Round 4: ssim_maps_ts_kernel<SSIM, EDGE> (one instance per term set of skip_table, the blur passes split to halve the live registers) against the
-    one generic kernel (VSZIP_SSIM_GENERIC_MAPS=1): the same f32 maps in the same order, so the f64 sums and the score are equal to the LAST BIT — on
-    sizes with interior and edge tiles, odd widths (the unfused column tail), several pairs per call (the two halves on two streams)."""
+    one generic kernel (VSZIP_SSIM_GENERIC_MAPS=1): the same f32 maps and per-pixel f64 terms; a block's four tiles are summed in one set of per-thread
+    sums (one reduction per block), so the scores agree to 1e-11, not to the bit — on sizes with interior and edge tiles, odd widths (the unfused column tail), several pairs per call (the two halves on two streams)."""
     pairs = []
     for seed in (3, 4, 5, 6, 7):
         pairs.append(_pair(shape, seed, 0.01 * seed))
@@ -94,7 +94,7 @@ def test_maps_term_set_kernels_match_the_generic_one(dev, oracle, shape):
     got = dev.ssimulacra2(r, d)
     with dev.options(VSZIP_SSIM_GENERIC_MAPS=1):
         generic = dev.ssimulacra2(r, d)
-    assert list(got) == list(generic), (shape, got, generic)
+    assert got == pytest.approx(generic, rel=0, abs=1e-11), (shape, got, generic)  # (same per-pixel terms; a block's tiles are summed in another order)
     if shape[0] <= 540:
         want = oracle.ssimulacra2(*pairs[0])
         assert got[0] == pytest.approx(want, abs=TOL)

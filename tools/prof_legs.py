@@ -3,8 +3,11 @@
 the leg's record(s) and `calls` = how often the timed call ran in this process (prewarm + warm-up + timed), so that a profile's
 total kernel time divides into a per-call time."""
 import json
+import os
 import sys
 from pathlib import Path
+
+os.environ.setdefault("VSZIP_BENCH_NO_FIRST_US", "1")
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))

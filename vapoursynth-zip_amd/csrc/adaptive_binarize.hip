@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int kMaxPlanesAB = 48;
+constexpr int kMaxPlanesAB = 192;  // planes per launch (64 YUV frames are ONE launch since round 4: four 48-plane launches paid four ramps and tails)
 constexpr int kRowsAB = 4;
 
 struct ABPlane {
@@ -26,9 +26,17 @@ __global__ __launch_bounds__(256) void adaptive_binarize_kernel(const ABParams p
     typedef uint8_t V16 __attribute__((ext_vector_type(16)));
     int pi = 0;
     const int blk = blockIdx.x;
-#pragma unroll 1
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (blk >= prm.p[i].block0) pi = i;
+
+    {  // block0 ascends: eight scalar steps for 192 planes (the linear scan was part of every workgroup's fixed cost)
+        int hi = prm.nplanes - 1;
+        while (pi < hi) {
+            const int mid = (pi + hi + 1) >> 1;
+            if (blk >= prm.p[mid].block0)
+                pi = mid;
+            else
+                hi = mid - 1;
+        }
+    }
     const ABPlane pl = prm.p[pi];
     const int y0 = (blk - pl.block0) * kRowsAB;
     const bool vec = ((reinterpret_cast<uintptr_t>(pl.a) | reinterpret_cast<uintptr_t>(pl.b) | reinterpret_cast<uintptr_t>(pl.dst) | (uintptr_t)pl.astride |

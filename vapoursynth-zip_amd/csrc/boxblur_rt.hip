@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int kMaxPlanesRT = 48;
+constexpr int kMaxPlanesRT = 192;  // planes per launch (round 4: 64 YUV frames are one launch per pass; 48 before)
 
 struct RPlane {
     const void *src;
@@ -33,11 +33,17 @@ struct RParams {
     int keep;  // the output is the next pass's input: plain stores (it stays in L2 / the Infinity Cache); 0: streamed out with the nt hint
 };
 
-__device__ __forceinline__ int rt_find(const RParams &prm, int b) {
-    int pi = 0;
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
-    return pi;
+template <typename P>
+__device__ __forceinline__ int rt_find(const P &prm, int b) {  // block0 ascends: eight scalar steps for 192 planes (a row-per-workgroup kernel pays this per row)
+    int lo = 0, hi = prm.nplanes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b >= prm.p[mid].block0)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
 }
 
 template <typename T>
@@ -225,10 +231,8 @@ __global__ __launch_bounds__(64) void boxblur_rt_vband_kernel(const RVParams prm
     extern __shared__ __attribute__((aligned(16))) uint4 vring[];
     const int D = 2 * prm.radius + 2;
     auto slot = [&](int row) -> uint4 & { return vring[(row % D) * 64 + (int)threadIdx.x]; };
-    int pi = 0;
     const int b = blockIdx.x;
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
+    const int pi = rt_find(prm, b);
     const RPlane pl = prm.p[pi];
     const int lb = b - pl.block0, ncg = prm.ncg[pi];
     const int x0 = ((lb % ncg) * 64 + (int)threadIdx.x) * V;

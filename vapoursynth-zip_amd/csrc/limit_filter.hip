@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int kMaxPlanesLF = 48;
+constexpr int kMaxPlanesLF = 192;  // planes per launch (64 YUV frames are ONE launch since round 4: four 48-plane launches paid four ramps and tails)
 // Rows per workgroup, measured on 16 4K YUV420P16 frames (tools/ab_stream.sh, round 2): 1 row 0.42 of the HBM
 // peak (a workgroup's fixed cost — plane lookup, two half-filled passes over a 480-vector row — dominates),
 // 2 rows + non-temporal loads 0.68, 4 rows 0.67. (A pure copy gains from short-lived workgroups in address
@@ -78,9 +78,17 @@ __global__ __launch_bounds__(256) void limit_filter_kernel(const LFParams prm) {
     typedef T VecT __attribute__((ext_vector_type(V)));
     int pi = 0;
     const int b = blockIdx.x;
-#pragma unroll 1
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
+
+    {  // block0 ascends: eight scalar steps for 192 planes (the linear scan was part of every workgroup's fixed cost)
+        int hi = prm.nplanes - 1;
+        while (pi < hi) {
+            const int mid = (pi + hi + 1) >> 1;
+            if (b >= prm.p[mid].block0)
+                pi = mid;
+            else
+                hi = mid - 1;
+        }
+    }
     const LFPlane pl = prm.p[pi];
     const int y0 = (b - pl.block0) * kRowsPerBlockLF;
     const T *flt = static_cast<const T *>(pl.flt), *src = static_cast<const T *>(pl.src), *ref = static_cast<const T *>(pl.ref);

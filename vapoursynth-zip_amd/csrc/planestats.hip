@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxPlanesPS = 48;
+constexpr int kMaxPlanesPS = 192;  // planes per launch (the per-plane table travels in the kernel argument: 7.7 KB): 64 YUV frames are ONE launch (round 4; 48 before)
 constexpr int kHistWords = 4096, kBucketWords = 16;
 [[maybe_unused]] constexpr int kSampleStep = 16;  // thresholded PlaneMinMax: table sizes; every 16th row is sampled
 
@@ -128,11 +128,16 @@ __device__ __forceinline__ void row_apply(const T *s, const T *r, int w, F &&fn)
     for (int x = x0 + (int)threadIdx.x; x < w; x += kThreads) fn(s[x], REF ? r[x] : s[x]);
 }
 
-__device__ __forceinline__ int find_plane(const PSParams &prm, int b) {
-    int pi = 0;
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
-    return pi;
+__device__ __forceinline__ int find_plane(const PSParams &prm, int b) {  // (block0 ascends: eight scalar steps for 192 planes)
+    int lo = 0, hi = prm.nplanes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b >= prm.p[mid].block0)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
 }
 
 // ---- PlaneAverage ---------------------------------------------------------------

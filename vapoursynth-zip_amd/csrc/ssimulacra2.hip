@@ -922,8 +922,8 @@ __global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
 //     instead of 12 x 16-byte once: LDS has the room, the generic kernel's array is at 0.38);
 //   * the E set loads and blurs the two means only; the S set skips edgeMap's division and its four f64 sums.
 // Every output accumulates its nine taps in tap order with the same fused (vertical, :318) / unfused (horizontal, :276) operations, so the f32 maps and
-// therefore the f64 sums are those of the generic kernel (tests/test_gpu_ssimulacra2.py::test_maps_term_set_kernels_match_the_generic_one: partial sums
-// equal to the last bit).
+// therefore every per-pixel f64 term are those of the generic kernel; the sums differ in their ORDER only (a block's four tiles in one set of
+// per-thread sums, below): tests/test_gpu_ssimulacra2.py::test_maps_term_set_kernels_match_the_generic_one holds the scores to 1e-11.
 template <bool SSIM, bool EDGE>
 __device__ __forceinline__ void ssim_maps_tile_ts(float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
     const int tid = threadIdx.x;
@@ -1023,9 +1023,12 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
     const int tx0 = bx * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
     float v1[kMapsNS], v2[kMapsNS];
     bool fetched = false;
+    // The block's tiles accumulate into ONE set of per-thread sums, reduced once (fixed order: lanes, then the four waves): a quarter of the wave
+    // reductions (72 ds_bpermute + 36 f64 adds each) and of the barriers of a reduction per tile. The block's sum goes into the slot of its first
+    // tile, the other tiles' slots hold exact zeros (the final kernel folds every slot).
+    double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int tx = tx0; tx < tx1; ++tx) {
         const int x0 = tx * TW;
-        double acc[6] = {0, 0, 0, 0, 0, 0};
         if (is_interior(x0)) {
             if (!fetched) ssim_maps_fetch(a, im1, im2, x0, y0, v1, v2);
             ssim_maps_park(v1, v2, s1, s2);
@@ -1037,21 +1040,22 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
             fetched = false;
             ssim_maps_tile<false>(a, im1, im2, SSIM, EDGE, x0, y0, s1, s2, vt, acc);
         }
-        // (the sums a term set does not have stay exact zeros: the final kernel reads all six)
+        __syncthreads();  // s1 / s2 / vt are rewritten by the next tile
+    }
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
-            if ((q < 2 && SSIM) || (q >= 2 && EDGE)) acc[q] = wave_reduce_sum(acc[q]);
-        if ((tid & 63) == 0) {
+    for (int q = 0; q < 6; ++q)
+        if ((q < 2 && SSIM) || (q >= 2 && EDGE)) acc[q] = wave_reduce_sum(acc[q]);
+    if ((tid & 63) == 0) {
 #pragma unroll
-            for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
-        }
-        __syncthreads();
-        if (tid < 6) {
-            const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
+    }
+    __syncthreads();
+    if (tid < 6) {
+        const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        for (int tx = tx0; tx < tx1; ++tx) {
             const int tile = by * a.tiles_x + tx;
-            a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
+            a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = tx == tx0 ? v : 0.0;
         }
-        __syncthreads();
     }
 }
 
@@ -1609,7 +1613,10 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         ma.partial = partial + (size_t)p0 * 18 * tiles0 * 6;
         ma.max_tiles = tiles0;
         if (ma.nactive > 0) {
-            ma.tpb = ma.tiles_x >= 32 ? 4 : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
+#ifndef VSZIP_SSIM_TPB
+#define VSZIP_SSIM_TPB 4
+#endif
+            ma.tpb = ma.tiles_x >= 32 ? VSZIP_SSIM_TPB : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
             const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * cnt);
             // one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>), or the one generic kernel (VSZIP_SSIM_GENERIC_MAPS=1)
             auto launch_maps = [&]() {
