@@ -1522,6 +1522,7 @@ def main() -> int:
             out["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K)
 
     if rank == 0:
+        out["config"]["timed_calls"] = getattr(timed, "calls", 0)  # calls of the workload's step in this process (tools/summarize_prof.py: launches per call)
         emit_line(out, json_out, detail_path_default())
         try:  # gpurun merges gpurun_out/ back: keep a copy of the full record there
             if (ROOT / "gpurun_out").is_dir():

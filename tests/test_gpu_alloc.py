@@ -1,10 +1,13 @@
 """vszip_dev_alloc / vszip_dev_alloc_probed (include/vszip_hip.h): placed and placement-probed device allocations, context options."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# the device's free memory moves under a test's feet when other xdist workers share the GPU: those assertions hold for a serial run (the driver's)
+ALONE = "PYTEST_XDIST_WORKER" not in os.environ
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +36,8 @@ def test_probe_sees_every_candidate_and_the_cheapest_is_kept(dev):
     assert len(seen) == 7 and len(set(seen)) == 7  # seven distinct allocations, all alive at once
     assert all_costs == [5.0, 3.0, 9.0, 1.5, 7.0, 1.5, 8.0] and best == 1.5 and ptr == seen[3]  # the first of equal costs
     held = free0 - torch.cuda.mem_get_info(0)[0]
-    assert nbytes <= held < 2 * nbytes  # the six losers are back with the device
+    if ALONE:
+        assert nbytes <= held < 2 * nbytes  # the six losers are back with the device
     # the winner is ordinary device memory
     a = np.arange(1 << 20, dtype=np.uint16).reshape(1024, 1024)
     dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, ptr, 2048, a.ctypes.data, 2048, 2048, 1024))
@@ -42,7 +46,8 @@ def test_probe_sees_every_candidate_and_the_cheapest_is_kept(dev):
     dev.sync()
     assert np.array_equal(a, b)
     dev.check(dev.lib.vszip_dev_free(dev.ctx, ptr))
-    assert free0 - torch.cuda.mem_get_info(0)[0] < (8 << 20)
+    if ALONE:
+        assert free0 - torch.cuda.mem_get_info(0)[0] < (8 << 20)
 
 
 def test_plain_allocation_without_a_probe(dev):
@@ -108,7 +113,8 @@ def test_freed_regions_are_parked_reused_and_trimmed(pdev):
     pdev.check(pdev.lib.vszip_dev_free(pdev.ctx, a))
     info = pdev.placement_info()
     assert info["parked_regions"] >= 1 and info["parked_bytes"] >= 256 << 20  # parked, not freed
-    assert free0 - torch.cuda.mem_get_info(0)[0] >= 256 << 20
+    if ALONE:
+        assert free0 - torch.cuda.mem_get_info(0)[0] >= 256 << 20
     b = _alloc(pdev, 250 << 20)  # the same granule: the parked region serves it when it is of the fast class, else it competes in a new walk
     after = pdev.placement_info()
     assert after["walks"] in (walks, walks + 1)
@@ -118,7 +124,8 @@ def test_freed_regions_are_parked_reused_and_trimmed(pdev):
     assert pdev.trim() >= 256 << 20
     assert pdev.placement_info()["parked_regions"] == 0
     pdev.sync()
-    assert free0 - torch.cuda.mem_get_info(0)[0] < (64 << 20)
+    if ALONE:
+        assert free0 - torch.cuda.mem_get_info(0)[0] < (64 << 20)
 
 
 def test_parked_memory_is_bounded_and_returns_when_an_allocation_needs_it(pdev):

@@ -65,12 +65,36 @@ def main():
 
                     lines.append(ast.literal_eval(line))  # tools/prof_legs.py printed dict reprs before it printed JSON
         bench = lines[-1] if len(lines) == 1 else (lines or None)
-    json.dump({"source": str(src), "bench_line_under_tracing": bench, "kernels": pmc}, open(f"{dst}_pmc.json", "w"), indent=1)
+    # HBM traffic per unit of work: sum over kernels of (traffic per launch x launches per call) / units per call. Launches per
+    # call = the trace's Calls / the line's config.timed_calls (--workload runs of bench.py: one workload per process).
+    per_unit = None
+    if isinstance(bench, dict) and bench.get("config", {}).get("timed_calls") and not bench.get("others"):
+        cfg = bench["config"]
+        calls = cfg["timed_calls"]
+        units = cfg.get("pairs_per_step_per_gpu") or cfg.get("frames_per_step_per_gpu")
+        unit_name = "pair" if cfg.get("pairs_per_step_per_gpu") else "frame"
+        if units:
+            tot, parts = 0.0, {}
+            for r in rows:
+                k = short(r["Name"])
+                m = pmc.get(k)
+                if m and "hbm_traffic_bytes_per_launch" in m:
+                    b = m["hbm_traffic_bytes_per_launch"] * int(r["Calls"]) / calls / units
+                    parts[k] = b
+                    tot += b
+            per_unit = {f"hbm_traffic_bytes_per_{unit_name}": tot, "by_kernel": parts, "timed_calls": calls, f"{unit_name}s_per_call": units}
+    json.dump({"source": str(src), "bench_line_under_tracing": bench, "hbm_traffic_per_unit": per_unit, "kernels": pmc}, open(f"{dst}_pmc.json", "w"), indent=1)
     with open(f"{dst}.md", "w") as o:
         o.write(f"# {dst.name}: rocprofv3 summary\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu ...` or `... tools/prof_legs.py <legs>` (tools/prof_all.sh), PMC in separate passes.\n\n")
         o.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
         for r in rows:
             o.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |\n")
+        if per_unit:
+            key = [k for k in per_unit if k.startswith("hbm_traffic_bytes_per_")][0]
+            o.write(f"\n## HBM traffic per {key.rsplit('_', 1)[1]} (FETCH_SIZE x 2 + WRITE_SIZE per launch x launches per call / units per call)\n\n")
+            o.write(f"**{per_unit[key] / 1e6:,.1f} MB** ({per_unit['timed_calls']} calls traced)\n\n")
+            for k, b in sorted(per_unit["by_kernel"].items(), key=lambda kv: -kv[1]):
+                o.write(f"- `{k}`: {b / 1e6:,.1f} MB\n")
         o.write("\n## PMC (mean per dispatch)\n\n")
         for k, m in pmc.items():
             o.write(f"### `{k}`\n\n")

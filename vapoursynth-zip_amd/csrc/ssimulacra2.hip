@@ -1613,10 +1613,21 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         ma.partial = partial + (size_t)p0 * 18 * tiles0 * 6;
         ma.max_tiles = tiles0;
         if (ma.nactive > 0) {
-#ifndef VSZIP_SSIM_TPB
-#define VSZIP_SSIM_TPB 4
+            // tiles (along x) per block: small scales keep one (enough blocks to fill the chip); the large ones walk 4 with the next tile's inputs in flight,
+            // and 6 or 12 while that still leaves 4 096 blocks (one reduction and one set of partials per block: 4K, 16 pairs per call, interleaved A/B:
+            // 2 / 4 / 6 / 8 / 12 tiles 5.56 / 6.14 / 6.28 / 5.45 / 6.34 k pairs/s — eight loses for a reason not found, gpurun_out r4_ssim_tpb)
+#ifdef VSZIP_SSIM_TPB
+            ma.tpb = ma.tiles_x >= 32 ? VSZIP_SSIM_TPB : 1;
+#else
+            ma.tpb = 1;
+            if (ma.tiles_x >= 32) {
+                ma.tpb = 4;
+                for (int t : {6, 12}) {
+                    const long nb = (long)((ma.tiles_x + t - 1) / t) * ma.tiles_y * ma.nactive * cnt;
+                    if (nb >= 4096) ma.tpb = t;
+                }
+            }
 #endif
-            ma.tpb = ma.tiles_x >= 32 ? VSZIP_SSIM_TPB : 1;  // small scales keep one tile per block (enough blocks to fill the chip)
             const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * cnt);
             // one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>), or the one generic kernel (VSZIP_SSIM_GENERIC_MAPS=1)
             auto launch_maps = [&]() {
