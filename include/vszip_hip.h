@@ -75,9 +75,11 @@ int vszip_abi_version(void);
  * nothing user space can see or request predicts it (profiles/r03_placement.md). The allocator walks candidate
  * allocations of the requested size (all held meanwhile, so each lies elsewhere), classifies each with a 2 ms copy in the ring
  * kernel's access shape, returns the fastest, keeps up to VSZIP_PLACEMENT_PARK_GIB (24) of further fast regions PARKED for the
- * requests that follow and frees the rest. The walk stops at the first fast region, holds at most VSZIP_PLACEMENT_WALK_GIB (64)
- * meanwhile, gives up after VSZIP_PLACEMENT_WALK_MS (2000: memory the device has not handed out before is cleared on first use,
- * about 50-90 ms per GiB) and ends early when the device is full; a walk that meets no fast region is the context's last. vszip_dev_free parks a placed region again;
+ * requests that follow and frees the rest. The walk stops at the first region of the best class (probe >= 5.55 TB/s; one of the middle class, >= 5.2 TB/s, is kept while
+ * eight more candidates are looked at), holds at most VSZIP_PLACEMENT_WALK_GIB (64)
+ * meanwhile, gives up after VSZIP_PLACEMENT_WALK_MS (3000: memory the device has not handed out before is cleared on first use,
+ * about 50-90 ms per GiB) and ends early when the device is full; a walk that meets no region worth keeping is the context's
+ * last (one that the clock cut short may be continued by the next request, up to 32 slow candidates in all). vszip_dev_free parks a placed region again;
  * parked memory returns to the driver when any allocation of the library would otherwise fail, in vszip_dev_trim and in
  * vszip_ctx_destroy. VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc / hipFree. */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);

@@ -77,6 +77,8 @@ def main():
             tot, parts = 0.0, {}
             for r in rows:
                 k = short(r["Name"])
+                if "placement_probe_kernel" in k or "__amd_rocclr" in k:  # the allocator's classification copy, the runtime's copies: not the workload
+                    continue
                 m = pmc.get(k)
                 if m and "hbm_traffic_bytes_per_launch" in m:
                     b = m["hbm_traffic_bytes_per_launch"] * int(r["Calls"]) / calls / units

@@ -287,7 +287,10 @@ __global__ __launch_bounds__(64) void placement_probe_kernel(char *base, const c
 }
 
 constexpr size_t kProbeSpan = (size_t)2 << 30;  // at most this much of a region is probed (its first 2 GiB)
-constexpr double kFastBytesPerSec = 5.3e12;      // placement_probe_kernel: fast regions move 5.5-5.85 TB/s, slow ones 4.6-4.85 (gpurun_out/r4_pool_probe.txt)
+// placement_probe_kernel's rate sorts regions into three classes on the devices seen (profiles/r04_placement_probe_calibration.txt, gpurun_out/r4_pool_probe*.txt):
+// 5.55-5.9 TB/s <-> the real launch at 568-585 us with its destination there (0.68-0.70), 5.2-5.35 TB/s <-> 594-608 us (0.65-0.67), 4.6-5.1 TB/s <-> 630-695 us.
+constexpr double kFastBytesPerSec = 5.2e12;      // good enough to keep
+constexpr double kBestBytesPerSec = 5.55e12;     // ends a walk at once
 constexpr size_t kPlacedGranule = (size_t)64 << 20;  // placed requests are rounded up to this: arenas of nearly equal size share parked regions
 
 // seconds per byte moved by the probe on [ptr, ptr + bytes); < 0: could not measure
@@ -392,6 +395,9 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         cand.push_back(ctx->parked[pick]);
         ctx->parked.erase(ctx->parked.begin() + pick);
     }
+    const double best_cost = 1.0 / kBestBytesPerSec;
+    int since_good = -1;  // candidates probed since the first one of the middle class
+    bool cut_short = false;
     for (int k = 0; k < max_cand; ++k) {
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) {
@@ -401,9 +407,14 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         double c = probe_region(ctx, p, bytes);
         if (c < 0) c = 1.0;  // unmeasurable: last choice
         cand.push_back({p, bytes, c});
-        if (c <= fast_cost) break;
+        if (c <= best_cost) break;                           // the best class: done
+        if (c <= fast_cost && since_good < 0) since_good = 0;  // the middle class: good enough, but look at eight more for the best
+        if (since_good >= 0 && ++since_good > 8) break;
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-        if (ms > (double)std::max(1, ctx->opt.placement_walk_ms)) break;
+        if (ms > (double)std::max(1, ctx->opt.placement_walk_ms)) {
+            cut_short = true;
+            break;
+        }
     }
     if (cand.empty()) {
         void *p = nullptr;
@@ -417,7 +428,12 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     ctx->placement_walks += 1;
     ctx->placement_probed += (int)cand.size();
     ctx->placement_last_walk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    if (cand[0].cost > fast_cost) ctx->placement_exhausted = true;
+    // No region worth keeping: this context stops searching - unless the clock cut the walk short after a few candidates (memory that has to be
+    // cleared costs up to 170 ms a candidate), then the next large request may look further, up to 32 slow candidates in all.
+    if (cand[0].cost > fast_cost) {
+        ctx->placement_slow_seen += (int)cand.size();
+        if (!cut_short || ctx->placement_slow_seen >= 32) ctx->placement_exhausted = true;
+    }
     // the slow ones are freed FIRST (in one go, after the walk), then the fast ones are parked
     for (size_t i = 1; i < cand.size(); ++i)
         if (cand[i].cost > fast_cost) (void)hipFree(cand[i].ptr);
