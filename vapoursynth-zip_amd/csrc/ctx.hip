@@ -366,8 +366,8 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         const auto &r = ctx->parked[i];
         if (r.bytes >= bytes && r.bytes / 2 <= bytes && (pick < 0 || r.cost < ctx->parked[pick].cost)) pick = (int)i;
     }
-    const double fast_cost = 1.0 / kFastBytesPerSec;
-    if (pick >= 0 && ctx->parked[pick].cost <= fast_cost) {
+    const double fast_cost = 1.0 / kFastBytesPerSec, best_cost = 1.0 / kBestBytesPerSec;
+    if (pick >= 0 && (ctx->parked[pick].cost <= best_cost || (ctx->placement_exhausted && ctx->parked[pick].cost <= fast_cost))) {
         ctx->placed.push_back(ctx->parked[pick]);
         *dptr = ctx->parked[pick].ptr;
         ctx->parked.erase(ctx->parked.begin() + pick);
@@ -391,12 +391,12 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     const int max_cand = (int)std::min<size_t>(64, std::max<size_t>(1, budget / bytes));
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<vszip_ctx::Region> cand;
-    if (pick >= 0) {  // a parked region of the slow class competes with what the walk finds
+    int since_good = -1;  // candidates probed since the first one of the middle class
+    if (pick >= 0) {  // a parked region of the middle or the slow class competes with what the walk finds
         cand.push_back(ctx->parked[pick]);
+        if (ctx->parked[pick].cost <= fast_cost) since_good = 0;
         ctx->parked.erase(ctx->parked.begin() + pick);
     }
-    const double best_cost = 1.0 / kBestBytesPerSec;
-    int since_good = -1;  // candidates probed since the first one of the middle class
     bool cut_short = false;
     for (int k = 0; k < max_cand; ++k) {
         void *p = nullptr;

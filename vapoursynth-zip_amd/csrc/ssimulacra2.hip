@@ -960,8 +960,24 @@ __device__ __forceinline__ void ssim_maps_tile_ts(float (*s1)[IW + 1], float (*s
             }
         }
     }
-    __syncthreads();
     constexpr int HC = 4;
+    // the centre samples edgeMap needs, read BEFORE the barrier: after it nobody reads s1 / s2 any more, so the next tile may be parked into them
+    // without a barrier at the end of this one (vt is protected by the barrier that follows the park)
+    float e1[HC], e2[HC];
+#ifdef VSZIP_SSIM_NO_PREREAD  // (A/B only: the centre samples after the barrier, a barrier at the end of every tile)
+    constexpr bool kPre = false;
+#else
+    constexpr bool kPre = true;
+#endif
+    if constexpr (EDGE && kPre) {
+        const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
+#pragma unroll
+        for (int o = 0; o < HC; ++o) {
+            e1[o] = s1[r + HALO][xs + o + HALO];
+            e2[o] = s2[r + HALO][xs + o + HALO];
+        }
+    }
+    __syncthreads();
     {
         const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
         v2f mu[HC], bs[HC];
@@ -994,12 +1010,15 @@ __device__ __forceinline__ void ssim_maps_tile_ts(float (*s1)[IW + 1], float (*s
         }
 #pragma unroll
         for (int o = 0; o < HC; ++o)
-            maps_pixel(mu[o].x, mu[o].y, bs[o].x, bs[o].y, EDGE ? s1[r + HALO][xs + o + HALO] : 0.0f, EDGE ? s2[r + HALO][xs + o + HALO] : 0.0f, SSIM, EDGE, acc);
+            maps_pixel(mu[o].x, mu[o].y, bs[o].x, bs[o].y, EDGE ? (kPre ? e1[o] : s1[r + HALO][xs + o + HALO]) : 0.0f, EDGE ? (kPre ? e2[o] : s2[r + HALO][xs + o + HALO]) : 0.0f, SSIM, EDGE, acc);
     }
 }
 
+// Waves per SIMD the instances are compiled for. 3: 136-138 VGPRs, no spills. 4 (128 VGPRs, 5-10 dwords spilled) was 7 % faster than 3 while a tile still
+// ended in a six-sum wave reduction and two more barriers (5.65 k against 5.30 k pairs/s); with one reduction per block and no barrier at a tile's end the
+// spills cost more than the fourth wave buys: 6.50-6.57 k at three waves against 6.24-6.46 k at four (interleaved A/B, profiles/r04_ssim_ab.txt).
 #ifndef VSZIP_SSIM_TS_WPE
-#define VSZIP_SSIM_TS_WPE 4
+#define VSZIP_SSIM_TS_WPE 3
 #endif
 template <bool SSIM, bool EDGE>
 __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(const MapsArgs a) {
@@ -1036,11 +1055,17 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
             fetched = tx + 1 < tx1 && is_interior(x0 + TW);
             if (fetched) ssim_maps_fetch(a, im1, im2, x0 + TW, y0, v1, v2);
             ssim_maps_tile_ts<SSIM, EDGE>(s1, s2, vt, acc);
+            // (no barrier here: see the centre samples in ssim_maps_tile_ts; a boundary tile that follows stages with a barrier of its own first)
+#ifdef VSZIP_SSIM_NO_PREREAD
+            __syncthreads();
+#else
+            if (tx + 1 < tx1 && !is_interior(x0 + TW)) __syncthreads();
+#endif
         } else {
             fetched = false;
             ssim_maps_tile<false>(a, im1, im2, SSIM, EDGE, x0, y0, s1, s2, vt, acc);
+            __syncthreads();  // the generic tile reads s1 / s2 / vt in its last phase: they are rewritten by the next tile
         }
-        __syncthreads();  // s1 / s2 / vt are rewritten by the next tile
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q)
