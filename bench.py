@@ -1325,7 +1325,7 @@ def main() -> int:
         # probe gets — libvszip.so's slabs are not probed: its BoxBlur is PCIe-bound long before this matters).
         pl_info = keep[2]
         out["config"]["placement_tries"] = pl_info["tries"]
-        out["config"]["placement_policy"] = ("vszip_dev_alloc (the library places requests of 512 MiB and more: include/vszip_hip.h)" if pl_info["tries"] <= 1
+        out["config"]["placement_policy"] = ("vszip_dev_alloc (the library places requests of 256 MiB and more: include/vszip_hip.h)" if pl_info["tries"] <= 1
                                              else f"best of 3 x {pl_info['tries']} probed arenas")
         try:  # what the allocator did for the two arenas of the headline batch
             pi_s, pi_d = dev.placement_info(keep[0].ptr), dev.placement_info(keep[1].ptr)

@@ -70,7 +70,7 @@ const char *vszip_last_error(vszip_ctx *ctx);
 int vszip_abi_version(void);
 
 /* ---- device memory + staging (replaces nothing: the reference is host-only) */
-/* vszip_dev_alloc. Requests of VSZIP_PLACEMENT_MIN_MIB (512) or more are PLACED: kernels with hundreds of concurrent row
+/* vszip_dev_alloc. Requests of VSZIP_PLACEMENT_MIN_MIB (256) or more are PLACED: kernels with hundreds of concurrent row
  * streams (the BoxBlur ring kernels) run 15-20 % faster or slower depending on which physical memory holds a resident batch, and
  * nothing user space can see or request predicts it (profiles/r03_placement.md). The allocator walks candidate
  * allocations of the requested size (all held meanwhile, so each lies elsewhere), classifies each with a 2 ms copy in the ring

@@ -166,7 +166,7 @@ Gpu *gpu_for_frame(int n, const FrameGate &gate) {
             return nullptr;
         }
         // The plugin's frames come over the host link: where a slab lies in VRAM is two orders of magnitude below what bounds it, and the
-        // allocator's placement walk (up to 2 s and 64 GiB held, per context, for slabs of 512 MiB and more: 8K RGBS frames) would cost twelve
+        // allocator's placement walk (up to 2 s and 64 GiB held, per context, for slabs of 256 MiB and more: 8K RGBS frames) would cost twelve
         // contexts a GPU their first frames — measured: the fused 8K pipeline 70 -> 9 fps with it. Plain allocations here.
         (void)vszip_ctx_set_option(g->ctx, "VSZIP_PLACEMENT", 0);
     }
