@@ -337,22 +337,38 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     // registers (each lane its own direction's 64 bytes), a step is v_readlane of the word that holds
     // column xl at lane mdis+fpath, a bit-field extract and a scalar add; the path goes to the
     // path to the lane of its column with a select. No LDS and no barrier in the chain.
+    // Round 4: software-pipelined. A block's step chain is serial (0.8 us of scalar work), but neither the NEXT block's codes nor this block's four
+    // output taps depend on anything but memory: the codes of block b - 1 are requested before block b is walked, and a block's taps are requested
+    // after its walk and consumed after the next block's — each round trip to memory (about 1 us, exposed twice per block before: a wave has 0.75
+    // neighbours on its SIMD to hide it behind) passes under a walk. profiles/r04_notes.md section 7.
     int carry = 0;  // fpath of the first column of the block to the right
+    uint32_t qn[kXB / 4];
+    auto load_codes = [&](int b, uint32_t *dstq) __attribute__((always_inline)) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pback + ((size_t)b * tpitch + min(lane, tpitch - 1)) * kXB);
+#pragma unroll
+        for (int i = 0; i < kXB / 16; ++i) {
+            const uint4 v = src[i];
+            dstq[4 * i] = v.x;
+            dstq[4 * i + 1] = v.y;
+            dstq[4 * i + 2] = v.z;
+            dstq[4 * i + 3] = v.w;
+        }
+    };
+    load_codes(nblk - 1, qn);
+    // the taps of the block walked before this one, in flight: (a, b) at +-dir of r1p / r1n, (c, d) at +-3 dir of r3p / r3n
+    float tpa = 0.f, tpb = 0.f, tpc = 0.f, tpd = 0.f;
+    int pxx = -1;
+    bool pcubic = false;
+    auto emit_prev = [&]() __attribute__((always_inline)) {
+        if (pxx >= 0) out[pxx] = pcubic ? 0.5625f * (tpa + tpb) - 0.0625f * (tpc + tpd) : (tpa + tpb) * 0.5f;
+    };
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int xb = blk * kXB;
         const int xe = min(kXB, w - xb);
         uint32_t q[kXB / 4];
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(pback + ((size_t)blk * tpitch + min(lane, tpitch - 1)) * kXB);
 #pragma unroll
-            for (int i = 0; i < kXB / 16; ++i) {
-                const uint4 v = src[i];
-                q[4 * i] = v.x;
-                q[4 * i + 1] = v.y;
-                q[4 * i + 2] = v.z;
-                q[4 * i + 3] = v.w;
-            }
-        }
+        for (int i = 0; i < kXB / 4; ++i) q[i] = qn[i];
+        if (blk > 0) load_codes(blk - 1, qn);
         int fp = __builtin_amdgcn_readfirstlane(carry);
         int fpv = 0;  // lane xl: fpath of column xb + xl
         auto walk = [&](auto full) {
@@ -375,18 +391,23 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         else
             walk(std::false_type{});
         carry = fp;
+        emit_prev();  // (the block to the right: its taps were requested a walk ago)
+        pxx = -1;
         if (lane < xe) {
             const int xx = xb + lane;
             const int dir = fpv, ad = abs(dir);
             dmap[xx] = dir;
-            float v;
-            if (xx >= ad * 3 && xx + ad * 3 <= w - 1)
-                v = 0.5625f * (rowv(r1p, xx + dir, w) + rowv(r1n, xx - dir, w)) - 0.0625f * (rowv(r3p, xx + dir * 3, w) + rowv(r3n, xx - dir * 3, w));
-            else
-                v = (rowv(r1p, xx + dir, w) + rowv(r1n, xx - dir, w)) * 0.5f;
-            out[xx] = v;
+            pxx = xx;
+            pcubic = xx >= ad * 3 && xx + ad * 3 <= w - 1;
+            tpa = rowv(r1p, xx + dir, w);
+            tpb = rowv(r1n, xx - dir, w);
+            if (pcubic) {
+                tpc = rowv(r3p, xx + dir * 3, w);
+                tpd = rowv(r3n, xx - dir * 3, w);
+            }
         }
     }
+    emit_prev();
 }
 
 // ---------------------------------------------------------------------------
