@@ -354,6 +354,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             dstq[4 * i + 3] = v.w;
         }
     };
+#ifdef VSZIP_E3_DIAG_NO_BACKTRACK  // (timing diagnostics only: no backtrack, no output)
+    if (nblk > 0) return;
+#endif
     load_codes(nblk - 1, qn);
     // the taps of the block walked before this one, in flight: (a, b) at +-dir of r1p / r1n, (c, d) at +-3 dir of r3p / r3n
     float tpa = 0.f, tpb = 0.f, tpc = 0.f, tpd = 0.f;
