@@ -221,7 +221,13 @@ class Timed:
         for _ in range(warmup):
             step()
         self.calls = getattr(self, "calls", 0) + ncalls + warmup + steps  # every call of `step` a profiler sees (tools/roofline_check.py)
+        # the closing barrier is inside the clock (contract): warm its path first (the first RCCL barriers of a process cost a millisecond each,
+        # which a 20-step region of 0.58 ms steps would carry as 8 %), and time one for the record (`config.barrier_ms`)
+        for _ in range(3):
+            self.barrier()
+        tb = time.perf_counter()
         self.barrier()
+        self.barrier_ms = (time.perf_counter() - tb) * 1e3
         self.dev.probe_enable(True)
         t0 = time.perf_counter()
         self.dev.timer_start()
@@ -1527,7 +1533,8 @@ def main() -> int:
             out["cpu_baseline"] = cpu_ssimulacra2(W4K, H4K)
 
     if rank == 0:
-        out["config"]["timed_calls"] = getattr(timed, "calls", 0) + UNTIMED_CALLS  # calls of the workload's step in this process (tools/summarize_prof.py: launches per call)
+        out["config"]["timed_calls"] = getattr(timed, "calls", 0) + UNTIMED_CALLS
+        out["config"]["barrier_ms"] = getattr(timed, "barrier_ms", None)  # one barrier (all ranks + device sync) as timed before the last timed region  # calls of the workload's step in this process (tools/summarize_prof.py: launches per call)
         emit_line(out, json_out, detail_path_default())
         try:  # gpurun merges gpurun_out/ back: keep a copy of the full record there
             if (ROOT / "gpurun_out").is_dir():
