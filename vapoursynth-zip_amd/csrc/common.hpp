@@ -83,6 +83,7 @@ struct vszip_ctx {
         double cost;  // probe seconds per byte moved; smaller is faster
     };
     std::vector<Region> parked, placed;
+    hipEvent_t probe_ev0 = nullptr, probe_ev1 = nullptr;  // the classification copy's own timing events
     int placement_walks = 0, placement_probed = 0, placement_slow_seen = 0;
     double placement_last_walk_ms = 0.0;
     bool placement_exhausted = false;  // a walk used its budget without finding a fast region: no further walks in this context

@@ -200,6 +200,8 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
     if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
     if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
+    if (ctx->probe_ev0) (void)hipEventDestroy(ctx->probe_ev0);
+    if (ctx->probe_ev1) (void)hipEventDestroy(ctx->probe_ev1);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (hipEvent_t e : ctx->probe_events) (void)hipEventDestroy(e);
@@ -304,12 +306,16 @@ double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from = 
     if (bands < 2) return -1.0;
     const dim3 grid(bands * 8);
     const char *fr = static_cast<const char *>(from);
+    if (!ctx->probe_ev0 && (hipEventCreate(&ctx->probe_ev0) != hipSuccess || hipEventCreate(&ctx->probe_ev1) != hipSuccess)) {  // (events of their own: a caller's vszip_timer_* pair may be open)
+        (void)hipGetLastError();
+        return -1.0;
+    }
     hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), fr, bands, band_rows);
-    if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) return -1.0;
+    if (hipEventRecord(ctx->probe_ev0, ctx->stream) != hipSuccess) return -1.0;
     const int n = 2;
     for (int i = 0; i < n; ++i) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(64), 0, ctx->stream, static_cast<char *>(ptr), fr, bands, band_rows);
     float ms = 0;
-    if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess || hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) {
+    if (hipEventRecord(ctx->probe_ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->probe_ev1) != hipSuccess || hipEventElapsedTime(&ms, ctx->probe_ev0, ctx->probe_ev1) != hipSuccess) {
         (void)hipGetLastError();
         return -1.0;
     }
