@@ -714,7 +714,10 @@ __device__ __forceinline__ void ssim_maps_fetch(const MapsArgs &a, const float *
     for (int k = 0; k < kMapsNS; ++k) {
         const int i = min(tid + 256 * k, IH * IW - 1);
         const int r = i / IW, c = i - r * IW;
-        const size_t o = (size_t)(y0 - HALO + r) * a.stride + (x0 - HALO + c);
+        // (tiles on the top / left edge: the blur's padding there is reflect-101, :254,357 - row / column -j is row / column j, whatever the output
+        // index, so the padded tile is a fixed function of the plane and the blocked path applies; the END of a line mirrors about the CURRENT output
+        // index, :260,364, which no padding expresses: those tiles keep the generic path)
+        const size_t o = (size_t)abs(y0 - HALO + r) * a.stride + abs(x0 - HALO + c);
         v1[k] = g1[o];
         v2[k] = g2[o];
     }
@@ -1038,7 +1041,9 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
     const int w = a.w, h = a.h;
     const int y0 = by * TH;
     const int tid = threadIdx.x;
-    auto is_interior = [&](int x0) { return x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h; };
+    // "interior" for the blocked path: clear of the bottom / right edge (and of the unfused column tail); top / left edge tiles are staged with
+    // their reflect-101 padding (ssim_maps_fetch) - 187 of a 4K plane's 375 edge tiles leave the generic path
+    auto is_interior = [&](int x0) { return x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h && w > HALO && h > HALO; };
     const int tx0 = bx * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
     float v1[kMapsNS], v2[kMapsNS];
     bool fetched = false;
