@@ -899,6 +899,9 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             }
         }
         if (ctx->opt.ring_periods > 0) target = ctx->opt.ring_periods;  // development sweep knob (-DVSZIP_DEV_VARIANTS)
+#ifdef VSZIP_RING_PERIODS_FIXED  // (tools/variant.sh sweeps: one translation unit, no option)
+        target = VSZIP_RING_PERIODS_FIXED;
+#endif
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         int blocks = 0, fit = n;
         for (int i = 0; i < n; ++i) {
