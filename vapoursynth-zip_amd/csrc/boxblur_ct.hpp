@@ -59,7 +59,10 @@ namespace {
 #ifndef VSZIP_ST8_AUX
 #define VSZIP_ST8_AUX 0
 #endif
-constexpr int kStoreAux = VSZIP_ST_AUX, kLoadAux = VSZIP_LD_AUX, kStoreAux8 = VSZIP_ST8_AUX;
+#ifndef VSZIP_ST16_AUX
+#define VSZIP_ST16_AUX 2
+#endif
+constexpr int kStoreAux = VSZIP_ST_AUX, kLoadAux = VSZIP_LD_AUX, kStoreAux8 = VSZIP_ST8_AUX, kStoreAux16 = VSZIP_ST16_AUX;  // (16: 8-bit planes, 16 pixels a lane)
 typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t U32x2 __attribute__((ext_vector_type(2)));
 
@@ -137,6 +140,25 @@ __device__ __forceinline__ void pack8(const uint32_t v[PX], Raw8<uint16_t> &r) {
 __device__ __forceinline__ void pack8(const uint32_t v[PX], Raw8<uint8_t> &r) {
     r.q.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
     r.q.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+}
+
+// The ring kernel's lane load: PXN pixels, packed. 8 pixels a lane for 16-bit planes (16 bytes) and for 8-bit planes of any width (8 bytes); 16 pixels a
+// lane for 8-bit planes whose widths are whole 16-pixel groups (round 4): a wave's row segment is then 960 bytes like a 16-bit plane's — with 480-byte
+// segments the 8-bit kernel's memory side alone took 425 us per 64-frame 4K launch whatever it computed (profiles/r04_notes.md section 3).
+template <typename T, int PXN>
+struct RawN : Raw8<T> {};
+template <>
+struct RawN<uint8_t, 16> {
+    uint4 q;
+};
+template <typename T>
+__device__ __forceinline__ void unpackN(const RawN<T, 8> &r, uint32_t v[8]) {
+    unpack8(static_cast<const Raw8<T> &>(r), v);
+}
+__device__ __forceinline__ void unpackN(const RawN<uint8_t, 16> &r, uint32_t v[16]) {
+    const uint32_t dw[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (dw[k >> 2] >> (8 * (k & 3))) & 0xffu;
 }
 
 // Edge-duplicating mirror of a virtual column (hBlurInt's implicit padding:
@@ -320,20 +342,20 @@ __global__ __launch_bounds__(64) void boxblur_ct_int_kernel(const BBParams prm) 
 // Ring kernel
 // ---------------------------------------------------------------------------
 
-template <int R, int SLOT_VGPRS = 4>
+template <int R, int SLOT_VGPRS = 4, int PXN = 8>
 struct RingGeom {
     static constexpr int K = 2 * R + 1;
-    static constexpr int HL = ((R + 1 + PX - 1) / PX) * PX;  // left halo  (>= R + 1)
-    static constexpr int HR = ((R + PX - 1) / PX) * PX;      // right halo (>= R)
-    static constexpr int OUT_LANES = 64 - HL / PX - HR / PX;
-    static constexpr int TWO = OUT_LANES * PX;
+    static constexpr int HL = ((R + 1 + PXN - 1) / PXN) * PXN;  // left halo  (>= R + 1)
+    static constexpr int HR = ((R + PXN - 1) / PXN) * PXN;      // right halo (>= R)
+    static constexpr int OUT_LANES = 64 - HL / PXN - HR / PXN;
+    static constexpr int TWO = OUT_LANES * PXN;
     // Rows prefetched ahead of their first use: D is odd so that NR is even (the LDS double
     // buffer alternates with the slot). The ring takes NR * SLOT_VGPRS registers, the rest of a
     // step about 56 (r=13 u16, D=1: 112 + 55 = 167 <= 168 -> 3 waves per SIMD out of the 512
     // VGPRs a SIMD lane has). A shallow prefetch (D = 1) is taken when it buys a wave per SIMD —
     // the other waves then hide the latency; otherwise D is 3, 5 or 7, whichever makes NR a
     // multiple of KL, the prefetch ring of the K_row column pixels (statically indexed, S % KL).
-    static constexpr int est_vgprs(int d) { return (2 * R + 1 + d) * SLOT_VGPRS + 56; }
+    static constexpr int est_vgprs(int d) { return (2 * R + 1 + d) * SLOT_VGPRS + (PXN == 16 ? 104 : 56); }
     static constexpr int tier(int v) { return v <= 128 ? 4 : (v <= 168 ? 3 : 2); }
     static constexpr int D3 = (2 * R + 4) % 3 == 0 ? 3 : ((2 * R + 6) % 3 == 0 ? 5 : 7);
 #ifdef VSZIP_RING_D
@@ -351,7 +373,7 @@ struct RingGeom {
     // 8-bit planes (2 VGPRs a slot) fit four waves per SIMD at every radius — and run 4-10 % faster with THREE (168 VGPRs, 3 072 waves per launch instead
     // of 4 096: r = 2 / 5 / 13 / 20 on 64 4K YUV420P8 frames 415 -> 387, 413 -> 384, 452 -> 412, 447 -> 440 us, interleaved A/B in one process,
     // gpurun_out/r4_u8_ab*.txt; two waves lose again: 451 / 486 us at r = 13 / 20). The prefetch depth does not matter (D = 1 ... 9: 452 ... 429 us at four waves).
-    static constexpr int WPE = SLOT_VGPRS == 2 ? (tier(est_vgprs(D)) > 3 ? 3 : tier(est_vgprs(D))) : tier(est_vgprs(D));
+    static constexpr int WPE = (SLOT_VGPRS == 2 && PXN == 8) ? (tier(est_vgprs(D)) > 3 ? 3 : tier(est_vgprs(D))) : tier(est_vgprs(D));
 #endif
     static_assert(NR % KL == 0, "K-column ring must divide the period");
     static constexpr uint32_t MAGIC = (uint32_t)(((1ull << 32) + K - 1) / K);  // ceil(2^32 / k): mulhi(n, MAGIC) == n / k
@@ -370,16 +392,18 @@ struct RingGeom {
 // real 8-pixel group, pixel order reversed in registers, so that the window sum is
 // the same compile-time-offset prefix difference everywhere. GENERAL = true takes
 // any width: plane edges are evaluated as prefix differences over real columns.
-template <typename T, int R, bool GENERAL>
+template <typename T, int R, bool GENERAL, int PXN = 8>
 struct RingWave {
-    using G = RingGeom<R, (int)(sizeof(T) * PX / 4)>;
-    using Vec = decltype(Raw8<T>{}.q);
+    static_assert(PXN == 8 || (PXN == 16 && sizeof(T) == 1 && !GENERAL), "16 pixels a lane: 8-bit planes, whole 16-pixel groups");
+    using G = RingGeom<R, (int)(sizeof(T) * PXN / 4), PXN>;
+    using RawT = RawN<T, PXN>;
+    using Vec = decltype(RawT{}.q);
     static constexpr int NR = G::NR;
     static constexpr uint64_t INV = ((1ull << 32) + R) / (uint64_t)G::K;
     static constexpr uint32_t INV2 = (uint32_t)(INV >> 16);
 
-    Raw8<T> ring[NR];
-    uint32_t col[PX];
+    RawT ring[NR];
+    uint32_t col[PXN];
     // K_row = 32768 + ((E_0 * invlo) >> 16) with E_0 = tmp[r] + 2*sum_{x<r} tmp[x] (hBlurInt's
     // start value, boxblur_comptime.zig:131-137) needs the vertical means of plane columns
     // 0..r only. Every wave keeps them itself: lane c < 32 slides the column sum of plane column
@@ -411,10 +435,10 @@ struct RingWave {
     uint32_t psel;   // v_perm selector: identity, or "reversed half of the mirror partner" (mirrored lanes)
     static constexpr uint32_t kOOB = 0xfffffff0u;
 
-    __device__ __forceinline__ Raw8<T> fetch_off(uint32_t row_off) const {
-        Raw8<T> t;
-        if constexpr (sizeof(T) == 2) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, coff, row_off, kLoadAux);
+    __device__ __forceinline__ RawT fetch_off(uint32_t row_off) const {
+        RawT t;
+        if constexpr (sizeof(T) * PXN == 16) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, coff, row_off, sizeof(T) == 2 ? kLoadAux : 0);
             t.q = make_uint4(v[0], v[1], v[2], v[3]);
         } else {
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, coff, row_off, 0);
@@ -449,9 +473,9 @@ struct RingWave {
     // Mirrored lanes hold the 8 pixels of their mirror image; put them in plane order
     // (reversed) once, when the row enters the window: one v_perm per dword with a
     // per-lane selector, identity for ordinary lanes.
-    __device__ __forceinline__ void fix_order(Raw8<T> &r) const {
+    __device__ __forceinline__ void fix_order(RawT &r) const {
         if constexpr (GENERAL) return;
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) * PXN == 16) {  // (16-bit x 8 and 8-bit x 16 alike: the selector reverses halves / bytes of the partner dword)
             const uint4 o = r.q;
             r.q.x = __builtin_amdgcn_perm(o.w, o.x, psel);
             r.q.y = __builtin_amdgcn_perm(o.z, o.y, psel);
@@ -479,11 +503,11 @@ struct RingWave {
     }
     template <int J>
     __device__ __forceinline__ void accum() {
-        uint32_t v[PX];
+        uint32_t v[PXN];
         fix_order(ring[J]);
-        unpack8(ring[J], v);
+        unpackN(ring[J], v);
 #pragma unroll
-        for (int k = 0; k < PX; ++k) col[k] += v[k];
+        for (int k = 0; k < PXN; ++k) col[k] += v[k];
     }
     // the D prefetched rows first: loads return in order, so by the time the window rows
     // have been summed the first steps of the band find their entering rows in place
@@ -500,29 +524,29 @@ struct RingWave {
     // i.e. [pixel-in-lane][lane]. For a fixed pixel index the 64 lanes touch 64
     // consecutive dwords, so every read and write is bank-conflict free (the natural
     // [lane][pixel] layout is an 8-way conflict: lane stride = 8 dwords over 32 banks).
-    static __device__ __forceinline__ int pidx(int c) { return (c & (PX - 1)) * 64 + (c >> 3); }
+    static __device__ __forceinline__ int pidx(int c) { return (c & (PXN - 1)) * 64 + c / PXN; }
 
     // Window sums E_x of one row from the prefix parked in LDS.
-    __device__ __forceinline__ void window_sums(const uint32_t *Pb, uint32_t e[PX]) const {
+    __device__ __forceinline__ void window_sums(const uint32_t *Pb, uint32_t e[PXN]) const {
         if constexpr (!GENERAL) {
 #pragma unroll
-            for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PXN; ++k) {
                 // compile-time offsets from the lane's own slot: (k+r) and (k-r-1) split
                 // into pixel-in-lane and lane displacement
                 const int hi = k + R, lo = k - R - 1;
-                const int hi_px = hi & (PX - 1), hi_ln = hi >> 3;
-                const int lo_px = lo & (PX - 1), lo_ln = (lo - lo_px) / PX;  // floor
+                const int hi_px = hi & (PXN - 1), hi_ln = hi / PXN;
+                const int lo_px = lo & (PXN - 1), lo_ln = (lo - lo_px) / PXN;  // floor
                 e[k] = Pb[hi_px * 64 + lane + hi_ln] - Pb[lo_px * 64 + lane + lo_ln];
             }
         } else {
             // Plane edges as prefix differences over real columns, Q(c) = sum_{j<=c} tmp[j], Q(-1) = 0:
             //   E_x = Q(min(x+r, w-1)) - Q(x-r-1) + Q(w-1) - Q(min(2w-2-x-r, w-1)) + Q(r-x-1)
             // (the mirrored terms cancel by themselves away from the edges).
-            const int off = lane * PX - c0;  // tile index of plane column c is c + off
-            auto lds = [&](int idx) { return Pb[pidx(min(max(idx, 0), 64 * PX - 1))]; };
+            const int off = lane * PXN - c0;  // tile index of plane column c is c + off
+            auto lds = [&](int idx) { return Pb[pidx(min(max(idx, 0), 64 * PXN - 1))]; };
             const uint32_t qw = lds(w - 1 + off);
 #pragma unroll
-            for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PXN; ++k) {
                 const int x = c0 + k;
                 const int lo = x - R - 1, ml = R - x - 1;
                 uint32_t v = lds(min(x + R, w - 1) + off) + qw - lds(min(2 * w - 2 - x - R, w - 1) + off);
@@ -536,13 +560,13 @@ struct RingWave {
     // dst[x] = (inv2*E_x + K_row) >> 16 (hBlurInt :130-159 in closed form). The 16.16
     // sum is the running mean + 0.5 and never exceeds 65535.5 * 65536, so it fits 32
     // bits: one 24-bit multiply-add per pixel, the result is the high half.
-    __device__ __forceinline__ void emit_row(const uint32_t e[PX], uint32_t row_off_bytes, uint32_t kr, bool live) const {
+    __device__ __forceinline__ void emit_row(const uint32_t e[PXN], uint32_t row_off_bytes, uint32_t kr, bool live) const {
         if constexpr (GENERAL) {
             if (!live || !is_out) return;
         }
-        uint32_t t[PX];
+        uint32_t t[PXN];
 #pragma unroll
-        for (int k = 0; k < PX; ++k) t[k] = __umul24(e[k], INV2) + kr;
+        for (int k = 0; k < PXN; ++k) t[k] = __umul24(e[k], INV2) + kr;
         if constexpr (!GENERAL) {
 #ifdef VSZIP_DIAG_NO_STORE  // (timing diagnostics only: one lane of the wave stores)
             const uint32_t vo = (live && lane == 8) ? sdoff : kOOB;
@@ -556,6 +580,20 @@ struct RingWave {
                 v.z = __builtin_amdgcn_perm(t[5], t[4], 0x07060302u);
                 v.w = __builtin_amdgcn_perm(t[7], t[6], 0x07060302u);
                 __builtin_amdgcn_raw_buffer_store_b128(v, rd, vo, row_off_bytes, kStoreAux);
+            } else if constexpr (PXN == 16) {
+                uint32_t dw[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t a0 = __builtin_amdgcn_perm(t[4 * g + 1], t[4 * g], 0x0c0c0602u);  // bytes: t0.2, t1.2, 0, 0
+                    const uint32_t a1 = __builtin_amdgcn_perm(t[4 * g + 3], t[4 * g + 2], 0x0c0c0602u);
+                    dw[g] = a0 | (a1 << 16);
+                }
+                U32x4 v;
+                v.x = dw[0];
+                v.y = dw[1];
+                v.z = dw[2];
+                v.w = dw[3];
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, vo, row_off_bytes, kStoreAux16);
             } else {
                 U32x2 v;
                 const uint32_t a0 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u);  // bytes: t0.2, t1.2, 0, 0
@@ -588,7 +626,7 @@ struct RingWave {
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < PX; ++k)
+                for (int k = 0; k < PXN; ++k)
                     if (c0 + k < w) q[k] = (T)(t[k] >> 16);
             }
         }
@@ -601,8 +639,8 @@ struct RingWave {
     // NR is even, so the buffer parity is a compile-time property of the slot.
     template <int S>
     __device__ __forceinline__ void step(int i, int y0) {
-        uint32_t *Pa = P + (S & 1) * (64 * PX);
-        const uint32_t *Pb = P + ((S & 1) ^ 1) * (64 * PX);
+        uint32_t *Pa = P + (S & 1) * (64 * PXN);
+        const uint32_t *Pb = P + ((S & 1) ^ 1) * (64 * PXN);
         // Steps are scheduled one at a time: without the fence the scheduler hoists the first
         // use of a prefetched row (fix_order) to just behind its load, and the s_waitcnt that
         // comes with it collapses the D-row prefetch distance to about one row.
@@ -610,14 +648,19 @@ struct RingWave {
 
         // B (first half): LDS reads of the previous row's prefix. The very first step of a
         // band has no previous row: it reads stale LDS and its store is switched off.
-        uint32_t e[PX];
+        uint32_t e[PXN];
         const bool have_prev = S > 0 || i > y0;
+#ifdef VSZIP_DIAG_NO_HORIZONTAL  // (timing diagnostics only: no prefix, no LDS, no window sums)
+#pragma unroll
+        for (int k = 0; k < PXN; ++k) e[k] = col[k];
+#else
         if (!GENERAL || have_prev) window_sums(Pb, e);
+#endif
 
         // A: vertical mean, rounded (:114-128; col carries the +r), wave-wide inclusive prefix
-        uint32_t p[PX];
+        uint32_t p[PXN];
 #pragma unroll
-        for (int k = 0; k < PX; ++k) {
+        for (int k = 0; k < PXN; ++k) {
             if constexpr (sizeof(T) == 1) {
                 // 8-bit samples: col <= 255 k + r < 2^14, so floor(col / k) == (col * ceil(2^19 / k)) >> 19 exactly
                 // (error term col * (M k - 2^19) < 2^19 since M k - 2^19 < k) and the product fits 32 bits: a
@@ -632,26 +675,31 @@ struct RingWave {
         if constexpr (GENERAL) {
             const uint32_t m = ld_ok ? 0xffffffffu : 0u;  // lanes outside the plane hold zeros
 #pragma unroll
-            for (int k = 0; k < PX; ++k) p[k] &= m;
+            for (int k = 0; k < PXN; ++k) p[k] &= m;
         }
+#ifdef VSZIP_DIAG_NO_HORIZONTAL
+        (void)Pa;
+        kr_prev += p[0] + p[7];
+#else
 #pragma unroll
-        for (int k = 1; k < PX; ++k) p[k] += p[k - 1];
-        const uint32_t incl = wave_incl_scan_dpp(p[PX - 1]);
-        const uint32_t base = incl - p[PX - 1];
+        for (int k = 1; k < PXN; ++k) p[k] += p[k - 1];
+        const uint32_t incl = wave_incl_scan_dpp(p[PXN - 1]);
+        const uint32_t base = incl - p[PXN - 1];
 #pragma unroll
-        for (int k = 0; k < PX; ++k) Pa[k * 64 + lane] = p[k] + base;
+        for (int k = 0; k < PXN; ++k) Pa[k * 64 + lane] = p[k] + base;
+#endif
 
         // slide the window to row i+1: entering row i+1+r (or row i once the window
         // hangs over the bottom edge, :61-66), leaving row i-r; refill the freed slot
         // with row i+1+r+D (|v| above the top edge, clamped below the bottom edge).
         {
             constexpr int E = (S + 1 + 2 * R) % NR;
-            uint32_t a[PX], sb[PX];
+            uint32_t a[PXN], sb[PXN];
             fix_order(ring[E]);
-            unpack8(ring[E], a);
-            unpack8(ring[S], sb);
+            unpackN(ring[E], a);
+            unpackN(ring[S], sb);
 #pragma unroll
-            for (int k = 0; k < PX; ++k) col[k] += a[k] - sb[k];
+            for (int k = 0; k < PXN; ++k) col[k] += a[k] - sb[k];
 #ifdef VSZIP_DIAG_NO_LOAD  // (timing diagnostics only: the ring keeps what the band's fill put there)
             if (next_off == 0xffffffffu) ring[S] = fetch_off(next_off);
 #else
@@ -688,7 +736,9 @@ struct RingWave {
             kn_off = row_off(i + 2 + R + G::KL);
             ko_off = row_off(i + 1 - R + G::KL);
         }
+#ifndef VSZIP_DIAG_NO_FENCE  // (timing diagnostics only: wrong results)
         wave_lds_fence();
+#endif
     }
 
     template <int... S>
@@ -697,12 +747,12 @@ struct RingWave {
     }
 };
 
-template <typename T, int R, bool GENERAL>
-__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX / 4)>::WPE)) void boxblur_ct_ring_kernel(const RingParams prm) {
-    using W = RingWave<T, R, GENERAL>;
+template <typename T, int R, bool GENERAL, int PXN = 8>
+__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PXN / 4), PXN>::WPE)) void boxblur_ct_ring_kernel(const RingParams prm) {
+    using W = RingWave<T, R, GENERAL, PXN>;
     using G = typename W::G;
     static_assert(G::NR % 2 == 0 && G::NR <= 64, "ring period must be even and fit a wave");
-    __shared__ __attribute__((aligned(16))) uint32_t P[2 * 64 * PX];
+    __shared__ __attribute__((aligned(16))) uint32_t P[2 * 64 * PXN];
 
     // XCD-aware remap: blocks b and b+8 share an XCD, so give every XCD one
     // contiguous chunk of the (plane, band, tile) list — neighbours share an L2.
@@ -732,32 +782,32 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     st.dstb = static_cast<char *>(pl.dst);
     const int lane = threadIdx.x;
     st.lane = lane;
-    const int vc0 = tx * G::TWO - G::HL + lane * PX;  // first (virtual) plane column of this lane
+    const int vc0 = tx * G::TWO - G::HL + lane * PXN;  // first (virtual) plane column of this lane
     st.c0 = vc0;
-    st.is_out = lane >= G::HL / PX && lane < G::HL / PX + G::OUT_LANES && vc0 < w;
+    st.is_out = lane >= G::HL / PXN && lane < G::HL / PXN + G::OUT_LANES && vc0 < w;
     st.doff = (uint32_t)(max(vc0, 0) * (int)sizeof(T));
-    st.out_full = vc0 + PX <= w;
+    st.out_full = vc0 + PXN <= w;
     if constexpr (!GENERAL) {
         // real 8-pixel group behind this lane: itself, or its edge-duplicating mirror image
         int g = vc0;
         st.rev = false;
         if (vc0 < 0) {
-            g = -vc0 - PX;
+            g = -vc0 - PXN;
             st.rev = true;
         } else if (vc0 >= w) {
-            g = 2 * w - vc0 - PX;
+            g = 2 * w - vc0 - PXN;
             st.rev = true;
         }
-        g = min(max(g, 0), w - PX);
+        g = min(max(g, 0), w - PXN);
         st.coff = (uint32_t)(g * (int)sizeof(T));
         st.ld_ok = true;
     } else {
         st.rev = false;
         st.ld_ok = vc0 >= 0 && vc0 < w;  // [w, stride) is readable padding
-        st.coff = (uint32_t)(min(max(vc0, 0), ((w - 1) / PX) * PX) * (int)sizeof(T));
+        st.coff = (uint32_t)(min(max(vc0, 0), ((w - 1) / PXN) * PXN) * (int)sizeof(T));
     }
 
-    st.psel = st.rev ? (sizeof(T) == 2 ? 0x05040706u : 0x04050607u) : 0x03020100u;
+    st.psel = st.rev ? (sizeof(T) == 2 ? 0x05040706u : 0x04050607u) : 0x03020100u;  // reversed: the partner dword's halves (16 bit) / bytes (8 bit) backwards
     st.sdoff = st.is_out ? st.doff : W::kOOB;
     // descriptors: raw (stride 0), 32-bit data format; num_records = plane bytes (ring_ok keeps it < 4 GiB)
     st.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pl.src), 0, (int)((uint32_t)pl.h * st.srow), 0x00020000);
@@ -766,7 +816,7 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
 
     st.fill_all(y0, std::make_integer_sequence<int, G::NR>{});
 #pragma unroll
-    for (int k = 0; k < PX; ++k) st.col[k] = R;  // the rounding term of (col + r) / k rides along
+    for (int k = 0; k < PXN; ++k) st.col[k] = R;  // the rounding term of (col + r) / k rides along
     st.accum_all(std::make_integer_sequence<int, (int)G::K>{});
     // K columns: window sum of rows y0-r .. y0+r at plane column min(lane, r), then the first KL
     // entering / leaving pixels
@@ -794,8 +844,8 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
 #pragma unroll 1
     for (int i0 = y0; i0 < y1; i0 += G::NR) st.period(i0, y0, std::make_integer_sequence<int, G::NR>{});
     {
-        uint32_t e[PX];  // last row of the band: slot NR-1 wrote the odd buffer
-        st.window_sums(P + 64 * PX, e);
+        uint32_t e[PXN];  // last row of the band: slot NR-1 wrote the odd buffer
+        st.window_sums(P + 64 * PXN, e);
         st.emit_row(e, st.out_off, st.kr_prev, true);
     }
 }
@@ -844,9 +894,9 @@ int launch_ct_int(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     return VSZIP_OK;
 }
 
-template <typename T, int R>
+template <typename T, int R, int PXN = 8>
 int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
-    using G = typename RingWave<T, R, false>::G;
+    using G = typename RingWave<T, R, false, PXN>::G;
     int done = 0;
     while (done < nplanes) {
         RingParams prm;
@@ -854,7 +904,7 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         bool mult8 = true;
         for (int i = 0; i < n; ++i) {
             const vszip_plane &s = planes[done + i];
-            mult8 = mult8 && (s.w % PX == 0);
+            mult8 = mult8 && (s.w % PXN == 0);
         }
         // Band length: every plane is cut into bands of about `target` ring periods. The choice
         // trades re-read halo rows (2r+D per band: shorter bands = more traffic) against how well
@@ -930,10 +980,14 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         const dim3 grid(((blocks + 7) / 8) * 8);
         {
             vszip_probe_scope probe(ctx);
-            if (mult8)
-                hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false>), grid, dim3(64), 0, ctx->stream, prm);
-            else
-                hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
+            if constexpr (PXN == 16) {  // (the caller checked: every width is whole 16-pixel groups)
+                hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false, 16>), grid, dim3(64), 0, ctx->stream, prm);
+            } else {
+                if (mult8)
+                    hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false>), grid, dim3(64), 0, ctx->stream, prm);
+                else
+                    hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
+            }
         }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
         done += fit;
@@ -957,6 +1011,23 @@ bool ring_ok(const vszip_plane *planes, int nplanes) {
     return true;
 }
 
+// 8-bit planes take 16 pixels a lane when every plane is whole 16-pixel groups on 16-byte aligned rows (every VapourSynth frame of an even-width-16
+// clip: 1920, 3840, 960 ... wide planes; a 1080p clip's 960-wide chroma as well)
+// Up to r = 19: beyond, the ring (2r + 1 + D slots of four VGPRs) leaves no room for two waves a SIMD and the instance spills
+// (64 4K YUV420P8 frames, 16 against 8 pixels a lane, tools/u8_px16_sweep.py: r = 1 ... 7 -10 ... -12 % of the time, 8 ... 16 -4 ... -8 %, 17 ... 19 -11 ... -13 %,
+// 20 ... 22 +12 ... +17 %)
+constexpr int kRing16MaxR = 19;
+template <typename T>
+bool ring16_ok(const vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
+    if (sizeof(T) != 1 || ctx->opt.ct_u8_px8) return false;
+    for (int i = 0; i < nplanes; ++i) {
+        const vszip_plane &p = planes[i];
+        if (p.w % 16 != 0 || p.w < 32) return false;
+        if ((reinterpret_cast<uintptr_t>(p.src) | reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.src_stride | (uintptr_t)p.dst_stride) & 15) return false;
+    }
+    return true;
+}
+
 // Development builds (-DVSZIP_DEV_R=13) instantiate a single radius to keep the
 // edit-compile-measure loop short; release builds carry all 22.
 #ifdef VSZIP_DEV_R
@@ -969,7 +1040,12 @@ template <typename T, int R, int RLO>
 struct CtIntDispatch {
     static int run(vszip_ctx *ctx, int r, const vszip_plane *planes, int nplanes) {
         if constexpr (VSZIP_R_ENABLED(R)) if (r == R) {
-            if (ctx->scan_mode == 0 && ring_ok<T>(planes, nplanes)) return launch_ct_ring<T, R>(ctx, planes, nplanes);
+            if (ctx->scan_mode == 0 && ring_ok<T>(planes, nplanes)) {
+                if constexpr (sizeof(T) == 1 && R <= kRing16MaxR) {
+                    if (ring16_ok<T>(ctx, planes, nplanes)) return launch_ct_ring<T, R, 16>(ctx, planes, nplanes);
+                }
+                return launch_ct_ring<T, R>(ctx, planes, nplanes);
+            }
             return launch_ct_int<T, R>(ctx, planes, nplanes);
         }
         if constexpr (R > RLO)
