@@ -376,3 +376,32 @@ def test_rt_integer_chain_in_bands(dev, oracle, dtype):
             assert np.array_equal(a, want), (dtype, shapes, args, "banded", int((a != want).sum()), np.argwhere(a != want)[:4].tolist())
             assert np.array_equal(b, want), (dtype, shapes, args, "whole columns")
             assert np.array_equal(c, want), (dtype, shapes, args, "per pass")
+
+
+@pytest.mark.parametrize("r", [1, 2, 5, 7, 8, 13, 15, 16, 19, 20, 22])
+def test_ct_u8_sixteen_pixels_a_lane(dev, oracle, r):
+    """Round 4: 8-bit planes whose widths are whole 16-pixel groups take the ring kernel with 16 pixels a lane (r <= 19; 960-byte row segments instead of 480).
+    Against the oracle and the 8-pixel instance (VSZIP_CT_U8_PX8=1), bit for bit: one-tile and multi-tile widths (992 output columns a wave), widths that end
+    inside the last wave's mirrored lanes, planes barely taller than a ring period, YUV 4:2:0 batches, a batch with one plane that is NOT whole groups
+    (everything falls back to 8 pixels), saturated rows."""
+    batches = [[(96, 32)], [(80, 48)], [(70, 992)], [(64, 1008)], [(61, 2000)], [(270, 1920), (135, 960), (135, 960)], [(59, 4096)], [(120, 64), (120, 72)]]
+    for shapes in batches:
+        if min(min(sh) for sh in shapes) <= 2 * r:  # (the filter refuses 2 r >= the smallest plane dimension)
+            continue
+        planes = [fx.splitmix64_plane(70 + i + r, sh, np.uint8) if i % 2 == 0 else fx.tiled_natural(sh, np.uint8, 1) for i, sh in enumerate(shapes)]
+        planes[0][5] = 255
+        planes[0][-1] = 0
+
+        def run():
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+            dev.boxblur(srcs, dsts, r, 1, r, 1)
+            return [dev.download(d) for d in dsts]
+
+        wide = run()
+        with dev.options(VSZIP_CT_U8_PX8=1):
+            narrow = run()
+        for p, a, b in zip(planes, wide, narrow):
+            want = oracle.boxblur(p, r, 1, r, 1)
+            assert np.array_equal(a, want), (r, shapes, p.shape, int((a != want).sum()), np.argwhere(a != want)[:4].tolist())
+            assert np.array_equal(b, want), (r, shapes, p.shape, "8 pixels a lane")
