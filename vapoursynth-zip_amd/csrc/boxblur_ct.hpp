@@ -347,7 +347,11 @@ struct RingGeom {
     static constexpr int K = 2 * R + 1;
     static constexpr int HL = ((R + 1 + PXN - 1) / PXN) * PXN;  // left halo  (>= R + 1)
     static constexpr int HR = ((R + PXN - 1) / PXN) * PXN;      // right halo (>= R)
+#ifdef VSZIP_RING_OUT_LANES  // (sweeps: fewer output lanes per wave, e.g. 56 = whole 128-byte lines per row segment)
+    static constexpr int OUT_LANES = VSZIP_RING_OUT_LANES < 64 - HL / PXN - HR / PXN ? VSZIP_RING_OUT_LANES : 64 - HL / PXN - HR / PXN;
+#else
     static constexpr int OUT_LANES = 64 - HL / PXN - HR / PXN;
+#endif
     static constexpr int TWO = OUT_LANES * PXN;
     // Rows prefetched ahead of their first use: D is odd so that NR is even (the LDS double
     // buffer alternates with the slot). The ring takes NR * SLOT_VGPRS registers, the rest of a

@@ -389,9 +389,10 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         if (vszip_hip_malloc(ctx, dptr, bytes) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
         return VSZIP_OK;
     }
-    // 2: walk. Everything stays allocated until the walk ends; it ends with the first region of the fast class, when the walk's
-    // budget (bytes held, wall time: memory the device has not handed out before is cleared on first use, ~50 ms per GiB) is
-    // used, or when the device is full. Slow regions freed here come back first in the next walk and cost 2.5 ms each then.
+    // 2: walk. Everything stays allocated until the walk ends; it ends with the first region of the best class (or eight candidates after the first
+    // of the middle class), when the walk's budget (bytes held, wall time: memory the device has not handed out before is cleared on first use,
+    // 50-170 ms per candidate of this size) is used, or when the device is full. Slow regions freed here come back first in the next walk and cost
+    // 2.5 ms each then.
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const size_t budget = (size_t)std::max(1, ctx->opt.placement_walk_gib) << 30;
     const int max_cand = (int)std::min<size_t>(64, std::max<size_t>(1, budget / bytes));
