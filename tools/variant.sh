@@ -8,7 +8,7 @@ python vapoursynth-zip_amd/build.py > /dev/null
 mkdir -p tools/ab /tmp/variant_$name
 B=vapoursynth-zip_amd/csrc/_build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-  $extra -c vapoursynth-zip_amd/csrc/$stem.hip -o /tmp/variant_$name/$stem.o
+  $(python -c "import sys; sys.path.insert(0, 'vapoursynth-zip_amd'); import build; print(' '.join(build.FILE_FLAGS.get('$stem', [])))") $extra -c vapoursynth-zip_amd/csrc/$stem.hip -o /tmp/variant_$name/$stem.o
 objs=$(ls $B/*.o | grep -v "/$stem.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/$name.so $objs /tmp/variant_$name/$stem.o
 echo tools/ab/$name.so

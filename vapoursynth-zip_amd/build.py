@@ -23,6 +23,9 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
 ]
+# per-source flags. eedi3: the SLP vectoriser pairs the line kernel's f32 adds into v_pk_add_f32, which on gfx950's 32-lane SIMDs saves no cycles,
+# and pays for the pairs with register copies (measured: +1.7 % with it off, profiles/r04_notes.md section 10)
+FILE_FLAGS = {"eedi3": ["-fno-slp-vectorize"]}
 
 
 def _stale(out: Path, deps) -> bool:
@@ -43,7 +46,8 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
         force = True
     # a change of flags (e.g. a development build before) invalidates every object
     stamp = OBJ / "flags.txt"
-    if not stamp.is_file() or stamp.read_text() != " ".join(flags):
+    stamp_text = " ".join(flags) + " | " + repr(sorted(FILE_FLAGS.items()))
+    if not stamp.is_file() or stamp.read_text() != stamp_text:
         force = True
     srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.cpp"))  # *.cpp: device-free host code (also built by tests/sanitize)
     hdrs = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list((PKG.parent / "include").glob("*.h"))
@@ -51,7 +55,7 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
     for s in srcs:
         o = OBJ / (s.stem + ".o")
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC, *flags, "-c", str(s), "-o", str(o)]
+            cmd = [HIPCC, *flags, *FILE_FLAGS.get(s.stem, []), "-c", str(s), "-o", str(o)]
             if keep_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append(cmd)
@@ -66,7 +70,7 @@ def build(force: bool = False, keep_temps: bool = False) -> Path:
         for warn in ex.map(run, jobs):
             if warn.strip():
                 sys.stderr.write(warn)
-    stamp.write_text(" ".join(flags))
+    stamp.write_text(stamp_text)
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

@@ -90,6 +90,26 @@ __device__ __forceinline__ float lane_above(float v, float edge) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));  // wave_shl:1
 }
 
+// wave shifts whose first / last lane reads 0 (bound_ctrl): foldable into the consuming VALU instruction
+__device__ __forceinline__ float lane_below0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));  // wave_shr:1
+}
+__device__ __forceinline__ float lane_above0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));  // wave_shl:1
+}
+template <int L>
+__device__ __forceinline__ int write_lane(int old, int s) {  // lane L of `old` := the (wave-uniform) s
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(s), "n"(L));
+    return old;
+}
+template <int B, int E, int S, class F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<B>), f(<B + S>) ... up to and including E
+    if constexpr (B <= E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + S, E, S>(f);
+    }
+}
+
 constexpr int kU = 4;  // directions per cost pass
 // NRAD is a template parameter so that the window-sum loop unrolls (with a runtime trip count
 // its LDS reads are issued one per iteration and each waits out the full LDS latency); MD is the
@@ -110,9 +130,16 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     constexpr int kTbW = 128 * NIT2 + 8;            // t_base / window-sum entries per direction
     const float kFltMax09 = FLT_MAX * 0.9f;
     __shared__ __attribute__((aligned(16))) float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
-    __shared__ __attribute__((aligned(16))) float tbws[2][kU][kTbW];  // t_base of the kU directions of the current pass, and their (2*nrad+1)-tap window sums
-    __shared__ float ctile[2 * MD + 1][kXB + 1];
-    float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[1];
+    // kRegWin (round 4, the default geometry): t_base never goes to LDS — see cost_pass_fixed below
+    constexpr bool kRegWin = FIXED && NIT2 == 1 && MD % kU == 0;
+    __shared__ __attribute__((aligned(16))) float tbws[kRegWin ? 1 : 2][kU][kTbW];  // the (2*nrad+1)-tap window sums of the kU directions of the current pass (and, without kRegWin, their t_base in front)
+#ifdef VSZIP_E3_CTILE65  // (sweeps: the round-3 tile, one 4-byte read per column in front of the Viterbi chain)
+    constexpr int kCtP = kXB + 1;
+#else
+    constexpr int kCtP = kXB + 4;  // 16-byte aligned rows: a direction's 64 costs come back as 16 ds_read_b128, free of bank conflicts at this pitch
+#endif
+    __shared__ __attribute__((aligned(16))) float ctile[2 * MD + 1][kCtP];
+    float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[kRegWin ? 0 : 1];
 
     int pi = 0;
     const int gl = prm.line_base + (int)blockIdx.x;
@@ -130,8 +157,8 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const float *r1p = pl.src + (size_t)src_col(dh, line - 1, pl.n_src) * pl.sstride;
     const float *r1n = pl.src + (size_t)src_col(dh, line + 1, pl.n_src) * pl.sstride;
     const float *r3n = pl.src + (size_t)src_col(dh, line + 3, pl.n_src) * pl.sstride;
-    // back-pointer codes of this line: [block][direction][64 columns], one byte each (0: stay, 1: from
-    // the direction below, 2: from the direction above); column 63 of a block is produced by the
+    // back-pointer codes of this line: [block][direction][64 columns], one byte each, the path's step as a signed
+    // two-bit number (0: stay, 3 = -1: from the direction below, 1: from the direction above); column 63 of a block is produced by the
     // first step of the next block
     uint8_t *pback = reinterpret_cast<uint8_t *>(pl.pback) + (size_t)off * ((w + kXB - 1) / kXB * kXB) * tpitch;
     float *out = pl.dst + (size_t)line * pl.dstride;
@@ -139,6 +166,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const int reach = 2 * mdis + nrad, roww = kXB + 2 * reach;
 
     float pcost = kFltMax09;  // DP state of direction `lane` (inactive lanes stay at the sentinel)
+    [[maybe_unused]] float dp_l = INFINITY, dp_r = INFINITY, dp_gamma = prm.gamma;  // see dp_step
     uint32_t held[kXB / 4];   // back-pointer codes of the previous block, waiting for their last column
 #pragma unroll
     for (int i = 0; i < kXB / 4; ++i) held[i] = 0;
@@ -249,10 +277,169 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             }
             wave_fence();  // tb / ws are rewritten by the next pass
         };
-#ifdef VSZIP_E3_DIAG_ONE_PASS  // (timing diagnostics only, tools/variant.sh: ONE of the eleven direction passes - wrong results)
-        cost_pass(0);
+        // Round 4, the default geometry (kRegWin): the cost phase is bound by the LDS pipeline (per pass ~240 LDS cycles a wave against ~300 VALU
+        // cycles, and four SIMDs share one LDS), so whatever a neighbouring LANE already holds comes through a DPP wave shift instead of LDS:
+        //  - a lane owns the t_base pair (2L, 2L+1); the 2*nrad+2 inputs of its two window sums are its own pair and the pairs of the nrad lanes
+        //    above, so t_base stays in registers (no store, no fence, no re-read; the sums keep the reference's k order);
+        //  - the directions of a pass differ by one lane in the shifted taps r1p/r1n/r3n[j - 2u]: one direction reads them (the smallest |u| end
+        //    that keeps the lanes that lose their neighbour outside the entries read back), the others shift them along.
+        // A pass is one sign of u (MD % kU == 0) and the last one holds the single direction +MD. profiles/r04_notes.md section 10.
+        auto stage_a = [&](auto ugc) __attribute__((always_inline)) {  // t_base and window sums of a pass -> ws
+            constexpr int ug = decltype(ugc)::value;
+            constexpr int nd = MD - ug + 1 < kU ? MD - ug + 1 : kU;  // directions of this pass
+            constexpr int jlo = (ug < 0 ? 2 * ug : 0) - NRAD;
+            constexpr int reachc = 2 * MD + NRAD;
+            const int t = 2 * lane;
+            const int j = jlo + t + reachc;  // rows[] index of column xb + jlo + t (even)
+            float2 b[nd], d[nd], f[nd];
+            // u < 0: direction i + 1 reads at lane L what direction i reads at lane L - 1, and needs its entries from 2 (i + 1) on only;
+            // u >= 0: direction i reads what direction i + 1 reads at lane L + 1, and nothing past entry 64 + 2 MD + 2 nrad (< 122) is read back
+            constexpr int ia = ug < 0 ? 0 : nd - 1;
+#ifdef VSZIP_E3_ASM_LDS  // (sweeps: the six 8-byte reads as six ds_read_b64 — the compiler pairs them into ds_read2_b64)
+            float2 a, c, e;
+            {
+                const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)&rows[0][j];
+                constexpr int sh = -2 * (ug + ia) * 4;
+                uint64_t qa, qc, qe, qb, qd, qf;
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qa) : "v"(base), "n"(0));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qc) : "v"(base), "n"(kRowW * 4));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qe) : "v"(base), "n"(2 * kRowW * 4));
+                const uint32_t bs = base + sh;
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb) : "v"(bs), "n"(kRowW * 4));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qd) : "v"(bs), "n"(2 * kRowW * 4));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qf) : "v"(bs), "n"(3 * kRowW * 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa), "+v"(qc), "+v"(qe), "+v"(qb), "+v"(qd), "+v"(qf));
+                auto f2 = [](uint64_t q) { return make_float2(__uint_as_float((uint32_t)q), __uint_as_float((uint32_t)(q >> 32))); };
+                a = f2(qa), c = f2(qc), e = f2(qe), b[ia] = f2(qb), d[ia] = f2(qd), f[ia] = f2(qf);
+            }
 #else
-        if constexpr (FIXED) {
+            const float2 a = *reinterpret_cast<const float2 *>(&rows[0][j]);
+            const float2 c = *reinterpret_cast<const float2 *>(&rows[1][j]);
+            const float2 e = *reinterpret_cast<const float2 *>(&rows[2][j]);
+            b[ia] = *reinterpret_cast<const float2 *>(&rows[1][j - 2 * (ug + ia)]);
+            d[ia] = *reinterpret_cast<const float2 *>(&rows[2][j - 2 * (ug + ia)]);
+            f[ia] = *reinterpret_cast<const float2 *>(&rows[3][j - 2 * (ug + ia)]);
+#endif
+#ifdef VSZIP_E3_TAPS_LDS  // (sweeps: every direction's shifted taps from LDS)
+#pragma unroll
+            for (int i = 0; i < nd; ++i) {
+                if (i == ia) continue;
+                b[i] = *reinterpret_cast<const float2 *>(&rows[1][j - 2 * (ug + i)]);
+                d[i] = *reinterpret_cast<const float2 *>(&rows[2][j - 2 * (ug + i)]);
+                f[i] = *reinterpret_cast<const float2 *>(&rows[3][j - 2 * (ug + i)]);
+            }
+            if constexpr (false) {
+#else
+            if constexpr (ug < 0) {
+#endif
+#pragma unroll
+                for (int i = 1; i < nd; ++i) {
+                    b[i] = make_float2(lane_below0(b[i - 1].x), lane_below0(b[i - 1].y));
+                    d[i] = make_float2(lane_below0(d[i - 1].x), lane_below0(d[i - 1].y));
+                    f[i] = make_float2(lane_below0(f[i - 1].x), lane_below0(f[i - 1].y));
+                }
+            } else
+#ifdef VSZIP_E3_TAPS_LDS
+                if constexpr (false)
+#endif
+            {
+#pragma unroll
+                for (int i = nd - 2; i >= 0; --i) {
+                    b[i] = make_float2(lane_above0(b[i + 1].x), lane_above0(b[i + 1].y));
+                    d[i] = make_float2(lane_above0(d[i + 1].x), lane_above0(d[i + 1].y));
+                    f[i] = make_float2(lane_above0(f[i + 1].x), lane_above0(f[i + 1].y));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < nd; ++i) {
+                float v[2 * NRAD + 2];
+                v[0] = fabsf(a.x - b[i].x) + fabsf(c.x - d[i].x) + fabsf(e.x - f[i].x);  // :415-425
+                v[1] = fabsf(a.y - b[i].y) + fabsf(c.y - d[i].y) + fabsf(e.y - f[i].y);
+#pragma unroll
+                for (int m = 1; m <= NRAD; ++m) {
+                    v[2 * m] = lane_above0(v[2 * m - 2]);
+                    v[2 * m + 1] = lane_above0(v[2 * m - 1]);
+                }
+                // sw0/sw1/sw2 (:443-450) start from 0 and add in k order; 0 + v[0] == v[0] for a sum of absolute values
+                float s0 = v[0], s1 = v[1];
+#pragma unroll
+                for (int k = 1; k <= 2 * NRAD; ++k) {
+                    s0 += v[k];
+                    s1 += v[k + 1];
+                }
+                if constexpr (NRAD % 2 == 0) {
+                    *reinterpret_cast<float2 *>(&ws[i][t + NRAD]) = make_float2(s0, s1);
+                } else {
+                    ws[i][t + NRAD] = s0;
+                    ws[i][t + NRAD + 1] = s1;
+                }
+            }
+        };
+        // The cost step of a pass reads ws and two taps a direction and ends in the cost tile. The passes are software-pipelined: the step's
+        // LDS reads are issued first, the NEXT pass's stage_a (whose ws stores stay behind those reads in program order — one wave's LDS
+        // operations execute in order, so there is neither a second ws buffer nor a fence between them) runs while they are in flight, and the
+        // step's arithmetic follows: one exposed LDS round trip per pass instead of two.
+        struct BRegs {
+            float sw0[kU], sw1[kU], sw2[kU], p1[kU], p2[kU];
+        };
+        const float r1c = rows[1][lx], r2c = rows[2][lx];
+        auto read_b = [&](auto ugc, BRegs &r) __attribute__((always_inline)) {
+            constexpr int ug = decltype(ugc)::value;
+            constexpr int nd = MD - ug + 1 < kU ? MD - ug + 1 : kU;
+            constexpr int jlo = (ug < 0 ? 2 * ug : 0) - NRAD;
+            const int base = lane - jlo;  // ws index of column x
+#pragma unroll
+            for (int i = 0; i < nd; ++i) {
+                const int u = ug + i;
+                r.sw1[i] = ws[i][base], r.sw0[i] = ws[i][base + u], r.sw2[i] = ws[i][base + 2 * u];
+                r.p1[i] = rows[1][lx + u], r.p2[i] = rows[2][lx - u];
+            }
+        };
+        auto comp_b = [&](auto ugc, const BRegs &r) __attribute__((always_inline)) {
+            constexpr int ug = decltype(ugc)::value;
+            constexpr int nd = MD - ug + 1 < kU ? MD - ug + 1 : kU;
+            float val[nd];
+#pragma unroll
+            for (int i = 0; i < nd; ++i) {
+                const int u = ug + i;
+                const float ip = (r.p1[i] + r.p2[i]) * 0.5f;
+                const float vv = fabsf(r1c - ip) + fabsf(r2c - ip);
+                val[i] = prm.alpha * (r.sw0[i] + r.sw1[i] + r.sw2[i]) + prm.beta * (float)abs(u) + prm.one_minus_ab * vv;
+            }
+            if (x < w) {
+#pragma unroll
+                for (int i = 0; i < nd; ++i) ctile[MD + ug + i][lane] = val[i];
+            }
+        };
+        auto cost_pass_fixed = [&](auto ugc) __attribute__((always_inline)) {  // (pass ug's stage_a has run)
+            constexpr int ug = decltype(ugc)::value;
+            BRegs r;
+#ifdef VSZIP_E3_NO_PIPE  // (sweeps: pass after pass)
+            wave_fence();
+            read_b(ugc, r);
+            comp_b(ugc, r);
+            wave_fence();
+            if constexpr (ug + kU <= MD) stage_a(std::integral_constant<int, ug + kU>{});
+#else
+            read_b(ugc, r);
+            __builtin_amdgcn_sched_barrier(0);  // the reads stay in front of the next pass's work
+            if constexpr (ug + kU <= MD) stage_a(std::integral_constant<int, ug + kU>{});
+            comp_b(ugc, r);
+#endif
+        };
+#ifdef VSZIP_E3_DIAG_ONE_PASS  // (timing diagnostics only, tools/variant.sh: ONE of the eleven direction passes - wrong results)
+        if constexpr (kRegWin) {
+            stage_a(std::integral_constant<int, 0>{});
+            BRegs r;
+            read_b(std::integral_constant<int, 0>{}, r);
+            comp_b(std::integral_constant<int, 0>{}, r);
+        } else
+            cost_pass(0);
+#else
+        if constexpr (kRegWin) {
+            stage_a(std::integral_constant<int, -MD>{});
+            static_for<-MD, MD, kU>(cost_pass_fixed);
+        } else if constexpr (FIXED) {
 #pragma unroll
             for (int ug = -MD; ug <= MD; ug += kU) cost_pass(ug);
         } else {
@@ -272,28 +459,64 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         // trip: the DP phase was half of the kernel's time at 1/5 of its instructions.)
         float tcv[kXB];
 #pragma unroll
-        for (int xl = 0; xl < kXB; ++xl) tcv[xl] = lane < tpitch ? ctile[lane][xl] : INFINITY;
+        for (int xl = 0; xl < kXB; ++xl) tcv[xl] = INFINITY;
+        if (lane < tpitch) {
+#ifdef VSZIP_E3_CTILE65
+#pragma unroll
+            for (int xl = 0; xl < kXB; ++xl) tcv[xl] = ctile[lane][xl];
+#else
+#pragma unroll
+            for (int q = 0; q < kXB / 4; ++q) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(&ctile[lane][4 * q]);
+                tcv[4 * q] = v4.x;
+                tcv[4 * q + 1] = v4.y;
+                tcv[4 * q + 2] = v4.z;
+                tcv[4 * q + 3] = v4.w;
+            }
+#endif
+        }
         uint32_t pk[kXB / 4];
 #pragma unroll
         for (int i = 0; i < kXB / 4; ++i) pk[i] = 0;
+        // Round 4: the step in five dependent instructions instead of eight. The new cost is min3(own, below + gamma, above + gamma) + tc whatever the
+        // tie-breaking picks (strict < only decides WHICH of equal values is taken), so the codes leave the chain: they are two compares beside it.
+        // The neighbours come through v_add_f32_dpp into registers whose edge lane (0 for "below", 63 for "above") was set to +inf once and is never
+        // written again — a lane without a neighbour keeps "+inf < own" false, as the reference's 0.9*FLT_MAX sentinel does (gamma >= 0 is validated).
+        // Codes are the signed two-bit step of the path: 0 stay, 3 (-1) from the direction below, 1 (+1) from the one above.
         auto dp_step = [&](float tc) -> uint32_t {
-            // A lane without a neighbour (direction -mdis has none below) receives ITS OWN cost instead of the
-            // reference's 0.9*FLT_MAX sentinel: own + gamma < own is as false as sentinel + gamma < own (gamma >= 0 is
-            // validated), and it saves loading the sentinel into the DPP destination before every shift. (Lane 63's
-            // "above" is irrelevant: lanes past the last direction are pinned at the sentinel by their infinite cost.)
+#ifdef VSZIP_E3_DP_R3  // (sweeps: the round-3 step)
             const float left_cc = lane_below(pcost, pcost) + prm.gamma, right_cc = lane_above(pcost, pcost) + prm.gamma;
             float bval = pcost;  // :536-548
             uint32_t code = 0;
             if (left_cc < bval) {
                 bval = left_cc;
-                code = 1;
+                code = 3;
             }
             if (right_cc < bval) {
                 bval = right_cc;
-                code = 2;
+                code = 1;
             }
             pcost = fminf(bval + tc, kFltMax09);
             return code;
+#else
+            uint32_t code;
+            float m1, bv;
+            uint64_t c1, c2;
+            asm volatile(
+                "v_add_f32_dpp %[vl], %[pc], %[g] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[vr], %[pc], %[g] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_min_f32_e32 %[m1], %[pc], %[vl]\n\t"
+                "v_min3_f32 %[bv], %[pc], %[vl], %[vr]\n\t"
+                "v_cmp_lt_f32_e64 %[c1], %[vl], %[pc]\n\t"
+                "v_add_f32_e32 %[bv], %[bv], %[tc]\n\t"
+                "v_cmp_lt_f32_e64 %[c2], %[vr], %[m1]\n\t"
+                "v_min_f32_e32 %[pc], %[mx], %[bv]\n\t"
+                "v_cndmask_b32_e64 %[code], 0, 3, %[c1]\n\t"
+                "v_cndmask_b32_e64 %[code], %[code], 1, %[c2]"
+                : [vl] "+v"(dp_l), [vr] "+v"(dp_r), [pc] "+v"(pcost), [m1] "=&v"(m1), [bv] "=&v"(bv), [c1] "=&s"(c1), [c2] "=&s"(c2), [code] "=&v"(code)
+                : [g] "v"(dp_gamma), [tc] "v"(tc), [mx] "v"(kFltMax09));
+            return code;
+#endif
         };
         auto store_block = [&](const uint32_t *q, int b) {  // 64 codes of direction `lane`, block b
             if (lane < tpitch) {
@@ -305,6 +528,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         // step 0 completes the previous block (its column 63)
         if (blk == 0) {
             pcost = lane < tpitch ? tcv[0] : kFltMax09;  // :461-463
+#ifndef VSZIP_E3_DP_R3
+            asm volatile("s_nop 1" : "+v"(pcost));  // a DPP read two wait states after the register's last write; inside dp_step the step's own tail provides them
+#endif
         } else {
             held[kXB / 4 - 1] |= dp_step(tcv[0]) << 24;
             store_block(held, blk - 1);
@@ -335,13 +561,13 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     // ---- backtrack (:557-565) + output (:577-591), block by block from the right ------------
     // fpath[x] = fpath[x+1] + bp[x][fpath[x+1]] is a scalar chain: the block's codes come back into
     // registers (each lane its own direction's 64 bytes), a step is v_readlane of the word that holds
-    // column xl at lane mdis+fpath, a bit-field extract and a scalar add; the path goes to the
-    // path to the lane of its column with a select. No LDS and no barrier in the chain.
+    // column xl at lane mdis+fpath, a signed bit-field extract and a scalar add; the path goes to the
+    // lane of its column with v_writelane. No LDS and no barrier in the chain.
     // Round 4: software-pipelined. A block's step chain is serial (0.8 us of scalar work), but neither the NEXT block's codes nor this block's four
     // output taps depend on anything but memory: the codes of block b - 1 are requested before block b is walked, and a block's taps are requested
     // after its walk and consumed after the next block's — each round trip to memory (about 1 us, exposed twice per block before: a wave has 0.75
     // neighbours on its SIMD to hide it behind) passes under a walk. profiles/r04_notes.md section 7.
-    int carry = 0;  // fpath of the first column of the block to the right
+    int carry = mdis;  // mdis + fpath of the first column of the block to the right
     uint32_t qn[kXB / 4];
     auto load_codes = [&](int b, uint32_t *dstq) __attribute__((always_inline)) {
         const uint4 *src = reinterpret_cast<const uint4 *>(pback + ((size_t)b * tpitch + min(lane, tpitch - 1)) * kXB);
@@ -372,33 +598,34 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
         for (int i = 0; i < kXB / 4; ++i) q[i] = qn[i];
         if (blk > 0) load_codes(blk - 1, qn);
-        int fp = __builtin_amdgcn_readfirstlane(carry);
-        int fpv = 0;  // lane xl: fpath of column xb + xl
+        // the chain variable is mdis + fpath (the lane that holds the current direction's codes): per column one v_readlane, one signed two-bit
+        // field extract and one add on the scalar unit; the column's value goes to its lane with v_writelane, off the chain
+        int fpm = __builtin_amdgcn_readfirstlane(carry);
+        int fpv = 0;  // lane xl: mdis + fpath of column xb + xl
         auto walk = [&](auto full) {
-#pragma unroll
-            for (int xl = kXB - 1; xl >= 0; --xl) {
+            static_for<0, kXB - 1, 1>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int xl = kXB - 1 - decltype(ic)::value;
                 if (decltype(full)::value || xl < xe) {
                     if (!decltype(full)::value && xb + xl == w - 1) {
-                        fp = 0;
+                        fpm = mdis;
                     } else {
-                        const int word = __builtin_amdgcn_readlane((int)q[xl >> 2], mdis + fp);
-                        // code 1: -1, code 2: +1 — bit arithmetic, so that the chain stays on the scalar unit
-                        fp += ((word >> (8 * (xl & 3) + 1)) & 1) - ((word >> (8 * (xl & 3))) & 1);
+                        const int word = __builtin_amdgcn_readlane((int)q[xl >> 2], fpm);
+                        fpm += (int)((uint32_t)word << (30 - 8 * (xl & 3))) >> 30;  // s_bfe_i32: 0, +1, or 3 = -1
                     }
-                    fpv = lane == xl ? fp : fpv;
+                    fpv = write_lane<xl>(fpv, fpm);
                 }
-            }
+            });
         };
         if (xe == kXB && blk != nblk - 1)
             walk(std::true_type{});
         else
             walk(std::false_type{});
-        carry = fp;
+        carry = fpm;
         emit_prev();  // (the block to the right: its taps were requested a walk ago)
         pxx = -1;
         if (lane < xe) {
             const int xx = xb + lane;
-            const int dir = fpv, ad = abs(dir);
+            const int dir = fpv - mdis, ad = abs(dir);
             dmap[xx] = dir;
             pxx = xx;
             pcubic = xx >= ad * 3 && xx + ad * 3 <= w - 1;
@@ -1238,9 +1465,13 @@ __device__ __forceinline__ float vcheck_pixel_bf(const VParams &prm, int L, int 
     return act ? blended : cint;
 }
 
+#ifndef VSZIP_VC_NT
+#define VSZIP_VC_NT 1024
+#endif
+constexpr int kVcNT = VSZIP_VC_NT;  // threads of a chain workgroup
 template <bool HP, int VC>
-__global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams prm) {
-    constexpr int C = 2;  // columns per thread: lines up to 2048 (LDS allows 1920)
+__global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams prm) {
+    constexpr int C = 2048 / kVcNT;  // columns per thread: lines up to 2048 (LDS allows 1920)
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     const int pslot = prm.plane_base + (int)blockIdx.x;
     const EPlane pl = prm.p[pslot];
@@ -1248,9 +1479,15 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams pr
     const int scstride = prm.scstride[pslot];
     const int L = pl.w, n_dst = pl.n_dst;
     const int tid = threadIdx.x;
+    // Round 4: ONE barrier per line. The blended line pd used to overwrite the un-blended one in its ring slot, and the rows pd+4 / pd+5 took
+    // the slots of rows pd-3 / pd-2 — all three read by this very line, so a barrier had to separate the line's reads from its writes and a
+    // second one its writes from the next line's reads. Now nothing a line writes is anything it reads: the blended lines alternate between two
+    // rows of their own (line pd reads pd-2 from one and writes pd to the other) and the ring holds nine rows (pd-3 .. pd+5).
+    constexpr int kRing = 9;
     float *ring = reinterpret_cast<float *>(vsm);
-    int8_t *dring = reinterpret_cast<int8_t *>(ring + (size_t)7 * L);
-    auto row = [&](int r) -> float * { return ring + (size_t)(r % 7) * L; };
+    float *blend = ring + (size_t)kRing * L;
+    int8_t *dring = reinterpret_cast<int8_t *>(blend + (size_t)2 * L);
+    auto row = [&](int r) -> float * { return ring + (size_t)(r % kRing) * L; };
     auto dmr = [&](int o) -> int8_t * { return dring + (size_t)(o & 3) * L; };
     // processed lines form one contiguous range of interpolated-line indices (:921-925)
     int first = 1, last = pl.n_interp - 2;
@@ -1262,93 +1499,96 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_lds_kernel(const VParams pr
         for (int r = pd0 - 3; r <= pd0 + 3; ++r) {
             if (r < 0 || r >= n_dst) continue;
             const float *g = pl.dst + (size_t)r * pl.dstride;
-            float *d = row(r);
+            float *d = r == pd0 - 2 ? blend + (size_t)((first - 1) & 1) * L : row(r);  // (line pd0-2: not part of the chain, or blended by an earlier launch)
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                if (tid + c * 1024 < L) d[tid + c * 1024] = g[tid + c * 1024];
+                if (tid + c * kVcNT < L) d[tid + c * kVcNT] = g[tid + c * kVcNT];
         }
         for (int o = first - 1; o <= first + 1; ++o) {
             const int *g = pl.dmap + (size_t)o * L;
             int8_t *d = dmr(o);
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                if (tid + c * 1024 < L) d[tid + c * 1024] = (int8_t)g[tid + c * 1024];
+                if (tid + c * kVcNT < L) d[tid + c * kVcNT] = (int8_t)g[tid + c * kVcNT];
         }
     }
     __syncthreads();
-    // The rows a line adds to the ring (pd+4, pd+5, the map row off+2, its sclip row) are loaded two
-    // lines ahead and parked in registers.
-    float a4[C], a5[C], asc[C], b4[C], b5[C], bsc[C];  // a*: for line off+1 (stored at the end of this iteration), b*: for line off+2
-    int ad[C], bd[C];
-    auto fetch = [&](int o, float *n4, float *n5, int *nd, float *sc) {  // new rows of line o (line o-1 stores them)
-        const int pdo = prm.field + 2 * o;
+    // The rows a line adds to the ring (pd+4, pd+5, the map row off+2, its sclip row) are loaded kAhead lines ahead and parked in registers.
+    // Round 4: the loop used to rotate two register sets with moves (a <- b at the end of a line), and a move of a register that a load is
+    // still writing waits for the load: every line waited out the global-memory latency of the loads it had just issued (s_waitcnt vmcnt(0) at
+    // the loop header — 1.7 us a line whatever the line's width). Now the sets are addressed round robin in a loop unrolled kAhead times (no
+    // moves) and every load is unconditional (clamped addresses instead of branches), so that the compiler can count: the wait in front of a
+    // set's first use leaves the younger sets' loads in flight.
+    constexpr int kAhead = 3;
+    float n4[kAhead][C], n5[kAhead][C], nsc[kAhead][C];  // set (o - first) % kAhead: the new rows of line o (line o-1 stores them at its end)
+    int nd[kAhead][C];
+    const float *scsrc = scp ? scp : pl.dst;  // (no sclip: any readable row, the value is not used)
+    const size_t scpitch = scp ? (size_t)scstride : (size_t)pl.dstride;
+    auto fetch = [&](int o, float *q4, float *q5, int *qd, float *qsc) __attribute__((always_inline)) {
+        const int oc = min(o, last);  // past the chain: a valid line, loaded and never stored
+        const int pdo = prm.field + 2 * oc;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int i = tid + c * 1024;
-            n4[c] = n5[c] = sc[c] = 0.0f;
-            nd[c] = 0;
-            if (i < L && o <= last) {
-                if (pdo + 2 < n_dst) n4[c] = pl.dst[(size_t)(pdo + 2) * pl.dstride + i];
-                if (pdo + 3 < n_dst) n5[c] = pl.dst[(size_t)(pdo + 3) * pl.dstride + i];
-                nd[c] = pl.dmap[(size_t)(o + 1) * L + i];
-                if (scp) sc[c] = scp[(size_t)pdo * scstride + i];
-            }
+            const int i = min(tid + c * kVcNT, L - 1);
+            q4[c] = pl.dst[(size_t)min(pdo + 2, n_dst - 1) * pl.dstride + i];
+            q5[c] = pl.dst[(size_t)min(pdo + 3, n_dst - 1) * pl.dstride + i];
+            qd[c] = pl.dmap[(size_t)(oc + 1) * L + i];
+            qsc[c] = scsrc[(size_t)pdo * scpitch + i];
         }
     };
     float sc[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int i = tid + c * 1024;
-        sc[c] = (scp && i < L) ? scp[(size_t)(prm.field + 2 * first) * scstride + i] : 0.0f;
-    }
-    fetch(first + 1, a4, a5, ad, asc);
-    int s0 = ((prm.field + 2 * first - 3) % 7 + 7) % 7;  // ring slot of row pd-3; row pd-3+k sits in slot (s0 + k) mod 7
+    for (int c = 0; c < C; ++c) sc[c] = scsrc[(size_t)(prm.field + 2 * first) * scpitch + min(tid + c * kVcNT, L - 1)];
+#pragma unroll
+    for (int j = 1; j < kAhead; ++j) fetch(first + j, n4[j], n5[j], nd[j], nsc[j]);
+    int s0 = ((prm.field + 2 * first - 3) % kRing + kRing) % kRing;  // ring slot of row pd-3; row pd-3+k sits in slot (s0 + k) mod kRing
     auto slot = [&](int k) -> float * {
         int q = s0 + k;
-        q = q >= 7 ? q - 7 : q;
+        q = q >= kRing ? q - kRing : q;
         return ring + q * L;
     };
-    for (int off = first; off <= last; ++off) {
-        const int pd = prm.field + 2 * off;
-        const bool nxt = off + 1 <= last;
-        fetch(off + 2, b4, b5, bd, bsc);
-        const float *d2p = slot(1), *d1p = slot(2), *dl = slot(3), *d1n = slot(4), *d2n = slot(5);
-        // rows pd-3 / pd+3 reflect at the frame border (only the first / last line of the chain)
-        const float *d3p = pd - 3 >= 0 ? slot(0) : row(reflect_row(pd - 3, n_dst));
-        const float *d3n = pd + 3 < n_dst ? slot(6) : row(reflect_row(pd + 3, n_dst));
-        const int8_t *dc = dmr(off), *dp = dmr(off - 1), *dn = dmr(off + 1);
-        float res[C];
+    for (int off0 = first; off0 <= last; off0 += kAhead) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int i = min(tid + c * 1024, L - 1);  // threads past the line compute on its last column and store nothing
-            const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
-            res[c] = vcheck_pixel_bf<HP, VC>(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
-        }
-        __syncthreads();  // every read of the un-blended line pd is done
-        float *gout = pl.dst + (size_t)pd * pl.dstride;
-        float *r4 = slot(0), *r5 = slot(1);  // rows pd+4 / pd+5 take the slots of rows pd-3 / pd-2
-        float *dlw = slot(3);
-        int8_t *dnew = dmr(off + 2);
+        for (int j = 0; j < kAhead; ++j) {
+            const int off = off0 + j;
+            if (off > last) break;
+            const int jn = (j + 1) % kAhead;  // the set of line off+1
+            const int pd = prm.field + 2 * off;
+            const bool nxt = off + 1 <= last;
+            fetch(off + kAhead, n4[j], n5[j], nd[j], nsc[j]);  // (set j held line off's rows: stored by line off-1)
+            const float *d2p = blend + (size_t)((off - 1) & 1) * L, *d1p = slot(2), *dl = slot(3), *d1n = slot(4), *d2n = slot(5);
+            // rows pd-3 / pd+3 reflect at the frame border (only the first / last line of the chain)
+            const float *d3p = pd - 3 >= 0 ? slot(0) : row(reflect_row(pd - 3, n_dst));
+            const float *d3n = pd + 3 < n_dst ? slot(6) : row(reflect_row(pd + 3, n_dst));
+            const int8_t *dc = dmr(off), *dp = dmr(off - 1), *dn = dmr(off + 1);
+            float res[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int i = tid + c * 1024;
-            if (i < L) {
-                dlw[i] = res[c];
-                gout[i] = res[c];
-                if (nxt) {
-                    if (pd + 4 < n_dst) r4[i] = a4[c];
-                    if (pd + 5 < n_dst) r5[i] = a5[c];
-                    dnew[i] = (int8_t)ad[c];
-                }
+            for (int c = 0; c < C; ++c) {
+                const int i = min(tid + c * kVcNT, L - 1);  // threads past the line compute on its last column and store nothing
+                const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
+                res[c] = vcheck_pixel_bf<HP, VC>(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
             }
-            sc[c] = asc[c];
-            a4[c] = b4[c];
-            a5[c] = b5[c];
-            ad[c] = bd[c];
-            asc[c] = bsc[c];
+            float *gout = pl.dst + (size_t)pd * pl.dstride;
+            float *r4 = slot(7), *r5 = slot(8);  // rows pd+4 / pd+5
+            float *blw = blend + (size_t)(off & 1) * L;
+            int8_t *dnew = dmr(off + 2);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = tid + c * kVcNT;
+                if (i < L) {
+                    blw[i] = res[c];
+                    gout[i] = res[c];
+                    if (nxt) {
+                        if (pd + 4 < n_dst) r4[i] = n4[jn][c];
+                        if (pd + 5 < n_dst) r5[i] = n5[jn][c];
+                        dnew[i] = (int8_t)nd[jn][c];
+                    }
+                }
+                if (scp) sc[c] = nsc[jn][c];
+            }
+            s0 = s0 + 2 >= kRing ? s0 + 2 - kRing : s0 + 2;
+            __syncthreads();  // the line's writes against the next line's reads
         }
-        s0 = s0 + 2 >= 7 ? s0 - 5 : s0 + 2;
-        __syncthreads();
     }
 }
 
@@ -1597,21 +1837,27 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
     const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !ctx->opt.vcheck_global;
     auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
-        const size_t lds = (size_t)maxL * (7 * sizeof(float) + 4);
+        const size_t lds = (size_t)maxL * (11 * sizeof(float) + 4);  // nine ring rows, two blended rows, four int8 map rows
         vp.plane_base = first;
-#define VSZIP_VC_LAUNCH(HPV)                                                                                      \
-    do {                                                                                                          \
-        if (up->vcheck == 1)                                                                                      \
-            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 1>), dim3(count), dim3(1024), lds, st, vp);         \
-        else if (up->vcheck == 2)                                                                                 \
-            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 2>), dim3(count), dim3(1024), lds, st, vp);         \
-        else                                                                                                      \
-            hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, 3>), dim3(count), dim3(1024), lds, st, vp);         \
+#define VSZIP_VC_LAUNCH1(HPV, VCV)                                                                                                                    \
+    do {                                                                                                                                              \
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eedi3_vcheck_lds_kernel<HPV, VCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, VCV>), dim3(count), dim3(kVcNT), lds, st, vp);                                               \
+    } while (0)
+#define VSZIP_VC_LAUNCH(HPV)                  \
+    do {                                      \
+        if (up->vcheck == 1)                  \
+            VSZIP_VC_LAUNCH1(HPV, 1);         \
+        else if (up->vcheck == 2)             \
+            VSZIP_VC_LAUNCH1(HPV, 2);         \
+        else                                  \
+            VSZIP_VC_LAUNCH1(HPV, 3);         \
     } while (0)
         if (hp)
             VSZIP_VC_LAUNCH(true);
         else
             VSZIP_VC_LAUNCH(false);
+#undef VSZIP_VC_LAUNCH1
 #undef VSZIP_VC_LAUNCH
     };
     // two plane heights in the call, the tuned line kernel and the LDS chain kernel: overlap (see `order` above).
