@@ -419,18 +419,40 @@ __device__ __forceinline__ float walk_shl1(float v) {  // lane i takes lane i + 
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 // {value of lane i - T0, value of lane i - T1} / {lane i + T0, lane i + T1}: T0 = 1, T1 = 2 or 3, chained single shifts
-template <int T1>
-__device__ __forceinline__ v2f walk_left_pair(float a, float b) {  // a travels T0 = 1 lane, b travels T1 lanes
-    float y = walk_shr1(b);
+// The T1-lane hop: T1 chained DPP shifts are T1 half-rate VALU instructions (4 cycles each on gfx950, tools/ubench/valu_rate.hip); one
+// ds_bpermute_b32 moves the value any distance through the LDS crossbar, which has room beside the table reads (no bank conflicts, no storage).
+// It wraps around the wave where the DPP shift feeds zeros: either way only halo lanes see the difference (see above).
+// Measured (tools/bil_ab.py, 1080p): the PLATEAU table form (one LDS read a lookup) gains 7 % (8-bit sigmaS = 2; the filter's defaults on 16-bit),
+// the packed forms (two reads a lookup, the LDS pipeline 65 % busy and two thirds of that bank conflicts) lose 2-3 %: the choice follows the form.
+#ifdef VSZIP_WALK_NO_BPERM  // (sweeps: the round-3 form everywhere)
+template <int FORM>
+constexpr bool kWalkBperm = false;
+#else
+template <int FORM>
+constexpr bool kWalkBperm = FORM == 2;
+#endif
+template <int T1, bool BP>
+__device__ __forceinline__ v2f walk_left_pair(float a, float b, int addr_l) {  // a travels T0 = 1 lane, b travels T1 lanes; addr_l = 4 * ((lane - T1) & 63)
+    float y;
+    if constexpr (BP) {
+        y = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(b)));
+    } else {
+        y = walk_shr1(b);
 #pragma unroll
-    for (int k = 1; k < T1; ++k) y = walk_shr1(y);
+        for (int k = 1; k < T1; ++k) y = walk_shr1(y);
+    }
     return v2f{walk_shr1(a), y};
 }
-template <int T1>
-__device__ __forceinline__ v2f walk_right_pair(float a, float b) {
-    float y = walk_shl1(b);
+template <int T1, bool BP>
+__device__ __forceinline__ v2f walk_right_pair(float a, float b, int addr_r) {
+    float y;
+    if constexpr (BP) {
+        y = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(b)));
+    } else {
+        y = walk_shl1(b);
 #pragma unroll
-    for (int k = 1; k < T1; ++k) y = walk_shl1(y);
+        for (int k = 1; k < T1; ++k) y = walk_shl1(y);
+    }
     return v2f{walk_shl1(a), y};
 }
 
@@ -449,6 +471,7 @@ struct WalkState {
     v2f sl[R], sr[R];                              // the tap columns as pairs over the tap distance: {x - T0, x - T1}, {x + T0, x + T1}
     v2f ha0[T0], hb0[T0];                          // handed-down weights of the yy = T0 taps: a = from the pixels at x - xx (rw3), b = from x + xx (rw1)
     v2f ha1[T1], hb1[T1];                          // ... of the yy = T1 taps
+    int addr_l, addr_r;                            // ds_bpermute addresses of the lanes T1 to the left / right
 };
 
 // The table in LDS. COARSE (0) = base[i >> 6] (u32 x 1024) - delta[i] (u16), any table that packs; FINE (1) = base4[i >> 2] (u32 x 16384) -
@@ -502,8 +525,8 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     // 1: the row loaded a step ago enters the rings (slot P), with its shifted copies
     const float v = (float)pend;
     st.sc[P] = v;
-    st.sl[P] = walk_left_pair<T1>(v, v);
-    st.sr[P] = walk_right_pair<T1>(v, v);
+    st.sl[P] = walk_left_pair<T1, kWalkBperm<FINE>>(v, v, st.addr_l);
+    st.sr[P] = walk_right_pair<T1, kWalkBperm<FINE>>(v, v, st.addr_r);
     // 2: the next row's load is in flight during the arithmetic
     pend = *nextp;
     // 3: the row CR above the newest one. Pairs run over the tap distance xx (v_pk_* : IEEE per element, the reference's order)
@@ -519,8 +542,8 @@ __device__ __forceinline__ void walk_step(WalkState<CR, CS> &st, const WalkLut<F
     auto sets = [&](const v2f swv, const v2f n1, const v2f n2, const v2f n3, const v2f n4, v2f &ha, v2f &hb) {
         const v2f rw2 = {lut(n2.x), lut(n2.y)}, rw4 = {lut(n4.x), lut(n4.y)};  // the downward taps (+yy, +xx), (+yy, -xx)
         const v2f rw1 = hb, rw3 = ha;  // handed down: (-yy, +xx) is the (+yy, -xx) tap of the pixel at x + xx, (-yy, -xx) the (+yy, +xx) tap of the one at x - xx
-        ha = walk_left_pair<T1>(rw2.x, rw2.y);   // what the pixels yy rows below take from their left / right neighbours
-        hb = walk_right_pair<T1>(rw4.x, rw4.y);
+        ha = walk_left_pair<T1, kWalkBperm<FINE>>(rw2.x, rw2.y, st.addr_l);   // what the pixels yy rows below take from their left / right neighbours
+        hb = walk_right_pair<T1, kWalkBperm<FINE>>(rw4.x, rw4.y, st.addr_r);
         const v2f wi = swv * (rw1 + rw2 + rw3 + rw4);
         const v2f si = swv * (n1 * rw1 + n2 * rw2 + n3 * rw3 + n4 * rw4);
         wsum += wi.x;
@@ -601,6 +624,8 @@ __global__ __launch_bounds__(1024) void bilateral_walk16_kernel(const BLParams p
         T *dcol = static_cast<T *>(pl.dst) + min(max(col, 0), pl.w - 1);
         const bool lane_out = lane >= CR && lane < 64 - CR && col < pl.w;
         W st;
+        st.addr_l = ((lane - W::T1) & 63) << 2;
+        st.addr_r = ((lane + W::T1) & 63) << 2;
 #pragma unroll
         for (int b = 0; b < W::R; ++b) {
             st.sc[b] = 0.0f;
@@ -636,8 +661,24 @@ __device__ __forceinline__ float walk_shl(float v) {
     for (int k = 0; k < N; ++k) v = walk_shl1(v);
     return v;
 }
+// a hop of N lanes: one ds_bpermute_b32 (see walk_left_pair) or N chained DPP shifts
+template <int N, bool BP>
+__device__ __forceinline__ float walk_hop_l(float v, int addr) {
+    if constexpr (BP && N > 1)
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+    else
+        return walk_shr<N>(v);
+}
+template <int N, bool BP>
+__device__ __forceinline__ float walk_hop_r(float v, int addr) {
+    if constexpr (BP && N > 1)
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+    else
+        return walk_shl<N>(v);
+}
 struct Walk3State {
     static constexpr int CR = 5, T0 = 1, T1 = 3, T2 = 5, R = 15;
+    int al3, ar3, al5, ar5;  // ds_bpermute addresses of the lanes 3 / 5 to the left / right
     float sc[R];
     v2f sl[R], sr[R];   // {x -+ 1, x -+ 3}
     float slz[R], srz[R];  // x -+ 5
@@ -653,11 +694,18 @@ __device__ __forceinline__ void walk3_step(Walk3State &st, const WalkLut<FORM> &
     const float v = (float)pend;
     st.sc[P] = v;
     {
-        const float l1 = walk_shr1(v), l3 = walk_shr<2>(l1), r1 = walk_shl1(v), r3 = walk_shl<2>(r1);
+        const float l1 = walk_shr1(v), r1 = walk_shl1(v);
+        float l3, r3, l5, r5;
+        constexpr bool BP = kWalkBperm<FORM>;
+        if constexpr (BP) {
+            l3 = walk_hop_l<T1, BP>(v, st.al3), r3 = walk_hop_r<T1, BP>(v, st.ar3), l5 = walk_hop_l<T2, BP>(v, st.al5), r5 = walk_hop_r<T2, BP>(v, st.ar5);
+        } else {
+            l3 = walk_shr<2>(l1), r3 = walk_shl<2>(r1), l5 = walk_shr<2>(l3), r5 = walk_shl<2>(r3);
+        }
         st.sl[P] = v2f{l1, l3};
         st.sr[P] = v2f{r1, r3};
-        st.slz[P] = walk_shr<2>(l3);
-        st.srz[P] = walk_shl<2>(r3);
+        st.slz[P] = l5;
+        st.srz[P] = r5;
     }
     pend = *nextp;
     constexpr int C = (P - CR + R) % R;
@@ -676,10 +724,10 @@ __device__ __forceinline__ void walk3_step(Walk3State &st, const WalkLut<FORM> &
         const float rw2z = lut(n2z), rw4z = lut(n4z);
         const v2f rw1 = hb, rw3 = ha;
         const float rw1z = hbz, rw3z = haz;
-        ha = v2f{walk_shr1(rw2.x), walk_shr<T1>(rw2.y)};
-        hb = v2f{walk_shl1(rw4.x), walk_shl<T1>(rw4.y)};
-        haz = walk_shr<T2>(rw2z);
-        hbz = walk_shl<T2>(rw4z);
+        ha = v2f{walk_shr1(rw2.x), walk_hop_l<T1, kWalkBperm<FORM>>(rw2.y, st.al3)};
+        hb = v2f{walk_shl1(rw4.x), walk_hop_r<T1, kWalkBperm<FORM>>(rw4.y, st.ar3)};
+        haz = walk_hop_l<T2, kWalkBperm<FORM>>(rw2z, st.al5);
+        hbz = walk_hop_r<T2, kWalkBperm<FORM>>(rw4z, st.ar5);
         const v2f wi = swv * (rw1 + rw2 + rw3 + rw4);
         const v2f si = swv * (n1 * rw1 + n2 * rw2 + n3 * rw3 + n4 * rw4);
         const float wiz = swq * (rw1z + rw2z + rw3z + rw4z);
@@ -763,6 +811,7 @@ __global__ __launch_bounds__(512) void bilateral_walk36_kernel(const BLParams pr
         T *dcol = static_cast<T *>(pl.dst) + min(max(col, 0), pl.w - 1);
         const bool lane_out = lane >= CR && lane < 64 - CR && col < pl.w;
         W st;
+        st.al3 = ((lane - 3) & 63) << 2, st.ar3 = ((lane + 3) & 63) << 2, st.al5 = ((lane - 5) & 63) << 2, st.ar5 = ((lane + 5) & 63) << 2;
 #pragma unroll
         for (int b = 0; b < W::R; ++b) {
             st.sc[b] = 0.0f;
