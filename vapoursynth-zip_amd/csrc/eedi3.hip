@@ -1420,7 +1420,8 @@ template <bool HP, int VC>
 __device__ __forceinline__ float vcheck_pixel_bf(const VParams &prm, int L, int i, int dirc, int dirt, int dirb, float cint, const float *d1p, const float *d1n,
                                                  const float *dl, const float *d2p, const float *d2n) {
     const int maxoff = !HP ? abs(dirc) : (((dirc & 1) == 0) ? abs(dirc >> 1) : max(abs(dirc >> 1), abs((dirc + 1) >> 1)));
-    const bool act = dirc != 0 && !(max(dirc * dirt, dirc * dirb) < 0 || (dirt == dirb && dirt == 0)) && !(i + maxoff >= L || i - maxoff < 0);
+    // (bitwise: with && / || the compiler builds an exec-mask region around the later terms)
+    const bool act = (dirc != 0) & !((max(dirc * dirt, dirc * dirb) < 0) | ((dirt | dirb) == 0)) & !((i + maxoff >= L) | (i - maxoff < 0));
     const int dsafe = act ? dirc : 0;
     float it, ib, vt, vb;
     int dabs;
@@ -1483,12 +1484,16 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
     // the slots of rows pd-3 / pd-2 — all three read by this very line, so a barrier had to separate the line's reads from its writes and a
     // second one its writes from the next line's reads. Now nothing a line writes is anything it reads: the blended lines alternate between two
     // rows of their own (line pd reads pd-2 from one and writes pd to the other) and the ring holds nine rows (pd-3 .. pd+5).
-    constexpr int kRing = 9;
+    // All rings have periods that divide nine lines (the rows' ring: 9 slots, two rows a line; blended lines: 3; map rows: 9; the prefetch sets: 3) and are
+    // addressed RELATIVE to the chain's first line, so in a loop unrolled nine times every slot is a compile-time multiple of L: the per-line slot
+    // arithmetic (a quarter of the step's instructions, and the step is bound by one wave's instruction stream) is gone.
+    constexpr int kRing = 9, kBlend = 3, kMapRing = 9;
     float *ring = reinterpret_cast<float *>(vsm);
-    float *blend = ring + (size_t)kRing * L;
-    int8_t *dring = reinterpret_cast<int8_t *>(blend + (size_t)2 * L);
-    auto row = [&](int r) -> float * { return ring + (size_t)(r % kRing) * L; };
-    auto dmr = [&](int o) -> int8_t * { return dring + (size_t)(o & 3) * L; };
+    // rows lie kPitch samples apart whatever the line's width: a slot's offset is then a compile-time constant that folds into the LDS instructions' immediates
+    constexpr int kPitch = kVcLdsMaxL;
+    float *blend = ring + (size_t)kRing * kPitch;
+    float *spare = blend + (size_t)kBlend * kPitch;  // where stores that are not due go
+    int8_t *dring = reinterpret_cast<int8_t *>(spare + kPitch);
     // processed lines form one contiguous range of interpolated-line indices (:921-925)
     int first = 1, last = pl.n_interp - 2;
     while (first <= last && prm.field + 2 * first < 2) ++first;
@@ -1496,17 +1501,18 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
     if (first > last) return;
     {
         const int pd0 = prm.field + 2 * first;
-        for (int r = pd0 - 3; r <= pd0 + 3; ++r) {
+        for (int k = 0; k <= 6; ++k) {  // row pd0 - 3 + k -> ring slot k; the line pd0 - 2 (not part of the chain, or blended by an earlier launch) -> blended slot kBlend - 1
+            const int r = pd0 - 3 + k;
             if (r < 0 || r >= n_dst) continue;
             const float *g = pl.dst + (size_t)r * pl.dstride;
-            float *d = r == pd0 - 2 ? blend + (size_t)((first - 1) & 1) * L : row(r);  // (line pd0-2: not part of the chain, or blended by an earlier launch)
+            float *d = k == 1 ? blend + (size_t)(kBlend - 1) * kPitch : ring + (size_t)k * kPitch;
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 if (tid + c * kVcNT < L) d[tid + c * kVcNT] = g[tid + c * kVcNT];
         }
-        for (int o = first - 1; o <= first + 1; ++o) {
-            const int *g = pl.dmap + (size_t)o * L;
-            int8_t *d = dmr(o);
+        for (int k = -1; k <= 1; ++k) {  // map row first + k -> slot (k + kMapRing) % kMapRing
+            const int *g = pl.dmap + (size_t)(first + k) * L;
+            int8_t *d = dring + (size_t)((k + kMapRing) % kMapRing) * kPitch;
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 if (tid + c * kVcNT < L) d[tid + c * kVcNT] = (int8_t)g[tid + c * kVcNT];
@@ -1524,16 +1530,23 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
     int nd[kAhead][C];
     const float *scsrc = scp ? scp : pl.dst;  // (no sclip: any readable row, the value is not used)
     const size_t scpitch = scp ? (size_t)scstride : (size_t)pl.dstride;
+    uint32_t icl[C];  // the thread's columns, clamped into the line, as BYTE offsets: a load is row pointer (scalar) + 32-bit lane offset
+#pragma unroll
+    for (int c = 0; c < C; ++c) icl[c] = 4u * (uint32_t)min(tid + c * kVcNT, L - 1);
+    auto at = [](const void *rowp, uint32_t byte_off) { return *reinterpret_cast<const uint32_t *>(static_cast<const char *>(rowp) + byte_off); };
     auto fetch = [&](int o, float *q4, float *q5, int *qd, float *qsc) __attribute__((always_inline)) {
         const int oc = min(o, last);  // past the chain: a valid line, loaded and never stored
         const int pdo = prm.field + 2 * oc;
+        const float *p4 = pl.dst + (size_t)min(pdo + 2, n_dst - 1) * pl.dstride, *p5 = pl.dst + (size_t)min(pdo + 3, n_dst - 1) * pl.dstride;
+        const int *pm = pl.dmap + (size_t)(oc + 1) * L;
+        const float *ps = scsrc + (size_t)pdo * scpitch;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int i = min(tid + c * kVcNT, L - 1);
-            q4[c] = pl.dst[(size_t)min(pdo + 2, n_dst - 1) * pl.dstride + i];
-            q5[c] = pl.dst[(size_t)min(pdo + 3, n_dst - 1) * pl.dstride + i];
-            qd[c] = pl.dmap[(size_t)(oc + 1) * L + i];
-            qsc[c] = scsrc[(size_t)pdo * scpitch + i];
+            asm("" : "+v"(icl[c]));  // keeps the offset's zero-extension in this block, where instruction selection can fold it into the load (saddr + 32-bit voffset)
+            q4[c] = __uint_as_float(at(p4, icl[c]));
+            q5[c] = __uint_as_float(at(p5, icl[c]));
+            qd[c] = (int)at(pm, icl[c]);
+            qsc[c] = __uint_as_float(at(ps, icl[c]));
         }
     };
     float sc[C];
@@ -1541,26 +1554,24 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
     for (int c = 0; c < C; ++c) sc[c] = scsrc[(size_t)(prm.field + 2 * first) * scpitch + min(tid + c * kVcNT, L - 1)];
 #pragma unroll
     for (int j = 1; j < kAhead; ++j) fetch(first + j, n4[j], n5[j], nd[j], nsc[j]);
-    int s0 = ((prm.field + 2 * first - 3) % kRing + kRing) % kRing;  // ring slot of row pd-3; row pd-3+k sits in slot (s0 + k) mod kRing
-    auto slot = [&](int k) -> float * {
-        int q = s0 + k;
-        q = q >= kRing ? q - kRing : q;
-        return ring + q * L;
-    };
-    for (int off0 = first; off0 <= last; off0 += kAhead) {
-#pragma unroll
-        for (int j = 0; j < kAhead; ++j) {
+    constexpr int kPeriod = 9;
+    for (int off0 = first; off0 <= last; off0 += kPeriod) {
+        static_for<0, kPeriod - 1, 1>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;  // (off - first) mod 9
             const int off = off0 + j;
-            if (off > last) break;
-            const int jn = (j + 1) % kAhead;  // the set of line off+1
+            if (off > last) return;
+            constexpr int js = j % kAhead, jn = (j + 1) % kAhead;  // the sets of lines off + kAhead (loaded now) and off + 1 (stored at the end)
+            auto slot = [&](int k) -> float * { return ring + (size_t)((2 * j + k) % kRing) * kPitch; };  // row pd - 3 + k
+            auto dmr = [&](int d) -> int8_t * { return dring + (size_t)((j + d + kMapRing) % kMapRing) * kPitch; };  // map row off + d
             const int pd = prm.field + 2 * off;
             const bool nxt = off + 1 <= last;
-            fetch(off + kAhead, n4[j], n5[j], nd[j], nsc[j]);  // (set j held line off's rows: stored by line off-1)
-            const float *d2p = blend + (size_t)((off - 1) & 1) * L, *d1p = slot(2), *dl = slot(3), *d1n = slot(4), *d2n = slot(5);
-            // rows pd-3 / pd+3 reflect at the frame border (only the first / last line of the chain)
-            const float *d3p = pd - 3 >= 0 ? slot(0) : row(reflect_row(pd - 3, n_dst));
-            const float *d3n = pd + 3 < n_dst ? slot(6) : row(reflect_row(pd + 3, n_dst));
-            const int8_t *dc = dmr(off), *dp = dmr(off - 1), *dn = dmr(off + 1);
+            fetch(off + kAhead, n4[js], n5[js], nd[js], nsc[js]);  // (set js held line off's rows: stored by line off-1)
+            const float *d2p = blend + (size_t)((j + kBlend - 1) % kBlend) * kPitch, *d1p = slot(2), *dl = slot(3), *d1n = slot(4), *d2n = slot(5);
+            // rows pd-3 / pd+3 reflect at the frame border (only the first / last line of the chain). The chain's range keeps 2 <= pd and pd + 2 < n_dst,
+            // so the only rows ever reflected are -1 -> 1 = pd - 1 and n_dst -> n_dst - 2 = pd + 1: both in the ring (no reflect_row loop per line)
+            const float *d3p = ring + (pd - 3 >= 0 ? (uint32_t)((2 * j + 0) % kRing) : (uint32_t)((2 * j + 2) % kRing)) * kPitch;
+            const float *d3n = ring + (pd + 3 < n_dst ? (uint32_t)((2 * j + 6) % kRing) : (uint32_t)((2 * j + 4) % kRing)) * kPitch;
+            const int8_t *dc = dmr(0), *dp = dmr(-1), *dn = dmr(1);
             float res[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -1568,27 +1579,28 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
                 const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
                 res[c] = vcheck_pixel_bf<HP, VC>(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
             }
+            // No lane masks and no branches in the stores: a thread past the line has computed the line's last column from the same inputs as the
+            // thread that owns it and stores the same values there; rows that are not due (past the chain or the plane) go to a spare row.
             float *gout = pl.dst + (size_t)pd * pl.dstride;
-            float *r4 = slot(7), *r5 = slot(8);  // rows pd+4 / pd+5
-            float *blw = blend + (size_t)(off & 1) * L;
-            int8_t *dnew = dmr(off + 2);
+            // (offsets from ONE LDS base, selected as integers: a select between pointers would make them generic pointers)
+            constexpr uint32_t kSpareOff = (uint32_t)(kRing + kBlend) * kPitch;
+            const uint32_t o4 = (nxt && pd + 4 < n_dst) ? (uint32_t)((2 * j + 7) % kRing) * kPitch : kSpareOff;  // rows pd+4 / pd+5
+            const uint32_t o5 = (nxt && pd + 5 < n_dst) ? (uint32_t)((2 * j + 8) % kRing) * kPitch : kSpareOff;
+            const uint32_t od = nxt ? (uint32_t)(kRing + kBlend + 1) * kPitch * 4u + (uint32_t)((j + 2) % kMapRing) * kPitch : kSpareOff * 4u;  // (bytes) map row off + 2
+            float *blw = blend + (size_t)(j % kBlend) * kPitch;
+            int8_t *ring8 = reinterpret_cast<int8_t *>(ring);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const int i = tid + c * kVcNT;
-                if (i < L) {
-                    blw[i] = res[c];
-                    gout[i] = res[c];
-                    if (nxt) {
-                        if (pd + 4 < n_dst) r4[i] = n4[jn][c];
-                        if (pd + 5 < n_dst) r5[i] = n5[jn][c];
-                        dnew[i] = (int8_t)nd[jn][c];
-                    }
-                }
+                const uint32_t i = icl[c] >> 2;
+                blw[i] = res[c];
+                gout[i] = res[c];
+                ring[o4 + i] = n4[jn][c];
+                ring[o5 + i] = n5[jn][c];
+                ring8[od + i] = (int8_t)nd[jn][c];
                 if (scp) sc[c] = nsc[jn][c];
             }
-            s0 = s0 + 2 >= kRing ? s0 + 2 - kRing : s0 + 2;
             __syncthreads();  // the line's writes against the next line's reads
-        }
+        });
     }
 }
 
@@ -1837,7 +1849,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
     const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !ctx->opt.vcheck_global;
     auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
-        const size_t lds = (size_t)maxL * (11 * sizeof(float) + 4);  // nine ring rows, two blended rows, four int8 map rows
+        const size_t lds = (size_t)kVcLdsMaxL * (13 * sizeof(float) + 9);  // nine ring rows, three blended rows, a spare row, nine int8 map rows, at the fixed pitch
         vp.plane_base = first;
 #define VSZIP_VC_LAUNCH1(HPV, VCV)                                                                                                                    \
     do {                                                                                                                                              \
