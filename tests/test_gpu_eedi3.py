@@ -29,6 +29,9 @@ CASES = [
     dict(field=1, vcheck=0), dict(field=1, vcheck=1), dict(field=1, vcheck=3),
     dict(field=1, mdis=31, nrad=3), dict(field=1, mdis=5, nrad=0), dict(field=1, gamma=0.0),
     dict(field=1, alpha=0.4, beta=0.3, gamma=40.0), dict(field=1, alpha=0.9, beta=0.05, gamma=2.0, mdis=30),
+    # the default mdis = 20 instantiation (window sums in registers through DPP, round 4) at every nrad: 0 has no shift, odd ones store their sums unaligned
+    dict(field=1, nrad=0), dict(field=0, nrad=1, dh=True), dict(field=1, nrad=3, vcheck=1), dict(field=0, nrad=3, alpha=0.1, beta=0.9, gamma=0.0),
+    dict(field=1, mdis=20, nrad=2, vcheck=3, vthresh0=8.0, vthresh1=4.0, vthresh2=1.0),
 ]
 
 
@@ -40,6 +43,18 @@ def test_matches_oracle(dev, oracle, kw):
     got = _gpu(dev, src, field, **kw)
     want = oracle.eedi3(src, field, **kw)
     assert np.array_equal(got, want), (kw, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("scale", [1e30, 3e37, 1e-30], ids=["1e30", "3e37", "1e-30"])
+def test_costs_beyond_the_sentinel_and_denormals(dev, oracle, scale):
+    """Samples whose costs overflow (the reference clamps a path cost at 0.9 * FLT_MAX, eedi3.zig:536-548: the Viterbi step's v_min against that bound
+    and its +inf edge lanes) or are denormal: the path and the interpolation still equal the oracle's."""
+    src = (fx.crop_rgbs()[1][:64, :200] * np.float32(scale)).astype(np.float32)
+    assert np.isfinite(src).all()
+    for kw in (dict(), dict(dh=True, vcheck=0)):
+        got = _gpu(dev, src, 1, **kw)
+        want = oracle.eedi3(src, 1, **kw)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (scale, kw, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
 
 
 GENERAL = [
