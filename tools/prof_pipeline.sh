@@ -1,10 +1,13 @@
-#!/bin/bash
-# GPU box: kernel trace of the config-5 chain (bench.py --workload pipeline).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/prof_pipeline
-rm -rf $out; mkdir -p $out
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/bench.py --workload pipeline --steps 3 --warmup 1 > $out/bench_trace.json 2> $out/trace.err
-f=$(find $out/trace -name '*kernel_stats.csv' | head -1)
-cp $f $out/kernel_stats.csv
-head -20 $f | cut -c1-200
+rm -rf /tmp/pp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $R/bench.py --workload pipeline --steps 5 --warmup 2 > /tmp/pp.json 2> /tmp/pp.err
+f=$(ls -t /tmp/pp/*/*kernel_stats.csv | head -1)
+cat /tmp/pp.json | head -c 1500; echo
+python3 - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if float(r["Percentage"]) > 0.3:
+        print(f'   {r["Name"][:100]:100s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:9.1f} us  {r["Percentage"]} %')
+PY
+cp $f $R/gpurun_out/r04_pipeline_kernel_stats.csv
