@@ -147,6 +147,22 @@ def test_vcheck_on_wide_lines(dev, oracle, w):
         assert np.array_equal(got, oracle.eedi3(src, 1, **kw)), kw
 
 
+@pytest.mark.parametrize("w", [1919, 1921, 2047, 2048, 2049, 2160, 2559, 2560, 2561, 3000])
+def test_vcheck_chain_kernels_by_line_width(dev, oracle, w):
+    """The vertical-consistency chain runs from LDS rings with two columns a thread up to 2048 samples a line, three up to 2560 (round 4: the second pass
+    of a 2x upscale of 1080p is 2160 wide), from global memory beyond: every width around the switches, enough lines for two turns of the nine-line
+    ring period, with an sclip and half-pel directions too."""
+    rng = np.random.default_rng(w)
+    src = fx.tiled_natural((48, w), np.float32, 1) + rng.random((48, w)).astype(np.float32) * np.float32(0.05)
+    sc = rng.random((96, w)).astype(np.float32)
+    for kw in (dict(), dict(vcheck=3, dh=True), dict(vcheck=1, hp=True, mdis=6)):
+        got = _gpu(dev, src, 1, **kw)
+        assert np.array_equal(got, oracle.eedi3(src, 1, **kw)), (w, kw)
+    s, c = dev.upload(np.ascontiguousarray(src)), dev.upload(sc)
+    (d,) = dev.eedi3([s], 0, dh=True, sclips=[c])
+    assert np.array_equal(dev.download(d), oracle.eedi3(src, 0, dh=True, sclip=sc)), w
+
+
 @pytest.mark.parametrize("w", [5, 8, 17, 31, 43, 45, 63])
 @pytest.mark.parametrize("kw", [dict(), dict(hp=True), dict(mdis=40, nrad=3), dict(mdis=31, nrad=0, vcheck=3), dict(dh=True)],
                          ids=["default", "hp", "mdis40", "mdis31", "dh"])

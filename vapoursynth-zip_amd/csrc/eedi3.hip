@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_wide_kernel(const VParams p
     }
 }
 
-constexpr int kVcLdsMaxL = 1920;
+constexpr int kVcLdsMaxL = 2560;  // widest line of the LDS chain kernel (three columns a thread at a 2560-sample row pitch: 156 KB); up to 2048: two columns, 2048-sample pitch
 // The per-line step is paced by instruction issue on ONE CU (PMC: 214 scalar + 126 vector
 // instructions per wave and line before this form), so the kernel is specialised on hp and the
 // vcheck mode, the pixel function is branch-free (a pixel that keeps cint gathers around itself and
@@ -1470,9 +1470,9 @@ __device__ __forceinline__ float vcheck_pixel_bf(const VParams &prm, int L, int 
 #define VSZIP_VC_NT 1024
 #endif
 constexpr int kVcNT = VSZIP_VC_NT;  // threads of a chain workgroup
-template <bool HP, int VC>
+template <bool HP, int VC, int C>  // C: columns per thread (2: lines up to 2048 samples, 3: up to 2560 — the second pass of a 2x upscale of 1080p is 2160 wide)
 __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams prm) {
-    constexpr int C = 2048 / kVcNT;  // columns per thread: lines up to 2048 (LDS allows 1920)
+    static_assert(kVcNT == 1024 && (C == 2 || C == 3), "rows of C * 1024 samples, padded to the pitch below");
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     const int pslot = prm.plane_base + (int)blockIdx.x;
     const EPlane pl = prm.p[pslot];
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
     constexpr int kRing = 9, kBlend = 3, kMapRing = 9;
     float *ring = reinterpret_cast<float *>(vsm);
     // rows lie kPitch samples apart whatever the line's width: a slot's offset is then a compile-time constant that folds into the LDS instructions' immediates
-    constexpr int kPitch = kVcLdsMaxL;
+    constexpr int kPitch = C == 2 ? 2048 : kVcLdsMaxL;
     float *blend = ring + (size_t)kRing * kPitch;
     float *spare = blend + (size_t)kBlend * kPitch;  // where stores that are not due go
     int8_t *dring = reinterpret_cast<int8_t *>(spare + kPitch);
@@ -1849,12 +1849,20 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
     const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !ctx->opt.vcheck_global;
     auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
-        const size_t lds = (size_t)kVcLdsMaxL * (13 * sizeof(float) + 9);  // nine ring rows, three blended rows, a spare row, nine int8 map rows, at the fixed pitch
+        const int cols = maxL <= 2048 ? 2 : 3;
+        const size_t lds = (size_t)(cols == 2 ? 2048 : kVcLdsMaxL) * (13 * sizeof(float) + 9);  // nine ring rows, three blended rows, a spare row, nine int8 map rows, at the fixed pitch
         vp.plane_base = first;
-#define VSZIP_VC_LAUNCH1(HPV, VCV)                                                                                                                    \
+#define VSZIP_VC_LAUNCH2(HPV, VCV, CV)                                                                                                                \
     do {                                                                                                                                              \
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eedi3_vcheck_lds_kernel<HPV, VCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, VCV>), dim3(count), dim3(kVcNT), lds, st, vp);                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eedi3_vcheck_lds_kernel<HPV, VCV, CV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, VCV, CV>), dim3(count), dim3(kVcNT), lds, st, vp);                                          \
+    } while (0)
+#define VSZIP_VC_LAUNCH1(HPV, VCV)            \
+    do {                                      \
+        if (cols == 2)                        \
+            VSZIP_VC_LAUNCH2(HPV, VCV, 2);    \
+        else                                  \
+            VSZIP_VC_LAUNCH2(HPV, VCV, 3);    \
     } while (0)
 #define VSZIP_VC_LAUNCH(HPV)                  \
     do {                                      \
@@ -1869,6 +1877,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
             VSZIP_VC_LAUNCH(true);
         else
             VSZIP_VC_LAUNCH(false);
+#undef VSZIP_VC_LAUNCH2
 #undef VSZIP_VC_LAUNCH1
 #undef VSZIP_VC_LAUNCH
     };
