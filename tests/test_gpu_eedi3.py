@@ -147,11 +147,11 @@ def test_vcheck_on_wide_lines(dev, oracle, w):
         assert np.array_equal(got, oracle.eedi3(src, 1, **kw)), kw
 
 
-@pytest.mark.parametrize("w", [1919, 1921, 2047, 2048, 2049, 2160, 2559, 2560, 2561, 3000])
+@pytest.mark.parametrize("w", [1919, 1921, 2047, 2048, 2049, 2160, 2559, 2560, 2561, 3000, 3840, 4095, 4096])
 def test_vcheck_chain_kernels_by_line_width(dev, oracle, w):
     """The vertical-consistency chain runs from LDS rings with two columns a thread up to 2048 samples a line, three up to 2560 (round 4: the second pass
-    of a 2x upscale of 1080p is 2160 wide), from global memory beyond: every width around the switches, enough lines for two turns of the nine-line
-    ring period, with an sclip and half-pel directions too."""
+    of a 2x upscale of 1080p is 2160 wide), four up to 4096 (the luma of a 4K frame), from global memory beyond (test_vcheck_on_wide_lines): every width
+    around the switches, enough lines for several turns of the six-line ring period, with an sclip and half-pel directions too."""
     rng = np.random.default_rng(w)
     src = fx.tiled_natural((48, w), np.float32, 1) + rng.random((48, w)).astype(np.float32) * np.float32(0.05)
     sc = rng.random((96, w)).astype(np.float32)

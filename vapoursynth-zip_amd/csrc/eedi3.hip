@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(1024) void eedi3_vcheck_wide_kernel(const VParams p
     }
 }
 
-constexpr int kVcLdsMaxL = 2560;  // widest line of the LDS chain kernel (three columns a thread at a 2560-sample row pitch: 156 KB); up to 2048: two columns, 2048-sample pitch
+constexpr int kVcLdsMaxL = 4096;  // widest line of the LDS chain kernel (four columns a thread)
 // The per-line step is paced by instruction issue on ONE CU (PMC: 214 scalar + 126 vector
 // instructions per wave and line before this form), so the kernel is specialised on hp and the
 // vcheck mode, the pixel function is branch-free (a pixel that keeps cint gathers around itself and
@@ -1466,138 +1466,134 @@ __device__ __forceinline__ float vcheck_pixel_bf(const VParams &prm, int L, int 
     return act ? blended : cint;
 }
 
-#ifndef VSZIP_VC_NT
-#define VSZIP_VC_NT 1024
-#endif
-constexpr int kVcNT = VSZIP_VC_NT;  // threads of a chain workgroup
-template <bool HP, int VC, int C>  // C: columns per thread (2: lines up to 2048 samples, 3: up to 2560 — the second pass of a 2x upscale of 1080p is 2160 wide)
+constexpr int kVcNT = 1024;  // threads of a chain workgroup (512 / 256 with more columns a thread measured 18 % / 90 % slower: the step is one wave's instruction stream)
+// Round 4. ONE barrier per line: nothing a line writes is anything it reads — the blended lines alternate between two rows of their own (line pd reads
+// pd - 2 from one and writes pd to the other), new rows go to slots no read of this line touches. The rings hold only what a line GATHERS from: the rows
+// pd -+ 3 are only ever read at the thread's own columns (the cubic of `cint`), so they stay in registers — pd + 3 is the odd row of the prefetch set of line
+// off + 1, pd - 3 a copy kept from the set of line off - 2 — and LDS holds three odd rows (pd - 1, pd + 1; pd + 3 written), three even ones (pd, pd + 2;
+// pd + 4 written), two blended lines and six map rows: 38 bytes a column, so that FOUR columns a thread (lines up to 4096 samples: the luma of a 4K frame)
+// fit the 160 KB. All ring periods divide six lines and the rings are addressed relative to the chain's first line at a fixed row pitch: in the 6x unrolled
+// loop every slot is a compile-time offset that folds into the LDS instructions' immediates (the per-line slot arithmetic was a quarter of the step's
+// instructions, and the step is bound by one wave's instruction stream: profiles/r04_notes.md section 10).
+// The rows a line adds (pd + 3, pd + 4, the map row off + 2, its sclip row) are loaded kAhead lines ahead into register sets addressed round robin (no
+// moves: a move of a register that a load is still writing waits for the load) with unconditional, clamped loads (row pointer (scalar) + 32-bit lane offset),
+// so that the compiler can count: the wait in front of a set's first use leaves the younger sets' loads in flight. Stores carry no lane masks or branches.
+// C: columns per thread (2: lines up to 2048 samples, 3: up to 2560 — the second pass of a 2x upscale of 1080p is 2160 wide —, 4: up to 4096).
+// SC: an sclip is present (its row rides in the prefetch sets; without one the sets are a quarter smaller).
+template <bool HP, int VC, int C, bool SC>
 __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams prm) {
-    static_assert(kVcNT == 1024 && (C == 2 || C == 3), "rows of C * 1024 samples, padded to the pitch below");
+    static_assert(kVcNT == 1024 && C >= 2 && C <= 4, "rows of C * 1024 samples");
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     const int pslot = prm.plane_base + (int)blockIdx.x;
     const EPlane pl = prm.p[pslot];
-    const float *scp = prm.scp[pslot];
-    const int scstride = prm.scstride[pslot];
+    const float *scp = SC ? prm.scp[pslot] : nullptr;  // (a plane without one in a launch that has some: its rows are loaded from the plane and not used)
+    const float *scsrc = scp ? scp : pl.dst;
+    const int scstride = scp ? prm.scstride[pslot] : pl.dstride;
     const int L = pl.w, n_dst = pl.n_dst;
     const int tid = threadIdx.x;
-    // Round 4: ONE barrier per line. The blended line pd used to overwrite the un-blended one in its ring slot, and the rows pd+4 / pd+5 took
-    // the slots of rows pd-3 / pd-2 — all three read by this very line, so a barrier had to separate the line's reads from its writes and a
-    // second one its writes from the next line's reads. Now nothing a line writes is anything it reads: the blended lines alternate between two
-    // rows of their own (line pd reads pd-2 from one and writes pd to the other) and the ring holds nine rows (pd-3 .. pd+5).
-    // All rings have periods that divide nine lines (the rows' ring: 9 slots, two rows a line; blended lines: 3; map rows: 9; the prefetch sets: 3) and are
-    // addressed RELATIVE to the chain's first line, so in a loop unrolled nine times every slot is a compile-time multiple of L: the per-line slot
-    // arithmetic (a quarter of the step's instructions, and the step is bound by one wave's instruction stream) is gone.
-    constexpr int kRing = 9, kBlend = 3, kMapRing = 9;
-    float *ring = reinterpret_cast<float *>(vsm);
-    // rows lie kPitch samples apart whatever the line's width: a slot's offset is then a compile-time constant that folds into the LDS instructions' immediates
-    constexpr int kPitch = C == 2 ? 2048 : kVcLdsMaxL;
-    float *blend = ring + (size_t)kRing * kPitch;
-    float *spare = blend + (size_t)kBlend * kPitch;  // where stores that are not due go
-    int8_t *dring = reinterpret_cast<int8_t *>(spare + kPitch);
-    // processed lines form one contiguous range of interpolated-line indices (:921-925)
-    int first = 1, last = pl.n_interp - 2;
+    constexpr int kPitch = C == 2 ? 2048 : C == 3 ? 2560 : 4096;  // fixed: slot offsets are compile-time constants
+    constexpr int kOdd = 3, kEven = 3, kBlend = 2, kMapRing = 6, kAhead = 3, kPeriod = 6;
+    float *odd = reinterpret_cast<float *>(vsm);           // odd rows (kept field lines): row pd - 1 + 2 k of line q in slot (q + k) % 3
+    float *even = odd + (size_t)kOdd * kPitch;             // interpolated, un-blended: row pd + 2 k in slot (q + k) % 3
+    float *blend = even + (size_t)kEven * kPitch;          // blended: line q reads slot (q + 1) & 1 (row pd - 2), writes slot q & 1
+    int8_t *dring = reinterpret_cast<int8_t *>(blend + (size_t)kBlend * kPitch);  // map row off + d in slot (q + d) % 6
+    int first = 1, last = pl.n_interp - 2;  // (:921-925)
     while (first <= last && prm.field + 2 * first < 2) ++first;
     while (last >= first && prm.field + 2 * last + 2 >= n_dst) --last;
     if (first > last) return;
-    {
-        const int pd0 = prm.field + 2 * first;
-        for (int k = 0; k <= 6; ++k) {  // row pd0 - 3 + k -> ring slot k; the line pd0 - 2 (not part of the chain, or blended by an earlier launch) -> blended slot kBlend - 1
-            const int r = pd0 - 3 + k;
-            if (r < 0 || r >= n_dst) continue;
-            const float *g = pl.dst + (size_t)r * pl.dstride;
-            float *d = k == 1 ? blend + (size_t)(kBlend - 1) * kPitch : ring + (size_t)k * kPitch;
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                if (tid + c * kVcNT < L) d[tid + c * kVcNT] = g[tid + c * kVcNT];
-        }
-        for (int k = -1; k <= 1; ++k) {  // map row first + k -> slot (k + kMapRing) % kMapRing
-            const int *g = pl.dmap + (size_t)(first + k) * L;
-            int8_t *d = dring + (size_t)((k + kMapRing) % kMapRing) * kPitch;
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                if (tid + c * kVcNT < L) d[tid + c * kVcNT] = (int8_t)g[tid + c * kVcNT];
-        }
-    }
-    __syncthreads();
-    // The rows a line adds to the ring (pd+4, pd+5, the map row off+2, its sclip row) are loaded kAhead lines ahead and parked in registers.
-    // Round 4: the loop used to rotate two register sets with moves (a <- b at the end of a line), and a move of a register that a load is
-    // still writing waits for the load: every line waited out the global-memory latency of the loads it had just issued (s_waitcnt vmcnt(0) at
-    // the loop header — 1.7 us a line whatever the line's width). Now the sets are addressed round robin in a loop unrolled kAhead times (no
-    // moves) and every load is unconditional (clamped addresses instead of branches), so that the compiler can count: the wait in front of a
-    // set's first use leaves the younger sets' loads in flight.
-    constexpr int kAhead = 3;
-    float n4[kAhead][C], n5[kAhead][C], nsc[kAhead][C];  // set (o - first) % kAhead: the new rows of line o (line o-1 stores them at its end)
-    int nd[kAhead][C];
-    const float *scsrc = scp ? scp : pl.dst;  // (no sclip: any readable row, the value is not used)
-    const size_t scpitch = scp ? (size_t)scstride : (size_t)pl.dstride;
-    uint32_t icl[C];  // the thread's columns, clamped into the line, as BYTE offsets: a load is row pointer (scalar) + 32-bit lane offset
+    const int pd0 = prm.field + 2 * first;
+    uint32_t icl[C];  // the thread's columns, clamped into the line, as byte offsets
 #pragma unroll
     for (int c = 0; c < C; ++c) icl[c] = 4u * (uint32_t)min(tid + c * kVcNT, L - 1);
     auto at = [](const void *rowp, uint32_t byte_off) { return *reinterpret_cast<const uint32_t *>(static_cast<const char *>(rowp) + byte_off); };
-    auto fetch = [&](int o, float *q4, float *q5, int *qd, float *qsc) __attribute__((always_inline)) {
-        const int oc = min(o, last);  // past the chain: a valid line, loaded and never stored
-        const int pdo = prm.field + 2 * oc;
-        const float *p4 = pl.dst + (size_t)min(pdo + 2, n_dst - 1) * pl.dstride, *p5 = pl.dst + (size_t)min(pdo + 3, n_dst - 1) * pl.dstride;
-        const int *pm = pl.dmap + (size_t)(oc + 1) * L;
-        const float *ps = scsrc + (size_t)pdo * scpitch;
+    auto rowp = [&](int r) { return pl.dst + (size_t)min(max(r, 0), n_dst - 1) * pl.dstride; };
+    {   // rows pd0 - 1 .. pd0 + 2 and the (already final) line pd0 - 2; map rows first - 1 .. first + 1
+        const float *g[5] = {rowp(pd0 - 1), rowp(pd0 + 1), rowp(pd0), rowp(pd0 + 2), rowp(pd0 - 2)};
+        float *d[5] = {odd, odd + kPitch, even, even + kPitch, blend + kPitch};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) d[k][icl[c] >> 2] = __uint_as_float(at(g[k], icl[c]));
+#pragma unroll
+        for (int k = -1; k <= 1; ++k) {
+            const int *gm = pl.dmap + (size_t)(first + k) * L;
+            int8_t *dm = dring + (size_t)((k + kMapRing) % kMapRing) * kPitch;
+#pragma unroll
+            for (int c = 0; c < C; ++c) dm[icl[c] >> 2] = (int8_t)at(gm, icl[c]);
+        }
+    }
+    // own-column copies of the odd rows behind the window: hist[(q + 1) % 3] is row pd - 3 of line q (the reflected row 1 for row -1)
+    float hist[3][C];
+    {
+        const float *h1 = rowp(pd0 - 3 < 0 ? pd0 - 1 : pd0 - 3), *h2 = rowp(pd0 - 1), *h0 = rowp(pd0 + 1);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            asm("" : "+v"(icl[c]));  // keeps the offset's zero-extension in this block, where instruction selection can fold it into the load (saddr + 32-bit voffset)
-            q4[c] = __uint_as_float(at(p4, icl[c]));
-            q5[c] = __uint_as_float(at(p5, icl[c]));
+            hist[1][c] = __uint_as_float(at(h1, icl[c]));
+            hist[2][c] = __uint_as_float(at(h2, icl[c]));
+            hist[0][c] = __uint_as_float(at(h0, icl[c]));
+        }
+    }
+    __syncthreads();
+    // prefetch set of line o (stored by line o - 1): rows pdo + 1 (odd) and pdo + 2 (even), map row o + 1, the sclip row pdo. A row past the plane is the row the
+    // reference reflects onto when it is read as pd + 3 (n_dst -> n_dst - 2) and anything valid otherwise (never used).
+    float so[kAhead][C], se[kAhead][C], ssc[kAhead][SC ? C : 1];
+    int sd[kAhead][C];
+    auto fetch = [&](int o, float *qo, float *qe, int *qd, float *qsc) __attribute__((always_inline)) {
+        const int pdo = prm.field + 2 * o;
+        const int ro = pdo + 1 < n_dst ? pdo + 1 : 2 * (n_dst - 1) - (pdo + 1);
+        const float *po = rowp(ro), *pe = rowp(pdo + 2);
+        const int *pm = pl.dmap + (size_t)min(o + 1, pl.n_interp - 1) * L;
+        const float *ps = SC ? scsrc + (size_t)min(pdo, n_dst - 1) * scstride : nullptr;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            asm("" : "+v"(icl[c]));  // (keeps the offset's zero-extension in this block: saddr + 32-bit voffset loads)
+            qo[c] = __uint_as_float(at(po, icl[c]));
+            qe[c] = __uint_as_float(at(pe, icl[c]));
             qd[c] = (int)at(pm, icl[c]);
-            qsc[c] = __uint_as_float(at(ps, icl[c]));
+            if constexpr (SC) qsc[c] = __uint_as_float(at(ps, icl[c]));
         }
     };
-    float sc[C];
+    float sc[SC ? C : 1];
+    if constexpr (SC) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) sc[c] = scsrc[(size_t)(prm.field + 2 * first) * scpitch + min(tid + c * kVcNT, L - 1)];
+        for (int c = 0; c < C; ++c) sc[c] = __uint_as_float(at(scsrc + (size_t)pd0 * scstride, icl[c]));
+    }
 #pragma unroll
-    for (int j = 1; j < kAhead; ++j) fetch(first + j, n4[j], n5[j], nd[j], nsc[j]);
-    constexpr int kPeriod = 9;
+    for (int j = 1; j < kAhead; ++j) fetch(first + j, so[j], se[j], sd[j], ssc[j]);
     for (int off0 = first; off0 <= last; off0 += kPeriod) {
         static_for<0, kPeriod - 1, 1>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;  // (off - first) mod 9
+            constexpr int j = decltype(jc)::value;  // q mod 6, q = off - first
             const int off = off0 + j;
             if (off > last) return;
-            constexpr int js = j % kAhead, jn = (j + 1) % kAhead;  // the sets of lines off + kAhead (loaded now) and off + 1 (stored at the end)
-            auto slot = [&](int k) -> float * { return ring + (size_t)((2 * j + k) % kRing) * kPitch; };  // row pd - 3 + k
-            auto dmr = [&](int d) -> int8_t * { return dring + (size_t)((j + d + kMapRing) % kMapRing) * kPitch; };  // map row off + d
-            const int pd = prm.field + 2 * off;
-            const bool nxt = off + 1 <= last;
-            fetch(off + kAhead, n4[js], n5[js], nd[js], nsc[js]);  // (set js held line off's rows: stored by line off-1)
-            const float *d2p = blend + (size_t)((j + kBlend - 1) % kBlend) * kPitch, *d1p = slot(2), *dl = slot(3), *d1n = slot(4), *d2n = slot(5);
-            // rows pd-3 / pd+3 reflect at the frame border (only the first / last line of the chain). The chain's range keeps 2 <= pd and pd + 2 < n_dst,
-            // so the only rows ever reflected are -1 -> 1 = pd - 1 and n_dst -> n_dst - 2 = pd + 1: both in the ring (no reflect_row loop per line)
-            const float *d3p = ring + (pd - 3 >= 0 ? (uint32_t)((2 * j + 0) % kRing) : (uint32_t)((2 * j + 2) % kRing)) * kPitch;
-            const float *d3n = ring + (pd + 3 < n_dst ? (uint32_t)((2 * j + 6) % kRing) : (uint32_t)((2 * j + 4) % kRing)) * kPitch;
+            constexpr int js = j % kAhead, jn = (j + 1) % kAhead;  // the sets of lines off + kAhead (loaded now) and off + 1 (stored at the end; its odd row is pd + 3)
+            fetch(off + kAhead, so[js], se[js], sd[js], ssc[js]);
+            const float *d1p = odd + (size_t)(j % kOdd) * kPitch, *d1n = odd + (size_t)((j + 1) % kOdd) * kPitch;
+            const float *dl = even + (size_t)(j % kEven) * kPitch, *d2n = even + (size_t)((j + 1) % kEven) * kPitch;
+            const float *d2p = blend + (size_t)((j + 1) & 1) * kPitch;
+            auto dmr = [&](int d) -> int8_t * { return dring + (size_t)((j + d + kMapRing) % kMapRing) * kPitch; };
             const int8_t *dc = dmr(0), *dp = dmr(-1), *dn = dmr(1);
             float res[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const int i = min(tid + c * kVcNT, L - 1);  // threads past the line compute on its last column and store nothing
-                const float cint = scp ? sc[c] : 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (d3p[i] + d3n[i]);
+                const int i = (int)(icl[c] >> 2);
+                const float cubic = 0.5625f * (d1p[i] + d1n[i]) - 0.0625f * (hist[(j + 1) % 3][c] + so[jn][c]);
+                const float cint = (SC && scp) ? sc[SC ? c : 0] : cubic;
                 res[c] = vcheck_pixel_bf<HP, VC>(prm, L, i, dc[i], dp[i], dn[i], cint, d1p, d1n, dl, d2p, d2n);
             }
-            // No lane masks and no branches in the stores: a thread past the line has computed the line's last column from the same inputs as the
-            // thread that owns it and stores the same values there; rows that are not due (past the chain or the plane) go to a spare row.
-            float *gout = pl.dst + (size_t)pd * pl.dstride;
-            // (offsets from ONE LDS base, selected as integers: a select between pointers would make them generic pointers)
-            constexpr uint32_t kSpareOff = (uint32_t)(kRing + kBlend) * kPitch;
-            const uint32_t o4 = (nxt && pd + 4 < n_dst) ? (uint32_t)((2 * j + 7) % kRing) * kPitch : kSpareOff;  // rows pd+4 / pd+5
-            const uint32_t o5 = (nxt && pd + 5 < n_dst) ? (uint32_t)((2 * j + 8) % kRing) * kPitch : kSpareOff;
-            const uint32_t od = nxt ? (uint32_t)(kRing + kBlend + 1) * kPitch * 4u + (uint32_t)((j + 2) % kMapRing) * kPitch : kSpareOff * 4u;  // (bytes) map row off + 2
-            float *blw = blend + (size_t)(j % kBlend) * kPitch;
-            int8_t *ring8 = reinterpret_cast<int8_t *>(ring);
+            // (a thread past the line repeats the last column's stores; the rows of a line past the chain go to their slots and are never read)
+            float *gout = pl.dst + (size_t)(prm.field + 2 * off) * pl.dstride;
+            float *blw = blend + (size_t)(j & 1) * kPitch, *ow = odd + (size_t)((j + 2) % kOdd) * kPitch, *ew = even + (size_t)((j + 2) % kEven) * kPitch;
+            int8_t *dnew = dmr(2);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const uint32_t i = icl[c] >> 2;
                 blw[i] = res[c];
                 gout[i] = res[c];
-                ring[o4 + i] = n4[jn][c];
-                ring[o5 + i] = n5[jn][c];
-                ring8[od + i] = (int8_t)nd[jn][c];
-                if (scp) sc[c] = nsc[jn][c];
+                ow[i] = so[jn][c];
+                ew[i] = se[jn][c];
+                dnew[i] = (int8_t)sd[jn][c];
+                hist[(j + 1) % 3][c] = so[jn][c];
+                if constexpr (SC) sc[c] = ssc[jn][c];
             }
             __syncthreads();  // the line's writes against the next line's reads
         });
@@ -1849,20 +1845,31 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
     const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !ctx->opt.vcheck_global;
     auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
-        const int cols = maxL <= 2048 ? 2 : 3;
-        const size_t lds = (size_t)(cols == 2 ? 2048 : kVcLdsMaxL) * (13 * sizeof(float) + 9);  // nine ring rows, three blended rows, a spare row, nine int8 map rows, at the fixed pitch
+        const int cols = maxL <= 2048 ? 2 : maxL <= 2560 ? 3 : 4;
+        bool any_sc = false;
+        for (int i = first; i < first + count; ++i) any_sc = any_sc || vp.scp[i] != nullptr;
         vp.plane_base = first;
-#define VSZIP_VC_LAUNCH2(HPV, VCV, CV)                                                                                                                \
+        const size_t lds = (size_t)(cols == 2 ? 2048 : cols == 3 ? 2560 : 4096) * (8 * sizeof(float) + 6);  // three odd, three even, two blended rows, six int8 map rows
+#define VSZIP_VC_LAUNCH3(HPV, VCV, CV, SCV)                                                                                                          \
     do {                                                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eedi3_vcheck_lds_kernel<HPV, VCV, CV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, VCV, CV>), dim3(count), dim3(kVcNT), lds, st, vp);                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eedi3_vcheck_lds_kernel<HPV, VCV, CV, SCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((eedi3_vcheck_lds_kernel<HPV, VCV, CV, SCV>), dim3(count), dim3(kVcNT), lds, st, vp);                                    \
+    } while (0)
+#define VSZIP_VC_LAUNCH2(HPV, VCV, CV)        \
+    do {                                      \
+        if (any_sc)                           \
+            VSZIP_VC_LAUNCH3(HPV, VCV, CV, true);  \
+        else                                  \
+            VSZIP_VC_LAUNCH3(HPV, VCV, CV, false); \
     } while (0)
 #define VSZIP_VC_LAUNCH1(HPV, VCV)            \
     do {                                      \
         if (cols == 2)                        \
             VSZIP_VC_LAUNCH2(HPV, VCV, 2);    \
-        else                                  \
+        else if (cols == 3)                   \
             VSZIP_VC_LAUNCH2(HPV, VCV, 3);    \
+        else                                  \
+            VSZIP_VC_LAUNCH2(HPV, VCV, 4);    \
     } while (0)
 #define VSZIP_VC_LAUNCH(HPV)                  \
     do {                                      \
@@ -1877,6 +1884,7 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
             VSZIP_VC_LAUNCH(true);
         else
             VSZIP_VC_LAUNCH(false);
+#undef VSZIP_VC_LAUNCH3
 #undef VSZIP_VC_LAUNCH2
 #undef VSZIP_VC_LAUNCH1
 #undef VSZIP_VC_LAUNCH
