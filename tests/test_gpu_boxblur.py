@@ -405,3 +405,46 @@ def test_ct_u8_sixteen_pixels_a_lane(dev, oracle, r):
             want = oracle.boxblur(p, r, 1, r, 1)
             assert np.array_equal(a, want), (r, shapes, p.shape, int((a != want).sum()), np.argwhere(a != want)[:4].tolist())
             assert np.array_equal(b, want), (r, shapes, p.shape, "8 pixels a lane")
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("r", [1, 5, 13, 19, 20, 22])
+def test_ct_ring_planes_split_by_columns(dev, oracle, dtype, r):
+    """Round 4: a plane whose width is not whole pixel groups is split by columns — the tiles whose every lane lies inside the plane go to the fast ring
+    kernel (8 or 16 pixels a lane), the last one or two to the general form — instead of sending the whole batch to the general form. Widths around every
+    boundary of the split for both lane widths (a tile is all inside iff t * TWO - HL + 64 * PX <= w), batches that mix aligned and unaligned planes
+    (1918 x 1078 and 1366 x 768 YUV 4:2:0 clips: 959- and 683-sample chroma), one-sample-over and one-sample-short widths, bit for bit against the oracle
+    and against the 8-pixels-a-lane path for 8-bit planes."""
+    px = 8
+    hl = (r + 1 + px - 1) // px * px
+    hr = (r + px - 1) // px * px
+    two8 = (64 - hl // px - hr // px) * px
+    first8 = 64 * px - hl  # narrowest width with one all-inside tile
+    widths = [first8 - 1, first8, first8 + 1, first8 + 7, first8 + two8 - 1, first8 + two8, first8 + two8 + 3, 2 * two8 + 5]
+    if dtype == np.uint8:
+        hl16 = (r + 1 + 15) // 16 * 16
+        hr16 = (r + 15) // 16 * 16
+        two16 = (64 - hl16 // 16 - hr16 // 16) * 16
+        first16 = 64 * 16 - hl16
+        widths += [first16 - 1, first16, first16 + 1, first16 + 9, first16 + two16 + 1]
+    batches = [[(64, w)] for w in widths] + [[(270, 1918), (135, 959), (135, 959)], [(96, 1366), (64, 683), (64, 683), (96, 1280)], [(60, 1920), (60, 1913)]]
+    for shapes in batches:
+        if min(min(sh) for sh in shapes) <= 2 * r:
+            continue
+        planes = [fx.splitmix64_plane(170 + i + r, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
+
+        def run():
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+            dev.boxblur(srcs, dsts, r, 1, r, 1)
+            return [dev.download(d) for d in dsts]
+
+        got = run()
+        for p, a in zip(planes, got):
+            want = oracle.boxblur(p, r, 1, r, 1)
+            assert np.array_equal(a, want), (r, shapes, p.shape, int((a != want).sum()), np.argwhere(a != want)[:4].tolist())
+        if dtype == np.uint8:
+            with dev.options(VSZIP_CT_U8_PX8=1):
+                narrow = run()
+            for a, b in zip(got, narrow):
+                assert np.array_equal(a, b), (r, shapes, "8 pixels a lane")

@@ -78,6 +78,7 @@ struct BBPlane {
     int ntx;     // column tiles
     int nbands;  // row bands
     int nperiods;  // ring kernel: ring periods covering the plane, ceil(h / NR), split evenly over the bands
+    int cx0;       // ring kernel: plane column of this launch's first tile (a plane may be split between two launches by columns)
 };
 
 struct BBParams {
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     st.dstb = static_cast<char *>(pl.dst);
     const int lane = threadIdx.x;
     st.lane = lane;
-    const int vc0 = tx * G::TWO - G::HL + lane * PXN;  // first (virtual) plane column of this lane
+    const int vc0 = pl.cx0 + tx * G::TWO - G::HL + lane * PXN;  // first (virtual) plane column of this lane
     st.c0 = vc0;
     st.is_out = lane >= G::HL / PXN && lane < G::HL / PXN + G::OUT_LANES && vc0 < w;
     st.doff = (uint32_t)(max(vc0, 0) * (int)sizeof(T));
@@ -898,18 +899,30 @@ int launch_ct_int(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     return VSZIP_OK;
 }
 
-template <typename T, int R, int PXN = 8>
-int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
+// columns [cx0, cx0 + ntx * TWO) of a plane (ntx == 0: nothing of this plane in this launch)
+struct RingSpan {
+    int cx0, ntx;
+};
+
+// One kernel instance over the given column spans of the planes. GEN = false is the fast form: every lane of every tile it is given must hold a whole pixel
+// group inside the plane or its left mirror image (the caller's rule); GEN = true takes any width and any tile.
+template <typename T, int R, int PXN, bool GEN>
+int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const RingSpan *all_spans, int nall) {
     using G = typename RingWave<T, R, false, PXN>::G;
+    std::vector<vszip_plane> planes_v;
+    std::vector<RingSpan> spans_v;
+    for (int i = 0; i < nall; ++i)
+        if (all_spans[i].ntx > 0) {
+            planes_v.push_back(all_planes[i]);
+            spans_v.push_back(all_spans[i]);
+        }
+    const vszip_plane *planes = planes_v.data();
+    const RingSpan *spans = spans_v.data();
+    const int nplanes = (int)planes_v.size();
     int done = 0;
     while (done < nplanes) {
         RingParams prm;
         const int n = std::min(kRingMaxPlanes, nplanes - done);
-        bool mult8 = true;
-        for (int i = 0; i < n; ++i) {
-            const vszip_plane &s = planes[done + i];
-            mult8 = mult8 && (s.w % PXN == 0);
-        }
         // Band length: every plane is cut into bands of about `target` ring periods. The choice
         // trades re-read halo rows (2r+D per band: shorter bands = more traffic) against how well
         // the waves fill the chip's wave slots over time: with W waves of up to max_len periods
@@ -928,7 +941,7 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
                 const vszip_plane &s = planes[done + i];
                 const int P = (s.h + G::NR - 1) / G::NR;
                 const int nb = bands_for(s.h, P, target);
-                const double ntx = (double)((s.w + G::TWO - 1) / G::TWO);
+                const double ntx = (double)spans[done + i].ntx;
                 work += ntx * (P + nb * halo_p);
                 waves += ntx * nb;
                 max_len = std::max(max_len, (double)((P + nb - 1) / nb) + halo_p);
@@ -969,7 +982,8 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             d.h = s.h;
             d.nperiods = (s.h + G::NR - 1) / G::NR;
             d.nbands = bands_for(s.h, d.nperiods, target);
-            d.ntx = (s.w + G::TWO - 1) / G::TWO;
+            d.ntx = spans[done + i].ntx;
+            d.cx0 = spans[done + i].cx0;
             d.block0 = blocks;
             if (blocks + d.ntx * d.nbands > kRingMaxBlocks) {  // very wide planes: the rest of the batch goes into the next launch
                 if (i == 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: launch table overflow (%d blocks)", blocks + d.ntx * d.nbands);
@@ -984,14 +998,7 @@ int launch_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         const dim3 grid(((blocks + 7) / 8) * 8);
         {
             vszip_probe_scope probe(ctx);
-            if constexpr (PXN == 16) {  // (the caller checked: every width is whole 16-pixel groups)
-                hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false, 16>), grid, dim3(64), 0, ctx->stream, prm);
-            } else {
-                if (mult8)
-                    hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, false>), grid, dim3(64), 0, ctx->stream, prm);
-                else
-                    hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, true>), grid, dim3(64), 0, ctx->stream, prm);
-            }
+            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, GEN, PXN>), grid, dim3(64), 0, ctx->stream, prm);
         }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
         done += fit;
@@ -1015,8 +1022,7 @@ bool ring_ok(const vszip_plane *planes, int nplanes) {
     return true;
 }
 
-// 8-bit planes take 16 pixels a lane when every plane is whole 16-pixel groups on 16-byte aligned rows (every VapourSynth frame of an even-width-16
-// clip: 1920, 3840, 960 ... wide planes; a 1080p clip's 960-wide chroma as well)
+// 8-bit planes take 16 pixels a lane when their rows are 16-byte aligned (every VapourSynth frame) and no plane is narrower than 32 samples.
 // Up to r = 19: beyond, the ring (2r + 1 + D slots of four VGPRs) leaves no room for two waves a SIMD and the instance spills
 // (64 4K YUV420P8 frames, 16 against 8 pixels a lane, tools/u8_px16_sweep.py: r = 1 ... 7 -10 ... -12 % of the time, 8 ... 16 -4 ... -8 %, 17 ... 19 -11 ... -13 %,
 // 20 ... 22 +12 ... +17 %)
@@ -1026,10 +1032,43 @@ bool ring16_ok(const vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     if (sizeof(T) != 1 || ctx->opt.ct_u8_px8) return false;
     for (int i = 0; i < nplanes; ++i) {
         const vszip_plane &p = planes[i];
-        if (p.w % 16 != 0 || p.w < 32) return false;
+        if (p.w < 32) return false;
         if ((reinterpret_cast<uintptr_t>(p.src) | reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.src_stride | (uintptr_t)p.dst_stride) & 15) return false;
     }
     return true;
+}
+
+// The ring kernel over a batch of planes. The fast form needs whole pixel groups (8 or 16 samples) up to the right edge; a plane whose width is not such a
+// multiple — cropped clips, 1366 x 768, 854 x 480, the 959-sample chroma of a 1918-wide clip — used to send the WHOLE batch to the general form (about half
+// the rate, profiles/r04_cliff_sweep_before.txt). Round 4: such a plane is split by columns — the tiles whose every lane lies inside the plane (or in its left
+// mirror image) go to the fast form with the aligned planes, the last one or two tiles to the general form in a second launch.
+template <typename T, int R, int PXF>
+int run_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
+    using GF = typename RingWave<T, R, false, PXF>::G;
+    using GG = typename RingWave<T, R, true, 8>::G;
+    std::vector<RingSpan> fast(nplanes), rest(nplanes);
+    bool any_rest = false, any_fast = false;
+    for (int i = 0; i < nplanes; ++i) {
+        const int w = planes[i].w;
+        if (w % PXF == 0) {
+            fast[i] = {0, (w + GF::TWO - 1) / GF::TWO};
+            rest[i] = {0, 0};
+        } else {
+            const int room = w + GF::HL - 64 * PXF;  // tile t is all inside iff t * TWO - HL + 64 * PXF <= w
+            const int nsafe = room >= 0 ? room / GF::TWO + 1 : 0;
+            fast[i] = {0, nsafe};
+            const int x = nsafe * GF::TWO;
+            rest[i] = {x, (w - x + GG::TWO - 1) / GG::TWO};
+        }
+        any_fast = any_fast || fast[i].ntx > 0;
+        any_rest = any_rest || rest[i].ntx > 0;
+    }
+    if (any_fast) {
+        const int rc = launch_ct_ring_spans<T, R, PXF, false>(ctx, planes, fast.data(), nplanes);
+        if (rc != VSZIP_OK) return rc;
+    }
+    if (any_rest) return launch_ct_ring_spans<T, R, 8, true>(ctx, planes, rest.data(), nplanes);
+    return VSZIP_OK;
 }
 
 // Development builds (-DVSZIP_DEV_R=13) instantiate a single radius to keep the
@@ -1046,9 +1085,9 @@ struct CtIntDispatch {
         if constexpr (VSZIP_R_ENABLED(R)) if (r == R) {
             if (ctx->scan_mode == 0 && ring_ok<T>(planes, nplanes)) {
                 if constexpr (sizeof(T) == 1 && R <= kRing16MaxR) {
-                    if (ring16_ok<T>(ctx, planes, nplanes)) return launch_ct_ring<T, R, 16>(ctx, planes, nplanes);
+                    if (ring16_ok<T>(ctx, planes, nplanes)) return run_ct_ring<T, R, 16>(ctx, planes, nplanes);
                 }
-                return launch_ct_ring<T, R>(ctx, planes, nplanes);
+                return run_ct_ring<T, R, 8>(ctx, planes, nplanes);
             }
             return launch_ct_int<T, R>(ctx, planes, nplanes);
         }

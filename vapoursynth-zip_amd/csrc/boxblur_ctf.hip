@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kMaxPlanesF = 48;
+constexpr int kMaxPlanesF = 192;  // planes per launch (round 4: 48 made a 64-frame 1080p call four launches, each planned as if it were the only one)
 
 struct FPlane {
     const void *src;
@@ -46,10 +46,17 @@ __global__ __launch_bounds__(256) void boxblur_ct_float_kernel(const FParams prm
     constexpr int K = 2 * R + 1, IW = FTW + 2 * R, IH = FTH + 2 * R;
     __shared__ float tile[IH][IW + 1];
     __shared__ float vt[FTH][IW + 1];
-    int pi = 0;
     const int b = blockIdx.x;
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
+    int pi = 0;  // the last plane whose first block is not beyond b
+    for (int lo = 1, hi = prm.nplanes - 1; lo <= hi;) {
+        const int mid = (lo + hi) >> 1;
+        if (b >= prm.p[mid].block0) {
+            pi = mid;
+            lo = mid + 1;
+        } else {
+            hi = mid - 1;
+        }
+    }
     const FPlane pl = prm.p[pi];
     const int lb = b - pl.block0;
     const int w = pl.w, h = pl.h;
@@ -450,10 +457,17 @@ __global__ __launch_bounds__(64) void boxblur_ctf_ring_kernel(const FRParams prm
     const int chunk = (prm.nblocks + 7) >> 3;  // XCD-aware: blocks b and b+8 share an XCD
     const int b = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (b >= prm.nblocks) return;
-    int pi = 0;
+    int pi = 0;  // the last plane whose first block is not beyond b
 #pragma unroll 1
-    for (int i = 1; i < prm.nplanes; ++i)
-        if (b >= prm.p[i].block0) pi = i;
+    for (int lo = 1, hi = prm.nplanes - 1; lo <= hi;) {
+        const int mid = (lo + hi) >> 1;
+        if (b >= prm.p[mid].block0) {
+            pi = mid;
+            lo = mid + 1;
+        } else {
+            hi = mid - 1;
+        }
+    }
     const FRPlane &pl = prm.p[pi];
     const int lb = b - pl.block0;
     const int tx = lb % pl.ntx, by = lb / pl.ntx;
@@ -583,24 +597,31 @@ int run_ct_float(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int rad
     // (every band re-reads 2r rows).
     const long round = RingDispatch<T, kFRMaxR>::round_waves(radius, ctx->num_cus > 0 ? ctx->num_cus : 256);
     std::vector<int> nb(nplanes, 0), ntxs(nplanes, 0), xbs(nplanes, 0);
-    long waves = 0;
-    for (int i = 0; i < nplanes; ++i) {
-        if (!ring_interior<T>(ctx, planes[i], radius, NR, HL, TWO, ntxs[i], xbs[i])) continue;
-        nb[i] = 1;
-        waves += ntxs[i];
-    }
-    for (;;) {
-        int worst = 0;
-        for (int i = 0; i < nplanes; ++i)
-            if (nb[i]) worst = std::max(worst, (planes[i].h - radius + nb[i] - 1) / nb[i]);
-        if (worst == 0 || worst < 2 * NR) break;  // (worst == 0: no plane takes the ring kernel)
-        long extra = 0;
-        for (int i = 0; i < nplanes; ++i)
-            if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) extra += ntxs[i];
-        if (waves + extra > round) break;
-        for (int i = 0; i < nplanes; ++i)
-            if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) ++nb[i];
-        waves += extra;
+    for (int i = 0; i < nplanes; ++i)
+        if (ring_interior<T>(ctx, planes[i], radius, NR, HL, TWO, ntxs[i], xbs[i])) nb[i] = 1;
+    // (planned per LAUNCH: the ring planes are taken kMaxPlanesF at a time below, and each launch is a resident round of its own)
+    for (int g0 = 0; g0 < nplanes;) {
+        int g1 = g0, cnt = 0;
+        long waves = 0;
+        for (; g1 < nplanes && cnt < kMaxPlanesF; ++g1)
+            if (nb[g1]) {
+                ++cnt;
+                waves += ntxs[g1];
+            }
+        for (;;) {
+            int worst = 0;
+            for (int i = g0; i < g1; ++i)
+                if (nb[i]) worst = std::max(worst, (planes[i].h - radius + nb[i] - 1) / nb[i]);
+            if (worst == 0 || worst < 2 * NR) break;  // (worst == 0: no plane takes the ring kernel)
+            long extra = 0;
+            for (int i = g0; i < g1; ++i)
+                if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) extra += ntxs[i];
+            if (waves + extra > round) break;
+            for (int i = g0; i < g1; ++i)
+                if (nb[i] && (planes[i].h - radius + nb[i] - 1) / nb[i] == worst) ++nb[i];
+            waves += extra;
+        }
+        g0 = g1;
     }
     // Bottom rows inside the ring kernel: needs a last band of a whole number of ring periods ending at h - NB and at
     // least one band before it (otherwise the bottom strip goes through the tile kernel as the right one does)
