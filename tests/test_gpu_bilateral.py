@@ -222,3 +222,34 @@ def test_large_yuv420_batches_cross_the_launch_table(dev, oracle, dtype):
         f, i = divmod(k, 3)
         assert np.array_equal(np.roll(first[i], f, axis=1)[:, 8 + f:-8].view(np.uint8), dev.download(dsts[k])[:, 8 + f:-8].view(np.uint8)), k
     dev.bilateral_free(cfg)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float16])
+@pytest.mark.parametrize("sig", [(7, 2), (16, 0.5)], ids=["luma_pbfic_chroma_taps", "all_pbfic_two_layer_counts"])
+def test_algorithm1_planes_of_a_batch_share_their_launches(dev, oracle, dtype, sig):
+    """Round 4: the algorithm-1 planes of a call are gathered and run as one batch of launches. A YUV 4:2:0 clip at sigmaS = 7 sigmaR = 2 auto-selects PBFIC
+    for the luma and the tap kernel for the chroma (sigmaS halves there) — interleaved in the call, 70 frames so that a batch (64 planes) fills and a second
+    one follows; at sigmaS = 16 every plane is PBFIC with two different layer counts (two layer-value tables in one launch). Every checked plane against the oracle."""
+    sS, sR = sig
+    shapes = [(72, 112), (36, 56), (36, 56)]
+    base = [fx.tiled_natural(s, dtype, i) for i, s in enumerate(shapes)]
+    hist = 256 if dtype == np.uint8 else 65536
+    cfg = dev.bilateral_cfg([sS], [sR], yuv=True, ssw=1, ssh=1, hist_len=hist)
+    algs = [cfg[i].algorithm for i in range(3)]
+    nums = [cfg[i].pbficnum for i in range(3)]
+    assert algs[0] == 1 and (algs[1] == 2 if sS == 7 else (algs[1] == 1 and nums[1] != nums[0])), (algs, nums)
+    frames = 70
+    planes, idx = [], []
+    for f in range(frames):
+        for i, p in enumerate(base):
+            planes.append(np.ascontiguousarray(np.roll(p, f, axis=1)))
+            idx.append(i)
+    srcs = [dev.upload(p) for p in planes]
+    dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+    peak = 255.0 if dtype == np.uint8 else None
+    dev.bilateral(srcs, dsts, cfg, idx, peak=peak)
+    for k in (0, 1, 2, 3, 3 * 63, 3 * 64, 3 * 64 + 1, 3 * 65 + 2, 3 * frames - 3, 3 * frames - 1, 100):
+        c = cfg[idx[k]]
+        w = oracle.bilateral_plane(planes[k], c.sigmaS, c.sigmaR, c.algorithm, c.radius, c.step, c.pbficnum)
+        assert np.array_equal(dev.download(dsts[k]).view(np.uint8), w.view(np.uint8)), (k, c.algorithm)
+    dev.bilateral_free(cfg)

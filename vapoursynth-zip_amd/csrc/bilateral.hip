@@ -906,30 +906,67 @@ __global__ __launch_bounds__(kBX *kBY) void bilateral_truncated_kernel(const BLP
 //   pbfic_out_kernel  layer = J/W, linear interpolation between the two layers that
 //                     bracket the pixel's ref value, finalize                       (:133-171)
 // ---------------------------------------------------------------------------
-struct PBArgs {
+// Round 4: a BATCH of planes per set of launches. One plane alone gives the IIR passes lines x 2 PBFICnum chains (1080p luma, four layers: 136 waves of the
+// horizontal pass, 64 blocks of the vertical one) and the per-plane entry ran four launches and a stream synchronise for each plane of a call: 1.2 k 1080p frames/s
+// at sigmaS = 7 next to 24 k at sigmaS = 5 (tools/bil_sigma_sweep.py). The planes of a call — as many as the scratch budget holds — now share the four launches;
+// a block finds its plane by binary search over the per-kernel block offsets, the layer values travel in the kernel arguments (no copy, no synchronise).
+constexpr int kMaxPB = 64;                       // planes per batch
+constexpr size_t kPBScratchBudget = 6ull << 30;  // W / J layer planes of a batch (a 1080p YUV frame with four layers: 100 MB)
+struct PBPlane {
     const void *src, *ref;
     void *dst;
-    int sstride, rstride, dstride, w, h;
-    float *wj;         // [2 * num] planes of w*h floats: W_0, J_0, W_1, J_1, ...
     const float *gr;
-    const void *pk;    // [num] layer values in T
-    int num;
-    float peak;
+    size_t wj_off;  // floats from PBBatch::wj: [2 * num] planes of w*h floats: W_0, J_0, W_1, J_1, ...
+    int sstride, rstride, dstride, w, h;
+    int num, pkt;   // layers; which of the batch's layer-value tables
     float b, b1, b2, b3;
+    int b0[4];      // first block of this plane in the wj / rg_h / rg_v / out launch
+};
+struct PBBatch {
+    PBPlane p[kMaxPB];
+    uint32_t pk[3][256];  // layer values, the bits of T (planes of one call have at most three configurations)
+    float *wj;
+    float peak;
+    int n;
 };
 
+template <int KRN>
+__device__ __forceinline__ int pb_find(const PBBatch &a, int b) {  // the last plane whose first block (of kernel KRN) is not beyond b
+    int pi = 0;
+    for (int lo = 1, hi = a.n - 1; lo <= hi;) {
+        const int mid = (lo + hi) >> 1;
+        if (b >= a.p[mid].b0[KRN]) {
+            pi = mid;
+            lo = mid + 1;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    return pi;
+}
 template <typename T>
-__global__ __launch_bounds__(256) void pbfic_wj_kernel(const PBArgs a) {
+__device__ __forceinline__ T pb_layer(const PBBatch &a, const PBPlane &pl, int k) {
+    const uint32_t bits = a.pk[pl.pkt][k];
+    T v;
+    __builtin_memcpy(&v, &bits, sizeof(T));
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pbfic_wj_kernel(const PBBatch a) {
     using S = BSmp<T>;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
-    if (x >= a.w) return;
-    const T rv = static_cast<const T *>(a.ref)[(size_t)y * a.rstride + x];
-    const T sv = static_cast<const T *>(a.src)[(size_t)y * a.sstride + x];
-    const T pk = static_cast<const T *>(a.pk)[k];
-    const float wv = a.gr[S::ridx(pk, rv)];
-    const size_t plane = (size_t)a.w * a.h, i = (size_t)y * a.w + x;
-    a.wj[(size_t)(2 * k) * plane + i] = wv;
-    a.wj[(size_t)(2 * k + 1) * plane + i] = wv * S::f(sv);
+    const PBPlane &pl = a.p[pb_find<0>(a, (int)blockIdx.x)];
+    const int lb = (int)blockIdx.x - pl.b0[0], nbx = (pl.w + 255) / 256;
+    const int x = (lb % nbx) * 256 + threadIdx.x, y = (lb / nbx) % pl.h, k = lb / (nbx * pl.h);
+    if (x >= pl.w) return;
+    const T rv = static_cast<const T *>(pl.ref)[(size_t)y * pl.rstride + x];
+    const T sv = static_cast<const T *>(pl.src)[(size_t)y * pl.sstride + x];
+    const T pk = pb_layer<T>(a, pl, k);
+    const float wv = pl.gr[S::ridx(pk, rv)];
+    const size_t plane = (size_t)pl.w * pl.h, i = (size_t)y * pl.w + x;
+    float *wj = a.wj + pl.wj_off;
+    wj[(size_t)(2 * k) * plane + i] = wv;
+    wj[(size_t)(2 * k + 1) * plane + i] = wv * S::f(sv);
 }
 
 // One wave per 64 rows (lane = row in the recursion, lane = column while a 64 x 64 tile moves between
@@ -1000,23 +1037,27 @@ __device__ __forceinline__ void pbfic_h_pass(float (*tile)[65], float *__restric
     }
 }
 
-__global__ __launch_bounds__(64) void pbfic_rg_h_kernel(const PBArgs a) {
+__global__ __launch_bounds__(64) void pbfic_rg_h_kernel(const PBBatch a) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x;
-    const int y0 = blockIdx.x * 64;
-    float *io = a.wj + (size_t)blockIdx.y * (size_t)a.w * a.h;
-    const int rows = min(64, a.h - y0);
-    pbfic_h_pass<1>(tile, io, y0, rows, a.w, lane, a.b, a.b1, a.b2, a.b3);
-    pbfic_h_pass<-1>(tile, io, y0, rows, a.w, lane, a.b, a.b1, a.b2, a.b3);
+    const PBPlane &pl = a.p[pb_find<1>(a, (int)blockIdx.x)];
+    const int lb = (int)blockIdx.x - pl.b0[1], nby = (pl.h + 63) / 64;
+    const int y0 = (lb % nby) * 64;
+    float *io = a.wj + pl.wj_off + (size_t)(lb / nby) * (size_t)pl.w * pl.h;
+    const int rows = min(64, pl.h - y0);
+    pbfic_h_pass<1>(tile, io, y0, rows, pl.w, lane, pl.b, pl.b1, pl.b2, pl.b3);
+    pbfic_h_pass<-1>(tile, io, y0, rows, pl.w, lane, pl.b, pl.b1, pl.b2, pl.b3);
 }
 
-__global__ __launch_bounds__(256) void pbfic_rg_v_kernel(const PBArgs a) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= a.w) return;
-    const size_t plane = (size_t)a.w * a.h;
-    float *io = a.wj + (size_t)blockIdx.y * plane + x;
-    const int w = a.w, h = a.h;
-    const float b = a.b, b1 = a.b1, b2 = a.b2, b3 = a.b3;
+__global__ __launch_bounds__(256) void pbfic_rg_v_kernel(const PBBatch a) {
+    const PBPlane &pl = a.p[pb_find<2>(a, (int)blockIdx.x)];
+    const int lb = (int)blockIdx.x - pl.b0[2], nbx = (pl.w + 255) / 256;
+    const int x = (lb % nbx) * 256 + threadIdx.x;
+    if (x >= pl.w) return;
+    const size_t plane = (size_t)pl.w * pl.h;
+    float *io = a.wj + pl.wj_off + (size_t)(lb / nbx) * plane + x;
+    const int w = pl.w, h = pl.h;
+    const float b = pl.b, b1 = pl.b1, b2 = pl.b2, b3 = pl.b3;
     // :368-387 — rows 0..2 reuse the nearest already-filtered row for the missing taps
     float p1, p2, p3;
     {
@@ -1066,28 +1107,30 @@ __global__ __launch_bounds__(256) void pbfic_rg_v_kernel(const PBArgs a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pbfic_out_kernel(const PBArgs a) {
+__global__ __launch_bounds__(256) void pbfic_out_kernel(const PBBatch a) {
     using S = BSmp<T>;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= a.w) return;
-    const T *pk = static_cast<const T *>(a.pk);
-    const float rf = S::f(static_cast<const T *>(a.ref)[(size_t)y * a.rstride + x]);
+    const PBPlane &pl = a.p[pb_find<3>(a, (int)blockIdx.x)];
+    const int lb = (int)blockIdx.x - pl.b0[3], nbx = (pl.w + 255) / 256;
+    const int x = (lb % nbx) * 256 + threadIdx.x, y = lb / nbx;
+    if (x >= pl.w) return;
+    const float rf = S::f(static_cast<const T *>(pl.ref)[(size_t)y * pl.rstride + x]);
     int k = 0;
-    for (; k < a.num - 2; ++k)
-        if (rf < S::f(pk[k + 1]) && rf >= S::f(pk[k])) break;
-    const float p0f = S::f(pk[k]), p1f = S::f(pk[k + 1]);
-    const size_t plane = (size_t)a.w * a.h, i = (size_t)y * a.w + x;
-    const float w0 = a.wj[(size_t)(2 * k) * plane + i], j0 = a.wj[(size_t)(2 * k + 1) * plane + i];
-    const float w1 = a.wj[(size_t)(2 * k + 2) * plane + i], j1 = a.wj[(size_t)(2 * k + 3) * plane + i];
+    for (; k < pl.num - 2; ++k)
+        if (rf < S::f(pb_layer<T>(a, pl, k + 1)) && rf >= S::f(pb_layer<T>(a, pl, k))) break;
+    const float p0f = S::f(pb_layer<T>(a, pl, k)), p1f = S::f(pb_layer<T>(a, pl, k + 1));
+    const size_t plane = (size_t)pl.w * pl.h, i = (size_t)y * pl.w + x;
+    const float *wj = a.wj + pl.wj_off;
+    const float w0 = wj[(size_t)(2 * k) * plane + i], j0 = wj[(size_t)(2 * k + 1) * plane + i];
+    const float w1 = wj[(size_t)(2 * k + 2) * plane + i], j1 = wj[(size_t)(2 * k + 3) * plane + i];
     const float lo = (w0 == 0.0f) ? 0.0f : __fdiv_rn(j0, w0);
     const float hi = (w1 == 0.0f) ? 0.0f : __fdiv_rn(j1, w1);
     const float vf = __fdiv_rn((p1f - rf) * lo + (rf - p0f) * hi, p1f - p0f);
-    T *dst = static_cast<T *>(a.dst);
+    T *dst = static_cast<T *>(pl.dst);
     if constexpr (S::is_int) {
         const float v = fminf(fmaxf(__fdiv_rn(vf, 1.0f) + 0.5f, 0.0f), a.peak);
-        dst[(size_t)y * a.dstride + x] = (T)truncf(v);
+        dst[(size_t)y * pl.dstride + x] = (T)truncf(v);
     } else {
-        dst[(size_t)y * a.dstride + x] = (T)vf;
+        dst[(size_t)y * pl.dstride + x] = (T)vf;
     }
 }
 
@@ -1104,47 +1147,78 @@ void rg_params(double sigma, float *b, float *b1, float *b2, float *b3) {
     *b3 = (float)(n3 / den);
 }
 
+// `count` consecutive algorithm-1 planes of a call, in batches the scratch budget holds
 template <typename T>
-int run_pbfic(vszip_ctx *ctx, const vszip_plane &s, const vszip_bilateral_cfg &c, float peak) {
-    const int num = c.pbficnum;
-    if (num < 2 || num > 256) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: PBFICnum %d out of range", num);
-    const size_t plane = (size_t)s.w * s.h;
-    const size_t pk_bytes = 1024;
-    int rc = vszip_ensure_scratch(ctx, pk_bytes + (size_t)2 * num * plane * sizeof(float));
-    if (rc != VSZIP_OK) return rc;
-    // layer values, in T exactly as :96-116 (integer: trunc(peak*k/(num-1) + .5); float: k/(num-1) in T)
-    T pk[256];
-    for (int k = 0; k < num; ++k) {
-        if constexpr (BSmp<T>::is_int) {
-            const float v = peak * (float)k / ((float)num - 1) + 0.5f;
-            pk[k] = (T)v;
-        } else {
-            pk[k] = (T)((T)(float)k / (T)(float)(num - 1));
+int run_pbfic(vszip_ctx *ctx, const vszip_plane *planes, const vszip_bilateral_cfg *const *cfgs, int count, float peak) {
+    for (int done = 0; done < count;) {
+        PBBatch a;
+        a.peak = peak;
+        int n = 0, ntab = 0;
+        const vszip_bilateral_cfg *tabs[3] = {nullptr, nullptr, nullptr};
+        size_t floats = 0;
+        long blocks[4] = {0, 0, 0, 0};
+        for (; done + n < count && n < kMaxPB; ++n) {
+            const vszip_plane &s = planes[done + n];
+            const vszip_bilateral_cfg &c = *cfgs[done + n];
+            const int num = c.pbficnum;
+            if (!s.src || !s.dst || s.w <= 0 || s.h <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: bad plane");
+            if (!c.gr_lut) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: LUTs missing (vszip_bilateral_luts)");
+            if (num < 2 || num > 256) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: PBFICnum %d out of range", num);
+            const size_t plane = (size_t)s.w * s.h, need = (size_t)2 * num * plane;
+            if (n > 0 && (floats + need) * sizeof(float) > kPBScratchBudget) break;
+            int t = 0;
+            while (t < ntab && tabs[t]->pbficnum != num) ++t;
+            if (t == ntab) {
+                if (ntab == 3) break;  // (a fourth layer count: the next batch)
+                tabs[ntab++] = &c;
+                // layer values, in T exactly as :96-116 (integer: trunc(peak*k/(num-1) + .5); float: k/(num-1) in T)
+                for (int k = 0; k < num; ++k) {
+                    T v;
+                    if constexpr (BSmp<T>::is_int) {
+                        const float f = peak * (float)k / ((float)num - 1) + 0.5f;
+                        v = (T)f;
+                    } else {
+                        v = (T)((T)(float)k / (T)(float)(num - 1));
+                    }
+                    uint32_t bits = 0;
+                    std::memcpy(&bits, &v, sizeof(T));
+                    a.pk[t][k] = bits;
+                }
+            }
+            PBPlane &d = a.p[n];
+            d.src = s.src;
+            d.ref = s.ref ? s.ref : s.src;
+            d.dst = s.dst;
+            d.gr = c.gr_lut;
+            d.wj_off = floats;
+            d.sstride = (int)s.src_stride;
+            d.rstride = s.ref ? (int)s.ref_stride : (int)s.src_stride;
+            d.dstride = (int)s.dst_stride;
+            d.w = s.w;
+            d.h = s.h;
+            d.num = num;
+            d.pkt = t;
+            rg_params(c.sigmaS, &d.b, &d.b1, &d.b2, &d.b3);
+            const long nbx = (s.w + 255) / 256, nby = (s.h + 63) / 64;
+            const long nb[4] = {nbx * s.h * num, nby * 2 * num, nbx * 2 * num, nbx * s.h};
+            for (int q = 0; q < 4; ++q) {
+                d.b0[q] = (int)blocks[q];
+                blocks[q] += nb[q];
+            }
+            if (blocks[0] > 0x7fffffffL) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "Bilateral: algorithm 1 batch too large");
+            floats += need;
         }
+        a.n = n;
+        const int rc = vszip_ensure_scratch(ctx, floats * sizeof(float));
+        if (rc != VSZIP_OK) return rc;
+        a.wj = static_cast<float *>(ctx->scratch);
+        hipLaunchKernelGGL((pbfic_wj_kernel<T>), dim3((unsigned)blocks[0]), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(pbfic_rg_h_kernel, dim3((unsigned)blocks[1]), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(pbfic_rg_v_kernel, dim3((unsigned)blocks[2]), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((pbfic_out_kernel<T>), dim3((unsigned)blocks[3]), dim3(256), 0, ctx->stream, a);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        done += n;
     }
-    VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scratch, pk, sizeof(T) * num, hipMemcpyHostToDevice, ctx->stream));
-    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // pk lives on this stack frame
-    PBArgs a;
-    a.src = s.src;
-    a.ref = s.ref ? s.ref : s.src;
-    a.dst = s.dst;
-    a.sstride = (int)s.src_stride;
-    a.rstride = s.ref ? (int)s.ref_stride : (int)s.src_stride;
-    a.dstride = (int)s.dst_stride;
-    a.w = s.w;
-    a.h = s.h;
-    a.pk = ctx->scratch;
-    a.wj = reinterpret_cast<float *>(static_cast<char *>(ctx->scratch) + pk_bytes);
-    a.gr = c.gr_lut;
-    a.num = num;
-    a.peak = peak;
-    rg_params(c.sigmaS, &a.b, &a.b1, &a.b2, &a.b3);
-    const dim3 gpx((s.w + 255) / 256, s.h, num);
-    hipLaunchKernelGGL((pbfic_wj_kernel<T>), gpx, dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(pbfic_rg_h_kernel, dim3((s.h + 63) / 64, 2 * num), dim3(64), 0, ctx->stream, a);
-    hipLaunchKernelGGL(pbfic_rg_v_kernel, dim3((s.w + 255) / 256, 2 * num), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((pbfic_out_kernel<T>), dim3((s.w + 255) / 256, s.h), dim3(256), 0, ctx->stream, a);
-    VSZIP_HIP_CHECK(ctx, hipGetLastError());
     return VSZIP_OK;
 }
 
@@ -1495,9 +1569,36 @@ VSZIP_EXPORT int vszip_bilateral_luts(vszip_ctx *ctx, vszip_bilateral_cfg *cfg, 
     return VSZIP_OK;
 }
 
+static int bilateral_alg2(vszip_ctx *ctx, int dtype, const vszip_plane *planes, const vszip_bilateral_cfg *const *cfgs, int nplanes, float peak);
+
 VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *planes, const vszip_bilateral_cfg *const *cfgs, int nplanes, float peak) {
     if (!ctx || !planes || !cfgs || nplanes <= 0) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // The algorithm-1 planes of the call — typically the luma of every frame: sigmaS is halved for subsampled chroma, which then stays with algorithm 2 —
+    // are independent of the others: they are gathered and share their launches (run_pbfic), the rest keeps its order.
+    int n1 = 0;
+    for (int i = 0; i < nplanes; ++i) n1 += (cfgs[i] && cfgs[i]->process && cfgs[i]->algorithm == 1) ? 1 : 0;
+    if (n1 == 0) return bilateral_alg2(ctx, dtype, planes, cfgs, nplanes, peak);
+    std::vector<vszip_plane> p1, p2;
+    std::vector<const vszip_bilateral_cfg *> c1, c2;
+    for (int i = 0; i < nplanes; ++i) {
+        const bool a1 = cfgs[i] && cfgs[i]->process && cfgs[i]->algorithm == 1;
+        (a1 ? p1 : p2).push_back(planes[i]);
+        (a1 ? c1 : c2).push_back(cfgs[i]);
+    }
+    int rc1;
+    switch (dtype) {
+        case VSZIP_U8: rc1 = run_pbfic<uint8_t>(ctx, p1.data(), c1.data(), n1, peak); break;
+        case VSZIP_U16: rc1 = run_pbfic<uint16_t>(ctx, p1.data(), c1.data(), n1, peak); break;
+        case VSZIP_F16: rc1 = run_pbfic<_Float16>(ctx, p1.data(), c1.data(), n1, peak); break;
+        case VSZIP_F32: rc1 = run_pbfic<float>(ctx, p1.data(), c1.data(), n1, peak); break;
+        default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: not supported Int format.");
+    }
+    if (rc1 != VSZIP_OK || p2.empty()) return rc1;
+    return bilateral_alg2(ctx, dtype, p2.data(), c2.data(), (int)p2.size(), peak);
+}
+
+static int bilateral_alg2(vszip_ctx *ctx, int dtype, const vszip_plane *planes, const vszip_bilateral_cfg *const *cfgs, int nplanes, float peak) {
     int done = 0;
     while (done < nplanes) {
         BLParams prm;
@@ -1509,24 +1610,6 @@ VSZIP_EXPORT int vszip_bilateral(vszip_ctx *ctx, int dtype, const vszip_plane *p
         // plane of the group brings a separate ref clip
         bool tiled = !ctx->opt.bilateral_untiled, joint = false;
         int max_radius = 0;
-        // algorithm 1 planes run one by one (each is its own set of launches)
-        if (cfgs[done] && cfgs[done]->process && cfgs[done]->algorithm == 1) {
-            const vszip_plane &s1 = planes[done];
-            const vszip_bilateral_cfg *c1 = cfgs[done];
-            if (!s1.src || !s1.dst || s1.w <= 0 || s1.h <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: bad plane %d", done);
-            if (!c1->gr_lut) return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: LUTs missing (vszip_bilateral_luts)");
-            int rc1;
-            switch (dtype) {
-                case VSZIP_U8: rc1 = run_pbfic<uint8_t>(ctx, s1, *c1, peak); break;
-                case VSZIP_U16: rc1 = run_pbfic<uint16_t>(ctx, s1, *c1, peak); break;
-                case VSZIP_F16: rc1 = run_pbfic<_Float16>(ctx, s1, *c1, peak); break;
-                case VSZIP_F32: rc1 = run_pbfic<float>(ctx, s1, *c1, peak); break;
-                default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "Bilateral: not supported Int format.");
-            }
-            if (rc1 != VSZIP_OK) return rc1;
-            ++done;
-            continue;
-        }
         for (int i = done; i < nplanes && i < done + kMaxPlanesBL; ++i) {
             if (!cfgs[i] || (cfgs[i]->process && cfgs[i]->algorithm == 1)) break;
             tiled = tiled && cfgs[i]->radius <= kTileMaxR;
