@@ -32,6 +32,9 @@ CASES = [
     # the default mdis = 20 instantiation (window sums in registers through DPP, round 4) at every nrad: 0 has no shift, odd ones store their sums unaligned
     dict(field=1, nrad=0), dict(field=0, nrad=1, dh=True), dict(field=1, nrad=3, vcheck=1), dict(field=0, nrad=3, alpha=0.1, beta=0.9, gamma=0.0),
     dict(field=1, mdis=20, nrad=2, vcheck=3, vthresh0=8.0, vthresh1=4.0, vthresh2=1.0),
+    # mdis below the default: the default's layout with the directions beyond mdis masked out (whole passes skipped, a pass cut in the middle, one direction)
+    dict(field=1, mdis=1), dict(field=0, mdis=3, nrad=1), dict(field=1, mdis=4, dh=True), dict(field=1, mdis=8, nrad=3), dict(field=0, mdis=12, gamma=0.0),
+    dict(field=1, mdis=17, nrad=0, vcheck=1), dict(field=1, mdis=19, alpha=0.5, beta=0.1),
 ]
 
 

@@ -118,8 +118,12 @@ constexpr int kU = 4;  // directions per cost pass
 // 5 waves per CU, and the kernel is latency bound.
 // FIXED: mdis == MD (the default 20): the direction loop unrolls and every LDS offset of a pass is an immediate
 // (with a runtime mdis a quarter of the cost phase's instructions are address arithmetic).
-template <int NRAD, int MD, bool FIXED>
+// MASK (round 4, with FIXED): the layout and the unrolled passes of mdis == MD, but only the directions |u| <= prm.mdis take part — the others keep an infinite
+// cost, which pins their Viterbi state at the sentinel exactly like the lanes past the last direction. A run-time mdis below the default used to take the
+// FIXED = false instance, whose cost pass is the round-3 form: slower at 21 directions than the fixed instance at 41 (tools/eedi3_param_sweep.py).
+template <int NRAD, int MD, bool FIXED, bool MASK = false>
 __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
+    static_assert(!MASK || FIXED, "MASK rides on the fixed layout");
     // The t_base and window-sum steps run a fixed number of 128-entry iterations (NIT2: every lane owns two
     // neighbouring entries, and the kU directions of a pass share ONE first column, so the span is the longest
     // of the pass) with no guard — entries past a direction's span are computed from padding and never read —
@@ -165,6 +169,10 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     int *dmap = pl.dmap + (size_t)off * w;
     const int reach = 2 * mdis + nrad, roww = kXB + 2 * reach;
 
+    const int mlim = MASK ? prm.mdis : MD;  // (MASK) directions beyond it never get a cost
+    if constexpr (MASK) {
+        for (int r = 0; r < 2 * MD + 1; ++r) ctile[r][lane] = INFINITY;
+    }
     float pcost = kFltMax09;  // DP state of direction `lane` (inactive lanes stay at the sentinel)
     [[maybe_unused]] float dp_l = INFINITY, dp_r = INFINITY, dp_gamma = prm.gamma;  // see dp_step
     uint32_t held[kXB / 4];   // back-pointer codes of the previous block, waiting for their last column
@@ -405,11 +413,25 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 const float ip = (r.p1[i] + r.p2[i]) * 0.5f;
                 const float vv = fabsf(r1c - ip) + fabsf(r2c - ip);
                 val[i] = prm.alpha * (r.sw0[i] + r.sw1[i] + r.sw2[i]) + prm.beta * (float)abs(u) + prm.one_minus_ab * vv;
+                if constexpr (MASK) val[i] = abs(u) <= mlim ? val[i] : INFINITY;
             }
             if (x < w) {
 #pragma unroll
                 for (int i = 0; i < nd; ++i) ctile[MD + ug + i][lane] = val[i];
             }
+        };
+        // MASK: a pass none of whose directions takes part is skipped (its tile rows stay infinite from the kernel's start); no software pipeline here
+        auto cost_pass_masked = [&](auto ugc) __attribute__((always_inline)) {
+            constexpr int ug = decltype(ugc)::value;
+            constexpr int nd = MD - ug + 1 < kU ? MD - ug + 1 : kU;
+            constexpr int lo = ug < 0 ? -(ug + nd - 1) : ug;  // the pass's smallest |u|
+            if (lo > mlim) return;
+            BRegs r;
+            stage_a(ugc);
+            wave_fence();
+            read_b(ugc, r);
+            comp_b(ugc, r);
+            wave_fence();
         };
         auto cost_pass_fixed = [&](auto ugc) __attribute__((always_inline)) {  // (pass ug's stage_a has run)
             constexpr int ug = decltype(ugc)::value;
@@ -436,7 +458,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         } else
             cost_pass(0);
 #else
-        if constexpr (kRegWin) {
+        if constexpr (kRegWin && MASK) {
+            static_for<-MD, MD, kU>(cost_pass_masked);
+        } else if constexpr (kRegWin) {
             stage_a(std::integral_constant<int, -MD>{});
             static_for<-MD, MD, kU>(cost_pass_fixed);
         } else if constexpr (FIXED) {
@@ -1686,7 +1710,9 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     if (any_mask && !mclip_strides) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: mclip strides missing", name);
     // the tuned kernel covers the common case; hp, mdis > 31 and mclip take the general one
     const bool general = hp || up->mdis > kMaxMdis || any_mask;
-    const int tpitch = hp ? 4 * up->mdis + 1 : 2 * up->mdis + 1;
+    // (mdis <= 20 on the tuned kernel: the layout of mdis = 20, see MASK)
+    const bool masked20 = !general && up->mdis < 20 && !ctx->opt.eedi3_no_fixed;
+    const int tpitch = hp ? 4 * up->mdis + 1 : (masked20 ? 2 * 20 + 1 : 2 * up->mdis + 1);
 
     // geometry of the vertical pipeline per plane (EEDI3H runs it on the transposed plane)
     struct Geo {
@@ -1942,6 +1968,8 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     do {                                                                                          \
         if (up->mdis == 20 && !ctx->opt.eedi3_no_fixed)                                    \
             hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true>), lgrid, lblock, 0, lst, ep);      \
+        else if (masked20)                                                                        \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true, true>), lgrid, lblock, 0, lst, ep); \
         else if (up->mdis <= 20)                                                                  \
             hipLaunchKernelGGL((eedi3_line_kernel<N, 20, false>), lgrid, lblock, 0, lst, ep);     \
         else                                                                                      \
