@@ -904,26 +904,26 @@ struct RingSpan {
     int cx0, ntx;
 };
 
-// One kernel instance over the given column spans of the planes. GEN = false is the fast form: every lane of every tile it is given must hold a whole pixel
-// group inside the plane or its left mirror image (the caller's rule); GEN = true takes any width and any tile.
-template <typename T, int R, int PXN, bool GEN>
-int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const RingSpan *all_spans, int nall) {
+// Band length of a launch: every plane is cut into bands of about `target` ring periods (returned; *waves_out = the waves of that plan).
+template <typename T, int R, int PXN>
+int ring_plan(const vszip_plane *planes, const RingSpan *spans, int n, double *waves_ret) {
     using G = typename RingWave<T, R, false, PXN>::G;
-    std::vector<vszip_plane> planes_v;
-    std::vector<RingSpan> spans_v;
-    for (int i = 0; i < nall; ++i)
-        if (all_spans[i].ntx > 0) {
-            planes_v.push_back(all_planes[i]);
-            spans_v.push_back(all_spans[i]);
-        }
-    const vszip_plane *planes = planes_v.data();
-    const RingSpan *spans = spans_v.data();
-    const int nplanes = (int)planes_v.size();
-    int done = 0;
-    while (done < nplanes) {
-        RingParams prm;
-        const int n = std::min(kRingMaxPlanes, nplanes - done);
-        // Band length: every plane is cut into bands of about `target` ring periods. The choice
+    // (the planes of a batch are a few geometries repeated — luma and chroma of every frame: the search below runs over the distinct ones, weighted)
+    struct Geo {
+        int h, ntx, count;
+    };
+    std::vector<Geo> geos;
+    for (int i = 0; i < n; ++i) {
+        bool found = false;
+        for (Geo &g : geos)
+            if (g.h == planes[i].h && g.ntx == spans[i].ntx) {
+                ++g.count;
+                found = true;
+                break;
+            }
+        if (!found) geos.push_back({planes[i].h, spans[i].ntx, 1});
+    }
+        // The choice
         // trades re-read halo rows (2r+D per band: shorter bands = more traffic) against how well
         // the waves fill the chip's wave slots over time: with W waves of up to max_len periods
         // running in ceil(W / slots) generations, the fraction of slot-time doing work is
@@ -937,11 +937,10 @@ int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const Ri
         double waves_out = 0;
         auto cost_for = [&](int target) {
             double work = 0, waves = 0, max_len = 0;
-            for (int i = 0; i < n; ++i) {
-                const vszip_plane &s = planes[done + i];
-                const int P = (s.h + G::NR - 1) / G::NR;
-                const int nb = bands_for(s.h, P, target);
-                const double ntx = (double)spans[done + i].ntx;
+            for (const Geo &g : geos) {
+                const int P = (g.h + G::NR - 1) / G::NR;
+                const int nb = bands_for(g.h, P, target);
+                const double ntx = (double)g.ntx * g.count;
                 work += ntx * (P + nb * halo_p);
                 waves += ntx * nb;
                 max_len = std::max(max_len, (double)((P + nb - 1) / nb) + halo_p);
@@ -965,9 +964,40 @@ int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const Ri
                 target = t;
             }
         }
+        *waves_ret = (cost_for(target), waves_out);
+        return target;
+}
+
+
+// One kernel instance over the given column spans of the planes. GEN = false is the fast form: every lane of every tile it is given must hold a whole pixel
+// group inside the plane or its left mirror image (the caller's rule); GEN = true takes any width and any tile.
+template <typename T, int R, int PXN, bool GEN>
+int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const RingSpan *all_spans, int nall) {
+    using G = typename RingWave<T, R, false, PXN>::G;
+    std::vector<vszip_plane> planes_v;
+    std::vector<RingSpan> spans_v;
+    for (int i = 0; i < nall; ++i)
+        if (all_spans[i].ntx > 0) {
+            planes_v.push_back(all_planes[i]);
+            spans_v.push_back(all_spans[i]);
+        }
+    const vszip_plane *planes = planes_v.data();
+    const RingSpan *spans = spans_v.data();
+    const int nplanes = (int)planes_v.size();
+    int done = 0;
+    while (done < nplanes) {
+        RingParams prm;
+        const int n = std::min(kRingMaxPlanes, nplanes - done);
+        auto bands_for = [](int h, int P, int target) { return std::max((h % G::NR != 0 && P >= 2) ? 2 : 1, (P + target / 2) / target); };
+        double waves_out = 0;
+        int target = ring_plan<T, R, PXN>(planes + done, spans + done, n, &waves_out);
         if (ctx->opt.ring_periods > 0) target = ctx->opt.ring_periods;  // development sweep knob (-DVSZIP_DEV_VARIANTS)
 #ifdef VSZIP_RING_PERIODS_FIXED  // (tools/variant.sh sweeps: one translation unit, no option)
         target = VSZIP_RING_PERIODS_FIXED;
+#endif
+#ifdef VSZIP_RING_PLAN_DEBUG  // (tools/variant.sh: what the band planner chose)
+        fprintf(stderr, "ring plan PX%d GEN%d r=%d: n=%d target=%d waves=%.0f slots=%d NR=%d | plane0 %dx%d ntx=%d\n", PXN, (int)GEN, R, n, target, waves_out, 256 * 4 * G::WPE, G::NR,
+                planes[done].w, planes[done].h, spans[done].ntx);
 #endif
         VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
         int blocks = 0, fit = n;
@@ -1027,13 +1057,41 @@ bool ring_ok(const vszip_plane *planes, int nplanes) {
 // (64 4K YUV420P8 frames, 16 against 8 pixels a lane, tools/u8_px16_sweep.py: r = 1 ... 7 -10 ... -12 % of the time, 8 ... 16 -4 ... -8 %, 17 ... 19 -11 ... -13 %,
 // 20 ... 22 +12 ... +17 %)
 constexpr int kRing16MaxR = 19;
-template <typename T>
+// A wave of the 16-pixel form puts out 992 (r <= 15) or 960 columns, one of the 8-pixel form 480 / 464: widths that fill the wide tiles badly lose more to
+// the empty lanes than the wider loads return — r = 13, 16 against 8 pixels a lane (tools/u8_px_by_size.py, Gpixel/s): 1280 x 720 941 / 1128, 2560 x 1440
+// 1516 / 1607, 4096 x 2160 1341 / 1637, but 1080p 1724 / 1613 and 4K 1815 / 1687. From r = 8 on the wide form is taken only where its tiles are at least
+// 0.93 as full as the narrow ones (small radii keep it everywhere: r = 2 wins 2-21 % at every size).
+template <typename T, int R>
 bool ring16_ok(const vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     if (sizeof(T) != 1 || ctx->opt.ct_u8_px8) return false;
+    using G16 = RingGeom<R, 4, 16>;
+    using G8 = RingGeom<R, 2, 8>;
+    double px = 0, t16 = 0, t8 = 0;
     for (int i = 0; i < nplanes; ++i) {
         const vszip_plane &p = planes[i];
         if (p.w < 32) return false;
         if ((reinterpret_cast<uintptr_t>(p.src) | reinterpret_cast<uintptr_t>(p.dst) | (uintptr_t)p.src_stride | (uintptr_t)p.dst_stride) & 15) return false;
+        px += (double)p.w * p.h;
+        t16 += (double)((p.w + G16::TWO - 1) / G16::TWO) * G16::TWO * p.h;
+        t8 += (double)((p.w + G8::TWO - 1) / G8::TWO) * G8::TWO * p.h;
+    }
+    if (R >= 8 && px / t16 < 0.93 * (px / t8)) return false;
+    // ... and only where its band plan fills its wave slots as the narrow form's does: two waves a SIMD with a third of the slots empty have nothing to hide their
+    // latencies behind (1920 x 1088: 62-69 % of 2 048 slots, 22 % slower than 1920 x 1080 at 87 %, while the narrow form fills 2 816 of its 3 072 either way;
+    // tools/u8_height_probe.py). The plans cost a few microseconds each: ring_plan searches over the batch's DISTINCT geometries — over all 192 planes it took
+    // 50-100 us of host time a call, which launches of 160-300 us (1080p batches) did not hide: every such leg ran 7 % below what the device delivers.
+    if (R >= 8) {
+        const int n = std::min(nplanes, kRingMaxPlanes);
+        std::vector<RingSpan> s16(n), s8(n);
+        for (int i = 0; i < n; ++i) {
+            s16[i] = {0, (planes[i].w + G16::TWO - 1) / G16::TWO};
+            s8[i] = {0, (planes[i].w + G8::TWO - 1) / G8::TWO};
+        }
+        double w16 = 0, w8 = 0;
+        ring_plan<T, R, 16>(planes, s16.data(), n, &w16);
+        ring_plan<T, R, 8>(planes, s8.data(), n, &w8);
+        const double f16 = w16 / (256.0 * 4 * G16::WPE), f8 = w8 / (256.0 * 4 * G8::WPE);
+        if (f16 < 0.8 && f8 > f16 + 0.05) return false;
     }
     return true;
 }
@@ -1085,7 +1143,7 @@ struct CtIntDispatch {
         if constexpr (VSZIP_R_ENABLED(R)) if (r == R) {
             if (ctx->scan_mode == 0 && ring_ok<T>(planes, nplanes)) {
                 if constexpr (sizeof(T) == 1 && R <= kRing16MaxR) {
-                    if (ring16_ok<T>(ctx, planes, nplanes)) return run_ct_ring<T, R, 16>(ctx, planes, nplanes);
+                    if (ring16_ok<T, R>(ctx, planes, nplanes)) return run_ct_ring<T, R, 16>(ctx, planes, nplanes);
                 }
                 return run_ct_ring<T, R, 8>(ctx, planes, nplanes);
             }
