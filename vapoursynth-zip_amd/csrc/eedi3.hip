@@ -137,11 +137,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     // kRegWin (round 4, the default geometry): t_base never goes to LDS — see cost_pass_fixed below
     constexpr bool kRegWin = FIXED && NIT2 == 1 && MD % kU == 0;
     __shared__ __attribute__((aligned(16))) float tbws[kRegWin ? 1 : 2][kU][kTbW];  // the (2*nrad+1)-tap window sums of the kU directions of the current pass (and, without kRegWin, their t_base in front)
-#ifdef VSZIP_E3_CTILE65  // (sweeps: the round-3 tile, one 4-byte read per column in front of the Viterbi chain)
-    constexpr int kCtP = kXB + 1;
-#else
     constexpr int kCtP = kXB + 4;  // 16-byte aligned rows: a direction's 64 costs come back as 16 ds_read_b128, free of bank conflicts at this pitch
-#endif
     __shared__ __attribute__((aligned(16))) float ctile[2 * MD + 1][kCtP];
     float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[kRegWin ? 0 : 1];
 
@@ -303,54 +299,20 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             // u < 0: direction i + 1 reads at lane L what direction i reads at lane L - 1, and needs its entries from 2 (i + 1) on only;
             // u >= 0: direction i reads what direction i + 1 reads at lane L + 1, and nothing past entry 64 + 2 MD + 2 nrad (< 122) is read back
             constexpr int ia = ug < 0 ? 0 : nd - 1;
-#ifdef VSZIP_E3_ASM_LDS  // (sweeps: the six 8-byte reads as six ds_read_b64 — the compiler pairs them into ds_read2_b64)
-            float2 a, c, e;
-            {
-                const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)&rows[0][j];
-                constexpr int sh = -2 * (ug + ia) * 4;
-                uint64_t qa, qc, qe, qb, qd, qf;
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qa) : "v"(base), "n"(0));
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qc) : "v"(base), "n"(kRowW * 4));
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qe) : "v"(base), "n"(2 * kRowW * 4));
-                const uint32_t bs = base + sh;
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb) : "v"(bs), "n"(kRowW * 4));
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qd) : "v"(bs), "n"(2 * kRowW * 4));
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qf) : "v"(bs), "n"(3 * kRowW * 4));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa), "+v"(qc), "+v"(qe), "+v"(qb), "+v"(qd), "+v"(qf));
-                auto f2 = [](uint64_t q) { return make_float2(__uint_as_float((uint32_t)q), __uint_as_float((uint32_t)(q >> 32))); };
-                a = f2(qa), c = f2(qc), e = f2(qe), b[ia] = f2(qb), d[ia] = f2(qd), f[ia] = f2(qf);
-            }
-#else
             const float2 a = *reinterpret_cast<const float2 *>(&rows[0][j]);
             const float2 c = *reinterpret_cast<const float2 *>(&rows[1][j]);
             const float2 e = *reinterpret_cast<const float2 *>(&rows[2][j]);
             b[ia] = *reinterpret_cast<const float2 *>(&rows[1][j - 2 * (ug + ia)]);
             d[ia] = *reinterpret_cast<const float2 *>(&rows[2][j - 2 * (ug + ia)]);
             f[ia] = *reinterpret_cast<const float2 *>(&rows[3][j - 2 * (ug + ia)]);
-#endif
-#ifdef VSZIP_E3_TAPS_LDS  // (sweeps: every direction's shifted taps from LDS)
-#pragma unroll
-            for (int i = 0; i < nd; ++i) {
-                if (i == ia) continue;
-                b[i] = *reinterpret_cast<const float2 *>(&rows[1][j - 2 * (ug + i)]);
-                d[i] = *reinterpret_cast<const float2 *>(&rows[2][j - 2 * (ug + i)]);
-                f[i] = *reinterpret_cast<const float2 *>(&rows[3][j - 2 * (ug + i)]);
-            }
-            if constexpr (false) {
-#else
             if constexpr (ug < 0) {
-#endif
 #pragma unroll
                 for (int i = 1; i < nd; ++i) {
                     b[i] = make_float2(lane_below0(b[i - 1].x), lane_below0(b[i - 1].y));
                     d[i] = make_float2(lane_below0(d[i - 1].x), lane_below0(d[i - 1].y));
                     f[i] = make_float2(lane_below0(f[i - 1].x), lane_below0(f[i - 1].y));
                 }
-            } else
-#ifdef VSZIP_E3_TAPS_LDS
-                if constexpr (false)
-#endif
-            {
+            } else {
 #pragma unroll
                 for (int i = nd - 2; i >= 0; --i) {
                     b[i] = make_float2(lane_above0(b[i + 1].x), lane_above0(b[i + 1].y));
@@ -485,10 +447,6 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
 #pragma unroll
         for (int xl = 0; xl < kXB; ++xl) tcv[xl] = INFINITY;
         if (lane < tpitch) {
-#ifdef VSZIP_E3_CTILE65
-#pragma unroll
-            for (int xl = 0; xl < kXB; ++xl) tcv[xl] = ctile[lane][xl];
-#else
 #pragma unroll
             for (int q = 0; q < kXB / 4; ++q) {
                 const float4 v4 = *reinterpret_cast<const float4 *>(&ctile[lane][4 * q]);
@@ -497,7 +455,6 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 tcv[4 * q + 2] = v4.z;
                 tcv[4 * q + 3] = v4.w;
             }
-#endif
         }
         uint32_t pk[kXB / 4];
 #pragma unroll
