@@ -1828,7 +1828,12 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     if (maxL > 8192) vp.gline = reinterpret_cast<float *>(base + gline_off);
     const bool vc_lds = up->vcheck > 0 && maxL <= kVcLdsMaxL && !ctx->opt.vcheck_global;
     auto launch_vcheck_lds = [&](hipStream_t st, int first, int count) {
-        const int cols = maxL <= 2048 ? 2 : maxL <= 2560 ? 3 : 4;
+        int gl = 0;  // the widest line of THIS launch (the short planes of a 4K 4:2:0 clip are 1920 wide: two columns a thread, not the luma's four)
+        for (int i = first; i < first + count; ++i) gl = std::max(gl, vp.p[i].w);
+#ifdef VSZIP_VC_COLS_BY_CALL  // (sweeps)
+        gl = maxL;
+#endif
+        const int cols = gl <= 2048 ? 2 : gl <= 2560 ? 3 : 4;
         bool any_sc = false;
         for (int i = first; i < first + count; ++i) any_sc = any_sc || vp.scp[i] != nullptr;
         vp.plane_base = first;
