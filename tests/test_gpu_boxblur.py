@@ -448,3 +448,41 @@ def test_ct_ring_planes_split_by_columns(dev, oracle, dtype, r):
                 narrow = run()
             for a, b in zip(got, narrow):
                 assert np.array_equal(a, b), (r, shapes, "8 pixels a lane")
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("r", [1, 2, 5, 8, 13, 16, 19, 20, 22])
+def test_horizontal_only_takes_the_ring_kernel(dev, oracle, dtype, r):
+    """Round 4: BoxBlur(hradius = r, vradius = 0) on integer planes runs through the compile-time-radius ring kernel with a one-row window — the reference's
+    run-time path computes the same closed form for a row. Against the oracle and against the RT row kernel (VSZIP_BOXBLUR_NO_CT_H=1), bit for bit: aligned and
+    cropped widths (both lane widths, the column split), one-tile and many-tile rows, planes shorter than the ring kernel takes (they stay with the RT kernel),
+    YUV 4:2:0 batches, saturated rows; hpasses = 2 and a vertical pass beside it stay on the RT path and agree as before."""
+    batches = [[(64, 1920)], [(70, 1918)], [(61, 992)], [(64, 1009)], [(80, 496)], [(55, 2000)], [(40, 640)], [(270, 1920), (135, 960), (135, 960)], [(96, 1366), (64, 683), (64, 683)],
+               [(59, 4096)], [(120, 64), (120, 72)]]
+    for shapes in batches:
+        if min(sh[1] for sh in shapes) <= 2 * r:
+            continue
+        planes = [fx.splitmix64_plane(270 + i + r, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
+        planes[0][3] = np.iinfo(dtype).max
+        planes[0][-1] = 0
+
+        def run(*args):
+            srcs = [dev.upload(p) for p in planes]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for p in planes]
+            dev.boxblur(srcs, dsts, *args)
+            return [dev.download(d) for d in dsts]
+
+        got = run(r, 1, 0, 0)
+        with dev.options(VSZIP_BOXBLUR_NO_CT_H=1):
+            rt = run(r, 1, 0, 0)
+        for p, a, b in zip(planes, got, rt):
+            want = oracle.boxblur(p, r, 1, 0, 0)
+            assert np.array_equal(a, want), (r, shapes, p.shape, int((a != want).sum()), np.argwhere(a != want)[:4].tolist())
+            assert np.array_equal(b, want), (r, shapes, p.shape, "RT row kernel")
+    p = fx.tiled_natural((96, 600), dtype, 2)
+    for args in ((r, 2, 0, 0), (r, 1, 3, 1), (r, 1, 0, 1)):
+        if 2 * args[2] >= 96:
+            continue
+        s, d = dev.upload(p), dev.empty(96, 600, dtype)
+        dev.boxblur([s], [d], *args)
+        assert np.array_equal(dev.download(d), oracle.boxblur(p, *args)), args

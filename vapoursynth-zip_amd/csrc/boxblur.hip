@@ -9,6 +9,12 @@ int vszip_bb_ct_u8_c(vszip_ctx *, int, const vszip_plane *, int);
 int vszip_bb_ct_u16_a(vszip_ctx *, int, const vszip_plane *, int);
 int vszip_bb_ct_u16_b(vszip_ctx *, int, const vszip_plane *, int);
 int vszip_bb_ct_u16_c(vszip_ctx *, int, const vszip_plane *, int);
+int vszip_bb_ct_u8_a_h(vszip_ctx *, int, const vszip_plane *, int);
+int vszip_bb_ct_u8_b_h(vszip_ctx *, int, const vszip_plane *, int);
+int vszip_bb_ct_u8_c_h(vszip_ctx *, int, const vszip_plane *, int);
+int vszip_bb_ct_u16_a_h(vszip_ctx *, int, const vszip_plane *, int);
+int vszip_bb_ct_u16_b_h(vszip_ctx *, int, const vszip_plane *, int);
+int vszip_bb_ct_u16_c_h(vszip_ctx *, int, const vszip_plane *, int);
 // boxblur_rt.hip
 int vszip_bb_rt(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses);
 int vszip_bb_ct_float(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int radius);
@@ -16,6 +22,12 @@ int vszip_bb_ct_float(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int 
 static int ct_int(vszip_ctx *ctx, int dtype, int r, const vszip_plane *planes, int nplanes) {
     if (dtype == VSZIP_U8) return r <= 8 ? vszip_bb_ct_u8_a(ctx, r, planes, nplanes) : r <= 15 ? vszip_bb_ct_u8_b(ctx, r, planes, nplanes) : vszip_bb_ct_u8_c(ctx, r, planes, nplanes);
     return r <= 8 ? vszip_bb_ct_u16_a(ctx, r, planes, nplanes) : r <= 15 ? vszip_bb_ct_u16_b(ctx, r, planes, nplanes) : vszip_bb_ct_u16_c(ctx, r, planes, nplanes);
+}
+
+// the horizontal pass alone through the compile-time-radius ring kernel (boxblur_ct.hpp, CtIntDispatch::run_h); VSZIP_ERR_UNSUPPORTED: not for these planes
+static int ct_int_h(vszip_ctx *ctx, int dtype, int r, const vszip_plane *planes, int nplanes) {
+    if (dtype == VSZIP_U8) return r <= 8 ? vszip_bb_ct_u8_a_h(ctx, r, planes, nplanes) : r <= 15 ? vszip_bb_ct_u8_b_h(ctx, r, planes, nplanes) : vszip_bb_ct_u8_c_h(ctx, r, planes, nplanes);
+    return r <= 8 ? vszip_bb_ct_u16_a_h(ctx, r, planes, nplanes) : r <= 15 ? vszip_bb_ct_u16_b_h(ctx, r, planes, nplanes) : vszip_bb_ct_u16_c_h(ctx, r, planes, nplanes);
 }
 
 VSZIP_EXPORT int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses) {
@@ -44,6 +56,11 @@ VSZIP_EXPORT int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *pla
             case VSZIP_F32: return vszip_bb_ct_float(ctx, dtype, planes, nplanes, hradius);
             default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: not supported Int format.");
         }
+    }
+    // one horizontal pass of r <= 22 on integer planes, nothing vertical: the ring kernel with a one-row window (same arithmetic as the RT row pass)
+    if (hblur && !vblur && hpasses == 1 && hradius <= 22 && (dtype == VSZIP_U8 || dtype == VSZIP_U16) && !ctx->opt.boxblur_no_ct_h) {
+        const int rc = ct_int_h(ctx, dtype, hradius, planes, nplanes);
+        if (rc != VSZIP_ERR_UNSUPPORTED) return rc;
     }
     return vszip_bb_rt(ctx, dtype, planes, nplanes, hradius, hpasses, vradius, vpasses);
 }

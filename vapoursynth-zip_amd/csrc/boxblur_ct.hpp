@@ -343,9 +343,10 @@ __global__ __launch_bounds__(64) void boxblur_ct_int_kernel(const BBParams prm) 
 // Ring kernel
 // ---------------------------------------------------------------------------
 
-template <int R, int SLOT_VGPRS = 4, int PXN = 8>
+// RV: the vertical radius — R, or 0 for a horizontal-only blur (round 4: the window is then the row itself, the ring only its prefetch)
+template <int R, int SLOT_VGPRS = 4, int PXN = 8, int RV = R>
 struct RingGeom {
-    static constexpr int K = 2 * R + 1;
+    static constexpr int K = 2 * RV + 1;  // rows of the (vertical) window
     static constexpr int HL = ((R + 1 + PXN - 1) / PXN) * PXN;  // left halo  (>= R + 1)
     static constexpr int HR = ((R + PXN - 1) / PXN) * PXN;      // right halo (>= R)
 #ifdef VSZIP_RING_OUT_LANES  // (sweeps: fewer output lanes per wave, e.g. 56 = whole 128-byte lines per row segment)
@@ -360,18 +361,18 @@ struct RingGeom {
     // VGPRs a SIMD lane has). A shallow prefetch (D = 1) is taken when it buys a wave per SIMD —
     // the other waves then hide the latency; otherwise D is 3, 5 or 7, whichever makes NR a
     // multiple of KL, the prefetch ring of the K_row column pixels (statically indexed, S % KL).
-    static constexpr int est_vgprs(int d) { return (2 * R + 1 + d) * SLOT_VGPRS + (PXN == 16 ? 104 : 56); }
+    static constexpr int est_vgprs(int d) { return (2 * RV + 1 + d) * SLOT_VGPRS + (PXN == 16 ? 104 : 56); }
     static constexpr int tier(int v) { return v <= 128 ? 4 : (v <= 168 ? 3 : 2); }
-    static constexpr int D3 = (2 * R + 4) % 3 == 0 ? 3 : ((2 * R + 6) % 3 == 0 ? 5 : 7);
+    static constexpr int D3 = (2 * RV + 4) % 3 == 0 ? 3 : ((2 * RV + 6) % 3 == 0 ? 5 : 7);
 #ifdef VSZIP_RING_D
     static constexpr int D = VSZIP_RING_D | 1;
-    static constexpr int KL = (2 * R + 1 + D) % 3 == 0 ? 3 : 2;
+    static constexpr int KL = (2 * RV + 1 + D) % 3 == 0 ? 3 : 2;
 #else
     static constexpr bool SHALLOW = tier(est_vgprs(1)) > tier(est_vgprs(D3));
     static constexpr int D = SHALLOW ? 1 : D3;
     static constexpr int KL = SHALLOW ? 2 : 3;
 #endif
-    static constexpr int NR = 2 * R + 1 + D;   // ring slots
+    static constexpr int NR = 2 * RV + 1 + D;   // ring slots
 #ifdef VSZIP_RING_WPE
     static constexpr int WPE = VSZIP_RING_WPE;
 #else
@@ -381,7 +382,7 @@ struct RingGeom {
     static constexpr int WPE = (SLOT_VGPRS == 2 && PXN == 8) ? (tier(est_vgprs(D)) > 3 ? 3 : tier(est_vgprs(D))) : tier(est_vgprs(D));
 #endif
     static_assert(NR % KL == 0, "K-column ring must divide the period");
-    static constexpr uint32_t MAGIC = (uint32_t)(((1ull << 32) + K - 1) / K);  // ceil(2^32 / k): mulhi(n, MAGIC) == n / k
+    static constexpr uint32_t MAGIC = K > 1 ? (uint32_t)(((1ull << 32) + K - 1) / K) : 0u;  // ceil(2^32 / k): mulhi(n, MAGIC) == n / k (k = 1: no division)
 };
 
 // All per-wave state of the ring kernel. step<S>() is instantiated once per ring
@@ -397,14 +398,15 @@ struct RingGeom {
 // real 8-pixel group, pixel order reversed in registers, so that the window sum is
 // the same compile-time-offset prefix difference everywhere. GENERAL = true takes
 // any width: plane edges are evaluated as prefix differences over real columns.
-template <typename T, int R, bool GENERAL, int PXN = 8>
+template <typename T, int R, bool GENERAL, int PXN = 8, bool HONLY = false>
 struct RingWave {
     static_assert(PXN == 8 || (PXN == 16 && sizeof(T) == 1 && !GENERAL), "16 pixels a lane: 8-bit planes, whole 16-pixel groups");
-    using G = RingGeom<R, (int)(sizeof(T) * PXN / 4), PXN>;
+    static constexpr int RV = HONLY ? 0 : R;  // vertical radius
+    using G = RingGeom<R, (int)(sizeof(T) * PXN / 4), PXN, RV>;
     using RawT = RawN<T, PXN>;
     using Vec = decltype(RawT{}.q);
     static constexpr int NR = G::NR;
-    static constexpr uint64_t INV = ((1ull << 32) + R) / (uint64_t)G::K;
+    static constexpr uint64_t INV = ((1ull << 32) + R) / (uint64_t)(2 * R + 1);  // (the horizontal window)
     static constexpr uint32_t INV2 = (uint32_t)(INV >> 16);
 
     RawT ring[NR];
@@ -460,7 +462,7 @@ struct RingWave {
     // E_0 of the current row from the K columns: lanes 0..r hold weight * tmp, the rest 0
     __device__ __forceinline__ uint32_t krow_now() const {
         constexpr uint32_t INVLO = (uint32_t)(INV & 0xffffu);
-        uint32_t v = __umul24(__umulhi(kcol, G::MAGIC), kwgt);
+        uint32_t v = __umul24(G::K > 1 ? __umulhi(kcol, G::MAGIC) : kcol, kwgt);
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
@@ -498,13 +500,13 @@ struct RingWave {
     // row i, not row i+1+r, i.e. virtual row v >= h stands for source row v-r-1.
     // With that map the ring's "entering row" slot is always the right one.
     __device__ __forceinline__ uint32_t row_off(int v) const {
-        const int r = v < 0 ? -v : (v < h ? v : v - R - 1);
+        const int r = v < 0 ? -v : (v < h ? v : v - RV - 1);
         return (uint32_t)min(r, h - 1) * srow;
     }
 
     template <int J>
     __device__ __forceinline__ void fill(int y0) {
-        ring[J] = fetch_off(row_off(y0 - R + J));
+        ring[J] = fetch_off(row_off(y0 - RV + J));
     }
     template <int J>
     __device__ __forceinline__ void accum() {
@@ -666,12 +668,14 @@ struct RingWave {
         uint32_t p[PXN];
 #pragma unroll
         for (int k = 0; k < PXN; ++k) {
-            if constexpr (sizeof(T) == 1) {
+            if constexpr (G::K == 1) {
+                p[k] = col[k];  // (horizontal only: the "vertical mean" of one row)
+            } else if constexpr (sizeof(T) == 1) {
                 // 8-bit samples: col <= 255 k + r < 2^14, so floor(col / k) == (col * ceil(2^19 / k)) >> 19 exactly
                 // (error term col * (M k - 2^19) < 2^19 since M k - 2^19 < k) and the product fits 32 bits: a
                 // full-rate 24-bit multiply and a shift instead of the quarter-rate v_mul_hi_u32
                 constexpr uint32_t M19 = (uint32_t)(((1u << 19) + G::K - 1) / G::K);
-                static_assert((uint64_t)(255u * G::K + R) * (M19 * G::K - (1u << 19)) < (1u << 19), "8-bit divide-by-k shortcut must be exact");
+                static_assert((uint64_t)(255u * G::K + RV) * (M19 * G::K - (1u << 19)) < (1u << 19), "8-bit divide-by-k shortcut must be exact");
                 p[k] = __umul24(col[k], M19) >> 19;
             } else {
                 p[k] = __umulhi(col[k], G::MAGIC);
@@ -698,7 +702,7 @@ struct RingWave {
         // hangs over the bottom edge, :61-66), leaving row i-r; refill the freed slot
         // with row i+1+r+D (|v| above the top edge, clamped below the bottom edge).
         {
-            constexpr int E = (S + 1 + 2 * R) % NR;
+            constexpr int E = (S + 1 + 2 * RV) % NR;
             uint32_t a[PXN], sb[PXN];
             fix_order(ring[E]);
             unpackN(ring[E], a);
@@ -737,9 +741,9 @@ struct RingWave {
             kn_off += srow;
             ko_off += srow;
         } else {
-            next_off = row_off(i + 2 + R + G::D);
-            kn_off = row_off(i + 2 + R + G::KL);
-            ko_off = row_off(i + 1 - R + G::KL);
+            next_off = row_off(i + 2 + RV + G::D);
+            kn_off = row_off(i + 2 + RV + G::KL);
+            ko_off = row_off(i + 1 - RV + G::KL);
         }
 #ifndef VSZIP_DIAG_NO_FENCE  // (timing diagnostics only: wrong results)
         wave_lds_fence();
@@ -752,10 +756,11 @@ struct RingWave {
     }
 };
 
-template <typename T, int R, bool GENERAL, int PXN = 8>
-__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PXN / 4), PXN>::WPE)) void boxblur_ct_ring_kernel(const RingParams prm) {
-    using W = RingWave<T, R, GENERAL, PXN>;
+template <typename T, int R, bool GENERAL, int PXN = 8, bool HONLY = false>
+__global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PXN / 4), PXN, (HONLY ? 0 : R)>::WPE)) void boxblur_ct_ring_kernel(const RingParams prm) {
+    using W = RingWave<T, R, GENERAL, PXN, HONLY>;
     using G = typename W::G;
+    constexpr int RV = W::RV;
     static_assert(G::NR % 2 == 0 && G::NR <= 64, "ring period must be even and fit a wave");
     __shared__ __attribute__((aligned(16))) uint32_t P[2 * 64 * PXN];
 
@@ -817,11 +822,11 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
     // descriptors: raw (stride 0), 32-bit data format; num_records = plane bytes (ring_ok keeps it < 4 GiB)
     st.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(pl.src), 0, (int)((uint32_t)pl.h * st.srow), 0x00020000);
     st.rd = __builtin_amdgcn_make_buffer_rsrc(pl.dst, 0, (int)((uint32_t)pl.h * st.drow), 0x00020000);
-    st.plain = (y0 - R >= 0) && (y0 + band_rows + R + G::D + 2 < pl.h);
+    st.plain = (y0 - RV >= 0) && (y0 + band_rows + RV + G::D + 2 < pl.h);
 
     st.fill_all(y0, std::make_integer_sequence<int, G::NR>{});
 #pragma unroll
-    for (int k = 0; k < PXN; ++k) st.col[k] = R;  // the rounding term of (col + r) / k rides along
+    for (int k = 0; k < PXN; ++k) st.col[k] = RV;  // the rounding term of (col + r) / k rides along
     st.accum_all(std::make_integer_sequence<int, (int)G::K>{});
     // K columns: window sum of rows y0-r .. y0+r at plane column min(lane, r), then the first KL
     // entering / leaving pixels
@@ -829,20 +834,20 @@ __global__ __launch_bounds__(64, (GENERAL ? 2 : RingGeom<R, (int)(sizeof(T) * PX
         const int kc = min(lane, R);
         st.kvo = (uint32_t)(kc * (int)sizeof(T));
         st.kwgt = lane < R ? 2u : (lane == R ? 1u : 0u);
-        uint32_t acc = R;
+        uint32_t acc = RV;
 #pragma unroll
-        for (int k = 0; k < (int)G::K; ++k) acc += st.fetch_px(st.row_off(y0 - R + k));
+        for (int k = 0; k < (int)G::K; ++k) acc += st.fetch_px(st.row_off(y0 - RV + k));
         st.kcol = acc;
 #pragma unroll
         for (int j = 0; j < G::KL; ++j) {
-            st.kn[j] = st.fetch_px(st.row_off(y0 + j + 1 + R));
-            st.ko[j] = st.fetch_px(st.row_off(y0 + j - R));
+            st.kn[j] = st.fetch_px(st.row_off(y0 + j + 1 + RV));
+            st.ko[j] = st.fetch_px(st.row_off(y0 + j - RV));
         }
-        st.kn_off = st.row_off(y0 + G::KL + 1 + R);
-        st.ko_off = st.row_off(y0 + G::KL - R);
+        st.kn_off = st.row_off(y0 + G::KL + 1 + RV);
+        st.ko_off = st.row_off(y0 + G::KL - RV);
         st.kr_prev = 0;
     }
-    st.next_off = st.row_off(y0 + 1 + R + G::D);  // window rows y0-r .. y0+r+D are in the ring
+    st.next_off = st.row_off(y0 + 1 + RV + G::D);  // window rows y0-r .. y0+r+D are in the ring
     st.out_off = (uint32_t)y0 * st.drow;
 
     const int y1 = y0 + band_rows;
@@ -905,9 +910,9 @@ struct RingSpan {
 };
 
 // Band length of a launch: every plane is cut into bands of about `target` ring periods (returned; *waves_out = the waves of that plan).
-template <typename T, int R, int PXN>
+template <typename T, int R, int PXN, bool HONLY = false>
 int ring_plan(const vszip_plane *planes, const RingSpan *spans, int n, double *waves_ret) {
-    using G = typename RingWave<T, R, false, PXN>::G;
+    using G = typename RingWave<T, R, false, PXN, HONLY>::G;
     // (the planes of a batch are a few geometries repeated — luma and chroma of every frame: the search below runs over the distinct ones, weighted)
     struct Geo {
         int h, ntx, count;
@@ -932,7 +937,7 @@ int ring_plan(const vszip_plane *planes, const RingSpan *spans, int n, double *w
         // (tools/sweep_periods.sh: e.g. 64 4K frames — 19 periods: 4+2 equal bands, 3072 waves =
         // every slot, 603 us; 26: 635 us; 16: 1.17 generations, 710 us; 39: half the slots, 694 us).
         auto bands_for = [](int h, int P, int target) { return std::max((h % G::NR != 0 && P >= 2) ? 2 : 1, (P + target / 2) / target); };
-        const double halo_p = (double)(2 * R + G::D) / G::NR;  // warm-up rows of a band, in periods
+        const double halo_p = (double)(G::K - 1 + G::D) / G::NR;  // warm-up rows of a band, in periods
         const double slots = 256.0 * 4 * G::WPE;
         double waves_out = 0;
         auto cost_for = [&](int target) {
@@ -971,9 +976,9 @@ int ring_plan(const vszip_plane *planes, const RingSpan *spans, int n, double *w
 
 // One kernel instance over the given column spans of the planes. GEN = false is the fast form: every lane of every tile it is given must hold a whole pixel
 // group inside the plane or its left mirror image (the caller's rule); GEN = true takes any width and any tile.
-template <typename T, int R, int PXN, bool GEN>
+template <typename T, int R, int PXN, bool GEN, bool HONLY = false>
 int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const RingSpan *all_spans, int nall) {
-    using G = typename RingWave<T, R, false, PXN>::G;
+    using G = typename RingWave<T, R, false, PXN, HONLY>::G;
     std::vector<vszip_plane> planes_v;
     std::vector<RingSpan> spans_v;
     for (int i = 0; i < nall; ++i)
@@ -990,7 +995,7 @@ int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const Ri
         const int n = std::min(kRingMaxPlanes, nplanes - done);
         auto bands_for = [](int h, int P, int target) { return std::max((h % G::NR != 0 && P >= 2) ? 2 : 1, (P + target / 2) / target); };
         double waves_out = 0;
-        int target = ring_plan<T, R, PXN>(planes + done, spans + done, n, &waves_out);
+        int target = ring_plan<T, R, PXN, HONLY>(planes + done, spans + done, n, &waves_out);
         if (ctx->opt.ring_periods > 0) target = ctx->opt.ring_periods;  // development sweep knob (-DVSZIP_DEV_VARIANTS)
 #ifdef VSZIP_RING_PERIODS_FIXED  // (tools/variant.sh sweeps: one translation unit, no option)
         target = VSZIP_RING_PERIODS_FIXED;
@@ -1028,7 +1033,7 @@ int launch_ct_ring_spans(vszip_ctx *ctx, const vszip_plane *all_planes, const Ri
         const dim3 grid(((blocks + 7) / 8) * 8);
         {
             vszip_probe_scope probe(ctx);
-            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, GEN, PXN>), grid, dim3(64), 0, ctx->stream, prm);
+            hipLaunchKernelGGL((boxblur_ct_ring_kernel<T, R, GEN, PXN, HONLY>), grid, dim3(64), 0, ctx->stream, prm);
         }
         VSZIP_HIP_CHECK(ctx, hipGetLastError());
         done += fit;
@@ -1061,11 +1066,11 @@ constexpr int kRing16MaxR = 19;
 // the empty lanes than the wider loads return — r = 13, 16 against 8 pixels a lane (tools/u8_px_by_size.py, Gpixel/s): 1280 x 720 941 / 1128, 2560 x 1440
 // 1516 / 1607, 4096 x 2160 1341 / 1637, but 1080p 1724 / 1613 and 4K 1815 / 1687. From r = 8 on the wide form is taken only where its tiles are at least
 // 0.93 as full as the narrow ones (small radii keep it everywhere: r = 2 wins 2-21 % at every size).
-template <typename T, int R>
+template <typename T, int R, bool HONLY = false>
 bool ring16_ok(const vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
     if (sizeof(T) != 1 || ctx->opt.ct_u8_px8) return false;
-    using G16 = RingGeom<R, 4, 16>;
-    using G8 = RingGeom<R, 2, 8>;
+    using G16 = RingGeom<R, 4, 16, (HONLY ? 0 : R)>;
+    using G8 = RingGeom<R, 2, 8, (HONLY ? 0 : R)>;
     double px = 0, t16 = 0, t8 = 0;
     for (int i = 0; i < nplanes; ++i) {
         const vszip_plane &p = planes[i];
@@ -1088,8 +1093,8 @@ bool ring16_ok(const vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
             s8[i] = {0, (planes[i].w + G8::TWO - 1) / G8::TWO};
         }
         double w16 = 0, w8 = 0;
-        ring_plan<T, R, 16>(planes, s16.data(), n, &w16);
-        ring_plan<T, R, 8>(planes, s8.data(), n, &w8);
+        ring_plan<T, R, 16, HONLY>(planes, s16.data(), n, &w16);
+        ring_plan<T, R, 8, HONLY>(planes, s8.data(), n, &w8);
         const double f16 = w16 / (256.0 * 4 * G16::WPE), f8 = w8 / (256.0 * 4 * G8::WPE);
         if (f16 < 0.8 && f8 > f16 + 0.05) return false;
     }
@@ -1100,10 +1105,10 @@ bool ring16_ok(const vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
 // multiple — cropped clips, 1366 x 768, 854 x 480, the 959-sample chroma of a 1918-wide clip — used to send the WHOLE batch to the general form (about half
 // the rate, profiles/r04_cliff_sweep_before.txt). Round 4: such a plane is split by columns — the tiles whose every lane lies inside the plane (or in its left
 // mirror image) go to the fast form with the aligned planes, the last one or two tiles to the general form in a second launch.
-template <typename T, int R, int PXF>
+template <typename T, int R, int PXF, bool HONLY = false>
 int run_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
-    using GF = typename RingWave<T, R, false, PXF>::G;
-    using GG = typename RingWave<T, R, true, 8>::G;
+    using GF = typename RingWave<T, R, false, PXF, HONLY>::G;
+    using GG = typename RingWave<T, R, true, 8, HONLY>::G;
     std::vector<RingSpan> fast(nplanes), rest(nplanes);
     bool any_rest = false, any_fast = false;
     for (int i = 0; i < nplanes; ++i) {
@@ -1122,10 +1127,10 @@ int run_ct_ring(vszip_ctx *ctx, const vszip_plane *planes, int nplanes) {
         any_rest = any_rest || rest[i].ntx > 0;
     }
     if (any_fast) {
-        const int rc = launch_ct_ring_spans<T, R, PXF, false>(ctx, planes, fast.data(), nplanes);
+        const int rc = launch_ct_ring_spans<T, R, PXF, false, HONLY>(ctx, planes, fast.data(), nplanes);
         if (rc != VSZIP_OK) return rc;
     }
-    if (any_rest) return launch_ct_ring_spans<T, R, 8, true>(ctx, planes, rest.data(), nplanes);
+    if (any_rest) return launch_ct_ring_spans<T, R, 8, true, HONLY>(ctx, planes, rest.data(), nplanes);
     return VSZIP_OK;
 }
 
@@ -1153,6 +1158,23 @@ struct CtIntDispatch {
             return CtIntDispatch<T, R - 1, RLO>::run(ctx, r, planes, nplanes);
         else
             return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: CT radius not built (development build?)");
+    }
+    // Round 4: a horizontal-only blur of radius r (one pass) through the ring kernel with a one-row window. The reference sends it down its run-time-radius path
+    // (the radii differ, boxblur.zig:188), whose integer row pass is the same closed form as the compile-time one (blurInt :24-40 / hBlurInt :130-159: same start
+    // value, same 16.16 constants, same edge-duplicating mirror), so the results are the RT kernels' bit for bit (tests/test_gpu_boxblur.py) — at the fused
+    // kernel's rate instead of the row-at-a-time kernel's (8-bit 1080p: 0.82 -> 1.8 Tpx/s). VSZIP_ERR_UNSUPPORTED: not for these planes, take the RT path.
+    static int run_h(vszip_ctx *ctx, int r, const vszip_plane *planes, int nplanes) {
+        if constexpr (VSZIP_R_ENABLED(R)) if (r == R) {
+            if (ctx->scan_mode != 0 || !ring_ok<T>(planes, nplanes)) return VSZIP_ERR_UNSUPPORTED;
+            if constexpr (sizeof(T) == 1) {
+                if (ring16_ok<T, R, true>(ctx, planes, nplanes)) return run_ct_ring<T, R, 16, true>(ctx, planes, nplanes);
+            }
+            return run_ct_ring<T, R, 8, true>(ctx, planes, nplanes);
+        }
+        if constexpr (R > RLO)
+            return CtIntDispatch<T, R - 1, RLO>::run_h(ctx, r, planes, nplanes);
+        else
+            return VSZIP_ERR_UNSUPPORTED;
     }
 };
 
