@@ -30,6 +30,8 @@ static int ct_int_h(vszip_ctx *ctx, int dtype, int r, const vszip_plane *planes,
     return r <= 8 ? vszip_bb_ct_u16_a_h(ctx, r, planes, nplanes) : r <= 15 ? vszip_bb_ct_u16_b_h(ctx, r, planes, nplanes) : vszip_bb_ct_u16_c_h(ctx, r, planes, nplanes);
 }
 
+int vszip_bb_ct_row_pass(vszip_ctx *ctx, int dtype, int r, const vszip_plane *planes, int nplanes) { return ct_int_h(ctx, dtype, r, planes, nplanes); }
+
 VSZIP_EXPORT int vszip_boxblur(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, int hradius, int hpasses, int vradius, int vpasses) {
     if (!ctx || !planes || nplanes <= 0) return VSZIP_ERR_ARG;
     if (hradius < 0 || vradius < 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "BoxBlur: negative radius");

@@ -15,6 +15,9 @@
 
 #include "common.hpp"
 
+// boxblur.hip: one integer row pass of r <= 22 through the ring kernel (VSZIP_ERR_UNSUPPORTED: not for these planes)
+int vszip_bb_ct_row_pass(vszip_ctx *ctx, int dtype, int r, const vszip_plane *planes, int nplanes);
+
 namespace {
 
 constexpr int kMaxPlanesRT = 192;  // planes per launch (round 4: 64 YUV frames are one launch per pass; 48 before)
@@ -1816,6 +1819,24 @@ int launch_vsmall(vszip_ctx *ctx, const std::vector<RPlane> &, int, int, bool) {
 template <typename T>
 int launch_pass(vszip_ctx *ctx, const std::vector<RPlane> &pl, int radius, bool vertical, bool keep) {
     constexpr bool is_int = std::is_integral<T>::value;
+    // Round 4: an integer ROW pass of r <= 22 goes through the compile-time-radius ring kernel with a one-row window (boxblur_ct.hpp, CtIntDispatch::run_h:
+    // the same closed form, at the fused kernel's rate) wherever that kernel takes the planes; VSZIP_BOXBLUR_NO_CT_H=1 keeps the kernels below
+    if constexpr (is_int) {
+        if (!vertical && radius >= 1 && radius <= 22 && !ctx->opt.boxblur_no_ct_h) {
+            std::vector<vszip_plane> vp(pl.size());
+            for (size_t i = 0; i < pl.size(); ++i) {
+                vp[i] = vszip_plane{};
+                vp[i].src = pl[i].src;
+                vp[i].dst = pl[i].dst;
+                vp[i].src_stride = pl[i].sstride;
+                vp[i].dst_stride = pl[i].dstride;
+                vp[i].w = pl[i].w;
+                vp[i].h = pl[i].h;
+            }
+            const int rc = vszip_bb_ct_row_pass(ctx, sizeof(T) == 1 ? VSZIP_U8 : VSZIP_U16, radius, vp.data(), (int)vp.size());
+            if (rc != VSZIP_ERR_UNSUPPORTED) return rc;
+        }
+    }
     size_t done = 0;
     while (done < pl.size()) {
         RParams prm;
