@@ -29,7 +29,8 @@ def test_average_matches_oracle(dev, oracle, dtype):
             a[::3, ::5] = 100
         else:
             a[::3, ::5] = 1.0
-        for excl in ([-1], [100, 7], [1], list(range(90, 130)) + [7, 7, 0, 1]):  # the last: 40+ values, duplicates
+        # (list lengths 0 after dropping -1, 1, 2, 3 -> 4, 6 -> 8: the kernel's compile-time sizes; the last: 40+ values, duplicates)
+        for excl in ([-1], [100, 7], [1], [100, 7, 250], [100, 7, 3, 9, 250, 1], list(range(90, 130)) + [7, 7, 0, 1]):
             da, db = dev.upload(a), dev.upload(b)
             avg, diff = dev.plane_average([da], excl, [db])
             oavg, odiff = oracle.plane_average(a, excl, b)

@@ -141,7 +141,7 @@ __device__ __forceinline__ int find_plane(const PSParams &prm, int b) {  // (blo
 }
 
 // ---- PlaneAverage ---------------------------------------------------------------
-// NEX: compile-time size of the exclude list (0, 1 or 8 entries; a list shorter than NEX is
+// NEX: compile-time size of the exclude list (0, 1, 2, 4 or 8 entries; a list shorter than NEX is
 // padded with copies of its first entry by the host) — the common exclude=[-1] on an integer
 // clip can never match and compiles to no compare at all. NEX < 0: a longer list, walked at run
 // time from the kernel argument (scalar loads).
@@ -879,7 +879,7 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
     for (int i = 0; i < L.prm.nexcl; ++i)
         if (!Smp<T>::is_int || (L.prm.excl[i] >= 0 && L.prm.excl[i] <= (int32_t)L.prm.peak)) L.prm.excl[n++] = L.prm.excl[i];
     L.prm.nexcl = n;
-    const int nex = n == 0 ? 0 : (n == 1 ? 1 : (n <= 8 ? 8 : -1));
+    const int nex = n == 0 ? 0 : (n == 1 ? 1 : (n == 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : -1))));  // (2 and 4 since round 4: exclude=[16, 235] paid eight compares a sample)
     for (int i = n; i < nex; ++i) L.prm.excl[i] = L.prm.excl[0];
     const dim3 grid(L.total_blocks), block(kThreads);
 #define VSZIP_AVG_LAUNCH(NEX)                                                                        \
@@ -895,6 +895,10 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
             VSZIP_AVG_LAUNCH(0);
         else if (nex == 1)
             VSZIP_AVG_LAUNCH(1);
+        else if (nex == 2)
+            VSZIP_AVG_LAUNCH(2);
+        else if (nex == 4)
+            VSZIP_AVG_LAUNCH(4);
         else if (nex == 8)
             VSZIP_AVG_LAUNCH(8);
         else
