@@ -1119,6 +1119,11 @@ def compact_leg(leg: dict) -> dict:
     lim = leg.get("limit")
     if isinstance(lim, dict) and "bound" in lim and "frac" in lim:
         o["limit"] = {"bound": lim["bound"], "frac": lim["frac"]}
+    cpu = leg.get("cpu_baseline")  # the CPU side of the same workload, timed in this run (same unit as `value`)
+    if isinstance(cpu, dict) and isinstance(cpu.get("value"), (int, float)):
+        o["cpu"] = {"value": cpu["value"], "cores": cpu.get("cores")}
+        if isinstance(o.get("value"), (int, float)) and cpu["value"] > 0:
+            o["cpu"]["x"] = o["value"] / cpu["value"]
     return o
 
 
@@ -1150,7 +1155,7 @@ def compact_line(full: dict, detail_name: str | None = None) -> dict:
         line["detail"] = detail_name
     line = _sig(line)
     # hard bound: shed the least important parts until the line fits
-    for shed in ("limit", "unit", "others"):
+    for shed in ("limit", "unit", "cpu", "others"):
         if len(json.dumps(line)) <= LINE_MAX_BYTES:
             break
         if shed == "others":

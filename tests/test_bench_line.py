@@ -60,8 +60,15 @@ def test_line_fits_the_drivers_tail_and_parses(full, tmp_path):
     # every leg: value / unit / frac / limit only
     assert set(d["others"]) == set(full["others"])
     for name, leg in d["others"].items():
-        assert set(leg) <= {"value", "unit", "frac", "whole_call_frac", "limit", "error"}, name
+        assert set(leg) <= {"value", "unit", "frac", "whole_call_frac", "limit", "cpu", "error"}, name
         assert "value" in leg or "error" in leg, name
+    # the CPU side of every BASELINE config travels on the line: value, cores and the ratio
+    for name in ("bilateral_1080p", "bilateral_4k", "ssimulacra2_4k", "eedi3_1080p", "boxblur_1080p", "boxblur_1080p_5pass"):
+        if "cpu_baseline" in full["others"].get(name, {}):
+            cpu = d["others"][name]["cpu"]
+            assert set(cpu) == {"value", "cores", "x"} and cpu["cores"] >= 1, name
+            assert math.isclose(cpu["x"], d["others"][name]["value"] / cpu["value"], rel_tol=1e-4), name
+    assert {"bilateral_1080p", "bilateral_4k", "ssimulacra2_4k", "eedi3_1080p"} <= {n for n, leg in d["others"].items() if "cpu" in leg}
     assert d["others"]["bilateral_1080p"]["limit"]["bound"] in ("valu", "lds")
     assert d["detail"] == "bench_detail.json"
 
