@@ -316,108 +316,22 @@ class Arena:
 
 def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=None):
     """`host_planes` (a list of 2-D arrays, one per plane of the batch) in a source arena, a destination arena of the
-    same geometry, and the BoxBlur launch `args` on them — with the PLACEMENT of both arenas probed
-    (vszip_dev_alloc_probed, include/vszip_hip.h).
-
-    WHERE an arena lies in VRAM decides how fast the ring kernels run on it: the identical launch on identical layouts
-    takes 565-595 us on some allocations and 640-680 us on most (profiles/r02_notes.md, tools/slab_*.py, vmm_alias.py: it
-    follows the PHYSICAL memory behind the planes — every virtual alias of one physical arena gives the same time, page
-    table fragments do not matter; streaming kernels do not care, the ring kernels' hundreds of concurrent row streams
-    do; devices differ in how many of their placements are fast). Nothing user space can see or request controls it, so
-    the placement is probed before any timed region, in three walks of `tries` candidate allocations each (all
-    candidates of a walk are held until it ends, so each lies elsewhere): the destination arena against the first
-    source arena, then the source arena against that destination, then the destination once more against the chosen
-    source (the two effects are not independent). Returns (step, keep, info): info lists every candidate's time.
-    tries = 1 (the default since round 4: the headline is what a plain allocation gets) does no probing;
-    VSZIP_BENCH_PLACEMENT_TRIES=N overrides; the default run measures the probed placement as a side scalar only
-    (config.probed_frac)."""
-    if tries is None:
-        tries = 1  # round 4: every leg's `value` / `frac` is measured on plain vszip_dev_alloc arenas — what a caller gets
-    if os.environ.get("VSZIP_BENCH_PLACEMENT_TRIES"):
-        tries = max(1, int(os.environ["VSZIP_BENCH_PLACEMENT_TRIES"]))
+    same geometry, and the BoxBlur launch `args` on them. Both arenas are plain vszip_dev_alloc requests: what a caller gets.
+    (Rounds 2-4 searched for a fast placement here, then inside the allocator; since round 5 the allocator builds large
+    arenas from physical pieces that lie far apart, which is what the fast placements had in common - include/vszip_hip.h.)
+    Returns (step, keep, info)."""
     shapes = [p.shape for p in host_planes]
-    probe_args = probe_args or args
     isz = np.dtype(dtype).itemsize
-
-    def launch_us(src, dst, n=10, with_args=None):
-        global UNTIMED_CALLS
-        table = dev.plane_table(src.planes, dst.planes)
-        use = with_args or probe_args
-        if use == args:
-            UNTIMED_CALLS += n + 2  # (launches of the measured kernel outside Timed: config.timed_calls counts them for the profile summaries)
-        for _ in range(2):
-            dev.boxblur_table(dtype, table, *use)
-        dev.sync()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            dev.boxblur_table(dtype, table, *use)
-        dev.sync()
-        return (time.perf_counter() - t0) / n * 1e6
-
-    first = {}
-
-    def first_candidate(p):
-        """the first destination candidate = what a caller who simply allocates gets: timed with the real arguments as well"""
-        if "us" not in first:
-            first["us"] = launch_us(src, lay.view(p), n=20, with_args=args)
-        return launch_us(src, lay.view(p))
-
-    def copy_planes(a_arena, b_arena):
-        for a_, b_ in zip(a_arena.planes, b_arena.planes):
-            dev.check(dev.lib.vszip_copy_d2d_2d(dev.ctx, b_.ptr, b_.stride * isz, a_.ptr, a_.stride * isz, a_.w * isz, a_.h))
-        dev.sync()
-
     t_alloc = time.perf_counter()
     src = Arena(dev, shapes, dtype, seed + 1)
+    dst = Arena(dev, shapes, dtype, seed + 2)
     t_alloc = time.perf_counter() - t_alloc
     for a, d in zip(host_planes, src.planes):
         a = np.ascontiguousarray(a)
         dev.check(dev.lib.vszip_copy_h2d_2d(dev.ctx, d.ptr, d.stride * isz, a.ctypes.data, a.strides[0], a.shape[1] * isz, a.shape[0]))
     dev.sync()
-    lay = Arena(dev, shapes, dtype, seed + 2, ptr=0)  # the destination layout (bound to an allocation below)
-    if tries <= 1:
-        t0_ = time.perf_counter()
-        dst, dst_us, src_us, dst2_us = Arena(dev, shapes, dtype, seed + 2), [None], [None], []
-        t_alloc += time.perf_counter() - t0_
-        if not os.environ.get("VSZIP_BENCH_NO_FIRST_US"):  # (tools/prof_legs.py: a profile of the leg should hold the timed launches only)
-            first["us"] = launch_us(src, dst, n=20, with_args=args)
-    else:
-        # 1: the destination arena, every candidate against the first source arena
-        ptr, best, dst_us = dev.alloc_probed(lay.nbytes, tries, first_candidate)
-        dst = lay.bind(ptr)
-        # 2: the source arena (a device-to-device copy of the first one) against that destination
-        def as_source(p):
-            cand = src.view(p)
-            copy_planes(src, cand)
-            return launch_us(cand, dst)
-
-        ptr, best_s, src_us = dev.alloc_probed(src.nbytes, tries, as_source)
-        src_us = [best] + src_us
-        if best_s < best:
-            src.free()
-            src.bind(ptr)
-            best = best_s
-        else:
-            dev.lib.vszip_dev_free(dev.ctx, ptr)
-        # 3: the destination once more, against the chosen source
-        ptr, best_d, dst2_us = dev.alloc_probed(lay.nbytes, tries, lambda p: launch_us(src, lay.view(p)))
-        if best_d < best:
-            dst.free()
-            dst.bind(ptr)
-        else:
-            dev.lib.vszip_dev_free(dev.ctx, ptr)
     table = dev.plane_table(src.planes, dst.planes)
-    def summary(v):
-        v = sorted(x for x in v if x is not None)
-        return None if not v else {"n": len(v), "min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
-
-    info = {"tries": tries, "alloc_seconds": round(t_alloc, 3), "first_allocation_us": None if "us" not in first else round(first["us"], 1),
-            "destination_candidates_us": summary(dst_us), "source_candidates_us": summary(src_us),
-            "destination_candidates_second_pass_us": summary(dst2_us), "probe_args": list(probe_args),
-            "note": "vszip_dev_alloc_probed: launch time of the batch on candidate allocations (10 launches each, wall clock, min / median / max over the "
-                    "candidates): the destination arena, then the source arena against the best destination, then the destination again against the best "
-                    "source; the fastest pair is kept and the rest freed before the timed region, see placed_batch; first_allocation_us: the first "
-                    "destination candidate with the measured arguments (what a caller who simply allocates gets); tries = 1: first allocation only"}
+    info = {"tries": 1, "alloc_seconds": round(t_alloc, 3), "arena": dev.arena_info(dst.ptr)}
     return (lambda: dev.boxblur_table(dtype, table, *args)), (src, dst, info), info
 
 
@@ -718,7 +632,7 @@ def planestats_leg(dev, timed, frames=64, only=None):
                                   "kernel_match": {"plane_average_4k": "average_kernel", "plane_minmax_4k": "minmax_kernel", "plane_minmax_thr_4k": "hist_sweep_kernel"}[name],
                                   "whole_call": {"note": "all kernels of the call + the scalars' way to the host + the one sync", "achieved": whole, "frac": whole / HBM_PEAK_GBS}},
                      "whole_call_frac": whole / HBM_PEAK_GBS,
-                     "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call ({3 * frames} planes in groups of 48 queued back to back, one sync), HBM-resident; value includes the sync"}
+                     "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call ({3 * frames} planes in launches of up to 192, one sync), HBM-resident; value includes the sync"}
     return out
 
 
@@ -1323,7 +1237,7 @@ def main() -> int:
             "dtype": "u16", "data": "synthetic",
             "rccl_ranks": rccl_ranks,
             "config": {"workload": "vszip.BoxBlur hradius=vradius=13, 3840x2160 YUV420P16, splitmix64 noise, HBM-resident",
-                       "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}", "placement": keep[2]},
+                       "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": profile_traffic("boxblur_ct_ring_kernel<unsigned short, 13", F) if a.radius == RADIUS else None,
                          "kernel": "boxblur_ct_ring_kernel<u16,13>", "avg_launch_us": avg_s * 1e6, "launches": launches,
@@ -1331,29 +1245,17 @@ def main() -> int:
                          "whole_filter": {"note": "ring kernel + launch gaps, HIP events over the whole timed region",
                                           "avg_us": group_s * 1e6, "achieved": alg_bytes / group_s / 1e9, "frac": alg_bytes / group_s / 1e9 / HBM_PEAK_GBS}},
         }
-        # Both numbers of the placement story as SCALARS (the driver's record keeps scalar config fields only): the fraction on the
-        # probed placement (= roofline.frac, what `value` is measured on) and on the first allocation (what a caller who does not
-        # probe gets — libvszip.so's slabs are not probed: its BoxBlur is PCIe-bound long before this matters).
+        # How the two arenas were allocated, as SCALARS (the driver's record keeps scalar config fields only)
         pl_info = keep[2]
-        out["config"]["placement_tries"] = pl_info["tries"]
-        out["config"]["placement_policy"] = ("vszip_dev_alloc (the library places requests of 256 MiB and more: include/vszip_hip.h)" if pl_info["tries"] <= 1
-                                             else f"best of 3 x {pl_info['tries']} probed arenas")
-        try:  # what the allocator did for the two arenas of the headline batch
-            pi_s, pi_d = dev.placement_info(keep[0].ptr), dev.placement_info(keep[1].ptr)
-            out["config"]["placement_src_probe_TBps"] = pi_s["bytes_per_second"] / 1e12
-            out["config"]["placement_dst_probe_TBps"] = pi_d["bytes_per_second"] / 1e12
-            out["config"]["placement_walks"] = pi_d["walks"]
-            out["config"]["placement_candidates_probed"] = pi_d["probed"]
-            out["config"]["placement_last_walk_ms"] = pi_d["last_walk_ms"]
-            out["config"]["placement_exhausted"] = pi_d["exhausted"]
-            out["config"]["placement_seconds"] = keep[2].get("alloc_seconds")
-        except Exception as e:
-            out["config"]["placement_error"] = str(e)[:100]
-        if pl_info["tries"] > 1:
-            out["config"]["probed_frac"] = achieved / HBM_PEAK_GBS
-        if pl_info.get("first_allocation_us"):
-            out["config"]["first_allocation_frac"] = alg_bytes / (pl_info["first_allocation_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            out["config"]["first_allocation_launch_us"] = pl_info["first_allocation_us"]
+        ar = pl_info.get("arena", {})
+        out["config"]["placement_policy"] = ("vszip_dev_alloc: large requests are assembled from separate physical pieces, the fastest of a few candidates kept (include/vszip_hip.h)"
+                                             if ar.get("pieces") else "plain hipMalloc")
+        out["config"]["arena_pieces"] = ar.get("pieces")
+        out["config"]["arena_piece_MiB"] = (ar.get("piece_bytes") or 0) / (1 << 20)
+        out["config"]["arena_candidates"] = ar.get("candidates")
+        out["config"]["arena_probe_TBps"] = (ar.get("probe_bytes_per_second") or 0) / 1e12
+        out["config"]["arena_build_ms"] = ar.get("build_ms")
+        out["config"]["placement_seconds"] = pl_info.get("alloc_seconds")
         out["roofline"]["traffic_source"] = ("replayed from the committed PMC passes of this command (profiles/r*_boxblur_pmc.json), not measured in this run"
                                              if out["roofline"]["traffic"] is not None else None)
         if rank == 0:
@@ -1374,7 +1276,7 @@ def main() -> int:
             out["config"]["clip_mean_luma"] = {"error": str(e)}
         del keep
         # Side scalar only (never `value`): the same launch on arenas the allocator did NOT place (VSZIP_PLACEMENT=0: plain hipMalloc)
-        if rank == 0 and world == 1 and not a.no_others and pl_info["tries"] <= 1 and a.radius == RADIUS:
+        if rank == 0 and world == 1 and not a.no_others and a.radius == RADIUS:
             try:
                 with dev.options(VSZIP_PLACEMENT=0):
                     step_p, keep_p = setup_boxblur(dev, rank, F, a.radius)

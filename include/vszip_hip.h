@@ -26,8 +26,9 @@
 extern "C" {
 #endif
 
-#define VSZIP_ABI_VERSION 3 /* 3 (round 4): vszip_ctx_set_option / _get_option, vszip_dev_trim, vszip_dev_placement_info, vszip_dev_probe_region,
-                               vszip_plane_average_async, vszip_plane_minmax_async added; vszip_dev_alloc places large requests (below); 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1: vszip_dev_alloc_probed,
+#define VSZIP_ABI_VERSION 4 /* 4 (round 5): vszip_dev_alloc stripes large requests (below); vszip_dev_arena_info added; vszip_dev_trim, vszip_dev_placement_info and
+                               vszip_dev_alloc_probed removed (nothing is searched for or parked any more); 3 (round 4): vszip_ctx_set_option / _get_option, vszip_dev_probe_region,
+                               vszip_plane_average_async, vszip_plane_minmax_async added; 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1:
                                vszip_chain_run, vszip_ssimulacra2_src, vszip_to_rgbs_linear, vszip_probe_read_each, vszip_resample_table */
 
 typedef struct vszip_ctx vszip_ctx;
@@ -70,40 +71,27 @@ const char *vszip_last_error(vszip_ctx *ctx);
 int vszip_abi_version(void);
 
 /* ---- device memory + staging (replaces nothing: the reference is host-only) */
-/* vszip_dev_alloc. Requests of VSZIP_PLACEMENT_MIN_MIB (256) or more are PLACED: kernels with hundreds of concurrent row
- * streams (the BoxBlur ring kernels) run 15-20 % faster or slower depending on which physical memory holds a resident batch, and
- * nothing user space can see or request predicts it (profiles/r03_placement.md). The allocator walks candidate
- * allocations of the requested size (all held meanwhile, so each lies elsewhere), classifies each with a 2 ms copy in the ring
- * kernel's access shape, returns the fastest, keeps up to VSZIP_PLACEMENT_PARK_GIB (24) of further fast regions PARKED for the
- * requests that follow and frees the rest. The walk stops at the first region of the best class (probe >= 5.55 TB/s; one of the middle class, >= 5.2 TB/s, is kept while
- * eight more candidates are looked at), holds at most VSZIP_PLACEMENT_WALK_GIB (64)
- * meanwhile, gives up after VSZIP_PLACEMENT_WALK_MS (3000: memory the device has not handed out before is cleared on first use,
- * about 50-90 ms per GiB) and ends early when the device is full; a walk that meets no region worth keeping is the context's
- * last (one that the clock cut short may be continued by the next request, up to 32 slow candidates in all). vszip_dev_free parks a placed region again;
- * parked memory returns to the driver when any allocation of the library would otherwise fail, in vszip_dev_trim and in
- * vszip_ctx_destroy. VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc / hipFree. */
+/* vszip_dev_alloc. Requests of VSZIP_PLACEMENT_MIN_MIB (256) or more are PLACED: kernels with thousands of concurrent row
+ * streams (the BoxBlur ring kernels) run 15-20 % slower with their destination planes in most physical memory than in some,
+ * a stable property of the allocation (profiles/r05_placement.md). An arena assembled from separate physical
+ * pieces is in the fast class far more often than one contiguous block, so such a request is built with the virtual-memory
+ * API - pieces of VSZIP_PLACEMENT_PIECE_MIB (128) from hipMemCreate, mapped side by side into one range - and classified with a
+ * 2 ms copy in the ring kernels' access shape; up to VSZIP_PLACEMENT_TRIES (6) candidates are looked at (all held meanwhile,
+ * never more than half of what hipMemGetInfo reports free), the search ends with the first one of the best class, else the
+ * fastest is kept, and every other candidate is released before the call returns. Nothing is cached or parked and there is no
+ * per-context state. The result is ordinary device memory for kernels and for this library's copies; the RUNTIME's own
+ * hipMemcpy2D* accept extents up to one piece only (vszip_copy_*_2d split by rows). vszip_dev_free unmaps and releases at once
+ * (after a device synchronise, like hipFree). VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc / hipFree. A runtime
+ * without virtual memory management falls back to hipMalloc. */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
-/* give every parked region back to the driver; *freed_bytes (may be NULL) = how much that was */
-int vszip_dev_trim(vszip_ctx *ctx, size_t *freed_bytes);
-/* What the allocator knows (any pointer may be NULL): the probe rate of the placed allocation `dptr` (bytes / s moved by the
- * classification copy; 0 = not a placed allocation), the parked regions and their bytes, walks done and candidates probed so far,
- * how long the last walk took, and whether a walk has used its whole budget without meeting a fast region (then this context
- * searches no more: later requests take a parked region or a plain allocation). */
-int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed, double *last_walk_ms,
-                             int *exhausted);
-/* the classification copy on a caller's region (overwrites its contents): bytes / s. `from` == NULL: tiles are read and written
- * inside the region; else they are read from `from` (another region of at least `bytes`, not modified) — a source / destination pair. */
+/* What `dptr` (as returned by vszip_dev_alloc) is made of; any pointer may be NULL. *pieces = 0: a plain allocation. *candidates: how
+ * many arenas the search built, *probe_bytes_per_second: the classification copy's rate on the one kept (0: one candidate, not probed). */
+int vszip_dev_arena_info(vszip_ctx *ctx, const void *dptr, size_t *pieces, size_t *piece_bytes, int *candidates, double *probe_bytes_per_second, double *build_ms);
+/* Diagnostic: a copy in the ring kernels' access shape on a caller's region (overwrites its contents): bytes / s. `from` == NULL: tiles
+ * are read and written inside the region; else they are read from `from` (another region of at least `bytes`, not modified). */
 int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, const void *from, double *bytes_per_second);
+/* any context of the process may free any allocation of that device; NULL is accepted */
 int vszip_dev_free(vszip_ctx *ctx, void *dptr);
-/* Device memory whose PLACEMENT in VRAM is chosen by measurement. The BoxBlur ring kernels (hundreds of concurrent row
- * streams) run 15-20 % faster or slower depending on which physical memory holds a resident batch — nothing user space
- * can see or request predicts it (profiles/r02_notes.md). Up to `tries` allocations of `bytes` are made
- * one after another and all held meanwhile (so each lies elsewhere); `probe(user, ptr)` is called once for each and
- * returns a cost (e.g. the seconds the caller's launch took with its planes in `ptr`); the allocation with the lowest
- * cost is returned in *dptr (free it with vszip_dev_free), its cost in *best_cost (may be NULL), the others are freed.
- * Stops early, with what it has, when the device runs out of memory. tries <= 1 or probe == NULL: plain vszip_dev_alloc. */
-typedef double (*vszip_placement_probe)(void *user, void *dptr);
-int vszip_dev_alloc_probed(vszip_ctx *ctx, size_t bytes, int tries, vszip_placement_probe probe, void *user, void **dptr, double *best_cost);
 int vszip_dev_memset(vszip_ctx *ctx, void *dptr, int value, size_t bytes);
 int vszip_host_alloc_pinned(vszip_ctx *ctx, size_t bytes, void **hptr);
 int vszip_host_free_pinned(vszip_ctx *ctx, void *hptr);

@@ -99,13 +99,6 @@ EXP int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     *dptr = malloc(bytes ? bytes : 1);
     return *dptr ? VSZIP_OK : VSZIP_ERR_NOMEM;
 }
-EXP int vszip_dev_alloc_probed(vszip_ctx *ctx, size_t bytes, int tries, vszip_placement_probe probe, void *user, void **dptr, double *best_cost) {
-    if (!ctx || !dptr) return VSZIP_ERR_ARG;
-    if (best_cost) *best_cost = 0.0;
-    const int rc = vszip_dev_alloc(ctx, bytes, dptr);
-    if (rc == VSZIP_OK && tries > 1 && probe && best_cost) *best_cost = probe(user, *dptr);
-    return rc;
-}
 EXP int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
     if (!ctx) return VSZIP_ERR_ARG;
     free(dptr);

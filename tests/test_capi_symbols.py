@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libvszip_hip.so does not export {name}"
     assert declared == set(vszip_amd.capi.SYMBOLS), (declared ^ set(vszip_amd.capi.SYMBOLS))
-    assert lib.vszip_abi_version() == 3
+    assert lib.vszip_abi_version() == 4
 
 
 def test_no_gpu_fails_loudly():

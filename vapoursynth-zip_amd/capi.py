@@ -79,13 +79,11 @@ SYMBOLS = {
     "vszip_ctx_abort": (_i, [_vp]),
     "vszip_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "vszip_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
-    "vszip_dev_trim": (_i, [_vp, C.POINTER(_sz)]),
-    "vszip_dev_placement_info": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(_i)]),
+    "vszip_dev_arena_info": (_i, [_vp, _vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_dev_probe_region": (_i, [_vp, _vp, _sz, _vp, C.POINTER(C.c_double)]),
     "vszip_last_error": (C.c_char_p, [_vp]),
     "vszip_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_dev_free": (_i, [_vp, _vp]),
-    "vszip_dev_alloc_probed": (_i, [_vp, _sz, _i, C.c_void_p, _vp, C.POINTER(_vp), C.POINTER(C.c_double)]),
     "vszip_dev_memset": (_i, [_vp, _vp, _i, _sz]),
     "vszip_host_alloc_pinned": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vszip_host_free_pinned": (_i, [_vp, _vp]),
@@ -273,18 +271,11 @@ class Device:
 
         return scope()
 
-    def trim(self) -> int:
-        """vszip_dev_trim: parked placement regions back to the driver; -> bytes freed"""
-        n = C.c_size_t()
-        self.check(self.lib.vszip_dev_trim(self.ctx, C.byref(n)))
-        return n.value
-
-    def placement_info(self, ptr: int = 0) -> dict:
-        """vszip_dev_placement_info: probe rate of a placed allocation (0: not placed), parked regions / bytes, walks, probed"""
-        bps, nreg, nby, walks, probed, ms, exh = C.c_double(), C.c_int(), C.c_size_t(), C.c_int(), C.c_int(), C.c_double(), C.c_int()
-        self.check(self.lib.vszip_dev_placement_info(self.ctx, C.c_void_p(ptr), C.byref(bps), C.byref(nreg), C.byref(nby), C.byref(walks), C.byref(probed), C.byref(ms), C.byref(exh)))
-        return {"bytes_per_second": bps.value, "parked_regions": nreg.value, "parked_bytes": nby.value, "walks": walks.value, "probed": probed.value,
-                "last_walk_ms": ms.value, "exhausted": bool(exh.value)}
+    def arena_info(self, ptr: int) -> dict:
+        """vszip_dev_arena_info: what a vszip_dev_alloc pointer is made of (pieces = 0: a plain allocation)"""
+        n, pb, nc, rate, ms = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_double(), C.c_double()
+        self.check(self.lib.vszip_dev_arena_info(self.ctx, C.c_void_p(ptr), C.byref(n), C.byref(pb), C.byref(nc), C.byref(rate), C.byref(ms)))
+        return {"pieces": n.value, "piece_bytes": pb.value, "candidates": nc.value, "probe_bytes_per_second": rate.value, "build_ms": ms.value}
 
     def probe_region(self, ptr: int, nbytes: int, src: int = 0) -> float:
         bps = C.c_double()
@@ -306,21 +297,6 @@ class Device:
         p = C.c_void_p()
         self.check(self.lib.vszip_dev_alloc(self.ctx, stride * h * dtype.itemsize + 256, C.byref(p)))
         return DevPlane(self, p.value, w, h, stride, dtype)
-
-    def alloc_probed(self, nbytes: int, tries: int, probe) -> tuple:
-        """vszip_dev_alloc_probed: `probe(ptr) -> cost` is called for each of up to `tries` candidate allocations;
-        -> (pointer of the cheapest, its cost, the costs of all candidates in allocation order)."""
-        costs = []
-
-        def cb(_user, ptr):
-            c = float(probe(ptr))
-            costs.append(c)
-            return c
-
-        fn = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p)(cb)
-        p, best = C.c_void_p(), C.c_double()
-        self.check(self.lib.vszip_dev_alloc_probed(self.ctx, nbytes, tries, C.cast(fn, C.c_void_p), None, C.byref(p), C.byref(best)))
-        return p.value, best.value, costs
 
     def upload(self, a: np.ndarray, align_elems: int = 32) -> DevPlane:
         assert a.ndim == 2 and a.strides[1] == a.itemsize

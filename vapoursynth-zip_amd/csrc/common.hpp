@@ -76,22 +76,12 @@ struct vszip_ctx {
     size_t chain_bytes = 0;
     void *ssim_lut = nullptr;  // SSIMULACRA2 colour pre-stage: cached conversion table (ssimulacra2.hip)
     int &scan_mode = opt.scan_mode;  // BoxBlur CT: 0 = ring kernel (DPP scan), 1 = generic kernel + shuffle scan, 2 = generic kernel + DPP scan
-    // placed allocations (ctx.hip): classified regions that are not in use, and the probe cost of the ones that are
-    struct Region {
-        void *ptr;
-        size_t bytes;
-        double cost;  // probe seconds per byte moved; smaller is faster
-    };
-    std::vector<Region> parked, placed;
-    hipEvent_t probe_ev0 = nullptr, probe_ev1 = nullptr;  // the classification copy's own timing events
-    int placement_walks = 0, placement_probed = 0, placement_slow_seen = 0;
-    double placement_last_walk_ms = 0.0;
-    bool placement_exhausted = false;  // a walk used its budget without finding a fast region: no further walks in this context
+    hipEvent_t probe_ev0 = nullptr, probe_ev1 = nullptr;  // vszip_dev_probe_region's own timing events
 };
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...);
 int vszip_ensure_scratch(vszip_ctx *ctx, size_t bytes);
-hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes);  // hipMalloc; parked placement regions are released before it fails (ctx.hip)
+hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes);  // the library's internal allocations (plain hipMalloc)
 int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
 void vszip_ssim_release(vszip_ctx *ctx);  // frees ctx->ssim_lut
 void vszip_chain_release(vszip_ctx *ctx);  // frees ctx->chain_buf

@@ -3,16 +3,15 @@
 
 #include "common.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <set>
-
-namespace {
-size_t trim_parked(vszip_ctx *ctx);
-}
 
 int vszip_set_error(vszip_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
@@ -179,7 +178,6 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    trim_parked(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
     vszip_ssim_release(ctx);
@@ -253,26 +251,214 @@ VSZIP_EXPORT int vszip_ctx_set_staging(vszip_ctx *ctx, int mode) {
 
 VSZIP_EXPORT const char *vszip_last_error(vszip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-// ---- placed allocations -------------------------------------------------------------------------------------
-// WHERE a resident batch lies in VRAM decides how fast kernels with many concurrent row streams run on it: the BoxBlur
-// ring kernel's 64-frame 4K launch takes 545-565 us with its planes in some physical regions and 640-680 us in others
-// (a property of the physical memory, in runs of ~10 GiB; no layout user space can choose changes it, streaming
-// kernels do not see it: profiles/r03_placement.md). Round 3 searched for a fast region in bench.py; since round 4 the
-// allocator does it for every caller: a request of VSZIP_PLACEMENT_MIN_MIB or more is served from a walk over candidate
-// allocations of that size (all held meanwhile, so each lies elsewhere), each classified by placement_probe_kernel — the
-// ring kernel's access shape without its arithmetic — in about 2 ms. The fastest is returned, the next best stay PARKED
-// (allocated, classified, not in use) up to VSZIP_PLACEMENT_PARK_GIB for the requests that follow (a batch is a source
-// and a destination arena), the rest are freed. vszip_dev_free parks a placed region again instead of freeing it.
-// Parked memory goes back to the driver when an allocation fails, in vszip_dev_trim and in vszip_ctx_destroy.
-// Bounded: the walk holds at most VSZIP_PLACEMENT_WALK_GIB and stops as soon as enough regions of the fast class have
-// turned up; VSZIP_PLACEMENT=0 turns all of it off (plain hipMalloc).
+// ---- striped, probed arenas ----------------------------------------------------------------------------------
+// WHERE a resident batch lies in VRAM decides how fast kernels with thousands of concurrent row streams run on it: the
+// BoxBlur ring kernel's 64-frame 4K launch takes 545-570 us with its DESTINATION planes in some memory and 600-680 us in
+// most, in three classes - a property of the physical memory behind the destination, stable for the life of the
+// allocation, the same for every source arena (profiles/r03_placement.md, profiles/r05_placement.md). Round 5's finding:
+// an arena assembled from separate physical pieces (hipMemCreate, mapped side by side with hipMemMap) is in the fast
+// class far more often than one contiguous block (first arena of a process: 13 of 16 against 4 of 16), costs a
+// millisecond to build, and can be given back piece by piece - but no way of choosing the pieces makes it certain. So a
+// request of VSZIP_PLACEMENT_MIN_MIB or more is served like this: up to VSZIP_PLACEMENT_TRIES candidate arenas are
+// built from pieces of VSZIP_PLACEMENT_PIECE_MIB, each classified by placement_probe_kernel (the ring kernel's access
+// shape without its arithmetic, 2 ms); the search ends with the first candidate of the best class, else the fastest
+// is kept. Everything else goes back to the driver before the call returns: nothing is parked, there is no per-context
+// state, and the candidates held at once never exceed half of what hipMemGetInfo reports free.
+// vszip_dev_free unmaps and releases. The registry is process-wide: any context may free any arena.
 namespace {
+
+struct StripedArena {
+    size_t bytes = 0, piece = 0;
+    double build_ms = 0.0, probe_bytes_per_s = 0.0;
+    int device = 0, candidates = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::mutex &striped_mu() {
+    static std::mutex *m = new std::mutex();
+    return *m;
+}
+std::map<char *, StripedArena> &striped_map() {  // keyed by the arena's first byte
+    static auto *m = new std::map<char *, StripedArena>();
+    return *m;
+}
+std::atomic<int> g_striped_count{0};
+
+// Reserved virtual ranges are never given back to the runtime: hipMemAddressFree corrupts the heap of this ROCm's libamdhip64 after a few
+// reserve / map / unmap / free cycles ("corrupted double-linked list" inside a later hipMemCreate; tools/alloc_crash_repro.py with each of the
+// three release calls left out in turn). A range that is no longer mapped costs address space only, and the next arena of its size takes it over.
+std::vector<std::pair<void *, size_t>> &va_idle() {
+    static auto *v = new std::vector<std::pair<void *, size_t>>();
+    return *v;
+}
+void *va_take(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(striped_mu());
+        auto &v = va_idle();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].second == bytes) {
+                void *p = v[i].first;
+                v.erase(v.begin() + i);
+                return p;
+            }
+    }
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, bytes, (size_t)2 << 20, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return va;
+}
+void va_give(void *va, size_t bytes) {
+    std::lock_guard<std::mutex> lk(striped_mu());
+    va_idle().emplace_back(va, bytes);
+}
+
+void striped_release(void *va, StripedArena &a, size_t mapped_pieces) {
+    for (size_t i = 0; i < mapped_pieces; ++i) (void)hipMemUnmap(static_cast<char *>(va) + i * a.piece, a.piece);  // (one mapping per call)
+    for (auto h : a.handles) (void)hipMemRelease(h);
+    a.handles.clear();
+    if (va) va_give(va, a.bytes);
+}
+
+double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from);
+
+// one candidate: n pieces created back to back and mapped in order. VSZIP_ERR_UNSUPPORTED: no virtual memory management here.
+int striped_build(vszip_ctx *ctx, size_t n, size_t piece, StripedArena *out, void **out_va) {
+    StripedArena a;
+    a.device = ctx->device;
+    a.piece = piece;
+    a.bytes = n * piece;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    void *va = va_take(a.bytes);
+    if (!va) return VSZIP_ERR_UNSUPPORTED;
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        const hipError_t e = hipMemCreate(&h, piece, &prop, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            striped_release(va, a, i);
+            return i == 0 && e != hipErrorOutOfMemory ? VSZIP_ERR_UNSUPPORTED : VSZIP_ERR_NOMEM;
+        }
+        a.handles.push_back(h);
+        if (hipMemMap(static_cast<char *>(va) + i * piece, piece, 0, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            striped_release(va, a, i);
+            return VSZIP_ERR_HIP;
+        }
+    }
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = ctx->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(va, a.bytes, &acc, 1) != hipSuccess) {
+        (void)hipGetLastError();
+        striped_release(va, a, n);
+        return VSZIP_ERR_HIP;
+    }
+    *out = std::move(a);
+    *out_va = va;
+    return VSZIP_OK;
+}
+
+// placement_probe_kernel's rate on the devices seen: 5.55-5.9 TB/s <-> the real launch at 560-585 us with its destination there (0.68-0.71),
+// 5.2-5.35 TB/s <-> 594-608 us, 4.6-5.1 TB/s <-> 630-695 us (profiles/r04_placement_probe_calibration.txt). Used ONLY to end the search early:
+// on a device that never reaches it (capped, busy, partitioned) the search looks at all its candidates and keeps the fastest.
+constexpr double kBestBytesPerSec = 5.55e12;
+
+int striped_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
+    const auto t_start = std::chrono::steady_clock::now();
+    constexpr size_t kMiB = (size_t)1 << 20;
+    // piece size: whole 2 MiB, at least 16 MiB (the runtime's 2-D copies accept extents up to the size of ONE mapped piece; copy2d splits by rows beyond that)
+    const size_t piece = (size_t)std::max(16, ctx->opt.placement_piece_mib) / 2 * 2 * kMiB;
+    const size_t n = (bytes + piece - 1) / piece, total = n * piece;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        free_b = total;
+    }
+    if (free_b < total) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "vszip_dev_alloc(%zu): %zu bytes of device memory free", bytes, free_b);
+    const int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 2 / total));
+    if (tries > 1) VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::pair<StripedArena, void *>> cand;
+    int best = -1;
+    for (int k = 0; k < tries; ++k) {
+        StripedArena a;
+        void *va = nullptr;
+        const int rc = striped_build(ctx, n, piece, &a, &va);
+        if (rc != VSZIP_OK) {
+            if (!cand.empty()) break;  // the device is fuller than it said: choose among what exists
+            if (rc == VSZIP_ERR_NOMEM) return vszip_set_error(ctx, rc, "vszip_dev_alloc(%zu): out of device memory", bytes);
+            if (rc == VSZIP_ERR_HIP) return vszip_set_error(ctx, rc, "vszip_dev_alloc(%zu): mapping a striped arena failed", bytes);
+            return rc;
+        }
+        if (tries > 1) {
+            double c = probe_region(ctx, va, a.bytes, nullptr);
+            // the first candidate also brings the clocks up: an idle device runs its first milliseconds slower, and candidates must be compared
+            // at one clock - repeat until two measurements in a row agree within 0.5 % (at most ~60 ms)
+            for (int i = 0; k == 0 && i < 20 && c > 0; ++i) {
+                const double c2 = probe_region(ctx, va, a.bytes, nullptr);
+                const bool steady = c2 > 0 && std::fabs(c2 - c) <= 0.005 * c;
+                c = c2;
+                if (steady) break;
+            }
+            a.probe_bytes_per_s = c > 0 ? 1.0 / c : 0.0;
+        }
+        cand.emplace_back(std::move(a), va);
+        if (best < 0 || cand.back().first.probe_bytes_per_s > cand[best].first.probe_bytes_per_s) best = (int)cand.size() - 1;
+        if (cand.back().first.probe_bytes_per_s >= kBestBytesPerSec) break;
+    }
+    for (int k = 0; k < (int)cand.size(); ++k)
+        if (k != best) striped_release(cand[k].second, cand[k].first, n);
+    StripedArena &a = cand[best].first;
+    a.candidates = (int)cand.size();
+    a.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    void *va = cand[best].second;
+    {
+        std::lock_guard<std::mutex> lk(striped_mu());
+        striped_map()[static_cast<char *>(va)] = std::move(a);
+        g_striped_count.fetch_add(1);
+    }
+    *dptr = va;
+    return VSZIP_OK;
+}
+
+// true: dptr was a striped arena and is gone
+bool striped_free(void *dptr) {
+    if (g_striped_count.load() == 0) return false;
+    StripedArena a;
+    {
+        std::lock_guard<std::mutex> lk(striped_mu());
+        auto it = striped_map().find(static_cast<char *>(dptr));
+        if (it == striped_map().end()) return false;
+        a = std::move(it->second);
+        striped_map().erase(it);
+        g_striped_count.fetch_sub(1);
+    }
+    (void)hipSetDevice(a.device);
+    (void)hipDeviceSynchronize();  // like hipFree: no stream of any context may still be using it
+    striped_release(dptr, a, a.bytes / a.piece);
+    return true;
+}
+
+// the piece size of the striped arena that holds p (0: p is not inside one)
+size_t striped_piece_of(const void *p) {
+    if (g_striped_count.load() == 0) return 0;
+    std::lock_guard<std::mutex> lk(striped_mu());
+    auto &m = striped_map();
+    auto it = m.upper_bound(const_cast<char *>(static_cast<const char *>(p)));
+    if (it == m.begin()) return 0;
+    --it;
+    return static_cast<const char *>(p) < it->first + it->second.bytes ? it->second.piece : 0;
+}
 
 typedef unsigned int pv4u __attribute__((ext_vector_type(4)));
 
 // One wave per (band, tile): moves a 960-byte column tile down `band_rows` rows of a 7680-byte-pitch view of the region,
-// reading its own band and writing the band half a region away (every tile is read once and written once per launch).
-// `from` != nullptr: the tiles are read from that region instead (a source arena allocated earlier) — the pair a batch will be.
+// reading its own band and writing the band half a region away (every tile is read once and written once per launch) - the ring kernel's
+// access shape without its arithmetic. `from` != nullptr: the tiles are read from that region instead - the pair a batch will be.
 __global__ __launch_bounds__(64) void placement_probe_kernel(char *base, const char *from, int bands, int band_rows) {
     constexpr long long kPitch = 7680;
     const int b = blockIdx.x >> 3, t = blockIdx.x & 7, lane = threadIdx.x;
@@ -288,20 +474,12 @@ __global__ __launch_bounds__(64) void placement_probe_kernel(char *base, const c
     }
 }
 
-constexpr size_t kProbeSpan = (size_t)2 << 30;  // at most this much of a region is probed (its first 2 GiB)
-// placement_probe_kernel's rate sorts regions into three classes on the devices seen (profiles/r04_placement_probe_calibration.txt, gpurun_out/r4_pool_probe*.txt):
-// 5.55-5.9 TB/s <-> the real launch at 568-585 us with its destination there (0.68-0.70), 5.2-5.35 TB/s <-> 594-608 us (0.65-0.67), 4.6-5.1 TB/s <-> 630-695 us.
-constexpr double kFastBytesPerSec = 5.2e12;      // good enough to keep
-constexpr double kBestBytesPerSec = 5.55e12;     // ends a walk at once
-constexpr size_t kPlacedGranule = (size_t)64 << 20;  // placed requests are rounded up to this: arenas of nearly equal size share parked regions
-
-// seconds per byte moved by the probe on [ptr, ptr + bytes); < 0: could not measure
-double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from = nullptr, size_t from_bytes = 0) {
-    if (from && from_bytes < bytes) bytes = from_bytes;
-    const size_t span = std::min(bytes, kProbeSpan);
+// seconds per byte moved by the probe on the first 2 GiB of [ptr, ptr + bytes); < 0: could not measure
+double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from) {
+    const size_t span = std::min(bytes, (size_t)2 << 30);
     const long long rows = (long long)(span / 7680);
     // ~3072 streams like the ring kernel's launch: 384 bands x 8 tiles, bands of 64 ... 540 rows
-    int band_rows = (int)std::min<long long>(540, std::max<long long>(64, rows / 384));
+    const int band_rows = (int)std::min<long long>(540, std::max<long long>(64, rows / 384));
     const int bands = (int)(rows / band_rows);
     if (bands < 2) return -1.0;
     const dim3 grid(bands * 8);
@@ -323,225 +501,66 @@ double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from = 
     return ms * 1e-3 / moved;
 }
 
-void park_region(vszip_ctx *ctx, const vszip_ctx::Region &r) {
-    ctx->parked.push_back(r);
-    // over the cap: the slowest go back to the driver
-    const size_t cap = (size_t)std::max(0, ctx->opt.placement_park_gib) << 30;
-    size_t total = 0;
-    for (const auto &q : ctx->parked) total += q.bytes;
-    while (total > cap && !ctx->parked.empty()) {
-        size_t worst = 0;
-        for (size_t i = 1; i < ctx->parked.size(); ++i)
-            if (ctx->parked[i].cost > ctx->parked[worst].cost) worst = i;
-        total -= ctx->parked[worst].bytes;
-        (void)hipFree(ctx->parked[worst].ptr);
-        ctx->parked.erase(ctx->parked.begin() + worst);
-    }
-}
-
-size_t trim_parked(vszip_ctx *ctx) {
-    size_t freed = 0;
-    for (const auto &q : ctx->parked) {
-        (void)hipFree(q.ptr);
-        freed += q.bytes;
-    }
-    ctx->parked.clear();
-    return freed;
-}
-
 }  // namespace
 
-// hipMalloc that gives parked memory back to the driver before it reports failure (every allocation of the library)
-hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && !ctx->parked.empty()) {
-        (void)hipGetLastError();
-        trim_parked(ctx);
-        e = hipMalloc(p, bytes);
-    }
-    return e;
-}
-
-namespace {
-
-int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
-    bytes = (bytes + kPlacedGranule - 1) / kPlacedGranule * kPlacedGranule;
-    // 1: a parked region of a fitting size (the fastest one)
-    int pick = -1;
-    for (size_t i = 0; i < ctx->parked.size(); ++i) {
-        const auto &r = ctx->parked[i];
-        if (r.bytes >= bytes && r.bytes / 2 <= bytes && (pick < 0 || r.cost < ctx->parked[pick].cost)) pick = (int)i;
-    }
-    const double fast_cost = 1.0 / kFastBytesPerSec, best_cost = 1.0 / kBestBytesPerSec;
-    if (pick >= 0 && (ctx->parked[pick].cost <= best_cost || (ctx->placement_exhausted && ctx->parked[pick].cost <= fast_cost))) {
-        ctx->placed.push_back(ctx->parked[pick]);
-        *dptr = ctx->parked[pick].ptr;
-        ctx->parked.erase(ctx->parked.begin() + pick);
-        return VSZIP_OK;
-    }
-    if (ctx->placement_exhausted) {  // an earlier walk used its whole budget without meeting a fast region: this device's next tens of GiB are slow, no more searching
-        if (pick >= 0) {
-            ctx->placed.push_back(ctx->parked[pick]);
-            *dptr = ctx->parked[pick].ptr;
-            ctx->parked.erase(ctx->parked.begin() + pick);
-            return VSZIP_OK;
-        }
-        if (vszip_hip_malloc(ctx, dptr, bytes) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-        return VSZIP_OK;
-    }
-    // 2: walk. Everything stays allocated until the walk ends; it ends with the first region of the best class (or eight candidates after the first
-    // of the middle class), when the walk's budget (bytes held, wall time: memory the device has not handed out before is cleared on first use,
-    // 50-170 ms per candidate of this size) is used, or when the device is full. Slow regions freed here come back first in the next walk and cost
-    // 2.5 ms each then.
-    VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t budget = (size_t)std::max(1, ctx->opt.placement_walk_gib) << 30;
-    const int max_cand = (int)std::min<size_t>(64, std::max<size_t>(1, budget / bytes));
-    const auto t_start = std::chrono::steady_clock::now();
-    std::vector<vszip_ctx::Region> cand;
-    int since_good = -1;  // candidates probed since the first one of the middle class
-    if (pick >= 0) {  // a parked region of the middle or the slow class competes with what the walk finds
-        cand.push_back(ctx->parked[pick]);
-        if (ctx->parked[pick].cost <= fast_cost) since_good = 0;
-        ctx->parked.erase(ctx->parked.begin() + pick);
-    }
-    bool cut_short = false;
-    for (int k = 0; k < max_cand; ++k) {
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-        double c = probe_region(ctx, p, bytes);
-        if (c < 0) c = 1.0;  // unmeasurable: last choice
-        cand.push_back({p, bytes, c});
-        if (c <= best_cost) break;                           // the best class: done
-        if (c <= fast_cost && since_good < 0) since_good = 0;  // the middle class: good enough, but look at eight more for the best
-        if (since_good >= 0 && ++since_good > 8) break;
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-        if (ms > (double)std::max(1, ctx->opt.placement_walk_ms)) {
-            cut_short = true;
-            break;
-        }
-    }
-    if (cand.empty()) {
-        void *p = nullptr;
-        if (vszip_hip_malloc(ctx, &p, bytes) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-        *dptr = p;
-        return VSZIP_OK;
-    }
-    std::sort(cand.begin(), cand.end(), [](const vszip_ctx::Region &a, const vszip_ctx::Region &b) { return a.cost < b.cost; });
-    *dptr = cand[0].ptr;
-    ctx->placed.push_back(cand[0]);
-    ctx->placement_walks += 1;
-    ctx->placement_probed += (int)cand.size();
-    ctx->placement_last_walk_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    // No region worth keeping: this context stops searching - unless the clock cut the walk short after a few candidates (memory that has to be
-    // cleared costs up to 170 ms a candidate), then the next large request may look further, up to 32 slow candidates in all.
-    if (cand[0].cost > fast_cost) {
-        ctx->placement_slow_seen += (int)cand.size();
-        if (!cut_short || ctx->placement_slow_seen >= 32) ctx->placement_exhausted = true;
-    }
-    // the slow ones are freed FIRST (in one go, after the walk), then the fast ones are parked
-    for (size_t i = 1; i < cand.size(); ++i)
-        if (cand[i].cost > fast_cost) (void)hipFree(cand[i].ptr);
-    for (size_t i = 1; i < cand.size(); ++i)
-        if (cand[i].cost <= fast_cost) park_region(ctx, cand[i]);
-    return VSZIP_OK;
-}
-
-}  // namespace
+hipError_t vszip_hip_malloc(vszip_ctx *, void **p, size_t bytes) { return hipMalloc(p, bytes); }
 
 VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (ctx->opt.placement && bytes >= ((size_t)std::max(1, ctx->opt.placement_min_mib) << 20)) return placed_alloc(ctx, bytes, dptr);
-    if (vszip_hip_malloc(ctx, dptr, bytes ? bytes : 1) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    if (ctx->opt.placement && bytes >= ((size_t)std::max(16, ctx->opt.placement_min_mib) << 20)) {
+        const int rc = striped_alloc(ctx, bytes, dptr);
+        if (rc != VSZIP_ERR_UNSUPPORTED) return rc;
+    }
+    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    }
     return VSZIP_OK;
 }
 
-VSZIP_EXPORT int vszip_dev_trim(vszip_ctx *ctx, size_t *freed_bytes) {
+VSZIP_EXPORT int vszip_dev_arena_info(vszip_ctx *ctx, const void *dptr, size_t *pieces, size_t *piece_bytes, int *candidates, double *probe_bytes_per_second, double *build_ms) {
     if (!ctx) return VSZIP_ERR_ARG;
-    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const size_t f = trim_parked(ctx);
-    if (freed_bytes) *freed_bytes = f;
-    return VSZIP_OK;
-}
-
-VSZIP_EXPORT int vszip_dev_placement_info(vszip_ctx *ctx, const void *dptr, double *bytes_per_second, int *parked_regions, size_t *parked_bytes, int *walks, int *probed, double *last_walk_ms,
-                                          int *exhausted) {
-    if (!ctx) return VSZIP_ERR_ARG;
-    if (bytes_per_second) {
-        *bytes_per_second = 0.0;
-        for (const auto &r : ctx->placed)
-            if (r.ptr == dptr && r.cost > 0) *bytes_per_second = 1.0 / r.cost;
+    size_t n = 0, pb = 0;
+    int nc = 0;
+    double ms = 0.0, rate = 0.0;
+    if (g_striped_count.load() != 0) {
+        std::lock_guard<std::mutex> lk(striped_mu());
+        auto it = striped_map().find(const_cast<char *>(static_cast<const char *>(dptr)));
+        if (it != striped_map().end()) {
+            n = it->second.handles.size();
+            pb = it->second.piece;
+            nc = it->second.candidates;
+            rate = it->second.probe_bytes_per_s;
+            ms = it->second.build_ms;
+        }
     }
-    if (parked_regions) *parked_regions = (int)ctx->parked.size();
-    if (parked_bytes) {
-        *parked_bytes = 0;
-        for (const auto &r : ctx->parked) *parked_bytes += r.bytes;
-    }
-    if (walks) *walks = ctx->placement_walks;
-    if (probed) *probed = ctx->placement_probed;
-    if (last_walk_ms) *last_walk_ms = ctx->placement_last_walk_ms;
-    if (exhausted) *exhausted = ctx->placement_exhausted ? 1 : 0;
+    if (pieces) *pieces = n;
+    if (piece_bytes) *piece_bytes = pb;
+    if (candidates) *candidates = nc;
+    if (probe_bytes_per_second) *probe_bytes_per_second = rate;
+    if (build_ms) *build_ms = ms;
     return VSZIP_OK;
 }
 
 VSZIP_EXPORT int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, const void *from, double *bytes_per_second) {
     if (!ctx || !dptr || !bytes_per_second) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const double c = probe_region(ctx, dptr, bytes, from, bytes);
+    const double c = probe_region(ctx, dptr, bytes, from);
     if (c <= 0) return vszip_set_error(ctx, VSZIP_ERR_ARG, "region of %zu bytes is too small to probe", bytes);
     *bytes_per_second = 1.0 / c;
     return VSZIP_OK;
 }
 
-VSZIP_EXPORT int vszip_dev_alloc_probed(vszip_ctx *ctx, size_t bytes, int tries, vszip_placement_probe probe, void *user, void **dptr, double *best_cost) {
-    if (!ctx || !dptr) return VSZIP_ERR_ARG;
-    if (tries <= 1 || !probe) {
-        if (best_cost) *best_cost = 0.0;
-        return vszip_dev_alloc(ctx, bytes, dptr);
-    }
-    VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    std::vector<void *> held;  // every candidate stays allocated until the walk is over: the next one lies elsewhere
-    void *best = nullptr;
-    double cost = 0.0;
-    for (int k = 0; k < tries; ++k) {
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-            (void)hipGetLastError();  // out of memory: choose among what fitted
-            break;
-        }
-        held.push_back(p);
-        const double c = probe(user, p);
-        if (!best || c < cost) {
-            best = p;
-            cost = c;
-        }
-    }
-    for (void *p : held)
-        if (p != best) (void)hipFree(p);
-    if (!best) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-    *dptr = best;
-    if (best_cost) *best_cost = cost;
-    return VSZIP_OK;
-}
-
 VSZIP_EXPORT int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
     if (!ctx) return VSZIP_ERR_ARG;
+    if (!dptr) return VSZIP_OK;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     vszip_bilateral_forget_lut(dptr);
-    for (size_t i = 0; i < ctx->placed.size(); ++i)
-        if (ctx->placed[i].ptr == dptr) {  // a classified region: kept for the next request of its size
-            const vszip_ctx::Region r = ctx->placed[i];
-            ctx->placed.erase(ctx->placed.begin() + i);
-            VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (like hipFree: nothing in flight may still use it when it is handed out again)
-            if (ctx->opt.placement) {
-                park_region(ctx, r);
-                return VSZIP_OK;
-            }
-            break;
-        }
+    if (striped_free(dptr)) {
+        (void)hipSetDevice(ctx->device);
+        return VSZIP_OK;
+    }
     VSZIP_HIP_CHECK(ctx, hipFree(dptr));
     return VSZIP_OK;
 }
@@ -620,6 +639,20 @@ static int copy2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, siz
             VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(a, wb, src, spitch, wb, rows, kind, ctx->stream));
             ctx->pending_out.push_back({dst, dpitch, a, wb, rows});
         }
+        return VSZIP_OK;
+    }
+    // A striped arena is several mapped pieces: the runtime's 2-D copy accepts an extent up to the size of ONE of them
+    // (hipMemcpy2DAsync: "invalid argument" beyond; tools/vmm/vmm_copies.hip) - larger planes go in row groups that fit.
+    size_t piece = kind != hipMemcpyHostToDevice ? striped_piece_of(src) : 0;
+    if (kind != hipMemcpyDeviceToHost) {
+        const size_t pd = striped_piece_of(dst);
+        piece = piece && pd ? std::min(piece, pd) : std::max(piece, pd);
+    }
+    const size_t pitch_max = std::max(kind == hipMemcpyHostToDevice ? (size_t)0 : spitch, kind == hipMemcpyDeviceToHost ? (size_t)0 : dpitch);
+    if (piece && pitch_max * rows > piece) {
+        const size_t step = std::max<size_t>(1, piece / pitch_max);
+        for (size_t y = 0; y < rows; y += step)
+            VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<char *>(dst) + y * dpitch, dpitch, static_cast<const char *>(src) + y * spitch, spitch, wb, std::min(step, rows - y), kind, ctx->stream));
         return VSZIP_OK;
     }
     VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, wb, rows, kind, ctx->stream));
