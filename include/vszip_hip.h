@@ -76,8 +76,8 @@ int vszip_abi_version(void);
  * a stable property of the allocation (profiles/r05_placement.md). An arena assembled from separate physical
  * pieces is in the fast class far more often than one contiguous block, so such a request is built with the virtual-memory
  * API - pieces of VSZIP_PLACEMENT_PIECE_MIB (128) from hipMemCreate, mapped side by side into one range - and classified with a
- * 2 ms copy in the ring kernels' access shape; up to VSZIP_PLACEMENT_TRIES (6) candidates are looked at (all held meanwhile,
- * never more than half of what hipMemGetInfo reports free), the search ends with the first one of the best class, else the
+ * 2 ms copy in the ring kernels' access shape; up to VSZIP_PLACEMENT_TRIES (12) candidates are looked at (all held meanwhile,
+ * never more than a quarter of what hipMemGetInfo reports free), the search ends with the first one of the best class, else the
  * fastest is kept, and every other candidate is released before the call returns. Nothing is cached or parked and there is no
  * per-context state. The result is ordinary device memory for kernels and for this library's copies; the RUNTIME's own
  * hipMemcpy2D* accept extents up to one piece only (vszip_copy_*_2d split by rows). vszip_dev_free unmaps and releases at once

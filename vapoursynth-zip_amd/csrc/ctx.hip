@@ -263,7 +263,7 @@ VSZIP_EXPORT const char *vszip_last_error(vszip_ctx *ctx) { return ctx ? ctx->er
 // built from pieces of VSZIP_PLACEMENT_PIECE_MIB, each classified by placement_probe_kernel (the ring kernel's access
 // shape without its arithmetic, 2 ms); the search ends with the first candidate of the best class, else the fastest
 // is kept. Everything else goes back to the driver before the call returns: nothing is parked, there is no per-context
-// state, and the candidates held at once never exceed half of what hipMemGetInfo reports free.
+// state, and the candidates held at once never exceed a quarter of what hipMemGetInfo reports free.
 // vszip_dev_free unmaps and releases. The registry is process-wide: any context may free any arena.
 namespace {
 
@@ -380,7 +380,7 @@ int striped_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         free_b = total;
     }
     if (free_b < total) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "vszip_dev_alloc(%zu): %zu bytes of device memory free", bytes, free_b);
-    const int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 2 / total));
+    const int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 4 / total));
     if (tries > 1) VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<std::pair<StripedArena, void *>> cand;
     int best = -1;
