@@ -39,7 +39,7 @@
 namespace {
 
 constexpr int kScales = 5;  // scales that carry a non-pruned weight
-constexpr int TW = 32, TH = 32, HALO = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
+constexpr int TW = 56, TH = 32, HALO = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;  // maps tiles: 56 x 32 outputs from 64 x 40 staged samples
 constexpr int kVecW = 8;    // reference SIMD width baked into the FMA rule
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -673,6 +673,10 @@ __device__ __forceinline__ double maps_div(double a, double b) {
 
 // ssimMap (:511-523) and edgeMap (:585-603) of one pixel, accumulated in f64
 __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, float bsq, float v1, float v2, bool do_ssim, bool do_edge, double acc[6]) {
+#ifdef VSZIP_SSIM_TIMING_NOF64  // timing only
+    acc[0] += (double)(mu1 + mu2 + b12 + bsq + v1 + v2);
+    return;
+#endif
     if (do_ssim) {
         const float m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2, md = mu1 - mu2;
         const double num_m = (double)fmaf(md, -md, 1.0f);
@@ -696,385 +700,416 @@ __device__ __forceinline__ void maps_pixel(float mu1, float mu2, float b12, floa
     }
 }
 
-// Interior tiles, register blocked: the tile is issue bound (98 % of the issue slots), so the
-// win is fewer instructions per pixel. Vertical pass: a thread owns one staged column and 8
-// output rows — 16 loads per frame instead of 72, and the products p*q, (p+q)^2 are formed once
-// per input row instead of once per tap. Horizontal pass: a thread owns 4 adjacent outputs of a
-// row — 12 loads per map instead of 36. Every output still accumulates its 9 taps in tap order
-// with the same fused / unfused operations, so the f32 maps are unchanged.
-constexpr int kMapsNS = (IH * IW + 255) / 256;  // staged samples per thread and frame
+// ---- the maps kernels ------------------------------------------------------------------------------------------------------------------
+// skip_table (ssimulacra2.zig:22-37) fixes per (scale, plane) whether ssimMap runs and whether edgeMap runs (edgeMap computes artifact AND detail
+// loss whenever either counts, :124): three term sets - S+E (scale 0's Y plane: more than half of the maps time at 4K), S, E - and one kernel
+// instance per set, ssim_maps_ts_kernel<SSIM, EDGE>.
+//
+// Tile geometry (round 5): 56 x 32 outputs from a 64 x 40 staged tile of both frames. The kernels are issue bound, so what counts is how many
+// of a block's 4 x 64 lanes every instruction occupies:
+//   * vertical pass (blurV :308-330): thread = one staged column (64) x one group of 8 output rows (4) = all 256 threads; the 16 samples of a
+//     column window sit in registers, every output accumulates its nine taps in tap order with fmaf. Round 4's 32 x 32 tile staged 40 columns:
+//     160 threads, the third wave half empty and the fourth idle, i.e. one of a CU's four SIMDs did no vertical work at all.
+//   * horizontal pass (blurH :247-306, unfused acc + k * s): thread = one row (32) x one strip of 7 adjacent outputs (8) = 256 threads, 15 LDS
+//     reads for 7 outputs (12 for 4 before); the per-pixel f64 terms (maps_pixel) follow in the same thread.
+// The means (mu1, mu2) are blurred first and stored as the .zw halves of the vertical results, then p, q are overwritten by p q and (p + q)^2
+// and (b12, bsq) follow into the .xy halves: half the live registers of doing all four at once. The E set blurs the two means only; the S set
+// skips edgeMap's division and its four f64 sums.
+// LDS: s1 / s2 in rows of 64 floats with the column XOR-swizzled by the row (c ^ 8 (r & 7): the centre samples edgeMap reads are 8 rows x 8 strips a
+// wave, which a plain pitch of 64 puts in 8 banks; in the vertical pass the swizzle is one of 8 per-thread constants, the row a compile-time offset),
+// the vertical results in rows of 65 x 16 bytes: 53 760 bytes a block = 42 allocation granules of 1 280 bytes = three blocks a CU, to the byte.
+constexpr int kVP = IW + 1;                   // row pitch of the vertical results, v4f slots
+constexpr int kVtSlots = TH * kVP;
+constexpr int kMapsLds = 2 * IH * IW * 4 + kVtSlots * 16;
+static_assert(IW == 64 && TH == 32 && TW % 8 == 0 && IW * (TH / 8) == 256 && TH * (TW / 7) == 256, "the maps kernels' thread maps are written for a 64 x 40 staged tile, 56 x 32 outputs");
+static_assert(kMapsLds <= 42 * 1280, "three blocks a CU: 160 KiB of LDS in granules of 1 280 bytes");
+__device__ __forceinline__ int s_at(int r, int c) { return r * IW + (c ^ ((r & 7) << 3)); }
+__device__ __forceinline__ int vt_at(int r, int c) { return r * kVP + c; }
 
-// the 40 x 40 input tile of both frames: all 14 loads of a thread in flight before anything waits on them
-// (global address space: plane pointers read from the pair table are generic to the compiler — flat
-// loads, each followed by a full s_waitcnt in the rolled loop)
+constexpr int kMapsNS = IH * IW / 256;  // staged samples per thread and frame (10)
+
+// the 64 x 40 input tile of both frames: all 20 loads of a thread in flight before anything waits on them (global address space: plane
+// pointers read from the pair table are generic to the compiler - flat loads, each followed by a full s_waitcnt in the rolled loop).
+// Top / left edge: the blur's padding there is reflect-101 (:254,357) - row / column -j is row / column j whatever the output index - so the
+// padded tile is a fixed function of the plane. CLAMP (border tiles): coordinates past the plane's end are clamped; such samples reach only
+// outputs that the border path recomputes or masks (the END of a line mirrors about the CURRENT output index, :260,364, which no padding expresses).
+template <bool CLAMP>
 __device__ __forceinline__ void ssim_maps_fetch(const MapsArgs &a, const float *im1, const float *im2, int x0, int y0, float v1[kMapsNS], float v2[kMapsNS]) {
     const float VSZIP_GLOBAL *g1 = (const float VSZIP_GLOBAL *)im1, *g2 = (const float VSZIP_GLOBAL *)im2;
     const int tid = threadIdx.x;
+    const int c = tid & (IW - 1), rb = tid >> 6;
+    int gx = abs(x0 - HALO + c);
+    if (CLAMP) gx = min(gx, a.w - 1);
 #pragma unroll
     for (int k = 0; k < kMapsNS; ++k) {
-        const int i = min(tid + 256 * k, IH * IW - 1);
-        const int r = i / IW, c = i - r * IW;
-        // (tiles on the top / left edge: the blur's padding there is reflect-101, :254,357 - row / column -j is row / column j, whatever the output
-        // index, so the padded tile is a fixed function of the plane and the blocked path applies; the END of a line mirrors about the CURRENT output
-        // index, :260,364, which no padding expresses: those tiles keep the generic path)
-        const size_t o = (size_t)abs(y0 - HALO + r) * a.stride + abs(x0 - HALO + c);
-        v1[k] = g1[o];
-        v2[k] = g2[o];
+        int gy = abs(y0 - HALO + rb + 4 * k);
+        if (CLAMP) gy = min(gy, a.h - 1);
+        // a 32-bit BYTE offset (planes are below 4 GiB): "scalar base + 32-bit lane offset" loads instead of a 64-bit address pair per load
+        const uint32_t o = (uint32_t)(gy * a.stride + gx) * 4u;
+#ifdef VSZIP_SSIM_TIMING_NOFETCH  // timing only
+        v1[k] = (float)(o & 255) * 0.001f;
+        v2[k] = (float)(o & 127) * 0.002f;
+        (void)g1;
+        (void)g2;
+#else
+        v1[k] = *reinterpret_cast<const float VSZIP_GLOBAL *>(reinterpret_cast<const char VSZIP_GLOBAL *>(g1) + o);
+        v2[k] = *reinterpret_cast<const float VSZIP_GLOBAL *>(reinterpret_cast<const char VSZIP_GLOBAL *>(g2) + o);
+#endif
     }
 }
-__device__ __forceinline__ void ssim_maps_park(const float v1[kMapsNS], const float v2[kMapsNS], float (*s1)[IW + 1], float (*s2)[IW + 1]) {
+__device__ __forceinline__ void ssim_maps_park(const float v1[kMapsNS], const float v2[kMapsNS], float *s1, float *s2) {
     const int tid = threadIdx.x;
+    const int wv = tid >> 6, c = tid & (IW - 1);
+    const int base[2] = {wv * IW + (c ^ (wv << 3)), wv * IW + (c ^ ((wv + 4) << 3))};  // rows wv + 4 k: (row & 7) = wv + 4 (k & 1)
 #pragma unroll
     for (int k = 0; k < kMapsNS; ++k) {
-        const int i = tid + 256 * k;
-        if (i < IH * IW) {
-            const int r = i / IW, c = i - r * IW;
-            s1[r][c] = v1[k];
-            s2[r][c] = v2[k];
-        }
+        s1[base[k & 1] + 4 * k * IW] = v1[k];
+        s2[base[k & 1] + 4 * k * IW] = v2[k];
     }
 }
 
-// interior tile whose inputs are already in s1 / s2
-__device__ __forceinline__ void ssim_maps_tile_blocked(bool do_ssim, bool do_edge, float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
+// vertical pass of a staged tile: thread (column c, rows 8 g .. 8 g + 7). FUSED: the reference's vector body (fmaf, :318); else its scalar
+// tail (acc + k * s, :326) - columns at and beyond w - w % 8.
+template <bool SSIM, bool FUSED>
+__device__ __forceinline__ void ssim_maps_vertical(const float *s1, const float *s2, v4f *vt) {
     const int tid = threadIdx.x;
-#ifndef VSZIP_SSIM_VR
-#define VSZIP_SSIM_VR 8
-#endif
-    // output rows per thread in the vertical pass: 8 -> 40 columns x 4 row groups = 160 of the 256 threads. 6 rows (240 threads) was
-    // measured in round 3 (tools/variant.sh, interleaved A/B on one device): 4.94-4.99 k pairs/s against 5.49-5.55 k — the shorter
-    // per-thread chains do not pay for the 25 % more tap loads and the clamped last group.
-    constexpr int VR = VSZIP_SSIM_VR;
-    if (tid < IW * ((TH + VR - 1) / VR)) {
-        const int c = tid % IW, r0 = (tid / IW) * VR;
-        float p[VR + 8], q[VR + 8], pq[VR + 8], sq[VR + 8];
+    constexpr int VR = 8;
+    const int c = tid & (IW - 1), r0 = (tid >> 6) * VR;
+    int sb[8];  // rows r0 + j, r0 a multiple of 8: the swizzle of row j is that of j & 7
+#pragma unroll
+    for (int m = 0; m < 8; ++m) sb[m] = r0 * IW + (c ^ (m << 3));
+    float *vo = reinterpret_cast<float *>(vt + vt_at(r0, c));
+    float p[VR + 8], q[VR + 8];
+#pragma unroll
+    for (int j = 0; j < VR + 8; ++j) {
+        p[j] = s1[sb[j & 7] + j * IW];
+        q[j] = s2[sb[j & 7] + j * IW];
+    }
+#pragma unroll
+    for (int o = 0; o < VR; ++o) {
+        v2f m = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const v2f kk = {c_kernel[k], c_kernel[k]}, pq = {p[o + k], q[o + k]};
+            m = FUSED ? __builtin_elementwise_fma(kk, pq, m) : m + kk * pq;
+        }
+        *reinterpret_cast<v2f *>(vo + o * kVP * 4 + 2) = m;
+    }
+    if constexpr (SSIM) {
 #pragma unroll
         for (int j = 0; j < VR + 8; ++j) {
-            const int rr = min(r0 + j, IH - 1);  // (the last group owns 2 rows: its other taps read the last row, their outputs are not stored)
-            p[j] = s1[rr][c];
-            q[j] = s2[rr][c];
-        }
-        if (do_ssim) {
-#pragma unroll
-            for (int j = 0; j < VR + 8; ++j) {
-                pq[j] = p[j] * q[j];
-                const float sum = p[j] + q[j];
-                sq[j] = sum * sum;
-            }
+            const float pp = p[j], qq = q[j], sum = pp + qq;
+            p[j] = pp * qq;
+            q[j] = sum * sum;
         }
 #pragma unroll
         for (int o = 0; o < VR; ++o) {
-            // (m1, m2) and (m12, msq) ride in one packed register pair each: v_pk_fma_f32, element-wise IEEE
-            v2f m = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {  // blurV vector body :318 (interior tiles lie left of the unfused tail)
-                const v2f kk = {c_kernel[k], c_kernel[k]};
-                m = __builtin_elementwise_fma(kk, v2f{p[o + k], q[o + k]}, m);
-                if (do_ssim) ms = __builtin_elementwise_fma(kk, v2f{pq[o + k], sq[o + k]}, ms);
-            }
-            if (r0 + o < TH) vt[r0 + o][c] = v4f{ms.x, ms.y, m.x, m.y};
-        }
-    }
-    __syncthreads();
-    constexpr int HC = 4;  // adjacent outputs per thread in the horizontal pass: 32 rows x 8 strips = 256 threads
-    {
-        const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
-        // one 16-byte LDS read per column; (mu1, mu2) and (b12, bsq) accumulate as packed pairs (v_pk_mul_f32 +
-        // v_pk_add_f32: unfused and element-wise IEEE, blurH :276)
-        v4f t[HC + 8];
-#pragma unroll
-        for (int j = 0; j < HC + 8; ++j) t[j] = vt[r][xs + j];
-#pragma unroll
-        for (int o = 0; o < HC; ++o) {
-            v2f mu = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
+            v2f ms = {0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const v2f kk = {c_kernel[k], c_kernel[k]};
-                mu = mu + kk * v2f{t[o + k].z, t[o + k].w};
-                if (do_ssim) bs = bs + kk * v2f{t[o + k].x, t[o + k].y};
+                const v2f kk = {c_kernel[k], c_kernel[k]}, pq = {p[o + k], q[o + k]};
+                ms = FUSED ? __builtin_elementwise_fma(kk, pq, ms) : ms + kk * pq;
             }
-            const float mu1 = mu.x, mu2 = mu.y, b12 = bs.x, bsq = bs.y;
-            maps_pixel(mu1, mu2, b12, bsq, s1[r + HALO][xs + o + HALO], s2[r + HALO][xs + o + HALO], do_ssim, do_edge, acc);
+            *reinterpret_cast<v2f *>(vo + o * kVP * 4) = ms;
         }
     }
 }
 
-// INTERIOR: the tile plus its halo lies inside the plane and left of the fused/unfused column
-// split, so every tap offset is a compile-time constant and the index arithmetic folds away.
-template <bool INTERIOR>
-__device__ __forceinline__ void ssim_maps_tile(const MapsArgs &a, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0,
-                                               float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
-    const int w = a.w, h = a.h;
-    const int cx0 = INTERIOR ? x0 - HALO : max(x0 - HALO, 0), cy0 = INTERIOR ? y0 - HALO : max(y0 - HALO, 0);  // real coords of LDS (0,0)
-    const int cw = INTERIOR ? IW : min(x0 + TW + HALO, w) - cx0, ch = INTERIOR ? IH : min(y0 + TH + HALO, h) - cy0;
-    const int tid = threadIdx.x;
+constexpr int HC = 7;  // adjacent outputs per thread in the horizontal pass: 32 rows x 8 strips
 
+// horizontal pass of the thread's 7 outputs from the vertical results
+template <bool SSIM>
+__device__ __forceinline__ void ssim_maps_horizontal(const v4f *vt, v2f mu[HC], v2f bs[HC]) {
+    const int tid = threadIdx.x;
+    const int r = tid >> 3, xs = (tid & 7) * HC;
+    const float *vi = reinterpret_cast<const float *>(vt + vt_at(r, xs));
+    {
+        v2f t[HC + 8];
+#pragma unroll
+        for (int j = 0; j < HC + 8; ++j) t[j] = *reinterpret_cast<const v2f *>(vi + 4 * j + 2);
+#pragma unroll
+        for (int o = 0; o < HC; ++o) {
+            v2f acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = acc + v2f{c_kernel[k], c_kernel[k]} * t[o + k];
+            mu[o] = acc;
+        }
+    }
+    if constexpr (SSIM) {
+        // (a scheduling fence: without it the compiler fuses the two halves' reads into 16-byte reads and holds all 60 values at once - 30 registers
+        // more than the kernel has at three blocks a CU, and a spilled value reloads through vmcnt, in line behind the next tile's 20 global loads)
+        asm volatile("" ::: "memory");
+        v2f t[HC + 8];
+#pragma unroll
+        for (int j = 0; j < HC + 8; ++j) t[j] = *reinterpret_cast<const v2f *>(vi + 4 * j);
+#pragma unroll
+        for (int o = 0; o < HC; ++o) {
+            v2f acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = acc + v2f{c_kernel[k], c_kernel[k]} * t[o + k];
+            bs[o] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < HC; ++o) bs[o] = v2f{0.0f, 0.0f};
+    }
+}
+
+// the second half of a tile clear of the plane's bottom / right edge (its vertical pass is done, no barrier yet)
+template <bool SSIM, bool EDGE>
+__device__ __forceinline__ void ssim_maps_tile_ts_h(const float *s1, const float *s2, const v4f *vt, double acc[6]) {
+    const int tid = threadIdx.x;
+    // the centre samples edgeMap needs, read BEFORE the barrier: after it nobody reads s1 / s2 any more, so the next tile may be parked into them
+    // without a barrier at the end of this one (vt is protected by the barrier that follows the park)
+    float e1[HC], e2[HC];
+    if constexpr (EDGE) {
+        const int rr = (tid >> 3) + HALO, cb = (tid & 7) * HC + HALO;
+#pragma unroll
+        for (int o = 0; o < HC; ++o) {
+            e1[o] = s1[s_at(rr, cb + o)];
+            e2[o] = s2[s_at(rr, cb + o)];
+        }
+    }
+    __syncthreads();
+    v2f mu[HC], bs[HC];
+    ssim_maps_horizontal<SSIM>(vt, mu, bs);
+#pragma unroll
+    for (int o = 0; o < HC; ++o) maps_pixel(mu[o].x, mu[o].y, bs[o].x, bs[o].y, EDGE ? e1[o] : 0.0f, EDGE ? e2[o] : 0.0f, SSIM, EDGE, acc);
+}
+
+// A tile on the plane's bottom / right edge (planes of at least 16 x 16). Round 4 sent these to the per-pixel generic path (4.5 % of a 4K
+// plane's tiles at several times an interior tile's cost). The end-of-line rule (tap_index: taps past the end mirror about the CURRENT output
+// index) changes the taps of the LAST FOUR outputs of a line only - an output i with n - 1 - i >= 4 has all its taps inside the line - so the
+// tile runs the blocked passes on a staged tile whose coordinates are clamped at the plane's end, and then
+//   * vertical: a thread recomputes those of its outputs that lie in the plane's last four rows with the mirrored taps (gathered from LDS),
+//     and columns at and beyond w - w % 8 take the unfused form (the reference's scalar tail, :326) - per thread, a column is one thread's;
+//   * horizontal: outputs in the plane's last four columns are recomputed with the mirrored taps (gathered from the vertical results),
+//     outputs beyond the plane are dropped.
+// (Not inlined, like the small-plane path below: inlined, their live ranges cost the interior path 29 scratch reloads a tile. They run on a few per
+// cent of the tiles; their sums come back by value.)
+struct MapsSums {
+    double v[6];
+};
+struct MapsGeom {
+    int stride, w, h;
+};
+template <bool SSIM, bool EDGE>
+__device__ __attribute__((noinline)) MapsSums ssim_maps_tile_border(MapsGeom g, const float *im1, const float *im2, int x0, int y0, float *s1, float *s2, v4f *vt) {
+    const int tid = threadIdx.x;
+    const int w = g.w, h = g.h;
+    MapsArgs a;  // (the fetch reads stride, w and h only)
+    a.stride = g.stride;
+    a.w = w;
+    a.h = h;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    {
+        float v1[kMapsNS], v2[kMapsNS];
+        ssim_maps_fetch<true>(a, im1, im2, x0, y0, v1, v2);
+        ssim_maps_park(v1, v2, s1, s2);
+    }
+    __syncthreads();
+    {
+        const int c = tid & (IW - 1), r0 = (tid >> 6) * 8;
+        const bool fused = x0 - HALO + c < w - (w % kVecW);
+        if (fused)
+            ssim_maps_vertical<SSIM, true>(s1, s2, vt);
+        else
+            ssim_maps_vertical<SSIM, false>(s1, s2, vt);
+        if (y0 + r0 + 7 >= h - HALO) {  // some of this thread's rows are among the plane's last four
+#pragma unroll 1
+            for (int o = 0; o < 8; ++o) {
+                const int y = y0 + r0 + o;
+                if (y < h - HALO || y >= h) continue;
+                v2f m = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
+#pragma unroll 1
+                for (int k = 0; k < 9; ++k) {
+                    const int rr = tap_index(k, y, h) - (y0 - HALO);  // (a reflected tap of the first rows: the same sample sits at the positive coordinate)
+                    const float p = s1[s_at(rr, c)], q = s2[s_at(rr, c)], sum = p + q;
+                    const v2f kk = {c_kernel[k], c_kernel[k]}, pq = {p, q}, prod = {p * q, sum * sum};
+                    if (fused) {
+                        m = __builtin_elementwise_fma(kk, pq, m);
+                        if (SSIM) ms = __builtin_elementwise_fma(kk, prod, ms);
+                    } else {
+                        m = m + kk * pq;
+                        if (SSIM) ms = ms + kk * prod;
+                    }
+                }
+                float *fix = reinterpret_cast<float *>(vt + vt_at(r0 + o, c));  // (through the same float-based v2f stores as ssim_maps_vertical: one access type for these bytes)
+                *reinterpret_cast<v2f *>(fix + 2) = m;
+                if (SSIM) *reinterpret_cast<v2f *>(fix) = ms;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 3, xs = (tid & 7) * HC;
+        const int y = y0 + r;
+        if (y < h) {
+            {
+                v2f mu[HC], bs[HC];
+                ssim_maps_horizontal<SSIM>(vt, mu, bs);
+#pragma unroll
+                for (int o = 0; o < HC; ++o) {
+                    if (x0 + xs + o >= w - HALO) continue;  // the plane's last four columns: below; beyond the plane: nothing
+                    const int cc = s_at(r + HALO, xs + o + HALO);
+                    maps_pixel(mu[o].x, mu[o].y, bs[o].x, bs[o].y, EDGE ? s1[cc] : 0.0f, EDGE ? s2[cc] : 0.0f, SSIM, EDGE, acc);
+                }
+            }
+#pragma unroll 1
+            for (int x = max(x0 + xs, w - HALO); x < min(x0 + xs + HC, w); ++x) {
+                v2f m2 = {0.0f, 0.0f}, b2 = {0.0f, 0.0f};
+#pragma unroll 1
+                for (int k = 0; k < 9; ++k) {
+                    const float *t = reinterpret_cast<const float *>(vt + vt_at(r, tap_index(k, x, w) - (x0 - HALO)));
+                    const v2f kk = {c_kernel[k], c_kernel[k]};
+                    m2 = m2 + kk * *reinterpret_cast<const v2f *>(t + 2);
+                    if (SSIM) b2 = b2 + kk * *reinterpret_cast<const v2f *>(t);
+                }
+                const int cc = s_at(r + HALO, x - x0 + HALO);
+                maps_pixel(m2.x, m2.y, b2.x, b2.y, EDGE ? s1[cc] : 0.0f, EDGE ? s2[cc] : 0.0f, SSIM, EDGE, acc);
+            }
+        }
+    }
+    MapsSums out;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) out.v[q] = acc[q];
+    return out;
+}
+
+// Planes smaller than 16 x 16 (the last scales of small clips): per-pixel, every tap through tap_index. (blurV :308-330, blurH :247-306)
+__device__ __attribute__((noinline)) MapsSums ssim_maps_tile_small(MapsGeom g, const float *im1, const float *im2, bool do_ssim, bool do_edge, int x0, int y0, float *s1, float *s2, v4f *vt) {
+    const int w = g.w, h = g.h;
+    struct { int stride; } a = {g.stride};
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int cx0 = max(x0 - HALO, 0), cy0 = max(y0 - HALO, 0);  // real coords of LDS (0,0)
+    const int cw = min(x0 + TW + HALO, w) - cx0, ch = min(y0 + TH + HALO, h) - cy0;
+    const int tid = threadIdx.x;
     for (int i = tid; i < ch * cw; i += 256) {
         const int r = i / cw, c = i - r * cw;
         const size_t o = (size_t)(cy0 + r) * a.stride + (cx0 + c);
-        s1[r][c] = im1[o];
-        s2[r][c] = im2[o];
+        s1[s_at(r, c)] = im1[o];
+        s2[s_at(r, c)] = im2[o];
     }
     __syncthreads();
-
-    // vertical pass: rows of the tile, every staged column (blurV :308-330)
-    const int th = INTERIOR ? TH : min(TH, h - y0);
+    const int th = min(TH, h - y0);
     const int wv = w - (w % kVecW);
     for (int i = tid; i < th * cw; i += 256) {
         const int r = i / cw, c = i - r * cw;
         const int y = y0 + r;
-        const bool fused = INTERIOR || (cx0 + c) < wv;
-        // two maps per packed instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): (m1, m2)
-        // and (m12, msq); element-wise IEEE, so every lane value equals the scalar form
+        const bool fused = (cx0 + c) < wv;
         v2f m = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int rr = INTERIOR ? r + k : tap_index(k, y, h) - cy0;
-            const float p = s1[rr][c], q = s2[rr][c];
+            const int rr = tap_index(k, y, h) - cy0;
+            const float p = s1[s_at(rr, c)], q = s2[s_at(rr, c)];
             const v2f kk = {c_kernel[k], c_kernel[k]};
             const v2f pq = {p, q};
             const float sum = p + q;
-            const v2f a = {p, sum}, b2 = {q, sum};
+            const v2f a2 = {p, sum}, b2 = {q, sum};
             if (fused) {
                 m = __builtin_elementwise_fma(kk, pq, m);
-                if (do_ssim) ms = __builtin_elementwise_fma(kk, a * b2, ms);
+                if (do_ssim) ms = __builtin_elementwise_fma(kk, a2 * b2, ms);
             } else {
                 m = m + kk * pq;
-                if (do_ssim) ms = ms + kk * (a * b2);
+                if (do_ssim) ms = ms + kk * (a2 * b2);
             }
         }
-        vt[r][c] = v4f{ms.x, ms.y, m.x, m.y};
+        vt[vt_at(r, c)] = v4f{ms.x, ms.y, m.x, m.y};
     }
     __syncthreads();
-
-    // horizontal pass (blurH :247-306, unfused acc + k*s) and the per-pixel maps
-    const int tw = INTERIOR ? TW : min(TW, w - x0);
+    const int tw = min(TW, w - x0);
     for (int i = tid; i < th * tw; i += 256) {
         const int r = i / tw, c = i - r * tw;
         const int x = x0 + c;
         v2f mu = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int cc = INTERIOR ? c + k : tap_index(k, x, w) - cx0;
+            const int cc = tap_index(k, x, w) - cx0;
             const v2f kk = {c_kernel[k], c_kernel[k]};
-            const v4f t = vt[r][cc];
+            const v4f t = vt[vt_at(r, cc)];
             mu = mu + kk * v2f{t.z, t.w};
             if (do_ssim) bs = bs + kk * v2f{t.x, t.y};
         }
-        maps_pixel(mu.x, mu.y, bs.x, bs.y, s1[y0 + r - cy0][x - cx0], s2[y0 + r - cy0][x - cx0], do_ssim, do_edge, acc);
+        maps_pixel(mu.x, mu.y, bs.x, bs.y, s1[s_at(y0 + r - cy0, x - cx0)], s2[s_at(y0 + r - cy0, x - cx0)], do_ssim, do_edge, acc);
     }
+    MapsSums out;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) out.v[q] = acc[q];
+    return out;
 }
 
-__global__ __launch_bounds__(256) void ssim_maps_kernel(const MapsArgs a) {
-    __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];  // XYB tile of both frames
-    __shared__ v4f vt[TH][IW + 1];                    // vertical pass of the 4 maps, interleaved: (b12, bsq, mu1, mu2) of a pixel in one 16-byte word
-    __shared__ double red[4][6];
-
-    const int ps = blockIdx.z % a.nactive, pair = blockIdx.z / a.nactive;
-    const PairPtrs &pp = a.tab[pair];
-    const float *im1 = pp.xyb1[a.plane[ps]], *im2 = pp.xyb2[a.plane[ps]];
-    const int w = a.w, h = a.h;
-    const int y0 = blockIdx.y * TH;
-    const bool do_ssim = a.flags[ps] & 1, do_edge = a.flags[ps] & 2;
-    const int tid = threadIdx.x;
-    auto is_interior = [&](int x0) { return x0 >= HALO && y0 >= HALO && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h; };
-    // A block walks a.tpb neighbouring tiles: the first scale's planes stream from HBM and with one tile per
-    // block nothing hid that latency (its launch cost twice as much per pixel as the cached scales), so the next
-    // interior tile's inputs are fetched into registers while this one is filtered.
-    const int tx0 = blockIdx.x * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
-    float v1[kMapsNS], v2[kMapsNS];
-    bool fetched = false;
-    for (int tx = tx0; tx < tx1; ++tx) {
-        const int x0 = tx * TW;
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        if (is_interior(x0)) {
-            if (!fetched) ssim_maps_fetch(a, im1, im2, x0, y0, v1, v2);
-            ssim_maps_park(v1, v2, s1, s2);
-            __syncthreads();
-            fetched = tx + 1 < tx1 && is_interior(x0 + TW);
-            if (fetched) ssim_maps_fetch(a, im1, im2, x0 + TW, y0, v1, v2);
-            ssim_maps_tile_blocked(do_ssim, do_edge, s1, s2, vt, acc);
-        } else {
-            fetched = false;
-            ssim_maps_tile<false>(a, im1, im2, do_ssim, do_edge, x0, y0, s1, s2, vt, acc);
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) acc[q] = wave_reduce_sum(acc[q]);
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
-        }
-        __syncthreads();
-        if (tid < 6) {
-            const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-            const int tile = blockIdx.y * a.tiles_x + tx;
-            a.partial[(((size_t)pair * 18 + a.slot[ps]) * a.max_tiles + tile) * 6 + tid] = v;
-        }
-        __syncthreads();  // s1 / s2 / vt / red are rewritten by the next tile
-    }
-}
-
-// ---- round 4: the maps kernel per TERM SET, register-lean ------------------------------------------------------------------------------
-// skip_table (ssimulacra2.zig:22-37) fixes per (scale, plane) whether ssimMap runs and whether edgeMap runs (edgeMap computes artifact AND detail loss
-// whenever either counts, :124): three term sets — S+E (scale 0's Y plane: 56 % of the maps time at 4K), S, E. ssim_maps_kernel above serves them all
-// with run-time flags and 167 VGPRs (three waves a SIMD; capped at 128 it spills). ssim_maps_ts_kernel<SSIM, EDGE> is the same arithmetic with the
-// flags compile-time and the two blur passes split so that the live state is half as large:
-//   * vertical: the (mu1, mu2) taps first — 2 x 16 staged samples in registers — and their 8 outputs stored as the .zw halves of vt; then p, q are
-//     overwritten by p q and (p + q)^2 and the (b12, bsq) taps follow into the .xy halves (the generic kernel holds all four 16-sample arrays);
-//   * horizontal: the .zw halves of 12 columns give mu1 / mu2 of the thread's 4 outputs, then the .xy halves give b12 / bsq (12 x 8-byte reads twice
-//     instead of 12 x 16-byte once: LDS has the room, the generic kernel's array is at 0.38);
-//   * the E set loads and blurs the two means only; the S set skips edgeMap's division and its four f64 sums.
-// Every output accumulates its nine taps in tap order with the same fused (vertical, :318) / unfused (horizontal, :276) operations, so the f32 maps and
-// therefore every per-pixel f64 term are those of the generic kernel; the sums differ in their ORDER only (a block's four tiles in one set of
-// per-thread sums, below): tests/test_gpu_ssimulacra2.py::test_maps_term_set_kernels_match_the_generic_one holds the scores to 1e-11.
-template <bool SSIM, bool EDGE>
-__device__ __forceinline__ void ssim_maps_tile_ts(float (*s1)[IW + 1], float (*s2)[IW + 1], v4f (*vt)[IW + 1], double acc[6]) {
-    const int tid = threadIdx.x;
-    constexpr int VR = 8;
-    if (tid < IW * ((TH + VR - 1) / VR)) {
-        const int c = tid % IW, r0 = (tid / IW) * VR;
-        float p[VR + 8], q[VR + 8];
-#pragma unroll
-        for (int j = 0; j < VR + 8; ++j) {
-            const int rr = min(r0 + j, IH - 1);
-            p[j] = s1[rr][c];
-            q[j] = s2[rr][c];
-        }
-#pragma unroll
-        for (int o = 0; o < VR; ++o) {
-            v2f m = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 9; ++k) m = __builtin_elementwise_fma(v2f{c_kernel[k], c_kernel[k]}, v2f{p[o + k], q[o + k]}, m);
-            if (r0 + o < TH) *reinterpret_cast<v2f *>(&reinterpret_cast<float *>(&vt[r0 + o][c])[2]) = m;
-        }
-        if constexpr (SSIM) {
-#pragma unroll
-            for (int j = 0; j < VR + 8; ++j) {
-                const float pp = p[j], qq = q[j], sum = pp + qq;
-                p[j] = pp * qq;
-                q[j] = sum * sum;
-            }
-#pragma unroll
-            for (int o = 0; o < VR; ++o) {
-                v2f ms = {0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < 9; ++k) ms = __builtin_elementwise_fma(v2f{c_kernel[k], c_kernel[k]}, v2f{p[o + k], q[o + k]}, ms);
-                if (r0 + o < TH) *reinterpret_cast<v2f *>(&vt[r0 + o][c]) = ms;
-            }
-        }
-    }
-    constexpr int HC = 4;
-    // the centre samples edgeMap needs, read BEFORE the barrier: after it nobody reads s1 / s2 any more, so the next tile may be parked into them
-    // without a barrier at the end of this one (vt is protected by the barrier that follows the park)
-    float e1[HC], e2[HC];
-#ifdef VSZIP_SSIM_NO_PREREAD  // (A/B only: the centre samples after the barrier, a barrier at the end of every tile)
-    constexpr bool kPre = false;
-#else
-    constexpr bool kPre = true;
-#endif
-    if constexpr (EDGE && kPre) {
-        const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
-#pragma unroll
-        for (int o = 0; o < HC; ++o) {
-            e1[o] = s1[r + HALO][xs + o + HALO];
-            e2[o] = s2[r + HALO][xs + o + HALO];
-        }
-    }
-    __syncthreads();
-    {
-        const int r = tid / (TW / HC), xs = (tid % (TW / HC)) * HC;
-        v2f mu[HC], bs[HC];
-        {
-            v2f t[HC + 8];
-#pragma unroll
-            for (int j = 0; j < HC + 8; ++j) t[j] = *reinterpret_cast<const v2f *>(&reinterpret_cast<const float *>(&vt[r][xs + j])[2]);
-#pragma unroll
-            for (int o = 0; o < HC; ++o) {
-                v2f a = {0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < 9; ++k) a = a + v2f{c_kernel[k], c_kernel[k]} * t[o + k];
-                mu[o] = a;
-            }
-        }
-        if constexpr (SSIM) {
-            v2f t[HC + 8];
-#pragma unroll
-            for (int j = 0; j < HC + 8; ++j) t[j] = *reinterpret_cast<const v2f *>(&vt[r][xs + j]);
-#pragma unroll
-            for (int o = 0; o < HC; ++o) {
-                v2f a = {0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < 9; ++k) a = a + v2f{c_kernel[k], c_kernel[k]} * t[o + k];
-                bs[o] = a;
-            }
-        } else {
-#pragma unroll
-            for (int o = 0; o < HC; ++o) bs[o] = v2f{0.0f, 0.0f};
-        }
-#pragma unroll
-        for (int o = 0; o < HC; ++o)
-            maps_pixel(mu[o].x, mu[o].y, bs[o].x, bs[o].y, EDGE ? (kPre ? e1[o] : s1[r + HALO][xs + o + HALO]) : 0.0f, EDGE ? (kPre ? e2[o] : s2[r + HALO][xs + o + HALO]) : 0.0f, SSIM, EDGE, acc);
-    }
-}
-
-// Waves per SIMD the instances are compiled for. 3: 136-138 VGPRs, no spills. 4 (128 VGPRs, 5-10 dwords spilled) was 7 % faster than 3 while a tile still
-// ended in a six-sum wave reduction and two more barriers (5.65 k against 5.30 k pairs/s); with one reduction per block and no barrier at a tile's end the
-// spills cost more than the fourth wave buys: 6.50-6.57 k at three waves against 6.24-6.46 k at four (interleaved A/B, profiles/r04_ssim_ab.txt).
-#ifndef VSZIP_SSIM_TS_WPE
-#define VSZIP_SSIM_TS_WPE 3
+// Three blocks a CU (12 waves, 3 a SIMD, at most 168 VGPRs): bounded by the LDS above.
+#ifndef VSZIP_SSIM_TS_BPC
+#define VSZIP_SSIM_TS_BPC 3
 #endif
 template <bool SSIM, bool EDGE>
-__global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(const MapsArgs a) {
-    __shared__ float s1[IH][IW + 1], s2[IH][IW + 1];
-    __shared__ v4f vt[TH][IW + 1];
-    __shared__ double red[4][6];
-    // XCD-aware order: workgroup i runs on XCD i % 8, so the logical blocks are dealt out in eight contiguous chunks — an XCD walks a band of tile
+__global__ __launch_bounds__(256, VSZIP_SSIM_TS_BPC) void ssim_maps_ts_kernel(const MapsArgs a) {
+    __shared__ float s1[IH * IW], s2[IH * IW];
+    __shared__ v4f vt[kVtSlots];
+    // XCD-aware order: workgroup i runs on XCD i % 8, so the logical blocks are dealt out in eight contiguous chunks - an XCD walks a band of tile
     // rows of one plane, and the 8-row / 8-column halo a tile shares with its neighbours is in that XCD's L2 (with the plain 3-D grid every
     // neighbour sat on another XCD and the halo came from memory again)
     const int chunk = (a.nblk + 7) >> 3;
     const int lb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (lb >= a.nblk) return;
-    const int bx = lb % a.gx, by = (lb / a.gx) % a.gy, bz = lb / (a.gx * a.gy);
-    const int ps = bz % a.nactive, pair = bz / a.nactive;
+    // (the divisions run on the vector unit; readfirstlane tells the compiler what it cannot see - these are the same in every lane - so that the
+    // plane pointers are scalar loads and the tile fetch is "scalar base + 32-bit lane offset")
+    const int bx = __builtin_amdgcn_readfirstlane(lb % a.gx), by = __builtin_amdgcn_readfirstlane((lb / a.gx) % a.gy), bz = __builtin_amdgcn_readfirstlane(lb / (a.gx * a.gy));
+    const int ps = __builtin_amdgcn_readfirstlane(bz % a.nactive), pair = __builtin_amdgcn_readfirstlane(bz / a.nactive);
     const PairPtrs &pp = a.tab[pair];
-    const float *im1 = pp.xyb1[a.plane[ps]], *im2 = pp.xyb2[a.plane[ps]];
+    const int pl = __builtin_amdgcn_readfirstlane(a.plane[ps]);
+    auto uniform_ptr = [](const float *p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const float *>(((uint64_t)hi << 32) | lo);
+    };
+    const float *im1 = uniform_ptr(pp.xyb1[pl]), *im2 = uniform_ptr(pp.xyb2[pl]);
     const int w = a.w, h = a.h;
     const int y0 = by * TH;
     const int tid = threadIdx.x;
-    // "interior" for the blocked path: clear of the bottom / right edge (and of the unfused column tail); top / left edge tiles are staged with
-    // their reflect-101 padding (ssim_maps_fetch) - 187 of a 4K plane's 375 edge tiles leave the generic path
-    auto is_interior = [&](int x0) { return x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h && w > HALO && h > HALO; };
+    const bool small = w < 16 || h < 16;
+    // "interior": clear of the bottom / right edge and of the unfused column tail; top / left edge tiles are staged with their reflect-101 padding
+    auto is_interior = [&](int x0) { return !small && x0 + TW + HALO <= w - (w % kVecW) && y0 + TH + HALO <= h; };
     const int tx0 = bx * a.tpb, tx1 = min(tx0 + a.tpb, a.tiles_x);
     float v1[kMapsNS], v2[kMapsNS];
     bool fetched = false;
-    // The block's tiles accumulate into ONE set of per-thread sums, reduced once (fixed order: lanes, then the four waves): a quarter of the wave
-    // reductions (72 ds_bpermute + 36 f64 adds each) and of the barriers of a reduction per tile. The block's sum goes into the slot of its first
-    // tile, the other tiles' slots hold exact zeros (the final kernel folds every slot).
+    // The block's tiles accumulate into ONE set of per-thread sums, reduced once (fixed order: lanes, then the four waves). The block's sum goes
+    // into the slot of its first tile, the other tiles' slots hold exact zeros (the final kernel folds every slot).
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int tx = tx0; tx < tx1; ++tx) {
         const int x0 = tx * TW;
         if (is_interior(x0)) {
-            if (!fetched) ssim_maps_fetch(a, im1, im2, x0, y0, v1, v2);
+            if (!fetched) ssim_maps_fetch<false>(a, im1, im2, x0, y0, v1, v2);
             ssim_maps_park(v1, v2, s1, s2);
             __syncthreads();
+#ifdef VSZIP_SSIM_FETCH_EARLY  // (A/B: the next tile requested before the vertical pass)
             fetched = tx + 1 < tx1 && is_interior(x0 + TW);
-            if (fetched) ssim_maps_fetch(a, im1, im2, x0 + TW, y0, v1, v2);
-            ssim_maps_tile_ts<SSIM, EDGE>(s1, s2, vt, acc);
-            // (no barrier here: see the centre samples in ssim_maps_tile_ts; a boundary tile that follows stages with a barrier of its own first)
-#ifdef VSZIP_SSIM_NO_PREREAD
-            __syncthreads();
+            if (fetched) ssim_maps_fetch<false>(a, im1, im2, x0 + TW, y0, v1, v2);
+            ssim_maps_vertical<SSIM, true>(s1, s2, vt);
 #else
-            if (tx + 1 < tx1 && !is_interior(x0 + TW)) __syncthreads();
+            ssim_maps_vertical<SSIM, true>(s1, s2, vt);
+            // the next tile's samples are requested here, between the passes: they arrive under the horizontal pass and the f64 terms, and their 20
+            // registers are not live during the vertical pass (whose column windows need 40)
+            fetched = tx + 1 < tx1 && is_interior(x0 + TW);
+            if (fetched) ssim_maps_fetch<false>(a, im1, im2, x0 + TW, y0, v1, v2);
 #endif
+            ssim_maps_tile_ts_h<SSIM, EDGE>(s1, s2, vt, acc);
+            // (no barrier here: see the centre samples in ssim_maps_tile_ts_h; a tile of another kind that follows stages behind a barrier of its own)
+            if (tx + 1 < tx1 && !is_interior(x0 + TW)) __syncthreads();
         } else {
             fetched = false;
-            ssim_maps_tile<false>(a, im1, im2, SSIM, EDGE, x0, y0, s1, s2, vt, acc);
-            __syncthreads();  // the generic tile reads s1 / s2 / vt in its last phase: they are rewritten by the next tile
+            const MapsGeom geom = {a.stride, w, h};
+            const MapsSums part = small ? ssim_maps_tile_small(geom, im1, im2, SSIM, EDGE, x0, y0, s1, s2, vt) : ssim_maps_tile_border<SSIM, EDGE>(geom, im1, im2, x0, y0, s1, s2, vt);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc[q] += part.v[q];
+            __syncthreads();  // these tiles read s1 / s2 / vt in their last phase: they are rewritten by the next tile
         }
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q)
         if ((q < 2 && SSIM) || (q >= 2 && EDGE)) acc[q] = wave_reduce_sum(acc[q]);
+    __syncthreads();
+    double(*red)[6] = reinterpret_cast<double(*)[6]>(vt);  // (the tiles are done with it)
     if ((tid & 63) == 0) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) red[tid >> 6][q] = acc[q];
@@ -1088,6 +1123,7 @@ __global__ __launch_bounds__(256, VSZIP_SSIM_TS_WPE) void ssim_maps_ts_kernel(co
         }
     }
 }
+
 
 struct FinalArgs {
     const double *partial;  // [pair][slot][tile][6]
@@ -1659,12 +1695,8 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
             }
 #endif
             const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * cnt);
-            // one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>), or the one generic kernel (VSZIP_SSIM_GENERIC_MAPS=1)
+            // one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>)
             auto launch_maps = [&]() {
-                if (ctx->opt.ssim_generic_maps) {
-                    hipLaunchKernelGGL(ssim_maps_kernel, mgrid, dim3(256), 0, st, ma);
-                    return;
-                }
                 for (int fl = 3; fl >= 1; --fl) {
                     MapsArgs mt = ma;
                     mt.nactive = 0;
