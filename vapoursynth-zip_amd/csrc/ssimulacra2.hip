@@ -1577,10 +1577,9 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     }
     VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab, bytes_tab + bytes_pyr, hipMemcpyHostToDevice, ctx->stream));
 
-    // the pipeline of pairs [p0, p0 + cnt) on `main_st`: pyramid pass, per-scale maps, final reduction
-    auto run_pairs = [&](int p0, int cnt, hipStream_t main_st, bool allow_side, hipEvent_t after_pyr) -> int {
+    // ---- the launches, by piece (pairs [p0, p0 + cnt) on stream st) ----
     // scales 0 + 1 + the scale-2 RGB: one pass over the source
-    {
+    auto launch_pyramid = [&](int p0, int cnt, hipStream_t st) {
         PyrArgs pa;
         pa.tab = pyr_dev + p0;
         pa.lut = lut_dev;
@@ -1602,64 +1601,38 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         const dim3 grid((w + 255) / 256, (h + 15) / 16, cnt);
         if (mode == PYR_YUV) {
             if (fmt->dtype == VSZIP_F32)
-                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<float>, grid, dim3(256), 0, main_st, pa, ya);
+                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<float>, grid, dim3(256), 0, st, pa, ya);
             else if (fmt->dtype == VSZIP_U8)
-                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<uint8_t>, grid, dim3(256), 0, main_st, pa, ya);
+                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<uint8_t>, grid, dim3(256), 0, st, pa, ya);
             else
-                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<uint16_t>, grid, dim3(256), 0, main_st, pa, ya);
+                hipLaunchKernelGGL(ssim_pyr_yuv_kernel<uint16_t>, grid, dim3(256), 0, st, pa, ya);
         } else if (mode == PYR_F32_LINEAR)
-            launch_pyr<float, PYR_F32_LINEAR>(gray, grid, main_st, pa);
+            launch_pyr<float, PYR_F32_LINEAR>(gray, grid, st, pa);
         else if (mode == PYR_F32_GAMMA)
-            launch_pyr<float, PYR_F32_GAMMA>(gray, grid, main_st, pa);
+            launch_pyr<float, PYR_F32_GAMMA>(gray, grid, st, pa);
         else if (fmt->dtype == VSZIP_U8)
-            launch_pyr<uint8_t, PYR_INT>(gray, grid, main_st, pa);
+            launch_pyr<uint8_t, PYR_INT>(gray, grid, st, pa);
         else
-            launch_pyr<uint16_t, PYR_INT>(gray, grid, main_st, pa);
-        if (after_pyr) VSZIP_HIP_CHECK(ctx, hipEventRecord(after_pyr, main_st));
-    }
-
-    FinalArgs fin;
-    fin.partial = partial + (size_t)p0 * 18 * tiles0 * 6;
-    // the averages go straight into the pinned host buffer (device-visible): no copy command at the end
-    VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&fin.avg), ctx->scalars_host, 0));
-    fin.avg += (size_t)p0 * 18 * 6;
-    fin.max_tiles = tiles0;
-    for (int i = 0; i < 18; ++i) {
-        fin.ntiles[i] = 0;
-        fin.one_per_pixels[i] = 0;
-    }
-    // Scales 2.. are a chain of small, launch-bound kernels (a sixteenth of the samples and less) that depends only on
-    // the pyramid pass: it runs on a second stream beside the two large maps launches instead of after them.
-    bool side = allow_side && kScales > 2 && !ctx->opt.ssim_one_stream;
-    if (side && !ctx->side_stream) {
-        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->side_stream = nullptr;
-            side = false;
-        }
-    }
-    if (side) {
-        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, main_st));
-        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-    }
-    for (int scale = 0; scale < kScales; ++scale) {
+            launch_pyr<uint16_t, PYR_INT>(gray, grid, st, pa);
+    };
+    // scales 2 ..: XYB of this scale + the next scale's RGB
+    auto launch_xyb_down = [&](int scale, int p0, int cnt, hipStream_t st) {
         const int cw = sw[scale], ch = sh[scale], nw = sw[scale + 1], nh = sh[scale + 1];
-        const bool on_side = side && scale >= 2;
-        hipStream_t st = on_side ? ctx->side_stream : main_st;
-        if (scale >= 2) {
-            XybArgs xa;
-            xa.tab = tab_dev + (size_t)scale * npairs + p0;
-            xa.stride = cw;
-            xa.w = cw;
-            xa.h = ch;
-            xa.nstride = nw;
-            xa.nw = nw;
-            xa.nh = nh;
-            xa.xstride = cw;
-            xa.k = kx;
-            hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, cnt), dim3(256), 0, st, xa);
-        }
+        XybArgs xa;
+        xa.tab = tab_dev + (size_t)scale * npairs + p0;
+        xa.stride = cw;
+        xa.w = cw;
+        xa.h = ch;
+        xa.nstride = nw;
+        xa.nw = nw;
+        xa.nh = nh;
+        xa.xstride = cw;
+        xa.k = kx;
+        hipLaunchKernelGGL(ssim_xyb_down_kernel, dim3((nw + 31) / 32, (nh + 7) / 8, cnt), dim3(256), 0, st, xa);
+    };
+    // the maps of one scale: one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>)
+    auto launch_maps = [&](int scale, int p0, int cnt, hipStream_t st, bool probe_it) {
+        const int cw = sw[scale], ch = sh[scale];
         MapsArgs ma;
         ma.tab = tab_dev + (size_t)scale * npairs + p0;
         ma.nactive = 0;
@@ -1671,6 +1644,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
             ma.flags[k] = (sk.ssim ? 0 : 1) | ((!sk.artifact || !sk.detail) ? 2 : 0);
             ma.slot[k] = scale * 3 + c;
         }
+        if (ma.nactive == 0) return;
         ma.stride = cw;
         ma.w = cw;
         ma.h = ch;
@@ -1678,92 +1652,121 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         ma.tiles_y = (ch + TH - 1) / TH;
         ma.partial = partial + (size_t)p0 * 18 * tiles0 * 6;
         ma.max_tiles = tiles0;
-        if (ma.nactive > 0) {
-            // tiles (along x) per block: small scales keep one (enough blocks to fill the chip); the large ones walk 4 with the next tile's inputs in flight,
-            // and 6 or 12 while that still leaves 4 096 blocks (one reduction and one set of partials per block: 4K, 16 pairs per call, interleaved A/B:
-            // 2 / 4 / 6 / 8 / 12 tiles 5.56 / 6.14 / 6.28 / 5.45 / 6.34 k pairs/s — eight loses for a reason not found, gpurun_out r4_ssim_tpb)
+        // tiles (along x) per block: small scales keep one (enough blocks to fill the chip); the large ones walk 4 with the next tile's inputs in flight,
+        // and 6 or 12 while that still leaves 4 096 blocks (one reduction and one set of partials per block)
 #ifdef VSZIP_SSIM_TPB
-            ma.tpb = ma.tiles_x >= 32 ? VSZIP_SSIM_TPB : 1;
+        ma.tpb = ma.tiles_x >= 32 ? VSZIP_SSIM_TPB : 1;
 #else
-            ma.tpb = 1;
-            if (ma.tiles_x >= 32) {
-                ma.tpb = 4;
-                for (int t : {6, 12}) {
-                    const long nb = (long)((ma.tiles_x + t - 1) / t) * ma.tiles_y * ma.nactive * cnt;
-                    if (nb >= 4096) ma.tpb = t;
-                }
+        ma.tpb = 1;
+        if (ma.tiles_x >= 32) {
+            ma.tpb = 4;
+            for (int t : {6, 12}) {
+                const long nb = (long)((ma.tiles_x + t - 1) / t) * ma.tiles_y * ma.nactive * cnt;
+                if (nb >= 4096) ma.tpb = t;
             }
+        }
 #endif
-            const dim3 mgrid((ma.tiles_x + ma.tpb - 1) / ma.tpb, ma.tiles_y, ma.nactive * cnt);
-            // one launch per term set of the scale's planes (ssim_maps_ts_kernel<SSIM, EDGE>)
-            auto launch_maps = [&]() {
-                for (int fl = 3; fl >= 1; --fl) {
-                    MapsArgs mt = ma;
-                    mt.nactive = 0;
-                    for (int k = 0; k < ma.nactive; ++k)
-                        if (ma.flags[k] == fl) {
-                            mt.plane[mt.nactive] = ma.plane[k];
-                            mt.flags[mt.nactive] = fl;
-                            mt.slot[mt.nactive] = ma.slot[k];
-                            ++mt.nactive;
-                        }
-                    if (mt.nactive == 0) continue;
-                    mt.gx = (int)mgrid.x;
-                    mt.gy = (int)mgrid.y;
-                    mt.nblk = mt.gx * mt.gy * mt.nactive * cnt;
-                    const dim3 g((unsigned)(((mt.nblk + 7) / 8) * 8));
-                    if (fl == 3)
-                        hipLaunchKernelGGL((ssim_maps_ts_kernel<true, true>), g, dim3(256), 0, st, mt);
-                    else if (fl == 1)
-                        hipLaunchKernelGGL((ssim_maps_ts_kernel<true, false>), g, dim3(256), 0, st, mt);
-                    else
-                        hipLaunchKernelGGL((ssim_maps_ts_kernel<false, true>), g, dim3(256), 0, st, mt);
+        const int gx = (ma.tiles_x + ma.tpb - 1) / ma.tpb, gy = ma.tiles_y;
+        if (probe_it && ctx->probe_on) vszip_probe_mark(ctx);  // (HIP events on the context's stream: other streams' launches are not probed)
+        for (int fl = 3; fl >= 1; --fl) {
+            MapsArgs mt = ma;
+            mt.nactive = 0;
+            for (int k = 0; k < ma.nactive; ++k)
+                if (ma.flags[k] == fl) {
+                    mt.plane[mt.nactive] = ma.plane[k];
+                    mt.flags[mt.nactive] = fl;
+                    mt.slot[mt.nactive] = ma.slot[k];
+                    ++mt.nactive;
                 }
-            };
-            if (!on_side && main_st == ctx->stream) {
-                vszip_probe_scope probe(ctx);  // (HIP events on the context's stream: other streams' launches are not probed)
-                launch_maps();
-            } else {
-                launch_maps();
-            }
+            if (mt.nactive == 0) continue;
+            mt.gx = gx;
+            mt.gy = gy;
+            mt.nblk = mt.gx * mt.gy * mt.nactive * cnt;
+            const dim3 g((unsigned)(((mt.nblk + 7) / 8) * 8));
+            if (fl == 3)
+                hipLaunchKernelGGL((ssim_maps_ts_kernel<true, true>), g, dim3(256), 0, st, mt);
+            else if (fl == 1)
+                hipLaunchKernelGGL((ssim_maps_ts_kernel<true, false>), g, dim3(256), 0, st, mt);
+            else
+                hipLaunchKernelGGL((ssim_maps_ts_kernel<false, true>), g, dim3(256), 0, st, mt);
         }
-        for (int k = 0; k < ma.nactive; ++k) {
-            fin.ntiles[ma.slot[k]] = ma.tiles_x * ma.tiles_y;
-            fin.one_per_pixels[ma.slot[k]] = 1.0 / (double)((uint32_t)cw * (uint32_t)ch);
-        }
-    }
-    if (side) {
-        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
-        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(main_st, ctx->side_join, 0));
-    }
-    hipLaunchKernelGGL(ssim_final_kernel, dim3(18, cnt), dim3(kFinThreads), 0, main_st, fin);
-    VSZIP_HIP_CHECK(ctx, hipGetLastError());
-    return VSZIP_OK;
+        if (probe_it && ctx->probe_on) vszip_probe_mark(ctx);
     };
-    // Two halves, staggered: the pyramid pass is HBM bound and the maps kernels are issue bound, so the second half's
-    // pyramid pass runs (on the second stream) beside the first half's maps instead of before them.
-    bool halves = npairs >= 4 && !ctx->opt.ssim_one_stream && !ctx->opt.ssim_no_halves;
-    if (halves && !ctx->side_stream) {
+    auto launch_final = [&](hipStream_t st) -> int {
+        FinalArgs fin;
+        fin.partial = partial;
+        // the averages go straight into the pinned host buffer (device-visible): no copy command at the end
+        VSZIP_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&fin.avg), ctx->scalars_host, 0));
+        fin.max_tiles = tiles0;
+        for (int i = 0; i < 18; ++i) {
+            fin.ntiles[i] = 0;
+            fin.one_per_pixels[i] = 0;
+        }
+        for (int scale = 0; scale < kScales; ++scale)
+            for (int c = 0; c < 3; ++c) {
+                if (skip_of(c, scale).all()) continue;
+                fin.ntiles[scale * 3 + c] = ((sw[scale] + TW - 1) / TW) * ((sh[scale] + TH - 1) / TH);
+                fin.one_per_pixels[scale * 3 + c] = 1.0 / (double)((uint32_t)sw[scale] * (uint32_t)sh[scale]);
+            }
+        hipLaunchKernelGGL(ssim_final_kernel, dim3(18, npairs), dim3(kFinThreads), 0, st, fin);
+        VSZIP_HIP_CHECK(ctx, hipGetLastError());
+        return VSZIP_OK;
+    };
+
+    // ---- the schedule ----
+    // The pyramid pass is HBM bound (311 MB a 4K pair), the maps kernels are issue bound: a call's pairs go in two HALVES on two streams, the second
+    // half's pyramid pass beside the first half's large maps scales. Scales 2 .. (a sixteenth of the samples and less, launch bound) run ONCE for all
+    // pairs, on the second stream, when both pyramid passes are done; then the final reduction.
+    // Measured and not kept (round 5, tools/ssim_ab.py, 4K, 16 pairs a call, one process): groups of 1 / 2 / 3 / 4 pairs alternating between the
+    // streams, so that a group's XYB planes (112 MB a pair) would be read back out of the Infinity Cache right after they were written - 5.9 / 6.4 / 6.9 /
+    // 6.9 k pairs/s against 6.95 k for the halves (smaller launches pay their ramps and tails eight times over; the maps kernels are not waiting for
+    // memory: with the tile fetch compiled out they run 3.5 % faster); a small first group (1 - 4 pairs, then halves of the rest) to shorten the
+    // only pyramid pass with nothing beside it - 6.93 / 6.93 / 6.77 / 6.74 k.
+    bool two = npairs >= 2 && kScales > 2 && !ctx->opt.ssim_one_stream;
+    if (two && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             ctx->side_stream = nullptr;
-            halves = false;
+            two = false;
         }
     }
-    if (halves) {
-        const int n1 = npairs / 2;
-        rc = run_pairs(0, n1, ctx->stream, false, ctx->side_fork);  // (the fork also orders the pointer-table upload before the second stream)
-        if (rc != VSZIP_OK) return rc;
-        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-        rc = run_pairs(n1, npairs - n1, ctx->side_stream, false, nullptr);
-        if (rc != VSZIP_OK) return rc;
-        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
-        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    if (!two) {
+        launch_pyramid(0, npairs, ctx->stream);
+        for (int scale = 0; scale < kScales; ++scale) {
+            if (scale >= 2) launch_xyb_down(scale, 0, npairs, ctx->stream);
+            launch_maps(scale, 0, npairs, ctx->stream, true);
+        }
     } else {
-        rc = run_pairs(0, npairs, ctx->stream, true, nullptr);
-        if (rc != VSZIP_OK) return rc;
+        hipStream_t st[2] = {ctx->stream, ctx->side_stream};
+        int sizes[2] = {npairs, 0}, ngroups = 1;
+        if (!ctx->opt.ssim_no_halves && npairs >= 4) {
+            sizes[0] = npairs / 2;
+            sizes[1] = npairs - sizes[0];
+            ngroups = 2;
+        }
+        for (int g = 0, p0 = 0; g < ngroups; p0 += sizes[g], ++g) {
+            const int cnt = sizes[g];
+            hipStream_t s_ = st[g & 1];
+            if (g == 1) VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(s_, ctx->side_fork, 0));  // (also orders the pointer-table upload before the second stream)
+            launch_pyramid(p0, cnt, s_);
+            if (g == 0) VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, s_));
+            launch_maps(0, p0, cnt, s_, s_ == ctx->stream);
+            launch_maps(1, p0, cnt, s_, s_ == ctx->stream);
+        }
+        if (ngroups == 1) VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[1], ctx->side_fork, 0));
+        // the small scales of every pair: the second stream, after the first stream's last pyramid pass (everything of its own is in stream order)
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, st[0]));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[1], ctx->side_join, 0));
+        for (int scale = 2; scale < kScales; ++scale) {
+            launch_xyb_down(scale, 0, npairs, st[1]);
+            launch_maps(scale, 0, npairs, st[1], false);
+        }
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, st[1]));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[0], ctx->side_join, 0));
     }
+    rc = launch_final(ctx->stream);
+    if (rc != VSZIP_OK) return rc;
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double(*avg)[18][6] = reinterpret_cast<const double(*)[18][6]>(ctx->scalars_host);
     for (int pair = 0; pair < npairs; ++pair) scores[pair] = score_of(avg[pair]);
