@@ -1,6 +1,6 @@
 // Instruction issue rates on gfx950: cycles per wave-instruction per SIMD with 1, 2 and 4 waves a SIMD, 128 instructions (8 independent
 // registers x 16) per loop iteration. hipcc --offload-arch=gfx950 -O3 -o tools/ab/valu_rate tools/ubench/valu_rate.hip ; run on the GPU box
-// (profiles/r04_valu_rates.txt). Cycles are at the nominal clock the runtime reports; the chip runs below it under load.
+// (profiles/r04_valu_rates.txt, r05_valu_rates.txt). Cycles are at the nominal clock the runtime reports; the chip runs below it under load.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
@@ -64,6 +64,22 @@
 #define I_PKADD(n) "v_pk_add_f32 " n ", %8, " n "\n"
 #define I_PKFMA(n) "v_pk_fma_f32 " n ", %8, " n ", " n "\n"
 #define I_PKMUL(n) "v_pk_mul_f32 " n ", %8, " n "\n"
+#define I_PKADDU16(n) "v_pk_add_u16 " n ", %8, " n "\n"
+#define I_PKSUBU16(n) "v_pk_sub_u16 " n ", " n ", %8\n"
+#define I_PKMADU16(n) "v_pk_mad_u16 " n ", %8, " n ", " n "\n"
+#define I_PKMULLOU16(n) "v_pk_mul_lo_u16 " n ", %8, " n "\n"
+#define I_PKLSHR16(n) "v_pk_lshrrev_b16 " n ", 3, " n "\n"
+#define I_PERM(n) "v_perm_b32 " n ", %8, " n ", %9\n"
+#define I_SDWA_B0(n) "v_add_u32_sdwa " n ", %8, " n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_SDWA_MOV(n) "v_mov_b32_sdwa " n ", " n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n"
+#define I_BFE(n) "v_bfe_u32 " n ", " n ", 8, 8\n"
+#define I_MUL24(n) "v_mul_u32_u24_e32 " n ", %8, " n "\n"
+#define I_MAD24(n) "v_mad_u32_u24 " n ", %8, " n ", " n "\n"
+#define I_MULHI(n) "v_mul_hi_u32 " n ", %8, " n "\n"
+#define I_LSHR(n) "v_lshrrev_b32_e32 " n ", 3, " n "\n"
+#define I_ADD3(n) "v_add3_u32 " n ", %8, " n ", " n "\n"
+#define I_SUBU(n) "v_sub_u32_e32 " n ", " n ", %8\n"
+#define I_ADD_DPP_U(n) "v_add_u32_dpp " n ", %8, " n " row_shr:1 row_mask:0xf bank_mask:0xf\n"
 #define I_ADD64(n) "v_add_f64 " n ", %8, " n "\n"
 #define I_FMA64(n) "v_fma_f64 " n ", %8, " n ", " n "\n"
 
@@ -95,6 +111,22 @@ KERNEL(k_add_sdwa, I_ADD_SDWA)
 KERNEL(k_readlane, I_READLANE)
 KERNEL(k_sadd, I_SADD)
 KERNEL(k_snop, I_SNOP)
+KERNEL(k_pk_add_u16, I_PKADDU16)
+KERNEL(k_pk_sub_u16, I_PKSUBU16)
+KERNEL(k_pk_mad_u16, I_PKMADU16)
+KERNEL(k_pk_mul_lo_u16, I_PKMULLOU16)
+KERNEL(k_pk_lshr_b16, I_PKLSHR16)
+KERNEL(k_perm_b32, I_PERM)
+KERNEL(k_add_u32_sdwa_byte, I_SDWA_B0)
+KERNEL(k_mov_sdwa_byte, I_SDWA_MOV)
+KERNEL(k_bfe_u32, I_BFE)
+KERNEL(k_mul_u32_u24, I_MUL24)
+KERNEL(k_mad_u32_u24, I_MAD24)
+KERNEL(k_mul_hi_u32, I_MULHI)
+KERNEL(k_lshrrev_b32, I_LSHR)
+KERNEL(k_add3_u32, I_ADD3)
+KERNEL(k_sub_u32, I_SUBU)
+KERNEL(k_add_u32_dpp, I_ADD_DPP_U)
 KERNELD(k_pkadd, I_PKADD)
 KERNELD(k_pkfma, I_PKFMA)
 KERNELD(k_pkmul, I_PKMUL)
@@ -136,6 +168,8 @@ int main() {
     RUN(k_lshlor); RUN(k_bfi); RUN(k_mullo); RUN(k_cvt); RUN(k_rcp); RUN(k_cnd_vcc); RUN(k_cnd_s); RUN(k_cmp_vcc); RUN(k_cmp_s);
     run("k_cmp_cnd (cmp,add,add,cnd)", k_cmp_cnd, out, clock_khz, cus, 4);
     RUN(k_dpp_wshr); RUN(k_dpp_rshr); RUN(k_add_dpp); RUN(k_add_sdwa); RUN(k_readlane); RUN(k_sadd); RUN(k_snop);
+    RUN(k_pk_add_u16); RUN(k_pk_sub_u16); RUN(k_pk_mad_u16); RUN(k_pk_mul_lo_u16); RUN(k_pk_lshr_b16); RUN(k_perm_b32); RUN(k_add_u32_sdwa_byte); RUN(k_mov_sdwa_byte);
+    RUN(k_bfe_u32); RUN(k_mul_u32_u24); RUN(k_mad_u32_u24); RUN(k_mul_hi_u32); RUN(k_lshrrev_b32); RUN(k_add3_u32); RUN(k_sub_u32); RUN(k_add_u32_dpp);
     RUN(k_pkadd); RUN(k_pkfma); RUN(k_pkmul); RUN(k_add64); RUN(k_fma64);
     return 0;
 }
