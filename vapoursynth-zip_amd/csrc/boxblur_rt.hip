@@ -1478,9 +1478,16 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
             cur[H + w + lane] = cur[H + max(w - 1 - lane, 0)];
         }
         vszip_wave_fence();
-        uint32_t e0 = cur[H + min(R, w - 1)];
-#pragma unroll
-        for (int i = 0; i < R; ++i) e0 += 2u * cur[H + min(i, w - 1)];
+        // E_0 = s[R] + 2 * sum_{i<R} s[i]: lane i reads sample i, one wave scan adds them (read one after another by every lane, as first written,
+        // these R + 1 dependent LDS round trips and their address arithmetic were 100 of a pass's ~530 instructions - half of a chroma row's).
+        // Measured and not kept: 16 outputs a lane and step instead of 8 (the halo groups unpacked and the first window summed once per 16) -
+        // 323 us against 263 for 5 passes of r = 13 on 32 x 1080p (two-way conflicts of the 16-byte reads at a 32-byte lane stride, 56 unpacked samples live).
+        uint32_t e0;
+        {
+            uint32_t x = lane <= R ? (uint32_t)cur[H + min(lane, w - 1)] : 0u;
+            x = lane < R ? 2u * x : x;
+            e0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(x), 63);
+        }
         const uint32_t kr = 32768u + (uint32_t)(((uint64_t)e0 * invlo) >> 16);
         const bool last = pass == npass - 1;
         for (int v = lane; v < nv; v += 64) {
