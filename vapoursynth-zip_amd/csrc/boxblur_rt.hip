@@ -2311,9 +2311,20 @@ int run_rt(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, int hradius, 
                 if (rem >= 2) span = rem <= kFcMaxPass ? rem : (rem - kFcMaxPass == 1 ? kFcMaxPass - 1 : kFcMaxPass);
             } else if constexpr (sizeof(T) <= 2) {
                 if (p == 0 && hb && hpasses >= 2) span = hpasses;
-                if (vertical) {  // what is left of the vertical passes, in chains of up to kFcMaxPass stages
+                if (vertical) {
+                    // What is left of the vertical passes, in chains of nearly equal length. A chain of P stages costs every row band P (3 R + 2) rows of
+                    // warm-up and drain and P (2 R + 3) ring rows of LDS, so short planes take shorter chains and pay another trip through memory instead:
+                    // at most a quarter of the shortest plane's rows may be warm-up (r = 13 on 1080p 4:2:0, 540-row chroma: 5 passes as 3 + 2 - 292 us
+                    // against 343 for one chain of 5 on 32 frames, 4 as 2 + 2 - 218 against 234; 4K keeps its chain of 5: 246 against 289;
+                    // tools/rt_pass_scaling.py)
                     const int rem = total - p;
-                    if (rem >= 2) span = rem <= kFcMaxPass ? rem : (rem - kFcMaxPass == 1 ? kFcMaxPass - 1 : kFcMaxPass);
+                    int minh = 1 << 30;
+                    for (int i = 0; i < ng; ++i) minh = std::min(minh, cur[i].h);
+                    const int pmax = std::max(2, std::min(kFcMaxPass, minh / (4 * (3 * vradius + 2))));
+                    if (rem >= 2) {
+                        const int nchains = (rem + pmax - 1) / pmax;
+                        span = (rem + nchains - 1) / nchains;
+                    }
                 }
             }
             const bool last = p + span - 1 == total - 1;
