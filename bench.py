@@ -933,6 +933,34 @@ def bind_to_gpu_numa(local_rank: int):
         return None
 
 
+def max_over_ranks(dt: float, use_dist: bool, coll_dev=None) -> float:
+    """the contract's timing rule: every rank's wall time of the timed region, MAX-reduced (RCCL on the GPUs, gloo in the CPU tests)"""
+    if not use_dist:
+        return dt
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_value(units_per_rank_per_step: int, steps: int, world: int, max_dt: float) -> float:
+    """`value` at N ranks: the units ALL ranks processed (weak scaling: the same work on every rank) divided by the slowest rank's time"""
+    return world * units_per_rank_per_step * steps / max_dt
+
+
+def gather_rank_records(rec: dict, use_dist: bool) -> list:
+    """every rank's small record (device, NUMA node, arena, launch time) on rank 0, for the sidecar"""
+    if not use_dist:
+        return [rec]
+    import torch.distributed as dist
+
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, rec)
+    return out
+
+
 def xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev, frames_per_rank=8):
     """The one real exchange of the design: XPSNR's per-clip accumulators {sum_wdist[3], sum_xpsnr[3], n}
     (src/vapoursynth/xpsnr.zig:89-96) from actual vszip_xpsnr_wsse_batch output on each rank's frames
@@ -1200,12 +1228,10 @@ def main() -> int:
 
     timed = Timed(dev, barrier, prewarm_s=0.3)
 
-    def max_over_ranks(dt):
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev or "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-        return dt
+    _max_over_ranks = max_over_ranks
+
+    def max_over_ranks(dt):  # (shadows the module's function inside main: the legs take a one-argument callable)
+        return _max_over_ranks(dt, use_dist, coll_dev)
 
     def reduce_scalars(v):
         return vszip_amd.cluster.allreduce_clip_scalars(v, device=coll_dev)
@@ -1232,7 +1258,7 @@ def main() -> int:
         group_s = region_ms * 1e-3 / launches                   # ring kernel + launch gaps
         out = {
             "metric": "frames/sec at 4K YUV420P16: Bilateral, BoxBlur, SSIMULACRA2 on 1/2/4/8 MI355X",
-            "value": world * F * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": whole_job_value(F, a.steps, world, dt), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "rccl_ranks": rccl_ranks,
@@ -1256,6 +1282,15 @@ def main() -> int:
         out["config"]["arena_probe_TBps"] = (ar.get("probe_bytes_per_second") or 0) / 1e12
         out["config"]["arena_build_ms"] = ar.get("build_ms")
         out["config"]["placement_seconds"] = pl_info.get("alloc_seconds")
+        out["config"]["value_is"] = "frames of all ranks (the same batch on every rank) / the slowest rank's time of the timed region"
+        # every rank's device, NUMA node, arena and launch time (sidecar): one process per GPU, local_rank == device index
+        assert share_gpu or local_rank == torch.cuda.current_device(), (local_rank, torch.cuda.current_device())
+        ranks = gather_rank_records({"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "numa_node": numa_node, "pcie_path": pcie_path(local_rank),
+                                     "arena": pl_info.get("arena"), "alloc_seconds": pl_info.get("alloc_seconds"), "avg_launch_us": avg_s * 1e6,
+                                     "frac": achieved / HBM_PEAK_GBS}, use_dist)
+        if rank == 0:
+            out["config"]["ranks"] = ranks
+            out["config"]["slowest_rank_frac"] = min(r["frac"] for r in ranks)
         out["roofline"]["traffic_source"] = ("replayed from the committed PMC passes of this command (profiles/r*_boxblur_pmc.json), not measured in this run"
                                              if out["roofline"]["traffic"] is not None else None)
         if rank == 0:
