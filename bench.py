@@ -933,7 +933,7 @@ def bind_to_gpu_numa(local_rank: int):
         return None
 
 
-def max_over_ranks(dt: float, use_dist: bool, coll_dev=None) -> float:
+def ranks_max(dt: float, use_dist: bool, coll_dev=None) -> float:
     """the contract's timing rule: every rank's wall time of the timed region, MAX-reduced (RCCL on the GPUs, gloo in the CPU tests)"""
     if not use_dist:
         return dt
@@ -1228,10 +1228,8 @@ def main() -> int:
 
     timed = Timed(dev, barrier, prewarm_s=0.3)
 
-    _max_over_ranks = max_over_ranks
-
-    def max_over_ranks(dt):  # (shadows the module's function inside main: the legs take a one-argument callable)
-        return _max_over_ranks(dt, use_dist, coll_dev)
+    def max_over_ranks(dt):  # (the legs take a one-argument callable)
+        return ranks_max(dt, use_dist, coll_dev)
 
     def reduce_scalars(v):
         return vszip_amd.cluster.allreduce_clip_scalars(v, device=coll_dev)

@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_dir):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
-    res["max_dt"] = bench.max_over_ranks(0.125 * (rank + 1), True, None)  # the slowest rank took 0.5 s
+    res["max_dt"] = bench.ranks_max(0.125 * (rank + 1), True, None)  # the slowest rank took 0.5 s
     res["value"] = bench.whole_job_value(64, 20, world, res["max_dt"])
     recs = bench.gather_rank_records({"rank": rank, "local_rank": rank, "device": rank, "frac": 0.7 - 0.01 * rank}, True)
     res["records"] = recs
