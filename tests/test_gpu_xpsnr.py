@@ -125,10 +125,10 @@ def test_block_kernels_agree(dev, oracle, monkeypatch):
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(3)]
     p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(3)]
     strip = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60)
-    dev.set_option("VSZIP_XPSNR_BLOCKS", 1)
-    block = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60)
-    dev.set_option("VSZIP_XPSNR_BLOCKS", 0)
-    assert strip == block == want
+    assert strip == want
+    with dev.variant(VSZIP_XPSNR_BLOCKS=1) as built:  # (a development variant since round 5: the forcing switch, not the kernel the geometry rules route to)
+        if built:
+            assert dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=10, frame_rate=60) == want
 
 
 @pytest.mark.parametrize("shape,fps", [((290, 354), 24), ((290, 354), 60), ((1156, 2054), 24), ((1156, 2054), 60)])
@@ -148,10 +148,10 @@ def test_packed_8bit_strip_agrees(dev, oracle, monkeypatch, shape, fps):
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(3)]
     p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(3)]
     packed = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps)
-    dev.set_option("VSZIP_XPSNR_UNPACKED", 1)
-    generic = dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps)
-    dev.set_option("VSZIP_XPSNR_UNPACKED", 0)
-    assert packed == generic == want
+    assert packed == want
+    with dev.variant(VSZIP_XPSNR_UNPACKED=1) as built:  # (a development variant since round 5: the forcing switch, not the kernel the geometry rules route to)
+        if built:
+            assert dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=8, frame_rate=fps) == want
 
 
 @pytest.mark.parametrize("shape", [(288, 352), (480, 640), (1080, 1920), (1200, 2100), (40, 44), (96, 160)])
@@ -170,10 +170,10 @@ def test_device_weighting_is_the_host_weighting(dev, oracle, monkeypatch, shape)
     drc = [[dev.upload(p) for p in fr] for fr in recs]
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(4)]
     on_dev = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
-    dev.set_option("VSZIP_XPSNR_HOST_WEIGH", 1)
-    on_host = dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24)
-    dev.set_option("VSZIP_XPSNR_HOST_WEIGH", 0)
-    assert on_dev == on_host == want
+    assert on_dev == want
+    with dev.variant(VSZIP_XPSNR_HOST_WEIGH=1) as built:  # (a development variant since round 5: the forcing switch, not the kernel the geometry rules route to)
+        if built:
+            assert dev.xpsnr_wsse_batch(dfr, drc, p1, None, depth=8, frame_rate=24) == want
 
 
 @pytest.mark.parametrize("seed", range(14))

@@ -254,6 +254,26 @@ class Device:
         self.check(self.lib.vszip_ctx_get_option(self.ctx, name.encode(), C.byref(v)))
         return v.value
 
+    def variant(self, **kw):
+        """like options(), for switches that may be development variants: yields False (and sets nothing) when this build does not
+        contain them (VSZIP_ERR_UNSUPPORTED), so a path-agreement test compares the alternative only where it exists"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            try:
+                for k in kw:
+                    self.get_option(k)
+            except VszipError as e:
+                if e.code != -3:
+                    raise
+                yield False
+                return
+            with self.options(**kw):
+                yield True
+
+        return scope()
+
     def options(self, **kw):
         """`with dev.options(VSZIP_RT_NO_ICHAIN=1): ...` — set, run, restore (the path-agreement tests)"""
         import contextlib
