@@ -317,8 +317,7 @@ class Arena:
 def placed_batch(dev, host_planes, dtype, args, seed, tries=None, probe_args=None):
     """`host_planes` (a list of 2-D arrays, one per plane of the batch) in a source arena, a destination arena of the
     same geometry, and the BoxBlur launch `args` on them. Both arenas are plain vszip_dev_alloc requests: what a caller gets.
-    (Rounds 2-4 searched for a fast placement here, then inside the allocator; since round 5 the allocator builds large
-    arenas from physical pieces that lie far apart, which is what the fast placements had in common - include/vszip_hip.h.)
+    (Rounds 2-3 searched for a fast placement here; since round 4 the allocator does, for every caller - include/vszip_hip.h.)
     Returns (step, keep, info)."""
     shapes = [p.shape for p in host_planes]
     isz = np.dtype(dtype).itemsize
@@ -1272,13 +1271,11 @@ def main() -> int:
         # How the two arenas were allocated, as SCALARS (the driver's record keeps scalar config fields only)
         pl_info = keep[2]
         ar = pl_info.get("arena", {})
-        out["config"]["placement_policy"] = ("vszip_dev_alloc: large requests are assembled from separate physical pieces, the fastest of a few candidates kept (include/vszip_hip.h)"
-                                             if ar.get("pieces") else "plain hipMalloc")
-        out["config"]["arena_pieces"] = ar.get("pieces")
-        out["config"]["arena_piece_MiB"] = (ar.get("piece_bytes") or 0) / (1 << 20)
+        out["config"]["placement_policy"] = ("vszip_dev_alloc: the fastest of up to 24 probed candidate allocations, nothing kept (include/vszip_hip.h)"
+                                             if ar.get("candidates") else "plain hipMalloc")
         out["config"]["arena_candidates"] = ar.get("candidates")
         out["config"]["arena_probe_TBps"] = (ar.get("probe_bytes_per_second") or 0) / 1e12
-        out["config"]["arena_build_ms"] = ar.get("build_ms")
+        out["config"]["arena_search_ms"] = ar.get("search_ms")
         out["config"]["placement_seconds"] = pl_info.get("alloc_seconds")
         out["config"]["value_is"] = "frames of all ranks (the same batch on every rank) / the slowest rank's time of the timed region"
         # every rank's device, NUMA node, arena and launch time (sidecar): one process per GPU, local_rank == device index

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VSZIP_ABI_VERSION 4 /* 4 (round 5): vszip_dev_alloc stripes large requests (below); vszip_dev_arena_info added; vszip_dev_trim, vszip_dev_placement_info and
+#define VSZIP_ABI_VERSION 4 /* 4 (round 5): vszip_dev_alloc searches a bounded number of candidates and keeps nothing (below); vszip_dev_arena_info added; vszip_dev_trim, vszip_dev_placement_info and
                                vszip_dev_alloc_probed removed (nothing is searched for or parked any more); 3 (round 4): vszip_ctx_set_option / _get_option, vszip_dev_probe_region,
                                vszip_plane_average_async, vszip_plane_minmax_async added; 2 (round 3): vszip_ssim_source grew (YUV sources); entry points added since 1:
                                vszip_chain_run, vszip_ssimulacra2_src, vszip_to_rgbs_linear, vszip_probe_read_each, vszip_resample_table */
@@ -73,20 +73,17 @@ int vszip_abi_version(void);
 /* ---- device memory + staging (replaces nothing: the reference is host-only) */
 /* vszip_dev_alloc. Requests of VSZIP_PLACEMENT_MIN_MIB (256) or more are PLACED: kernels with thousands of concurrent row
  * streams (the BoxBlur ring kernels) run 15-20 % slower with their destination planes in most physical memory than in some,
- * a stable property of the allocation (profiles/r05_placement.md). An arena assembled from separate physical
- * pieces is in the fast class far more often than one contiguous block, so such a request is built with the virtual-memory
- * API - pieces of VSZIP_PLACEMENT_PIECE_MIB (128) from hipMemCreate, mapped side by side into one range - and classified with a
- * 2 ms copy in the ring kernels' access shape; up to VSZIP_PLACEMENT_TRIES (12) candidates are looked at (all held meanwhile,
- * never more than a quarter of what hipMemGetInfo reports free), the search ends with the first one of the best class, else the
- * fastest is kept, and every other candidate is released before the call returns. Nothing is cached or parked and there is no
- * per-context state. The result is ordinary device memory for kernels and for this library's copies; the RUNTIME's own
- * hipMemcpy2D* accept extents up to one piece only (vszip_copy_*_2d split by rows). vszip_dev_free unmaps and releases at once
- * (after a device synchronise, like hipFree). VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc / hipFree. A runtime
- * without virtual memory management falls back to hipMalloc. */
+ * a stable property of the allocation that nothing user space can see predicts (profiles/r05_placement.md). Up
+ * to VSZIP_PLACEMENT_TRIES (24) candidate allocations of the requested size are made (all held meanwhile, so each lies
+ * elsewhere; never more than a quarter of what hipMemGetInfo reports free), each classified with a 2 ms copy in the ring
+ * kernels' access shape; the search ends with the first candidate of the best class, else the fastest is kept, and every other
+ * candidate is freed before the call returns (a few milliseconds per candidate; more where the driver clears memory that was
+ * used before). Nothing is cached or parked and there is no per-context state. vszip_dev_free is hipFree.
+ * VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc. */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
-/* What `dptr` (as returned by vszip_dev_alloc) is made of; any pointer may be NULL. *pieces = 0: a plain allocation. *candidates: how
- * many arenas the search built, *probe_bytes_per_second: the classification copy's rate on the one kept (0: one candidate, not probed). */
-int vszip_dev_arena_info(vszip_ctx *ctx, const void *dptr, size_t *pieces, size_t *piece_bytes, int *candidates, double *probe_bytes_per_second, double *build_ms);
+/* What the search did for `dptr` (as returned by vszip_dev_alloc); any pointer may be NULL. *candidates = 0: a plain allocation;
+ * *probe_bytes_per_second: the classification copy's rate on the one kept (0: one candidate, not probed). */
+int vszip_dev_arena_info(vszip_ctx *ctx, const void *dptr, int *candidates, double *probe_bytes_per_second, double *search_ms);
 /* Diagnostic: a copy in the ring kernels' access shape on a caller's region (overwrites its contents): bytes / s. `from` == NULL: tiles
  * are read and written inside the region; else they are read from `from` (another region of at least `bytes`, not modified). */
 int vszip_dev_probe_region(vszip_ctx *ctx, void *dptr, size_t bytes, const void *from, double *bytes_per_second);

@@ -24,8 +24,8 @@ def main():
     keepers = []
     print("mode piece_MiB    tries  alloc_s  launch_us  frac   (u16 r=13, 64 x 4K)")
     for rnd in range(rounds):
-        for mode, piece, pool in ((0, 128, 1), (1, 128, 1), (1, 128, 6), (1, 64, 6), (1, 256, 6), (1, 128, 12)):
-            with dev.options(VSZIP_PLACEMENT=mode, VSZIP_PLACEMENT_PIECE_MIB=piece, VSZIP_PLACEMENT_TRIES=pool):
+        for mode, piece, pool in ((0, 0, 1), (1, 0, 1), (1, 0, 8), (1, 0, 16), (1, 0, 32)):
+            with dev.options(VSZIP_PLACEMENT=mode, VSZIP_PLACEMENT_TRIES=pool):
                 step, keep = bench.setup_boxblur(dev, 0, F, 13)
             _, _, dom, n = timed.run(step, 200, 5)
             us = dom * 1e3 / n

@@ -79,7 +79,7 @@ SYMBOLS = {
     "vszip_ctx_abort": (_i, [_vp]),
     "vszip_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "vszip_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
-    "vszip_dev_arena_info": (_i, [_vp, _vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vszip_dev_arena_info": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vszip_dev_probe_region": (_i, [_vp, _vp, _sz, _vp, C.POINTER(C.c_double)]),
     "vszip_last_error": (C.c_char_p, [_vp]),
     "vszip_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -292,10 +292,10 @@ class Device:
         return scope()
 
     def arena_info(self, ptr: int) -> dict:
-        """vszip_dev_arena_info: what a vszip_dev_alloc pointer is made of (pieces = 0: a plain allocation)"""
-        n, pb, nc, rate, ms = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_double(), C.c_double()
-        self.check(self.lib.vszip_dev_arena_info(self.ctx, C.c_void_p(ptr), C.byref(n), C.byref(pb), C.byref(nc), C.byref(rate), C.byref(ms)))
-        return {"pieces": n.value, "piece_bytes": pb.value, "candidates": nc.value, "probe_bytes_per_second": rate.value, "build_ms": ms.value}
+        """vszip_dev_arena_info: what the placement search did for a vszip_dev_alloc pointer (candidates = 0: a plain allocation)"""
+        nc, rate, ms = C.c_int(), C.c_double(), C.c_double()
+        self.check(self.lib.vszip_dev_arena_info(self.ctx, C.c_void_p(ptr), C.byref(nc), C.byref(rate), C.byref(ms)))
+        return {"candidates": nc.value, "probe_bytes_per_second": rate.value, "search_ms": ms.value}
 
     def probe_region(self, ptr: int, nbytes: int, src: int = 0) -> float:
         bps = C.c_double()

@@ -251,207 +251,94 @@ VSZIP_EXPORT int vszip_ctx_set_staging(vszip_ctx *ctx, int mode) {
 
 VSZIP_EXPORT const char *vszip_last_error(vszip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-// ---- striped, probed arenas ----------------------------------------------------------------------------------
+// ---- placed allocations -------------------------------------------------------------------------------------------
 // WHERE a resident batch lies in VRAM decides how fast kernels with thousands of concurrent row streams run on it: the
-// BoxBlur ring kernel's 64-frame 4K launch takes 545-570 us with its DESTINATION planes in some memory and 600-680 us in
+// BoxBlur ring kernel's 64-frame 4K launch takes 545-585 us with its DESTINATION planes in some memory and 600-690 us in
 // most, in three classes - a property of the physical memory behind the destination, stable for the life of the
-// allocation, the same for every source arena (profiles/r03_placement.md, profiles/r05_placement.md). Round 5's finding:
-// an arena assembled from separate physical pieces (hipMemCreate, mapped side by side with hipMemMap) is in the fast
-// class far more often than one contiguous block (first arena of a process: 13 of 16 against 4 of 16), costs a
-// millisecond to build, and can be given back piece by piece - but no way of choosing the pieces makes it certain. So a
-// request of VSZIP_PLACEMENT_MIN_MIB or more is served like this: up to VSZIP_PLACEMENT_TRIES candidate arenas are
-// built from pieces of VSZIP_PLACEMENT_PIECE_MIB, each classified by placement_probe_kernel (the ring kernel's access
-// shape without its arithmetic, 2 ms); the search ends with the first candidate of the best class, else the fastest
-// is kept. Everything else goes back to the driver before the call returns: nothing is parked, there is no per-context
-// state, and the candidates held at once never exceed a quarter of what hipMemGetInfo reports free.
-// vszip_dev_free unmaps and releases. The registry is process-wide: any context may free any arena.
+// allocation, nearly independent of the source arena (profiles/r03_placement.md, r05_placement.md). Nothing user space
+// can see or request predicts it, but a 2 ms copy in the ring kernel's access shape (placement_probe_kernel) measures it.
+// So a request of VSZIP_PLACEMENT_MIN_MIB or more is served from a short search: up to VSZIP_PLACEMENT_TRIES candidate
+// allocations of the requested size (all held meanwhile, so each lies elsewhere; never more than a quarter of what
+// hipMemGetInfo reports free), each classified; the search ends with the first candidate of the best class, else the
+// fastest is kept, and every other candidate is freed before the call returns. Nothing is parked, there is no
+// per-context state and vszip_dev_free is hipFree. Round 4's version of this walked up to 64 GiB for up to 3 s, parked
+// 24 GiB of fast regions per context and gave up for good after one unlucky walk; round 5 also tried to BUILD
+// fast arenas from hipMemCreate pieces instead of searching for them - more often fast than a plain block, never
+// reliably, mispredicted by the probe, and at the price of two defects of this runtime's virtual-memory calls
+// (profiles/r05_placement.md) - and kept plain allocations.
 namespace {
 
-struct StripedArena {
-    size_t bytes = 0, piece = 0;
-    double build_ms = 0.0, probe_bytes_per_s = 0.0;
-    int device = 0, candidates = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
+struct PlacedInfo {
+    int candidates;
+    double probe_bytes_per_s, build_ms;
 };
-std::mutex &striped_mu() {
+std::mutex &placed_mu() {
     static std::mutex *m = new std::mutex();
     return *m;
 }
-std::map<char *, StripedArena> &striped_map() {  // keyed by the arena's first byte
-    static auto *m = new std::map<char *, StripedArena>();
+std::map<void *, PlacedInfo> &placed_map() {  // process-wide: what vszip_dev_arena_info reports (any context may free any allocation)
+    static auto *m = new std::map<void *, PlacedInfo>();
     return *m;
 }
-std::atomic<int> g_striped_count{0};
-
-// Reserved virtual ranges are never given back to the runtime: hipMemAddressFree corrupts the heap of this ROCm's libamdhip64 after a few
-// reserve / map / unmap / free cycles ("corrupted double-linked list" inside a later hipMemCreate; tools/alloc_crash_repro.py with each of the
-// three release calls left out in turn). A range that is no longer mapped costs address space only, and the next arena of its size takes it over.
-std::vector<std::pair<void *, size_t>> &va_idle() {
-    static auto *v = new std::vector<std::pair<void *, size_t>>();
-    return *v;
-}
-void *va_take(size_t bytes) {
-    {
-        std::lock_guard<std::mutex> lk(striped_mu());
-        auto &v = va_idle();
-        for (size_t i = 0; i < v.size(); ++i)
-            if (v[i].second == bytes) {
-                void *p = v[i].first;
-                v.erase(v.begin() + i);
-                return p;
-            }
-    }
-    void *va = nullptr;
-    if (hipMemAddressReserve(&va, bytes, (size_t)2 << 20, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    return va;
-}
-void va_give(void *va, size_t bytes) {
-    std::lock_guard<std::mutex> lk(striped_mu());
-    va_idle().emplace_back(va, bytes);
-}
-
-void striped_release(void *va, StripedArena &a, size_t mapped_pieces) {
-    for (size_t i = 0; i < mapped_pieces; ++i) (void)hipMemUnmap(static_cast<char *>(va) + i * a.piece, a.piece);  // (one mapping per call)
-    for (auto h : a.handles) (void)hipMemRelease(h);
-    a.handles.clear();
-    if (va) va_give(va, a.bytes);
-}
+std::atomic<int> g_placed_count{0};
 
 double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from);
-
-// one candidate: n pieces created back to back and mapped in order. VSZIP_ERR_UNSUPPORTED: no virtual memory management here.
-int striped_build(vszip_ctx *ctx, size_t n, size_t piece, StripedArena *out, void **out_va) {
-    StripedArena a;
-    a.device = ctx->device;
-    a.piece = piece;
-    a.bytes = n * piece;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->device;
-    void *va = va_take(a.bytes);
-    if (!va) return VSZIP_ERR_UNSUPPORTED;
-    for (size_t i = 0; i < n; ++i) {
-        hipMemGenericAllocationHandle_t h;
-        const hipError_t e = hipMemCreate(&h, piece, &prop, 0);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            striped_release(va, a, i);
-            return i == 0 && e != hipErrorOutOfMemory ? VSZIP_ERR_UNSUPPORTED : VSZIP_ERR_NOMEM;
-        }
-        a.handles.push_back(h);
-        if (hipMemMap(static_cast<char *>(va) + i * piece, piece, 0, h, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            striped_release(va, a, i);
-            return VSZIP_ERR_HIP;
-        }
-    }
-    hipMemAccessDesc acc = {};
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = ctx->device;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(va, a.bytes, &acc, 1) != hipSuccess) {
-        (void)hipGetLastError();
-        striped_release(va, a, n);
-        return VSZIP_ERR_HIP;
-    }
-    *out = std::move(a);
-    *out_va = va;
-    return VSZIP_OK;
-}
 
 // placement_probe_kernel's rate on the devices seen: 5.55-5.9 TB/s <-> the real launch at 560-585 us with its destination there (0.68-0.71),
 // 5.2-5.35 TB/s <-> 594-608 us, 4.6-5.1 TB/s <-> 630-695 us (profiles/r04_placement_probe_calibration.txt). Used ONLY to end the search early:
 // on a device that never reaches it (capped, busy, partitioned) the search looks at all its candidates and keeps the fastest.
 constexpr double kBestBytesPerSec = 5.55e12;
 
-int striped_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
+int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     const auto t_start = std::chrono::steady_clock::now();
-    constexpr size_t kMiB = (size_t)1 << 20;
-    // piece size: whole 2 MiB, at least 16 MiB (the runtime's 2-D copies accept extents up to the size of ONE mapped piece; copy2d splits by rows beyond that)
-    const size_t piece = (size_t)std::max(16, ctx->opt.placement_piece_mib) / 2 * 2 * kMiB;
-    const size_t n = (bytes + piece - 1) / piece, total = n * piece;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();
-        free_b = total;
+        free_b = bytes;
     }
-    if (free_b < total) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "vszip_dev_alloc(%zu): %zu bytes of device memory free", bytes, free_b);
-    const int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 4 / total));
+    const int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 4 / std::max<size_t>(bytes, 1)));
     if (tries > 1) VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<std::pair<StripedArena, void *>> cand;
+    std::vector<std::pair<void *, double>> cand;  // pointer, probe rate
     int best = -1;
     for (int k = 0; k < tries; ++k) {
-        StripedArena a;
-        void *va = nullptr;
-        const int rc = striped_build(ctx, n, piece, &a, &va);
-        if (rc != VSZIP_OK) {
-            if (!cand.empty()) break;  // the device is fuller than it said: choose among what exists
-            if (rc == VSZIP_ERR_NOMEM) return vszip_set_error(ctx, rc, "vszip_dev_alloc(%zu): out of device memory", bytes);
-            if (rc == VSZIP_ERR_HIP) return vszip_set_error(ctx, rc, "vszip_dev_alloc(%zu): mapping a striped arena failed", bytes);
-            return rc;
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;  // the device is fuller than it said: choose among what exists
         }
+        double rate = 0.0;
         if (tries > 1) {
-            double c = probe_region(ctx, va, a.bytes, nullptr);
+            double c = probe_region(ctx, p, bytes, nullptr);
             // the first candidate also brings the clocks up: an idle device runs its first milliseconds slower, and candidates must be compared
             // at one clock - repeat until two measurements in a row agree within 0.5 % (at most ~60 ms)
             for (int i = 0; k == 0 && i < 20 && c > 0; ++i) {
-                const double c2 = probe_region(ctx, va, a.bytes, nullptr);
+                const double c2 = probe_region(ctx, p, bytes, nullptr);
                 const bool steady = c2 > 0 && std::fabs(c2 - c) <= 0.005 * c;
                 c = c2;
                 if (steady) break;
             }
-            a.probe_bytes_per_s = c > 0 ? 1.0 / c : 0.0;
+            rate = c > 0 ? 1.0 / c : 0.0;
         }
-        cand.emplace_back(std::move(a), va);
-        if (best < 0 || cand.back().first.probe_bytes_per_s > cand[best].first.probe_bytes_per_s) best = (int)cand.size() - 1;
-        if (cand.back().first.probe_bytes_per_s >= kBestBytesPerSec) break;
+        cand.emplace_back(p, rate);
+        if (best < 0 || rate > cand[best].second) best = (int)cand.size() - 1;
+        if (rate >= kBestBytesPerSec) break;
     }
+    if (cand.empty()) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
     for (int k = 0; k < (int)cand.size(); ++k)
-        if (k != best) striped_release(cand[k].second, cand[k].first, n);
-    StripedArena &a = cand[best].first;
-    a.candidates = (int)cand.size();
-    a.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    void *va = cand[best].second;
+        if (k != best) (void)hipFree(cand[k].first);
     {
-        std::lock_guard<std::mutex> lk(striped_mu());
-        striped_map()[static_cast<char *>(va)] = std::move(a);
-        g_striped_count.fetch_add(1);
+        std::lock_guard<std::mutex> lk(placed_mu());
+        placed_map()[cand[best].first] = {(int)cand.size(), cand[best].second, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()};
+        g_placed_count.fetch_add(1);
     }
-    *dptr = va;
+    *dptr = cand[best].first;
     return VSZIP_OK;
 }
 
-// true: dptr was a striped arena and is gone
-bool striped_free(void *dptr) {
-    if (g_striped_count.load() == 0) return false;
-    StripedArena a;
-    {
-        std::lock_guard<std::mutex> lk(striped_mu());
-        auto it = striped_map().find(static_cast<char *>(dptr));
-        if (it == striped_map().end()) return false;
-        a = std::move(it->second);
-        striped_map().erase(it);
-        g_striped_count.fetch_sub(1);
-    }
-    (void)hipSetDevice(a.device);
-    (void)hipDeviceSynchronize();  // like hipFree: no stream of any context may still be using it
-    striped_release(dptr, a, a.bytes / a.piece);
-    return true;
-}
-
-// the piece size of the striped arena that holds p (0: p is not inside one)
-size_t striped_piece_of(const void *p) {
-    if (g_striped_count.load() == 0) return 0;
-    std::lock_guard<std::mutex> lk(striped_mu());
-    auto &m = striped_map();
-    auto it = m.upper_bound(const_cast<char *>(static_cast<const char *>(p)));
-    if (it == m.begin()) return 0;
-    --it;
-    return static_cast<const char *>(p) < it->first + it->second.bytes ? it->second.piece : 0;
+void placed_forget(void *dptr) {
+    if (g_placed_count.load() == 0) return;
+    std::lock_guard<std::mutex> lk(placed_mu());
+    if (placed_map().erase(dptr)) g_placed_count.fetch_sub(1);
 }
 
 typedef unsigned int pv4u __attribute__((ext_vector_type(4)));
@@ -508,10 +395,7 @@ hipError_t vszip_hip_malloc(vszip_ctx *, void **p, size_t bytes) { return hipMal
 VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return VSZIP_ERR_ARG;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (ctx->opt.placement && bytes >= ((size_t)std::max(16, ctx->opt.placement_min_mib) << 20)) {
-        const int rc = striped_alloc(ctx, bytes, dptr);
-        if (rc != VSZIP_ERR_UNSUPPORTED) return rc;
-    }
+    if (ctx->opt.placement && bytes >= ((size_t)std::max(16, ctx->opt.placement_min_mib) << 20)) return placed_alloc(ctx, bytes, dptr);
     if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) {
         (void)hipGetLastError();
         return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
@@ -519,27 +403,17 @@ VSZIP_EXPORT int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     return VSZIP_OK;
 }
 
-VSZIP_EXPORT int vszip_dev_arena_info(vszip_ctx *ctx, const void *dptr, size_t *pieces, size_t *piece_bytes, int *candidates, double *probe_bytes_per_second, double *build_ms) {
+VSZIP_EXPORT int vszip_dev_arena_info(vszip_ctx *ctx, const void *dptr, int *candidates, double *probe_bytes_per_second, double *search_ms) {
     if (!ctx) return VSZIP_ERR_ARG;
-    size_t n = 0, pb = 0;
-    int nc = 0;
-    double ms = 0.0, rate = 0.0;
-    if (g_striped_count.load() != 0) {
-        std::lock_guard<std::mutex> lk(striped_mu());
-        auto it = striped_map().find(const_cast<char *>(static_cast<const char *>(dptr)));
-        if (it != striped_map().end()) {
-            n = it->second.handles.size();
-            pb = it->second.piece;
-            nc = it->second.candidates;
-            rate = it->second.probe_bytes_per_s;
-            ms = it->second.build_ms;
-        }
+    PlacedInfo pi = {0, 0.0, 0.0};
+    if (g_placed_count.load() != 0) {
+        std::lock_guard<std::mutex> lk(placed_mu());
+        auto it = placed_map().find(const_cast<void *>(dptr));
+        if (it != placed_map().end()) pi = it->second;
     }
-    if (pieces) *pieces = n;
-    if (piece_bytes) *piece_bytes = pb;
-    if (candidates) *candidates = nc;
-    if (probe_bytes_per_second) *probe_bytes_per_second = rate;
-    if (build_ms) *build_ms = ms;
+    if (candidates) *candidates = pi.candidates;
+    if (probe_bytes_per_second) *probe_bytes_per_second = pi.probe_bytes_per_s;
+    if (search_ms) *search_ms = pi.build_ms;
     return VSZIP_OK;
 }
 
@@ -557,10 +431,7 @@ VSZIP_EXPORT int vszip_dev_free(vszip_ctx *ctx, void *dptr) {
     if (!dptr) return VSZIP_OK;
     VSZIP_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     vszip_bilateral_forget_lut(dptr);
-    if (striped_free(dptr)) {
-        (void)hipSetDevice(ctx->device);
-        return VSZIP_OK;
-    }
+    placed_forget(dptr);
     VSZIP_HIP_CHECK(ctx, hipFree(dptr));
     return VSZIP_OK;
 }
@@ -639,20 +510,6 @@ static int copy2d(vszip_ctx *ctx, void *dst, size_t dpitch, const void *src, siz
             VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(a, wb, src, spitch, wb, rows, kind, ctx->stream));
             ctx->pending_out.push_back({dst, dpitch, a, wb, rows});
         }
-        return VSZIP_OK;
-    }
-    // A striped arena is several mapped pieces: the runtime's 2-D copy accepts an extent up to the size of ONE of them
-    // (hipMemcpy2DAsync: "invalid argument" beyond; tools/vmm/vmm_copies.hip) - larger planes go in row groups that fit.
-    size_t piece = kind != hipMemcpyHostToDevice ? striped_piece_of(src) : 0;
-    if (kind != hipMemcpyDeviceToHost) {
-        const size_t pd = striped_piece_of(dst);
-        piece = piece && pd ? std::min(piece, pd) : std::max(piece, pd);
-    }
-    const size_t pitch_max = std::max(kind == hipMemcpyHostToDevice ? (size_t)0 : spitch, kind == hipMemcpyDeviceToHost ? (size_t)0 : dpitch);
-    if (piece && pitch_max * rows > piece) {
-        const size_t step = std::max<size_t>(1, piece / pitch_max);
-        for (size_t y = 0; y < rows; y += step)
-            VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<char *>(dst) + y * dpitch, dpitch, static_cast<const char *>(src) + y * spitch, spitch, wb, std::min(step, rows - y), kind, ctx->stream));
         return VSZIP_OK;
     }
     VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, wb, rows, kind, ctx->stream));
