@@ -169,6 +169,22 @@ def profile_traffic(kernel_prefix: str, frames: int):
     return best
 
 
+def profile_launch_us(kernel_sub: str):
+    """the dominant kernel's average launch duration in the newest committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/r*_boxblur_kernel_stats.csv) - REPLAYED, the second basis of roofline.frac; (us, calls, file name) or None"""
+    import csv
+
+    files = sorted((ROOT / "profiles").glob("r*_boxblur_kernel_stats.csv"))
+    for f in reversed(files):
+        try:
+            for r in csv.DictReader(f.open()):
+                if kernel_sub in r["Name"]:
+                    return float(r["AverageNs"]) / 1e3, int(r["Calls"]), f.name
+        except Exception:
+            continue
+    return None
+
+
 def limit_from_profile(name: str, kernel_sub: str):
     """What bounds a leg that HBM does not: issue and LDS-array busy fractions of its dominant kernel, from the committed PMC
     passes of the same workload (profiles/r*_<name>_pmc.json, tools/prof_all.sh: separate --pmc runs) — REPLAYED, not measured in
@@ -1017,7 +1033,7 @@ def xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev, frames_per_rank=8):
 # ---------------------------------------------------------------------------
 LINE_MAX_BYTES = 7600
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rccl_ranks")
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_us", "launches", "algorithmic_bytes_per_launch", "frac_median")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_us", "launches", "algorithmic_bytes_per_launch", "frac_median", "frac_rocprof", "rocprof_avg_launch_us", "rocprof_source")
 
 
 def _sig(v, digits=6):
@@ -1286,6 +1302,11 @@ def main() -> int:
         if rank == 0:
             out["config"]["ranks"] = ranks
             out["config"]["slowest_rank_frac"] = min(r["frac"] for r in ranks)
+        prof = profile_launch_us("boxblur_ct_ring_kernel<unsigned short, 13") if a.radius == RADIUS else None
+        if prof:  # both bases of the fraction on the line: HIP events of THIS run (frac) and the committed rocprofv3 average (frac_rocprof)
+            out["roofline"]["frac_rocprof"] = alg_bytes / (prof[0] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["rocprof_avg_launch_us"] = prof[0]
+            out["roofline"]["rocprof_source"] = f"profiles/{prof[2]} ({prof[1]} calls; replayed)"
         out["roofline"]["traffic_source"] = ("replayed from the committed PMC passes of this command (profiles/r*_boxblur_pmc.json), not measured in this run"
                                              if out["roofline"]["traffic"] is not None else None)
         if rank == 0:
