@@ -1493,10 +1493,28 @@ __global__ __launch_bounds__(64) void boxblur_rt_hsmall_kernel(const RParams prm
         for (int v = lane; v < nv; v += 64) {
             const int x0 = 8 * v;
             uint32_t t[NT];  // t[8 G + i] = sample x0 + i: the group and G groups on either side (three 16-byte reads for R <= 8, five beyond)
+            // 16-byte reads, spelled out: left to itself the compiler narrows the five reads to the 18 dwords the windows touch and issues them as
+            // 8-byte ds_read2_b32 pairs at a 16-byte lane stride - four lanes a bank: 68 % of this kernel's LDS cycles were bank conflicts and the
+            // LDS pipe, not the VALU, was what bounded it (profiles/r05_notes.md section 2). ds_read_b128 at a 16-byte lane stride is conflict free.
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 q[2 * G + 1];
+            {
+                const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(cur + H + x0 - 8 * G);  // (the low half of a shared pointer is its LDS offset)
+                if constexpr (G == 1)
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2])
+                                 : "v"(a)
+                                 : "memory");
+                else
+                    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\t"
+                                 "ds_read_b128 %4, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[2 * G])
+                                 : "v"(a)
+                                 : "memory");
+            }
 #pragma unroll
             for (int g = 0; g < 2 * G + 1; ++g) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(cur + H + x0 + 8 * (g - G));
-                const uint32_t dw[4] = {q.x, q.y, q.z, q.w};
+                const uint32_t dw[4] = {q[g].x, q[g].y, q[g].z, q[g].w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t[8 * g + k] = (dw[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
             }
