@@ -128,7 +128,35 @@ def test_options_by_name(pdev):
     assert pdev.get_option("VSZIP_RT_NO_ICHAIN") == 0
     with pytest.raises(vszip_amd.VszipError, match="unknown option"):
         pdev.set_option("VSZIP_NO_SUCH_THING", 1)
+    # values are range-checked: flags take 0 / 1, integers their documented range; a refused value changes nothing
+    for name, bad in (("VSZIP_RT_NO_ICHAIN", 2), ("VSZIP_STAGING", 2), ("VSZIP_SCAN_MODE", 3), ("VSZIP_PLACEMENT_TRIES", 0), ("VSZIP_PLACEMENT_MIN_MIB", 1), ("VSZIP_PLACEMENT", -1)):
+        before = pdev.get_option(name)
+        with pytest.raises(vszip_amd.VszipError, match="out of range") as e:
+            pdev.set_option(name, bad)
+        assert e.value.code == -1 and pdev.get_option(name) == before
+    pdev.set_option("VSZIP_SCAN_MODE", 2)
+    assert pdev.get_option("VSZIP_SCAN_MODE") == 2
+    pdev.set_option("VSZIP_SCAN_MODE", 0)
     try:
         pdev.get_option("VSZIP_RT_FUSED")
     except vszip_amd.VszipError as e:  # the default build: a development variant
         assert e.code == -3 and "development variant" in str(e)
+
+
+def test_environment_values_are_validated_too():
+    """the environment is read once per context: an out-of-range or non-numeric value where a number is due keeps the default, VSZIP_STAGING keeps its
+    historical spellings ("1", "pinned"; any other text leaves it off)"""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r); import torch, vszip_amd; d = vszip_amd.Device(0); "
+        "print(d.get_option('VSZIP_STAGING'), d.get_option('VSZIP_SCAN_MODE'), d.get_option('VSZIP_PLACEMENT_TRIES'), d.get_option('VSZIP_RT_NO_ICHAIN'), d.get_option('VSZIP_PLACEMENT_MIN_MIB'))"
+    ) % str(__import__("pathlib").Path(__file__).resolve().parents[1])
+    env = dict(os.environ, VSZIP_STAGING="yes", VSZIP_SCAN_MODE="7", VSZIP_PLACEMENT_TRIES="many", VSZIP_RT_NO_ICHAIN="on", VSZIP_PLACEMENT_MIN_MIB="512")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[-5:] == ["0", "0", "24", "1", "512"], r.stdout
+    env["VSZIP_STAGING"] = "pinned"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.stdout.split()[-5] == "1", r.stdout

@@ -3,6 +3,7 @@
 
 #include "common.hpp"
 
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -75,19 +76,50 @@ const OptionDesc kOptions[] = {
 #undef VSZIP_DEV_OPT
 };
 
-// flags: "" / "0" off, any other text on; integers as they are ("pinned" is VSZIP_STAGING's historical spelling of 1)
-int option_value(const char *text) {
+// Value ranges: the integer options by name, every other option is a flag (0 / 1).
+struct OptionRange {
+    const char *env;
+    int lo, hi;
+};
+const OptionRange kRanges[] = {
+    {"VSZIP_SCAN_MODE", 0, 2},         {"VSZIP_PLACEMENT_MIN_MIB", 16, 1 << 20}, {"VSZIP_PLACEMENT_TRIES", 1, 64},  {"VSZIP_RT_ICHAIN_BANDS", 0, 256},
+    {"VSZIP_RT_VSMALL_MAX", 0, 8},     {"VSZIP_RT_VBAND", 0, 1 << 16},           {"VSZIP_RT_VRING_MAXR", 0, 127},   {"VSZIP_RT_GROUP_MB", 0, 1 << 20},
+    {"VSZIP_RING_PERIODS", 0, 1 << 16},
+};
+bool option_in_range(const char *env, int v) {
+    for (const OptionRange &r : kRanges)
+        if (strcmp(r.env, env) == 0) return v >= r.lo && v <= r.hi;
+    return v == 0 || v == 1;
+}
+
+// Environment text -> value. Integers as they are; for a flag "" / "0" is off and any other text on - except VSZIP_STAGING, whose historical
+// spellings are "1" and "pinned" only (any other text leaves staging off, as before round 4). *ok = false: not a value of this option.
+int option_value(const char *env, const char *text, bool *ok) {
+    *ok = true;
     if (!text || !*text) return 0;
     char *end = nullptr;
     const long v = strtol(text, &end, 10);
-    if (end != text && *end == 0) return (int)v;
+    if (end != text && *end == 0) {
+        *ok = v >= INT_MIN && v <= INT_MAX && option_in_range(env, (int)v);
+        return (int)v;
+    }
+    if (strcmp(env, "VSZIP_STAGING") == 0) return strcmp(text, "pinned") == 0 ? 1 : 0;
+    for (const OptionRange &r : kRanges)
+        if (strcmp(r.env, env) == 0) {  // text where a number is due: ignored
+            *ok = false;
+            return 0;
+        }
     return 1;
 }
 
 void options_from_env(vszip_options *o) {
     for (const OptionDesc &d : kOptions) {
         if (!d.field) continue;
-        if (const char *e = getenv(d.env)) o->*d.field = option_value(e);
+        if (const char *e = getenv(d.env)) {
+            bool ok;
+            const int v = option_value(d.env, e, &ok);
+            if (ok) o->*d.field = v;  // (an out-of-range value in the environment keeps the default)
+        }
     }
 }
 }  // namespace
@@ -97,6 +129,7 @@ VSZIP_EXPORT int vszip_ctx_set_option(vszip_ctx *ctx, const char *name, int valu
     for (const OptionDesc &d : kOptions)
         if (strcmp(d.env, name) == 0) {
             if (!d.field) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s is a development variant: build with -DVSZIP_DEV_VARIANTS", name);
+            if (!option_in_range(name, value)) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s = %d is out of range", name, value);
             if (d.field == &vszip_options::staging) return vszip_ctx_set_staging(ctx, value);  // (drains what is staged first)
             ctx->opt.*d.field = value;
             return VSZIP_OK;
