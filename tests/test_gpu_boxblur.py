@@ -351,7 +351,9 @@ def test_rt_integer_chain_in_bands(dev, oracle, dtype):
     different counts for luma and chroma, widths that are not whole 4-sample groups, saturated and zero rows, radii to 30, 2 ... 7 passes."""
     cases = [([(1080, 36)], (0, 0, 13, 5)), ([(541, 130), (270, 65), (270, 65)], (0, 0, 5, 3)), ([(400, 70)], (0, 0, 2, 3)), ([(385, 64)], (0, 0, 3, 4)),
              ([(257, 33)], (0, 0, 1, 5)), ([(900, 48)], (0, 0, 30, 2)), ([(700, 41)], (0, 0, 22, 3)), ([(513, 260)], (2, 2, 13, 2)), ([(640, 5)], (0, 0, 4, 6)),
-             ([(300, 3)], (0, 0, 2, 7)), ([(1081, 20)], (1, 2, 13, 5)), ([(136, 50)], (0, 0, 9, 3)), ([(2160, 64), (1080, 32)], (0, 0, 5, 3))]
+             ([(300, 3)], (0, 0, 2, 7)), ([(1081, 20)], (1, 2, 13, 5)), ([(136, 50)], (0, 0, 9, 3)), ([(2160, 64), (1080, 32)], (0, 0, 5, 3)),
+             # round 5: chains cut into nearly equal lengths bounded by the shortest plane's height, P (3 R + 2) <= h / 4: 5 passes as 3 + 2, 4 as 2 + 2, 5 as 2 + 2 + 1
+             ([(540, 64)], (0, 0, 13, 5)), ([(540, 72)], (0, 0, 13, 4)), ([(540, 96), (270, 48), (270, 48)], (13, 5, 13, 5)), ([(1080, 40), (540, 20)], (0, 0, 13, 5))]
     for shapes, args in cases:
         planes = [fx.splitmix64_plane(41 + i, sh, dtype) if i % 2 == 0 else fx.tiled_natural(sh, dtype, 1) for i, sh in enumerate(shapes)]
         planes[0][3] = np.iinfo(dtype).max
