@@ -187,6 +187,10 @@ template <>
 struct Raw<uint16_t, 4> {
     using type = u32x2;
 };
+template <>
+struct Raw<uint8_t, 8> {
+    using type = u32x2;
+};
 template <typename T>
 using GP = const T __attribute__((address_space(1))) *;  // a plane pointer, known to be global memory
 template <typename T, int N>
@@ -237,6 +241,29 @@ __device__ __forceinline__ void add_u64(uint64_t *p, uint64_t v) { atomicAdd(rei
 // arrays, with clamped (always valid) addresses and no branch in between, so that they are all in
 // flight together; then the arithmetic. Row validity is applied in the second phase.
 
+// The BV samples either side of a lane's 4: its neighbours' centre loads, moved across lanes
+// (wave_shr / wave_shl); only lane 0 (left) and lane 63 (right) need memory, and they share ONE load
+// instruction (`edge`: lane 0's left samples or lane 63's right samples, StripHalo::x). Round 5: the two
+// sub-dword halo loads a row were a third of the kernel's load instructions and 18 % of its time.
+template <typename T, int BV>
+struct StripHalo {
+    static constexpr int kBits = 8 * (int)sizeof(T) * BV;
+    int x;       // where this lane's edge samples start (lanes 0 and 63 only)
+    bool edge;
+    __device__ __forceinline__ StripHalo(int lane, int xlft, int xrgt) : x(lane == 0 ? xlft : xrgt), edge(lane == 0 || lane == 63) {}
+    __device__ __forceinline__ static uint32_t first_word(uint32_t q) { return q; }
+    __device__ __forceinline__ static uint32_t last_word(uint32_t q) { return q; }
+    __device__ __forceinline__ static uint32_t first_word(u32x2 q) { return q.x; }
+    __device__ __forceinline__ static uint32_t last_word(u32x2 q) { return q.y; }
+    template <typename Q>
+    __device__ __forceinline__ static void get(Q centre, uint32_t edge_samples, int lane, uint32_t &left, uint32_t &right) {
+        const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_word(centre), 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first_word(centre), 0x130, 0xf, 0xf, false);  // wave_shl:1
+        left = lane == 0 ? edge_samples : l >> (32 - kBits);
+        right = lane == 63 ? edge_samples : (kBits == 32 ? r : r & ((1u << (kBits & 31)) - 1u));
+    }
+};
+
 // SSE of a strip of an SSE-only plane (chroma; every plane when b < 4): calcSquaredError :214-251
 template <typename T, int VEC>
 __device__ __forceinline__ void sse_strip(const XGeo &g, GP<T> org, GP<T> rec, uint64_t *out, int sx, int brow, int seg, int lane) {
@@ -272,12 +299,12 @@ __device__ __forceinline__ void sse_strip(const XGeo &g, GP<T> org, GP<T> rec, u
     if (valid && (lane == 0 || up != key)) add_u64(out + g.out_off + (size_t)brow * g.nbx + key, sse);
 }
 
-// Geometry of one luma strip and of this lane's 4 samples in it.
-template <int BV>
+// Geometry of one luma strip and of this lane's PX samples in it (PX == 8 only where a block is whole 8-sample groups: one key a lane).
+template <int BV, int PX = 4>
 struct LumaLane {
     int w, h, oy, ys, ye, x0, xc, xlft, xrgt, key, y_act, h_act;
     bool valid;
-    bool mx[4];  // sample j lies in the activity columns of its block
+    bool mx[PX];  // sample j lies in the activity columns of its block
     __device__ __forceinline__ bool init(const XGeo &g, int RS, int sx, int brow, int seg, int lane) {
         const int b = g.bx;
         w = g.w;
@@ -287,11 +314,11 @@ struct LumaLane {
         ys = oy + seg * RS;
         ye = min(ys + RS, oy + bh);
         if (ys >= ye) return false;
-        x0 = (sx * 64 + lane) * 4;
+        x0 = (sx * 64 + lane) * PX;
         valid = x0 < w;
         xc = valid ? x0 : 0;             // centre load position
         xlft = max(xc - BV, 0);          // left halo (BV samples ending at xc-1)
-        xrgt = min(xc + 4, w - BV);      // right halo (BV samples from xc+4)
+        xrgt = min(xc + PX, w - BV);     // right halo (BV samples from xc+PX)
         key = valid ? x0 / b : -1;
         const int ox = key * b, bw = min(b, w - ox);
         // calcSquaredErrorAndWeight :283-286
@@ -300,7 +327,7 @@ struct LumaLane {
         const int w_act = (ox + bw < w) ? bw : bw - BV;
         h_act = (oy + bh < h) ? bh : bh - BV;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PX; ++j) {
             const int xr = x0 + j - ox;
             mx[j] = valid && x0 + j < w && xr >= x_act && xr < w_act && (BV == 1 || w_act > 12);
         }
@@ -328,13 +355,16 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, GP<T> org, GP<T>
     const int c1 = tmode == 1 ? 1 : 2;
 
     typename Raw<T, 4>::type qc[NR], qr[RS], q1[RS], q2[RS];
-    uint32_t ql[NR], qg[NR];
+    uint32_t qe[NR];
+    const StripHalo<T, BV> halo(lane, L.xlft, L.xrgt);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const GP<T> row = org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o;
-        qc[i] = load_raw<T, 4>(row + L.xc);
-        ql[i] = load_raw<T, BV>(row + L.xlft);
-        qg[i] = load_raw<T, BV>(row + L.xrgt);
+        qc[i] = load_raw<T, 4>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + L.xc);
+        qe[i] = 0;
+    }
+    if (halo.edge) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) qe[i] = load_raw<T, BV>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + halo.x);
     }
 #pragma unroll
     for (int i = 0; i < RS; ++i) qr[i] = load_raw<T, 4>(rec + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
@@ -356,8 +386,10 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, GP<T> org, GP<T>
             const int y = ys - 1 + i;
             int v[6];
             unpack<T, 4>(qc[i], v + 1);
-            v[0] = (int)ql[i];
-            v[5] = (int)qg[i];
+            uint32_t lft, rgt;
+            StripHalo<T, BV>::get(qc[i], qe[i], lane, lft, rgt);
+            v[0] = (int)lft;
+            v[5] = (int)rgt;
             const bool emit = i >= 2 && y - 1 < ye && L.act_row(y - 1);  // the row completed by this iteration
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -392,9 +424,11 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, GP<T> org, GP<T>
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 int v[8];
+                uint32_t lft, rgt;
+                StripHalo<T, BV>::get(qc[2 * i + rr], qe[2 * i + rr], lane, lft, rgt);
                 unpack<T, 4>(qc[2 * i + rr], v + 2);
-                unpack<T, 2>(ql[2 * i + rr], v);
-                unpack<T, 2>(qg[2 * i + rr], v + 6);
+                unpack<T, 2>(lft, v);
+                unpack<T, 2>(rgt, v + 6);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int *u = v + 2 * q;
@@ -472,130 +506,176 @@ __device__ __forceinline__ uint32_t abs_dot2(v2s v, uint32_t mask, uint32_t acc)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, mask), acc, false);
 }
 
-template <int BV>
+template <int BV, int NG>  // NG groups of 4 pixels a lane: one 4- or 8-byte load a row and plane
 __device__ __forceinline__ void luma_strip_u8(const XStripArgs &a, GP<uint8_t> org, GP<uint8_t> rec, GP<uint8_t> p1, GP<uint8_t> p2, uint64_t *out, int sx,
                                               int brow, int seg, int lane) {
-    constexpr int RS = BV == 1 ? kRowsBv1 : kRowsBv2, NR = RS + 2 * BV;
+    constexpr int RS = BV == 1 ? kRowsBv1 : kRowsBv2, NR = RS + 2 * BV, PX = 4 * NG, kHaloBits = 8 * BV;
+    using Q = typename Raw<uint8_t, PX>::type;
     const XGeo &g = a.g[0];
-    LumaLane<BV> L;
+    LumaLane<BV, PX> L;
     if (!L.init(g, RS, sx, brow, seg, lane)) return;
     const ptrdiff_t o = g.stride;
     const int w = L.w, h = L.h, ys = L.ys, ye = L.ye, x0 = L.x0;
     const bool valid = L.valid;
-    const uint32_t vm = !valid ? 0u : (x0 + 3 < w ? 0xffffffffu : 0x0000ffffu);  // bytes of this lane inside the plane (w is even)
+    uint32_t vm[NG];  // bytes of each group inside the plane (w is even)
+#pragma unroll
+    for (int k = 0; k < NG; ++k) vm[k] = !valid || x0 + 4 * k >= w ? 0u : (x0 + 4 * k + 3 < w ? 0xffffffffu : 0x0000ffffu);
     const int tmode = a.tmode;
+#ifdef VSZIP_XPSNR_TIMING_NOTEMP
+    const bool has1 = false, has2 = false;
+#else
     const bool has1 = p1 != nullptr, has2 = p1 != nullptr && p2 != nullptr;
+#endif
 
-    uint32_t qc[NR], ql[NR], qg[NR], qr[RS], q1[RS], q2[RS];
+    Q qc[NR], qr[RS], q1[RS], q2[RS];
+    uint32_t qe[NR];
+    const StripHalo<uint8_t, BV> halo(lane, L.xlft, L.xrgt);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const GP<uint8_t> row = org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o;
-        qc[i] = load_raw<uint8_t, 4>(row + L.xc);
-        ql[i] = load_raw<uint8_t, BV>(row + L.xlft);
-        qg[i] = load_raw<uint8_t, BV>(row + L.xrgt);
+        qc[i] = load_raw<uint8_t, PX>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + L.xc);
+        qe[i] = 0;
+    }
+    if (halo.edge) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) qe[i] = load_raw<uint8_t, BV>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + halo.x);
     }
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
-        qr[i] = load_raw<uint8_t, 4>(rec + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
-        q1[i] = q2[i] = 0;
+        qr[i] = load_raw<uint8_t, PX>(rec + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+        q1[i] = q2[i] = Q{};
     }
     if (tmode && has1) {
 #pragma unroll
-        for (int i = 0; i < RS; ++i) q1[i] = load_raw<uint8_t, 4>(p1 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+        for (int i = 0; i < RS; ++i) q1[i] = load_raw<uint8_t, PX>(p1 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
     }
     if (tmode == 2 && has2) {
 #pragma unroll
-        for (int i = 0; i < RS; ++i) q2[i] = load_raw<uint8_t, 4>(p2 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
+        for (int i = 0; i < RS; ++i) q2[i] = load_raw<uint8_t, PX>(p2 + (ptrdiff_t)min(ys + i, h - 1) * o + L.xc);
     }
+    // group k of a row: its 4 centre bytes and the BV samples either side (the lane's other group or the halo)
+    auto word = [](const Q &q, int k) -> uint32_t {
+        if constexpr (NG == 1)
+            return q;
+        else
+            return k == 0 ? q.x : q.y;
+    };
+    auto sides = [&](const Q &q, uint32_t edge, int k, uint32_t &lft, uint32_t &rgt) {
+        uint32_t hl, hr;
+        StripHalo<uint8_t, BV>::get(q, edge, lane, hl, hr);
+        lft = k == 0 ? hl : word(q, k - 1) >> (32 - kHaloBits);
+        rgt = k == NG - 1 ? hr : word(q, k + 1) & ((1u << kHaloBits) - 1u);
+    };
 
     uint32_t oo = 0, rr2 = 0, orr = 0, sa = 0, ta = 0;
     if constexpr (BV == 1) {
-        const uint32_t m01 = (L.mx[0] ? 1u : 0u) | (L.mx[1] ? 0x10000u : 0u), m23 = (L.mx[2] ? 1u : 0u) | (L.mx[3] ? 0x10000u : 0u);
-        const uint32_t t01 = (vm & 0xffu ? 1u : 0u) | (vm & 0xff00u ? 0x10000u : 0u);
-        const uint32_t t23 = (vm & 0xff0000u ? 1u : 0u) | (vm & 0xff000000u ? 0x10000u : 0u);
-        v2s P01 = {0, 0}, P23 = {0, 0}, N01 = {0, 0}, N23 = {0, 0};  // P: h0(y-1) - h1n(y-2); N: h1n(y-1), h1n = l + 2c + r
+        uint32_t m01[NG], m23[NG], t01[NG], t23[NG];
+        v2s P01[NG], P23[NG], N01[NG], N23[NG];  // P: h0(y-1) - h1n(y-2); N: h1n(y-1), h1n = l + 2c + r
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            m01[k] = (L.mx[4 * k] ? 1u : 0u) | (L.mx[4 * k + 1] ? 0x10000u : 0u);
+            m23[k] = (L.mx[4 * k + 2] ? 1u : 0u) | (L.mx[4 * k + 3] ? 0x10000u : 0u);
+            t01[k] = (vm[k] & 0xffu ? 1u : 0u) | (vm[k] & 0xff00u ? 0x10000u : 0u);
+            t23[k] = (vm[k] & 0xff0000u ? 1u : 0u) | (vm[k] & 0xff000000u ? 0x10000u : 0u);
+            P01[k] = P23[k] = N01[k] = N23[k] = (v2s){0, 0};
+        }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int y = ys - 1 + i;
-            const uint32_t C = qc[i];
-            // pixel pairs as packed u16: centre (c0,c1) (c2,c3), left neighbours (l,c0) (c1,c2), right neighbours (c1,c2) (c3,r)
-            const v2s c01 = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c010c00u)), c23 = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c030c02u));
-            const v2s l01 = as_v2s(__builtin_amdgcn_perm(ql[i], C, 0x0c000c04u)), mid = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c020c01u));
-            const v2s r23 = as_v2s(__builtin_amdgcn_perm(qg[i], C, 0x0c040c03u));
-            const v2s s01 = l01 + mid, s23 = mid + r23;
-            const v2s n01 = c01 * (v2s){2, 2} + s01, n23 = c23 * (v2s){2, 2} + s23;
-            const v2s h01 = c01 * (v2s){12, 12} - s01 * (v2s){2, 2}, h23 = c23 * (v2s){12, 12} - s23 * (v2s){2, 2};
-            if (i >= 2 && y - 1 < ye && L.act_row(y - 1)) {
-                sa = abs_dot2(P01 - n01, m01, sa);
-                sa = abs_dot2(P23 - n23, m23, sa);
-            }
-            P01 = h01 - N01;
-            P23 = h23 - N23;
-            N01 = n01;
-            N23 = n23;
-            if (i >= 1 && i <= RS && y < ye) {
-                const uint32_t Cm = C & vm, Rm = qr[i - 1] & vm, T1 = q1[i - 1], T2 = q2[i - 1];
-                oo = dot4(Cm, Cm, oo);
-                rr2 = dot4(Rm, Rm, rr2);
-                orr = dot4(Cm, Rm, orr);
-                if (tmode == 1) {
-                    ta = __builtin_amdgcn_sad_u8(Cm, T1 & vm, ta);  // tempDiff1 :111-140
-                } else if (tmode == 2) {                             // tempDiff2 :142-170: |o - 2 p1 + p2|
-                    const v2s a01 = as_v2s(__builtin_amdgcn_perm(0u, T1, 0x0c010c00u)), a23 = as_v2s(__builtin_amdgcn_perm(0u, T1, 0x0c030c02u));
-                    const v2s b01 = as_v2s(__builtin_amdgcn_perm(0u, T2, 0x0c010c00u)), b23 = as_v2s(__builtin_amdgcn_perm(0u, T2, 0x0c030c02u));
-                    ta = abs_dot2(c01 - a01 * (v2s){2, 2} + b01, t01, ta);
-                    ta = abs_dot2(c23 - a23 * (v2s){2, 2} + b23, t23, ta);
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const uint32_t C = word(qc[i], k);
+                uint32_t lft, rgt;
+                sides(qc[i], qe[i], k, lft, rgt);
+                // pixel pairs as packed u16: centre (c0,c1) (c2,c3), left neighbours (l,c0) (c1,c2), right neighbours (c1,c2) (c3,r)
+                const v2s c01 = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c010c00u)), c23 = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c030c02u));
+                const v2s l01 = as_v2s(__builtin_amdgcn_perm(lft, C, 0x0c000c04u)), mid = as_v2s(__builtin_amdgcn_perm(0u, C, 0x0c020c01u));
+                const v2s r23 = as_v2s(__builtin_amdgcn_perm(rgt, C, 0x0c040c03u));
+                const v2s s01 = l01 + mid, s23 = mid + r23;
+                const v2s n01 = c01 * (v2s){2, 2} + s01, n23 = c23 * (v2s){2, 2} + s23;
+                const v2s h01 = c01 * (v2s){12, 12} - s01 * (v2s){2, 2}, h23 = c23 * (v2s){12, 12} - s23 * (v2s){2, 2};
+                if (i >= 2 && y - 1 < ye && L.act_row(y - 1)) {
+                    sa = abs_dot2(P01[k] - n01, m01[k], sa);
+                    sa = abs_dot2(P23[k] - n23, m23[k], sa);
+                }
+                P01[k] = h01 - N01[k];
+                P23[k] = h23 - N23[k];
+                N01[k] = n01;
+                N23[k] = n23;
+                if (i >= 1 && i <= RS && y < ye) {
+                    const uint32_t Cm = C & vm[k], Rm = word(qr[i - 1], k) & vm[k], T1 = word(q1[i - 1], k), T2 = word(q2[i - 1], k);
+                    oo = dot4(Cm, Cm, oo);
+                    rr2 = dot4(Rm, Rm, rr2);
+                    orr = dot4(Cm, Rm, orr);
+                    if (tmode == 1) {
+                        ta = __builtin_amdgcn_sad_u8(Cm, T1 & vm[k], ta);  // tempDiff1 :111-140
+                    } else if (tmode == 2) {                                // tempDiff2 :142-170: |o - 2 p1 + p2|
+                        const v2s a01 = as_v2s(__builtin_amdgcn_perm(0u, T1, 0x0c010c00u)), a23 = as_v2s(__builtin_amdgcn_perm(0u, T1, 0x0c030c02u));
+                        const v2s b01 = as_v2s(__builtin_amdgcn_perm(0u, T2, 0x0c010c00u)), b23 = as_v2s(__builtin_amdgcn_perm(0u, T2, 0x0c030c02u));
+                        ta = abs_dot2(c01 - a01 * (v2s){2, 2} + b01, t01[k], ta);
+                        ta = abs_dot2(c23 - a23 * (v2s){2, 2} + b23, t23[k], ta);
+                    }
                 }
             }
         }
     } else {
-        int Pp[2] = {0, 0}, Pn[2] = {0, 0};
-        const bool tq[2] = {valid, valid && x0 + 2 < w};
+        int Pp[NG][2], Pn[NG][2];
+        bool tq[NG][2];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            Pp[k][0] = Pp[k][1] = Pn[k][0] = Pn[k][1] = 0;
+            tq[k][0] = valid && x0 + 4 * k < w;
+            tq[k][1] = valid && x0 + 4 * k + 2 < w;
+        }
 #pragma unroll
         for (int i = 0; i < NR / 2; ++i) {
             const int y = ys - 2 + 2 * i;
-            uint32_t An[2][2], Bn[2][2], s4[2] = {0, 0};
-            int Cs[2][2];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t C = qc[2 * i + r], LL = ql[2 * i + r], RR = qg[2 * i + r];
-                // position 0 sees (LL.b0, LL.b1, C.b0..b3), position 1 (C.b0..b3, RR.b0, RR.b1); weights are per byte, lowest first
-                An[r][0] = dot4(C, 0x00010101u, dot4(LL, 0x00000100u, 0));
-                Bn[r][0] = dot4(C, 0x01020303u, dot4(LL, 0x00000201u, 0));
-                Cs[r][0] = (int)dot4(C, 0x00000c0cu, 0) - (int)dot4(C, 0x01030000u, dot4(LL, 0x00000301u, 0));
-                An[r][1] = dot4(C, 0x01010100u, dot4(RR, 0x00000001u, 0));
-                Bn[r][1] = dot4(C, 0x03030201u, dot4(RR, 0x00000102u, 0));
-                Cs[r][1] = (int)dot4(C, 0x0c0c0000u, 0) - (int)dot4(C, 0x00000301u, dot4(RR, 0x00000103u, 0));
-                s4[0] = dot4(C, 0x00000101u, s4[0]);
-                s4[1] = dot4(C, 0x01010000u, s4[1]);
-            }
-            const bool emit = i >= 2 && y - 2 < ye && L.act_row(y - 2);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = Pp[q] - (int)Bn[0][q] - (int)An[1][q];
-                if (emit && L.mx[2 * q]) sa += (uint32_t)abs(f);
-                Pp[q] = Pn[q] + Cs[0][q] + Cs[1][q];
-                Pn[q] = -(int)An[0][q] - (int)Bn[1][q];
-            }
-            if (i >= 1 && i <= RS / 2 && y < ye) {
-                uint32_t s1[2] = {0, 0}, s2[2] = {0, 0};
+            for (int k = 0; k < NG; ++k) {
+                uint32_t An[2][2], Bn[2][2], s4[2] = {0, 0};
+                int Cs[2][2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const int k = 2 * (i - 1) + r;
-                    const uint32_t Cm = qc[2 * i + r] & vm, Rm = qr[k] & vm;
-                    oo = dot4(Cm, Cm, oo);
-                    rr2 = dot4(Rm, Rm, rr2);
-                    orr = dot4(Cm, Rm, orr);
-                    s1[0] = dot4(q1[k], 0x00000101u, s1[0]);
-                    s1[1] = dot4(q1[k], 0x01010000u, s1[1]);
-                    s2[0] = dot4(q2[k], 0x00000101u, s2[0]);
-                    s2[1] = dot4(q2[k], 0x01010000u, s2[1]);
+                    const uint32_t C = word(qc[2 * i + r], k);
+                    uint32_t LL, RR;
+                    sides(qc[2 * i + r], qe[2 * i + r], k, LL, RR);
+                    // position 0 sees (LL.b0, LL.b1, C.b0..b3), position 1 (C.b0..b3, RR.b0, RR.b1); weights are per byte, lowest first
+                    An[r][0] = dot4(C, 0x00010101u, dot4(LL, 0x00000100u, 0));
+                    Bn[r][0] = dot4(C, 0x01020303u, dot4(LL, 0x00000201u, 0));
+                    Cs[r][0] = (int)dot4(C, 0x00000c0cu, 0) - (int)dot4(C, 0x01030000u, dot4(LL, 0x00000301u, 0));
+                    An[r][1] = dot4(C, 0x01010100u, dot4(RR, 0x00000001u, 0));
+                    Bn[r][1] = dot4(C, 0x03030201u, dot4(RR, 0x00000102u, 0));
+                    Cs[r][1] = (int)dot4(C, 0x0c0c0000u, 0) - (int)dot4(C, 0x00000301u, dot4(RR, 0x00000103u, 0));
+                    s4[0] = dot4(C, 0x00000101u, s4[0]);
+                    s4[1] = dot4(C, 0x01010000u, s4[1]);
                 }
-                if (tmode) {  // diff1st / diff2nd :66-109
-                    const int c1 = tmode == 1 ? 1 : 2;
+                const bool emit = i >= 2 && y - 2 < ye && L.act_row(y - 2);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        if (tq[q]) ta += (uint32_t)abs((int)s4[q] - c1 * (int)s1[q] + (int)s2[q]);
+                for (int q = 0; q < 2; ++q) {
+                    const int f = Pp[k][q] - (int)Bn[0][q] - (int)An[1][q];
+                    if (emit && L.mx[4 * k + 2 * q]) sa += (uint32_t)abs(f);
+                    Pp[k][q] = Pn[k][q] + Cs[0][q] + Cs[1][q];
+                    Pn[k][q] = -(int)An[0][q] - (int)Bn[1][q];
+                }
+                if (i >= 1 && i <= RS / 2 && y < ye) {
+                    uint32_t s1[2] = {0, 0}, s2[2] = {0, 0};
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int kk = 2 * (i - 1) + r;
+                        const uint32_t Cm = word(qc[2 * i + r], k) & vm[k], Rm = word(qr[kk], k) & vm[k], T1 = word(q1[kk], k), T2 = word(q2[kk], k);
+                        oo = dot4(Cm, Cm, oo);
+                        rr2 = dot4(Rm, Rm, rr2);
+                        orr = dot4(Cm, Rm, orr);
+                        s1[0] = dot4(T1, 0x00000101u, s1[0]);
+                        s1[1] = dot4(T1, 0x01010000u, s1[1]);
+                        s2[0] = dot4(T2, 0x00000101u, s2[0]);
+                        s2[1] = dot4(T2, 0x01010000u, s2[1]);
+                    }
+                    if (tmode) {  // diff1st / diff2nd :66-109
+                        const int c1 = tmode == 1 ? 1 : 2;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            if (tq[k][q]) ta += (uint32_t)abs((int)s4[q] - c1 * (int)s1[q] + (int)s2[q]);
+                    }
                 }
             }
         }
@@ -712,7 +792,7 @@ __global__ __launch_bounds__(256) void xpsnr_weigh_kernel(const WArgs a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void xpsnr_strip_kernel(const XStripArgs a) {
+__global__ __launch_bounds__(256, 4) void xpsnr_strip_kernel(const XStripArgs a) {
     const int lane = threadIdx.x & 63;
     int sid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the strip geometry in SGPRs
     int c = 0;
@@ -740,10 +820,15 @@ __global__ __launch_bounds__(256) void xpsnr_strip_kernel(const XStripArgs a) {
                     luma_strip<T, 1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
                 else
                     luma_strip<T, 2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+            } else if (g.vec == 8) {
+                if (a.bv == 1)
+                    luma_strip_u8<1, 2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+                else
+                    luma_strip_u8<2, 2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
             } else if (a.bv == 1) {
-                luma_strip_u8<1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+                luma_strip_u8<1, 1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
             } else {
-                luma_strip_u8<2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
+                luma_strip_u8<2, 1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
             }
         } else if (a.bv == 1) {
             luma_strip<T, 1>(a, o, r, t1, t2, out, sx, brow, seg, lane);
@@ -951,7 +1036,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
                 }
                 return true;
             };
-            g.vec = luma ? 4 : (fits(4) ? 4 : fits(2) ? 2 : 1);
+            g.vec = luma ? (bps == 1 && sa.packed && fits(8) ? 8 : 4) : (fits(4) ? 4 : fits(2) ? 2 : 1);  // luma: 8 samples a lane where a block is whole 8-sample groups
             if (luma && !fits(4)) strips = false;
             const int rs = luma ? (p.b_val == 1 ? kRowsBv1 : kRowsBv2) : kRowsSse;
             const int nby = (g.h + g.by - 1) / g.by;
