@@ -264,6 +264,8 @@ struct StripHalo {
     }
 };
 
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+
 // SSE of a strip of an SSE-only plane (chroma; every plane when b < 4): calcSquaredError :214-251
 template <typename T, int VEC>
 __device__ __forceinline__ void sse_strip(const XGeo &g, GP<T> org, GP<T> rec, uint64_t *out, int sx, int brow, int seg, int lane) {
@@ -293,6 +295,47 @@ __device__ __forceinline__ void sse_strip(const XGeo &g, GP<T> org, GP<T> rec, u
             }
         }
     }
+    const int key = valid ? x0 / g.bx : -1;
+    sse = seg_reduce(sse, key, lane);
+    const int up = __shfl_up(key, 1, 64);
+    if (valid && (lane == 0 || up != key)) add_u64(out + g.out_off + (size_t)brow * g.nbx + key, sse);
+}
+
+// The same strip for 8-bit samples, 8 of them a lane, kept packed: SSE = sum(o*o) + sum(r*r) - 2 sum(o*r) from three
+// v_dot4_u32_u8 a group of 4 (each sum of a strip stays below 2^24).
+__device__ __forceinline__ void sse_strip_u8x8(const XGeo &g, GP<uint8_t> org, GP<uint8_t> rec, uint64_t *out, int sx, int brow, int seg, int lane) {
+    const int ys = brow * g.by + seg * kRowsSse, ye = min(min(ys + kRowsSse, brow * g.by + g.by), g.h);
+    if (ys >= ye) return;
+    const int x0 = (sx * 64 + lane) * 8;
+    const bool valid = x0 < g.w;
+    const int xl = valid ? x0 : 0;
+    u32x2 qo[kRowsSse], qr[kRowsSse];
+#pragma unroll
+    for (int i = 0; i < kRowsSse; ++i) {
+        const ptrdiff_t q = (ptrdiff_t)min(ys + i, g.h - 1) * g.stride + xl;
+        qo[i] = load_raw<uint8_t, 8>(org + q);
+        qr[i] = load_raw<uint8_t, 8>(rec + q);
+    }
+    uint32_t vm[2];  // bytes of each group of 4 inside the plane
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = !valid ? 0 : min(max(g.w - (x0 + 4 * k), 0), 4);
+        vm[k] = n >= 4 ? 0xffffffffu : (1u << (8 * n)) - 1u;
+    }
+    uint32_t oo = 0, rr = 0, orr = 0;
+#pragma unroll
+    for (int i = 0; i < kRowsSse; ++i) {
+        if (ys + i < ye) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t o = qo[i][k] & vm[k], r = qr[i][k] & vm[k];
+                oo = dot4(o, o, oo);
+                rr = dot4(r, r, rr);
+                orr = dot4(o, r, orr);
+            }
+        }
+    }
+    uint64_t sse = (uint64_t)(oo + rr - 2u * orr);
     const int key = valid ? x0 / g.bx : -1;
     sse = seg_reduce(sse, key, lane);
     const int up = __shfl_up(key, 1, 64);
@@ -500,7 +543,6 @@ __device__ __forceinline__ void luma_strip(const XStripArgs &a, GP<T> org, GP<T>
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s as_v2s(uint32_t v) { return __builtin_bit_cast(v2s, v); }
-__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 __device__ __forceinline__ uint32_t abs_dot2(v2s v, uint32_t mask, uint32_t acc) {  // acc + |v.lo| * mask.lo + |v.hi| * mask.hi
     const v2s a = __builtin_elementwise_max(v, -v);
     return __builtin_amdgcn_udot2(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, mask), acc, false);
@@ -535,7 +577,12 @@ __device__ __forceinline__ void luma_strip_u8(const XStripArgs &a, GP<uint8_t> o
         qc[i] = load_raw<uint8_t, PX>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + L.xc);
         qe[i] = 0;
     }
-    if (halo.edge) {
+#ifndef VSZIP_XPSNR_TIMING_NOEDGE
+    if (halo.edge)
+#else
+    if (false)
+#endif
+    {
 #pragma unroll
         for (int i = 0; i < NR; ++i) qe[i] = load_raw<uint8_t, BV>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + halo.x);
     }
@@ -835,6 +882,8 @@ __global__ __launch_bounds__(256, 4) void xpsnr_strip_kernel(const XStripArgs a)
         } else {
             luma_strip<T, 2>(a, o, r, t1, t2, out, sx, brow, seg, lane);
         }
+    } else if (g.vec == 8) {
+        if constexpr (sizeof(T) == 1) sse_strip_u8x8(g, o, r, out, sx, brow, seg, lane);
     } else if (g.vec == 4) {
         sse_strip<T, 4>(g, o, r, out, sx, brow, seg, lane);
     } else if (g.vec == 2) {
@@ -1036,7 +1085,7 @@ VSZIP_EXPORT int vszip_xpsnr_wsse_batch(vszip_ctx *ctx, int bytes_per_sample, in
                 }
                 return true;
             };
-            g.vec = luma ? (bps == 1 && sa.packed && fits(8) ? 8 : 4) : (fits(4) ? 4 : fits(2) ? 2 : 1);  // luma: 8 samples a lane where a block is whole 8-sample groups
+            g.vec = luma ? (bps == 1 && sa.packed && fits(8) ? 8 : 4) : (bps == 1 && sa.packed && fits(8) ? 8 : fits(4) ? 4 : fits(2) ? 2 : 1);  // luma: 8 samples a lane where a block is whole 8-sample groups
             if (luma && !fits(4)) strips = false;
             const int rs = luma ? (p.b_val == 1 ? kRowsBv1 : kRowsBv2) : kRowsSse;
             const int nby = (g.h + g.by - 1) / g.by;
