@@ -91,6 +91,22 @@ def test_yuv_fused_score_matches_oracle(dev, oracle, name, crop):
         assert got == pytest.approx(want, abs=TOL), (name, crop, align, got, want)
 
 
+@pytest.mark.parametrize("loc", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("name", ["YUV420P8", "YUV420P16", "YUV422P8"])
+def test_yuv_fused_score_every_siting(dev, oracle, name, loc):
+    """The fused pass under every _ChromaLocation, on a frame of several tiles each way: co-sited chroma (left / top) gives resampling
+    tables whose first tap is NOT monotonic (a sample that sits on a chroma sample has one non-zero tap, its neighbour four, starting
+    one sample earlier), and a tile's chroma rows / columns start at the SMALLEST first tap of its rows / columns (round 5: the tile
+    took its first row's, and top-sited clips read one row off)."""
+    bits, ssw, ssh, sample = FORMATS[name]
+    ref = _clip(bits, ssw, ssh, sample, None, loc)
+    dis = [vh.std_boxblur(p, 1, 1) for p in ref]
+    fmt = _fmt(dev, ref, bits, ssw, ssh, loc=loc)
+    got = dev.ssimulacra2_src(fmt, [dev.upload(p, 32) for p in ref], [dev.upload(p, 32) for p in dis])[0]
+    want = oracle.ssimulacra2(vh.yuv_to_linear_rgbs(ref, bits, ssw, ssh, 1, loc), vh.yuv_to_linear_rgbs(dis, bits, ssw, ssh, 1, loc))
+    assert got == pytest.approx(want, abs=TOL), (name, loc, got, want)
+
+
 @pytest.mark.parametrize("key", sorted(fx.ref_goldens()["yuv"]["ssimulacra2"]))
 def test_reference_goldens_from_raw_yuv(dev, key):
     """The reference's own YUV keys, computed by the GPU from the YUV planes (the fixture carries `_Matrix = 1`,

@@ -457,8 +457,18 @@ __device__ __forceinline__ void pyr_image_yuv(const PyrArgs &a, const YuvArgs &y
     const PyrGOut o2[3] = {(PyrGOut)pp.o2[0], (PyrGOut)pp.o2[1], (PyrGOut)pp.o2[2]};
     const int X0 = blockIdx.x * 256, Y0 = blockIdx.y * 16;
     const int ylast = min(Y0 + 15, a.h - 1);
-    const int r0 = ya.vleft ? ya.vleft[Y0] : Y0;
-    const int r1 = ya.vleft ? min(ya.vleft[ylast] + 3, ya.ch - 1) : ylast;
+    // the chroma rows the tile taps: from the SMALLEST first tap of its rows (co-sited chroma: a row that sits on a chroma row has one
+    // non-zero tap, the row below it four that start one row EARLIER - the table is not monotonic; round 5)
+    int r0 = Y0, r1 = ylast;
+    if (ya.vleft) {
+        r0 = ya.ch;
+        r1 = 0;
+        for (int y = Y0; y <= ylast; ++y) {
+            const int v = ya.vleft[y];
+            r0 = min(r0, v);
+            r1 = max(r1, min(v + 3, ya.ch - 1));
+        }
+    }
     // ---- phase A: chroma rows r0 .. r1 at full width into hbuf[plane][row - r0][column - X0]
     {
         const int t = threadIdx.x;
