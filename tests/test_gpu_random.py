@@ -299,3 +299,67 @@ def test_more_planes_than_one_kernel_table(dev, oracle):
     outs = dev.eedi3([dev.upload(p) for p in fl], 1)
     for i in (0, 47, 48, 59):
         assert np.array_equal(dev.download(outs[i]), oracle.eedi3(fl[i], 1))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ssim_yuv_sources_random(dev, oracle, seed):
+    """SSIMULACRA2 from YUV clips (round 5, after a fused-pass bug that only top-sited 4:2:0 showed): random subsampling, depth, chroma siting,
+    matrix, range and geometry (several tiles each way, ragged last tiles, odd pitches) - the conversion alone is BIT-EXACT against the
+    oracle's zimg restatement and the fused pass scores what the oracle scores on the oracle's converted planes."""
+    from oracle import vs_host as vh
+
+    rng = np.random.default_rng(SEED_BASE + 8000 + seed)
+    ssw, ssh = [(1, 1), (1, 1), (1, 0), (0, 0), (2, 2), (0, 1), (2, 0)][int(rng.integers(0, 7))]
+    bits, dtype = [(8, np.uint8), (10, np.uint16), (16, np.uint16), (32, np.float32)][int(rng.integers(0, 4))]
+    loc, matrix = int(rng.integers(0, 6)), int(rng.choice([1, 6, 9]))
+    limited = bool(rng.integers(0, 4))  # mostly limited range, like the clips VapourSynth hands over
+    h = int(rng.integers(3, 60 if seed % 3 else 180)) << max(ssh, 1)
+    w = int(rng.integers(3, 90 if seed % 3 else 300)) << max(ssw, 1)
+    cs = ((h + (1 << ssh) - 1) >> ssh, (w + (1 << ssw) - 1) >> ssw)
+
+    def clip():
+        if dtype == np.float32:
+            return [rng.random((h, w)).astype(np.float32)] + [(rng.random(cs) - 0.5).astype(np.float32) for _ in range(2)]
+        lo, hi = ((16 << (bits - 8), 235 << (bits - 8)) if limited else (0, (1 << bits) - 1))
+        y = fx.tiled_natural((h, w), np.uint16, seed % 3).astype(np.float64) / 65535.0
+        return [(lo + y * (hi - lo)).astype(dtype)] + [rng.integers(0, 1 << bits, size=cs).astype(dtype) for _ in range(2)]
+
+    ref = clip()
+    dis = [np.clip(p.astype(np.float64) + rng.normal(0, 0.01 * (1.0 if dtype == np.float32 else float(1 << bits)), p.shape), 0 if dtype != np.float32 else -0.5,
+                   1.0 if dtype == np.float32 else (1 << bits) - 1).astype(dtype) for p in ref]
+    fmt = dev.ssim_source("YUV", dtype, bits, True, limited=limited, ssw=ssw, ssh=ssh, matrix=matrix, chroma_loc=loc)
+    pitch = 1 if seed % 4 == 0 else 32
+    want_rgb = [vh.srgb_to_linear(p) for p in vh.yuv_to_rgbs(ref, bits, ssw, ssh, matrix, loc, limited=limited)]
+    got_rgb = [dev.download(d) for d in dev.to_rgbs_linear(fmt, [dev.upload(p, pitch) for p in ref])]
+    what = (seed, (h, w), (ssw, ssh), bits, loc, matrix, limited, pitch)
+    for c in range(3):
+        assert np.array_equal(got_rgb[c].view(np.uint32), want_rgb[c].view(np.uint32)), what + (c,)
+    if min(h, w) >= 8:
+        want_dis = [vh.srgb_to_linear(p) for p in vh.yuv_to_rgbs(dis, bits, ssw, ssh, matrix, loc, limited=limited)]
+        got = dev.ssimulacra2_src(fmt, [dev.upload(p, pitch) for p in ref], [dev.upload(p, pitch) for p in dis])[0]
+        assert got == pytest.approx(oracle.ssimulacra2(want_rgb, want_dis), abs=1e-7), what
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_xpsnr_batch_random(dev, oracle, seed):
+    """The strip kernel's lane widths (round 5: 8 pixels a lane where a block is whole 8-sample groups, 4 otherwise; halo samples from the
+    neighbouring lanes) over random even sizes on both sides of the 2048 x 1152 switch, both depths, 4:2:0 / 4:4:4 / 4:2:2, tight rows."""
+    rng = np.random.default_rng(SEED_BASE + 8500 + seed)
+    big = seed % 4 == 0
+    h = int(rng.integers(600, 700)) * 2 if big else int(rng.integers(9, 380)) * 2
+    w = int(rng.integers(900, 1100)) * 2 if big else int(rng.integers(9, 700)) * 2
+    ssw, ssh = [(1, 1), (0, 0), (1, 0)][int(rng.integers(0, 3))]
+    dtype, depth = [(np.uint8, 8), (np.uint16, 10)][int(rng.integers(0, 2))]
+    peak = (1 << depth) - 1
+    shapes = [(h, w), (h >> ssh, w >> ssw), (h >> ssh, w >> ssw)]
+    nf = 3
+    frames = [[rng.integers(0, peak + 1, size=s).astype(dtype) for s in shapes] for _ in range(nf)]
+    recs = [[np.clip(p.astype(np.int64) + rng.integers(-9, 10, p.shape), 0, peak).astype(dtype) for p in fr] for fr in frames]
+    fps = int(rng.choice([24, 60]))
+    want = [oracle.xpsnr_wsse(frames[n], recs[n], frames[n - 1][0] if n >= 1 else None, frames[n - 2][0] if n >= 2 else None, depth=depth, frame_rate=fps) for n in range(nf)]
+    pitch = 1 if seed % 3 == 0 else 256
+    dfr = [[dev.upload(p, pitch) for p in fr] for fr in frames]
+    drc = [[dev.upload(p, pitch) for p in fr] for fr in recs]
+    p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(nf)]
+    p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(nf)]
+    assert dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=depth, frame_rate=fps) == want, (seed, h, w, ssw, ssh, depth, fps, pitch)
