@@ -363,3 +363,46 @@ def test_xpsnr_batch_random(dev, oracle, seed):
     p1 = [dfr[n - 1][0] if n >= 1 else None for n in range(nf)]
     p2 = [dfr[n - 2][0] if n >= 2 else None for n in range(nf)]
     assert dev.xpsnr_wsse_batch(dfr, drc, p1, p2, depth=depth, frame_rate=fps) == want, (seed, h, w, ssw, ssh, depth, fps, pitch)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_point_filters_random(dev, oracle, seed):
+    """Limiter, LimitFilter (with and without the third clip) and AdaptiveBinarize: random plane sizes (down to one sample, odd pitches, several
+    planes a call), sample types, bounds and thresholds - bit-exact."""
+    rng = np.random.default_rng(SEED_BASE + 9500 + seed)
+    dtype = [np.uint8, np.uint16, np.float32][int(rng.integers(0, 3))]
+    n = int(rng.integers(1, 5))
+    shapes = [(int(rng.integers(1, 200)), int(rng.integers(1, 700))) for _ in range(n)]
+    peak = float(np.iinfo(dtype).max) if np.dtype(dtype).kind == "u" else 1.0
+    mk = lambda s: _plane(rng, s, dtype)
+    pitch = 1 if seed % 2 else 64
+    # Limiter
+    srcs = [mk(s) for s in shapes]
+    lo = [float(rng.uniform(0, 0.6)) * peak for _ in range(n)]
+    hi = [l + float(rng.uniform(0, 0.4)) * peak for l in lo]
+    if np.dtype(dtype).kind == "u":
+        lo, hi = [float(int(v)) for v in lo], [float(int(v)) for v in hi]
+    ds, dd = [dev.upload(p, pitch) for p in srcs], [dev.empty(s[0], s[1], dtype) for s in shapes]
+    dev.limiter(ds, dd, lo, hi)
+    for i in range(n):
+        assert np.array_equal(dev.download(dd[i]), oracle.limiter(srcs[i], lo[i], hi[i])), ("limiter", seed, i, shapes[i], lo[i], hi[i])
+    # LimitFilter
+    flts = [mk(s) for s in shapes]
+    refs = [mk(s) for s in shapes] if seed % 3 else None
+    dark = [float(rng.uniform(0, 0.05)) * peak for _ in range(n)]
+    bright = [float(rng.uniform(0, 0.05)) * peak for _ in range(n)]
+    elast = [float(rng.uniform(1.0, 4.0)) for _ in range(n)]
+    df, dr = [dev.upload(p, pitch) for p in flts], ([dev.upload(p, pitch) for p in refs] if refs else None)
+    dev.limit_filter(df, ds, dd, dark, bright, elast, refs=dr)
+    for i in range(n):
+        want = oracle.limit_filter(flts[i], srcs[i], refs[i] if refs else None, np.float32(dark[i]), np.float32(bright[i]), np.float32(elast[i]))
+        got = dev.download(dd[i])
+        assert np.array_equal(got.view(np.uint32) if dtype == np.float32 else got, want.view(np.uint32) if dtype == np.float32 else want), ("limit_filter", seed, i, shapes[i])
+    # AdaptiveBinarize (8-bit only)
+    a = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in shapes]
+    b = [np.clip(p.astype(np.int16) + rng.integers(-6, 7, p.shape), 0, 255).astype(np.uint8) for p in a]
+    c = int(rng.integers(0, 8))
+    da, db, do = [dev.upload(p, pitch) for p in a], [dev.upload(p, pitch) for p in b], [dev.empty(s[0], s[1], np.uint8) for s in shapes]
+    dev.adaptive_binarize(da, db, do, c)
+    for i in range(n):
+        assert np.array_equal(dev.download(do[i]), oracle.adaptive_binarize(a[i], b[i], c)), ("adaptive_binarize", seed, i, shapes[i], c)
