@@ -158,7 +158,7 @@ struct XGeo {     // strip decomposition of one plane
     int nsx;           // strips across (64 * vec samples each)
     int segs;          // row segments per block row
     int nstrips;       // nsx * segs * block rows
-    int vec;           // samples per lane on the SSE-only path (4, 2 or 1)
+    int vec;           // samples per lane: 8, 4, 2 or 1 on the SSE-only path, 8 or 4 on luma with activity sums
     int out_off;       // u64 index of this plane's block sums in a frame's result
 };
 
@@ -563,7 +563,7 @@ __device__ __forceinline__ void luma_strip_u8(const XStripArgs &a, GP<uint8_t> o
 #pragma unroll
     for (int k = 0; k < NG; ++k) vm[k] = !valid || x0 + 4 * k >= w ? 0u : (x0 + 4 * k + 3 < w ? 0xffffffffu : 0x0000ffffu);
     const int tmode = a.tmode;
-#ifdef VSZIP_XPSNR_TIMING_NOTEMP
+#ifdef VSZIP_XPSNR_TIMING_NOTEMP  // timing only (profiles/r05_notes.md 8): results are wrong
     const bool has1 = false, has2 = false;
 #else
     const bool has1 = p1 != nullptr, has2 = p1 != nullptr && p2 != nullptr;
@@ -577,7 +577,7 @@ __device__ __forceinline__ void luma_strip_u8(const XStripArgs &a, GP<uint8_t> o
         qc[i] = load_raw<uint8_t, PX>(org + (ptrdiff_t)min(max(ys - BV + i, 0), h - 1) * o + L.xc);
         qe[i] = 0;
     }
-#ifndef VSZIP_XPSNR_TIMING_NOEDGE
+#ifndef VSZIP_XPSNR_TIMING_NOEDGE  // (defined: timing only, results are wrong)
     if (halo.edge)
 #else
     if (false)
