@@ -107,6 +107,24 @@ def test_yuv_fused_score_every_siting(dev, oracle, name, loc):
     assert got == pytest.approx(want, abs=TOL), (name, loc, got, want)
 
 
+@pytest.mark.parametrize("loc", [0, 1, 2, 3])
+@pytest.mark.parametrize("bits,crop", [(8, None), (16, None), (10, None), (8, (316, 628)), (8, (136, 244)), (16, (64, 68))])
+def test_yuv420_split_pass_is_the_tile_kernel(dev, oracle, bits, crop, loc):
+    """4:2:0 integer clips (round 5) go through ssim_yuv420_rgb_kernel (persistent workgroups, transfer table in LDS, taps from the tables'
+    period; the frame's outermost tiles from the tables) + the f32 pyramid pass; VSZIP_SSIM_NO_YUV420_LDS=1 sends them through the fused tile
+    kernel like every other YUV format. Same f32 operations in the same order: the scores are EQUAL, for every chroma siting (co-sited
+    chroma makes the tables' first taps non-monotonic) and on frames of one tile, of ragged tiles and of several tiles each way."""
+    ref = _clip(bits, 1, 1, "int", crop, loc)
+    dis = [vh.std_boxblur(p, 1, 1) for p in ref]
+    fmt = _fmt(dev, ref, bits, 1, 1, loc=loc)
+    up = lambda ps: [dev.upload(p, 32) for p in ps]
+    got = dev.ssimulacra2_src(fmt, up(ref) + up(dis) + up(ref), up(dis) + up(ref) + up(ref))
+    with dev.options(VSZIP_SSIM_NO_YUV420_LDS=1):
+        tile = dev.ssimulacra2_src(fmt, up(ref) + up(dis) + up(ref), up(dis) + up(ref) + up(ref))
+    assert got == tile, (bits, crop, loc, got, tile)
+    assert got[2] > 99.9
+
+
 @pytest.mark.parametrize("key", sorted(fx.ref_goldens()["yuv"]["ssimulacra2"]))
 def test_reference_goldens_from_raw_yuv(dev, key):
     """The reference's own YUV keys, computed by the GPU from the YUV planes (the fixture carries `_Matrix = 1`,

@@ -198,6 +198,7 @@ struct PyrPair {
     float *x0a[3], *x0b[3];         // scale-0 XYB planes of frame 1 / 2 (NULL = pruned)
     float *x1a[3], *x1b[3];         // scale-1 XYB planes
     float *r2a[3], *r2b[3];         // scale-2 linear RGB
+    float *rgb1[3], *rgb2[3];       // 4:2:0 integer clips (round 5): the frames' linear RGB, written by ssim_yuv420_rgb_kernel, read by the f32 pass (PyrArgs::from_rgb)
 };
 
 struct PyrArgs {
@@ -206,6 +207,7 @@ struct PyrArgs {
     int lut_lds;        // PYR_INT: number of entries staged in LDS (0: gathered from global memory)
     int vec_ok;         // every source plane base and the row pitch are aligned to 4 samples, and w % 4 == 0
     int sstride;        // source row pitch, elements
+    int from_rgb;       // PYR_F32_LINEAR: the sources are the pair's rgb1 / rgb2 planes (dense rows of w floats), not src1 / src2
     int w, h, w1, h1, w2, h2;
     XybK k;
 };
@@ -393,6 +395,9 @@ __global__ __launch_bounds__(256) void ssim_pyr_kernel(const PyrArgs a) {
     for (int c = 0; c < 3; ++c) {
         f1.src[c] = tp->src1[c]; f1.o0[c] = tp->x0a[c]; f1.o1[c] = tp->x1a[c]; f1.o2[c] = tp->r2a[c];
         f2.src[c] = tp->src2[c]; f2.o0[c] = tp->x0b[c]; f2.o1[c] = tp->x1b[c]; f2.o2[c] = tp->r2b[c];
+        if constexpr (MODE == PYR_F32_LINEAR && !GRAY) {
+            if (a.from_rgb) f1.src[c] = tp->rgb1[c], f2.src[c] = tp->rgb2[c];
+        }
     }
     // workgroup-uniform: the whole 256 x 16 sample block is inside the plane and the planes allow vector accesses
     const bool fast = a.vec_ok && (int)(blockIdx.x + 1) * 256 <= a.w && (int)(blockIdx.y + 1) * 16 <= a.h;
@@ -597,6 +602,310 @@ __global__ __launch_bounds__(256) void ssim_pyr_yuv_kernel(const PyrArgs a, cons
     } else {
         pyr_image_yuv<T, false>(a, ya, f1, hbuf, bx, by);
         pyr_image_yuv<T, false>(a, ya, f2, hbuf, bx, by);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4:2:0 integer YUV sources, round 5: the colour pre-stage as a pass of its own, with persistent workgroups.
+// ssim_pyr_yuv_kernel spends 43 % of its time in the transfer table (48 gathers a thread from a 256 KB table: 40 GB of L2
+// requests a launch, the L2's request rate) and 25 % in phase A's single-sample loads. A table in LDS needs a workgroup that
+// lives long enough to pay for loading it, and one that owns a CU's LDS cannot also hold the XYB conversion's 120+ registers
+// at a useful occupancy (a fused persistent kernel was built first: no faster, profiles/r05_notes.md 9). So the work is split:
+// ssim_yuv420_rgb_kernel (here: one workgroup a CU, the table's [0, 1] range + margins in LDS, the rest in global memory)
+// writes each frame's LINEAR RGB planes, and ssim_pyr_kernel<float, PYR_F32_LINEAR> (PyrArgs::from_rgb) reads them back -
+// 200 MB a 4K pair through HBM, both passes at rates the fused kernel is far from.
+// A workgroup is TEAMS teams of 256 threads; a team takes a tile of 256 x 16 luma samples: its raw chroma samples (<= 12 rows
+// of <= 132 a plane) and luma samples are fetched one tile AHEAD into registers with whole-dword loads and parked in the team's
+// LDS slice; every thread filters what its 4 x 4 block needs straight from there - horizontal 4-tap on the 6 chroma
+// rows the block touches, then the vertical 4-tap, both in zimg's order (yuv_two_acc): no plane of horizontally filtered rows.
+// Tiles whose columns and rows all follow the resampling tables' period (the frame's interior) take taps and coefficients from
+// the kernel argument; the outermost tiles go through a second launch of the same kernel (EDGE) that reads the tables and
+// clamps like ssim_pyr_yuv_kernel - a path of its own, because its table values cost the interior's a wave a SIMD, and as a
+// called function its spills landed on the common path (scratch reloads share the loads' counter). Same f32 operations in the same order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kYlRows = 12;  // chroma rows a 16-row luma tile of a 4:2:0 clip taps at most
+constexpr int kYlNr = 6;     // ... and a 4-row luma block
+
+struct YuvLds {
+    const int *hspan, *vspan;  // [2 * tile column] / [2 * tile row]: first and last chroma column / row the tile taps
+    int dh[4], dv[4];          // regular columns / rows: first tap of sample x0 + i = (x0 >> 1) + dh[i], x0 a multiple of 4
+    float ch[4][4], cv[4][4];  // ... and their coefficients
+    int xr0, xr1, yr0, yr1;    // the regular ranges [xr0, xr1) x [yr0, yr1), multiples of 4
+    int tx0, tx1, ty0, ty1;    // the interior: tiles [tx0, tx1) x [ty0, ty1) are whole, vector-aligned and regular in both axes
+    int lut_lo, lut_n;         // LDS holds lut[lut_lo, lut_lo + lut_n)
+    int low_zero;              // lut[0 .. lut_lo] are all 0.0f: an index below the range reads entry lut_lo
+    int nbx, nby, ntiles;      // tiles across and down a frame; tiles of the launch (pairs x 2 frames x the interior's, or the rest's, tiles)
+};
+
+template <typename T>
+struct YlGeo {
+    static constexpr int B = (int)sizeof(T);
+    static constexpr int PD = B == 1 ? 36 : 68;            // dwords a staged chroma row: 132 samples + alignment slack
+    static constexpr int RAW_DW = 2 * kYlRows * PD;        // one tile's raw chroma, both planes
+    static constexpr int NLD = (RAW_DW + 255) / 256;       // staging loads a thread
+    static constexpr int TEAMS = B == 1 ? 4 : 3;           // what leaves (most of) the table's [0, 1] range room in 160 KB
+};
+
+constexpr int kYlEdgeTeams = 2;  // the EDGE launch: its table values and selects want 256 registers a thread
+template <typename T, bool EDGE>  // EDGE: the launch over the frame's outermost tiles (everything outside the interior)
+__global__ __launch_bounds__(256 * (EDGE ? kYlEdgeTeams : YlGeo<T>::TEAMS)) void ssim_yuv420_rgb_kernel(const PyrArgs a, const YuvArgs ya, const YuvLds yl) {
+    using G = YlGeo<T>;
+    constexpr int B = G::B, PD = G::PD, RAW_DW = G::RAW_DW, NLD = G::NLD, TEAMS = EDGE ? kYlEdgeTeams : G::TEAMS;
+    typedef const T __attribute__((address_space(1))) *GSrc;
+    typedef const uint32_t __attribute__((address_space(1))) *GDw;
+    typedef const float __attribute__((address_space(3))) *LdsF;
+    typedef const float __attribute__((address_space(1))) *GblF;
+    extern __shared__ __attribute__((aligned(16))) uint32_t yl_lds[];
+    float *lut = reinterpret_cast<float *>(yl_lds);
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), t = threadIdx.x & 255;
+    const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint32_t *cur_raw = yl_lds + ((yl.lut_n + 3) & ~3) + team * RAW_DW;  // (one slice a team: a second one would cost the table 3 400 entries of its upper end)
+    for (int i = threadIdx.x; i < yl.lut_n; i += 256 * TEAMS) lut[i] = a.lut[yl.lut_lo + i];
+
+    const int tw = yl.tx1 - yl.tx0, th = yl.ty1 - yl.ty0;
+    const int n_top = yl.nbx * yl.ty0, n_bottom = yl.nbx * (yl.nby - yl.ty1), side = yl.nbx - tw;  // EDGE: full rows above and below, the columns either side
+    const int tiles_a_frame = EDGE ? n_top + n_bottom + th * side : tw * th, stride = gridDim.x * TEAMS;
+    // one tile's geometry (team-uniform) and this thread's fetched samples
+    struct Tile {
+        int bxt, byt, z, f, cba, r0, r1;
+        bool on, fast;
+        uint32_t c[NLD], y[4][B];
+    };
+    auto fetch = [&](int id, Tile &q) {
+        q.on = id < yl.ntiles;
+        if (!q.on) return;
+        const int fr = id / tiles_a_frame, rem = id - fr * tiles_a_frame;
+        q.z = fr >> 1;
+        q.f = fr & 1;
+        if constexpr (!EDGE) {
+            const int ty = rem / tw;
+            q.byt = yl.ty0 + ty;
+            q.bxt = yl.tx0 + rem - ty * tw;
+        } else if (rem < n_top + n_bottom) {
+            const int e = rem < n_top ? rem : rem - n_top, ty = e / yl.nbx;
+            q.byt = rem < n_top ? ty : yl.ty1 + ty;
+            q.bxt = e - ty * yl.nbx;
+        } else {
+            const int e = rem - n_top - n_bottom, ty = e / side, c = e - ty * side;
+            q.byt = yl.ty0 + ty;
+            q.bxt = c < yl.tx0 ? c : yl.tx1 + (c - yl.tx0);
+        }
+        q.r0 = yl.vspan[2 * q.byt];
+        q.r1 = yl.vspan[2 * q.byt + 1];
+        q.cba = (yl.hspan[2 * q.bxt] * B) & ~3;  // bytes
+        q.fast = !EDGE || (a.vec_ok && (q.bxt + 1) * 256 <= a.w && (q.byt + 1) * 16 <= a.h);
+        const PyrPair *__restrict__ tp = a.tab + q.z;
+        const int crow_bytes = ya.cw * B;  // a multiple of 4 (host-checked): whole dwords never leave a row
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = t + 256 * k, prow = idx / PD, dcol = idx - prow * PD;
+            const int pl = prow >= kYlRows ? 1 : 0, row = prow - pl * kYlRows;
+            q.c[k] = 0;
+            if (idx < RAW_DW && q.cba + 4 * dcol < crow_bytes) {
+                const char *base = static_cast<const char *>(q.f ? tp->src2[1 + pl] : tp->src1[1 + pl]);
+                q.c[k] = *(GDw)(base + (size_t)min(q.r0 + row, q.r1) * ya.cstride * B + q.cba + 4 * dcol);
+            }
+        }
+        if (q.fast) {
+            const char *base = static_cast<const char *>(q.f ? tp->src2[0] : tp->src1[0]);
+            const int x0 = (q.bxt * 64 + lane) * 4, y0 = (q.byt * 4 + wv) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < B; ++j) q.y[r][j] = *(GDw)(base + ((size_t)(y0 + r) * a.sstride + x0) * B + 4 * j);
+        }
+    };
+
+    Tile nx;
+    int id = blockIdx.x * TEAMS + team;
+    fetch(id, nx);
+    const int rounds = (yl.ntiles + stride - 1) / stride;  // the same for every team: the barrier below is the whole workgroup's
+    int dvmin = yl.dv[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) dvmin = min(dvmin, yl.dv[r]);
+    for (int round = 0; round < rounds; ++round, id += stride) {
+        if (round) __syncthreads();  // every wave is done with the previous tile's samples
+        if (nx.on) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k)
+                if (t + 256 * k < RAW_DW) cur_raw[t + 256 * k] = nx.c[k];
+        }
+        __syncthreads();  // (also: the table is in place before the first tile)
+        const Tile q = nx;
+        fetch(id + stride, nx);
+        if (!q.on) continue;
+
+        const PyrPair *__restrict__ tp = a.tab + q.z;
+        typedef float __attribute__((address_space(1))) *GOut;
+        GOut out[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = (GOut)(q.f ? tp->rgb2[c] : tp->rgb1[c]);
+        const int bx = q.bxt * 64 + lane, by = q.byt * 4 + wv, x0 = bx * 4, y0 = by * 4;
+        if (!q.fast && !(x0 < a.w && y0 < a.h)) continue;
+        float uv[2][4][4];
+        if constexpr (!EDGE) {
+            // Byte offset, in a staged row, of the first tap of each of the block's 4 columns (no clamp: the taps are inside the plane). The 16
+            // taps of a row lie within NW aligned dwords from the first one's: those are read whole and each column's 4 samples cut out with
+            // v_alignbyte (sample-wise LDS reads at odd byte addresses kept the LDS pipe busy 20 cycles an instruction).
+            constexpr int NW = B == 1 ? 3 : 4;  // (host-checked: dh spans at most 2 samples)
+            int tb[4], tbmin;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tb[i] = ((x0 >> 1) + yl.dh[i]) * B - q.cba;
+            tbmin = min(min(tb[0], tb[1]), min(tb[2], tb[3])) & ~3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tb[i] -= tbmin;  // 0 .. 4 NW - 4 B
+            const int jrow = (y0 >> 1) + dvmin - q.r0;  // the block's first chroma row in the staged tile
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const char *row0 = reinterpret_cast<const char *>(cur_raw + pl * kYlRows * PD) + jrow * (PD * 4) + tbmin;
+                float hv[kYlNr][4];
+#pragma unroll
+                for (int jr = 0; jr < kYlNr; ++jr) {
+                    uint32_t d[NW + 1];
+#pragma unroll
+                    for (int m = 0; m < NW; ++m) d[m] = *reinterpret_cast<const uint32_t *>(row0 + jr * (PD * 4) + 4 * m);
+                    d[NW] = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // the 4 B bytes from offset tb[i]: dwords tb[i] / 4 .. of d, shifted by tb[i] % 4 bytes
+                        uint32_t wlo = d[0], wmd = d[1], whi = d[2];
+#pragma unroll
+                        for (int m = 1; m + 1 < NW; ++m)
+                            if ((tb[i] >> 2) == m) wlo = d[m], wmd = d[m + 1], whi = d[m + 2];
+                        const uint32_t s0 = __builtin_amdgcn_alignbyte(wmd, wlo, (uint32_t)tb[i] & 3u);
+                        float x[4];
+                        if constexpr (B == 1) {
+                            x[0] = yuv_cvt<uint8_t>((uint8_t)(s0 & 0xffu), ya.cs, ya.co); x[1] = yuv_cvt<uint8_t>((uint8_t)((s0 >> 8) & 0xffu), ya.cs, ya.co);
+                            x[2] = yuv_cvt<uint8_t>((uint8_t)((s0 >> 16) & 0xffu), ya.cs, ya.co); x[3] = yuv_cvt<uint8_t>((uint8_t)(s0 >> 24), ya.cs, ya.co);
+                        } else {
+                            const uint32_t s1 = __builtin_amdgcn_alignbyte(whi, wmd, (uint32_t)tb[i] & 3u);
+                            x[0] = yuv_cvt<uint16_t>((uint16_t)(s0 & 0xffffu), ya.cs, ya.co); x[1] = yuv_cvt<uint16_t>((uint16_t)(s0 >> 16), ya.cs, ya.co);
+                            x[2] = yuv_cvt<uint16_t>((uint16_t)(s1 & 0xffffu), ya.cs, ya.co); x[3] = yuv_cvt<uint16_t>((uint16_t)(s1 >> 16), ya.cs, ya.co);
+                        }
+                        hv[jr][i] = yuv_two_acc(yl.ch[i][0], yl.ch[i][1], yl.ch[i][2], yl.ch[i][3], x[0], x[1], x[2], x[3]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = yl.dv[r] - dvmin;  // uniform: 0 .. kYlNr - 4
+#pragma unroll
+                    for (int bb = 0; bb <= kYlNr - 4; ++bb)
+                        if (b == bb) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                uv[pl][r][i] = yuv_two_acc(yl.cv[r][0], yl.cv[r][1], yl.cv[r][2], yl.cv[r][3], hv[bb][i], hv[bb + 1][i], hv[bb + 2][i], hv[bb + 3][i]);
+                        }
+                }
+            }
+        } else {
+            // taps and coefficients out of the tables, samples clamped like ssim_pyr_yuv_kernel's; the vertical taps picked out of the kYlNr
+            // filtered rows with (wave-uniform) selects
+            int jmin = ya.ch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) jmin = min(jmin, ya.vleft[min(y0 + r, a.h - 1)]);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const char *plane = reinterpret_cast<const char *>(cur_raw + pl * kYlRows * PD);
+                float hv[kYlNr][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int X = min(x0 + i, a.w - 1), hl = ya.hleft[X];
+                    const v4f c = *reinterpret_cast<const v4f *>(ya.hcoef + 4 * (size_t)X);
+                    int to[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) to[k] = min(hl + k, ya.cw - 1) * B - q.cba;
+#pragma unroll
+                    for (int jr = 0; jr < kYlNr; ++jr) {
+                        const char *row = plane + (min(jmin + jr, q.r1) - q.r0) * (PD * 4);
+                        float x[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {  // (the sample out of its aligned dword: sample-wise reads at odd addresses are slow)
+                            const uint32_t dw = *reinterpret_cast<const uint32_t *>(row + (to[k] & ~3));
+                            const uint32_t sv = B == 1 ? (dw >> (8 * (to[k] & 3))) & 0xffu : (dw >> (8 * (to[k] & 2))) & 0xffffu;
+                            x[k] = yuv_cvt<T>((T)sv, ya.cs, ya.co);
+                        }
+                        hv[jr][i] = yuv_two_acc(c.x, c.y, c.z, c.w, x[0], x[1], x[2], x[3]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = min(y0 + r, a.h - 1), vl = ya.vleft[y];
+                    const v4f c = *reinterpret_cast<const v4f *>(ya.vcoef + 4 * (size_t)y);
+                    float x[4][4];  // [tap][column]: chroma row min(vl + k, ch - 1), one of the kYlNr rows from jmin
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int jj = min(vl + k, ya.ch - 1) - jmin;
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            float v = hv[0][ii];
+#pragma unroll
+                            for (int bb = 1; bb < kYlNr; ++bb) v = jj == bb ? hv[bb][ii] : v;
+                            x[k][ii] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) uv[pl][r][ii] = yuv_two_acc(c.x, c.y, c.z, c.w, x[0][ii], x[1][ii], x[2][ii], x[3][ii]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float yy[4];
+            if (q.fast) {
+                if constexpr (B == 1) {
+                    const uint32_t v = q.y[r][0];
+                    yy[0] = yuv_cvt<uint8_t>((uint8_t)(v & 0xffu), ya.ys, ya.yo); yy[1] = yuv_cvt<uint8_t>((uint8_t)((v >> 8) & 0xffu), ya.ys, ya.yo);
+                    yy[2] = yuv_cvt<uint8_t>((uint8_t)((v >> 16) & 0xffu), ya.ys, ya.yo); yy[3] = yuv_cvt<uint8_t>((uint8_t)(v >> 24), ya.ys, ya.yo);
+                } else {
+                    const uint32_t v0 = q.y[r][0], v1 = q.y[r][B - 1];
+                    yy[0] = yuv_cvt<uint16_t>((uint16_t)(v0 & 0xffffu), ya.ys, ya.yo); yy[1] = yuv_cvt<uint16_t>((uint16_t)(v0 >> 16), ya.ys, ya.yo);
+                    yy[2] = yuv_cvt<uint16_t>((uint16_t)(v1 & 0xffffu), ya.ys, ya.yo); yy[3] = yuv_cvt<uint16_t>((uint16_t)(v1 >> 16), ya.ys, ya.yo);
+                }
+            } else {
+                const GSrc row = (GSrc)(q.f ? tp->src2[0] : tp->src1[0]) + (size_t)min(y0 + r, a.h - 1) * a.sstride;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yy[i] = yuv_cvt<T>(row[min(x0 + i, a.w - 1)], ya.ys, ya.yo);
+            }
+            // The row's 12 lookups: out of LDS (typed address spaces: a select between two generic pointers would turn every lookup into a flat
+            // load); entries outside the staged range are fetched afterwards, all twelve loads of a row behind ONE branch (a branch and a
+            // wait per lookup made the kernel four times slower: out-of-gamut samples are common in converted video). low_zero: the table is
+            // 0 up to lut_lo (zimg clamps negative input first), so only values beyond the range's upper end leave LDS.
+            float lin[3][4];
+            int ti[3][4];
+            bool out_of_lds = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float g = fmaf(ya.m[3 * c + 2], uv[1][r][i], fmaf(ya.m[3 * c + 1], uv[0][r][i], ya.m[3 * c] * yy[i]));
+                    float tt = rintf(fmaf(g, 32768.0f, 16384.0f));
+                    tt = fminf(fmaxf(tt, 0.0f), 65536.0f);
+                    int li = (int)tt - yl.lut_lo;
+                    if (yl.low_zero) li = max(li, 0);
+                    lin[c][i] = ((LdsF)lut)[min((uint32_t)li, (uint32_t)yl.lut_n - 1u)];
+                    const bool beyond = (uint32_t)li >= (uint32_t)yl.lut_n;
+                    ti[c][i] = beyond ? (int)tt : -1;
+                    out_of_lds = out_of_lds || beyond;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(out_of_lds) != 0) {  // (a wave-level branch: a lane-level one was if-converted into twelve loads a row, always)
+                asm volatile("" ::: "memory");
+                float gl[3][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gl[c][i] = ((GblF)a.lut)[max(ti[c][i], 0)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) lin[c][i] = ti[c][i] >= 0 ? gl[c][i] : lin[c][i];
+            }
+            if (q.fast || y0 + r < a.h) {
+                const size_t o = (size_t)(y0 + r) * a.w + x0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pyr_put4(out[c], o, q.fast, a.w - x0, lin[c][0], lin[c][1], lin[c][2], lin[c][3]);
+            }
+        }
     }
 }
 
@@ -1298,6 +1607,16 @@ static const std::vector<float> &srgb_table() {
     }();
     return t;
 }
+// the table's leading zeros (negative input is clamped first): entries [0, n] are 0.0f - what ssim_yuv420_rgb_kernel need not stage
+static int srgb_table_zero_upto() {
+    static const int n = [] {
+        const std::vector<float> &v = srgb_table();
+        int k = 0;
+        while (v[0] == 0.0f && k + 1 < 65537 && v[k + 1] == 0.0f) ++k;
+        return k;
+    }();
+    return n;
+}
 static float srgb_lookup(float x) {
     float t = std::nearbyintf(x * 32768.0f + 16384.0f);
     t = std::min(std::max(t, 0.0f), 65536.0f);
@@ -1320,6 +1639,11 @@ struct SsimLutCache {
     int yw = 0, yh = 0, yssw = -1, yssh = -1, yloc = -1;
     char *ydev = nullptr;
     size_t ybytes = 0;
+    // ... and, for 4:2:0, what ssim_yuv420_rgb_kernel needs of them (ssim_yuv420_plan); yl_ok: the tables fit its assumptions
+    bool yl_ok = false;
+    YuvLds yl{};
+    int yl_span = 0;       // widest tile span, chroma samples
+    int yl_lds_limit = 0;  // bytes of LDS a workgroup may take (0: not asked yet, < 0: the attribute call failed)
 };
 
 SsimLutCache *lut_cache_of(vszip_ctx *ctx) {
@@ -1412,12 +1736,72 @@ static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_
     return VSZIP_OK;
 }
 
+// 4:2:0: tile spans, the tables' period and the range of columns / rows that follow it, from the host copy of the
+// resampling tables (left[w] | left[h] | coef[4 w] | coef[4 h]); spans[] receives hspan[2 nbx] | vspan[2 nby]. A table's first tap is
+// NOT monotonic when chroma is co-sited (a sample on a chroma sample has one non-zero tap, its neighbour four that start one earlier):
+// spans are min / max over the tile.
+static bool ssim_yuv420_plan(const int32_t *hleft, const float *hcoef, const int32_t *vleft, const float *vcoef, int w, int h, int cw, int ch, YuvLds *yl, int *span,
+                             std::vector<int32_t> *spans) {
+    if (w < 8 || h < 8) return false;
+    const int nbx = (w + 255) / 256, nby = (h + 15) / 16;
+    spans->assign((size_t)2 * nbx + 2 * nby, 0);
+    *span = 0;
+    for (int b = 0; b < nbx; ++b) {
+        int lo = INT32_MAX, hi = 0;
+        for (int X = b * 256; X < std::min(b * 256 + 256, w); ++X) lo = std::min(lo, hleft[X]), hi = std::max(hi, std::min(hleft[X] + 3, cw - 1));
+        if (lo < 0) return false;
+        (*spans)[2 * b] = lo;
+        (*spans)[2 * b + 1] = hi;
+        *span = std::max(*span, hi - lo + 1);
+    }
+    for (int b = 0; b < nby; ++b) {
+        int lo = INT32_MAX, hi = 0;
+        for (int y = b * 16; y < std::min(b * 16 + 16, h); ++y) lo = std::min(lo, vleft[y]), hi = std::max(hi, std::min(vleft[y] + 3, ch - 1));
+        if (lo < 0 || hi - lo + 1 > kYlRows) return false;
+        (*spans)[2 * nbx + 2 * b] = lo;
+        (*spans)[2 * nbx + 2 * b + 1] = hi;
+    }
+    for (int y0 = 0; y0 < h; y0 += 4) {  // a 4-row block's taps: kYlNr chroma rows from the smallest first tap
+        int lo = INT32_MAX, hi = 0;
+        for (int y = y0; y < y0 + 4; ++y) lo = std::min(lo, vleft[std::min(y, h - 1)]), hi = std::max(hi, std::min(vleft[std::min(y, h - 1)] + 3, ch - 1));
+        if (hi - lo + 1 > kYlNr) return false;
+    }
+    auto period = [](const int32_t *left, const float *coef, int n, int cn, int *d, float (*c)[4], int *r0, int *r1) {
+        const int ref = ((n / 2) / 4) * 4;
+        for (int i = 0; i < 4; ++i) {
+            d[i] = left[ref + i] - (ref >> 1);  // first tap of sample x0 + i = (x0 >> 1) + d[i], x0 a multiple of 4
+            std::memcpy(c[i], coef + 4 * (size_t)(ref + i), 16);
+        }
+        auto regular = [&](int x) {
+            const int i = x & 3;
+            return left[x] == ((x - i) >> 1) + d[i] && left[x] + 3 <= cn - 1 && std::memcmp(coef + 4 * (size_t)x, c[i], 16) == 0;
+        };
+        int lo = ref, hi = ref;
+        while (hi < n && regular(hi)) ++hi;
+        while (lo > 0 && regular(lo - 1)) --lo;
+        *r0 = (lo + 3) & ~3;
+        *r1 = hi == n ? n : (hi & ~3);
+    };
+    period(hleft, hcoef, w, cw, yl->dh, yl->ch, &yl->xr0, &yl->xr1);
+    period(vleft, vcoef, h, ch, yl->dv, yl->cv, &yl->yr0, &yl->yr1);
+    int dvmin = yl->dv[0], dvmax = yl->dv[0];
+    for (int r = 1; r < 4; ++r) dvmin = std::min(dvmin, yl->dv[r]), dvmax = std::max(dvmax, yl->dv[r]);
+    if (dvmax - dvmin > kYlNr - 4) return false;
+    int dhmin = yl->dh[0], dhmax = yl->dh[0];
+    for (int i = 1; i < 4; ++i) dhmin = std::min(dhmin, yl->dh[i]), dhmax = std::max(dhmax, yl->dh[i]);
+    if (dhmax - dhmin > 2) return false;  // (the interior path reads a row's 16 taps out of 3 / 4 aligned dwords)
+    yl->nbx = nbx;
+    yl->nby = nby;
+    return true;
+}
+
 // YUV sources: the kernel arguments of one clip geometry — resampling tables resident (cached in the context),
 // zimg's conversion constants and matrix.
 static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, int h, YuvArgs *ya) {
     const int cw = (w + (1 << fmt->ssw) - 1) >> fmt->ssw, ch = (h + (1 << fmt->ssh) - 1) >> fmt->ssh;
     SsimLutCache *lc = lut_cache_of(ctx);
-    const size_t off_v = (size_t)w * 4, off_hc = off_v + (size_t)h * 4, off_vc = off_hc + (size_t)w * 16, bytes = off_vc + (size_t)h * 16;
+    const size_t off_v = (size_t)w * 4, off_hc = off_v + (size_t)h * 4, off_vc = off_hc + (size_t)w * 16, off_sp = off_vc + (size_t)h * 16;
+    const size_t bytes = off_sp + ((size_t)(w + 255) / 256 + (size_t)(h + 15) / 16) * 8;  // + hspan | vspan (ssim_yuv420_plan)
     if (!(lc->yw == w && lc->yh == h && lc->yssw == fmt->ssw && lc->yssh == fmt->ssh && lc->yloc == fmt->chroma_loc)) {
         std::vector<char> host(bytes);
         // Position of a sited chroma sample relative to the centre of its 2^ss luma samples, in luma samples, by zimg's
@@ -1440,6 +1824,13 @@ static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, in
             const int rc = vszip_resample_table(ch, h, -offset(fmt->ssh, true) / (1 << fmt->ssh), reinterpret_cast<int32_t *>(host.data() + off_v), reinterpret_cast<float *>(host.data() + off_vc));
             if (rc != VSZIP_OK) return vszip_set_error(ctx, rc, "SSIMULACRA2: no vertical resampling table for %d -> %d", ch, h);
         }
+        lc->yl_ok = false;
+        if (fmt->ssw == 1 && fmt->ssh == 1) {
+            std::vector<int32_t> spans;
+            lc->yl_ok = ssim_yuv420_plan(reinterpret_cast<const int32_t *>(host.data()), reinterpret_cast<const float *>(host.data() + off_hc), reinterpret_cast<const int32_t *>(host.data() + off_v),
+                                         reinterpret_cast<const float *>(host.data() + off_vc), w, h, cw, ch, &lc->yl, &lc->yl_span, &spans);
+            if (lc->yl_ok) std::memcpy(host.data() + off_sp, spans.data(), spans.size() * 4);
+        }
         VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a launch still reading the old tables
         if (lc->ybytes < bytes) {
             if (lc->ydev) (void)hipFree(lc->ydev);
@@ -1450,6 +1841,10 @@ static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, in
         }
         VSZIP_HIP_CHECK(ctx, hipMemcpy(lc->ydev, host.data(), bytes, hipMemcpyHostToDevice));
         lc->yw = w; lc->yh = h; lc->yssw = fmt->ssw; lc->yssh = fmt->ssh; lc->yloc = fmt->chroma_loc;
+    }
+    if (lc->yl_ok) {
+        lc->yl.hspan = reinterpret_cast<const int *>(lc->ydev + off_sp);
+        lc->yl.vspan = lc->yl.hspan + 2 * lc->yl.nbx;
     }
     ya->hleft = fmt->ssw ? reinterpret_cast<const int *>(lc->ydev) : nullptr;
     ya->vleft = fmt->ssh ? reinterpret_cast<const int *>(lc->ydev + off_v) : nullptr;
@@ -1510,6 +1905,31 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         if (rc != VSZIP_OK) return rc;
     }
 
+    // 4:2:0 integer clips whose tables and planes fit ssim_yuv420_rgb_kernel: the colour pre-stage as a pass of its own (200 MB of scratch a 4K pair more)
+    bool split = false;
+    int yl_teams = 0, yl_pd = 0;
+    if (mode == PYR_YUV) {
+        SsimLutCache *lc = lut_cache_of(ctx);
+        const int B = fmt->dtype == VSZIP_U8 ? 1 : 2;
+        yl_teams = B == 1 ? YlGeo<uint8_t>::TEAMS : YlGeo<uint16_t>::TEAMS;
+        yl_pd = B == 1 ? YlGeo<uint8_t>::PD : YlGeo<uint16_t>::PD;
+        split = lc->yl_ok && !ctx->opt.ssim_no_yuv420_lds && fmt->linearize && (fmt->dtype == VSZIP_U8 || fmt->dtype == VSZIP_U16) && lc->yl_lds_limit >= 0 && (w & 3) == 0 &&
+                (ya.cw * B) % 4 == 0 && ((size_t)ya.cstride * B) % 4 == 0 && lc->yl_span * B + 3 <= yl_pd * 4;
+        for (int i = 0; split && i < npairs; ++i)
+            for (int c = 1; c < 3; ++c)
+                if ((reinterpret_cast<uintptr_t>(ref_planes[i * nsp + c]) | reinterpret_cast<uintptr_t>(dis_planes[i * nsp + c])) & 3) split = false;
+        if (split && lc->yl_lds_limit == 0) {  // once a context: may a workgroup take the whole LDS?
+            const int want = 160 * 1024;
+            bool ok = true;
+            for (const void *fn : {reinterpret_cast<const void *>(ssim_yuv420_rgb_kernel<uint8_t, false>), reinterpret_cast<const void *>(ssim_yuv420_rgb_kernel<uint8_t, true>),
+                                   reinterpret_cast<const void *>(ssim_yuv420_rgb_kernel<uint16_t, false>), reinterpret_cast<const void *>(ssim_yuv420_rgb_kernel<uint16_t, true>)})
+                ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+            (void)hipGetLastError();
+            lc->yl_lds_limit = ok ? want : -1;
+            split = ok;
+        }
+    }
+
     int sw[kScales + 1], sh[kScales + 1];
     sw[0] = w;
     sh[0] = h;
@@ -1526,7 +1946,8 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     }
     const int tiles0 = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
     const size_t f_x0 = 2 * nneed[0] * npx[0], f_x1 = 2 * nneed[1] * npx[1], f_r2 = 6 * npx[2], f_xs = 6 * npx[2], f_r3 = 6 * npx[3], f_r4 = 6 * npx[4];
-    const size_t f_pair = (f_x0 + f_x1 + f_r2 + f_xs + f_r3 + f_r4 + 63) & ~(size_t)63;
+    const size_t f_rgb = split ? 6 * npx[0] : 0;  // the two frames' linear RGB between the pre-stage pass and the pyramid pass
+    const size_t f_pair = (f_x0 + f_x1 + f_r2 + f_xs + f_r3 + f_r4 + f_rgb + 63) & ~(size_t)63;
     const size_t bytes_part = ((size_t)npairs * 18 * tiles0 * 6 * sizeof(double) + 255) & ~(size_t)255;
     const size_t bytes_avg = ((size_t)npairs * 18 * 6 * sizeof(double) + 255) & ~(size_t)255;
     const size_t bytes_tab = ((size_t)kScales * npairs * sizeof(PairPtrs) + 255) & ~(size_t)255;
@@ -1583,6 +2004,10 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         for (int c = 0; c < 3; ++c) {
             py.r2a[c] = r2 + (size_t)c * npx[2];
             py.r2b[c] = r2 + (size_t)(3 + c) * npx[2];
+            if (split) {
+                py.rgb1[c] = r4 + f_r4 + (size_t)c * npx[0];
+                py.rgb2[c] = r4 + f_r4 + (size_t)(3 + c) * npx[0];
+            }
         }
     }
     VSZIP_HIP_CHECK(ctx, hipMemcpyAsync(tab_dev, tab, bytes_tab + bytes_pyr, hipMemcpyHostToDevice, ctx->stream));
@@ -1601,6 +2026,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
             pa.vec_ok = (bits & (4 * bps - 1)) == 0 && (w & 3) == 0;  // (the XYB planes are dense: rows of w floats, 16-byte aligned when w % 4 == 0)
         }
         pa.sstride = (int)stride;
+        pa.from_rgb = 0;
         pa.w = w;
         pa.h = h;
         pa.w1 = sw[1];
@@ -1609,7 +2035,41 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         pa.h2 = sh[2];
         pa.k = kx;
         const dim3 grid((w + 255) / 256, (h + 15) / 16, cnt);
-        if (mode == PYR_YUV) {
+        if (mode == PYR_YUV && split) {
+            SsimLutCache *lc = lut_cache_of(ctx);
+            const int raw_bytes = yl_teams * 2 * kYlRows * yl_pd * 4;
+            YuvLds yl = lc->yl;
+            yl.lut_n = std::min(65537, ((lc->yl_lds_limit - raw_bytes) / 4 - 4) & ~3);
+            const int zero_upto = srgb_table_zero_upto();
+            yl.low_zero = zero_upto > 0 && zero_upto + yl.lut_n <= 65537;
+            yl.lut_lo = yl.low_zero ? zero_upto : std::min(std::max(32768 - yl.lut_n / 2, 0), 65537 - yl.lut_n);
+            yl.tx0 = (yl.xr0 + 255) / 256;
+            yl.tx1 = std::max(yl.tx0, std::min(yl.xr1, w) / 256);
+            yl.ty0 = (yl.yr0 + 15) / 16;
+            yl.ty1 = std::max(yl.ty0, std::min(yl.yr1, h) / 16);
+            if (!pa.vec_ok) yl.tx1 = yl.tx0, yl.ty1 = yl.ty0;  // (no interior: every tile through the EDGE launch)
+            const int lds = ((yl.lut_n + 3) & ~3) * 4 + raw_bytes;
+            const int inner = (yl.tx1 - yl.tx0) * (yl.ty1 - yl.ty0), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+            for (int edge = 0; edge < 2; ++edge) {
+                yl.ntiles = cnt * 2 * (edge ? yl.nbx * yl.nby - inner : inner);
+                if (yl.ntiles == 0) continue;
+                const int teams = edge ? kYlEdgeTeams : yl_teams;  // (the LDS carve-up is the interior's either way: the EDGE launch uses its first slices)
+                const dim3 groups(std::min(cus, (yl.ntiles + teams - 1) / teams)), threads(256 * teams);
+                if (fmt->dtype == VSZIP_U8 && !edge)
+                    hipLaunchKernelGGL((ssim_yuv420_rgb_kernel<uint8_t, false>), groups, threads, lds, st, pa, ya, yl);
+                else if (fmt->dtype == VSZIP_U8)
+                    hipLaunchKernelGGL((ssim_yuv420_rgb_kernel<uint8_t, true>), groups, threads, lds, st, pa, ya, yl);
+                else if (!edge)
+                    hipLaunchKernelGGL((ssim_yuv420_rgb_kernel<uint16_t, false>), groups, threads, lds, st, pa, ya, yl);
+                else
+                    hipLaunchKernelGGL((ssim_yuv420_rgb_kernel<uint16_t, true>), groups, threads, lds, st, pa, ya, yl);
+            }
+            PyrArgs pb = pa;  // the f32 pass over the frames' linear RGB planes (dense rows of w floats, 16-byte aligned: w % 4 == 0)
+            pb.from_rgb = 1;
+            pb.sstride = w;
+            pb.vec_ok = 1;
+            launch_pyr<float, PYR_F32_LINEAR>(false, grid, st, pb);
+        } else if (mode == PYR_YUV) {
             if (fmt->dtype == VSZIP_F32)
                 hipLaunchKernelGGL(ssim_pyr_yuv_kernel<float>, grid, dim3(256), 0, st, pa, ya);
             else if (fmt->dtype == VSZIP_U8)
