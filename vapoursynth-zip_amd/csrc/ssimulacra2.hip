@@ -618,10 +618,11 @@ __global__ __launch_bounds__(256) void ssim_pyr_yuv_kernel(const PyrArgs a, cons
 // of <= 132 a plane) and luma samples are fetched one tile AHEAD into registers with whole-dword loads and parked in the team's
 // LDS slice; every thread filters what its 4 x 4 block needs straight from there - horizontal 4-tap on the 6 chroma
 // rows the block touches, then the vertical 4-tap, both in zimg's order (yuv_two_acc): no plane of horizontally filtered rows.
-// Tiles whose columns and rows all follow the resampling tables' period (the frame's interior) take taps and coefficients from
-// the kernel argument; the outermost tiles go through a second launch of the same kernel (EDGE) that reads the tables and
-// clamps like ssim_pyr_yuv_kernel - a path of its own, because its table values cost the interior's a wave a SIMD, and as a
-// called function its spills landed on the common path (scratch reloads share the loads' counter). Same f32 operations in the same order.
+// Whole tiles take taps and coefficients from the kernel argument - the resampling tables' period, which every column and row
+// follows except the frame's first and last few: those samples come out wrong and ssim_yuv420_fixup_kernel redoes them, one thread
+// a sample (72 k of a 4K frame's 8.3 M). Ragged tiles at the right and the bottom go through a second launch of the same kernel
+// (EDGE) that reads the tables and clamps like ssim_pyr_yuv_kernel - a path of its own, because its table values cost the interior's
+// a wave a SIMD, and as a called function its spills landed on the common path. Same f32 operations in the same order.
 // ---------------------------------------------------------------------------------------------
 constexpr int kYlRows = 12;  // chroma rows a 16-row luma tile of a 4:2:0 clip taps at most
 constexpr int kYlNr = 6;     // ... and a 4-row luma block
@@ -948,6 +949,56 @@ __global__ __launch_bounds__(256) void yuv_to_rgbs_kernel(const void *s0, const 
     for (int c = 0; c < 3; ++c) {
         const float g = fmaf(ya.m[3 * c + 2], uv[1], fmaf(ya.m[3 * c + 1], uv[0], ya.m[3 * c] * yy));
         dst[c][(size_t)y * dstride + x] = yuv_transfer(g, lut, ya.linearize);
+    }
+}
+
+// ssim_yuv420_rgb_kernel's interior launch treats EVERY column and row of the whole tiles as if it followed the tables' period; the few that
+// do not (the frame's first and last columns / rows: [0, xr0), [xr1, wf), [0, yr0), [yr1, hf)) get wrong values there and the right ones
+// here, one thread a sample like yuv_to_rgbs_kernel, behind it in stream order. blockIdx.y = frame of the launch (pair * 2 + which).
+template <typename T>
+__global__ __launch_bounds__(256) void ssim_yuv420_fixup_kernel(const PyrArgs a, const YuvArgs ya, const YuvLds yl, int wf, int hf) {
+    const int ncol = yl.xr0 + (wf - yl.xr1), nrow = yl.yr0 + (hf - yl.yr1);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int x, y;
+    if (idx < ncol * hf) {  // the column strips, column-major inside a row
+        y = idx / ncol;
+        const int c = idx - y * ncol;
+        x = c < yl.xr0 ? c : yl.xr1 + (c - yl.xr0);
+    } else if (idx < ncol * hf + nrow * wf) {
+        const int e = idx - ncol * hf, r = e / wf;
+        x = e - r * wf;
+        y = r < yl.yr0 ? r : yl.yr1 + (r - yl.yr0);
+    } else {
+        return;
+    }
+    const PyrPair *__restrict__ tp = a.tab + (blockIdx.y >> 1);
+    const bool second = blockIdx.y & 1;
+    const int hl = ya.hleft[x], vl = ya.vleft[y];
+    float hc[4], vc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hc[k] = ya.hcoef[4 * (size_t)x + k], vc[k] = ya.vcoef[4 * (size_t)y + k];
+    float uv[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const T *src = static_cast<const T *>(second ? tp->src2[1 + pl] : tp->src1[1 + pl]);
+        float rows[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T *row = src + (size_t)min(vl + j, ya.ch - 1) * ya.cstride;
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = yuv_cvt<T>(row[min(hl + k, ya.cw - 1)], ya.cs, ya.co);
+            rows[j] = yuv_two_acc(hc[0], hc[1], hc[2], hc[3], t[0], t[1], t[2], t[3]);
+        }
+        uv[pl] = yuv_two_acc(vc[0], vc[1], vc[2], vc[3], rows[0], rows[1], rows[2], rows[3]);
+    }
+    const T *ysrc = static_cast<const T *>(second ? tp->src2[0] : tp->src1[0]);
+    const float yy = yuv_cvt<T>(ysrc[(size_t)y * a.sstride + x], ya.ys, ya.yo);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = fmaf(ya.m[3 * c + 2], uv[1], fmaf(ya.m[3 * c + 1], uv[0], ya.m[3 * c] * yy));
+        float *dst = second ? tp->rgb2[c] : tp->rgb1[c];
+        dst[(size_t)y * a.w + x] = yuv_transfer(g, a.lut, 1);
     }
 }
 
@@ -2043,11 +2094,15 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
             const int zero_upto = srgb_table_zero_upto();
             yl.low_zero = zero_upto > 0 && zero_upto + yl.lut_n <= 65537;
             yl.lut_lo = yl.low_zero ? zero_upto : std::min(std::max(32768 - yl.lut_n / 2, 0), 65537 - yl.lut_n);
-            yl.tx0 = (yl.xr0 + 255) / 256;
-            yl.tx1 = std::max(yl.tx0, std::min(yl.xr1, w) / 256);
-            yl.ty0 = (yl.yr0 + 15) / 16;
-            yl.ty1 = std::max(yl.ty0, std::min(yl.yr1, h) / 16);
-            if (!pa.vec_ok) yl.tx1 = yl.tx0, yl.ty1 = yl.ty0;  // (no interior: every tile through the EDGE launch)
+            // the interior launch takes every WHOLE tile (its first / last columns and rows, where the tables leave their period, are redone by
+            // ssim_yuv420_fixup_kernel); the EDGE launch the ragged tiles at the right and the bottom, or everything when the luma planes do not vector-load
+            yl.tx0 = yl.ty0 = 0;
+            yl.tx1 = pa.vec_ok ? w / 256 : 0;
+            yl.ty1 = pa.vec_ok ? h / 16 : 0;
+            if (yl.tx1 == 0 || yl.ty1 == 0) yl.tx1 = yl.ty1 = 0;
+            int wf = yl.tx1 * 256, hf = yl.ty1 * 16;
+            // (the period must hold somewhere inside the whole tiles, or the interior has nothing regular to offer)
+            if (yl.xr0 >= std::min(yl.xr1, wf) || yl.yr0 >= std::min(yl.yr1, hf)) yl.tx1 = yl.ty1 = wf = hf = 0;
             const int lds = ((yl.lut_n + 3) & ~3) * 4 + raw_bytes;
             const int inner = (yl.tx1 - yl.tx0) * (yl.ty1 - yl.ty0), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
             for (int edge = 0; edge < 2; ++edge) {
@@ -2063,6 +2118,19 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
                     hipLaunchKernelGGL((ssim_yuv420_rgb_kernel<uint16_t, false>), groups, threads, lds, st, pa, ya, yl);
                 else
                     hipLaunchKernelGGL((ssim_yuv420_rgb_kernel<uint16_t, true>), groups, threads, lds, st, pa, ya, yl);
+            }
+            if (inner) {
+                YuvLds yf = yl;
+                yf.xr1 = std::min(yl.xr1, wf);  // (columns / rows past the whole tiles are the EDGE launch's)
+                yf.yr1 = std::min(yl.yr1, hf);
+                const long npx_fix = (long)(yf.xr0 + wf - yf.xr1) * hf + (long)(yf.yr0 + hf - yf.yr1) * wf;
+                if (npx_fix > 0) {
+                    const dim3 fgrid((unsigned)((npx_fix + 255) / 256), (unsigned)(cnt * 2));
+                    if (fmt->dtype == VSZIP_U8)
+                        hipLaunchKernelGGL(ssim_yuv420_fixup_kernel<uint8_t>, fgrid, dim3(256), 0, st, pa, ya, yf, wf, hf);
+                    else
+                        hipLaunchKernelGGL(ssim_yuv420_fixup_kernel<uint16_t>, fgrid, dim3(256), 0, st, pa, ya, yf, wf, hf);
+                }
             }
             PyrArgs pb = pa;  // the f32 pass over the frames' linear RGB planes (dense rows of w floats, 16-byte aligned: w % 4 == 0)
             pb.from_rgb = 1;
