@@ -610,8 +610,8 @@ __global__ __launch_bounds__(256) void ssim_pyr_yuv_kernel(const PyrArgs a, cons
 // ssim_pyr_yuv_kernel spends 43 % of its time in the transfer table (48 gathers a thread from a 256 KB table: 40 GB of L2
 // requests a launch, the L2's request rate) and 25 % in phase A's single-sample loads. A table in LDS needs a workgroup that
 // lives long enough to pay for loading it, and one that owns a CU's LDS cannot also hold the XYB conversion's 120+ registers
-// at a useful occupancy (a fused persistent kernel was built first: no faster, profiles/r05_notes.md 9). So the work is split:
-// ssim_yuv420_rgb_kernel (here: one workgroup a CU, the table's [0, 1] range + margins in LDS, the rest in global memory)
+// at a useful occupancy (a fused persistent kernel was built first: no faster, profiles/r05_notes.md 9, 12). So the work is split:
+// ssim_yuv420_rgb_kernel (here: one workgroup a CU, the table from 0 to 1.14 in LDS, what lies beyond in global memory)
 // writes each frame's LINEAR RGB planes, and ssim_pyr_kernel<float, PYR_F32_LINEAR> (PyrArgs::from_rgb) reads them back -
 // 200 MB a 4K pair through HBM, both passes at rates the fused kernel is far from.
 // A workgroup is TEAMS teams of 256 threads; a team takes a tile of 256 x 16 luma samples: its raw chroma samples (<= 12 rows
@@ -632,7 +632,7 @@ struct YuvLds {
     int dh[4], dv[4];          // regular columns / rows: first tap of sample x0 + i = (x0 >> 1) + dh[i], x0 a multiple of 4
     float ch[4][4], cv[4][4];  // ... and their coefficients
     int xr0, xr1, yr0, yr1;    // the regular ranges [xr0, xr1) x [yr0, yr1), multiples of 4
-    int tx0, tx1, ty0, ty1;    // the interior: tiles [tx0, tx1) x [ty0, ty1) are whole, vector-aligned and regular in both axes
+    int tx0, tx1, ty0, ty1;    // the interior launch's tiles [tx0, tx1) x [ty0, ty1): whole and vector-aligned (the EDGE launch takes the others)
     int lut_lo, lut_n;         // LDS holds lut[lut_lo, lut_lo + lut_n)
     int low_zero;              // lut[0 .. lut_lo] are all 0.0f: an index below the range reads entry lut_lo
     int nbx, nby, ntiles;      // tiles across and down a frame; tiles of the launch (pairs x 2 frames x the interior's, or the rest's, tiles)
