@@ -872,34 +872,34 @@ __global__ __launch_bounds__(256 * (EDGE ? kYlEdgeTeams : YlGeo<T>::TEAMS)) void
             // wait per lookup made the kernel four times slower: out-of-gamut samples are common in converted video). low_zero: the table is
             // 0 up to lut_lo (zimg clamps negative input first), so only values beyond the range's upper end leave LDS.
             float lin[3][4];
-            int ti[3][4];
-            bool out_of_lds = false;
+            uint32_t li[3][4], li_max = 0;  // index into the staged range; beyond it (or, without low_zero, below it: a wrapped negative): >= lut_n
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float g = fmaf(ya.m[3 * c + 2], uv[1][r][i], fmaf(ya.m[3 * c + 1], uv[0][r][i], ya.m[3 * c] * yy[i]));
-                    float tt = rintf(fmaf(g, 32768.0f, 16384.0f));
-                    tt = fminf(fmaxf(tt, 0.0f), 65536.0f);
-                    int li = (int)tt - yl.lut_lo;
-                    if (yl.low_zero) li = max(li, 0);
-                    lin[c][i] = ((LdsF)lut)[min((uint32_t)li, (uint32_t)yl.lut_n - 1u)];
-                    const bool beyond = (uint32_t)li >= (uint32_t)yl.lut_n;
-                    ti[c][i] = beyond ? (int)tt : -1;
-                    out_of_lds = out_of_lds || beyond;
+                    // (no clamp to [0, 65536] here: the conversion saturates, the LDS index is clamped below and the global one in the branch)
+                    int k = (int)rintf(fmaf(g, 32768.0f, 16384.0f)) - yl.lut_lo;
+                    if (yl.low_zero) k = max(k, 0);
+                    li[c][i] = (uint32_t)k;
+                    li_max = max(li_max, (uint32_t)k);
+                    lin[c][i] = ((LdsF)lut)[min((uint32_t)k, (uint32_t)yl.lut_n - 1u)];
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(out_of_lds) != 0) {  // (a wave-level branch: a lane-level one was if-converted into twelve loads a row, always)
+            if (__builtin_amdgcn_ballot_w64(li_max >= (uint32_t)yl.lut_n) != 0) {  // (a wave-level branch: a lane-level one was if-converted into twelve loads a row, always)
                 asm volatile("" ::: "memory");
                 float gl[3][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) gl[c][i] = ((GblF)a.lut)[max(ti[c][i], 0)];
+                    for (int c = 0; c < 3; ++c) {
+                        const int t = min(max((int)li[c][i] + yl.lut_lo, 0), 65536);
+                        gl[c][i] = ((GblF)a.lut)[li[c][i] >= (uint32_t)yl.lut_n ? t : 0];
+                    }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) lin[c][i] = ti[c][i] >= 0 ? gl[c][i] : lin[c][i];
+                    for (int c = 0; c < 3; ++c) lin[c][i] = li[c][i] >= (uint32_t)yl.lut_n ? gl[c][i] : lin[c][i];
             }
             if (q.fast || y0 + r < a.h) {
                 const size_t o = (size_t)(y0 + r) * a.w + x0;
