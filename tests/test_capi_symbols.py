@@ -57,6 +57,46 @@ def test_resample_table_equals_the_oracle_restatement():
         assert np.array_equal(coef[:, :w].view(np.uint32), c0.view(np.uint32)), (src, dst, shift)
         assert not coef[:, w:].any()
 
+def test_resample_tables_as_the_420_prestage_pass_assumes():
+    """What ssim_yuv420_rgb_kernel's period path and ssim_yuv420_plan rely on, checked on the product's own tables for 2x enlargement under
+    the sitings VapourSynth has (shift 0: centred chroma, +-0.25 source samples: co-sited):
+      * co-sited tables are NOT monotonic in their first tap (a sample on a chroma sample has one non-zero tap, its neighbour four that start
+        one sample earlier) - the round-5 bug: a tile must take the smallest first tap of its rows, not its first row's;
+      * away from the ends the table has period 4 in the destination (first tap = (x >> 1) + d[x & 3], coefficients by x & 3): the interior path
+        keeps four taps-and-coefficients sets in the kernel argument;
+      * the four first taps of a group differ by at most 2 source samples, a 16-row tile taps at most 12 source rows and a 4-row block at
+        most 6 (the LDS slice, the dword windows and the filtered rows a thread holds are sized by these)."""
+    import numpy as np
+
+    import vszip_amd
+
+    for src, dst in [(960, 1920), (540, 1080), (1920, 3840), (1080, 2160), (160, 320)]:
+        for shift in (0.25, 0.0, -0.25):
+            left, coef = vszip_amd.capi.resample_table(src, dst, shift)
+            if shift != 0.0:  # (+-0.25 source samples: a destination sample sits ON every source sample)
+                assert (np.diff(left) < 0).any(), (src, dst, "co-sited tables step back")
+            ref = (dst // 2 // 4) * 4
+            d = [int(left[ref + i]) - (ref >> 1) for i in range(4)]
+            regular = np.array([left[x] == ((x - (x & 3)) >> 1) + d[x & 3] and np.array_equal(coef[x].view(np.uint32), coef[ref + (x & 3)].view(np.uint32)) and left[x] + 3 <= src - 1
+                                for x in range(dst)])
+            first = last = ref  # the run of regular samples around the reference group
+            while first > 0 and regular[first - 1]:
+                first -= 1
+            while last < dst and regular[last]:
+                last += 1
+            assert first <= 8 and dst - last <= 8, (src, dst, shift, first, last)  # only the ends leave the period
+            if shift >= 0.0:
+                assert max(d) - min(d) <= 2, (src, dst, shift, d)
+            else:  # bottom-sited chroma (shift -0.25, vertical axis only): the group spans 3 and ssim_yuv420_plan sends the clip to the fused tile kernel
+                assert max(d) - min(d) == 3, (src, dst, shift, d)
+                continue
+            right = np.minimum(left + 3, src - 1)
+            for t0 in range(0, dst, 16):
+                assert right[t0:t0 + 16].max() - left[t0:t0 + 16].min() + 1 <= 12, (src, dst, shift, t0)
+            for t0 in range(0, dst, 4):
+                assert right[t0:t0 + 4].max() - left[t0:t0 + 4].min() + 1 <= 6, (src, dst, shift, t0)
+
+
 
 def test_the_environment_is_read_in_one_place():
     """every switch is parsed once, in vszip_ctx_create (ctx.hip, from csrc/options.inc); no dispatch calls getenv."""
