@@ -165,12 +165,12 @@ __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
                 const int x = min(ox * 2 + ix, a.w - 1), y = min(oy * 2 + iy, a.h - 1);
                 const size_t o = (size_t)y * a.stride + x;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) v[c][iy * 2 + ix] = rgb[c][o];
+                for (int c = 0; c < 3; ++c) v[c][iy * 2 + ix] = ((const float __attribute__((address_space(1))) *)rgb[c])[o];  // (the planes come out of a table: typed as global memory, or the accesses are flat ones)
             }
         if (nxt[0]) {
             const size_t o = (size_t)oy * a.nstride + ox;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) nxt[c][o] = (((v[c][0] + v[c][1]) + v[c][2]) + v[c][3]) * 0.25f;
+            for (int c = 0; c < 3; ++c) ((float __attribute__((address_space(1))) *)nxt[c])[o] = (((v[c][0] + v[c][1]) + v[c][2]) + v[c][3]) * 0.25f;
         }
 #pragma unroll
         for (int iy = 0; iy < 2; ++iy)
@@ -181,9 +181,10 @@ __global__ __launch_bounds__(256) void ssim_xyb_down_kernel(const XybArgs a) {
                 float X, Y, B = 0.0f;
                 to_xyb_px(a.k, v[0][iy * 2 + ix], v[1][iy * 2 + ix], v[2][iy * 2 + ix], need_b, X, Y, B);
                 const size_t o = (size_t)y * a.xstride + x;
-                if (xyb[0]) xyb[0][o] = X;
-                if (xyb[1]) xyb[1][o] = Y;
-                if (need_b) xyb[2][o] = B;
+                typedef float __attribute__((address_space(1))) *GOut;
+                if (xyb[0]) ((GOut)xyb[0])[o] = X;
+                if (xyb[1]) ((GOut)xyb[1])[o] = Y;
+                if (need_b) ((GOut)xyb[2])[o] = B;
             }
     }
 }
@@ -224,7 +225,9 @@ __device__ __forceinline__ float pyr_linear(T v, const float *lut, const float *
         t = fminf(fmaxf(t, 0.0f), 65536.0f);
         return lut[(int)t];
     } else {
-        return use_lds ? lds_lut[(uint32_t)v] : lut[(uint32_t)v];
+        // (typed address spaces and a workgroup-uniform branch: a select between the two generic pointers made every lookup a flat load - round 5)
+        if (use_lds) return ((const float __attribute__((address_space(3))) *)lds_lut)[(uint32_t)v];
+        return ((const float __attribute__((address_space(1))) *)lut)[(uint32_t)v];
     }
 }
 
@@ -361,12 +364,21 @@ __device__ __forceinline__ void pyr_image(const PyrArgs &a, const PyrPtrs &pp, c
             }
         }
         float lin[3][4][4];
+        if (use_lds) {  // (one uniform branch around all 48 lookups, not one each)
 #pragma unroll
-        for (int c = 0; c < NP; ++c)
+            for (int c = 0; c < NP; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lin[c][r][i] = pyr_linear<T, MODE>(raw[c][r][i], a.lut, lds_lut, use_lds);
+                    for (int i = 0; i < 4; ++i) lin[c][r][i] = pyr_linear<T, MODE>(raw[c][r][i], a.lut, lds_lut, true);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NP; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lin[c][r][i] = pyr_linear<T, MODE>(raw[c][r][i], a.lut, lds_lut, false);
+        }
         if constexpr (GRAY) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
