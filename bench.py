@@ -86,10 +86,92 @@ def rgbs_pair(w: int, h: int, seed: int = 1):
 
 # ---------------------------------------------------------------------------
 # CPU baselines: the oracle (scalar C++ port of the reference arithmetic), one unit
-# per thread on all host cores, bounded sample.
+# per thread on the host cores this process may actually USE, bounded sample, with a
+# single-thread rate beside it so the record shows how well the threads scaled.
 # ---------------------------------------------------------------------------
-def _timed_pool(fn, cores: int, budget_s: float, unit_desc: str, t_single: float):
-    """Waves of `cores` units (one per thread) until the budget is used; at least one wave."""
+def _cgroup_cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (None: unlimited / unknown).
+    cgroup v2 `cpu.max` ("<quota> <period>" | "max <period>") of this process's group and its
+    ancestors; cgroup v1 `cpu.cfs_quota_us / cpu.cfs_period_us`."""
+    best = None
+
+    def take(q):
+        nonlocal best
+        if q is not None and q > 0:
+            best = q if best is None else min(best, q)
+
+    try:
+        rel = ""
+        for ln in Path("/proc/self/cgroup").read_text().splitlines():
+            parts = ln.split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2].strip("/")
+        d = Path("/sys/fs/cgroup") / rel if rel else Path("/sys/fs/cgroup")
+        seen = 0
+        while seen < 32:
+            f = d / "cpu.max"
+            if f.is_file():
+                q, per = (f.read_text().split() + ["100000"])[:2]
+                if q != "max":
+                    take(float(q) / float(per))
+            if d == Path("/sys/fs/cgroup") or d == d.parent:
+                break
+            d = d.parent
+            seen += 1
+    except (OSError, ValueError):
+        pass
+    for base in ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+        try:
+            q = float(Path(base, "cpu.cfs_quota_us").read_text())
+            per = float(Path(base, "cpu.cfs_period_us").read_text())
+            if q > 0 and per > 0:
+                take(q / per)
+        except (OSError, ValueError):
+            pass
+    return best
+
+
+def effective_cpus(quota=..., affinity=None, nominal=None):
+    """{nominal, affinity, quota, effective}: `effective` = the threads that can run at once =
+    min(os.cpu_count(), scheduler affinity, ceil(cgroup CPU quota)), at least 1. The GPU boxes of this pool
+    show 256 logical CPUs under a 16-CPU quota: 256 threads there are 16 CPUs' worth of time, sliced."""
+    import math
+
+    nominal = nominal or os.cpu_count() or 1
+    if affinity is None:
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            affinity = nominal
+    if quota is ...:
+        quota = _cgroup_cpu_quota()
+    eff = min(nominal, affinity)
+    if quota:
+        eff = min(eff, max(1, math.ceil(quota - 1e-9)))
+    return {"nominal": int(nominal), "affinity": int(affinity), "quota": quota, "effective": max(1, int(eff))}
+
+
+def cpu_threads() -> int:
+    """threads of every CPU leg: the effective CPU count (VSZIP_BENCH_CPU_THREADS overrides, for scaling studies)"""
+    ov = os.environ.get("VSZIP_BENCH_CPU_THREADS")
+    return max(1, int(ov)) if ov else effective_cpus()["effective"]
+
+
+def _timed_pool(fn, cores: int, budget_s: float, unit_desc: str, t_single: float, single_budget_s: float = 1.0):
+    """First ONE thread alone (whole units for `single_budget_s`, at least one: `single_thread_value`), then
+    waves of `cores` units (one per thread) until the budget is used, at least one wave. `scaling` =
+    value / (threads x single_thread_value): 1.0 = every thread ran as fast as the lone one; well below means the
+    host could not run `cores` threads at once (quota, SMT siblings, memory bandwidth) and says so in the record.
+    `t_single` (the caller's untimed first unit, cold) is kept only as `first_unit_s`."""
+    n1 = 0
+    t0 = time.perf_counter()
+    while True:
+        fn(0)
+        n1 += 1
+        dt1 = time.perf_counter() - t0
+        if dt1 >= single_budget_s:
+            break
+    single = n1 / dt1
     n = 0
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
@@ -99,15 +181,26 @@ def _timed_pool(fn, cores: int, budget_s: float, unit_desc: str, t_single: float
             dt = time.perf_counter() - t0
             if dt >= budget_s or dt + dt / (n // cores) > 2.5 * budget_s:
                 break
-    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x {unit_desc}, one per thread on {cores} threads, {dt:.1f}s"}
+    value = n / dt
+    eff = effective_cpus()
+    rec = {"value": value, "unit": "frames/s", "cores": cores, "kind": "port",
+           "threads": cores, "single_thread_value": single, "scaling": value / (cores * single),
+           "cores_nominal": eff["nominal"], "cores_effective": eff["effective"], "cpu_quota": eff["quota"],
+           "first_unit_s": t_single,
+           "sample": f"{n} x {unit_desc}, one per thread on {cores} threads ({eff['nominal']} logical CPUs, "
+                     f"{eff['effective']} usable: affinity {eff['affinity']}, cgroup quota {eff['quota']}), {dt:.1f}s; "
+                     f"one thread alone: {n1} in {dt1:.1f}s"}
+    if rec["scaling"] < 0.7:
+        rec["scaling_note"] = ("threads ran slower together than alone: SMT siblings share a core's units, all threads share the "
+                               "sockets' memory bandwidth, and a cgroup quota slices time when threads > quota")
+    return rec
 
 
 def cpu_boxblur(budget_s=6.0, w=W4K, h=H4K, blank=False):
     from oracle import oracle as orc
 
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = cpu_threads()
     frame = [np.zeros(sh, np.uint16) for sh in yuv420_shapes(w, h)] if blank else make_frame(0, w, h)
 
     def one(_):
@@ -122,7 +215,7 @@ def cpu_boxblur(budget_s=6.0, w=W4K, h=H4K, blank=False):
 def cpu_bilateral(w, h, budget_s=6.0):
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = cpu_threads()
     frame = natural_frame(w, h)
     prm = orc.bilateral_params([2], [2], yuv=True, ssw=1, ssh=1)
 
@@ -138,7 +231,7 @@ def cpu_bilateral(w, h, budget_s=6.0):
 def cpu_ssimulacra2(w, h, budget_s=8.0):
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = cpu_threads()
     ref, dis = rgbs_pair(w, h)
 
     def one(_):
@@ -518,7 +611,7 @@ def eedi3_leg(dev, timed, no_cpu, frames=16):
     if not no_cpu:
         from oracle import oracle as orc
 
-        cores = os.cpu_count() or 1
+        cores = cpu_threads()
 
         def one(_):
             for p in base:
@@ -613,7 +706,7 @@ def xpsnr_leg(dev, timed, no_cpu, frames=8, workers=8, batch=64, per_frame=True)
     if not no_cpu:
         from oracle import oracle as orc
 
-        cores = os.cpu_count() or 1
+        cores = cpu_threads()
 
         def one(_):
             orc.xpsnr_wsse(org[2], rec[2], org[1][0], org[0][0], depth=8, frame_rate=24)
@@ -895,7 +988,7 @@ def boxblur_1080p_5pass_leg(dev, timed, no_cpu, frames=32):
     if not no_cpu:
         from oracle import oracle as orc
 
-        cores = os.cpu_count() or 1
+        cores = cpu_threads()
         frame = [np.zeros(sh, np.uint16) for sh in yuv420_shapes(W1080, H1080)]
 
         def one(_):
@@ -1081,6 +1174,9 @@ def compact_leg(leg: dict) -> dict:
         o["cpu"] = {"value": cpu["value"], "cores": cpu.get("cores")}
         if isinstance(o.get("value"), (int, float)) and cpu["value"] > 0:
             o["cpu"]["x"] = o["value"] / cpu["value"]
+        for src, dst in (("single_thread_value", "single"), ("scaling", "scaling")):  # how the threads scaled
+            if isinstance(cpu.get(src), (int, float)):
+                o["cpu"][dst] = cpu[src]
     return o
 
 

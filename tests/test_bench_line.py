@@ -66,7 +66,7 @@ def test_line_fits_the_drivers_tail_and_parses(full, tmp_path):
     for name in ("bilateral_1080p", "bilateral_4k", "ssimulacra2_4k", "eedi3_1080p", "boxblur_1080p", "boxblur_1080p_5pass"):
         if "cpu_baseline" in full["others"].get(name, {}):
             cpu = d["others"][name]["cpu"]
-            assert set(cpu) == {"value", "cores", "x"} and cpu["cores"] >= 1, name
+            assert {"value", "cores", "x"} <= set(cpu) <= {"value", "cores", "x", "single", "scaling"} and cpu["cores"] >= 1, name
             assert math.isclose(cpu["x"], d["others"][name]["value"] / cpu["value"], rel_tol=1e-4), name
     assert {"bilateral_1080p", "bilateral_4k", "ssimulacra2_4k", "eedi3_1080p"} <= {n for n, leg in d["others"].items() if "cpu" in leg}
     assert d["others"]["bilateral_1080p"]["limit"]["bound"] in ("valu", "lds")
@@ -125,3 +125,34 @@ def test_unwritable_sidecar_does_not_cost_the_line(full, tmp_path):
     line = bench.emit_line(full, buf, tmp_path / "no_such_dir" / "bench_detail.json")
     d = json.loads(line)
     assert "detail" not in d and d["value"] > 0
+
+
+def test_effective_cpus_takes_the_smallest_of_nominal_affinity_and_quota():
+    """the GPU boxes show 256 logical CPUs under a 16-CPU cgroup quota"""
+    e = bench.effective_cpus(quota=16.0, affinity=256, nominal=256)
+    assert e == {"nominal": 256, "affinity": 256, "quota": 16.0, "effective": 16}
+    assert bench.effective_cpus(quota=None, affinity=8, nominal=64)["effective"] == 8
+    assert bench.effective_cpus(quota=2.5, affinity=8, nominal=8)["effective"] == 3
+    assert bench.effective_cpus(quota=0.5, affinity=8, nominal=8)["effective"] == 1
+    here = bench.effective_cpus()
+    assert 1 <= here["effective"] <= here["nominal"]
+
+
+def test_cpu_record_carries_threads_single_thread_rate_and_scaling(monkeypatch):
+    """a CPU leg's record: threads, value, single_thread_value, scaling = value / (threads x single); cores = what ran"""
+    import time
+
+    monkeypatch.setenv("VSZIP_BENCH_CPU_THREADS", "2")
+    assert bench.cpu_threads() == 2
+
+    def unit(_):
+        time.sleep(0.01)  # releases the GIL like the oracle's C calls do
+
+    rec = bench._timed_pool(unit, 2, 0.2, "sleep unit", 0.01, single_budget_s=0.1)
+    assert {"value", "unit", "cores", "kind", "sample", "threads", "single_thread_value", "scaling", "cores_nominal", "cores_effective"} <= set(rec)
+    assert rec["cores"] == rec["threads"] == 2
+    assert math.isclose(rec["scaling"], rec["value"] / (2 * rec["single_thread_value"]), rel_tol=1e-9)
+    assert 0.7 <= rec["scaling"] <= 1.3 and "scaling_note" not in rec
+    leg = bench.compact_leg({"value": 1000.0, "unit": "frames/s", "cpu_baseline": rec})
+    assert set(leg["cpu"]) == {"value", "cores", "x", "single", "scaling"}
+    assert math.isclose(leg["cpu"]["x"], 1000.0 / rec["value"], rel_tol=1e-9)

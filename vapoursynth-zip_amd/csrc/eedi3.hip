@@ -121,8 +121,9 @@ constexpr int kU = 4;  // directions per cost pass
 // MASK (round 4, with FIXED): the layout and the unrolled passes of mdis == MD, but only the directions |u| <= prm.mdis take part — the others keep an infinite
 // cost, which pins their Viterbi state at the sentinel exactly like the lanes past the last direction. A run-time mdis below the default used to take the
 // FIXED = false instance, whose cost pass is the round-3 form: slower at 21 directions than the fixed instance at 41 (tools/eedi3_param_sweep.py).
+// (the default geometry's LDS, round 6, lets 14 waves share a CU; registers for three a SIMD: a fourth measured no faster, see profiles/r06_notes.md)
 template <int NRAD, int MD, bool FIXED, bool MASK = false>
-__global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MASK && MD % kU == 0 && MD <= 20 ? 3 : 1))) void eedi3_line_kernel(const EParams prm) {
     static_assert(!MASK || FIXED, "MASK rides on the fixed layout");
     // The t_base and window-sum steps run a fixed number of 128-entry iterations (NIT2: every lane owns two
     // neighbouring entries, and the kU directions of a pass share ONE first column, so the span is the longest
@@ -133,13 +134,31 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     constexpr int kRowW = 128 * NIT2 + 2 * MD + 8;  // staged columns per source row: block + reach 2*mdis + nrad each side, padded for the overshoot
     constexpr int kTbW = 128 * NIT2 + 8;            // t_base / window-sum entries per direction
     const float kFltMax09 = FLT_MAX * 0.9f;
-    __shared__ __attribute__((aligned(16))) float rows[4][kRowW];  // r3p, r1p, r1n, r3n around the block, mirror padding applied
     // kRegWin (round 4, the default geometry): t_base never goes to LDS — see cost_pass_fixed below
     constexpr bool kRegWin = FIXED && NIT2 == 1 && MD % kU == 0;
-    __shared__ __attribute__((aligned(16))) float tbws[kRegWin ? 1 : 2][kU][kTbW];  // the (2*nrad+1)-tap window sums of the kU directions of the current pass (and, without kRegWin, their t_base in front)
     constexpr int kCtP = kXB + 4;  // 16-byte aligned rows: a direction's 64 costs come back as 16 ds_read_b128, free of bank conflicts at this pitch
-    __shared__ __attribute__((aligned(16))) float ctile[2 * MD + 1][kCtP];
+    // LDS of a wave: rows[4][kRowW] (r3p, r1p, r1n, r3n around the block, mirror padding applied), tbws (the (2*nrad+1)-tap window sums of the kU
+    // directions of the current pass and, without kRegWin, their t_base in front) and the cost tile ctile[2 MD + 1][kCtP].
+    // Round 6 (kOverlay, the default geometry): the staged rows and the window sums live only during the cost phase, the tile is read only after it,
+    // so they SHARE memory: rows and tbws lie over the tile's last rows, whose costs (the directions u >= kDefer0 - MD, produced by the last passes)
+    // wait in registers until the last pass has read its taps. 11 152 B a wave instead of 16 144: 14 waves a CU instead of 9 or 10.
+    constexpr bool kOverlay = kRegWin && !MASK;
+    constexpr int kTileF = (2 * MD + 1) * kCtP, kRowsF = 4 * kRowW, kTbF = (kRegWin ? 1 : 2) * kU * kTbW, kTailF = kRowsF + kTbF;
+    constexpr int kLdsF = kOverlay ? (kTileF > kTailF ? kTileF : kTailF) : kTileF + kTailF;
+    constexpr int kTailAt = kLdsF - kTailF;  // (floats) where rows start
+    static_assert(kTailAt % 4 == 0 && kRowsF % 4 == 0, "16-byte aligned rows");
+    constexpr int kDefer0 = kOverlay ? kTailAt / kCtP : 2 * MD + 1;  // first tile row the staged rows overlap
+    constexpr int kNDefer = 2 * MD + 1 - kDefer0;
+    __shared__ __attribute__((aligned(16))) float lds[kLdsF];
+    float (*ctile)[kCtP] = reinterpret_cast<float (*)[kCtP]>(lds);
+    float (*rows)[kRowW] = reinterpret_cast<float (*)[kRowW]>(lds + kTailAt);
+    float (*tbws)[kU][kTbW] = reinterpret_cast<float (*)[kU][kTbW]>(lds + kTailAt + kRowsF);
     float (*tb)[kTbW] = tbws[0], (*ws)[kTbW] = tbws[kRegWin ? 0 : 1];
+#ifdef VSZIP_E3_PAD_LDS  // (occupancy sweeps only: that many bytes of LDS a wave more)
+    __shared__ float padlds[VSZIP_E3_PAD_LDS / 4];
+    if (prm.nplanes < 0) padlds[threadIdx.x] = prm.gamma;
+    asm volatile("" ::"v"(padlds[threadIdx.x ^ 1]));
+#endif
 
     int pi = 0;
     const int gl = prm.line_base + (int)blockIdx.x;
@@ -157,9 +176,10 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     const float *r1p = pl.src + (size_t)src_col(dh, line - 1, pl.n_src) * pl.sstride;
     const float *r1n = pl.src + (size_t)src_col(dh, line + 1, pl.n_src) * pl.sstride;
     const float *r3n = pl.src + (size_t)src_col(dh, line + 3, pl.n_src) * pl.sstride;
-    // back-pointer codes of this line: [block][direction][64 columns], one byte each, the path's step as a signed
-    // two-bit number (0: stay, 3 = -1: from the direction below, 1: from the direction above); column 63 of a block is produced by the
-    // first step of the next block
+    // back-pointer codes of this line: [block][direction][64 columns], TWO BITS each (16 bytes a direction and block), the path's step as a
+    // signed two-bit number (0: stay, 3 = -1: from the direction below, 1: from the direction above), column c in bits 31 - 2 (c & 15) .. 30 - 2 (c & 15)
+    // of word c >> 4 (the forward pass shifts them in from the right); column 63 of a block is produced by the first step of the next block.
+    // (The scratch area is sized for a byte a code, round 4's form; a line uses the first quarter of its share.)
     uint8_t *pback = reinterpret_cast<uint8_t *>(pl.pback) + (size_t)off * ((w + kXB - 1) / kXB * kXB) * tpitch;
     float *out = pl.dst + (size_t)line * pl.dstride;
     int *dmap = pl.dmap + (size_t)off * w;
@@ -171,9 +191,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     }
     float pcost = kFltMax09;  // DP state of direction `lane` (inactive lanes stay at the sentinel)
     [[maybe_unused]] float dp_l = INFINITY, dp_r = INFINITY, dp_gamma = prm.gamma;  // see dp_step
-    uint32_t held[kXB / 4];   // back-pointer codes of the previous block, waiting for their last column
+    uint32_t held[kXB / 16];  // back-pointer codes of the previous block, waiting for their last column
 #pragma unroll
-    for (int i = 0; i < kXB / 4; ++i) held[i] = 0;
+    for (int i = 0; i < kXB / 16; ++i) held[i] = 0;
     const int nblk = (w + kXB - 1) / kXB;
     for (int blk = 0; blk < nblk; ++blk) {
         const int xb = blk * kXB;
@@ -305,14 +325,29 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             b[ia] = *reinterpret_cast<const float2 *>(&rows[1][j - 2 * (ug + ia)]);
             d[ia] = *reinterpret_cast<const float2 *>(&rows[2][j - 2 * (ug + ia)]);
             f[ia] = *reinterpret_cast<const float2 *>(&rows[3][j - 2 * (ug + ia)]);
+#ifdef VSZIP_E3_TAPS_LDS  // (sweeps: every direction's shifted taps from LDS)
+#pragma unroll
+            for (int i = 0; i < nd; ++i) {
+                if (i == ia) continue;
+                b[i] = *reinterpret_cast<const float2 *>(&rows[1][j - 2 * (ug + i)]);
+                d[i] = *reinterpret_cast<const float2 *>(&rows[2][j - 2 * (ug + i)]);
+                f[i] = *reinterpret_cast<const float2 *>(&rows[3][j - 2 * (ug + i)]);
+            }
+            if constexpr (false) {
+#else
             if constexpr (ug < 0) {
+#endif
 #pragma unroll
                 for (int i = 1; i < nd; ++i) {
                     b[i] = make_float2(lane_below0(b[i - 1].x), lane_below0(b[i - 1].y));
                     d[i] = make_float2(lane_below0(d[i - 1].x), lane_below0(d[i - 1].y));
                     f[i] = make_float2(lane_below0(f[i - 1].x), lane_below0(f[i - 1].y));
                 }
-            } else {
+            } else
+#ifdef VSZIP_E3_TAPS_LDS
+                if constexpr (false)
+#endif
+            {
 #pragma unroll
                 for (int i = nd - 2; i >= 0; --i) {
                     b[i] = make_float2(lane_above0(b[i + 1].x), lane_above0(b[i + 1].y));
@@ -353,6 +388,7 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
             float sw0[kU], sw1[kU], sw2[kU], p1[kU], p2[kU];
         };
         const float r1c = rows[1][lx], r2c = rows[2][lx];
+        [[maybe_unused]] float defer[kNDefer > 0 ? kNDefer : 1];
         auto read_b = [&](auto ugc, BRegs &r) __attribute__((always_inline)) {
             constexpr int ug = decltype(ugc)::value;
             constexpr int nd = MD - ug + 1 < kU ? MD - ug + 1 : kU;
@@ -377,9 +413,15 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 val[i] = prm.alpha * (r.sw0[i] + r.sw1[i] + r.sw2[i]) + prm.beta * (float)abs(u) + prm.one_minus_ab * vv;
                 if constexpr (MASK) val[i] = abs(u) <= mlim ? val[i] : INFINITY;
             }
+            if constexpr (kOverlay) {  // tile rows under the staged rows wait in registers (see kOverlay)
+#pragma unroll
+                for (int i = 0; i < nd; ++i)
+                    if (MD + ug + i >= kDefer0) defer[MD + ug + i - kDefer0] = val[i];
+            }
             if (x < w) {
 #pragma unroll
-                for (int i = 0; i < nd; ++i) ctile[MD + ug + i][lane] = val[i];
+                for (int i = 0; i < nd; ++i)
+                    if (MD + ug + i < kDefer0) ctile[MD + ug + i][lane] = val[i];
             }
         };
         // MASK: a pass none of whose directions takes part is skipped (its tile rows stay infinite from the kernel's start); no software pipeline here
@@ -433,20 +475,29 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
         }
 #endif
         wave_fence();
+        if constexpr (kOverlay && kNDefer > 0) {  // every tap of the block has been read: the last directions' costs take their rows
+            if (x < w) {
+#pragma unroll
+                for (int i = 0; i < kNDefer; ++i) ctile[kDefer0 + i][lane] = defer[i];
+            }
+            wave_fence();
+        }
         // ---- DP phase, lanes = direction index ---------------------------------------
         const int xe = min(kXB, w - xb);
         // The Viterbi recurrence is a dependent chain along x, so nothing in it may wait on memory:
         // the costs of the block's 64 columns are read from LDS into registers up front, the 64 steps
-        // are unrolled, the back-pointer of a step is a 2-bit code packed into registers (16 of them
-        // per block) and written out — straight to global memory, 64 bytes per direction — only after
-        // the block; lanes past the last direction get an infinite cost, which pins them at the
-        // 0.9*FLT_MAX sentinel the reference gives a missing neighbour, so no step needs a lane mask.
-        // (With the cost read and the int8 store inside the loop every step waited out an LDS round
-        // trip: the DP phase was half of the kernel's time at 1/5 of its instructions.)
-        float tcv[kXB];
+        // are unrolled, the back-pointer of a step is a 2-bit code shifted into registers (4 of them
+        // per block) and written out — straight to global memory, 16 bytes per direction — only after
+        // the block.
+        // Round 6: the phase runs with EXEC = the directions (lane < tpitch). A DPP read of a lane that EXEC disables is an invalid source like
+        // a lane out of range: with bound_ctrl off the destination keeps its value, so the last direction's "above" register stays at the +inf it
+        // was given once — the same mechanism that serves lanes 0 and 63 — and the lanes past the last direction need neither an infinite
+        // cost (64 moves a block) nor a state.
+        uint32_t pk[kXB / 16];
 #pragma unroll
-        for (int xl = 0; xl < kXB; ++xl) tcv[xl] = INFINITY;
+        for (int i = 0; i < kXB / 16; ++i) pk[i] = 0;
         if (lane < tpitch) {
+            float tcv[kXB];
 #pragma unroll
             for (int q = 0; q < kXB / 4; ++q) {
                 const float4 v4 = *reinterpret_cast<const float4 *>(&ctile[lane][4 * q]);
@@ -455,86 +506,71 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                 tcv[4 * q + 2] = v4.z;
                 tcv[4 * q + 3] = v4.w;
             }
-        }
-        uint32_t pk[kXB / 4];
-#pragma unroll
-        for (int i = 0; i < kXB / 4; ++i) pk[i] = 0;
-        // Round 4: the step in five dependent instructions instead of eight. The new cost is min3(own, below + gamma, above + gamma) + tc whatever the
-        // tie-breaking picks (strict < only decides WHICH of equal values is taken), so the codes leave the chain: they are two compares beside it.
-        // The neighbours come through v_add_f32_dpp into registers whose edge lane (0 for "below", 63 for "above") was set to +inf once and is never
-        // written again — a lane without a neighbour keeps "+inf < own" false, as the reference's 0.9*FLT_MAX sentinel does (gamma >= 0 is validated).
-        // Codes are the signed two-bit step of the path: 0 stay, 3 (-1) from the direction below, 1 (+1) from the one above.
-        auto dp_step = [&](float tc) -> uint32_t {
-#ifdef VSZIP_E3_DP_R3  // (sweeps: the round-3 step)
-            const float left_cc = lane_below(pcost, pcost) + prm.gamma, right_cc = lane_above(pcost, pcost) + prm.gamma;
-            float bval = pcost;  // :536-548
-            uint32_t code = 0;
-            if (left_cc < bval) {
-                bval = left_cc;
-                code = 3;
+            // The step (round 4: five dependent instructions; round 6: nine VALU instructions instead of eleven). The new cost is
+            // min3(own, below + gamma, above + gamma) + tc whatever the tie-breaking picks (strict < only decides WHICH of equal values is taken), so
+            // the codes leave the chain. The reference's order — centre unless the one below is smaller, that unless the one above is smaller still
+            // (:536-548) — is: moved = (own != the minimum), and if moved, from below = (below == the minimum). Both compares land in SGPR pairs and
+            // enter the code word as carries: word = 2 word + bit, twice (hi = moved & below, lo = moved: 00 stay, 11 = -1 below, 01 = +1 above).
+            // The neighbours come through v_add_f32_dpp into registers whose edge lane was set to +inf once and is never written again — a lane without
+            // a neighbour keeps "+inf < own" false, as the reference's 0.9*FLT_MAX sentinel does (gamma >= 0 is validated).
+            // Wait states inside the block: the two v_addc stand between the write of the state and the next step's DPP reads of it.
+            auto dp_step = [&](float tc, uint32_t &word) __attribute__((always_inline)) {
+                float bv;
+                uint64_t cm, cl, co;
+                asm volatile(
+                    "v_add_f32_dpp %[vl], %[pc], %[g] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[vr], %[pc], %[g] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_min3_f32 %[bv], %[pc], %[vl], %[vr]\n\t"
+                    "v_cmp_neq_f32_e64 %[cm], %[pc], %[bv]\n\t"
+                    "v_cmp_eq_f32_e64 %[cl], %[vl], %[bv]\n\t"
+                    "v_add_f32_e32 %[bv], %[bv], %[tc]\n\t"
+                    "s_and_b64 %[cl], %[cl], %[cm]\n\t"
+                    "v_min_f32_e32 %[pc], %[mx], %[bv]\n\t"
+                    "v_addc_co_u32_e64 %[wd], %[co], %[wd], %[wd], %[cl]\n\t"
+                    "v_addc_co_u32_e64 %[wd], %[co], %[wd], %[wd], %[cm]"
+                    : [vl] "+v"(dp_l), [vr] "+v"(dp_r), [pc] "+v"(pcost), [bv] "=&v"(bv), [cm] "=&s"(cm), [cl] "=&s"(cl), [co] "=&s"(co), [wd] "+v"(word)
+                    : [g] "v"(dp_gamma), [tc] "v"(tc), [mx] "v"(kFltMax09)
+                    : "scc");
+            };
+            auto store_block = [&](const uint32_t *q, int b) __attribute__((always_inline)) {  // 64 codes of direction `lane`, block b
+                *reinterpret_cast<uint4 *>(pback + ((size_t)b * tpitch + lane) * (kXB / 4)) = make_uint4(q[0], q[1], q[2], q[3]);
+            };
+            // step 0 completes the previous block (its column 63)
+            if (blk == 0) {
+                pcost = tcv[0];  // :461-463
+                asm volatile("s_nop 1" : "+v"(pcost));  // a DPP read two wait states after the register's last write; inside dp_step the step's own tail provides them
+            } else {
+                dp_step(tcv[0], held[kXB / 16 - 1]);
+                store_block(held, blk - 1);
             }
-            if (right_cc < bval) {
-                bval = right_cc;
-                code = 1;
-            }
-            pcost = fminf(bval + tc, kFltMax09);
-            return code;
-#else
-            uint32_t code;
-            float m1, bv;
-            uint64_t c1, c2;
-            asm volatile(
-                "v_add_f32_dpp %[vl], %[pc], %[g] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                "v_add_f32_dpp %[vr], %[pc], %[g] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                "v_min_f32_e32 %[m1], %[pc], %[vl]\n\t"
-                "v_min3_f32 %[bv], %[pc], %[vl], %[vr]\n\t"
-                "v_cmp_lt_f32_e64 %[c1], %[vl], %[pc]\n\t"
-                "v_add_f32_e32 %[bv], %[bv], %[tc]\n\t"
-                "v_cmp_lt_f32_e64 %[c2], %[vr], %[m1]\n\t"
-                "v_min_f32_e32 %[pc], %[mx], %[bv]\n\t"
-                "v_cndmask_b32_e64 %[code], 0, 3, %[c1]\n\t"
-                "v_cndmask_b32_e64 %[code], %[code], 1, %[c2]"
-                : [vl] "+v"(dp_l), [vr] "+v"(dp_r), [pc] "+v"(pcost), [m1] "=&v"(m1), [bv] "=&v"(bv), [c1] "=&s"(c1), [c2] "=&s"(c2), [code] "=&v"(code)
-                : [g] "v"(dp_gamma), [tc] "v"(tc), [mx] "v"(kFltMax09));
-            return code;
-#endif
-        };
-        auto store_block = [&](const uint32_t *q, int b) {  // 64 codes of direction `lane`, block b
-            if (lane < tpitch) {
-                uint4 *dst = reinterpret_cast<uint4 *>(pback + ((size_t)b * tpitch + lane) * kXB);
-#pragma unroll
-                for (int i = 0; i < kXB / 16; ++i) dst[i] = make_uint4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
-            }
-        };
-        // step 0 completes the previous block (its column 63)
-        if (blk == 0) {
-            pcost = lane < tpitch ? tcv[0] : kFltMax09;  // :461-463
-#ifndef VSZIP_E3_DP_R3
-            asm volatile("s_nop 1" : "+v"(pcost));  // a DPP read two wait states after the register's last write; inside dp_step the step's own tail provides them
-#endif
-        } else {
-            held[kXB / 4 - 1] |= dp_step(tcv[0]) << 24;
-            store_block(held, blk - 1);
-        }
 #ifdef VSZIP_E3_DIAG_NO_DP  // (timing diagnostics only: four of the 64 Viterbi steps of a block - wrong results)
-        if (xe == kXB) {
+            if (xe == kXB) {
 #pragma unroll
-            for (int xl = 1; xl < 5; ++xl) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
-        } else
+                for (int xl = 1; xl < 5; ++xl) dp_step(tcv[xl], pk[(xl - 1) >> 4]);
+            } else
 #else
-        if (xe == kXB) {
+            if (xe == kXB) {
 #pragma unroll
-            for (int xl = 1; xl < kXB; ++xl) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
-        } else
+                for (int xl = 1; xl < kXB; ++xl) dp_step(tcv[xl], pk[(xl - 1) >> 4]);
+            } else
 #endif
-        {
+            {
 #pragma unroll
-            for (int xl = 1; xl < kXB; ++xl)
-                if (xl < xe) pk[(xl - 1) >> 2] |= dp_step(tcv[xl]) << (8 * ((xl - 1) & 3));
+                for (int xl = 1; xl < kXB; ++xl)
+                    if (xl < xe) dp_step(tcv[xl], pk[(xl - 1) >> 4]);
+            }
+            if (blk == nblk - 1) {
+                // the line's last block: its words are as full as they get (xe - 1 codes; even a whole block has no column 63) — move the codes to their places
+#pragma unroll
+                for (int j = 0; j < kXB / 16; ++j) {
+                    const int n = min(max(xe - 1 - 16 * j, 0), 16);
+                    pk[j] = n ? pk[j] << (2 * (16 - n)) : 0u;
+                }
+                store_block(pk, blk);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < kXB / 4; ++i) held[i] = pk[i];
-        if (blk == nblk - 1) store_block(held, blk);
+        for (int i = 0; i < kXB / 16; ++i) held[i] = pk[i];
     }
     __syncthreads();
     __threadfence_block();
@@ -549,17 +585,13 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     // after its walk and consumed after the next block's — each round trip to memory (about 1 us, exposed twice per block before: a wave has 0.75
     // neighbours on its SIMD to hide it behind) passes under a walk. profiles/r04_notes.md section 7.
     int carry = mdis;  // mdis + fpath of the first column of the block to the right
-    uint32_t qn[kXB / 4];
+    uint32_t qn[kXB / 16];
     auto load_codes = [&](int b, uint32_t *dstq) __attribute__((always_inline)) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(pback + ((size_t)b * tpitch + min(lane, tpitch - 1)) * kXB);
-#pragma unroll
-        for (int i = 0; i < kXB / 16; ++i) {
-            const uint4 v = src[i];
-            dstq[4 * i] = v.x;
-            dstq[4 * i + 1] = v.y;
-            dstq[4 * i + 2] = v.z;
-            dstq[4 * i + 3] = v.w;
-        }
+        const uint4 v = *reinterpret_cast<const uint4 *>(pback + ((size_t)b * tpitch + min(lane, tpitch - 1)) * (kXB / 4));
+        dstq[0] = v.x;
+        dstq[1] = v.y;
+        dstq[2] = v.z;
+        dstq[3] = v.w;
     };
 #ifdef VSZIP_E3_DIAG_NO_BACKTRACK  // (timing diagnostics only: no backtrack, no output)
     if (nblk > 0) return;
@@ -575,9 +607,9 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int xb = blk * kXB;
         const int xe = min(kXB, w - xb);
-        uint32_t q[kXB / 4];
+        uint32_t q[kXB / 16];
 #pragma unroll
-        for (int i = 0; i < kXB / 4; ++i) q[i] = qn[i];
+        for (int i = 0; i < kXB / 16; ++i) q[i] = qn[i];
         if (blk > 0) load_codes(blk - 1, qn);
         // the chain variable is mdis + fpath (the lane that holds the current direction's codes): per column one v_readlane, one signed two-bit
         // field extract and one add on the scalar unit; the column's value goes to its lane with v_writelane, off the chain
@@ -590,8 +622,8 @@ __global__ __launch_bounds__(64) void eedi3_line_kernel(const EParams prm) {
                     if (!decltype(full)::value && xb + xl == w - 1) {
                         fpm = mdis;
                     } else {
-                        const int word = __builtin_amdgcn_readlane((int)q[xl >> 2], fpm);
-                        fpm += (int)((uint32_t)word << (30 - 8 * (xl & 3))) >> 30;  // s_bfe_i32: 0, +1, or 3 = -1
+                        const int word = __builtin_amdgcn_readlane((int)q[xl >> 4], fpm);
+                        fpm += (int)((uint32_t)word << (2 * (xl & 15))) >> 30;  // s_bfe_i32: 0, +1, or 3 = -1
                     }
                     fpv = write_lane<xl>(fpv, fpm);
                 }
