@@ -78,7 +78,11 @@ int vszip_abi_version(void);
  * elsewhere; never more than a quarter of what hipMemGetInfo reports free), each classified with a 2 ms copy in the ring
  * kernels' access shape; the search ends with the first candidate of the best class, else the fastest is kept, and every other
  * candidate is freed before the call returns (a few milliseconds per candidate; more where the driver clears memory that was
- * used before). Nothing is cached or parked and there is no per-context state. vszip_dev_free is hipFree.
+ * used before). The search is bounded: no candidate is started after VSZIP_PLACEMENT_BUDGET_MS (300) of wall clock; it ends early
+ * at a candidate within 1.5 % of the best probe rate this process has seen on the device (a device's first search: at the
+ * calibrated best class); and a device whose searches found all candidates alike twice in a row (one class of memory, or too
+ * busy to measure) is served with plain hipMalloc from then on. No memory is cached or parked; the only state is that per-device
+ * record (best rate seen, verdict). vszip_dev_free is hipFree.
  * VSZIP_PLACEMENT=0 (or vszip_ctx_set_option): plain hipMalloc. */
 int vszip_dev_alloc(vszip_ctx *ctx, size_t bytes, void **dptr);
 /* What the search did for `dptr` (as returned by vszip_dev_alloc); any pointer may be NULL. *candidates = 0: a plain allocation;

@@ -91,6 +91,21 @@ def test_everything_goes_back_to_the_driver(pdev):
         assert free0 - torch.cuda.mem_get_info(0)[0] < (8 << 20)
 
 
+def test_the_search_stops_at_its_wall_clock_budget(pdev):
+    """no candidate is started once VSZIP_PLACEMENT_BUDGET_MS have passed — with a budget of 0 the first candidate is the only one"""
+    with pdev.options(VSZIP_PLACEMENT_BUDGET_MS=0, VSZIP_PLACEMENT_TRIES=24):
+        a = _alloc(pdev, 200 << 20)
+    ia = pdev.arena_info(a)
+    assert ia["candidates"] == 1 and ia["search_ms"] < 500
+    with pdev.options(VSZIP_PLACEMENT_BUDGET_MS=60000, VSZIP_PLACEMENT_TRIES=6):
+        b = _alloc(pdev, 200 << 20)
+    ib = pdev.arena_info(b)
+    assert 1 <= ib["candidates"] <= 6
+    assert pdev.get_option("VSZIP_PLACEMENT_BUDGET_MS") == 300
+    for p in (a, b):
+        pdev.check(pdev.lib.vszip_dev_free(pdev.ctx, p))
+
+
 def test_any_context_frees_any_allocation_and_placement_off_is_plain(pdev, dev):
     a = _alloc(pdev, 256 << 20)
     assert dev.arena_info(a)["candidates"] >= 1  # the record is the process's, not the context's

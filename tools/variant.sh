@@ -1,6 +1,7 @@
 #!/bin/bash
 # Container: build a variant of libvszip_hip.so with ONE source recompiled under extra flags.
 #   tools/variant.sh <name> <source stem> "<extra flags>"   ->  tools/ab/<name>.so   (travels with gpurun, git-ignored)
+# (timing-only macros - VSZIP_*_TIMING_*, VSZIP_*DIAG_* - also need -DVSZIP_DEV_VARIANTS in the flags: common.hpp refuses them otherwise)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; stem=$2; extra=$3

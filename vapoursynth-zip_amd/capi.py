@@ -20,6 +20,9 @@ _NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.float16)
 _DT2NP = {v: k for k, v in _NP2DT.items()}
 
 
+VARIANTS_ABSENT: dict = {}  # development-variant switches a test asked for that this build does not contain -> how often (Device.variant)
+
+
 class VszipError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(msg)
@@ -267,6 +270,8 @@ class Device:
             except VszipError as e:
                 if e.code != -3:
                     raise
+                for k in kw:  # counted: tests/conftest.py reports how many cross-checks a default build left out
+                    VARIANTS_ABSENT[k] = VARIANTS_ABSENT.get(k, 0) + 1
                 yield False
                 return
             with self.options(**kw):

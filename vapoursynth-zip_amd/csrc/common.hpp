@@ -13,6 +13,15 @@
 
 #define VSZIP_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Timing-only macros compile kernels that knowingly produce WRONG results (a phase stubbed out to see what it costs; the measurements are
+// on file under profiles/). A stray -D in a build script must not ship one: they exist only in development builds.
+#if !defined(VSZIP_DEV_VARIANTS) &&                                                                                                              \
+    (defined(VSZIP_XPSNR_TIMING_NOTEMP) || defined(VSZIP_XPSNR_TIMING_NOEDGE) || defined(VSZIP_SSIM_TIMING_NOF64) || defined(VSZIP_SSIM_TIMING_NOFETCH) || \
+     defined(VSZIP_E3_DIAG_ONE_PASS) || defined(VSZIP_E3_DIAG_NO_DP) || defined(VSZIP_E3_DIAG_NO_BACKTRACK) || defined(VSZIP_DIAG_NO_KCOL) ||        \
+     defined(VSZIP_DIAG_NO_FENCE) || defined(VSZIP_DIAG_NO_STORE) || defined(VSZIP_DIAG_NO_LOAD) || defined(VSZIP_DIAG_NO_HORIZONTAL))
+#error "VSZIP_*_TIMING_* / VSZIP_*DIAG_* macros build kernels with wrong results: they need -DVSZIP_DEV_VARIANTS (tools/variant.sh)"
+#endif
+
 // csrc/options.inc: every switch, parsed once per context (ctx.hip)
 struct vszip_options {
 #define VSZIP_OPT(field, env, def) int field = def;

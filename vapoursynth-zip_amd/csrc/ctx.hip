@@ -83,6 +83,7 @@ struct OptionRange {
 };
 const OptionRange kRanges[] = {
     {"VSZIP_SCAN_MODE", 0, 2},         {"VSZIP_PLACEMENT_MIN_MIB", 16, 1 << 20}, {"VSZIP_PLACEMENT_TRIES", 1, 64},  {"VSZIP_RT_ICHAIN_BANDS", 0, 256},
+    {"VSZIP_PLACEMENT_BUDGET_MS", 0, 60000},
     {"VSZIP_RT_VSMALL_MAX", 0, 8},     {"VSZIP_RT_VBAND", 0, 1 << 16},           {"VSZIP_RT_VRING_MAXR", 0, 127},   {"VSZIP_RT_GROUP_MB", 0, 1 << 20},
     {"VSZIP_RING_PERIODS", 0, 1 << 16},
 };
@@ -318,22 +319,49 @@ std::atomic<int> g_placed_count{0};
 double probe_region(vszip_ctx *ctx, void *ptr, size_t bytes, const void *from);
 
 // placement_probe_kernel's rate on the devices seen: 5.55-5.9 TB/s <-> the real launch at 560-585 us with its destination there (0.68-0.71),
-// 5.2-5.35 TB/s <-> 594-608 us, 4.6-5.1 TB/s <-> 630-695 us (profiles/r04_placement_probe_calibration.txt). Used ONLY to end the search early:
-// on a device that never reaches it (capped, busy, partitioned) the search looks at all its candidates and keeps the fastest.
+// 5.2-5.35 TB/s <-> 594-608 us, 4.6-5.1 TB/s <-> 630-695 us (profiles/r04_placement_probe_calibration.txt).
+// Round 6: the search is bounded three ways, none of them a property of ONE device model:
+//  - wall clock: VSZIP_PLACEMENT_BUDGET_MS (default 300) — a fresh allocation costs 3 ms to probe on an idle MI355X and 50-170 ms where
+//    the driver clears memory first, so on a slow or shared device the search looks at the few candidates the budget pays for;
+//  - early exit RELATIVE to what this process has seen on this device: a candidate within 1.5 % of the best probe rate on record
+//    ends the search (the absolute 5.55 TB/s of the calibration above still ends a device's FIRST search early, and is never required);
+//  - a verdict per device: a search that looked at four candidates or more and found them all within 3 % of each other (one class of
+//    memory, or a device so busy that the probe measures its neighbours) marks the device "flat" for this process — later requests
+//    take a plain hipMalloc. Two flat searches in a row are needed before the verdict sticks; one search that finds a spread clears it.
 constexpr double kBestBytesPerSec = 5.55e12;
+constexpr double kNearBest = 0.985, kFlatSpread = 0.03;
+constexpr int kMaxDevices = 64;
+struct DevicePlacement {
+    double best_rate = 0.0;  // best probe rate any search of this process saw on the device
+    int flat_searches = 0;   // consecutive searches whose candidates were all one class
+};
+DevicePlacement g_dev_placement[kMaxDevices];  // guarded by placed_mu()
 
 int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
     const auto t_start = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    const int dev = ctx->device >= 0 && ctx->device < kMaxDevices ? ctx->device : 0;
+    double best_on_record = 0.0;
+    bool flat = false;
+    {
+        std::lock_guard<std::mutex> lk(placed_mu());
+        best_on_record = g_dev_placement[dev].best_rate;
+        flat = g_dev_placement[dev].flat_searches >= 2;
+    }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();
         free_b = bytes;
     }
-    const int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 4 / std::max<size_t>(bytes, 1)));
+    int tries = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->opt.placement_tries), free_b / 4 / std::max<size_t>(bytes, 1)));
+    if (flat) tries = 1;  // (this process found nothing to choose between on this device)
+    const double budget_ms = (double)std::max(0, ctx->opt.placement_budget_ms);
     if (tries > 1) VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<std::pair<void *, double>> cand;  // pointer, probe rate
     int best = -1;
+    double worst_rate = 0.0;
     for (int k = 0; k < tries; ++k) {
+        if (k > 0 && elapsed_ms() >= budget_ms) break;  // the wall-clock bound: keep the fastest so far
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -343,8 +371,8 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         if (tries > 1) {
             double c = probe_region(ctx, p, bytes, nullptr);
             // the first candidate also brings the clocks up: an idle device runs its first milliseconds slower, and candidates must be compared
-            // at one clock - repeat until two measurements in a row agree within 0.5 % (at most ~60 ms)
-            for (int i = 0; k == 0 && i < 20 && c > 0; ++i) {
+            // at one clock - repeat until two measurements in a row agree within 0.5 % (at most ~60 ms, and never past the budget)
+            for (int i = 0; k == 0 && i < 20 && c > 0 && elapsed_ms() < budget_ms; ++i) {
                 const double c2 = probe_region(ctx, p, bytes, nullptr);
                 const bool steady = c2 > 0 && std::fabs(c2 - c) <= 0.005 * c;
                 c = c2;
@@ -354,15 +382,24 @@ int placed_alloc(vszip_ctx *ctx, size_t bytes, void **dptr) {
         }
         cand.emplace_back(p, rate);
         if (best < 0 || rate > cand[best].second) best = (int)cand.size() - 1;
-        if (rate >= kBestBytesPerSec) break;
+        if (rate > 0 && (worst_rate == 0.0 || rate < worst_rate)) worst_rate = rate;
+        if (rate > 0 && best_on_record > 0 ? rate >= kNearBest * best_on_record : rate >= kBestBytesPerSec) break;
     }
     if (cand.empty()) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
     for (int k = 0; k < (int)cand.size(); ++k)
         if (k != best) (void)hipFree(cand[k].first);
     {
         std::lock_guard<std::mutex> lk(placed_mu());
-        placed_map()[cand[best].first] = {(int)cand.size(), cand[best].second, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()};
+        placed_map()[cand[best].first] = {(int)cand.size(), cand[best].second, elapsed_ms()};
         g_placed_count.fetch_add(1);
+        DevicePlacement &dp = g_dev_placement[dev];
+        if (cand[best].second > dp.best_rate) dp.best_rate = cand[best].second;
+        if (cand.size() >= 4 && worst_rate > 0) {
+            if (cand[best].second - worst_rate <= kFlatSpread * cand[best].second)
+                ++dp.flat_searches;
+            else
+                dp.flat_searches = 0;
+        }
     }
     *dptr = cand[best].first;
     return VSZIP_OK;
