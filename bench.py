@@ -886,6 +886,16 @@ def plugin_legs():
     vs.lib().fakevs_set_pool_refill(0)
     vs.core_standins(True)
     try:
+        # round 6: the headline filter as a script runs it — every frame up and down the host link (24.9 MB each way; config.pcie_fed_fps is the same
+        # traffic from hipHostMalloc'd buffers through the C ABI, the bound this leg can reach)
+        y16 = make_frame(0, W4K, H4K)
+        clip = vs.source([[np.roll(p, 7 * f, axis=1) for p in y16] for f in range(8)], vs.YUV420P16).vszip.BoxBlur(hradius=RADIUS, vradius=RADIUS)
+        clip.pull(32, 16)
+        sec = clip.pull(256, 16, warm_per_thread=3)
+        out["plugin_boxblur_4k"] = {"value": 256 / sec, "unit": "frames/s", "threads": 16, "host_link_GBps": 256 * 2 * 24.8832e-3 / sec,
+                                    "workload": "libvszip.so: vszip.BoxBlur(hradius=vradius=13) on 3840x2160 YUV420P16 frames in host memory, 16 worker threads; "
+                                                "host_link_GBps counts both directions"}
+        del clip, y16
         base = [fx.tiled_natural((H4K, W4K), np.uint8, p) for p in range(3)]
         rng = np.random.default_rng(1)
         noise = rng.integers(-3, 4, (H4K, W4K), dtype=np.int16)
@@ -1169,6 +1179,9 @@ def compact_leg(leg: dict) -> dict:
     lim = leg.get("limit")
     if isinstance(lim, dict) and "bound" in lim and "frac" in lim:
         o["limit"] = {"bound": lim["bound"], "frac": lim["frac"]}
+    for k in ("threads", "host_link_GBps"):  # the plugin legs: worker threads and what crossed the host link
+        if isinstance(leg.get(k), (int, float)):
+            o[k] = leg[k]
     cpu = leg.get("cpu_baseline")  # the CPU side of the same workload, timed in this run (same unit as `value`)
     if isinstance(cpu, dict) and isinstance(cpu.get("value"), (int, float)):
         o["cpu"] = {"value": cpu["value"], "cores": cpu.get("cores")}
@@ -1208,7 +1221,7 @@ def compact_line(full: dict, detail_name: str | None = None) -> dict:
         line["detail"] = detail_name
     line = _sig(line)
     # hard bound: shed the least important parts until the line fits
-    for shed in ("limit", "unit", "cpu", "others"):
+    for shed in ("limit", "unit", "threads", "cpu", "others"):
         if len(json.dumps(line)) <= LINE_MAX_BYTES:
             break
         if shed == "others":

@@ -194,6 +194,15 @@ def fusion_stats():
     return a.value, b.value
 
 
+def upload_stats():
+    """(host planes the plugin copied to a device, uploads it answered with a copy the same getFrame had made) since it was loaded."""
+    lib()
+    pl = C.CDLL(str(PLUGIN))
+    a, b = C.c_long(), C.c_long()
+    pl.vszip_plugin_upload_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def standin_log():
     out, buf, i = [], C.create_string_buffer(256), 0
     while lib().fakevs_standin_log(i, buf, 256):

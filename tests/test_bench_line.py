@@ -60,7 +60,7 @@ def test_line_fits_the_drivers_tail_and_parses(full, tmp_path):
     # every leg: value / unit / frac / limit only
     assert set(d["others"]) == set(full["others"])
     for name, leg in d["others"].items():
-        assert set(leg) <= {"value", "unit", "frac", "whole_call_frac", "limit", "cpu", "error"}, name
+        assert set(leg) <= {"value", "unit", "frac", "whole_call_frac", "limit", "cpu", "error", "threads", "host_link_GBps"}, name
         assert "value" in leg or "error" in leg, name
     # the CPU side of every BASELINE config travels on the line: value, cores and the ratio
     for name in ("bilateral_1080p", "bilateral_4k", "ssimulacra2_4k", "eedi3_1080p", "boxblur_1080p", "boxblur_1080p_5pass"):

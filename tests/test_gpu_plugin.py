@@ -728,8 +728,12 @@ def test_fused_pipeline_into_ssimulacra2(oracle):
     base = [np.ascontiguousarray(p[:160, :256]) for p in fx.crop_rgbs()]
     src = vs.source([base], vs.RGBS, props={"_Transfer": 8})
     f0, s0 = vs.fusion_stats()
+    u0, d0 = vs.upload_stats()
     s = src.vszip.SSIMULACRA2(src.vszip.Bilateral(sigmaS=2.0, sigmaR=2.0).vszip.BoxBlur(hradius=2, vradius=2)).get_frame(0).props["SSIMULACRA2"]
     assert vs.fusion_stats() == (f0 + 1, s0 + 2)
+    # round 6: "uploads the source frame ONCE" is counted — three planes cross the link, the chain's root is answered by the reference's copy
+    # (until then the frame went up twice: the 8K pipeline's trace showed six plane copies a frame, 70 fps where three give 140)
+    assert vs.upload_stats() == (u0 + 3, d0 + 3)
     prm = oracle.bilateral_params([2], [2], yuv=False, ssw=0, ssh=0)
     want = [oracle.boxblur(oracle.bilateral_plane(p, prm["sigmaS"][i], prm["sigmaR"][i], prm["algorithm"][i], prm["radius"][i], prm["step"][i], prm["PBFICnum"][i]), 2, 1, 2, 1)
             for i, p in enumerate(base)]

@@ -40,6 +40,17 @@ struct Gpu {
     char *slab = nullptr;
     size_t slab_size = 0, used = 0;
     std::vector<void *> retired;
+    // Host planes this getFrame has uploaded already: a frame that enters a fused graph twice - SSIMULACRA2(src, src.Bilateral().BoxBlur()) reads
+    // `src` as the reference AND as the chain's root - crosses the link once (round 6: the 8K pipeline's trace showed six plane copies a frame,
+    // 70 fps; three: 130). Filters never write into an uploaded plane (outputs are blank() planes), so sharing the device copy is safe.
+    struct Uploaded {
+        const void *host;
+        ptrdiff_t host_stride;
+        int w, h, bps;
+        void *dptr;
+        ptrdiff_t dstride;
+    };
+    std::vector<Uploaded> uploaded;
 
     Gpu() = default;
     Gpu(const Gpu &) = delete;
@@ -56,6 +67,7 @@ struct Gpu {
 
     void reset() {
         used = 0;
+        uploaded.clear();
         for (void *p : retired) vszip_dev_free(ctx, p);
         retired.clear();
     }
@@ -195,6 +207,8 @@ struct HeavyFrameScope {
     }
 };
 
+std::atomic<long> g_plane_uploads{0}, g_plane_uploads_shared{0};  // diagnostics: host planes copied to a device; uploads answered by a copy the same getFrame had made
+
 struct DPlane {
     void *ptr = nullptr;
     ptrdiff_t stride = 0;  // elements
@@ -240,11 +254,25 @@ struct Z {
         d.bps = vf->bytesPerSample;
         d.w = api->getFrameWidth(f, plane);
         d.h = api->getFrameHeight(f, plane);
+        const void *host = api->getReadPtr(f, plane);
+        const ptrdiff_t hs = api->getStride(f, plane);
+        for (const Gpu::Uploaded &u : g->uploaded)
+            if (u.host == host && u.host_stride == hs && u.w == d.w && u.h == d.h && u.bps == d.bps) {
+                d.ptr = u.dptr;
+                d.stride = u.dstride;
+                g_plane_uploads_shared.fetch_add(1);
+                return d;
+            }
         const size_t pitch = ((size_t)d.w * d.bps + 255) & ~(size_t)255;
         d.stride = (ptrdiff_t)(pitch / d.bps);
         d.ptr = g->alloc(pitch * d.h);
         if (!d.ptr) return d;
-        if (vszip_copy_h2d_2d(g->ctx, d.ptr, pitch, api->getReadPtr(f, plane), (size_t)api->getStride(f, plane), (size_t)d.w * d.bps, d.h) != VSZIP_OK) d.ptr = nullptr;
+        if (vszip_copy_h2d_2d(g->ctx, d.ptr, pitch, host, (size_t)hs, (size_t)d.w * d.bps, d.h) != VSZIP_OK) {
+            d.ptr = nullptr;
+            return d;
+        }
+        g_plane_uploads.fetch_add(1);
+        g->uploaded.push_back({host, hs, d.w, d.h, d.bps, d.ptr, d.stride});
         return d;
     }
     DPlane blank(Gpu *g, int w, int h, int bps) const {
@@ -2181,6 +2209,12 @@ const char *kEedi3Args =
 extern "C" __attribute__((visibility("default"))) void vszip_plugin_fusion_stats(long *frames, long *stages) {
     if (frames) *frames = g_fused_frames.load();
     if (stages) *stages = g_fused_stages.load();
+}
+
+// ... and how many host planes crossed the link / were answered by a device copy the same getFrame already had.
+extern "C" __attribute__((visibility("default"))) void vszip_plugin_upload_stats(long *uploads, long *shared) {
+    if (uploads) *uploads = g_plane_uploads.load();
+    if (shared) *shared = g_plane_uploads_shared.load();
 }
 
 VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin *plugin, const VSPLUGINAPI *vspapi) {
