@@ -1135,7 +1135,7 @@ def xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev, frames_per_rank=8):
 # frac (+ limit); every other field goes to the sidecar file named in the line's `detail`.
 # ---------------------------------------------------------------------------
 LINE_MAX_BYTES = 7600
-CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rccl_ranks")
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rccl_ranks", "collective_backend")
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_us", "launches", "algorithmic_bytes_per_launch", "frac_median", "frac_rocprof", "rocprof_avg_launch_us", "rocprof_source")
 
 
@@ -1291,10 +1291,13 @@ def main() -> int:
     ap.add_argument("--workload", default="boxblur", choices=["boxblur", "bilateral", "ssimulacra2", "pipeline"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true")
+    ap.add_argument("--exchange-only", action="store_true", help="--no-cpu --no-others, but the per-clip exchange step (XPSNR accumulators over the collective backend) still runs: the RCCL smoke test")
     ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="kernel time of the launch-duration sample (roofline.launch_us)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1: print the rank-launch command and exit (no GPU)")
     a = ap.parse_args()
+    if a.exchange_only:
+        a.no_cpu = a.no_others = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a, [x for x in sys.argv[1:] if x != "--dry-launch"])
@@ -1384,6 +1387,7 @@ def main() -> int:
             "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "rccl_ranks": rccl_ranks,
+            "collective_backend": dist.get_backend() if use_dist else None,  # "nccl" = RCCL; None: one rank, no process group
             "config": {"workload": "vszip.BoxBlur hradius=vradius=13, 3840x2160 YUV420P16, splitmix64 noise, HBM-resident",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-parallel x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -1448,7 +1452,7 @@ def main() -> int:
                 out["config"]["unplaced_error"] = str(e)[:100]
         # The exchange step on real data: XPSNR's per-clip accumulators over RCCL (all ranks take part)
         try:
-            if not a.no_others:
+            if not a.no_others or a.exchange_only:
                 out["config"]["xpsnr_clip"] = xpsnr_clip_leg(dev, vszip_amd, rank, world, coll_dev)
         except Exception as e:
             out["config"]["xpsnr_clip"] = {"error": str(e)}
