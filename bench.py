@@ -513,6 +513,20 @@ def setup_ssimulacra2_yuv420p8(dev, w, h, pairs):
     return (lambda: dev.ssimulacra2_src(fmt, r, d)), (r, d)
 
 
+def setup_ssimulacra2_yuv444p8(dev, w, h, pairs):
+    """SSIMULACRA2 from YUV444P8 planes (round 6): no resampling, the matrix and the transfer table in a pre-stage pass of its own with the table in LDS."""
+    ref, dis = yuv420p8_pair(w, h)
+    up2 = lambda p: np.ascontiguousarray(np.repeat(np.repeat(p, 2, axis=0), 2, axis=1)[:h, :w])
+    ref = [ref[0], up2(ref[1]), up2(ref[2])]
+    dis = [dis[0], up2(dis[1]), up2(dis[2])]
+    fmt = dev.ssim_source("YUV", np.uint8, 8, ssw=0, ssh=0, matrix=1, chroma_loc=0)
+    r, d = [], []
+    for p in range(pairs):
+        r += [dev.upload(np.roll(x, p * 8, axis=1)) for x in ref]
+        d += [dev.upload(np.roll(x, p * 8, axis=1)) for x in dis]
+    return (lambda: dev.ssimulacra2_src(fmt, r, d)), (r, d)
+
+
 def setup_ssimulacra2(dev, w, h, pairs):
     ref, dis = rgbs_pair(w, h)
     r, d = [], []
@@ -797,7 +811,7 @@ def boxblur_other_paths_leg(dev, timed, frames_in=8, only=None):
         if only and name != only:
             continue
         srcs, dsts = [], []
-        frames = 64 if dt_ == np.uint8 else frames_in
+        frames = 64 if (dt_ == np.uint8 or name == "boxblur_rt_float_r5x3_4k") else frames_in  # (the float chain is bound by the parallelism a call offers: quoted at 64 frames like the headline)
         placement = None
         if name.startswith("boxblur_ct_"):  # the ring kernels: placement probed like the headline's
             step, keep_, placement = placed_batch(dev, [np.roll(p, f + 1, axis=1) for f in range(frames) for p in base], dt_, args, 8000)
@@ -820,6 +834,30 @@ def boxblur_other_paths_leg(dev, timed, frames_in=8, only=None):
             out[name]["placement"] = placement
             del keep_
         del srcs, dsts
+    return out
+
+
+def frames_per_call_sweep(dev, timed):
+    """Frames per call 1 / 4 / 16 / 64 of the headline launch and of the float pass chain: every HBM-resident figure of
+    this file is quoted at 64 frames (192 planes) a launch, a shape a batch API reaches and a one-frame-per-getFrame host does not — the sweep
+    says what the same kernels give a caller that passes fewer frames. Plain allocations (no placement search); frames/s per entry."""
+    out = {}
+    base16 = make_frame(5, W4K, H4K)
+    basef = [(p.astype(np.float32) / 65535.0) for p in base16]
+    with dev.options(VSZIP_PLACEMENT=0):
+        for name, base, args, dt_ in (("boxblur_r13_4k_u16", base16, (RADIUS, 1, RADIUS, 1), np.uint16), ("boxblur_rt_float_r5x3_4k", basef, (5, 3, 5, 3), np.float32)):
+            srcs = [dev.upload(np.roll(p, f + 1, axis=1)) for f in range(64) for p in base]
+            dsts = [dev.empty(p.shape[0], p.shape[1], p.dtype) for f in range(64) for p in base]
+            vals = []
+            for n in (1, 4, 16, 64):
+                table = dev.plane_table(srcs[: 3 * n], dsts[: 3 * n])
+                step = lambda: dev.boxblur_table(dt_, table, *args)
+                steps = max(3, (200 if dt_ == np.uint16 else 24) // n)
+                dt, _, _, _ = timed.run(step, steps, 2)
+                vals.append(n * steps / dt)
+            out[name] = vals
+            del srcs, dsts
+    out["frames_per_call"] = [1, 4, 16, 64]
     return out
 
 
@@ -1527,6 +1565,14 @@ def main() -> int:
                                                  "workload": "vszip.SSIMULACRA2 ref vs dist from 3840x2160 YUV420P8 planes (chroma upsampling + matrix + EOTF fused into "
                                                              "the first pass; 24.9 MB per pair), HBM-resident"}
             del keep
+            st, keep = setup_ssimulacra2_yuv444p8(dev, W4K, H4K, 16)
+            dt3, _, _, _ = timed.run(st, 5, 1)
+            with dev.options(VSZIP_SSIM_NO_YUV420_LDS=1):  # the fused tile kernel these clips took until round 6
+                dt4, _, _, _ = timed.run(st, 3, 1)
+            others["ssimulacra2_4k_yuv444p8"] = {"value": 16 * 5 / dt3, "unit": "pairs/s", "ms_per_pair": dt3 * 1e3 / 80, "pairs_per_call": 16, "fused_tile_kernel_pairs_s": 16 * 3 / dt4,
+                                                 "workload": "vszip.SSIMULACRA2 ref vs dist from 3840x2160 YUV444P8 planes (matrix + EOTF as a pre-stage pass with the table in LDS; "
+                                                             "49.8 MB per pair), HBM-resident; fused_tile_kernel_pairs_s: the same call with VSZIP_SSIM_NO_YUV420_LDS=1"}
+            del keep
             for leg_name, leg in (("eedi3_1080p", lambda: eedi3_leg(dev, timed, a.no_cpu)), ("xpsnr_1080p", lambda: xpsnr_leg(dev, timed, a.no_cpu))):
                 try:
                     others[leg_name] = leg()
@@ -1558,6 +1604,10 @@ def main() -> int:
                 others["boxblur_1080p_r1x2_yuv420p8"] = boxblur_gauss_leg(dev, timed)
             except Exception as e:
                 others["boxblur_1080p_5pass"] = {"error": str(e)}
+            try:
+                out["config"]["frames_per_call_sweep"] = frames_per_call_sweep(dev, timed)
+            except Exception as e:
+                out["config"]["frames_per_call_sweep"] = {"error": str(e)[:100]}
             try:
                 others.update(plugin_legs())
             except Exception as e:

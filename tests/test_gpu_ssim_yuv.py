@@ -125,6 +125,29 @@ def test_yuv420_split_pass_is_the_tile_kernel(dev, oracle, bits, crop, loc):
     assert got[2] > 99.9
 
 
+@pytest.mark.parametrize("loc", [0, 1])
+@pytest.mark.parametrize("ssw", [0, 1])
+@pytest.mark.parametrize("bits,crop", [(8, None), (16, None), (10, None), (8, (316, 628)), (8, (136, 244)), (16, (64, 68)), (8, (8, 12)), (16, (318, 636))])
+def test_yuv444_and_422_row_pass_is_the_tile_kernel(dev, oracle, bits, crop, ssw, loc):
+    """4:4:4 and 4:2:2 integer clips (round 6) go through ssim_yuvrow_rgb_kernel (persistent workgroups, transfer table in LDS; 4:2:2: taps from
+    the horizontal table's period, the frame's first and last columns from the table) + the f32 pyramid pass; VSZIP_SSIM_NO_YUV420_LDS=1 sends
+    them through the fused tile kernel. Same f32 operations in the same order: the scores are EQUAL - left- and centre-sited chroma, 8 / 10 / 16
+    bit, widths of one group, of several, ragged against the tile kernel's 256-sample tiles - and equal to the oracle's."""
+    if ssw == 0 and loc:
+        pytest.skip("4:4:4 has no chroma siting")
+    ref = _clip(bits, ssw, 0, "int", crop, loc)
+    dis = [vh.std_boxblur(p, 1, 1) for p in ref]
+    fmt = _fmt(dev, ref, bits, ssw, 0, loc=loc)
+    up = lambda ps: [dev.upload(p, 32) for p in ps]
+    got = dev.ssimulacra2_src(fmt, up(ref) + up(dis) + up(ref), up(dis) + up(ref) + up(ref))
+    with dev.options(VSZIP_SSIM_NO_YUV420_LDS=1):
+        tile = dev.ssimulacra2_src(fmt, up(ref) + up(dis) + up(ref), up(dis) + up(ref) + up(ref))
+    assert got == tile, (bits, crop, ssw, loc, got, tile)
+    assert got[2] > 99.9
+    want = oracle.ssimulacra2(vh.yuv_to_linear_rgbs(ref, bits, ssw, 0, 1, loc), vh.yuv_to_linear_rgbs(dis, bits, ssw, 0, 1, loc))
+    assert got[0] == pytest.approx(want, abs=TOL)
+
+
 @pytest.mark.parametrize("key", sorted(fx.ref_goldens()["yuv"]["ssimulacra2"]))
 def test_reference_goldens_from_raw_yuv(dev, key):
     """The reference's own YUV keys, computed by the GPU from the YUV planes (the fixture carries `_Matrix = 1`,

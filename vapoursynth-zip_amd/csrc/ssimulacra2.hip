@@ -922,6 +922,170 @@ __global__ __launch_bounds__(256 * (EDGE ? kYlEdgeTeams : YlGeo<T>::TEAMS)) void
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4:4:4 and 4:2:2 integer YUV sources, round 6: the same split as 4:2:0's — the colour pre-stage as a pass of its own with the transfer
+// table in LDS, the f32 pyramid pass behind it — for the formats whose chroma rows ARE the luma rows (no vertical resampling), where
+// the pass needs no tiles at all: a persistent workgroup a CU (1024 threads), a work item = 4 neighbouring luma samples of a row,
+// every sample read with whole-dword loads straight from global memory (4:2:2: the 6 chroma samples its four 4-tap windows span come as
+// 3 / 4 aligned dwords, cut with v_alignbyte; taps and coefficients of the horizontal table's period in the kernel argument; the groups
+// of the frame's first and last columns, where the table leaves its period, read the table and clamp). The fused kernel these formats
+// took until now is bound by the L2's request rate (48 gathers a thread from the 256 KB table). Same f32 operations in the same order.
+// ---------------------------------------------------------------------------------------------
+struct YuvRow {
+    int dh[4];            // regular columns: first tap of sample x0 + i = (x0 >> 1) + dh[i], x0 a multiple of 4 (4:2:2)
+    float ch[4][4];       // ... and their coefficients
+    int xr0, xr1;         // the regular range [xr0, xr1), multiples of 4
+    int lut_lo, lut_n, low_zero;  // as YuvLds
+    int gpr;              // groups a row (w / 4)
+    long ngroups;         // of the launch: pairs x 2 frames x h x gpr
+};
+
+template <typename T, bool HSUB>
+__global__ __launch_bounds__(1024) void ssim_yuvrow_rgb_kernel(const PyrArgs a, const YuvArgs ya, const YuvRow yr) {
+    constexpr int B = (int)sizeof(T);
+    typedef const uint32_t __attribute__((address_space(1))) *GDw;
+    typedef const T __attribute__((address_space(1))) *GSrc;
+    typedef const float __attribute__((address_space(3))) *LdsF;
+    typedef const float __attribute__((address_space(1))) *GblF;
+    typedef float __attribute__((address_space(1))) *GOut;
+    extern __shared__ __attribute__((aligned(16))) uint32_t yr_lds[];
+    float *lut = reinterpret_cast<float *>(yr_lds);
+    for (int i = threadIdx.x; i < yr.lut_n; i += 1024) lut[i] = a.lut[yr.lut_lo + i];
+    __syncthreads();
+    const long per_frame = (long)a.h * yr.gpr, stride = (long)gridDim.x * 1024;
+    auto unpack4 = [](const uint32_t *d, float s, float o, float *out) {  // four samples from their dword(s) -> zimg's float
+        if constexpr (B == 1) {
+            out[0] = yuv_cvt<uint8_t>((uint8_t)(d[0] & 0xffu), s, o); out[1] = yuv_cvt<uint8_t>((uint8_t)((d[0] >> 8) & 0xffu), s, o);
+            out[2] = yuv_cvt<uint8_t>((uint8_t)((d[0] >> 16) & 0xffu), s, o); out[3] = yuv_cvt<uint8_t>((uint8_t)(d[0] >> 24), s, o);
+        } else {
+            out[0] = yuv_cvt<uint16_t>((uint16_t)(d[0] & 0xffffu), s, o); out[1] = yuv_cvt<uint16_t>((uint16_t)(d[0] >> 16), s, o);
+            out[2] = yuv_cvt<uint16_t>((uint16_t)(d[1] & 0xffffu), s, o); out[3] = yuv_cvt<uint16_t>((uint16_t)(d[1] >> 16), s, o);
+        }
+    };
+    // A work item's samples are requested one item AHEAD (the loop was bound by the latency of load -> convert -> store with one item a
+    // thread in flight: 850 us a launch of 16 4K frames against 450 with the next item's loads under the current one's arithmetic).
+    constexpr int NW = B == 1 ? 3 : 4;  // 4:2:2: aligned dwords that hold a group's 16 taps (host-checked: dh spans at most 2 samples)
+    struct Item {
+        long g;
+        int y, x0, fr, tbmin;
+        bool regular;
+        uint32_t dy[B], dc[2][HSUB ? NW : B];
+    };
+    auto fetch = [&](long g, Item &q) {
+        q.g = g;
+        if (g >= yr.ngroups) return;
+        q.fr = (int)(g / per_frame);
+        const int rem = (int)(g - (long)q.fr * per_frame);
+        q.y = rem / yr.gpr;
+        q.x0 = (rem - q.y * yr.gpr) * 4;
+        const PyrPair *__restrict__ tp = a.tab + (q.fr >> 1);
+        const bool second = q.fr & 1;
+        const char *sy = static_cast<const char *>(second ? tp->src2[0] : tp->src1[0]) + ((size_t)q.y * a.sstride + q.x0) * B;
+#pragma unroll
+        for (int j = 0; j < B; ++j) q.dy[j] = *(GDw)(sy + 4 * j);
+        q.regular = !HSUB || (q.x0 >= yr.xr0 && q.x0 + 4 <= yr.xr1);
+        q.tbmin = 0;
+        if constexpr (HSUB) {
+            int tmin = ((q.x0 >> 1) + yr.dh[0]) * B;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) tmin = min(tmin, ((q.x0 >> 1) + yr.dh[i]) * B);
+            q.tbmin = tmin & ~3;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const char *crow = static_cast<const char *>(second ? tp->src2[1 + pl] : tp->src1[1 + pl]) + (size_t)q.y * ya.cstride * B;
+            if constexpr (!HSUB) {
+#pragma unroll
+                for (int j = 0; j < B; ++j) q.dc[pl][j] = *(GDw)(crow + (size_t)q.x0 * B + 4 * j);
+            } else {
+                const int last_dw = ya.cw * B - 4;  // byte offset of the row's last whole dword (cw * B is a multiple of 4)
+#pragma unroll
+                for (int m = 0; m < NW; ++m) q.dc[pl][m] = *(GDw)(crow + min(max(q.tbmin, 0) + 4 * m, last_dw));
+            }
+        }
+    };
+    Item nx;
+    fetch((long)blockIdx.x * 1024 + threadIdx.x, nx);
+    while (nx.g < yr.ngroups) {
+        const Item q = nx;
+        fetch(q.g + stride, nx);
+        const int y = q.y, x0 = q.x0;
+        const PyrPair *__restrict__ tp = a.tab + (q.fr >> 1);
+        const bool second = q.fr & 1;
+        float yy[4], uv[2][4];
+        unpack4(q.dy, ya.ys, ya.yo, yy);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            if constexpr (!HSUB) {
+                unpack4(q.dc[pl], ya.cs, ya.co, uv[pl]);
+            } else if (q.regular) {
+                uint32_t d[NW + 1];
+#pragma unroll
+                for (int m = 0; m < NW; ++m) d[m] = q.dc[pl][m];
+                d[NW] = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = ((x0 >> 1) + yr.dh[i]) * B - q.tbmin;  // 0 .. 4 NW - 4 B
+                    uint32_t wlo = d[0], wmd = d[1], whi = d[2];
+#pragma unroll
+                    for (int m = 1; m + 1 < NW; ++m)
+                        if ((off >> 2) == m) wlo = d[m], wmd = d[m + 1], whi = d[m + 2];
+                    uint32_t sd[2];
+                    sd[0] = __builtin_amdgcn_alignbyte(wmd, wlo, (uint32_t)off & 3u);
+                    sd[B - 1] = B == 1 ? sd[0] : __builtin_amdgcn_alignbyte(whi, wmd, (uint32_t)off & 3u);
+                    float x[4];
+                    unpack4(sd, ya.cs, ya.co, x);
+                    uv[pl][i] = yuv_two_acc(yr.ch[i][0], yr.ch[i][1], yr.ch[i][2], yr.ch[i][3], x[0], x[1], x[2], x[3]);
+                }
+            } else {  // the frame's first / last columns: taps and coefficients from the table, samples clamped into the row
+                const GSrc row = (GSrc)(static_cast<const char *>(second ? tp->src2[1 + pl] : tp->src1[1 + pl]) + (size_t)y * ya.cstride * B);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hl = ya.hleft[x0 + i];
+                    const v4f c = *reinterpret_cast<const v4f *>(ya.hcoef + 4 * (size_t)(x0 + i));
+                    float x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] = yuv_cvt<T>(row[min(hl + k, ya.cw - 1)], ya.cs, ya.co);
+                    uv[pl][i] = yuv_two_acc(c.x, c.y, c.z, c.w, x[0], x[1], x[2], x[3]);
+                }
+            }
+        }
+        // the 12 lookups: LDS first, what lies beyond the staged range fetched behind ONE wave-level branch (see ssim_yuv420_rgb_kernel)
+        float lin[3][4];
+        uint32_t li[3][4], li_max = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gg = fmaf(ya.m[3 * c + 2], uv[1][i], fmaf(ya.m[3 * c + 1], uv[0][i], ya.m[3 * c] * yy[i]));
+                int k = (int)rintf(fmaf(gg, 32768.0f, 16384.0f)) - yr.lut_lo;
+                if (yr.low_zero) k = max(k, 0);
+                li[c][i] = (uint32_t)k;
+                li_max = max(li_max, (uint32_t)k);
+                lin[c][i] = ((LdsF)lut)[min((uint32_t)k, (uint32_t)yr.lut_n - 1u)];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(li_max >= (uint32_t)yr.lut_n) != 0) {
+            asm volatile("" ::: "memory");
+            float gl[3][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int t = min(max((int)li[c][i] + yr.lut_lo, 0), 65536);
+                    gl[c][i] = ((GblF)a.lut)[li[c][i] >= (uint32_t)yr.lut_n ? t : 0];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lin[c][i] = li[c][i] >= (uint32_t)yr.lut_n ? gl[c][i] : lin[c][i];
+        }
+        const size_t o = (size_t)y * a.w + x0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pyr_put4((GOut)(second ? tp->rgb2[c] : tp->rgb1[c]), o, true, 4, lin[c][0], lin[c][1], lin[c][2], lin[c][3]);
+    }
+}
+
 // The YUV pre-stage alone (vszip_to_rgbs_linear): one thread per output sample, everything from global memory
 // (16 chroma taps per plane through the caches) — the mixed-format fallback and the tests' view of the conversion.
 template <typename T>
@@ -1707,6 +1871,10 @@ struct SsimLutCache {
     YuvLds yl{};
     int yl_span = 0;       // widest tile span, chroma samples
     int yl_lds_limit = 0;  // bytes of LDS a workgroup may take (0: not asked yet, < 0: the attribute call failed)
+    // ... for 4:4:4 / 4:2:2, what ssim_yuvrow_rgb_kernel needs (the horizontal table's period); yr_ok: the format is one of the two and the table fits
+    bool yr_ok = false;
+    YuvRow yr{};
+    int yr_lds_limit = 0;
 };
 
 SsimLutCache *lut_cache_of(vszip_ctx *ctx) {
@@ -1799,6 +1967,25 @@ static int ssim_prepare(vszip_ctx *ctx, const vszip_ssim_source *fmt, int *mode_
     return VSZIP_OK;
 }
 
+// A resampling table's period: taps and coefficients of the four samples of a group x0 .. x0 + 3 (x0 a multiple of 4) relative to x0 >> 1, taken
+// from the middle of the axis, and the range [r0, r1) of samples (multiples of 4) that follow it.
+static void ssim_axis_period(const int32_t *left, const float *coef, int n, int cn, int *d, float (*c)[4], int *r0, int *r1) {
+    const int ref = ((n / 2) / 4) * 4;
+    for (int i = 0; i < 4; ++i) {
+        d[i] = left[ref + i] - (ref >> 1);  // first tap of sample x0 + i = (x0 >> 1) + d[i], x0 a multiple of 4
+        std::memcpy(c[i], coef + 4 * (size_t)(ref + i), 16);
+    }
+    auto regular = [&](int x) {
+        const int i = x & 3;
+        return left[x] == ((x - i) >> 1) + d[i] && left[x] + 3 <= cn - 1 && std::memcmp(coef + 4 * (size_t)x, c[i], 16) == 0;
+    };
+    int lo = ref, hi = ref;
+    while (hi < n && regular(hi)) ++hi;
+    while (lo > 0 && regular(lo - 1)) --lo;
+    *r0 = (lo + 3) & ~3;
+    *r1 = hi == n ? n : (hi & ~3);
+}
+
 // 4:2:0: tile spans, the tables' period and the range of columns / rows that follow it, from the host copy of the
 // resampling tables (left[w] | left[h] | coef[4 w] | coef[4 h]); spans[] receives hspan[2 nbx] | vspan[2 nby]. A table's first tap is
 // NOT monotonic when chroma is co-sited (a sample on a chroma sample has one non-zero tap, its neighbour four that start one earlier):
@@ -1829,24 +2016,8 @@ static bool ssim_yuv420_plan(const int32_t *hleft, const float *hcoef, const int
         for (int y = y0; y < y0 + 4; ++y) lo = std::min(lo, vleft[std::min(y, h - 1)]), hi = std::max(hi, std::min(vleft[std::min(y, h - 1)] + 3, ch - 1));
         if (hi - lo + 1 > kYlNr) return false;
     }
-    auto period = [](const int32_t *left, const float *coef, int n, int cn, int *d, float (*c)[4], int *r0, int *r1) {
-        const int ref = ((n / 2) / 4) * 4;
-        for (int i = 0; i < 4; ++i) {
-            d[i] = left[ref + i] - (ref >> 1);  // first tap of sample x0 + i = (x0 >> 1) + d[i], x0 a multiple of 4
-            std::memcpy(c[i], coef + 4 * (size_t)(ref + i), 16);
-        }
-        auto regular = [&](int x) {
-            const int i = x & 3;
-            return left[x] == ((x - i) >> 1) + d[i] && left[x] + 3 <= cn - 1 && std::memcmp(coef + 4 * (size_t)x, c[i], 16) == 0;
-        };
-        int lo = ref, hi = ref;
-        while (hi < n && regular(hi)) ++hi;
-        while (lo > 0 && regular(lo - 1)) --lo;
-        *r0 = (lo + 3) & ~3;
-        *r1 = hi == n ? n : (hi & ~3);
-    };
-    period(hleft, hcoef, w, cw, yl->dh, yl->ch, &yl->xr0, &yl->xr1);
-    period(vleft, vcoef, h, ch, yl->dv, yl->cv, &yl->yr0, &yl->yr1);
+    ssim_axis_period(hleft, hcoef, w, cw, yl->dh, yl->ch, &yl->xr0, &yl->xr1);
+    ssim_axis_period(vleft, vcoef, h, ch, yl->dv, yl->cv, &yl->yr0, &yl->yr1);
     int dvmin = yl->dv[0], dvmax = yl->dv[0];
     for (int r = 1; r < 4; ++r) dvmin = std::min(dvmin, yl->dv[r]), dvmax = std::max(dvmax, yl->dv[r]);
     if (dvmax - dvmin > kYlNr - 4) return false;
@@ -1893,6 +2064,16 @@ static int ssim_yuv_args(vszip_ctx *ctx, const vszip_ssim_source *fmt, int w, in
             lc->yl_ok = ssim_yuv420_plan(reinterpret_cast<const int32_t *>(host.data()), reinterpret_cast<const float *>(host.data() + off_hc), reinterpret_cast<const int32_t *>(host.data() + off_v),
                                          reinterpret_cast<const float *>(host.data() + off_vc), w, h, cw, ch, &lc->yl, &lc->yl_span, &spans);
             if (lc->yl_ok) std::memcpy(host.data() + off_sp, spans.data(), spans.size() * 4);
+        }
+        lc->yr_ok = false;
+        if (fmt->ssh == 0 && fmt->ssw == 0) {
+            lc->yr_ok = true;  // 4:4:4: no table at all
+        } else if (fmt->ssh == 0 && fmt->ssw == 1 && w >= 8) {
+            YuvRow &yr = lc->yr;
+            ssim_axis_period(reinterpret_cast<const int32_t *>(host.data()), reinterpret_cast<const float *>(host.data() + off_hc), w, cw, yr.dh, yr.ch, &yr.xr0, &yr.xr1);
+            int dhmin = yr.dh[0], dhmax = yr.dh[0];
+            for (int i = 1; i < 4; ++i) dhmin = std::min(dhmin, yr.dh[i]), dhmax = std::max(dhmax, yr.dh[i]);
+            lc->yr_ok = dhmax - dhmin <= 2;  // (a group's 16 taps out of 3 / 4 aligned dwords)
         }
         VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a launch still reading the old tables
         if (lc->ybytes < bytes) {
@@ -1993,6 +2174,28 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         }
     }
 
+    // 4:4:4 / 4:2:2 integer clips (round 6): the same split with ssim_yuvrow_rgb_kernel
+    bool split_row = false;
+    if (mode == PYR_YUV && !split) {
+        SsimLutCache *lc = lut_cache_of(ctx);
+        const int B = fmt->dtype == VSZIP_U8 ? 1 : 2;
+        split_row = lc->yr_ok && fmt->ssh == 0 && fmt->ssw <= 1 && !ctx->opt.ssim_no_yuv420_lds && fmt->linearize && (fmt->dtype == VSZIP_U8 || fmt->dtype == VSZIP_U16) &&
+                    lc->yr_lds_limit >= 0 && (w & 3) == 0 && ((size_t)stride * B) % 4 == 0 && ((size_t)ya.cstride * B) % 4 == 0 && (ya.cw * B) % 4 == 0 && (size_t)w * h < ((size_t)1 << 30);
+        for (int i = 0; split_row && i < npairs; ++i)
+            for (int c = 0; c < 3; ++c)
+                if ((reinterpret_cast<uintptr_t>(ref_planes[i * nsp + c]) | reinterpret_cast<uintptr_t>(dis_planes[i * nsp + c])) & 3) split_row = false;
+        if (split_row && lc->yr_lds_limit == 0) {
+            const int want = 160 * 1024;
+            bool ok = true;
+            for (const void *fn : {reinterpret_cast<const void *>(ssim_yuvrow_rgb_kernel<uint8_t, false>), reinterpret_cast<const void *>(ssim_yuvrow_rgb_kernel<uint8_t, true>),
+                                   reinterpret_cast<const void *>(ssim_yuvrow_rgb_kernel<uint16_t, false>), reinterpret_cast<const void *>(ssim_yuvrow_rgb_kernel<uint16_t, true>)})
+                ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+            (void)hipGetLastError();
+            lc->yr_lds_limit = ok ? want : -1;
+            split_row = ok;
+        }
+    }
+
     int sw[kScales + 1], sh[kScales + 1];
     sw[0] = w;
     sh[0] = h;
@@ -2008,8 +2211,11 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         for (int c = 0; c < 3; ++c) nneed[s] += skip_of(c, s).all() ? 0 : 1;
     }
     const int tiles0 = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
-    const size_t f_x0 = 2 * nneed[0] * npx[0], f_x1 = 2 * nneed[1] * npx[1], f_r2 = 6 * npx[2], f_xs = 6 * npx[2], f_r3 = 6 * npx[3], f_r4 = 6 * npx[4];
-    const size_t f_rgb = split ? 6 * npx[0] : 0;  // the two frames' linear RGB between the pre-stage pass and the pyramid pass
+    // (every region starts on a multiple of 4 floats: the linear-RGB planes behind them are written and read with 16-byte accesses - ADVICE r5: 6 npx[3] + 6 npx[4]
+    // is 2 mod 4 for e.g. 1924 x 1080)
+    auto al4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    const size_t f_x0 = al4(2 * nneed[0] * npx[0]), f_x1 = al4(2 * nneed[1] * npx[1]), f_r2 = al4(6 * npx[2]), f_xs = al4(6 * npx[2]), f_r3 = al4(6 * npx[3]), f_r4 = al4(6 * npx[4]);
+    const size_t f_rgb = (split || split_row) ? 6 * npx[0] : 0;  // the two frames' linear RGB between the pre-stage pass and the pyramid pass
     const size_t f_pair = (f_x0 + f_x1 + f_r2 + f_xs + f_r3 + f_r4 + f_rgb + 63) & ~(size_t)63;
     const size_t bytes_part = ((size_t)npairs * 18 * tiles0 * 6 * sizeof(double) + 255) & ~(size_t)255;
     const size_t bytes_avg = ((size_t)npairs * 18 * 6 * sizeof(double) + 255) & ~(size_t)255;
@@ -2067,7 +2273,7 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         for (int c = 0; c < 3; ++c) {
             py.r2a[c] = r2 + (size_t)c * npx[2];
             py.r2b[c] = r2 + (size_t)(3 + c) * npx[2];
-            if (split) {
+            if (split || split_row) {
                 py.rgb1[c] = r4 + f_r4 + (size_t)c * npx[0];
                 py.rgb2[c] = r4 + f_r4 + (size_t)(3 + c) * npx[0];
             }
@@ -2145,6 +2351,31 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
                 }
             }
             PyrArgs pb = pa;  // the f32 pass over the frames' linear RGB planes (dense rows of w floats, 16-byte aligned: w % 4 == 0)
+            pb.from_rgb = 1;
+            pb.sstride = w;
+            pb.vec_ok = 1;
+            launch_pyr<float, PYR_F32_LINEAR>(false, grid, st, pb);
+        } else if (mode == PYR_YUV && split_row) {
+            SsimLutCache *lc = lut_cache_of(ctx);
+            YuvRow yr = lc->yr;
+            yr.lut_n = std::min(65537, (lc->yr_lds_limit / 4 - 8) & ~3);
+            const int zero_upto = srgb_table_zero_upto();
+            yr.low_zero = zero_upto > 0 && zero_upto + yr.lut_n <= 65537;
+            yr.lut_lo = yr.low_zero ? zero_upto : std::min(std::max(32768 - yr.lut_n / 2, 0), 65537 - yr.lut_n);
+            yr.gpr = w / 4;
+            yr.ngroups = (long)cnt * 2 * h * yr.gpr;
+            const int lds = ((yr.lut_n + 3) & ~3) * 4, cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+            const dim3 groups((unsigned)std::min<long>(cus, (yr.ngroups + 1023) / 1024)), threads(1024);
+            const bool hsub = fmt->ssw == 1;
+            if (fmt->dtype == VSZIP_U8 && !hsub)
+                hipLaunchKernelGGL((ssim_yuvrow_rgb_kernel<uint8_t, false>), groups, threads, lds, st, pa, ya, yr);
+            else if (fmt->dtype == VSZIP_U8)
+                hipLaunchKernelGGL((ssim_yuvrow_rgb_kernel<uint8_t, true>), groups, threads, lds, st, pa, ya, yr);
+            else if (!hsub)
+                hipLaunchKernelGGL((ssim_yuvrow_rgb_kernel<uint16_t, false>), groups, threads, lds, st, pa, ya, yr);
+            else
+                hipLaunchKernelGGL((ssim_yuvrow_rgb_kernel<uint16_t, true>), groups, threads, lds, st, pa, ya, yr);
+            PyrArgs pb = pa;  // the f32 pass over the frames' linear RGB planes
             pb.from_rgb = 1;
             pb.sstride = w;
             pb.vec_ok = 1;
