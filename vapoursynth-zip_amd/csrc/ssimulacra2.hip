@@ -2495,15 +2495,13 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
     };
 
     // ---- the schedule ----
-    // The pyramid pass is HBM bound (311 MB a 4K pair), the maps kernels are issue bound: a call's pairs go in two HALVES on two streams, the second
-    // half's pyramid pass beside the first half's large maps scales. Scales 2 .. (a sixteenth of the samples and less, launch bound) run ONCE for all
-    // pairs, on the second stream, when both pyramid passes are done; then the final reduction.
-    // Measured and not kept (round 5, tools/ssim_ab.py, 4K, 16 pairs a call, one process): groups of 1 / 2 / 3 / 4 pairs alternating between the
-    // streams, so that a group's XYB planes (112 MB a pair) would be read back out of the Infinity Cache right after they were written - 5.9 / 6.4 / 6.9 /
-    // 6.9 k pairs/s against 6.95 k for the halves (smaller launches pay their ramps and tails eight times over; the maps kernels are not waiting for
-    // memory: with the tile fetch compiled out they run 3.5 % faster); a small first group (1 - 4 pairs, then halves of the rest) to shorten the
-    // only pyramid pass with nothing beside it - 6.93 / 6.93 / 6.77 / 6.74 k.
-    bool two = npairs >= 2 && kScales > 2 && !ctx->opt.ssim_one_stream;
+    // Two streams: the pyramid pass of all pairs, then the large scales' maps kernels (issue bound) on the context's stream and BESIDE them, on a
+    // second stream, the small scales (2 ..: a sixteenth of the samples and less, launch bound); join, final reduction.
+    // Round 6 (tools/ssim_small_calls.py, interleaved library A/B, pairs/s, linear RGBS): round 5 cut a call of 4 pairs and more into two halves -
+    // the second half's pyramid pass beside the first half's maps - and ran the small scales after both; the small scales beside the maps is
+    // faster at every size: 1080p x 1 / 4 / 16 pairs a call 5.7 / 15.5 / 25.0 k against 4.5 / 11.7 / 22.5 k, 4K 3.95 / 5.8 / 7.7 k against 2.9 / 5.25 / 7.36 k
+    // (one pair - a VapourSynth getFrame - ran on ONE stream before: ADVICE r5). Round 5's other measured alternatives: profiles/r05_notes.md 1.
+    bool two = kScales > 2 && !ctx->opt.ssim_one_stream;
     if (two && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
@@ -2520,29 +2518,15 @@ VSZIP_EXPORT int vszip_ssimulacra2_src(vszip_ctx *ctx, const vszip_ssim_source *
         }
     } else {
         hipStream_t st[2] = {ctx->stream, ctx->side_stream};
-        int sizes[2] = {npairs, 0}, ngroups = 1;
-        if (!ctx->opt.ssim_no_halves && npairs >= 4) {
-            sizes[0] = npairs / 2;
-            sizes[1] = npairs - sizes[0];
-            ngroups = 2;
-        }
-        for (int g = 0, p0 = 0; g < ngroups; p0 += sizes[g], ++g) {
-            const int cnt = sizes[g];
-            hipStream_t s_ = st[g & 1];
-            if (g == 1) VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(s_, ctx->side_fork, 0));  // (also orders the pointer-table upload before the second stream)
-            launch_pyramid(p0, cnt, s_);
-            if (g == 0) VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, s_));
-            launch_maps(0, p0, cnt, s_, s_ == ctx->stream);
-            launch_maps(1, p0, cnt, s_, s_ == ctx->stream);
-        }
-        if (ngroups == 1) VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[1], ctx->side_fork, 0));
-        // the small scales of every pair: the second stream, after the first stream's last pyramid pass (everything of its own is in stream order)
-        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, st[0]));
-        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[1], ctx->side_join, 0));
+        launch_pyramid(0, npairs, st[0]);
+        VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, st[0]));
+        VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[1], ctx->side_fork, 0));  // (also orders the pointer-table upload before the second stream)
         for (int scale = 2; scale < kScales; ++scale) {
             launch_xyb_down(scale, 0, npairs, st[1]);
             launch_maps(scale, 0, npairs, st[1], false);
         }
+        launch_maps(0, 0, npairs, st[0], true);
+        launch_maps(1, 0, npairs, st[0], true);
         VSZIP_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, st[1]));
         VSZIP_HIP_CHECK(ctx, hipStreamWaitEvent(st[0], ctx->side_join, 0));
     }
