@@ -184,6 +184,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
     float *out = pl.dst + (size_t)line * pl.dstride;
     int *dmap = pl.dmap + (size_t)off * w;
     const int reach = 2 * mdis + nrad, roww = kXB + 2 * reach;
+    // the four source rows start on 8-byte boundaries (every VapourSynth plane: 32-byte aligned rows): blocks inside the line are staged in pairs
+    const bool pair_ok = __builtin_amdgcn_readfirstlane((int)(((reinterpret_cast<uintptr_t>(r3p) | reinterpret_cast<uintptr_t>(r1p) | reinterpret_cast<uintptr_t>(r1n) | reinterpret_cast<uintptr_t>(r3n)) & 7) == 0)) != 0;
 
     const int mlim = MASK ? prm.mdis : MD;  // (MASK) directions beyond it never get a cost
     if constexpr (MASK) {
@@ -201,12 +203,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
         const int c0 = xb - reach;  // plane column of rows[.][0]
         // ---- stage the four source rows once per block ------------------------------------
         wave_fence();
-        for (int t = lane; t < roww; t += 64) {
-            const int c = min(c0 + t, w - 1 + reach);  // columns past the padding are never read back
-            rows[0][t] = rowv(r3p, c, w);
-            rows[1][t] = rowv(r1p, c, w);
-            rows[2][t] = rowv(r1n, c, w);
-            rows[3][t] = rowv(r3n, c, w);
+        // Round 6: a block whose staged columns all lie inside the line (every block but the first and the last one or two) needs no mirror
+        // arithmetic, and with an even first column its samples come as 8-byte pairs: 2 loads and 2 LDS writes a row instead of 3 + 3 and the
+        // ~8 instructions of rowv() a sample - 5 % of the kernel's instructions went into this staging loop.
+        if (c0 >= 0 && c0 + roww <= w && pair_ok && (c0 & 1) == 0) {  // (wave-uniform)
+            for (int t = 2 * lane; t < roww; t += 128) {
+                const float2 v0 = *reinterpret_cast<const float2 *>(r3p + c0 + t), v1 = *reinterpret_cast<const float2 *>(r1p + c0 + t);
+                const float2 v2 = *reinterpret_cast<const float2 *>(r1n + c0 + t), v3 = *reinterpret_cast<const float2 *>(r3n + c0 + t);
+                *reinterpret_cast<float2 *>(&rows[0][t]) = v0;
+                *reinterpret_cast<float2 *>(&rows[1][t]) = v1;
+                *reinterpret_cast<float2 *>(&rows[2][t]) = v2;
+                *reinterpret_cast<float2 *>(&rows[3][t]) = v3;
+            }
+        } else {
+            for (int t = lane; t < roww; t += 64) {
+                const int c = min(c0 + t, w - 1 + reach);  // columns past the padding are never read back
+                rows[0][t] = rowv(r3p, c, w);
+                rows[1][t] = rowv(r1p, c, w);
+                rows[2][t] = rowv(r1n, c, w);
+                rows[3][t] = rowv(r3n, c, w);
+            }
         }
         wave_fence();
         const int lx = lane + reach;  // rows[] index of column x
@@ -1495,7 +1511,7 @@ constexpr int kVcNT = 1024;  // threads of a chain workgroup (512 / 256 with mor
 // SC: an sclip is present (its row rides in the prefetch sets; without one the sets are a quarter smaller).
 template <bool HP, int VC, int C, bool SC>
 __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams prm) {
-    static_assert(kVcNT == 1024 && C >= 2 && C <= 4, "rows of C * 1024 samples");
+    static_assert(kVcNT == 1024 && C >= 1 && C <= 4, "rows of C * 1024 samples");
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     const int pslot = prm.plane_base + (int)blockIdx.x;
     const EPlane pl = prm.p[pslot];
@@ -1504,7 +1520,7 @@ __global__ __launch_bounds__(kVcNT) void eedi3_vcheck_lds_kernel(const VParams p
     const int scstride = scp ? prm.scstride[pslot] : pl.dstride;
     const int L = pl.w, n_dst = pl.n_dst;
     const int tid = threadIdx.x;
-    constexpr int kPitch = C == 2 ? 2048 : C == 3 ? 2560 : 4096;  // fixed: slot offsets are compile-time constants
+    constexpr int kPitch = C == 1 ? 1024 : C == 2 ? 2048 : C == 3 ? 2560 : 4096;  // fixed: slot offsets are compile-time constants
     constexpr int kOdd = 3, kEven = 3, kBlend = 2, kMapRing = 6, kAhead = 3, kPeriod = 6;
     float *odd = reinterpret_cast<float *>(vsm);           // odd rows (kept field lines): row pd - 1 + 2 k of line q in slot (q + k) % 3
     float *even = odd + (size_t)kOdd * kPitch;             // interpolated, un-blended: row pd + 2 k in slot (q + k) % 3
@@ -1865,11 +1881,11 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
 #ifdef VSZIP_VC_COLS_BY_CALL  // (sweeps)
         gl = maxL;
 #endif
-        const int cols = gl <= 2048 ? 2 : gl <= 2560 ? 3 : 4;
+        const int cols = gl <= 1024 ? 1 : gl <= 2048 ? 2 : gl <= 2560 ? 3 : 4;  // (round 6: one column a thread for lines up to 1024 samples - the chroma of a 1080p 4:2:0 frame; with two, half the workgroup idled through every line)
         bool any_sc = false;
         for (int i = first; i < first + count; ++i) any_sc = any_sc || vp.scp[i] != nullptr;
         vp.plane_base = first;
-        const size_t lds = (size_t)(cols == 2 ? 2048 : cols == 3 ? 2560 : 4096) * (8 * sizeof(float) + 6);  // three odd, three even, two blended rows, six int8 map rows
+        const size_t lds = (size_t)(cols == 1 ? 1024 : cols == 2 ? 2048 : cols == 3 ? 2560 : 4096) * (8 * sizeof(float) + 6);  // three odd, three even, two blended rows, six int8 map rows
 #define VSZIP_VC_LAUNCH3(HPV, VCV, CV, SCV)                                                                                                          \
     do {                                                                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eedi3_vcheck_lds_kernel<HPV, VCV, CV, SCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -1884,7 +1900,9 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     } while (0)
 #define VSZIP_VC_LAUNCH1(HPV, VCV)            \
     do {                                      \
-        if (cols == 2)                        \
+        if (cols == 1)                        \
+            VSZIP_VC_LAUNCH2(HPV, VCV, 1);    \
+        else if (cols == 2)                   \
             VSZIP_VC_LAUNCH2(HPV, VCV, 2);    \
         else if (cols == 3)                   \
             VSZIP_VC_LAUNCH2(HPV, VCV, 3);    \
