@@ -134,6 +134,73 @@ def test_minmax_single_read_and_its_second_sweep(dev, oracle, dtype, monkeypatch
             assert df[i] == (odf if np.dtype(dtype).kind == "u" else pytest.approx(odf, rel=1e-12))
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.float16])
+def test_minmax_temporal_prediction_hits_and_misses(dev, oracle, dtype):
+    """Round 6: a thresholded call of the same shape as the previous one sweeps its planes ONCE over the value ranges the previous call's answers
+    predict (hist_sweep_kernel MODE 1); planes whose answers lie elsewhere - a scene cut - are flagged and take the two histogram sweeps.
+    The same planes again (prediction exact), a slightly different frame (prediction close), inverted content (prediction wrong on every plane),
+    constant planes, a mix of hits and misses in one call, other thresholds (another shape: no prediction), and VSZIP_MINMAX_NO_PREDICT=1:
+    every result equals the oracle's."""
+    import vszip_amd
+
+    d = vszip_amd.Device(0)  # a context of its own: the prediction table is per context
+    try:
+        shapes = [(203, 331), (120, 200), (203, 331), (64, 96)]
+        kind = np.dtype(dtype).kind
+        frame_a = [fx.tiled_natural(s, dtype, i % 3) for i, s in enumerate(shapes)]
+        if kind == "u":
+            frame_b = [np.clip(p.astype(np.int32) + 37, 0, 65535).astype(dtype) for p in frame_a]  # the "next frame": a small shift
+            frame_c = [(65535 - p).astype(dtype) for p in frame_a]                                  # a scene cut: everything elsewhere
+            frame_d = [frame_a[0], frame_c[1], np.full(shapes[2], 777, dtype), frame_b[3]]           # hits, a miss and a constant plane in one call
+        else:
+            frame_b = [np.clip(p.astype(np.float32) + 0.0006, 0, 1).astype(dtype) for p in frame_a]
+            frame_c = [(1.0 - p.astype(np.float32)).astype(dtype) for p in frame_a]
+            frame_d = [frame_a[0], frame_c[1], np.full(shapes[2], 0.3, dtype), frame_b[3]]
+        refs = [fx.splitmix64_plane(60 + i, s, dtype) for i, s in enumerate(shapes)]
+        dr = [d.upload(r) for r in refs]
+
+        def check(frame, thr, with_ref, tag):
+            ds = [d.upload(p) for p in frame]
+            mn, mx, df = d.plane_minmax(ds, thr[0], thr[1], dr if with_ref else None)
+            for i, p in enumerate(frame):
+                omn, omx, odf = oracle.plane_minmax(p, thr[0], thr[1], refs[i] if with_ref else None)
+                assert (mn[i], mx[i]) == (omn, omx), (tag, dtype, thr, i, mn[i], omn, mx[i], omx)
+                if with_ref:
+                    assert df[i] == (odf if kind == "u" else pytest.approx(odf, rel=1e-12)), (tag, i)
+
+        for with_ref in (False, True):
+            thr = (0.1, 0.1)
+            check(frame_a, thr, with_ref, "first call: two sweeps")
+            check(frame_a, thr, with_ref, "the same frame: predicted")
+            check(frame_b, thr, with_ref, "the next frame: predicted, close")
+            check(frame_c, thr, with_ref, "scene cut: every plane flagged")
+            check(frame_c, thr, with_ref, "after the cut: predicted again")
+            check(frame_d, thr, with_ref, "hits, a miss and a constant plane")
+            check(frame_a, (0.02, 0.3), with_ref, "other thresholds: another shape, two sweeps")
+            check(frame_b, (0.02, 0.3), with_ref, "predicted under the new thresholds")
+            check(frame_a, (1.0, 1.0), with_ref, "nothing qualifies")
+            check(frame_b, (1.0, 1.0), with_ref, "nothing qualifies, predicted")
+            check(frame_a, (0.999, 0.0), with_ref, "extreme quantile")
+            check(frame_c, (0.999, 0.0), with_ref, "extreme quantile, predicted from the wrong end")
+            with d.options(VSZIP_MINMAX_NO_PREDICT=1):
+                check(frame_a, (0.999, 0.0), with_ref, "prediction off")
+    finally:
+        d.close()
+
+
+def test_minmax_temporal_prediction_across_batches(dev, oracle):
+    """more than 192 planes a call: every batch of the queue keeps its own predictions (400 planes = 192 + 192 + 16), two rounds of two frames"""
+    shapes = [(96, 160), (48, 80), (37, 53)]
+    f0 = [fx.tiled_natural(shapes[i % 3], np.uint16, i % 3) if i % 4 else fx.splitmix64_plane(300 + i, shapes[i % 3], np.uint16) for i in range(400)]
+    f1 = [np.roll(p, 3, axis=1) if i % 7 else (65535 - p).astype(np.uint16) for i, p in enumerate(f0)]
+    for frame in (f0, f1, f0, f1):
+        ds = [dev.upload(p) for p in frame]
+        mn, mx, _ = dev.plane_minmax(ds, 0.05, 0.1)
+        for i, p in enumerate(frame):
+            omn, omx, _ = oracle.plane_minmax(p, 0.05, 0.1)
+            assert (mn[i], mx[i]) == (omn, omx), i
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 def test_many_planes_one_call_and_the_async_entry_points(dev, oracle, dtype):
     """Round 4: a call of more than 192 planes is queued as groups back to back with ONE synchronise at the end (results of every group in their own entries of

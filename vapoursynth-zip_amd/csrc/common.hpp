@@ -81,6 +81,11 @@ struct vszip_ctx {
         size_t wb, rows;
     };
     std::vector<PendingOut> pending_out;
+    // thresholded PlaneMinMax on 16-bit / float planes: where the previous call's answers lay, per plane (device, [planes][2] words), and what that
+    // call looked like — a call of the same shape (the next frames of a clip) looks there first and reads its planes once (planestats.hip)
+    void *minmax_pred = nullptr;
+    size_t minmax_pred_planes = 0;
+    std::vector<uint64_t> minmax_sig;  // per batch of the call: signature of the last thresholded call that left predictions (0: none)
     void *chain_buf = nullptr;  // vszip_chain_run: intermediate planes (grow-only)
     size_t chain_bytes = 0;
     void *ssim_lut = nullptr;  // SSIMULACRA2 colour pre-stage: cached conversion table (ssimulacra2.hip)
@@ -94,6 +99,7 @@ hipError_t vszip_hip_malloc(vszip_ctx *ctx, void **p, size_t bytes);  // the lib
 int vszip_ensure_scalars(vszip_ctx *ctx, size_t bytes);
 void vszip_ssim_release(vszip_ctx *ctx);  // frees ctx->ssim_lut
 void vszip_chain_release(vszip_ctx *ctx);  // frees ctx->chain_buf
+void vszip_planestats_release(vszip_ctx *ctx);  // frees ctx->minmax_pred
 void vszip_bilateral_forget_lut(const void *dptr);  // vszip_dev_free: a packed range LUT goes with its allocation
 // Bracket the launch of a filter's dominant kernel; no-ops unless the probe is enabled.
 void vszip_probe_mark(vszip_ctx *ctx);

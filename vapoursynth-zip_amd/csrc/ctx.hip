@@ -216,6 +216,7 @@ VSZIP_EXPORT void vszip_ctx_destroy(vszip_ctx *ctx) {
     if (ctx->xpsnr_sums) (void)hipFree(ctx->xpsnr_sums);
     vszip_ssim_release(ctx);
     vszip_chain_release(ctx);
+    vszip_planestats_release(ctx);
     if (ctx->scalars_dev) (void)hipFree(ctx->scalars_dev);
     if (ctx->scalars_host) (void)hipHostFree(ctx->scalars_host);
     if (ctx->stage) (void)hipHostFree(ctx->stage);

@@ -13,12 +13,25 @@
 // and a second sweep histograms the low byte inside those two buckets. Integer results
 // are exact; float sums differ from the reference's sequential f64 order by rounding only.
 #include "common.hpp"
+#include <cstring>
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxPlanesPS = 192;  // planes per launch (the per-plane table travels in the kernel argument: 7.7 KB): 64 YUV frames are ONE launch (round 4; 48 before)
 constexpr int kHistWords = 4096, kBucketWords = 16;
+// thresholded PlaneMinMax, single-read sweep: the candidate ranges (see hist_sweep_kernel MODE 1). Round 6, tools/minmax_thr_timing.py (64 x 4K YUV420P16 a call,
+// k frames/s on noise / the test picture / the picture x 257; two sweeps: 93 on all three): 1280 values x 4 copies (round 3's, sized for a row sample's error)
+// 134 / 93 / 93; 768 x 4: 131 / 111 / 111; 512 x 4: 137 / 122 / 124; 512 x 8: 137 / 132 / 135; 256 x 8: 135 / 133 / 137 - on pictures the samples INSIDE a range
+// (and their queues on equal values) are what the sweep pays for, and the previous frame's answer needs no wide range: +-256 values (one 8-bit level).
+#ifndef VSZIP_MM_RANGE  // (sweeps)
+#define VSZIP_MM_RANGE 512
+#endif
+#ifndef VSZIP_MM_RCOPIES
+#define VSZIP_MM_RCOPIES 8
+#endif
+constexpr int kRange = VSZIP_MM_RANGE, kRangeCopies = VSZIP_MM_RCOPIES;  // values a candidate range spans (a multiple of 256), interleaved copies of its bins
+static_assert(kRange % 256 == 0 && kRange >= 256, "range_scan walks 256-bin chunks");
 [[maybe_unused]] constexpr int kSampleStep = 16;  // thresholded PlaneMinMax: table sizes; every 16th row is sampled
 
 struct PSPlane {
@@ -43,6 +56,7 @@ struct PSParams {
                          // high bucket, [512..] round 3: the histograms of the two candidate RANGES of the single-read path
     uint32_t *bucket;    // [nplanes][kBucketWords]: see locate_buckets
     uint32_t *shist;     // [nplanes][256]: high-byte histogram of the row SAMPLE (single-read path)
+    uint32_t *pred;      // [nplanes][2] or NULL: the candidate ranges' first values for the NEXT call on the same planes, written with every result (round 6, see run_minmax_t)
     double *result;      // [nplanes][4]
     float minthr, maxthr;
     float peak;
@@ -514,6 +528,10 @@ __device__ __forceinline__ void write_result(const PSParams &prm, int pi, int is
         res[2] = d / total;
     }
     prm.bucket[pi * kBucketWords + 11] = 1u;
+    if (prm.pred) {  // where the next frame's thresholds are looked for first: a range of kRange values centred on this frame's answers
+        prm.pred[pi * 2] = (uint32_t)max((int)retmin - kRange / 2, 0);
+        prm.pred[pi * 2 + 1] = (uint32_t)max((int)retmax - kRange / 2, 0);
+    }
 }
 
 // the plane's results from the bucket words (st[], LDS) and the low-byte histograms of the second sweep (planeminmax.zig:43-64)
@@ -562,7 +580,6 @@ __global__ __launch_bounds__(64) void thr_final_kernel(const PSParams prm, int w
 // starts at the samples below the range). When an answer lies outside its range — the sampled quantile was more than two 8-bit
 // levels off — the plane is flagged and goes through the two histogram sweeps; their workgroups return at once for every other plane.
 // Results are identical either way (tests/test_gpu_planestats.py::test_minmax_single_read_and_its_second_sweep forces both).
-constexpr int kCandHalf = 2, kRange = (2 * kCandHalf + 1) * 256, kRangeCopies = 4;
 // LDS histogram adds that survive real pictures: neighbouring samples of a picture share their high byte, so 64 lanes x 8 samples
 // would queue on one or two LDS words (measured: the histogram sweep took 3x as long on the test picture as on noise). The table is
 // kept in kCopies interleaved copies (lane & 15: sixteen neighbouring banks), which divides the queue by sixteen. (Merging the runs
@@ -626,8 +643,8 @@ __global__ __launch_bounds__(kThreads) void hist_sample_kernel(const PSParams pr
         // Nothing in the sample exceeds a threshold (thr = 1, or a plane too short to be sampled): an empty range that everything lies below
         // (low side) / whose end everything lies at or above (high side); the sweep's last workgroup then either knows that no value
         // qualifies or flags the plane.
-        bk[8] = tmp[0] == 0xffffffffu ? 0x10000u : (uint32_t)max((int)tmp[0] - kCandHalf, 0) << 8;
-        bk[9] = tmp[2] == 0xffffffffu ? (uint32_t)-kRange : (uint32_t)max((int)tmp[2] - kCandHalf, 0) << 8;
+        bk[8] = tmp[0] == 0xffffffffu ? 0x10000u : (uint32_t)max(((int)tmp[0] << 8) + 128 - kRange / 2, 0);
+        bk[9] = tmp[2] == 0xffffffffu ? (uint32_t)-kRange : (uint32_t)max(((int)tmp[2] << 8) + 128 - kRange / 2, 0);
     }
 }
 
@@ -704,6 +721,8 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
                 const uint32_t dl = idx - lo_start, eh = idx - hi_start - (uint32_t)kRange;
                 below_lo += dl >> 31;
                 below_hi_end += eh >> 31;
+                // (round 6, measured and not kept: ONE unconditional add a sample, out-of-range samples into a word of the thread's own - 80 k frames/s
+                // against 92-134 k: the add itself is what costs, and the branches skip it for most samples)
                 if (dl < (uint32_t)kRange) atomicAdd(&tab[dl * kRangeCopies + rcopy], 1u);
                 if (eh + (uint32_t)kRange < (uint32_t)kRange) atomicAdd(&tab[(eh + 2u * kRange) * kRangeCopies + rcopy], 1u);
             }
@@ -887,6 +906,7 @@ int prepare(vszip_ctx *ctx, const vszip_plane *planes, int nplanes, bool need_re
     prm.bucket = reinterpret_cast<uint32_t *>(p);
     p += (size_t)nplanes * kBucketWords * sizeof(uint32_t);
     prm.shist = reinterpret_cast<uint32_t *>(p);
+    prm.pred = nullptr;
     return VSZIP_OK;
 }
 
@@ -959,10 +979,55 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
     return VSZIP_OK;
 }
 
+// Thresholded calls on 16-bit / float planes, round 6: TEMPORAL prediction. The two-level radix reads every plane twice because the buckets the
+// thresholds fall into are known only after a full sweep; round 3's single-read sweep (MODE 1: exact histograms of two candidate ranges of
+// 5 x 256 values + the counts below them, flagged planes fall back to the two sweeps) needed a row-sample pass to predict the ranges and lost
+// on pictures. A clip's next frame is the better predictor: every result leaves "its answer, two 8-bit levels either side" in a per-context
+// table (PSParams::pred), and a call of the same shape as the previous one (plane count and sizes, sample type, thresholds) sweeps ONCE over
+// those ranges. A scene cut, another clip or a first call cost what they always did — the flagged planes' two sweeps — and the results are the
+// reference's either way (tests/test_gpu_planestats.py::test_minmax_temporal_prediction*). VSZIP_MINMAX_NO_PREDICT=1: always two sweeps.
+static uint64_t minmax_signature(const Launch &L, int dtype_size, bool ref) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix((uint64_t)L.prm.nplanes);
+    mix((uint64_t)dtype_size);
+    mix(ref ? 2 : 1);
+    mix((uint64_t)L.prm.hist_size);
+    uint32_t a, b;
+    std::memcpy(&a, &L.prm.minthr, 4);
+    std::memcpy(&b, &L.prm.maxthr, 4);
+    mix(((uint64_t)a << 32) | b);
+    for (int i = 0; i < L.prm.nplanes; ++i) mix(((uint64_t)(uint32_t)L.prm.p[i].w << 32) | (uint32_t)L.prm.p[i].h);
+    return h ? h : 1;
+}
+
 template <typename T, bool REF>
-int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
+int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch) {
     constexpr int is_int = Smp<T>::is_int ? 1 : 0;
     constexpr int wide = sizeof(T) > 1 ? 1 : 0;
+    bool predicted = false;
+    if (wide && !no_thr && !ctx->opt.minmax_no_predict && batch >= 0) {
+        const size_t first = (size_t)batch * kMaxPlanesPS, need = first + (size_t)L.prm.nplanes;
+        if (ctx->minmax_pred_planes < need) {  // grow-only, old predictions kept
+            const size_t cap = std::max<size_t>(need, 2 * ctx->minmax_pred_planes);
+            void *np = nullptr;
+            VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (vszip_hip_malloc(ctx, &np, cap * 2 * sizeof(uint32_t)) != hipSuccess) return vszip_set_error(ctx, VSZIP_ERR_NOMEM, "PlaneMinMax: prediction table allocation failed");
+            if (ctx->minmax_pred) {
+                VSZIP_HIP_CHECK(ctx, hipMemcpy(np, ctx->minmax_pred, ctx->minmax_pred_planes * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                (void)hipFree(ctx->minmax_pred);
+            }
+            ctx->minmax_pred = np;
+            ctx->minmax_pred_planes = cap;
+        }
+        L.prm.pred = static_cast<uint32_t *>(ctx->minmax_pred) + first * 2;
+        if (ctx->minmax_sig.size() <= (size_t)batch) ctx->minmax_sig.resize((size_t)batch + 1, 0);
+        const uint64_t sig = minmax_signature(L, (int)sizeof(T), REF);
+        predicted = ctx->minmax_sig[(size_t)batch] == sig;
+        ctx->minmax_sig[(size_t)batch] = sig;  // (this call leaves predictions for the next one, whichever way it runs)
+    } else {
+        L.prm.pred = nullptr;
+    }
     if (no_thr) {
         {
             vszip_probe_scope probe(ctx);
@@ -972,23 +1037,28 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
     } else {
         // hist, bucket and shist are contiguous: one memset
         VSZIP_HIP_CHECK(ctx, hipMemsetAsync(L.prm.hist, 0, (size_t)L.prm.nplanes * (kHistWords + kBucketWords + 256) * sizeof(uint32_t), ctx->stream));
-        const int single = wide && ctx->opt.minmax_single_read ? 1 : 0;  // opt-in: measured slower than the two sweeps on two of three contents
+        const int sampled = wide && ctx->opt.minmax_single_read ? 1 : 0;  // (development variant: the ranges from a row-sample pass, round 3)
+        const int single = sampled || predicted ? 1 : 0;
         const int grid = std::min(L.total_blocks, (REF ? 2 : 3) * 256), grid0 = std::min(L.total_blocks, 3 * 256);
-#ifdef VSZIP_DEV_VARIANTS  // the single-read path (hist_sample_kernel + MODE 1 sweep): measured slower, not in the default build
         if constexpr (wide != 0) {
             if (single) {
-                hipLaunchKernelGGL((hist_sample_kernel<T>), dim3(L.prm.nplanes * kSampleBlocks), dim3(kThreads), 0, ctx->stream, L.prm);
-                vszip_probe_scope probe(ctx);
-                hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 1>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
+#ifdef VSZIP_DEV_VARIANTS
+                if (sampled)
+                    hipLaunchKernelGGL((hist_sample_kernel<T>), dim3(L.prm.nplanes * kSampleBlocks), dim3(kThreads), 0, ctx->stream, L.prm);
+                else
+#endif
+                    // the predicted range starts -> bucket words 8 / 9 of every plane (where the sample pass leaves its own)
+                    VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(L.prm.bucket + 8, kBucketWords * sizeof(uint32_t), L.prm.pred, 2 * sizeof(uint32_t), 2 * sizeof(uint32_t), (size_t)L.prm.nplanes,
+                                                          hipMemcpyDeviceToDevice, ctx->stream));
+                {
+                    vszip_probe_scope probe(ctx);
+                    hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 1>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
+                }
+                // the two-level radix for the planes the single sweep flagged (the others' workgroups return at once)
+                hipLaunchKernelGGL((hist_sweep_kernel<T, false, 0>), dim3(std::min(grid0, 256)), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 1);
             }
         }
-        // the two-level radix: every plane (8-bit clips), or the planes the single sweep flagged (the others' workgroups return at once)
-        if (single) {
-            hipLaunchKernelGGL((hist_sweep_kernel<T, false, 0>), dim3(std::min(grid0, 256)), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 1);
-        } else
-#endif
-        {
-            (void)single;
+        if (!single) {
             (void)grid0;
             vszip_probe_scope probe(ctx);
             hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 0>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
@@ -1004,11 +1074,18 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr) {
 }
 
 template <typename T>
-int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr) {
-    return ref ? run_minmax_t<T, true>(ctx, L, no_thr) : run_minmax_t<T, false>(ctx, L, no_thr);
+int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr, int batch) {
+    return ref ? run_minmax_t<T, true>(ctx, L, no_thr, batch) : run_minmax_t<T, false>(ctx, L, no_thr, batch);
 }
 
 }  // namespace
+
+void vszip_planestats_release(vszip_ctx *ctx) {
+    if (ctx->minmax_pred) (void)hipFree(ctx->minmax_pred);
+    ctx->minmax_pred = nullptr;
+    ctx->minmax_pred_planes = 0;
+    ctx->minmax_sig.clear();
+}
 
 static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
                                double *result_dev) {
@@ -1041,7 +1118,7 @@ static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *pla
 }
 
 static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
-                              double *result_dev) {
+                              double *result_dev, int batch) {
     if (minthr < 0 || minthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: minthr should be a float between 0.0 and 1.0");
     if (maxthr < 0 || maxthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: maxthr should be a float between 0.0 and 1.0");
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
@@ -1055,10 +1132,10 @@ static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *plan
     L.prm.peak = (float)(L.prm.hist_size - 1);
     const bool no_thr = (maxthr == 0.0f) && (minthr == 0.0f);
     switch (dtype) {
-        case VSZIP_U8: rc = run_minmax<uint8_t>(ctx, L, ref, no_thr); break;
-        case VSZIP_U16: rc = run_minmax<uint16_t>(ctx, L, ref, no_thr); break;
-        case VSZIP_F16: rc = run_minmax<_Float16>(ctx, L, ref, no_thr); break;
-        case VSZIP_F32: rc = run_minmax<float>(ctx, L, ref, no_thr); break;
+        case VSZIP_U8: rc = run_minmax<uint8_t>(ctx, L, ref, no_thr, batch); break;
+        case VSZIP_U16: rc = run_minmax<uint16_t>(ctx, L, ref, no_thr, batch); break;
+        case VSZIP_F16: rc = run_minmax<_Float16>(ctx, L, ref, no_thr, batch); break;
+        case VSZIP_F32: rc = run_minmax<float>(ctx, L, ref, no_thr, batch); break;
         default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: not supported Int format.");
     }
     return rc;
@@ -1076,7 +1153,7 @@ static int plane_average_queue(vszip_ctx *ctx, int dtype, const vszip_plane *pla
 }
 static int plane_minmax_queue(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample, double *result_dev) {
     for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
-        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, result_dev + (size_t)o * 4);
+        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, result_dev + (size_t)o * 4, o / kMaxPlanesPS);
         if (rc != VSZIP_OK) return rc;
     }
     return VSZIP_OK;
