@@ -755,6 +755,13 @@ def planestats_leg(dev, timed, frames=64, only=None):
                                   "whole_call": {"note": "all kernels of the call + the scalars' way to the host + the one sync", "achieved": whole, "frac": whole / HBM_PEAK_GBS}},
                      "whole_call_frac": whole / HBM_PEAK_GBS,
                      "workload": f"{name}: {frames} x 3840x2160 YUV420P16 per call ({3 * frames} planes in launches of up to 192, one sync), HBM-resident; value includes the sync"}
+        if name == "plane_minmax_thr_4k":
+            # round 6: the timed calls are a clip's steady state - every call after the first sweeps its planes once over the ranges the previous call's answers
+            # predict; the same call with the prediction off (what a first call or a scene cut pays: the two sweeps) beside it
+            with dev.options(VSZIP_MINMAX_NO_PREDICT=1):
+                dt2, _, _, _ = timed.run(fn, 6, 1)
+            out[name]["two_sweeps_value"] = frames * 6 / dt2
+            out[name]["workload"] += "; steady state of a clip (ranges predicted from the previous call); two_sweeps_value: VSZIP_MINMAX_NO_PREDICT=1"
     return out
 
 
