@@ -11,7 +11,7 @@ from pathlib import Path
 d = Path(sys.argv[1])
 NOT_THE_LEG = ("placement_probe_kernel", "__amd_rocclr")
 TWO_STREAMS = {"eedi3": "the line kernel of the short planes runs beside the vertical-consistency chains (two streams): kernel time sums to more than the wall clock",
-               "ssimulacra2_4k": "two half-batches on two streams overlap: kernel time sums to more than the wall clock"}
+               "ssimulacra2_4k": "the small scales run on a second stream beside the large scales' maps kernels: kernel time sums to more than the wall clock"}
 print("| leg | basis | algorithmic bytes / call | calls | kernels counted | kernel us / call (profile) | frac from the profile | frac the leg reports | profile / leg | note |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for jf in sorted(d.glob("*.json")):
