@@ -226,6 +226,36 @@ def test_planestats_random(dev, oracle, seed):
         assert (mn[i], mx[i]) == (omn, omx), (seed, i, thr)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_minmax_prediction_random_sequences(dev, oracle, seed):
+    """Thresholded PlaneMinMax over a SEQUENCE of calls (round 6: a call of the previous call's shape reads its planes once over the ranges the previous
+    answers predict; a miss takes the two sweeps): the same frame again, a nearby frame, unrelated content, a change of thresholds or of the plane set -
+    whatever the prediction table holds (this test's own history and every earlier test's on the shared context), each result is the oracle's."""
+    rng = np.random.default_rng(SEED_BASE + 5500 + seed)
+    dtype = [np.uint16, np.float32, np.float16, np.uint16][seed % 4]
+    kind = np.dtype(dtype).kind
+    nplanes = int(rng.integers(1, 6))
+    shapes = [(int(rng.integers(2, 220)), int(rng.integers(8, 520))) for _ in range(nplanes)]
+    thr = (float(rng.choice([0.01, 0.1, 0.25])), float(rng.choice([0.02, 0.1, 0.4])))
+    frame = [_plane(rng, s, dtype) for s in shapes]
+    for step in range(7):
+        what = int(rng.integers(0, 5))
+        if what == 1:  # the next frame: a small drift
+            frame = [np.clip(p.astype(np.float64) + (rng.integers(-150, 151) if kind == "u" else rng.uniform(-0.002, 0.002)), 0, 65535 if kind == "u" else 1).astype(dtype) for p in frame]
+        elif what == 2:  # a cut
+            frame = [_plane(rng, s, dtype) for s in shapes]
+        elif what == 3:
+            thr = (float(rng.choice([0.0, 0.01, 0.1, 0.25, 1.0])), float(rng.choice([0.02, 0.1, 0.4])))
+        elif what == 4 and nplanes > 1:  # another plane set (another shape: no prediction)
+            shapes = shapes[::-1]
+            frame = [_plane(rng, s, dtype) for s in shapes]
+        srcs = [dev.upload(p, int(rng.choice([1, 8, 32]))) for p in frame]
+        mn, mx, _ = dev.plane_minmax(srcs, thr[0], thr[1])
+        for i, p in enumerate(frame):
+            omn, omx = oracle.plane_minmax(p, thr[0], thr[1])[:2]
+            assert (mn[i], mx[i]) == (omn, omx), (seed, step, what, i, thr, p.shape)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_ssimulacra2_random_sizes(dev, oracle, seed):
     """Odd and tiny frames (down to one 8x8 tile at scale 0; five halvings) and a batch of pairs."""
