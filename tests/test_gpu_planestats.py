@@ -188,6 +188,21 @@ def test_minmax_temporal_prediction_hits_and_misses(dev, oracle, dtype):
         d.close()
 
 
+def test_minmax_temporal_prediction_on_10_bit_clips(dev, oracle):
+    """10-bit samples in 16-bit words: the histogram is 1 024 values long, a predicted range of 512 covers half of it and may reach past its end"""
+    shapes = [(203, 331), (120, 200), (77, 96)]
+    f0 = [(fx.tiled_natural(s, np.uint16, i) >> 6).astype(np.uint16) for i, s in enumerate(shapes)]
+    f1 = [np.clip(p.astype(np.int32) + 3, 0, 1023).astype(np.uint16) for p in f0]
+    f2 = [(1023 - p).astype(np.uint16) for p in f0]
+    for thr in ((0.1, 0.1), (0.0, 0.6), (0.9, 0.02)):
+        for frame in (f0, f0, f1, f2, f2, f0):
+            ds = [dev.upload(p) for p in frame]
+            mn, mx, _ = dev.plane_minmax(ds, thr[0], thr[1], bits=10)
+            for i, p in enumerate(frame):
+                omn, omx, _ = oracle.plane_minmax(p, thr[0], thr[1], bits=10)
+                assert (mn[i], mx[i]) == (omn, omx), (thr, i)
+
+
 def test_minmax_temporal_prediction_across_batches(dev, oracle):
     """more than 192 planes a call: every batch of the queue keeps its own predictions (400 planes = 192 + 192 + 16), two rounds of two frames"""
     shapes = [(96, 160), (48, 80), (37, 53)]

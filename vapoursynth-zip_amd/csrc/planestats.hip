@@ -982,7 +982,7 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
 // Thresholded calls on 16-bit / float planes, round 6: TEMPORAL prediction. The two-level radix reads every plane twice because the buckets the
 // thresholds fall into are known only after a full sweep; round 3's single-read sweep (MODE 1: exact histograms of two candidate ranges of
 // 5 x 256 values + the counts below them, flagged planes fall back to the two sweeps) needed a row-sample pass to predict the ranges and lost
-// on pictures. A clip's next frame is the better predictor: every result leaves "its answer, two 8-bit levels either side" in a per-context
+// on pictures. A clip's next frame is the better predictor: every result leaves "a range of kRange = 512 values centred on its answer" in a per-context
 // table (PSParams::pred), and a call of the same shape as the previous one (plane count and sizes, sample type, thresholds) sweeps ONCE over
 // those ranges. A scene cut, another clip or a first call cost what they always did — the flagged planes' two sweeps — and the results are the
 // reference's either way (tests/test_gpu_planestats.py::test_minmax_temporal_prediction*). VSZIP_MINMAX_NO_PREDICT=1: always two sweeps.
