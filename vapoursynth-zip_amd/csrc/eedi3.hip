@@ -50,6 +50,7 @@ struct EParams {
     int mdis, nrad;
     float alpha, beta, gamma, one_minus_ab;
     int line_base;  // first global line id of this launch (a call may launch its tall and its short planes separately)
+    int copy_kept;  // the tuned line kernel also writes the KEPT field line beside its interpolated one (round 6: no copy kernel in front of it)
 };
 
 __device__ __forceinline__ int reflect_row(int y, int h) {  // eedi3.zig:88-96
@@ -226,6 +227,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
         }
         wave_fence();
         const int lx = lane + reach;  // rows[] index of column x
+        // The kept field line next to this one (processPlane copies them first, eedi3.zig(vs):41-56): destination line - 1 (field 1) / + 1 (field 0) is the staged
+        // row r1p / r1n as it is - one LDS read and one 256-byte store a block instead of a 400 MB copy kernel in front of every call (round 6).
+        if (prm.copy_kept && x < w) (prm.field ? out - pl.dstride : out + pl.dstride)[x] = rows[prm.field ? 1 : 2][lx];
         // ---- cost phase, lanes = x; kU directions per pass -------------------------------
         // The three steps of a direction (t_base -> window sums -> cost) are a chain of LDS
         // round trips; one direction at a time leaves the wave waiting on LDS latency most of
@@ -1966,7 +1970,8 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     }
     ep.line_base = 0;
     vp.plane_base = 0;
-    hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw / 4 + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);  // (grid-stride rows: any x grid serves)
+    ep.copy_kept = general ? 0 : 1;  // (the tuned line kernel writes the kept lines itself)
+    if (general) hipLaunchKernelGGL(eedi3_copy_kernel, dim3((maxw / 4 + 255) / 256, maxsrc, nplanes), dim3(256), 0, ctx->stream, ep);  // (grid-stride rows: any x grid serves)
     if (general) {
         switch (up->nrad) {
             case 0: launch_general<0>(ctx, hp, (unsigned)lines, ep, gx); break;
