@@ -739,9 +739,10 @@ def planestats_leg(dev, timed, frames=64, only=None):
         planes += [dev.upload(np.roll(p, f * 3, axis=1)) for p in base]
     fb = sum(2 * s[0] * s[1] for s in yuv420_shapes(W4K, H4K)) * frames
     out = {}
-    for name, fn in (("plane_average_4k", lambda: dev.plane_average(planes, exclude=[-1])),
-                     ("plane_minmax_4k", lambda: dev.plane_minmax(planes)),
-                     ("plane_minmax_thr_4k", lambda: dev.plane_minmax(planes, 0.1, 0.1))):
+    # (argument blocks built once, as a per-frame caller in C holds them: building a 192-entry ctypes table per call cost the legs 30-40 us of Python)
+    for name, fn in (("plane_average_4k", dev.prepared_plane_average(planes, exclude=[-1])),
+                     ("plane_minmax_4k", dev.prepared_plane_minmax(planes)),
+                     ("plane_minmax_thr_4k", dev.prepared_plane_minmax(planes, 0.1, 0.1))):
         if only and name != only:
             continue
         dt, region_ms, dom_ms, launches = timed.run(fn, 10, 2)

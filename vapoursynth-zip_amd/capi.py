@@ -443,6 +443,34 @@ class Device:
         """dsts[i] = 255 where clips2[i] - clips[i] >= c else 0 (u8 planes)."""
         self.check(self.lib.vszip_adaptive_binarize(self.ctx, self.plane_table(clips, dsts, clips2), len(clips), int(c)))
 
+    def prepared_plane_average(self, srcs, exclude=(), refs=None, bits=None):
+        """-> a callable running vszip_plane_average on argument blocks built once (a per-frame caller in C pays no Python marshalling either);
+        it returns the ctypes result arrays (avg, diff)."""
+        n = len(srcs)
+        table = self.plane_table(srcs, None, refs)
+        ex = (C.c_int32 * max(1, len(exclude)))(*exclude)
+        avg, diff = (C.c_double * n)(), (C.c_double * n)()
+        b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
+        dt, nex, fn, ctx, check = _NP2DT[srcs[0].dtype], len(exclude), self.lib.vszip_plane_average, self.ctx, self.check
+
+        def run():
+            check(fn(ctx, dt, table, n, ex, nex, b, avg, diff))
+            return avg, diff
+        return run
+
+    def prepared_plane_minmax(self, srcs, minthr=0.0, maxthr=0.0, refs=None, bits=None):
+        """-> a callable running vszip_plane_minmax on argument blocks built once; it returns the ctypes result arrays (min, max, diff)."""
+        n = len(srcs)
+        table = self.plane_table(srcs, None, refs)
+        mn, mx, df = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        b = bits if bits is not None else 8 * srcs[0].dtype.itemsize
+        dt, fn, ctx, check = _NP2DT[srcs[0].dtype], self.lib.vszip_plane_minmax, self.ctx, self.check
+
+        def run():
+            check(fn(ctx, dt, table, n, minthr, maxthr, b, mn, mx, df))
+            return mn, mx, df
+        return run
+
     def plane_minmax(self, srcs, minthr=0.0, maxthr=0.0, refs=None, bits=None):
         n = len(srcs)
         table = self.plane_table(srcs, None, refs)

@@ -14,6 +14,8 @@
 // are exact; float sums differ from the reference's sequential f64 order by rounding only.
 #include "common.hpp"
 #include <cstring>
+#include <functional>
+#include <type_traits>
 
 namespace {
 
@@ -671,6 +673,47 @@ __device__ __forceinline__ uint32_t range_scan(const uint32_t *tab, bool from_to
     return ans;
 }
 
+// Round 6, the packed form of the single-read sweep for 16-bit integer planes (VSZIP_MM_NO_PACKED restores the per-sample form for sweeps).
+// The per-sample form spends ~10 VALU instructions a sample (two differences, two range tests, two sign bits, their sums) and its time does not
+// depend on the content: it is issue bound. Here a DWORD (two samples) goes through
+//   t = v_pk_sub_u16(p, start x 0x10001)          the samples' distances from a range's start, modulo 2^16: in the range <=> t < kRange
+//   sum_t = v_sad_u16(t, 0, sum_t), sum_p likewise  |t - 0| + |t' - 0| + sum: one instruction adds two 16-bit halves to a 32-bit sum
+// and "samples below the start" is not counted at all: the sum of t over n samples is sum(p) - n start + 65536 x (samples below the start), exactly.
+// The test reads a half in place (v_cmp_gt_u16 with an SDWA half select) and the rare add computes its address with one v_mad_u16 (half select through
+// op_sel): 4.5 instructions a sample in front of the adds.
+typedef unsigned short mm_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mm_pk_sub_u16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(mm_us2, a) - __builtin_bit_cast(mm_us2, b)); }
+// one half of t against the range, and the add where it lies inside. `addr` is a register whose upper half stays zero (v_mad_u16 writes the lower).
+template <int HALF, int OFF>
+__device__ __forceinline__ void mm_range_add(uint32_t t, uint32_t range, uint32_t copy4, uint32_t &addr, uint32_t one) {
+    static_assert(kRange * kRangeCopies * 4 <= 65536, "v_mad_u16 computes the byte offset inside a range's table");
+    uint64_t m, sv;
+    if constexpr (HALF == 0)
+        asm volatile(
+            "v_cmp_gt_u16_sdwa %[m], %[rng], %[t] src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "s_and_saveexec_b64 %[sv], %[m]\n\t"
+            "s_cbranch_execz .Lmm_skip_%=\n\t"
+            "v_mad_u16 %[a], %[t], %[mul], %[c4] op_sel:[0,0,0,0]\n\t"
+            "ds_add_u32 %[a], %[one] offset:%[off]\n"
+            ".Lmm_skip_%=:\n\t"
+            "s_or_b64 exec, exec, %[sv]"
+            : [m] "=&s"(m), [sv] "=&s"(sv), [a] "+v"(addr)
+            : [rng] "s"(range), [t] "v"(t), [c4] "v"(copy4), [one] "v"(one), [mul] "i"(kRangeCopies * 4), [off] "i"(OFF)
+            : "memory");
+    else
+        asm volatile(
+            "v_cmp_gt_u16_sdwa %[m], %[rng], %[t] src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "s_and_saveexec_b64 %[sv], %[m]\n\t"
+            "s_cbranch_execz .Lmm_skip_%=\n\t"
+            "v_mad_u16 %[a], %[t], %[mul], %[c4] op_sel:[1,0,0,0]\n\t"
+            "ds_add_u32 %[a], %[one] offset:%[off]\n"
+            ".Lmm_skip_%=:\n\t"
+            "s_or_b64 exec, exec, %[sv]"
+            : [m] "=&s"(m), [sv] "=&s"(sv), [a] "+v"(addr)
+            : [rng] "s"(range), [t] "v"(t), [c4] "v"(copy4), [one] "v"(one), [mul] "i"(kRangeCopies * 4), [off] "i"(OFF)
+            : "memory");
+}
+
 // The sweeps. MODE 0: histogram of idx >> 8 (u8: idx itself — one level is all it needs) for the two-level radix; with `flagged` only
 // the planes the single-read path could not answer. MODE 1: the single-read path's counts and range histograms. Both: the abs-diff sum.
 // Persistent workgroups of 512 threads, each over a contiguous range of the call's 8-row units (flushing its tables where the range
@@ -683,6 +726,11 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
     constexpr int V = 16 / (int)sizeof(T);
     constexpr bool wide = sizeof(T) > 1;
     constexpr int kTab = MODE == 0 ? 256 * kCopies : 2 * kRange * kRangeCopies;
+#ifdef VSZIP_MM_NO_PACKED
+    constexpr bool kPacked = false;
+#else
+    constexpr bool kPacked = MODE == 1 && !REF && std::is_same<T, uint16_t>::value;  // see mm_range_add
+#endif
     __shared__ uint32_t tab[kTab];  // MODE 0: the histogram's copies; MODE 1: the low range's bins, then the high range's (kRangeCopies interleaved copies each)
     __shared__ double shd[kSweepThreads / 64];
     __shared__ uint32_t shc[2][kSweepThreads / 64];
@@ -702,7 +750,9 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
         }
         for (int i = tid; i < kTab; i += kSweepThreads) tab[i] = 0;
         __syncthreads();
-        const uint32_t lo_start = MODE == 1 ? bk[8] : 0u, hi_start = MODE == 1 ? bk[9] : 0u;
+        // MODE 1: where the two ranges start - the previous call's answers (PSParams::pred; the plane's last workgroup replaces them only after every
+        // workgroup of the plane has handed in its ticket, i.e. has read them) or, in the dev build's sampled variant, what the sample pass left in the bucket
+        const uint32_t lo_start = MODE == 1 ? (prm.pred ? prm.pred[pi * 2] : bk[8]) : 0u, hi_start = MODE == 1 ? (prm.pred ? prm.pred[pi * 2 + 1] : bk[9]) : 0u;
         const int y0 = (u - pl.block0) * prm.rows_per_block;
         const int nrows = min((ue - pl.block0) * prm.rows_per_block, pl.h) - y0;
         const T *src = static_cast<const T *>(pl.src) + (size_t)y0 * pl.sstride;
@@ -711,7 +761,8 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
                          (!REF || ((reinterpret_cast<uintptr_t>(ref) & 15) == 0 && ((size_t)pl.rstride * sizeof(T)) % 16 == 0));
         const int nv = vec ? pl.w / V : 0;
         double dacc = 0;
-        uint32_t below_lo = 0, below_hi_end = 0;  // MODE 1: samples below the low range / below the END of the high range
+        // MODE 1: samples below the low range / below the END of the high range (kPacked: below its START - the flush adds the samples inside)
+        uint32_t below_lo = 0, below_hi_end = 0;
         auto one = [&](T sv, T rv) {
             const uint32_t idx = S::idx(sv);
             if constexpr (MODE == 0) {
@@ -720,7 +771,7 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
                 // idx and the range starts are below 2^17: the sign bit of the difference is the borrow
                 const uint32_t dl = idx - lo_start, eh = idx - hi_start - (uint32_t)kRange;
                 below_lo += dl >> 31;
-                below_hi_end += eh >> 31;
+                below_hi_end += (kPacked ? idx - hi_start : eh) >> 31;
                 // (round 6, measured and not kept: ONE unconditional add a sample, out-of-range samples into a word of the thread's own - 80 k frames/s
                 // against 92-134 k: the add itself is what costs, and the branches skip it for most samples)
                 if (dl < (uint32_t)kRange) atomicAdd(&tab[dl * kRangeCopies + rcopy], 1u);
@@ -758,18 +809,123 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
 #pragma unroll
                 for (int k = 0; k < V; ++k) one(a.e[k], REF ? b.e[k] : a.e[k]);
             };
-            while (ry < nrows) {  // (not workgroup-uniform: no barriers inside)
-                Vec a0, b0, a1, b1;
-                fetch(a0, b0);
-                advance();
-                const bool two = ry < nrows;
-                if (two) {
-                    fetch(a1, b1);
+            // The loop over a lane's vectors (not workgroup-uniform: no barriers inside): a pair is tallied while the NEXT pair's loads are in flight - four
+            // 16-byte loads a lane instead of two (24 waves a CU x 64 lanes x 32 bytes in flight were fewer than the memory system's latency x rate).
+            auto pipelined = [&](auto &&tl, auto &&after) {
+#ifdef VSZIP_MM_NO_PIPE  // (sweeps: load a pair, tally it)
+                constexpr bool kPipe = false;
+#else
+                constexpr bool kPipe = !REF;  // (with a reference clip twice the registers: one workgroup a CU less)
+#endif
+                if constexpr (!kPipe) {
+                while (ry < nrows) {
+                    Vec a0, b0, a1, b1;
+                    fetch(a0, b0);
                     advance();
+                    const bool two = ry < nrows;
+                    if (two) {
+                        fetch(a1, b1);
+                        advance();
+                    }
+                    tl(a0, b0);
+                    if (two) tl(a1, b1);
+                    after();
                 }
-                tally(a0, b0);
-                if (two) tally(a1, b1);
-            }
+                } else {
+                // Every load is issued whether or not its vector exists (past the end it re-reads the range's last row): conditional loads have no static
+                // count, and the compiler then waits for ALL of them (vmcnt(0)) in front of the tally.
+                Vec a0, b0, a1, b1, n0, m0, n1, m1;
+                auto fetch_any = [&](Vec &a, Vec &b) {
+                    const int r = min(ry, nrows - 1);
+                    a.q = reinterpret_cast<const uint4 *>(src + (size_t)r * pl.sstride)[vx];
+                    if constexpr (REF) b.q = reinterpret_cast<const uint4 *>(ref + (size_t)r * pl.rstride)[vx];
+                };
+#ifdef VSZIP_MM_FETCH4  // (sweeps: four loads, then their tallies)
+                while (ry < nrows) {
+                    const bool h0 = true;
+                    fetch_any(a0, b0);
+                    advance();
+                    const bool h1 = ry < nrows;
+                    fetch_any(a1, b1);
+                    advance();
+                    const bool g0 = ry < nrows;
+                    fetch_any(n0, m0);
+                    advance();
+                    const bool g1 = ry < nrows;
+                    fetch_any(n1, m1);
+                    advance();
+                    if (h0) tl(a0, b0);
+                    if (h1) tl(a1, b1);
+                    if (g0) tl(n0, m0);
+                    if (g1) tl(n1, m1);
+                    after();
+                }
+#else
+                bool h0 = ry < nrows;
+                fetch_any(a0, b0);
+                advance();
+                bool h1 = ry < nrows;
+                fetch_any(a1, b1);
+                advance();
+                while (h0) {  // (two turns a trip, the register sets changing roles: a copy at the end of a turn would wait for the loads it copies)
+                    const bool g0 = ry < nrows;
+                    fetch_any(n0, m0);
+                    advance();
+                    const bool g1 = ry < nrows;
+                    fetch_any(n1, m1);
+                    advance();
+                    tl(a0, b0);
+                    if (h1) tl(a1, b1);
+                    after();
+                    if (!g0) break;
+                    h0 = ry < nrows;
+                    fetch_any(a0, b0);
+                    advance();
+                    h1 = ry < nrows;
+                    fetch_any(a1, b1);
+                    advance();
+                    tl(n0, m0);
+                    if (g1) tl(n1, m1);
+                    after();
+                }
+#endif
+                }
+            };
+            // start values from the dev build's row sample can lie past 16 bits (its "nothing qualifies" markers): those planes take the per-sample form
+            const bool packed = kPacked && (lo_start | hi_start) < 0x10000u;
+            if (packed) {
+                const uint32_t lo2 = lo_start * 0x10001u, hi2 = hi_start * 0x10001u, copy4 = (uint32_t)rcopy * 4u, one1 = 1u;
+                uint32_t sum_p = 0, sum_l = 0, sum_h = 0, nvec = 0, addr = 0;
+                auto fold = [&]() {  // 32-bit sums hold 65 536 samples of 16 bits
+                    const uint64_t n = (uint64_t)nvec * V;
+                    below_lo += (uint32_t)(((uint64_t)sum_l + n * lo_start - sum_p) >> 16);
+                    below_hi_end += (uint32_t)(((uint64_t)sum_h + n * hi_start - sum_p) >> 16);
+                    sum_p = sum_l = sum_h = nvec = 0;
+                };
+                auto tally2 = [&](uint32_t pd) {
+                    const uint32_t tl = mm_pk_sub_u16(pd, lo2), th = mm_pk_sub_u16(pd, hi2);
+                    sum_p = __builtin_amdgcn_sad_u16(pd, 0u, sum_p);
+                    sum_l = __builtin_amdgcn_sad_u16(tl, 0u, sum_l);
+                    sum_h = __builtin_amdgcn_sad_u16(th, 0u, sum_h);
+                    mm_range_add<0, 0>(tl, (uint32_t)kRange, copy4, addr, one1);
+                    mm_range_add<0, kRange * kRangeCopies * 4>(th, (uint32_t)kRange, copy4, addr, one1);
+                    mm_range_add<1, 0>(tl, (uint32_t)kRange, copy4, addr, one1);
+                    mm_range_add<1, kRange * kRangeCopies * 4>(th, (uint32_t)kRange, copy4, addr, one1);
+                };
+                auto tally4 = [&](const uint4 &q) {
+                    tally2(q.x);
+                    tally2(q.y);
+                    tally2(q.z);
+                    tally2(q.w);
+                    ++nvec;
+                };
+                pipelined([&](const Vec &a, const Vec &) { tally4(a.q); }, [&]() {
+                    if (nvec >= 8000u) fold();
+                });
+                fold();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the adds above are invisible to the compiler's counters
+            } else
+                pipelined(tally, []() {});
         }
         const int x0 = nv * V, tw = pl.w - x0;  // the columns past the last whole vector (all of them on unaligned planes)
         if (tw > 0) {
@@ -794,6 +950,7 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
 #pragma unroll
                 for (int k = 0; k < kRangeCopies; ++k) c += tab[i * kRangeCopies + k];
                 if (c) atomicAdd(&g[512 + i], c);
+                if (kPacked && i >= kRange) below_hi_end += c;  // below the high range's start + inside it = below its end
             }
             const uint32_t wl = wave_reduce_sum(below_lo), wh = wave_reduce_sum(below_hi_end);
             if ((tid & 63) == 0) {
@@ -849,8 +1006,10 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
                 if (totalmax < total) retmax = hi_start + range_scan(g + 512 + kRange, true, nhi, totalmax, fine, &okh);
                 if (okl && okh)
                     write_result(prm, pi, S::is_int ? 1 : 0, retmin, retmax);
-                else if (tid == 0)
+                else if (tid == 0) {
                     bk[4] = 1u;  // the two histogram sweeps answer this plane
+                    prm.result[(size_t)pi * 4 + 3] = 1.0;  // (the result's spare word: a caller that defers those sweeps looks here after its synchronise)
+                }
             }
         }
         __syncthreads();
@@ -1002,7 +1161,7 @@ static uint64_t minmax_signature(const Launch &L, int dtype_size, bool ref) {
 }
 
 template <typename T, bool REF>
-int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch) {
+int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch, std::function<int()> *deferred) {
     constexpr int is_int = Smp<T>::is_int ? 1 : 0;
     constexpr int wide = sizeof(T) > 1 ? 1 : 0;
     bool predicted = false;
@@ -1042,24 +1201,39 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch) {
         const int grid = std::min(L.total_blocks, (REF ? 2 : 3) * 256), grid0 = std::min(L.total_blocks, 3 * 256);
         if constexpr (wide != 0) {
             if (single) {
+                Launch S = L;  // (the sampled variant's sweep reads its range starts from the bucket, the predicted one from PSParams::pred)
 #ifdef VSZIP_DEV_VARIANTS
-                if (sampled)
+                if (sampled) {
+                    S.prm.pred = nullptr;
                     hipLaunchKernelGGL((hist_sample_kernel<T>), dim3(L.prm.nplanes * kSampleBlocks), dim3(kThreads), 0, ctx->stream, L.prm);
-                else
+                }
 #endif
-                    // the predicted range starts -> bucket words 8 / 9 of every plane (where the sample pass leaves its own)
-                    VSZIP_HIP_CHECK(ctx, hipMemcpy2DAsync(L.prm.bucket + 8, kBucketWords * sizeof(uint32_t), L.prm.pred, 2 * sizeof(uint32_t), 2 * sizeof(uint32_t), (size_t)L.prm.nplanes,
-                                                          hipMemcpyDeviceToDevice, ctx->stream));
                 {
                     vszip_probe_scope probe(ctx);
-                    hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 1>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
+                    hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 1>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, S.prm, L.total_blocks, 0);
                 }
-                // the two-level radix for the planes the single sweep flagged (the others' workgroups return at once)
-                hipLaunchKernelGGL((hist_sweep_kernel<T, false, 0>), dim3(std::min(grid0, 256)), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 1);
+                // The planes the single sweep flagged (an answer outside its range) go through the two-level radix; every other plane's workgroups return at
+                // once - three launches that do nothing in a clip's steady state. A caller that synchronises anyway (vszip_plane_minmax, one group of planes)
+                // takes them as a closure instead and runs it only if the flags in the results' spare words say so.
+                auto fallback = [ctx, L, grid0]() -> int {
+                    hipLaunchKernelGGL((hist_sweep_kernel<T, false, 0>), dim3(std::min(grid0, 256)), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 1);
+                    const int kb = std::min(128, std::max(8, 4096 / L.prm.nplanes));
+                    hipLaunchKernelGGL((hist_refine_kernel<T>), dim3(L.prm.nplanes * kb), dim3(kThreads), 0, ctx->stream, L.prm, kb);
+                    hipLaunchKernelGGL(thr_final_kernel, dim3(L.prm.nplanes), dim3(64), 0, ctx->stream, L.prm, wide, is_int);
+                    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+                    return VSZIP_OK;
+                };
+                if (deferred && !sampled) {
+                    *deferred = fallback;
+                    VSZIP_HIP_CHECK(ctx, hipGetLastError());
+                    return VSZIP_OK;
+                }
+                return fallback();
             }
         }
-        if (!single) {
+        {
             (void)grid0;
+            (void)single;
             vszip_probe_scope probe(ctx);
             hipLaunchKernelGGL((hist_sweep_kernel<T, REF, 0>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, L.prm, L.total_blocks, 0);
         }
@@ -1074,8 +1248,8 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch) {
 }
 
 template <typename T>
-int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr, int batch) {
-    return ref ? run_minmax_t<T, true>(ctx, L, no_thr, batch) : run_minmax_t<T, false>(ctx, L, no_thr, batch);
+int run_minmax(vszip_ctx *ctx, Launch &L, bool ref, bool no_thr, int batch, std::function<int()> *deferred) {
+    return ref ? run_minmax_t<T, true>(ctx, L, no_thr, batch, deferred) : run_minmax_t<T, false>(ctx, L, no_thr, batch, deferred);
 }
 
 }  // namespace
@@ -1118,7 +1292,7 @@ static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *pla
 }
 
 static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample,
-                              double *result_dev, int batch) {
+                              double *result_dev, int batch, std::function<int()> *deferred = nullptr) {
     if (minthr < 0 || minthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: minthr should be a float between 0.0 and 1.0");
     if (maxthr < 0 || maxthr > 1) return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: maxthr should be a float between 0.0 and 1.0");
     const bool ref = planes && nplanes > 0 && planes[0].ref != nullptr;
@@ -1132,10 +1306,10 @@ static int plane_minmax_batch(vszip_ctx *ctx, int dtype, const vszip_plane *plan
     L.prm.peak = (float)(L.prm.hist_size - 1);
     const bool no_thr = (maxthr == 0.0f) && (minthr == 0.0f);
     switch (dtype) {
-        case VSZIP_U8: rc = run_minmax<uint8_t>(ctx, L, ref, no_thr, batch); break;
-        case VSZIP_U16: rc = run_minmax<uint16_t>(ctx, L, ref, no_thr, batch); break;
-        case VSZIP_F16: rc = run_minmax<_Float16>(ctx, L, ref, no_thr, batch); break;
-        case VSZIP_F32: rc = run_minmax<float>(ctx, L, ref, no_thr, batch); break;
+        case VSZIP_U8: rc = run_minmax<uint8_t>(ctx, L, ref, no_thr, batch, deferred); break;
+        case VSZIP_U16: rc = run_minmax<uint16_t>(ctx, L, ref, no_thr, batch, deferred); break;
+        case VSZIP_F16: rc = run_minmax<_Float16>(ctx, L, ref, no_thr, batch, deferred); break;
+        case VSZIP_F32: rc = run_minmax<float>(ctx, L, ref, no_thr, batch, deferred); break;
         default: return vszip_set_error(ctx, VSZIP_ERR_ARG, "PlaneMinMax: not supported Int format.");
     }
     return rc;
@@ -1151,9 +1325,11 @@ static int plane_average_queue(vszip_ctx *ctx, int dtype, const vszip_plane *pla
     }
     return VSZIP_OK;
 }
-static int plane_minmax_queue(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample, double *result_dev) {
+static int plane_minmax_queue(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, float minthr, float maxthr, int bits_per_sample, double *result_dev,
+                              std::function<int()> *deferred = nullptr) {
+    if (nplanes > kMaxPlanesPS) deferred = nullptr;  // (the groups share the scratch tables in stream order: a later group's sweep wipes what a deferred fallback needs)
     for (int o = 0; o < nplanes; o += kMaxPlanesPS) {
-        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, result_dev + (size_t)o * 4, o / kMaxPlanesPS);
+        const int rc = plane_minmax_batch(ctx, dtype, planes + o, std::min(kMaxPlanesPS, nplanes - o), minthr, maxthr, bits_per_sample, result_dev + (size_t)o * 4, o / kMaxPlanesPS, deferred);
         if (rc != VSZIP_OK) return rc;
     }
     return VSZIP_OK;
@@ -1186,9 +1362,20 @@ VSZIP_EXPORT int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane
     double *host = nullptr, *dev = nullptr;
     int rc = result_buffer(ctx, nplanes, &host, &dev);
     if (rc != VSZIP_OK) return rc;
-    rc = plane_minmax_queue(ctx, dtype, planes, nplanes, minthr, maxthr, bits_per_sample, dev);
+    for (int i = 0; i < nplanes; ++i) host[(size_t)i * 4 + 3] = 0.0;  // (a sweep that cannot answer a plane sets this word)
+    std::function<int()> fallback;
+    rc = plane_minmax_queue(ctx, dtype, planes, nplanes, minthr, maxthr, bits_per_sample, dev, &fallback);
     if (rc != VSZIP_OK) return rc;
     VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (fallback) {
+        bool flagged = false;
+        for (int i = 0; i < nplanes; ++i) flagged = flagged || host[(size_t)i * 4 + 3] != 0.0;
+        if (flagged) {
+            rc = fallback();
+            if (rc != VSZIP_OK) return rc;
+            VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     return fetch(ctx, nplanes, host, vmin, vmax, planes[0].ref ? diff : nullptr);
 }
 
