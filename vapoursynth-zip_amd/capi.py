@@ -430,6 +430,23 @@ class Device:
         table = self.plane_table(srcs, dsts)
         self.check(self.lib.vszip_limiter(self.ctx, _NP2DT[srcs[0].dtype], table, n, (C.c_double * n)(*[float(v) for v in lo]), (C.c_double * n)(*[float(v) for v in hi])))
 
+    def prepared_limiter(self, srcs, dsts, lo, hi):
+        """-> a callable queueing vszip_limiter on argument blocks built once."""
+        n = len(srcs)
+        table = self.plane_table(srcs, dsts)
+        los, his = (C.c_double * n)(*[float(v) for v in lo]), (C.c_double * n)(*[float(v) for v in hi])
+        dt, fn, ctx, check = _NP2DT[srcs[0].dtype], self.lib.vszip_limiter, self.ctx, self.check
+        return lambda: check(fn(ctx, dt, table, n, los, his))
+
+    def prepared_limit_filter(self, flts, srcs, dsts, dark_thr, bright_thr, elast):
+        """-> a callable queueing vszip_limit_filter (no third clip) on argument blocks built once."""
+        n = len(flts)
+        table = self.plane_table(flts, dsts, srcs)
+        fa = lambda v: (C.c_float * n)(*[float(x) for x in v])
+        d, b, e = fa(dark_thr), fa(bright_thr), fa(elast)
+        dt, fn, ctx, check = _NP2DT[flts[0].dtype], self.lib.vszip_limit_filter, self.ctx, self.check
+        return lambda: check(fn(ctx, dt, table, None, None, n, d, b, e))
+
     def limit_filter(self, flts, srcs, dsts, dark_thr, bright_thr, elast, refs=None):
         """vszip.LimitFilter per plane; thresholds already on the clip's scale. refs: optional third clip's planes."""
         n = len(flts)
