@@ -198,7 +198,8 @@ int vszip_adaptive_binarize(vszip_ctx *ctx, const vszip_plane *planes, int nplan
 int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
                        float minthr, float maxthr, int bits_per_sample,
                        double *vmin, double *vmax, double *diff);
-/* ... and without the synchronise: pinned_results[i][0] = min, [i][1] = max, [i][2] = diff (see vszip_plane_average_async) */
+/* ... and without the synchronise: pinned_results[i][0] = min, [i][1] = max, [i][2] = diff (see vszip_plane_average_async); [i][3] is scratch
+ * (a thresholded sweep may leave a marker there) */
 int vszip_plane_minmax_async(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes,
                              float minthr, float maxthr, int bits_per_sample, double *pinned_results);
 
