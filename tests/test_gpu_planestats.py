@@ -188,6 +188,42 @@ def test_minmax_temporal_prediction_hits_and_misses(dev, oracle, dtype):
         d.close()
 
 
+def test_minmax_temporal_prediction_ranges_at_the_top_of_16_bits(dev, oracle):
+    """A predicted range that would reach past 65 535: the packed sweep measures a sample's distance from the range's start modulo 2^16, so the DARK samples of a
+    plane that also holds values next to 65 535 would wrap into such a range - the starts are kept at or below 65 536 - 512. Planes that are half 0 ... 300 and
+    half 65 535 - (0 ... 300), thresholds that put the maximum (and, inverted, the minimum) into the top levels."""
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    try:
+        rng = np.random.default_rng(77)
+        shapes = [(120, 256), (96, 200), (64, 96)]
+
+        def frame(k):
+            out = []
+            for i, (h, w) in enumerate(shapes):
+                dark = rng.integers(0, 300, (h, w), dtype=np.int64)
+                p = np.where(((np.arange(w)[None, :] + i + k) // 8) % 2 == 0, dark, 65535 - dark)
+                out.append(p.astype(np.uint16))
+            return out
+
+        for invert in (False, True):
+            for thr in ((0.1, 0.1), (0.3, 0.01), (0.45, 0.45), (0.0, 0.2)):
+                for k in range(4):  # the first call of a shape runs the two sweeps, the others are predicted
+                    f = [(65535 - p).astype(np.uint16) for p in frame(k)] if invert else frame(k)
+                    before = d.get_option("VSZIP_STAT_MINMAX_FALLBACKS")
+                    mn, mx, _ = d.plane_minmax([d.upload(p) for p in f], thr[0], thr[1])
+                    for i, p in enumerate(f):
+                        omn, omx, _ = oracle.plane_minmax(p, thr[0], thr[1], None)
+                        assert (mn[i], mx[i]) == (omn, omx), (invert, thr, k, i, mn[i], omn, mx[i], omx)
+                    # the frames of one sequence are draws from one distribution: their answers lie a few values apart, and a predicted call whose
+                    # ranges hold them needs no second look
+                    if k >= 1:
+                        assert d.get_option("VSZIP_STAT_MINMAX_FALLBACKS") == before, (invert, thr, k)
+    finally:
+        d.close()
+
+
 def test_minmax_temporal_prediction_on_10_bit_clips(dev, oracle):
     """10-bit samples in 16-bit words: the histogram is 1 024 values long, a predicted range of 512 covers half of it and may reach past its end"""
     shapes = [(203, 331), (120, 200), (77, 96)]

@@ -86,6 +86,7 @@ struct vszip_ctx {
     void *minmax_pred = nullptr;
     size_t minmax_pred_planes = 0;
     std::vector<uint64_t> minmax_sig;  // per batch of the call: signature of the last thresholded call that left predictions (0: none)
+    int minmax_fallbacks = 0;  // synchronous predicted calls whose flags asked for the two sweeps (vszip_ctx_get_option "VSZIP_STAT_MINMAX_FALLBACKS": read-only)
     void *chain_buf = nullptr;  // vszip_chain_run: intermediate planes (grow-only)
     size_t chain_bytes = 0;
     void *ssim_lut = nullptr;  // SSIMULACRA2 colour pre-stage: cached conversion table (ssimulacra2.hip)

@@ -140,6 +140,10 @@ VSZIP_EXPORT int vszip_ctx_set_option(vszip_ctx *ctx, const char *name, int valu
 
 VSZIP_EXPORT int vszip_ctx_get_option(vszip_ctx *ctx, const char *name, int *value) {
     if (!ctx || !name || !value) return VSZIP_ERR_ARG;
+    if (strcmp(name, "VSZIP_STAT_MINMAX_FALLBACKS") == 0) {  // a counter, not a switch (tests: did a clip's steady state stay on the single sweep?)
+        *value = ctx->minmax_fallbacks;
+        return VSZIP_OK;
+    }
     for (const OptionDesc &d : kOptions)
         if (strcmp(d.env, name) == 0) {
             if (!d.field) return vszip_set_error(ctx, VSZIP_ERR_UNSUPPORTED, "%s is a development variant: build with -DVSZIP_DEV_VARIANTS", name);

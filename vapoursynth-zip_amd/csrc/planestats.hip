@@ -531,8 +531,10 @@ __device__ __forceinline__ void write_result(const PSParams &prm, int pi, int is
     }
     prm.bucket[pi * kBucketWords + 11] = 1u;
     if (prm.pred) {  // where the next frame's thresholds are looked for first: a range of kRange values centred on this frame's answers
-        prm.pred[pi * 2] = (uint32_t)max((int)retmin - kRange / 2, 0);
-        prm.pred[pi * 2 + 1] = (uint32_t)max((int)retmax - kRange / 2, 0);
+        // (... and ending at or below 65 536: the packed sweep measures distances from a range's start modulo 2^16 - a range reaching past the top would
+        // collect the plane's darkest samples, and its plane would be flagged on every call)
+        prm.pred[pi * 2] = (uint32_t)min(max((int)retmin - kRange / 2, 0), 65536 - kRange);
+        prm.pred[pi * 2 + 1] = (uint32_t)min(max((int)retmax - kRange / 2, 0), 65536 - kRange);
     }
 }
 
@@ -891,8 +893,9 @@ __global__ __launch_bounds__(kSweepThreads) void hist_sweep_kernel(const PSParam
 #endif
                 }
             };
-            // start values from the dev build's row sample can lie past 16 bits (its "nothing qualifies" markers): those planes take the per-sample form
-            const bool packed = kPacked && (lo_start | hi_start) < 0x10000u;
+            // ranges that end past 65 536 (the dev build's row sample leaves such starts, and its "nothing qualifies" markers) take the per-sample form: modulo 2^16
+            // the plane's darkest samples would fall into them
+            const bool packed = kPacked && lo_start <= 65536u - kRange && hi_start <= 65536u - kRange;
             if (packed) {
                 const uint32_t lo2 = lo_start * 0x10001u, hi2 = hi_start * 0x10001u, copy4 = (uint32_t)rcopy * 4u, one1 = 1u;
                 uint32_t sum_p = 0, sum_l = 0, sum_h = 0, nvec = 0, addr = 0;
@@ -1371,6 +1374,7 @@ VSZIP_EXPORT int vszip_plane_minmax(vszip_ctx *ctx, int dtype, const vszip_plane
         bool flagged = false;
         for (int i = 0; i < nplanes; ++i) flagged = flagged || host[(size_t)i * 4 + 3] != 0.0;
         if (flagged) {
+            ++ctx->minmax_fallbacks;
             rc = fallback();
             if (rc != VSZIP_OK) return rc;
             VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
