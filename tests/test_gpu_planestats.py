@@ -224,6 +224,43 @@ def test_minmax_temporal_prediction_ranges_at_the_top_of_16_bits(dev, oracle):
         d.close()
 
 
+def test_minmax_predictions_of_interleaved_clips(dev, oracle):
+    """The thresholded statistics of several clips of a filter graph arrive interleaved on one context: each signature (plane count and sizes, sample type,
+    thresholds) keeps its own prediction table (four per plane group, least recently used replaced). Three clips in turn: from their second frames on every
+    call is predicted and none needs the two sweeps; a fifth signature evicts the oldest, whose next call is a first call again."""
+    import vszip_amd
+
+    d = vszip_amd.Device(0)
+    try:
+        clips = [([(120, 200), (60, 100), (60, 100)], (0.1, 0.1)), ([(96, 160)], (0.05, 0.2)), ([(120, 200), (60, 100), (60, 100)], (0.3, 0.02))]
+
+        def frame(ci, k):
+            return [np.clip(fx.tiled_natural(s, np.uint16, (ci + i) % 3).astype(np.int32) + 11 * k, 0, 65535).astype(np.uint16) for i, s in enumerate(clips[ci][0])]
+
+        def call(ci, k):
+            f = frame(ci, k)
+            thr = clips[ci][1]
+            p0, f0 = d.get_option("VSZIP_STAT_MINMAX_PREDICTED"), d.get_option("VSZIP_STAT_MINMAX_FALLBACKS")
+            mn, mx, _ = d.plane_minmax([d.upload(p) for p in f], thr[0], thr[1])
+            for i, p in enumerate(f):
+                omn, omx, _ = oracle.plane_minmax(p, thr[0], thr[1], None)
+                assert (mn[i], mx[i]) == (omn, omx), (ci, k, i)
+            return d.get_option("VSZIP_STAT_MINMAX_PREDICTED") - p0, d.get_option("VSZIP_STAT_MINMAX_FALLBACKS") - f0
+
+        for k in range(4):
+            for ci in range(3):
+                assert call(ci, k) == ((1, 0) if k else (0, 0)), (ci, k)
+        # two more signatures: five in all, four tables - clip 0's (the least recently used) goes
+        clips.append(([(64, 96)], (0.2, 0.2)))
+        clips.append(([(64, 96)], (0.25, 0.2)))
+        assert call(3, 0) == (0, 0) and call(4, 0) == (0, 0)
+        assert call(0, 4) == (0, 0)   # a first call again
+        assert call(0, 5) == (1, 0)
+        assert call(2, 4) == (1, 0)   # still there
+    finally:
+        d.close()
+
+
 def test_minmax_temporal_prediction_on_10_bit_clips(dev, oracle):
     """10-bit samples in 16-bit words: the histogram is 1 024 values long, a predicted range of 512 covers half of it and may reach past its end"""
     shapes = [(203, 331), (120, 200), (77, 96)]

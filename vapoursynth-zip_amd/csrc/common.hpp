@@ -85,7 +85,10 @@ struct vszip_ctx {
     // call looked like — a call of the same shape (the next frames of a clip) looks there first and reads its planes once (planestats.hip)
     void *minmax_pred = nullptr;
     size_t minmax_pred_planes = 0;
-    std::vector<uint64_t> minmax_sig;  // per batch of the call: signature of the last thresholded call that left predictions (0: none)
+    std::vector<uint64_t> minmax_sig;   // per plane group of a call, kPredSlots entries: signatures of the thresholded calls that left predictions (0: none)
+    std::vector<uint64_t> minmax_used;  // ... and when each was last used (minmax_tick)
+    uint64_t minmax_tick = 0;
+    int minmax_predicted = 0;  // plane groups of thresholded calls that ran the single predicted sweep ("VSZIP_STAT_MINMAX_PREDICTED": read-only)
     int minmax_fallbacks = 0;  // synchronous predicted calls whose flags asked for the two sweeps (vszip_ctx_get_option "VSZIP_STAT_MINMAX_FALLBACKS": read-only)
     void *chain_buf = nullptr;  // vszip_chain_run: intermediate planes (grow-only)
     size_t chain_bytes = 0;

@@ -140,6 +140,10 @@ VSZIP_EXPORT int vszip_ctx_set_option(vszip_ctx *ctx, const char *name, int valu
 
 VSZIP_EXPORT int vszip_ctx_get_option(vszip_ctx *ctx, const char *name, int *value) {
     if (!ctx || !name || !value) return VSZIP_ERR_ARG;
+    if (strcmp(name, "VSZIP_STAT_MINMAX_PREDICTED") == 0) {
+        *value = ctx->minmax_predicted;
+        return VSZIP_OK;
+    }
     if (strcmp(name, "VSZIP_STAT_MINMAX_FALLBACKS") == 0) {  // a counter, not a switch (tests: did a clip's steady state stay on the single sweep?)
         *value = ctx->minmax_fallbacks;
         return VSZIP_OK;

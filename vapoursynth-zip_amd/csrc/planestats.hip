@@ -1148,6 +1148,7 @@ int run_average(vszip_ctx *ctx, Launch &L, bool ref) {
 // table (PSParams::pred), and a call of the same shape as the previous one (plane count and sizes, sample type, thresholds) sweeps ONCE over
 // those ranges. A scene cut, another clip or a first call cost what they always did — the flagged planes' two sweeps — and the results are the
 // reference's either way (tests/test_gpu_planestats.py::test_minmax_temporal_prediction*). VSZIP_MINMAX_NO_PREDICT=1: always two sweeps.
+constexpr int kPredSlots = 4;
 static uint64_t minmax_signature(const Launch &L, int dtype_size, bool ref) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
@@ -1169,8 +1170,10 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch, std::functio
     constexpr int wide = sizeof(T) > 1 ? 1 : 0;
     bool predicted = false;
     if (wide && !no_thr && !ctx->opt.minmax_no_predict && batch >= 0) {
-        const size_t first = (size_t)batch * kMaxPlanesPS, need = first + (size_t)L.prm.nplanes;
-        if (ctx->minmax_pred_planes < need) {  // grow-only, old predictions kept
+        // kPredSlots tables per plane group, by signature, least recently used replaced: the thresholded statistics of several clips (or one clip under
+        // several thresholds) of a filter graph arrive interleaved on one context, and each keeps its own predictions
+        const size_t group = (size_t)batch * kPredSlots, need = (group + kPredSlots) * kMaxPlanesPS;
+        if (ctx->minmax_pred_planes < need) {  // grow-only, old predictions kept (a group's tables do not move when later groups are added)
             const size_t cap = std::max<size_t>(need, 2 * ctx->minmax_pred_planes);
             void *np = nullptr;
             VSZIP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1182,11 +1185,24 @@ int run_minmax_t(vszip_ctx *ctx, Launch &L, bool no_thr, int batch, std::functio
             ctx->minmax_pred = np;
             ctx->minmax_pred_planes = cap;
         }
-        L.prm.pred = static_cast<uint32_t *>(ctx->minmax_pred) + first * 2;
-        if (ctx->minmax_sig.size() <= (size_t)batch) ctx->minmax_sig.resize((size_t)batch + 1, 0);
+        if (ctx->minmax_sig.size() < group + kPredSlots) {
+            ctx->minmax_sig.resize(group + kPredSlots, 0);
+            ctx->minmax_used.resize(group + kPredSlots, 0);
+        }
         const uint64_t sig = minmax_signature(L, (int)sizeof(T), REF);
-        predicted = ctx->minmax_sig[(size_t)batch] == sig;
-        ctx->minmax_sig[(size_t)batch] = sig;  // (this call leaves predictions for the next one, whichever way it runs)
+        size_t slot = group;
+        for (size_t k = group; k < group + kPredSlots; ++k) {
+            if (ctx->minmax_sig[k] == sig) {
+                slot = k;
+                predicted = true;
+                break;
+            }
+            if (ctx->minmax_used[k] < ctx->minmax_used[slot]) slot = k;
+        }
+        ctx->minmax_sig[slot] = sig;  // (this call leaves predictions for the next one of its signature, whichever way it runs)
+        ctx->minmax_used[slot] = ++ctx->minmax_tick;
+        L.prm.pred = static_cast<uint32_t *>(ctx->minmax_pred) + slot * kMaxPlanesPS * 2;
+        if (predicted) ++ctx->minmax_predicted;
     } else {
         L.prm.pred = nullptr;
     }
@@ -1262,6 +1278,7 @@ void vszip_planestats_release(vszip_ctx *ctx) {
     ctx->minmax_pred = nullptr;
     ctx->minmax_pred_planes = 0;
     ctx->minmax_sig.clear();
+    ctx->minmax_used.clear();
 }
 
 static int plane_average_batch(vszip_ctx *ctx, int dtype, const vszip_plane *planes, int nplanes, const int32_t *exclude, int nexclude, int bits_per_sample,
