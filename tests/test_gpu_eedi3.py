@@ -99,6 +99,60 @@ def test_mclip(dev, oracle, hp, horizontal):
     assert np.array_equal(dev.download(d0), oracle.eedi3(src, 1, hp=hp, horizontal=horizontal, mclip=np.zeros_like(mask)))
 
 
+def _mclip_masks(shape, rng):
+    h, w = shape
+    sparse = (rng.random(shape) < 0.01).astype(np.uint8) * 255
+    sparse[h // 4:h // 4 + 6] = 0
+    dense = (rng.random(shape) < 0.9).astype(np.uint8) * 255
+    edges = np.zeros(shape, np.uint8)
+    edges[:, : min(3, w)] = 255                      # only the first columns (the rest of a long line: blocks without any column)
+    far = np.zeros(shape, np.uint8)
+    far[:, w - 1] = 255                              # only the last column
+    far[::3] = 0
+    blocks = np.zeros(shape, np.uint8)               # whole stretches without a sample: the tuned kernel skips those blocks' costs
+    for x0 in range(150, w, 300):
+        blocks[:, x0:x0 + 7] = 255
+    first_off = np.full(shape, 255, np.uint8)
+    first_off[:, : min(40, w)] = 0                   # column 1 outside bmask on some lines (:494-496) and inside on others
+    first_off[1::2, : min(22, w)] = 255
+    return dict(sparse=sparse, dense=dense, ones=np.full(shape, 255, np.uint8), first=edges, last=far, blocks=blocks, first_off=first_off)
+
+
+@pytest.mark.parametrize("geom", [(40, 401), (24, 64), (24, 65), (20, 130), (16, 33), (12, 700)], ids=lambda g: f"{g[1]}x{g[0]}")
+@pytest.mark.parametrize("kw", [dict(field=1), dict(field=0, dh=True), dict(field=1, mdis=12, nrad=1), dict(field=0, mdis=5, nrad=3, vcheck=0), dict(field=1, mdis=19, gamma=0.0, vcheck=3)],
+                         ids=lambda c: ",".join(f"{k}={v}" for k, v in c.items()))
+def test_mclip_on_the_tuned_line_kernel(dev, oracle, geom, kw):
+    """Round 6 (late): mclip with mdis <= 20 runs on the tuned line kernel (eedi3_line_kernel<..., MCLIP>): bmask words a block on the scalar unit, a column outside
+    bmask repeats the codes before it, a block without any column in bmask skips its costs. Masks that exercise each rule, widths around the 64-column blocks, the
+    mdis = 20 and the mdis < 20 layouts; and mdis = 25 calls, which the general kernel serves - all bit-exact against the oracle."""
+    h, w = geom
+    src = np.ascontiguousarray(np.tile(fx.crop_rgbs()[2], (1, 3))[:h, :w])
+    kw = dict(kw)
+    field = kw.pop("field")
+    s = dev.upload(src)
+    for name, mask in _mclip_masks((h, w), np.random.default_rng(h * 1000 + w)).items():
+        want = oracle.eedi3(src, field, mclip=mask, **kw)
+        (d,) = dev.eedi3([s], field, mclips=[dev.upload(mask)], **kw)
+        got = dev.download(d)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, geom, kw, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
+        if name in ("sparse", "blocks") and "mdis" not in kw:  # the general kernel's masked path keeps its own check: mdis > 20 sends an mclip call there
+            (d,) = dev.eedi3([s], field, mclips=[dev.upload(mask)], mdis=25, **kw)
+            want25 = oracle.eedi3(src, field, mclip=mask, mdis=25, **kw)
+            assert np.array_equal(dev.download(d).view(np.uint32), want25.view(np.uint32)), ("general kernel", name, geom, kw)
+
+
+def test_mclip_on_some_planes_of_a_call(dev, oracle):
+    """planes with and without an mclip in one call (a YUV clip whose mclip is Gray: the plugin passes the mask for the luma only), and EEDI3H's transposed masks"""
+    rng = np.random.default_rng(9)
+    planes = [np.ascontiguousarray(fx.crop_rgbs()[i][:60 + 10 * i, :200 + 37 * i]) for i in range(3)]
+    masks = [(rng.random(planes[0].shape) < 0.02).astype(np.uint8) * 255, None, (rng.random(planes[2].shape) < 0.3).astype(np.uint8) * 255]
+    for horizontal in (False, True):
+        ds = dev.eedi3([dev.upload(p) for p in planes], 1, dh=True, horizontal=horizontal, mclips=[dev.upload(m) if m is not None else None for m in masks])
+        for i, p in enumerate(planes):
+            want = oracle.eedi3(p, 1, dh=True, horizontal=horizontal, mclip=masks[i])
+            assert np.array_equal(dev.download(ds[i]).view(np.uint32), want.view(np.uint32)), (horizontal, i)
+
+
 def test_horizontal_matches_oracle_and_identity(dev, oracle):
     src = fx.crop_rgbs()[0][:150, :200]
     for dh in (False, True):

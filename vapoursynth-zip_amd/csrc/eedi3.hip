@@ -51,6 +51,9 @@ struct EParams {
     float alpha, beta, gamma, one_minus_ab;
     int line_base;  // first global line id of this launch (a call may launch its tall and its short planes separately)
     int copy_kept;  // the tuned line kernel also writes the KEPT field line beside its interpolated one (round 6: no copy kernel in front of it)
+    // eedi3_line_kernel<..., MCLIP> only: the planes' mclip (geometry of the - transposed - source plane) or NULL
+    const uint8_t *mask[kMaxPlanesE];
+    int mstride[kMaxPlanesE];
 };
 
 __device__ __forceinline__ int reflect_row(int y, int h) {  // eedi3.zig:88-96
@@ -123,9 +126,19 @@ constexpr int kU = 4;  // directions per cost pass
 // cost, which pins their Viterbi state at the sentinel exactly like the lanes past the last direction. A run-time mdis below the default used to take the
 // FIXED = false instance, whose cost pass is the round-3 form: slower at 21 directions than the fixed instance at 41 (tools/eedi3_param_sweep.py).
 // (the default geometry's LDS, round 6, lets 14 waves share a CU; registers for three a SIMD: a fourth measured no faster, see profiles/r06_notes.md)
-template <int NRAD, int MD, bool FIXED, bool MASK = false>
+// MCLIP (round 6, late): the mclip forms of the reference's line loop (eedi3.zig:368-399, :431-440, :492-505, :567-577) on this kernel - before, any mclip sent
+// the call to the general kernel (16 x 1080p a call: 710-810 fps against 4 300 without a mask; tools/eedi3_variants_timing.py). bmask[x] = "a mask sample
+// within mdis of x" (buildBmask :285-304) is a 64-bit word a block, built with three ballots and shifts on the scalar unit:
+//   * a line without any mask sample is the plain vertical cubic (:392-399);
+//   * a column outside bmask keeps the costs of the column before it and REPEATS that column's back-pointers (:492-505: pbackt[x-1] = pbackt[x-2]; column 1:
+//     the costs of column 1 themselves, pointers 0) - two instructions on the code word instead of a Viterbi step, behind a scalar branch on the word's bit;
+//   * a block without any column in bmask (other than the line's first, whose costs the reference always computes) skips its staging and its whole cost phase:
+//     nothing reads the costs of such columns, and its 64 codes are one code repeated;
+//   * the path is walked as always and set to 0 outside bmask afterwards (:567-577).
+template <int NRAD, int MD, bool FIXED, bool MASK = false, bool MCLIP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MASK && MD % kU == 0 && MD <= 20 ? 3 : 1))) void eedi3_line_kernel(const EParams prm) {
     static_assert(!MASK || FIXED, "MASK rides on the fixed layout");
+    static_assert(!MCLIP || FIXED, "MCLIP rides on the fixed layout");
     // The t_base and window-sum steps run a fixed number of 128-entry iterations (NIT2: every lane owns two
     // neighbouring entries, and the kU directions of a pass share ONE first column, so the span is the longest
     // of the pass) with no guard — entries past a direction's span are computed from padding and never read —
@@ -188,6 +201,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
     // the four source rows start on 8-byte boundaries (every VapourSynth plane: 32-byte aligned rows): blocks inside the line are staged in pairs
     const bool pair_ok = __builtin_amdgcn_readfirstlane((int)(((reinterpret_cast<uintptr_t>(r3p) | reinterpret_cast<uintptr_t>(r1p) | reinterpret_cast<uintptr_t>(r1n) | reinterpret_cast<uintptr_t>(r3n)) & 7) == 0)) != 0;
 
+    [[maybe_unused]] float *kept = prm.field ? out - pl.dstride : out + pl.dstride;  // (copy_kept) the kept field line beside this one
+    [[maybe_unused]] const uint8_t *maskp = nullptr;
+    if constexpr (MCLIP) {
+        maskp = prm.mask[pi] ? prm.mask[pi] + (size_t)(dh ? off : line) * prm.mstride[pi] : nullptr;  // (a plane without an mclip: every column takes part)
+        if (maskp) {
+            bool m = false;
+            for (int q = lane; q < w; q += 64) m = m || maskp[q] != 0;
+            if (__builtin_amdgcn_ballot_w64(m) == 0) {  // :392-399: nothing to connect on this line
+                for (int q = lane; q < w; q += 64) {
+                    dmap[q] = 0;
+                    out[q] = 0.5625f * (r1p[q] + r1n[q]) - 0.0625f * (r3p[q] + r3n[q]);
+                    if (prm.copy_kept) kept[q] = (prm.field ? r1p : r1n)[q];
+                }
+                return;
+            }
+        }
+    }
+    // (MCLIP) bit l of a block's word: a mask sample within mdis of column 64 blk + l. Three ballots (the block and its neighbours), then the 128-bit pairs
+    // (block : left neighbour) and (right neighbour : block) are OR-ed with their shifts by 0 ... mdis in doubling steps - all of it wave-uniform
+    [[maybe_unused]] auto block_bmask = [&](int b) -> uint64_t {
+        if (!maskp) return ~0ull;
+        const int q0 = b * kXB + lane;
+        auto word = [&](int q) -> uint64_t { return __builtin_amdgcn_ballot_w64(q >= 0 && q < w && maskp[min(max(q, 0), w - 1)] != 0); };
+        const uint64_t a0 = word(q0 - kXB), a1 = word(q0), a2 = word(q0 + kXB);
+        const int r = FIXED && !MASK ? MD : prm.mdis;  // (the reference dilates by the call's mdis)
+        uint64_t hi = a1, lo = a0;  // towards higher columns: samples to the LEFT reach up to mdis columns right
+        uint64_t uh = a2, ul = a1;  // towards lower columns
+        auto up = [&](int sft) {
+            hi |= (hi << sft) | (lo >> (64 - sft));
+            lo |= lo << sft;
+        };
+        auto down = [&](int sft) {
+            ul |= (ul >> sft) | (uh << (64 - sft));
+            uh |= uh >> sft;
+        };
+        int cover = 1;
+        while (2 * cover <= r + 1) {
+            up(cover);
+            down(cover);
+            cover *= 2;
+        }
+        if (r + 1 - cover > 0) {
+            up(r + 1 - cover);
+            down(r + 1 - cover);
+        }
+        return hi | ul;
+    };
     const int mlim = MASK ? prm.mdis : MD;  // (MASK) directions beyond it never get a cost
     if constexpr (MASK) {
         for (int r = 0; r < 2 * MD + 1; ++r) ctile[r][lane] = INFINITY;
@@ -202,6 +262,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
         const int xb = blk * kXB;
         const int x = xb + lane;
         const int c0 = xb - reach;  // plane column of rows[.][0]
+        [[maybe_unused]] uint64_t bm = ~0ull;
+        if constexpr (MCLIP) bm = block_bmask(blk);
+        const bool skip = MCLIP && blk != 0 && bm == 0;  // (wave-uniform) no column of the block takes part: no staging, no costs
+        if (skip) {
+            if (prm.copy_kept && x < w) kept[x] = (prm.field ? r1p : r1n)[x];
+        } else {
         // ---- stage the four source rows once per block ------------------------------------
         wave_fence();
         // Round 6: a block whose staged columns all lie inside the line (every block but the first and the last one or two) needs no mirror
@@ -229,7 +295,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
         const int lx = lane + reach;  // rows[] index of column x
         // The kept field line next to this one (processPlane copies them first, eedi3.zig(vs):41-56): destination line - 1 (field 1) / + 1 (field 0) is the staged
         // row r1p / r1n as it is - one LDS read and one 256-byte store a block instead of a 400 MB copy kernel in front of every call (round 6).
-        if (prm.copy_kept && x < w) (prm.field ? out - pl.dstride : out + pl.dstride)[x] = rows[prm.field ? 1 : 2][lx];
+        if (prm.copy_kept && x < w) kept[x] = rows[prm.field ? 1 : 2][lx];
         // ---- cost phase, lanes = x; kU directions per pass -------------------------------
         // The three steps of a direction (t_base -> window sums -> cost) are a chain of LDS
         // round trips; one direction at a time leaves the wave waiting on LDS latency most of
@@ -502,6 +568,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
             }
             wave_fence();
         }
+        }  // (!skip)
         // ---- DP phase, lanes = direction index ---------------------------------------
         const int xe = min(kXB, w - xb);
         // The Viterbi recurrence is a dependent chain along x, so nothing in it may wait on memory:
@@ -518,13 +585,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
         for (int i = 0; i < kXB / 16; ++i) pk[i] = 0;
         if (lane < tpitch) {
             float tcv[kXB];
+            if (!skip) {
 #pragma unroll
-            for (int q = 0; q < kXB / 4; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4 *>(&ctile[lane][4 * q]);
-                tcv[4 * q] = v4.x;
-                tcv[4 * q + 1] = v4.y;
-                tcv[4 * q + 2] = v4.z;
-                tcv[4 * q + 3] = v4.w;
+                for (int q = 0; q < kXB / 4; ++q) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(&ctile[lane][4 * q]);
+                    tcv[4 * q] = v4.x;
+                    tcv[4 * q + 1] = v4.y;
+                    tcv[4 * q + 2] = v4.z;
+                    tcv[4 * q + 3] = v4.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < kXB; ++q) tcv[q] = 0.f;  // (never used: every column of a skipped block repeats the codes before it)
             }
             // The step (round 4: five dependent instructions; round 6: nine VALU instructions instead of eleven). The new cost is
             // min3(own, below + gamma, above + gamma) + tc whatever the tie-breaking picks (strict < only decides WHICH of equal values is taken), so
@@ -555,12 +627,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
             auto store_block = [&](const uint32_t *q, int b) __attribute__((always_inline)) {  // 64 codes of direction `lane`, block b
                 *reinterpret_cast<uint4 *>(pback + ((size_t)b * tpitch + lane) * (kXB / 4)) = make_uint4(q[0], q[1], q[2], q[3]);
             };
+            // (MCLIP) column xb + xl of this block: a Viterbi step if bmask holds it; else the costs stay and the codes of the column before it are repeated
+            // (:492-505) - the low two bits of the word that holds them: the step's own word, the word before it, or the previous block's last word
+            auto column = [&](int xl, uint32_t &word, uint32_t before) __attribute__((always_inline)) {
+                if (!MCLIP || ((bm >> xl) & 1ull)) {
+                    dp_step(tcv[xl], word);
+                } else if (blk == 0 && xl == 1) {  // :494-496: the line's second column starts from its own costs, pointers 0
+                    pcost = tcv[1];
+                    asm volatile("s_nop 1" : "+v"(pcost));
+                    word <<= 2;
+                } else {
+                    word = (word << 2) | (before & 3u);
+                }
+            };
+            auto column_at = [&](int xl) __attribute__((always_inline)) {  // xl >= 1: code position xl - 1 of this block
+                const int pos = xl - 1, j = pos >> 4;
+                column(xl, pk[j], (pos & 15) ? pk[j] : (j ? pk[j > 0 ? j - 1 : 0] : held[kXB / 16 - 1]));
+            };
             // step 0 completes the previous block (its column 63)
             if (blk == 0) {
                 pcost = tcv[0];  // :461-463
                 asm volatile("s_nop 1" : "+v"(pcost));  // a DPP read two wait states after the register's last write; inside dp_step the step's own tail provides them
             } else {
-                dp_step(tcv[0], held[kXB / 16 - 1]);
+                column(0, held[kXB / 16 - 1], held[kXB / 16 - 1]);
                 store_block(held, blk - 1);
             }
 #ifdef VSZIP_E3_DIAG_NO_DP  // (timing diagnostics only: four of the 64 Viterbi steps of a block - wrong results)
@@ -569,7 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
                 for (int xl = 1; xl < 5; ++xl) dp_step(tcv[xl], pk[(xl - 1) >> 4]);
             } else
 #else
-            if (xe == kXB) {
+            if (xe == kXB && (!MCLIP || bm == ~0ull)) {  // (MCLIP: a block wholly inside bmask - every block of a call whose mask is dense - takes the plain steps, no branch a column)
 #pragma unroll
                 for (int xl = 1; xl < kXB; ++xl) dp_step(tcv[xl], pk[(xl - 1) >> 4]);
             } else
@@ -577,7 +666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
             {
 #pragma unroll
                 for (int xl = 1; xl < kXB; ++xl)
-                    if (xl < xe) dp_step(tcv[xl], pk[(xl - 1) >> 4]);
+                    if (xl < xe) column_at(xl);
             }
             if (blk == nblk - 1) {
                 // the line's last block: its words are as full as they get (xe - 1 codes; even a whole block has no column 63) — move the codes to their places
@@ -654,11 +743,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FIXED && !MA
         else
             walk(std::false_type{});
         carry = fpm;
+        [[maybe_unused]] uint64_t obm = ~0ull;
+        if constexpr (MCLIP) obm = block_bmask(blk);
         emit_prev();  // (the block to the right: its taps were requested a walk ago)
         pxx = -1;
         if (lane < xe) {
             const int xx = xb + lane;
-            const int dir = fpv - mdis, ad = abs(dir);
+            const int dir = (!MCLIP || ((obm >> lane) & 1ull)) ? fpv - mdis : 0, ad = abs(dir);  // (:567-577: the path outside bmask is 0)
             dmap[xx] = dir;
             pxx = xx;
             pcubic = xx >= ad * 3 && xx + ad * 3 <= w - 1;
@@ -1717,8 +1808,8 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
     bool any_mask = false;
     for (int i = 0; i < nplanes && mclips; ++i) any_mask = any_mask || mclips[i] != nullptr;
     if (any_mask && !mclip_strides) return vszip_set_error(ctx, VSZIP_ERR_ARG, "%s: mclip strides missing", name);
-    // the tuned kernel covers the common case; hp, mdis > 31 and mclip take the general one
-    const bool general = hp || up->mdis > kMaxMdis || any_mask;
+    // the tuned kernel covers the common case and, on its fixed layout (mdis <= 20), mclip; hp, mdis > 31 and mclip with 20 < mdis <= 31 take the general one
+    const bool general = hp || up->mdis > kMaxMdis || (any_mask && (up->mdis > 20 || ctx->opt.eedi3_no_fixed));
     // (mdis <= 20 on the tuned kernel: the layout of mdis = 20, see MASK)
     const bool masked20 = !general && up->mdis < 20 && !ctx->opt.eedi3_no_fixed;
     const int tpitch = hp ? 4 * up->mdis + 1 : (masked20 ? 2 * 20 + 1 : 2 * up->mdis + 1);
@@ -1871,6 +1962,8 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         maxw = std::max(maxw, g.L);
         maxsrc = std::max(maxsrc, g.n_src);
         vp.p[slot] = d;
+        ep.mask[slot] = gx.mask[slot];
+        ep.mstride[slot] = gx.mstride[slot];
     }
     if (ntall == nplanes) lines_tall = line0;
     int maxL = 0;
@@ -1983,7 +2076,11 @@ static int eedi3_batch(vszip_ctx *ctx, const vszip_plane *planes, const float *c
         const dim3 lblock(64);
 #define VSZIP_E3_LAUNCH(N)                                                                        \
     do {                                                                                          \
-        if (up->mdis == 20 && !ctx->opt.eedi3_no_fixed)                                    \
+        if (any_mask && up->mdis == 20)                                                            \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true, false, true>), lgrid, lblock, 0, lst, ep); \
+        else if (any_mask)                                                                        \
+            hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true, true, true>), lgrid, lblock, 0, lst, ep); \
+        else if (up->mdis == 20 && !ctx->opt.eedi3_no_fixed)                                    \
             hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true>), lgrid, lblock, 0, lst, ep);      \
         else if (masked20)                                                                        \
             hipLaunchKernelGGL((eedi3_line_kernel<N, 20, true, true>), lgrid, lblock, 0, lst, ep); \
