@@ -965,6 +965,16 @@ def plugin_legs():
                                                  "workload": "libvszip.so: vszip.SSIMULACRA2 on 3840x2160 YUV420P8 clips in host memory (colour pre-stage on the device; the output "
                                                              "clip is the host-converted reference, converted eagerly by the test host outside the clock), 16 worker threads"}
         del clip, ra, rb, yref, ydis
+        # round 6 (late): BASELINE config 4 as a script. Half of a dh frame's lines are the source's own and never cross the link (the plugin copies them on the host):
+        # 12.4 MB up + 12.4 MB of interpolated lines down a frame
+        e3 = [np.ascontiguousarray(fx.tiled_natural(s, np.float32, p)) for p, s in enumerate(yuv420_shapes(W1080, H1080))]
+        clip = vs.source([[np.roll(p, 5 * f, axis=1) for p in e3] for f in range(8)], vs.YUV420PS).vszip.EEDI3(field=1, dh=True)
+        clip.pull(32, 16)
+        sec = clip.pull(256, 16, warm_per_thread=3)
+        out["plugin_eedi3_1080p"] = {"value": 256 / sec, "unit": "frames/s", "threads": 16, "host_link_GBps": 256 * 2 * 12.4416e-3 / sec,
+                                     "workload": "libvszip.so: vszip.EEDI3(field=1, dh=True) on 1920x1080 YUV420PS frames in host memory, 16 worker threads; the kept field's lines "
+                                                 "are copied on the host, the interpolated lines come down the link; host_link_GBps counts both directions"}
+        del clip, e3
         b8 = [np.ascontiguousarray(fx.tiled_natural((H8K, W8K), np.float32, p)) for p in range(3)]
         src = vs.source([[np.roll(p, 19 * f, axis=1) for p in b8] for f in range(2)], vs.RGBS, props={"_Transfer": 8})
         f0, s0 = vs.fusion_stats()
@@ -1341,7 +1351,15 @@ def main() -> int:
     ap.add_argument("--radius", type=int, default=RADIUS, help="development: BoxBlur radius (headline = 13)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="kernel time of the launch-duration sample (roofline.launch_us)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1: print the rank-launch command and exit (no GPU)")
+    ap.add_argument("--plugin-legs-only", action="store_true", help="internal: run the legs through libvszip.so and print their records as one JSON line (see plugin_child below)")
     a = ap.parse_args()
+    if a.plugin_legs_only:
+        sys.path.insert(0, str(ROOT / "tests"))
+        out_fd = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        out_fd.write(json.dumps(plugin_legs()) + "\n")
+        out_fd.flush()
+        return 0
     if a.exchange_only:
         a.no_cpu = a.no_others = True
 
@@ -1362,6 +1380,23 @@ def main() -> int:
     if world != max(1, a.gpus):
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
+
+    # The plugin legs run in a CHILD process of their own, started here - before this process touches the GPU - and waited for: a VapourSynth host is a
+    # process in which the plugin is the first thing to initialise the HIP runtime, and the order matters. Round 6: EEDI3 through the plugin ran 2.5 k fps
+    # in such a process and 1.1-1.5 k in this one after its own context (or a bare hipFree(NULL)) had initialised the runtime first; loading the plugin
+    # host first IN this process fixed that leg and cost the headline its placement (probe 4.7 TB/s, 95 k fps). tools/plugin_bench.py always ran the clean
+    # order. Not under a profiler (the child would be an exec behind a preloaded tool that has initialised the GPU): the legs then run in-process as before.
+    plugin_child = None
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if not a.no_others and rank == 0 and world == 1 and not profiled and os.environ.get("VSZIP_BENCH_PLUGIN_INPROC") != "1":
+        try:
+            import subprocess
+
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--plugin-legs-only"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+            plugin_child = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        except Exception as e:
+            print(f"bench.py: the plugin legs' child process failed ({e}); running them in-process", file=sys.stderr)
+            plugin_child = None
 
     # torch first: its bundled HIP runtime must be the one libvszip_hip.so binds to
     import torch
@@ -1617,7 +1652,7 @@ def main() -> int:
             except Exception as e:
                 out["config"]["frames_per_call_sweep"] = {"error": str(e)[:100]}
             try:
-                others.update(plugin_legs())
+                others.update(plugin_child if plugin_child is not None else plugin_legs())
             except Exception as e:
                 others["plugin_legs"] = {"error": str(e)}
             out["others"] = others

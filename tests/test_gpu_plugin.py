@@ -163,6 +163,15 @@ def test_eedi3_through_plugin(oracle):
     assert np.array_equal(dbl.get_frame(0)[0], oracle.eedi3(planes[0], 1)) and np.array_equal(dbl.get_frame(1)[0], oracle.eedi3(planes[0], 0))
     h = vs.source([[planes[0]]], vs.GRAYS).vszip.EEDI3H(field=1).get_frame(0)
     assert np.array_equal(h[0], oracle.eedi3(planes[0], 1, horizontal=True))
+    # (round 6: only the interpolated lines come down the link, the kept field's lines are copied from the source frame on the host) every plane, both
+    # fields, with and without dh; EEDI3H with dh downloads whole planes
+    for field in (0, 1):
+        for dh in (False, True):
+            got = src.vszip.EEDI3(field=field, dh=dh).get_frame(1)
+            for p in range(3):
+                assert np.array_equal(got[p], oracle.eedi3(planes[p], field, dh=dh)), (field, dh, p)
+    hd = vs.source([[planes[0]]], vs.GRAYS).vszip.EEDI3H(field=0, dh=True).get_frame(0)
+    assert np.array_equal(hd[0], oracle.eedi3(planes[0], 0, dh=True, horizontal=True))
 
 
 def test_eedi3_hp_mdis40_mclip_through_plugin(oracle):

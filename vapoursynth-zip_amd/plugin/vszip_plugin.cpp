@@ -2063,8 +2063,36 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
         }
         int rc = vszip_eedi3_mclip(g->ctx, tab.data(), scp ? scl.data() : nullptr, scp ? scs.data() : nullptr, mcp ? mcl.data() : nullptr, mcp ? mcs.data() : nullptr,
                                    (int)tab.size(), field, d->horizontal, &d->prm);
-        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i)
-            if (!z.download(g, outs[i], dst, (int)i)) rc = VSZIP_ERR_HIP;
+        // EEDI3 (vertical): half of the output's lines are the source's own - the kept field, processPlane eedi3.zig(vs):41-56 - and the host holds them already:
+        // only the interpolated lines cross the link (the download is what bounds this filter through the plugin: 25 MB a 1080p dh frame against 12 up), and this
+        // thread copies the kept lines from the source frame while the GPU works. EEDI3H's kept samples are columns, interleaved within every row: the whole plane.
+        for (size_t i = 0; rc == VSZIP_OK && i < outs.size(); ++i) {
+            if (d->horizontal) {
+                if (!z.download(g, outs[i], dst, (int)i)) rc = VSZIP_ERR_HIP;
+                continue;
+            }
+            const DPlane &o = outs[i];
+            const ptrdiff_t hs = api->getStride(dst, (int)i);
+            uint8_t *hp = api->getWritePtr(dst, (int)i);
+            const int n_interp = (o.h - field + 1) / 2;  // lines field, field + 2, ...
+            if (n_interp > 0 && vszip_copy_d2h_2d(g->ctx, hp + (size_t)field * hs, (size_t)hs * 2, static_cast<const uint8_t *>(o.ptr) + (size_t)field * o.stride * o.bps, (size_t)o.stride * o.bps * 2,
+                                                  (size_t)o.w * o.bps, n_interp) != VSZIP_OK)
+                rc = VSZIP_ERR_HIP;
+        }
+        if (rc == VSZIP_OK && !d->horizontal) {
+            const bool dh = d->prm.dh != 0;
+            for (int p = 0; p < vf->numPlanes; ++p) {
+                const uint8_t *sp = api->getReadPtr(src, p);
+                const ptrdiff_t ss = api->getStride(src, p), hs = api->getStride(dst, p);
+                uint8_t *hp = api->getWritePtr(dst, p);
+                const int sh = api->getFrameHeight(src, p), oh = api->getFrameHeight(dst, p);
+                const size_t row = (size_t)api->getFrameWidth(dst, p) * 4;
+                for (int y = 1 - field; y < oh; y += 2) {
+                    const int k = dh ? y / 2 : y;  // dh: output line 2 k + (1 - field) is source line k
+                    if (k < sh) memcpy(hp + (size_t)y * hs, sp + (size_t)k * ss, row);
+                }
+            }
+        }
         if (rc == VSZIP_OK) rc = vszip_ctx_sync(g->ctx);
         if (rc != VSZIP_OK) return done(fail(z, g, dst, name, "GPU kernel failed"));
         api->mapSetInt(props, "_FieldBased", 0, maReplace);
