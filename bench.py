@@ -1384,8 +1384,8 @@ def main() -> int:
     # The plugin legs run in a CHILD process of their own, started here - before this process touches the GPU - and waited for: a VapourSynth host is a
     # process in which the plugin is the first thing to initialise the HIP runtime, and the order matters. Round 6: EEDI3 through the plugin ran 2.5 k fps
     # in such a process and 1.1-1.5 k in this one after its own context (or a bare hipFree(NULL)) had initialised the runtime first; loading the plugin
-    # host first IN this process fixed that leg and cost the headline its placement (probe 4.7 TB/s, 95 k fps). tools/plugin_bench.py always ran the clean
-    # order. Not under a profiler (the child would be an exec behind a preloaded tool that has initialised the GPU): the legs then run in-process as before.
+    # host first IN this process fixed that leg and cost the headline its placement (probe 4.7 TB/s, 95 k fps). The mechanism: the plugin sets GPU_MAX_HW_QUEUES=16
+    # when it is loaded, and the runtime reads that when it initialises (profiles/r06_notes.md 13). tools/plugin_bench.py always ran the clean order. Not under a profiler (the child would be an exec behind a preloaded tool that has initialised the GPU): the legs then run in-process as before.
     plugin_child = None
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if not a.no_others and rank == 0 and world == 1 and not profiled and os.environ.get("VSZIP_BENCH_PLUGIN_INPROC") != "1":
