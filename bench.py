@@ -1338,6 +1338,28 @@ def launch_ranks(a, argv) -> int:
     return r.returncode
 
 
+
+def plugin_legs_child():
+    """The plugin legs in a CHILD process (`bench.py --plugin-legs-only`), waited for: a VapourSynth host is a process in which the plugin is loaded before any HIP
+    call, and the order matters - `VapourSynthPluginInit2` sets GPU_MAX_HW_QUEUES=16 (twelve streams folded onto the default four hardware queues make one frame's
+    2 ms chain hold up three other frames' kernels) and the runtime reads that when it initialises. Round 6: EEDI3 through the plugin ran 2.5 k fps in such a process
+    and 1.1-1.5 k in this one, whose own context had initialised the runtime first; loading the plugin first IN this process gave all of it sixteen queues and cost the
+    headline its placement search (profiles/r06_notes.md 13). The child is started where the legs always ran - after the other legs, this process idle - because a
+    child run FIRST leaves the driver scrubbing the memory it freed: the headline's first candidate allocations then took 1.3 s each and the search's budget ended
+    after one or two (0.63 on one run). Not under a profiler (the child would be an exec behind a preloaded tool): None -> the caller runs the legs in-process."""
+    import subprocess
+
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled or os.environ.get("VSZIP_BENCH_PLUGIN_INPROC") == "1":
+        return None
+    try:
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--plugin-legs-only"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:
+        print(f"bench.py: the plugin legs' child process failed ({e}); running them in-process", file=sys.stderr)
+        return None
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1380,23 +1402,6 @@ def main() -> int:
     if world != max(1, a.gpus):
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
-
-    # The plugin legs run in a CHILD process of their own, started here - before this process touches the GPU - and waited for: a VapourSynth host is a
-    # process in which the plugin is the first thing to initialise the HIP runtime, and the order matters. Round 6: EEDI3 through the plugin ran 2.5 k fps
-    # in such a process and 1.1-1.5 k in this one after its own context (or a bare hipFree(NULL)) had initialised the runtime first; loading the plugin
-    # host first IN this process fixed that leg and cost the headline its placement (probe 4.7 TB/s, 95 k fps). The mechanism: the plugin sets GPU_MAX_HW_QUEUES=16
-    # when it is loaded, and the runtime reads that when it initialises (profiles/r06_notes.md 13). tools/plugin_bench.py always ran the clean order. Not under a profiler (the child would be an exec behind a preloaded tool that has initialised the GPU): the legs then run in-process as before.
-    plugin_child = None
-    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if not a.no_others and rank == 0 and world == 1 and not profiled and os.environ.get("VSZIP_BENCH_PLUGIN_INPROC") != "1":
-        try:
-            import subprocess
-
-            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--plugin-legs-only"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-            plugin_child = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        except Exception as e:
-            print(f"bench.py: the plugin legs' child process failed ({e}); running them in-process", file=sys.stderr)
-            plugin_child = None
 
     # torch first: its bundled HIP runtime must be the one libvszip_hip.so binds to
     import torch
@@ -1652,6 +1657,7 @@ def main() -> int:
             except Exception as e:
                 out["config"]["frames_per_call_sweep"] = {"error": str(e)[:100]}
             try:
+                plugin_child = plugin_legs_child()
                 others.update(plugin_child if plugin_child is not None else plugin_legs())
             except Exception as e:
                 others["plugin_legs"] = {"error": str(e)}
