@@ -208,6 +208,44 @@ def test_eedi3_random(dev, oracle, seed):
     assert np.array_equal(dev.download(d), oracle.eedi3(p, field, **kw)), (seed, field, kw, p.shape)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_eedi3_mclip_random(dev, oracle, seed):
+    """mclip on the tuned line kernel (mdis <= 20) and, for larger mdis, on the general one: random widths around the 64-column blocks, masks from empty to dense
+    made of samples, runs, empty lines and empty stretches; sclip on some; two planes a call, the second without a mask on some"""
+    rng = np.random.default_rng(SEED_BASE + 4500 + seed)
+    mdis = int(rng.integers(1, 21)) if seed % 4 else int(rng.integers(21, 32))
+    nrad = int(rng.integers(0, 4))
+    dh = bool(rng.integers(0, 2))
+    w = int(rng.integers(2 * mdis + nrad + 4, 2 * mdis + nrad + 330))
+    h = int(rng.integers(4, 30)) * 2
+    field = int(rng.integers(0, 2))
+    kw = dict(dh=dh, mdis=mdis, nrad=nrad, vcheck=int(rng.integers(0, 4)), gamma=float(rng.choice([0.0, 5.0, 20.0, 80.0])))
+    planes, masks = [], []
+    for k in range(2):
+        p = rng.random((h, w)).astype(np.float32)
+        dens = float(rng.choice([0.0, 0.002, 0.02, 0.3, 0.95]))
+        m = (rng.random((h, w)) < dens).astype(np.uint8) * int(rng.choice([1, 128, 255]))
+        for _ in range(int(rng.integers(0, 4))):  # runs of samples
+            y, x0, n = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(1, 90))
+            m[y, x0:x0 + n] = 255
+        m[int(rng.integers(0, h))] = 0
+        x0 = int(rng.integers(0, w))
+        m[:, x0:x0 + int(rng.integers(0, 200))] = 0
+        if rng.integers(0, 3) == 0:
+            m[:, :2] = 255
+        planes.append(p)
+        masks.append(m if (k == 0 or seed % 3) else None)
+    sclips = None
+    if seed % 2 and kw["vcheck"] > 0:
+        sclips = [rng.random((2 * h if dh else h, w)).astype(np.float32) for _ in planes]
+    ds = dev.eedi3([dev.upload(p) for p in planes], field, mclips=[dev.upload(m) if m is not None else None for m in masks],
+                   sclips=[dev.upload(x) for x in sclips] if sclips else None, **kw)
+    for k, p in enumerate(planes):
+        want = oracle.eedi3(p, field, mclip=masks[k], sclip=sclips[k] if sclips else None, **kw)
+        got = dev.download(ds[k])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, k, field, kw, p.shape, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_planestats_random(dev, oracle, seed):
     rng = np.random.default_rng(SEED_BASE + 5000 + seed)
