@@ -255,6 +255,14 @@ def test_second_clips_through_plugin(oracle):
     sc = np.ascontiguousarray(fx.crop_rgbs()[2][:128, :200])
     e = vs.source([[f]], vs.GRAYS).vszip.EEDI3(field=1, dh=1, sclip=vs.source([[sc]], vs.GRAYS)).get_frame(0)
     assert np.array_equal(e[0], oracle.eedi3(f, 1, dh=True, sclip=sc))
+    # (round 6: only the sclip's interpolated lines are uploaded) the other field, without dh, every vcheck level, and EEDI3H (whole sclip, transposed on the device)
+    for field, dh, vcheck in ((0, True, 2), (0, False, 1), (1, False, 3)):
+        scl = sc if dh else sc[:64]
+        e = vs.source([[f]], vs.GRAYS).vszip.EEDI3(field=field, dh=dh, vcheck=vcheck, sclip=vs.source([[scl]], vs.GRAYS)).get_frame(0)
+        assert np.array_equal(e[0], oracle.eedi3(f, field, dh=dh, vcheck=vcheck, sclip=scl)), (field, dh, vcheck)
+    sch = np.ascontiguousarray(fx.crop_rgbs()[2][:64, :400])
+    eh = vs.source([[f]], vs.GRAYS).vszip.EEDI3H(field=0, dh=1, sclip=vs.source([[sch]], vs.GRAYS)).get_frame(0)
+    assert np.array_equal(eh[0], oracle.eedi3(f, 0, dh=True, sclip=sch, horizontal=True))
 
 
 def test_depth_conversions_are_delegated_to_the_host(oracle):

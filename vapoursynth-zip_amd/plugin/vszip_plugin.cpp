@@ -275,6 +275,27 @@ struct Z {
         g->uploaded.push_back({host, hs, d.w, d.h, d.bps, d.ptr, d.stride});
         return d;
     }
+    // every second row of a host plane, from row `first` on, into a device plane of the full geometry (the other rows stay unwritten): EEDI3's sclip is
+    // read on the interpolated lines only (vcheckLine, eedi3.zig:915-1046 - `scpp` is the line being blended), so half of it never needs to cross the link
+    DPlane upload_alternate_rows(Gpu *g, const VSFrame *f, int plane, int first) const {
+        DPlane d;
+        const VSVideoFormat *vf = api->getVideoFrameFormat(f);
+        d.bps = vf->bytesPerSample;
+        d.w = api->getFrameWidth(f, plane);
+        d.h = api->getFrameHeight(f, plane);
+        const uint8_t *host = api->getReadPtr(f, plane);
+        const ptrdiff_t hs = api->getStride(f, plane);
+        const size_t pitch = ((size_t)d.w * d.bps + 255) & ~(size_t)255;
+        d.stride = (ptrdiff_t)(pitch / d.bps);
+        d.ptr = g->alloc(pitch * d.h);
+        if (!d.ptr) return d;
+        const int rows = (d.h - first + 1) / 2;
+        if (rows > 0 && vszip_copy_h2d_2d(g->ctx, static_cast<uint8_t *>(d.ptr) + (size_t)first * pitch, pitch * 2, host + (size_t)first * hs, (size_t)hs * 2, (size_t)d.w * d.bps, rows) != VSZIP_OK)
+            d.ptr = nullptr;
+        else
+            g_plane_uploads.fetch_add(1);
+        return d;
+    }
     DPlane blank(Gpu *g, int w, int h, int bps) const {
         DPlane d;
         d.bps = bps;
@@ -2054,7 +2075,7 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
         std::vector<ptrdiff_t> mcs(vf->numPlanes, mk.stride);
         for (int p = 0; p < vf->numPlanes; ++p) {
             DPlane s = z.upload(g, src, p), o = z.blank(g, api->getFrameWidth(dst, p), api->getFrameHeight(dst, p), 4), c;
-            if (scp) c = z.upload(g, scp, p);
+            if (scp) c = d->horizontal ? z.upload(g, scp, p) : z.upload_alternate_rows(g, scp, p, field);  // (EEDI3H transposes the whole sclip on the device)
             if (!s.ptr || !o.ptr || (scp && !c.ptr)) return done(fail(z, g, dst, name, "device staging failed"));
             tab.push_back(mk_plane(s, &o, nullptr));
             outs.push_back(o);
