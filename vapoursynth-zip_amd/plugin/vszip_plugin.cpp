@@ -2074,7 +2074,9 @@ const VSFrame *VS_CC eedi3GetFrame(int n, int reason, void *inst, void **, VSFra
         std::vector<const uint8_t *> mcl(vf->numPlanes, static_cast<const uint8_t *>(mk.ptr));
         std::vector<ptrdiff_t> mcs(vf->numPlanes, mk.stride);
         for (int p = 0; p < vf->numPlanes; ++p) {
-            DPlane s = z.upload(g, src, p), o = z.blank(g, api->getFrameWidth(dst, p), api->getFrameHeight(dst, p), 4), c;
+            // without dh the lines being interpolated are never read (the taps are lines +-1 and +-3, reflected with their parity kept): only the kept field goes up
+            const bool half_src = !d->horizontal && d->prm.dh == 0;
+            DPlane s = half_src ? z.upload_alternate_rows(g, src, p, 1 - field) : z.upload(g, src, p), o = z.blank(g, api->getFrameWidth(dst, p), api->getFrameHeight(dst, p), 4), c;
             if (scp) c = d->horizontal ? z.upload(g, scp, p) : z.upload_alternate_rows(g, scp, p, field);  // (EEDI3H transposes the whole sclip on the device)
             if (!s.ptr || !o.ptr || (scp && !c.ptr)) return done(fail(z, g, dst, name, "device staging failed"));
             tab.push_back(mk_plane(s, &o, nullptr));
